@@ -1,0 +1,163 @@
+/*
+ * noiseflow_hip.h — C ABI of the MI355X-native Noise Flow bijector stack.
+ *
+ * This is the drop-in boundary for the ONE hot path this repository implements:
+ * the reference's bijector chain evaluated in the likelihood direction
+ * (NLL + log|det J|) and in the sampling direction.  The reference has no native
+ * boundary of its own (it is 100 % Python on the TensorFlow 1.12 runtime); the
+ * calls below replace the `sess.run(...)` feeds of
+ *     train_noise_flow.py:112-113   (loss, sd_z)           -> nf_nll
+ *     train_noise_flow.py:167-168   (x_sample)             -> nf_sample
+ *     borealisflows/NoiseFlowWrapper.py:81-87              -> nf_sample
+ * and the graph construction + Saver.restore of
+ *     borealisflows/noise_flow_model.py:54-235, NoiseFlowWrapper.py:46-79 -> nf_create
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++ / torch types cross this boundary;
+ *   - all tensor pointers passed to nf_nll / nf_sample / nf_synth_patches are
+ *     DEVICE pointers (HBM) owned by the caller, fp32, NHWC, contiguous;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream);
+ *   - every function returns 0 on success and a negative NF_E* code on failure;
+ *     nf_last_error() returns a thread-local description of the last failure;
+ *   - a handle is immutable after nf_create: nf_nll / nf_sample are re-entrant
+ *     and may be called concurrently from many host threads (the reference's
+ *     16-32 Python threads sharing one tf.Session, job_noise_flow.sh:36,
+ *     train_dncnn_noiseflow.py:195); they never allocate and never synchronise.
+ */
+#ifndef NOISEFLOW_HIP_H
+#define NOISEFLOW_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NF_ABI_VERSION 1
+
+/* error codes */
+#define NF_OK            0
+#define NF_EINVAL       -1   /* bad argument / unsupported configuration      */
+#define NF_EHIP         -2   /* a HIP runtime call failed                     */
+#define NF_ECOND        -3   /* unknown camera id (cond_utils.py:216-217)     */
+#define NF_ENOMEM       -4
+
+/* layer types = the bijectors of the shipped / job-script architectures
+ * (noise_flow_model.py:71-235).  An `unc` arch entry is a CONV1X1 followed by a
+ * COUPLING (noise_flow_model.py:79-104). */
+#define NF_LAYER_CONV1X1   1   /* layers.py:74-145  Conv2d1x1, decomp = LU, no bias        */
+#define NF_LAYER_COUPLING  2   /* layers.py:251-375 AffineCoupling + real_nvp_conv_template */
+#define NF_LAYER_SDN5      3   /* AffineCouplingSdnEx5.py:22-132 + cond_utils.py:205-239    */
+#define NF_LAYER_GAIN4     4   /* AffineCouplingGainEx4.py:23-127 + cond_utils.py:432-440   */
+
+/* Raw (checkpoint-semantics, un-folded) parameter layout of one layer inside the
+ * flat `params` array, starting at `param_offset` floats.  C = 4 channels.
+ *
+ *  CONV1X1   (36 floats)  P[4][4] row-major, sign_S[4], log_S[4], L_vec[6], U_vec[6]
+ *                         (matrix_param.py:100-140; vectors in tfdist.fill_triangular order)
+ *  COUPLING  (width w)    l_1/W[3][3][2][w], l_1/b[w], bn1_mean[w], bn1_var[w],
+ *                         l_2/W[w][w],       l_2/b[w], bn2_mean[w], bn2_var[w],
+ *                         l_last/W[3][3][w+1][4], l_last/b[4], l_last/logs[4],
+ *                         rescaling_scale[1]
+ *                         = 27w + w*w + 36w + 36 + 4 + 4 + 1 ... see nf_layer_param_count()
+ *  SDN5      (23 floats)  beta1, beta2, gain_params[5], cam_params[3][5], c_i
+ *  GAIN4     (1 float)    gain_val
+ */
+typedef struct nf_layer_desc {
+    int32_t type;          /* NF_LAYER_*                                  */
+    int32_t width;         /* coupling CNN width (COUPLING only, else 0)  */
+    int64_t param_offset;  /* offset in floats into `params`              */
+} nf_layer_desc;
+
+typedef struct nf_config {
+    int32_t height;        /* patch H (<= 64)                             */
+    int32_t width;         /* patch W (<= 64), H*W <= 4096                */
+    int32_t channels;      /* must be 4 (packed Bayer raw)                */
+    int32_t n_layers;      /* number of nf_layer_desc entries, NLL order  */
+    int32_t device;        /* HIP device ordinal, -1 = current device     */
+    int32_t reserved;      /* must be 0                                   */
+} nf_config;
+
+/* Per-call conditioning: ONE value per call, not per patch — the reference
+ * feeds length-1 lists (MiniBatchSampler.py:61-64, NoiseFlowWrapper.py:85-86).
+ * cam in {0..4} = IP, GP, S6, N6, G4; an unknown ISO silently selects gain
+ * parameter 0 (cond_utils.py:227-229); an unknown camera is an error. */
+typedef struct nf_cond {
+    float iso;
+    float cam;
+    float nlf0;            /* carried for interface parity; unused by sdn5 */
+    float nlf1;
+} nf_cond;
+
+typedef struct nf_handle nf_handle;
+
+/* flags for nf_nll */
+#define NF_ACCUMULATE   1u   /* add into sums_out instead of overwriting it          */
+#define NF_NO_PRIOR     2u   /* nll_out receives -sum(log-dets) only (no base logp)   */
+
+int         nf_abi_version(void);
+const char *nf_last_error(void);
+
+/* Number of raw floats a layer of this type/width occupies in `params`; <0 on error. */
+int64_t     nf_layer_param_count(int32_t type, int32_t width);
+
+/* Build a model: fold the raw parameters (PLU -> A and A^-1, BN-eval and
+ * exp(3*logs) folded into the conv weights, edge-indicator channel reduced to a
+ * 16-entry border table, gain folded into the neighbouring 1x1 matrix) and upload
+ * the two device-resident programs (NLL order / sampling order). */
+int nf_create(const nf_config *cfg, const nf_layer_desc *layers,
+              const float *params, size_t n_params, nf_handle **out);
+int nf_destroy(nf_handle *h);
+
+/* Likelihood direction.  Replaces NoiseFlow._loss / .inverse
+ * (noise_flow_model.py:394-428, 458-484).
+ *   x, y      [B,H,W,4] noise / clean image (y may be NULL if the model has no SDN5 layer)
+ *   nll_out   [B]  per-patch NLL (or NULL)
+ *   sd_out    [B]  per-patch sqrt(var_hwc z) (or NULL)
+ *   logdet_out[B]  per-patch sum of log|det J| over all layers (or NULL)
+ *   z_out     [B,H,W,4] latent (or NULL)
+ *   sums_out  double[3] on the DEVICE: sum_b nll, sum_b sd, B (or NULL)
+ */
+int nf_nll(nf_handle *h, const float *x, const float *y, int64_t B, const nf_cond *cond,
+           float *nll_out, float *sd_out, float *logdet_out, float *z_out,
+           double *sums_out, uint32_t flags, void *stream);
+
+/* Sampling direction.  Replaces NoiseFlow.sample / .forward
+ * (noise_flow_model.py:430-456): z = eps*temp, then the bijectors in reverse.
+ *   eps       [B,H,W,4] caller-supplied N(0,1) draw, or NULL to generate it
+ *             in-kernel with Philox4x32-10 keyed (seed, patch_index_base + b, pixel)
+ *   x_out     [B,H,W,4] synthesised noise (unclipped, as the reference)
+ */
+int nf_sample(nf_handle *h, const float *y, const float *eps, uint64_t seed,
+              int64_t patch_index_base, float temp, int64_t B, const nf_cond *cond,
+              float *x_out, void *stream);
+
+/* Counter-based synthetic SIDD-like patches, identical for any sharding:
+ *   y_k ~ U[0,1)^(HxWx4),  x_k = eps * sqrt(beta1*y_k + beta2),  eps ~ N(0,1),
+ * keyed by (seed, global patch index k = patch_index_base + b, pixel). */
+int nf_synth_patches(uint64_t seed, int64_t patch_index_base, int64_t B,
+                     int32_t height, int32_t width, float beta1, float beta2,
+                     float *y_out, float *x_out, void *stream);
+
+/* Host-only view of the folded program (no GPU needed; used by the CPU test
+ * tier to check the C++ folding against the numpy oracle).
+ *   direction 0 = NLL order, 1 = sampling order
+ *   ops_out   int32 pairs (type, float offset) — at most ops_cap pairs
+ *   folded    folded parameter block — at most folded_cap floats
+ *   ld_const  sum of the constant log-dets (H*W*sum log_S, -H*W*C*log gain_val)
+ */
+int nf_fold_params(const nf_config *cfg, const nf_layer_desc *layers,
+                   const float *params, size_t n_params, int32_t direction,
+                   int32_t *ops_out, int32_t ops_cap, int32_t *n_ops,
+                   float *folded, size_t folded_cap, size_t *n_folded,
+                   double *ld_const);
+
+/* Host-only: the SDN5 scalars the kernels receive for a given (iso, cam):
+ * out[0] = beta1/gain, out[1] = beta2 (cond_utils.py:205-239). */
+int nf_sdn5_scalars(const float *sdn_params /*23 floats*/, const nf_cond *cond, double out[2]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NOISEFLOW_HIP_H */

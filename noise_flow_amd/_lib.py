@@ -1,0 +1,109 @@
+"""ctypes binding of the C ABI in ``include/noiseflow_hip.h``.
+
+The HIP library is the product path: if ``libnoiseflow_hip.so`` is missing this
+module raises — there is no CPU fallback anywhere under ``noise_flow_amd/``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libnoiseflow_hip.so")
+
+NF_LAYER_CONV1X1 = 1
+NF_LAYER_COUPLING = 2
+NF_LAYER_SDN5 = 3
+NF_LAYER_GAIN4 = 4
+
+NF_ACCUMULATE = 1
+NF_NO_PRIOR = 2
+
+NF_OK = 0
+NF_EINVAL = -1
+NF_EHIP = -2
+NF_ECOND = -3
+NF_ENOMEM = -4
+
+# device op codes (csrc/nf_device.h) — exposed for the folding tests
+NF_OP_MIX, NF_OP_COUPLING_FWD, NF_OP_COUPLING_REV, NF_OP_SDN_DIV, NF_OP_SDN_MUL, NF_OP_SCALE = 1, 2, 3, 4, 5, 6
+
+
+class nf_layer_desc(C.Structure):
+    _fields_ = [("type", C.c_int32), ("width", C.c_int32), ("param_offset", C.c_int64)]
+
+
+class nf_config(C.Structure):
+    _fields_ = [("height", C.c_int32), ("width", C.c_int32), ("channels", C.c_int32),
+                ("n_layers", C.c_int32), ("device", C.c_int32), ("reserved", C.c_int32)]
+
+
+class nf_cond(C.Structure):
+    _fields_ = [("iso", C.c_float), ("cam", C.c_float), ("nlf0", C.c_float), ("nlf1", C.c_float)]
+
+
+class NoiseFlowLibError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__("noiseflow_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the shared library once.  torch is imported first so that the HIP
+    runtime torch ships (same SONAME, libamdhip64.so.7) is the one both share —
+    device pointers and streams then belong to a single runtime."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "HIP extension not built: %s is missing. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C noise_flow_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    try:
+        import torch  # noqa: F401  (loads libamdhip64 first)
+    except Exception:  # pragma: no cover - torch is plumbing only
+        pass
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, u32, u64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float
+    lib.nf_abi_version.restype = C.c_int
+    lib.nf_abi_version.argtypes = []
+    lib.nf_last_error.restype = C.c_char_p
+    lib.nf_last_error.argtypes = []
+    lib.nf_layer_param_count.restype = i64
+    lib.nf_layer_param_count.argtypes = [i32, i32]
+    lib.nf_create.restype = C.c_int
+    lib.nf_create.argtypes = [C.POINTER(nf_config), C.POINTER(nf_layer_desc), C.POINTER(C.c_float), C.c_size_t,
+                              C.POINTER(vp)]
+    lib.nf_destroy.restype = C.c_int
+    lib.nf_destroy.argtypes = [vp]
+    lib.nf_nll.restype = C.c_int
+    lib.nf_nll.argtypes = [vp, vp, vp, i64, C.POINTER(nf_cond), vp, vp, vp, vp, vp, u32, vp]
+    lib.nf_sample.restype = C.c_int
+    lib.nf_sample.argtypes = [vp, vp, vp, u64, i64, f32, i64, C.POINTER(nf_cond), vp, vp]
+    lib.nf_synth_patches.restype = C.c_int
+    lib.nf_synth_patches.argtypes = [u64, i64, i64, i32, i32, f32, f32, vp, vp, vp]
+    lib.nf_fold_params.restype = C.c_int
+    lib.nf_fold_params.argtypes = [C.POINTER(nf_config), C.POINTER(nf_layer_desc), C.POINTER(C.c_float), C.c_size_t,
+                                   i32, C.POINTER(i32), i32, C.POINTER(i32), C.POINTER(C.c_float), C.c_size_t,
+                                   C.POINTER(C.c_size_t), C.POINTER(C.c_double)]
+    lib.nf_sdn5_scalars.restype = C.c_int
+    lib.nf_sdn5_scalars.argtypes = [C.POINTER(C.c_float), C.POINTER(nf_cond), C.POINTER(C.c_double)]
+    if lib.nf_abi_version() != 1:
+        raise ImportError("noiseflow_hip ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != NF_OK:
+        msg = load().nf_last_error()
+        raise NoiseFlowLibError(rc, msg.decode("utf-8", "replace") if msg else "")
+
+
+EXPORTED_SYMBOLS = (
+    "nf_abi_version", "nf_last_error", "nf_layer_param_count", "nf_create", "nf_destroy", "nf_nll",
+    "nf_sample", "nf_synth_patches", "nf_fold_params", "nf_sdn5_scalars",
+)

@@ -1,0 +1,80 @@
+// Shared host/device definitions of the folded Noise Flow program.
+//
+// A model is compiled by the host (nf_host.cpp) into a short straight-line
+// "program" of ops over the 4 channel values of every pixel of one patch; the
+// fused kernel (nf_kernels.hip) interprets it with one workgroup per patch and
+// all intermediate tensors in registers / LDS.
+#pragma once
+#include <stdint.h>
+
+#define NF_MAX_OPS 64
+
+// device op codes
+enum : int32_t {
+    NF_OP_MIX          = 1,  // z <- z @ M               (16 floats, row-major [c][k])
+    NF_OP_COUPLING_FWD = 2,  // NLL dir:  z1 <- z1*exp(ls) + shift ; ld += sum ls
+    NF_OP_COUPLING_REV = 3,  // sampling: z1 <- (z1 - shift)*exp(-ls)
+    NF_OP_SDN_DIV      = 4,  // NLL dir:  z <- z / sqrt(k1*y + b2) ; ld -= sum log scale
+    NF_OP_SDN_MUL      = 5,  // sampling: z <- z * sqrt(k1*y + b2)
+    NF_OP_SCALE        = 6,  // z <- z * s               (1 float; un-folded gain layer)
+};
+
+struct NfOp {
+    int32_t type;
+    int32_t off;    // offset in floats into the folded parameter block (multiple of 4)
+};
+
+struct NfProgram {
+    int32_t n_ops;
+    int32_t width;  // coupling CNN width of this program (all couplings share it)
+    NfOp ops[NF_MAX_OPS];
+};
+
+// Folded coupling block layout (floats), w = CNN width; every section starts at a
+// multiple of 4 floats so border-table rows can be fetched as one 16-byte load.
+//   E   [16][4]        border table: (b3 + edge-channel taps outside the image) * exp(3 logs),
+//                      indexed by mask = top | bottom<<1 | left<<2 | right<<3
+//   W3  [9][w][4]      l_last weights * exp(3 logs)           (tap-major)
+//   W1  [9][2][w]      l_1 weights   / sqrt(var1 + eps)
+//   B1  [w]            (b1 - mean1)  / sqrt(var1 + eps)
+//   W2  [w][w]         l_2 weights   / sqrt(var2 + eps)
+//   B2  [w]            (b2 - mean2)  / sqrt(var2 + eps)
+//   S   [4]            rescaling_scale, 0, 0, 0
+__host__ __device__ constexpr int nf_cpl_off_E(int)    { return 0; }
+__host__ __device__ constexpr int nf_cpl_off_W3(int)   { return 64; }
+__host__ __device__ constexpr int nf_cpl_off_W1(int w) { return 64 + 36 * w; }
+__host__ __device__ constexpr int nf_cpl_off_B1(int w) { return 64 + 36 * w + 18 * w; }
+__host__ __device__ constexpr int nf_cpl_off_W2(int w) { return 64 + 36 * w + 18 * w + w; }
+__host__ __device__ constexpr int nf_cpl_off_B2(int w) { return 64 + 36 * w + 18 * w + w + w * w; }
+__host__ __device__ constexpr int nf_cpl_off_S(int w)  { return 64 + 36 * w + 18 * w + 2 * w + w * w; }
+__host__ __device__ constexpr int nf_cpl_size(int w)   { return 64 + 36 * w + 18 * w + 2 * w + w * w + 4; }
+
+// launch flags
+enum : uint32_t {
+    NF_K_PRIOR     = 1u,   // nll = -(logdet + logp(z)); otherwise nll = -logdet
+    NF_K_PHILOX_IN = 2u,   // input = Philox normal draw (sampling with in-kernel eps)
+};
+
+struct NfLaunch {
+    const float *params;   // folded parameter block (device)
+    const float *in;       // [B,H,W,4] input tensor (x or eps); unused with NF_K_PHILOX_IN
+    const float *y;        // [B,H,W,4] clean image (SDN ops) or null
+    float *out;            // [B,H,W,4] output tensor (z or x) or null
+    float *nll_out;        // [B] or null
+    float *sd_out;         // [B] or null
+    float *ld_out;         // [B] or null
+    double *sums;          // double[3] accumulators or null
+    int64_t B;
+    int64_t patch_base;    // global index of patch 0 (Philox key)
+    uint64_t seed;
+    double ld_const;       // constant part of the log-det sum
+    float in_scale;        // input multiplier (sampling temperature)
+    float sdn_k1, sdn_b2;  // beta1/gain, beta2
+    int32_t H, W;
+    uint32_t flags;
+};
+
+// Philox stream ids (4th counter word)
+#define NF_STREAM_Y    0u   // synthetic clean image
+#define NF_STREAM_XEPS 1u   // synthetic noise draw
+#define NF_STREAM_SAMP 2u   // sampling-direction base draw

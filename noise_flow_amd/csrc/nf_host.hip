@@ -1,0 +1,558 @@
+// Host side of the C ABI (include/noiseflow_hip.h): parameter folding, program
+// construction, conditioning scalars, launches.  No torch, no Python here.
+//
+// Reference call sites replaced (paths relative to /root/reference):
+//   matrix_param.py:100-140      PLU -> A, A^-1, log|det|        (fold_conv1x1)
+//   layers.py:378-401            BN eval folded into l_1 / l_2    (fold_coupling)
+//   layers.py:555-583,651-674    edge channel + exp(3*logs)       (fold_coupling)
+//   cond_utils.py:205-239        sdn5 scalars                     (sdn5_scalars)
+//   cond_utils.py:432-440        gain4                            (build_program)
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/noiseflow_hip.h"
+#include "nf_device.h"
+
+hipError_t nf_launch_flow(const NfProgram &prog, const NfLaunch &a, int n_cu, hipStream_t stream);
+hipError_t nf_launch_synth(uint64_t seed, int64_t patch_base, int64_t B, int HW, float beta1, float beta2,
+                           float *y_out, float *x_out, hipStream_t stream);
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+int fail_hip(hipError_t e, const char *what)
+{
+    return fail(NF_EHIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+constexpr double kBnEps = 1e-4;          // layers.py:378
+constexpr double kLogscaleFactor = 3.0;  // layers.py:653
+constexpr int kC = 4;
+
+int64_t layer_param_count(int32_t type, int32_t w)
+{
+    switch (type) {
+    case NF_LAYER_CONV1X1: return 16 + 4 + 4 + 6 + 6;
+    case NF_LAYER_COUPLING:
+        if (w <= 0) return -1;
+        return 9 * 2 * (int64_t)w + w + w + w      // l_1/W, l_1/b, bn1 mean, var
+               + (int64_t)w * w + w + w + w        // l_2/W, l_2/b, bn2 mean, var
+               + 9 * ((int64_t)w + 1) * 4 + 4 + 4  // l_last/W, b, logs
+               + 1;                                // rescaling_scale
+    case NF_LAYER_SDN5: return 1 + 1 + 5 + 15 + 1;
+    case NF_LAYER_GAIN4: return 1;
+    default: return -1;
+    }
+}
+
+// ---- PLU parameterisation (matrix_param.py:31-56, 100-140) -----------------
+struct Mat4 {
+    double m[4][4];
+};
+
+Mat4 matmul(const Mat4 &a, const Mat4 &b)
+{
+    Mat4 r;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < 4; ++k) s += a.m[i][k] * b.m[k][j];
+            r.m[i][j] = s;
+        }
+    return r;
+}
+
+void fold_conv1x1(const float *p, Mat4 &A, Mat4 &Ainv, double &log_abs_det)
+{
+    const float *P = p, *sign_s = p + 16, *log_s = p + 20, *lv = p + 24, *uv = p + 30;
+    Mat4 Pm, L, U;
+    memset(&L, 0, sizeof(L));
+    memset(&U, 0, sizeof(U));
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) Pm.m[i][j] = P[i * 4 + j];
+    // tfdist.fill_triangular(v, lower) for the 3x3 strict triangle, padded by one
+    // zero row on top and one zero column on the right:  [[v3,0,0],[v5,v4,0],[v2,v1,v0]]
+    L.m[1][0] = lv[3];
+    L.m[2][0] = lv[5]; L.m[2][1] = lv[4];
+    L.m[3][0] = lv[2]; L.m[3][1] = lv[1]; L.m[3][2] = lv[0];
+    for (int i = 0; i < 4; ++i) L.m[i][i] = 1.0;
+    // upper: [[v0,v1,v2],[0,v4,v5],[0,0,v3]] padded by a zero row at the bottom and a zero column on the left
+    U.m[0][1] = uv[0]; U.m[0][2] = uv[1]; U.m[0][3] = uv[2];
+    U.m[1][2] = uv[4]; U.m[1][3] = uv[5];
+    U.m[2][3] = uv[3];
+    log_abs_det = 0.0;
+    for (int i = 0; i < 4; ++i) {
+        U.m[i][i] = (double)sign_s[i] * exp((double)log_s[i]);
+        log_abs_det += (double)log_s[i];
+    }
+    A = matmul(Pm, matmul(L, U));
+    // A^-1 = U^-1 L^-1 P^T by two triangular solves (matrix_param.py:132-136)
+    Mat4 X;   // X = L^-1 P^T  (forward substitution, unit diagonal)
+    for (int c = 0; c < 4; ++c)
+        for (int i = 0; i < 4; ++i) {
+            double s = Pm.m[c][i];   // P^T[i][c]
+            for (int k = 0; k < i; ++k) s -= L.m[i][k] * X.m[k][c];
+            X.m[i][c] = s;
+        }
+    for (int c = 0; c < 4; ++c)      // back substitution with U
+        for (int i = 3; i >= 0; --i) {
+            double s = X.m[i][c];
+            for (int k = i + 1; k < 4; ++k) s -= U.m[i][k] * Ainv.m[k][c];
+            Ainv.m[i][c] = s / U.m[i][i];
+        }
+}
+
+// ---- coupling CNN folding ---------------------------------------------------
+void fold_coupling(const float *p, int w, float *out)
+{
+    const float *W1 = p;
+    const float *b1 = W1 + 18 * w;
+    const float *m1 = b1 + w;
+    const float *v1 = m1 + w;
+    const float *W2 = v1 + w;
+    const float *b2 = W2 + w * w;
+    const float *m2 = b2 + w;
+    const float *v2 = m2 + w;
+    const float *W3 = v2 + w;            // [3][3][w+1][4]
+    const float *b3 = W3 + 9 * (w + 1) * 4;
+    const float *logs = b3 + 4;
+    const float *resc = logs + 4;
+
+    std::vector<double> s1(w), s2(w);
+    for (int j = 0; j < w; ++j) {
+        s1[j] = 1.0 / sqrt((double)v1[j] + kBnEps);
+        s2[j] = 1.0 / sqrt((double)v2[j] + kBnEps);
+    }
+    double es[4];
+    for (int j = 0; j < 4; ++j) es[j] = exp(kLogscaleFactor * (double)logs[j]);
+
+    float *E = out + nf_cpl_off_E(w);
+    for (int mask = 0; mask < 16; ++mask) {
+        const bool top = mask & 1, bottom = mask & 2, left = mask & 4, right = mask & 8;
+        for (int j = 0; j < 4; ++j) {
+            double s = b3[j];
+            for (int di = 0; di < 3; ++di)
+                for (int dj = 0; dj < 3; ++dj) {
+                    const bool outside = (di == 0 && top) || (di == 2 && bottom) || (dj == 0 && left) || (dj == 2 && right);
+                    if (outside) s += (double)W3[((di * 3 + dj) * (w + 1) + w) * 4 + j];
+                }
+            E[mask * 4 + j] = (float)(s * es[j]);
+        }
+    }
+    float *W3o = out + nf_cpl_off_W3(w);
+    for (int tap = 0; tap < 9; ++tap)
+        for (int i = 0; i < w; ++i)
+            for (int j = 0; j < 4; ++j)
+                W3o[(tap * w + i) * 4 + j] = (float)((double)W3[(tap * (w + 1) + i) * 4 + j] * es[j]);
+    float *W1o = out + nf_cpl_off_W1(w);
+    for (int tap = 0; tap < 9; ++tap)
+        for (int c = 0; c < 2; ++c)
+            for (int j = 0; j < w; ++j)
+                W1o[(tap * 2 + c) * w + j] = (float)((double)W1[(tap * 2 + c) * w + j] * s1[j]);
+    float *B1o = out + nf_cpl_off_B1(w);
+    for (int j = 0; j < w; ++j) B1o[j] = (float)(((double)b1[j] - (double)m1[j]) * s1[j]);
+    float *W2o = out + nf_cpl_off_W2(w);
+    for (int i = 0; i < w; ++i)
+        for (int j = 0; j < w; ++j) W2o[i * w + j] = (float)((double)W2[i * w + j] * s2[j]);
+    float *B2o = out + nf_cpl_off_B2(w);
+    for (int j = 0; j < w; ++j) B2o[j] = (float)(((double)b2[j] - (double)m2[j]) * s2[j]);
+    float *S = out + nf_cpl_off_S(w);
+    S[0] = resc[0];
+    S[1] = S[2] = S[3] = 0.0f;
+}
+
+// ---- sdn5 host scalars (cond_utils.py:205-239) -------------------------------
+int sdn5_scalars(const float *sp, const nf_cond *cond, double out[2])
+{
+    if (!cond) return fail(NF_EINVAL, "model has an SDN5 layer but cond is NULL");
+    const double beta1_v = sp[0], beta2_v = sp[1];
+    const float *gain_params = sp + 2, *cam_params = sp + 7;
+    const double c_i = sp[22];
+    int cam_idx = -1;
+    for (int i = 0; i < 5; ++i)
+        if ((float)i == cond->cam) cam_idx = i;
+    if (cam_idx < 0) return fail(NF_ECOND, "unknown camera id %g (expected 0..4 = IP,GP,S6,N6,G4)", (double)cond->cam);
+    double cp[3];
+    for (int r = 0; r < 3; ++r) cp[r] = exp(c_i * (double)cam_params[r * 5 + cam_idx]);
+    static const float iso_vals[5] = {100.f, 400.f, 800.f, 1600.f, 3200.f};
+    double g = 0.0;   // unknown ISO -> empty one-hot -> reduce_sum = 0 (cond_utils.py:227-229)
+    for (int i = 0; i < 5; ++i)
+        if (iso_vals[i] == cond->iso) g = gain_params[i];
+    const double gain = exp(c_i * g * cp[2]) * (double)cond->iso;
+    const double beta1 = exp(c_i * beta1_v * cp[0]);
+    const double beta2 = exp(c_i * beta2_v * cp[1]);
+    out[0] = beta1 / gain;
+    out[1] = beta2;
+    return NF_OK;
+}
+
+// ---- program construction -----------------------------------------------------
+struct Built {
+    NfProgram prog;
+    std::vector<float> block;
+    double ld_const = 0.0;
+    bool has_sdn = false;
+    std::vector<float> sdn_params;
+};
+
+int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float *params, size_t n_params,
+                  int direction, Built &out)
+{
+    if (!cfg || !layers || !params) return fail(NF_EINVAL, "null argument");
+    if (cfg->channels != kC) return fail(NF_EINVAL, "channels must be 4 (packed raw), got %d", cfg->channels);
+    if (cfg->height < 1 || cfg->width < 1 || cfg->height * cfg->width > 4096 || cfg->height > 64 || cfg->width > 64)
+        return fail(NF_EINVAL, "patch size %dx%d unsupported (max 64x64)", cfg->height, cfg->width);
+    if (cfg->n_layers < 1) return fail(NF_EINVAL, "n_layers must be >= 1");
+    if (cfg->reserved != 0) return fail(NF_EINVAL, "nf_config.reserved must be 0");
+    const double HW = (double)cfg->height * cfg->width;
+
+    // intermediate list in NLL order
+    struct Item {
+        int type;               // NF_OP_* of the NLL direction
+        std::vector<float> blk; // folded block (fwd)
+        Mat4 A, Ainv;
+        double scale = 1.0;     // gain value for SCALE items
+        int w = 0;
+    };
+    std::vector<Item> items;
+    int width = 0;
+    out.ld_const = 0.0;
+    out.has_sdn = false;
+    for (int li = 0; li < cfg->n_layers; ++li) {
+        const nf_layer_desc &L = layers[li];
+        const int64_t cnt = layer_param_count(L.type, L.width);
+        if (cnt < 0) return fail(NF_EINVAL, "layer %d: unknown type %d / width %d", li, L.type, L.width);
+        if (L.param_offset < 0 || (uint64_t)L.param_offset + (uint64_t)cnt > n_params)
+            return fail(NF_EINVAL, "layer %d: parameters [%lld, +%lld) exceed n_params=%zu", li,
+                        (long long)L.param_offset, (long long)cnt, n_params);
+        const float *p = params + L.param_offset;
+        Item it;
+        switch (L.type) {
+        case NF_LAYER_CONV1X1: {
+            double lad;
+            fold_conv1x1(p, it.A, it.Ainv, lad);
+            it.type = NF_OP_MIX;
+            out.ld_const += HW * lad;                       // layers.py:129-130
+            break;
+        }
+        case NF_LAYER_COUPLING: {
+            if (L.width != 4 && L.width != 8 && L.width != 16)
+                return fail(NF_EINVAL, "layer %d: coupling width %d unsupported (4, 8, 16)", li, L.width);
+            if (width && width != L.width) return fail(NF_EINVAL, "all coupling layers must share one width");
+            width = L.width;
+            it.type = NF_OP_COUPLING_FWD;
+            it.w = L.width;
+            it.blk.assign(nf_cpl_size(L.width), 0.0f);
+            fold_coupling(p, L.width, it.blk.data());
+            break;
+        }
+        case NF_LAYER_SDN5:
+            it.type = NF_OP_SDN_DIV;
+            out.has_sdn = true;
+            out.sdn_params.assign(p, p + 23);
+            break;
+        case NF_LAYER_GAIN4:
+            if (!(p[0] > 0.0f)) return fail(NF_EINVAL, "layer %d: gain_val must be > 0", li);
+            it.type = NF_OP_SCALE;
+            it.scale = (double)p[0];
+            out.ld_const -= HW * kC * log((double)p[0]);   // AffineCouplingGainEx4.py:114-127
+            break;
+        }
+        items.push_back(it);
+    }
+
+    // Fold every gain into a neighbouring 1x1 matrix (NLL: z/g then z@A == z@(A/g)).
+    for (size_t i = 0; i < items.size(); ++i) {
+        if (items[i].type != NF_OP_SCALE) continue;
+        Item *tgt = nullptr;
+        if (i + 1 < items.size() && items[i + 1].type == NF_OP_MIX) tgt = &items[i + 1];
+        else if (i > 0 && items[i - 1].type == NF_OP_MIX) tgt = &items[i - 1];
+        if (!tgt) continue;
+        const double g = items[i].scale;
+        for (int r = 0; r < 4; ++r)
+            for (int c = 0; c < 4; ++c) {
+                tgt->A.m[r][c] /= g;
+                tgt->Ainv.m[r][c] *= g;
+            }
+        items[i].type = 0;   // removed
+    }
+
+    std::vector<Item *> order;
+    for (auto &it : items)
+        if (it.type != 0) order.push_back(&it);
+    if (direction == 1) std::vector<Item *>(order.rbegin(), order.rend()).swap(order);
+    if (order.size() > NF_MAX_OPS) return fail(NF_EINVAL, "too many layers (%zu > %d)", order.size(), NF_MAX_OPS);
+
+    memset(&out.prog, 0, sizeof(out.prog));
+    out.prog.width = width ? width : 4;
+    out.block.clear();
+    for (Item *it : order) {
+        NfOp &op = out.prog.ops[out.prog.n_ops++];
+        op.off = (int32_t)out.block.size();
+        switch (it->type) {
+        case NF_OP_MIX: {
+            op.type = NF_OP_MIX;
+            const Mat4 &M = direction == 0 ? it->A : it->Ainv;
+            for (int r = 0; r < 4; ++r)
+                for (int c = 0; c < 4; ++c) out.block.push_back((float)M.m[r][c]);
+            break;
+        }
+        case NF_OP_COUPLING_FWD:
+            op.type = direction == 0 ? NF_OP_COUPLING_FWD : NF_OP_COUPLING_REV;
+            out.block.insert(out.block.end(), it->blk.begin(), it->blk.end());
+            break;
+        case NF_OP_SDN_DIV:
+            op.type = direction == 0 ? NF_OP_SDN_DIV : NF_OP_SDN_MUL;
+            break;
+        case NF_OP_SCALE: {
+            op.type = NF_OP_SCALE;
+            const double s = direction == 0 ? 1.0 / it->scale : it->scale;
+            out.block.push_back((float)s);
+            out.block.push_back(0.f);
+            out.block.push_back(0.f);
+            out.block.push_back(0.f);
+            break;
+        }
+        }
+    }
+    if (out.block.empty()) out.block.assign(4, 0.0f);
+    return NF_OK;
+}
+
+struct DeviceGuard {
+    int prev = -1;
+    bool changed = false;
+    int enter(int dev)
+    {
+        hipError_t e = hipGetDevice(&prev);
+        if (e != hipSuccess) return fail_hip(e, "hipGetDevice");
+        if (prev != dev) {
+            e = hipSetDevice(dev);
+            if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
+            changed = true;
+        }
+        return NF_OK;
+    }
+    ~DeviceGuard()
+    {
+        if (changed) (void)hipSetDevice(prev);
+    }
+};
+
+}  // namespace
+
+struct nf_handle {
+    nf_config cfg;
+    int device = 0;
+    int n_cu = 256;
+    Built fwd, rev;
+    float *d_fwd = nullptr;
+    float *d_rev = nullptr;
+};
+
+extern "C" {
+
+int nf_abi_version(void) { return NF_ABI_VERSION; }
+
+const char *nf_last_error(void) { return g_last_error.c_str(); }
+
+int64_t nf_layer_param_count(int32_t type, int32_t width) { return layer_param_count(type, width); }
+
+int nf_fold_params(const nf_config *cfg, const nf_layer_desc *layers, const float *params, size_t n_params,
+                   int32_t direction, int32_t *ops_out, int32_t ops_cap, int32_t *n_ops, float *folded,
+                   size_t folded_cap, size_t *n_folded, double *ld_const)
+{
+    if (direction != 0 && direction != 1) return fail(NF_EINVAL, "direction must be 0 or 1");
+    Built b;
+    int rc = build_program(cfg, layers, params, n_params, direction, b);
+    if (rc != NF_OK) return rc;
+    if (n_ops) *n_ops = b.prog.n_ops;
+    if (n_folded) *n_folded = b.block.size();
+    if (ld_const) *ld_const = b.ld_const;
+    if (ops_out) {
+        if (ops_cap < b.prog.n_ops) return fail(NF_EINVAL, "ops_cap too small");
+        for (int i = 0; i < b.prog.n_ops; ++i) {
+            ops_out[2 * i] = b.prog.ops[i].type;
+            ops_out[2 * i + 1] = b.prog.ops[i].off;
+        }
+    }
+    if (folded) {
+        if (folded_cap < b.block.size()) return fail(NF_EINVAL, "folded_cap too small");
+        memcpy(folded, b.block.data(), b.block.size() * sizeof(float));
+    }
+    return NF_OK;
+}
+
+int nf_sdn5_scalars(const float *sdn_params, const nf_cond *cond, double out[2])
+{
+    if (!sdn_params || !out) return fail(NF_EINVAL, "null argument");
+    return sdn5_scalars(sdn_params, cond, out);
+}
+
+int nf_create(const nf_config *cfg, const nf_layer_desc *layers, const float *params, size_t n_params, nf_handle **out)
+{
+    if (!out) return fail(NF_EINVAL, "out is NULL");
+    *out = nullptr;
+    nf_handle *h = new (std::nothrow) nf_handle();
+    if (!h) return fail(NF_ENOMEM, "out of host memory");
+    int rc = build_program(cfg, layers, params, n_params, 0, h->fwd);
+    if (rc == NF_OK) rc = build_program(cfg, layers, params, n_params, 1, h->rev);
+    if (rc != NF_OK) {
+        delete h;
+        return rc;
+    }
+    h->cfg = *cfg;
+    hipError_t e;
+    if (cfg->device >= 0) {
+        h->device = cfg->device;
+    } else if ((e = hipGetDevice(&h->device)) != hipSuccess) {
+        delete h;
+        return fail_hip(e, "hipGetDevice");
+    }
+    DeviceGuard guard;
+    if ((rc = guard.enter(h->device)) != NF_OK) {
+        delete h;
+        return rc;
+    }
+    int n_cu = 0;
+    if ((e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device)) != hipSuccess) {
+        delete h;
+        return fail_hip(e, "hipDeviceGetAttribute");
+    }
+    h->n_cu = n_cu > 0 ? n_cu : 256;
+    const size_t nb_f = h->fwd.block.size() * sizeof(float), nb_r = h->rev.block.size() * sizeof(float);
+    if ((e = hipMalloc((void **)&h->d_fwd, nb_f)) != hipSuccess || (e = hipMalloc((void **)&h->d_rev, nb_r)) != hipSuccess) {
+        if (h->d_fwd) (void)hipFree(h->d_fwd);
+        delete h;
+        return fail_hip(e, "hipMalloc(params)");
+    }
+    if ((e = hipMemcpy(h->d_fwd, h->fwd.block.data(), nb_f, hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(h->d_rev, h->rev.block.data(), nb_r, hipMemcpyHostToDevice)) != hipSuccess) {
+        (void)hipFree(h->d_fwd);
+        (void)hipFree(h->d_rev);
+        delete h;
+        return fail_hip(e, "hipMemcpy(params)");
+    }
+    *out = h;
+    return NF_OK;
+}
+
+int nf_destroy(nf_handle *h)
+{
+    if (!h) return NF_OK;
+    DeviceGuard guard;
+    (void)guard.enter(h->device);
+    if (h->d_fwd) (void)hipFree(h->d_fwd);
+    if (h->d_rev) (void)hipFree(h->d_rev);
+    delete h;
+    return NF_OK;
+}
+
+int nf_nll(nf_handle *h, const float *x, const float *y, int64_t B, const nf_cond *cond, float *nll_out, float *sd_out,
+           float *logdet_out, float *z_out, double *sums_out, uint32_t flags, void *stream)
+{
+    if (!h) return fail(NF_EINVAL, "handle is NULL");
+    if (B < 0) return fail(NF_EINVAL, "B must be >= 0");
+    if (B > 0 && !x) return fail(NF_EINVAL, "x is NULL");
+    if (h->fwd.has_sdn && B > 0 && !y) return fail(NF_EINVAL, "model has an SDN5 layer but y is NULL");
+    double sc[2] = {0.0, 1.0};
+    if (h->fwd.has_sdn) {
+        int rc = sdn5_scalars(h->fwd.sdn_params.data(), cond, sc);
+        if (rc != NF_OK) return rc;
+    }
+    DeviceGuard guard;
+    int rc = guard.enter(h->device);
+    if (rc != NF_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (sums_out && !(flags & NF_ACCUMULATE)) {
+        hipError_t e = hipMemsetAsync(sums_out, 0, 3 * sizeof(double), st);
+        if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync(sums)");
+    }
+    if (B == 0) return NF_OK;
+    NfLaunch a;
+    memset(&a, 0, sizeof(a));
+    a.params = h->d_fwd;
+    a.in = x;
+    a.y = y;
+    a.out = z_out;
+    a.nll_out = nll_out;
+    a.sd_out = sd_out;
+    a.ld_out = logdet_out;
+    a.sums = sums_out;
+    a.B = B;
+    a.ld_const = h->fwd.ld_const;
+    a.in_scale = 1.0f;
+    a.sdn_k1 = (float)sc[0];
+    a.sdn_b2 = (float)sc[1];
+    a.H = h->cfg.height;
+    a.W = h->cfg.width;
+    a.flags = (flags & NF_NO_PRIOR) ? 0u : NF_K_PRIOR;
+    hipError_t e = nf_launch_flow(h->fwd.prog, a, h->n_cu, st);
+    if (e != hipSuccess) return fail_hip(e, "nf_nll launch");
+    return NF_OK;
+}
+
+int nf_sample(nf_handle *h, const float *y, const float *eps, uint64_t seed, int64_t patch_index_base, float temp,
+              int64_t B, const nf_cond *cond, float *x_out, void *stream)
+{
+    if (!h) return fail(NF_EINVAL, "handle is NULL");
+    if (B < 0) return fail(NF_EINVAL, "B must be >= 0");
+    if (B == 0) return NF_OK;
+    if (!x_out) return fail(NF_EINVAL, "x_out is NULL");
+    if (h->rev.has_sdn && !y) return fail(NF_EINVAL, "model has an SDN5 layer but y is NULL");
+    double sc[2] = {0.0, 1.0};
+    if (h->rev.has_sdn) {
+        int rc = sdn5_scalars(h->rev.sdn_params.data(), cond, sc);
+        if (rc != NF_OK) return rc;
+    }
+    DeviceGuard guard;
+    int rc = guard.enter(h->device);
+    if (rc != NF_OK) return rc;
+    NfLaunch a;
+    memset(&a, 0, sizeof(a));
+    a.params = h->d_rev;
+    a.in = eps;
+    a.y = y;
+    a.out = x_out;
+    a.B = B;
+    a.patch_base = patch_index_base;
+    a.seed = seed;
+    a.in_scale = temp;
+    a.sdn_k1 = (float)sc[0];
+    a.sdn_b2 = (float)sc[1];
+    a.H = h->cfg.height;
+    a.W = h->cfg.width;
+    a.flags = eps ? 0u : NF_K_PHILOX_IN;
+    hipError_t e = nf_launch_flow(h->rev.prog, a, h->n_cu, (hipStream_t)stream);
+    if (e != hipSuccess) return fail_hip(e, "nf_sample launch");
+    return NF_OK;
+}
+
+int nf_synth_patches(uint64_t seed, int64_t patch_index_base, int64_t B, int32_t height, int32_t width, float beta1,
+                     float beta2, float *y_out, float *x_out, void *stream)
+{
+    if (B < 0 || height < 1 || width < 1) return fail(NF_EINVAL, "bad shape");
+    if (!y_out && !x_out) return fail(NF_EINVAL, "both outputs are NULL");
+    hipError_t e = nf_launch_synth(seed, patch_index_base, B, height * width, beta1, beta2, y_out, x_out, (hipStream_t)stream);
+    if (e != hipSuccess) return fail_hip(e, "nf_synth_patches launch");
+    return NF_OK;
+}
+
+}  // extern "C"

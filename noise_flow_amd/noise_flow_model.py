@@ -1,0 +1,328 @@
+"""``NoiseFlow`` — the reference's operator surface on the MI355X HIP library.
+
+Mirrors ``borealisflows/noise_flow_model.py::NoiseFlow`` (reference file:line in
+each docstring): same constructor arguments, same method names, argument order
+and conditioning convention (``iso`` / ``cam`` / ``nlf0`` / ``nlf1`` are
+length-1 lists or scalars — ONE value per call, ``MiniBatchSampler.py:61-64``).
+The TF graph tensors become eager arrays: numpy in → numpy out, torch (CUDA)
+tensor in → torch tensor out (zero-copy).  Every method runs the fused HIP
+kernels through the C ABI; there is no CPU execution path.
+
+``x`` = real noise, ``y`` = clean image, ``z`` = latent
+(``train_noise_flow.py:284-285``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import threading
+from types import SimpleNamespace
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import _lib, params as _params
+from .ckpt import load_checkpoint, save_checkpoint
+
+_U64 = (1 << 64) - 1
+
+
+def _first(v, default=0.0) -> float:
+    """Conditioning values arrive as length-1 lists (reference feed dicts) or scalars."""
+    if v is None:
+        return float(default)
+    a = np.asarray(v if not hasattr(v, "detach") else v.detach().cpu().numpy(), dtype=np.float64).reshape(-1)
+    if a.size != 1:
+        raise ValueError("conditioning is per call, not per patch: expected one value, got %d "
+                         "(reference feeds length-1 lists)" % a.size)
+    return float(a[0])
+
+
+class _Dev:
+    """Device plumbing (torch is used ONLY for HBM allocations and streams)."""
+
+    def __init__(self, device=None):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("noise_flow_amd needs a ROCm GPU (MI355X): torch.cuda.is_available() is False "
+                               "and there is no CPU fallback")
+        self.torch = torch
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else int(device))
+
+    def to_dev(self, a, shape_tail=None):
+        """→ (contiguous float32 CUDA tensor, was_numpy)."""
+        torch = self.torch
+        was_np = not isinstance(a, torch.Tensor)
+        if was_np:
+            t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device, non_blocking=False)
+        else:
+            t = a.to(device=self.device, dtype=torch.float32).contiguous()
+        if shape_tail is not None and tuple(t.shape[1:]) != tuple(shape_tail):
+            raise ValueError("expected tensor of shape [B,%s], got %s" % (",".join(map(str, shape_tail)), tuple(t.shape)))
+        return t, was_np
+
+    def empty(self, shape, dtype=None):
+        return self.torch.empty(shape, dtype=dtype or self.torch.float32, device=self.device)
+
+    def stream_ptr(self) -> int:
+        return int(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    @staticmethod
+    def back(t, as_numpy: bool):
+        return t.cpu().numpy() if as_numpy else t
+
+
+class FlowHandle:
+    """Owns one ``nf_handle`` (a folded, device-resident model)."""
+
+    def __init__(self, arch, variables: Dict[str, np.ndarray], x_shape, width: int,
+                 binding: str = "loss_first", device: Optional[int] = None, layers=None, tmpl=None):
+        self.lib = _lib.load()
+        if layers is None:
+            self.layers, descs, flat = _params.pack(arch, variables, width, binding)
+        else:   # an explicit sub-list of bijectors (noise_flow_amd.layers)
+            self.layers, descs, flat = _params.pack_layers(layers, variables, width, tmpl or {})
+        H, W, Cc = (int(v) for v in x_shape)
+        self.x_shape = (H, W, Cc)
+        cfg = _lib.nf_config(H, W, Cc, len(self.layers), -1 if device is None else int(device), 0)
+        h = C.c_void_p()
+        _lib.check(self.lib.nf_create(C.byref(cfg), descs, flat.ctypes.data_as(C.POINTER(C.c_float)), flat.size,
+                                      C.byref(h)))
+        self._h = h
+        self.has_sdn = any(L.kind == "sdn5" for L in self.layers)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.nf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def ptr(self):
+        return self._h
+
+
+class NoiseFlow(object):
+    """Reference: ``borealisflows/noise_flow_model.py:44-513``.
+
+    Parameters
+    ----------
+    x_shape : [H, W, C]          (noise_flow_model.py:46)
+    is_training : bool           accepted for signature parity.  Batch-statistics
+                                 BN (``True``) couples all patches of a call
+                                 (layers.py:388-398) and is not part of the fused
+                                 eval path; pass ``bn_mode='running'`` semantics
+                                 (``False``) for every NLL / sampling measurement
+                                 (train_noise_flow.py:112-113,167-168).
+    hps : namespace with ``arch, width, decomp, flow_permutation, squeeze_factor,
+          n_levels`` (and optionally ``seed``).
+    variables : optional ``{name: ndarray}`` under the reference's checkpoint
+          names; default = fresh initialisation with the reference initialisers.
+    binding : 'loss_first' | 'sample_first' — template→layer binding (quirk Q1).
+    """
+
+    def __init__(self, x_shape, is_training=False, hps=None, variables=None, binding="loss_first", device=None):
+        if hps is None:
+            raise ValueError("hps is required (arch, width, ...)")
+        self.x_shape = [int(v) for v in x_shape]
+        self.hps = hps
+        self.depth = getattr(hps, "depth", -1)
+        self.n_levels = int(getattr(hps, "n_levels", 1))
+        self._is_training = is_training
+        self.binding = binding
+        if self.n_levels != 1:
+            raise NotImplementedError("n_levels > 1 (split2d) is outside the hot path (shipped: n_levels = 1)")
+        if int(getattr(hps, "squeeze_factor", 1)) != 1:
+            raise NotImplementedError("squeeze_factor != 1 is outside the hot path (shipped: 1)")
+        if int(getattr(hps, "flow_permutation", 1)) != 1:
+            raise NotImplementedError("flow_permutation must be 1 (Conv2d1x1), as shipped")
+        if str(getattr(hps, "decomp", "LU")) != "LU":
+            raise NotImplementedError("decomp must be 'LU', as shipped (hps.txt:67)")
+        self.arch = hps.arch
+        self.width = int(getattr(hps, "width", 4))
+        self._dev = _Dev(device)
+        self._seed = int(getattr(hps, "seed", 0) or 0)
+        self._draws = 0
+        self._lock = threading.Lock()
+        self._variables = dict(variables) if variables is not None else _params.init_variables(
+            self.arch, self.width, self.x_shape[-1], self._seed)
+        self.model = [_params.parse_arch(self.arch)]   # bijector list per level (define_flow_structure)
+        self._flow = FlowHandle(self.arch, self._variables, self.x_shape, self.width, binding, self._dev.device.index)
+
+    # ------------------------------------------------------------------ variables
+    @property
+    def variables(self) -> Dict[str, np.ndarray]:
+        return self._variables
+
+    def num_params(self) -> int:
+        return _params.count_trainable(self._variables)
+
+    def load_variables(self, variables: Dict[str, np.ndarray], binding: Optional[str] = None) -> None:
+        """Swap in a new variable set (the equivalent of ``Saver.restore``)."""
+        if binding is not None:
+            self.binding = binding
+        self._variables = dict(variables)
+        old = self._flow
+        self._flow = FlowHandle(self.arch, self._variables, self.x_shape, self.width, self.binding,
+                                self._dev.device.index)
+        old.close()
+
+    def restore(self, ckpt_prefix: str, binding: Optional[str] = None) -> None:
+        """``saver.restore(sess, prefix)`` (NoiseFlowWrapper.py:77) on a TF bundle, without TF."""
+        self.load_variables(load_checkpoint(ckpt_prefix), binding)
+
+    def save(self, ckpt_prefix: str) -> None:
+        save_checkpoint(ckpt_prefix, self._variables)
+
+    def get_layer_names(self):
+        """noise_flow_model.py:508-513 (matches hps.txt:1-18)."""
+        return [L.name for L in self.model[0]]
+
+    # ------------------------------------------------------------------ helpers
+    def _cond(self, nlf0, nlf1, iso, cam):
+        return _lib.nf_cond(_first(iso), _first(cam), _first(nlf0), _first(nlf1))
+
+    def _check_mode(self):
+        if self._is_training is True:
+            raise NotImplementedError(
+                "is_training=True (batch-statistics BN, layers.py:388-398) is not on the fused eval path; "
+                "construct NoiseFlow with is_training=False")
+
+    def _run_nll(self, x, y, cond, want_z: bool, flags: int = 0, want_sums: bool = False):
+        dev = self._dev
+        tail = tuple(self.x_shape)
+        xt, was_np = dev.to_dev(x, tail)
+        yt = None
+        if y is not None:
+            yt, _ = dev.to_dev(y, tail)
+            if yt.shape[0] != xt.shape[0]:
+                raise ValueError("x and y batch sizes differ")
+        B = int(xt.shape[0])
+        torch = dev.torch
+        nll = dev.empty((B,))
+        sd = dev.empty((B,))
+        ld = dev.empty((B,))
+        z = dev.empty(xt.shape) if want_z else None
+        sums = torch.zeros((3,), dtype=torch.float64, device=dev.device) if want_sums else None
+        with torch.cuda.device(dev.device):
+            _lib.check(self._flow.lib.nf_nll(
+                self._flow.ptr, xt.data_ptr(), yt.data_ptr() if yt is not None else None, B, C.byref(cond),
+                nll.data_ptr(), sd.data_ptr(), ld.data_ptr(), z.data_ptr() if z is not None else None,
+                sums.data_ptr() if sums is not None else None, flags, dev.stream_ptr()))
+        return nll, sd, ld, z, sums, was_np
+
+    # ------------------------------------------------------------------ NLL direction
+    def inverse(self, x, objective, yy=None, nlf0=None, nlf1=None, iso=None, cam=None):
+        """noise_flow_model.py:394-428: run every bijector's
+        ``_inverse_and_log_det_jacobian``; returns ``(z, objective + Σ log|det J|)``."""
+        self._check_mode()
+        if yy is None and self._flow.has_sdn:
+            raise ValueError("this architecture has an sdn5 layer: the clean image yy is required")
+        nll, sd, ld, z, _, was_np = self._run_nll(x, yy, self._cond(nlf0, nlf1, iso, cam), True, _lib.NF_NO_PRIOR)
+        if objective is None:
+            obj = ld
+        elif isinstance(objective, self._dev.torch.Tensor):
+            obj = objective.to(ld.device, ld.dtype) + ld
+        else:
+            obj = ld + self._dev.torch.as_tensor(np.asarray(objective, np.float32), device=ld.device)
+        return self._dev.back(z, was_np), self._dev.back(obj, was_np)
+
+    def _loss(self, x, y, nlf0=None, nlf1=None, iso=None, cam=None, reuse=False):
+        """noise_flow_model.py:458-480 → ``(nll[B], sd_z)``."""
+        self._check_mode()
+        cond_on = getattr(self.hps, "sidd_cond", "mix") not in (None, "uncond")
+        yy = y if (cond_on or self._flow.has_sdn) else None
+        nll, sd, _, _, _, was_np = self._run_nll(x, yy, self._cond(nlf0, nlf1, iso, cam), False)
+        self.hps.top_shape = list(self.x_shape)
+        sd_z = sd.double().mean().float()
+        return self._dev.back(nll, was_np), (float(sd_z) if was_np else sd_z)
+
+    def loss(self, x, y, nlf0=None, nlf1=None, iso=None, cam=None, reuse=False):
+        """noise_flow_model.py:482-484 → ``(mean_b nll_b, sd_z)``."""
+        self._check_mode()
+        cond_on = getattr(self.hps, "sidd_cond", "mix") not in (None, "uncond")
+        yy = y if (cond_on or self._flow.has_sdn) else None
+        _, _, _, _, sums, was_np = self._run_nll(x, yy, self._cond(nlf0, nlf1, iso, cam), False, 0, True)
+        mean = sums[:2] / sums[2]
+        if was_np:
+            m = mean.cpu().numpy()
+            return np.float32(m[0]), np.float32(m[1])
+        return mean[0].float(), mean[1].float()
+
+    def nll_sums(self, x, y, nlf0=None, nlf1=None, iso=None, cam=None, sums=None):
+        """Device-resident ``float64[3] = (Σ nll, Σ sd, count)`` for one shard of a
+        data-parallel evaluation; pass ``sums`` back in to keep accumulating.  The
+        caller finishes the mean with one RCCL all-reduce (``noise_flow_amd.dist``)."""
+        self._check_mode()
+        dev = self._dev
+        tail = tuple(self.x_shape)
+        xt, _ = dev.to_dev(x, tail)
+        yt = dev.to_dev(y, tail)[0] if y is not None else None
+        torch = dev.torch
+        flags = _lib.NF_ACCUMULATE
+        if sums is None:
+            sums = torch.zeros((3,), dtype=torch.float64, device=dev.device)
+        cond = self._cond(nlf0, nlf1, iso, cam)
+        with torch.cuda.device(dev.device):
+            _lib.check(self._flow.lib.nf_nll(self._flow.ptr, xt.data_ptr(), yt.data_ptr() if yt is not None else None,
+                                             int(xt.shape[0]), C.byref(cond), None, None, None, None,
+                                             sums.data_ptr(), flags, dev.stream_ptr()))
+        return sums
+
+    # ------------------------------------------------------------------ sampling direction
+    def forward(self, z, eps_std=None, yy=None, nlf0=None, nlf1=None, iso=None, cam=None):
+        """noise_flow_model.py:430-447: bijectors in reverse order, ``_forward`` each.
+        ``eps_std`` only matters for multi-level split priors (unused at n_levels = 1)."""
+        self._check_mode()
+        return self._run_sample(z, 1.0, yy, self._cond(nlf0, nlf1, iso, cam), z_is_eps=True)
+
+    def sample(self, y, eps_std=None, yy=None, nlf0=None, nlf1=None, iso=None, cam=None, eps=None, seed=None):
+        """noise_flow_model.py:449-456: ``z = ε·eps_std`` (prior.sample, :499-504), then
+        :meth:`forward`.  ``y`` only supplies the batch shape in the reference.
+
+        ``eps`` (optional, [B,H,W,C]) supplies the N(0,1) draw — the parity path,
+        since TF's ``random_normal`` stream cannot be reproduced (quirk Q11).
+        Without it ε is generated in-kernel (Philox4x32-10 keyed by ``seed``, a
+        running patch counter and the pixel index)."""
+        self._check_mode()
+        temp = 1.0 if eps_std is None else _first(eps_std)
+        cond = self._cond(nlf0, nlf1, iso, cam)
+        if eps is not None:
+            return self._run_sample(eps, temp, yy, cond, z_is_eps=True)
+        return self._run_sample(y, temp, yy, cond, z_is_eps=False, seed=seed)
+
+    def _run_sample(self, z_or_y, temp, yy, cond, z_is_eps, seed=None):
+        dev = self._dev
+        tail = tuple(self.x_shape)
+        if yy is None and self._flow.has_sdn:
+            raise ValueError("this architecture has an sdn5 layer: the clean image yy is required")
+        zt, was_np = dev.to_dev(z_or_y, tail)
+        yt = dev.to_dev(yy, tail)[0] if yy is not None else None
+        B = int(zt.shape[0])
+        out = dev.empty(zt.shape)
+        if z_is_eps:
+            base, sd = 0, 0
+        else:
+            sd = self._seed if seed is None else int(seed)
+            with self._lock:
+                base = self._draws
+                self._draws += B
+        with dev.torch.cuda.device(dev.device):
+            _lib.check(self._flow.lib.nf_sample(
+                self._flow.ptr, yt.data_ptr() if yt is not None else None, zt.data_ptr() if z_is_eps else None,
+                sd & _U64, base, float(temp), B, C.byref(cond), out.data_ptr(), dev.stream_ptr()))
+        return dev.back(out, was_np)
+
+
+def default_hps(**kw) -> SimpleNamespace:
+    """The hyper-parameters the hot path reads, with the shipped values
+    (models/NoiseFlow/hps.txt)."""
+    d = dict(arch="sdn5|unc|unc|unc|unc|gain4|unc|unc|unc|unc", width=4, decomp="LU", flow_permutation=1,
+             squeeze_factor=1, squeeze_type="chessboard", n_levels=1, depth=-1, sidd_cond="mix", gain_init=-5.0,
+             x_shape=[None, 32, 32, 4], seed=0, temp=1.0)
+    d.update(kw)
+    return SimpleNamespace(**d)

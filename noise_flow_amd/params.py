@@ -1,0 +1,223 @@
+"""Architecture string → layer list → flat raw parameter block of the C ABI.
+
+Host-side mirror of ``NoiseFlow.noise_flow_arch`` (reference
+``borealisflows/noise_flow_model.py:71-235``), of the variable naming the
+reference's checkpoints use and of the reference
+initialisers.  The *folding* of these raw parameters (PLU → A, BN-eval, edge
+channel, exp(3·logs)) happens inside the HIP library (``csrc/nf_host.hip``).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+from . import _lib
+
+SUPPORTED_LAYERS = ("unc", "sdn5", "gain4")
+C_I = 1.0   # train_noise_flow.py:207 / NoiseFlowWrapper.py:125
+
+
+@dataclass
+class LayerSpec:
+    kind: str        # 'conv1x1' | 'coupling' | 'sdn5' | 'gain4'
+    name: str        # display name as in hps.txt:1-18 (get_layer_names)
+    arch_index: int  # position i in arch.split('|')
+    nf_type: int     # NF_LAYER_*
+    width: int = 0
+
+
+def parse_arch(arch: str) -> List[LayerSpec]:
+    """noise_flow_model.py:71-235 with flow_permutation = 1 (Conv2d1x1 before every
+    AffineCoupling, noise_flow_model.py:85-90)."""
+    if not arch:
+        raise ValueError("hps.arch must be a non-empty 'a|b|c' string (revnet2d stacks are out of scope)")
+    layers: List[LayerSpec] = []
+    for i, lyr in enumerate(arch.split("|")):
+        if lyr == "unc":
+            layers.append(LayerSpec("conv1x1", "Conv2d_1x1_%d" % i, i, _lib.NF_LAYER_CONV1X1))
+            layers.append(LayerSpec("coupling", "unc_%d" % i, i, _lib.NF_LAYER_COUPLING))
+        elif lyr == "sdn5":
+            layers.append(LayerSpec("sdn5", "sdn_%d" % i, i, _lib.NF_LAYER_SDN5))
+        elif lyr == "gain4":
+            layers.append(LayerSpec("gain4", "gain_%d" % i, i, _lib.NF_LAYER_GAIN4))
+        else:
+            raise NotImplementedError(
+                "arch layer %r is not on the MI355X hot path (supported: %s)" % (lyr, "|".join(SUPPORTED_LAYERS)))
+    return layers
+
+
+def template_scope(k: int) -> str:
+    """tf.make_template scope of the k-th coupling CNN created (layers.py:449,498)."""
+    return "model/real_nvp_conv_template" + ("" if k == 0 else "_%d" % k)
+
+
+def template_binding(layers: List[LayerSpec], binding: str) -> Dict[int, int]:
+    """arch_index of each ``unc`` → template number.
+
+    Template scopes are numbered in the order the coupling CNNs are first CALLED
+    (SURVEY.md quirk Q1): NLL order when the loss graph is built first
+    (``train_noise_flow.py:302``) — ``loss_first`` — and reversed when only the
+    sampling graph exists (``NoiseFlowWrapper.py:64``) — ``sample_first``.
+    """
+    if binding not in ("loss_first", "sample_first"):
+        raise ValueError("binding must be 'loss_first' or 'sample_first'")
+    ids = [l.arch_index for l in layers if l.kind == "coupling"]
+    if binding == "sample_first":
+        ids = ids[::-1]
+    return {i: k for k, i in enumerate(ids)}
+
+
+def conv1x1_names(i: int) -> Dict[str, str]:
+    pre = "level0/bijector%d/Conv2d_1x1_%d/" % (i, i)
+    sfx = "_matpar_lu_conv2d_1x1_%d_0" % i
+    return {k: pre + k + sfx for k in ("P", "sign_S", "log_S", "L_vec", "U_vec")}
+
+
+def _f32(a) -> np.ndarray:
+    return np.asarray(a, dtype=np.float32).reshape(-1)
+
+
+def pack(arch: str, variables: Dict[str, np.ndarray], width: int, binding: str = "loss_first"):
+    """→ (layers, descs ctypes array, params float32 ndarray) in the canonical raw
+    layout documented in include/noiseflow_hip.h."""
+    layers = parse_arch(arch)
+    return pack_layers(layers, variables, width, template_binding(layers, binding))
+
+
+def pack_layers(layers: List[LayerSpec], variables: Dict[str, np.ndarray], width: int, tmpl: Dict[int, int]):
+    """Pack an explicit layer list (e.g. ONE bijector of a larger architecture);
+    ``tmpl`` maps the arch index of each coupling to its template scope number."""
+    chunks: List[np.ndarray] = []
+    offsets: List[int] = []
+    pos = 0
+
+    def need(name: str) -> np.ndarray:
+        if name not in variables:
+            raise KeyError("checkpoint variable %r not found" % name)
+        return variables[name]
+
+    for L in layers:
+        if L.kind == "conv1x1":
+            n = conv1x1_names(L.arch_index)
+            blk = np.concatenate([_f32(need(n["P"])), _f32(need(n["sign_S"])), _f32(need(n["log_S"])),
+                                  _f32(need(n["L_vec"])), _f32(need(n["U_vec"]))])
+        elif L.kind == "coupling":
+            L.width = int(width)
+            t = template_scope(tmpl[L.arch_index]) + "/"
+            w1 = np.asarray(need(t + "l_1/W"), np.float32)
+            if w1.shape != (3, 3, 2, width):
+                raise ValueError("%sl_1/W has shape %s, expected (3,3,2,%d)" % (t, w1.shape, width))
+            blk = np.concatenate([
+                _f32(w1), _f32(need(t + "l_1/b")),
+                _f32(need(t + "bn_nvp_conv_1/mean")), _f32(need(t + "bn_nvp_conv_1/var")),
+                _f32(need(t + "l_2/W")), _f32(need(t + "l_2/b")),
+                _f32(need(t + "bn_nvp_conv_2/mean")), _f32(need(t + "bn_nvp_conv_2/var")),
+                _f32(need(t + "l_last/W")), _f32(need(t + "l_last/b")), _f32(need(t + "l_last/logs")),
+                _f32(need("level0/bijector%d/rescaling_scale0" % L.arch_index)),
+            ])
+        elif L.kind == "sdn5":
+            blk = np.concatenate([
+                _f32(need("model/sdn_gain/beta1")), _f32(need("model/sdn_gain/beta2")),
+                _f32(need("model/sdn_gain/gain_params")), _f32(need("model/sdn_gain/cam_params")),
+                np.asarray([C_I], np.float32)])
+        else:  # gain4
+            blk = _f32(need("model/sdn_gain/gain_val"))
+        expect = _lib.load().nf_layer_param_count(L.nf_type, L.width)
+        if blk.size != expect:
+            raise ValueError("layer %s: %d raw parameters, C ABI expects %d" % (L.name, blk.size, expect))
+        offsets.append(pos)
+        chunks.append(blk)
+        pos += blk.size
+    params = np.ascontiguousarray(np.concatenate(chunks), dtype=np.float32)
+    descs = (_lib.nf_layer_desc * len(layers))()
+    for d, L, off in zip(descs, layers, offsets):
+        d.type, d.width, d.param_offset = L.nf_type, L.width, off
+    return layers, descs, params
+
+
+# ----------------------------------------------------------------------------
+# fresh initialisation (what tf.global_variables_initializer would produce)
+# ----------------------------------------------------------------------------
+def _fill_triangular_positions(n: int, upper: bool) -> np.ndarray:
+    """Index map of tfdist.fill_triangular: entry (i,j) holds k+1 where vector
+    element k lands (0 = outside the triangle)."""
+    m = n * (n + 1) // 2
+    v = np.arange(1, m + 1)
+    if upper:
+        return np.triu(np.concatenate([v, v[n:][::-1]]).reshape(n, n))
+    return np.tril(np.concatenate([v[n:], v[::-1]]).reshape(n, n))
+
+
+def stricttri2vec(mat: np.ndarray, upper: bool) -> np.ndarray:
+    """matrix_param.py:59-97."""
+    trim = mat[:-1, 1:] if upper else mat[1:, :-1]
+    n = trim.shape[0]
+    pos = _fill_triangular_positions(n, upper)
+    out = np.zeros(n * (n + 1) // 2, dtype=mat.dtype)
+    for i in range(n):
+        for j in range(n):
+            if pos[i, j]:
+                out[pos[i, j] - 1] = trim[i, j]
+    return out
+
+
+def init_variables(arch: str, width: int = 4, channels: int = 4, seed: int = 0) -> Dict[str, np.ndarray]:
+    """Fresh variables under the reference's names with the reference's
+    initialisers: QR-orthogonal 1x1 matrix → scipy LU (layers.py:95,
+    matrix_param.py:100-123); l_1/l_2 ~ N(0, (width/512·0.05)²), zero biases
+    (layers.py:598-609); zero l_last W/b/logs (layers.py:662-673); BN mean 0,
+    var 1 (layers.py:382-387); rescaling_scale 1e-4 (layers.py:271-273);
+    sdn/gain parameters of train_noise_flow.py:201-214 and cond_utils.py:438."""
+    import scipy.linalg as sla
+    rng = np.random.RandomState(seed)
+    layers = parse_arch(arch)
+    v: Dict[str, np.ndarray] = {}
+    c2 = channels // 2
+    k = 0
+    for L in layers:
+        if L.kind in ("coupling", "sdn5", "gain4"):
+            v["level0/bijector%d/rescaling_scale0" % L.arch_index] = np.float32(1e-4)
+        if L.kind == "conv1x1":
+            q = sla.qr(rng.randn(channels, channels))[0].astype(np.float32)
+            p, l, u = sla.lu(q)
+            s = np.diag(u)
+            n = conv1x1_names(L.arch_index)
+            v[n["P"]] = p.astype(np.float32)
+            v[n["sign_S"]] = np.sign(s).astype(np.float32)
+            v[n["log_S"]] = np.log(np.abs(s)).astype(np.float32)
+            v[n["L_vec"]] = stricttri2vec(l, False).astype(np.float32)
+            v[n["U_vec"]] = stricttri2vec(np.triu(u, 1), True).astype(np.float32)
+        elif L.kind == "coupling":
+            t = template_scope(k) + "/"
+            k += 1
+            std = width / 512 * 0.05
+            v[t + "l_1/W"] = (rng.randn(3, 3, c2, width) * std).astype(np.float32)
+            v[t + "l_1/b"] = np.zeros((1, 1, 1, width), np.float32)
+            v[t + "l_2/W"] = (rng.randn(1, 1, width, width) * std).astype(np.float32)
+            v[t + "l_2/b"] = np.zeros((1, 1, 1, width), np.float32)
+            v[t + "l_last/W"] = np.zeros((3, 3, width + 1, 2 * c2), np.float32)
+            v[t + "l_last/b"] = np.zeros((1, 1, 1, 2 * c2), np.float32)
+            v[t + "l_last/logs"] = np.zeros((1, 2 * c2), np.float32)
+            for b in ("bn_nvp_conv_1", "bn_nvp_conv_2"):
+                v[t + b + "/mean"] = np.zeros((width,), np.float32)
+                v[t + b + "/var"] = np.ones((width,), np.float32)
+    if any(L.kind in ("sdn5", "gain4") for L in layers):
+        v["model/sdn_gain/beta1"] = np.full((1,), -5.0 / C_I, np.float32)
+        v["model/sdn_gain/beta2"] = np.zeros((1,), np.float32)
+        v["model/sdn_gain/gain_params"] = np.full((5,), -5.0 / C_I, np.float32)
+        v["model/sdn_gain/cam_params"] = np.ones((3, 5), np.float32)
+        v["model/sdn_gain/gain_val"] = np.ones((1,), np.float32)
+    return v
+
+
+def count_trainable(variables: Dict[str, np.ndarray]) -> int:
+    """``num_params`` as logged to hps.txt (train_noise_flow.py:309-312): all
+    variables except the LU permutation / signs and the BN running statistics."""
+    n = 0
+    for name, arr in variables.items():
+        if "/P_matpar" in name or "/sign_S_matpar" in name or name.endswith("/mean") or name.endswith("/var"):
+            continue
+        n += int(np.asarray(arr).size)
+    return n

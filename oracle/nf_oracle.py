@@ -1,0 +1,475 @@
+"""CPU ORACLE — test infrastructure only.
+
+A numpy restatement of the reference's Noise Flow bijector stack (SURVEY.md
+Appendix A), used ONLY as the checker by ``tests/``, ``__graft_entry__.smoke()``
+and the ``cpu_baseline`` leg of ``bench.py``.  Nothing under ``noise_flow_amd/``
+imports it; the product path is the HIP library and fails loudly without it.
+
+PARITY PINNING: the reference cannot run here (TensorFlow 1.12 / TFP 0.5 are not
+installed, there is no network) and it ships no tests or golden vectors, so this
+oracle is **"parity unpinned"** by reference outputs.  What pins it instead
+(tests/test_oracle.py): the shipped checkpoint (143 tensors / 2433 trainable
+parameters), fresh-init analytic known answers (NLL = ½·HWC·log2π + ½‖x‖² for
+``unc`` stacks, closed-form ``sdn5`` scale), structural invariants
+(sample∘nll = id, slogdet(A) = Σ log_S, log-det vs a finite-difference Jacobian
+on a toy patch) and the plausibility band of the shipped model on S6-NLF noise
+(NLL/dim within 0.05 nat of the generating density, sd_z in [0.8, 1.0]).
+
+Every function cites the reference file:line (relative to /root/reference) it
+follows.  ``dtype=np.float64`` is the truth the HIP path is compared against;
+``dtype=np.float32`` follows the same op order in single precision (what the TF1
+CPU graph would compute, up to its unknowable accumulation order).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+ISO_VALS = (100.0, 400.0, 800.0, 1600.0, 3200.0)   # cond_utils.py:225
+CAM_NAMES = ("IP", "GP", "S6", "N6", "G4")          # cond_utils.py:213, sidd_utils.py:262
+BN_EPS = 1e-4                                       # layers.py:378
+BN_DECAY = 0.1                                      # layers.py:378
+LOGSCALE_FACTOR = 3.0                               # layers.py:653
+
+
+# ----------------------------------------------------------------------------
+# matrix_param.py — PLU parameterisation of the 1x1 conv
+# ----------------------------------------------------------------------------
+def fill_triangular(v: np.ndarray, upper: bool) -> np.ndarray:
+    """``tfdist.fill_triangular`` (TF 1.12 ``distributions/util.py``) for a 1-D
+    vector of length n(n+1)/2, as called from matrix_param.py:44."""
+    v = np.asarray(v)
+    m = v.shape[-1]
+    n = int(round((np.sqrt(8 * m + 1) - 1) / 2))
+    if n * (n + 1) // 2 != m:
+        raise ValueError("vector length %d is not triangular" % m)
+    if upper:
+        flat = np.concatenate([v, v[n:][::-1]])
+        return np.triu(flat.reshape(n, n))
+    flat = np.concatenate([v[n:], v[::-1]])
+    return np.tril(flat.reshape(n, n))
+
+
+def fill_triangular_inverse(mat: np.ndarray, upper: bool) -> np.ndarray:
+    """``tfdist.fill_triangular_inverse`` as used at matrix_param.py:87: element k
+    of the vector is read from where :func:`fill_triangular` would put it."""
+    mat = np.asarray(mat)
+    n = mat.shape[-1]
+    m = n * (n + 1) // 2
+    probe = fill_triangular(np.arange(1, m + 1, dtype=np.float64), upper)
+    out = np.zeros(m, dtype=mat.dtype)
+    for i in range(n):
+        for j in range(n):
+            k = int(probe[i, j])
+            if k:
+                out[k - 1] = mat[i, j]
+    return out
+
+
+def vec2stricttri(v: np.ndarray, upper: bool) -> np.ndarray:
+    """matrix_param.py:31-56: fill the (n-1)x(n-1) triangle, then pad to n x n
+    so the result is *strictly* triangular."""
+    base = fill_triangular(v, upper)
+    if upper:   # one zero row at the bottom, one zero column on the left
+        return np.pad(base, [(0, 1), (1, 0)])
+    return np.pad(base, [(1, 0), (0, 1)])   # zero row on top, zero column on the right
+
+
+def stricttri2vec(mat: np.ndarray, upper: bool) -> np.ndarray:
+    """matrix_param.py:59-97 (inverse of :func:`vec2stricttri`)."""
+    mat = np.asarray(mat)
+    if upper:
+        trim = np.triu(mat[:-1, 1:])
+    else:
+        trim = np.tril(mat[1:, :-1])
+    return fill_triangular_inverse(trim, upper)
+
+
+def matrix_param_lu(P, sign_S, log_S, L_vec, U_vec, dtype=np.float64):
+    """matrix_param.py:100-140 → (A, A_inv, log_abs_det)."""
+    P = np.asarray(P, dtype)
+    log_S = np.asarray(log_S, dtype)
+    n = log_S.shape[0]
+    L = vec2stricttri(np.asarray(L_vec, dtype), upper=False) + np.eye(n, dtype=dtype)
+    U = vec2stricttri(np.asarray(U_vec, dtype), upper=True) + np.diag(np.asarray(sign_S, dtype) * np.exp(log_S))
+    A = P @ (L @ U)                                              # :130
+    import scipy.linalg as sla
+    inner = sla.solve_triangular(L, P.T, lower=True)             # :135-136
+    A_inv = sla.solve_triangular(U, inner, lower=False)
+    return A.astype(dtype), A_inv.astype(dtype), dtype(np.sum(log_S))   # :138
+
+
+def lu_init_from_matrix(A0: np.ndarray) -> Dict[str, np.ndarray]:
+    """matrix_param.py:100-123: initial (P, sign_S, log_S, L_vec, U_vec) from a matrix."""
+    import scipy.linalg as sla
+    p, l, u = sla.lu(A0)
+    s = np.diag(u)
+    return {
+        "P": p.astype(np.float32),
+        "sign_S": np.sign(s).astype(np.float32),
+        "log_S": np.log(np.abs(s)).astype(np.float32),
+        "L_vec": stricttri2vec(l, upper=False).astype(np.float32),
+        "U_vec": stricttri2vec(np.triu(u, k=1), upper=True).astype(np.float32),
+    }
+
+
+# ----------------------------------------------------------------------------
+# layers.py — conv wrappers, batch norm, coupling CNN
+# ----------------------------------------------------------------------------
+def conv2d_nhwc(x: np.ndarray, w: np.ndarray, pad_same: bool) -> np.ndarray:
+    """``tf.nn.conv2d`` NHWC, stride 1 (cross-correlation), 'SAME' zero pad or
+    'VALID' (layers.py:604, :665)."""
+    kh, kw, cin, cout = w.shape
+    if pad_same:
+        a, b = (kh - 1) // 2, (kw - 1) // 2
+        x = np.pad(x, [(0, 0), (a, a), (b, b), (0, 0)])
+    n, hp, wp, _ = x.shape
+    ho, wo = hp - kh + 1, wp - kw + 1
+    out = np.zeros((n, ho, wo, cout), dtype=x.dtype)
+    for di in range(kh):
+        for dj in range(kw):
+            out += x[:, di:di + ho, dj:dj + wo, :] @ w[di, dj]
+    return out
+
+
+def add_edge_padding(x: np.ndarray) -> np.ndarray:
+    """layers.py:555-583 for a 3x3 filter: zero-pad by one pixel and append a
+    channel that is 1 on the outer ring of the padded map."""
+    xp = np.pad(x, [(0, 0), (1, 1), (1, 1), (0, 0)])
+    e = np.zeros(xp.shape[:3] + (1,), dtype=x.dtype)
+    e[:, :1, :, 0] = 1
+    e[:, -1:, :, 0] = 1
+    e[:, :, :1, 0] = 1
+    e[:, :, -1:, 0] = 1
+    return np.concatenate([xp, e], axis=3)
+
+
+def batch_norm(h, mean, var, training: bool):
+    """layers.py:378-401.  Eval: stored statistics.  Training: moments over
+    (N,H,W); returns the EMA-updated running stats as well."""
+    dt = h.dtype.type
+    if training:
+        m = h.mean(axis=(0, 1, 2))
+        v = h.var(axis=(0, 1, 2))
+        new_mean = mean - dt(BN_DECAY) * (mean - m)
+        new_var = var - dt(BN_DECAY) * (var - v)
+        return (h - m) / np.sqrt(v + dt(BN_EPS)), new_mean, new_var
+    return (h - mean) / np.sqrt(var + dt(BN_EPS)), mean, var
+
+
+def coupling_cnn(z0: np.ndarray, p: Dict[str, np.ndarray], training: bool = False):
+    """real_nvp_conv_template._fn, layers.py:463-497 → (shift, raw_log_scale)."""
+    dt = z0.dtype.type
+    h = conv2d_nhwc(z0, p["l_1/W"], True) + p["l_1/b"].reshape(1, 1, 1, -1)       # :469, 586-613
+    h, _, _ = batch_norm(h, p["bn1/mean"], p["bn1/var"], training)               # :472-477
+    h = np.maximum(h, dt(0))                                                     # :478
+    h = conv2d_nhwc(h, p["l_2/W"], True) + p["l_2/b"].reshape(1, 1, 1, -1)        # :480
+    h, _, _ = batch_norm(h, p["bn2/mean"], p["bn2/var"], training)               # :483-488
+    h = np.maximum(h, dt(0))                                                     # :489
+    o = conv2d_nhwc(add_edge_padding(h), p["l_last/W"], False)                   # :491, 651-666
+    o = o + p["l_last/b"].reshape(1, 1, 1, -1)                                   # :670
+    o = o * np.exp(p["l_last/logs"].reshape(1, 1, 1, -1) * dt(LOGSCALE_FACTOR))  # :671-673
+    c2 = o.shape[-1] // 2
+    return o[..., :c2], o[..., c2:]                                              # :494 tf.split
+
+
+# ----------------------------------------------------------------------------
+# bijectors
+# ----------------------------------------------------------------------------
+def affine_coupling_inverse(z, p, training=False):
+    """AffineCoupling._inverse_and_log_det_jacobian, layers.py:355-375 (NLL direction)."""
+    c2 = z.shape[-1] // 2
+    z0, z1 = z[..., :c2], z[..., c2:]
+    shift, raw = coupling_cnn(z0, p, training)
+    ls = p["rescaling_scale"] * np.tanh(raw)
+    x1 = z1 * np.exp(ls) + shift
+    return np.concatenate([z0, x1], axis=-1), ls.sum(axis=(1, 2, 3))
+
+
+def affine_coupling_forward(x, p, training=False):
+    """AffineCoupling._forward, layers.py:275-291 (sampling direction)."""
+    c2 = x.shape[-1] // 2
+    x0, x1 = x[..., :c2], x[..., c2:]
+    shift, raw = coupling_cnn(x0, p, training)
+    ls = p["rescaling_scale"] * np.tanh(raw)
+    y1 = (x1 - shift) * np.exp(-ls)
+    return np.concatenate([x0, y1], axis=-1)
+
+
+def conv1x1_inverse(z, A, log_abs_det):
+    """Conv2d1x1._inverse_and_log_det_jacobian, layers.py:117-130,137-140: z @ A per pixel."""
+    h, w = z.shape[1:3]
+    ld = np.full((z.shape[0],), log_abs_det * (h * w), dtype=z.dtype)
+    return z @ A, ld
+
+
+def conv1x1_forward(x, A_inv):
+    """Conv2d1x1._forward, layers.py:108-115: x @ A_inv per pixel."""
+    return x @ A_inv
+
+
+def sdn_ex5_scalars(p: Dict[str, np.ndarray], iso: float, cam: float, c_i: float = 1.0, dtype=np.float64):
+    """Host scalars of sdn_model_params_ex5, cond_utils.py:205-239 → (beta1, beta2, gain)."""
+    dt = dtype
+    cam_vals = np.arange(5, dtype=np.float64)
+    idx = np.where(cam_vals == float(cam))[0]
+    if idx.size == 0:
+        raise IndexError("unknown camera id %r" % (cam,))        # cam_idx[0] on an empty tensor, :216-217
+    cp = np.exp(dt(c_i) * np.asarray(p["cam_params"], dt)[:, idx[0]])     # :218-220
+    k = np.where(np.asarray(ISO_VALS) == float(iso))[0]
+    g = np.asarray(p["gain_params"], dt)[k[0]] if k.size else dt(0)        # :227-229 (unknown ISO → 0)
+    gain = np.exp(dt(c_i) * g * cp[2]) * dt(iso)                          # :230
+    beta1 = np.exp(dt(c_i) * np.asarray(p["beta1"], dt).reshape(-1)[0] * cp[0])   # :236
+    beta2 = np.exp(dt(c_i) * np.asarray(p["beta2"], dt).reshape(-1)[0] * cp[1])   # :237
+    return dt(beta1), dt(beta2), dt(gain)
+
+
+def sdn_ex5_scale(y, p, iso, cam):
+    dt = y.dtype.type
+    b1, b2, gain = sdn_ex5_scalars(p, iso, cam, dtype=dt)
+    return np.sqrt(b1 * y / gain + b2)                                    # cond_utils.py:238
+
+
+def sdn_ex5_inverse(x, y, p, iso, cam):
+    """AffineCouplingSdnEx5._inverse_and_log_det_jacobian, AffineCouplingSdnEx5.py:118-132."""
+    scale = sdn_ex5_scale(y, p, iso, cam)
+    return x / scale, -np.log(scale).sum(axis=(1, 2, 3))
+
+
+def sdn_ex5_forward(z, y, p, iso, cam):
+    """AffineCouplingSdnEx5._forward, AffineCouplingSdnEx5.py:50-66."""
+    return z * sdn_ex5_scale(y, p, iso, cam)
+
+
+def gain_ex4_inverse(z, gain_val):
+    """AffineCouplingGainEx4._inverse_and_log_det_jacobian, AffineCouplingGainEx4.py:114-127."""
+    dt = z.dtype.type
+    g = dt(np.asarray(gain_val).reshape(-1)[0])
+    n = z.shape[1] * z.shape[2] * z.shape[3]
+    return z / g, np.full((z.shape[0],), -n * np.log(g), dtype=z.dtype)
+
+
+def gain_ex4_forward(x, gain_val):
+    """AffineCouplingGainEx4._forward, AffineCouplingGainEx4.py:49-65."""
+    return x * x.dtype.type(np.asarray(gain_val).reshape(-1)[0])
+
+
+def prior_logp(z):
+    """gaussian_diag.logp with mean = logsd = 0, noise_flow_model.py:486-497,537-539."""
+    dt = z.dtype.type
+    return (dt(-0.5) * (dt(np.log(2 * np.pi)) + z * z)).sum(axis=(1, 2, 3))
+
+
+# ----------------------------------------------------------------------------
+# variable naming (checkpoint names, Appendix B of SURVEY.md) and binding
+# ----------------------------------------------------------------------------
+def parse_arch(arch: str) -> List[Tuple[str, int]]:
+    """noise_flow_model.py:71-235: 'a|b|c' → [(layer_type, i)], i = position in arch."""
+    out = []
+    for i, lyr in enumerate(arch.split("|")):
+        if lyr not in ("unc", "sdn5", "gain4"):
+            raise ValueError("oracle supports unc|sdn5|gain4 only, got %r" % lyr)
+        out.append((lyr, i))
+    return out
+
+
+def layer_names(arch: str) -> List[str]:
+    """NoiseFlow.get_layer_names, noise_flow_model.py:508-513 (= hps.txt:1-18)."""
+    names = []
+    for lyr, i in parse_arch(arch):
+        if lyr == "unc":
+            names += ["Conv2d_1x1_%d" % i, "unc_%d" % i]
+        elif lyr == "sdn5":
+            names.append("sdn_%d" % i)
+        else:
+            names.append("gain_%d" % i)
+    return names
+
+
+def template_name(k: int) -> str:
+    return "model/real_nvp_conv_template" + ("" if k == 0 else "_%d" % k)
+
+
+def bind_variables(arch: str, variables: Dict[str, np.ndarray], binding: str = "loss_first", dtype=np.float64):
+    """Attach checkpoint variables to layers.
+
+    ``binding``: tf.make_template scopes are numbered in the
+    order the coupling CNNs are FIRST CALLED — NLL order when the loss graph is
+    built first (train_noise_flow.py:302), reversed when only the sampling graph
+    is built (NoiseFlowWrapper.py:64, noise_flow_model.py:435).
+    """
+    if binding not in ("loss_first", "sample_first"):
+        raise ValueError("binding must be loss_first or sample_first")
+    arch_l = parse_arch(arch)
+    unc_ids = [i for lyr, i in arch_l if lyr == "unc"]
+    order = unc_ids if binding == "loss_first" else unc_ids[::-1]
+    tmpl_of = {i: k for k, i in enumerate(order)}
+    f = lambda a: np.asarray(a, dtype)
+    layers = []
+    for lyr, i in arch_l:
+        if lyr == "unc":
+            pre = "level0/bijector%d/Conv2d_1x1_%d/" % (i, i)
+            sfx = "_matpar_lu_conv2d_1x1_%d_0" % i
+            A, A_inv, lad = matrix_param_lu(variables[pre + "P" + sfx], variables[pre + "sign_S" + sfx],
+                                            variables[pre + "log_S" + sfx], variables[pre + "L_vec" + sfx],
+                                            variables[pre + "U_vec" + sfx], dtype)
+            layers.append({"type": "conv1x1", "name": "Conv2d_1x1_%d" % i, "A": A, "A_inv": A_inv, "log_abs_det": lad})
+            t = template_name(tmpl_of[i]) + "/"
+            p = {
+                "l_1/W": f(variables[t + "l_1/W"]), "l_1/b": f(variables[t + "l_1/b"]).reshape(-1),
+                "bn1/mean": f(variables[t + "bn_nvp_conv_1/mean"]), "bn1/var": f(variables[t + "bn_nvp_conv_1/var"]),
+                "l_2/W": f(variables[t + "l_2/W"]), "l_2/b": f(variables[t + "l_2/b"]).reshape(-1),
+                "bn2/mean": f(variables[t + "bn_nvp_conv_2/mean"]), "bn2/var": f(variables[t + "bn_nvp_conv_2/var"]),
+                "l_last/W": f(variables[t + "l_last/W"]), "l_last/b": f(variables[t + "l_last/b"]).reshape(-1),
+                "l_last/logs": f(variables[t + "l_last/logs"]).reshape(-1),
+                "rescaling_scale": dtype(variables["level0/bijector%d/rescaling_scale0" % i]),
+            }
+            layers.append({"type": "coupling", "name": "unc_%d" % i, "p": p})
+        elif lyr == "sdn5":
+            p = {k: f(variables["model/sdn_gain/" + k]) for k in ("beta1", "beta2", "gain_params", "cam_params")}
+            layers.append({"type": "sdn5", "name": "sdn_%d" % i, "p": p})
+        else:
+            layers.append({"type": "gain4", "name": "gain_%d" % i, "gain_val": f(variables["model/sdn_gain/gain_val"])})
+    return layers
+
+
+def fresh_variables(arch: str, width: int = 4, channels: int = 4, seed: int = 0) -> Dict[str, np.ndarray]:
+    """Fresh-init variables under the reference's names and initialisers:
+    QR-orthogonal 1x1 matrix (layers.py:95) decomposed by scipy LU
+    (matrix_param.py:100-123); l_1/l_2 ~ N(0, (width/512*0.05)^2), biases 0
+    (layers.py:598-609); l_last W=b=logs=0 (layers.py:662-673); BN mean 0 / var 1
+    (layers.py:382-387); rescaling_scale 1e-4 (layers.py:271-273); sdn/gain
+    parameters from train_noise_flow.py:201-214 and cond_utils.py:438."""
+    import scipy.linalg as sla
+    rng = np.random.RandomState(seed)
+    v: Dict[str, np.ndarray] = {}
+    c2 = channels // 2
+    k = 0
+    for lyr, i in parse_arch(arch):
+        v["level0/bijector%d/rescaling_scale0" % i] = np.float32(1e-4)
+        if lyr == "unc":
+            q = sla.qr(rng.randn(channels, channels))[0].astype(np.float32)
+            lu = lu_init_from_matrix(q)
+            pre = "level0/bijector%d/Conv2d_1x1_%d/" % (i, i)
+            sfx = "_matpar_lu_conv2d_1x1_%d_0" % i
+            for nm, arr in lu.items():
+                v[pre + nm + sfx] = arr
+            t = template_name(k) + "/"
+            k += 1
+            std = width / 512 * 0.05
+            v[t + "l_1/W"] = (rng.randn(3, 3, c2, width) * std).astype(np.float32)
+            v[t + "l_1/b"] = np.zeros((1, 1, 1, width), np.float32)
+            v[t + "l_2/W"] = (rng.randn(1, 1, width, width) * std).astype(np.float32)
+            v[t + "l_2/b"] = np.zeros((1, 1, 1, width), np.float32)
+            v[t + "l_last/W"] = np.zeros((3, 3, width + 1, 2 * c2), np.float32)
+            v[t + "l_last/b"] = np.zeros((1, 1, 1, 2 * c2), np.float32)
+            v[t + "l_last/logs"] = np.zeros((1, 2 * c2), np.float32)
+            for b in ("bn_nvp_conv_1", "bn_nvp_conv_2"):
+                v[t + b + "/mean"] = np.zeros((width,), np.float32)
+                v[t + b + "/var"] = np.ones((width,), np.float32)
+    if any(l in ("sdn5", "gain4") for l, _ in parse_arch(arch)):
+        v["model/sdn_gain/beta1"] = np.full((1,), -5.0, np.float32)
+        v["model/sdn_gain/beta2"] = np.zeros((1,), np.float32)
+        v["model/sdn_gain/gain_params"] = np.full((5,), -5.0, np.float32)
+        v["model/sdn_gain/cam_params"] = np.ones((3, 5), np.float32)
+        v["model/sdn_gain/gain_val"] = np.ones((1,), np.float32)
+    return v
+
+
+def count_trainable(variables: Dict[str, np.ndarray]) -> int:
+    """num_params as written to hps.txt (train_noise_flow.py:309-312): everything
+    except the LU permutation/sign and the BN running statistics."""
+    n = 0
+    for name, arr in variables.items():
+        if "/P_matpar" in name or "/sign_S_matpar" in name or name.endswith("/mean") or name.endswith("/var"):
+            continue
+        n += int(np.asarray(arr).size)
+    return n
+
+
+# ----------------------------------------------------------------------------
+# the model
+# ----------------------------------------------------------------------------
+class NoiseFlowOracle:
+    """NoiseFlow (noise_flow_model.py:44-513) restated on numpy, eval-mode BN by
+    default.  ``x`` = noise, ``y`` = clean image, ``z`` = latent."""
+
+    def __init__(self, arch: str, variables: Dict[str, np.ndarray], binding: str = "loss_first",
+                 dtype=np.float64, sidd_cond: str = "mix"):
+        self.arch = arch
+        self.dtype = dtype
+        self.sidd_cond = sidd_cond
+        self.layers = bind_variables(arch, variables, binding, dtype)
+
+    # -- NLL direction: NoiseFlow.inverse, noise_flow_model.py:394-428 --------
+    def inverse(self, x, y=None, iso=None, cam=None, training=False, return_layers=False):
+        dt = self.dtype
+        z = np.asarray(x, dt)
+        y = None if y is None else np.asarray(y, dt)
+        obj = np.zeros((z.shape[0],), dt)
+        per_layer = []
+        for L in self.layers:
+            if L["type"] == "conv1x1":
+                z, ld = conv1x1_inverse(z, L["A"], L["log_abs_det"])
+            elif L["type"] == "coupling":
+                z, ld = affine_coupling_inverse(z, L["p"], training)
+            elif L["type"] == "sdn5":
+                z, ld = sdn_ex5_inverse(z, y, L["p"], iso, cam)
+            else:
+                z, ld = gain_ex4_inverse(z, L["gain_val"])
+            obj = obj + ld
+            if return_layers:
+                per_layer.append((L["name"], z.copy(), ld.copy()))
+        if return_layers:
+            return z, obj, per_layer
+        return z, obj
+
+    # -- NoiseFlow._loss / loss, noise_flow_model.py:458-484 ------------------
+    def nll(self, x, y=None, iso=None, cam=None, training=False):
+        """→ (nll[B], sd_z scalar, z)."""
+        z, obj = self.inverse(x, y, iso, cam, training)
+        obj = obj + prior_logp(z)
+        var = z.var(axis=(1, 2, 3))                   # tf.nn.moments → population variance, :477
+        return -obj, np.sqrt(var).mean(), z
+
+    def loss(self, x, y=None, iso=None, cam=None, training=False):
+        nll, sd_z, _ = self.nll(x, y, iso, cam, training)
+        return nll.mean(), sd_z
+
+    # -- sampling direction: NoiseFlow.forward/sample, noise_flow_model.py:430-456
+    def forward(self, z, y=None, iso=None, cam=None, training=False):
+        dt = self.dtype
+        x = np.asarray(z, dt)
+        y = None if y is None else np.asarray(y, dt)
+        for L in reversed(self.layers):
+            if L["type"] == "conv1x1":
+                x = conv1x1_forward(x, L["A_inv"])
+            elif L["type"] == "coupling":
+                x = affine_coupling_forward(x, L["p"], training)
+            elif L["type"] == "sdn5":
+                x = sdn_ex5_forward(x, y, L["p"], iso, cam)
+            else:
+                x = gain_ex4_forward(x, L["gain_val"])
+        return x
+
+    def sample(self, eps, temp, y=None, iso=None, cam=None, training=False):
+        """prior.sample(eps_std) = eps * temp (noise_flow_model.py:499-504), then forward."""
+        return self.forward(np.asarray(eps, self.dtype) * self.dtype(temp), y, iso, cam, training)
+
+
+# ----------------------------------------------------------------------------
+# closed-form baselines (sidd/PatchStatsCalculator.py:104-115)
+# ----------------------------------------------------------------------------
+def nll_gauss(x, sd):
+    """Per-patch NLL of x under N(0, sd^2) i.i.d."""
+    x = np.asarray(x, np.float64)
+    n = x[0].size
+    return 0.5 * n * np.log(2 * np.pi * sd * sd) + 0.5 * (x * x).sum(axis=(1, 2, 3)) / (sd * sd)
+
+
+def nll_sdn(x, y, b1, b2):
+    """Per-patch NLL of x under the camera NLF N(0, b1*y + b2)."""
+    x = np.asarray(x, np.float64)
+    var = b1 * np.asarray(y, np.float64) + b2
+    return 0.5 * (np.log(2 * np.pi * var) + x * x / var).sum(axis=(1, 2, 3))

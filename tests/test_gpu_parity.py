@@ -1,0 +1,270 @@
+"""GPU parity: the HIP path (through the C ABI) against the fp64 CPU oracle.
+
+Tolerances (BASELINE.json north_star): per-patch NLL within 1e-5 relative;
+latents / samples within 1e-5 of the tensor's scale (max |value|), i.e.
+|hip - oracle| <= 1e-5 * max|oracle| elementwise.
+"""
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import FULL_ARCH, SHIPPED_DIR, make_inputs, trained_like_variables
+
+pytestmark = pytest.mark.gpu
+
+NLL_RTOL = 1e-5
+ELEM_RTOL = 1e-5
+
+
+def _model(arch, variables, x_shape=(32, 32, 4), width=4, binding="loss_first"):
+    from noise_flow_amd import NoiseFlow, default_hps
+    hps = default_hps(arch=arch, width=width)
+    return NoiseFlow(list(x_shape), False, hps, variables=variables, binding=binding)
+
+
+def _oracle(arch, variables, binding="loss_first"):
+    from oracle.nf_oracle import NoiseFlowOracle
+    return NoiseFlowOracle(arch, variables, binding)
+
+
+def _close_elem(a, ref, rtol=ELEM_RTOL):
+    scale = np.abs(ref).max()
+    err = np.abs(np.asarray(a, np.float64) - ref).max()
+    assert err <= rtol * scale, "max err %.3e > %.1e * %.3e" % (err, rtol, scale)
+
+
+def test_library_is_the_hip_extension():
+    from noise_flow_amd import _lib
+    lib = _lib.load()
+    assert lib.nf_abi_version() == 1
+    assert _lib.LIB_PATH.endswith("noise_flow_amd/csrc/libnoiseflow_hip.so")
+
+
+@pytest.mark.parametrize("iso,cam,b1", [(100, 2, 0.000479), (800, 2, 0.003696), (3200, 2, 0.01993), (400, 0, 0.000735),
+                                        (1600, 4, 0.005)])
+def test_nll_full_arch_shipped(shipped_variables, oracle_full, iso, cam, b1):
+    x, y = make_inputs(24, seed=iso + cam, b1=b1)
+    m = _model(FULL_ARCH, shipped_variables)
+    nll, sd_z = m._loss(x, y, [0.0], [0.0], [iso], [cam])
+    ref_nll, ref_sd, _ = oracle_full.nll(x, y, iso, cam)
+    np.testing.assert_allclose(nll, ref_nll, rtol=NLL_RTOL)
+    assert abs(sd_z - ref_sd) <= 1e-5 * ref_sd
+    mean_nll, sd2 = m.loss(x, y, [0.0], [0.0], [iso], [cam])
+    assert abs(mean_nll - ref_nll.mean()) <= NLL_RTOL * abs(ref_nll.mean())
+    assert abs(sd2 - ref_sd) <= 1e-5 * ref_sd
+
+
+def test_inverse_latent_and_objective(shipped_variables, oracle_full):
+    x, y = make_inputs(8, seed=3)
+    m = _model(FULL_ARCH, shipped_variables)
+    z, obj = m.inverse(x, np.zeros(8, np.float32), y, [0.0], [0.0], [100], [2])
+    ref_z, ref_obj = oracle_full.inverse(x, y, 100, 2)
+    _close_elem(z, ref_z)
+    np.testing.assert_allclose(obj, ref_obj, rtol=NLL_RTOL)
+
+
+def test_sampling_with_supplied_eps(shipped_variables, oracle_full):
+    rng = np.random.RandomState(11)
+    _, y = make_inputs(8, seed=5)
+    eps = rng.randn(8, 32, 32, 4).astype(np.float32)
+    m = _model(FULL_ARCH, shipped_variables)
+    for temp in (1.0, 0.6):
+        xs = m.sample(y, temp, y, [0.0], [0.0], [100], [2], eps=eps)
+        ref = oracle_full.sample(eps, temp, y, 100, 2)
+        _close_elem(xs, ref)
+
+
+def test_forward_is_inverse_of_inverse_full_batch(shipped_variables):
+    """Size-independent property at BASELINE's full sampling size (B = 4096)."""
+    import torch
+    from noise_flow_amd.patches import synth_patches
+    m = _model(FULL_ARCH, shipped_variables)
+    x, y = synth_patches(0, 0, 4096)
+    z, _ = m.inverse(x, None, y, [0.0], [0.0], [100], [2])
+    x2 = m.forward(z, None, y, [0.0], [0.0], [100], [2])
+    err = (x2 - x).abs().max().item()
+    assert err <= 1e-5 * x.abs().max().item(), err
+    assert torch.isfinite(z).all()
+
+
+def test_per_layer_bijectors_match_oracle(shipped_variables, oracle_full):
+    """Each bijector alone (single-layer programs) against the oracle's layer."""
+    x, y = make_inputs(4, seed=9)
+    _, _, per_layer = oracle_full.inverse(x, y, 100, 2, return_layers=True)
+    from noise_flow_amd.layers import bijectors_from_arch
+    bij = bijectors_from_arch(FULL_ARCH, shipped_variables, (32, 32, 4), 4)
+    assert [b.name for b in bij] == [n for n, _, _ in per_layer]
+    z = x.astype(np.float64)
+    for b, (name, ref_z, ref_ld) in zip(bij, per_layer):
+        zin = z.astype(np.float32)
+        if b.conditional:
+            out, ld = b._inverse_and_log_det_jacobian(zin, y, [0.0], [0.0], [100], [2])
+            back = b._forward(np.asarray(ref_z, np.float32), y, [0.0], [0.0], [100], [2])
+        else:
+            out, ld = b._inverse_and_log_det_jacobian(zin)
+            back = b._forward(np.asarray(ref_z, np.float32))
+        _close_elem(out, ref_z)
+        np.testing.assert_allclose(ld, ref_ld, rtol=1e-5, atol=1e-3)
+        _close_elem(back, z, rtol=2e-5)
+        z = ref_z
+
+
+@pytest.mark.parametrize("arch,width,hw", [("unc", 4, (32, 32)), ("unc|unc", 8, (32, 32)), ("unc|gain4|unc", 16, (16, 16)),
+                                           ("sdn5|unc|gain4|unc", 4, (64, 64)), ("gain4|unc", 4, (8, 8)),
+                                           ("unc|sdn5", 4, (5, 7)), ("unc", 4, (1, 1)), ("unc|unc", 4, (1, 9))])
+def test_other_archs_widths_and_patch_sizes(arch, width, hw):
+    H, W = hw
+    v = trained_like_variables(arch, width, seed=H * 100 + W)
+    x, y = make_inputs(6, H, W, seed=2)
+    m = _model(arch, v, (H, W, 4), width)
+    o = _oracle(arch, v)
+    nll, sd = m._loss(x, y, [0.0], [0.0], [100], [2])
+    ref_nll, ref_sd, ref_z = o.nll(x, y, 100, 2)
+    np.testing.assert_allclose(nll, ref_nll, rtol=NLL_RTOL, atol=1e-4)
+    z, _ = m.inverse(x, None, y, [0.0], [0.0], [100], [2])
+    _close_elem(z, ref_z)
+    eps = np.random.RandomState(4).randn(6, H, W, 4).astype(np.float32)
+    xs = m.sample(y, 0.8, y, [0.0], [0.0], [100], [2], eps=eps)
+    _close_elem(xs, o.sample(eps, 0.8, y, 100, 2))
+
+
+def test_fresh_init_unc_known_answer():
+    """C1: fresh `unc` stack -> NLL = 1/2*HWC*log(2*pi) + 1/2*||x||^2 exactly."""
+    from noise_flow_amd import params
+    v = params.init_variables("unc|unc|unc", 4, 4, seed=7)
+    m = _model("unc|unc|unc", v)
+    x = np.random.RandomState(0).randn(256, 32, 32, 4).astype(np.float32)
+    from noise_flow_amd import default_hps, NoiseFlow
+    hps = default_hps(arch="unc|unc|unc", sidd_cond="uncond")
+    m = NoiseFlow([32, 32, 4], False, hps, variables=v)
+    nll, _ = m._loss(x, None)
+    want = 0.5 * 4096 * np.log(2 * np.pi) + 0.5 * (x.astype(np.float64) ** 2).sum(axis=(1, 2, 3))
+    np.testing.assert_allclose(nll, want, rtol=1e-5)
+
+
+def test_binding_orders_differ(shipped_variables):
+    x, y = make_inputs(4, seed=1)
+    a = _model(FULL_ARCH, shipped_variables, binding="loss_first")._loss(x, y, [0], [0], [100], [2])[0]
+    b = _model(FULL_ARCH, shipped_variables, binding="sample_first")._loss(x, y, [0], [0], [100], [2])[0]
+    ref_b = _oracle(FULL_ARCH, shipped_variables, "sample_first").nll(x, y, 100, 2)[0]
+    np.testing.assert_allclose(b, ref_b, rtol=NLL_RTOL)
+    assert np.abs(a - b).min() > 100.0
+
+
+def test_unknown_iso_and_camera(shipped_variables, oracle_full):
+    from noise_flow_amd._lib import NoiseFlowLibError, NF_ECOND
+    x, y = make_inputs(2, seed=8)
+    m = _model(FULL_ARCH, shipped_variables)
+    nll, _ = m._loss(x, y, [0], [0], [250], [2])          # unknown ISO -> g = 0 (cond_utils.py:227-229)
+    np.testing.assert_allclose(nll, oracle_full.nll(x, y, 250, 2)[0], rtol=NLL_RTOL)
+    with pytest.raises(NoiseFlowLibError) as ei:
+        m._loss(x, y, [0], [0], [100], [7])
+    assert ei.value.code == NF_ECOND
+
+
+def test_empty_and_ragged_batches(shipped_variables, oracle_full):
+    m = _model(FULL_ARCH, shipped_variables)
+    x, y = make_inputs(0)
+    nll, _ = m._loss(x, y, [0], [0], [100], [2])
+    assert nll.shape == (0,)
+    assert m.sample(y, 1.0, y, [0], [0], [100], [2]).shape == (0, 32, 32, 4)
+    for B in (1, 3, 257, 1281):
+        x, y = make_inputs(B, seed=B)
+        nll, _ = m._loss(x, y, [0], [0], [100], [2])
+        idx = np.unique(np.r_[0, B // 2, B - 1])
+        ref = oracle_full.nll(x[idx], y[idx], 100, 2)[0]
+        np.testing.assert_allclose(nll[idx], ref, rtol=NLL_RTOL)
+        assert np.isfinite(nll).all()
+
+
+def test_torch_tensors_stay_on_device(shipped_variables, oracle_full):
+    import torch
+    x, y = make_inputs(5, seed=4)
+    m = _model(FULL_ARCH, shipped_variables)
+    xt, yt = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    nll, sd = m._loss(xt, yt, [0], [0], [100], [2])
+    assert isinstance(nll, torch.Tensor) and nll.is_cuda
+    np.testing.assert_allclose(nll.cpu().numpy(), oracle_full.nll(x, y, 100, 2)[0], rtol=NLL_RTOL)
+
+
+def test_in_kernel_philox_sampling_matches_numpy_philox(shipped_variables, oracle_full):
+    from oracle import philox
+    _, y = make_inputs(6, seed=6)
+    m = _model(FULL_ARCH, shipped_variables)
+    xs1 = m.sample(y, 0.6, y, [0], [0], [100], [2], seed=1234)          # patches 0..5
+    xs2 = m.sample(y[:3], 0.6, y[:3], [0], [0], [100], [2], seed=1234)  # patches 6..8 (running counter)
+    eps = philox.sample_eps(1234, 0, 9)
+    ref1 = oracle_full.sample(eps[:6], 0.6, y, 100, 2)
+    ref2 = oracle_full.sample(eps[6:], 0.6, y[:3], 100, 2)
+    _close_elem(xs1, ref1, rtol=2e-5)
+    _close_elem(xs2, ref2, rtol=2e-5)
+
+
+def test_synth_patches_bit_exact_indexing():
+    """y (uniform) is bit-exact vs the numpy Philox; any sharding gives identical patches."""
+    from noise_flow_amd.patches import synth_patches, shard_range
+    from oracle import philox
+    x, y = synth_patches(0, 5, 7)
+    rx, ry = philox.synth_patches(0, 5, 7)
+    assert np.array_equal(y.cpu().numpy(), ry)
+    np.testing.assert_allclose(x.cpu().numpy(), rx, rtol=0, atol=2e-6 * np.abs(rx).max())
+    full = synth_patches(3, 0, 10)[1].cpu().numpy()
+    parts = []
+    for r in range(4):
+        a, b = shard_range(10, r, 4)
+        parts.append(synth_patches(3, a, b - a)[1].cpu().numpy())
+    assert np.array_equal(np.concatenate(parts), full)
+    big = synth_patches(0, (1 << 33) + 1, 2)[1].cpu().numpy()      # 64-bit patch indices
+    assert np.array_equal(big, philox.synth_patches(0, (1 << 33) + 1, 2)[1])
+
+
+def test_sums_accumulate_across_chunks(shipped_variables, oracle_full):
+    x, y = make_inputs(40, seed=12)
+    m = _model(FULL_ARCH, shipped_variables)
+    sums = None
+    for a in range(0, 40, 16):
+        sums = m.nll_sums(x[a:a + 16], y[a:a + 16], [0], [0], [100], [2], sums)
+    s = sums.cpu().numpy()
+    ref_nll, _, ref_z = oracle_full.nll(x, y, 100, 2)
+    assert s[2] == 40
+    assert abs(s[0] - ref_nll.sum()) <= NLL_RTOL * abs(ref_nll.sum())
+    ref_sd = np.sqrt(ref_z.var(axis=(1, 2, 3))).sum()
+    assert abs(s[1] - ref_sd) <= 1e-5 * ref_sd
+
+
+def test_concurrent_callers_share_one_handle(shipped_variables, oracle_full):
+    """The reference shares one session across 16-32 threads (job_noise_flow.sh:36)."""
+    m = _model(FULL_ARCH, shipped_variables)
+    x, y = make_inputs(8, seed=21)
+    ref = oracle_full.nll(x, y, 100, 2)[0]
+    errs = []
+
+    def work():
+        try:
+            for _ in range(5):
+                nll, _ = m._loss(x, y, [0], [0], [100], [2])
+                np.testing.assert_allclose(nll, ref, rtol=NLL_RTOL)
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    th = [threading.Thread(target=work) for _ in range(16)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs[0]
+
+
+def test_wrapper_drop_in():
+    from noise_flow_amd import NoiseFlowWrapper
+    w = NoiseFlowWrapper(SHIPPED_DIR, sampling_temperature=0.6)
+    assert w.hps.arch == FULL_ARCH and w.x_shape == [None, 32, 32, 4] and w.temp == 0.6
+    assert w.nf_model.num_params() == 2433
+    assert w.nf_model.get_layer_names()[:3] == ["sdn_0", "Conv2d_1x1_1", "unc_1"]
+    clean = np.full((64, 32, 32, 4), 0.5, np.float32)
+    noise = w.sample_noise_nf(clean, 0.0, 0.0, 800.0, 2.0)
+    assert noise.shape == clean.shape and noise.dtype == np.float32
+    # S6 / ISO 800 camera NLF: var = 0.003696*y + 2e-6 ; temperature 0.6 scales sd by ~0.6
+    sd = noise.std()
+    want = 0.6 * np.sqrt(0.003696 * 0.5 + 2e-6)
+    assert 0.6 * want < sd < 1.5 * want, (sd, want)
+    assert abs(noise.mean()) < 0.1 * sd

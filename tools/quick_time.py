@@ -1,0 +1,28 @@
+"""Tuning aid: time the fused NLL / sampling kernels for one workgroup geometry.
+Usage: NF_GEOM=<256|512|1024> python tools/quick_time.py [B] [iters]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from noise_flow_amd import NoiseFlow, default_hps
+from noise_flow_amd.ckpt import load_checkpoint
+from noise_flow_amd.patches import synth_patches
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+v = load_checkpoint(os.path.join(root, "models/NoiseFlow/ckpt/model.ckpt.best"))
+m = NoiseFlow([32, 32, 4], False, default_hps(), variables=v)
+x, y = synth_patches(0, 0, B)
+eps = torch.randn_like(x)
+for name, fn in (("nll", lambda: m.nll_sums(x, y, [0], [0], [100], [2])),
+                 ("sample_eps", lambda: m.sample(y, 1.0, y, [0], [0], [100], [2], eps=eps)),
+                 ("sample_philox", lambda: m.sample(y, 1.0, y, [0], [0], [100], [2]))):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    print("geom=%s B=%d %s: %.3f ms  %.3e patches/s" % (os.environ.get("NF_GEOM", "256"), B, name, dt * 1e3, B / dt))
