@@ -1,0 +1,62 @@
+"""Data-parallel evaluation over the patch index range (one process per GPU).
+
+The reference has NO multi-device path for Noise Flow (``--num_gpus`` is parsed
+and never read, ``sidd/ArgParser.py:108-109``); patches are independent in eval
+mode, so the only exchange this path needs is the final reduction of the epoch
+statistics that ``train_noise_flow.py:402-407`` averages on the host:
+
+    (Σ_b nll_b, Σ_b sd_b, count)  --one all-reduce(sum) of 3 fp64 scalars-->  means
+
+``backend="nccl"`` is RCCL over xGMI on ROCm; the message is 24 bytes, i.e. pure
+latency — it is issued ONCE per evaluation, never per minibatch.  Sampling needs
+no collective at all (outputs stay sharded).
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+from .patches import shard_range  # noqa: F401  (re-exported)
+
+
+def allreduce_sums(sums, group=None):
+    """In-place SUM all-reduce of the ``float64[3]`` accumulator (device tensor for
+    RCCL, CPU tensor for gloo).  No-op when torch.distributed is not initialised."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+    return sums
+
+
+def evaluate_sharded(eval_chunk: Callable[[int, int, object], object], n_total: int, chunk: int,
+                     rank: int, world: int, sums, group=None) -> Tuple[float, float, int]:
+    """Evaluate patches [0, n_total) split in contiguous blocks over ``world`` ranks.
+
+    ``eval_chunk(first_patch, count, sums)`` must ADD ``(Σ nll, Σ sd, count)`` of
+    patches ``first_patch … first_patch+count-1`` into ``sums`` (for the HIP path:
+    ``NoiseFlow.nll_sums`` on ``synth_patches(seed, first_patch, count)``).
+    Returns the global ``(mean_nll, mean_sd_z, n)`` — identical for every ``world``.
+    """
+    start, stop = shard_range(n_total, rank, world)
+    k = start
+    while k < stop:
+        n = min(chunk, stop - k)
+        eval_chunk(k, n, sums)
+        k += n
+    allreduce_sums(sums, group)
+    s = sums.detach().cpu().numpy()
+    n = int(round(float(s[2])))
+    if n != n_total:
+        raise RuntimeError("sharded evaluation covered %d patches, expected %d" % (n, n_total))
+    return float(s[0] / s[2]), float(s[1] / s[2]), n
+
+
+def flow_eval_chunk(model, seed: int, cond=( [0.0], [0.0], [100.0], [2.0]), height: int = 32, width: int = 32):
+    """The HIP-path ``eval_chunk`` for :func:`evaluate_sharded` on synthetic patches."""
+    from .patches import synth_patches
+    nlf0, nlf1, iso, cam = cond
+
+    def run(first, count, sums):
+        x, y = synth_patches(seed, first, count, height, width, device=model._dev.device.index)
+        model.nll_sums(x, y, nlf0, nlf1, iso, cam, sums)
+        return sums
+    return run
