@@ -1,0 +1,171 @@
+"""CPU tier: the C-ABI library loads, exports every symbol include/*.h declares, and
+its host-side folding (PLU -> A/A^-1, BN-eval, edge table, exp(3 logs), gain,
+sdn5 scalars) agrees with the numpy oracle.  No compute calls without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import FULL_ARCH, ROOT, trained_like_variables
+from oracle import nf_oracle as O
+
+
+def _fold(arch, variables, width, direction, hw=(32, 32)):
+    from noise_flow_amd import _lib, params
+    lib = _lib.load()
+    layers, descs, flat = params.pack(arch, variables, width)
+    cfg = _lib.nf_config(hw[0], hw[1], 4, len(layers), -1, 0)
+    ops = (C.c_int32 * 256)()
+    n_ops, nf, ld = C.c_int32(), C.c_size_t(), C.c_double()
+    folded = np.zeros(1 << 16, np.float32)
+    rc = lib.nf_fold_params(C.byref(cfg), descs, flat.ctypes.data_as(C.POINTER(C.c_float)), flat.size, direction,
+                            ops, 128, C.byref(n_ops), folded.ctypes.data_as(C.POINTER(C.c_float)), folded.size,
+                            C.byref(nf), C.byref(ld))
+    _lib.check(rc)
+    return [(ops[2 * i], ops[2 * i + 1]) for i in range(n_ops.value)], folded[:nf.value].copy(), ld.value
+
+
+def test_header_symbols_are_exported():
+    from noise_flow_amd import _lib
+    lib = _lib.load()
+    hdr = open(os.path.join(ROOT, "include", "noiseflow_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(nf_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
+    for s in declared:
+        assert hasattr(lib, s), s
+    assert lib.nf_abi_version() == 1
+    # the product has no CPU fallback: the python surface refuses to run without a GPU
+    import torch
+    if not torch.cuda.is_available():
+        from noise_flow_amd import NoiseFlow, default_hps
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            NoiseFlow([32, 32, 4], False, default_hps())
+
+
+def test_layer_param_counts():
+    from noise_flow_amd import _lib
+    lib = _lib.load()
+    assert lib.nf_layer_param_count(_lib.NF_LAYER_CONV1X1, 0) == 36
+    assert lib.nf_layer_param_count(_lib.NF_LAYER_COUPLING, 4) == 72 + 4 + 8 + 16 + 4 + 8 + 180 + 4 + 4 + 1
+    assert lib.nf_layer_param_count(_lib.NF_LAYER_SDN5, 0) == 23
+    assert lib.nf_layer_param_count(_lib.NF_LAYER_GAIN4, 0) == 1
+    assert lib.nf_layer_param_count(99, 0) < 0
+    # trainable parameter count of the shipped arch from the ABI's own layout:
+    # 8*(36-20) + 8*(301-16) + 10 rescaling... cross-checked against hps.txt in test_ckpt_hps
+
+
+@pytest.mark.parametrize("width", [4, 8, 16])
+def test_folding_matches_oracle(shipped_variables, width):
+    from noise_flow_amd import _lib
+    arch = FULL_ARCH if width == 4 else "unc|gain4|unc|sdn5"
+    v = shipped_variables if width == 4 else trained_like_variables(arch, width, seed=width)
+    layers = O.bind_variables(arch, v)
+    ops, blk, ld = _fold(arch, v, width, 0)
+    ops_r, blk_r, ld_r = _fold(arch, v, width, 1)
+    # constant log-det: H*W*sum log_S - H*W*C*log(gain)
+    want_ld = sum(1024 * L["log_abs_det"] for L in layers if L["type"] == "conv1x1")
+    gains = [float(np.asarray(L["gain_val"]).reshape(-1)[0]) for L in layers if L["type"] == "gain4"]
+    want_ld -= sum(4096 * np.log(g) for g in gains)
+    assert abs(ld - want_ld) < 1e-9 and ld == ld_r
+    # op sequence: gain folded into the following 1x1 matrix
+    kinds = [L["type"] for L in layers if L["type"] != "gain4"]
+    code = {"conv1x1": _lib.NF_OP_MIX, "coupling": _lib.NF_OP_COUPLING_FWD, "sdn5": _lib.NF_OP_SDN_DIV}
+    assert [t for t, _ in ops] == [code[k] for k in kinds]
+    rcode = {"conv1x1": _lib.NF_OP_MIX, "coupling": _lib.NF_OP_COUPLING_REV, "sdn5": _lib.NF_OP_SDN_MUL}
+    assert [t for t, _ in ops_r] == [rcode[k] for k in kinds[::-1]]
+    assert all(off % 4 == 0 for _, off in ops + ops_r)
+
+    w = width
+    kept = [L for L in layers if L["type"] != "gain4"]
+    gain_before = {}
+    g = 1.0
+    for L in layers:
+        if L["type"] == "gain4":
+            g = float(np.asarray(L["gain_val"]).reshape(-1)[0])
+        elif L["type"] == "conv1x1":
+            gain_before[L["name"]] = g
+            g = 1.0
+    for (t, off), L in zip(ops, kept):
+        if L["type"] == "conv1x1":
+            np.testing.assert_allclose(blk[off:off + 16].reshape(4, 4), L["A"] / gain_before[L["name"]], rtol=2e-7, atol=1e-9)
+        elif L["type"] == "coupling":
+            p = L["p"]
+            s1 = 1 / np.sqrt(p["bn1/var"] + 1e-4)
+            s2 = 1 / np.sqrt(p["bn2/var"] + 1e-4)
+            es = np.exp(3 * p["l_last/logs"])
+            b = blk[off:]
+            W3 = b[64:64 + 36 * w].reshape(9, w, 4)
+            np.testing.assert_allclose(W3, p["l_last/W"].reshape(9, w + 1, 4)[:, :w] * es, rtol=2e-7, atol=1e-12)
+            o1 = 64 + 36 * w
+            np.testing.assert_allclose(b[o1:o1 + 18 * w].reshape(9, 2, w), p["l_1/W"].reshape(9, 2, w) * s1, rtol=2e-7, atol=1e-12)
+            np.testing.assert_allclose(b[o1 + 18 * w:o1 + 19 * w], (p["l_1/b"] - p["bn1/mean"]) * s1, rtol=2e-7, atol=1e-9)
+            o2 = o1 + 19 * w
+            np.testing.assert_allclose(b[o2:o2 + w * w].reshape(w, w), p["l_2/W"].reshape(w, w) * s2, rtol=2e-7, atol=1e-12)
+            np.testing.assert_allclose(b[o2 + w * w:o2 + w * w + w], (p["l_2/b"] - p["bn2/mean"]) * s2, rtol=2e-7, atol=1e-9)
+            assert b[o2 + w * w + w] == np.float32(p["rescaling_scale"])
+            # border table: run the oracle's padded conv on an all-zero hidden map -> pure bias + edge taps
+            zero = np.zeros((1, 3, 3, w))
+            e = O.conv2d_nhwc(O.add_edge_padding(zero), p["l_last/W"], False) + p["l_last/b"]
+            e = e * es
+            E = b[:64].reshape(16, 4)
+            for r in range(3):
+                for c in range(3):
+                    mask = (1 if r == 0 else 0) | (2 if r == 2 else 0) | (4 if c == 0 else 0) | (8 if c == 2 else 0)
+                    np.testing.assert_allclose(E[mask], e[0, r, c], rtol=3e-7, atol=1e-9)
+            # degenerate 1x1 patch: every outer tap is outside
+            e1 = (O.conv2d_nhwc(O.add_edge_padding(np.zeros((1, 1, 1, w))), p["l_last/W"], False) + p["l_last/b"]) * es
+            np.testing.assert_allclose(E[15], e1[0, 0, 0], rtol=3e-7, atol=1e-9)
+    for (t, off), L in zip(ops_r, kept[::-1]):
+        if L["type"] == "conv1x1":
+            np.testing.assert_allclose(blk_r[off:off + 16].reshape(4, 4), L["A_inv"] * gain_before[L["name"]], rtol=2e-7, atol=1e-9)
+
+
+def test_lone_gain_becomes_scale_op():
+    from noise_flow_amd import _lib
+    v = trained_like_variables("gain4|sdn5", 4)
+    ops, blk, ld = _fold("gain4|sdn5", v, 4, 0)
+    assert [t for t, _ in ops] == [_lib.NF_OP_SCALE, _lib.NF_OP_SDN_DIV]
+    assert abs(blk[ops[0][1]] - 1 / 1.3) < 1e-7
+    ops, blk, _ = _fold("gain4|sdn5", v, 4, 1)
+    assert [t for t, _ in ops] == [_lib.NF_OP_SDN_MUL, _lib.NF_OP_SCALE]
+    assert abs(blk[ops[1][1]] - 1.3) < 1e-7
+
+
+@pytest.mark.parametrize("iso,cam", [(100, 2), (400, 0), (800, 4), (1600, 1), (3200, 3), (250, 2)])
+def test_sdn5_scalars_match_oracle(shipped_variables, iso, cam):
+    from noise_flow_amd import _lib
+    lib = _lib.load()
+    sp = np.concatenate([shipped_variables["model/sdn_gain/" + k].reshape(-1) for k in
+                         ("beta1", "beta2", "gain_params", "cam_params")] + [np.ones(1, np.float32)]).astype(np.float32)
+    out = (C.c_double * 2)()
+    cond = _lib.nf_cond(iso, cam, 0, 0)
+    _lib.check(lib.nf_sdn5_scalars(sp.ctypes.data_as(C.POINTER(C.c_float)), C.byref(cond), out))
+    L = O.bind_variables(FULL_ARCH, shipped_variables)[0]
+    b1, b2, gain = O.sdn_ex5_scalars(L["p"], iso, cam)
+    assert abs(out[0] - b1 / gain) <= 1e-12 * abs(b1 / gain) and abs(out[1] - b2) <= 1e-12 * b2
+
+
+def test_error_reporting(shipped_variables):
+    from noise_flow_amd import _lib, params
+    lib = _lib.load()
+    sp = np.zeros(23, np.float32)
+    out = (C.c_double * 2)()
+    rc = lib.nf_sdn5_scalars(sp.ctypes.data_as(C.POINTER(C.c_float)), C.byref(_lib.nf_cond(100, 5, 0, 0)), out)
+    assert rc == _lib.NF_ECOND and b"camera" in lib.nf_last_error()
+    layers, descs, flat = params.pack(FULL_ARCH, shipped_variables, 4)
+    n_ops = C.c_int32()
+
+    def fold(cfg, n=flat.size):
+        return lib.nf_fold_params(C.byref(cfg), descs, flat.ctypes.data_as(C.POINTER(C.c_float)), n, 0, None, 0,
+                                  C.byref(n_ops), None, 0, None, None)
+    assert fold(_lib.nf_config(32, 32, 3, len(layers), -1, 0)) == _lib.NF_EINVAL and b"channels" in lib.nf_last_error()
+    assert fold(_lib.nf_config(128, 128, 4, len(layers), -1, 0)) == _lib.NF_EINVAL
+    assert fold(_lib.nf_config(32, 32, 4, len(layers), -1, 0), n=100) == _lib.NF_EINVAL
+    assert fold(_lib.nf_config(32, 32, 4, len(layers), -1, 0)) == 0 and n_ops.value == 17
+    with pytest.raises(NotImplementedError):
+        params.parse_arch("unc|sdn4")
+    with pytest.raises(KeyError):
+        params.pack("unc|unc|unc|unc|unc|unc|unc|unc|unc", shipped_variables, 4)   # no 9th template in the ckpt

@@ -268,3 +268,51 @@ def test_wrapper_drop_in():
     want = 0.6 * np.sqrt(0.003696 * 0.5 + 2e-6)
     assert 0.6 * want < sd < 1.5 * want, (sd, want)
     assert abs(noise.mean()) < 0.1 * sd
+
+
+def test_golden_fixture_full_arch(shipped_variables):
+    """The committed golden vectors (tests/golden, made by tools/make_golden.py)."""
+    import os
+    from conftest import GOLDEN_DIR
+    g = np.load(os.path.join(GOLDEN_DIR, "full_arch_shipped.npz"))
+    m = _model(FULL_ARCH, shipped_variables)
+    y = g["y"]
+    for iso, cam in ((100, 2), (800, 2), (3200, 1)):
+        tag = "iso%d_cam%d" % (iso, cam)
+        nll, sd = m._loss(g["x_" + tag], y, [0], [0], [iso], [cam])
+        np.testing.assert_allclose(nll, g["nll_" + tag], rtol=NLL_RTOL)
+        assert abs(sd - float(g["sdz_" + tag])) <= 1e-5 * float(g["sdz_" + tag])
+        z, obj = m.inverse(g["x_" + tag], None, y, [0], [0], [iso], [cam])
+        _close_elem(z, g["z_" + tag].astype(np.float64))
+        np.testing.assert_allclose(obj, g["logdet_" + tag], rtol=NLL_RTOL)
+    for temp in (1.0, 0.6):
+        xs = m.sample(y, temp, y, [0], [0], [100], [2], eps=g["eps"])
+        _close_elem(xs, g["sample_t%.1f_iso100_cam2" % temp].astype(np.float64))
+
+
+def test_sharded_evaluation_is_sharding_invariant(shipped_variables):
+    """C4 logic on one GPU: evaluating [0,N) as 1, 2 or 4 shards gives the same mean NLL."""
+    import torch
+    from noise_flow_amd.dist import evaluate_sharded, flow_eval_chunk
+    m = _model(FULL_ARCH, shipped_variables)
+    run = flow_eval_chunk(m, seed=5)
+    n = 3000
+    ref = None
+    for world in (1, 2, 4):
+        total = torch.zeros(3, dtype=torch.float64, device="cuda")
+        for r in range(world):
+            from noise_flow_amd.patches import shard_range
+            a, b = shard_range(n, r, world)
+            k = a
+            while k < b:
+                c = min(700, b - k)
+                run(k, c, total)
+                k += c
+        s = total.cpu().numpy()
+        assert s[2] == n
+        if ref is None:
+            ref = s
+        else:
+            assert abs(s[0] - ref[0]) <= 1e-9 * abs(ref[0]) and abs(s[1] - ref[1]) <= 1e-9 * abs(ref[1])
+    mean, sd, cnt = evaluate_sharded(run, n, 512, 0, 1, torch.zeros(3, dtype=torch.float64, device="cuda"))
+    assert cnt == n and abs(mean - ref[0] / n) <= 1e-9 * abs(mean)

@@ -1,0 +1,109 @@
+"""CPU tier: patch indexing / minibatch contract and the N>1 path
+(world_size-2 gloo, run here without a GPU)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def test_patch_origins_match_reference_rule():
+    from noise_flow_amd.patches import patch_origins, patch_index_to_origin
+    ii, jj, n = patch_origins(100, 100, 32, 32)
+    assert n == 9 and ii == [0, 0, 0, 32, 32, 32, 64, 64, 64] and jj == [0, 32, 64] * 3
+    ii, jj, n = patch_origins(100, 70, 32, 32, n_pat_per_im=5)
+    assert n == 5 and list(zip(ii, jj)) == [(0, 0), (0, 32), (32, 0), (32, 32), (64, 0)]
+    assert patch_origins(31, 100, 32, 32)[2] == 0
+    for h, w, ph, pw in ((100, 100, 32, 32), (64, 200, 32, 64), (33, 33, 32, 32)):
+        ii, jj, n = patch_origins(h, w, ph, pw)
+        assert [(i, j) for i, j in zip(ii, jj)] == [patch_index_to_origin(k, h, w, ph, pw) for k in range(n)]
+    with pytest.raises(IndexError):
+        patch_index_to_origin(9, 100, 100, 32, 32)
+    a = patch_origins(100, 100, 32, 32, shuffle_seed=3)
+    assert sorted(zip(a[0], a[1])) == sorted(zip(*patch_origins(100, 100, 32, 32)[:2]))
+
+
+def test_bayer_packing_order_and_round_trip():
+    from noise_flow_amd.patches import pack_raw, unpack_raw, extract_patches, make_minibatch
+    raw = np.arange(8 * 12, dtype=np.float32).reshape(8, 12)
+    p = pack_raw(raw)
+    assert p.shape == (4, 6, 4)
+    assert (p[0, 0] == [raw[0, 0], raw[0, 1], raw[1, 1], raw[1, 0]]).all()      # sidd_utils.py:741-744
+    assert np.array_equal(unpack_raw(p), raw)
+    img = np.random.RandomState(0).rand(70, 100, 4)
+    pt = extract_patches(img, 32, 32)
+    assert pt.shape == (6, 32, 32, 4) and np.array_equal(pt[4], img[32:64, 32:64])
+    mb = make_minibatch(pt + 0.1, pt, np.arange(6), 1e-3, 1e-6, 100, 2)
+    assert mb["_x"].dtype == np.float64 and np.allclose(mb["_x"], 0.1)
+    assert mb["iso"] == [100] and mb["cam"] == [2] and set(mb) >= {"_x", "_y", "pid", "nlf0", "nlf1", "iso", "cam", "fn", "metadata"}
+
+
+def test_shard_range_partitions_exactly():
+    from noise_flow_amd.patches import shard_range
+    for n in (0, 1, 7, 1024, 1048576, 1000003):
+        for world in (1, 2, 3, 4, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_range(10, 4, 4)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_total, chunk, q):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from noise_flow_amd.dist import evaluate_sharded
+    from oracle import philox
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    sums = torch.zeros(3, dtype=torch.float64)
+
+    def eval_chunk(first, count, acc):
+        # stand-in evaluator with the real data contract: statistics are a pure function of the patch index
+        x, y = philox.synth_patches(7, first, count, 8, 8)
+        acc += torch.tensor([float((x.astype(np.float64) ** 2).sum()), float(y.astype(np.float64).sum()), count],
+                            dtype=torch.float64)
+    out = evaluate_sharded(eval_chunk, n_total, chunk, rank, world, sums)
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_evaluation_gloo(world):
+    import torch.multiprocessing as mp
+    from oracle import philox
+    n_total, chunk = 101, 16
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, chunk, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=120) for _ in procs]
+    [p.join(timeout=60) for p in procs]
+    x, y = philox.synth_patches(7, 0, n_total, 8, 8)
+    want = ((x.astype(np.float64) ** 2).sum() / n_total, y.astype(np.float64).sum() / n_total, n_total)
+    for _, out in res:
+        assert out[2] == n_total
+        assert abs(out[0] - want[0]) <= 1e-12 * abs(want[0]) and abs(out[1] - want[1]) <= 1e-12 * abs(want[1])
+    assert all(p.exitcode == 0 for p in procs)
+
+
+def test_evaluate_sharded_single_process_detects_miscount():
+    import torch
+    from noise_flow_amd.dist import evaluate_sharded
+    sums = torch.zeros(3, dtype=torch.float64)
+    with pytest.raises(RuntimeError):
+        evaluate_sharded(lambda a, n, s: s.add_(torch.tensor([0.0, 0.0, n - 1.0], dtype=torch.float64)), 10, 4, 0, 1, sums)
