@@ -49,6 +49,32 @@ __host__ __device__ constexpr int nf_cpl_off_B2(int w) { return 64 + 36 * w + 18
 __host__ __device__ constexpr int nf_cpl_off_S(int w)  { return 64 + 36 * w + 18 * w + 2 * w + w * w; }
 __host__ __device__ constexpr int nf_cpl_size(int w)   { return 64 + 36 * w + 18 * w + 2 * w + w * w + 4; }
 
+// ---- "matrix-core" layout (width 4 only), used by nf_flow_mfma_kernel ------------------
+// Every conv of the width-4 stack has exactly 4 output channels, i.e. it is
+//   out[pixel][i] = sum_k W[k][i] * in[pixel][k]          (k = tap x input channel)
+// which v_mfma_f32_4x4x1_16b_f32 evaluates for 64 pixels at once with the weights as
+// the A operand (lane l supplies W[k][l & 3]) and the lane's own pixel as the B operand.
+// Weights are therefore stored j-major ([out channel j][k]) so that a lane reads the A
+// operands of consecutive k with 16-byte LDS loads.
+//   MIX       Mt [4][4]            Mt[j][c] = M[c][j]
+//   COUPLING  E  [16][4]  @0       border table (as above)
+//             B1 [4]      @64
+//             B2 [4]      @68
+//             S  [4]      @72      rescaling_scale, 0, 0, 0
+//             W1t[4][3][8] @76     W1t[j][di][dj*2+c]  (6 of 8 used per filter row)
+//             W2t[4][4]   @172     W2t[j][i]
+//             W3t[4][36]  @188     W3t[j][tap*4+i]
+#define NF2_MIX_SIZE 16
+#define NF2_CPL_E 0
+#define NF2_CPL_B1 64
+#define NF2_CPL_B2 68
+#define NF2_CPL_S 72
+#define NF2_CPL_W1T 76
+#define NF2_CPL_W2T 172
+#define NF2_CPL_W3T 188
+#define NF2_CPL_SIZE 332
+#define NF2_MAX_FLOATS 6144   // 24 KiB of LDS for the whole model's weights
+
 // launch flags
 enum : uint32_t {
     NF_K_PRIOR     = 1u,   // nll = -(logdet + logp(z)); otherwise nll = -logdet
@@ -72,6 +98,7 @@ struct NfLaunch {
     float sdn_k1, sdn_b2;  // beta1/gain, beta2
     int32_t H, W;
     uint32_t flags;
+    int32_t n_params;      // floats in the parameter block (matrix-core kernel stages it in LDS)
 };
 
 // Philox stream ids (4th counter word)

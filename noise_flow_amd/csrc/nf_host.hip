@@ -11,6 +11,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -18,7 +19,7 @@
 #include "../../include/noiseflow_hip.h"
 #include "nf_device.h"
 
-hipError_t nf_launch_flow(const NfProgram &prog, const NfLaunch &a, int n_cu, hipStream_t stream);
+hipError_t nf_launch_flow(const NfProgram &prog, const NfLaunch &a, int n_cu, hipStream_t stream, bool matrix_core);
 hipError_t nf_launch_synth(uint64_t seed, int64_t patch_base, int64_t B, int HW, float beta1, float beta2,
                            float *y_out, float *x_out, hipStream_t stream);
 
@@ -178,6 +179,24 @@ void fold_coupling(const float *p, int w, float *out)
     S[1] = S[2] = S[3] = 0.0f;
 }
 
+// The same folded coupling block re-laid out j-major for the matrix-core kernel
+// (nf_device.h, NF2_CPL_*), width 4 only.
+void relayout_coupling_v2(const float *v1, float *out)
+{
+    const int w = 4;
+    memcpy(out + NF2_CPL_E, v1 + nf_cpl_off_E(w), 64 * sizeof(float));
+    memcpy(out + NF2_CPL_B1, v1 + nf_cpl_off_B1(w), 4 * sizeof(float));
+    memcpy(out + NF2_CPL_B2, v1 + nf_cpl_off_B2(w), 4 * sizeof(float));
+    memcpy(out + NF2_CPL_S, v1 + nf_cpl_off_S(w), 4 * sizeof(float));
+    for (int j = 0; j < 4; ++j) {
+        for (int di = 0; di < 3; ++di)
+            for (int q = 0; q < 8; ++q)
+                out[NF2_CPL_W1T + 24 * j + 8 * di + q] = q < 6 ? v1[nf_cpl_off_W1(w) + (di * 6 + q) * 4 + j] : 0.0f;
+        for (int i = 0; i < 4; ++i) out[NF2_CPL_W2T + 4 * j + i] = v1[nf_cpl_off_W2(w) + i * 4 + j];
+        for (int k = 0; k < 36; ++k) out[NF2_CPL_W3T + 36 * j + k] = v1[nf_cpl_off_W3(w) + k * 4 + j];
+    }
+}
+
 // ---- sdn5 host scalars (cond_utils.py:205-239) -------------------------------
 int sdn5_scalars(const float *sp, const nf_cond *cond, double out[2])
 {
@@ -207,6 +226,8 @@ int sdn5_scalars(const float *sp, const nf_cond *cond, double out[2])
 struct Built {
     NfProgram prog;
     std::vector<float> block;
+    NfProgram prog2;             // matrix-core (MFMA) layout, width 4 only
+    std::vector<float> block2;   // empty when unavailable
     double ld_const = 0.0;
     bool has_sdn = false;
     std::vector<float> sdn_params;
@@ -333,7 +354,39 @@ int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float
         }
     }
     if (out.block.empty()) out.block.assign(4, 0.0f);
+
+    // matrix-core re-layout (same op sequence, j-major weights), when the model qualifies
+    out.block2.clear();
+    memset(&out.prog2, 0, sizeof(out.prog2));
+    if (out.prog.width == 4) {
+        out.prog2.width = 4;
+        for (int i = 0; i < out.prog.n_ops; ++i) {
+            const NfOp &src = out.prog.ops[i];
+            NfOp &dst = out.prog2.ops[out.prog2.n_ops++];
+            dst.type = src.type;
+            dst.off = (int32_t)out.block2.size();
+            const float *v1 = out.block.data() + src.off;
+            if (src.type == NF_OP_MIX) {
+                for (int j = 0; j < 4; ++j)
+                    for (int c = 0; c < 4; ++c) out.block2.push_back(v1[c * 4 + j]);
+            } else if (src.type == NF_OP_COUPLING_FWD || src.type == NF_OP_COUPLING_REV) {
+                out.block2.resize(out.block2.size() + NF2_CPL_SIZE);
+                relayout_coupling_v2(v1, out.block2.data() + dst.off);
+            } else if (src.type == NF_OP_SCALE) {
+                out.block2.insert(out.block2.end(), v1, v1 + 4);
+            }
+        }
+        if (out.block2.empty()) out.block2.assign(4, 0.0f);
+        if (out.block2.size() > NF2_MAX_FLOATS) out.block2.clear();   // too large for LDS: scalar path only
+    }
     return NF_OK;
+}
+
+// NF_KERNEL=valu forces the scalar-weight VALU kernel (A/B testing); default = matrix core
+bool use_matrix_core()
+{
+    const char *e = getenv("NF_KERNEL");
+    return !(e && strcmp(e, "valu") == 0);
 }
 
 struct DeviceGuard {
@@ -365,9 +418,13 @@ struct nf_handle {
     Built fwd, rev;
     float *d_fwd = nullptr;
     float *d_rev = nullptr;
+    float *d_fwd2 = nullptr;   // matrix-core layout (null when unavailable)
+    float *d_rev2 = nullptr;
 };
 
 extern "C" {
+
+int nf_destroy(nf_handle *h);
 
 int nf_abi_version(void) { return NF_ABI_VERSION; }
 
@@ -450,6 +507,16 @@ int nf_create(const nf_config *cfg, const nf_layer_desc *layers, const float *pa
         delete h;
         return fail_hip(e, "hipMemcpy(params)");
     }
+    for (int d = 0; d < 2; ++d) {
+        const std::vector<float> &b2 = d == 0 ? h->fwd.block2 : h->rev.block2;
+        float **dst = d == 0 ? &h->d_fwd2 : &h->d_rev2;
+        if (b2.empty()) continue;
+        if ((e = hipMalloc((void **)dst, b2.size() * sizeof(float))) != hipSuccess ||
+            (e = hipMemcpy(*dst, b2.data(), b2.size() * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) {
+            nf_destroy(h);
+            return fail_hip(e, "hipMalloc/hipMemcpy(matrix-core params)");
+        }
+    }
     *out = h;
     return NF_OK;
 }
@@ -461,6 +528,8 @@ int nf_destroy(nf_handle *h)
     (void)guard.enter(h->device);
     if (h->d_fwd) (void)hipFree(h->d_fwd);
     if (h->d_rev) (void)hipFree(h->d_rev);
+    if (h->d_fwd2) (void)hipFree(h->d_fwd2);
+    if (h->d_rev2) (void)hipFree(h->d_rev2);
     delete h;
     return NF_OK;
 }
@@ -504,7 +573,12 @@ int nf_nll(nf_handle *h, const float *x, const float *y, int64_t B, const nf_con
     a.H = h->cfg.height;
     a.W = h->cfg.width;
     a.flags = (flags & NF_NO_PRIOR) ? 0u : NF_K_PRIOR;
-    hipError_t e = nf_launch_flow(h->fwd.prog, a, h->n_cu, st);
+    const bool mc = h->d_fwd2 && use_matrix_core();
+    if (mc) {
+        a.params = h->d_fwd2;
+        a.n_params = (int32_t)h->fwd.block2.size();
+    }
+    hipError_t e = nf_launch_flow(mc ? h->fwd.prog2 : h->fwd.prog, a, h->n_cu, st, mc);
     if (e != hipSuccess) return fail_hip(e, "nf_nll launch");
     return NF_OK;
 }
@@ -540,7 +614,12 @@ int nf_sample(nf_handle *h, const float *y, const float *eps, uint64_t seed, int
     a.H = h->cfg.height;
     a.W = h->cfg.width;
     a.flags = eps ? 0u : NF_K_PHILOX_IN;
-    hipError_t e = nf_launch_flow(h->rev.prog, a, h->n_cu, (hipStream_t)stream);
+    const bool mc = h->d_rev2 && use_matrix_core();
+    if (mc) {
+        a.params = h->d_rev2;
+        a.n_params = (int32_t)h->rev.block2.size();
+    }
+    hipError_t e = nf_launch_flow(mc ? h->rev.prog2 : h->rev.prog, a, h->n_cu, (hipStream_t)stream, mc);
     if (e != hipSuccess) return fail_hip(e, "nf_sample launch");
     return NF_OK;
 }

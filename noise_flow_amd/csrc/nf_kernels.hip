@@ -18,12 +18,27 @@
 #include <atomic>
 #include "nf_device.h"
 
+// occupancy target (waves per SIMD) the register allocator must honour, per geometry
+#ifndef NF_PRIO
+#define NF_PRIO 2
+#endif
+#define NF_PRIO_UP()   do { if (NF_PRIO) __builtin_amdgcn_s_setprio(NF_PRIO); } while (0)
+#define NF_PRIO_DOWN() do { if (NF_PRIO) __builtin_amdgcn_s_setprio(0); } while (0)
+#ifndef NF_WPE_512
+#define NF_WPE_512 5
+#endif
+#ifndef NF_WPE_256
+#define NF_WPE_256 3
+#endif
+#define NF_MIN_WAVES(T, P, M) (((T) == 512 && (P) == 2 && (M)) ? NF_WPE_512 : ((T) == 256 && (P) == 4 && (M)) ? NF_WPE_256 : 1)
+
 namespace {
 
 // Model parameters are immutable for the lifetime of a handle: address them through
 // the constant address space so that every wave-uniform fetch becomes an s_load
 // (scalar cache, SGPR operands) instead of a per-lane global_load into VGPRs.
 typedef const float __attribute__((address_space(4))) *cfloat_p;
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 // --------------------------------------------------------------------------
 // Philox4x32-10 counter-based RNG (Salmon et al. 2011) — keyed by
@@ -73,6 +88,17 @@ __device__ __forceinline__ void philox_normal4(uint64_t seed, int64_t patch, uin
     box_muller(r.z, r.w, v[2], v[3]);
 }
 
+// exp / tanh on the hardware transcendental unit (v_exp_f32, v_rcp_f32: 1 ulp each).
+// |ls| <= rescaling_scale < 1, so exp(ls) carries ~2e-7 relative error; tanh has
+// ~1e-7 ABSOLUTE error (it only ever enters as scale*tanh(raw)), both far inside
+// the 1e-5 parity budget (tests/test_gpu_parity.py measures it).
+__device__ __forceinline__ float nf_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+__device__ __forceinline__ float nf_tanh(float x)
+{
+    const float t = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);   // exp(2x); inf/0 saturate correctly
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(t + 1.0f);
+}
+
 __device__ __forceinline__ float wave_sum(float v)
 {
 #pragma unroll
@@ -88,10 +114,11 @@ __device__ __forceinline__ float wave_sum(float v)
 // Pixel p of the patch is owned by thread p % THREADS (slot p / THREADS), so the
 // [H,W,4] fp32 patch is read/written as fully coalesced 16-byte lanes.
 // --------------------------------------------------------------------------
-template <int WIDTH, int THREADS, int PX>
-__global__ __launch_bounds__(THREADS) void nf_flow_kernel(const NfProgram prog, const NfLaunch a)
+template <int WIDTH, int THREADS, int PX, bool PHILOX, bool MFMA>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_WAVES(THREADS, PX, MFMA)))) void nf_flow_kernel(const NfProgram prog, const NfLaunch a)
 {
     static_assert(WIDTH % 4 == 0, "WIDTH must be a multiple of 4");
+    static_assert(!MFMA || WIDTH == 4, "the matrix-core path is the width-4 specialisation");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int H = a.H, W = a.W, HW = H * W;
@@ -99,9 +126,11 @@ __global__ __launch_bounds__(THREADS) void nf_flow_kernel(const NfProgram prog, 
     const int tile_px = ((H + 2) * Wp + 1) & ~1;         // even -> 16-byte aligned sections
     float2 *const t0 = reinterpret_cast<float2 *>(smem);  // z0 tile  [tile_px] float2
     float *const th = smem + 2 * tile_px;                 // h2 tile  [tile_px][WIDTH]
-    float *const red = th + WIDTH * tile_px;              // reduction scratch [3][THREADS/64]
+    float *const red = th + WIDTH * tile_px;              // reduction scratch [3][THREADS/64] (+pad)
+    float *const wl = red + ((3 * (THREADS / 64) + 3) & ~3);   // MFMA: the whole folded model, j-major
 
     const int t = threadIdx.x;
+    const int j4 = t & 3;   // MFMA: which output channel's weights this lane feeds as the A operand
 
     // per-pixel constants (same for every patch this workgroup processes)
     int lidx[PX];      // index of the pixel inside the zero-bordered tiles
@@ -119,6 +148,8 @@ __global__ __launch_bounds__(THREADS) void nf_flow_kernel(const NfProgram prog, 
 
     // zero both tiles once: the 1-pixel border is never written again
     for (int i = t; i < tile_px * (2 + WIDTH); i += THREADS) smem[i] = 0.0f;
+    if (MFMA)
+        for (int i = t; i < a.n_params; i += THREADS) wl[i] = a.params[i];
     __syncthreads();
 
     const int n_ops = prog.n_ops;
@@ -129,7 +160,7 @@ __global__ __launch_bounds__(THREADS) void nf_flow_kernel(const NfProgram prog, 
 
         // ---- prologue: the 4 channels of each owned pixel -> registers ----
         float z[PX][4];
-        if (a.flags & NF_K_PHILOX_IN) {
+        if (PHILOX) {
 #pragma unroll
             for (int k = 0; k < PX; ++k) {
                 philox_normal4(a.seed, a.patch_base + b, (uint32_t)(t + THREADS * k), NF_STREAM_SAMP, z[k]);
@@ -157,22 +188,36 @@ __global__ __launch_bounds__(THREADS) void nf_flow_kernel(const NfProgram prog, 
 
             if (type == NF_OP_MIX) {
                 // Conv2d1x1: per-pixel z <- z @ M   (layers.py:108-124)
-                float m[16];
+                if constexpr (MFMA) {
+                    const float4 m = *reinterpret_cast<const float4 *>(wl + prog.ops[op].off + 4 * j4);   // M[0..3][j4]
 #pragma unroll
-                for (int i = 0; i < 16; ++i) m[i] = P[i];
+                    for (int k = 0; k < PX; ++k) {
+                        v4f acc = {0.f, 0.f, 0.f, 0.f};
+                        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(m.x, z[k][0], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(m.y, z[k][1], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(m.z, z[k][2], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(m.w, z[k][3], acc, 0, 0, 0);
 #pragma unroll
-                for (int k = 0; k < PX; ++k) {
-                    float o[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float s = z[k][0] * m[j];
-                        s = fmaf(z[k][1], m[4 + j], s);
-                        s = fmaf(z[k][2], m[8 + j], s);
-                        s = fmaf(z[k][3], m[12 + j], s);
-                        o[j] = s;
+                        for (int j = 0; j < 4; ++j) z[k][j] = acc[j];
                     }
+                } else {
+                    float m[16];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) z[k][j] = o[j];
+                    for (int i = 0; i < 16; ++i) m[i] = P[i];
+#pragma unroll
+                    for (int k = 0; k < PX; ++k) {
+                        float o[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            float s = z[k][0] * m[j];
+                            s = fmaf(z[k][1], m[4 + j], s);
+                            s = fmaf(z[k][2], m[8 + j], s);
+                            s = fmaf(z[k][3], m[12 + j], s);
+                            o[j] = s;
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) z[k][j] = o[j];
+                    }
                 }
             } else if (type == NF_OP_COUPLING_FWD || type == NF_OP_COUPLING_REV) {
                 // ---- AffineCoupling (layers.py:275-291 / 355-375) ----
@@ -183,6 +228,45 @@ __global__ __launch_bounds__(THREADS) void nf_flow_kernel(const NfProgram prog, 
                 __syncthreads();
 
                 // 2) l_1 (3x3 SAME, BN folded) -> ReLU -> l_2 (1x1, BN folded) -> ReLU
+                if constexpr (MFMA) {
+                    const float *wb = wl + prog.ops[op].off;
+                    const float4 b1 = *reinterpret_cast<const float4 *>(wb + NF2_CPL_B1);
+                    const float4 b2 = *reinterpret_cast<const float4 *>(wb + NF2_CPL_B2);
+                    const float4 w2 = *reinterpret_cast<const float4 *>(wb + NF2_CPL_W2T + 4 * j4);
+                    v4f h1[PX];
+#pragma unroll
+                    for (int k = 0; k < PX; ++k) h1[k] = v4f{b1.x, b1.y, b1.z, b1.w};
+                    NF_PRIO_UP();
+#pragma unroll
+                    for (int di = 0; di < 3; ++di) {
+                        // this lane's A operands of one filter row: W1[(di,dj,c)][j4]
+                        const float4 wA = *reinterpret_cast<const float4 *>(wb + NF2_CPL_W1T + 24 * j4 + 8 * di);
+                        const float2 wB = *reinterpret_cast<const float2 *>(wb + NF2_CPL_W1T + 24 * j4 + 8 * di + 4);
+                        const float wr[6] = {wA.x, wA.y, wA.z, wA.w, wB.x, wB.y};
+#pragma unroll
+                        for (int dj = 0; dj < 3; ++dj) {
+                            const int doff = (di - 1) * Wp + (dj - 1);
+#pragma unroll
+                            for (int k = 0; k < PX; ++k) {
+                                const float2 v = t0[lidx[k] + doff];
+                                h1[k] = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[2 * dj + 0], v.x, h1[k], 0, 0, 0);
+                                h1[k] = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[2 * dj + 1], v.y, h1[k], 0, 0, 0);
+                            }
+                        }
+                    }
+                    NF_PRIO_DOWN();
+#pragma unroll
+                    for (int k = 0; k < PX; ++k) {
+                        v4f h2 = {b2.x, b2.y, b2.z, b2.w};
+                        h2 = __builtin_amdgcn_mfma_f32_4x4x1f32(w2.x, fmaxf(h1[k][0], 0.0f), h2, 0, 0, 0);
+                        h2 = __builtin_amdgcn_mfma_f32_4x4x1f32(w2.y, fmaxf(h1[k][1], 0.0f), h2, 0, 0, 0);
+                        h2 = __builtin_amdgcn_mfma_f32_4x4x1f32(w2.z, fmaxf(h1[k][2], 0.0f), h2, 0, 0, 0);
+                        h2 = __builtin_amdgcn_mfma_f32_4x4x1f32(w2.w, fmaxf(h1[k][3], 0.0f), h2, 0, 0, 0);
+                        if (act[k])
+                            *reinterpret_cast<float4 *>(th + (size_t)lidx[k] * 4) =
+                                make_float4(fmaxf(h2[0], 0.0f), fmaxf(h2[1], 0.0f), fmaxf(h2[2], 0.0f), fmaxf(h2[3], 0.0f));
+                    }
+                } else
                 {
                     const cfloat_p W1 = P + nf_cpl_off_W1(WIDTH);
                     const cfloat_p B1 = P + nf_cpl_off_B1(WIDTH);
@@ -235,9 +319,47 @@ __global__ __launch_bounds__(THREADS) void nf_flow_kernel(const NfProgram prog, 
 
                 // 3) l_last (zero pad + border-indicator channel, 3x3 VALID, *exp(3 logs) folded)
                 {
-                    const cfloat_p W3 = P + nf_cpl_off_W3(WIDTH);
-                    const float sc = P[nf_cpl_off_S(WIDTH)];
                     float o[PX][4];
+                    float sc;
+                    if constexpr (MFMA) {
+                        const float *wb = wl + prog.ops[op].off;
+                        sc = wb[NF2_CPL_S];
+                        v4f acc[PX];
+#pragma unroll
+                        for (int k = 0; k < PX; ++k) {
+                            const float4 e = *reinterpret_cast<const float4 *>(wb + NF2_CPL_E + 4 * bmask[k]);
+                            acc[k] = v4f{e.x, e.y, e.z, e.w};
+                        }
+                        NF_PRIO_UP();
+#pragma unroll
+                        for (int di = 0; di < 3; ++di) {
+                            float w3[12];   // this lane's A operands of one filter row: W3[(di,dj,i)][j4]
+#pragma unroll
+                            for (int q = 0; q < 3; ++q) {
+                                const float4 w = *reinterpret_cast<const float4 *>(wb + NF2_CPL_W3T + 36 * j4 + 12 * di + 4 * q);
+                                w3[4 * q + 0] = w.x; w3[4 * q + 1] = w.y; w3[4 * q + 2] = w.z; w3[4 * q + 3] = w.w;
+                            }
+#pragma unroll
+                            for (int dj = 0; dj < 3; ++dj) {
+                                const int doff = (di - 1) * Wp + (dj - 1);
+#pragma unroll
+                                for (int k = 0; k < PX; ++k) {
+                                    const float4 hv = *reinterpret_cast<const float4 *>(th + (size_t)(lidx[k] + doff) * 4);
+                                    acc[k] = __builtin_amdgcn_mfma_f32_4x4x1f32(w3[4 * dj + 0], hv.x, acc[k], 0, 0, 0);
+                                    acc[k] = __builtin_amdgcn_mfma_f32_4x4x1f32(w3[4 * dj + 1], hv.y, acc[k], 0, 0, 0);
+                                    acc[k] = __builtin_amdgcn_mfma_f32_4x4x1f32(w3[4 * dj + 2], hv.z, acc[k], 0, 0, 0);
+                                    acc[k] = __builtin_amdgcn_mfma_f32_4x4x1f32(w3[4 * dj + 3], hv.w, acc[k], 0, 0, 0);
+                                }
+                            }
+                        }
+                        NF_PRIO_DOWN();
+#pragma unroll
+                        for (int k = 0; k < PX; ++k)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) o[k][j] = acc[k][j];
+                    } else {
+                    const cfloat_p W3 = P + nf_cpl_off_W3(WIDTH);
+                    sc = P[nf_cpl_off_S(WIDTH)];
 #pragma unroll
                     for (int k = 0; k < PX; ++k) {
                         // bias + the indicator-channel taps that fall outside the image (per-lane row)
@@ -267,18 +389,19 @@ __global__ __launch_bounds__(THREADS) void nf_flow_kernel(const NfProgram prog, 
                             }
                         }
                     }
+                    }
                     // shift = o[0:2], raw log-scale = o[2:4]  (tf.split, layers.py:494)
 #pragma unroll
                     for (int k = 0; k < PX; ++k) {
-                        const float ls0 = sc * tanhf(o[k][2]);
-                        const float ls1 = sc * tanhf(o[k][3]);
+                        const float ls0 = sc * nf_tanh(o[k][2]);
+                        const float ls1 = sc * nf_tanh(o[k][3]);
                         if (type == NF_OP_COUPLING_FWD) {
-                            z[k][2] = fmaf(z[k][2], expf(ls0), o[k][0]);
-                            z[k][3] = fmaf(z[k][3], expf(ls1), o[k][1]);
+                            z[k][2] = fmaf(z[k][2], nf_exp(ls0), o[k][0]);
+                            z[k][3] = fmaf(z[k][3], nf_exp(ls1), o[k][1]);
                             if (act[k]) ld += ls0 + ls1;
                         } else {
-                            z[k][2] = (z[k][2] - o[k][0]) * expf(-ls0);
-                            z[k][3] = (z[k][3] - o[k][1]) * expf(-ls1);
+                            z[k][2] = (z[k][2] - o[k][0]) * nf_exp(-ls0);
+                            z[k][3] = (z[k][3] - o[k][1]) * nf_exp(-ls1);
                         }
                     }
                 }
@@ -292,12 +415,14 @@ __global__ __launch_bounds__(THREADS) void nf_flow_kernel(const NfProgram prog, 
                     const float yy[4] = {yv.x, yv.y, yv.z, yv.w};
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        const float s = sqrtf(fmaf(yy[c], a.sdn_k1, a.sdn_b2));
+                        // scale = sqrt(v), v = beta1*y/gain + beta2 > 0: z/scale = z*rsq(v), log scale = ln2/2*log2(v)
+                        // (v_rsq_f32 / v_log_f32: 1 ulp; once per element per patch)
+                        const float v = fmaf(yy[c], a.sdn_k1, a.sdn_b2);
                         if (type == NF_OP_SDN_DIV) {
-                            z[k][c] = z[k][c] / s;
-                            if (act[k]) ld -= logf(s);
+                            z[k][c] = z[k][c] * __builtin_amdgcn_rsqf(v);
+                            if (act[k]) ld = fmaf(-0.34657359027997264f, __builtin_amdgcn_logf(v), ld);
                         } else {
-                            z[k][c] = z[k][c] * s;
+                            z[k][c] = z[k][c] * __builtin_amdgcn_sqrtf(v);
                         }
                     }
                 }
@@ -400,13 +525,15 @@ __global__ __launch_bounds__(256) void nf_synth_kernel(uint64_t seed, int64_t pa
     }
 }
 
-template <int WIDTH, int THREADS, int PX>
-hipError_t launch_flow(const NfProgram &prog, const NfLaunch &a, int n_cu, hipStream_t stream)
+template <int WIDTH, int THREADS, int PX, bool PHILOX, bool MFMA>
+hipError_t launch_flow_v(const NfProgram &prog, const NfLaunch &a, int n_cu, hipStream_t stream)
 {
     const int tile_px = ((a.H + 2) * (a.W + 2) + 1) & ~1;
-    const size_t lds = sizeof(float) * ((size_t)tile_px * (2 + WIDTH) + 3 * (THREADS / 64) + 4);
+    size_t lds_f = (size_t)tile_px * (2 + WIDTH) + ((3 * (THREADS / 64) + 3) & ~3);
+    if (MFMA) lds_f += (size_t)((a.n_params + 3) & ~3);
+    const size_t lds = sizeof(float) * lds_f;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    const void *fn = reinterpret_cast<const void *>(&nf_flow_kernel<WIDTH, THREADS, PX>);
+    const void *fn = reinterpret_cast<const void *>(&nf_flow_kernel<WIDTH, THREADS, PX, PHILOX, MFMA>);
     // (lds bytes << 8 | resident workgroups per CU) of the last query; racy but idempotent
     static std::atomic<uint64_t> cache{0};
     uint64_t c = cache.load(std::memory_order_relaxed);
@@ -429,39 +556,53 @@ hipError_t launch_flow(const NfProgram &prog, const NfLaunch &a, int n_cu, hipSt
     int64_t groups = (int64_t)n_cu * occ;
     if (a.B < groups) groups = a.B;
     if (groups < 1) groups = 1;
-    hipLaunchKernelGGL((nf_flow_kernel<WIDTH, THREADS, PX>), dim3((unsigned)groups), dim3(THREADS), lds, stream, prog, a);
+    hipLaunchKernelGGL((nf_flow_kernel<WIDTH, THREADS, PX, PHILOX, MFMA>), dim3((unsigned)groups), dim3(THREADS), lds,
+                       stream, prog, a);
     return hipGetLastError();
 }
 
-template <int WIDTH>
+template <int WIDTH, int THREADS, int PX, bool MFMA>
+hipError_t launch_flow(const NfProgram &prog, const NfLaunch &a, int n_cu, hipStream_t stream)
+{
+    // the in-kernel Philox/Box-Muller prologue is a separate instantiation so that its
+    // registers and libm code never burden the likelihood path
+    if (a.flags & NF_K_PHILOX_IN) return launch_flow_v<WIDTH, THREADS, PX, true, MFMA>(prog, a, n_cu, stream);
+    return launch_flow_v<WIDTH, THREADS, PX, false, MFMA>(prog, a, n_cu, stream);
+}
+
+inline int env_int(const char *name)
+{
+    const char *e = getenv(name);
+    return e ? atoi(e) : 0;
+}
+
+template <int WIDTH, bool MFMA>
 hipError_t dispatch_geom(const NfProgram &prog, const NfLaunch &a, int n_cu, hipStream_t stream)
 {
     const int hw = a.H * a.W;
-    if (hw <= 64) return launch_flow<WIDTH, 64, 1>(prog, a, n_cu, stream);
-    if (hw <= 256) return launch_flow<WIDTH, 256, 1>(prog, a, n_cu, stream);
+    if (hw <= 64) return launch_flow<WIDTH, 64, 1, MFMA>(prog, a, n_cu, stream);
+    if (hw <= 256) return launch_flow<WIDTH, 256, 1, MFMA>(prog, a, n_cu, stream);
     if (hw <= 1024) {
         // workgroup geometry for the 32x32 patch; NF_GEOM=<threads> overrides (tuning aid)
-        static const int geom = [] {
-            const char *e = getenv("NF_GEOM");
-            return e ? atoi(e) : 0;
-        }();
-        if (geom == 512) return launch_flow<WIDTH, 512, 2>(prog, a, n_cu, stream);
-        if (geom == 1024) return launch_flow<WIDTH, 1024, 1>(prog, a, n_cu, stream);
-        return launch_flow<WIDTH, 256, 4>(prog, a, n_cu, stream);
+        static const int geom = env_int("NF_GEOM");
+        if (geom == 512) return launch_flow<WIDTH, 512, 2, MFMA>(prog, a, n_cu, stream);
+        if (geom == 1024) return launch_flow<WIDTH, 1024, 1, MFMA>(prog, a, n_cu, stream);
+        return launch_flow<WIDTH, 256, 4, MFMA>(prog, a, n_cu, stream);
     }
-    if (hw <= 4096) return launch_flow<WIDTH, 1024, 4>(prog, a, n_cu, stream);
+    if (hw <= 4096) return launch_flow<WIDTH, 1024, 4, MFMA>(prog, a, n_cu, stream);
     return hipErrorInvalidValue;
 }
 
 }  // namespace
 
 // ---- entry points used by nf_host.hip ----
-hipError_t nf_launch_flow(const NfProgram &prog, const NfLaunch &a, int n_cu, hipStream_t stream)
+hipError_t nf_launch_flow(const NfProgram &prog, const NfLaunch &a, int n_cu, hipStream_t stream, bool matrix_core)
 {
+    if (matrix_core) return prog.width == 4 ? dispatch_geom<4, true>(prog, a, n_cu, stream) : hipErrorInvalidValue;
     switch (prog.width) {
-    case 4: return dispatch_geom<4>(prog, a, n_cu, stream);
-    case 8: return dispatch_geom<8>(prog, a, n_cu, stream);
-    case 16: return dispatch_geom<16>(prog, a, n_cu, stream);
+    case 4: return dispatch_geom<4, false>(prog, a, n_cu, stream);
+    case 8: return dispatch_geom<8, false>(prog, a, n_cu, stream);
+    case 16: return dispatch_geom<16, false>(prog, a, n_cu, stream);
     default: return hipErrorInvalidValue;
     }
 }
