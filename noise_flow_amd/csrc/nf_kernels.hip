@@ -99,6 +99,11 @@ __device__ __forceinline__ float nf_tanh(float x)
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(t + 1.0f);
 }
 
+// ReLU as ONE instruction: v_med3_f32(x, 0, +inf).  fmaxf() costs two (it canonicalises
+// its input first); inline asm is not an option because hipcc pads no VALU->MFMA hazard
+// wait states around an asm statement.
+__device__ __forceinline__ float nf_relu(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff()); }
+
 __device__ __forceinline__ float wave_sum(float v)
 {
 #pragma unroll
@@ -114,7 +119,7 @@ __device__ __forceinline__ float wave_sum(float v)
 // Pixel p of the patch is owned by thread p % THREADS (slot p / THREADS), so the
 // [H,W,4] fp32 patch is read/written as fully coalesced 16-byte lanes.
 // --------------------------------------------------------------------------
-template <int WIDTH, int THREADS, int PX, bool PHILOX, bool MFMA>
+template <int WIDTH, int THREADS, int PX, bool PHILOX, bool MFMA, bool FULL>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_WAVES(THREADS, PX, MFMA)))) void nf_flow_kernel(const NfProgram prog, const NfLaunch a)
 {
     static_assert(WIDTH % 4 == 0, "WIDTH must be a multiple of 4");
@@ -139,7 +144,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
 #pragma unroll
     for (int k = 0; k < PX; ++k) {
         const int p = t + THREADS * k;
-        act[k] = p < HW;
+        act[k] = FULL || p < HW;   // FULL: the patch fills the workgroup exactly -> no masking code at all
         const int pp = act[k] ? p : 0;
         const int r = pp / W, c = pp - r * W;
         lidx[k] = (r + 1) * Wp + (c + 1);
@@ -258,13 +263,13 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
 #pragma unroll
                     for (int k = 0; k < PX; ++k) {
                         v4f h2 = {b2.x, b2.y, b2.z, b2.w};
-                        h2 = __builtin_amdgcn_mfma_f32_4x4x1f32(w2.x, fmaxf(h1[k][0], 0.0f), h2, 0, 0, 0);
-                        h2 = __builtin_amdgcn_mfma_f32_4x4x1f32(w2.y, fmaxf(h1[k][1], 0.0f), h2, 0, 0, 0);
-                        h2 = __builtin_amdgcn_mfma_f32_4x4x1f32(w2.z, fmaxf(h1[k][2], 0.0f), h2, 0, 0, 0);
-                        h2 = __builtin_amdgcn_mfma_f32_4x4x1f32(w2.w, fmaxf(h1[k][3], 0.0f), h2, 0, 0, 0);
+                        h2 = __builtin_amdgcn_mfma_f32_4x4x1f32(w2.x, nf_relu(h1[k][0]), h2, 0, 0, 0);
+                        h2 = __builtin_amdgcn_mfma_f32_4x4x1f32(w2.y, nf_relu(h1[k][1]), h2, 0, 0, 0);
+                        h2 = __builtin_amdgcn_mfma_f32_4x4x1f32(w2.z, nf_relu(h1[k][2]), h2, 0, 0, 0);
+                        h2 = __builtin_amdgcn_mfma_f32_4x4x1f32(w2.w, nf_relu(h1[k][3]), h2, 0, 0, 0);
                         if (act[k])
                             *reinterpret_cast<float4 *>(th + (size_t)lidx[k] * 4) =
-                                make_float4(fmaxf(h2[0], 0.0f), fmaxf(h2[1], 0.0f), fmaxf(h2[2], 0.0f), fmaxf(h2[3], 0.0f));
+                                make_float4(nf_relu(h2[0]), nf_relu(h2[1]), nf_relu(h2[2]), nf_relu(h2[3]));
                     }
                 } else
                 {
@@ -302,7 +307,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
                         for (int j = 0; j < WIDTH; ++j) h2[j] = B2[j];
 #pragma unroll
                         for (int i = 0; i < WIDTH; ++i) {
-                            const float hi = fmaxf(h1[k][i], 0.0f);
+                            const float hi = nf_relu(h1[k][i]);
 #pragma unroll
                             for (int j = 0; j < WIDTH; ++j) h2[j] = fmaf(hi, W2[i * WIDTH + j], h2[j]);
                         }
@@ -310,8 +315,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
                             float4 *dst = reinterpret_cast<float4 *>(th + (size_t)lidx[k] * WIDTH);
 #pragma unroll
                             for (int q = 0; q < WIDTH / 4; ++q)
-                                dst[q] = make_float4(fmaxf(h2[4 * q + 0], 0.0f), fmaxf(h2[4 * q + 1], 0.0f),
-                                                     fmaxf(h2[4 * q + 2], 0.0f), fmaxf(h2[4 * q + 3], 0.0f));
+                                dst[q] = make_float4(nf_relu(h2[4 * q + 0]), nf_relu(h2[4 * q + 1]),
+                                                     nf_relu(h2[4 * q + 2]), nf_relu(h2[4 * q + 3]));
                         }
                     }
                 }
@@ -525,15 +530,15 @@ __global__ __launch_bounds__(256) void nf_synth_kernel(uint64_t seed, int64_t pa
     }
 }
 
-template <int WIDTH, int THREADS, int PX, bool PHILOX, bool MFMA>
-hipError_t launch_flow_v(const NfProgram &prog, const NfLaunch &a, int n_cu, hipStream_t stream)
+template <int WIDTH, int THREADS, int PX, bool PHILOX, bool MFMA, bool FULL>
+hipError_t launch_flow_f(const NfProgram &prog, const NfLaunch &a, int n_cu, hipStream_t stream)
 {
     const int tile_px = ((a.H + 2) * (a.W + 2) + 1) & ~1;
     size_t lds_f = (size_t)tile_px * (2 + WIDTH) + ((3 * (THREADS / 64) + 3) & ~3);
     if (MFMA) lds_f += (size_t)((a.n_params + 3) & ~3);
     const size_t lds = sizeof(float) * lds_f;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    const void *fn = reinterpret_cast<const void *>(&nf_flow_kernel<WIDTH, THREADS, PX, PHILOX, MFMA>);
+    const void *fn = reinterpret_cast<const void *>(&nf_flow_kernel<WIDTH, THREADS, PX, PHILOX, MFMA, FULL>);
     // (lds bytes << 8 | resident workgroups per CU) of the last query; racy but idempotent
     static std::atomic<uint64_t> cache{0};
     uint64_t c = cache.load(std::memory_order_relaxed);
@@ -556,9 +561,18 @@ hipError_t launch_flow_v(const NfProgram &prog, const NfLaunch &a, int n_cu, hip
     int64_t groups = (int64_t)n_cu * occ;
     if (a.B < groups) groups = a.B;
     if (groups < 1) groups = 1;
-    hipLaunchKernelGGL((nf_flow_kernel<WIDTH, THREADS, PX, PHILOX, MFMA>), dim3((unsigned)groups), dim3(THREADS), lds,
+    hipLaunchKernelGGL((nf_flow_kernel<WIDTH, THREADS, PX, PHILOX, MFMA, FULL>), dim3((unsigned)groups), dim3(THREADS), lds,
                        stream, prog, a);
     return hipGetLastError();
+}
+
+template <int WIDTH, int THREADS, int PX, bool PHILOX, bool MFMA>
+hipError_t launch_flow_v(const NfProgram &prog, const NfLaunch &a, int n_cu, hipStream_t stream)
+{
+    // full-patch specialisation only for the production shapes (32x32, 64x64) to bound code size
+    if (THREADS * PX >= 1024 && a.H * a.W == THREADS * PX)
+        return launch_flow_f<WIDTH, THREADS, PX, PHILOX, MFMA, true>(prog, a, n_cu, stream);
+    return launch_flow_f<WIDTH, THREADS, PX, PHILOX, MFMA, false>(prog, a, n_cu, stream);
 }
 
 template <int WIDTH, int THREADS, int PX, bool MFMA>
