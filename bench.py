@@ -186,9 +186,9 @@ def main():
             xc, yc = x0.cpu().numpy(), y0.cpu().numpy()
             cpu.nll(xc[:128], yc[:128], 100.0, 2.0)                       # warm-up
             tp = time.perf_counter()
-            cpu.nll(xc[:256], yc[:256], 100.0, 2.0)
-            rate = 256 / (time.perf_counter() - tp)
-            n_batches = int(max(1, min(64, round(args.cpu_seconds * rate / B))))
+            cpu.nll(xc, yc, 100.0, 2.0)                                   # one full batch sizes the sample
+            t_batch = time.perf_counter() - tp
+            n_batches = int(max(1, min(64, round(args.cpu_seconds / t_batch))))
             tc = time.perf_counter()
             for _ in range(n_batches):
                 cpu.nll(xc, yc, 100.0, 2.0)

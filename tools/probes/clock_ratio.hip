@@ -22,8 +22,17 @@ template <int CHAINS> void run(unsigned long long *d, int blocks)
 {
     unsigned long long h[3];
     const int iters = 100000;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     k<CHAINS><<<blocks, 256>>>(d, iters, 0.5f);
+    (void)hipEventRecord(e0);
+    k<CHAINS><<<blocks, 256>>>(d, iters, 0.5f);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     (void)hipMemcpy(h, d, 24, hipMemcpyDeviceToHost);
+    printf("[host: kernel %.3f ms = %.1f cyc per MFMA per SIMD at the counter clock] ", ms,
+           ms * 1e-3 * (100.0e6 * (double)h[0] / (double)h[1]) / ((double)iters * CHAINS * (blocks / 256)));
     printf("chains/wave=%d waves/SIMD=%d: counter %.0f MHz; %.1f cycles per MFMA per wave -> %.1f cycles per MFMA per SIMD\n", CHAINS,
            blocks / 256, 100.0 * (double)h[0] / (double)h[1], (double)h[0] / iters / CHAINS, (double)h[0] / iters / CHAINS / (blocks / 256));
 }
