@@ -184,16 +184,27 @@ void fold_coupling(const float *p, int w, float *out)
 void relayout_coupling_v2(const float *v1, float *out)
 {
     const int w = 4;
+    const double k2 = 2.0 * 1.4426950408889634;   // 2*log2(e): raw columns feed exp2() directly
+    const double log2e = 1.4426950408889634;
     memcpy(out + NF2_CPL_E, v1 + nf_cpl_off_E(w), 64 * sizeof(float));
+    for (int m = 0; m < 16; ++m)
+        for (int j = 2; j < 4; ++j) out[NF2_CPL_E + 4 * m + j] = (float)((double)v1[nf_cpl_off_E(w) + 4 * m + j] * k2);
     memcpy(out + NF2_CPL_B1, v1 + nf_cpl_off_B1(w), 4 * sizeof(float));
     memcpy(out + NF2_CPL_B2, v1 + nf_cpl_off_B2(w), 4 * sizeof(float));
-    memcpy(out + NF2_CPL_S, v1 + nf_cpl_off_S(w), 4 * sizeof(float));
+    const double sc = v1[nf_cpl_off_S(w)];
+    out[NF2_CPL_S + 0] = (float)sc;
+    out[NF2_CPL_S + 1] = (float)(sc * log2e);          // scl:   ls*log2(e) = scl*tanh(raw)
+    out[NF2_CPL_S + 2] = (float)(-2.0 * sc * log2e);   // -2*scl
+    out[NF2_CPL_S + 3] = 0.0f;
     for (int j = 0; j < 4; ++j) {
         for (int di = 0; di < 3; ++di)
             for (int q = 0; q < 8; ++q)
                 out[NF2_CPL_W1T + 24 * j + 8 * di + q] = q < 6 ? v1[nf_cpl_off_W1(w) + (di * 6 + q) * 4 + j] : 0.0f;
         for (int i = 0; i < 4; ++i) out[NF2_CPL_W2T + 4 * j + i] = v1[nf_cpl_off_W2(w) + i * 4 + j];
-        for (int k = 0; k < 36; ++k) out[NF2_CPL_W3T + 36 * j + k] = v1[nf_cpl_off_W3(w) + k * 4 + j];
+        for (int k = 0; k < 36; ++k) {
+            const double wv = v1[nf_cpl_off_W3(w) + k * 4 + j];
+            out[NF2_CPL_W3T + 36 * j + k] = (float)(j >= 2 ? wv * k2 : wv);
+        }
     }
 }
 

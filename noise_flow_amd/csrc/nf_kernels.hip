@@ -99,10 +99,15 @@ __device__ __forceinline__ float nf_tanh(float x)
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(t + 1.0f);
 }
 
-// ReLU as ONE instruction: v_med3_f32(x, 0, +inf).  fmaxf() costs two (it canonicalises
-// its input first); inline asm is not an option because hipcc pads no VALU->MFMA hazard
-// wait states around an asm statement.
-__device__ __forceinline__ float nf_relu(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff()); }
+// ReLU as ONE instruction: signed-integer max of the bit pattern with 0 (negative floats,
+// including -0.0, have the sign bit set).  fmaxf()/v_med3 cost two because the compiler
+// canonicalises the MFMA result first; inline asm is not an option because hipcc pads no
+// VALU->MFMA hazard wait states around an asm statement.
+__device__ __forceinline__ float nf_relu(float x)
+{
+    const int b = __float_as_int(x);
+    return __int_as_float(b > 0 ? b : 0);
+}
 
 __device__ __forceinline__ float wave_sum(float v)
 {
@@ -137,18 +142,43 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
     const int t = threadIdx.x;
     const int j4 = t & 3;   // MFMA: which output channel's weights this lane feeds as the A operand
 
-    // per-pixel constants (same for every patch this workgroup processes)
+    // Pixel ownership.
+    //  * default: pixel p of the patch belongs to thread p % THREADS (slot p / THREADS);
+    //  * BLK (matrix-core path, full 32x32 / 64x64 patches): every lane owns a 2x2 pixel block, so
+    //    the 4x4 input window of the block is read from LDS ONCE (16 loads instead of 36 per conv)
+    //    and the LDS tiles are split in two column-parity planes to keep those reads conflict-free:
+    //    entry(r', c') = ((r'*2 + (c'&1)) * PW + (c'>>1)),  r' = row+1, c' = col+1, PW = W/2 + 1.
+    constexpr bool BLK = MFMA && FULL && PX == 4;
+    const int PW = (W >> 1) + 1;
     int lidx[PX];      // index of the pixel inside the zero-bordered tiles
+    int gidx[PX];      // index of the pixel inside the patch (float4 units)
     int bmask[PX];     // border mask: top | bottom<<1 | left<<2 | right<<3
     bool act[PX];
+    int wbase = 0;     // BLK: tile entry of the window origin (r' = 2*br, c' = 2*bc)
+    if constexpr (BLK) {
+        const int bw = W >> 1;
+        const int br = t / bw, bc = t - br * bw;
+        wbase = (2 * br * 2) * PW + bc;
 #pragma unroll
-    for (int k = 0; k < PX; ++k) {
-        const int p = t + THREADS * k;
-        act[k] = FULL || p < HW;   // FULL: the patch fills the workgroup exactly -> no masking code at all
-        const int pp = act[k] ? p : 0;
-        const int r = pp / W, c = pp - r * W;
-        lidx[k] = (r + 1) * Wp + (c + 1);
-        bmask[k] = (r == 0 ? 1 : 0) | (r == H - 1 ? 2 : 0) | (c == 0 ? 4 : 0) | (c == W - 1 ? 8 : 0);
+        for (int k = 0; k < PX; ++k) {
+            const int dy = k >> 1, dx = k & 1;
+            const int r = 2 * br + dy, c = 2 * bc + dx;
+            act[k] = true;
+            gidx[k] = r * W + c;
+            lidx[k] = wbase + ((dy + 1) * 2 + ((dx + 1) & 1)) * PW + ((dx + 1) >> 1);
+            bmask[k] = (r == 0 ? 1 : 0) | (r == H - 1 ? 2 : 0) | (c == 0 ? 4 : 0) | (c == W - 1 ? 8 : 0);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < PX; ++k) {
+            const int p = t + THREADS * k;
+            act[k] = FULL || p < HW;   // FULL: the patch fills the workgroup exactly -> no masking code at all
+            const int pp = act[k] ? p : 0;
+            const int r = pp / W, c = pp - r * W;
+            gidx[k] = pp;
+            lidx[k] = (r + 1) * Wp + (c + 1);
+            bmask[k] = (r == 0 ? 1 : 0) | (r == H - 1 ? 2 : 0) | (c == 0 ? 4 : 0) | (c == W - 1 ? 8 : 0);
+        }
     }
 
     // zero both tiles once: the 1-pixel border is never written again
@@ -168,7 +198,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
         if (PHILOX) {
 #pragma unroll
             for (int k = 0; k < PX; ++k) {
-                philox_normal4(a.seed, a.patch_base + b, (uint32_t)(t + THREADS * k), NF_STREAM_SAMP, z[k]);
+                philox_normal4(a.seed, a.patch_base + b, (uint32_t)gidx[k], NF_STREAM_SAMP, z[k]);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) z[k][c] *= a.in_scale;
             }
@@ -177,7 +207,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
 #pragma unroll
             for (int k = 0; k < PX; ++k) {
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (act[k]) v = in4[t + THREADS * k];
+                if (act[k]) v = in4[gidx[k]];
                 z[k][0] = v.x * a.in_scale;
                 z[k][1] = v.y * a.in_scale;
                 z[k][2] = v.z * a.in_scale;
@@ -185,7 +215,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
             }
         }
 
-        float ld = 0.0f;   // this thread's share of the data-dependent log-det
+        float ld = 0.0f;    // this thread's share of the data-dependent log-det (natural log)
+        float ld2 = 0.0f;   // ... and the part accumulated in log2 units (matrix-core couplings)
 
         for (int op = 0; op < n_ops; ++op) {
             const int type = prog.ops[op].type;
@@ -241,6 +272,35 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
                     v4f h1[PX];
 #pragma unroll
                     for (int k = 0; k < PX; ++k) h1[k] = v4f{b1.x, b1.y, b1.z, b1.w};
+                    if constexpr (BLK) {
+                        float w1[3][6];   // this lane's A operands: W1[(di,dj,c)][j4]
+#pragma unroll
+                        for (int di = 0; di < 3; ++di) {
+                            const float4 wA = *reinterpret_cast<const float4 *>(wb + NF2_CPL_W1T + 24 * j4 + 8 * di);
+                            const float2 wB = *reinterpret_cast<const float2 *>(wb + NF2_CPL_W1T + 24 * j4 + 8 * di + 4);
+                            w1[di][0] = wA.x; w1[di][1] = wA.y; w1[di][2] = wA.z; w1[di][3] = wA.w; w1[di][4] = wB.x; w1[di][5] = wB.y;
+                        }
+                        NF_PRIO_UP();
+#pragma unroll
+                        for (int wr = 0; wr < 4; ++wr) {
+                            float2 v[4];   // one row of the 4x4 window, shared by the 2x2 output pixels
+#pragma unroll
+                            for (int wc = 0; wc < 4; ++wc) v[wc] = t0[wbase + (wr * 2 + (wc & 1)) * PW + (wc >> 1)];
+#pragma unroll
+                            for (int dy = 0; dy < 2; ++dy) {
+                                const int di = wr - dy;
+                                if (di < 0 || di > 2) continue;
+#pragma unroll
+                                for (int dj = 0; dj < 3; ++dj)
+#pragma unroll
+                                    for (int dx = 0; dx < 2; ++dx) {
+                                        const int k = dy * 2 + dx;
+                                        h1[k] = __builtin_amdgcn_mfma_f32_4x4x1f32(w1[di][2 * dj + 0], v[dx + dj].x, h1[k], 0, 0, 0);
+                                        h1[k] = __builtin_amdgcn_mfma_f32_4x4x1f32(w1[di][2 * dj + 1], v[dx + dj].y, h1[k], 0, 0, 0);
+                                    }
+                            }
+                        }
+                    } else {
                     NF_PRIO_UP();
 #pragma unroll
                     for (int di = 0; di < 3; ++di) {
@@ -258,6 +318,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
                                 h1[k] = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[2 * dj + 1], v.y, h1[k], 0, 0, 0);
                             }
                         }
+                    }
                     }
                     NF_PRIO_DOWN();
 #pragma unroll
@@ -328,13 +389,46 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
                     float sc;
                     if constexpr (MFMA) {
                         const float *wb = wl + prog.ops[op].off;
-                        sc = wb[NF2_CPL_S];
+                        sc = 0.0f;
                         v4f acc[PX];
 #pragma unroll
                         for (int k = 0; k < PX; ++k) {
                             const float4 e = *reinterpret_cast<const float4 *>(wb + NF2_CPL_E + 4 * bmask[k]);
                             acc[k] = v4f{e.x, e.y, e.z, e.w};
                         }
+                        if constexpr (BLK) {
+                            float w3[3][12];   // this lane's A operands: W3[(di,dj,i)][j4]
+#pragma unroll
+                            for (int q = 0; q < 9; ++q) {
+                                const float4 w = *reinterpret_cast<const float4 *>(wb + NF2_CPL_W3T + 36 * j4 + 4 * q);
+                                w3[q / 3][4 * (q % 3) + 0] = w.x; w3[q / 3][4 * (q % 3) + 1] = w.y;
+                                w3[q / 3][4 * (q % 3) + 2] = w.z; w3[q / 3][4 * (q % 3) + 3] = w.w;
+                            }
+                            NF_PRIO_UP();
+#pragma unroll
+                            for (int wr = 0; wr < 4; ++wr) {
+                                float4 hv[4];   // one row of the 4x4 window of h2
+#pragma unroll
+                                for (int wc = 0; wc < 4; ++wc)
+                                    hv[wc] = *reinterpret_cast<const float4 *>(th + (size_t)(wbase + (wr * 2 + (wc & 1)) * PW + (wc >> 1)) * 4);
+#pragma unroll
+                                for (int dy = 0; dy < 2; ++dy) {
+                                    const int di = wr - dy;
+                                    if (di < 0 || di > 2) continue;
+#pragma unroll
+                                    for (int dj = 0; dj < 3; ++dj)
+#pragma unroll
+                                        for (int dx = 0; dx < 2; ++dx) {
+                                            const int k = dy * 2 + dx;
+                                            const float4 h = hv[dx + dj];
+                                            acc[k] = __builtin_amdgcn_mfma_f32_4x4x1f32(w3[di][4 * dj + 0], h.x, acc[k], 0, 0, 0);
+                                            acc[k] = __builtin_amdgcn_mfma_f32_4x4x1f32(w3[di][4 * dj + 1], h.y, acc[k], 0, 0, 0);
+                                            acc[k] = __builtin_amdgcn_mfma_f32_4x4x1f32(w3[di][4 * dj + 2], h.z, acc[k], 0, 0, 0);
+                                            acc[k] = __builtin_amdgcn_mfma_f32_4x4x1f32(w3[di][4 * dj + 3], h.w, acc[k], 0, 0, 0);
+                                        }
+                                }
+                            }
+                        } else {
                         NF_PRIO_UP();
 #pragma unroll
                         for (int di = 0; di < 3; ++di) {
@@ -356,6 +450,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
                                     acc[k] = __builtin_amdgcn_mfma_f32_4x4x1f32(w3[4 * dj + 3], hv.w, acc[k], 0, 0, 0);
                                 }
                             }
+                        }
                         }
                         NF_PRIO_DOWN();
 #pragma unroll
@@ -396,17 +491,43 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
                     }
                     }
                     // shift = o[0:2], raw log-scale = o[2:4]  (tf.split, layers.py:494)
-#pragma unroll
-                    for (int k = 0; k < PX; ++k) {
-                        const float ls0 = sc * nf_tanh(o[k][2]);
-                        const float ls1 = sc * nf_tanh(o[k][3]);
+                    if constexpr (MFMA) {
+                        // matrix-core layout: the host pre-scaled the raw columns by 2*log2(e), so
+                        //   t = exp2(raw') = exp(2 raw);  ls*log2(e) = scl*tanh(raw) = scl - 2 scl/(t + 1)
+                        // and the log-det is accumulated in log2 units (ld2), converted once per patch.
+                        const float scl = wl[prog.ops[op].off + NF2_CPL_S + 1];
+                        const float m2scl = wl[prog.ops[op].off + NF2_CPL_S + 2];
                         if (type == NF_OP_COUPLING_FWD) {
-                            z[k][2] = fmaf(z[k][2], nf_exp(ls0), o[k][0]);
-                            z[k][3] = fmaf(z[k][3], nf_exp(ls1), o[k][1]);
-                            if (act[k]) ld += ls0 + ls1;
+#pragma unroll
+                            for (int k = 0; k < PX; ++k) {
+                                const float l0 = fmaf(__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(o[k][2]) + 1.0f), m2scl, scl);
+                                const float l1 = fmaf(__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(o[k][3]) + 1.0f), m2scl, scl);
+                                z[k][2] = fmaf(z[k][2], __builtin_amdgcn_exp2f(l0), o[k][0]);
+                                z[k][3] = fmaf(z[k][3], __builtin_amdgcn_exp2f(l1), o[k][1]);
+                                if (act[k]) ld2 += l0 + l1;
+                            }
                         } else {
-                            z[k][2] = (z[k][2] - o[k][0]) * nf_exp(-ls0);
-                            z[k][3] = (z[k][3] - o[k][1]) * nf_exp(-ls1);
+#pragma unroll
+                            for (int k = 0; k < PX; ++k) {
+                                const float l0 = fmaf(__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(o[k][2]) + 1.0f), m2scl, scl);
+                                const float l1 = fmaf(__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(o[k][3]) + 1.0f), m2scl, scl);
+                                z[k][2] = (z[k][2] - o[k][0]) * __builtin_amdgcn_exp2f(-l0);
+                                z[k][3] = (z[k][3] - o[k][1]) * __builtin_amdgcn_exp2f(-l1);
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < PX; ++k) {
+                            const float ls0 = sc * nf_tanh(o[k][2]);
+                            const float ls1 = sc * nf_tanh(o[k][3]);
+                            if (type == NF_OP_COUPLING_FWD) {
+                                z[k][2] = fmaf(z[k][2], nf_exp(ls0), o[k][0]);
+                                z[k][3] = fmaf(z[k][3], nf_exp(ls1), o[k][1]);
+                                if (act[k]) ld += ls0 + ls1;
+                            } else {
+                                z[k][2] = (z[k][2] - o[k][0]) * nf_exp(-ls0);
+                                z[k][3] = (z[k][3] - o[k][1]) * nf_exp(-ls1);
+                            }
                         }
                     }
                 }
@@ -416,7 +537,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
 #pragma unroll
                 for (int k = 0; k < PX; ++k) {
                     float4 yv = make_float4(1.f, 1.f, 1.f, 1.f);
-                    if (act[k]) yv = y4[t + THREADS * k];
+                    if (act[k]) yv = y4[gidx[k]];
                     const float yy[4] = {yv.x, yv.y, yv.z, yv.w};
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
@@ -445,7 +566,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
             float4 *out4 = reinterpret_cast<float4 *>(a.out + patch_off);
 #pragma unroll
             for (int k = 0; k < PX; ++k)
-                if (act[k]) out4[t + THREADS * k] = make_float4(z[k][0], z[k][1], z[k][2], z[k][3]);
+                if (act[k]) out4[gidx[k]] = make_float4(z[k][0], z[k][1], z[k][2], z[k][3]);
         }
         if (a.nll_out || a.sd_out || a.ld_out || a.sums) {
             float s1 = 0.f, s2 = 0.f;
@@ -458,7 +579,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
                         s2 = fmaf(z[k][c], z[k][c], s2);
                     }
                 }
-            float r0 = wave_sum(ld), r1 = wave_sum(s1), r2 = wave_sum(s2);
+            float r0 = wave_sum(fmaf(ld2, 0.6931471805599453f, ld)), r1 = wave_sum(s1), r2 = wave_sum(s2);
             constexpr int NW = THREADS / 64;
             if (NW > 1) {
                 const int wv = t >> 6;
