@@ -76,8 +76,13 @@ typedef struct nf_config {
     int32_t channels;      /* must be 4 (packed Bayer raw)                */
     int32_t n_layers;      /* number of nf_layer_desc entries, NLL order  */
     int32_t device;        /* HIP device ordinal, -1 = current device     */
-    int32_t reserved;      /* must be 0                                   */
+    int32_t flags;         /* NF_CFG_* bits (0 = everything in fp32)       */
 } nf_config;
+
+/* nf_config.flags */
+#define NF_CFG_FP16_CNN 1   /* coupling CNN convs in fp16 (fp32 accumulate) on the matrix cores;
+                              1x1 mixes, tanh/exp, log-det and prior stay fp32.  Width 4, full
+                              32x32 or 64x64 patches only (BASELINE configs[4]).            */
 
 /* Per-call conditioning: ONE value per call, not per patch — the reference
  * feeds length-1 lists (MiniBatchSampler.py:61-64, NoiseFlowWrapper.py:85-86).

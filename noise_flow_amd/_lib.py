@@ -16,6 +16,8 @@ NF_LAYER_COUPLING = 2
 NF_LAYER_SDN5 = 3
 NF_LAYER_GAIN4 = 4
 
+NF_CFG_FP16_CNN = 1
+
 NF_ACCUMULATE = 1
 NF_NO_PRIOR = 2
 
@@ -35,7 +37,7 @@ class nf_layer_desc(C.Structure):
 
 class nf_config(C.Structure):
     _fields_ = [("height", C.c_int32), ("width", C.c_int32), ("channels", C.c_int32),
-                ("n_layers", C.c_int32), ("device", C.c_int32), ("reserved", C.c_int32)]
+                ("n_layers", C.c_int32), ("device", C.c_int32), ("flags", C.c_int32)]
 
 
 class nf_cond(C.Structure):

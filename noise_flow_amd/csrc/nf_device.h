@@ -75,10 +75,34 @@ __host__ __device__ constexpr int nf_cpl_size(int w)   { return 64 + 36 * w + 18
 #define NF2_CPL_SIZE 332
 #define NF2_MAX_FLOATS 6144   // 24 KiB of LDS for the whole model's weights
 
+// ---- fp16-CNN layout (matrix-core path, BASELINE configs[4]) ---------------------------
+// Same ops; the three convs of the coupling CNN run on v_mfma_f32_4x4x4_16b_f16 (K = 4 per
+// instruction, fp32 accumulate) with fp16 weights and fp16 activations; everything else
+// (1x1 mixes, biases, border table, tanh/exp, log-det, prior) stays fp32.  Offsets in
+// 32-bit words; one A operand = 4 halves = 2 words.
+//   MIX       Mt [4][4] fp32 (as above)
+//   COUPLING  E  [16][4] fp32 @0, B1[4] @64, B2[4] @68, S[4] @72 (sc, sc*log2e, -2 sc*log2e, 0)
+//             W1h[4][3][4][2w] @76    per out channel j, filter row di, group g: 4 halves
+//                                     g0 = dx0:(dj0c0,dj0c1,dj1c0,dj1c1)  g1 = dx0:(dj2c0,dj2c1,0,0)
+//                                     g2 = dx1:(0,0,dj0c0,dj0c1)          g3 = dx1:(dj1c0,dj1c1,dj2c0,dj2c1)
+//                                     (the B operand is always the 8-byte pair of horizontally
+//                                      adjacent z0 pixels the lane already holds)
+//             W2h[4][2w]    @172      per j: (i0,i1,i2,i3)
+//             W3h[4][9][2w] @180      per j, tap: (i0,i1,i2,i3)
+#define NF3_CPL_E 0
+#define NF3_CPL_B1 64
+#define NF3_CPL_B2 68
+#define NF3_CPL_S 72
+#define NF3_CPL_W1H 76
+#define NF3_CPL_W2H 172
+#define NF3_CPL_W3H 180
+#define NF3_CPL_SIZE 252
+
 // launch flags
 enum : uint32_t {
     NF_K_PRIOR     = 1u,   // nll = -(logdet + logp(z)); otherwise nll = -logdet
     NF_K_PHILOX_IN = 2u,   // input = Philox normal draw (sampling with in-kernel eps)
+    NF_K_FP16_CNN  = 4u,   // parameter block is the fp16-CNN layout (NF3_*)
 };
 
 struct NfLaunch {

@@ -208,6 +208,48 @@ void relayout_coupling_v2(const float *v1, float *out)
     }
 }
 
+// fp16-CNN re-layout (nf_device.h, NF3_CPL_*): folded weights rounded to IEEE half.
+uint16_t to_half(float f)
+{
+    _Float16 h = (_Float16)f;   // round-to-nearest-even
+    uint16_t u;
+    memcpy(&u, &h, 2);
+    return u;
+}
+
+void relayout_coupling_v3(const float *v1, float *out)
+{
+    const int w = 4;
+    const double log2e = 1.4426950408889634;
+    memcpy(out + NF3_CPL_E, v1 + nf_cpl_off_E(w), 64 * sizeof(float));
+    memcpy(out + NF3_CPL_B1, v1 + nf_cpl_off_B1(w), 4 * sizeof(float));
+    memcpy(out + NF3_CPL_B2, v1 + nf_cpl_off_B2(w), 4 * sizeof(float));
+    const double sc = v1[nf_cpl_off_S(w)];
+    out[NF3_CPL_S + 0] = (float)sc;
+    out[NF3_CPL_S + 1] = (float)(sc * log2e);
+    out[NF3_CPL_S + 2] = (float)(-2.0 * sc * log2e);
+    out[NF3_CPL_S + 3] = 0.0f;
+    uint16_t *h1 = reinterpret_cast<uint16_t *>(out + NF3_CPL_W1H);
+    uint16_t *h2 = reinterpret_cast<uint16_t *>(out + NF3_CPL_W2H);
+    uint16_t *h3 = reinterpret_cast<uint16_t *>(out + NF3_CPL_W3H);
+    auto W1 = [&](int di, int dj, int c, int j) { return to_half(v1[nf_cpl_off_W1(w) + ((di * 3 + dj) * 2 + c) * 4 + j]); };
+    for (int j = 0; j < 4; ++j) {
+        for (int di = 0; di < 3; ++di) {
+            uint16_t *g = h1 + ((j * 3 + di) * 4) * 4;   // 4 groups x 4 halves
+            const uint16_t z = 0;
+            const uint16_t grp[4][4] = {
+                {W1(di, 0, 0, j), W1(di, 0, 1, j), W1(di, 1, 0, j), W1(di, 1, 1, j)},   // dx=0, window pair (wc0,wc1)
+                {W1(di, 2, 0, j), W1(di, 2, 1, j), z, z},                               // dx=0, pair (wc2,wc3)
+                {z, z, W1(di, 0, 0, j), W1(di, 0, 1, j)},                               // dx=1, pair (wc0,wc1)
+                {W1(di, 1, 0, j), W1(di, 1, 1, j), W1(di, 2, 0, j), W1(di, 2, 1, j)}};  // dx=1, pair (wc2,wc3)
+            memcpy(g, grp, sizeof(grp));
+        }
+        for (int i = 0; i < 4; ++i) h2[j * 4 + i] = to_half(v1[nf_cpl_off_W2(w) + i * 4 + j]);
+        for (int tap = 0; tap < 9; ++tap)
+            for (int i = 0; i < 4; ++i) h3[(j * 9 + tap) * 4 + i] = to_half(v1[nf_cpl_off_W3(w) + (tap * 4 + i) * 4 + j]);
+    }
+}
+
 // ---- sdn5 host scalars (cond_utils.py:205-239) -------------------------------
 int sdn5_scalars(const float *sp, const nf_cond *cond, double out[2])
 {
@@ -239,6 +281,8 @@ struct Built {
     std::vector<float> block;
     NfProgram prog2;             // matrix-core (MFMA) layout, width 4 only
     std::vector<float> block2;   // empty when unavailable
+    NfProgram prog3;             // fp16-CNN layout (NF_CFG_FP16_CNN), width 4 only
+    std::vector<float> block3;
     double ld_const = 0.0;
     bool has_sdn = false;
     std::vector<float> sdn_params;
@@ -252,7 +296,7 @@ int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float
     if (cfg->height < 1 || cfg->width < 1 || cfg->height * cfg->width > 4096 || cfg->height > 64 || cfg->width > 64)
         return fail(NF_EINVAL, "patch size %dx%d unsupported (max 64x64)", cfg->height, cfg->width);
     if (cfg->n_layers < 1) return fail(NF_EINVAL, "n_layers must be >= 1");
-    if (cfg->reserved != 0) return fail(NF_EINVAL, "nf_config.reserved must be 0");
+    if (cfg->flags & ~NF_CFG_FP16_CNN) return fail(NF_EINVAL, "nf_config.flags has unknown bits set");
     const double HW = (double)cfg->height * cfg->width;
 
     // intermediate list in NLL order
@@ -390,6 +434,29 @@ int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float
         if (out.block2.empty()) out.block2.assign(4, 0.0f);
         if (out.block2.size() > NF2_MAX_FLOATS) out.block2.clear();   // too large for LDS: scalar path only
     }
+    out.block3.clear();
+    memset(&out.prog3, 0, sizeof(out.prog3));
+    if (out.prog.width == 4 && (cfg->flags & NF_CFG_FP16_CNN)) {
+        out.prog3.width = 4;
+        for (int i = 0; i < out.prog.n_ops; ++i) {
+            const NfOp &src = out.prog.ops[i];
+            NfOp &dst = out.prog3.ops[out.prog3.n_ops++];
+            dst.type = src.type;
+            dst.off = (int32_t)out.block3.size();
+            const float *v1 = out.block.data() + src.off;
+            if (src.type == NF_OP_MIX) {
+                for (int j = 0; j < 4; ++j)
+                    for (int c = 0; c < 4; ++c) out.block3.push_back(v1[c * 4 + j]);
+            } else if (src.type == NF_OP_COUPLING_FWD || src.type == NF_OP_COUPLING_REV) {
+                out.block3.resize(out.block3.size() + NF3_CPL_SIZE);
+                relayout_coupling_v3(v1, out.block3.data() + dst.off);
+            } else if (src.type == NF_OP_SCALE) {
+                out.block3.insert(out.block3.end(), v1, v1 + 4);
+            }
+        }
+        if (out.block3.empty()) out.block3.assign(4, 0.0f);
+        if (out.block3.size() > NF2_MAX_FLOATS) return fail(NF_EINVAL, "model too large for the fp16-CNN LDS image");
+    }
     return NF_OK;
 }
 
@@ -431,6 +498,8 @@ struct nf_handle {
     float *d_rev = nullptr;
     float *d_fwd2 = nullptr;   // matrix-core layout (null when unavailable)
     float *d_rev2 = nullptr;
+    float *d_fwd3 = nullptr;   // fp16-CNN layout (NF_CFG_FP16_CNN)
+    float *d_rev3 = nullptr;
 };
 
 extern "C" {
@@ -518,9 +587,16 @@ int nf_create(const nf_config *cfg, const nf_layer_desc *layers, const float *pa
         delete h;
         return fail_hip(e, "hipMemcpy(params)");
     }
-    for (int d = 0; d < 2; ++d) {
-        const std::vector<float> &b2 = d == 0 ? h->fwd.block2 : h->rev.block2;
-        float **dst = d == 0 ? &h->d_fwd2 : &h->d_rev2;
+    if (cfg->flags & NF_CFG_FP16_CNN) {
+        const int hw = cfg->height * cfg->width;
+        if (h->fwd.block3.empty() || !((cfg->height == 32 && cfg->width == 32) || (cfg->height == 64 && cfg->width == 64)) || hw == 0) {
+            delete h;
+            return fail(NF_EINVAL, "NF_CFG_FP16_CNN needs coupling width 4 and full 32x32 or 64x64 patches");
+        }
+    }
+    for (int d = 0; d < 4; ++d) {
+        const std::vector<float> &b2 = d == 0 ? h->fwd.block2 : d == 1 ? h->rev.block2 : d == 2 ? h->fwd.block3 : h->rev.block3;
+        float **dst = d == 0 ? &h->d_fwd2 : d == 1 ? &h->d_rev2 : d == 2 ? &h->d_fwd3 : &h->d_rev3;
         if (b2.empty()) continue;
         if ((e = hipMalloc((void **)dst, b2.size() * sizeof(float))) != hipSuccess ||
             (e = hipMemcpy(*dst, b2.data(), b2.size() * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) {
@@ -541,6 +617,8 @@ int nf_destroy(nf_handle *h)
     if (h->d_rev) (void)hipFree(h->d_rev);
     if (h->d_fwd2) (void)hipFree(h->d_fwd2);
     if (h->d_rev2) (void)hipFree(h->d_rev2);
+    if (h->d_fwd3) (void)hipFree(h->d_fwd3);
+    if (h->d_rev3) (void)hipFree(h->d_rev3);
     delete h;
     return NF_OK;
 }
@@ -584,12 +662,16 @@ int nf_nll(nf_handle *h, const float *x, const float *y, int64_t B, const nf_con
     a.H = h->cfg.height;
     a.W = h->cfg.width;
     a.flags = (flags & NF_NO_PRIOR) ? 0u : NF_K_PRIOR;
-    const bool mc = h->d_fwd2 && use_matrix_core();
-    if (mc) {
+    const bool mc = h->d_fwd3 || (h->d_fwd2 && use_matrix_core());
+    if (h->d_fwd3) {
+        a.params = h->d_fwd3;
+        a.n_params = (int32_t)h->fwd.block3.size();
+        a.flags |= NF_K_FP16_CNN;
+    } else if (mc) {
         a.params = h->d_fwd2;
         a.n_params = (int32_t)h->fwd.block2.size();
     }
-    hipError_t e = nf_launch_flow(mc ? h->fwd.prog2 : h->fwd.prog, a, h->n_cu, st, mc);
+    hipError_t e = nf_launch_flow(h->d_fwd3 ? h->fwd.prog3 : mc ? h->fwd.prog2 : h->fwd.prog, a, h->n_cu, st, mc);
     if (e != hipSuccess) return fail_hip(e, "nf_nll launch");
     return NF_OK;
 }
@@ -625,12 +707,16 @@ int nf_sample(nf_handle *h, const float *y, const float *eps, uint64_t seed, int
     a.H = h->cfg.height;
     a.W = h->cfg.width;
     a.flags = eps ? 0u : NF_K_PHILOX_IN;
-    const bool mc = h->d_rev2 && use_matrix_core();
-    if (mc) {
+    const bool mc = h->d_rev3 || (h->d_rev2 && use_matrix_core());
+    if (h->d_rev3) {
+        a.params = h->d_rev3;
+        a.n_params = (int32_t)h->rev.block3.size();
+        a.flags |= NF_K_FP16_CNN;
+    } else if (mc) {
         a.params = h->d_rev2;
         a.n_params = (int32_t)h->rev.block2.size();
     }
-    hipError_t e = nf_launch_flow(mc ? h->rev.prog2 : h->rev.prog, a, h->n_cu, (hipStream_t)stream, mc);
+    hipError_t e = nf_launch_flow(h->d_rev3 ? h->rev.prog3 : mc ? h->rev.prog2 : h->rev.prog, a, h->n_cu, (hipStream_t)stream, mc);
     if (e != hipSuccess) return fail_hip(e, "nf_sample launch");
     return NF_OK;
 }

@@ -39,6 +39,8 @@ namespace {
 // (scalar cache, SGPR operands) instead of a per-lane global_load into VGPRs.
 typedef const float __attribute__((address_space(4))) *cfloat_p;
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef _Float16 v4h __attribute__((ext_vector_type(4)));
+typedef _Float16 v2h __attribute__((ext_vector_type(2)));
 
 // --------------------------------------------------------------------------
 // Philox4x32-10 counter-based RNG (Salmon et al. 2011) — keyed by
@@ -124,11 +126,13 @@ __device__ __forceinline__ float wave_sum(float v)
 // Pixel p of the patch is owned by thread p % THREADS (slot p / THREADS), so the
 // [H,W,4] fp32 patch is read/written as fully coalesced 16-byte lanes.
 // --------------------------------------------------------------------------
-template <int WIDTH, int THREADS, int PX, bool PHILOX, bool MFMA, bool FULL>
+template <int WIDTH, int THREADS, int PX, bool PHILOX, bool MFMA, bool FULL, int PREC>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_WAVES(THREADS, PX, MFMA)))) void nf_flow_kernel(const NfProgram prog, const NfLaunch a)
 {
     static_assert(WIDTH % 4 == 0, "WIDTH must be a multiple of 4");
     static_assert(!MFMA || WIDTH == 4, "the matrix-core path is the width-4 specialisation");
+    static_assert(PREC == 0 || (MFMA && FULL && PX == 4), "the fp16-CNN mode exists for full 2x2-blocked patches only");
+    constexpr bool H16 = PREC == 1;   // coupling-CNN convs on fp16 matrix cores (fp32 accumulate)
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int H = a.H, W = a.W, HW = H * W;
@@ -136,7 +140,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
     const int tile_px = ((H + 2) * Wp + 1) & ~1;         // even -> 16-byte aligned sections
     float2 *const t0 = reinterpret_cast<float2 *>(smem);  // z0 tile  [tile_px] float2
     float *const th = smem + 2 * tile_px;                 // h2 tile  [tile_px][WIDTH]
-    float *const red = th + WIDTH * tile_px;              // reduction scratch [3][THREADS/64] (+pad)
+    // fp16-CNN mode: the same two tiles hold half2 / 4 x half per pixel, plain row-major
+    uint32_t *const t0h = reinterpret_cast<uint32_t *>(smem);         // [tile_px] half2
+    uint2 *const thh = reinterpret_cast<uint2 *>(smem + tile_px);     // [tile_px] 4 x half
+    constexpr int TILE_WORDS = H16 ? 3 : 2 + WIDTH;                   // 32-bit words per tile pixel
+    float *const red = smem + TILE_WORDS * tile_px;       // reduction scratch [3][THREADS/64] (+pad)
     float *const wl = red + ((3 * (THREADS / 64) + 3) & ~3);   // MFMA: the whole folded model, j-major
 
     const int t = threadIdx.x;
@@ -158,14 +166,14 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
     if constexpr (BLK) {
         const int bw = W >> 1;
         const int br = t / bw, bc = t - br * bw;
-        wbase = (2 * br * 2) * PW + bc;
+        wbase = H16 ? (2 * br) * Wp + 2 * bc : (2 * br * 2) * PW + bc;
 #pragma unroll
         for (int k = 0; k < PX; ++k) {
             const int dy = k >> 1, dx = k & 1;
             const int r = 2 * br + dy, c = 2 * bc + dx;
             act[k] = true;
             gidx[k] = r * W + c;
-            lidx[k] = wbase + ((dy + 1) * 2 + ((dx + 1) & 1)) * PW + ((dx + 1) >> 1);
+            lidx[k] = H16 ? (r + 1) * Wp + (c + 1) : wbase + ((dy + 1) * 2 + ((dx + 1) & 1)) * PW + ((dx + 1) >> 1);
             bmask[k] = (r == 0 ? 1 : 0) | (r == H - 1 ? 2 : 0) | (c == 0 ? 4 : 0) | (c == W - 1 ? 8 : 0);
         }
     } else {
@@ -182,7 +190,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
     }
 
     // zero both tiles once: the 1-pixel border is never written again
-    for (int i = t; i < tile_px * (2 + WIDTH); i += THREADS) smem[i] = 0.0f;
+    for (int i = t; i < tile_px * TILE_WORDS; i += THREADS) smem[i] = 0.0f;
     if (MFMA)
         for (int i = t; i < a.n_params; i += THREADS) wl[i] = a.params[i];
     __syncthreads();
@@ -259,12 +267,61 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
                 // ---- AffineCoupling (layers.py:275-291 / 355-375) ----
                 // 1) publish the pass-through half
 #pragma unroll
-                for (int k = 0; k < PX; ++k)
-                    if (act[k]) t0[lidx[k]] = make_float2(z[k][0], z[k][1]);
+                for (int k = 0; k < PX; ++k) {
+                    if constexpr (H16) {
+                        const v2h zh = {(_Float16)z[k][0], (_Float16)z[k][1]};
+                        t0h[lidx[k]] = __builtin_bit_cast(uint32_t, zh);
+                    } else {
+                        if (act[k]) t0[lidx[k]] = make_float2(z[k][0], z[k][1]);
+                    }
+                }
                 __syncthreads();
 
                 // 2) l_1 (3x3 SAME, BN folded) -> ReLU -> l_2 (1x1, BN folded) -> ReLU
-                if constexpr (MFMA) {
+                if constexpr (H16) {
+                    const float *wb = wl + prog.ops[op].off;
+                    const uint32_t *wbw = reinterpret_cast<const uint32_t *>(wb);
+                    const float4 b1 = *reinterpret_cast<const float4 *>(wb + NF3_CPL_B1);
+                    const float4 b2 = *reinterpret_cast<const float4 *>(wb + NF3_CPL_B2);
+                    v4h w1h[3][4];   // [filter row][group]: this lane's A operands (4 halves each)
+#pragma unroll
+                    for (int di = 0; di < 3; ++di)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            w1h[di][g] = *reinterpret_cast<const v4h *>(wbw + NF3_CPL_W1H + ((j4 * 3 + di) * 4 + g) * 2);
+                    const v4h w2h = *reinterpret_cast<const v4h *>(wbw + NF3_CPL_W2H + j4 * 2);
+                    v4f h1[PX];
+#pragma unroll
+                    for (int k = 0; k < PX; ++k) h1[k] = v4f{b1.x, b1.y, b1.z, b1.w};
+                    NF_PRIO_UP();
+#pragma unroll
+                    for (int wr = 0; wr < 4; ++wr) {
+                        // one window row = two 8-byte pairs of horizontally adjacent pixels (2 ch each)
+                        const v4h p01 = *reinterpret_cast<const v4h *>(t0h + wbase + wr * Wp);
+                        const v4h p23 = *reinterpret_cast<const v4h *>(t0h + wbase + wr * Wp + 2);
+#pragma unroll
+                        for (int dy = 0; dy < 2; ++dy) {
+                            const int di = wr - dy;
+                            if (di < 0 || di > 2) continue;
+#pragma unroll
+                            for (int dx = 0; dx < 2; ++dx) {
+                                const int k = dy * 2 + dx;
+                                h1[k] = __builtin_amdgcn_mfma_f32_4x4x4f16(w1h[di][2 * dx + 0], p01, h1[k], 0, 0, 0);
+                                h1[k] = __builtin_amdgcn_mfma_f32_4x4x4f16(w1h[di][2 * dx + 1], p23, h1[k], 0, 0, 0);
+                            }
+                        }
+                    }
+                    NF_PRIO_DOWN();
+#pragma unroll
+                    for (int k = 0; k < PX; ++k) {
+                        const v4h a1 = {(_Float16)nf_relu(h1[k][0]), (_Float16)nf_relu(h1[k][1]),
+                                        (_Float16)nf_relu(h1[k][2]), (_Float16)nf_relu(h1[k][3])};
+                        const v4f h2 = __builtin_amdgcn_mfma_f32_4x4x4f16(w2h, a1, v4f{b2.x, b2.y, b2.z, b2.w}, 0, 0, 0);
+                        const v4h a2 = {(_Float16)nf_relu(h2[0]), (_Float16)nf_relu(h2[1]),
+                                        (_Float16)nf_relu(h2[2]), (_Float16)nf_relu(h2[3])};
+                        thh[lidx[k]] = __builtin_bit_cast(uint2, a2);
+                    }
+                } else if constexpr (MFMA) {
                     const float *wb = wl + prog.ops[op].off;
                     const float4 b1 = *reinterpret_cast<const float4 *>(wb + NF2_CPL_B1);
                     const float4 b2 = *reinterpret_cast<const float4 *>(wb + NF2_CPL_B2);
@@ -387,7 +444,46 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
                 {
                     float o[PX][4];
                     float sc;
-                    if constexpr (MFMA) {
+                    if constexpr (H16) {
+                        const float *wb = wl + prog.ops[op].off;
+                        const uint32_t *wbw = reinterpret_cast<const uint32_t *>(wb);
+                        sc = 0.0f;
+                        v4h w3h[9];
+#pragma unroll
+                        for (int tap = 0; tap < 9; ++tap)
+                            w3h[tap] = *reinterpret_cast<const v4h *>(wbw + NF3_CPL_W3H + (j4 * 9 + tap) * 2);
+                        v4f acc[PX];
+#pragma unroll
+                        for (int k = 0; k < PX; ++k) {
+                            const float4 e = *reinterpret_cast<const float4 *>(wb + NF3_CPL_E + 4 * bmask[k]);
+                            acc[k] = v4f{e.x, e.y, e.z, e.w};
+                        }
+                        NF_PRIO_UP();
+#pragma unroll
+                        for (int wr = 0; wr < 4; ++wr) {
+                            const uint4 q01 = *reinterpret_cast<const uint4 *>(thh + wbase + wr * Wp);
+                            const uint4 q23 = *reinterpret_cast<const uint4 *>(thh + wbase + wr * Wp + 2);
+                            const v4h hv[4] = {__builtin_bit_cast(v4h, make_uint2(q01.x, q01.y)), __builtin_bit_cast(v4h, make_uint2(q01.z, q01.w)),
+                                               __builtin_bit_cast(v4h, make_uint2(q23.x, q23.y)), __builtin_bit_cast(v4h, make_uint2(q23.z, q23.w))};
+#pragma unroll
+                            for (int dy = 0; dy < 2; ++dy) {
+                                const int di = wr - dy;
+                                if (di < 0 || di > 2) continue;
+#pragma unroll
+                                for (int dj = 0; dj < 3; ++dj)
+#pragma unroll
+                                    for (int dx = 0; dx < 2; ++dx) {
+                                        const int k = dy * 2 + dx;
+                                        acc[k] = __builtin_amdgcn_mfma_f32_4x4x4f16(w3h[di * 3 + dj], hv[dx + dj], acc[k], 0, 0, 0);
+                                    }
+                            }
+                        }
+                        NF_PRIO_DOWN();
+#pragma unroll
+                        for (int k = 0; k < PX; ++k)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) o[k][j] = acc[k][j];
+                    } else if constexpr (MFMA) {
                         const float *wb = wl + prog.ops[op].off;
                         sc = 0.0f;
                         v4f acc[PX];
@@ -495,8 +591,15 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
                         // matrix-core layout: the host pre-scaled the raw columns by 2*log2(e), so
                         //   t = exp2(raw') = exp(2 raw);  ls*log2(e) = scl*tanh(raw) = scl - 2 scl/(t + 1)
                         // and the log-det is accumulated in log2 units (ld2), converted once per patch.
-                        const float scl = wl[prog.ops[op].off + NF2_CPL_S + 1];
+                        const float scl = wl[prog.ops[op].off + NF2_CPL_S + 1];     // (NF3_CPL_S == NF2_CPL_S)
                         const float m2scl = wl[prog.ops[op].off + NF2_CPL_S + 2];
+                        if constexpr (H16) {
+#pragma unroll
+                            for (int k = 0; k < PX; ++k) {
+                                o[k][2] *= 2.8853900817779268f;   // fp16 weights are not pre-scaled by 2*log2(e)
+                                o[k][3] *= 2.8853900817779268f;
+                            }
+                        }
                         if (type == NF_OP_COUPLING_FWD) {
 #pragma unroll
                             for (int k = 0; k < PX; ++k) {
@@ -651,15 +754,15 @@ __global__ __launch_bounds__(256) void nf_synth_kernel(uint64_t seed, int64_t pa
     }
 }
 
-template <int WIDTH, int THREADS, int PX, bool PHILOX, bool MFMA, bool FULL>
-hipError_t launch_flow_f(const NfProgram &prog, const NfLaunch &a, int n_cu, hipStream_t stream)
+template <int WIDTH, int THREADS, int PX, bool PHILOX, bool MFMA, bool FULL, int PREC>
+hipError_t launch_flow_p(const NfProgram &prog, const NfLaunch &a, int n_cu, hipStream_t stream)
 {
     const int tile_px = ((a.H + 2) * (a.W + 2) + 1) & ~1;
-    size_t lds_f = (size_t)tile_px * (2 + WIDTH) + ((3 * (THREADS / 64) + 3) & ~3);
+    size_t lds_f = (size_t)tile_px * (PREC == 1 ? 3 : 2 + WIDTH) + ((3 * (THREADS / 64) + 3) & ~3);
     if (MFMA) lds_f += (size_t)((a.n_params + 3) & ~3);
     const size_t lds = sizeof(float) * lds_f;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    const void *fn = reinterpret_cast<const void *>(&nf_flow_kernel<WIDTH, THREADS, PX, PHILOX, MFMA, FULL>);
+    const void *fn = reinterpret_cast<const void *>(&nf_flow_kernel<WIDTH, THREADS, PX, PHILOX, MFMA, FULL, PREC>);
     // (lds bytes << 8 | resident workgroups per CU) of the last query; racy but idempotent
     static std::atomic<uint64_t> cache{0};
     uint64_t c = cache.load(std::memory_order_relaxed);
@@ -682,9 +785,19 @@ hipError_t launch_flow_f(const NfProgram &prog, const NfLaunch &a, int n_cu, hip
     int64_t groups = (int64_t)n_cu * occ;
     if (a.B < groups) groups = a.B;
     if (groups < 1) groups = 1;
-    hipLaunchKernelGGL((nf_flow_kernel<WIDTH, THREADS, PX, PHILOX, MFMA, FULL>), dim3((unsigned)groups), dim3(THREADS), lds,
+    hipLaunchKernelGGL((nf_flow_kernel<WIDTH, THREADS, PX, PHILOX, MFMA, FULL, PREC>), dim3((unsigned)groups), dim3(THREADS), lds,
                        stream, prog, a);
     return hipGetLastError();
+}
+
+template <int WIDTH, int THREADS, int PX, bool PHILOX, bool MFMA, bool FULL>
+hipError_t launch_flow_f(const NfProgram &prog, const NfLaunch &a, int n_cu, hipStream_t stream)
+{
+    if constexpr (MFMA && FULL && PX == 4) {
+        if (a.flags & NF_K_FP16_CNN) return launch_flow_p<WIDTH, THREADS, PX, PHILOX, MFMA, FULL, 1>(prog, a, n_cu, stream);
+    }
+    if (a.flags & NF_K_FP16_CNN) return hipErrorInvalidValue;
+    return launch_flow_p<WIDTH, THREADS, PX, PHILOX, MFMA, FULL, 0>(prog, a, n_cu, stream);
 }
 
 template <int WIDTH, int THREADS, int PX, bool PHILOX, bool MFMA>

@@ -75,7 +75,8 @@ class FlowHandle:
     """Owns one ``nf_handle`` (a folded, device-resident model)."""
 
     def __init__(self, arch, variables: Dict[str, np.ndarray], x_shape, width: int,
-                 binding: str = "loss_first", device: Optional[int] = None, layers=None, tmpl=None):
+                 binding: str = "loss_first", device: Optional[int] = None, layers=None, tmpl=None,
+                 cnn_dtype: str = "fp32"):
         self.lib = _lib.load()
         if layers is None:
             self.layers, descs, flat = _params.pack(arch, variables, width, binding)
@@ -83,7 +84,10 @@ class FlowHandle:
             self.layers, descs, flat = _params.pack_layers(layers, variables, width, tmpl or {})
         H, W, Cc = (int(v) for v in x_shape)
         self.x_shape = (H, W, Cc)
-        cfg = _lib.nf_config(H, W, Cc, len(self.layers), -1 if device is None else int(device), 0)
+        if cnn_dtype not in ("fp32", "fp16"):
+            raise ValueError("cnn_dtype must be 'fp32' or 'fp16'")
+        flags = _lib.NF_CFG_FP16_CNN if cnn_dtype == "fp16" else 0
+        cfg = _lib.nf_config(H, W, Cc, len(self.layers), -1 if device is None else int(device), flags)
         h = C.c_void_p()
         _lib.check(self.lib.nf_create(C.byref(cfg), descs, flat.ctypes.data_as(C.POINTER(C.c_float)), flat.size,
                                       C.byref(h)))
@@ -122,10 +126,12 @@ class NoiseFlow(object):
           n_levels`` (and optionally ``seed``).
     variables : optional ``{name: ndarray}`` under the reference's checkpoint
           names; default = fresh initialisation with the reference initialisers.
+    cnn_dtype : 'fp32' (default) | 'fp16' — precision of the coupling-CNN convolutions.
     binding : 'loss_first' | 'sample_first' — template→layer binding (quirk Q1).
     """
 
-    def __init__(self, x_shape, is_training=False, hps=None, variables=None, binding="loss_first", device=None):
+    def __init__(self, x_shape, is_training=False, hps=None, variables=None, binding="loss_first", device=None,
+                 cnn_dtype=None):
         if hps is None:
             raise ValueError("hps is required (arch, width, ...)")
         self.x_shape = [int(v) for v in x_shape]
@@ -151,7 +157,11 @@ class NoiseFlow(object):
         self._variables = dict(variables) if variables is not None else _params.init_variables(
             self.arch, self.width, self.x_shape[-1], self._seed)
         self.model = [_params.parse_arch(self.arch)]   # bijector list per level (define_flow_structure)
-        self._flow = FlowHandle(self.arch, self._variables, self.x_shape, self.width, binding, self._dev.device.index)
+        # 'fp16': coupling-CNN convs in half precision on the matrix cores, everything else fp32
+        # (BASELINE configs[4]); also selectable as hps.cnn_dtype.  Default: all fp32.
+        self.cnn_dtype = cnn_dtype or str(getattr(hps, "cnn_dtype", "fp32"))
+        self._flow = FlowHandle(self.arch, self._variables, self.x_shape, self.width, binding, self._dev.device.index,
+                                cnn_dtype=self.cnn_dtype)
 
     # ------------------------------------------------------------------ variables
     @property
@@ -168,7 +178,7 @@ class NoiseFlow(object):
         self._variables = dict(variables)
         old = self._flow
         self._flow = FlowHandle(self.arch, self._variables, self.x_shape, self.width, self.binding,
-                                self._dev.device.index)
+                                self._dev.device.index, cnn_dtype=self.cnn_dtype)
         old.close()
 
     def restore(self, ckpt_prefix: str, binding: Optional[str] = None) -> None:

@@ -174,24 +174,57 @@ def coupling_cnn(z0: np.ndarray, p: Dict[str, np.ndarray], training: bool = Fals
     return o[..., :c2], o[..., c2:]                                              # :494 tf.split
 
 
+def _h(a):
+    """Round to IEEE half (round-to-nearest-even) and come back in the working dtype."""
+    a = np.asarray(a)
+    return a.astype(np.float16).astype(a.dtype)
+
+
+def coupling_cnn_fp16(z0: np.ndarray, p: Dict[str, np.ndarray]):
+    """The coupling CNN as the HIP library's fp16 mode evaluates it (BASELINE configs[4]:
+    "fp16 coupling CNN with fp32 log-det accumulate"): BN-eval and exp(3*logs) are folded
+    into the conv weights FIRST (as csrc/nf_host.hip does), then the folded weights and the
+    three CNN inputs (z0, relu(h1), relu(h2)) are rounded to fp16; biases, the border table
+    and every accumulation stay in fp32 (here: the working dtype).  Same math as
+    :func:`coupling_cnn` when nothing is rounded."""
+    dt = z0.dtype.type
+    s1 = 1.0 / np.sqrt(p["bn1/var"] + dt(BN_EPS))
+    s2 = 1.0 / np.sqrt(p["bn2/var"] + dt(BN_EPS))
+    es = np.exp(p["l_last/logs"].reshape(-1) * dt(LOGSCALE_FACTOR))
+    w = p["l_2/W"].shape[-1]
+    W1 = _h(p["l_1/W"] * s1)
+    b1 = ((p["l_1/b"] - p["bn1/mean"]) * s1).astype(np.float32).astype(z0.dtype)
+    W2 = _h(p["l_2/W"] * s2)
+    b2 = ((p["l_2/b"] - p["bn2/mean"]) * s2).astype(np.float32).astype(z0.dtype)
+    W3 = p["l_last/W"] * es
+    W3h = W3.copy()
+    W3h[:, :, :w, :] = _h(W3[:, :, :w, :])                       # activations x fp16 weights ...
+    h = np.maximum(conv2d_nhwc(_h(z0), W1, True) + b1, dt(0))
+    h = np.maximum(conv2d_nhwc(_h(h), W2, True) + b2, dt(0))
+    hp = add_edge_padding(_h(h))                                 # ... the edge channel stays exact (fp32 table)
+    o = conv2d_nhwc(hp, W3h, False) + (p["l_last/b"] * es).reshape(1, 1, 1, -1)
+    c2 = o.shape[-1] // 2
+    return o[..., :c2], o[..., c2:]
+
+
 # ----------------------------------------------------------------------------
 # bijectors
 # ----------------------------------------------------------------------------
-def affine_coupling_inverse(z, p, training=False):
+def affine_coupling_inverse(z, p, training=False, cnn_fp16=False):
     """AffineCoupling._inverse_and_log_det_jacobian, layers.py:355-375 (NLL direction)."""
     c2 = z.shape[-1] // 2
     z0, z1 = z[..., :c2], z[..., c2:]
-    shift, raw = coupling_cnn(z0, p, training)
+    shift, raw = coupling_cnn_fp16(z0, p) if cnn_fp16 else coupling_cnn(z0, p, training)
     ls = p["rescaling_scale"] * np.tanh(raw)
     x1 = z1 * np.exp(ls) + shift
     return np.concatenate([z0, x1], axis=-1), ls.sum(axis=(1, 2, 3))
 
 
-def affine_coupling_forward(x, p, training=False):
+def affine_coupling_forward(x, p, training=False, cnn_fp16=False):
     """AffineCoupling._forward, layers.py:275-291 (sampling direction)."""
     c2 = x.shape[-1] // 2
     x0, x1 = x[..., :c2], x[..., c2:]
-    shift, raw = coupling_cnn(x0, p, training)
+    shift, raw = coupling_cnn_fp16(x0, p) if cnn_fp16 else coupling_cnn(x0, p, training)
     ls = p["rescaling_scale"] * np.tanh(raw)
     y1 = (x1 - shift) * np.exp(-ls)
     return np.concatenate([x0, y1], axis=-1)
@@ -396,9 +429,10 @@ class NoiseFlowOracle:
     default.  ``x`` = noise, ``y`` = clean image, ``z`` = latent."""
 
     def __init__(self, arch: str, variables: Dict[str, np.ndarray], binding: str = "loss_first",
-                 dtype=np.float64, sidd_cond: str = "mix"):
+                 dtype=np.float64, sidd_cond: str = "mix", cnn_dtype: str = "fp32"):
         self.arch = arch
         self.dtype = dtype
+        self.cnn_fp16 = cnn_dtype == "fp16"   # emulate the library's fp16 coupling-CNN mode
         self.sidd_cond = sidd_cond
         self.layers = bind_variables(arch, variables, binding, dtype)
 
@@ -413,7 +447,7 @@ class NoiseFlowOracle:
             if L["type"] == "conv1x1":
                 z, ld = conv1x1_inverse(z, L["A"], L["log_abs_det"])
             elif L["type"] == "coupling":
-                z, ld = affine_coupling_inverse(z, L["p"], training)
+                z, ld = affine_coupling_inverse(z, L["p"], training, self.cnn_fp16)
             elif L["type"] == "sdn5":
                 z, ld = sdn_ex5_inverse(z, y, L["p"], iso, cam)
             else:
@@ -446,7 +480,7 @@ class NoiseFlowOracle:
             if L["type"] == "conv1x1":
                 x = conv1x1_forward(x, L["A_inv"])
             elif L["type"] == "coupling":
-                x = affine_coupling_forward(x, L["p"], training)
+                x = affine_coupling_forward(x, L["p"], training, self.cnn_fp16)
             elif L["type"] == "sdn5":
                 x = sdn_ex5_forward(x, y, L["p"], iso, cam)
             else:

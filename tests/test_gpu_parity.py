@@ -383,3 +383,40 @@ def test_epoch_harness_matches_oracle_and_sampler_statistics(shipped_variables, 
     # the trained model's samples are about as close (marginally) to the real noise as a camera-NLF draw
     assert out["KLD_NF"] < 0.05 and out["KLD_NLF"] < 0.05 and 0.8 < out["sdz"] < 1.1
     assert -3.2 < out["NLL"] / 4096 < -2.5
+
+
+@pytest.mark.parametrize("hw,B", [((32, 32), 12), ((64, 64), 5)])
+def test_fp16_coupling_cnn_mode(shipped_variables, oracle_full, hw, B):
+    """BASELINE configs[4]: fp16 coupling CNN (fp32 accumulate, fp32 log-det) on the matrix
+    cores.  Checked against the oracle's emulation of the same rounding points (folded
+    weights and the three CNN inputs rounded to half); tolerance 1e-4 relative on the NLL,
+    2e-3 of the tensor scale elementwise (a near-tie at a half-rounding point may flip one
+    activation by one fp16 ulp).  Also: the mode stays within 1e-4 of the all-fp32 model."""
+    from noise_flow_amd import NoiseFlow, default_hps
+    H, W = hw
+    x, y = make_inputs(B, H, W, seed=16)
+    m = NoiseFlow([H, W, 4], False, default_hps(), variables=shipped_variables, cnn_dtype="fp16")
+    o16 = _oracle(FULL_ARCH, shipped_variables)
+    o16.cnn_fp16 = True
+    nll, sd = m._loss(x, y, [0], [0], [100], [2])
+    ref, rsd, rz = o16.nll(x, y, 100, 2)
+    np.testing.assert_allclose(nll, ref, rtol=1e-4)
+    assert abs(sd - rsd) <= 1e-4 * rsd
+    z, _ = m.inverse(x, None, y, [0], [0], [100], [2])
+    _close_elem(z, rz, rtol=2e-3)
+    # round trip: the two directions see pass-through halves that differ by fp32 round-off of the
+    # 1x1 mixes, which can flip a half-rounding of a CNN input -> 1e-3-of-scale, not 1e-5
+    x2 = m.forward(z, None, y, [0], [0], [100], [2])
+    assert np.abs(x2 - x).max() <= 1e-3 * np.abs(x).max()
+    eps = np.random.RandomState(3).randn(B, H, W, 4).astype(np.float32)
+    xs = m.sample(y, 0.6, y, [0], [0], [100], [2], eps=eps)
+    _close_elem(xs, o16.sample(eps, 0.6, y, 100, 2), rtol=2e-3)
+    ref32 = oracle_full.nll(x, y, 100, 2)[0]
+    np.testing.assert_allclose(nll, ref32, rtol=1e-4)
+
+
+def test_fp16_mode_rejects_unsupported_shapes(shipped_variables):
+    from noise_flow_amd import NoiseFlow, default_hps
+    from noise_flow_amd._lib import NoiseFlowLibError
+    with pytest.raises(NoiseFlowLibError):
+        NoiseFlow([16, 16, 4], False, default_hps(), variables=shipped_variables, cnn_dtype="fp16")
