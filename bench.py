@@ -20,6 +20,7 @@ Rank 0 prints ONE JSON line.  Besides the contract keys it carries
                 timed on this box's host cores on a bounded sample (N = 1 only)
   sampling      the sampling direction at BASELINE configs[2] (batch 4096)
   nll_check     GPU mean NLL vs the fp64 CPU oracle on a 64-patch subset
+  fp16_cnn_64x64  BASELINE configs[4] shape (64x64x4, fp16 coupling CNN / fp32 log-det)
 """
 from __future__ import annotations
 
@@ -169,6 +170,43 @@ def main():
                     "ms_per_step": 1e3 * ts / ks, "kernel_ms": e0.elapsed_time(e1) / ks, "temp": 1.0,
                     "eps": "in-kernel Philox4x32-10", "workload": "configs[2]: inverse sampling, clean patch + fixed cam/ISO"}
 
+    # ---- BASELINE configs[4] shape: 64x64x4 patches, fp16 coupling CNN / fp32 log-det (rank 0) ----
+    fp16_cnn = None
+    if rank == 0:
+        try:
+            m16 = NoiseFlow([64, 64, 4], False, default_hps(), variables=variables, device=local_rank, cnn_dtype="fp16")
+            B16 = 1024
+            x16, y16 = synth_patches(args.seed, 1 << 41, B16, 64, 64, device=local_rank)
+            s16 = torch.zeros(3, dtype=torch.float64, device=dev)
+            k16 = max(10, min(K, 50))
+
+            def step16():
+                rc = lib.nf_nll(m16._flow.ptr, x16.data_ptr(), y16.data_ptr(), B16, C.byref(cond), None, None, None,
+                                None, s16.data_ptr(), _lib.NF_ACCUMULATE, sptr)
+                if rc != 0:
+                    _lib.check(rc)
+            for _ in range(5):
+                step16()
+            torch.cuda.synchronize(dev)
+            f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            f0.record(stream)
+            for _ in range(k16):
+                step16()
+            f1.record(stream)
+            torch.cuda.synchronize(dev)
+            ms16 = f0.elapsed_time(f1) / k16
+            bytes16 = 2 * 64 * 64 * 4 * 4 * B16
+            fp16_cnn = {"workload": "configs[4] shape: forward NLL, 64x64x4 patches, fp16 coupling CNN "
+                                    "(v_mfma_f32_4x4x4_16b_f16, fp32 accumulate + fp32 log-det), fp32 I/O, 1 GPU",
+                        "batch": B16, "steps": k16, "kernel_ms": ms16, "value": B16 / (ms16 * 1e-3), "unit": "patches/s",
+                        "pixels_per_s": B16 * 4096 / (ms16 * 1e-3),
+                        "hbm": {"achieved": bytes16 / (ms16 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": bytes16 / (ms16 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "algorithmic_bytes_per_launch": bytes16}}
+            del m16, x16, y16
+        except Exception as e:   # the headline metric must not depend on the optional mode
+            fp16_cnn = {"error": str(e)}
+
     # ---- parity + CPU baseline: rank 0, N = 1 only (oracle/ is the checker, never the product) ----
     if rank == 0 and world == 1:
         from oracle.nf_oracle import NoiseFlowOracle
@@ -227,7 +265,7 @@ def main():
                          "valu_fp32": {"achieved": tfl, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                                        "frac": tfl / VALU_PEAK_TFLOPS,
                                        "note": "the fused kernel is fp32-VALU-bound (~156 flop/B), see DESIGN.md"}},
-            "cpu_baseline": cpu_baseline, "sampling": sampling, "nll_check": nll_check,
+            "cpu_baseline": cpu_baseline, "sampling": sampling, "nll_check": nll_check, "fp16_cnn_64x64": fp16_cnn,
         }
         print(json.dumps(out), flush=True)
     if world > 1:
