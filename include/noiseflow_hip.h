@@ -50,6 +50,13 @@ extern "C" {
 #define NF_LAYER_COUPLING  2   /* layers.py:251-375 AffineCoupling + real_nvp_conv_template */
 #define NF_LAYER_SDN5      3   /* AffineCouplingSdnEx5.py:22-132 + cond_utils.py:205-239    */
 #define NF_LAYER_GAIN4     4   /* AffineCouplingGainEx4.py:23-127 + cond_utils.py:432-440   */
+/* secondary variants reachable from job_noise_flow.sh (arch "sdn4|gain4") and the
+ * plain sdn / gain layers: the same elementwise kernels with other host scalars */
+#define NF_LAYER_SDN4      5   /* AffineCouplingSdnEx4.py + cond_utils.py:178-202 (no camera parameters) */
+#define NF_LAYER_SDN       6   /* AffineCouplingSdn.py    + cond_utils.py:41-52   scale = sqrt(sig(b1) y + sig(b2)) */
+#define NF_LAYER_GAIN      7   /* AffineCouplingGain.py   + cond_utils.py:319-330 scale = sig(g1) iso + sig(g2);
+                                  log|det| = -log(scale) ONCE per patch, exactly as the reference writes it
+                                  (AffineCouplingGain.py:113-127 omits the H*W*C factor) */
 
 /* Raw (checkpoint-semantics, un-folded) parameter layout of one layer inside the
  * flat `params` array, starting at `param_offset` floats.  C = 4 channels.
@@ -63,6 +70,9 @@ extern "C" {
  *                         = 27w + w*w + 36w + 36 + 4 + 4 + 1 ... see nf_layer_param_count()
  *  SDN5      (23 floats)  beta1, beta2, gain_params[5], cam_params[3][5], c_i
  *  GAIN4     (1 float)    gain_val
+ *  SDN4      (7 floats)   beta1, beta2, gain_params[5]
+ *  SDN       (2 floats)   b1, b2
+ *  GAIN      (2 floats)   g1, g2
  */
 typedef struct nf_layer_desc {
     int32_t type;          /* NF_LAYER_*                                  */

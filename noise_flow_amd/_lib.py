@@ -15,6 +15,9 @@ NF_LAYER_CONV1X1 = 1
 NF_LAYER_COUPLING = 2
 NF_LAYER_SDN5 = 3
 NF_LAYER_GAIN4 = 4
+NF_LAYER_SDN4 = 5
+NF_LAYER_SDN = 6
+NF_LAYER_GAIN = 7
 
 NF_CFG_FP16_CNN = 1
 
@@ -28,7 +31,7 @@ NF_ECOND = -3
 NF_ENOMEM = -4
 
 # device op codes (csrc/nf_device.h) — exposed for the folding tests
-NF_OP_MIX, NF_OP_COUPLING_FWD, NF_OP_COUPLING_REV, NF_OP_SDN_DIV, NF_OP_SDN_MUL, NF_OP_SCALE = 1, 2, 3, 4, 5, 6
+NF_OP_MIX, NF_OP_COUPLING_FWD, NF_OP_COUPLING_REV, NF_OP_SDN_DIV, NF_OP_SDN_MUL, NF_OP_SCALE, NF_OP_SCALE_COND = 1, 2, 3, 4, 5, 6, 7
 
 
 class nf_layer_desc(C.Structure):

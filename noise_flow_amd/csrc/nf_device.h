@@ -17,11 +17,13 @@ enum : int32_t {
     NF_OP_SDN_DIV      = 4,  // NLL dir:  z <- z / sqrt(k1*y + b2) ; ld -= sum log scale
     NF_OP_SDN_MUL      = 5,  // sampling: z <- z * sqrt(k1*y + b2)
     NF_OP_SCALE        = 6,  // z <- z * s               (1 float; un-folded gain layer)
+    NF_OP_SCALE_COND   = 7,  // z <- z * cond_a[slot]    (per-call scalar: plain `gain` layer)
 };
 
 struct NfOp {
     int32_t type;
-    int32_t off;    // offset in floats into the folded parameter block (multiple of 4)
+    int32_t off;    // offset in floats into the folded parameter block (multiple of 4);
+                    // for SDN_* / SCALE_COND ops: the conditioning slot (0..3)
 };
 
 struct NfProgram {
@@ -119,7 +121,8 @@ struct NfLaunch {
     uint64_t seed;
     double ld_const;       // constant part of the log-det sum
     float in_scale;        // input multiplier (sampling temperature)
-    float sdn_k1, sdn_b2;  // beta1/gain, beta2
+    float cond_a[4];       // per-call scalars of the conditional ops, indexed by NfOp::off (slot):
+    float cond_b[4];       //   SDN_*: scale = sqrt(cond_a*y + cond_b);  SCALE_COND: z *= cond_a
     int32_t H, W;
     uint32_t flags;
     int32_t n_params;      // floats in the parameter block (matrix-core kernel stages it in LDS)

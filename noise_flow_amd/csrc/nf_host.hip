@@ -59,6 +59,9 @@ int64_t layer_param_count(int32_t type, int32_t w)
                + 1;                                // rescaling_scale
     case NF_LAYER_SDN5: return 1 + 1 + 5 + 15 + 1;
     case NF_LAYER_GAIN4: return 1;
+    case NF_LAYER_SDN4: return 7;
+    case NF_LAYER_SDN: return 2;
+    case NF_LAYER_GAIN: return 2;
     default: return -1;
     }
 }
@@ -275,8 +278,46 @@ int sdn5_scalars(const float *sp, const nf_cond *cond, double out[2])
     return NF_OK;
 }
 
+struct CondLayer {
+    int kind;                  // NF_LAYER_SDN5 / SDN4 / SDN / GAIN
+    std::vector<float> p;      // its raw parameters
+};
+
+double sigmoid(double x) { return 1.0 / (1.0 + exp(-x)); }
+
+// Per-call scalars of one conditional layer -> (a, b): SDN kinds: scale^2 = a*y + b; GAIN: scale = a.
+int cond_scalars(const CondLayer &L, const nf_cond *cond, double out[2])
+{
+    switch (L.kind) {
+    case NF_LAYER_SDN5: return sdn5_scalars(L.p.data(), cond, out);
+    case NF_LAYER_SDN4: {   // cond_utils.py:178-202 (c = 1)
+        if (!cond) return fail(NF_EINVAL, "model has an SDN4 layer but cond is NULL");
+        static const float iso_vals[5] = {100.f, 400.f, 800.f, 1600.f, 3200.f};
+        double g = 0.0;
+        for (int i = 0; i < 5; ++i)
+            if (iso_vals[i] == cond->iso) g = L.p[2 + i];
+        const double gain = exp(g) * (double)cond->iso;
+        out[0] = exp((double)L.p[0]) / gain;
+        out[1] = exp((double)L.p[1]);
+        return NF_OK;
+    }
+    case NF_LAYER_SDN:      // cond_utils.py:41-52
+        out[0] = sigmoid(L.p[0]);
+        out[1] = sigmoid(L.p[1]);
+        return NF_OK;
+    case NF_LAYER_GAIN:     // cond_utils.py:319-330 with gain = iso (AffineCouplingGain.py:52,113)
+        if (!cond) return fail(NF_EINVAL, "model has a GAIN layer but cond is NULL");
+        out[0] = sigmoid(L.p[0]) * (double)cond->iso + sigmoid(L.p[1]);
+        out[1] = 0.0;
+        if (!(out[0] > 0.0)) return fail(NF_EINVAL, "gain scale must be > 0");
+        return NF_OK;
+    }
+    return fail(NF_EINVAL, "bad conditional layer");
+}
+
 // ---- program construction -----------------------------------------------------
 struct Built {
+    std::vector<CondLayer> cond;   // conditioning slots, in the order the ops reference them
     NfProgram prog;
     std::vector<float> block;
     NfProgram prog2;             // matrix-core (MFMA) layout, width 4 only
@@ -284,8 +325,7 @@ struct Built {
     NfProgram prog3;             // fp16-CNN layout (NF_CFG_FP16_CNN), width 4 only
     std::vector<float> block3;
     double ld_const = 0.0;
-    bool has_sdn = false;
-    std::vector<float> sdn_params;
+    bool has_sdn = false;      // some op reads the clean image y
 };
 
 int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float *params, size_t n_params,
@@ -306,11 +346,13 @@ int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float
         Mat4 A, Ainv;
         double scale = 1.0;     // gain value for SCALE items
         int w = 0;
+        int slot = 0;           // conditioning slot of SDN / SCALE_COND items
     };
     std::vector<Item> items;
     int width = 0;
     out.ld_const = 0.0;
     out.has_sdn = false;
+    out.cond.clear();
     for (int li = 0; li < cfg->n_layers; ++li) {
         const nf_layer_desc &L = layers[li];
         const int64_t cnt = layer_param_count(L.type, L.width);
@@ -340,10 +382,20 @@ int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float
             break;
         }
         case NF_LAYER_SDN5:
-            it.type = NF_OP_SDN_DIV;
-            out.has_sdn = true;
-            out.sdn_params.assign(p, p + 23);
+        case NF_LAYER_SDN4:
+        case NF_LAYER_SDN:
+        case NF_LAYER_GAIN: {
+            if (out.cond.size() >= 4) return fail(NF_EINVAL, "at most 4 conditional (sdn/gain) layers per model");
+            it.type = L.type == NF_LAYER_GAIN ? NF_OP_SCALE_COND : NF_OP_SDN_DIV;
+            it.slot = (int)out.cond.size();
+            CondLayer c;
+            c.kind = L.type;
+            c.p.assign(p, p + cnt);
+            if (L.type == NF_LAYER_SDN5) c.p.resize(23);
+            out.cond.push_back(c);
+            if (L.type != NF_LAYER_GAIN) out.has_sdn = true;
             break;
+        }
         case NF_LAYER_GAIN4:
             if (!(p[0] > 0.0f)) return fail(NF_EINVAL, "layer %d: gain_val must be > 0", li);
             it.type = NF_OP_SCALE;
@@ -396,6 +448,11 @@ int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float
             break;
         case NF_OP_SDN_DIV:
             op.type = direction == 0 ? NF_OP_SDN_DIV : NF_OP_SDN_MUL;
+            op.off = it->slot;
+            break;
+        case NF_OP_SCALE_COND:
+            op.type = NF_OP_SCALE_COND;
+            op.off = it->slot;
             break;
         case NF_OP_SCALE: {
             op.type = NF_OP_SCALE;
@@ -429,6 +486,8 @@ int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float
                 relayout_coupling_v2(v1, out.block2.data() + dst.off);
             } else if (src.type == NF_OP_SCALE) {
                 out.block2.insert(out.block2.end(), v1, v1 + 4);
+            } else {
+                dst.off = src.off;   // conditioning slot
             }
         }
         if (out.block2.empty()) out.block2.assign(4, 0.0f);
@@ -452,6 +511,8 @@ int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float
                 relayout_coupling_v3(v1, out.block3.data() + dst.off);
             } else if (src.type == NF_OP_SCALE) {
                 out.block3.insert(out.block3.end(), v1, v1 + 4);
+            } else {
+                dst.off = src.off;   // conditioning slot
             }
         }
         if (out.block3.empty()) out.block3.assign(4, 0.0f);
@@ -629,11 +690,20 @@ int nf_nll(nf_handle *h, const float *x, const float *y, int64_t B, const nf_con
     if (!h) return fail(NF_EINVAL, "handle is NULL");
     if (B < 0) return fail(NF_EINVAL, "B must be >= 0");
     if (B > 0 && !x) return fail(NF_EINVAL, "x is NULL");
-    if (h->fwd.has_sdn && B > 0 && !y) return fail(NF_EINVAL, "model has an SDN5 layer but y is NULL");
-    double sc[2] = {0.0, 1.0};
-    if (h->fwd.has_sdn) {
-        int rc = sdn5_scalars(h->fwd.sdn_params.data(), cond, sc);
+    if (h->fwd.has_sdn && B > 0 && !y) return fail(NF_EINVAL, "model has a signal-dependent layer but y is NULL");
+    float ca[4] = {0.f, 0.f, 0.f, 0.f}, cb[4] = {1.f, 1.f, 1.f, 1.f};
+    double ld_call = 0.0;   // per-call part of the constant log-det (plain `gain` layers)
+    for (size_t i = 0; i < h->fwd.cond.size(); ++i) {
+        double sc[2];
+        int rc = cond_scalars(h->fwd.cond[i], cond, sc);
         if (rc != NF_OK) return rc;
+        if (h->fwd.cond[i].kind == NF_LAYER_GAIN) {
+            ca[i] = (float)(1.0 / sc[0]);            // NLL direction divides
+            ld_call -= log(sc[0]);                   // AffineCouplingGain.py:113-127 (no H*W*C factor)
+        } else {
+            ca[i] = (float)sc[0];
+            cb[i] = (float)sc[1];
+        }
     }
     DeviceGuard guard;
     int rc = guard.enter(h->device);
@@ -655,10 +725,10 @@ int nf_nll(nf_handle *h, const float *x, const float *y, int64_t B, const nf_con
     a.ld_out = logdet_out;
     a.sums = sums_out;
     a.B = B;
-    a.ld_const = h->fwd.ld_const;
+    a.ld_const = h->fwd.ld_const + ld_call;
     a.in_scale = 1.0f;
-    a.sdn_k1 = (float)sc[0];
-    a.sdn_b2 = (float)sc[1];
+    memcpy(a.cond_a, ca, sizeof(ca));
+    memcpy(a.cond_b, cb, sizeof(cb));
     a.H = h->cfg.height;
     a.W = h->cfg.width;
     a.flags = (flags & NF_NO_PRIOR) ? 0u : NF_K_PRIOR;
@@ -683,11 +753,14 @@ int nf_sample(nf_handle *h, const float *y, const float *eps, uint64_t seed, int
     if (B < 0) return fail(NF_EINVAL, "B must be >= 0");
     if (B == 0) return NF_OK;
     if (!x_out) return fail(NF_EINVAL, "x_out is NULL");
-    if (h->rev.has_sdn && !y) return fail(NF_EINVAL, "model has an SDN5 layer but y is NULL");
-    double sc[2] = {0.0, 1.0};
-    if (h->rev.has_sdn) {
-        int rc = sdn5_scalars(h->rev.sdn_params.data(), cond, sc);
+    if (h->rev.has_sdn && !y) return fail(NF_EINVAL, "model has a signal-dependent layer but y is NULL");
+    float ca[4] = {0.f, 0.f, 0.f, 0.f}, cb[4] = {1.f, 1.f, 1.f, 1.f};
+    for (size_t i = 0; i < h->rev.cond.size(); ++i) {
+        double sc[2];
+        int rc = cond_scalars(h->rev.cond[i], cond, sc);
         if (rc != NF_OK) return rc;
+        ca[i] = (float)sc[0];                        // sampling direction multiplies
+        cb[i] = (float)sc[1];
     }
     DeviceGuard guard;
     int rc = guard.enter(h->device);
@@ -702,8 +775,8 @@ int nf_sample(nf_handle *h, const float *y, const float *eps, uint64_t seed, int
     a.patch_base = patch_index_base;
     a.seed = seed;
     a.in_scale = temp;
-    a.sdn_k1 = (float)sc[0];
-    a.sdn_b2 = (float)sc[1];
+    memcpy(a.cond_a, ca, sizeof(ca));
+    memcpy(a.cond_b, cb, sizeof(cb));
     a.H = h->cfg.height;
     a.W = h->cfg.width;
     a.flags = eps ? 0u : NF_K_PHILOX_IN;

@@ -637,6 +637,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
             } else if (type == NF_OP_SDN_DIV || type == NF_OP_SDN_MUL) {
                 // AffineCouplingSdnEx5: scale = sqrt(beta1*y/gain + beta2)  (cond_utils.py:238)
                 const float4 *y4 = reinterpret_cast<const float4 *>(a.y + patch_off);
+                const float ck1 = a.cond_a[prog.ops[op].off & 3], cb2 = a.cond_b[prog.ops[op].off & 3];
 #pragma unroll
                 for (int k = 0; k < PX; ++k) {
                     float4 yv = make_float4(1.f, 1.f, 1.f, 1.f);
@@ -646,7 +647,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
                     for (int c = 0; c < 4; ++c) {
                         // scale = sqrt(v), v = beta1*y/gain + beta2 > 0: z/scale = z*rsq(v), log scale = ln2/2*log2(v)
                         // (v_rsq_f32 / v_log_f32: 1 ulp; once per element per patch)
-                        const float v = fmaf(yy[c], a.sdn_k1, a.sdn_b2);
+                        const float v = fmaf(yy[c], ck1, cb2);
                         if (type == NF_OP_SDN_DIV) {
                             z[k][c] = z[k][c] * __builtin_amdgcn_rsqf(v);
                             if (act[k]) ld = fmaf(-0.34657359027997264f, __builtin_amdgcn_logf(v), ld);
@@ -655,8 +656,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
                         }
                     }
                 }
-            } else if (type == NF_OP_SCALE) {
-                const float s = P[0];
+            } else if (type == NF_OP_SCALE || type == NF_OP_SCALE_COND) {
+                const float s = type == NF_OP_SCALE ? P[0] : a.cond_a[prog.ops[op].off & 3];
 #pragma unroll
                 for (int k = 0; k < PX; ++k)
 #pragma unroll

@@ -130,7 +130,20 @@ class AffineCouplingGainEx4(_Conditional):
     """AffineCouplingGainEx4.py:23-127 + cond_utils.py:432-440."""
 
 
-_CLASS = {"conv1x1": Conv2d1x1, "coupling": AffineCoupling, "sdn5": AffineCouplingSdnEx5, "gain4": AffineCouplingGainEx4}
+class AffineCouplingSdnEx4(_Conditional):
+    """AffineCouplingSdnEx4.py + cond_utils.py:178-202 (sdn5 without camera parameters)."""
+
+
+class AffineCouplingSdn(_Conditional):
+    """AffineCouplingSdn.py + cond_utils.py:41-52: scale = sqrt(sigmoid(b1)*y + sigmoid(b2))."""
+
+
+class AffineCouplingGain(_Conditional):
+    """AffineCouplingGain.py + cond_utils.py:319-330: scale = sigmoid(g1)*iso + sigmoid(g2);
+    log|det| = -/+ log(scale) ONCE per patch, as the reference writes it (no H*W*C factor)."""
+
+
+_CLASS = {"sdn4": AffineCouplingSdnEx4, "sdn": AffineCouplingSdn, "gain": AffineCouplingGain, "conv1x1": Conv2d1x1, "coupling": AffineCoupling, "sdn5": AffineCouplingSdnEx5, "gain4": AffineCouplingGainEx4}
 
 
 def bijectors_from_arch(arch: str, variables: Dict[str, np.ndarray], x_shape, width: int,

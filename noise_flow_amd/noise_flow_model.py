@@ -92,7 +92,7 @@ class FlowHandle:
         _lib.check(self.lib.nf_create(C.byref(cfg), descs, flat.ctypes.data_as(C.POINTER(C.c_float)), flat.size,
                                       C.byref(h)))
         self._h = h
-        self.has_sdn = any(L.kind == "sdn5" for L in self.layers)
+        self.has_sdn = any(L.kind in ("sdn5", "sdn4", "sdn") for L in self.layers)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -231,7 +231,7 @@ class NoiseFlow(object):
         ``_inverse_and_log_det_jacobian``; returns ``(z, objective + Σ log|det J|)``."""
         self._check_mode()
         if yy is None and self._flow.has_sdn:
-            raise ValueError("this architecture has an sdn5 layer: the clean image yy is required")
+            raise ValueError("this architecture has a signal-dependent layer: the clean image yy is required")
         nll, sd, ld, z, _, was_np = self._run_nll(x, yy, self._cond(nlf0, nlf1, iso, cam), True, _lib.NF_NO_PRIOR)
         if objective is None:
             obj = ld
@@ -309,7 +309,7 @@ class NoiseFlow(object):
         dev = self._dev
         tail = tuple(self.x_shape)
         if yy is None and self._flow.has_sdn:
-            raise ValueError("this architecture has an sdn5 layer: the clean image yy is required")
+            raise ValueError("this architecture has a signal-dependent layer: the clean image yy is required")
         zt, was_np = dev.to_dev(z_or_y, tail)
         yt = dev.to_dev(yy, tail)[0] if yy is not None else None
         B = int(zt.shape[0])

@@ -15,13 +15,13 @@ import numpy as np
 
 from . import _lib
 
-SUPPORTED_LAYERS = ("unc", "sdn5", "gain4")
+SUPPORTED_LAYERS = ("unc", "sdn5", "gain4", "sdn4", "sdn", "gain")
 C_I = 1.0   # train_noise_flow.py:207 / NoiseFlowWrapper.py:125
 
 
 @dataclass
 class LayerSpec:
-    kind: str        # 'conv1x1' | 'coupling' | 'sdn5' | 'gain4'
+    kind: str        # 'conv1x1' | 'coupling' | 'sdn5' | 'gain4' | 'sdn4' | 'sdn' | 'gain'
     name: str        # display name as in hps.txt:1-18 (get_layer_names)
     arch_index: int  # position i in arch.split('|')
     nf_type: int     # NF_LAYER_*
@@ -42,6 +42,12 @@ def parse_arch(arch: str) -> List[LayerSpec]:
             layers.append(LayerSpec("sdn5", "sdn_%d" % i, i, _lib.NF_LAYER_SDN5))
         elif lyr == "gain4":
             layers.append(LayerSpec("gain4", "gain_%d" % i, i, _lib.NF_LAYER_GAIN4))
+        elif lyr == "sdn4":      # noise_flow_model.py:148-158 (job_noise_flow.sh: "sdn4|gain4")
+            layers.append(LayerSpec("sdn4", "sdn_%d" % i, i, _lib.NF_LAYER_SDN4))
+        elif lyr == "sdn":       # noise_flow_model.py:106-114
+            layers.append(LayerSpec("sdn", "sdn_%d" % i, i, _lib.NF_LAYER_SDN))
+        elif lyr == "gain":      # noise_flow_model.py:183-192
+            layers.append(LayerSpec("gain", "gain_%d" % i, i, _lib.NF_LAYER_GAIN))
         else:
             raise NotImplementedError(
                 "arch layer %r is not on the MI355X hot path (supported: %s)" % (lyr, "|".join(SUPPORTED_LAYERS)))
@@ -122,6 +128,13 @@ def pack_layers(layers: List[LayerSpec], variables: Dict[str, np.ndarray], width
                 _f32(need("model/sdn_gain/beta1")), _f32(need("model/sdn_gain/beta2")),
                 _f32(need("model/sdn_gain/gain_params")), _f32(need("model/sdn_gain/cam_params")),
                 np.asarray([C_I], np.float32)])
+        elif L.kind == "sdn4":   # variables of sdn_model_params_ex4 (cond_utils.py:178-202), scope 'sdn_gain'
+            blk = np.concatenate([_f32(need("model/sdn_gain/beta1")), _f32(need("model/sdn_gain/beta2")),
+                                  _f32(need("model/sdn_gain/gain_params"))])
+        elif L.kind == "sdn":    # sdn_model_params (cond_utils.py:41-52): created under the 'model' scope
+            blk = np.concatenate([_f32(need("model/b1")), _f32(need("model/b2"))])
+        elif L.kind == "gain":   # gain_model_params (cond_utils.py:319-330)
+            blk = np.concatenate([_f32(need("model/g1")), _f32(need("model/g2"))])
         else:  # gain4
             blk = _f32(need("model/sdn_gain/gain_val"))
         expect = _lib.load().nf_layer_param_count(L.nf_type, L.width)
@@ -177,7 +190,7 @@ def init_variables(arch: str, width: int = 4, channels: int = 4, seed: int = 0) 
     c2 = channels // 2
     k = 0
     for L in layers:
-        if L.kind in ("coupling", "sdn5", "gain4"):
+        if L.kind != "conv1x1":
             v["level0/bijector%d/rescaling_scale0" % L.arch_index] = np.float32(1e-4)
         if L.kind == "conv1x1":
             q = sla.qr(rng.randn(channels, channels))[0].astype(np.float32)
@@ -203,7 +216,13 @@ def init_variables(arch: str, width: int = 4, channels: int = 4, seed: int = 0) 
             for b in ("bn_nvp_conv_1", "bn_nvp_conv_2"):
                 v[t + b + "/mean"] = np.zeros((width,), np.float32)
                 v[t + b + "/var"] = np.ones((width,), np.float32)
-    if any(L.kind in ("sdn5", "gain4") for L in layers):
+    if any(L.kind == "sdn" for L in layers):
+        v["model/b1"] = np.full((1,), -3.0, np.float32)     # cond_utils.py:43-46
+        v["model/b2"] = np.full((1,), 3.0, np.float32)
+    if any(L.kind == "gain" for L in layers):
+        v["model/g1"] = np.full((1,), -3.0, np.float32)     # cond_utils.py:321-324
+        v["model/g2"] = np.full((1,), 3.0, np.float32)
+    if any(L.kind in ("sdn5", "gain4", "sdn4") for L in layers):
         v["model/sdn_gain/beta1"] = np.full((1,), -5.0 / C_I, np.float32)
         v["model/sdn_gain/beta2"] = np.zeros((1,), np.float32)
         v["model/sdn_gain/gain_params"] = np.full((5,), -5.0 / C_I, np.float32)

@@ -264,6 +264,32 @@ def sdn_ex5_scale(y, p, iso, cam):
     return np.sqrt(b1 * y / gain + b2)                                    # cond_utils.py:238
 
 
+def _sigmoid(v):
+    return 1.0 / (1.0 + np.exp(-v))
+
+
+def sdn_ex4_scale(y, p, iso):
+    """sdn_model_params_ex4, cond_utils.py:178-202 (c = 1, no camera parameters)."""
+    dt = y.dtype.type
+    k = np.where(np.asarray(ISO_VALS) == float(iso))[0]
+    g = np.asarray(p["gain_params"], dt)[k[0]] if k.size else dt(0)
+    gain = np.exp(g) * dt(iso)
+    beta1 = np.exp(np.asarray(p["beta1"], dt).reshape(-1)[0])
+    beta2 = np.exp(np.asarray(p["beta2"], dt).reshape(-1)[0])
+    return np.sqrt(beta1 * y / gain + beta2)
+
+
+def sdn_plain_scale(y, p):
+    """sdn_model_params, cond_utils.py:41-52."""
+    dt = y.dtype.type
+    return np.sqrt(dt(_sigmoid(float(np.asarray(p["b1"]).reshape(-1)[0]))) * y + dt(_sigmoid(float(np.asarray(p["b2"]).reshape(-1)[0]))))
+
+
+def gain_plain_scale(p, iso, dtype):
+    """gain_model_params(iso), cond_utils.py:319-330 via AffineCouplingGain.py:52."""
+    return dtype(_sigmoid(float(np.asarray(p["g1"]).reshape(-1)[0])) * float(iso) + _sigmoid(float(np.asarray(p["g2"]).reshape(-1)[0])))
+
+
 def sdn_ex5_inverse(x, y, p, iso, cam):
     """AffineCouplingSdnEx5._inverse_and_log_det_jacobian, AffineCouplingSdnEx5.py:118-132."""
     scale = sdn_ex5_scale(y, p, iso, cam)
@@ -301,8 +327,8 @@ def parse_arch(arch: str) -> List[Tuple[str, int]]:
     """noise_flow_model.py:71-235: 'a|b|c' → [(layer_type, i)], i = position in arch."""
     out = []
     for i, lyr in enumerate(arch.split("|")):
-        if lyr not in ("unc", "sdn5", "gain4"):
-            raise ValueError("oracle supports unc|sdn5|gain4 only, got %r" % lyr)
+        if lyr not in ("unc", "sdn5", "gain4", "sdn4", "sdn", "gain"):
+            raise ValueError("oracle supports unc|sdn5|gain4|sdn4|sdn|gain only, got %r" % lyr)
         out.append((lyr, i))
     return out
 
@@ -313,7 +339,7 @@ def layer_names(arch: str) -> List[str]:
     for lyr, i in parse_arch(arch):
         if lyr == "unc":
             names += ["Conv2d_1x1_%d" % i, "unc_%d" % i]
-        elif lyr == "sdn5":
+        elif lyr in ("sdn5", "sdn4", "sdn"):
             names.append("sdn_%d" % i)
         else:
             names.append("gain_%d" % i)
@@ -362,6 +388,13 @@ def bind_variables(arch: str, variables: Dict[str, np.ndarray], binding: str = "
         elif lyr == "sdn5":
             p = {k: f(variables["model/sdn_gain/" + k]) for k in ("beta1", "beta2", "gain_params", "cam_params")}
             layers.append({"type": "sdn5", "name": "sdn_%d" % i, "p": p})
+        elif lyr == "sdn4":
+            p = {k: f(variables["model/sdn_gain/" + k]) for k in ("beta1", "beta2", "gain_params")}
+            layers.append({"type": "sdn4", "name": "sdn_%d" % i, "p": p})
+        elif lyr == "sdn":
+            layers.append({"type": "sdn", "name": "sdn_%d" % i, "p": {"b1": f(variables["model/b1"]), "b2": f(variables["model/b2"])}})
+        elif lyr == "gain":
+            layers.append({"type": "gain", "name": "gain_%d" % i, "p": {"g1": f(variables["model/g1"]), "g2": f(variables["model/g2"])}})
         else:
             layers.append({"type": "gain4", "name": "gain_%d" % i, "gain_val": f(variables["model/sdn_gain/gain_val"])})
     return layers
@@ -401,7 +434,13 @@ def fresh_variables(arch: str, width: int = 4, channels: int = 4, seed: int = 0)
             for b in ("bn_nvp_conv_1", "bn_nvp_conv_2"):
                 v[t + b + "/mean"] = np.zeros((width,), np.float32)
                 v[t + b + "/var"] = np.ones((width,), np.float32)
-    if any(l in ("sdn5", "gain4") for l, _ in parse_arch(arch)):
+    if any(l == "sdn" for l, _ in parse_arch(arch)):
+        v["model/b1"] = np.full((1,), -3.0, np.float32)
+        v["model/b2"] = np.full((1,), 3.0, np.float32)
+    if any(l == "gain" for l, _ in parse_arch(arch)):
+        v["model/g1"] = np.full((1,), -3.0, np.float32)
+        v["model/g2"] = np.full((1,), 3.0, np.float32)
+    if any(l in ("sdn5", "gain4", "sdn4") for l, _ in parse_arch(arch)):
         v["model/sdn_gain/beta1"] = np.full((1,), -5.0, np.float32)
         v["model/sdn_gain/beta2"] = np.zeros((1,), np.float32)
         v["model/sdn_gain/gain_params"] = np.full((5,), -5.0, np.float32)
@@ -450,6 +489,14 @@ class NoiseFlowOracle:
                 z, ld = affine_coupling_inverse(z, L["p"], training, self.cnn_fp16)
             elif L["type"] == "sdn5":
                 z, ld = sdn_ex5_inverse(z, y, L["p"], iso, cam)
+            elif L["type"] in ("sdn4", "sdn"):
+                scale = sdn_ex4_scale(y, L["p"], iso) if L["type"] == "sdn4" else sdn_plain_scale(y, L["p"])
+                z, ld = z / scale, -np.log(scale).sum(axis=(1, 2, 3))
+            elif L["type"] == "gain":
+                # AffineCouplingGain.py:113-127: log|det| = -log(scale), a [1]-tensor broadcast over the
+                # batch — the reference omits the H*W*C factor; restated as written
+                g = gain_plain_scale(L["p"], iso, dt)
+                z, ld = z / g, np.full((z.shape[0],), -np.log(g), dtype=z.dtype)
             else:
                 z, ld = gain_ex4_inverse(z, L["gain_val"])
             obj = obj + ld
@@ -483,6 +530,12 @@ class NoiseFlowOracle:
                 x = affine_coupling_forward(x, L["p"], training, self.cnn_fp16)
             elif L["type"] == "sdn5":
                 x = sdn_ex5_forward(x, y, L["p"], iso, cam)
+            elif L["type"] == "sdn4":
+                x = x * sdn_ex4_scale(y, L["p"], iso)
+            elif L["type"] == "sdn":
+                x = x * sdn_plain_scale(y, L["p"])
+            elif L["type"] == "gain":
+                x = x * gain_plain_scale(L["p"], iso, dt)
             else:
                 x = gain_ex4_forward(x, L["gain_val"])
         return x

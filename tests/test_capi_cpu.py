@@ -52,6 +52,8 @@ def test_layer_param_counts():
     assert lib.nf_layer_param_count(_lib.NF_LAYER_COUPLING, 4) == 72 + 4 + 8 + 16 + 4 + 8 + 180 + 4 + 4 + 1
     assert lib.nf_layer_param_count(_lib.NF_LAYER_SDN5, 0) == 23
     assert lib.nf_layer_param_count(_lib.NF_LAYER_GAIN4, 0) == 1
+    assert lib.nf_layer_param_count(_lib.NF_LAYER_SDN4, 0) == 7
+    assert lib.nf_layer_param_count(_lib.NF_LAYER_SDN, 0) == 2 and lib.nf_layer_param_count(_lib.NF_LAYER_GAIN, 0) == 2
     assert lib.nf_layer_param_count(99, 0) < 0
     # trainable parameter count of the shipped arch from the ABI's own layout:
     # 8*(36-20) + 8*(301-16) + 10 rescaling... cross-checked against hps.txt in test_ckpt_hps
@@ -123,6 +125,20 @@ def test_folding_matches_oracle(shipped_variables, width):
             np.testing.assert_allclose(blk_r[off:off + 16].reshape(4, 4), L["A_inv"] * gain_before[L["name"]], rtol=2e-7, atol=1e-9)
 
 
+def test_secondary_layers_fold_to_conditional_slots():
+    from noise_flow_amd import _lib
+    v = trained_like_variables("sdn4|unc|gain|sdn", 4)
+    ops, blk, ld = _fold("sdn4|unc|gain|sdn", v, 4, 0)
+    assert [t for t, _ in ops] == [_lib.NF_OP_SDN_DIV, _lib.NF_OP_MIX, _lib.NF_OP_COUPLING_FWD, _lib.NF_OP_SCALE_COND,
+                                   _lib.NF_OP_SDN_DIV]
+    assert [off for t, off in ops if t in (_lib.NF_OP_SDN_DIV, _lib.NF_OP_SCALE_COND)] == [0, 1, 2]   # slots
+    ops, _, _ = _fold("sdn4|unc|gain|sdn", v, 4, 1)
+    assert [t for t, _ in ops] == [_lib.NF_OP_SDN_MUL, _lib.NF_OP_SCALE_COND, _lib.NF_OP_COUPLING_REV, _lib.NF_OP_MIX,
+                                   _lib.NF_OP_SDN_MUL]
+    with pytest.raises(_lib.NoiseFlowLibError):
+        _fold("sdn|sdn4|sdn5|gain|sdn4", v | trained_like_variables("sdn5", 4), 4, 0)          # > 4 conditional layers
+
+
 def test_lone_gain_becomes_scale_op():
     from noise_flow_amd import _lib
     v = trained_like_variables("gain4|sdn5", 4)
@@ -166,6 +182,6 @@ def test_error_reporting(shipped_variables):
     assert fold(_lib.nf_config(32, 32, 4, len(layers), -1, 0), n=100) == _lib.NF_EINVAL
     assert fold(_lib.nf_config(32, 32, 4, len(layers), -1, 0)) == 0 and n_ops.value == 17
     with pytest.raises(NotImplementedError):
-        params.parse_arch("unc|sdn4")
+        params.parse_arch("unc|sdn3")
     with pytest.raises(KeyError):
         params.pack("unc|unc|unc|unc|unc|unc|unc|unc|unc", shipped_variables, 4)   # no 9th template in the ckpt

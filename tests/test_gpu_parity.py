@@ -420,3 +420,39 @@ def test_fp16_mode_rejects_unsupported_shapes(shipped_variables):
     from noise_flow_amd._lib import NoiseFlowLibError
     with pytest.raises(NoiseFlowLibError):
         NoiseFlow([16, 16, 4], False, default_hps(), variables=shipped_variables, cnn_dtype="fp16")
+
+
+@pytest.mark.parametrize("arch,iso", [("sdn4|gain4", 800), ("sdn4|unc|gain4|unc", 100), ("sdn|unc|gain|unc", 400),
+                                      ("gain|sdn", 1600), ("sdn4|gain4", 250)])
+def test_secondary_layer_variants(arch, iso):
+    """sdn4 (job_noise_flow.sh 'sdn4|gain4'), plain sdn and plain gain: same kernels, other host scalars."""
+    v = trained_like_variables(arch, 4, seed=11)
+    for k in ("model/b1", "model/g1"):
+        if k in v:
+            v[k] = np.asarray([-1.0], np.float32)
+    if "model/g1" in v:
+        v["model/g1"] = np.asarray([-6.0], np.float32)      # scale = sig(g1)*iso + sig(g2) stays O(1)
+    x, y = make_inputs(6, seed=iso)
+    m = _model(arch, v)
+    o = _oracle(arch, v)
+    nll, sd = m._loss(x, y, [0], [0], [iso], [2])
+    ref, rsd, rz = o.nll(x, y, iso, 2)
+    np.testing.assert_allclose(nll, ref, rtol=NLL_RTOL)
+    z, obj = m.inverse(x, None, y, [0], [0], [iso], [2])
+    _close_elem(z, rz)
+    np.testing.assert_allclose(obj, o.inverse(x, y, iso, 2)[1], rtol=NLL_RTOL, atol=1e-3)
+    eps = np.random.RandomState(2).randn(6, 32, 32, 4).astype(np.float32)
+    _close_elem(m.sample(y, 0.7, y, [0], [0], [iso], [2], eps=eps), o.sample(eps, 0.7, y, iso, 2))
+    from noise_flow_amd.layers import bijectors_from_arch
+    bij = bijectors_from_arch(arch, v, (32, 32, 4), 4)
+    _, _, per = o.inverse(x, y, iso, 2, return_layers=True)
+    zz = x.astype(np.float64)
+    for b, (name, ref_z, ref_ld) in zip(bij, per):
+        assert b.name == name
+        if b.conditional:
+            out, ld = b._inverse_and_log_det_jacobian(np.float32(zz), y, [0], [0], [iso], [2])
+        else:
+            out, ld = b._inverse_and_log_det_jacobian(np.float32(zz))
+        _close_elem(out, ref_z)
+        np.testing.assert_allclose(ld, ref_ld, rtol=1e-5, atol=1e-3)
+        zz = ref_z

@@ -164,3 +164,25 @@ def test_philox_known_answers():
     assert 0.0 <= y.min() and y.max() < 1.0 and abs(y.mean() - 0.5) < 0.01
     eps = x / np.sqrt(np.float32(0.000479) * y + np.float32(2e-6))
     assert abs(eps.std() - 1.0) < 0.01 and abs(eps.mean()) < 0.01
+
+
+def test_secondary_layers_invariants():
+    """sdn4 / sdn / gain: fresh-init closed forms, round trip, and the reference's
+    once-per-patch log-det of the plain gain layer (AffineCouplingGain.py:113-127)."""
+    y = np.random.RandomState(0).rand(2, 8, 8, 4)
+    x = np.random.RandomState(1).randn(2, 8, 8, 4) * 0.1
+    v = O.fresh_variables("sdn4|gain4")
+    m = O.NoiseFlowOracle("sdn4|gain4", v)
+    # fresh sdn4: beta1 = exp(-5), beta2 = 1, gain = exp(-5)*iso  ->  scale = sqrt(y/iso + 1)
+    np.testing.assert_allclose(O.sdn_ex4_scale(y, m.layers[0]["p"], 400.0), np.sqrt(y / 400.0 + 1.0), rtol=1e-6)
+    z, obj = m.inverse(x, y, 400.0, 2)
+    assert np.abs(m.forward(z, y, 400.0, 2) - x).max() < 1e-15
+    v = O.fresh_variables("sdn|gain")
+    m = O.NoiseFlowOracle("sdn|gain", v)
+    sig = lambda t: 1 / (1 + np.exp(-t))
+    z, obj = m.inverse(x, y, 100.0, 2)
+    scale = np.sqrt(sig(-3.0) * y + sig(3.0))
+    g = sig(-3.0) * 100.0 + sig(3.0)
+    np.testing.assert_allclose(z, x / scale / g, rtol=1e-12)
+    np.testing.assert_allclose(obj, -np.log(scale).sum((1, 2, 3)) - np.log(g), rtol=1e-12)   # NOT -HWC*log(g)
+    assert O.layer_names("sdn|unc|gain") == ["sdn_0", "Conv2d_1x1_1", "unc_1", "gain_2"]
