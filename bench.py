@@ -74,9 +74,12 @@ def main():
         sys.exit("bench.py needs an MI355X: no GPU visible and there is no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # NF_BENCH_FORCE_DIST=1 runs the RCCL code path on a single rank too (validation aid)
+    use_dist = world > 1 or bool(os.environ.get("NF_BENCH_FORCE_DIST"))
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
 
     from noise_flow_amd import NoiseFlow, default_hps, _lib
     from noise_flow_amd.ckpt import load_checkpoint
@@ -105,12 +108,12 @@ def main():
             _lib.check(rc)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     for i in range(Wm):
         nll_step(i)
-    if world > 1:
+    if use_dist:
         allreduce_sums(sums.clone())        # warm the RCCL communicator outside the timed region
     sums.zero_()
     torch.cuda.synchronize(dev)
@@ -123,7 +126,7 @@ def main():
     for i in range(K):
         nll_step(i)
     ev1.record(stream)
-    if world > 1:
+    if use_dist:
         allreduce_sums(sums)                # ONE RCCL all-reduce of 3 fp64 scalars finishes the evaluation
     torch.cuda.synchronize(dev)
     barrier()
@@ -132,7 +135,7 @@ def main():
     kernel_ms = ev0.elapsed_time(ev1) / K   # average launch duration over the timed region (HIP events)
 
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
     s = sums.cpu().numpy()
@@ -268,7 +271,7 @@ def main():
             "cpu_baseline": cpu_baseline, "sampling": sampling, "nll_check": nll_check, "fp16_cnn_64x64": fp16_cnn,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("NF_LIB_OVERRIDE") or os.path.join(_HERE, "csrc", "libnoiseflow_hip.so")   # override: tuning experiments only
+LIB_PATH = os.path.join(_HERE, "csrc", "libnoiseflow_hip.so")
 
 NF_LAYER_CONV1X1 = 1
 NF_LAYER_COUPLING = 2

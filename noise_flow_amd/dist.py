@@ -22,7 +22,7 @@ def allreduce_sums(sums, group=None):
     """In-place SUM all-reduce of the ``float64[3]`` accumulator (device tensor for
     RCCL, CPU tensor for gloo).  No-op when torch.distributed is not initialised."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
     return sums
 

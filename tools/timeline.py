@@ -1,8 +1,14 @@
-"""Debug aid (needs a -DNF_TIMELINE build of the library via NF_LIB_OVERRIDE): cycle stamps of wave 0 / workgroup 0."""
+"""Debug aid: cycle stamps of wave 0 / workgroup 0.  Needs a library built from a kernel source
+instrumented with NF_STAMP() cycle-counter writes into the logdet buffer (see git history of
+this file's commit); pass its path as NF_TIMELINE_LIB — it is loaded INSTEAD of the product
+library for this tool only."""
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from noise_flow_amd import NoiseFlow, default_hps, _lib
+from noise_flow_amd import _lib
+if os.environ.get("NF_TIMELINE_LIB"):
+    _lib.LIB_PATH = os.environ["NF_TIMELINE_LIB"]
+from noise_flow_amd import NoiseFlow, default_hps
 from noise_flow_amd.ckpt import load_checkpoint
 from noise_flow_amd.patches import synth_patches
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
