@@ -135,7 +135,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
     constexpr bool H16 = PREC == 1;   // coupling-CNN convs on fp16 matrix cores (fp32 accumulate)
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
-    const int H = a.H, W = a.W, HW = H * W;
+    // FULL = square patch that fills the workgroup exactly (32x32 or 64x64): the geometry is a
+    // compile-time constant, so every tile offset folds into a DS-instruction immediate
+    constexpr int SIDE = THREADS * PX == 1024 ? 32 : THREADS * PX == 4096 ? 64 : 0;
+    static_assert(!FULL || SIDE != 0, "FULL needs a 32x32 or 64x64 workgroup footprint");
+    const int H = FULL ? SIDE : a.H, W = FULL ? SIDE : a.W, HW = H * W;
     const int Wp = W + 2;
     const int tile_px = ((H + 2) * Wp + 1) & ~1;         // even -> 16-byte aligned sections
     float2 *const t0 = reinterpret_cast<float2 *>(smem);  // z0 tile  [tile_px] float2
@@ -805,8 +809,10 @@ template <int WIDTH, int THREADS, int PX, bool PHILOX, bool MFMA>
 hipError_t launch_flow_v(const NfProgram &prog, const NfLaunch &a, int n_cu, hipStream_t stream)
 {
     // full-patch specialisation only for the production shapes (32x32, 64x64) to bound code size
-    if (THREADS * PX >= 1024 && a.H * a.W == THREADS * PX)
-        return launch_flow_f<WIDTH, THREADS, PX, PHILOX, MFMA, true>(prog, a, n_cu, stream);
+    if constexpr (THREADS * PX == 1024 || THREADS * PX == 4096) {
+        if (a.H == a.W && a.H * a.W == THREADS * PX)
+            return launch_flow_f<WIDTH, THREADS, PX, PHILOX, MFMA, true>(prog, a, n_cu, stream);
+    }
     return launch_flow_f<WIDTH, THREADS, PX, PHILOX, MFMA, false>(prog, a, n_cu, stream);
 }
 
