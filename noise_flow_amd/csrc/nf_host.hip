@@ -617,6 +617,16 @@ int nf_create(const nf_config *cfg, const nf_layer_desc *layers, const float *pa
         return rc;
     }
     h->cfg = *cfg;
+    {   // the two LDS tiles of the scalar-weight kernel must fit one CU (160 KiB)
+        const size_t tile_px = ((size_t)(cfg->height + 2) * (cfg->width + 2) + 1) & ~(size_t)1;
+        const size_t lds = sizeof(float) * (tile_px * (2 + (size_t)h->fwd.prog.width) + 64);
+        if (lds > 160 * 1024 && h->fwd.block2.empty()) {
+            const int w = h->fwd.prog.width;
+            delete h;
+            return fail(NF_EINVAL, "a %dx%d patch with coupling width %d needs %zu KiB of LDS (> 160): unsupported",
+                        cfg->height, cfg->width, w, lds / 1024);
+        }
+    }
     hipError_t e;
     if (cfg->device >= 0) {
         h->device = cfg->device;

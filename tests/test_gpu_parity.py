@@ -112,7 +112,9 @@ def test_per_layer_bijectors_match_oracle(shipped_variables, oracle_full):
 
 @pytest.mark.parametrize("arch,width,hw", [("unc", 4, (32, 32)), ("unc|unc", 8, (32, 32)), ("unc|gain4|unc", 16, (16, 16)),
                                            ("sdn5|unc|gain4|unc", 4, (64, 64)), ("gain4|unc", 4, (8, 8)),
-                                           ("unc|sdn5", 4, (5, 7)), ("unc", 4, (1, 1)), ("unc|unc", 4, (1, 9))])
+                                           ("unc|sdn5", 4, (5, 7)), ("unc", 4, (1, 1)), ("unc|unc", 4, (1, 9)),
+                                           ("sdn5|unc|unc", 4, (16, 64)), ("unc|gain4|unc", 4, (64, 16)),
+                                           ("sdn5|unc", 4, (48, 48)), ("unc|unc", 8, (48, 48))])
 def test_other_archs_widths_and_patch_sizes(arch, width, hw):
     H, W = hw
     v = trained_like_variables(arch, width, seed=H * 100 + W)
@@ -249,6 +251,33 @@ def test_concurrent_callers_share_one_handle(shipped_variables, oracle_full):
             errs.append(e)
 
     th = [threading.Thread(target=work) for _ in range(16)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs[0]
+
+
+def test_concurrent_callers_on_their_own_streams(shipped_variables, oracle_full):
+    """Each caller thread launches on its own HIP stream (per-call stream argument of the C ABI)."""
+    import torch
+    m = _model(FULL_ARCH, shipped_variables)
+    x, y = make_inputs(64, seed=33)
+    ref = oracle_full.nll(x, y, 100, 2)[0]
+    xt, yt = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    torch.cuda.synchronize()
+    errs = []
+
+    def work():
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for _ in range(10):
+                    nll, _ = m._loss(xt, yt, [0], [0], [100], [2])
+                st.synchronize()
+            np.testing.assert_allclose(nll.cpu().numpy(), ref, rtol=NLL_RTOL)
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    th = [threading.Thread(target=work) for _ in range(8)]
     [t.start() for t in th]
     [t.join() for t in th]
     assert not errs, errs[0]
@@ -413,6 +442,14 @@ def test_fp16_coupling_cnn_mode(shipped_variables, oracle_full, hw, B):
     _close_elem(xs, o16.sample(eps, 0.6, y, 100, 2), rtol=2e-3)
     ref32 = oracle_full.nll(x, y, 100, 2)[0]
     np.testing.assert_allclose(nll, ref32, rtol=1e-4)
+
+
+def test_oversized_tile_is_rejected_at_create():
+    from noise_flow_amd._lib import NoiseFlowLibError, NF_EINVAL
+    v = trained_like_variables("unc", 8)
+    with pytest.raises(NoiseFlowLibError) as ei:
+        _model("unc", v, (64, 64, 4), 8)          # 66*66*(2+8)*4 B = 170 KiB of LDS
+    assert ei.value.code == NF_EINVAL and "LDS" in str(ei.value)
 
 
 def test_fp16_mode_rejects_unsupported_shapes(shipped_variables):
