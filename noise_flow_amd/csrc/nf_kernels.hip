@@ -140,7 +140,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
     constexpr int SIDE = THREADS * PX == 1024 ? 32 : THREADS * PX == 4096 ? 64 : 0;
     static_assert(!FULL || SIDE != 0, "FULL needs a 32x32 or 64x64 workgroup footprint");
     const int H = FULL ? SIDE : a.H, W = FULL ? SIDE : a.W, HW = H * W;
-    const int Wp = W + 2;
+    // row pitch of the plain row-major tiles; fp16 mode at 32x32: 48 entries so that the next
+    // block row (2 tile rows down) starts a multiple of 128 B (half2) / 256 B (4 x half) away
+    const int Wp = (H16 && SIDE == 32) ? 48 : W + 2;
     const int tile_px = ((H + 2) * Wp + 1) & ~1;         // even -> 16-byte aligned sections
     float2 *const t0 = reinterpret_cast<float2 *>(smem);  // z0 tile  [tile_px] float2
     float *const th = smem + 2 * tile_px;                 // h2 tile  [tile_px][WIDTH]
@@ -318,11 +320,12 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
                     NF_PRIO_DOWN();
 #pragma unroll
                     for (int k = 0; k < PX; ++k) {
-                        const v4h a1 = {(_Float16)nf_relu(h1[k][0]), (_Float16)nf_relu(h1[k][1]),
-                                        (_Float16)nf_relu(h1[k][2]), (_Float16)nf_relu(h1[k][3])};
+                        // ReLU after the conversion, two halves per instruction (v_pk_max_f16)
+                        const v4h a1 = __builtin_elementwise_max(
+                            v4h{(_Float16)h1[k][0], (_Float16)h1[k][1], (_Float16)h1[k][2], (_Float16)h1[k][3]}, v4h{0, 0, 0, 0});
                         const v4f h2 = __builtin_amdgcn_mfma_f32_4x4x4f16(w2h, a1, v4f{b2.x, b2.y, b2.z, b2.w}, 0, 0, 0);
-                        const v4h a2 = {(_Float16)nf_relu(h2[0]), (_Float16)nf_relu(h2[1]),
-                                        (_Float16)nf_relu(h2[2]), (_Float16)nf_relu(h2[3])};
+                        const v4h a2 = __builtin_elementwise_max(
+                            v4h{(_Float16)h2[0], (_Float16)h2[1], (_Float16)h2[2], (_Float16)h2[3]}, v4h{0, 0, 0, 0});
                         thh[lidx[k]] = __builtin_bit_cast(uint2, a2);
                     }
                 } else if constexpr (MFMA) {
@@ -764,6 +767,7 @@ hipError_t launch_flow_p(const NfProgram &prog, const NfLaunch &a, int n_cu, hip
 {
     const int tile_px = ((a.H + 2) * (a.W + 2) + 1) & ~1;
     size_t lds_f = (size_t)tile_px * (PREC == 1 ? 3 : 2 + WIDTH) + ((3 * (THREADS / 64) + 3) & ~3);
+    if (PREC == 1 && a.H == 32) lds_f = (size_t)(34 * 48) * 3 + ((3 * (THREADS / 64) + 3) & ~3);   // padded row pitch
     if (MFMA) lds_f += (size_t)((a.n_params + 3) & ~3);
     const size_t lds = sizeof(float) * lds_f;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
