@@ -72,15 +72,16 @@ __device__ __forceinline__ float u01_24(uint32_t r) { return (float)(r >> 8) * 5
 // u32 -> U(0,1) with 23 bits, never 0 (exact in fp32)
 __device__ __forceinline__ float u01_open(uint32_t r) { return (float)(r >> 9) * 1.1920928955078125e-7f + 5.9604644775390625e-8f; }
 
-// Box-Muller: two uniforms -> two N(0,1)
+// Box-Muller: two uniforms -> two N(0,1), on the hardware transcendental unit:
+// r = sqrt(-2 ln u1) via v_log_f32 (log2) + v_sqrt_f32; sin/cos(2 pi u2) via v_sin_f32 / v_cos_f32,
+// whose argument is in revolutions.  ~1e-6 absolute agreement with the libm formulation
+// (oracle/philox.py); the u32 stream itself is bit-exact.
 __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float &n0, float &n1)
 {
     const float u1 = u01_open(a), u2 = u01_open(b);
-    const float r = sqrtf(-2.0f * logf(u1));
-    float s, c;
-    sincosf(6.283185307179586f * u2, &s, &c);
-    n0 = r * c;
-    n1 = r * s;
+    const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
+    n0 = r * __builtin_amdgcn_cosf(u2);
+    n1 = r * __builtin_amdgcn_sinf(u2);
 }
 
 __device__ __forceinline__ void philox_normal4(uint64_t seed, int64_t patch, uint32_t pixel, uint32_t stream, float v[4])
