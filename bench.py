@@ -277,6 +277,7 @@ def main():
         }
         print(json.dumps(out), flush=True)
     if use_dist:
+        dist.barrier()                      # rank 0's extra sections are done before any rank tears down
         dist.destroy_process_group()
 
 
