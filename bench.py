@@ -16,8 +16,9 @@ ONE RCCL all-reduce of (sum nll, sum sd_z, count) inside the timed region.
 Rank 0 prints ONE JSON line.  Besides the contract keys it carries
   roofline      the dominant kernel against the dense fp32 matrix/vector peak (the binding
                 roofline: algorithmic flops / HIP-event time), with the HBM view nested
-  cpu_baseline  the op-per-layer torch-CPU port of the reference graph (oracle/),
-                timed on this box's host cores on a bounded sample (N = 1 only)
+  cpu_baseline  CPU ports of the reference arithmetic (oracle/): fused plain-C/OpenMP (the
+                reported value) and the op-per-layer torch-CPU restatement of the TF1 graph,
+                timed on this box's host cores on bounded samples (N = 1 only)
   sampling      the sampling direction at BASELINE configs[2] (batch 4096)
   nll_check     GPU mean NLL vs the fp64 CPU oracle on a 64-patch subset
   fp16_cnn_64x64  BASELINE configs[4] shape (64x64x4, fp16 coupling CNN / fp32 log-det)
@@ -39,6 +40,31 @@ ALGO_BYTES_PER_PATCH = 2 * 32 * 32 * 4 * 4          # read x and y once (fp32): 
 ALGO_FLOP_PER_PATCH = 5.1e6
 HBM_PEAK_GBS = 8000.0                                # MI355X_MICROARCH.md: 8 TB/s spec
 VALU_PEAK_TFLOPS = 157.3                             # fp32 vector peak
+
+
+def _usable_cores(threads: int) -> int:
+    """Threads actually backed by CPU time: min(threads, cgroup CPU quota, affinity mask)."""
+    n = threads
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                txt = f.read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(round(int(txt[0]) / int(txt[1])))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                        n = min(n, max(1, int(round(q / int(g.read())))))
+            break
+        except Exception:
+            continue
+    return int(n)
 
 
 def parse_args():
@@ -222,23 +248,41 @@ def main():
                      "rel_err_mean": float(abs(g.mean() - ref.mean()) / abs(ref.mean())),
                      "max_rel_err_per_patch": float(np.max(np.abs(g - ref) / np.abs(ref))), "tolerance": 1e-5}
         if not args.no_cpu_baseline:
+            xc, yc = x0.cpu().numpy(), y0.cpu().numpy()
+            # (1) fused plain-C / OpenMP port of the reference arithmetic (oracle/nf_oracle.c): what a good
+            #     CPU implementation does on all host cores -> the reported cpu_baseline
+            from oracle.nf_oracle_c import COracle
+            cc = COracle(ARCH_LABEL, variables)
+            host_cores = _usable_cores(os.cpu_count() or 1)           # affinity mask and cgroup CPU quota
+            cc.set_threads(host_cores)
+            cc.nll(xc[:256], yc[:256], 100.0, 2.0)                      # warm-up (thread pool, page faults)
+            n_batches, tc, budget = 0, 0.0, 0.6 * args.cpu_seconds
+            t_start = time.perf_counter()
+            while tc < budget and n_batches < 4096:                     # time-bounded sample
+                cc.nll(xc, yc, 100.0, 2.0)
+                n_batches += 1
+                tc = time.perf_counter() - t_start
+            cpu_baseline = {"value": n_batches * B / tc, "unit": "patches/s", "cores": _usable_cores(cc.threads()),
+                            "kind": "port",
+                            "sample": "forward NLL of %d batches x %d patches (same workload), fused plain-C fp32 port "
+                                      "of the reference arithmetic with OpenMP over patches (%d threads; TF1 "
+                                      "unavailable), %.1f s" % (n_batches, B, cc.threads(), tc)}
+            # (2) op-per-layer torch-CPU port: how the TF1 graph actually executes (every op materialised)
             from oracle.nf_cpu_torch import TorchCpuFlow
             cpu = TorchCpuFlow(ARCH_LABEL, variables)
-            xc, yc = x0.cpu().numpy(), y0.cpu().numpy()
-            cpu.nll(xc[:128], yc[:128], 100.0, 2.0)                       # warm-up
-            tp = time.perf_counter()
-            cpu.nll(xc, yc, 100.0, 2.0)                                   # one full batch sizes the sample
-            t_batch = time.perf_counter() - tp
-            n_batches = int(max(1, min(64, round(args.cpu_seconds / t_batch))))
-            tc = time.perf_counter()
-            for _ in range(n_batches):
+            torch.set_num_threads(host_cores)
+            cpu.nll(xc[:128], yc[:128], 100.0, 2.0)
+            n_batches, tc, budget = 0, 0.0, 0.4 * args.cpu_seconds
+            t_start = time.perf_counter()
+            while tc < budget and n_batches < 64:
                 cpu.nll(xc, yc, 100.0, 2.0)
-            tc = time.perf_counter() - tc
-            cpu_baseline = {"value": n_batches * B / tc, "unit": "patches/s", "cores": int(torch.get_num_threads()),
-                            "kind": "port",
-                            "sample": "forward NLL of %d batches x %d patches (same workload), torch-CPU fp32 "
-                                      "op-per-layer restatement of the TF1 graph (TF1 unavailable), %.1f s"
-                                      % (n_batches, B, tc)}
+                n_batches += 1
+                tc = time.perf_counter() - t_start
+            cpu_baseline["op_per_layer_torch"] = {
+                "value": n_batches * B / tc, "unit": "patches/s", "cores": _usable_cores(int(torch.get_num_threads())),
+                "kind": "port",
+                "sample": "forward NLL of %d batches x %d patches, torch-CPU fp32 op-per-layer restatement of the "
+                          "TF1 graph, %.1f s" % (n_batches, B, tc)}
 
     if rank == 0:
         traffic = None

@@ -493,3 +493,23 @@ def test_secondary_layer_variants(arch, iso):
         _close_elem(out, ref_z)
         np.testing.assert_allclose(ld, ref_ld, rtol=1e-5, atol=1e-3)
         zz = ref_z
+
+
+def test_full_bench_batch_against_c_oracle(shipped_variables):
+    """Every patch of a full configs[1] batch (1024) and a configs[2] batch (4096 eps-supplied
+    samples) against the plain-C oracle (fp32, reference op order)."""
+    from oracle.nf_oracle_c import COracle
+    from noise_flow_amd.patches import synth_patches
+    m = _model(FULL_ARCH, shipped_variables)
+    c = COracle(FULL_ARCH, shipped_variables)
+    x, y = synth_patches(0, 0, 1024)
+    nll, sd = m._loss(x, y, [0], [0], [100], [2])
+    xn, yn = x.cpu().numpy(), y.cpu().numpy()
+    ref, rsd, _ = c.nll(xn, yn, 100.0, 2.0)
+    np.testing.assert_allclose(nll.cpu().numpy(), ref, rtol=NLL_RTOL)
+    assert abs(float(sd) - rsd.mean()) <= 1e-5 * rsd.mean()
+    _, y4 = synth_patches(1, 0, 4096, want_x=False)
+    eps = np.random.RandomState(0).randn(4096, 32, 32, 4).astype(np.float32)
+    xs = m.sample(y4, 1.0, y4, [0], [0], [100], [2], eps=eps)
+    r = c.sample(eps, 1.0, y4.cpu().numpy(), 100.0, 2.0)
+    _close_elem(np.asarray(xs), r.astype(np.float64))

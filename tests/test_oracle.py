@@ -186,3 +186,26 @@ def test_secondary_layers_invariants():
     np.testing.assert_allclose(z, x / scale / g, rtol=1e-12)
     np.testing.assert_allclose(obj, -np.log(scale).sum((1, 2, 3)) - np.log(g), rtol=1e-12)   # NOT -HWC*log(g)
     assert O.layer_names("sdn|unc|gain") == ["sdn_0", "Conv2d_1x1_1", "unc_1", "gain_2"]
+
+
+@pytest.mark.parametrize("arch,width,hw", [(FULL_ARCH, 4, (32, 32)), ("unc|gain4|unc", 8, (9, 6)), ("sdn4|unc|gain|sdn", 4, (16, 16)),
+                                           ("unc", 16, (5, 5))])
+def test_c_oracle_matches_numpy_oracle(shipped_variables, arch, width, hw):
+    """The plain-C restatement (fp32, un-folded, reference op order) against the fp64 numpy oracle."""
+    from oracle.nf_oracle_c import COracle
+    v = shipped_variables if arch == FULL_ARCH else trained_like_variables(arch, width, seed=4)
+    if "model/g1" in v:
+        v["model/g1"] = np.asarray([-6.0], np.float32)
+    H, W = hw
+    x, y = make_inputs(5, H, W, seed=7)
+    o = O.NoiseFlowOracle(arch, v)
+    c = COracle(arch, v)
+    nll, sd, z = c.nll(x, y, 800.0, 2.0, want_z=True)
+    ref, rsd, rz = o.nll(x, y, 800.0, 2.0)
+    np.testing.assert_allclose(nll, ref, rtol=5e-6, atol=1e-3)
+    assert np.abs(z - rz).max() <= 5e-6 * np.abs(rz).max()
+    assert abs(sd.mean() - rsd) <= 1e-5 * rsd
+    eps = np.random.RandomState(1).randn(5, H, W, 4).astype(np.float32)
+    xs = c.sample(eps, 0.6, y, 800.0, 2.0)
+    r = o.sample(eps, 0.6, y, 800.0, 2.0)
+    assert np.abs(xs - r).max() <= 5e-6 * np.abs(r).max()
