@@ -371,8 +371,8 @@ int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float
             break;
         }
         case NF_LAYER_COUPLING: {
-            if (L.width != 4 && L.width != 8 && L.width != 16)
-                return fail(NF_EINVAL, "layer %d: coupling width %d unsupported (4, 8, 16)", li, L.width);
+            if (L.width != 4 && L.width != 8 && L.width != 16 && L.width != 32)
+                return fail(NF_EINVAL, "layer %d: coupling width %d unsupported (4, 8, 16, 32)", li, L.width);
             if (width && width != L.width) return fail(NF_EINVAL, "all coupling layers must share one width");
             width = L.width;
             it.type = NF_OP_COUPLING_FWD;

@@ -842,15 +842,21 @@ hipError_t dispatch_geom(const NfProgram &prog, const NfLaunch &a, int n_cu, hip
     const int hw = a.H * a.W;
     if (hw <= 64) return launch_flow<WIDTH, 64, 1, MFMA>(prog, a, n_cu, stream);
     if (hw <= 256) return launch_flow<WIDTH, 256, 1, MFMA>(prog, a, n_cu, stream);
-    if (hw <= 1024) {
-        // workgroup geometry for the 32x32 patch; NF_GEOM=<threads> overrides (tuning aid)
-        static const int geom = env_int("NF_GEOM");
-        if (geom == 512) return launch_flow<WIDTH, 512, 2, MFMA>(prog, a, n_cu, stream);
-        if (geom == 1024) return launch_flow<WIDTH, 1024, 1, MFMA>(prog, a, n_cu, stream);
-        return launch_flow<WIDTH, 256, 4, MFMA>(prog, a, n_cu, stream);
+    if constexpr (WIDTH >= 32) {
+        // wide CNNs keep one pixel per lane (the per-pixel hidden vector alone is WIDTH registers)
+        if (hw <= 1024) return launch_flow<WIDTH, 1024, 1, MFMA>(prog, a, n_cu, stream);
+        return hipErrorInvalidValue;
+    } else {
+        if (hw <= 1024) {
+            // workgroup geometry for the 32x32 patch; NF_GEOM=<threads> overrides (tuning aid)
+            static const int geom = env_int("NF_GEOM");
+            if (geom == 512) return launch_flow<WIDTH, 512, 2, MFMA>(prog, a, n_cu, stream);
+            if (geom == 1024) return launch_flow<WIDTH, 1024, 1, MFMA>(prog, a, n_cu, stream);
+            return launch_flow<WIDTH, 256, 4, MFMA>(prog, a, n_cu, stream);
+        }
+        if (hw <= 4096) return launch_flow<WIDTH, 1024, 4, MFMA>(prog, a, n_cu, stream);
+        return hipErrorInvalidValue;
     }
-    if (hw <= 4096) return launch_flow<WIDTH, 1024, 4, MFMA>(prog, a, n_cu, stream);
-    return hipErrorInvalidValue;
 }
 
 }  // namespace
@@ -863,6 +869,7 @@ hipError_t nf_launch_flow(const NfProgram &prog, const NfLaunch &a, int n_cu, hi
     case 4: return dispatch_geom<4, false>(prog, a, n_cu, stream);
     case 8: return dispatch_geom<8, false>(prog, a, n_cu, stream);
     case 16: return dispatch_geom<16, false>(prog, a, n_cu, stream);
+    case 32: return dispatch_geom<32, false>(prog, a, n_cu, stream);
     default: return hipErrorInvalidValue;
     }
 }

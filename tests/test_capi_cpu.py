@@ -59,7 +59,7 @@ def test_layer_param_counts():
     # 8*(36-20) + 8*(301-16) + 10 rescaling... cross-checked against hps.txt in test_ckpt_hps
 
 
-@pytest.mark.parametrize("width", [4, 8, 16])
+@pytest.mark.parametrize("width", [4, 8, 16, 32])
 def test_folding_matches_oracle(shipped_variables, width):
     from noise_flow_amd import _lib
     arch = FULL_ARCH if width == 4 else "unc|gain4|unc|sdn5"

@@ -114,7 +114,8 @@ def test_per_layer_bijectors_match_oracle(shipped_variables, oracle_full):
                                            ("sdn5|unc|gain4|unc", 4, (64, 64)), ("gain4|unc", 4, (8, 8)),
                                            ("unc|sdn5", 4, (5, 7)), ("unc", 4, (1, 1)), ("unc|unc", 4, (1, 9)),
                                            ("sdn5|unc|unc", 4, (16, 64)), ("unc|gain4|unc", 4, (64, 16)),
-                                           ("sdn5|unc", 4, (48, 48)), ("unc|unc", 8, (48, 48))])
+                                           ("sdn5|unc", 4, (48, 48)), ("unc|unc", 8, (48, 48)),
+                                           ("unc|unc", 32, (16, 16)), ("sdn5|unc|gain4|unc", 32, (32, 32))])
 def test_other_archs_widths_and_patch_sizes(arch, width, hw):
     H, W = hw
     v = trained_like_variables(arch, width, seed=H * 100 + W)
