@@ -209,3 +209,23 @@ def test_c_oracle_matches_numpy_oracle(shipped_variables, arch, width, hw):
     xs = c.sample(eps, 0.6, y, 800.0, 2.0)
     r = o.sample(eps, 0.6, y, 800.0, 2.0)
     assert np.abs(xs - r).max() <= 5e-6 * np.abs(r).max()
+
+
+def test_config_c1_unconditional_flow_256_patches_cpu():
+    """BASELINE configs[0]: a single unconditional Conv1x1 + AffineCoupling flow, 256 synthetic
+    32x32x4 patches, CPU only.  Fresh init (reference initialisers): the coupling is the identity
+    up to rescaling_scale*tanh(0) and A is orthogonal, so NLL = 3763.97 + 1/2 ||x||^2 exactly;
+    with a trained-like coupling the plain-C and numpy restatements agree."""
+    from oracle.nf_oracle_c import COracle
+    from oracle import philox
+    x, _ = philox.synth_patches(0, 0, 256)
+    v = O.fresh_variables("unc", seed=0)
+    nll, sd, _ = COracle("unc", v).nll(x)
+    want = 0.5 * 4096 * np.log(2 * np.pi) + 0.5 * (x.astype(np.float64) ** 2).sum((1, 2, 3))
+    np.testing.assert_allclose(nll, want, rtol=1e-6)
+    np.testing.assert_allclose(O.NoiseFlowOracle("unc", v, sidd_cond="uncond").nll(x[:8])[0], want[:8], rtol=1e-9)
+    v = trained_like_variables("unc", 4, seed=1)
+    a = COracle("unc", v).nll(x)[0]
+    b = O.NoiseFlowOracle("unc", v).nll(x[:32])[0]
+    np.testing.assert_allclose(a[:32], b, rtol=5e-6)
+    assert np.isfinite(a).all()
