@@ -223,7 +223,7 @@ def test_config_c1_unconditional_flow_256_patches_cpu():
     nll, sd, _ = COracle("unc", v).nll(x)
     want = 0.5 * 4096 * np.log(2 * np.pi) + 0.5 * (x.astype(np.float64) ** 2).sum((1, 2, 3))
     np.testing.assert_allclose(nll, want, rtol=1e-6)
-    np.testing.assert_allclose(O.NoiseFlowOracle("unc", v, sidd_cond="uncond").nll(x[:8])[0], want[:8], rtol=1e-9)
+    np.testing.assert_allclose(O.NoiseFlowOracle("unc", v, sidd_cond="uncond").nll(x[:8])[0], want[:8], rtol=1e-7)   # Q is orthogonal only to fp32 round-off
     v = trained_like_variables("unc", 4, seed=1)
     a = COracle("unc", v).nll(x)[0]
     b = O.NoiseFlowOracle("unc", v).nll(x[:32])[0]
