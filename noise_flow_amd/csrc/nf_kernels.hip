@@ -5,7 +5,11 @@
 // needs with a spatial halo (the pass-through half z0 and the hidden map h2) are
 // staged in zero-bordered LDS tiles, so 'SAME' padding needs no bounds checks and
 // HBM traffic is the algorithmic minimum (read x and y once, write 1-3 scalars).
-// All model parameters are wave-uniform and fetched through the scalar cache.
+// Weights reach the FMAs in one of two ways (same arithmetic):
+//   scalar      wave-uniform s_loads into SGPRs, v_pk_fma_f32 with SGPR operands (widths 4..32);
+//   matrix core width 4: every conv has exactly 4 output channels and maps onto
+//               v_mfma_f32_4x4x1_16b_f32 (fp32) or v_mfma_f32_4x4x4_16b_f16 (fp16-CNN mode) with the
+//               weights as the A operand, read j-major from an LDS image of the whole model.
 //
 // Replaces (reference, /root/reference): the TF graph built by
 // borealisflows/noise_flow_model.py:394-456 out of layers.py:74-145 (Conv2d1x1),
@@ -18,12 +22,14 @@
 #include <atomic>
 #include "nf_device.h"
 
-// occupancy target (waves per SIMD) the register allocator must honour, per geometry
+// s_setprio level of a wave while it streams MFMAs (0 = off): keeps bursts of matrix
+// instructions contiguous on a SIMD that other waves share (+5 % at 512-thread geometry)
 #ifndef NF_PRIO
 #define NF_PRIO 2
 #endif
 #define NF_PRIO_UP()   do { if (NF_PRIO) __builtin_amdgcn_s_setprio(NF_PRIO); } while (0)
 #define NF_PRIO_DOWN() do { if (NF_PRIO) __builtin_amdgcn_s_setprio(0); } while (0)
+// occupancy target (waves per SIMD) the register allocator must honour, per geometry
 #ifndef NF_WPE_512
 #define NF_WPE_512 5
 #endif
@@ -124,8 +130,11 @@ __device__ __forceinline__ float wave_sum(float v)
 //   WIDTH   coupling CNN width
 //   THREADS workgroup size (multiple of 64)
 //   PX      pixels per thread; H*W <= THREADS*PX
-// Pixel p of the patch is owned by thread p % THREADS (slot p / THREADS), so the
-// [H,W,4] fp32 patch is read/written as fully coalesced 16-byte lanes.
+//   PHILOX  input = in-kernel Philox/Box-Muller draw (sampling without a supplied eps)
+//   MFMA    matrix-core weight delivery (width 4)
+//   FULL    square 32x32 / 64x64 patch filling the workgroup exactly: compile-time geometry, no masks
+//   PREC    0 = all fp32, 1 = fp16 coupling-CNN convs (fp32 accumulate; FULL matrix-core only)
+// Global I/O is 16 bytes per lane per pixel ([H,W,4] fp32, NHWC).
 // --------------------------------------------------------------------------
 template <int WIDTH, int THREADS, int PX, bool PHILOX, bool MFMA, bool FULL, int PREC>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_WAVES(THREADS, PX, MFMA)))) void nf_flow_kernel(const NfProgram prog, const NfLaunch a)
