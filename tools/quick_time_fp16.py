@@ -2,6 +2,9 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from noise_flow_amd import _lib as _nf_lib
+if os.environ.get("NF_TOOL_LIB"):   # A/B a differently-built library (this tool only)
+    _nf_lib.LIB_PATH = os.environ["NF_TOOL_LIB"]
 from noise_flow_amd import NoiseFlow, default_hps
 from noise_flow_amd.ckpt import load_checkpoint
 from noise_flow_amd.patches import synth_patches
