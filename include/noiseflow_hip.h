@@ -22,7 +22,8 @@
  *   - a handle is immutable after nf_create: nf_nll / nf_sample are re-entrant
  *     and may be called concurrently from many host threads (the reference's
  *     16-32 Python threads sharing one tf.Session, job_noise_flow.sh:36,
- *     train_dncnn_noiseflow.py:195); they never allocate and never synchronise.
+ *     train_dncnn_noiseflow.py:195); they never allocate and never synchronise
+ *     (the nf_*_batchstats variants are the documented exception).
  */
 #ifndef NOISEFLOW_HIP_H
 #define NOISEFLOW_HIP_H
@@ -147,6 +148,23 @@ int nf_nll(nf_handle *h, const float *x, const float *y, int64_t B, const nf_con
 int nf_sample(nf_handle *h, const float *y, const float *eps, uint64_t seed,
               int64_t patch_index_base, float temp, int64_t B, const nf_cond *cond,
               float *x_out, void *stream);
+
+/* Batch-statistics variants = the reference's `is_training=True` graphs (layers.py:386-398; what
+ * NoiseFlowWrapper.py:49 builds): every batch_norm of the coupling CNNs normalises with the moments
+ * of the CURRENT call's B patches over (N,H,W) instead of the stored running statistics, so the
+ * result of one patch depends on all patches of the call.  Same arguments as nf_nll / nf_sample, plus
+ *   moments_out  HOST float [n_couplings][4][w] (or NULL): batch mean1, var1, mean2, var2 of each
+ *                coupling, couplings in NLL layer order — what the reference's assign_sub EMA
+ *                (layers.py:392-393, decay 0.1) consumes; applying it is the caller's business.
+ * Unlike nf_nll / nf_sample these calls run 2 statistics passes per coupling before the fused pass,
+ * SYNCHRONISE `stream`, use a per-handle scratch (allocated on first use; concurrent calls on one
+ * handle serialise) and are fp32 only.  B must be >= 1. */
+int nf_nll_batchstats(nf_handle *h, const float *x, const float *y, int64_t B, const nf_cond *cond,
+                      float *nll_out, float *sd_out, float *logdet_out, float *z_out,
+                      double *sums_out, uint32_t flags, float *moments_out, void *stream);
+int nf_sample_batchstats(nf_handle *h, const float *y, const float *eps, uint64_t seed,
+                         int64_t patch_index_base, float temp, int64_t B, const nf_cond *cond,
+                         float *x_out, float *moments_out, void *stream);
 
 /* Counter-based synthetic SIDD-like patches, identical for any sharding:
  *   y_k ~ U[0,1)^(HxWx4),  x_k = eps * sqrt(beta1*y_k + beta2),  eps ~ N(0,1),

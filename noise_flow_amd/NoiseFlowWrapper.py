@@ -11,8 +11,10 @@ Two reference quirks are explicit options here:
   to the layers in reversed order (``'sample_first'``).  The default here is
   ``'loss_first'`` — the binding the model was trained with.
 * Q2 ``is_training=True`` in the reference's feed (``NoiseFlowWrapper.py:86``)
-  switches BN to batch statistics; this wrapper uses the stored running
-  statistics (the evaluation mode of ``train_noise_flow.py:167-168``).
+  switches BN to batch statistics.  The default here, ``bn_mode='running'``,
+  uses the stored running statistics (the evaluation mode of
+  ``train_noise_flow.py:167-168``); ``bn_mode='batch'`` reproduces the
+  reference wrapper literally (moments of the call's own patches).
 """
 from __future__ import annotations
 
@@ -26,7 +28,11 @@ from .noise_flow_model import NoiseFlow
 
 
 class NoiseFlowWrapper:
-    def __init__(self, path, sampling_temperature=0.6, binding="loss_first", device=None, seed=None):
+    def __init__(self, path, sampling_temperature=0.6, binding="loss_first", device=None, seed=None,
+                 bn_mode="running"):
+        if bn_mode not in ("running", "batch"):
+            raise ValueError("bn_mode must be 'running' or 'batch'")
+        self.bn_mode = bn_mode
         self.logger = logging.getLogger(__name__)
         self.nf_path = path
         self.nf_model = None
@@ -46,7 +52,7 @@ class NoiseFlowWrapper:
         if not hasattr(self.hps, "x_shape") or isinstance(self.hps.x_shape, str):
             setattr(self.hps, "x_shape", self.x_shape)
         self.logger.info("Building Noise Flow")
-        self.nf_model = NoiseFlow(self.x_shape[1:], False, self.hps, binding=self.binding, device=self.device)
+        self.nf_model = NoiseFlow(self.x_shape[1:], self.bn_mode == "batch", self.hps, binding=self.binding, device=self.device)
         self.logger.info("Restoring best model")
         self.nf_model.restore(self.model_checkpoint_path)
 

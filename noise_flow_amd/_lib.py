@@ -88,6 +88,10 @@ def load() -> C.CDLL:
     lib.nf_nll.argtypes = [vp, vp, vp, i64, C.POINTER(nf_cond), vp, vp, vp, vp, vp, u32, vp]
     lib.nf_sample.restype = C.c_int
     lib.nf_sample.argtypes = [vp, vp, vp, u64, i64, f32, i64, C.POINTER(nf_cond), vp, vp]
+    lib.nf_nll_batchstats.restype = C.c_int
+    lib.nf_nll_batchstats.argtypes = [vp, vp, vp, i64, C.POINTER(nf_cond), vp, vp, vp, vp, vp, u32, vp, vp]
+    lib.nf_sample_batchstats.restype = C.c_int
+    lib.nf_sample_batchstats.argtypes = [vp, vp, vp, u64, i64, f32, i64, C.POINTER(nf_cond), vp, vp, vp]
     lib.nf_synth_patches.restype = C.c_int
     lib.nf_synth_patches.argtypes = [u64, i64, i64, i32, i32, f32, f32, vp, vp, vp]
     lib.nf_fold_params.restype = C.c_int
@@ -111,4 +115,5 @@ def check(rc: int) -> None:
 EXPORTED_SYMBOLS = (
     "nf_abi_version", "nf_last_error", "nf_layer_param_count", "nf_create", "nf_destroy", "nf_nll",
     "nf_sample", "nf_synth_patches", "nf_fold_params", "nf_sdn5_scalars",
+    "nf_nll_batchstats", "nf_sample_batchstats",
 )

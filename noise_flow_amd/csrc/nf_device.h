@@ -126,7 +126,15 @@ struct NfLaunch {
     int32_t H, W;
     uint32_t flags;
     int32_t n_params;      // floats in the parameter block (matrix-core kernel stages it in LDS)
+    // batch-statistics pass (scalar-weight kernel only): when `stats` is set the kernel stops at
+    // coupling op `stats_op` and adds the per-channel sum / sum of squares of that layer's first
+    // (stage 1) or second (stage 2) pre-normalisation activation to stats[slot][2*width]
+    double *stats;
+    int32_t stats_op;
+    int32_t stats_stage;
 };
+
+#define NF_STATS_SLOTS 64   // power of two
 
 // Philox stream ids (4th counter word)
 #define NF_STREAM_Y    0u   // synthetic clean image

@@ -14,6 +14,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <algorithm>
+#include <mutex>
 #include <vector>
 
 #include "../../include/noiseflow_hip.h"
@@ -561,6 +563,13 @@ struct nf_handle {
     float *d_rev2 = nullptr;
     float *d_fwd3 = nullptr;   // fp16-CNN layout (NF_CFG_FP16_CNN)
     float *d_rev3 = nullptr;
+    // batch-statistics mode (nf_*_batchstats): the raw model and a lazily allocated scratch
+    std::vector<nf_layer_desc> layers;
+    std::vector<float> raw;
+    std::mutex bs_mu;
+    float *d_bs_params = nullptr;
+    double *d_bs_stats = nullptr;
+    size_t bs_cap = 0;
 };
 
 extern "C" {
@@ -617,6 +626,8 @@ int nf_create(const nf_config *cfg, const nf_layer_desc *layers, const float *pa
         return rc;
     }
     h->cfg = *cfg;
+    h->layers.assign(layers, layers + cfg->n_layers);
+    h->raw.assign(params, params + n_params);
     {   // the two LDS tiles of the scalar-weight kernel must fit one CU (160 KiB)
         const size_t tile_px = ((size_t)(cfg->height + 2) * (cfg->width + 2) + 1) & ~(size_t)1;
         const size_t lds = sizeof(float) * (tile_px * (2 + (size_t)h->fwd.prog.width) + 64);
@@ -690,12 +701,15 @@ int nf_destroy(nf_handle *h)
     if (h->d_rev2) (void)hipFree(h->d_rev2);
     if (h->d_fwd3) (void)hipFree(h->d_fwd3);
     if (h->d_rev3) (void)hipFree(h->d_rev3);
+    if (h->d_bs_params) (void)hipFree(h->d_bs_params);
+    if (h->d_bs_stats) (void)hipFree(h->d_bs_stats);
     delete h;
     return NF_OK;
 }
 
-int nf_nll(nf_handle *h, const float *x, const float *y, int64_t B, const nf_cond *cond, float *nll_out, float *sd_out,
-           float *logdet_out, float *z_out, double *sums_out, uint32_t flags, void *stream)
+// ---- argument checking + NfLaunch assembly shared by the resident and the batch-statistics paths ----
+static int nll_args(nf_handle *h, const float *x, const float *y, int64_t B, const nf_cond *cond, float *nll_out,
+                    float *sd_out, float *logdet_out, float *z_out, double *sums_out, uint32_t flags, NfLaunch &a)
 {
     if (!h) return fail(NF_EINVAL, "handle is NULL");
     if (B < 0) return fail(NF_EINVAL, "B must be >= 0");
@@ -715,18 +729,7 @@ int nf_nll(nf_handle *h, const float *x, const float *y, int64_t B, const nf_con
             cb[i] = (float)sc[1];
         }
     }
-    DeviceGuard guard;
-    int rc = guard.enter(h->device);
-    if (rc != NF_OK) return rc;
-    hipStream_t st = (hipStream_t)stream;
-    if (sums_out && !(flags & NF_ACCUMULATE)) {
-        hipError_t e = hipMemsetAsync(sums_out, 0, 3 * sizeof(double), st);
-        if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync(sums)");
-    }
-    if (B == 0) return NF_OK;
-    NfLaunch a;
     memset(&a, 0, sizeof(a));
-    a.params = h->d_fwd;
     a.in = x;
     a.y = y;
     a.out = z_out;
@@ -735,35 +738,23 @@ int nf_nll(nf_handle *h, const float *x, const float *y, int64_t B, const nf_con
     a.ld_out = logdet_out;
     a.sums = sums_out;
     a.B = B;
-    a.ld_const = h->fwd.ld_const + ld_call;
+    a.ld_const = ld_call;   // + the model's constant part, added by the launcher
     a.in_scale = 1.0f;
     memcpy(a.cond_a, ca, sizeof(ca));
     memcpy(a.cond_b, cb, sizeof(cb));
     a.H = h->cfg.height;
     a.W = h->cfg.width;
     a.flags = (flags & NF_NO_PRIOR) ? 0u : NF_K_PRIOR;
-    const bool mc = h->d_fwd3 || (h->d_fwd2 && use_matrix_core());
-    if (h->d_fwd3) {
-        a.params = h->d_fwd3;
-        a.n_params = (int32_t)h->fwd.block3.size();
-        a.flags |= NF_K_FP16_CNN;
-    } else if (mc) {
-        a.params = h->d_fwd2;
-        a.n_params = (int32_t)h->fwd.block2.size();
-    }
-    hipError_t e = nf_launch_flow(h->d_fwd3 ? h->fwd.prog3 : mc ? h->fwd.prog2 : h->fwd.prog, a, h->n_cu, st, mc);
-    if (e != hipSuccess) return fail_hip(e, "nf_nll launch");
     return NF_OK;
 }
 
-int nf_sample(nf_handle *h, const float *y, const float *eps, uint64_t seed, int64_t patch_index_base, float temp,
-              int64_t B, const nf_cond *cond, float *x_out, void *stream)
+static int sample_args(nf_handle *h, const float *y, const float *eps, uint64_t seed, int64_t patch_index_base,
+                       float temp, int64_t B, const nf_cond *cond, float *x_out, NfLaunch &a)
 {
     if (!h) return fail(NF_EINVAL, "handle is NULL");
     if (B < 0) return fail(NF_EINVAL, "B must be >= 0");
-    if (B == 0) return NF_OK;
-    if (!x_out) return fail(NF_EINVAL, "x_out is NULL");
-    if (h->rev.has_sdn && !y) return fail(NF_EINVAL, "model has a signal-dependent layer but y is NULL");
+    if (B > 0 && !x_out) return fail(NF_EINVAL, "x_out is NULL");
+    if (h->rev.has_sdn && B > 0 && !y) return fail(NF_EINVAL, "model has a signal-dependent layer but y is NULL");
     float ca[4] = {0.f, 0.f, 0.f, 0.f}, cb[4] = {1.f, 1.f, 1.f, 1.f};
     for (size_t i = 0; i < h->rev.cond.size(); ++i) {
         double sc[2];
@@ -772,12 +763,7 @@ int nf_sample(nf_handle *h, const float *y, const float *eps, uint64_t seed, int
         ca[i] = (float)sc[0];                        // sampling direction multiplies
         cb[i] = (float)sc[1];
     }
-    DeviceGuard guard;
-    int rc = guard.enter(h->device);
-    if (rc != NF_OK) return rc;
-    NfLaunch a;
     memset(&a, 0, sizeof(a));
-    a.params = h->d_rev;
     a.in = eps;
     a.y = y;
     a.out = x_out;
@@ -790,18 +776,197 @@ int nf_sample(nf_handle *h, const float *y, const float *eps, uint64_t seed, int
     a.H = h->cfg.height;
     a.W = h->cfg.width;
     a.flags = eps ? 0u : NF_K_PHILOX_IN;
-    const bool mc = h->d_rev3 || (h->d_rev2 && use_matrix_core());
-    if (h->d_rev3) {
-        a.params = h->d_rev3;
-        a.n_params = (int32_t)h->rev.block3.size();
+    return NF_OK;
+}
+
+// launch on the handle's resident (running-statistics) programs
+static int launch_resident(nf_handle *h, int direction, NfLaunch &a, hipStream_t st, const char *what)
+{
+    const Built &b = direction == 0 ? h->fwd : h->rev;
+    float *d1 = direction == 0 ? h->d_fwd : h->d_rev;
+    float *d2 = direction == 0 ? h->d_fwd2 : h->d_rev2;
+    float *d3 = direction == 0 ? h->d_fwd3 : h->d_rev3;
+    if (direction == 0) a.ld_const += b.ld_const;
+    const bool mc = d3 || (d2 && use_matrix_core());
+    a.params = d1;
+    if (d3) {
+        a.params = d3;
+        a.n_params = (int32_t)b.block3.size();
         a.flags |= NF_K_FP16_CNN;
     } else if (mc) {
-        a.params = h->d_rev2;
-        a.n_params = (int32_t)h->rev.block2.size();
+        a.params = d2;
+        a.n_params = (int32_t)b.block2.size();
     }
-    hipError_t e = nf_launch_flow(h->d_rev3 ? h->rev.prog3 : mc ? h->rev.prog2 : h->rev.prog, a, h->n_cu, (hipStream_t)stream, mc);
-    if (e != hipSuccess) return fail_hip(e, "nf_sample launch");
+    hipError_t e = nf_launch_flow(d3 ? b.prog3 : mc ? b.prog2 : b.prog, a, h->n_cu, st, mc);
+    if (e != hipSuccess) return fail_hip(e, what);
     return NF_OK;
+}
+
+int nf_nll(nf_handle *h, const float *x, const float *y, int64_t B, const nf_cond *cond, float *nll_out, float *sd_out,
+           float *logdet_out, float *z_out, double *sums_out, uint32_t flags, void *stream)
+{
+    NfLaunch a;
+    int rc = nll_args(h, x, y, B, cond, nll_out, sd_out, logdet_out, z_out, sums_out, flags, a);
+    if (rc != NF_OK) return rc;
+    DeviceGuard guard;
+    if ((rc = guard.enter(h->device)) != NF_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (sums_out && !(flags & NF_ACCUMULATE)) {
+        hipError_t e = hipMemsetAsync(sums_out, 0, 3 * sizeof(double), st);
+        if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync(sums)");
+    }
+    if (B == 0) return NF_OK;
+    return launch_resident(h, 0, a, st, "nf_nll launch");
+}
+
+int nf_sample(nf_handle *h, const float *y, const float *eps, uint64_t seed, int64_t patch_index_base, float temp,
+              int64_t B, const nf_cond *cond, float *x_out, void *stream)
+{
+    NfLaunch a;
+    int rc = sample_args(h, y, eps, seed, patch_index_base, temp, B, cond, x_out, a);
+    if (rc != NF_OK) return rc;
+    if (B == 0) return NF_OK;
+    DeviceGuard guard;
+    if ((rc = guard.enter(h->device)) != NF_OK) return rc;
+    return launch_resident(h, 1, a, (hipStream_t)stream, "nf_sample launch");
+}
+
+// ---- batch-statistics mode (is_training=True graphs: layers.py:386-398) ----
+// The normalisation of every coupling CNN uses the moments of the CURRENT call's B patches, which
+// couples all patches: the moments of coupling c depend on the outputs of couplings < c under THEIR
+// batch moments.  So the call runs 2 statistics passes per coupling, in execution order (each one
+// re-runs the prefix with the moments found so far and an identity normalisation in the layer under
+// measurement), re-folds, and finishes with one ordinary fused pass.
+static int run_batchstats(nf_handle *h, int direction, NfLaunch a, float *moments_out, hipStream_t st)
+{
+    if (h->cfg.flags & NF_CFG_FP16_CNN) return fail(NF_EINVAL, "batch-statistics mode is fp32 only");
+    std::lock_guard<std::mutex> lock(h->bs_mu);   // one scratch per handle: calls serialise
+    const size_t need = std::max(std::max(h->fwd.block.size(), h->rev.block.size()),
+                                 std::max(h->fwd.block2.size(), h->rev.block2.size()));
+    hipError_t e;
+    if (!h->d_bs_params) {
+        if ((e = hipMalloc((void **)&h->d_bs_params, need * sizeof(float))) != hipSuccess) return fail_hip(e, "hipMalloc(batchstats params)");
+        h->bs_cap = need;
+        if ((e = hipMalloc((void **)&h->d_bs_stats, NF_STATS_SLOTS * 64 * sizeof(double))) != hipSuccess)
+            return fail_hip(e, "hipMalloc(batchstats accumulators)");
+    }
+    std::vector<float> p = h->raw;
+    std::vector<int> cpl;   // coupling layers in execution order
+    for (int i = 0; i < h->cfg.n_layers; ++i)
+        if (h->layers[i].type == NF_LAYER_COUPLING) cpl.push_back(i);
+    if (direction == 1) std::reverse(cpl.begin(), cpl.end());
+    const double n = (double)a.B * a.H * a.W;
+    std::vector<double> acc(NF_STATS_SLOTS * 64);
+    const double ld_call = a.ld_const;
+
+    for (size_t c = 0; c < cpl.size(); ++c) {
+        const nf_layer_desc &L = h->layers[cpl[c]];
+        const int w = L.width;
+        float *lp = p.data() + L.param_offset;
+        float *mean1 = lp + 19 * w, *var1 = lp + 20 * w;
+        float *mean2 = lp + 22 * w + w * w, *var2 = lp + 23 * w + w * w;
+        for (int stage = 1; stage <= 2; ++stage) {
+            float *mean = stage == 1 ? mean1 : mean2, *var = stage == 1 ? var1 : var2;
+            for (int j = 0; j < w; ++j) {
+                mean[j] = 0.0f;
+                var[j] = (float)(1.0 - kBnEps);   // identity: the kernel then sees the raw activation
+            }
+            Built b;
+            int rc = build_program(&h->cfg, h->layers.data(), p.data(), p.size(), direction, b);
+            if (rc != NF_OK) return rc;
+            int op_index = -1, seen = 0;
+            for (int i = 0; i < b.prog.n_ops; ++i)
+                if (b.prog.ops[i].type == NF_OP_COUPLING_FWD || b.prog.ops[i].type == NF_OP_COUPLING_REV)
+                    if (seen++ == (int)c) {
+                        op_index = i;
+                        break;
+                    }
+            if (op_index < 0 || b.block.size() > h->bs_cap) return fail(NF_EINVAL, "internal: batch-statistics program mismatch");
+            NfLaunch s = a;
+            s.params = h->d_bs_params;
+            s.out = nullptr;
+            s.nll_out = s.sd_out = s.ld_out = nullptr;
+            s.sums = nullptr;
+            s.stats = h->d_bs_stats;
+            s.stats_op = op_index;
+            s.stats_stage = stage;
+            if ((e = hipMemcpyAsync(h->d_bs_params, b.block.data(), b.block.size() * sizeof(float), hipMemcpyHostToDevice, st)) != hipSuccess ||
+                (e = hipMemsetAsync(h->d_bs_stats, 0, NF_STATS_SLOTS * 2 * w * sizeof(double), st)) != hipSuccess)
+                return fail_hip(e, "batch-statistics upload");
+            if ((e = nf_launch_flow(b.prog, s, h->n_cu, st, false)) != hipSuccess) return fail_hip(e, "batch-statistics launch");
+            if ((e = hipMemcpyAsync(acc.data(), h->d_bs_stats, NF_STATS_SLOTS * 2 * w * sizeof(double), hipMemcpyDeviceToHost, st)) != hipSuccess ||
+                (e = hipStreamSynchronize(st)) != hipSuccess)
+                return fail_hip(e, "batch-statistics readback");
+            for (int j = 0; j < w; ++j) {
+                double sum = 0.0, sq = 0.0;
+                for (int slot = 0; slot < NF_STATS_SLOTS; ++slot) {
+                    sum += acc[(size_t)slot * 2 * w + j];
+                    sq += acc[(size_t)slot * 2 * w + w + j];
+                }
+                const double m = sum / n;
+                double v = sq / n - m * m;            // tf.nn.moments: population variance
+                if (v < 0.0) v = 0.0;
+                mean[j] = (float)m;
+                var[j] = (float)v;
+            }
+        }
+        if (moments_out) {
+            // rows follow the NLL layer order whatever the direction: [coupling][mean1|var1|mean2|var2][w]
+            size_t row = 0;
+            for (int i = 0; i < cpl[c]; ++i)
+                if (h->layers[i].type == NF_LAYER_COUPLING) ++row;
+            float *dst = moments_out + row * 4 * (size_t)w;
+            memcpy(dst, mean1, w * sizeof(float));
+            memcpy(dst + w, var1, w * sizeof(float));
+            memcpy(dst + 2 * w, mean2, w * sizeof(float));
+            memcpy(dst + 3 * w, var2, w * sizeof(float));
+        }
+    }
+
+    // final pass with the batch moments folded in
+    Built b;
+    int rc = build_program(&h->cfg, h->layers.data(), p.data(), p.size(), direction, b);
+    if (rc != NF_OK) return rc;
+    const bool mc = !b.block2.empty() && b.block2.size() <= h->bs_cap && use_matrix_core();
+    const std::vector<float> &blk = mc ? b.block2 : b.block;
+    a.params = h->d_bs_params;
+    a.n_params = mc ? (int32_t)blk.size() : 0;
+    a.ld_const = ld_call + (direction == 0 ? b.ld_const : 0.0);
+    if ((e = hipMemcpyAsync(h->d_bs_params, blk.data(), blk.size() * sizeof(float), hipMemcpyHostToDevice, st)) != hipSuccess)
+        return fail_hip(e, "batch-statistics upload");
+    if ((e = nf_launch_flow(mc ? b.prog2 : b.prog, a, h->n_cu, st, mc)) != hipSuccess) return fail_hip(e, "batch-statistics final launch");
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return fail_hip(e, "batch-statistics final sync");   // the scratch is reused
+    return NF_OK;
+}
+
+int nf_nll_batchstats(nf_handle *h, const float *x, const float *y, int64_t B, const nf_cond *cond, float *nll_out,
+                      float *sd_out, float *logdet_out, float *z_out, double *sums_out, uint32_t flags,
+                      float *moments_out, void *stream)
+{
+    NfLaunch a;
+    int rc = nll_args(h, x, y, B, cond, nll_out, sd_out, logdet_out, z_out, sums_out, flags, a);
+    if (rc != NF_OK) return rc;
+    if (B == 0) return fail(NF_EINVAL, "batch statistics of an empty batch are undefined");
+    DeviceGuard guard;
+    if ((rc = guard.enter(h->device)) != NF_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (sums_out && !(flags & NF_ACCUMULATE)) {
+        hipError_t e = hipMemsetAsync(sums_out, 0, 3 * sizeof(double), st);
+        if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync(sums)");
+    }
+    return run_batchstats(h, 0, a, moments_out, st);
+}
+
+int nf_sample_batchstats(nf_handle *h, const float *y, const float *eps, uint64_t seed, int64_t patch_index_base,
+                         float temp, int64_t B, const nf_cond *cond, float *x_out, float *moments_out, void *stream)
+{
+    NfLaunch a;
+    int rc = sample_args(h, y, eps, seed, patch_index_base, temp, B, cond, x_out, a);
+    if (rc != NF_OK) return rc;
+    if (B == 0) return fail(NF_EINVAL, "batch statistics of an empty batch are undefined");
+    DeviceGuard guard;
+    if ((rc = guard.enter(h->device)) != NF_OK) return rc;
+    return run_batchstats(h, 1, a, moments_out, (hipStream_t)stream);
 }
 
 int nf_synth_patches(uint64_t seed, int64_t patch_index_base, int64_t B, int32_t height, int32_t width, float beta1,

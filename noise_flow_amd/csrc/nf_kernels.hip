@@ -125,6 +125,24 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
+// Batch-statistics pass (nf_nll_batchstats / nf_sample_batchstats): per-channel sum and sum of
+// squares of one pixel's pre-normalisation activations, reduced over the wavefront and added to
+// the call-wide fp64 accumulators stats[0..WIDTH) / stats[WIDTH..2*WIDTH) of this workgroup's slot
+// (NF_STATS_SLOTS slots spread the atomics; the host adds them up)  (layers.py:388-391).
+template <int WIDTH>
+__device__ __forceinline__ void stats_accumulate(const float (&h)[WIDTH], bool active, double *stats, int t)
+{
+#pragma unroll
+    for (int j = 0; j < WIDTH; ++j) {
+        const float v = active ? h[j] : 0.0f;
+        const float s = wave_sum(v), q = wave_sum(v * v);
+        if ((t & 63) == 0) {
+            atomicAdd(&stats[j], (double)s);
+            atomicAdd(&stats[WIDTH + j], (double)q);
+        }
+    }
+}
+
 // --------------------------------------------------------------------------
 // The fused flow kernel.
 //   WIDTH   coupling CNN width
@@ -435,8 +453,13 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
                             }
                         }
                     }
+                    // batch-statistics pass: the host folded an identity normalisation into the layer
+                    // under measurement, so h1 / h2 here ARE its pre-normalisation activations
+                    const int stats_stage = (a.stats && op == a.stats_op) ? a.stats_stage : 0;
+                    double *const stats = a.stats + (blockIdx.x & (NF_STATS_SLOTS - 1)) * (2 * WIDTH);
 #pragma unroll
                     for (int k = 0; k < PX; ++k) {
+                        if (stats_stage == 1) stats_accumulate<WIDTH>(h1[k], act[k], stats, t);
                         float h2[WIDTH];
 #pragma unroll
                         for (int j = 0; j < WIDTH; ++j) h2[j] = B2[j];
@@ -446,6 +469,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
 #pragma unroll
                             for (int j = 0; j < WIDTH; ++j) h2[j] = fmaf(hi, W2[i * WIDTH + j], h2[j]);
                         }
+                        if (stats_stage == 2) stats_accumulate<WIDTH>(h2, act[k], stats, t);
                         if (act[k]) {
                             float4 *dst = reinterpret_cast<float4 *>(th + (size_t)lidx[k] * WIDTH);
 #pragma unroll
@@ -456,6 +480,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
                     }
                 }
                 __syncthreads();
+                if constexpr (!MFMA) {
+                    if (a.stats && op == a.stats_op) break;   // statistics gathered: this patch is done
+                }
 
                 // 3) l_last (zero pad + border-indicator channel, 3x3 VALID, *exp(3 logs) folded)
                 {
@@ -680,6 +707,10 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
 #pragma unroll
                     for (int c = 0; c < 4; ++c) z[k][c] *= s;
             }
+        }
+
+        if constexpr (!MFMA) {
+            if (a.stats) continue;   // batch-statistics pass: no outputs
         }
 
         // ---- epilogue ----

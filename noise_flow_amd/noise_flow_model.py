@@ -93,6 +93,11 @@ class FlowHandle:
                                       C.byref(h)))
         self._h = h
         self.has_sdn = any(L.kind in ("sdn5", "sdn4", "sdn") for L in self.layers)
+        self.width = int(width)
+        # template scope of every coupling CNN, NLL layer order (the rows of nf_*_batchstats' moments)
+        tb = tmpl if layers is not None else _params.template_binding(self.layers, binding)
+        self.coupling_scopes = [_params.template_scope((tb or {}).get(L.arch_index, 0))
+                                for L in self.layers if L.kind == "coupling"]
 
     def close(self):
         if getattr(self, "_h", None):
@@ -116,12 +121,14 @@ class NoiseFlow(object):
     Parameters
     ----------
     x_shape : [H, W, C]          (noise_flow_model.py:46)
-    is_training : bool           accepted for signature parity.  Batch-statistics
-                                 BN (``True``) couples all patches of a call
-                                 (layers.py:388-398) and is not part of the fused
-                                 eval path; pass ``bn_mode='running'`` semantics
-                                 (``False``) for every NLL / sampling measurement
-                                 (train_noise_flow.py:112-113,167-168).
+    is_training : bool           ``False`` (default): stored running BN statistics, the
+                                 fused single-pass path of every NLL / sampling
+                                 measurement (train_noise_flow.py:112-113,167-168).
+                                 ``True``: batch-statistics BN (layers.py:386-398) —
+                                 every call normalises with the moments of its own
+                                 patches (2 statistics passes per coupling, then the
+                                 fused pass) and moves the running statistics by the
+                                 reference's EMA (decay 0.1) in :attr:`variables`.
     hps : namespace with ``arch, width, decomp, flow_permutation, squeeze_factor,
           n_levels`` (and optionally ``seed``).
     variables : optional ``{name: ndarray}`` under the reference's checkpoint
@@ -197,10 +204,26 @@ class NoiseFlow(object):
         return _lib.nf_cond(_first(iso), _first(cam), _first(nlf0), _first(nlf1))
 
     def _check_mode(self):
-        if self._is_training is True:
-            raise NotImplementedError(
-                "is_training=True (batch-statistics BN, layers.py:388-398) is not on the fused eval path; "
-                "construct NoiseFlow with is_training=False")
+        if self._is_training not in (True, False):
+            raise NotImplementedError("is_training must be a Python bool (the reference's placeholder is fed per run; "
+                                      "construct one NoiseFlow per mode)")
+
+    def _moments_buffer(self):
+        n = len(self._flow.coupling_scopes)
+        return np.zeros((max(n, 1), 4, self._flow.width), np.float32)
+
+    def _apply_bn_ema(self, moments: np.ndarray) -> None:
+        """layers.py:392-393: ``train_m -= decay*(train_m - m)`` (same for the variance) with the
+        batch moments the call just used; the handle itself never reads the running statistics
+        in this mode, so only :attr:`variables` (what ``save`` writes) moves."""
+        decay = np.float32(0.1)
+        with self._lock:
+            for row, scope in enumerate(self._flow.coupling_scopes):
+                for k, name in enumerate(("bn_nvp_conv_1/mean", "bn_nvp_conv_1/var",
+                                          "bn_nvp_conv_2/mean", "bn_nvp_conv_2/var")):
+                    key = scope + "/" + name
+                    old = np.asarray(self._variables[key], np.float32)
+                    self._variables[key] = (old - decay * (old - moments[row, k].reshape(old.shape))).astype(np.float32)
 
     def _run_nll(self, x, y, cond, want_z: bool, flags: int = 0, want_sums: bool = False):
         dev = self._dev
@@ -218,11 +241,16 @@ class NoiseFlow(object):
         ld = dev.empty((B,))
         z = dev.empty(xt.shape) if want_z else None
         sums = torch.zeros((3,), dtype=torch.float64, device=dev.device) if want_sums else None
-        with torch.cuda.device(dev.device):
-            _lib.check(self._flow.lib.nf_nll(
-                self._flow.ptr, xt.data_ptr(), yt.data_ptr() if yt is not None else None, B, C.byref(cond),
+        args = (self._flow.ptr, xt.data_ptr(), yt.data_ptr() if yt is not None else None, B, C.byref(cond),
                 nll.data_ptr(), sd.data_ptr(), ld.data_ptr(), z.data_ptr() if z is not None else None,
-                sums.data_ptr() if sums is not None else None, flags, dev.stream_ptr()))
+                sums.data_ptr() if sums is not None else None, flags)
+        with torch.cuda.device(dev.device):
+            if self._is_training:
+                mom = self._moments_buffer()
+                _lib.check(self._flow.lib.nf_nll_batchstats(*args, mom.ctypes.data, dev.stream_ptr()))
+                self._apply_bn_ema(mom)
+            else:
+                _lib.check(self._flow.lib.nf_nll(*args, dev.stream_ptr()))
         return nll, sd, ld, z, sums, was_np
 
     # ------------------------------------------------------------------ NLL direction
@@ -277,10 +305,15 @@ class NoiseFlow(object):
         if sums is None:
             sums = torch.zeros((3,), dtype=torch.float64, device=dev.device)
         cond = self._cond(nlf0, nlf1, iso, cam)
+        args = (self._flow.ptr, xt.data_ptr(), yt.data_ptr() if yt is not None else None, int(xt.shape[0]),
+                C.byref(cond), None, None, None, None, sums.data_ptr(), flags)
         with torch.cuda.device(dev.device):
-            _lib.check(self._flow.lib.nf_nll(self._flow.ptr, xt.data_ptr(), yt.data_ptr() if yt is not None else None,
-                                             int(xt.shape[0]), C.byref(cond), None, None, None, None,
-                                             sums.data_ptr(), flags, dev.stream_ptr()))
+            if self._is_training:
+                mom = self._moments_buffer()
+                _lib.check(self._flow.lib.nf_nll_batchstats(*args, mom.ctypes.data, dev.stream_ptr()))
+                self._apply_bn_ema(mom)
+            else:
+                _lib.check(self._flow.lib.nf_nll(*args, dev.stream_ptr()))
         return sums
 
     # ------------------------------------------------------------------ sampling direction
@@ -321,10 +354,15 @@ class NoiseFlow(object):
             with self._lock:
                 base = self._draws
                 self._draws += B
+        args = (self._flow.ptr, yt.data_ptr() if yt is not None else None, zt.data_ptr() if z_is_eps else None,
+                sd & _U64, base, float(temp), B, C.byref(cond), out.data_ptr())
         with dev.torch.cuda.device(dev.device):
-            _lib.check(self._flow.lib.nf_sample(
-                self._flow.ptr, yt.data_ptr() if yt is not None else None, zt.data_ptr() if z_is_eps else None,
-                sd & _U64, base, float(temp), B, C.byref(cond), out.data_ptr(), dev.stream_ptr()))
+            if self._is_training:
+                mom = self._moments_buffer()
+                _lib.check(self._flow.lib.nf_sample_batchstats(*args, mom.ctypes.data, dev.stream_ptr()))
+                self._apply_bn_ema(mom)
+            else:
+                _lib.check(self._flow.lib.nf_sample(*args, dev.stream_ptr()))
         return dev.back(out, was_np)
 
 

@@ -158,14 +158,22 @@ def batch_norm(h, mean, var, training: bool):
     return (h - mean) / np.sqrt(var + dt(BN_EPS)), mean, var
 
 
-def coupling_cnn(z0: np.ndarray, p: Dict[str, np.ndarray], training: bool = False):
-    """real_nvp_conv_template._fn, layers.py:463-497 → (shift, raw_log_scale)."""
+def coupling_cnn(z0: np.ndarray, p: Dict[str, np.ndarray], training: bool = False, record=None):
+    """real_nvp_conv_template._fn, layers.py:463-497 → (shift, raw_log_scale).
+    ``record`` (a dict, training mode) receives the batch moments used and the EMA-updated
+    running statistics the reference's assign_sub ops would leave behind (layers.py:392-393)."""
     dt = z0.dtype.type
     h = conv2d_nhwc(z0, p["l_1/W"], True) + p["l_1/b"].reshape(1, 1, 1, -1)       # :469, 586-613
-    h, _, _ = batch_norm(h, p["bn1/mean"], p["bn1/var"], training)               # :472-477
+    if training and record is not None:
+        record["mean1"], record["var1"] = h.mean(axis=(0, 1, 2)), h.var(axis=(0, 1, 2))
+    h, nm1, nv1 = batch_norm(h, p["bn1/mean"], p["bn1/var"], training)           # :472-477
     h = np.maximum(h, dt(0))                                                     # :478
     h = conv2d_nhwc(h, p["l_2/W"], True) + p["l_2/b"].reshape(1, 1, 1, -1)        # :480
-    h, _, _ = batch_norm(h, p["bn2/mean"], p["bn2/var"], training)               # :483-488
+    if training and record is not None:
+        record["mean2"], record["var2"] = h.mean(axis=(0, 1, 2)), h.var(axis=(0, 1, 2))
+    h, nm2, nv2 = batch_norm(h, p["bn2/mean"], p["bn2/var"], training)           # :483-488
+    if training and record is not None:
+        record.update(new_mean1=nm1, new_var1=nv1, new_mean2=nm2, new_var2=nv2)
     h = np.maximum(h, dt(0))                                                     # :489
     o = conv2d_nhwc(add_edge_padding(h), p["l_last/W"], False)                   # :491, 651-666
     o = o + p["l_last/b"].reshape(1, 1, 1, -1)                                   # :670
@@ -210,21 +218,21 @@ def coupling_cnn_fp16(z0: np.ndarray, p: Dict[str, np.ndarray]):
 # ----------------------------------------------------------------------------
 # bijectors
 # ----------------------------------------------------------------------------
-def affine_coupling_inverse(z, p, training=False, cnn_fp16=False):
+def affine_coupling_inverse(z, p, training=False, cnn_fp16=False, record=None):
     """AffineCoupling._inverse_and_log_det_jacobian, layers.py:355-375 (NLL direction)."""
     c2 = z.shape[-1] // 2
     z0, z1 = z[..., :c2], z[..., c2:]
-    shift, raw = coupling_cnn_fp16(z0, p) if cnn_fp16 else coupling_cnn(z0, p, training)
+    shift, raw = coupling_cnn_fp16(z0, p) if cnn_fp16 else coupling_cnn(z0, p, training, record)
     ls = p["rescaling_scale"] * np.tanh(raw)
     x1 = z1 * np.exp(ls) + shift
     return np.concatenate([z0, x1], axis=-1), ls.sum(axis=(1, 2, 3))
 
 
-def affine_coupling_forward(x, p, training=False, cnn_fp16=False):
+def affine_coupling_forward(x, p, training=False, cnn_fp16=False, record=None):
     """AffineCoupling._forward, layers.py:275-291 (sampling direction)."""
     c2 = x.shape[-1] // 2
     x0, x1 = x[..., :c2], x[..., c2:]
-    shift, raw = coupling_cnn_fp16(x0, p) if cnn_fp16 else coupling_cnn(x0, p, training)
+    shift, raw = coupling_cnn_fp16(x0, p) if cnn_fp16 else coupling_cnn(x0, p, training, record)
     ls = p["rescaling_scale"] * np.tanh(raw)
     y1 = (x1 - shift) * np.exp(-ls)
     return np.concatenate([x0, y1], axis=-1)
@@ -475,6 +483,14 @@ class NoiseFlowOracle:
         self.sidd_cond = sidd_cond
         self.layers = bind_variables(arch, variables, binding, dtype)
 
+    def _record(self, L, training):
+        """Training mode: ``last_batch_moments[layer name]`` ← the moments of the latest call."""
+        if not training:
+            return None
+        if not hasattr(self, "last_batch_moments"):
+            self.last_batch_moments = {}
+        return self.last_batch_moments.setdefault(L["name"], {})
+
     # -- NLL direction: NoiseFlow.inverse, noise_flow_model.py:394-428 --------
     def inverse(self, x, y=None, iso=None, cam=None, training=False, return_layers=False):
         dt = self.dtype
@@ -486,7 +502,7 @@ class NoiseFlowOracle:
             if L["type"] == "conv1x1":
                 z, ld = conv1x1_inverse(z, L["A"], L["log_abs_det"])
             elif L["type"] == "coupling":
-                z, ld = affine_coupling_inverse(z, L["p"], training, self.cnn_fp16)
+                z, ld = affine_coupling_inverse(z, L["p"], training, self.cnn_fp16, self._record(L, training))
             elif L["type"] == "sdn5":
                 z, ld = sdn_ex5_inverse(z, y, L["p"], iso, cam)
             elif L["type"] in ("sdn4", "sdn"):
@@ -527,7 +543,7 @@ class NoiseFlowOracle:
             if L["type"] == "conv1x1":
                 x = conv1x1_forward(x, L["A_inv"])
             elif L["type"] == "coupling":
-                x = affine_coupling_forward(x, L["p"], training, self.cnn_fp16)
+                x = affine_coupling_forward(x, L["p"], training, self.cnn_fp16, self._record(L, training))
             elif L["type"] == "sdn5":
                 x = sdn_ex5_forward(x, y, L["p"], iso, cam)
             elif L["type"] == "sdn4":
