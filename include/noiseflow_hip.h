@@ -166,6 +166,42 @@ int nf_sample_batchstats(nf_handle *h, const float *y, const float *eps, uint64_
                          int64_t patch_index_base, float temp, int64_t B, const nf_cond *cond,
                          float *x_out, float *moments_out, void *stream);
 
+/* ---- Training step ------------------------------------------------------
+ * Replaces `sess.run([train_op, loss, sd_z], {..., is_training: True})` (train_noise_flow.py:64-66)
+ * with `train_op = AdamOptimizer(lr, 0.9, 0.999, 1e-8).minimize(loss)` or
+ * `MomentumOptimizer(lr, 0.9).minimize(loss)` (train_noise_flow.py:187-198): forward in the NLL
+ * direction with batch-statistics BN, loss = mean_b nll_b, its gradient w.r.t. every trainable
+ * variable, the BN running-statistics EMA (layers.py:392-393) and the optimizer update.  The
+ * trainer owns a device-resident copy of the RAW parameters (layout of nf_create), the optimizer
+ * slots and an activation workspace sized for `max_batch` patches; a step only enqueues kernels on
+ * `stream` (no allocation, no synchronisation).  One stream at a time per trainer.
+ * Layers: CONV1X1, COUPLING (width 4/8/16/32), SDN5, GAIN4; fp32 (nf_config.flags must be 0).
+ * Trainable = everything except P / sign_S of CONV1X1, the BN statistics and c_i of SDN5. */
+typedef struct nf_trainer nf_trainer;
+#define NF_OPT_ADAM     0
+#define NF_OPT_MOMENTUM 1
+
+int nf_trainer_create(const nf_config *cfg, const nf_layer_desc *layers, const float *params,
+                      size_t n_params, int64_t max_batch, int32_t optimizer, nf_trainer **out);
+int nf_trainer_destroy(nf_trainer *t);
+
+/* Forward + backward of one minibatch (1 <= B <= max_batch); moves the BN running statistics.
+ *   grads_out  DEVICE float[n_params] in the raw layout, zeros at non-trainable positions, or NULL
+ *              to keep the gradient in the trainer (then nf_trainer_apply(t, NULL, ...) uses it).
+ *              A data-parallel caller all-reduces this buffer between the two calls.
+ *   loss_out   DEVICE float[2] = (mean_b nll_b, sd_z) or NULL  */
+int nf_trainer_forward_backward(nf_trainer *t, const float *x, const float *y, int64_t B,
+                                const nf_cond *cond, float *grads_out, float *loss_out, void *stream);
+/* One optimizer update from `grads` (DEVICE float[n_params]; NULL = the trainer's own buffer). */
+int nf_trainer_apply(nf_trainer *t, const float *grads, float lr, void *stream);
+/* = nf_trainer_forward_backward(..., NULL, loss_out) + nf_trainer_apply(t, NULL, lr). */
+int nf_trainer_step(nf_trainer *t, const float *x, const float *y, int64_t B, const nf_cond *cond,
+                    float lr, float *loss_out, void *stream);
+/* Copy the current raw parameters to / from HOST memory (synchronises `stream`). */
+int nf_trainer_get_params(nf_trainer *t, float *params_out, size_t n_params, void *stream);
+int nf_trainer_set_params(nf_trainer *t, const float *params, size_t n_params, void *stream);
+int64_t nf_trainer_steps(const nf_trainer *t);   /* optimizer updates applied so far */
+
 /* Counter-based synthetic SIDD-like patches, identical for any sharding:
  *   y_k ~ U[0,1)^(HxWx4),  x_k = eps * sqrt(beta1*y_k + beta2),  eps ~ N(0,1),
  * keyed by (seed, global patch index k = patch_index_base + b, pixel). */

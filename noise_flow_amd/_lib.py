@@ -92,6 +92,23 @@ def load() -> C.CDLL:
     lib.nf_nll_batchstats.argtypes = [vp, vp, vp, i64, C.POINTER(nf_cond), vp, vp, vp, vp, vp, u32, vp, vp]
     lib.nf_sample_batchstats.restype = C.c_int
     lib.nf_sample_batchstats.argtypes = [vp, vp, vp, u64, i64, f32, i64, C.POINTER(nf_cond), vp, vp, vp]
+    lib.nf_trainer_create.restype = C.c_int
+    lib.nf_trainer_create.argtypes = [C.POINTER(nf_config), C.POINTER(nf_layer_desc), C.POINTER(C.c_float), C.c_size_t,
+                                      i64, i32, C.POINTER(vp)]
+    lib.nf_trainer_destroy.restype = C.c_int
+    lib.nf_trainer_destroy.argtypes = [vp]
+    lib.nf_trainer_forward_backward.restype = C.c_int
+    lib.nf_trainer_forward_backward.argtypes = [vp, vp, vp, i64, C.POINTER(nf_cond), vp, vp, vp]
+    lib.nf_trainer_apply.restype = C.c_int
+    lib.nf_trainer_apply.argtypes = [vp, vp, f32, vp]
+    lib.nf_trainer_step.restype = C.c_int
+    lib.nf_trainer_step.argtypes = [vp, vp, vp, i64, C.POINTER(nf_cond), f32, vp, vp]
+    lib.nf_trainer_get_params.restype = C.c_int
+    lib.nf_trainer_get_params.argtypes = [vp, vp, C.c_size_t, vp]
+    lib.nf_trainer_set_params.restype = C.c_int
+    lib.nf_trainer_set_params.argtypes = [vp, vp, C.c_size_t, vp]
+    lib.nf_trainer_steps.restype = i64
+    lib.nf_trainer_steps.argtypes = [vp]
     lib.nf_synth_patches.restype = C.c_int
     lib.nf_synth_patches.argtypes = [u64, i64, i64, i32, i32, f32, f32, vp, vp, vp]
     lib.nf_fold_params.restype = C.c_int
@@ -116,4 +133,8 @@ EXPORTED_SYMBOLS = (
     "nf_abi_version", "nf_last_error", "nf_layer_param_count", "nf_create", "nf_destroy", "nf_nll",
     "nf_sample", "nf_synth_patches", "nf_fold_params", "nf_sdn5_scalars",
     "nf_nll_batchstats", "nf_sample_batchstats",
+    "nf_trainer_create", "nf_trainer_destroy", "nf_trainer_forward_backward", "nf_trainer_apply", "nf_trainer_step",
+    "nf_trainer_get_params", "nf_trainer_set_params", "nf_trainer_steps",
 )
+NF_OPT_ADAM = 0
+NF_OPT_MOMENTUM = 1

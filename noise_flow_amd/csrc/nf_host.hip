@@ -20,6 +20,7 @@
 
 #include "../../include/noiseflow_hip.h"
 #include "nf_device.h"
+#include "nf_internal.h"
 
 hipError_t nf_launch_flow(const NfProgram &prog, const NfLaunch &a, int n_cu, hipStream_t stream, bool matrix_core);
 hipError_t nf_launch_synth(uint64_t seed, int64_t patch_base, int64_t B, int HW, float beta1, float beta2,
@@ -551,6 +552,18 @@ struct DeviceGuard {
 };
 
 }  // namespace
+
+int nf_fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    return fail(code, "%s", buf);
+}
+
+int nf_fail_hip(hipError_t e, const char *what) { return fail_hip(e, what); }
 
 struct nf_handle {
     nf_config cfg;

@@ -1,0 +1,8 @@
+// Host-side helpers shared by the translation units of libnoiseflow_hip.so (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// record a thread-local error message (returned by nf_last_error) and hand back `code`
+int nf_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+int nf_fail_hip(hipError_t e, const char *what);

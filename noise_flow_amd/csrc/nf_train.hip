@@ -1,0 +1,1328 @@
+// Training step of the Noise Flow stack on gfx950: forward in the NLL direction with
+// batch-statistics BN, backward, BN running-statistics EMA and the optimizer update — everything
+// device-resident and stream-ordered (no host synchronisation inside a step).
+//
+// Reference call sites replaced (paths relative to /root/reference):
+//   train_noise_flow.py:64-66     sess.run([train_op, loss, sd_z], {..., is_training: True})
+//   train_noise_flow.py:187-198   tf.train.AdamOptimizer(lr, 0.9, 0.999, 1e-8) / MomentumOptimizer(lr, 0.9)
+//   noise_flow_model.py:394-428, 458-484   inverse + loss (the differentiated function)
+//   layers.py:355-375, 463-497, 378-401    AffineCoupling, its CNN, batch_norm(training=True) + EMA
+//   layers.py:117-130, matrix_param.py:100-140   Conv2d1x1 through its PLU parameters
+//   AffineCouplingSdnEx5.py:118-132 + cond_utils.py:205-239, AffineCouplingGainEx4.py:114-127
+//
+// Structure.  Batch-statistics BN couples all patches of the minibatch at 16 points of the forward
+// pass and 16 of the backward pass, so a step is a sequence of layer kernels over HBM-resident
+// activations ([B,H,W,C] fp32, NHWC, one thread per pixel) rather than one fused per-patch kernel;
+// at the reference's minibatch sizes (138 patches = 2.3 MB per tensor) every tensor lives in the
+// L2 / Infinity Cache and a step is bound by kernel-launch latency, not by HBM.  Per-channel and
+// per-parameter sums are reduced in registers -> wavefront shuffles -> fp64 atomics; the BN
+// finalisers, the PLU / sdn5 chain rule and the optimizer run as tiny device kernels so the host
+// only enqueues.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+#include <algorithm>
+#include <new>
+#include <vector>
+
+#include "../../include/noiseflow_hip.h"
+#include "nf_internal.h"
+
+namespace {
+
+constexpr int TB = 256;                 // threads per block of the pixel kernels
+constexpr float kBnEps = 1e-4f;         // layers.py:378
+constexpr float kBnDecay = 0.1f;        // layers.py:378
+constexpr float kLogscale = 3.0f;       // layers.py:653
+constexpr int kMaxLayers = 64;
+
+struct Geo {
+    int B, H, W, HW;
+    int64_t npix;    // B*H*W
+    int64_t nloop;   // npix rounded up to a multiple of 64: whole wavefronts iterate together
+};
+
+struct TLayer {
+    int type;    // NF_LAYER_*
+    int width;
+    int off;     // offset of the layer's raw parameters (floats)
+    int aux;     // index among the layers of the same type
+};
+
+struct TLayers {
+    int n;
+    TLayer l[kMaxLayers];
+};
+
+__device__ __forceinline__ float wsum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// add `v` into the fp64 accumulator (one atomic per wavefront)
+__device__ __forceinline__ void acc_add(double *dst, float v)
+{
+    const float s = wsum(v);
+    if ((threadIdx.x & 63) == 0) atomicAdd(dst, (double)s);
+}
+
+// per-patch accumulator: wavefronts that sit inside one patch reduce first
+__device__ __forceinline__ void patch_add(float *arr, int b, bool valid, float v)
+{
+    const int b0 = __shfl(b, 0);
+    if (__all(!valid || b == b0)) {
+        const float s = wsum(valid ? v : 0.0f);
+        if ((threadIdx.x & 63) == 0 && b0 >= 0) atomicAdd(&arr[b0], s);
+    } else if (valid) {
+        atomicAdd(&arr[b], v);
+    }
+}
+
+#define NF_PIXEL_LOOP(g, p) \
+    for (int64_t p = (int64_t)blockIdx.x * TB + threadIdx.x; p < (g).nloop; p += (int64_t)gridDim.x * TB)
+
+// ---------------------------------------------------------------------------------------------
+// per-step scalar preparation: A = P L U, sdn5 (a, b), constant log-det
+// ---------------------------------------------------------------------------------------------
+// vector element -> matrix entry of tfdist.fill_triangular padded to a strict triangle
+// (matrix_param.py:31-56); the same table as fold_conv1x1 in nf_host.hip
+__device__ const int kLr[6] = {3, 3, 3, 1, 2, 2}, kLc[6] = {2, 1, 0, 0, 1, 0};
+__device__ const int kUr[6] = {0, 0, 0, 2, 1, 1}, kUc[6] = {1, 2, 3, 3, 2, 3};
+
+__device__ void plu_matrices(const float *p, double Pm[4][4], double L[4][4], double U[4][4])
+{
+    const float *sign_s = p + 16, *log_s = p + 20, *lv = p + 24, *uv = p + 30;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            Pm[i][j] = p[i * 4 + j];
+            L[i][j] = i == j ? 1.0 : 0.0;
+            U[i][j] = 0.0;
+        }
+    for (int k = 0; k < 6; ++k) {
+        L[kLr[k]][kLc[k]] = lv[k];
+        U[kUr[k]][kUc[k]] = uv[k];
+    }
+    for (int i = 0; i < 4; ++i) U[i][i] = (double)sign_s[i] * exp((double)log_s[i]);
+}
+
+struct CondIdx {
+    float iso;
+    int iso_idx;   // index into gain_params or -1 (unknown ISO -> 0, cond_utils.py:227-229)
+    int cam_idx;   // 0..4
+};
+
+__device__ void sdn5_eval(const float *sp, CondIdx ci, double &a, double &b)
+{
+    const double c_i = sp[22];
+    double cp[3];
+    for (int r = 0; r < 3; ++r) cp[r] = exp(c_i * (double)sp[7 + r * 5 + ci.cam_idx]);
+    const double g = ci.iso_idx >= 0 ? (double)sp[2 + ci.iso_idx] : 0.0;
+    const double gain = exp(c_i * g * cp[2]) * (double)ci.iso;
+    a = exp(c_i * (double)sp[0] * cp[0]) / gain;
+    b = exp(c_i * (double)sp[1] * cp[1]);
+}
+
+__global__ void k_prep(TLayers ls, const float *__restrict__ P, CondIdx ci, int HW, float *__restrict__ Abuf,
+                       float *__restrict__ abbuf, double *__restrict__ ldc)
+{
+    const int l = threadIdx.x;
+    if (l >= ls.n) return;
+    const TLayer L = ls.l[l];
+    const float *p = P + L.off;
+    if (L.type == NF_LAYER_CONV1X1) {
+        double Pm[4][4], Lm[4][4], Um[4][4], LU[4][4];
+        plu_matrices(p, Pm, Lm, Um);
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) {
+                double s = 0.0;
+                for (int k = 0; k < 4; ++k) s += Lm[i][k] * Um[k][j];
+                LU[i][j] = s;
+            }
+        double lad = 0.0;
+        for (int i = 0; i < 4; ++i) {
+            lad += (double)p[20 + i];
+            for (int j = 0; j < 4; ++j) {
+                double s = 0.0;
+                for (int k = 0; k < 4; ++k) s += Pm[i][k] * LU[k][j];
+                Abuf[L.aux * 16 + i * 4 + j] = (float)s;
+            }
+        }
+        atomicAdd(ldc, (double)HW * lad);                                  // layers.py:129-130
+    } else if (L.type == NF_LAYER_SDN5) {
+        double a, b;
+        sdn5_eval(p, ci, a, b);
+        abbuf[L.aux * 2] = (float)a;
+        abbuf[L.aux * 2 + 1] = (float)b;
+    } else if (L.type == NF_LAYER_GAIN4) {
+        atomicAdd(ldc, -(double)HW * 4.0 * log((double)p[0]));             // AffineCouplingGainEx4.py:114-127
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------
+__global__ void k_sdn_fwd(Geo g, const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ ab,
+                          float *__restrict__ z, float *__restrict__ ld)
+{
+    const float a = ab[0], b = ab[1];
+    NF_PIXEL_LOOP(g, p) {
+        const bool valid = p < g.npix;
+        const int pb = valid ? (int)(p / g.HW) : -1;
+        float l = 0.0f;
+        if (valid) {
+            const float4 xv = reinterpret_cast<const float4 *>(x)[p], yv = reinterpret_cast<const float4 *>(y)[p];
+            const float s0 = sqrtf(fmaf(a, yv.x, b)), s1 = sqrtf(fmaf(a, yv.y, b)), s2 = sqrtf(fmaf(a, yv.z, b)),
+                        s3 = sqrtf(fmaf(a, yv.w, b));
+            reinterpret_cast<float4 *>(z)[p] = make_float4(xv.x / s0, xv.y / s1, xv.z / s2, xv.w / s3);
+            l = -(logf(s0) + logf(s1) + logf(s2) + logf(s3));
+        }
+        patch_add(ld, pb, valid, l);
+    }
+}
+
+__global__ void k_scale_fwd(Geo g, const float *__restrict__ zin, const float *__restrict__ gain, float *__restrict__ zout)
+{
+    const float inv = 1.0f / gain[0];
+    NF_PIXEL_LOOP(g, p) {
+        if (p < g.npix) {
+            const float4 v = reinterpret_cast<const float4 *>(zin)[p];
+            reinterpret_cast<float4 *>(zout)[p] = make_float4(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
+        }
+    }
+}
+
+__global__ void k_mix_fwd(Geo g, const float *__restrict__ zin, const float *__restrict__ A, float *__restrict__ zout)
+{
+    float m[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m[i] = A[i];
+    NF_PIXEL_LOOP(g, p) {
+        if (p < g.npix) {
+            const float4 v = reinterpret_cast<const float4 *>(zin)[p];
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = v.x * m[j] + v.y * m[4 + j] + v.z * m[8 + j] + v.w * m[12 + j];
+            reinterpret_cast<float4 *>(zout)[p] = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
+// l_1: 3x3 SAME conv of the pass-through half + bias; per-channel sum / sum of squares
+template <int W>
+__global__ void k_c1_fwd(Geo g, const float *__restrict__ zin, const float *__restrict__ P, int off, float *__restrict__ h1,
+                         double *__restrict__ stats)
+{
+    const float *W1 = P + off, *b1 = W1 + 18 * W;
+    float s[W], q[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) s[j] = q[j] = 0.0f;
+    NF_PIXEL_LOOP(g, p) {
+        if (p < g.npix) {
+            const int b = (int)(p / g.HW), rem = (int)(p - (int64_t)b * g.HW), r = rem / g.W, c = rem - r * g.W;
+            float h[W];
+#pragma unroll
+            for (int j = 0; j < W; ++j) h[j] = b1[j];
+            for (int di = 0; di < 3; ++di) {
+                const int rr = r + di - 1;
+                if (rr < 0 || rr >= g.H) continue;
+                for (int dj = 0; dj < 3; ++dj) {
+                    const int cc = c + dj - 1;
+                    if (cc < 0 || cc >= g.W) continue;
+                    const float2 v = *reinterpret_cast<const float2 *>(zin + ((int64_t)b * g.HW + rr * g.W + cc) * 4);
+                    const float *w = W1 + (di * 3 + dj) * 2 * W;
+#pragma unroll
+                    for (int j = 0; j < W; ++j) h[j] = fmaf(v.x, w[j], fmaf(v.y, w[W + j], h[j]));
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+                h1[p * W + j] = h[j];
+                s[j] += h[j];
+                q[j] = fmaf(h[j], h[j], q[j]);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+        acc_add(stats + j, s[j]);
+        acc_add(stats + W + j, q[j]);
+    }
+}
+
+// batch moments -> (mean, 1/sqrt(var+eps)); running statistics <- EMA (layers.py:388-393)
+__global__ void k_bn_finalize(int W, const double *__restrict__ stats, double n, float *__restrict__ P, int off_mean,
+                              int off_var, float *__restrict__ bn)
+{
+    const int j = threadIdx.x;
+    if (j >= W) return;
+    const double m = stats[j] / n;
+    double v = stats[W + j] / n - m * m;
+    if (v < 0.0) v = 0.0;
+    bn[j] = (float)m;
+    bn[W + j] = (float)(1.0 / sqrt(v + (double)kBnEps));
+    P[off_mean + j] -= kBnDecay * (P[off_mean + j] - (float)m);
+    P[off_var + j] -= kBnDecay * (P[off_var + j] - (float)v);
+}
+
+// BN1 + ReLU + l_2 (1x1) + bias; statistics of the result
+template <int W>
+__global__ void k_c2_fwd(Geo g, const float *__restrict__ h1, const float *__restrict__ bn1, const float *__restrict__ P,
+                         int off_w2, float *__restrict__ h2, double *__restrict__ stats)
+{
+    const float *W2 = P + off_w2, *b2 = W2 + W * W;
+    float s[W], q[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) s[j] = q[j] = 0.0f;
+    NF_PIXEL_LOOP(g, p) {
+        if (p < g.npix) {
+            float h[W];
+#pragma unroll
+            for (int j = 0; j < W; ++j) h[j] = b2[j];
+#pragma unroll
+            for (int i = 0; i < W; ++i) {
+                const float a = fmaxf((h1[p * W + i] - bn1[i]) * bn1[W + i], 0.0f);
+#pragma unroll
+                for (int j = 0; j < W; ++j) h[j] = fmaf(a, W2[i * W + j], h[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+                h2[p * W + j] = h[j];
+                s[j] += h[j];
+                q[j] = fmaf(h[j], h[j], q[j]);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+        acc_add(stats + j, s[j]);
+        acc_add(stats + W + j, q[j]);
+    }
+}
+
+// the l_last pre-activation u = conv3x3_VALID(pad(relu(bn2(h2))) ++ edge) + b  (layers.py:491, 555-583, 651-670)
+template <int W>
+__device__ __forceinline__ void l_last_u(const Geo &g, int b, int r, int c, const float *__restrict__ h2,
+                                         const float *__restrict__ bn2, const float *__restrict__ W3,
+                                         const float *__restrict__ b3, float u[4])
+{
+#pragma unroll
+    for (int k = 0; k < 4; ++k) u[k] = b3[k];
+    for (int di = 0; di < 3; ++di) {
+        const int rr = r + di - 1;
+        for (int dj = 0; dj < 3; ++dj) {
+            const int cc = c + dj - 1;
+            const float *w = W3 + (di * 3 + dj) * (W + 1) * 4;
+            if (rr < 0 || rr >= g.H || cc < 0 || cc >= g.W) {   // on the padding ring: zeros + indicator 1
+#pragma unroll
+                for (int k = 0; k < 4; ++k) u[k] += w[W * 4 + k];
+            } else {
+                const float *hp = h2 + ((int64_t)b * g.HW + rr * g.W + cc) * W;
+#pragma unroll
+                for (int i = 0; i < W; ++i) {
+                    const float a = fmaxf((hp[i] - bn2[i]) * bn2[W + i], 0.0f);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) u[k] = fmaf(a, w[i * 4 + k], u[k]);
+                }
+            }
+        }
+    }
+}
+
+// BN2 + ReLU + l_last + affine transform of the second half (layers.py:355-375)
+template <int W>
+__global__ void k_c3_fwd(Geo g, const float *__restrict__ zin, const float *__restrict__ h2, const float *__restrict__ bn2,
+                         const float *__restrict__ P, int off_w3, float *__restrict__ zout, float *__restrict__ ld)
+{
+    const float *W3 = P + off_w3, *b3 = W3 + 36 * (W + 1), *logs = b3 + 4;
+    const float sc = logs[4];
+    NF_PIXEL_LOOP(g, p) {
+        const bool valid = p < g.npix;
+        const int b = valid ? (int)(p / g.HW) : -1;
+        float l = 0.0f;
+        if (valid) {
+            const int rem = (int)(p - (int64_t)b * g.HW), r = rem / g.W, c = rem - r * g.W;
+            float u[4];
+            l_last_u<W>(g, b, r, c, h2, bn2, W3, b3, u);
+            const float4 zi = reinterpret_cast<const float4 *>(zin)[p];
+            const float sh0 = u[0] * expf(kLogscale * logs[0]), sh1 = u[1] * expf(kLogscale * logs[1]);
+            const float ls0 = sc * tanhf(u[2] * expf(kLogscale * logs[2])), ls1 = sc * tanhf(u[3] * expf(kLogscale * logs[3]));
+            reinterpret_cast<float4 *>(zout)[p] = make_float4(zi.x, zi.y, fmaf(zi.z, expf(ls0), sh0), fmaf(zi.w, expf(ls1), sh1));
+            l = ls0 + ls1;
+        }
+        patch_add(ld, b, valid, l);
+    }
+}
+
+__global__ void k_prior(Geo g, const float *__restrict__ z, float *__restrict__ s1, float *__restrict__ s2)
+{
+    NF_PIXEL_LOOP(g, p) {
+        const bool valid = p < g.npix;
+        const int b = valid ? (int)(p / g.HW) : -1;
+        float a = 0.0f, q = 0.0f;
+        if (valid) {
+            const float4 v = reinterpret_cast<const float4 *>(z)[p];
+            a = v.x + v.y + v.z + v.w;
+            q = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+        patch_add(s1, b, valid, a);
+        patch_add(s2, b, valid, q);
+    }
+}
+
+// loss = mean_b nll_b, sd_z = mean_b sqrt(var_hwc z_b)   (noise_flow_model.py:458-484)
+__global__ void k_loss(int B, double n, const float *__restrict__ ld, const float *__restrict__ s1,
+                       const float *__restrict__ s2, const double *__restrict__ ldc, float *__restrict__ out)
+{
+    __shared__ double sh[2][TB];
+    double a = 0.0, d = 0.0;
+    for (int b = threadIdx.x; b < B; b += TB) {
+        a += -((double)ld[b] + ldc[0]) + 0.5 * n * 1.8378770664093453 + 0.5 * (double)s2[b];
+        const double m = (double)s1[b] / n;
+        double v = (double)s2[b] / n - m * m;
+        d += sqrt(v > 0.0 ? v : 0.0);
+    }
+    sh[0][threadIdx.x] = a;
+    sh[1][threadIdx.x] = d;
+    __syncthreads();
+    for (int o = TB / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
+            sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[0] = (float)(sh[0][0] / B);
+        out[1] = (float)(sh[1][0] / B);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------------
+// d loss / d z of the prior term: z / B
+__global__ void k_dz_init(Geo g, const float *__restrict__ z, float invB, float *__restrict__ dz)
+{
+    NF_PIXEL_LOOP(g, p) {
+        if (p < g.npix) {
+            const float4 v = reinterpret_cast<const float4 *>(z)[p];
+            reinterpret_cast<float4 *>(dz)[p] = make_float4(v.x * invB, v.y * invB, v.z * invB, v.w * invB);
+        }
+    }
+}
+
+// gain4: z_out = z_in / g
+__global__ void k_scale_bwd(Geo g, const float *__restrict__ zout, const float *__restrict__ gain, float *__restrict__ dz,
+                            double *__restrict__ dgain)
+{
+    const float inv = 1.0f / gain[0];
+    float acc = 0.0f;
+    NF_PIXEL_LOOP(g, p) {
+        if (p < g.npix) {
+            const float4 d = reinterpret_cast<const float4 *>(dz)[p], z = reinterpret_cast<const float4 *>(zout)[p];
+            acc -= (d.x * z.x + d.y * z.y + d.z * z.z + d.w * z.w) * inv;
+            reinterpret_cast<float4 *>(dz)[p] = make_float4(d.x * inv, d.y * inv, d.z * inv, d.w * inv);
+        }
+    }
+    acc_add(dgain, acc);
+}
+
+// sdn5: z = x / sqrt(a y + b), loss += (1/B) sum log scale
+__global__ void k_sdn_bwd(Geo g, const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ ab,
+                          float invB, float *__restrict__ dz, double *__restrict__ dab)
+{
+    const float a = ab[0], b = ab[1];
+    float ga = 0.0f, gb = 0.0f;
+    NF_PIXEL_LOOP(g, p) {
+        if (p < g.npix) {
+            const float4 xv = reinterpret_cast<const float4 *>(x)[p], yv = reinterpret_cast<const float4 *>(y)[p];
+            float4 d = reinterpret_cast<const float4 *>(dz)[p];
+            const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ys[4] = {yv.x, yv.y, yv.z, yv.w};
+            float ds[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float s2 = fmaf(a, ys[k], b), is = rsqrtf(s2);
+                // d loss / d scale = -dz x / scale^2 + invB / scale ;  d scale / d(a,b) = (y, 1) / (2 scale)
+                const float gs = (-ds[k] * xs[k] / s2 + invB * is) * 0.5f * is;
+                ga = fmaf(gs, ys[k], ga);
+                gb += gs;
+                ds[k] *= is;
+            }
+            reinterpret_cast<float4 *>(dz)[p] = make_float4(ds[0], ds[1], ds[2], ds[3]);
+        }
+    }
+    acc_add(dab, ga);
+    acc_add(dab + 1, gb);
+}
+
+// 1x1 mix: z_out = z_in A
+__global__ void k_mix_bwd(Geo g, const float *__restrict__ zin, const float *__restrict__ A, float *__restrict__ dz,
+                          double *__restrict__ dA)
+{
+    float m[16], acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        m[i] = A[i];
+        acc[i] = 0.0f;
+    }
+    NF_PIXEL_LOOP(g, p) {
+        if (p < g.npix) {
+            const float4 zv = reinterpret_cast<const float4 *>(zin)[p], dv = reinterpret_cast<const float4 *>(dz)[p];
+            const float zi[4] = {zv.x, zv.y, zv.z, zv.w}, d[4] = {dv.x, dv.y, dv.z, dv.w};
+            float o[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                o[i] = m[i * 4] * d[0] + m[i * 4 + 1] * d[1] + m[i * 4 + 2] * d[2] + m[i * 4 + 3] * d[3];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i * 4 + j] = fmaf(zi[i], d[j], acc[i * 4 + j]);
+            }
+            reinterpret_cast<float4 *>(dz)[p] = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc_add(dA + i, acc[i]);
+}
+
+// coupling, stage 1: through the affine transform, tanh, exp(3 logs); leaves d loss / d u in `gu`,
+// d loss / d z1 in dz[2:4]; accumulates d rescaling_scale, d logs, d l_last/b
+template <int W>
+__global__ void k_c3_bwd(Geo g, const float *__restrict__ zin, const float *__restrict__ h2, const float *__restrict__ bn2,
+                         const float *__restrict__ P, int off_w3, float invB, float *__restrict__ dz,
+                         float *__restrict__ gu, double *__restrict__ G)
+{
+    const float *W3 = P + off_w3, *b3 = W3 + 36 * (W + 1), *logs = b3 + 4;
+    const float sc = logs[4];
+    const int off_b3 = off_w3 + 36 * (W + 1);
+    float e3[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) e3[k] = expf(kLogscale * logs[k]);
+    float g_s = 0.0f, g_logs[4] = {0.f, 0.f, 0.f, 0.f}, g_b3[4] = {0.f, 0.f, 0.f, 0.f};
+    NF_PIXEL_LOOP(g, p) {
+        if (p < g.npix) {
+            const int b = (int)(p / g.HW), rem = (int)(p - (int64_t)b * g.HW), r = rem / g.W, c = rem - r * g.W;
+            float u[4];
+            l_last_u<W>(g, b, r, c, h2, bn2, W3, b3, u);
+            const float4 zi = reinterpret_cast<const float4 *>(zin)[p];
+            float4 d = reinterpret_cast<const float4 *>(dz)[p];
+            const float z1[2] = {zi.z, zi.w}, gx1[2] = {d.z, d.w};
+            float go[4], o[4], gz1[2];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = u[k] * e3[k];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const float t = tanhf(o[2 + k]), E = expf(sc * t);
+                gz1[k] = gx1[k] * E;
+                const float gls = gx1[k] * z1[k] * E - invB;   // loss = mean(-(sum ls + ...))
+                g_s = fmaf(gls, t, g_s);
+                go[k] = gx1[k];                              // shift
+                go[2 + k] = gls * sc * (1.0f - t * t);       // raw
+            }
+            float guv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                g_logs[k] = fmaf(kLogscale * go[k], o[k], g_logs[k]);
+                guv[k] = go[k] * e3[k];
+                g_b3[k] += guv[k];
+            }
+            reinterpret_cast<float4 *>(gu)[p] = make_float4(guv[0], guv[1], guv[2], guv[3]);
+            d.z = gz1[0];
+            d.w = gz1[1];
+            reinterpret_cast<float4 *>(dz)[p] = d;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        acc_add(G + off_b3 + k, g_b3[k]);
+        acc_add(G + off_b3 + 4 + k, g_logs[k]);
+    }
+    acc_add(G + off_b3 + 8, g_s);
+}
+
+// d l_last/W: one filter tap per blockIdx.y
+template <int W>
+__global__ void k_w3_grad(Geo g, const float *__restrict__ h2, const float *__restrict__ bn2, const float *__restrict__ gu,
+                          int off_w3, double *__restrict__ G)
+{
+    const int tap = blockIdx.y, di = tap / 3, dj = tap - di * 3;
+    float acc[W + 1][4];
+#pragma unroll
+    for (int i = 0; i <= W; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[i][k] = 0.0f;
+    NF_PIXEL_LOOP(g, p) {
+        if (p < g.npix) {
+            const int b = (int)(p / g.HW), rem = (int)(p - (int64_t)b * g.HW), r = rem / g.W, c = rem - r * g.W;
+            const int rr = r + di - 1, cc = c + dj - 1;
+            const float4 gv = reinterpret_cast<const float4 *>(gu)[p];
+            const float gk[4] = {gv.x, gv.y, gv.z, gv.w};
+            if (rr < 0 || rr >= g.H || cc < 0 || cc >= g.W) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[W][k] += gk[k];
+            } else {
+                const float *hp = h2 + ((int64_t)b * g.HW + rr * g.W + cc) * W;
+#pragma unroll
+                for (int i = 0; i < W; ++i) {
+                    const float a = fmaxf((hp[i] - bn2[i]) * bn2[W + i], 0.0f);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[i][k] = fmaf(a, gk[k], acc[i][k]);
+                }
+            }
+        }
+    }
+    double *dst = G + off_w3 + tap * (W + 1) * 4;
+#pragma unroll
+    for (int i = 0; i <= W; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc_add(dst + i * 4 + k, acc[i][k]);
+}
+
+// coupling, stage 2: transposed l_last + ReLU mask -> d loss / d xhat2 (into t1) and the two
+// batch sums the BN backward needs
+template <int W>
+__global__ void k_c3_dh(Geo g, const float *__restrict__ h2, const float *__restrict__ bn2, const float *__restrict__ P,
+                        int off_w3, const float *__restrict__ gu, float *__restrict__ t1, double *__restrict__ bstats)
+{
+    const float *W3 = P + off_w3;
+    float s[W], q[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) s[j] = q[j] = 0.0f;
+    NF_PIXEL_LOOP(g, p) {
+        if (p < g.npix) {
+            const int b = (int)(p / g.HW), rem = (int)(p - (int64_t)b * g.HW), r = rem / g.W, c = rem - r * g.W;
+            float gh[W];
+#pragma unroll
+            for (int i = 0; i < W; ++i) gh[i] = 0.0f;
+            for (int di = 0; di < 3; ++di) {
+                const int qr = r - (di - 1);
+                if (qr < 0 || qr >= g.H) continue;
+                for (int dj = 0; dj < 3; ++dj) {
+                    const int qc = c - (dj - 1);
+                    if (qc < 0 || qc >= g.W) continue;
+                    const float4 gv = reinterpret_cast<const float4 *>(gu)[(int64_t)b * g.HW + qr * g.W + qc];
+                    const float *w = W3 + (di * 3 + dj) * (W + 1) * 4;
+#pragma unroll
+                    for (int i = 0; i < W; ++i)
+                        gh[i] += w[i * 4] * gv.x + w[i * 4 + 1] * gv.y + w[i * 4 + 2] * gv.z + w[i * 4 + 3] * gv.w;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < W; ++i) {
+                const float xh = (h2[p * W + i] - bn2[i]) * bn2[W + i];
+                const float gx = xh > 0.0f ? gh[i] : 0.0f;
+                t1[p * W + i] = gx;
+                s[i] += gx;
+                q[i] = fmaf(gx, xh, q[i]);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+        acc_add(bstats + j, s[j]);
+        acc_add(bstats + W + j, q[j]);
+    }
+}
+
+__global__ void k_bnb_finalize(int W, const double *__restrict__ bstats, double n, float *__restrict__ bb)
+{
+    const int j = threadIdx.x;
+    if (j >= W) return;
+    bb[j] = (float)(bstats[j] / n);
+    bb[W + j] = (float)(bstats[W + j] / n);
+}
+
+// coupling, stage 3: BN2 backward -> g_h2 (t1, in place), d l_2/b; transposed l_2 + ReLU mask ->
+// d loss / d xhat1 (t2) and its two batch sums
+template <int W>
+__global__ void k_c2_bwd(Geo g, const float *__restrict__ h1, const float *__restrict__ bn1, const float *__restrict__ h2,
+                         const float *__restrict__ bn2, const float *__restrict__ bb2, const float *__restrict__ P,
+                         int off_w2, float *__restrict__ t1, float *__restrict__ t2, double *__restrict__ bstats,
+                         double *__restrict__ G)
+{
+    const float *W2 = P + off_w2;
+    float s[W], q[W], gb[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) s[j] = q[j] = gb[j] = 0.0f;
+    NF_PIXEL_LOOP(g, p) {
+        if (p < g.npix) {
+            float gh2[W];
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+                const float xh = (h2[p * W + j] - bn2[j]) * bn2[W + j];
+                gh2[j] = bn2[W + j] * (t1[p * W + j] - bb2[j] - xh * bb2[W + j]);
+                t1[p * W + j] = gh2[j];
+                gb[j] += gh2[j];
+            }
+#pragma unroll
+            for (int i = 0; i < W; ++i) {
+                const float xh = (h1[p * W + i] - bn1[i]) * bn1[W + i];
+                float gh = 0.0f;
+#pragma unroll
+                for (int j = 0; j < W; ++j) gh = fmaf(W2[i * W + j], gh2[j], gh);
+                const float gx = xh > 0.0f ? gh : 0.0f;
+                t2[p * W + i] = gx;
+                s[i] += gx;
+                q[i] = fmaf(gx, xh, q[i]);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+        acc_add(bstats + j, s[j]);
+        acc_add(bstats + W + j, q[j]);
+        acc_add(G + off_w2 + W * W + j, gb[j]);
+    }
+}
+
+// d l_2/W: one input channel per blockIdx.y
+template <int W>
+__global__ void k_w2_grad(Geo g, const float *__restrict__ h1, const float *__restrict__ bn1, const float *__restrict__ t1,
+                          int off_w2, double *__restrict__ G)
+{
+    const int i = blockIdx.y;
+    const float m = bn1[i], rs = bn1[W + i];
+    float acc[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) acc[j] = 0.0f;
+    NF_PIXEL_LOOP(g, p) {
+        if (p < g.npix) {
+            const float a = fmaxf((h1[p * W + i] - m) * rs, 0.0f);
+#pragma unroll
+            for (int j = 0; j < W; ++j) acc[j] = fmaf(a, t1[p * W + j], acc[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < W; ++j) acc_add(G + off_w2 + i * W + j, acc[j]);
+}
+
+// coupling, stage 4: BN1 backward -> g_h1 (t2, in place), d l_1/b
+template <int W>
+__global__ void k_c1_bwd(Geo g, const float *__restrict__ h1, const float *__restrict__ bn1, const float *__restrict__ bb1,
+                         int off_b1, float *__restrict__ t2, double *__restrict__ G)
+{
+    float gb[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) gb[j] = 0.0f;
+    NF_PIXEL_LOOP(g, p) {
+        if (p < g.npix) {
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+                const float xh = (h1[p * W + j] - bn1[j]) * bn1[W + j];
+                const float gh = bn1[W + j] * (t2[p * W + j] - bb1[j] - xh * bb1[W + j]);
+                t2[p * W + j] = gh;
+                gb[j] += gh;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < W; ++j) acc_add(G + off_b1 + j, gb[j]);
+}
+
+// d l_1/W: one filter tap per blockIdx.y
+template <int W>
+__global__ void k_w1_grad(Geo g, const float *__restrict__ zin, const float *__restrict__ t2, int off_w1,
+                          double *__restrict__ G)
+{
+    const int tap = blockIdx.y, di = tap / 3, dj = tap - di * 3;
+    float acc[2][W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) acc[0][j] = acc[1][j] = 0.0f;
+    NF_PIXEL_LOOP(g, p) {
+        if (p < g.npix) {
+            const int b = (int)(p / g.HW), rem = (int)(p - (int64_t)b * g.HW), r = rem / g.W, c = rem - r * g.W;
+            const int rr = r + di - 1, cc = c + dj - 1;
+            if (rr >= 0 && rr < g.H && cc >= 0 && cc < g.W) {
+                const float2 v = *reinterpret_cast<const float2 *>(zin + ((int64_t)b * g.HW + rr * g.W + cc) * 4);
+#pragma unroll
+                for (int j = 0; j < W; ++j) {
+                    const float gh = t2[p * W + j];
+                    acc[0][j] = fmaf(v.x, gh, acc[0][j]);
+                    acc[1][j] = fmaf(v.y, gh, acc[1][j]);
+                }
+            }
+        }
+    }
+    double *dst = G + off_w1 + tap * 2 * W;
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+        acc_add(dst + j, acc[0][j]);
+        acc_add(dst + W + j, acc[1][j]);
+    }
+}
+
+// coupling, stage 5: transposed l_1 adds the CNN path into d loss / d z0
+template <int W>
+__global__ void k_c1_dz(Geo g, const float *__restrict__ t2, const float *__restrict__ P, int off_w1, float *__restrict__ dz)
+{
+    const float *W1 = P + off_w1;
+    NF_PIXEL_LOOP(g, p) {
+        if (p < g.npix) {
+            const int b = (int)(p / g.HW), rem = (int)(p - (int64_t)b * g.HW), r = rem / g.W, c = rem - r * g.W;
+            float a0 = 0.0f, a1 = 0.0f;
+            for (int di = 0; di < 3; ++di) {
+                const int qr = r - (di - 1);
+                if (qr < 0 || qr >= g.H) continue;
+                for (int dj = 0; dj < 3; ++dj) {
+                    const int qc = c - (dj - 1);
+                    if (qc < 0 || qc >= g.W) continue;
+                    const float *gh = t2 + ((int64_t)b * g.HW + qr * g.W + qc) * W;
+                    const float *w = W1 + (di * 3 + dj) * 2 * W;
+#pragma unroll
+                    for (int j = 0; j < W; ++j) {
+                        a0 = fmaf(w[j], gh[j], a0);
+                        a1 = fmaf(w[W + j], gh[j], a1);
+                    }
+                }
+            }
+            float2 *d = reinterpret_cast<float2 *>(dz + p * 4);
+            const float2 v = *d;
+            *d = make_float2(v.x + a0, v.y + a1);
+        }
+    }
+}
+
+// chain rule of the scalar parameterisations: dA -> PLU factors, d(a,b) -> sdn5 variables, gain_val
+__global__ void k_finish(TLayers ls, const float *__restrict__ P, CondIdx ci, int HW, const double *__restrict__ dAbuf,
+                         const double *__restrict__ dabbuf, const double *__restrict__ dgbuf, double *__restrict__ G)
+{
+    const int l = threadIdx.x;
+    if (l >= ls.n) return;
+    const TLayer L = ls.l[l];
+    const float *p = P + L.off;
+    double *gp = G + L.off;
+    if (L.type == NF_LAYER_CONV1X1) {
+        double Pm[4][4], Lm[4][4], Um[4][4], dM[4][4], dL[4][4], dU[4][4];
+        plu_matrices(p, Pm, Lm, Um);
+        const double *dA = dAbuf + L.aux * 16;
+        for (int i = 0; i < 4; ++i)          // dM = P^T dA   (A = P M, M = L U)
+            for (int j = 0; j < 4; ++j) {
+                double s = 0.0;
+                for (int k = 0; k < 4; ++k) s += Pm[k][i] * dA[k * 4 + j];
+                dM[i][j] = s;
+            }
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) {
+                double s = 0.0, t = 0.0;
+                for (int k = 0; k < 4; ++k) {
+                    s += dM[i][k] * Um[j][k];   // dL = dM U^T
+                    t += Lm[k][i] * dM[k][j];   // dU = L^T dM
+                }
+                dL[i][j] = s;
+                dU[i][j] = t;
+            }
+        for (int i = 0; i < 4; ++i) gp[20 + i] = dU[i][i] * Um[i][i] - (double)HW;   // log_S: diagonal + log-det term
+        for (int k = 0; k < 6; ++k) {
+            gp[24 + k] = dL[kLr[k]][kLc[k]];
+            gp[30 + k] = dU[kUr[k]][kUc[k]];
+        }
+    } else if (L.type == NF_LAYER_SDN5) {
+        double a, b;
+        sdn5_eval(p, ci, a, b);
+        const double ga = dabbuf[L.aux * 2], gb = dabbuf[L.aux * 2 + 1];
+        const double c_i = p[22];
+        double cp[3];
+        for (int r = 0; r < 3; ++r) cp[r] = exp(c_i * (double)p[7 + r * 5 + ci.cam_idx]);
+        const double beta1 = p[0], beta2 = p[1];
+        const double gpar = ci.iso_idx >= 0 ? (double)p[2 + ci.iso_idx] : 0.0;
+        gp[0] = ga * a * c_i * cp[0];
+        gp[1] = gb * b * c_i * cp[1];
+        if (ci.iso_idx >= 0) gp[2 + ci.iso_idx] = -ga * a * c_i * cp[2];
+        gp[7 + 0 * 5 + ci.cam_idx] = ga * a * c_i * c_i * beta1 * cp[0];
+        gp[7 + 1 * 5 + ci.cam_idx] = gb * b * c_i * c_i * beta2 * cp[1];
+        gp[7 + 2 * 5 + ci.cam_idx] = -ga * a * c_i * c_i * gpar * cp[2];
+    } else if (L.type == NF_LAYER_GAIN4) {
+        gp[0] = dgbuf[L.aux] + (double)HW * 4.0 / (double)p[0];
+    }
+}
+
+__global__ void k_grads_out(int n, const double *__restrict__ G, const uint8_t *__restrict__ mask, float *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = mask[i] ? (float)G[i] : 0.0f;
+}
+
+// tf.train.AdamOptimizer._apply_dense (lr_t computed by the host from the step count)
+__global__ void k_adam(int n, float *__restrict__ P, const float *__restrict__ grads, float *__restrict__ m,
+                       float *__restrict__ v, const uint8_t *__restrict__ mask, float lr_t, float b1, float b2, float eps)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && mask[i]) {
+        const float gr = grads[i];
+        const float mi = m[i] + (gr - m[i]) * (1.0f - b1);
+        const float vi = v[i] + (gr * gr - v[i]) * (1.0f - b2);
+        m[i] = mi;
+        v[i] = vi;
+        P[i] -= lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+
+// tf.train.MomentumOptimizer(lr, 0.9): accum = 0.9 accum + g; theta -= lr accum
+__global__ void k_momentum(int n, float *__restrict__ P, const float *__restrict__ grads, float *__restrict__ acc,
+                           const uint8_t *__restrict__ mask, float lr, float mom)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && mask[i]) {
+        const float a = mom * acc[i] + grads[i];
+        acc[i] = a;
+        P[i] -= lr * a;
+    }
+}
+
+struct Cpl {      // per-coupling workspace
+    float *h1 = nullptr, *h2 = nullptr;
+    int f_bn1, f_bn2, f_bb1, f_bb2;       // offsets into the float scalar buffer
+    int d_st1, d_st2, d_bs1, d_bs2;       // offsets into the double buffer
+};
+
+}  // namespace
+
+struct nf_trainer {
+    nf_config cfg;
+    int device = 0;
+    int64_t max_batch = 0;
+    int optimizer = 0;
+    int64_t step = 0;
+    int n_params = 0;
+    int width = 0;
+    std::vector<nf_layer_desc> layers;
+    TLayers tl;
+    std::vector<Cpl> cpl;           // indexed by TLayer::aux of coupling layers
+    float *d_params = nullptr, *d_m = nullptr, *d_v = nullptr, *d_gradf = nullptr;
+    uint8_t *d_mask = nullptr;
+    double *d_dbl = nullptr;        // [0,n_params) gradients, then dA / dab / dgain / BN sums / ldc
+    size_t n_dbl = 0;
+    int d_dA = 0, d_dab = 0, d_dg = 0, d_ldc = 0;
+    float *d_flt = nullptr;         // A matrices, sdn5 (a,b), BN scalars
+    size_t n_flt = 0;
+    int f_A = 0, f_ab = 0;
+    float *d_patch = nullptr;       // ld[B], s1[B], s2[B]
+    std::vector<float *> zs;        // zs[l] = input of layer l (zs[0] is the caller's x), zs[n] = latent
+    float *t1 = nullptr, *t2 = nullptr, *gu = nullptr, *dz = nullptr;
+    std::vector<void *> owned;
+    bool has_sdn = false;
+};
+
+namespace {
+
+int dev_alloc(nf_trainer *t, void **p, size_t bytes)
+{
+    hipError_t e = hipMalloc(p, bytes ? bytes : 16);
+    if (e != hipSuccess) return nf_fail_hip(e, "hipMalloc(trainer workspace)");
+    t->owned.push_back(*p);
+    return NF_OK;
+}
+
+inline unsigned blocks_for(int64_t npix)
+{
+    int64_t b = (npix + TB - 1) / TB;
+    return (unsigned)std::min<int64_t>(std::max<int64_t>(b, 1), 4096);
+}
+
+struct Guard {
+    int prev = -1;
+    bool changed = false;
+    int enter(int dev)
+    {
+        hipError_t e = hipGetDevice(&prev);
+        if (e != hipSuccess) return nf_fail_hip(e, "hipGetDevice");
+        if (prev != dev) {
+            if ((e = hipSetDevice(dev)) != hipSuccess) return nf_fail_hip(e, "hipSetDevice");
+            changed = true;
+        }
+        return NF_OK;
+    }
+    ~Guard()
+    {
+        if (changed) (void)hipSetDevice(prev);
+    }
+};
+
+template <int W>
+void coupling_forward(nf_trainer *t, const Geo &g, const TLayer &L, const float *zin, float *zout, hipStream_t st)
+{
+    const Cpl &c = t->cpl[L.aux];
+    const unsigned nb = blocks_for(g.npix);
+    const int w = W, off_w1 = L.off, off_m1 = L.off + 19 * w, off_w2 = L.off + 21 * w, off_m2 = L.off + 22 * w + w * w,
+              off_w3 = L.off + 24 * w + w * w;
+    const double n = (double)g.npix;
+    hipLaunchKernelGGL(k_c1_fwd<W>, dim3(nb), dim3(TB), 0, st, g, zin, t->d_params, off_w1, c.h1, t->d_dbl + c.d_st1);
+    hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(64), 0, st, w, t->d_dbl + c.d_st1, n, t->d_params, off_m1, off_m1 + w,
+                       t->d_flt + c.f_bn1);
+    hipLaunchKernelGGL(k_c2_fwd<W>, dim3(nb), dim3(TB), 0, st, g, c.h1, t->d_flt + c.f_bn1, t->d_params, off_w2, c.h2,
+                       t->d_dbl + c.d_st2);
+    hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(64), 0, st, w, t->d_dbl + c.d_st2, n, t->d_params, off_m2, off_m2 + w,
+                       t->d_flt + c.f_bn2);
+    hipLaunchKernelGGL(k_c3_fwd<W>, dim3(nb), dim3(TB), 0, st, g, zin, c.h2, t->d_flt + c.f_bn2, t->d_params, off_w3, zout,
+                       t->d_patch);
+}
+
+template <int W>
+void coupling_backward(nf_trainer *t, const Geo &g, const TLayer &L, const float *zin, float invB, hipStream_t st)
+{
+    const Cpl &c = t->cpl[L.aux];
+    const unsigned nb = blocks_for(g.npix);
+    const unsigned ng = std::min(nb, 256u);   // the weight-gradient kernels: fewer, longer threads
+    const int w = W, off_w1 = L.off, off_b1 = L.off + 18 * w, off_w2 = L.off + 21 * w, off_w3 = L.off + 24 * w + w * w;
+    const double n = (double)g.npix;
+    const float *bn1 = t->d_flt + c.f_bn1, *bn2 = t->d_flt + c.f_bn2;
+    float *bb1 = t->d_flt + c.f_bb1, *bb2 = t->d_flt + c.f_bb2;
+    double *G = t->d_dbl;
+    hipLaunchKernelGGL(k_c3_bwd<W>, dim3(nb), dim3(TB), 0, st, g, zin, c.h2, bn2, t->d_params, off_w3, invB, t->dz, t->gu, G);
+    hipLaunchKernelGGL(k_w3_grad<W>, dim3(ng, 9), dim3(TB), 0, st, g, c.h2, bn2, t->gu, off_w3, G);
+    hipLaunchKernelGGL(k_c3_dh<W>, dim3(nb), dim3(TB), 0, st, g, c.h2, bn2, t->d_params, off_w3, t->gu, t->t1, G + c.d_bs2);
+    hipLaunchKernelGGL(k_bnb_finalize, dim3(1), dim3(64), 0, st, w, G + c.d_bs2, n, bb2);
+    hipLaunchKernelGGL(k_c2_bwd<W>, dim3(nb), dim3(TB), 0, st, g, c.h1, bn1, c.h2, bn2, bb2, t->d_params, off_w2, t->t1, t->t2,
+                       G + c.d_bs1, G);
+    hipLaunchKernelGGL(k_w2_grad<W>, dim3(ng, w), dim3(TB), 0, st, g, c.h1, bn1, t->t1, off_w2, G);
+    hipLaunchKernelGGL(k_bnb_finalize, dim3(1), dim3(64), 0, st, w, G + c.d_bs1, n, bb1);
+    hipLaunchKernelGGL(k_c1_bwd<W>, dim3(nb), dim3(TB), 0, st, g, c.h1, bn1, bb1, off_b1, t->t2, G);
+    hipLaunchKernelGGL(k_w1_grad<W>, dim3(ng, 9), dim3(TB), 0, st, g, zin, t->t2, off_w1, G);
+    hipLaunchKernelGGL(k_c1_dz<W>, dim3(nb), dim3(TB), 0, st, g, t->t2, t->d_params, off_w1, t->dz);
+}
+
+#define NF_WIDTH_SWITCH(w, CALL)            \
+    switch (w) {                            \
+    case 4: CALL(4); break;                 \
+    case 8: CALL(8); break;                 \
+    case 16: CALL(16); break;               \
+    case 32: CALL(32); break;               \
+    default: break;                         \
+    }
+
+int cond_index(const nf_cond *cond, bool needed, CondIdx &ci)
+{
+    ci.iso = 0.f;
+    ci.iso_idx = -1;
+    ci.cam_idx = 0;
+    if (!needed) return NF_OK;
+    if (!cond) return nf_fail(NF_EINVAL, "model has an SDN5 layer but cond is NULL");
+    static const float iso_vals[5] = {100.f, 400.f, 800.f, 1600.f, 3200.f};
+    ci.iso = cond->iso;
+    for (int i = 0; i < 5; ++i)
+        if (iso_vals[i] == cond->iso) ci.iso_idx = i;
+    int cam = -1;
+    for (int i = 0; i < 5; ++i)
+        if ((float)i == cond->cam) cam = i;
+    if (cam < 0) return nf_fail(NF_ECOND, "unknown camera id %g (expected 0..4 = IP,GP,S6,N6,G4)", (double)cond->cam);
+    ci.cam_idx = cam;
+    return NF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nf_trainer_destroy(nf_trainer *t)
+{
+    if (!t) return NF_OK;
+    Guard guard;
+    (void)guard.enter(t->device);
+    for (void *p : t->owned) (void)hipFree(p);
+    delete t;
+    return NF_OK;
+}
+
+int nf_trainer_create(const nf_config *cfg, const nf_layer_desc *layers, const float *params, size_t n_params,
+                      int64_t max_batch, int32_t optimizer, nf_trainer **out)
+{
+    if (!out) return nf_fail(NF_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (!cfg || !layers || !params) return nf_fail(NF_EINVAL, "null argument");
+    if (cfg->channels != 4) return nf_fail(NF_EINVAL, "channels must be 4 (packed raw), got %d", cfg->channels);
+    if (cfg->height < 1 || cfg->width < 1) return nf_fail(NF_EINVAL, "bad patch size %dx%d", cfg->height, cfg->width);
+    if (cfg->flags != 0) return nf_fail(NF_EINVAL, "training is fp32: nf_config.flags must be 0");
+    if (cfg->n_layers < 1 || cfg->n_layers > kMaxLayers) return nf_fail(NF_EINVAL, "n_layers must be in 1..%d", kMaxLayers);
+    if (max_batch < 1) return nf_fail(NF_EINVAL, "max_batch must be >= 1");
+    if (optimizer != NF_OPT_ADAM && optimizer != NF_OPT_MOMENTUM) return nf_fail(NF_EINVAL, "unknown optimizer %d", optimizer);
+    if (n_params > (size_t)1 << 24) return nf_fail(NF_EINVAL, "n_params too large");
+
+    nf_trainer *t = new (std::nothrow) nf_trainer();
+    if (!t) return nf_fail(NF_ENOMEM, "out of host memory");
+    t->cfg = *cfg;
+    t->max_batch = max_batch;
+    t->optimizer = optimizer;
+    t->n_params = (int)n_params;
+    t->layers.assign(layers, layers + cfg->n_layers);
+    std::vector<uint8_t> mask(n_params, 0);
+    int n_mix = 0, n_cpl = 0, n_sdn = 0, n_gain = 0;
+    memset(&t->tl, 0, sizeof(t->tl));
+    t->tl.n = cfg->n_layers;
+    for (int i = 0; i < cfg->n_layers; ++i) {
+        const nf_layer_desc &L = layers[i];
+        const int64_t cnt = nf_layer_param_count(L.type, L.width);
+        if (cnt < 0 || L.param_offset < 0 || (uint64_t)L.param_offset + (uint64_t)cnt > n_params) {
+            delete t;
+            return nf_fail(NF_EINVAL, "layer %d: bad type / width / parameter range", i);
+        }
+        TLayer &T = t->tl.l[i];
+        T.type = L.type;
+        T.width = L.width;
+        T.off = (int)L.param_offset;
+        uint8_t *mk = mask.data() + L.param_offset;
+        switch (L.type) {
+        case NF_LAYER_CONV1X1:
+            T.aux = n_mix++;
+            for (int k = 20; k < 36; ++k) mk[k] = 1;   // log_S, L_vec, U_vec (P, sign_S are constants)
+            break;
+        case NF_LAYER_COUPLING: {
+            const int w = L.width;
+            if (w != 4 && w != 8 && w != 16 && w != 32) {
+                delete t;
+                return nf_fail(NF_EINVAL, "layer %d: coupling width %d unsupported (4, 8, 16, 32)", i, w);
+            }
+            if (t->width && t->width != w) {
+                delete t;
+                return nf_fail(NF_EINVAL, "all coupling layers must share one width");
+            }
+            t->width = w;
+            T.aux = n_cpl++;
+            for (int64_t k = 0; k < cnt; ++k) mk[k] = 1;
+            for (int k = 0; k < 2 * w; ++k) mk[19 * w + k] = mk[22 * w + w * w + k] = 0;   // BN running statistics
+            break;
+        }
+        case NF_LAYER_SDN5:
+            T.aux = n_sdn++;
+            for (int k = 0; k < 22; ++k) mk[k] = 1;    // c_i is a constant
+            t->has_sdn = true;
+            break;
+        case NF_LAYER_GAIN4:
+            T.aux = n_gain++;
+            mk[0] = 1;
+            break;
+        default:
+            delete t;
+            return nf_fail(NF_EINVAL, "layer %d: training covers CONV1X1, COUPLING, SDN5 and GAIN4 layers (type %d given)", i, L.type);
+        }
+    }
+
+    hipError_t e;
+    if (cfg->device >= 0) {
+        t->device = cfg->device;
+    } else if ((e = hipGetDevice(&t->device)) != hipSuccess) {
+        delete t;
+        return nf_fail_hip(e, "hipGetDevice");
+    }
+    Guard guard;
+    int rc = guard.enter(t->device);
+    if (rc != NF_OK) {
+        delete t;
+        return rc;
+    }
+
+    const int w = t->width ? t->width : 4;
+    const size_t act = (size_t)max_batch * cfg->height * cfg->width;   // pixels
+    // double workspace
+    size_t nd = n_params;
+    t->d_dA = (int)nd; nd += 16 * (size_t)n_mix;
+    t->d_dab = (int)nd; nd += 2 * (size_t)n_sdn;
+    t->d_dg = (int)nd; nd += (size_t)n_gain;
+    t->d_ldc = (int)nd; nd += 1;
+    t->cpl.resize(n_cpl);
+    for (Cpl &c : t->cpl) {
+        c.d_st1 = (int)nd; nd += 2 * w;
+        c.d_st2 = (int)nd; nd += 2 * w;
+        c.d_bs1 = (int)nd; nd += 2 * w;
+        c.d_bs2 = (int)nd; nd += 2 * w;
+    }
+    t->n_dbl = nd;
+    // float scalars
+    size_t nf = 0;
+    t->f_A = (int)nf; nf += 16 * (size_t)n_mix;
+    t->f_ab = (int)nf; nf += 2 * (size_t)n_sdn;
+    for (Cpl &c : t->cpl) {
+        c.f_bn1 = (int)nf; nf += 2 * w;
+        c.f_bn2 = (int)nf; nf += 2 * w;
+        c.f_bb1 = (int)nf; nf += 2 * w;
+        c.f_bb2 = (int)nf; nf += 2 * w;
+    }
+    t->n_flt = nf;
+
+#define NF_TRY(x)                 \
+    if ((rc = (x)) != NF_OK) {    \
+        nf_trainer_destroy(t);    \
+        return rc;                \
+    }
+    NF_TRY(dev_alloc(t, (void **)&t->d_params, n_params * sizeof(float)));
+    NF_TRY(dev_alloc(t, (void **)&t->d_m, n_params * sizeof(float)));
+    NF_TRY(dev_alloc(t, (void **)&t->d_v, n_params * sizeof(float)));
+    NF_TRY(dev_alloc(t, (void **)&t->d_gradf, n_params * sizeof(float)));
+    NF_TRY(dev_alloc(t, (void **)&t->d_mask, n_params));
+    NF_TRY(dev_alloc(t, (void **)&t->d_dbl, nd * sizeof(double)));
+    NF_TRY(dev_alloc(t, (void **)&t->d_flt, nf * sizeof(float)));
+    NF_TRY(dev_alloc(t, (void **)&t->d_patch, 3 * (size_t)max_batch * sizeof(float)));
+    t->zs.assign(cfg->n_layers + 1, nullptr);
+    for (int i = 1; i <= cfg->n_layers; ++i) NF_TRY(dev_alloc(t, (void **)&t->zs[i], act * 4 * sizeof(float)));
+    for (Cpl &c : t->cpl) {
+        NF_TRY(dev_alloc(t, (void **)&c.h1, act * w * sizeof(float)));
+        NF_TRY(dev_alloc(t, (void **)&c.h2, act * w * sizeof(float)));
+    }
+    NF_TRY(dev_alloc(t, (void **)&t->t1, act * w * sizeof(float)));
+    NF_TRY(dev_alloc(t, (void **)&t->t2, act * w * sizeof(float)));
+    NF_TRY(dev_alloc(t, (void **)&t->gu, act * 4 * sizeof(float)));
+    NF_TRY(dev_alloc(t, (void **)&t->dz, act * 4 * sizeof(float)));
+#undef NF_TRY
+    if ((e = hipMemcpy(t->d_params, params, n_params * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(t->d_mask, mask.data(), n_params, hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemset(t->d_m, 0, n_params * sizeof(float))) != hipSuccess ||
+        (e = hipMemset(t->d_v, 0, n_params * sizeof(float))) != hipSuccess ||
+        (e = hipMemset(t->d_gradf, 0, n_params * sizeof(float))) != hipSuccess) {
+        nf_trainer_destroy(t);
+        return nf_fail_hip(e, "trainer initialisation");
+    }
+    *out = t;
+    return NF_OK;
+}
+
+int nf_trainer_forward_backward(nf_trainer *t, const float *x, const float *y, int64_t B, const nf_cond *cond,
+                                float *grads_out, float *loss_out, void *stream)
+{
+    if (!t) return nf_fail(NF_EINVAL, "trainer is NULL");
+    if (B < 1 || B > t->max_batch) return nf_fail(NF_EINVAL, "B must be in 1..max_batch (%lld)", (long long)t->max_batch);
+    if (!x) return nf_fail(NF_EINVAL, "x is NULL");
+    if (t->has_sdn && !y) return nf_fail(NF_EINVAL, "model has a signal-dependent layer but y is NULL");
+    CondIdx ci;
+    int rc = cond_index(cond, t->has_sdn, ci);
+    if (rc != NF_OK) return rc;
+    Guard guard;
+    if ((rc = guard.enter(t->device)) != NF_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+
+    Geo g;
+    g.B = (int)B;
+    g.H = t->cfg.height;
+    g.W = t->cfg.width;
+    g.HW = g.H * g.W;
+    g.npix = B * (int64_t)g.HW;
+    g.nloop = (g.npix + 63) & ~(int64_t)63;
+    const unsigned nb = blocks_for(g.npix);
+    const float invB = 1.0f / (float)B;
+    const int n = t->cfg.n_layers;
+    hipError_t e;
+    if ((e = hipMemsetAsync(t->d_dbl, 0, t->n_dbl * sizeof(double), st)) != hipSuccess ||
+        (e = hipMemsetAsync(t->d_patch, 0, 3 * (size_t)t->max_batch * sizeof(float), st)) != hipSuccess)
+        return nf_fail_hip(e, "hipMemsetAsync(trainer accumulators)");
+    float *ld = t->d_patch, *s1 = ld + t->max_batch, *s2 = s1 + t->max_batch;
+    double *G = t->d_dbl;
+
+    hipLaunchKernelGGL(k_prep, dim3(1), dim3(64), 0, st, t->tl, t->d_params, ci, g.HW, t->d_flt + t->f_A, t->d_flt + t->f_ab,
+                       G + t->d_ldc);
+    // ---- forward ----
+    t->zs[0] = const_cast<float *>(x);
+    for (int l = 0; l < n; ++l) {
+        const TLayer &L = t->tl.l[l];
+        const float *zin = t->zs[l];
+        float *zout = t->zs[l + 1];
+        switch (L.type) {
+        case NF_LAYER_SDN5:
+            hipLaunchKernelGGL(k_sdn_fwd, dim3(nb), dim3(TB), 0, st, g, zin, y, t->d_flt + t->f_ab + 2 * L.aux, zout, ld);
+            break;
+        case NF_LAYER_GAIN4:
+            hipLaunchKernelGGL(k_scale_fwd, dim3(nb), dim3(TB), 0, st, g, zin, t->d_params + L.off, zout);
+            break;
+        case NF_LAYER_CONV1X1:
+            hipLaunchKernelGGL(k_mix_fwd, dim3(nb), dim3(TB), 0, st, g, zin, t->d_flt + t->f_A + 16 * L.aux, zout);
+            break;
+        case NF_LAYER_COUPLING:
+#define NF_CALL(WW) coupling_forward<WW>(t, g, L, zin, zout, st)
+            NF_WIDTH_SWITCH(L.width, NF_CALL)
+#undef NF_CALL
+            break;
+        }
+    }
+    hipLaunchKernelGGL(k_prior, dim3(nb), dim3(TB), 0, st, g, t->zs[n], s1, s2);
+    if (loss_out)
+        hipLaunchKernelGGL(k_loss, dim3(1), dim3(TB), 0, st, (int)B, (double)g.HW * 4.0, ld, s1, s2, G + t->d_ldc, loss_out);
+    // ---- backward ----
+    hipLaunchKernelGGL(k_dz_init, dim3(nb), dim3(TB), 0, st, g, t->zs[n], invB, t->dz);
+    for (int l = n - 1; l >= 0; --l) {
+        const TLayer &L = t->tl.l[l];
+        switch (L.type) {
+        case NF_LAYER_SDN5:
+            hipLaunchKernelGGL(k_sdn_bwd, dim3(nb), dim3(TB), 0, st, g, t->zs[l], y, t->d_flt + t->f_ab + 2 * L.aux, invB, t->dz,
+                               G + t->d_dab + 2 * L.aux);
+            break;
+        case NF_LAYER_GAIN4:
+            hipLaunchKernelGGL(k_scale_bwd, dim3(nb), dim3(TB), 0, st, g, t->zs[l + 1], t->d_params + L.off, t->dz,
+                               G + t->d_dg + L.aux);
+            break;
+        case NF_LAYER_CONV1X1:
+            hipLaunchKernelGGL(k_mix_bwd, dim3(nb), dim3(TB), 0, st, g, t->zs[l], t->d_flt + t->f_A + 16 * L.aux, t->dz,
+                               G + t->d_dA + 16 * L.aux);
+            break;
+        case NF_LAYER_COUPLING:
+#define NF_CALL(WW) coupling_backward<WW>(t, g, L, t->zs[l], invB, st)
+            NF_WIDTH_SWITCH(L.width, NF_CALL)
+#undef NF_CALL
+            break;
+        }
+    }
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, st, t->tl, t->d_params, ci, g.HW, G + t->d_dA, G + t->d_dab, G + t->d_dg, G);
+    float *gout = grads_out ? grads_out : t->d_gradf;
+    hipLaunchKernelGGL(k_grads_out, dim3((t->n_params + TB - 1) / TB), dim3(TB), 0, st, t->n_params, G, t->d_mask, gout);
+    t->zs[0] = nullptr;
+    if ((e = hipGetLastError()) != hipSuccess) return nf_fail_hip(e, "trainer launch");
+    return NF_OK;
+}
+
+int nf_trainer_apply(nf_trainer *t, const float *grads, float lr, void *stream)
+{
+    if (!t) return nf_fail(NF_EINVAL, "trainer is NULL");
+    Guard guard;
+    int rc = guard.enter(t->device);
+    if (rc != NF_OK) return rc;
+    const float *gr = grads ? grads : t->d_gradf;
+    const unsigned nb = (unsigned)((t->n_params + TB - 1) / TB);
+    t->step += 1;
+    if (t->optimizer == NF_OPT_ADAM) {
+        const double b1 = 0.9, b2 = 0.999;
+        const float lr_t = (float)((double)lr * sqrt(1.0 - pow(b2, (double)t->step)) / (1.0 - pow(b1, (double)t->step)));
+        hipLaunchKernelGGL(k_adam, dim3(nb), dim3(TB), 0, (hipStream_t)stream, t->n_params, t->d_params, gr, t->d_m, t->d_v,
+                           t->d_mask, lr_t, 0.9f, 0.999f, 1e-8f);
+    } else {
+        hipLaunchKernelGGL(k_momentum, dim3(nb), dim3(TB), 0, (hipStream_t)stream, t->n_params, t->d_params, gr, t->d_m,
+                           t->d_mask, lr, 0.9f);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return nf_fail_hip(e, "optimizer launch");
+    return NF_OK;
+}
+
+int nf_trainer_step(nf_trainer *t, const float *x, const float *y, int64_t B, const nf_cond *cond, float lr,
+                    float *loss_out, void *stream)
+{
+    int rc = nf_trainer_forward_backward(t, x, y, B, cond, nullptr, loss_out, stream);
+    if (rc != NF_OK) return rc;
+    return nf_trainer_apply(t, nullptr, lr, stream);
+}
+
+int nf_trainer_get_params(nf_trainer *t, float *params_out, size_t n_params, void *stream)
+{
+    if (!t || !params_out) return nf_fail(NF_EINVAL, "null argument");
+    if (n_params != (size_t)t->n_params) return nf_fail(NF_EINVAL, "n_params mismatch (%zu vs %d)", n_params, t->n_params);
+    Guard guard;
+    int rc = guard.enter(t->device);
+    if (rc != NF_OK) return rc;
+    hipError_t e = hipMemcpyAsync(params_out, t->d_params, n_params * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return nf_fail_hip(e, "nf_trainer_get_params");
+    return NF_OK;
+}
+
+int nf_trainer_set_params(nf_trainer *t, const float *params, size_t n_params, void *stream)
+{
+    if (!t || !params) return nf_fail(NF_EINVAL, "null argument");
+    if (n_params != (size_t)t->n_params) return nf_fail(NF_EINVAL, "n_params mismatch (%zu vs %d)", n_params, t->n_params);
+    Guard guard;
+    int rc = guard.enter(t->device);
+    if (rc != NF_OK) return rc;
+    hipError_t e = hipMemcpyAsync(t->d_params, params, n_params * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return nf_fail_hip(e, "nf_trainer_set_params");
+    return NF_OK;
+}
+
+int64_t nf_trainer_steps(const nf_trainer *t) { return t ? t->step : -1; }
+
+}  // extern "C"

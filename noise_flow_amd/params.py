@@ -9,7 +9,7 @@ channel, exp(3·logs)) happens inside the HIP library (``csrc/nf_host.hip``).
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Dict, List, Tuple
+from typing import Dict, List, Tuple, Optional
 
 import numpy as np
 
@@ -92,6 +92,30 @@ def pack(arch: str, variables: Dict[str, np.ndarray], width: int, binding: str =
     return pack_layers(layers, variables, width, template_binding(layers, binding))
 
 
+def layer_variable_names(L: LayerSpec, tmpl: Dict[int, int]) -> List[Optional[str]]:
+    """Checkpoint names of one layer's variables in the order of the raw layout
+    (include/noiseflow_hip.h); ``None`` marks a constant that is not a variable (sdn5's c_i)."""
+    if L.kind == "conv1x1":
+        n = conv1x1_names(L.arch_index)
+        return [n["P"], n["sign_S"], n["log_S"], n["L_vec"], n["U_vec"]]
+    if L.kind == "coupling":
+        t = template_scope(tmpl[L.arch_index]) + "/"
+        return [t + "l_1/W", t + "l_1/b", t + "bn_nvp_conv_1/mean", t + "bn_nvp_conv_1/var",
+                t + "l_2/W", t + "l_2/b", t + "bn_nvp_conv_2/mean", t + "bn_nvp_conv_2/var",
+                t + "l_last/W", t + "l_last/b", t + "l_last/logs",
+                "level0/bijector%d/rescaling_scale0" % L.arch_index]
+    if L.kind == "sdn5":
+        return ["model/sdn_gain/beta1", "model/sdn_gain/beta2", "model/sdn_gain/gain_params",
+                "model/sdn_gain/cam_params", None]
+    if L.kind == "sdn4":   # variables of sdn_model_params_ex4 (cond_utils.py:178-202), scope 'sdn_gain'
+        return ["model/sdn_gain/beta1", "model/sdn_gain/beta2", "model/sdn_gain/gain_params"]
+    if L.kind == "sdn":    # sdn_model_params (cond_utils.py:41-52): created under the 'model' scope
+        return ["model/b1", "model/b2"]
+    if L.kind == "gain":   # gain_model_params (cond_utils.py:319-330)
+        return ["model/g1", "model/g2"]
+    return ["model/sdn_gain/gain_val"]   # gain4
+
+
 def pack_layers(layers: List[LayerSpec], variables: Dict[str, np.ndarray], width: int, tmpl: Dict[int, int]):
     """Pack an explicit layer list (e.g. ONE bijector of a larger architecture);
     ``tmpl`` maps the arch index of each coupling to its template scope number."""
@@ -105,38 +129,14 @@ def pack_layers(layers: List[LayerSpec], variables: Dict[str, np.ndarray], width
         return variables[name]
 
     for L in layers:
-        if L.kind == "conv1x1":
-            n = conv1x1_names(L.arch_index)
-            blk = np.concatenate([_f32(need(n["P"])), _f32(need(n["sign_S"])), _f32(need(n["log_S"])),
-                                  _f32(need(n["L_vec"])), _f32(need(n["U_vec"]))])
-        elif L.kind == "coupling":
+        if L.kind == "coupling":
             L.width = int(width)
             t = template_scope(tmpl[L.arch_index]) + "/"
             w1 = np.asarray(need(t + "l_1/W"), np.float32)
             if w1.shape != (3, 3, 2, width):
                 raise ValueError("%sl_1/W has shape %s, expected (3,3,2,%d)" % (t, w1.shape, width))
-            blk = np.concatenate([
-                _f32(w1), _f32(need(t + "l_1/b")),
-                _f32(need(t + "bn_nvp_conv_1/mean")), _f32(need(t + "bn_nvp_conv_1/var")),
-                _f32(need(t + "l_2/W")), _f32(need(t + "l_2/b")),
-                _f32(need(t + "bn_nvp_conv_2/mean")), _f32(need(t + "bn_nvp_conv_2/var")),
-                _f32(need(t + "l_last/W")), _f32(need(t + "l_last/b")), _f32(need(t + "l_last/logs")),
-                _f32(need("level0/bijector%d/rescaling_scale0" % L.arch_index)),
-            ])
-        elif L.kind == "sdn5":
-            blk = np.concatenate([
-                _f32(need("model/sdn_gain/beta1")), _f32(need("model/sdn_gain/beta2")),
-                _f32(need("model/sdn_gain/gain_params")), _f32(need("model/sdn_gain/cam_params")),
-                np.asarray([C_I], np.float32)])
-        elif L.kind == "sdn4":   # variables of sdn_model_params_ex4 (cond_utils.py:178-202), scope 'sdn_gain'
-            blk = np.concatenate([_f32(need("model/sdn_gain/beta1")), _f32(need("model/sdn_gain/beta2")),
-                                  _f32(need("model/sdn_gain/gain_params"))])
-        elif L.kind == "sdn":    # sdn_model_params (cond_utils.py:41-52): created under the 'model' scope
-            blk = np.concatenate([_f32(need("model/b1")), _f32(need("model/b2"))])
-        elif L.kind == "gain":   # gain_model_params (cond_utils.py:319-330)
-            blk = np.concatenate([_f32(need("model/g1")), _f32(need("model/g2"))])
-        else:  # gain4
-            blk = _f32(need("model/sdn_gain/gain_val"))
+        blk = np.concatenate([_f32(need(nm)) if nm is not None else np.asarray([C_I], np.float32)
+                              for nm in layer_variable_names(L, tmpl)])
         expect = _lib.load().nf_layer_param_count(L.nf_type, L.width)
         if blk.size != expect:
             raise ValueError("layer %s: %d raw parameters, C ABI expects %d" % (L.name, blk.size, expect))
@@ -148,6 +148,26 @@ def pack_layers(layers: List[LayerSpec], variables: Dict[str, np.ndarray], width
     for d, L, off in zip(descs, layers, offsets):
         d.type, d.width, d.param_offset = L.nf_type, L.width, off
     return layers, descs, params
+
+
+def unpack_layers(layers: List[LayerSpec], flat: np.ndarray, variables: Dict[str, np.ndarray], tmpl: Dict[int, int]):
+    """Inverse of :func:`pack_layers`: a copy of ``variables`` with every variable the layers own
+    replaced by its slice of the raw vector ``flat`` (shapes and dtypes of ``variables`` kept)."""
+    out = dict(variables)
+    pos = 0
+    flat = np.asarray(flat, np.float32).reshape(-1)
+    for L in layers:
+        for nm in layer_variable_names(L, tmpl):
+            if nm is None:
+                pos += 1
+                continue
+            ref = np.asarray(variables[nm])
+            n = int(ref.size)
+            out[nm] = flat[pos:pos + n].reshape(ref.shape).astype(ref.dtype if ref.dtype.kind == "f" else np.float32)
+            pos += n
+    if pos != flat.size:
+        raise ValueError("raw vector has %d floats, the layers own %d" % (flat.size, pos))
+    return out
 
 
 # ----------------------------------------------------------------------------

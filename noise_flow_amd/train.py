@@ -1,0 +1,152 @@
+"""Training step of the Noise Flow stack — host mirror of the reference's
+``sess.run([train_op, loss, sd_z], {..., is_training: True})`` (``train_noise_flow.py:50-77``)
+with ``train_op = get_optimizer(hps, lr, loss)`` (``train_noise_flow.py:187-198``).
+
+``Trainer`` owns one ``nf_trainer`` (C ABI, ``include/noiseflow_hip.h``): the raw parameters, the
+optimizer slots and the activation workspace live on the GPU; ``step`` only enqueues kernels on
+torch's current stream.  Data-parallel training = ``forward_backward`` → one RCCL all-reduce of
+the 2 433-float gradient → ``apply`` (``step(..., group=...)`` does exactly that); BN moments stay
+per rank (the reference is single-process, SURVEY.md §8e caveat).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import _lib
+from . import params as _params
+from .noise_flow_model import _Dev, _first
+
+
+class Trainer:
+    """Parameters
+    ----------
+    x_shape : [H, W, C]
+    hps : namespace with ``arch``, ``width`` and optionally ``optim`` ('adam' | 'sgd',
+          train_noise_flow.py:190-196) and ``seed``
+    variables : ``{name: ndarray}`` under the reference's checkpoint names; default = fresh
+          initialisation with the reference's initialisers
+    max_batch : largest minibatch a step will see (sizes the activation workspace);
+          default ``hps.n_batch_train`` or 138 (job_noise_flow.sh)
+    """
+
+    def __init__(self, x_shape, hps, variables: Optional[Dict[str, np.ndarray]] = None, binding: str = "loss_first",
+                 device=None, max_batch: Optional[int] = None, optim: Optional[str] = None):
+        self.lib = _lib.load()
+        self.x_shape = [int(v) for v in x_shape]
+        self.hps = hps
+        self.arch = hps.arch
+        self.width = int(getattr(hps, "width", 4))
+        self.binding = binding
+        self._dev = _Dev(device)
+        seed = int(getattr(hps, "seed", 0) or 0)
+        self._variables = dict(variables) if variables is not None else _params.init_variables(
+            self.arch, self.width, self.x_shape[-1], seed)
+        self.layers = _params.parse_arch(self.arch)
+        self._tmpl = _params.template_binding(self.layers, binding)
+        self.layers, descs, flat = _params.pack_layers(self.layers, self._variables, self.width, self._tmpl)
+        self.n_params = int(flat.size)
+        optim = optim or str(getattr(hps, "optim", "adam"))
+        if optim not in ("adam", "sgd"):
+            raise ValueError("optim must be 'adam' or 'sgd' (train_noise_flow.py:190-196)")
+        self.optim = optim
+        self.max_batch = int(max_batch or getattr(hps, "n_batch_train", 138) or 138)
+        H, W, Cc = self.x_shape
+        cfg = _lib.nf_config(H, W, Cc, len(self.layers), self._dev.device.index, 0)
+        h = C.c_void_p()
+        _lib.check(self.lib.nf_trainer_create(C.byref(cfg), descs, flat.ctypes.data_as(C.POINTER(C.c_float)), flat.size,
+                                              self.max_batch, _lib.NF_OPT_ADAM if optim == "adam" else _lib.NF_OPT_MOMENTUM,
+                                              C.byref(h)))
+        self._h = h
+        torch = self._dev.torch
+        self._grads = torch.zeros((self.n_params,), dtype=torch.float32, device=self._dev.device)
+        self._loss = torch.zeros((2,), dtype=torch.float32, device=self._dev.device)
+        self.has_sdn = any(L.kind == "sdn5" for L in self.layers)
+
+    # ------------------------------------------------------------------ lifetime
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.nf_trainer_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ one step
+    def _inputs(self, x, y):
+        tail = tuple(self.x_shape)
+        xt, _ = self._dev.to_dev(x, tail)
+        yt = self._dev.to_dev(y, tail)[0] if y is not None else None
+        if yt is not None and yt.shape[0] != xt.shape[0]:
+            raise ValueError("x and y batch sizes differ")
+        if yt is None and self.has_sdn:
+            raise ValueError("this architecture has a signal-dependent layer: the clean image y is required")
+        return xt, yt
+
+    def forward_backward(self, x, y, nlf0=None, nlf1=None, iso=None, cam=None):
+        """→ (grads, loss2): device tensors — the raw-layout gradient of ``mean_b nll_b`` (zeros at
+        non-trainable positions) and ``(loss, sd_z)``.  Moves the BN running statistics."""
+        xt, yt = self._inputs(x, y)
+        cond = _lib.nf_cond(_first(iso), _first(cam), _first(nlf0), _first(nlf1))
+        dev = self._dev
+        with dev.torch.cuda.device(dev.device):
+            _lib.check(self.lib.nf_trainer_forward_backward(
+                self._h, xt.data_ptr(), yt.data_ptr() if yt is not None else None, int(xt.shape[0]), C.byref(cond),
+                self._grads.data_ptr(), self._loss.data_ptr(), dev.stream_ptr()))
+        return self._grads, self._loss
+
+    def apply(self, lr: float, grads=None):
+        g = self._grads if grads is None else grads
+        dev = self._dev
+        with dev.torch.cuda.device(dev.device):
+            _lib.check(self.lib.nf_trainer_apply(self._h, g.data_ptr(), float(lr), dev.stream_ptr()))
+
+    def step(self, x, y, nlf0=None, nlf1=None, iso=None, cam=None, lr: float = 1e-4, group=None, sync: bool = True):
+        """One ``sess.run([train_op, loss, sd_z])`` → ``(train_loss, sd_z)``.
+
+        ``group``: a ``torch.distributed`` process group (or ``True`` for the default group) —
+        averages the gradient over ranks with one all-reduce before the update.
+        ``sync=False`` returns the device tensor ``[loss, sd_z]`` without waiting."""
+        grads, loss = self.forward_backward(x, y, nlf0, nlf1, iso, cam)
+        if group is not None:
+            import torch.distributed as dist
+            grp = None if group is True else group
+            dist.all_reduce(grads, op=dist.ReduceOp.SUM, group=grp)
+            grads.div_(dist.get_world_size(grp))
+        self.apply(lr, grads)
+        if not sync:
+            return loss
+        v = loss.cpu().numpy()
+        return np.float32(v[0]), np.float32(v[1])
+
+    # ------------------------------------------------------------------ parameters
+    @property
+    def steps(self) -> int:
+        return int(self.lib.nf_trainer_steps(self._h))
+
+    def raw_params(self) -> np.ndarray:
+        out = np.empty((self.n_params,), np.float32)
+        dev = self._dev
+        with dev.torch.cuda.device(dev.device):
+            _lib.check(self.lib.nf_trainer_get_params(self._h, out.ctypes.data, out.size, dev.stream_ptr()))
+        return out
+
+    @property
+    def variables(self) -> Dict[str, np.ndarray]:
+        """The current variables under the reference's checkpoint names (trained values and the
+        EMA-updated BN statistics); synchronises."""
+        self._variables = _params.unpack_layers(self.layers, self.raw_params(), self._variables, self._tmpl)
+        return self._variables
+
+    def raw_to_variables(self, flat) -> Dict[str, np.ndarray]:
+        """Name view of any raw-layout vector (e.g. the gradient)."""
+        return _params.unpack_layers(self.layers, np.asarray(flat, np.float32), self._variables, self._tmpl)
+
+    def save(self, ckpt_prefix: str) -> None:
+        from .ckpt import save_checkpoint
+        save_checkpoint(ckpt_prefix, self.variables)

@@ -1,0 +1,216 @@
+"""CPU ORACLE for the TRAINING step (test infrastructure only — never imported by the product).
+
+Restates, on torch-CPU float64 with autograd, what one ``sess.run([train_op, loss, sd_z],
+{..., is_training: True})`` of the reference computes (train_noise_flow.py:64-66, 187-198):
+
+* forward in the NLL direction with batch-statistics BN (layers.py:386-398) from the RAW
+  checkpoint variables (PLU factors, CNN weights, sdn/gain parameters) — the same arithmetic as
+  ``oracle/nf_oracle.py`` (which it is pinned against, ``tests/test_oracle.py``), written so that
+  autograd can differentiate it;
+* ``loss = mean_b nll_b`` (noise_flow_model.py:482-484) and its gradient w.r.t. every trainable
+  variable (everything except the LU permutation / signs and the BN running statistics,
+  train_noise_flow.py:309-312);
+* the BN running-statistics EMA (layers.py:392-393);
+* ``tf.train.AdamOptimizer(lr, 0.9, 0.999, 1e-8)`` / ``MomentumOptimizer(lr, 0.9)`` updates
+  (train_noise_flow.py:187-198) restated from TensorFlow 1.12's documented update rules
+  (``adam.py``: lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m,v EMAs; theta -= lr_t*m/(sqrt(v)+eps);
+  ``momentum.py``: accum = 0.9*accum + g; theta -= lr*accum).
+
+Parity status: UNPINNED against the reference itself — TensorFlow 1.12 is not installable here, so
+no reference-produced gradients exist; the oracle is pinned to ``nf_oracle`` (forward value) and to
+central finite differences of that forward (gradients).
+"""
+from __future__ import annotations
+
+from typing import Dict, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import nf_oracle as O
+
+BN_EPS = O.BN_EPS
+BN_DECAY = O.BN_DECAY
+LOGSCALE_FACTOR = O.LOGSCALE_FACTOR
+
+
+def is_trainable(name: str) -> bool:
+    """train_noise_flow.py:309-312 / tf.trainable_variables(): P and sign_S are created with
+    trainable=False (matrix_param.py:113-118), BN statistics too (layers.py:380-385)."""
+    return not ("/P_matpar" in name or "/sign_S_matpar" in name or name.endswith("/mean") or name.endswith("/var"))
+
+
+def _tri_positions(n: int, upper: bool):
+    """(rows, cols) of the matrix entry each vector element lands on (matrix_param.py:31-56)."""
+    m = (n - 1) * n // 2
+    probe = O.vec2stricttri(np.arange(1, m + 1, dtype=np.float64), upper)
+    rows, cols = np.zeros(m, np.int64), np.zeros(m, np.int64)
+    for i in range(n):
+        for j in range(n):
+            k = int(probe[i, j])
+            if k:
+                rows[k - 1], cols[k - 1] = i, j
+    return torch.from_numpy(rows), torch.from_numpy(cols)
+
+
+class GradOracle:
+    def __init__(self, arch: str, variables: Dict[str, np.ndarray], binding: str = "loss_first", c_i: float = 1.0):
+        self.arch = arch
+        self.binding = binding
+        self.c_i = float(c_i)
+        self.names = list(variables.keys())
+        self.shapes = {k: np.asarray(v).shape for k, v in variables.items()}
+        self.t = {k: torch.tensor(np.asarray(v, np.float64), dtype=torch.float64, requires_grad=is_trainable(k))
+                  for k, v in variables.items()}
+        arch_l = O.parse_arch(arch)
+        unc_ids = [i for lyr, i in arch_l if lyr == "unc"]
+        order = unc_ids if binding == "loss_first" else unc_ids[::-1]
+        self.tmpl_of = {i: k for k, i in enumerate(order)}
+        self.arch_l = arch_l
+
+    # -- pieces -----------------------------------------------------------------------------
+    def _A(self, i):
+        pre = "level0/bijector%d/Conv2d_1x1_%d/" % (i, i)
+        sfx = "_matpar_lu_conv2d_1x1_%d_0" % i
+        P, sgn, logS = self.t[pre + "P" + sfx], self.t[pre + "sign_S" + sfx], self.t[pre + "log_S" + sfx]
+        Lv, Uv = self.t[pre + "L_vec" + sfx].reshape(-1), self.t[pre + "U_vec" + sfx].reshape(-1)
+        n = logS.numel()
+        lr, lc = _tri_positions(n, False)
+        ur, uc = _tri_positions(n, True)
+        L = torch.eye(n, dtype=torch.float64).index_put((lr, lc), Lv)
+        U = torch.diag(sgn.reshape(-1) * torch.exp(logS.reshape(-1))).index_put((ur, uc), Uv)
+        return P @ (L @ U), logS.sum()                                    # matrix_param.py:130,138
+
+    def _bn_train(self, h, scope, which, new_running):
+        m = h.mean(dim=(0, 2, 3))
+        v = h.var(dim=(0, 2, 3), unbiased=False)                          # tf.nn.moments
+        for nm, val in (("mean", m), ("var", v)):
+            key = scope + "bn_nvp_conv_%d/%s" % (which, nm)
+            old = self.t[key].detach()
+            new_running[key] = (old - BN_DECAY * (old - val.detach())).numpy().reshape(self.shapes[key])
+        return (h - m[None, :, None, None]) / torch.sqrt(v[None, :, None, None] + BN_EPS)
+
+    def _cnn(self, z0, i, new_running):
+        t = O.template_name(self.tmpl_of[i]) + "/"
+        g = lambda k: self.t[t + k]
+        w1 = g("l_1/W").permute(3, 2, 0, 1)
+        h = F.conv2d(z0, w1, g("l_1/b").reshape(-1), padding=1)           # layers.py:469
+        h = torch.relu(self._bn_train(h, t, 1, new_running))
+        w2 = g("l_2/W").reshape(g("l_2/W").shape[-2], g("l_2/W").shape[-1]).t()[:, :, None, None]
+        h = F.conv2d(h, w2, g("l_2/b").reshape(-1))                       # :480
+        h = torch.relu(self._bn_train(h, t, 2, new_running))
+        hp = F.pad(h, (1, 1, 1, 1))                                       # add_edge_padding, :555-583
+        e = torch.zeros_like(hp[:, :1])
+        e[:, :, 0, :] = 1
+        e[:, :, -1, :] = 1
+        e[:, :, :, 0] = 1
+        e[:, :, :, -1] = 1
+        w3 = g("l_last/W").permute(3, 2, 0, 1)
+        o = F.conv2d(torch.cat([hp, e], 1), w3, g("l_last/b").reshape(-1))   # :665-670
+        o = o * torch.exp(g("l_last/logs").reshape(1, -1, 1, 1) * LOGSCALE_FACTOR)   # :671-673
+        c2 = o.shape[1] // 2
+        return o[:, :c2], o[:, c2:]
+
+    def _sdn5_scale(self, y, iso, cam):
+        c = self.c_i
+        cam_idx = int(cam)
+        if float(cam) not in (0.0, 1.0, 2.0, 3.0, 4.0):
+            raise IndexError("unknown camera id %r" % (cam,))
+        cp = torch.exp(c * self.t["model/sdn_gain/cam_params"][:, cam_idx])
+        ks = [k for k, v in enumerate(O.ISO_VALS) if float(v) == float(iso)]
+        g = self.t["model/sdn_gain/gain_params"].reshape(-1)[ks[0]] if ks else torch.zeros((), dtype=torch.float64)
+        gain = torch.exp(c * g * cp[2]) * float(iso)
+        b1 = torch.exp(c * self.t["model/sdn_gain/beta1"].reshape(-1)[0] * cp[0])
+        b2 = torch.exp(c * self.t["model/sdn_gain/beta2"].reshape(-1)[0] * cp[1])
+        return torch.sqrt(b1 * y / gain + b2)
+
+    # -- the step's forward -----------------------------------------------------------------
+    def forward(self, x, y, iso, cam) -> Tuple[torch.Tensor, torch.Tensor, Dict[str, np.ndarray]]:
+        """→ (loss, sd_z, new running statistics)."""
+        z = torch.tensor(np.asarray(x, np.float64)).permute(0, 3, 1, 2)
+        yt = torch.tensor(np.asarray(y, np.float64)).permute(0, 3, 1, 2) if y is not None else None
+        B, C, H, W = z.shape
+        obj = torch.zeros(B, dtype=torch.float64)
+        new_running: Dict[str, np.ndarray] = {}
+        for lyr, i in self.arch_l:
+            if lyr == "unc":
+                A, lad = self._A(i)
+                z = torch.einsum("bchw,ck->bkhw", z, A)                   # layers.py:117-130
+                obj = obj + H * W * lad
+                c2 = C // 2
+                z0, z1 = z[:, :c2], z[:, c2:]
+                shift, raw = self._cnn(z0, i, new_running)
+                ls = self.t["level0/bijector%d/rescaling_scale0" % i].reshape(()) * torch.tanh(raw)
+                z = torch.cat([z0, z1 * torch.exp(ls) + shift], 1)        # layers.py:355-375
+                obj = obj + ls.sum(dim=(1, 2, 3))
+            elif lyr == "sdn5":
+                scale = self._sdn5_scale(yt, iso, cam)
+                z = z / scale
+                obj = obj - torch.log(scale).sum(dim=(1, 2, 3))
+            elif lyr == "gain4":
+                g = self.t["model/sdn_gain/gain_val"].reshape(-1)[0]
+                z = z / g
+                obj = obj - C * H * W * torch.log(g)
+            else:
+                raise ValueError("the training oracle covers unc|sdn5|gain4, got %r" % lyr)
+        logp = (-0.5 * (np.log(2 * np.pi) + z * z)).sum(dim=(1, 2, 3))
+        nll = -(obj + logp)
+        sd_z = torch.sqrt(z.var(dim=(1, 2, 3), unbiased=False)).mean()
+        return nll.mean(), sd_z, new_running
+
+    def loss_and_grads(self, x, y, iso, cam):
+        """→ (loss, sd_z, {name: d loss / d variable} for trainables, new running statistics)."""
+        for v in self.t.values():
+            if v.grad is not None:
+                v.grad = None
+        loss, sd_z, new_running = self.forward(x, y, iso, cam)
+        loss.backward()
+        grads = {}
+        for k, v in self.t.items():
+            if v.requires_grad:
+                g = v.grad if v.grad is not None else torch.zeros_like(v)
+                grads[k] = g.numpy().reshape(self.shapes[k]).copy()
+        return float(loss.detach()), float(sd_z.detach()), grads, new_running
+
+
+# ------------------------------------------------------------------------------------------
+# optimizers (train_noise_flow.py:187-198)
+# ------------------------------------------------------------------------------------------
+def adam_step(variables, grads, state, lr, beta1=0.9, beta2=0.999, eps=1e-8, dtype=np.float64):
+    """One ``tf.train.AdamOptimizer.minimize`` update.  ``state`` = {"t": int, "m": {}, "v": {}}
+    (mutated); returns the updated variables (new dict)."""
+    state["t"] = t = state.get("t", 0) + 1
+    lr_t = dtype(lr) * np.sqrt(1.0 - dtype(beta2) ** t) / (1.0 - dtype(beta1) ** t)
+    out = dict(variables)
+    for k, g in grads.items():
+        g = np.asarray(g, dtype)
+        m = state.setdefault("m", {}).get(k, np.zeros_like(g))
+        v = state.setdefault("v", {}).get(k, np.zeros_like(g))
+        m = beta1 * m + (1 - beta1) * g
+        v = beta2 * v + (1 - beta2) * g * g
+        state["m"][k], state["v"][k] = m, v
+        out[k] = (np.asarray(variables[k], dtype) - lr_t * m / (np.sqrt(v) + eps)).astype(np.asarray(variables[k]).dtype)
+    return out
+
+
+def momentum_step(variables, grads, state, lr, momentum=0.9, dtype=np.float64):
+    """One ``tf.train.MomentumOptimizer(lr, 0.9).minimize`` update."""
+    out = dict(variables)
+    for k, g in grads.items():
+        g = np.asarray(g, dtype)
+        a = momentum * state.setdefault("a", {}).get(k, np.zeros_like(g)) + g
+        state["a"][k] = a
+        out[k] = (np.asarray(variables[k], dtype) - dtype(lr) * a).astype(np.asarray(variables[k]).dtype)
+    return out
+
+
+def train_step(arch, variables, x, y, iso, cam, state, lr, binding="loss_first", optim="adam"):
+    """The whole ``sess.run([train_op, loss, sd_z])``: → (new variables, loss, sd_z)."""
+    o = GradOracle(arch, variables, binding)
+    loss, sd_z, grads, new_running = o.loss_and_grads(x, y, iso, cam)
+    step = adam_step if optim == "adam" else momentum_step
+    new_vars = step(variables, grads, state, lr)
+    for k, v in new_running.items():
+        new_vars[k] = v.astype(np.asarray(variables[k]).dtype)
+    return new_vars, loss, sd_z

@@ -1,0 +1,85 @@
+"""CPU tier: the training-step oracle (oracle/nf_grad_oracle.py) pinned to the forward oracle and
+to central finite differences of it; the raw-layout pack/unpack round trip the trainer relies on."""
+import numpy as np
+
+from conftest import trained_like_variables, make_inputs
+
+
+ARCH = "sdn5|unc|gain4|unc"
+
+
+def _setup(B=3, hw=(12, 10), width=4, seed=3):
+    v = trained_like_variables(ARCH, width, seed=seed)
+    x, y = make_inputs(B, hw[0], hw[1], seed=seed + 1, b1=0.003696)
+    return v, x, y
+
+
+def test_forward_value_equals_the_forward_oracle_in_training_mode():
+    from oracle.nf_oracle import NoiseFlowOracle
+    from oracle.nf_grad_oracle import GradOracle
+    v, x, y = _setup()
+    ref = NoiseFlowOracle(ARCH, v)
+    nll, sd, _ = ref.nll(x, y, 800, 2, training=True)
+    loss, sd_z, grads, new_running = GradOracle(ARCH, v).loss_and_grads(x, y, 800, 2)
+    assert abs(loss - nll.mean()) <= 1e-12 * abs(nll.mean())
+    assert abs(sd_z - sd) <= 1e-12 * sd
+    # EMA targets = what the forward oracle records
+    for lname, rec in ref.last_batch_moments.items():
+        assert set(("new_mean1", "new_var1", "new_mean2", "new_var2")) <= set(rec)
+    got = sorted(k for k in new_running)
+    assert len(got) == 8 and all(k.endswith("/mean") or k.endswith("/var") for k in got)
+
+
+def test_gradients_match_central_finite_differences():
+    from oracle.nf_oracle import NoiseFlowOracle
+    from oracle.nf_grad_oracle import GradOracle, is_trainable
+    v, x, y = _setup()
+    _, _, grads, _ = GradOracle(ARCH, v).loss_and_grads(x, y, 800, 2)
+    f = lambda vv: NoiseFlowOracle(ARCH, vv).nll(x, y, 800, 2, training=True)[0].mean()
+    rng = np.random.RandomState(0)
+    gmax = max(np.abs(g).max() for g in grads.values())
+    names = sorted(k for k in v if is_trainable(k) and k in grads)
+    for k in names:
+        a = np.asarray(v[k], np.float64)
+        idx = tuple(rng.randint(s) for s in a.shape) if a.shape else ()
+        h = 1e-7
+        vp, vm = dict(v), dict(v)
+        ap, am = a.copy(), a.copy()
+        ap[idx] += h
+        am[idx] -= h
+        vp[k], vm[k] = ap, am
+        fd = (f(vp) - f(vm)) / (2 * h)
+        assert abs(fd - grads[k][idx]) <= 1e-5 * max(abs(fd), 1e-3 * gmax), (k, fd, grads[k][idx])
+
+
+def test_adam_and_momentum_restatements():
+    from oracle.nf_grad_oracle import adam_step, momentum_step
+    v = {"a": np.array([1.0, -2.0]), "b": np.array([0.5])}
+    g = {"a": np.array([0.1, -0.3])}
+    st = {}
+    out = adam_step(v, g, st, 0.01)
+    # first Adam step moves every entry with a gradient by lr * sign(g) (bias-corrected)
+    np.testing.assert_allclose(out["a"], v["a"] - 0.01 * np.sign(g["a"]), rtol=1e-6)
+    assert out["b"] is v["b"] and st["t"] == 1
+    st2 = {}
+    o1 = momentum_step(v, g, st2, 0.1)
+    o2 = momentum_step(o1, g, st2, 0.1)
+    np.testing.assert_allclose(o2["a"], v["a"] - 0.1 * g["a"] - 0.1 * (1.9 * g["a"]))
+
+
+def test_raw_layout_pack_unpack_round_trip():
+    from noise_flow_amd import params as P
+    v = trained_like_variables(ARCH, 8, seed=5)
+    layers = P.parse_arch(ARCH)
+    tmpl = P.template_binding(layers, "loss_first")
+    layers, descs, flat = P.pack_layers(layers, v, 8, tmpl)
+    back = P.unpack_layers(layers, flat, v, tmpl)
+    for k in v:
+        assert np.array_equal(np.asarray(back[k], np.float32).reshape(-1), np.asarray(v[k], np.float32).reshape(-1)), k
+        assert np.asarray(back[k]).shape == np.asarray(v[k]).shape
+    flat2 = flat + 1.0
+    moved = P.unpack_layers(layers, flat2, v, tmpl)
+    owned = [nm for L in layers for nm in P.layer_variable_names(L, tmpl) if nm is not None]
+    for k in owned:
+        np.testing.assert_allclose(np.asarray(moved[k]).reshape(-1), np.asarray(v[k], np.float32).reshape(-1) + 1.0)
+    assert sum(int(np.asarray(v[k]).size) for k in owned) + 1 == flat.size   # + sdn5's constant c_i
