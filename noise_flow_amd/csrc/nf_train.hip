@@ -41,6 +41,7 @@ struct Geo {
     int B, H, W, HW;
     int64_t npix;    // B*H*W
     int64_t nloop;   // npix rounded up to a multiple of 64: whole wavefronts iterate together
+    int nslot;       // partial-sum slots the reducers of this step read (= grid.x of the pixel kernels)
 };
 
 struct TLayer {
@@ -62,11 +63,44 @@ __device__ __forceinline__ float wsum(float v)
     return v;
 }
 
-// add `v` into the fp64 accumulator (one atomic per wavefront)
-__device__ __forceinline__ void acc_add(double *dst, float v)
+// Reductions over the minibatch (BN moments, parameter gradients) avoid atomics: device-scope
+// atomics on one cache line serialise at ~10 ns each on this part (measured: 8k of them made a 5 us
+// kernel take 75 us).  Instead every workgroup reduces its share (registers -> wavefront shuffles ->
+// LDS) and stores ONE partial per value into its own slot; a later kernel adds the slots up in
+// fp64.  Deterministic for a given grid, so a training run is reproducible bit for bit.
+constexpr int NSLOT = 512;   // >= the largest grid.x of a reducing kernel
+
+struct Acc {      // value k of this accumulator group lives at p[k*NSLOT + slot]
+    float *p;
+};
+__host__ __device__ __forceinline__ Acc operator+(Acc a, int k) { return Acc{a.p + (size_t)k * NSLOT}; }
+
+// every thread of the workgroup must call this (it contains barriers)
+__device__ __forceinline__ void acc_add(Acc dst, float v, int nslot)
 {
+    __shared__ float part[TB / 64];
     const float s = wsum(v);
-    if ((threadIdx.x & 63) == 0) atomicAdd(dst, (double)s);
+    __syncthreads();                       // the previous use of `part` is over
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tot = 0.0f;
+#pragma unroll
+        for (int i = 0; i < TB / 64; ++i) tot += part[i];
+        dst.p[blockIdx.x] = tot;
+        // kernels launched with fewer workgroups than `nslot` clear the slots nobody owns
+        for (int k = blockIdx.x + gridDim.x; k < nslot; k += gridDim.x) dst.p[k] = 0.0f;
+    }
+}
+
+// sum of the first `nslot` slots of one value, computed by one whole wavefront
+__device__ __forceinline__ double acc_total(Acc a, int nslot)
+{
+    double s = 0.0;
+    for (int i = threadIdx.x & 63; i < nslot; i += 64) s += (double)a.p[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    return s;
 }
 
 // per-patch accumulator: wavefronts that sit inside one patch reduce first
@@ -213,7 +247,7 @@ __global__ void k_mix_fwd(Geo g, const float *__restrict__ zin, const float *__r
 // l_1: 3x3 SAME conv of the pass-through half + bias; per-channel sum / sum of squares
 template <int W>
 __global__ void k_c1_fwd(Geo g, const float *__restrict__ zin, const float *__restrict__ P, int off, float *__restrict__ h1,
-                         double *__restrict__ stats)
+                         Acc stats)
 {
     const float *W1 = P + off, *b1 = W1 + 18 * W;
     float s[W], q[W];
@@ -247,20 +281,20 @@ __global__ void k_c1_fwd(Geo g, const float *__restrict__ zin, const float *__re
     }
 #pragma unroll
     for (int j = 0; j < W; ++j) {
-        acc_add(stats + j, s[j]);
-        acc_add(stats + W + j, q[j]);
+        acc_add(stats + j, s[j], g.nslot);
+        acc_add(stats + W + j, q[j], g.nslot);
     }
 }
 
 // batch moments -> (mean, 1/sqrt(var+eps)); running statistics <- EMA (layers.py:388-393)
-__global__ void k_bn_finalize(int W, const double *__restrict__ stats, double n, float *__restrict__ P, int off_mean,
-                              int off_var, float *__restrict__ bn)
+__global__ void k_bn_finalize(int W, Acc stats, int nslot, double n, float *__restrict__ P, int off_mean, int off_var,
+                              float *__restrict__ bn)
 {
-    const int j = threadIdx.x;
-    if (j >= W) return;
-    const double m = stats[j] / n;
-    double v = stats[W + j] / n - m * m;
+    const int j = blockIdx.x;   // one wavefront per channel
+    const double m = acc_total(stats + j, nslot) / n;
+    double v = acc_total(stats + W + j, nslot) / n - m * m;
     if (v < 0.0) v = 0.0;
+    if (threadIdx.x != 0) return;
     bn[j] = (float)m;
     bn[W + j] = (float)(1.0 / sqrt(v + (double)kBnEps));
     P[off_mean + j] -= kBnDecay * (P[off_mean + j] - (float)m);
@@ -270,7 +304,7 @@ __global__ void k_bn_finalize(int W, const double *__restrict__ stats, double n,
 // BN1 + ReLU + l_2 (1x1) + bias; statistics of the result
 template <int W>
 __global__ void k_c2_fwd(Geo g, const float *__restrict__ h1, const float *__restrict__ bn1, const float *__restrict__ P,
-                         int off_w2, float *__restrict__ h2, double *__restrict__ stats)
+                         int off_w2, float *__restrict__ h2, Acc stats)
 {
     const float *W2 = P + off_w2, *b2 = W2 + W * W;
     float s[W], q[W];
@@ -297,8 +331,8 @@ __global__ void k_c2_fwd(Geo g, const float *__restrict__ h1, const float *__res
     }
 #pragma unroll
     for (int j = 0; j < W; ++j) {
-        acc_add(stats + j, s[j]);
-        acc_add(stats + W + j, q[j]);
+        acc_add(stats + j, s[j], g.nslot);
+        acc_add(stats + W + j, q[j], g.nslot);
     }
 }
 
@@ -416,7 +450,7 @@ __global__ void k_dz_init(Geo g, const float *__restrict__ z, float invB, float 
 
 // gain4: z_out = z_in / g
 __global__ void k_scale_bwd(Geo g, const float *__restrict__ zout, const float *__restrict__ gain, float *__restrict__ dz,
-                            double *__restrict__ dgain)
+                            Acc dgain)
 {
     const float inv = 1.0f / gain[0];
     float acc = 0.0f;
@@ -427,12 +461,12 @@ __global__ void k_scale_bwd(Geo g, const float *__restrict__ zout, const float *
             reinterpret_cast<float4 *>(dz)[p] = make_float4(d.x * inv, d.y * inv, d.z * inv, d.w * inv);
         }
     }
-    acc_add(dgain, acc);
+    acc_add(dgain, acc, g.nslot);
 }
 
 // sdn5: z = x / sqrt(a y + b), loss += (1/B) sum log scale
 __global__ void k_sdn_bwd(Geo g, const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ ab,
-                          float invB, float *__restrict__ dz, double *__restrict__ dab)
+                          float invB, float *__restrict__ dz, Acc dab)
 {
     const float a = ab[0], b = ab[1];
     float ga = 0.0f, gb = 0.0f;
@@ -454,13 +488,13 @@ __global__ void k_sdn_bwd(Geo g, const float *__restrict__ x, const float *__res
             reinterpret_cast<float4 *>(dz)[p] = make_float4(ds[0], ds[1], ds[2], ds[3]);
         }
     }
-    acc_add(dab, ga);
-    acc_add(dab + 1, gb);
+    acc_add(dab, ga, g.nslot);
+    acc_add(dab + 1, gb, g.nslot);
 }
 
 // 1x1 mix: z_out = z_in A
 __global__ void k_mix_bwd(Geo g, const float *__restrict__ zin, const float *__restrict__ A, float *__restrict__ dz,
-                          double *__restrict__ dA)
+                          Acc dA)
 {
     float m[16], acc[16];
 #pragma unroll
@@ -483,7 +517,7 @@ __global__ void k_mix_bwd(Geo g, const float *__restrict__ zin, const float *__r
         }
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc_add(dA + i, acc[i]);
+    for (int i = 0; i < 16; ++i) acc_add(dA + i, acc[i], g.nslot);
 }
 
 // coupling, stage 1: through the affine transform, tanh, exp(3 logs); leaves d loss / d u in `gu`,
@@ -491,7 +525,7 @@ __global__ void k_mix_bwd(Geo g, const float *__restrict__ zin, const float *__r
 template <int W>
 __global__ void k_c3_bwd(Geo g, const float *__restrict__ zin, const float *__restrict__ h2, const float *__restrict__ bn2,
                          const float *__restrict__ P, int off_w3, float invB, float *__restrict__ dz,
-                         float *__restrict__ gu, double *__restrict__ G)
+                         float *__restrict__ gu, Acc G)
 {
     const float *W3 = P + off_w3, *b3 = W3 + 36 * (W + 1), *logs = b3 + 4;
     const float sc = logs[4];
@@ -535,16 +569,16 @@ __global__ void k_c3_bwd(Geo g, const float *__restrict__ zin, const float *__re
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        acc_add(G + off_b3 + k, g_b3[k]);
-        acc_add(G + off_b3 + 4 + k, g_logs[k]);
+        acc_add(G + off_b3 + k, g_b3[k], g.nslot);
+        acc_add(G + off_b3 + 4 + k, g_logs[k], g.nslot);
     }
-    acc_add(G + off_b3 + 8, g_s);
+    acc_add(G + off_b3 + 8, g_s, g.nslot);
 }
 
 // d l_last/W: one filter tap per blockIdx.y
 template <int W>
 __global__ void k_w3_grad(Geo g, const float *__restrict__ h2, const float *__restrict__ bn2, const float *__restrict__ gu,
-                          int off_w3, double *__restrict__ G)
+                          int off_w3, Acc G)
 {
     const int tap = blockIdx.y, di = tap / 3, dj = tap - di * 3;
     float acc[W + 1][4];
@@ -572,18 +606,18 @@ __global__ void k_w3_grad(Geo g, const float *__restrict__ h2, const float *__re
             }
         }
     }
-    double *dst = G + off_w3 + tap * (W + 1) * 4;
+    const Acc dst = G + off_w3 + tap * (W + 1) * 4;
 #pragma unroll
     for (int i = 0; i <= W; ++i)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) acc_add(dst + i * 4 + k, acc[i][k]);
+        for (int k = 0; k < 4; ++k) acc_add(dst + i * 4 + k, acc[i][k], g.nslot);
 }
 
 // coupling, stage 2: transposed l_last + ReLU mask -> d loss / d xhat2 (into t1) and the two
 // batch sums the BN backward needs
 template <int W>
 __global__ void k_c3_dh(Geo g, const float *__restrict__ h2, const float *__restrict__ bn2, const float *__restrict__ P,
-                        int off_w3, const float *__restrict__ gu, float *__restrict__ t1, double *__restrict__ bstats)
+                        int off_w3, const float *__restrict__ gu, float *__restrict__ t1, Acc bstats)
 {
     const float *W3 = P + off_w3;
     float s[W], q[W];
@@ -620,17 +654,30 @@ __global__ void k_c3_dh(Geo g, const float *__restrict__ h2, const float *__rest
     }
 #pragma unroll
     for (int j = 0; j < W; ++j) {
-        acc_add(bstats + j, s[j]);
-        acc_add(bstats + W + j, q[j]);
+        acc_add(bstats + j, s[j], g.nslot);
+        acc_add(bstats + W + j, q[j], g.nslot);
     }
 }
 
-__global__ void k_bnb_finalize(int W, const double *__restrict__ bstats, double n, float *__restrict__ bb)
+__global__ void k_bnb_finalize(int W, Acc bstats, int nslot, double n, float *__restrict__ bb)
 {
-    const int j = threadIdx.x;
-    if (j >= W) return;
-    bb[j] = (float)(bstats[j] / n);
-    bb[W + j] = (float)(bstats[W + j] / n);
+    const int j = blockIdx.x;   // one wavefront per channel
+    const double a = acc_total(bstats + j, nslot) / n, b = acc_total(bstats + W + j, nslot) / n;
+    if (threadIdx.x != 0) return;
+    bb[j] = (float)a;
+    bb[W + j] = (float)b;
+}
+
+// G[i] = sum of the partials of value i, one wavefront per value
+__global__ void k_reduce(int n, const float *__restrict__ part, int nslot, double *__restrict__ G)
+{
+    const int i = blockIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int k = threadIdx.x; k < nslot; k += 64) s += (double)part[(size_t)i * NSLOT + k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (threadIdx.x == 0) G[i] = s;
 }
 
 // coupling, stage 3: BN2 backward -> g_h2 (t1, in place), d l_2/b; transposed l_2 + ReLU mask ->
@@ -638,8 +685,7 @@ __global__ void k_bnb_finalize(int W, const double *__restrict__ bstats, double 
 template <int W>
 __global__ void k_c2_bwd(Geo g, const float *__restrict__ h1, const float *__restrict__ bn1, const float *__restrict__ h2,
                          const float *__restrict__ bn2, const float *__restrict__ bb2, const float *__restrict__ P,
-                         int off_w2, float *__restrict__ t1, float *__restrict__ t2, double *__restrict__ bstats,
-                         double *__restrict__ G)
+                         int off_w2, float *__restrict__ t1, float *__restrict__ t2, Acc bstats, Acc G)
 {
     const float *W2 = P + off_w2;
     float s[W], q[W], gb[W];
@@ -670,16 +716,16 @@ __global__ void k_c2_bwd(Geo g, const float *__restrict__ h1, const float *__res
     }
 #pragma unroll
     for (int j = 0; j < W; ++j) {
-        acc_add(bstats + j, s[j]);
-        acc_add(bstats + W + j, q[j]);
-        acc_add(G + off_w2 + W * W + j, gb[j]);
+        acc_add(bstats + j, s[j], g.nslot);
+        acc_add(bstats + W + j, q[j], g.nslot);
+        acc_add(G + off_w2 + W * W + j, gb[j], g.nslot);
     }
 }
 
 // d l_2/W: one input channel per blockIdx.y
 template <int W>
 __global__ void k_w2_grad(Geo g, const float *__restrict__ h1, const float *__restrict__ bn1, const float *__restrict__ t1,
-                          int off_w2, double *__restrict__ G)
+                          int off_w2, Acc G)
 {
     const int i = blockIdx.y;
     const float m = bn1[i], rs = bn1[W + i];
@@ -694,13 +740,13 @@ __global__ void k_w2_grad(Geo g, const float *__restrict__ h1, const float *__re
         }
     }
 #pragma unroll
-    for (int j = 0; j < W; ++j) acc_add(G + off_w2 + i * W + j, acc[j]);
+    for (int j = 0; j < W; ++j) acc_add(G + off_w2 + i * W + j, acc[j], g.nslot);
 }
 
 // coupling, stage 4: BN1 backward -> g_h1 (t2, in place), d l_1/b
 template <int W>
 __global__ void k_c1_bwd(Geo g, const float *__restrict__ h1, const float *__restrict__ bn1, const float *__restrict__ bb1,
-                         int off_b1, float *__restrict__ t2, double *__restrict__ G)
+                         int off_b1, float *__restrict__ t2, Acc G)
 {
     float gb[W];
 #pragma unroll
@@ -717,13 +763,12 @@ __global__ void k_c1_bwd(Geo g, const float *__restrict__ h1, const float *__res
         }
     }
 #pragma unroll
-    for (int j = 0; j < W; ++j) acc_add(G + off_b1 + j, gb[j]);
+    for (int j = 0; j < W; ++j) acc_add(G + off_b1 + j, gb[j], g.nslot);
 }
 
 // d l_1/W: one filter tap per blockIdx.y
 template <int W>
-__global__ void k_w1_grad(Geo g, const float *__restrict__ zin, const float *__restrict__ t2, int off_w1,
-                          double *__restrict__ G)
+__global__ void k_w1_grad(Geo g, const float *__restrict__ zin, const float *__restrict__ t2, int off_w1, Acc G)
 {
     const int tap = blockIdx.y, di = tap / 3, dj = tap - di * 3;
     float acc[2][W];
@@ -744,11 +789,11 @@ __global__ void k_w1_grad(Geo g, const float *__restrict__ zin, const float *__r
             }
         }
     }
-    double *dst = G + off_w1 + tap * 2 * W;
+    const Acc dst = G + off_w1 + tap * 2 * W;
 #pragma unroll
     for (int j = 0; j < W; ++j) {
-        acc_add(dst + j, acc[0][j]);
-        acc_add(dst + W + j, acc[1][j]);
+        acc_add(dst + j, acc[0][j], g.nslot);
+        acc_add(dst + W + j, acc[1][j], g.nslot);
     }
 }
 
@@ -891,8 +936,10 @@ struct nf_trainer {
     std::vector<Cpl> cpl;           // indexed by TLayer::aux of coupling layers
     float *d_params = nullptr, *d_m = nullptr, *d_v = nullptr, *d_gradf = nullptr;
     uint8_t *d_mask = nullptr;
-    double *d_dbl = nullptr;        // [0,n_params) gradients, then dA / dab / dgain / BN sums / ldc
+    double *d_dbl = nullptr;        // [0,n_params) gradients, then dA / dab / dgain / BN sums, last: ldc
     size_t n_dbl = 0;
+    float *d_part = nullptr;        // per-workgroup partials of every reducible value: [n_dbl - 1][NSLOT]
+    Acc acc(int idx) const { return Acc{d_part + (size_t)idx * NSLOT}; }
     int d_dA = 0, d_dab = 0, d_dg = 0, d_ldc = 0;
     float *d_flt = nullptr;         // A matrices, sdn5 (a,b), BN scalars
     size_t n_flt = 0;
@@ -916,8 +963,9 @@ int dev_alloc(nf_trainer *t, void **p, size_t bytes)
 
 inline unsigned blocks_for(int64_t npix)
 {
+    // grid-stride loops; at most NSLOT workgroups (= 2 per CU), one partial-sum slot each
     int64_t b = (npix + TB - 1) / TB;
-    return (unsigned)std::min<int64_t>(std::max<int64_t>(b, 1), 4096);
+    return (unsigned)std::min<int64_t>(std::max<int64_t>(b, 1), NSLOT);
 }
 
 struct Guard {
@@ -947,12 +995,12 @@ void coupling_forward(nf_trainer *t, const Geo &g, const TLayer &L, const float 
     const int w = W, off_w1 = L.off, off_m1 = L.off + 19 * w, off_w2 = L.off + 21 * w, off_m2 = L.off + 22 * w + w * w,
               off_w3 = L.off + 24 * w + w * w;
     const double n = (double)g.npix;
-    hipLaunchKernelGGL(k_c1_fwd<W>, dim3(nb), dim3(TB), 0, st, g, zin, t->d_params, off_w1, c.h1, t->d_dbl + c.d_st1);
-    hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(64), 0, st, w, t->d_dbl + c.d_st1, n, t->d_params, off_m1, off_m1 + w,
+    hipLaunchKernelGGL(k_c1_fwd<W>, dim3(nb), dim3(TB), 0, st, g, zin, t->d_params, off_w1, c.h1, t->acc(c.d_st1));
+    hipLaunchKernelGGL(k_bn_finalize, dim3(w), dim3(64), 0, st, w, t->acc(c.d_st1), (int)nb, n, t->d_params, off_m1, off_m1 + w,
                        t->d_flt + c.f_bn1);
     hipLaunchKernelGGL(k_c2_fwd<W>, dim3(nb), dim3(TB), 0, st, g, c.h1, t->d_flt + c.f_bn1, t->d_params, off_w2, c.h2,
-                       t->d_dbl + c.d_st2);
-    hipLaunchKernelGGL(k_bn_finalize, dim3(1), dim3(64), 0, st, w, t->d_dbl + c.d_st2, n, t->d_params, off_m2, off_m2 + w,
+                       t->acc(c.d_st2));
+    hipLaunchKernelGGL(k_bn_finalize, dim3(w), dim3(64), 0, st, w, t->acc(c.d_st2), (int)nb, n, t->d_params, off_m2, off_m2 + w,
                        t->d_flt + c.f_bn2);
     hipLaunchKernelGGL(k_c3_fwd<W>, dim3(nb), dim3(TB), 0, st, g, zin, c.h2, t->d_flt + c.f_bn2, t->d_params, off_w3, zout,
                        t->d_patch);
@@ -963,20 +1011,20 @@ void coupling_backward(nf_trainer *t, const Geo &g, const TLayer &L, const float
 {
     const Cpl &c = t->cpl[L.aux];
     const unsigned nb = blocks_for(g.npix);
-    const unsigned ng = std::min(nb, 256u);   // the weight-gradient kernels: fewer, longer threads
     const int w = W, off_w1 = L.off, off_b1 = L.off + 18 * w, off_w2 = L.off + 21 * w, off_w3 = L.off + 24 * w + w * w;
     const double n = (double)g.npix;
     const float *bn1 = t->d_flt + c.f_bn1, *bn2 = t->d_flt + c.f_bn2;
     float *bb1 = t->d_flt + c.f_bb1, *bb2 = t->d_flt + c.f_bb2;
-    double *G = t->d_dbl;
+    const Acc G = t->acc(0);
+    const unsigned ng = std::min(nb, 96u);   // filter-gradient kernels: grid.y multiplies the workgroup count
     hipLaunchKernelGGL(k_c3_bwd<W>, dim3(nb), dim3(TB), 0, st, g, zin, c.h2, bn2, t->d_params, off_w3, invB, t->dz, t->gu, G);
     hipLaunchKernelGGL(k_w3_grad<W>, dim3(ng, 9), dim3(TB), 0, st, g, c.h2, bn2, t->gu, off_w3, G);
-    hipLaunchKernelGGL(k_c3_dh<W>, dim3(nb), dim3(TB), 0, st, g, c.h2, bn2, t->d_params, off_w3, t->gu, t->t1, G + c.d_bs2);
-    hipLaunchKernelGGL(k_bnb_finalize, dim3(1), dim3(64), 0, st, w, G + c.d_bs2, n, bb2);
+    hipLaunchKernelGGL(k_c3_dh<W>, dim3(nb), dim3(TB), 0, st, g, c.h2, bn2, t->d_params, off_w3, t->gu, t->t1, t->acc(c.d_bs2));
+    hipLaunchKernelGGL(k_bnb_finalize, dim3(w), dim3(64), 0, st, w, t->acc(c.d_bs2), (int)nb, n, bb2);
     hipLaunchKernelGGL(k_c2_bwd<W>, dim3(nb), dim3(TB), 0, st, g, c.h1, bn1, c.h2, bn2, bb2, t->d_params, off_w2, t->t1, t->t2,
-                       G + c.d_bs1, G);
+                       t->acc(c.d_bs1), G);
     hipLaunchKernelGGL(k_w2_grad<W>, dim3(ng, w), dim3(TB), 0, st, g, c.h1, bn1, t->t1, off_w2, G);
-    hipLaunchKernelGGL(k_bnb_finalize, dim3(1), dim3(64), 0, st, w, G + c.d_bs1, n, bb1);
+    hipLaunchKernelGGL(k_bnb_finalize, dim3(w), dim3(64), 0, st, w, t->acc(c.d_bs1), (int)nb, n, bb1);
     hipLaunchKernelGGL(k_c1_bwd<W>, dim3(nb), dim3(TB), 0, st, g, c.h1, bn1, bb1, off_b1, t->t2, G);
     hipLaunchKernelGGL(k_w1_grad<W>, dim3(ng, 9), dim3(TB), 0, st, g, zin, t->t2, off_w1, G);
     hipLaunchKernelGGL(k_c1_dz<W>, dim3(nb), dim3(TB), 0, st, g, t->t2, t->d_params, off_w1, t->dz);
@@ -1118,7 +1166,6 @@ int nf_trainer_create(const nf_config *cfg, const nf_layer_desc *layers, const f
     t->d_dA = (int)nd; nd += 16 * (size_t)n_mix;
     t->d_dab = (int)nd; nd += 2 * (size_t)n_sdn;
     t->d_dg = (int)nd; nd += (size_t)n_gain;
-    t->d_ldc = (int)nd; nd += 1;
     t->cpl.resize(n_cpl);
     for (Cpl &c : t->cpl) {
         c.d_st1 = (int)nd; nd += 2 * w;
@@ -1126,6 +1173,7 @@ int nf_trainer_create(const nf_config *cfg, const nf_layer_desc *layers, const f
         c.d_bs1 = (int)nd; nd += 2 * w;
         c.d_bs2 = (int)nd; nd += 2 * w;
     }
+    t->d_ldc = (int)nd; nd += 1;   // last: the only value accumulated directly (k_prep), not through slots
     t->n_dbl = nd;
     // float scalars
     size_t nf = 0;
@@ -1150,6 +1198,7 @@ int nf_trainer_create(const nf_config *cfg, const nf_layer_desc *layers, const f
     NF_TRY(dev_alloc(t, (void **)&t->d_gradf, n_params * sizeof(float)));
     NF_TRY(dev_alloc(t, (void **)&t->d_mask, n_params));
     NF_TRY(dev_alloc(t, (void **)&t->d_dbl, nd * sizeof(double)));
+    NF_TRY(dev_alloc(t, (void **)&t->d_part, (nd - 1) * NSLOT * sizeof(float)));
     NF_TRY(dev_alloc(t, (void **)&t->d_flt, nf * sizeof(float)));
     NF_TRY(dev_alloc(t, (void **)&t->d_patch, 3 * (size_t)max_batch * sizeof(float)));
     t->zs.assign(cfg->n_layers + 1, nullptr);
@@ -1167,7 +1216,9 @@ int nf_trainer_create(const nf_config *cfg, const nf_layer_desc *layers, const f
         (e = hipMemcpy(t->d_mask, mask.data(), n_params, hipMemcpyHostToDevice)) != hipSuccess ||
         (e = hipMemset(t->d_m, 0, n_params * sizeof(float))) != hipSuccess ||
         (e = hipMemset(t->d_v, 0, n_params * sizeof(float))) != hipSuccess ||
-        (e = hipMemset(t->d_gradf, 0, n_params * sizeof(float))) != hipSuccess) {
+        (e = hipMemset(t->d_gradf, 0, n_params * sizeof(float))) != hipSuccess ||
+        // slots of values no kernel ever writes (constants, the gain parameters of other ISOs) stay zero
+        (e = hipMemset(t->d_part, 0, (nd - 1) * NSLOT * sizeof(float))) != hipSuccess) {
         nf_trainer_destroy(t);
         return nf_fail_hip(e, "trainer initialisation");
     }
@@ -1197,10 +1248,11 @@ int nf_trainer_forward_backward(nf_trainer *t, const float *x, const float *y, i
     g.npix = B * (int64_t)g.HW;
     g.nloop = (g.npix + 63) & ~(int64_t)63;
     const unsigned nb = blocks_for(g.npix);
+    g.nslot = (int)nb;
     const float invB = 1.0f / (float)B;
     const int n = t->cfg.n_layers;
     hipError_t e;
-    if ((e = hipMemsetAsync(t->d_dbl, 0, t->n_dbl * sizeof(double), st)) != hipSuccess ||
+    if ((e = hipMemsetAsync(t->d_dbl + t->d_ldc, 0, sizeof(double), st)) != hipSuccess ||
         (e = hipMemsetAsync(t->d_patch, 0, 3 * (size_t)t->max_batch * sizeof(float), st)) != hipSuccess)
         return nf_fail_hip(e, "hipMemsetAsync(trainer accumulators)");
     float *ld = t->d_patch, *s1 = ld + t->max_batch, *s2 = s1 + t->max_batch;
@@ -1241,15 +1293,15 @@ int nf_trainer_forward_backward(nf_trainer *t, const float *x, const float *y, i
         switch (L.type) {
         case NF_LAYER_SDN5:
             hipLaunchKernelGGL(k_sdn_bwd, dim3(nb), dim3(TB), 0, st, g, t->zs[l], y, t->d_flt + t->f_ab + 2 * L.aux, invB, t->dz,
-                               G + t->d_dab + 2 * L.aux);
+                               t->acc(t->d_dab + 2 * L.aux));
             break;
         case NF_LAYER_GAIN4:
             hipLaunchKernelGGL(k_scale_bwd, dim3(nb), dim3(TB), 0, st, g, t->zs[l + 1], t->d_params + L.off, t->dz,
-                               G + t->d_dg + L.aux);
+                               t->acc(t->d_dg + L.aux));
             break;
         case NF_LAYER_CONV1X1:
             hipLaunchKernelGGL(k_mix_bwd, dim3(nb), dim3(TB), 0, st, g, t->zs[l], t->d_flt + t->f_A + 16 * L.aux, t->dz,
-                               G + t->d_dA + 16 * L.aux);
+                               t->acc(t->d_dA + 16 * L.aux));
             break;
         case NF_LAYER_COUPLING:
 #define NF_CALL(WW) coupling_backward<WW>(t, g, L, t->zs[l], invB, st)
@@ -1258,6 +1310,7 @@ int nf_trainer_forward_backward(nf_trainer *t, const float *x, const float *y, i
             break;
         }
     }
+    hipLaunchKernelGGL(k_reduce, dim3((unsigned)t->d_ldc), dim3(64), 0, st, t->d_ldc, t->d_part, (int)nb, G);
     hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, st, t->tl, t->d_params, ci, g.HW, G + t->d_dA, G + t->d_dab, G + t->d_dg, G);
     float *gout = grads_out ? grads_out : t->d_gradf;
     hipLaunchKernelGGL(k_grads_out, dim3((t->n_params + TB - 1) / TB), dim3(TB), 0, st, t->n_params, G, t->d_mask, gout);
