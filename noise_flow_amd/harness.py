@@ -12,6 +12,13 @@ hot path, with the reference's call pattern and on-disk formats.
   fixed ISO 100 / camera S6, sample, marginal KL vs the real noise, NLL of the
   sample.
 
+* ``train_epoch`` / ``fit`` — ``train_multithread`` / ``train_thread`` and the epoch loop of
+  ``main`` (reference ``train_noise_flow.py:27-77, 379-511``): one training step per minibatch
+  dict, epoch loss = mean of the per-minibatch losses, test / sampling on the reference's epoch
+  schedule, ``model.ckpt-<epoch>`` + ``model.ckpt.best`` checkpoints, the three TSV logs.
+  The reference runs its 16 training threads Hogwild-style on one session; here the steps of an
+  epoch are enqueued in order on one stream (deterministic).
+
 Minibatch dicts follow ``noise_flow_amd.patches.make_minibatch``.  Threads are
 optional (``n_threads``): the HIP handle is re-entrant like the shared tf.Session.
 """
@@ -25,6 +32,11 @@ from typing import Iterable, List, Sequence
 import numpy as np
 
 from .metrics import kl_div_3_data, noise_bin_edges
+
+
+def _np(a) -> np.ndarray:
+    """numpy view of a minibatch field (numpy array or torch tensor on any device)."""
+    return a.detach().cpu().numpy() if hasattr(a, "detach") else np.asarray(a)
 
 
 class ResultLogger(object):
@@ -51,6 +63,7 @@ class ResultLogger(object):
             pass
 
 
+TRAIN_COLUMNS = ["epoch", "NLL", "NLL_G", "NLL_SDN", "sdz", "train_time"]                # train_noise_flow.py:346
 TEST_COLUMNS = ["epoch", "NLL", "NLL_G", "NLL_SDN", "sdz", "msg"]                       # train_noise_flow.py:340
 SAMPLE_COLUMNS = ["epoch", "NLL", "NLL_G", "NLL_SDN", "sdz", "sample_time",             # train_noise_flow.py:344-348
                   "KLD_G", "KLD_NLF", "KLD_NF", "KLD_R"]
@@ -115,16 +128,87 @@ def sample_epoch(nf, minibatches: Iterable[dict], temp: float = 1.0, fix_iso: fl
     def one(mb):
         y = mb["_y"]
         xs = nf.sample(y, temp, y, [nlf0], [nlf1], [fix_iso], [fix_cam])
-        kl_nf = kl_div_3_data(np.asarray(mb["_x"]).ravel(), np.asarray(xs).ravel(), edges)[0]
+        kl_nf = kl_div_3_data(_np(mb["_x"]).ravel(), _np(xs).ravel(), edges)[0]
         loss, sd_z = nf.loss(xs, y, [nlf0], [nlf1], [fix_iso], [fix_cam])
         return kl_nf, float(loss), float(sd_z)
 
     res = _run_threads(one, mbs, n_threads)
     kl_nlf = []
     for mb in mbs:   # the camera-NLF baseline draw (host side, like kldiv_patch_set)
-        y = np.asarray(mb["_y"], np.float64)
+        y = _np(mb["_y"]).astype(np.float64)
         nl = np.sqrt(nlf0 * y + nlf1) * rng.standard_normal(y.shape)
-        kl_nlf.append(kl_div_3_data(np.asarray(mb["_x"]).ravel(), nl.ravel(), edges)[0])
+        kl_nlf.append(kl_div_3_data(_np(mb["_x"]).ravel(), nl.ravel(), edges)[0])
     return {"NLL": float(np.mean([r[1] for r in res])), "sdz": float(np.mean([r[2] for r in res])),
             "KLD_NF": float(np.mean([r[0] for r in res])), "KLD_NLF": float(np.mean(kl_nlf)),
             "sample_time": time.time() - t0}
+
+
+def train_epoch(trainer, minibatches: Iterable[dict], lr: float, group=None):
+    """``train_multithread`` (train_noise_flow.py:27-77, 484-504) → (mean over minibatches of the
+    training loss, mean sd_z, per-batch losses).  Steps are enqueued back to back; the losses are
+    read once at the end of the epoch (one synchronisation per epoch, not per step)."""
+    outs = []
+    for mb in minibatches:
+        out = trainer.step(mb["_x"], mb["_y"], mb["nlf0"], mb["nlf1"], mb["iso"], mb["cam"], lr=lr, group=group,
+                           sync=False)
+        outs.append(out.clone())
+    if not outs:
+        return float("nan"), float("nan"), []
+    vals = np.stack([o.cpu().numpy() for o in outs]).astype(np.float64)
+    return float(vals[:, 0].mean()), float(vals[:, 1].mean()), [float(v) for v in vals[:, 0]]
+
+
+def _is_eval_epoch(epoch: int, epochs_full_valid: int) -> bool:
+    """train_noise_flow.py:386-387."""
+    return epoch < 10 or (epoch < 100 and epoch % 10 == 0) or epoch % epochs_full_valid == 0
+
+
+def fit(trainer, nf_eval, train_mbs: Sequence[dict], test_mbs: Sequence[dict], logdir: str, epochs: int, lr: float,
+        epochs_full_valid: int = 10, nll_gauss: float = 0.0, nll_sdn: float = 0.0, do_sampling: bool = True,
+        start_epoch: int = 1, group=None, log=None):
+    """The epoch loop of ``train_noise_flow.py:379-511``: per epoch test (on the reference's
+    schedule; saves ``ckpt/model.ckpt-<epoch>`` and ``ckpt/model.ckpt.best``), sampling, training;
+    appends to ``train.txt`` / ``test.txt`` / ``sample.txt`` under ``logdir``.
+
+    ``trainer``: :class:`noise_flow_amd.train.Trainer`; ``nf_eval``: an eval-mode
+    :class:`NoiseFlow` of the same architecture (refreshed from the trainer before each test /
+    sampling epoch).  → dict of the per-epoch result lists."""
+    import os
+    os.makedirs(os.path.join(logdir, "ckpt"), exist_ok=True)
+    ckpt_path = os.path.join(logdir, "ckpt", "model.ckpt")
+    append = start_epoch > 1
+    train_logger = ResultLogger(os.path.join(logdir, "train.txt"), TRAIN_COLUMNS, append)
+    test_logger = ResultLogger(os.path.join(logdir, "test.txt"), TEST_COLUMNS, append)
+    sample_logger = ResultLogger(os.path.join(logdir, "sample.txt"), SAMPLE_COLUMNS, append)
+    res = {"train": [], "test": [], "sample": []}
+    best = float("inf")
+    train_time = 0.0
+    for epoch in range(start_epoch, epochs + 1):
+        evaluate = _is_eval_epoch(epoch, epochs_full_valid)
+        if evaluate:
+            nf_eval.load_variables(trainer.variables)
+            nll, sdz, _ = test_epoch(nf_eval, test_mbs)
+            res["test"].append(nll)
+            trainer.save("%s-%d" % (ckpt_path, epoch))
+            is_best = int(nll < best)
+            if is_best:
+                best = nll
+                trainer.save(ckpt_path + ".best")
+            test_logger.log({"epoch": epoch, "NLL": nll, "NLL_G": nll_gauss, "NLL_SDN": nll_sdn, "sdz": sdz, "msg": is_best})
+            if do_sampling:
+                sr = sample_epoch(nf_eval, test_mbs, temp=1.0)
+                res["sample"].append(sr["NLL"])
+                sample_logger.log({"epoch": epoch, "NLL": sr["NLL"], "NLL_G": nll_gauss, "NLL_SDN": nll_sdn, "sdz": sr["sdz"],
+                                   "sample_time": sr["sample_time"], "KLD_G": 0.0, "KLD_NLF": sr["KLD_NLF"],
+                                   "KLD_NF": sr["KLD_NF"], "KLD_R": 0.0})
+        t = time.time()
+        nll_tr, sdz_tr, _ = train_epoch(trainer, train_mbs, lr, group)
+        train_time += time.time() - t
+        res["train"].append(nll_tr)
+        train_logger.log({"epoch": epoch, "train_time": int(train_time), "NLL": nll_tr, "NLL_G": nll_gauss, "NLL_SDN": nll_sdn,
+                          "sdz": sdz_tr})
+        if log is not None and evaluate:
+            log("epoch %d  train %.4f  test %.4f  best %.4f" % (epoch, nll_tr, res["test"][-1], best))
+    for lg in (train_logger, test_logger, sample_logger):
+        lg.close()
+    return res

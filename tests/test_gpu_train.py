@@ -216,3 +216,64 @@ def test_trainer_c_abi_errors(shipped_variables):
     h = C.c_void_p()
     rc = lib.nf_trainer_create(C.byref(cfg), descs, flat.ctypes.data_as(C.POINTER(C.c_float)), flat.size, 4, 0, C.byref(h))
     assert rc == _lib.NF_EINVAL and b"training covers" in lib.nf_last_error()
+
+
+def test_fit_epoch_loop_logs_checkpoints_and_learns(tmp_path):
+    """harness.fit = the epoch loop of train_noise_flow.py:379-511 on synthetic NLF noise."""
+    from noise_flow_amd import NoiseFlow, default_hps, patches
+    from noise_flow_amd.harness import fit, TRAIN_COLUMNS, TEST_COLUMNS, SAMPLE_COLUMNS
+    from noise_flow_amd.train import Trainer
+    arch = "sdn5|unc|gain4|unc"
+    hps = default_hps(arch=arch, seed=1)
+    tr = Trainer([32, 32, 4], hps, max_batch=32)
+    nf = NoiseFlow([32, 32, 4], False, hps, variables=tr.variables)
+    nlf = (0.003696, 2e-6)
+
+    def mbs(first, n):
+        out = []
+        for k in range(n):
+            x, y = patches.synth_patches(3, first + 32 * k, 32, nlf=nlf)
+            out.append({"_x": x, "_y": y, "nlf0": [nlf[0]], "nlf1": [nlf[1]], "iso": [800.0], "cam": [2.0]})
+        return out
+
+    logdir = str(tmp_path)
+    res = fit(tr, nf, mbs(0, 6), mbs(1000, 2), logdir, epochs=12, lr=2e-3, epochs_full_valid=10)
+    assert len(res["train"]) == 12 and len(res["test"]) == 10      # epochs 1..9 and 10
+    assert res["test"][-1] < res["test"][0] - 10.0                  # it learns
+    for name, cols, rows in (("train.txt", TRAIN_COLUMNS, 12), ("test.txt", TEST_COLUMNS, 10), ("sample.txt", SAMPLE_COLUMNS, 10)):
+        lines = open(os.path.join(logdir, name)).read().split("\n")
+        assert lines[0].split("\t") == cols and len(lines) == rows + 1, name
+    # the best checkpoint restores into the eval path and reproduces the best test loss
+    from noise_flow_amd.harness import test_epoch
+    m = NoiseFlow([32, 32, 4], False, hps)
+    m.restore(os.path.join(logdir, "ckpt", "model.ckpt.best"))
+    nll, _, _ = test_epoch(m, mbs(1000, 2))
+    assert abs(nll - min(res["test"])) <= 1e-4 * abs(nll)
+    assert os.path.exists(os.path.join(logdir, "ckpt", "model.ckpt-10.index"))
+
+
+def test_data_parallel_step_on_a_one_rank_group(shipped_variables):
+    """step(group=...) = forward_backward -> all_reduce(SUM)/world -> apply; on a 1-rank RCCL group it
+    must leave bit-identical parameters (the collective itself is exercised)."""
+    import torch
+    import torch.distributed as dist
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        created = True
+    try:
+        x, y = make_inputs(8, seed=12, b1=0.003696)
+        a = _trainer(FULL_ARCH, shipped_variables)
+        b = _trainer(FULL_ARCH, shipped_variables)
+        for _ in range(3):
+            la = a.step(x, y, [0.0], [0.0], [800], [2], lr=1e-3)
+            lb = b.step(x, y, [0.0], [0.0], [800], [2], lr=1e-3, group=True)
+            # the reported loss sums per-patch float atomics (order-dependent in the last bits) ...
+            assert abs(la[0] - lb[0]) <= 1e-6 * abs(la[0]) and abs(la[1] - lb[1]) <= 1e-6 * la[1]
+        # ... the gradients and the update are slot-reduced and deterministic
+        assert np.array_equal(a.raw_params(), b.raw_params())
+    finally:
+        if created:
+            dist.destroy_process_group()
