@@ -93,11 +93,42 @@ __device__ __forceinline__ void acc_add(Acc dst, float v, int nslot)
     }
 }
 
-// sum of the first `nslot` slots of one value, computed by one whole wavefront
+// N consecutive values with ONE barrier pair (the per-value form above costs two barriers each)
+template <int N>
+__device__ __forceinline__ void acc_add_n(Acc dst, const float (&v)[N], int nslot)
+{
+    __shared__ float part[TB / 64][N];
+    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    __syncthreads();                       // the previous use of `part` is over
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const float s = wsum(v[k]);
+        if (ln == 0) part[wv][k] = s;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < N; k += TB) {
+        float tot = 0.0f;
+#pragma unroll
+        for (int i = 0; i < TB / 64; ++i) tot += part[i][k];
+        float *d = dst.p + (size_t)k * NSLOT;
+        d[blockIdx.x] = tot;
+        for (int q = blockIdx.x + gridDim.x; q < nslot; q += gridDim.x) d[q] = 0.0f;
+    }
+}
+
+// sum of the first `nslot` slots of one value, computed by one whole wavefront; the loads are
+// issued together (the slots were written by other XCDs, so each one is a long-latency miss)
 __device__ __forceinline__ double acc_total(Acc a, int nslot)
 {
+    float x[NSLOT / 64];
+#pragma unroll
+    for (int k = 0; k < NSLOT / 64; ++k) {
+        const int i = (threadIdx.x & 63) + 64 * k;
+        x[k] = i < nslot ? a.p[i] : 0.0f;
+    }
     double s = 0.0;
-    for (int i = threadIdx.x & 63; i < nslot; i += 64) s += (double)a.p[i];
+#pragma unroll
+    for (int k = 0; k < NSLOT / 64; ++k) s += (double)x[k];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     return s;
@@ -279,33 +310,62 @@ __global__ void k_c1_fwd(Geo g, const float *__restrict__ zin, const float *__re
             }
         }
     }
+    float sq[2 * W];
 #pragma unroll
     for (int j = 0; j < W; ++j) {
-        acc_add(stats + j, s[j], g.nslot);
-        acc_add(stats + W + j, q[j], g.nslot);
+        sq[j] = s[j];
+        sq[W + j] = q[j];
     }
+    acc_add_n<2 * W>(stats, sq, g.nslot);
 }
 
-// batch moments -> (mean, 1/sqrt(var+eps)); running statistics <- EMA (layers.py:388-393)
-__global__ void k_bn_finalize(int W, Acc stats, int nslot, double n, float *__restrict__ P, int off_mean, int off_var,
-                              float *__restrict__ bn)
+// BN finalisers, fused into the kernel that consumes them: EVERY workgroup adds up the slot sums
+// (one wavefront per channel, fp64) and keeps (mean, 1/sqrt(var+eps)) in LDS; workgroup 0 also
+// publishes them for the backward pass and moves the running statistics (layers.py:388-393).
+template <int W>
+__device__ __forceinline__ void bn_from_slots(Acc stats, int nslot, double n, float *sh, float *__restrict__ P,
+                                              int off_mean, int off_var, float *__restrict__ bn_out)
 {
-    const int j = blockIdx.x;   // one wavefront per channel
-    const double m = acc_total(stats + j, nslot) / n;
-    double v = acc_total(stats + W + j, nslot) / n - m * m;
-    if (v < 0.0) v = 0.0;
-    if (threadIdx.x != 0) return;
-    bn[j] = (float)m;
-    bn[W + j] = (float)(1.0 / sqrt(v + (double)kBnEps));
-    P[off_mean + j] -= kBnDecay * (P[off_mean + j] - (float)m);
-    P[off_var + j] -= kBnDecay * (P[off_var + j] - (float)v);
+    for (int j = threadIdx.x >> 6; j < W; j += TB / 64) {
+        const double m = acc_total(stats + j, nslot) / n;
+        double v = acc_total(stats + W + j, nslot) / n - m * m;
+        if (v < 0.0) v = 0.0;
+        if ((threadIdx.x & 63) == 0) {
+            const float mf = (float)m, rf = (float)(1.0 / sqrt(v + (double)kBnEps));
+            sh[j] = mf;
+            sh[W + j] = rf;
+            if (blockIdx.x == 0 && blockIdx.y == 0) {
+                bn_out[j] = mf;
+                bn_out[W + j] = rf;
+                P[off_mean + j] -= kBnDecay * (P[off_mean + j] - mf);
+                P[off_var + j] -= kBnDecay * (P[off_var + j] - (float)v);
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// the two batch means of the BN backward formula, same scheme
+template <int W>
+__device__ __forceinline__ void bnb_from_slots(Acc bstats, int nslot, double n, float *sh)
+{
+    for (int j = threadIdx.x >> 6; j < W; j += TB / 64) {
+        const double a = acc_total(bstats + j, nslot) / n, b = acc_total(bstats + W + j, nslot) / n;
+        if ((threadIdx.x & 63) == 0) {
+            sh[j] = (float)a;
+            sh[W + j] = (float)b;
+        }
+    }
+    __syncthreads();
 }
 
 // BN1 + ReLU + l_2 (1x1) + bias; statistics of the result
 template <int W>
-__global__ void k_c2_fwd(Geo g, const float *__restrict__ h1, const float *__restrict__ bn1, const float *__restrict__ P,
-                         int off_w2, float *__restrict__ h2, Acc stats)
+__global__ void k_c2_fwd(Geo g, const float *__restrict__ h1, Acc stats1, double n, float *__restrict__ P, int off_m1,
+                         float *__restrict__ bn1_out, int off_w2, float *__restrict__ h2, Acc stats)
 {
+    __shared__ float bn1[2 * W];
+    bn_from_slots<W>(stats1, g.nslot, n, bn1, P, off_m1, off_m1 + W, bn1_out);
     const float *W2 = P + off_w2, *b2 = W2 + W * W;
     float s[W], q[W];
 #pragma unroll
@@ -329,11 +389,13 @@ __global__ void k_c2_fwd(Geo g, const float *__restrict__ h1, const float *__res
             }
         }
     }
+    float sq[2 * W];
 #pragma unroll
     for (int j = 0; j < W; ++j) {
-        acc_add(stats + j, s[j], g.nslot);
-        acc_add(stats + W + j, q[j], g.nslot);
+        sq[j] = s[j];
+        sq[W + j] = q[j];
     }
+    acc_add_n<2 * W>(stats, sq, g.nslot);
 }
 
 // the l_last pre-activation u = conv3x3_VALID(pad(relu(bn2(h2))) ++ edge) + b  (layers.py:491, 555-583, 651-670)
@@ -367,9 +429,12 @@ __device__ __forceinline__ void l_last_u(const Geo &g, int b, int r, int c, cons
 
 // BN2 + ReLU + l_last + affine transform of the second half (layers.py:355-375)
 template <int W>
-__global__ void k_c3_fwd(Geo g, const float *__restrict__ zin, const float *__restrict__ h2, const float *__restrict__ bn2,
-                         const float *__restrict__ P, int off_w3, float *__restrict__ zout, float *__restrict__ ld)
+__global__ void k_c3_fwd(Geo g, const float *__restrict__ zin, const float *__restrict__ h2, Acc stats2, double n,
+                         float *__restrict__ P, int off_m2, float *__restrict__ bn2_out, int off_w3,
+                         float *__restrict__ zout, float *__restrict__ ld)
 {
+    __shared__ float bn2[2 * W];
+    bn_from_slots<W>(stats2, g.nslot, n, bn2, P, off_m2, off_m2 + W, bn2_out);
     const float *W3 = P + off_w3, *b3 = W3 + 36 * (W + 1), *logs = b3 + 4;
     const float sc = logs[4];
     NF_PIXEL_LOOP(g, p) {
@@ -488,8 +553,8 @@ __global__ void k_sdn_bwd(Geo g, const float *__restrict__ x, const float *__res
             reinterpret_cast<float4 *>(dz)[p] = make_float4(ds[0], ds[1], ds[2], ds[3]);
         }
     }
-    acc_add(dab, ga, g.nslot);
-    acc_add(dab + 1, gb, g.nslot);
+    const float gab[2] = {ga, gb};
+    acc_add_n<2>(dab, gab, g.nslot);
 }
 
 // 1x1 mix: z_out = z_in A
@@ -516,8 +581,7 @@ __global__ void k_mix_bwd(Geo g, const float *__restrict__ zin, const float *__r
             reinterpret_cast<float4 *>(dz)[p] = make_float4(o[0], o[1], o[2], o[3]);
         }
     }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc_add(dA + i, acc[i], g.nslot);
+    acc_add_n<16>(dA, acc, g.nslot);
 }
 
 // coupling, stage 1: through the affine transform, tanh, exp(3 logs); leaves d loss / d u in `gu`,
@@ -567,12 +631,8 @@ __global__ void k_c3_bwd(Geo g, const float *__restrict__ zin, const float *__re
             reinterpret_cast<float4 *>(dz)[p] = d;
         }
     }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        acc_add(G + off_b3 + k, g_b3[k], g.nslot);
-        acc_add(G + off_b3 + 4 + k, g_logs[k], g.nslot);
-    }
-    acc_add(G + off_b3 + 8, g_s, g.nslot);
+    const float tail[9] = {g_b3[0], g_b3[1], g_b3[2], g_b3[3], g_logs[0], g_logs[1], g_logs[2], g_logs[3], g_s};
+    acc_add_n<9>(G + off_b3, tail, g.nslot);   // l_last/b, l_last/logs, rescaling_scale are adjacent
 }
 
 // d l_last/W: one filter tap per blockIdx.y
@@ -606,11 +666,12 @@ __global__ void k_w3_grad(Geo g, const float *__restrict__ h2, const float *__re
             }
         }
     }
-    const Acc dst = G + off_w3 + tap * (W + 1) * 4;
+    float flat[(W + 1) * 4];
 #pragma unroll
     for (int i = 0; i <= W; ++i)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) acc_add(dst + i * 4 + k, acc[i][k], g.nslot);
+        for (int k = 0; k < 4; ++k) flat[i * 4 + k] = acc[i][k];
+    acc_add_n<(W + 1) * 4>(G + off_w3 + tap * (W + 1) * 4, flat, g.nslot);
 }
 
 // coupling, stage 2: transposed l_last + ReLU mask -> d loss / d xhat2 (into t1) and the two
@@ -652,20 +713,13 @@ __global__ void k_c3_dh(Geo g, const float *__restrict__ h2, const float *__rest
             }
         }
     }
+    float sq[2 * W];
 #pragma unroll
     for (int j = 0; j < W; ++j) {
-        acc_add(bstats + j, s[j], g.nslot);
-        acc_add(bstats + W + j, q[j], g.nslot);
+        sq[j] = s[j];
+        sq[W + j] = q[j];
     }
-}
-
-__global__ void k_bnb_finalize(int W, Acc bstats, int nslot, double n, float *__restrict__ bb)
-{
-    const int j = blockIdx.x;   // one wavefront per channel
-    const double a = acc_total(bstats + j, nslot) / n, b = acc_total(bstats + W + j, nslot) / n;
-    if (threadIdx.x != 0) return;
-    bb[j] = (float)a;
-    bb[W + j] = (float)b;
+    acc_add_n<2 * W>(bstats, sq, g.nslot);
 }
 
 // G[i] = sum of the partials of value i, one wavefront per value
@@ -684,9 +738,11 @@ __global__ void k_reduce(int n, const float *__restrict__ part, int nslot, doubl
 // d loss / d xhat1 (t2) and its two batch sums
 template <int W>
 __global__ void k_c2_bwd(Geo g, const float *__restrict__ h1, const float *__restrict__ bn1, const float *__restrict__ h2,
-                         const float *__restrict__ bn2, const float *__restrict__ bb2, const float *__restrict__ P,
+                         const float *__restrict__ bn2, Acc bstats2, double n, const float *__restrict__ P,
                          int off_w2, float *__restrict__ t1, float *__restrict__ t2, Acc bstats, Acc G)
 {
+    __shared__ float bb2[2 * W];
+    bnb_from_slots<W>(bstats2, g.nslot, n, bb2);
     const float *W2 = P + off_w2;
     float s[W], q[W], gb[W];
 #pragma unroll
@@ -714,12 +770,14 @@ __global__ void k_c2_bwd(Geo g, const float *__restrict__ h1, const float *__res
             }
         }
     }
+    float sq[2 * W];
 #pragma unroll
     for (int j = 0; j < W; ++j) {
-        acc_add(bstats + j, s[j], g.nslot);
-        acc_add(bstats + W + j, q[j], g.nslot);
-        acc_add(G + off_w2 + W * W + j, gb[j], g.nslot);
+        sq[j] = s[j];
+        sq[W + j] = q[j];
     }
+    acc_add_n<2 * W>(bstats, sq, g.nslot);
+    acc_add_n<W>(G + off_w2 + W * W, gb, g.nslot);
 }
 
 // d l_2/W: one input channel per blockIdx.y
@@ -739,15 +797,16 @@ __global__ void k_w2_grad(Geo g, const float *__restrict__ h1, const float *__re
             for (int j = 0; j < W; ++j) acc[j] = fmaf(a, t1[p * W + j], acc[j]);
         }
     }
-#pragma unroll
-    for (int j = 0; j < W; ++j) acc_add(G + off_w2 + i * W + j, acc[j], g.nslot);
+    acc_add_n<W>(G + off_w2 + i * W, acc, g.nslot);
 }
 
 // coupling, stage 4: BN1 backward -> g_h1 (t2, in place), d l_1/b
 template <int W>
-__global__ void k_c1_bwd(Geo g, const float *__restrict__ h1, const float *__restrict__ bn1, const float *__restrict__ bb1,
+__global__ void k_c1_bwd(Geo g, const float *__restrict__ h1, const float *__restrict__ bn1, Acc bstats1, double n,
                          int off_b1, float *__restrict__ t2, Acc G)
 {
+    __shared__ float bb1[2 * W];
+    bnb_from_slots<W>(bstats1, g.nslot, n, bb1);
     float gb[W];
 #pragma unroll
     for (int j = 0; j < W; ++j) gb[j] = 0.0f;
@@ -762,8 +821,7 @@ __global__ void k_c1_bwd(Geo g, const float *__restrict__ h1, const float *__res
             }
         }
     }
-#pragma unroll
-    for (int j = 0; j < W; ++j) acc_add(G + off_b1 + j, gb[j], g.nslot);
+    acc_add_n<W>(G + off_b1, gb, g.nslot);
 }
 
 // d l_1/W: one filter tap per blockIdx.y
@@ -789,12 +847,13 @@ __global__ void k_w1_grad(Geo g, const float *__restrict__ zin, const float *__r
             }
         }
     }
-    const Acc dst = G + off_w1 + tap * 2 * W;
+    float flat[2 * W];
 #pragma unroll
     for (int j = 0; j < W; ++j) {
-        acc_add(dst + j, acc[0][j], g.nslot);
-        acc_add(dst + W + j, acc[1][j], g.nslot);
+        flat[j] = acc[0][j];
+        flat[W + j] = acc[1][j];
     }
+    acc_add_n<2 * W>(G + off_w1 + tap * 2 * W, flat, g.nslot);
 }
 
 // coupling, stage 5: transposed l_1 adds the CNN path into d loss / d z0
@@ -996,14 +1055,10 @@ void coupling_forward(nf_trainer *t, const Geo &g, const TLayer &L, const float 
               off_w3 = L.off + 24 * w + w * w;
     const double n = (double)g.npix;
     hipLaunchKernelGGL(k_c1_fwd<W>, dim3(nb), dim3(TB), 0, st, g, zin, t->d_params, off_w1, c.h1, t->acc(c.d_st1));
-    hipLaunchKernelGGL(k_bn_finalize, dim3(w), dim3(64), 0, st, w, t->acc(c.d_st1), (int)nb, n, t->d_params, off_m1, off_m1 + w,
-                       t->d_flt + c.f_bn1);
-    hipLaunchKernelGGL(k_c2_fwd<W>, dim3(nb), dim3(TB), 0, st, g, c.h1, t->d_flt + c.f_bn1, t->d_params, off_w2, c.h2,
-                       t->acc(c.d_st2));
-    hipLaunchKernelGGL(k_bn_finalize, dim3(w), dim3(64), 0, st, w, t->acc(c.d_st2), (int)nb, n, t->d_params, off_m2, off_m2 + w,
-                       t->d_flt + c.f_bn2);
-    hipLaunchKernelGGL(k_c3_fwd<W>, dim3(nb), dim3(TB), 0, st, g, zin, c.h2, t->d_flt + c.f_bn2, t->d_params, off_w3, zout,
-                       t->d_patch);
+    hipLaunchKernelGGL(k_c2_fwd<W>, dim3(nb), dim3(TB), 0, st, g, c.h1, t->acc(c.d_st1), n, t->d_params, off_m1,
+                       t->d_flt + c.f_bn1, off_w2, c.h2, t->acc(c.d_st2));
+    hipLaunchKernelGGL(k_c3_fwd<W>, dim3(nb), dim3(TB), 0, st, g, zin, c.h2, t->acc(c.d_st2), n, t->d_params, off_m2,
+                       t->d_flt + c.f_bn2, off_w3, zout, t->d_patch);
 }
 
 template <int W>
@@ -1014,18 +1069,15 @@ void coupling_backward(nf_trainer *t, const Geo &g, const TLayer &L, const float
     const int w = W, off_w1 = L.off, off_b1 = L.off + 18 * w, off_w2 = L.off + 21 * w, off_w3 = L.off + 24 * w + w * w;
     const double n = (double)g.npix;
     const float *bn1 = t->d_flt + c.f_bn1, *bn2 = t->d_flt + c.f_bn2;
-    float *bb1 = t->d_flt + c.f_bb1, *bb2 = t->d_flt + c.f_bb2;
     const Acc G = t->acc(0);
     const unsigned ng = std::min(nb, 96u);   // filter-gradient kernels: grid.y multiplies the workgroup count
     hipLaunchKernelGGL(k_c3_bwd<W>, dim3(nb), dim3(TB), 0, st, g, zin, c.h2, bn2, t->d_params, off_w3, invB, t->dz, t->gu, G);
     hipLaunchKernelGGL(k_w3_grad<W>, dim3(ng, 9), dim3(TB), 0, st, g, c.h2, bn2, t->gu, off_w3, G);
     hipLaunchKernelGGL(k_c3_dh<W>, dim3(nb), dim3(TB), 0, st, g, c.h2, bn2, t->d_params, off_w3, t->gu, t->t1, t->acc(c.d_bs2));
-    hipLaunchKernelGGL(k_bnb_finalize, dim3(w), dim3(64), 0, st, w, t->acc(c.d_bs2), (int)nb, n, bb2);
-    hipLaunchKernelGGL(k_c2_bwd<W>, dim3(nb), dim3(TB), 0, st, g, c.h1, bn1, c.h2, bn2, bb2, t->d_params, off_w2, t->t1, t->t2,
-                       t->acc(c.d_bs1), G);
+    hipLaunchKernelGGL(k_c2_bwd<W>, dim3(nb), dim3(TB), 0, st, g, c.h1, bn1, c.h2, bn2, t->acc(c.d_bs2), n, t->d_params, off_w2,
+                       t->t1, t->t2, t->acc(c.d_bs1), G);
     hipLaunchKernelGGL(k_w2_grad<W>, dim3(ng, w), dim3(TB), 0, st, g, c.h1, bn1, t->t1, off_w2, G);
-    hipLaunchKernelGGL(k_bnb_finalize, dim3(w), dim3(64), 0, st, w, t->acc(c.d_bs1), (int)nb, n, bb1);
-    hipLaunchKernelGGL(k_c1_bwd<W>, dim3(nb), dim3(TB), 0, st, g, c.h1, bn1, bb1, off_b1, t->t2, G);
+    hipLaunchKernelGGL(k_c1_bwd<W>, dim3(nb), dim3(TB), 0, st, g, c.h1, bn1, t->acc(c.d_bs1), n, off_b1, t->t2, G);
     hipLaunchKernelGGL(k_w1_grad<W>, dim3(ng, 9), dim3(TB), 0, st, g, zin, t->t2, off_w1, G);
     hipLaunchKernelGGL(k_c1_dz<W>, dim3(nb), dim3(TB), 0, st, g, t->t2, t->d_params, off_w1, t->dz);
 }
