@@ -221,6 +221,10 @@ __global__ void k_prep(TLayers ls, const float *__restrict__ P, CondIdx ci, int 
         sdn5_eval(p, ci, a, b);
         abbuf[L.aux * 2] = (float)a;
         abbuf[L.aux * 2 + 1] = (float)b;
+    } else if (L.type == NF_LAYER_SDN4) {                                  // cond_utils.py:178-202 (c = 1, no camera)
+        const double gpar = ci.iso_idx >= 0 ? (double)p[2 + ci.iso_idx] : 0.0;
+        abbuf[L.aux * 2] = (float)(exp((double)p[0]) / (exp(gpar) * (double)ci.iso));
+        abbuf[L.aux * 2 + 1] = (float)exp((double)p[1]);
     } else if (L.type == NF_LAYER_GAIN4) {
         atomicAdd(ldc, -(double)HW * 4.0 * log((double)p[0]));             // AffineCouplingGainEx4.py:114-127
     }
@@ -936,6 +940,13 @@ __global__ void k_finish(TLayers ls, const float *__restrict__ P, CondIdx ci, in
         gp[7 + 0 * 5 + ci.cam_idx] = ga * a * c_i * c_i * beta1 * cp[0];
         gp[7 + 1 * 5 + ci.cam_idx] = gb * b * c_i * c_i * beta2 * cp[1];
         gp[7 + 2 * 5 + ci.cam_idx] = -ga * a * c_i * c_i * gpar * cp[2];
+    } else if (L.type == NF_LAYER_SDN4) {
+        const double gpar = ci.iso_idx >= 0 ? (double)p[2 + ci.iso_idx] : 0.0;
+        const double a = exp((double)p[0]) / (exp(gpar) * (double)ci.iso), b = exp((double)p[1]);
+        const double ga = dabbuf[L.aux * 2], gb = dabbuf[L.aux * 2 + 1];
+        gp[0] = ga * a;
+        gp[1] = gb * b;
+        if (ci.iso_idx >= 0) gp[2 + ci.iso_idx] = -ga * a;
     } else if (L.type == NF_LAYER_GAIN4) {
         gp[0] = dgbuf[L.aux] + (double)HW * 4.0 / (double)p[0];
     }
@@ -1008,6 +1019,7 @@ struct nf_trainer {
     float *t1 = nullptr, *t2 = nullptr, *gu = nullptr, *dz = nullptr;
     std::vector<void *> owned;
     bool has_sdn = false;
+    bool needs_cam = false;         // an SDN5 layer is present: the camera id must be one of 0..4
 };
 
 namespace {
@@ -1091,13 +1103,13 @@ void coupling_backward(nf_trainer *t, const Geo &g, const TLayer &L, const float
     default: break;                         \
     }
 
-int cond_index(const nf_cond *cond, bool needed, CondIdx &ci)
+int cond_index(const nf_cond *cond, bool needed, bool needs_cam, CondIdx &ci)
 {
     ci.iso = 0.f;
     ci.iso_idx = -1;
     ci.cam_idx = 0;
     if (!needed) return NF_OK;
-    if (!cond) return nf_fail(NF_EINVAL, "model has an SDN5 layer but cond is NULL");
+    if (!cond) return nf_fail(NF_EINVAL, "model has a signal-dependent layer but cond is NULL");
     static const float iso_vals[5] = {100.f, 400.f, 800.f, 1600.f, 3200.f};
     ci.iso = cond->iso;
     for (int i = 0; i < 5; ++i)
@@ -1105,6 +1117,7 @@ int cond_index(const nf_cond *cond, bool needed, CondIdx &ci)
     int cam = -1;
     for (int i = 0; i < 5; ++i)
         if ((float)i == cond->cam) cam = i;
+    if (cam < 0 && !needs_cam) cam = 0;
     if (cam < 0) return nf_fail(NF_ECOND, "unknown camera id %g (expected 0..4 = IP,GP,S6,N6,G4)", (double)cond->cam);
     ci.cam_idx = cam;
     return NF_OK;
@@ -1186,6 +1199,12 @@ int nf_trainer_create(const nf_config *cfg, const nf_layer_desc *layers, const f
             T.aux = n_sdn++;
             for (int k = 0; k < 22; ++k) mk[k] = 1;    // c_i is a constant
             t->has_sdn = true;
+            t->needs_cam = true;
+            break;
+        case NF_LAYER_SDN4:
+            T.aux = n_sdn++;
+            for (int k = 0; k < 7; ++k) mk[k] = 1;
+            t->has_sdn = true;
             break;
         case NF_LAYER_GAIN4:
             T.aux = n_gain++;
@@ -1193,7 +1212,7 @@ int nf_trainer_create(const nf_config *cfg, const nf_layer_desc *layers, const f
             break;
         default:
             delete t;
-            return nf_fail(NF_EINVAL, "layer %d: training covers CONV1X1, COUPLING, SDN5 and GAIN4 layers (type %d given)", i, L.type);
+            return nf_fail(NF_EINVAL, "layer %d: training covers CONV1X1, COUPLING, SDN5, SDN4 and GAIN4 layers (type %d given)", i, L.type);
         }
     }
 
@@ -1286,7 +1305,7 @@ int nf_trainer_forward_backward(nf_trainer *t, const float *x, const float *y, i
     if (!x) return nf_fail(NF_EINVAL, "x is NULL");
     if (t->has_sdn && !y) return nf_fail(NF_EINVAL, "model has a signal-dependent layer but y is NULL");
     CondIdx ci;
-    int rc = cond_index(cond, t->has_sdn, ci);
+    int rc = cond_index(cond, t->has_sdn, t->needs_cam, ci);
     if (rc != NF_OK) return rc;
     Guard guard;
     if ((rc = guard.enter(t->device)) != NF_OK) return rc;
@@ -1320,6 +1339,7 @@ int nf_trainer_forward_backward(nf_trainer *t, const float *x, const float *y, i
         float *zout = t->zs[l + 1];
         switch (L.type) {
         case NF_LAYER_SDN5:
+        case NF_LAYER_SDN4:
             hipLaunchKernelGGL(k_sdn_fwd, dim3(nb), dim3(TB), 0, st, g, zin, y, t->d_flt + t->f_ab + 2 * L.aux, zout, ld);
             break;
         case NF_LAYER_GAIN4:
@@ -1344,6 +1364,7 @@ int nf_trainer_forward_backward(nf_trainer *t, const float *x, const float *y, i
         const TLayer &L = t->tl.l[l];
         switch (L.type) {
         case NF_LAYER_SDN5:
+        case NF_LAYER_SDN4:
             hipLaunchKernelGGL(k_sdn_bwd, dim3(nb), dim3(TB), 0, st, g, t->zs[l], y, t->d_flt + t->f_ab + 2 * L.aux, invB, t->dz,
                                t->acc(t->d_dab + 2 * L.aux));
             break;

@@ -63,7 +63,7 @@ class Trainer:
         torch = self._dev.torch
         self._grads = torch.zeros((self.n_params,), dtype=torch.float32, device=self._dev.device)
         self._loss = torch.zeros((2,), dtype=torch.float32, device=self._dev.device)
-        self.has_sdn = any(L.kind == "sdn5" for L in self.layers)
+        self.has_sdn = any(L.kind in ("sdn5", "sdn4") for L in self.layers)
 
     # ------------------------------------------------------------------ lifetime
     def close(self):

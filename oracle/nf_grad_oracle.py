@@ -148,12 +148,20 @@ class GradOracle:
                 scale = self._sdn5_scale(yt, iso, cam)
                 z = z / scale
                 obj = obj - torch.log(scale).sum(dim=(1, 2, 3))
+            elif lyr == "sdn4":                                           # cond_utils.py:178-202
+                ks = [k for k, v in enumerate(O.ISO_VALS) if float(v) == float(iso)]
+                gp = self.t["model/sdn_gain/gain_params"].reshape(-1)[ks[0]] if ks else torch.zeros((), dtype=torch.float64)
+                gain = torch.exp(gp) * float(iso)
+                scale = torch.sqrt(torch.exp(self.t["model/sdn_gain/beta1"].reshape(-1)[0]) * yt / gain
+                                   + torch.exp(self.t["model/sdn_gain/beta2"].reshape(-1)[0]))
+                z = z / scale
+                obj = obj - torch.log(scale).sum(dim=(1, 2, 3))
             elif lyr == "gain4":
                 g = self.t["model/sdn_gain/gain_val"].reshape(-1)[0]
                 z = z / g
                 obj = obj - C * H * W * torch.log(g)
             else:
-                raise ValueError("the training oracle covers unc|sdn5|gain4, got %r" % lyr)
+                raise ValueError("the training oracle covers unc|sdn5|sdn4|gain4, got %r" % lyr)
         logp = (-0.5 * (np.log(2 * np.pi) + z * z)).sum(dim=(1, 2, 3))
         nll = -(obj + logp)
         sd_z = torch.sqrt(z.var(dim=(1, 2, 3), unbiased=False)).mean()

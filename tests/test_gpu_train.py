@@ -80,7 +80,11 @@ def test_gradients_full_arch_shipped(shipped_variables):
 @pytest.mark.parametrize("arch,width,hw,B,iso,cam", [("unc|unc", 8, (24, 40), 5, 400, 1),
                                                      ("sdn5|unc|gain4|unc", 16, (16, 16), 7, 1600, 3),
                                                      ("sdn5|unc|gain4|unc", 4, (20, 12), 3, 250, 0),     # unknown ISO
-                                                     ("unc", 32, (8, 8), 9, 100, 2)])
+                                                     ("unc", 32, (8, 8), 9, 100, 2),
+                                                     ("sdn4|gain4", 4, (32, 32), 4, 800, 9),            # job_noise_flow.sh "S-G"
+                                                     ("sdn4|unc|gain4", 4, (16, 16), 4, 123, 2),
+                                                     ("sdn5|gain4", 4, (32, 32), 4, 3200, 4),           # "S-G-CAM"
+                                                     ("unc|unc|unc|unc", 4, (32, 32), 3, 100, 2)])      # "Ax4"
 def test_gradients_other_widths_and_shapes(arch, width, hw, B, iso, cam):
     v = trained_like_variables(arch, width, seed=6)
     x, y = make_inputs(B, hw[0], hw[1], seed=17)
@@ -211,7 +215,7 @@ def test_trainer_c_abi_errors(shipped_variables):
     rc = lib.nf_trainer_forward_backward(tr._h, x.data_ptr(), x.data_ptr(), 2, C.byref(bad), None, None, None)
     assert rc == _lib.NF_ECOND
     # unsupported layer type for training
-    layers, descs, flat = P.pack("sdn4|unc", trained_like_variables("sdn4|unc", 4, seed=1), 4)
+    layers, descs, flat = P.pack("sdn|unc", trained_like_variables("sdn|unc", 4, seed=1), 4)
     cfg = _lib.nf_config(32, 32, 4, len(layers), -1, 0)
     h = C.c_void_p()
     rc = lib.nf_trainer_create(C.byref(cfg), descs, flat.ctypes.data_as(C.POINTER(C.c_float)), flat.size, 4, 0, C.byref(h))

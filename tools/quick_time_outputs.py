@@ -21,11 +21,17 @@ modes = {"nll_out only": (nll.data_ptr(), None, None, None, None, 0),
          "nll+sd+ld": (nll.data_ptr(), sd.data_ptr(), ld.data_ptr(), None, None, 0),
          "z_out only": (None, None, None, z.data_ptr(), None, 0),
          "all": (nll.data_ptr(), sd.data_ptr(), ld.data_ptr(), z.data_ptr(), sums.data_ptr(), _lib.NF_ACCUMULATE)}
-for name, (a, b, c, d, e, fl) in modes.items():
+def _warm():
+    for _ in range(3000):   # ~0.2 s: leave the idle clocks before the first measurement
+        lib.nf_nll(m._flow.ptr, x.data_ptr(), y.data_ptr(), B, C.byref(cond), nll.data_ptr(), None, None, None, None, 0, st)
+    torch.cuda.synchronize()
+_warm()
+for rnd in range(3):
+  for name, (a, b, c, d, e, fl) in modes.items():
     def fn():
         rc = lib.nf_nll(m._flow.ptr, x.data_ptr(), y.data_ptr(), B, C.byref(cond), a, b, c, d, e, fl, st)
         assert rc == 0
-    for _ in range(10):
+    for _ in range(50):
         fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -35,4 +41,4 @@ for name, (a, b, c, d, e, fl) in modes.items():
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
-    print("B=%d %-30s %.4f ms  %.3e patches/s" % (B, name, ms, B / (ms * 1e-3)))
+    print("round %d B=%d %-30s %.4f ms  %.3e patches/s" % (rnd, B, name, ms, B / (ms * 1e-3)))
