@@ -1016,7 +1016,12 @@ struct nf_trainer {
     int f_A = 0, f_ab = 0;
     float *d_patch = nullptr;       // ld[B], s1[B], s2[B]
     std::vector<float *> zs;        // zs[l] = input of layer l (zs[0] is the caller's x), zs[n] = latent
-    float *t1 = nullptr, *t2 = nullptr, *gu = nullptr, *dz = nullptr;
+    // backward temporaries, double-buffered by coupling parity: the filter-gradient kernels of one
+    // coupling run on `side` while the main stream is already in the next coupling
+    float *t1[2] = {nullptr, nullptr}, *t2[2] = {nullptr, nullptr}, *gu[2] = {nullptr, nullptr}, *dz = nullptr;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork[3] = {nullptr, nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
+    bool done_pending[2] = {false, false};
     std::vector<void *> owned;
     bool has_sdn = false;
     bool needs_cam = false;         // an SDN5 layer is present: the camera id must be one of 0..4
@@ -1083,15 +1088,31 @@ void coupling_backward(nf_trainer *t, const Geo &g, const TLayer &L, const float
     const float *bn1 = t->d_flt + c.f_bn1, *bn2 = t->d_flt + c.f_bn2;
     const Acc G = t->acc(0);
     const unsigned ng = std::min(nb, 96u);   // filter-gradient kernels: grid.y multiplies the workgroup count
-    hipLaunchKernelGGL(k_c3_bwd<W>, dim3(nb), dim3(TB), 0, st, g, zin, c.h2, bn2, t->d_params, off_w3, invB, t->dz, t->gu, G);
-    hipLaunchKernelGGL(k_w3_grad<W>, dim3(ng, 9), dim3(TB), 0, st, g, c.h2, bn2, t->gu, off_w3, G);
-    hipLaunchKernelGGL(k_c3_dh<W>, dim3(nb), dim3(TB), 0, st, g, c.h2, bn2, t->d_params, off_w3, t->gu, t->t1, t->acc(c.d_bs2));
+    // The three filter-gradient kernels only feed the parameter gradient, not d loss / d z: they run
+    // on the side stream, forked after their producer, while the main stream walks on.  The
+    // temporaries they read are double-buffered by coupling parity; before a buffer set is reused
+    // the main stream waits for the side work of the coupling that used it last.
+    const int par = L.aux & 1;
+    float *t1 = t->t1[par], *t2 = t->t2[par], *gu = t->gu[par];
+    hipStream_t sd = t->side;
+    if (t->done_pending[par]) {
+        (void)hipStreamWaitEvent(st, t->ev_done[par], 0);
+        t->done_pending[par] = false;
+    }
+    hipLaunchKernelGGL(k_c3_bwd<W>, dim3(nb), dim3(TB), 0, st, g, zin, c.h2, bn2, t->d_params, off_w3, invB, t->dz, gu, G);
+    hipLaunchKernelGGL(k_c3_dh<W>, dim3(nb), dim3(TB), 0, st, g, c.h2, bn2, t->d_params, off_w3, gu, t1, t->acc(c.d_bs2));
     hipLaunchKernelGGL(k_c2_bwd<W>, dim3(nb), dim3(TB), 0, st, g, c.h1, bn1, c.h2, bn2, t->acc(c.d_bs2), n, t->d_params, off_w2,
-                       t->t1, t->t2, t->acc(c.d_bs1), G);
-    hipLaunchKernelGGL(k_w2_grad<W>, dim3(ng, w), dim3(TB), 0, st, g, c.h1, bn1, t->t1, off_w2, G);
-    hipLaunchKernelGGL(k_c1_bwd<W>, dim3(nb), dim3(TB), 0, st, g, c.h1, bn1, t->acc(c.d_bs1), n, off_b1, t->t2, G);
-    hipLaunchKernelGGL(k_w1_grad<W>, dim3(ng, 9), dim3(TB), 0, st, g, zin, t->t2, off_w1, G);
-    hipLaunchKernelGGL(k_c1_dz<W>, dim3(nb), dim3(TB), 0, st, g, t->t2, t->d_params, off_w1, t->dz);
+                       t1, t2, t->acc(c.d_bs1), G);
+    hipLaunchKernelGGL(k_c1_bwd<W>, dim3(nb), dim3(TB), 0, st, g, c.h1, bn1, t->acc(c.d_bs1), n, off_b1, t2, G);
+    // one fork per coupling (every event operation costs host time): all three producers are done
+    (void)hipEventRecord(t->ev_fork[0], st);
+    (void)hipStreamWaitEvent(sd, t->ev_fork[0], 0);
+    hipLaunchKernelGGL(k_w3_grad<W>, dim3(ng, 9), dim3(TB), 0, sd, g, c.h2, bn2, gu, off_w3, G);
+    hipLaunchKernelGGL(k_w2_grad<W>, dim3(ng, w), dim3(TB), 0, sd, g, c.h1, bn1, t1, off_w2, G);
+    hipLaunchKernelGGL(k_w1_grad<W>, dim3(ng, 9), dim3(TB), 0, sd, g, zin, t2, off_w1, G);
+    (void)hipEventRecord(t->ev_done[par], sd);
+    t->done_pending[par] = true;
+    hipLaunchKernelGGL(k_c1_dz<W>, dim3(nb), dim3(TB), 0, st, g, t2, t->d_params, off_w1, t->dz);
 }
 
 #define NF_WIDTH_SWITCH(w, CALL)            \
@@ -1132,6 +1153,14 @@ int nf_trainer_destroy(nf_trainer *t)
     if (!t) return NF_OK;
     Guard guard;
     (void)guard.enter(t->device);
+    if (t->side) {
+        (void)hipStreamSynchronize(t->side);
+        (void)hipStreamDestroy(t->side);
+    }
+    for (hipEvent_t ev : t->ev_fork)
+        if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : t->ev_done)
+        if (ev) (void)hipEventDestroy(ev);
     for (void *p : t->owned) (void)hipFree(p);
     delete t;
     return NF_OK;
@@ -1278,9 +1307,11 @@ int nf_trainer_create(const nf_config *cfg, const nf_layer_desc *layers, const f
         NF_TRY(dev_alloc(t, (void **)&c.h1, act * w * sizeof(float)));
         NF_TRY(dev_alloc(t, (void **)&c.h2, act * w * sizeof(float)));
     }
-    NF_TRY(dev_alloc(t, (void **)&t->t1, act * w * sizeof(float)));
-    NF_TRY(dev_alloc(t, (void **)&t->t2, act * w * sizeof(float)));
-    NF_TRY(dev_alloc(t, (void **)&t->gu, act * 4 * sizeof(float)));
+    for (int k = 0; k < 2; ++k) {
+        NF_TRY(dev_alloc(t, (void **)&t->t1[k], act * w * sizeof(float)));
+        NF_TRY(dev_alloc(t, (void **)&t->t2[k], act * w * sizeof(float)));
+        NF_TRY(dev_alloc(t, (void **)&t->gu[k], act * 4 * sizeof(float)));
+    }
     NF_TRY(dev_alloc(t, (void **)&t->dz, act * 4 * sizeof(float)));
 #undef NF_TRY
     if ((e = hipMemcpy(t->d_params, params, n_params * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess ||
@@ -1292,6 +1323,17 @@ int nf_trainer_create(const nf_config *cfg, const nf_layer_desc *layers, const f
         (e = hipMemset(t->d_part, 0, (nd - 1) * NSLOT * sizeof(float))) != hipSuccess) {
         nf_trainer_destroy(t);
         return nf_fail_hip(e, "trainer initialisation");
+    }
+    if ((e = hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking)) != hipSuccess) {
+        nf_trainer_destroy(t);
+        return nf_fail_hip(e, "hipStreamCreate(trainer side stream)");
+    }
+    for (int k = 0; k < 5; ++k) {
+        hipEvent_t *ev = k < 3 ? &t->ev_fork[k] : &t->ev_done[k - 3];
+        if ((e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess) {
+            nf_trainer_destroy(t);
+            return nf_fail_hip(e, "hipEventCreate(trainer)");
+        }
     }
     *out = t;
     return NF_OK;
@@ -1383,6 +1425,11 @@ int nf_trainer_forward_backward(nf_trainer *t, const float *x, const float *y, i
             break;
         }
     }
+    for (int par = 0; par < 2; ++par)   // join the side stream: its slots are read next
+        if (t->done_pending[par]) {
+            (void)hipStreamWaitEvent(st, t->ev_done[par], 0);
+            t->done_pending[par] = false;
+        }
     hipLaunchKernelGGL(k_reduce, dim3((unsigned)t->d_ldc), dim3(64), 0, st, t->d_ldc, t->d_part, (int)nb, G);
     hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, st, t->tl, t->d_params, ci, g.HW, G + t->d_dA, G + t->d_dab, G + t->d_dg, G);
     float *gout = grads_out ? grads_out : t->d_gradf;

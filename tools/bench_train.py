@@ -24,10 +24,12 @@ for B in [int(b) for b in a.batches.split(",")]:
     t = time.perf_counter()
     for _ in range(a.steps):
         tr.step(x, y, [0], [0], [800], [2], lr=1e-4, sync=False)
+    host = (time.perf_counter() - t) / a.steps       # host time to enqueue one step
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t) / a.steps
     out = {"what": "training step (fwd batch-BN + bwd + EMA + Adam)", "B": B, "ms_per_step": round(dt * 1e3, 4),
-           "patches_per_s": round(B / dt, 1), "steps": a.steps}
+           "patches_per_s": round(B / dt, 1), "steps": a.steps,
+           "host_enqueue_ms_per_step": round(host * 1e3, 4)}
     if a.cpu and B <= 138:
         from oracle.nf_grad_oracle import train_step
         xs, ys = x.cpu().numpy(), y.cpu().numpy()
