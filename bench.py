@@ -125,14 +125,17 @@ def main():
     pool = max(1, min(args.pool, K + Wm))
     batches = [synth_patches(args.seed, (j * world + rank) * B, B, device=local_rank) for j in range(pool)]
     sums = torch.zeros(3, dtype=torch.float64, device=dev)
+    # per-workgroup partial sums go to the C ABI's slotted accumulator (NF_SUMS_WIDE: 64 slots on separate
+    # cache lines); ONE nf_sums_reduce after the last step folds it into (sum nll, sum sd, count)
+    wide = torch.zeros(_lib.NF_SUMS_SLOTS * _lib.NF_SUMS_STRIDE, dtype=torch.float64, device=dev)
     stream = torch.cuda.current_stream(dev)
     sptr = int(stream.cuda_stream)
     hptr = model._flow.ptr
 
-    def nll_step(i, flags=_lib.NF_ACCUMULATE):
+    def nll_step(i, flags=_lib.NF_ACCUMULATE | _lib.NF_SUMS_WIDE):
         x, y = batches[i % pool]
         rc = lib.nf_nll(hptr, x.data_ptr(), y.data_ptr(), B, C.byref(cond), None, None, None, None,
-                        sums.data_ptr(), flags, sptr)
+                        wide.data_ptr(), flags, sptr)
         if rc != 0:
             _lib.check(rc)
 
@@ -145,6 +148,7 @@ def main():
     if use_dist:
         allreduce_sums(sums.clone())        # warm the RCCL communicator outside the timed region
     sums.zero_()
+    wide.zero_()
     torch.cuda.synchronize(dev)
     barrier()
     torch.cuda.synchronize(dev)
@@ -155,6 +159,7 @@ def main():
     for i in range(K):
         nll_step(i)
     ev1.record(stream)
+    _lib.check(lib.nf_sums_reduce(wide.data_ptr(), sums.data_ptr(), 0, sptr))   # inside the timed wall clock
     if use_dist:
         allreduce_sums(sums)                # ONE RCCL all-reduce of 3 fp64 scalars finishes the evaluation
     torch.cuda.synchronize(dev)
@@ -209,12 +214,12 @@ def main():
             m16 = NoiseFlow([64, 64, 4], False, default_hps(), variables=variables, device=local_rank, cnn_dtype="fp16")
             B16 = 1024
             x16, y16 = synth_patches(args.seed, 1 << 41, B16, 64, 64, device=local_rank)
-            s16 = torch.zeros(3, dtype=torch.float64, device=dev)
+            s16 = torch.zeros(_lib.NF_SUMS_SLOTS * _lib.NF_SUMS_STRIDE, dtype=torch.float64, device=dev)
             k16 = max(10, min(K, 50))
 
             def step16():
                 rc = lib.nf_nll(m16._flow.ptr, x16.data_ptr(), y16.data_ptr(), B16, C.byref(cond), None, None, None,
-                                None, s16.data_ptr(), _lib.NF_ACCUMULATE, sptr)
+                                None, s16.data_ptr(), _lib.NF_ACCUMULATE | _lib.NF_SUMS_WIDE, sptr)
                 if rc != 0:
                     _lib.check(rc)
             for _ in range(5):

@@ -111,6 +111,16 @@ typedef struct nf_handle nf_handle;
 /* flags for nf_nll */
 #define NF_ACCUMULATE   1u   /* add into sums_out instead of overwriting it          */
 #define NF_NO_PRIOR     2u   /* nll_out receives -sum(log-dets) only (no base logp)   */
+#define NF_SUMS_WIDE    4u   /* sums_out is the slotted layout below, not double[3]   */
+
+/* Slotted sums (NF_SUMS_WIDE): sums_out = double[NF_SUMS_SLOTS * NF_SUMS_STRIDE] on the device;
+ * slot s (at sums_out + s*NF_SUMS_STRIDE) holds (sum nll, sum sd, count) of the workgroups with
+ * index = s mod NF_SUMS_SLOTS.  Every workgroup adds its two sums atomically; with the plain
+ * double[3] all of those atomics hit one cache line and serialise (~10 ns each, 5.6 us of a 55 us
+ * launch at B = 1024), the slots are 128 B apart.  Accumulate over as many calls as wanted, then
+ * fold once with nf_sums_reduce (or add the slots up yourself). */
+#define NF_SUMS_SLOTS   64
+#define NF_SUMS_STRIDE  16
 
 int         nf_abi_version(void);
 const char *nf_last_error(void);
@@ -133,11 +143,16 @@ int nf_destroy(nf_handle *h);
  *   sd_out    [B]  per-patch sqrt(var_hwc z) (or NULL)
  *   logdet_out[B]  per-patch sum of log|det J| over all layers (or NULL)
  *   z_out     [B,H,W,4] latent (or NULL)
- *   sums_out  double[3] on the DEVICE: sum_b nll, sum_b sd, B (or NULL)
+ *   sums_out  double[3] on the DEVICE: sum_b nll, sum_b sd, B (or NULL); with NF_SUMS_WIDE the
+ *             slotted layout above
  */
 int nf_nll(nf_handle *h, const float *x, const float *y, int64_t B, const nf_cond *cond,
            float *nll_out, float *sd_out, float *logdet_out, float *z_out,
            double *sums_out, uint32_t flags, void *stream);
+
+/* out3[k] (+)= sum over the slots of a NF_SUMS_WIDE buffer (flags: NF_ACCUMULATE adds into out3).
+ * Both pointers are DEVICE memory; one tiny kernel on `stream`. */
+int nf_sums_reduce(const double *wide, double *out3, uint32_t flags, void *stream);
 
 /* Sampling direction.  Replaces NoiseFlow.sample / .forward
  * (noise_flow_model.py:430-456): z = eps*temp, then the bijectors in reverse.

@@ -25,6 +25,9 @@ NF_ACCUMULATE = 1
 NF_NO_PRIOR = 2
 
 NF_OK = 0
+NF_SUMS_WIDE = 4
+NF_SUMS_SLOTS = 64
+NF_SUMS_STRIDE = 16
 NF_EINVAL = -1
 NF_EHIP = -2
 NF_ECOND = -3
@@ -109,6 +112,8 @@ def load() -> C.CDLL:
     lib.nf_trainer_set_params.argtypes = [vp, vp, C.c_size_t, vp]
     lib.nf_trainer_steps.restype = i64
     lib.nf_trainer_steps.argtypes = [vp]
+    lib.nf_sums_reduce.restype = C.c_int
+    lib.nf_sums_reduce.argtypes = [vp, vp, u32, vp]
     lib.nf_synth_patches.restype = C.c_int
     lib.nf_synth_patches.argtypes = [u64, i64, i64, i32, i32, f32, f32, vp, vp, vp]
     lib.nf_fold_params.restype = C.c_int
@@ -132,7 +137,7 @@ def check(rc: int) -> None:
 EXPORTED_SYMBOLS = (
     "nf_abi_version", "nf_last_error", "nf_layer_param_count", "nf_create", "nf_destroy", "nf_nll",
     "nf_sample", "nf_synth_patches", "nf_fold_params", "nf_sdn5_scalars",
-    "nf_nll_batchstats", "nf_sample_batchstats",
+    "nf_nll_batchstats", "nf_sample_batchstats", "nf_sums_reduce",
     "nf_trainer_create", "nf_trainer_destroy", "nf_trainer_forward_backward", "nf_trainer_apply", "nf_trainer_step",
     "nf_trainer_get_params", "nf_trainer_set_params", "nf_trainer_steps",
 )

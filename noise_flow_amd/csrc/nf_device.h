@@ -105,6 +105,7 @@ enum : uint32_t {
     NF_K_PRIOR     = 1u,   // nll = -(logdet + logp(z)); otherwise nll = -logdet
     NF_K_PHILOX_IN = 2u,   // input = Philox normal draw (sampling with in-kernel eps)
     NF_K_FP16_CNN  = 4u,   // parameter block is the fp16-CNN layout (NF3_*)
+    NF_K_SUMS_WIDE = 8u,   // `sums` is the slotted layout of NF_SUMS_WIDE (include/noiseflow_hip.h)
 };
 
 struct NfLaunch {

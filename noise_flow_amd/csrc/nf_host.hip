@@ -25,6 +25,7 @@
 hipError_t nf_launch_flow(const NfProgram &prog, const NfLaunch &a, int n_cu, hipStream_t stream, bool matrix_core);
 hipError_t nf_launch_synth(uint64_t seed, int64_t patch_base, int64_t B, int HW, float beta1, float beta2,
                            float *y_out, float *x_out, hipStream_t stream);
+hipError_t nf_launch_sums_reduce(const double *wide, double *out3, bool accumulate, hipStream_t stream);
 
 namespace {
 
@@ -758,6 +759,7 @@ static int nll_args(nf_handle *h, const float *x, const float *y, int64_t B, con
     a.H = h->cfg.height;
     a.W = h->cfg.width;
     a.flags = (flags & NF_NO_PRIOR) ? 0u : NF_K_PRIOR;
+    if (flags & NF_SUMS_WIDE) a.flags |= NF_K_SUMS_WIDE;
     return NF_OK;
 }
 
@@ -825,7 +827,8 @@ int nf_nll(nf_handle *h, const float *x, const float *y, int64_t B, const nf_con
     if ((rc = guard.enter(h->device)) != NF_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     if (sums_out && !(flags & NF_ACCUMULATE)) {
-        hipError_t e = hipMemsetAsync(sums_out, 0, 3 * sizeof(double), st);
+        const size_t nb = (flags & NF_SUMS_WIDE) ? (size_t)NF_SUMS_SLOTS * NF_SUMS_STRIDE : 3;
+        hipError_t e = hipMemsetAsync(sums_out, 0, nb * sizeof(double), st);
         if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync(sums)");
     }
     if (B == 0) return NF_OK;
@@ -964,7 +967,8 @@ int nf_nll_batchstats(nf_handle *h, const float *x, const float *y, int64_t B, c
     if ((rc = guard.enter(h->device)) != NF_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     if (sums_out && !(flags & NF_ACCUMULATE)) {
-        hipError_t e = hipMemsetAsync(sums_out, 0, 3 * sizeof(double), st);
+        const size_t nb = (flags & NF_SUMS_WIDE) ? (size_t)NF_SUMS_SLOTS * NF_SUMS_STRIDE : 3;
+        hipError_t e = hipMemsetAsync(sums_out, 0, nb * sizeof(double), st);
         if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync(sums)");
     }
     return run_batchstats(h, 0, a, moments_out, st);
@@ -980,6 +984,14 @@ int nf_sample_batchstats(nf_handle *h, const float *y, const float *eps, uint64_
     DeviceGuard guard;
     if ((rc = guard.enter(h->device)) != NF_OK) return rc;
     return run_batchstats(h, 1, a, moments_out, (hipStream_t)stream);
+}
+
+int nf_sums_reduce(const double *wide, double *out3, uint32_t flags, void *stream)
+{
+    if (!wide || !out3) return fail(NF_EINVAL, "null argument");
+    hipError_t e = nf_launch_sums_reduce(wide, out3, (flags & NF_ACCUMULATE) != 0, (hipStream_t)stream);
+    if (e != hipSuccess) return fail_hip(e, "nf_sums_reduce launch");
+    return NF_OK;
 }
 
 int nf_synth_patches(uint64_t seed, int64_t patch_index_base, int64_t B, int32_t height, int32_t width, float beta1,

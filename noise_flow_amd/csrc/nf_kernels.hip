@@ -20,6 +20,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <atomic>
+#include "../../include/noiseflow_hip.h"   // NF_SUMS_SLOTS / NF_SUMS_STRIDE
 #include "nf_device.h"
 
 // s_setprio level of a wave while it streams MFMAs (0 = off): keeps bursts of matrix
@@ -773,10 +774,32 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
     }
 
     if (a.sums && t == 0) {
-        atomicAdd(&a.sums[0], acc_nll);
-        atomicAdd(&a.sums[1], acc_sd);
-        if (blockIdx.x == 0) atomicAdd(&a.sums[2], (double)a.B);
+        // device-scope atomics on ONE cache line serialise at ~10 ns each (2 per workgroup = 5.6 us of a
+        // 55 us launch at B = 1024); the slotted layout spreads them over NF_SUMS_SLOTS lines
+        double *sp = a.sums;
+        if (a.flags & NF_K_SUMS_WIDE) sp += (size_t)(blockIdx.x & (NF_SUMS_SLOTS - 1)) * NF_SUMS_STRIDE;
+        atomicAdd(&sp[0], acc_nll);
+        atomicAdd(&sp[1], acc_sd);
+        if (blockIdx.x == 0) atomicAdd(&sp[2], (double)a.B);
     }
+}
+
+// fold the slotted sums into the plain (sum nll, sum sd, count) triple — one wavefront
+__global__ __launch_bounds__(64) void nf_sums_reduce_kernel(const double *__restrict__ wide, double *__restrict__ out3,
+                                                            int accumulate)
+{
+    static_assert(NF_SUMS_SLOTS == 64, "one lane per slot");
+    const int s = threadIdx.x;
+    double v[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        v[k] = wide[(size_t)s * NF_SUMS_STRIDE + k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o);
+    }
+    if (s == 0)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) out3[k] = (accumulate ? out3[k] : 0.0) + v[k];
 }
 
 // --------------------------------------------------------------------------
@@ -912,6 +935,12 @@ hipError_t nf_launch_flow(const NfProgram &prog, const NfLaunch &a, int n_cu, hi
     case 32: return dispatch_geom<32, false>(prog, a, n_cu, stream);
     default: return hipErrorInvalidValue;
     }
+}
+
+hipError_t nf_launch_sums_reduce(const double *wide, double *out3, bool accumulate, hipStream_t stream)
+{
+    hipLaunchKernelGGL(nf_sums_reduce_kernel, dim3(1), dim3(64), 0, stream, wide, out3, accumulate ? 1 : 0);
+    return hipGetLastError();
 }
 
 hipError_t nf_launch_synth(uint64_t seed, int64_t patch_base, int64_t B, int HW, float beta1, float beta2,

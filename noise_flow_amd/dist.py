@@ -42,6 +42,9 @@ def evaluate_sharded(eval_chunk: Callable[[int, int, object], object], n_total: 
         n = min(chunk, stop - k)
         eval_chunk(k, n, sums)
         k += n
+    finish = getattr(eval_chunk, "finish", None)   # the HIP path accumulates in slots and folds once
+    if finish is not None:
+        finish(sums)
     allreduce_sums(sums, group)
     s = sums.detach().cpu().numpy()
     n = int(round(float(s[2])))
@@ -55,8 +58,18 @@ def flow_eval_chunk(model, seed: int, cond=( [0.0], [0.0], [100.0], [2.0]), heig
     from .patches import synth_patches
     nlf0, nlf1, iso, cam = cond
 
+    wide = model.new_sums()   # slotted accumulator of this evaluation (no same-line atomics)
+
     def run(first, count, sums):
         x, y = synth_patches(seed, first, count, height, width, device=model._dev.device.index)
-        model.nll_sums(x, y, nlf0, nlf1, iso, cam, sums)
+        model.nll_sums(x, y, nlf0, nlf1, iso, cam, wide)
         return sums
+
+    def finish(sums):
+        """Fold the slotted accumulator into the plain triple (once, before the all-reduce)."""
+        model.fold_sums(wide, out=sums)
+        wide.zero_()
+        return sums
+
+    run.finish = finish
     return run

@@ -228,12 +228,48 @@ def test_sums_accumulate_across_chunks(shipped_variables, oracle_full):
     sums = None
     for a in range(0, 40, 16):
         sums = m.nll_sums(x[a:a + 16], y[a:a + 16], [0], [0], [100], [2], sums)
-    s = sums.cpu().numpy()
+    s = m.fold_sums(sums).cpu().numpy()
     ref_nll, _, ref_z = oracle_full.nll(x, y, 100, 2)
     assert s[2] == 40
     assert abs(s[0] - ref_nll.sum()) <= NLL_RTOL * abs(ref_nll.sum())
     ref_sd = np.sqrt(ref_z.var(axis=(1, 2, 3))).sum()
     assert abs(s[1] - ref_sd) <= 1e-5 * ref_sd
+
+
+def test_slotted_sums_equal_plain_sums(shipped_variables, oracle_full):
+    """NF_SUMS_WIDE: per-workgroup sums land in 64 slots on separate cache lines; folded they equal
+    the plain double[3] accumulator and the oracle."""
+    import ctypes as C
+    import torch
+    from noise_flow_amd import _lib
+    x, y = make_inputs(40, seed=8)
+    m = _model(FULL_ARCH, shipped_variables)
+    lib = _lib.load()
+    xt, yt = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    cond = _lib.nf_cond(100.0, 2.0, 0.0, 0.0)
+    st = torch.cuda.current_stream().cuda_stream
+    plain = torch.zeros(3, dtype=torch.float64, device="cuda")
+    wide = torch.full((_lib.NF_SUMS_SLOTS * _lib.NF_SUMS_STRIDE,), 7.0, dtype=torch.float64, device="cuda")   # garbage: call 1 clears it
+    out = torch.full((3,), 5.0, dtype=torch.float64, device="cuda")
+    for k, (a, b) in enumerate(((0, 24), (24, 40))):
+        fl = _lib.NF_ACCUMULATE if k else 0
+        assert lib.nf_nll(m._flow.ptr, xt[a:b].data_ptr(), yt[a:b].data_ptr(), b - a, C.byref(cond), None, None, None, None,
+                          plain.data_ptr(), _lib.NF_ACCUMULATE, st) == 0
+        assert lib.nf_nll(m._flow.ptr, xt[a:b].data_ptr(), yt[a:b].data_ptr(), b - a, C.byref(cond), None, None, None, None,
+                          wide.data_ptr(), fl | _lib.NF_SUMS_WIDE, st) == 0
+    assert lib.nf_sums_reduce(wide.data_ptr(), out.data_ptr(), 0, st) == 0          # overwrite
+    p, o = plain.cpu().numpy(), out.cpu().numpy()
+    assert o[2] == 40 and p[2] == 40
+    np.testing.assert_allclose(o[:2], p[:2], rtol=1e-12)
+    assert lib.nf_sums_reduce(wide.data_ptr(), out.data_ptr(), _lib.NF_ACCUMULATE, st) == 0   # add
+    np.testing.assert_allclose(out.cpu().numpy(), 2 * o, rtol=1e-12)
+    ref_nll, _, _ = oracle_full.nll(x, y, 100, 2)
+    assert abs(o[0] / 40 - ref_nll.mean()) <= NLL_RTOL * abs(ref_nll.mean())
+    # the model-level accumulator is the slotted one
+    s = m.nll_sums(x[:24], y[:24], [0], [0], [100], [2])
+    s = m.nll_sums(x[24:], y[24:], [0], [0], [100], [2], s)
+    assert s.numel() == _lib.NF_SUMS_SLOTS * _lib.NF_SUMS_STRIDE
+    np.testing.assert_allclose(m.fold_sums(s).cpu().numpy(), o, rtol=1e-12)
 
 
 def test_concurrent_callers_share_one_handle(shipped_variables, oracle_full):
@@ -338,6 +374,7 @@ def test_sharded_evaluation_is_sharding_invariant(shipped_variables):
                 c = min(700, b - k)
                 run(k, c, total)
                 k += c
+        run.finish(total)            # fold the slotted accumulator (once per evaluation)
         s = total.cpu().numpy()
         assert s[2] == n
         if ref is None:
@@ -367,6 +404,7 @@ def test_one_million_patches_sharded_properties(shipped_variables):
                 c = min(chunk, b - k)
                 run(k, c, total)
                 k += c
+        run.finish(total)
         s = total.cpu().numpy()
         assert s[2] == n
         means.append((s[0] / n, s[1] / n))
