@@ -224,11 +224,24 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
         }
     }
 
+    // Touch the first patch's inputs before the LDS set-up below: with one patch per workgroup (B = the
+    // resident capacity) every workgroup would otherwise sit through the set-up and THEN through the HBM
+    // latency of its first loads, all at the same time.  The values are discarded; the real loads hit L2.
+    float4 warm_x = make_float4(0.f, 0.f, 0.f, 0.f), warm_y = warm_x;
+#ifndef NF_NO_WARM
+    if ((int64_t)blockIdx.x < a.B) {
+        const size_t off0 = (size_t)blockIdx.x * (size_t)HW;
+        if (!PHILOX && act[0]) warm_x = reinterpret_cast<const float4 *>(a.in)[off0 + gidx[0]];
+        if (a.y && act[0]) warm_y = reinterpret_cast<const float4 *>(a.y)[off0 + gidx[0]];
+    }
+#endif
+
     // zero both tiles once: the 1-pixel border is never written again
     for (int i = t; i < tile_px * TILE_WORDS; i += THREADS) smem[i] = 0.0f;
     if (MFMA)
         for (int i = t; i < a.n_params; i += THREADS) wl[i] = a.params[i];
     __syncthreads();
+    asm volatile("" ::"v"(warm_x.x), "v"(warm_x.w), "v"(warm_y.x), "v"(warm_y.w));   // keep the warm-up loads
 
     const int n_ops = prog.n_ops;
     double acc_nll = 0.0, acc_sd = 0.0;   // thread 0 only
