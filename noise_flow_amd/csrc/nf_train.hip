@@ -234,22 +234,22 @@ __global__ void k_prep(TLayers ls, const float *__restrict__ P, CondIdx ci, int 
 // forward
 // ---------------------------------------------------------------------------------------------
 __global__ void k_sdn_fwd(Geo g, const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ ab,
-                          float *__restrict__ z, float *__restrict__ ld)
+                          float *__restrict__ z, Acc ldacc)
 {
+    // the loss needs only the batch total of this layer's log-det: one slot-reduced value, no atomics
     const float a = ab[0], b = ab[1];
+    float l = 0.0f;
     NF_PIXEL_LOOP(g, p) {
-        const bool valid = p < g.npix;
-        const int pb = valid ? (int)(p / g.HW) : -1;
-        float l = 0.0f;
-        if (valid) {
+        if (p < g.npix) {
             const float4 xv = reinterpret_cast<const float4 *>(x)[p], yv = reinterpret_cast<const float4 *>(y)[p];
             const float s0 = sqrtf(fmaf(a, yv.x, b)), s1 = sqrtf(fmaf(a, yv.y, b)), s2 = sqrtf(fmaf(a, yv.z, b)),
                         s3 = sqrtf(fmaf(a, yv.w, b));
             reinterpret_cast<float4 *>(z)[p] = make_float4(xv.x / s0, xv.y / s1, xv.z / s2, xv.w / s3);
-            l = -(logf(s0) + logf(s1) + logf(s2) + logf(s3));
+            l -= logf(s0) + logf(s1) + logf(s2) + logf(s3);
         }
-        patch_add(ld, pb, valid, l);
     }
+    const float lv[1] = {l};
+    acc_add_n<1>(ldacc, lv, g.nslot);
 }
 
 __global__ void k_scale_fwd(Geo g, const float *__restrict__ zin, const float *__restrict__ gain, float *__restrict__ zout)
@@ -435,17 +435,16 @@ __device__ __forceinline__ void l_last_u(const Geo &g, int b, int r, int c, cons
 template <int W>
 __global__ void k_c3_fwd(Geo g, const float *__restrict__ zin, const float *__restrict__ h2, Acc stats2, double n,
                          float *__restrict__ P, int off_m2, float *__restrict__ bn2_out, int off_w3,
-                         float *__restrict__ zout, float *__restrict__ ld)
+                         float *__restrict__ zout, Acc ldacc)
 {
     __shared__ float bn2[2 * W];
     bn_from_slots<W>(stats2, g.nslot, n, bn2, P, off_m2, off_m2 + W, bn2_out);
     const float *W3 = P + off_w3, *b3 = W3 + 36 * (W + 1), *logs = b3 + 4;
     const float sc = logs[4];
+    float l = 0.0f;
     NF_PIXEL_LOOP(g, p) {
-        const bool valid = p < g.npix;
-        const int b = valid ? (int)(p / g.HW) : -1;
-        float l = 0.0f;
-        if (valid) {
+        if (p < g.npix) {
+            const int b = (int)(p / g.HW);
             const int rem = (int)(p - (int64_t)b * g.HW), r = rem / g.W, c = rem - r * g.W;
             float u[4];
             l_last_u<W>(g, b, r, c, h2, bn2, W3, b3, u);
@@ -453,10 +452,11 @@ __global__ void k_c3_fwd(Geo g, const float *__restrict__ zin, const float *__re
             const float sh0 = u[0] * expf(kLogscale * logs[0]), sh1 = u[1] * expf(kLogscale * logs[1]);
             const float ls0 = sc * tanhf(u[2] * expf(kLogscale * logs[2])), ls1 = sc * tanhf(u[3] * expf(kLogscale * logs[3]));
             reinterpret_cast<float4 *>(zout)[p] = make_float4(zi.x, zi.y, fmaf(zi.z, expf(ls0), sh0), fmaf(zi.w, expf(ls1), sh1));
-            l = ls0 + ls1;
+            l += ls0 + ls1;
         }
-        patch_add(ld, b, valid, l);
     }
+    const float lv[1] = {l};
+    acc_add_n<1>(ldacc, lv, g.nslot);
 }
 
 __global__ void k_prior(Geo g, const float *__restrict__ z, float *__restrict__ s1, float *__restrict__ s2)
@@ -476,13 +476,15 @@ __global__ void k_prior(Geo g, const float *__restrict__ z, float *__restrict__ 
 }
 
 // loss = mean_b nll_b, sd_z = mean_b sqrt(var_hwc z_b)   (noise_flow_model.py:458-484)
-__global__ void k_loss(int B, double n, const float *__restrict__ ld, const float *__restrict__ s1,
+__global__ void k_loss(int B, double n, Acc ld0, int n_layers, int nslot, const float *__restrict__ s1,
                        const float *__restrict__ s2, const double *__restrict__ ldc, float *__restrict__ out)
 {
     __shared__ double sh[2][TB];
+    double ldsum = 0.0;   // sum over layers and patches of the data-dependent log-dets (every wavefront computes it)
+    for (int l = 0; l < n_layers; ++l) ldsum += acc_total(ld0 + l, nslot);
     double a = 0.0, d = 0.0;
     for (int b = threadIdx.x; b < B; b += TB) {
-        a += -((double)ld[b] + ldc[0]) + 0.5 * n * 1.8378770664093453 + 0.5 * (double)s2[b];
+        a += 0.5 * n * 1.8378770664093453 + 0.5 * (double)s2[b] - ldc[0];
         const double m = (double)s1[b] / n;
         double v = (double)s2[b] / n - m * m;
         d += sqrt(v > 0.0 ? v : 0.0);
@@ -498,7 +500,7 @@ __global__ void k_loss(int B, double n, const float *__restrict__ ld, const floa
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        out[0] = (float)(sh[0][0] / B);
+        out[0] = (float)((sh[0][0] - ldsum) / B);
         out[1] = (float)(sh[1][0] / B);
     }
 }
@@ -1010,7 +1012,7 @@ struct nf_trainer {
     size_t n_dbl = 0;
     float *d_part = nullptr;        // per-workgroup partials of every reducible value: [n_dbl - 1][NSLOT]
     Acc acc(int idx) const { return Acc{d_part + (size_t)idx * NSLOT}; }
-    int d_dA = 0, d_dab = 0, d_dg = 0, d_ldc = 0;
+    int d_dA = 0, d_dab = 0, d_dg = 0, d_ld0 = 0, d_ldc = 0;
     float *d_flt = nullptr;         // A matrices, sdn5 (a,b), BN scalars
     size_t n_flt = 0;
     int f_A = 0, f_ab = 0;
@@ -1064,7 +1066,7 @@ struct Guard {
 };
 
 template <int W>
-void coupling_forward(nf_trainer *t, const Geo &g, const TLayer &L, const float *zin, float *zout, hipStream_t st)
+void coupling_forward(nf_trainer *t, const Geo &g, const TLayer &L, const float *zin, float *zout, Acc ldacc, hipStream_t st)
 {
     const Cpl &c = t->cpl[L.aux];
     const unsigned nb = blocks_for(g.npix);
@@ -1075,7 +1077,7 @@ void coupling_forward(nf_trainer *t, const Geo &g, const TLayer &L, const float 
     hipLaunchKernelGGL(k_c2_fwd<W>, dim3(nb), dim3(TB), 0, st, g, c.h1, t->acc(c.d_st1), n, t->d_params, off_m1,
                        t->d_flt + c.f_bn1, off_w2, c.h2, t->acc(c.d_st2));
     hipLaunchKernelGGL(k_c3_fwd<W>, dim3(nb), dim3(TB), 0, st, g, zin, c.h2, t->acc(c.d_st2), n, t->d_params, off_m2,
-                       t->d_flt + c.f_bn2, off_w3, zout, t->d_patch);
+                       t->d_flt + c.f_bn2, off_w3, zout, ldacc);
 }
 
 template <int W>
@@ -1266,6 +1268,7 @@ int nf_trainer_create(const nf_config *cfg, const nf_layer_desc *layers, const f
     t->d_dA = (int)nd; nd += 16 * (size_t)n_mix;
     t->d_dab = (int)nd; nd += 2 * (size_t)n_sdn;
     t->d_dg = (int)nd; nd += (size_t)n_gain;
+    t->d_ld0 = (int)nd; nd += (size_t)cfg->n_layers;   // batch total of each layer's data-dependent log-det
     t->cpl.resize(n_cpl);
     for (Cpl &c : t->cpl) {
         c.d_st1 = (int)nd; nd += 2 * w;
@@ -1300,7 +1303,7 @@ int nf_trainer_create(const nf_config *cfg, const nf_layer_desc *layers, const f
     NF_TRY(dev_alloc(t, (void **)&t->d_dbl, nd * sizeof(double)));
     NF_TRY(dev_alloc(t, (void **)&t->d_part, (nd - 1) * NSLOT * sizeof(float)));
     NF_TRY(dev_alloc(t, (void **)&t->d_flt, nf * sizeof(float)));
-    NF_TRY(dev_alloc(t, (void **)&t->d_patch, 3 * (size_t)max_batch * sizeof(float)));
+    NF_TRY(dev_alloc(t, (void **)&t->d_patch, 2 * (size_t)max_batch * sizeof(float)));
     t->zs.assign(cfg->n_layers + 1, nullptr);
     for (int i = 1; i <= cfg->n_layers; ++i) NF_TRY(dev_alloc(t, (void **)&t->zs[i], act * 4 * sizeof(float)));
     for (Cpl &c : t->cpl) {
@@ -1366,9 +1369,9 @@ int nf_trainer_forward_backward(nf_trainer *t, const float *x, const float *y, i
     const int n = t->cfg.n_layers;
     hipError_t e;
     if ((e = hipMemsetAsync(t->d_dbl + t->d_ldc, 0, sizeof(double), st)) != hipSuccess ||
-        (e = hipMemsetAsync(t->d_patch, 0, 3 * (size_t)t->max_batch * sizeof(float), st)) != hipSuccess)
+        (e = hipMemsetAsync(t->d_patch, 0, 2 * (size_t)t->max_batch * sizeof(float), st)) != hipSuccess)
         return nf_fail_hip(e, "hipMemsetAsync(trainer accumulators)");
-    float *ld = t->d_patch, *s1 = ld + t->max_batch, *s2 = s1 + t->max_batch;
+    float *s1 = t->d_patch, *s2 = s1 + t->max_batch;
     double *G = t->d_dbl;
 
     hipLaunchKernelGGL(k_prep, dim3(1), dim3(64), 0, st, t->tl, t->d_params, ci, g.HW, t->d_flt + t->f_A, t->d_flt + t->f_ab,
@@ -1382,7 +1385,7 @@ int nf_trainer_forward_backward(nf_trainer *t, const float *x, const float *y, i
         switch (L.type) {
         case NF_LAYER_SDN5:
         case NF_LAYER_SDN4:
-            hipLaunchKernelGGL(k_sdn_fwd, dim3(nb), dim3(TB), 0, st, g, zin, y, t->d_flt + t->f_ab + 2 * L.aux, zout, ld);
+            hipLaunchKernelGGL(k_sdn_fwd, dim3(nb), dim3(TB), 0, st, g, zin, y, t->d_flt + t->f_ab + 2 * L.aux, zout, t->acc(t->d_ld0 + l));
             break;
         case NF_LAYER_GAIN4:
             hipLaunchKernelGGL(k_scale_fwd, dim3(nb), dim3(TB), 0, st, g, zin, t->d_params + L.off, zout);
@@ -1391,7 +1394,7 @@ int nf_trainer_forward_backward(nf_trainer *t, const float *x, const float *y, i
             hipLaunchKernelGGL(k_mix_fwd, dim3(nb), dim3(TB), 0, st, g, zin, t->d_flt + t->f_A + 16 * L.aux, zout);
             break;
         case NF_LAYER_COUPLING:
-#define NF_CALL(WW) coupling_forward<WW>(t, g, L, zin, zout, st)
+#define NF_CALL(WW) coupling_forward<WW>(t, g, L, zin, zout, t->acc(t->d_ld0 + l), st)
             NF_WIDTH_SWITCH(L.width, NF_CALL)
 #undef NF_CALL
             break;
@@ -1399,7 +1402,8 @@ int nf_trainer_forward_backward(nf_trainer *t, const float *x, const float *y, i
     }
     hipLaunchKernelGGL(k_prior, dim3(nb), dim3(TB), 0, st, g, t->zs[n], s1, s2);
     if (loss_out)
-        hipLaunchKernelGGL(k_loss, dim3(1), dim3(TB), 0, st, (int)B, (double)g.HW * 4.0, ld, s1, s2, G + t->d_ldc, loss_out);
+        hipLaunchKernelGGL(k_loss, dim3(1), dim3(TB), 0, st, (int)B, (double)g.HW * 4.0, t->acc(t->d_ld0), n, (int)nb, s1, s2,
+                           G + t->d_ldc, loss_out);
     // ---- backward ----
     hipLaunchKernelGGL(k_dz_init, dim3(nb), dim3(TB), 0, st, g, t->zs[n], invB, t->dz);
     for (int l = n - 1; l >= 0; --l) {
