@@ -78,6 +78,9 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=1024, help="patches per GPU per step (configs[1]: 1024)")
     ap.add_argument("--sample-batch", type=int, default=4096, help="sampling-direction batch (configs[2]: 4096)")
     ap.add_argument("--pool", type=int, default=16, help="distinct resident batches cycled through")
+    ap.add_argument("--ramp-ms", type=float, default=250.0,
+                    help="untimed clock ramp before the W warm-up steps: the same step repeated for this long, so that "
+                         "a short W does not leave the GPU at its idle clocks (0 disables)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
@@ -143,6 +146,12 @@ def main():
         if use_dist:
             dist.barrier()
 
+    if args.ramp_ms > 0:                    # untimed: leave the idle clocks (reported as "clock_ramp_ms")
+        t_r = time.perf_counter()
+        while (time.perf_counter() - t_r) * 1e3 < args.ramp_ms:
+            for i in range(64):
+                nll_step(i)
+            torch.cuda.synchronize(dev)
     for i in range(Wm):
         nll_step(i)
     if use_dist:
@@ -354,7 +363,7 @@ def main():
                                  "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PATCH * B,
                                  "note": "structurally capped near 13 %: 32 KiB and 5.1 MFLOP per patch"}},
             "cpu_baseline": cpu_baseline, "sampling": sampling, "nll_check": nll_check, "fp16_cnn_64x64": fp16_cnn,
-            "training": training,
+            "training": training, "clock_ramp_ms": args.ramp_ms,
         }
         print(json.dumps(out), flush=True)
     if use_dist:
