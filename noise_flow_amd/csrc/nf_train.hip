@@ -134,6 +134,30 @@ __device__ __forceinline__ double acc_total(Acc a, int nslot)
     return s;
 }
 
+// two values at once: all 2*NSLOT/64 loads are in flight together (each is a remote-L2 / memory miss)
+__device__ __forceinline__ void acc_total2(Acc a, Acc b, int nslot, double &sa, double &sb)
+{
+    float x[NSLOT / 64], y[NSLOT / 64];
+#pragma unroll
+    for (int k = 0; k < NSLOT / 64; ++k) {
+        const int i = (threadIdx.x & 63) + 64 * k;
+        x[k] = i < nslot ? a.p[i] : 0.0f;
+        y[k] = i < nslot ? b.p[i] : 0.0f;
+    }
+    sa = 0.0;
+    sb = 0.0;
+#pragma unroll
+    for (int k = 0; k < NSLOT / 64; ++k) {
+        sa += (double)x[k];
+        sb += (double)y[k];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        sa += __shfl_xor(sa, o);
+        sb += __shfl_xor(sb, o);
+    }
+}
+
 // per-patch accumulator: wavefronts that sit inside one patch reduce first
 __device__ __forceinline__ void patch_add(float *arr, int b, bool valid, float v)
 {
@@ -331,8 +355,10 @@ __device__ __forceinline__ void bn_from_slots(Acc stats, int nslot, double n, fl
                                               int off_mean, int off_var, float *__restrict__ bn_out)
 {
     for (int j = threadIdx.x >> 6; j < W; j += TB / 64) {
-        const double m = acc_total(stats + j, nslot) / n;
-        double v = acc_total(stats + W + j, nslot) / n - m * m;
+        double sm, sq;
+        acc_total2(stats + j, stats + W + j, nslot, sm, sq);
+        const double m = sm / n;
+        double v = sq / n - m * m;
         if (v < 0.0) v = 0.0;
         if ((threadIdx.x & 63) == 0) {
             const float mf = (float)m, rf = (float)(1.0 / sqrt(v + (double)kBnEps));
@@ -354,10 +380,11 @@ template <int W>
 __device__ __forceinline__ void bnb_from_slots(Acc bstats, int nslot, double n, float *sh)
 {
     for (int j = threadIdx.x >> 6; j < W; j += TB / 64) {
-        const double a = acc_total(bstats + j, nslot) / n, b = acc_total(bstats + W + j, nslot) / n;
+        double a, b;
+        acc_total2(bstats + j, bstats + W + j, nslot, a, b);
         if ((threadIdx.x & 63) == 0) {
-            sh[j] = (float)a;
-            sh[W + j] = (float)b;
+            sh[j] = (float)(a / n);
+            sh[W + j] = (float)(b / n);
         }
     }
     __syncthreads();
