@@ -68,7 +68,7 @@ __device__ __forceinline__ float wsum(float v)
 // kernel take 75 us).  Instead every workgroup reduces its share (registers -> wavefront shuffles ->
 // LDS) and stores ONE partial per value into its own slot; a later kernel adds the slots up in
 // fp64.  Deterministic for a given grid, so a training run is reproducible bit for bit.
-constexpr int NSLOT = 512;   // >= the largest grid.x of a reducing kernel
+constexpr int NSLOT = 1024;  // >= the largest grid.x of a reducing kernel
 
 struct Acc {      // value k of this accumulator group lives at p[k*NSLOT + slot]
     float *p;
@@ -1069,7 +1069,9 @@ int dev_alloc(nf_trainer *t, void **p, size_t bytes)
 inline unsigned blocks_for(int64_t npix)
 {
     // grid-stride loops; at most NSLOT workgroups (= 2 per CU), one partial-sum slot each
-    int64_t b = (npix + TB - 1) / TB;
+    // ~2 pixels per thread for small minibatches (fewer slots to add up, fewer workgroups to
+    // launch), every SIMD 4 waves deep for large ones
+    int64_t b = (npix + 2 * TB - 1) / (2 * TB);
     return (unsigned)std::min<int64_t>(std::max<int64_t>(b, 1), NSLOT);
 }
 
