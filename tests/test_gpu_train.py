@@ -281,3 +281,72 @@ def test_data_parallel_step_on_a_one_rank_group(shipped_variables):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+DP_ARCH = "sdn5|unc|gain4|unc"
+
+
+def _dp_worker(rank, world, port, outdir):
+    """One data-parallel rank (both ranks share the single GPU of the test box; gloo carries the
+    CUDA gradient).  Each rank trains on its own shard with group=True."""
+    import sys
+    import torch.distributed as dist
+    from conftest import ROOT, make_inputs, trained_like_variables
+    sys.path.insert(0, ROOT)
+    from noise_flow_amd import default_hps
+    from noise_flow_amd.train import Trainer
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    v = trained_like_variables(DP_ARCH, 4, seed=9)
+    tr = Trainer([32, 32, 4], default_hps(arch=DP_ARCH), variables=v, max_batch=8)
+    losses = []
+    for k in range(3):
+        x, y = make_inputs(8, seed=300 + 10 * k + rank, b1=0.003696)
+        losses.append(tr.step(x, y, [0.0], [0.0], [800], [2], lr=1e-3, group=True))
+    np.save(os.path.join(outdir, "params_%d.npy" % rank), tr.raw_params())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_data_parallel_training_matches_manual_gradient_averaging(tmp_path):
+    """world_size 2: forward_backward on each rank's shard → all-reduce(SUM)/2 → apply.  Both ranks
+    must end with identical trainable parameters, equal (bit for bit) to two single-process
+    trainers whose gradients are averaged by hand; BN running statistics stay per rank."""
+    import socket
+    import torch
+    import torch.multiprocessing as mp
+    from noise_flow_amd import params as P
+    from oracle.nf_grad_oracle import is_trainable
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    [p.start() for p in procs]
+    [p.join(timeout=300) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    p0, p1 = (np.load(os.path.join(str(tmp_path), "params_%d.npy" % r)) for r in range(2))
+
+    v = trained_like_variables(DP_ARCH, 4, seed=9)
+    a, b = _trainer(DP_ARCH, v, max_batch=8), _trainer(DP_ARCH, v, max_batch=8)
+    for k in range(3):
+        gs = []
+        for rank, tr in enumerate((a, b)):
+            x, y = make_inputs(8, seed=300 + 10 * k + rank, b1=0.003696)
+            g, _ = tr.forward_backward(x, y, [0.0], [0.0], [800], [2])
+            gs.append(g.clone())
+        mean = (gs[0] + gs[1]) / 2
+        a.apply(1e-3, mean)
+        b.apply(1e-3, mean)
+    # which raw entries are trainable
+    mask = np.zeros(a.n_params, bool)
+    pos = 0
+    for L in a.layers:
+        for nm in P.layer_variable_names(L, a._tmpl):
+            n = 1 if nm is None else int(np.asarray(v[nm]).size)
+            mask[pos:pos + n] = nm is not None and is_trainable(nm)
+            pos += n
+    assert np.array_equal(p0[mask], p1[mask])
+    assert np.array_equal(p0[mask], a.raw_params()[mask])
+    assert np.array_equal(p0, a.raw_params()) and np.array_equal(p1, b.raw_params())   # incl. per-rank BN statistics
+    assert not np.array_equal(p0[~mask], p1[~mask])
