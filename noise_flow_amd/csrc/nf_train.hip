@@ -303,12 +303,20 @@ __global__ void k_mix_fwd(Geo g, const float *__restrict__ zin, const float *__r
     }
 }
 
-// l_1: 3x3 SAME conv of the pass-through half + bias; per-channel sum / sum of squares
-template <int W>
-__global__ void k_c1_fwd(Geo g, const float *__restrict__ zin, const float *__restrict__ P, int off, float *__restrict__ h1,
-                         Acc stats)
+// l_1: 3x3 SAME conv of the pass-through half + bias; per-channel sum / sum of squares.
+// MIX = the preceding Conv2d1x1 is folded in: `zin` is then the tensor BEFORE the 1x1 mix, the two
+// pass-through channels of every neighbour are recomputed on the fly (8 FMAs) and the mixed pixel is
+// stored to `zmixed` for the rest of the step — one launch and one pass over z less per `unc`.
+template <int W, bool MIX>
+__global__ void k_c1_fwd(Geo g, const float *__restrict__ zin, const float *__restrict__ A, float *__restrict__ zmixed,
+                         const float *__restrict__ P, int off, float *__restrict__ h1, Acc stats)
 {
     const float *W1 = P + off, *b1 = W1 + 18 * W;
+    float m[16];
+    if (MIX) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) m[i] = A[i];
+    }
     float s[W], q[W];
 #pragma unroll
     for (int j = 0; j < W; ++j) s[j] = q[j] = 0.0f;
@@ -324,7 +332,19 @@ __global__ void k_c1_fwd(Geo g, const float *__restrict__ zin, const float *__re
                 for (int dj = 0; dj < 3; ++dj) {
                     const int cc = c + dj - 1;
                     if (cc < 0 || cc >= g.W) continue;
-                    const float2 v = *reinterpret_cast<const float2 *>(zin + ((int64_t)b * g.HW + rr * g.W + cc) * 4);
+                    const int64_t qi = (int64_t)b * g.HW + rr * g.W + cc;
+                    float2 v;
+                    if (MIX) {
+                        const float4 u = reinterpret_cast<const float4 *>(zin)[qi];
+                        v.x = u.x * m[0] + u.y * m[4] + u.z * m[8] + u.w * m[12];
+                        v.y = u.x * m[1] + u.y * m[5] + u.z * m[9] + u.w * m[13];
+                        if (di == 1 && dj == 1)
+                            reinterpret_cast<float4 *>(zmixed)[p] =
+                                make_float4(v.x, v.y, u.x * m[2] + u.y * m[6] + u.z * m[10] + u.w * m[14],
+                                            u.x * m[3] + u.y * m[7] + u.z * m[11] + u.w * m[15]);
+                    } else {
+                        v = *reinterpret_cast<const float2 *>(zin + qi * 4);
+                    }
                     const float *w = W1 + (di * 3 + dj) * 2 * W;
 #pragma unroll
                     for (int j = 0; j < W; ++j) h[j] = fmaf(v.x, w[j], fmaf(v.y, w[W + j], h[j]));
@@ -889,11 +909,21 @@ __global__ void k_w1_grad(Geo g, const float *__restrict__ zin, const float *__r
     acc_add_n<2 * W>(G + off_w1 + tap * 2 * W, flat, g.nslot);
 }
 
-// coupling, stage 5: transposed l_1 adds the CNN path into d loss / d z0
-template <int W>
-__global__ void k_c1_dz(Geo g, const float *__restrict__ t2, const float *__restrict__ P, int off_w1, float *__restrict__ dz)
+// coupling, stage 5: transposed l_1 adds the CNN path into d loss / d z0.
+// MIX = the backward of the preceding Conv2d1x1 is folded in (per pixel: dA += z_in^T d, d <- d A^T).
+template <int W, bool MIX>
+__global__ void k_c1_dz(Geo g, const float *__restrict__ t2, const float *__restrict__ P, int off_w1, float *__restrict__ dz,
+                        const float *__restrict__ zmix_in, const float *__restrict__ A, Acc dA)
 {
     const float *W1 = P + off_w1;
+    float m[16], acc[16];
+    if (MIX) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            m[i] = A[i];
+            acc[i] = 0.0f;
+        }
+    }
     NF_PIXEL_LOOP(g, p) {
         if (p < g.npix) {
             const int b = (int)(p / g.HW), rem = (int)(p - (int64_t)b * g.HW), r = rem / g.W, c = rem - r * g.W;
@@ -913,11 +943,25 @@ __global__ void k_c1_dz(Geo g, const float *__restrict__ t2, const float *__rest
                     }
                 }
             }
-            float2 *d = reinterpret_cast<float2 *>(dz + p * 4);
-            const float2 v = *d;
-            *d = make_float2(v.x + a0, v.y + a1);
+            if (MIX) {
+                const float4 dv = reinterpret_cast<const float4 *>(dz)[p], zv = reinterpret_cast<const float4 *>(zmix_in)[p];
+                const float d[4] = {dv.x + a0, dv.y + a1, dv.z, dv.w}, zi[4] = {zv.x, zv.y, zv.z, zv.w};
+                float o[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    o[i] = m[i * 4] * d[0] + m[i * 4 + 1] * d[1] + m[i * 4 + 2] * d[2] + m[i * 4 + 3] * d[3];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i * 4 + j] = fmaf(zi[i], d[j], acc[i * 4 + j]);
+                }
+                reinterpret_cast<float4 *>(dz)[p] = make_float4(o[0], o[1], o[2], o[3]);
+            } else {
+                float2 *d = reinterpret_cast<float2 *>(dz + p * 4);
+                const float2 v = *d;
+                *d = make_float2(v.x + a0, v.y + a1);
+            }
         }
     }
+    if (MIX) acc_add_n<16>(dA, acc, g.nslot);
 }
 
 // chain rule of the scalar parameterisations: dA -> PLU factors, d(a,b) -> sdn5 variables, gain_val
@@ -1095,14 +1139,21 @@ struct Guard {
 };
 
 template <int W>
-void coupling_forward(nf_trainer *t, const Geo &g, const TLayer &L, const float *zin, float *zout, Acc ldacc, hipStream_t st)
+void coupling_forward(nf_trainer *t, const Geo &g, const TLayer &L, const float *zin, float *zout, Acc ldacc,
+                      const float *zpre, const float *A, hipStream_t st)
 {
     const Cpl &c = t->cpl[L.aux];
     const unsigned nb = blocks_for(g.npix);
     const int w = W, off_w1 = L.off, off_m1 = L.off + 19 * w, off_w2 = L.off + 21 * w, off_m2 = L.off + 22 * w + w * w,
               off_w3 = L.off + 24 * w + w * w;
     const double n = (double)g.npix;
-    hipLaunchKernelGGL(k_c1_fwd<W>, dim3(nb), dim3(TB), 0, st, g, zin, t->d_params, off_w1, c.h1, t->acc(c.d_st1));
+    // zpre != null: the preceding Conv2d1x1 is folded into l_1 (which then also writes `zin`)
+    if (zpre)
+        hipLaunchKernelGGL((k_c1_fwd<W, true>), dim3(nb), dim3(TB), 0, st, g, zpre, A, const_cast<float *>(zin), t->d_params,
+                           off_w1, c.h1, t->acc(c.d_st1));
+    else
+        hipLaunchKernelGGL((k_c1_fwd<W, false>), dim3(nb), dim3(TB), 0, st, g, zin, (const float *)nullptr, (float *)nullptr,
+                           t->d_params, off_w1, c.h1, t->acc(c.d_st1));
     hipLaunchKernelGGL(k_c2_fwd<W>, dim3(nb), dim3(TB), 0, st, g, c.h1, t->acc(c.d_st1), n, t->d_params, off_m1,
                        t->d_flt + c.f_bn1, off_w2, c.h2, t->acc(c.d_st2));
     hipLaunchKernelGGL(k_c3_fwd<W>, dim3(nb), dim3(TB), 0, st, g, zin, c.h2, t->acc(c.d_st2), n, t->d_params, off_m2,
@@ -1110,7 +1161,8 @@ void coupling_forward(nf_trainer *t, const Geo &g, const TLayer &L, const float 
 }
 
 template <int W>
-void coupling_backward(nf_trainer *t, const Geo &g, const TLayer &L, const float *zin, float invB, hipStream_t st)
+void coupling_backward(nf_trainer *t, const Geo &g, const TLayer &L, const float *zin, float invB, const float *zmix_in,
+                       const float *A, Acc dA, hipStream_t st)
 {
     const Cpl &c = t->cpl[L.aux];
     const unsigned nb = blocks_for(g.npix);
@@ -1143,7 +1195,12 @@ void coupling_backward(nf_trainer *t, const Geo &g, const TLayer &L, const float
     hipLaunchKernelGGL(k_w1_grad<W>, dim3(ng, 9), dim3(TB), 0, sd, g, zin, t2, off_w1, G);
     (void)hipEventRecord(t->ev_done[par], sd);
     t->done_pending[par] = true;
-    hipLaunchKernelGGL(k_c1_dz<W>, dim3(nb), dim3(TB), 0, st, g, t2, t->d_params, off_w1, t->dz);
+    // zmix_in != null: the backward of the preceding Conv2d1x1 is folded into this last stage
+    if (zmix_in)
+        hipLaunchKernelGGL((k_c1_dz<W, true>), dim3(nb), dim3(TB), 0, st, g, t2, t->d_params, off_w1, t->dz, zmix_in, A, dA);
+    else
+        hipLaunchKernelGGL((k_c1_dz<W, false>), dim3(nb), dim3(TB), 0, st, g, t2, t->d_params, off_w1, t->dz,
+                           (const float *)nullptr, (const float *)nullptr, dA);
 }
 
 #define NF_WIDTH_SWITCH(w, CALL)            \
@@ -1420,13 +1477,18 @@ int nf_trainer_forward_backward(nf_trainer *t, const float *x, const float *y, i
             hipLaunchKernelGGL(k_scale_fwd, dim3(nb), dim3(TB), 0, st, g, zin, t->d_params + L.off, zout);
             break;
         case NF_LAYER_CONV1X1:
+            if (l + 1 < n && t->tl.l[l + 1].type == NF_LAYER_COUPLING) break;   // folded into the coupling's l_1 kernel
             hipLaunchKernelGGL(k_mix_fwd, dim3(nb), dim3(TB), 0, st, g, zin, t->d_flt + t->f_A + 16 * L.aux, zout);
             break;
-        case NF_LAYER_COUPLING:
-#define NF_CALL(WW) coupling_forward<WW>(t, g, L, zin, zout, t->acc(t->d_ld0 + l), st)
+        case NF_LAYER_COUPLING: {
+            const bool fold = l > 0 && t->tl.l[l - 1].type == NF_LAYER_CONV1X1;
+            const float *zpre = fold ? t->zs[l - 1] : nullptr;
+            const float *Am = fold ? t->d_flt + t->f_A + 16 * t->tl.l[l - 1].aux : nullptr;
+#define NF_CALL(WW) coupling_forward<WW>(t, g, L, zin, zout, t->acc(t->d_ld0 + l), zpre, Am, st)
             NF_WIDTH_SWITCH(L.width, NF_CALL)
 #undef NF_CALL
             break;
+        }
         }
     }
     hipLaunchKernelGGL(k_prior, dim3(nb), dim3(TB), 0, st, g, t->zs[n], s1, s2);
@@ -1451,11 +1513,17 @@ int nf_trainer_forward_backward(nf_trainer *t, const float *x, const float *y, i
             hipLaunchKernelGGL(k_mix_bwd, dim3(nb), dim3(TB), 0, st, g, t->zs[l], t->d_flt + t->f_A + 16 * L.aux, t->dz,
                                t->acc(t->d_dA + 16 * L.aux));
             break;
-        case NF_LAYER_COUPLING:
-#define NF_CALL(WW) coupling_backward<WW>(t, g, L, t->zs[l], invB, st)
+        case NF_LAYER_COUPLING: {
+            const bool fold = l > 0 && t->tl.l[l - 1].type == NF_LAYER_CONV1X1;
+            const float *zmix_in = fold ? t->zs[l - 1] : nullptr;
+            const float *Am = fold ? t->d_flt + t->f_A + 16 * t->tl.l[l - 1].aux : nullptr;
+            const Acc dA = t->acc(fold ? t->d_dA + 16 * t->tl.l[l - 1].aux : 0);
+#define NF_CALL(WW) coupling_backward<WW>(t, g, L, t->zs[l], invB, zmix_in, Am, dA, st)
             NF_WIDTH_SWITCH(L.width, NF_CALL)
 #undef NF_CALL
+            if (fold) --l;   // the Conv2d1x1 below was handled by the coupling's last stage
             break;
+        }
         }
     }
     for (int par = 0; par < 2; ++par)   // join the side stream: its slots are read next
