@@ -527,8 +527,15 @@ __global__ void k_loss(int B, double n, Acc ld0, int n_layers, int nslot, const 
                        const float *__restrict__ s2, const double *__restrict__ ldc, float *__restrict__ out)
 {
     __shared__ double sh[2][TB];
-    double ldsum = 0.0;   // sum over layers and patches of the data-dependent log-dets (every wavefront computes it)
-    for (int l = 0; l < n_layers; ++l) ldsum += acc_total(ld0 + l, nslot);
+    __shared__ double shl[TB / 64];
+    // sum over layers and patches of the data-dependent log-dets: the layers are dealt to the wavefronts
+    double lpart = 0.0;
+    for (int l = threadIdx.x >> 6; l < n_layers; l += TB / 64) lpart += acc_total(ld0 + l, nslot);
+    if ((threadIdx.x & 63) == 0) shl[threadIdx.x >> 6] = lpart;
+    __syncthreads();
+    double ldsum = 0.0;
+#pragma unroll
+    for (int i = 0; i < TB / 64; ++i) ldsum += shl[i];
     double a = 0.0, d = 0.0;
     for (int b = threadIdx.x; b < B; b += TB) {
         a += 0.5 * n * 1.8378770664093453 + 0.5 * (double)s2[b] - ldc[0];
