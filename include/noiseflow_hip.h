@@ -208,6 +208,10 @@ int nf_trainer_destroy(nf_trainer *t);
  *   loss_out   DEVICE float[2] = (mean_b nll_b, sd_z) or NULL  */
 int nf_trainer_forward_backward(nf_trainer *t, const float *x, const float *y, int64_t B,
                                 const nf_cond *cond, float *grads_out, float *loss_out, void *stream);
+/* Forward half only: (loss, sd_z) of a minibatch under batch-statistics BN, running statistics moved,
+ * no gradient — the `sidd_cond == 'condSDN'` branch of train_thread (train_noise_flow.py:61-63). */
+int nf_trainer_forward(nf_trainer *t, const float *x, const float *y, int64_t B, const nf_cond *cond,
+                       float *loss_out, void *stream);
 /* One optimizer update from `grads` (DEVICE float[n_params]; NULL = the trainer's own buffer). */
 int nf_trainer_apply(nf_trainer *t, const float *grads, float lr, void *stream);
 /* = nf_trainer_forward_backward(..., NULL, loss_out) + nf_trainer_apply(t, NULL, lr). */

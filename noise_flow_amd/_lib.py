@@ -102,6 +102,8 @@ def load() -> C.CDLL:
     lib.nf_trainer_destroy.argtypes = [vp]
     lib.nf_trainer_forward_backward.restype = C.c_int
     lib.nf_trainer_forward_backward.argtypes = [vp, vp, vp, i64, C.POINTER(nf_cond), vp, vp, vp]
+    lib.nf_trainer_forward.restype = C.c_int
+    lib.nf_trainer_forward.argtypes = [vp, vp, vp, i64, C.POINTER(nf_cond), vp, vp]
     lib.nf_trainer_apply.restype = C.c_int
     lib.nf_trainer_apply.argtypes = [vp, vp, f32, vp]
     lib.nf_trainer_step.restype = C.c_int
@@ -138,7 +140,7 @@ EXPORTED_SYMBOLS = (
     "nf_abi_version", "nf_last_error", "nf_layer_param_count", "nf_create", "nf_destroy", "nf_nll",
     "nf_sample", "nf_synth_patches", "nf_fold_params", "nf_sdn5_scalars",
     "nf_nll_batchstats", "nf_sample_batchstats", "nf_sums_reduce",
-    "nf_trainer_create", "nf_trainer_destroy", "nf_trainer_forward_backward", "nf_trainer_apply", "nf_trainer_step",
+    "nf_trainer_create", "nf_trainer_destroy", "nf_trainer_forward_backward", "nf_trainer_forward", "nf_trainer_apply", "nf_trainer_step",
     "nf_trainer_get_params", "nf_trainer_set_params", "nf_trainer_steps",
 )
 NF_OPT_ADAM = 0

@@ -1435,8 +1435,23 @@ int nf_trainer_create(const nf_config *cfg, const nf_layer_desc *layers, const f
     return NF_OK;
 }
 
+static int trainer_run(nf_trainer *t, const float *x, const float *y, int64_t B, const nf_cond *cond, float *grads_out,
+                       float *loss_out, void *stream, bool backward);
+
 int nf_trainer_forward_backward(nf_trainer *t, const float *x, const float *y, int64_t B, const nf_cond *cond,
                                 float *grads_out, float *loss_out, void *stream)
+{
+    return trainer_run(t, x, y, B, cond, grads_out, loss_out, stream, true);
+}
+
+int nf_trainer_forward(nf_trainer *t, const float *x, const float *y, int64_t B, const nf_cond *cond, float *loss_out,
+                       void *stream)
+{
+    return trainer_run(t, x, y, B, cond, nullptr, loss_out, stream, false);
+}
+
+static int trainer_run(nf_trainer *t, const float *x, const float *y, int64_t B, const nf_cond *cond, float *grads_out,
+                       float *loss_out, void *stream, bool backward)
 {
     if (!t) return nf_fail(NF_EINVAL, "trainer is NULL");
     if (B < 1 || B > t->max_batch) return nf_fail(NF_EINVAL, "B must be in 1..max_batch (%lld)", (long long)t->max_batch);
@@ -1502,6 +1517,11 @@ int nf_trainer_forward_backward(nf_trainer *t, const float *x, const float *y, i
     if (loss_out)
         hipLaunchKernelGGL(k_loss, dim3(1), dim3(TB), 0, st, (int)B, (double)g.HW * 4.0, t->acc(t->d_ld0), n, (int)nb, s1, s2,
                            G + t->d_ldc, loss_out);
+    if (!backward) {
+        t->zs[0] = nullptr;
+        if ((e = hipGetLastError()) != hipSuccess) return nf_fail_hip(e, "trainer launch");
+        return NF_OK;
+    }
     // ---- backward ----
     hipLaunchKernelGGL(k_dz_init, dim3(nb), dim3(TB), 0, st, g, t->zs[n], invB, t->dz);
     for (int l = n - 1; l >= 0; --l) {

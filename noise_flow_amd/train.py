@@ -100,6 +100,22 @@ class Trainer:
                 self._grads.data_ptr(), self._loss.data_ptr(), dev.stream_ptr()))
         return self._grads, self._loss
 
+    def forward(self, x, y, nlf0=None, nlf1=None, iso=None, cam=None, sync: bool = True):
+        """``sess.run([loss, sd_z], {..., is_training: True})`` without ``train_op`` — the
+        ``sidd_cond == 'condSDN'`` branch of ``train_thread`` (train_noise_flow.py:61-63): batch-
+        statistics forward, running statistics moved, parameters untouched."""
+        xt, yt = self._inputs(x, y)
+        cond = _lib.nf_cond(_first(iso), _first(cam), _first(nlf0), _first(nlf1))
+        dev = self._dev
+        with dev.torch.cuda.device(dev.device):
+            _lib.check(self.lib.nf_trainer_forward(
+                self._h, xt.data_ptr(), yt.data_ptr() if yt is not None else None, int(xt.shape[0]), C.byref(cond),
+                self._loss.data_ptr(), dev.stream_ptr()))
+        if not sync:
+            return self._loss
+        v = self._loss.cpu().numpy()
+        return np.float32(v[0]), np.float32(v[1])
+
     def apply(self, lr: float, grads=None):
         g = self._grads if grads is None else grads
         dev = self._dev

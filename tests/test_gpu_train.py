@@ -199,6 +199,27 @@ def test_trained_parameters_round_trip_into_the_eval_path(tmp_path):
     np.testing.assert_allclose(nll, ref, rtol=1e-5)
 
 
+def test_forward_only_equals_the_batch_statistics_eval_path(shipped_variables):
+    """Trainer.forward (condSDN branch) = NoiseFlow(is_training=True).loss: same loss / sd_z, same EMA,
+    parameters untouched."""
+    from noise_flow_amd import NoiseFlow, default_hps
+    x, y = make_inputs(12, seed=77, b1=0.003696)
+    tr = _trainer(FULL_ARCH, shipped_variables)
+    before = tr.raw_params()
+    loss, sd = tr.forward(x, y, [0.0], [0.0], [800], [2])
+    m = NoiseFlow([32, 32, 4], True, default_hps(), variables=shipped_variables)
+    ref_loss, ref_sd = m.loss(x, y, [0.0], [0.0], [800], [2])
+    assert abs(loss - ref_loss) <= 1e-5 * abs(ref_loss) and abs(sd - ref_sd) <= 1e-5 * ref_sd
+    after = tr.variables
+    for k, v in m.variables.items():
+        a = np.asarray(after[k], np.float32).reshape(-1)
+        if "bn_nvp_conv" in k:
+            assert np.abs(a - np.asarray(v, np.float32).reshape(-1)).max() <= 1e-5 * max(np.abs(v).max(), 1e-3), k
+        else:
+            assert np.array_equal(a, np.asarray(shipped_variables[k], np.float32).reshape(-1)), k
+    assert tr.steps == 0 and not np.array_equal(before, tr.raw_params())     # only the BN statistics moved
+
+
 def test_trainer_c_abi_errors(shipped_variables):
     import ctypes as C
     import torch
