@@ -686,7 +686,7 @@ int nf_create(const nf_config *cfg, const nf_layer_desc *layers, const float *pa
     if (cfg->flags & NF_CFG_FP16_CNN) {
         const int hw = cfg->height * cfg->width;
         if (h->fwd.block3.empty() || !((cfg->height == 32 && cfg->width == 32) || (cfg->height == 64 && cfg->width == 64)) || hw == 0) {
-            delete h;
+            nf_destroy(h);   // the scalar-layout blocks are already on the device
             return fail(NF_EINVAL, "NF_CFG_FP16_CNN needs coupling width 4 and full 32x32 or 64x64 patches");
         }
     }
@@ -860,11 +860,16 @@ static int run_batchstats(nf_handle *h, int direction, NfLaunch a, float *moment
     const size_t need = std::max(std::max(h->fwd.block.size(), h->rev.block.size()),
                                  std::max(h->fwd.block2.size(), h->rev.block2.size()));
     hipError_t e;
-    if (!h->d_bs_params) {
-        if ((e = hipMalloc((void **)&h->d_bs_params, need * sizeof(float))) != hipSuccess) return fail_hip(e, "hipMalloc(batchstats params)");
-        h->bs_cap = need;
-        if ((e = hipMalloc((void **)&h->d_bs_stats, NF_STATS_SLOTS * 64 * sizeof(double))) != hipSuccess)
-            return fail_hip(e, "hipMalloc(batchstats accumulators)");
+    if (!h->d_bs_params &&
+        (e = hipMalloc((void **)&h->d_bs_params, need * sizeof(float))) != hipSuccess) {
+        h->d_bs_params = nullptr;
+        return fail_hip(e, "hipMalloc(batchstats params)");
+    }
+    h->bs_cap = need;
+    if (!h->d_bs_stats &&
+        (e = hipMalloc((void **)&h->d_bs_stats, NF_STATS_SLOTS * 64 * sizeof(double))) != hipSuccess) {
+        h->d_bs_stats = nullptr;
+        return fail_hip(e, "hipMalloc(batchstats accumulators)");
     }
     std::vector<float> p = h->raw;
     std::vector<int> cpl;   // coupling layers in execution order
