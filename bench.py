@@ -89,6 +89,12 @@ def parse_args():
 
 def main():
     args = parse_args()
+    # stdout carries exactly ONE line, the JSON, written last: native libraries (RCCL prints a version
+    # banner through C stdio, flushed at exit AFTER Python's output) would otherwise follow it.  Everything
+    # else that targets fd 1 goes to stderr; the JSON is written straight to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -365,10 +371,13 @@ def main():
             "cpu_baseline": cpu_baseline, "sampling": sampling, "nll_check": nll_check, "fp16_cnn_64x64": fp16_cnn,
             "training": training, "clock_ramp_ms": args.ramp_ms,
         }
-        print(json.dumps(out), flush=True)
+        line = json.dumps(out)
     if use_dist:
         dist.barrier()                      # rank 0's extra sections are done before any rank tears down
         dist.destroy_process_group()
+    if rank == 0:
+        os.write(json_fd, (line + "\n").encode())
+    os.close(json_fd)
 
 
 if __name__ == "__main__":
