@@ -552,3 +552,27 @@ def test_full_bench_batch_against_c_oracle(shipped_variables):
     xs = m.sample(y4, 1.0, y4, [0], [0], [100], [2], eps=eps)
     r = c.sample(eps, 1.0, y4.cpu().numpy(), 100.0, 2.0)
     _close_elem(np.asarray(xs), r.astype(np.float64))
+
+
+def test_extreme_inputs_stay_finite_and_match(shipped_variables, oracle_full):
+    """Edge inputs the SIDD pipeline can produce: black (y = 0 -> scale = sqrt(beta2)), saturated
+    (y = 1), exactly-zero noise, and noise 30 sigma out.  Finite everywhere, same tolerance."""
+    rng = np.random.RandomState(4)
+    y = np.stack([np.zeros((32, 32, 4)), np.ones((32, 32, 4)), rng.rand(32, 32, 4), rng.rand(32, 32, 4)]).astype(np.float32)
+    sd = np.sqrt(0.000479 * y + 2e-6)
+    x = (rng.randn(4, 32, 32, 4) * sd).astype(np.float32)
+    x[2] = 0.0
+    x[3] *= 30.0
+    m = _model(FULL_ARCH, shipped_variables)
+    nll, _ = m._loss(x, y, [0], [0], [100], [2])
+    ref, _, ref_z = oracle_full.nll(x, y, 100, 2)
+    assert np.isfinite(nll).all()
+    np.testing.assert_allclose(nll, ref, rtol=NLL_RTOL)
+    z, _ = m.inverse(x, None, y, [0], [0], [100], [2])
+    _close_elem(z, ref_z)
+    eps = rng.randn(4, 32, 32, 4).astype(np.float32) * 6.0          # far tails of the base measure
+    xs = m.sample(y, 1.0, y, [0], [0], [100], [2], eps=eps)
+    assert np.isfinite(xs).all()
+    # 6-sigma latents are amplified ~1000x through the eight inverse 1x1 / coupling pairs: fp32 round-off
+    # of the intermediate values (not of the output scale) sets the error here, 3.4e-5 measured
+    _close_elem(xs, oracle_full.sample(eps, 1.0, y, 100, 2), rtol=1e-4)
