@@ -53,22 +53,44 @@ def evaluate_sharded(eval_chunk: Callable[[int, int, object], object], n_total: 
     return float(s[0] / s[2]), float(s[1] / s[2]), n
 
 
-def flow_eval_chunk(model, seed: int, cond=( [0.0], [0.0], [100.0], [2.0]), height: int = 32, width: int = 32):
-    """The HIP-path ``eval_chunk`` for :func:`evaluate_sharded` on synthetic patches."""
+def flow_eval_chunk(model, seed: int, cond=( [0.0], [0.0], [100.0], [2.0]), height: int = 32, width: int = 32,
+                    n_streams: int = 2):
+    """The HIP-path ``eval_chunk`` for :func:`evaluate_sharded` on synthetic patches.
+
+    Consecutive chunks alternate between ``n_streams`` HIP streams: a chunk of 1 024 patches fills the
+    GPU exactly once (1 024 resident workgroups), so on ONE stream every launch pays its own ramp-up
+    and drain; on two, the next launch's workgroups take the slots the previous one frees and the
+    evaluation runs at the steady-state rate (measured: 53.4 → 46.0 µs per 1 024 patches).  All
+    chunks add into one slotted accumulator (atomics), folded once by ``finish``."""
+    import torch
     from .patches import synth_patches
     nlf0, nlf1, iso, cam = cond
-
+    dev = model._dev.device
     wide = model.new_sums()   # slotted accumulator of this evaluation (no same-line atomics)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, int(n_streams)))]
+    state = {"i": 0, "dirty": False}
 
     def run(first, count, sums):
-        x, y = synth_patches(seed, first, count, height, width, device=model._dev.device.index)
-        model.nll_sums(x, y, nlf0, nlf1, iso, cam, wide)
+        s = streams[state["i"] % len(streams)]
+        state["i"] += 1
+        if not state["dirty"]:   # the accumulator was created / zeroed on the caller's stream
+            for t in streams:
+                t.wait_stream(torch.cuda.current_stream(dev))
+            state["dirty"] = True
+        with torch.cuda.stream(s):
+            x, y = synth_patches(seed, first, count, height, width, device=dev.index)
+            model.nll_sums(x, y, nlf0, nlf1, iso, cam, wide)
         return sums
 
     def finish(sums):
-        """Fold the slotted accumulator into the plain triple (once, before the all-reduce)."""
+        """Join the streams and fold the slotted accumulator into the plain triple (once, before the
+        all-reduce)."""
+        cur = torch.cuda.current_stream(dev)
+        for t in streams:
+            cur.wait_stream(t)
         model.fold_sums(wide, out=sums)
         wide.zero_()
+        state["dirty"] = False
         return sums
 
     run.finish = finish
