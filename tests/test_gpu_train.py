@@ -371,3 +371,23 @@ def test_two_rank_data_parallel_training_matches_manual_gradient_averaging(tmp_p
     assert np.array_equal(p0[mask], a.raw_params()[mask])
     assert np.array_equal(p0, a.raw_params()) and np.array_equal(p1, b.raw_params())   # incl. per-rank BN statistics
     assert not np.array_equal(p0[~mask], p1[~mask])
+
+
+def test_gradients_with_the_reversed_template_binding():
+    """binding='sample_first' (quirk Q1): the coupling CNN variables are bound to the layers in reversed
+    order; trainer and oracle must agree on which template each gradient belongs to."""
+    from noise_flow_amd import default_hps
+    from noise_flow_amd.train import Trainer
+    from oracle.nf_grad_oracle import GradOracle
+    arch = "sdn5|unc|unc|gain4|unc"
+    v = trained_like_variables(arch, 4, seed=21)
+    x, y = make_inputs(5, seed=23, b1=0.003696)
+    tr = Trainer([32, 32, 4], default_hps(arch=arch), variables=v, binding="sample_first", max_batch=8)
+    grads, loss = tr.forward_backward(x, y, [0.0], [0.0], [800], [2])
+    ref_loss, ref_sd, ref_grads, _ = GradOracle(arch, v, binding="sample_first").loss_and_grads(x, y, 800, 2)
+    lv = loss.cpu().numpy()
+    assert abs(lv[0] - ref_loss) <= 1e-5 * abs(ref_loss)
+    _check_grads(tr, grads, ref_grads)
+    # and the two bindings really differ
+    other = GradOracle(arch, v, binding="loss_first").loss_and_grads(x, y, 800, 2)[0]
+    assert abs(other - ref_loss) > 1e-3 * abs(ref_loss)
