@@ -14,6 +14,7 @@ kernels through the C ABI; there is no CPU execution path.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import threading
 from types import SimpleNamespace
 from typing import Dict, Optional
@@ -37,6 +38,35 @@ def _first(v, default=0.0) -> float:
     return float(a[0])
 
 
+_NARROW_POOL = None
+
+
+def _to_float32(a) -> np.ndarray:
+    """Contiguous float32 view/copy of a host array.  float64 minibatches (the reference's dtype, quirk Q9)
+    are narrowed in parallel slices — numpy's cast releases the GIL but is single-threaded (6 GB/s), and
+    torch's threaded CPU cast oversubscribes a cgroup-limited container (measured 10x slower)."""
+    a = np.asarray(a)
+    if a.dtype == np.float32 or a.size < (1 << 20) or a.ndim == 0:
+        return np.ascontiguousarray(a, dtype=np.float32)
+    global _NARROW_POOL
+    if _NARROW_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        try:
+            n = len(os.sched_getaffinity(0))
+        except Exception:
+            n = os.cpu_count() or 1
+        _NARROW_POOL = ThreadPoolExecutor(max_workers=max(1, min(8, n)))
+    out = np.empty(a.shape, np.float32)
+    n = a.shape[0]
+    parts = min(8, n)
+    edges = [n * k // parts for k in range(parts + 1)]
+
+    def cast(k):
+        out[edges[k]:edges[k + 1]] = a[edges[k]:edges[k + 1]]
+    list(_NARROW_POOL.map(cast, range(parts)))
+    return out
+
+
 class _Dev:
     """Device plumbing (torch is used ONLY for HBM allocations and streams)."""
 
@@ -53,7 +83,7 @@ class _Dev:
         torch = self.torch
         was_np = not isinstance(a, torch.Tensor)
         if was_np:
-            t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device, non_blocking=False)
+            t = torch.from_numpy(_to_float32(a)).to(self.device, non_blocking=False)
         else:
             t = a.to(device=self.device, dtype=torch.float32).contiguous()
         if shape_tail is not None and tuple(t.shape[1:]) != tuple(shape_tail):
@@ -66,9 +96,17 @@ class _Dev:
     def stream_ptr(self) -> int:
         return int(self.torch.cuda.current_stream(self.device).cuda_stream)
 
-    @staticmethod
-    def back(t, as_numpy: bool):
-        return t.cpu().numpy() if as_numpy else t
+    def back(self, t, as_numpy: bool):
+        """Results go back the way the inputs came.  numpy: through a page-locked host tensor from torch's
+        caching host allocator for large tensors (64 MiB: 10 ms pageable, 1.3 ms pinned); the returned array
+        owns that block until it is garbage-collected."""
+        if not as_numpy:
+            return t
+        if t.numel() < (1 << 23):     # below 32 MiB the pageable path is as fast (measured) and has no set-up cost
+            return t.cpu().numpy()
+        h = self.torch.empty(t.shape, dtype=t.dtype, device="cpu", pin_memory=True)
+        h.copy_(t)
+        return h.numpy()
 
 
 class FlowHandle:
