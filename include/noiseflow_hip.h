@@ -189,7 +189,8 @@ int nf_sample_batchstats(nf_handle *h, const float *y, const float *eps, uint64_
  * variable, the BN running-statistics EMA (layers.py:392-393) and the optimizer update.  The
  * trainer owns a device-resident copy of the RAW parameters (layout of nf_create), the optimizer
  * slots and an activation workspace sized for `max_batch` patches; a step only enqueues kernels on
- * `stream` (no allocation, no synchronisation).  One stream at a time per trainer.
+ * `stream` — and on an internal side stream forked from and joined back into it with events — with no
+ * allocation and no host synchronisation.  One stream at a time per trainer.
  * Layers: CONV1X1, COUPLING (width 4/8/16/32), SDN5, SDN4, GAIN4 — every architecture of
  * job_noise_flow.sh; fp32 (nf_config.flags must be 0).
  * Trainable = everything except P / sign_S of CONV1X1, the BN statistics and c_i of SDN5. */
