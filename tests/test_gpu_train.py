@@ -391,3 +391,37 @@ def test_gradients_with_the_reversed_template_binding():
     # and the two bindings really differ
     other = GradOracle(arch, v, binding="loss_first").loss_and_grads(x, y, 800, 2)[0]
     assert abs(other - ref_loss) > 1e-3 * abs(ref_loss)
+
+
+def test_training_golden_fixture(shipped_variables):
+    """tests/golden/train_step_shipped.npz (made by tools/make_golden_train.py from the fp64 autograd
+    oracle): loss, every gradient tensor, the BN EMA and one Adam step of the shipped model."""
+    from conftest import ROOT
+    from oracle.nf_grad_oracle import is_trainable
+    g = np.load(os.path.join(ROOT, "tests", "golden", "train_step_shipped.npz"))
+    x, y, iso, cam, lr = g["x"], g["y"], float(g["iso"]), float(g["cam"]), float(g["lr"])
+    tr = _trainer(FULL_ARCH, shipped_variables)
+    grads, loss = tr.forward_backward(x, y, [0.0], [0.0], [iso], [cam])
+    lv = loss.cpu().numpy()
+    assert abs(lv[0] - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    assert abs(lv[1] - float(g["sd_z"])) <= 1e-5 * float(g["sd_z"])
+    ref_grads = {k[len("grad/"):]: g[k] for k in g.files if k.startswith("grad/")}
+    assert _check_grads(tr, grads, ref_grads) == 2431
+    v = tr.variables
+    for k in g.files:
+        if k.startswith("bn/"):
+            want = g[k]
+            assert np.abs(v[k[3:]] - want).max() <= 1e-5 * max(np.abs(want).max(), 1e-3), k
+    tr.apply(lr)
+    after = tr.variables
+    for k, gr in ref_grads.items():
+        if not is_trainable(k) or k.endswith("/b") or ("adam/" + k) not in g.files or k not in after:
+            continue
+        want = g["adam/" + k].reshape(-1)
+        got = np.asarray(after[k], np.float32).reshape(-1)
+        if got.shape != want.shape:
+            continue                                         # unused rescaling_scale of sdn_0 / gain_5
+        solid = np.abs(gr.reshape(-1)) > 1e-3 * max(np.abs(gr).max(), 1e-30)   # well above the fp32 noise floor
+        if solid.any():
+            # first Adam step = lr * g / (|g| + eps'): the bulk must move exactly like the oracle's
+            assert np.abs(got[solid] - want[solid]).max() <= 0.02 * lr + 1e-6 * np.abs(want[solid]).max(), k

@@ -83,3 +83,25 @@ def test_raw_layout_pack_unpack_round_trip():
     for k in owned:
         np.testing.assert_allclose(np.asarray(moved[k]).reshape(-1), np.asarray(v[k], np.float32).reshape(-1) + 1.0)
     assert sum(int(np.asarray(v[k]).size) for k in owned) + 1 == flat.size   # + sdn5's constant c_i
+
+
+def test_training_golden_fixture_matches_the_oracle(shipped_variables):
+    """tests/golden/train_step_shipped.npz (tools/make_golden_train.py) freezes the training oracle."""
+    import os
+    from conftest import ROOT
+    from oracle.nf_grad_oracle import GradOracle, adam_step
+    g = np.load(os.path.join(ROOT, "tests", "golden", "train_step_shipped.npz"))
+    arch = str(g["arch"])
+    loss, sd_z, grads, new_running = GradOracle(arch, shipped_variables).loss_and_grads(g["x"], g["y"], int(g["iso"]), int(g["cam"]))
+    assert abs(loss - float(g["loss"])) <= 1e-10 * abs(loss) and abs(sd_z - float(g["sd_z"])) <= 1e-10 * sd_z
+    n = 0
+    for k, v in grads.items():
+        ref = g["grad/" + k]
+        assert np.abs(np.asarray(v, np.float32) - ref).max() <= 1e-6 * max(np.abs(ref).max(), 1e-6), k
+        n += ref.size
+    assert n == 2433
+    for k, v in new_running.items():
+        assert np.abs(np.asarray(v, np.float32) - g["bn/" + k]).max() <= 1e-6 * max(np.abs(g["bn/" + k]).max(), 1e-6), k
+    after = adam_step(shipped_variables, grads, {}, float(g["lr"]))
+    for k in grads:
+        np.testing.assert_allclose(np.asarray(after[k], np.float32), g["adam/" + k], rtol=1e-6, atol=1e-9)
