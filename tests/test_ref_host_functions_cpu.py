@@ -1,0 +1,98 @@
+"""CPU tier: the host-side functions either side of the hot path against OUTPUTS OF THE REFERENCE
+ITSELF (tests/golden/ref_host_functions.npz, produced by tools/make_golden_ref_host.py executing the
+reference's own definitions in the build container).  These rows are reference-pinned."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, SHIPPED_DIR
+
+
+@pytest.fixture(scope="module")
+def ref():
+    return np.load(os.path.join(ROOT, "tests", "golden", "ref_host_functions.npz"))
+
+
+def test_bayer_packing_matches_reference(ref):
+    from noise_flow_amd.patches import pack_raw, unpack_raw
+    packed = pack_raw(ref["pack_in"])
+    assert packed.shape == ref["pack_out"].shape and np.array_equal(packed, ref["pack_out"])
+    assert np.array_equal(unpack_raw(ref["pack_out"]), ref["unpack_out"])
+
+
+def test_patch_origins_match_reference(ref):
+    from noise_flow_amd.patches import patch_origins
+    for k, (h, w, ph, pw, n) in enumerate(ref["origins_cases"]):
+        ii, jj, n_p = patch_origins(int(h), int(w), int(ph), int(pw), None if n < 0 else int(n))
+        want = ref["origins_%d" % k]
+        assert n_p == int(ref["origins_n_%d" % k])
+        assert list(ii) == list(want[0]) and list(jj) == list(want[1]), k
+
+
+def test_histogram_and_kl_match_reference(ref):
+    from noise_flow_amd.metrics import get_histogram, kl_div_3_data
+    edges = ref["kl_edges"]
+    hist, centers = get_histogram(ref["kl_p"], edges, -0.3, 0.3, 200)
+    np.testing.assert_allclose(hist, ref["hist_p"], rtol=0, atol=0)
+    np.testing.assert_allclose(centers, ref["hist_centers"], rtol=1e-15)
+    np.testing.assert_allclose(kl_div_3_data(ref["kl_p"], ref["kl_q"], edges, -0.3, 0.3, 200), ref["kl3_edges"], rtol=1e-12)
+    np.testing.assert_allclose(kl_div_3_data(ref["kl_u"], ref["kl_v"]), ref["kl3_default"], rtol=1e-12)
+    hd, cd = get_histogram(ref["kl_u"])
+    np.testing.assert_allclose(hd, ref["hist_default"], rtol=0, atol=0)
+    np.testing.assert_allclose(cd, ref["hist_default_centers"], rtol=1e-15)
+
+
+def test_wrapper_hps_loader_matches_reference(ref):
+    from noise_flow_amd.hps import hps_loader
+    want = json.loads(str(ref["wrapper_hps_json"]))
+    got = vars(hps_loader(os.path.join(SHIPPED_DIR, "hps.txt")))
+    assert set(got) == set(want)
+    for k, w in want.items():
+        if k == "param_inits":
+            g = got[k]
+            assert [g[0], g[1], g[2]] == w[:3]
+            assert np.asarray(g[3]).tolist() == w[3] and np.asarray(g[4]).tolist() == w[4]
+        else:
+            assert type(got[k]).__name__ == w[0] and got[k] == w[1], (k, got[k], w)
+
+
+def test_result_logger_and_hps_files_match_reference(ref, tmp_path):
+    from noise_flow_amd.harness import ResultLogger
+    from noise_flow_amd.hps import hps_logger, hps_loader_raw
+    cols = [str(c) for c in ref["logger_cols"]]
+    rows = json.loads(str(ref["logger_rows_json"]))
+    # the generator logged python / numpy scalars; replay the same values with the same types
+    rows[1]["NLL"] = np.float32(rows[1]["NLL"])
+    rows[1]["sdz"] = np.float64(rows[1]["sdz"])
+    path = os.path.join(str(tmp_path), "test.txt")
+    lg = ResultLogger(path, cols)
+    for r in rows:
+        lg.log(r)
+    lg.close()
+    lg2 = ResultLogger(path, cols, True)
+    lg2.log(rows[0])
+    lg2.close()
+    assert open(path).read() == str(ref["logger_file"])
+
+    class H:
+        pass
+    h = H()
+    h.arch, h.width, h.lr, h.flag, h.none = "sdn5|unc|gain4|unc", 4, 1e-4, True, None
+    h.with_comma = "a,b"
+    hp = os.path.join(str(tmp_path), "hps.txt")
+    hps_logger(hp, h, ["sdn_0", "Conv2d_1x1_1", "unc_1"], 2433)
+    assert open(hp, newline="").read() == str(ref["hps_logger_file"])
+    assert vars(hps_loader_raw(hp)) == json.loads(str(ref["hps_loader_json"]))
+
+
+def test_closed_form_baselines_match_reference(ref):
+    """NLL_G / NLL_SDN of PatchStatsCalculator.calc_baselines: mean over minibatches of per-patch NLLs."""
+    from noise_flow_amd.metrics import nll_gauss, nll_sdn
+    x, y = ref["baseline_x"], ref["baseline_y"]
+    b1, b2 = ref["baseline_nlf"]
+    g = np.mean([nll_gauss(x[k], np.sqrt(float(ref["baseline_vr_gauss"]))) for k in range(x.shape[0])])
+    s = np.mean([nll_sdn(x[k], y[k], b1, b2) for k in range(x.shape[0])])
+    assert abs(g - float(ref["baseline_nll_gauss"])) <= 1e-12 * abs(g)
+    assert abs(s - float(ref["baseline_nll_sdn"])) <= 1e-12 * abs(s)
