@@ -96,3 +96,14 @@ def test_closed_form_baselines_match_reference(ref):
     s = np.mean([nll_sdn(x[k], y[k], b1, b2) for k in range(x.shape[0])])
     assert abs(g - float(ref["baseline_nll_gauss"])) <= 1e-12 * abs(g)
     assert abs(s - float(ref["baseline_nll_sdn"])) <= 1e-12 * abs(s)
+
+
+def test_fresh_sdn_gain_initialisation_matches_reference(ref):
+    """train_noise_flow.init_params → the values a fresh model starts its sdn / gain parameters from."""
+    from noise_flow_amd.params import init_variables, C_I
+    v = init_variables("sdn5|unc|unc|unc|unc|gain4|unc|unc|unc|unc", 4, 4, 0)
+    assert float(C_I) == float(ref["init_c_i"])
+    assert np.all(np.asarray(v["model/sdn_gain/beta1"], np.float64) == float(ref["init_beta1"]))
+    assert np.all(np.asarray(v["model/sdn_gain/beta2"], np.float64) == float(ref["init_beta2"]))
+    assert np.array_equal(np.asarray(v["model/sdn_gain/gain_params"], np.float64).reshape(-1), ref["init_gain_params"])
+    assert np.array_equal(np.asarray(v["model/sdn_gain/cam_params"], np.float64), ref["init_cam_params"])

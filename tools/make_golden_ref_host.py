@@ -13,7 +13,8 @@ Pinned: pack_raw / unpack_raw, sample_indices_uniform, get_histogram, kl_div_3_d
 (sidd/sidd_utils.py:732-764, 830-846, 1247-1274), NoiseFlowWrapper.hps_loader on the shipped hps.txt
 (borealisflows/NoiseFlowWrapper.py:96-138), ResultLogger / hps_logger / hps_loader
 (borealisflows/utils.py:90-135), the Gaussian / camera-NLF baseline formulas of
-PatchStatsCalculator.calc_baselines (sidd/PatchStatsCalculator.py:92-123).
+PatchStatsCalculator.calc_baselines (sidd/PatchStatsCalculator.py:92-123), the initial sdn / gain
+parameter values of train_noise_flow.init_params (train_noise_flow.py:201-214).
 """
 import ast
 import gc
@@ -152,6 +153,16 @@ def main():
     out["baseline_nlf"] = np.asarray([0.003696, 2e-6])
     out["baseline_nll_gauss"] = np.asarray(nll_gauss)
     out["baseline_nll_sdn"] = np.asarray(nll_sdn)
+
+    # ---- train_noise_flow.init_params: initial values of the sdn / gain parameters ------------------
+    ns = {"np": np}
+    take("train_noise_flow.py", ["init_params"], ns)
+    h1 = H()
+    h1.arch = "sdn5|unc|unc|unc|unc|gain4|unc|unc|unc|unc"
+    ns["init_params"](h1)
+    c_i, b1, b2, gp, cp = h1.param_inits
+    out["init_c_i"], out["init_beta1"], out["init_beta2"] = np.asarray(c_i), np.asarray(b1), np.asarray(b2)
+    out["init_gain_params"], out["init_cam_params"] = np.asarray(gp), np.asarray(cp)
 
     path = os.path.join(ROOT, "tests", "golden", "ref_host_functions.npz")
     np.savez_compressed(path, **out)
