@@ -43,3 +43,42 @@ def test_standalone_c_client(tmp_path, shipped_variables):
     assert sums[2] == B and abs(sums[0] - vals[:, 0].astype(np.float64).sum()) < 1e-3
     xs = m.sample(y, 0.6, y, [0], [0], [100], [2], seed=99)
     assert abs(checksum - float(xs.double().sum())) <= 1e-6 * float(xs.abs().double().sum())
+
+
+def test_standalone_c_training_client(tmp_path):
+    """The trainer driven by a plain C program: same losses and (bit for bit) the same parameters as
+    the Python Trainer on the same Philox-keyed minibatches."""
+    from conftest import trained_like_variables
+    from noise_flow_amd import default_hps, params
+    from noise_flow_amd.patches import synth_patches
+    from noise_flow_amd.train import Trainer
+    arch = "sdn5|unc|unc|gain4|unc"
+    v = trained_like_variables(arch, 4, seed=13)
+    layers, descs, flat = params.pack(arch, v, 4)
+    model = tmp_path / "model.bin"
+    with open(model, "wb") as f:
+        f.write(struct.pack("<i", len(layers)))
+        for d in descs:
+            f.write(struct.pack("<iiq", d.type, d.width, d.param_offset))
+        f.write(struct.pack("<q", flat.size))
+        f.write(flat.tobytes())
+    exe = tmp_path / "c_abi_train_demo"
+    csrc = os.path.join(ROOT, "noise_flow_amd", "csrc")
+    subprocess.check_call(["gcc", "-std=c99", "-O2", os.path.join(ROOT, "examples", "c_abi_train_demo.c"),
+                           "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__",
+                           "-L" + csrc, "-lnoiseflow_hip", "-L/opt/rocm/lib", "-lamdhip64",
+                           "-Wl,-rpath," + csrc, "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
+    B, K, lr = 24, 4, 1e-3
+    outp = tmp_path / "trained.bin"
+    out = subprocess.check_output([str(exe), str(model), str(B), str(K), repr(lr), str(outp)], text=True).strip().splitlines()
+    losses = [(float(l.split()[3]), float(l.split()[5])) for l in out[:K]]
+    assert out[K].split()[1:] == ["-1", "NF_EINVAL"]
+    trained = np.fromfile(str(outp), np.float32)
+
+    tr = Trainer([32, 32, 4], default_hps(arch=arch), variables=v, max_batch=B)
+    for k in range(K):
+        x, y = synth_patches(11, k * B, B, nlf=(0.003696, 0.000002))
+        loss, sd = tr.step(x, y, [0.0], [0.0], [800.0], [2.0], lr=lr)
+        assert abs(loss - losses[k][0]) <= 1e-6 * abs(loss) and abs(sd - losses[k][1]) <= 1e-6 * sd
+    assert np.array_equal(tr.raw_params(), trained)
+    assert losses[-1][0] < losses[0][0]
