@@ -185,3 +185,24 @@ def test_error_reporting(shipped_variables):
         params.parse_arch("unc|sdn3")
     with pytest.raises(KeyError):
         params.pack("unc|unc|unc|unc|unc|unc|unc|unc|unc", shipped_variables, 4)   # no 9th template in the ckpt
+
+
+def test_product_never_touches_the_oracle():
+    """oracle/ is test infrastructure: no product module, driver script or native source may import,
+    load or mention it (only tests/, __graft_entry__.smoke() and bench.py's checker legs do)."""
+    import glob
+    import re
+    files = (glob.glob(os.path.join(ROOT, "noise_flow_amd", "*.py")) + glob.glob(os.path.join(ROOT, "noise_flow_amd", "csrc", "*"))
+             + [os.path.join(ROOT, f) for f in ("train_noise_flow_amd.py", "sample_noise_flow_amd.py")]
+             + glob.glob(os.path.join(ROOT, "include", "*.h")) + glob.glob(os.path.join(ROOT, "examples", "*.c")))
+    # imports / loads only — a comment may name the oracle file a constant was cross-checked against
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b|libnf_oracle|nf_oracle_c|nf_grad_oracle|import_module\([\'\"]oracle", re.M)
+    for f in files:
+        if f.endswith((".o", ".so")):
+            continue
+        txt = open(f, errors="replace").read()
+        assert not pat.search(txt), f
+    # bench.py may use it only inside the rank-0 checker / cpu_baseline sections
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    first = bench.index("from oracle")
+    assert first > bench.index("parity + CPU baseline: rank 0, N = 1 only")
