@@ -206,3 +206,19 @@ def test_product_never_touches_the_oracle():
     bench = open(os.path.join(ROOT, "bench.py")).read()
     first = bench.index("from oracle")
     assert first > bench.index("parity + CPU baseline: rank 0, N = 1 only")
+
+
+def test_missing_extension_fails_loudly(tmp_path):
+    """No .so -> ImportError naming the build command, in a fresh interpreter (there is no fallback)."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from noise_flow_amd import _lib\n"
+            "_lib.LIB_PATH = %r\n"
+            "try:\n"
+            "    _lib.load()\n"
+            "except ImportError as e:\n"
+            "    assert 'HIP extension not built' in str(e) and 'no CPU fallback' in str(e), e\n"
+            "    print('OK')\n") % (ROOT, os.path.join(str(tmp_path), "libnoiseflow_hip.so"))
+    out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert out.returncode == 0 and out.stdout.decode().strip().endswith("OK"), out.stderr.decode()[-1500:]
