@@ -414,6 +414,14 @@ def main():
     if use_dist:
         dist.barrier()                      # rank 0's extra sections are done before any rank tears down
         dist.destroy_process_group()
+    # flush what native libraries still hold in C stdio (RCCL's banner) so that the JSON is the last thing
+    # written even when the caller merges stdout and stderr
+    sys.stdout.flush()
+    sys.stderr.flush()
+    try:
+        C.CDLL(None).fflush(None)
+    except Exception:
+        pass
     if rank == 0:
         os.write(json_fd, (line + "\n").encode())
     os.close(json_fd)
