@@ -528,8 +528,11 @@ int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float
 // NF_KERNEL=valu forces the scalar-weight VALU kernel (A/B testing); default = matrix core
 bool use_matrix_core()
 {
-    const char *e = getenv("NF_KERNEL");
-    return !(e && strcmp(e, "valu") == 0);
+    static const bool mc = [] {
+        const char *e = getenv("NF_KERNEL");
+        return !(e && strcmp(e, "valu") == 0);
+    }();   // read once: this sits on the per-call path
+    return mc;
 }
 
 struct DeviceGuard {
