@@ -4,24 +4,30 @@
     python bench.py --gpus N --steps K --warmup W
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is one pass of the fused likelihood-direction kernel (per-patch NLL +
-log|det J| + batch sums) over ONE batch of 1024 synthetic 32x32x4 raw patches per
-GPU — BASELINE.json configs[1], the configuration the metric is quoted on — with
-the shipped Noise Flow checkpoint.  Inputs are resident in HBM before the timed
-region; patches are a pure function of (seed, global patch index), so any
-sharding evaluates the same data.  For N > 1 the patch range is sharded across
-ranks (weak scaling: 1024 patches per GPU per step) and the evaluation ends with
-ONE RCCL all-reduce of (sum nll, sum sd_z, count) inside the timed region.
+N = 1 (the headline, BASELINE configs[1] — the configuration the metric is quoted on): a "step" is one
+pass of the fused likelihood-direction kernel (per-patch NLL written to HBM + log|det J| + batch sums)
+over ONE batch of 1024 synthetic 32x32x4 raw patches with the shipped Noise Flow checkpoint, inputs
+resident in HBM.  With --steps < 200 the K-step block is timed R = 11 times back to back and the MEDIAN
+block is reported (a 20-step block is ~1.1 ms of device time; one block is a noisy sample).
 
+N > 1 (BASELINE configs[3]): a "step" is one COMPLETE evaluation of the 2^20-patch range, sharded in
+contiguous blocks of the patch index over the ranks (strong scaling: the total work is fixed).  Every
+rank keeps its block resident in HBM (34 GB / N), evaluates it with the persistent fused kernel and the
+evaluation ends with ONE RCCL all-reduce of (sum nll, sum sd_z, count) — 24 bytes, the only collective;
+no barrier and no read-back inside the timed region.  NF_BENCH_FORCE_DIST=1 runs this leg on one rank.
+
+Patches are a pure function of (seed, global patch index), so any sharding evaluates the same data.
 Rank 0 prints ONE JSON line.  Besides the contract keys it carries
-  roofline      the dominant kernel against the dense fp32 matrix/vector peak (the binding
-                roofline: algorithmic flops / HIP-event time), with the HBM view nested
+  roofline      the dominant kernel against the dense fp32 matrix/vector peak (the binding roofline:
+                algorithmic flops / wall-clock step time), with the HBM view nested
   cpu_baseline  CPU ports of the reference arithmetic (oracle/): fused plain-C/OpenMP (the
                 reported value) and the op-per-layer torch-CPU restatement of the TF1 graph,
                 timed on this box's host cores on bounded samples (N = 1 only)
   sampling      the sampling direction at BASELINE configs[2] (batch 4096)
   nll_check     GPU mean NLL vs the fp64 CPU oracle on a 64-patch subset
   fp16_cnn_64x64  BASELINE configs[4] shape (64x64x4, fp16 coupling CNN / fp32 log-det)
+  wide_cnn      the paper-scale coupling CNN (width 32 / 16) on the f32 matrix cores, own roofline
+  sharded_1m    configs[3] on this one GPU (2^20 resident patches, no process group)
   training      one training step (fwd batch-BN + bwd + EMA + Adam) at the reference's minibatch of 138
   two_streams   the headline workload with consecutive steps alternating between two HIP streams
 """
@@ -29,6 +35,7 @@ from __future__ import annotations
 
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
 import sys
@@ -72,11 +79,15 @@ def _usable_cores(threads: int) -> int:
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # defaults: 0.13 s of timed work after 13 ms of warm-up — a 20-step warm-up (1.3 ms) ends before the
+    # defaults: 0.11 s of timed work after 13 ms of warm-up — a 20-step warm-up (1.3 ms) ends before the
     # GPU has left its idle clocks and reads ~5 % slow (measured: 62.7 us/step vs 59.5 us steady state)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--batch", type=int, default=1024, help="patches per GPU per step (configs[1]: 1024)")
+    ap.add_argument("--batch", type=int, default=1024, help="N = 1: patches per step (configs[1]: 1024)")
+    ap.add_argument("--total-patches", type=int, default=1 << 20,
+                    help="N > 1: size of the patch range one step evaluates, sharded over the ranks (configs[3]: 2^20)")
+    ap.add_argument("--shard-chunk", type=int, default=0,
+                    help="N > 1: patches per kernel launch inside a rank's block (0 = the whole block in one launch)")
     ap.add_argument("--sample-batch", type=int, default=4096, help="sampling-direction batch (configs[2]: 4096)")
     ap.add_argument("--pool", type=int, default=16, help="distinct resident batches cycled through")
     ap.add_argument("--ramp-ms", type=float, default=250.0,
@@ -84,8 +95,33 @@ def parse_args():
                          "a short W does not leave the GPU at its idle clocks (0 disables)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="headline only (profiling runs)")
     ap.add_argument("--seed", type=int, default=0)
     return ap.parse_args()
+
+
+def _kernel_source_sha() -> str:
+    """Content hash of the kernel sources a PMC traffic measurement belongs to (the GPU box has no .git)."""
+    h = hashlib.sha256()
+    for name in ("nf_kernels.hip", "nf_device.h"):
+        with open(os.path.join(ROOT, "noise_flow_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def _traffic():
+    """HBM bytes per launch from the committed PMC passes (profiles/traffic.json) — only when that file was
+    measured on THIS kernel source; otherwise null (a replayed number must not outlive its kernel)."""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(tpath) as f:
+            t = json.load(f)
+        if t.get("kernel_source_sha") != _kernel_source_sha():
+            return None, "profiles/traffic.json was measured on a different nf_kernels.hip (sha %s): not reported" % t.get(
+                "kernel_source_sha")
+        return t.get("hbm_bytes_per_launch"), "profiles/traffic.json (PMC FETCH_SIZE/WRITE_SIZE passes on this kernel source)"
+    except Exception as e:
+        return None, "no traffic record: %s" % e
 
 
 def main():
@@ -105,7 +141,6 @@ def main():
                      % (args.gpus, args.gpus))
         args.gpus = world
 
-    import numpy as np
     import torch
     import torch.distributed as dist
 
@@ -113,304 +148,21 @@ def main():
         sys.exit("bench.py needs an MI355X: no GPU visible and there is no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    # NF_BENCH_FORCE_DIST=1 runs the RCCL code path on a single rank too (validation aid)
+    # NF_BENCH_FORCE_DIST=1 runs the N > 1 leg (configs[3] + RCCL) on a single rank too (validation aid)
     use_dist = world > 1 or bool(os.environ.get("NF_BENCH_FORCE_DIST"))
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
 
-    from noise_flow_amd import NoiseFlow, default_hps, _lib
+    from noise_flow_amd import NoiseFlow, default_hps
     from noise_flow_amd.ckpt import load_checkpoint
-    from noise_flow_amd.patches import synth_patches
-    from noise_flow_amd.dist import allreduce_sums
 
     variables = load_checkpoint(os.path.join(ROOT, "models", "NoiseFlow", "ckpt", "model.ckpt.best"))
     model = NoiseFlow([32, 32, 4], False, default_hps(), variables=variables, device=local_rank)
-    lib = _lib.load()
-    B, K, Wm = args.batch, args.steps, args.warmup
-    cond = _lib.nf_cond(100.0, 2.0, 0.000479, 0.000002)      # ISO 100, S6 (train_noise_flow.py:143-147)
-
-    # ---- resident synthetic data: batch j of rank r holds patches [(j*world + r)*B, +B) ----
-    pool = max(1, min(args.pool, K + Wm))
-    batches = [synth_patches(args.seed, (j * world + rank) * B, B, device=local_rank) for j in range(pool)]
-    sums = torch.zeros(3, dtype=torch.float64, device=dev)
-    # per-workgroup partial sums go to the C ABI's slotted accumulator (NF_SUMS_WIDE: 64 slots on separate
-    # cache lines); ONE nf_sums_reduce after the last step folds it into (sum nll, sum sd, count)
-    wide = torch.zeros(_lib.NF_SUMS_SLOTS * _lib.NF_SUMS_STRIDE, dtype=torch.float64, device=dev)
-    stream = torch.cuda.current_stream(dev)
-    sptr = int(stream.cuda_stream)
-    hptr = model._flow.ptr
-
-    def nll_step(i, flags=_lib.NF_ACCUMULATE | _lib.NF_SUMS_WIDE):
-        x, y = batches[i % pool]
-        rc = lib.nf_nll(hptr, x.data_ptr(), y.data_ptr(), B, C.byref(cond), None, None, None, None,
-                        wide.data_ptr(), flags, sptr)
-        if rc != 0:
-            _lib.check(rc)
-
-    def barrier():
-        if use_dist:
-            dist.barrier()
-
-    if args.ramp_ms > 0:                    # untimed: leave the idle clocks (reported as "clock_ramp_ms")
-        t_r = time.perf_counter()
-        while (time.perf_counter() - t_r) * 1e3 < args.ramp_ms:
-            for i in range(64):
-                nll_step(i)
-            torch.cuda.synchronize(dev)
-    for i in range(Wm):
-        nll_step(i)
-    if use_dist:
-        allreduce_sums(sums.clone())        # warm the RCCL communicator outside the timed region
-    sums.zero_()
-    wide.zero_()
-    torch.cuda.synchronize(dev)
-    barrier()
-    torch.cuda.synchronize(dev)
-
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    for i in range(K):
-        nll_step(i)
-    ev1.record(stream)
-    _lib.check(lib.nf_sums_reduce(wide.data_ptr(), sums.data_ptr(), 0, sptr))   # inside the timed wall clock
-    if use_dist:
-        allreduce_sums(sums)                # ONE RCCL all-reduce of 3 fp64 scalars finishes the evaluation
-    torch.cuda.synchronize(dev)
-    barrier()
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / K   # average launch duration over the timed region (HIP events)
-
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if use_dist:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = float(tmax.item())
-    s = sums.cpu().numpy()
-    total_patches = world * B * K
-    assert int(round(s[2])) == total_patches, (s, total_patches)
-    value = total_patches / elapsed
-
-    # ---- the same K steps alternating between TWO streams (rank 0): a 1024-patch launch fills the GPU exactly
-    # once, so back-to-back launches on one stream each pay their own ramp-up and drain; on two streams the next
-    # launch takes the workgroup slots the previous one frees (what noise_flow_amd.dist.flow_eval_chunk does) ----
-    two_streams = None
-    if rank == 0:
-        try:
-            side = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
-            wide2 = torch.zeros_like(wide)
-            torch.cuda.synchronize(dev)
-
-            def nll_step2(i):
-                x, y = batches[i % pool]
-                rc = lib.nf_nll(hptr, x.data_ptr(), y.data_ptr(), B, C.byref(cond), None, None, None, None,
-                                wide2.data_ptr(), _lib.NF_ACCUMULATE | _lib.NF_SUMS_WIDE, int(side[i & 1].cuda_stream))
-                if rc != 0:
-                    _lib.check(rc)
-            for i in range(max(Wm, 50)):
-                nll_step2(i)
-            torch.cuda.synchronize(dev)
-            wide2.zero_()
-            torch.cuda.synchronize(dev)
-            t2 = time.perf_counter()
-            for i in range(K):
-                nll_step2(i)
-            torch.cuda.synchronize(dev)
-            el2 = time.perf_counter() - t2
-            s2 = torch.zeros(3, dtype=torch.float64, device=dev)
-            _lib.check(lib.nf_sums_reduce(wide2.data_ptr(), s2.data_ptr(), 0, sptr))
-            s2 = s2.cpu().numpy()
-            assert int(round(s2[2])) == B * K
-            two_streams = {"value": B * K / el2, "unit": "patches/s", "ms_per_step": el2 / K * 1e3, "steps": K, "streams": 2,
-                           "mean_nll": float(s2[0] / s2[2]),
-                           "note": "same workload and kernel, consecutive steps alternate between two HIP streams so that "
-                                   "launches overlap their ramp-up / drain; the headline value stays single-stream so that "
-                                   "roofline.kernel_ms agrees with rocprof's per-kernel duration"}
-        except Exception as e:
-            two_streams = {"error": str(e)}
-
-    # ---- sampling direction (configs[2]): B = 4096, fixed cam / ISO, in-kernel Philox eps ----
-    sampling = None
-    nll_check = None
-    cpu_baseline = None
-    if rank == 0:
-        SB = args.sample_batch
-        _, ys = synth_patches(args.seed, 1 << 40, SB, device=local_rank, want_x=False)
-        xs = torch.empty_like(ys)
-        ks = max(10, min(K, 100))
-
-        def sample_step(i):
-            rc = lib.nf_sample(hptr, ys.data_ptr(), None, args.seed, i * SB, 1.0, SB, C.byref(cond), xs.data_ptr(), sptr)
-            if rc != 0:
-                _lib.check(rc)
-
-        for i in range(5):
-            sample_step(i)
-        torch.cuda.synchronize(dev)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ts = time.perf_counter()
-        e0.record(stream)
-        for i in range(ks):
-            sample_step(i)
-        e1.record(stream)
-        torch.cuda.synchronize(dev)
-        ts = time.perf_counter() - ts
-        sampling = {"value": SB * ks / ts, "unit": "patches/s", "batch": SB, "steps": ks,
-                    "ms_per_step": 1e3 * ts / ks, "kernel_ms": e0.elapsed_time(e1) / ks, "temp": 1.0,
-                    "eps": "in-kernel Philox4x32-10", "workload": "configs[2]: inverse sampling, clean patch + fixed cam/ISO"}
-
-    # ---- BASELINE configs[4] shape: 64x64x4 patches, fp16 coupling CNN / fp32 log-det (rank 0) ----
-    fp16_cnn = None
-    if rank == 0:
-        try:
-            m16 = NoiseFlow([64, 64, 4], False, default_hps(), variables=variables, device=local_rank, cnn_dtype="fp16")
-            B16 = 1024
-            x16, y16 = synth_patches(args.seed, 1 << 41, B16, 64, 64, device=local_rank)
-            s16 = torch.zeros(_lib.NF_SUMS_SLOTS * _lib.NF_SUMS_STRIDE, dtype=torch.float64, device=dev)
-            k16 = max(10, min(K, 50))
-
-            def step16():
-                rc = lib.nf_nll(m16._flow.ptr, x16.data_ptr(), y16.data_ptr(), B16, C.byref(cond), None, None, None,
-                                None, s16.data_ptr(), _lib.NF_ACCUMULATE | _lib.NF_SUMS_WIDE, sptr)
-                if rc != 0:
-                    _lib.check(rc)
-            for _ in range(5):
-                step16()
-            torch.cuda.synchronize(dev)
-            f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            f0.record(stream)
-            for _ in range(k16):
-                step16()
-            f1.record(stream)
-            torch.cuda.synchronize(dev)
-            ms16 = f0.elapsed_time(f1) / k16
-            bytes16 = 2 * 64 * 64 * 4 * 4 * B16
-            fp16_cnn = {"workload": "configs[4] shape: forward NLL, 64x64x4 patches, fp16 coupling CNN "
-                                    "(v_mfma_f32_4x4x4_16b_f16, fp32 accumulate + fp32 log-det), fp32 I/O, 1 GPU",
-                        "batch": B16, "steps": k16, "kernel_ms": ms16, "value": B16 / (ms16 * 1e-3), "unit": "patches/s",
-                        "pixels_per_s": B16 * 4096 / (ms16 * 1e-3),
-                        "hbm": {"achieved": bytes16 / (ms16 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": bytes16 / (ms16 * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                "algorithmic_bytes_per_launch": bytes16}}
-            del m16, x16, y16
-        except Exception as e:   # the headline metric must not depend on the optional mode
-            fp16_cnn = {"error": str(e)}
-
-    # ---- training step at the reference's minibatch of 138 patches (rank 0) ----
-    training = None
-    if rank == 0:
-        try:
-            from noise_flow_amd.train import Trainer
-            TB_ = 138                                            # job_noise_flow.sh: --n_batch_train 138
-            trn = Trainer([32, 32, 4], default_hps(), variables=variables, device=local_rank, max_batch=TB_)
-            xt_, yt_ = synth_patches(args.seed, 1 << 42, TB_, device=local_rank)
-            kt = max(10, min(K, 50))
-            for _ in range(5):
-                trn.step(xt_, yt_, [0.0], [0.0], [100.0], [2.0], lr=1e-4, sync=False)
-            torch.cuda.synchronize(dev)
-            g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            g0.record(stream)
-            for _ in range(kt):
-                trn.step(xt_, yt_, [0.0], [0.0], [100.0], [2.0], lr=1e-4, sync=False)
-            g1.record(stream)
-            torch.cuda.synchronize(dev)
-            mst = g0.elapsed_time(g1) / kt
-            training = {"workload": "one training step = forward with batch-statistics BN + backward + BN EMA + Adam "
-                                    "(train_noise_flow.py:64-66,187-198), shipped architecture, 138 patches 32x32x4",
-                        "batch": TB_, "steps": kt, "ms_per_step": mst, "value": TB_ / (mst * 1e-3), "unit": "patches/s",
-                        "bound": "kernel latency: ~120 stream-ordered launches per step (profiles/r01_train_kernel_stats.csv)"}
-            trn.close()
-            del trn, xt_, yt_
-        except Exception as e:   # the headline metric must not depend on the optional section
-            training = {"error": str(e)}
-
-    # ---- parity + CPU baseline: rank 0, N = 1 only (oracle/ is the checker, never the product) ----
-    if rank == 0 and world == 1:
-        from oracle.nf_oracle import NoiseFlowOracle
-        x0, y0 = batches[0]
-        nb = 64
-        nll_gpu, _ = model._loss(x0[:nb], y0[:nb], [0.0], [0.0], [100.0], [2.0])
-        ref = NoiseFlowOracle(ARCH_LABEL, variables).nll(x0[:nb].cpu().numpy(), y0[:nb].cpu().numpy(), 100.0, 2.0)[0]
-        g = nll_gpu.double().cpu().numpy()
-        nll_check = {"patches": nb, "gpu_mean_nll": float(g.mean()), "cpu_fp64_mean_nll": float(ref.mean()),
-                     "rel_err_mean": float(abs(g.mean() - ref.mean()) / abs(ref.mean())),
-                     "max_rel_err_per_patch": float(np.max(np.abs(g - ref) / np.abs(ref))), "tolerance": 1e-5}
-        if not args.no_cpu_baseline:
-            xc, yc = x0.cpu().numpy(), y0.cpu().numpy()
-            # (1) fused plain-C / OpenMP port of the reference arithmetic (oracle/nf_oracle.c): what a good
-            #     CPU implementation does on all host cores -> the reported cpu_baseline
-            from oracle.nf_oracle_c import COracle
-            cc = COracle(ARCH_LABEL, variables)
-            host_cores = _usable_cores(os.cpu_count() or 1)           # affinity mask and cgroup CPU quota
-            cc.set_threads(host_cores)
-            cc.nll(xc[:256], yc[:256], 100.0, 2.0)                      # warm-up (thread pool, page faults)
-            n_batches, tc, budget = 0, 0.0, 0.6 * args.cpu_seconds
-            t_start = time.perf_counter()
-            while tc < budget and n_batches < 4096:                     # time-bounded sample
-                cc.nll(xc, yc, 100.0, 2.0)
-                n_batches += 1
-                tc = time.perf_counter() - t_start
-            cpu_baseline = {"value": n_batches * B / tc, "unit": "patches/s", "cores": _usable_cores(cc.threads()),
-                            "kind": "port",
-                            "sample": "forward NLL of %d batches x %d patches (same workload), fused plain-C fp32 port "
-                                      "of the reference arithmetic with OpenMP over patches (%d threads; TF1 "
-                                      "unavailable), %.1f s" % (n_batches, B, cc.threads(), tc)}
-            # (2) op-per-layer torch-CPU port: how the TF1 graph actually executes (every op materialised)
-            from oracle.nf_cpu_torch import TorchCpuFlow
-            cpu = TorchCpuFlow(ARCH_LABEL, variables)
-            torch.set_num_threads(host_cores)
-            cpu.nll(xc[:128], yc[:128], 100.0, 2.0)
-            n_batches, tc, budget = 0, 0.0, 0.4 * args.cpu_seconds
-            t_start = time.perf_counter()
-            while tc < budget and n_batches < 64:
-                cpu.nll(xc, yc, 100.0, 2.0)
-                n_batches += 1
-                tc = time.perf_counter() - t_start
-            cpu_baseline["op_per_layer_torch"] = {
-                "value": n_batches * B / tc, "unit": "patches/s", "cores": _usable_cores(int(torch.get_num_threads())),
-                "kind": "port",
-                "sample": "forward NLL of %d batches x %d patches, torch-CPU fp32 op-per-layer restatement of the "
-                          "TF1 graph, %.1f s" % (n_batches, B, tc)}
-
-    if rank == 0:
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                with open(tpath) as f:
-                    traffic = json.load(f).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        gbs = ALGO_BYTES_PER_PATCH * B / (kernel_ms * 1e-3) / 1e9
-        tfl = ALGO_FLOP_PER_PATCH * B / (kernel_ms * 1e-3) / 1e12
-        out = {
-            "metric": "patches/sec (32x32x4) fwd-NLL and inverse-sample; mean NLL vs CPU ref",
-            "value": value, "unit": "patches/s", "n_gpus": world, "steps": K, "warmup": Wm,
-            "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: full NoiseFlow arch (%s) forward NLL, batch %d synthetic 32x32x4 "
-                                   "patches per GPU, shipped checkpoint, ISO 100 / cam S6" % (ARCH_LABEL, B),
-                       "batch_per_gpu": B, "global_batch": B * world, "patch": "32x32x4",
-                       "parallelism": "dp%d: patch-index sharding, one RCCL all-reduce of 3 fp64 scalars" % world},
-            "mean_nll": float(s[0] / s[2]), "sd_z": float(s[1] / s[2]),
-            # The fused kernel is compute-bound (~156 flop/B): its FMAs are v_mfma_f32_4x4x1 on the fp32
-            # matrix/vector datapath (dense fp32 peak 157.3 TFLOP/s) -> that is the binding roofline.
-            # The HBM view the task also asks for is nested under "hbm"; "traffic" = HBM bytes per
-            # launch from the FETCH_SIZE / WRITE_SIZE PMC passes (profiles/traffic.json).
-            "roofline": {"bound": "mfma", "achieved": tfl, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": tfl / VALU_PEAK_TFLOPS, "traffic": traffic,
-                         "dtype": "f32 (v_mfma_f32_4x4x1_16b_f32, exact fp32; shares the fp32 datapath with VALU)",
-                         "kernel": "nf_flow_kernel<4,256,4,false,true,true,0>", "kernel_ms": kernel_ms,
-                         "algorithmic_flop_per_launch": ALGO_FLOP_PER_PATCH * B,
-                         "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PATCH * B,
-                                 "note": "structurally capped near 13 %: 32 KiB and 5.1 MFLOP per patch"}},
-            "cpu_baseline": cpu_baseline, "sampling": sampling, "nll_check": nll_check, "fp16_cnn_64x64": fp16_cnn,
-            "training": training, "two_streams": two_streams, "clock_ramp_ms": args.ramp_ms,
-        }
-        line = json.dumps(out)
+    ctx = dict(args=args, rank=rank, local_rank=local_rank, world=world, dev=dev, model=model, variables=variables)
+    out = sharded_leg(ctx) if use_dist else single_gpu_leg(ctx)
+    line = json.dumps(out) if rank == 0 else None
     if use_dist:
         dist.barrier()                      # rank 0's extra sections are done before any rank tears down
         dist.destroy_process_group()
@@ -425,6 +177,478 @@ def main():
     if rank == 0:
         os.write(json_fd, (line + "\n").encode())
     os.close(json_fd)
+
+
+def _clock_ramp(step, ramp_ms, dev):
+    """Untimed: leave the idle clocks (reported as "clock_ramp_ms")."""
+    import torch
+    if ramp_ms <= 0:
+        return
+    t_r = time.perf_counter()
+    while (time.perf_counter() - t_r) * 1e3 < ramp_ms:
+        for i in range(64):
+            step(i)
+        torch.cuda.synchronize(dev)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# N > 1: BASELINE configs[3] — 2^20 patches sharded by patch index, ONE all-reduce per evaluation
+# ---------------------------------------------------------------------------------------------------------
+def sharded_leg(ctx):
+    import torch
+    import torch.distributed as dist
+    from noise_flow_amd.dist import ResidentShard, timed_sharded_evaluations
+    args, rank, world, dev, model = ctx["args"], ctx["rank"], ctx["world"], ctx["dev"], ctx["model"]
+    K, Wm, n_total = args.steps, args.warmup, args.total_patches
+    shard = ResidentShard(model, args.seed, n_total, rank, world)
+    n_local = shard.stop - shard.start
+    chunk = args.shard_chunk if args.shard_chunk > 0 else max(1, n_local)
+    eval_chunk = shard.eval_chunk()
+    stream = torch.cuda.current_stream(dev)
+    new_sums = lambda: torch.zeros(3, dtype=torch.float64, device=dev)   # noqa: E731
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+
+    def on_step(i, what):            # the rank's own device work of evaluation i, before the collective
+        ev[i][0 if what == "begin" else 1].record(stream)
+
+    if args.ramp_ms > 0:             # untimed clock ramp on a slice of the resident block
+        nb = min(1024, n_local)
+        scratch = model.new_sums()
+        _clock_ramp(lambda i: model.nll_sums(shard.x[:nb], shard.y[:nb], [0.0], [0.0], [100.0], [2.0], scratch),
+                    args.ramp_ms, dev)
+    res = timed_sharded_evaluations(eval_chunk, n_total, chunk, rank, world, K, Wm, new_sums,
+                                    sync=lambda: torch.cuda.synchronize(dev), on_step=on_step)
+    elapsed_local = res["elapsed"]
+    kernel_ms_local = sum(a.elapsed_time(b) for a, b in ev) / K
+
+    # the all-reduce on its own (untimed diagnostic): 24-byte message, pure latency
+    probe = torch.zeros(3, dtype=torch.float64, device=dev)
+    for _ in range(5):
+        dist.all_reduce(probe)
+    torch.cuda.synchronize(dev)
+    t_a = time.perf_counter()
+    n_probe = 50
+    for _ in range(n_probe):
+        dist.all_reduce(probe)
+    torch.cuda.synchronize(dev)
+    allreduce_us = (time.perf_counter() - t_a) / n_probe * 1e6
+
+    stats = torch.tensor([elapsed_local, kernel_ms_local, allreduce_us], dtype=torch.float64, device=dev)
+    gathered = [torch.zeros_like(stats) for _ in range(world)]
+    dist.all_gather(gathered, stats)
+    per_rank = [g.cpu().tolist() for g in gathered]
+    elapsed = max(p[0] for p in per_rank)
+    if rank != 0:
+        return None
+    means = [r[0] for r in res["results"]]
+    value = n_total * K / elapsed
+    ms_step = 1e3 * elapsed / K
+    kernel_ms = max(p[1] for p in per_rank)
+    gbs = ALGO_BYTES_PER_PATCH * (n_total / world) / (kernel_ms * 1e-3) / 1e9       # per GPU
+    tfl = ALGO_FLOP_PER_PATCH * (n_total / world) / (kernel_ms * 1e-3) / 1e12
+    return {
+        "metric": "patches/sec (32x32x4) fwd-NLL and inverse-sample; mean NLL vs CPU ref",
+        "value": value, "unit": "patches/s", "n_gpus": world, "steps": K, "warmup": Wm,
+        "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[3]: forward NLL over %d synthetic 32x32x4 patches (full arch %s, shipped checkpoint, "
+                               "ISO 100 / cam S6), patch range sharded in contiguous blocks over %d GPU(s); one step = one "
+                               "complete evaluation ending in ONE all-reduce of (sum nll, sum sd_z, count)"
+                               % (n_total, ARCH_LABEL, world),
+                   "total_patches": n_total, "global_batch": n_total, "patches_per_gpu": n_total // world, "patch": "32x32x4",
+                   "launch_chunk": chunk, "inputs": "resident in HBM (%.1f GB per GPU)" % (shard.nbytes / 1e9),
+                   "parallelism": "dp%d: patch-index sharding, %s" % (
+                       world, "one RCCL all-reduce of 3 fp64 scalars per evaluation" if world > 1 else
+                       "single rank (NF_BENCH_FORCE_DIST: the RCCL call is issued on a 1-rank group)")},
+        "mean_nll": means[-1], "sd_z": res["results"][-1][1],
+        "mean_nll_identical_across_steps": bool(max(means) - min(means) <= 1e-9 * abs(means[0])),
+        "per_rank": {"elapsed_s": [p[0] for p in per_rank], "kernel_ms_per_step": [p[1] for p in per_rank],
+                     "allreduce_us": [p[2] for p in per_rank]},
+        "collective": {"allreduce_us": max(p[2] for p in per_rank), "per_step": 1,
+                       "share_of_step": max(p[2] for p in per_rank) * 1e-3 / ms_step,
+                       "non_kernel_share_of_step": max(0.0, 1.0 - kernel_ms / ms_step),
+                       "note": "allreduce_us = one all-reduce + device sync, timed alone after the run; "
+                               "non_kernel_share = 1 - (slowest rank's kernel time / step time)"},
+        "roofline": {"bound": "mfma", "achieved": tfl, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": tfl / VALU_PEAK_TFLOPS, "traffic": None, "scope": "per GPU, slowest rank's kernel time",
+                     "kernel": "nf_flow_kernel<4,256,4,false,true,true,0>", "kernel_ms": kernel_ms,
+                     "algorithmic_flop_per_launch": ALGO_FLOP_PER_PATCH * n_total / world,
+                     "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                             "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PATCH * n_total / world}},
+        "cpu_baseline": None, "clock_ramp_ms": args.ramp_ms,
+    }
+
+
+# ---------------------------------------------------------------------------------------------------------
+# N = 1: BASELINE configs[1] headline + the other single-GPU sections
+# ---------------------------------------------------------------------------------------------------------
+def single_gpu_leg(ctx):
+    import numpy as np
+    import torch
+    from noise_flow_amd import NoiseFlow, default_hps, _lib
+    from noise_flow_amd.patches import synth_patches
+    args, local_rank, dev, model, variables = ctx["args"], ctx["local_rank"], ctx["dev"], ctx["model"], ctx["variables"]
+    lib = _lib.load()
+    B, K, Wm = args.batch, args.steps, args.warmup
+    R = 1 if K >= 200 else 11               # short blocks are repeated and the median block reported
+    cond = _lib.nf_cond(100.0, 2.0, 0.000479, 0.000002)      # ISO 100, S6 (train_noise_flow.py:143-147)
+
+    # ---- resident synthetic data: batch j holds patches [j*B, +B) ----
+    pool = max(1, min(args.pool, K * R + Wm))
+    batches = [synth_patches(args.seed, j * B, B, device=local_rank) for j in range(pool)]
+    nll_buf = torch.empty(B, dtype=torch.float32, device=dev)      # the metric includes the per-patch NLL (SURVEY §8d)
+    sums = torch.zeros(3, dtype=torch.float64, device=dev)
+    # per-workgroup partial sums go to the C ABI's slotted accumulator (NF_SUMS_WIDE: 64 slots on separate
+    # cache lines); ONE nf_sums_reduce after the last step folds it into (sum nll, sum sd, count)
+    wide = torch.zeros(_lib.NF_SUMS_SLOTS * _lib.NF_SUMS_STRIDE, dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    sptr = int(stream.cuda_stream)
+    hptr = model._flow.ptr
+
+    def nll_step(i, flags=_lib.NF_ACCUMULATE | _lib.NF_SUMS_WIDE):
+        x, y = batches[i % pool]
+        rc = lib.nf_nll(hptr, x.data_ptr(), y.data_ptr(), B, C.byref(cond), nll_buf.data_ptr(), None, None, None,
+                        wide.data_ptr(), flags, sptr)
+        if rc != 0:
+            _lib.check(rc)
+
+    _clock_ramp(nll_step, args.ramp_ms, dev)
+    for i in range(Wm):
+        nll_step(i)
+    sums.zero_()
+    wide.zero_()
+    torch.cuda.synchronize(dev)
+
+    blocks, kblocks = [], []
+    step_no = 0
+    for r in range(R):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        for _ in range(K):
+            nll_step(step_no)
+            step_no += 1
+        ev1.record(stream)
+        torch.cuda.synchronize(dev)
+        blocks.append(time.perf_counter() - t0)
+        kblocks.append(ev0.elapsed_time(ev1) / K)
+    _lib.check(lib.nf_sums_reduce(wide.data_ptr(), sums.data_ptr(), 0, sptr))
+    torch.cuda.synchronize(dev)
+    elapsed = float(np.median(blocks))
+    kernel_ms = float(np.median(kblocks))   # average launch duration over the (median) timed block (HIP events)
+    s = sums.cpu().numpy()
+    assert int(round(s[2])) == B * K * R, (s, B * K * R)
+    value = B * K / elapsed
+    ms_step = 1e3 * elapsed / K
+
+    extras = {}
+    if not args.no_extras:
+        for name, fn in (("two_streams", _two_streams), ("sampling", _sampling), ("fp16_cnn_64x64", _fp16_cnn),
+                         ("wide_cnn", _wide_cnn), ("sharded_1m", _sharded_1m), ("training", _training)):
+            try:
+                extras[name] = fn(ctx, batches, cond, wide)
+            except Exception as e:           # the headline metric must not depend on an optional section
+                extras[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+
+    # ---- parity + CPU baseline (oracle/ is the checker, never the product) ----
+    from oracle.nf_oracle import NoiseFlowOracle
+    x0, y0 = batches[0]
+    nb = 64
+    nll_gpu, _ = model._loss(x0[:nb], y0[:nb], [0.0], [0.0], [100.0], [2.0])
+    ref = NoiseFlowOracle(ARCH_LABEL, variables).nll(x0[:nb].cpu().numpy(), y0[:nb].cpu().numpy(), 100.0, 2.0)[0]
+    g = nll_gpu.double().cpu().numpy()
+    nll_check = {"patches": nb, "gpu_mean_nll": float(g.mean()), "cpu_fp64_mean_nll": float(ref.mean()),
+                 "rel_err_mean": float(abs(g.mean() - ref.mean()) / abs(ref.mean())),
+                 "max_rel_err_per_patch": float(np.max(np.abs(g - ref) / np.abs(ref))), "tolerance": 1e-5}
+    cpu_baseline = None
+    if not args.no_cpu_baseline:
+        cpu_baseline = _cpu_baseline(args, variables, x0.cpu().numpy(), y0.cpu().numpy(), B)
+
+    traffic, traffic_src = _traffic()
+    # roofline from the WALL-CLOCK step time (what the driver's clock can confirm); the HIP-event figure is nested
+    gbs = ALGO_BYTES_PER_PATCH * B / (ms_step * 1e-3) / 1e9
+    tfl = ALGO_FLOP_PER_PATCH * B / (ms_step * 1e-3) / 1e12
+    out = {
+        "metric": "patches/sec (32x32x4) fwd-NLL and inverse-sample; mean NLL vs CPU ref",
+        "value": value, "unit": "patches/s", "n_gpus": 1, "steps": K, "warmup": Wm,
+        "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[1]: full NoiseFlow arch (%s) forward NLL (per-patch NLL + batch sums), batch %d "
+                               "synthetic 32x32x4 patches, shipped checkpoint, ISO 100 / cam S6" % (ARCH_LABEL, B),
+                   "batch_per_gpu": B, "global_batch": B, "patch": "32x32x4",
+                   "parallelism": "single GPU, no collective (N > 1 runs configs[3]: patch-index sharding + one all-reduce)"},
+        "timing": {"repetitions": R, "statistic": "median of R back-to-back K-step blocks" if R > 1 else "one K-step block",
+                   "block_ms": [1e3 * b for b in blocks], "block_ms_min": 1e3 * min(blocks), "block_ms_max": 1e3 * max(blocks)},
+        "mean_nll": float(s[0] / s[2]), "sd_z": float(s[1] / s[2]),
+        # The fused kernel is compute-bound (~156 flop/B): its FMAs are v_mfma_f32_4x4x1 on the fp32
+        # matrix/vector datapath (dense fp32 peak 157.3 TFLOP/s) -> that is the binding roofline.
+        # The HBM view the task also asks for is nested under "hbm"; "traffic" = HBM bytes per
+        # launch from the FETCH_SIZE / WRITE_SIZE PMC passes (profiles/traffic.json).
+        "roofline": {"bound": "mfma", "achieved": tfl, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": tfl / VALU_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                     "time_base": "wall-clock ms_per_step",
+                     "dtype": "f32 (v_mfma_f32_4x4x1_16b_f32, exact fp32; shares the fp32 datapath with VALU)",
+                     "kernel": "nf_flow_kernel<4,256,4,false,true,true,0>", "kernel_ms": kernel_ms,
+                     "frac_from_kernel_ms": ALGO_FLOP_PER_PATCH * B / (kernel_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS,
+                     "algorithmic_flop_per_launch": ALGO_FLOP_PER_PATCH * B,
+                     "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                             "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PATCH * B,
+                             "note": "structurally capped near 13 %: 32 KiB and 5.1 MFLOP per patch"}},
+        "cpu_baseline": cpu_baseline, "nll_check": nll_check, "clock_ramp_ms": args.ramp_ms,
+    }
+    out.update(extras)
+    return out
+
+
+def _two_streams(ctx, batches, cond, wide):
+    """The same K steps alternating between TWO streams: a 1024-patch launch fills the GPU exactly once, so
+    back-to-back launches on one stream each pay their own ramp-up and drain; on two streams the next launch takes
+    the workgroup slots the previous one frees (what noise_flow_amd.dist.flow_eval_chunk does)."""
+    import torch
+    from noise_flow_amd import _lib
+    args, dev, model = ctx["args"], ctx["dev"], ctx["model"]
+    lib, B, K, pool = _lib.load(), args.batch, args.steps, len(batches)
+    side = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    wide2 = torch.zeros_like(wide)
+    nll2 = [torch.empty(B, dtype=torch.float32, device=dev) for _ in side]
+    torch.cuda.synchronize(dev)
+
+    def step(i):
+        x, y = batches[i % pool]
+        rc = lib.nf_nll(model._flow.ptr, x.data_ptr(), y.data_ptr(), B, C.byref(cond), nll2[i & 1].data_ptr(), None, None, None,
+                        wide2.data_ptr(), _lib.NF_ACCUMULATE | _lib.NF_SUMS_WIDE, int(side[i & 1].cuda_stream))
+        if rc != 0:
+            _lib.check(rc)
+    for i in range(max(args.warmup, 50)):
+        step(i)
+    torch.cuda.synchronize(dev)
+    wide2.zero_()
+    torch.cuda.synchronize(dev)
+    K2 = max(K, 200)
+    t2 = time.perf_counter()
+    for i in range(K2):
+        step(i)
+    torch.cuda.synchronize(dev)
+    el2 = time.perf_counter() - t2
+    s2 = torch.zeros(3, dtype=torch.float64, device=dev)
+    _lib.check(lib.nf_sums_reduce(wide2.data_ptr(), s2.data_ptr(), 0, int(torch.cuda.current_stream(dev).cuda_stream)))
+    s2 = s2.cpu().numpy()
+    assert int(round(s2[2])) == B * K2
+    return {"value": B * K2 / el2, "unit": "patches/s", "ms_per_step": el2 / K2 * 1e3, "steps": K2, "streams": 2,
+            "mean_nll": float(s2[0] / s2[2]),
+            "note": "same workload and kernel, consecutive steps alternate between two HIP streams so that launches overlap "
+                    "their ramp-up / drain; the headline value stays single-stream so that roofline.kernel_ms agrees with "
+                    "rocprof's per-kernel duration"}
+
+
+def _sampling(ctx, batches, cond, wide):
+    """Sampling direction (configs[2]): B = 4096, fixed cam / ISO, in-kernel Philox eps."""
+    import torch
+    from noise_flow_amd import _lib
+    from noise_flow_amd.patches import synth_patches
+    args, dev, model = ctx["args"], ctx["dev"], ctx["model"]
+    lib, SB = _lib.load(), args.sample_batch
+    stream = torch.cuda.current_stream(dev)
+    sptr = int(stream.cuda_stream)
+    _, ys = synth_patches(args.seed, 1 << 40, SB, device=dev.index, want_x=False)
+    xs = torch.empty_like(ys)
+    ks = max(10, min(args.steps, 100))
+
+    def sample_step(i):
+        rc = lib.nf_sample(model._flow.ptr, ys.data_ptr(), None, args.seed, i * SB, 1.0, SB, C.byref(cond), xs.data_ptr(), sptr)
+        if rc != 0:
+            _lib.check(rc)
+
+    for i in range(5):
+        sample_step(i)
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ts = time.perf_counter()
+    e0.record(stream)
+    for i in range(ks):
+        sample_step(i)
+    e1.record(stream)
+    torch.cuda.synchronize(dev)
+    ts = time.perf_counter() - ts
+    return {"value": SB * ks / ts, "unit": "patches/s", "batch": SB, "steps": ks,
+            "ms_per_step": 1e3 * ts / ks, "kernel_ms": e0.elapsed_time(e1) / ks, "temp": 1.0,
+            "eps": "in-kernel Philox4x32-10", "workload": "configs[2]: inverse sampling, clean patch + fixed cam/ISO"}
+
+
+def _time_nll(model, x, y, cond, n, dev):
+    """Average HIP-event duration (ms) of n NLL launches with slotted sums on the current stream."""
+    import torch
+    from noise_flow_amd import _lib
+    lib = _lib.load()
+    stream = torch.cuda.current_stream(dev)
+    sptr = int(stream.cuda_stream)
+    acc = torch.zeros(_lib.NF_SUMS_SLOTS * _lib.NF_SUMS_STRIDE, dtype=torch.float64, device=dev)
+    nll = torch.empty(x.shape[0], dtype=torch.float32, device=dev)
+
+    def step():
+        rc = lib.nf_nll(model._flow.ptr, x.data_ptr(), y.data_ptr(), int(x.shape[0]), C.byref(cond), nll.data_ptr(), None, None,
+                        None, acc.data_ptr(), _lib.NF_ACCUMULATE | _lib.NF_SUMS_WIDE, sptr)
+        if rc != 0:
+            _lib.check(rc)
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize(dev)
+    f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    f0.record(stream)
+    for _ in range(n):
+        step()
+    f1.record(stream)
+    torch.cuda.synchronize(dev)
+    return f0.elapsed_time(f1) / n, nll
+
+
+def _fp16_cnn(ctx, batches, cond, wide):
+    """BASELINE configs[4] shape: 64x64x4 patches, fp16 coupling CNN / fp32 log-det."""
+    from noise_flow_amd import NoiseFlow, default_hps
+    from noise_flow_amd.patches import synth_patches
+    args, dev = ctx["args"], ctx["dev"]
+    m16 = NoiseFlow([64, 64, 4], False, default_hps(), variables=ctx["variables"], device=dev.index, cnn_dtype="fp16")
+    B16 = 1024
+    x16, y16 = synth_patches(args.seed, 1 << 41, B16, 64, 64, device=dev.index)
+    k16 = max(10, min(args.steps, 50))
+    ms16, _ = _time_nll(m16, x16, y16, cond, k16, dev)
+    bytes16 = 2 * 64 * 64 * 4 * 4 * B16
+    flop16 = 4 * ALGO_FLOP_PER_PATCH * B16
+    return {"workload": "configs[4] shape: forward NLL, 64x64x4 patches, fp16 coupling CNN "
+                        "(v_mfma_f32_4x4x4_16b_f16, fp32 accumulate + fp32 log-det), fp32 I/O, 1 GPU",
+            "batch": B16, "steps": k16, "kernel_ms": ms16, "value": B16 / (ms16 * 1e-3), "unit": "patches/s",
+            "pixels_per_s": B16 * 4096 / (ms16 * 1e-3), "algorithmic_tflops": flop16 / (ms16 * 1e-3) / 1e12,
+            "hbm": {"achieved": bytes16 / (ms16 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": bytes16 / (ms16 * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bytes16}}
+
+
+def wide_flop_per_pixel(width: int, n_couplings: int = 8) -> float:
+    """Algorithmic flops per pixel of the shipped layer sequence with coupling-CNN width w
+    (layers.py:463-497): per coupling 1x1 mix 16 + l_1 18w + l_2 w^2 + l_last 9(w+1)4 MAC, + ~56 flop of
+    bias/BN/ReLU/tanh/exp/affine; + ~40 flop for sdn/gain/prior per pixel (generalised in w)."""
+    mac = 16 + 18 * width + width * width + 36 * (width + 1)
+    return n_couplings * (2 * mac + 56) + 40
+
+
+def _wide_cnn(ctx, batches, cond, wide):
+    """Paper-scale coupling CNN (job_noise_flow.sh:19: width 32; also 16): same layer sequence, fresh wide CNN weights
+    (no wide checkpoint ships), forward NLL at B = 1024, 32x32x4 — f32 matrix cores (v_mfma_f32_32x32x2_f32)."""
+    import numpy as np
+    from noise_flow_amd import NoiseFlow, default_hps, params as _params
+    args, dev = ctx["args"], ctx["dev"]
+    x, y = batches[0]
+    out = {}
+    for w in (32, 16):
+        hps = default_hps(width=w)
+        var = _params.init_variables(hps.arch, w, 4, 1234)
+        rng = np.random.RandomState(w)
+        for k in list(var):                 # fresh init has a zero last layer: perturb so that every term is live
+            if k.endswith("l_last/W") or k.endswith("l_last/b"):
+                var[k] = (0.02 * rng.randn(*var[k].shape)).astype(np.float32)
+        m = NoiseFlow([32, 32, 4], False, hps, variables=var, device=dev.index)
+        kw = max(5, min(args.steps, 20))
+        ms, nll = _time_nll(m, x, y, cond, kw, dev)
+        flop = wide_flop_per_pixel(w) * 1024 * x.shape[0]
+        tfl = flop / (ms * 1e-3) / 1e12
+        out["w%d" % w] = {"width": w, "batch": int(x.shape[0]), "steps": kw, "kernel_ms": ms,
+                          "value": x.shape[0] / (ms * 1e-3), "unit": "patches/s",
+                          "finite": bool(np.isfinite(nll.cpu().numpy()).all()),
+                          "roofline": {"bound": "mfma", "achieved": tfl, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                       "frac": tfl / VALU_PEAK_TFLOPS, "algorithmic_flop_per_launch": flop,
+                                       "mac_per_pixel_per_coupling": 16 + 18 * w + w * w + 36 * (w + 1),
+                                       "dtype": "f32 in / f32 accumulate (exact fp32)"}}
+        del m
+    out["workload"] = "forward NLL, 1024 synthetic 32x32x4 patches, arch %s with coupling-CNN width 32 / 16" % ARCH_LABEL
+    return out
+
+
+def _sharded_1m(ctx, batches, cond, wide):
+    """configs[3] on ONE GPU without a process group: 2^20 resident patches, K' complete evaluations."""
+    import torch
+    from noise_flow_amd.dist import ResidentShard, timed_sharded_evaluations
+    args, dev, model = ctx["args"], ctx["dev"], ctx["model"]
+    n_total = args.total_patches
+    shard = ResidentShard(model, args.seed, n_total, 0, 1)
+    ks = 3
+    res = timed_sharded_evaluations(shard.eval_chunk(), n_total, n_total, 0, 1, ks, 1,
+                                    lambda: torch.zeros(3, dtype=torch.float64, device=dev),
+                                    sync=lambda: torch.cuda.synchronize(dev))
+    el = res["elapsed"]
+    out = {"workload": "configs[3] on one GPU: forward NLL over %d resident patches per evaluation, one launch" % n_total,
+           "steps": ks, "ms_per_step": 1e3 * el / ks, "value": n_total * ks / el, "unit": "patches/s",
+           "mean_nll": res["results"][-1][0], "resident_gb": shard.nbytes / 1e9}
+    del shard
+    torch.cuda.empty_cache()
+    return out
+
+
+def _training(ctx, batches, cond, wide):
+    """Training step at the reference's minibatch of 138 patches."""
+    import torch
+    from noise_flow_amd import default_hps
+    from noise_flow_amd.patches import synth_patches
+    from noise_flow_amd.train import Trainer
+    args, dev = ctx["args"], ctx["dev"]
+    stream = torch.cuda.current_stream(dev)
+    TB_ = 138                                            # job_noise_flow.sh: --n_batch_train 138
+    trn = Trainer([32, 32, 4], default_hps(), variables=ctx["variables"], device=dev.index, max_batch=TB_)
+    xt_, yt_ = synth_patches(args.seed, 1 << 42, TB_, device=dev.index)
+    kt = max(10, min(args.steps, 50))
+    for _ in range(5):
+        trn.step(xt_, yt_, [0.0], [0.0], [100.0], [2.0], lr=1e-4, sync=False)
+    torch.cuda.synchronize(dev)
+    g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    g0.record(stream)
+    for _ in range(kt):
+        trn.step(xt_, yt_, [0.0], [0.0], [100.0], [2.0], lr=1e-4, sync=False)
+    g1.record(stream)
+    torch.cuda.synchronize(dev)
+    mst = g0.elapsed_time(g1) / kt
+    trn.close()
+    return {"workload": "one training step = forward with batch-statistics BN + backward + BN EMA + Adam "
+                        "(train_noise_flow.py:64-66,187-198), shipped architecture, 138 patches 32x32x4",
+            "batch": TB_, "steps": kt, "ms_per_step": mst, "value": TB_ / (mst * 1e-3), "unit": "patches/s",
+            "bound": "kernel latency: a chain of stream-ordered launches per step (profiles/)"}
+
+
+def _cpu_baseline(args, variables, xc, yc, B):
+    import torch
+    # (1) fused plain-C / OpenMP port of the reference arithmetic (oracle/nf_oracle.c): what a good
+    #     CPU implementation does on all host cores -> the reported cpu_baseline
+    from oracle.nf_oracle_c import COracle
+    cc = COracle(ARCH_LABEL, variables)
+    host_cores = _usable_cores(os.cpu_count() or 1)           # affinity mask and cgroup CPU quota
+    cc.set_threads(host_cores)
+    cc.nll(xc[:256], yc[:256], 100.0, 2.0)                      # warm-up (thread pool, page faults)
+    n_batches, tc, budget = 0, 0.0, 0.6 * args.cpu_seconds
+    t_start = time.perf_counter()
+    while tc < budget and n_batches < 4096:                     # time-bounded sample
+        cc.nll(xc, yc, 100.0, 2.0)
+        n_batches += 1
+        tc = time.perf_counter() - t_start
+    cpu_baseline = {"value": n_batches * B / tc, "unit": "patches/s", "cores": _usable_cores(cc.threads()),
+                    "kind": "port",
+                    "sample": "forward NLL of %d batches x %d patches (same workload), fused plain-C fp32 port "
+                              "of the reference arithmetic with OpenMP over patches (%d threads; TF1 "
+                              "unavailable), %.1f s" % (n_batches, B, cc.threads(), tc)}
+    # (2) op-per-layer torch-CPU port: how the TF1 graph actually executes (every op materialised)
+    from oracle.nf_cpu_torch import TorchCpuFlow
+    cpu = TorchCpuFlow(ARCH_LABEL, variables)
+    torch.set_num_threads(host_cores)
+    cpu.nll(xc[:128], yc[:128], 100.0, 2.0)
+    n_batches, tc, budget = 0, 0.0, 0.4 * args.cpu_seconds
+    t_start = time.perf_counter()
+    while tc < budget and n_batches < 64:
+        cpu.nll(xc, yc, 100.0, 2.0)
+        n_batches += 1
+        tc = time.perf_counter() - t_start
+    cpu_baseline["op_per_layer_torch"] = {
+        "value": n_batches * B / tc, "unit": "patches/s", "cores": _usable_cores(int(torch.get_num_threads())),
+        "kind": "port",
+        "sample": "forward NLL of %d batches x %d patches, torch-CPU fp32 op-per-layer restatement of the "
+                  "TF1 graph, %.1f s" % (n_batches, B, tc)}
+    return cpu_baseline
 
 
 if __name__ == "__main__":

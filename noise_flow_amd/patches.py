@@ -95,15 +95,25 @@ def shard_range(n_total: int, rank: int, world: int) -> Tuple[int, int]:
 
 
 def synth_patches(seed: int, first_patch: int, count: int, height: int = 32, width: int = 32,
-                  nlf=S6_ISO100_NLF, device=None, want_x: bool = True):
+                  nlf=S6_ISO100_NLF, device=None, want_x: bool = True, out=None):
     """Device-resident synthetic patches ``k = first_patch … first_patch+count-1``:
     ``y_k ~ U[0,1)``, ``x_k = ε·sqrt(β1·y_k + β2)`` → (x, y) float32 CUDA tensors
-    [count, H, W, 4].  Identical for any sharding of the index range."""
+    [count, H, W, 4].  Identical for any sharding of the index range.  ``out=(x, y)`` writes into
+    caller-owned contiguous tensors of that shape (e.g. slices of a resident shard) instead."""
     import torch
     lib = _lib.load()
     dev = torch.device("cuda", torch.cuda.current_device() if device is None else int(device))
-    y = torch.empty((count, height, width, 4), dtype=torch.float32, device=dev)
-    x = torch.empty_like(y) if want_x else None
+    if out is not None:
+        x, y = out
+        for t in (x, y):
+            if t is not None and (tuple(t.shape) != (count, height, width, 4) or t.dtype != torch.float32
+                                  or not t.is_contiguous() or t.device != dev):
+                raise ValueError("out tensors must be contiguous float32 [count,H,W,4] on %s" % dev)
+        if y is None:
+            raise ValueError("out[1] (y) is required")
+    else:
+        y = torch.empty((count, height, width, 4), dtype=torch.float32, device=dev)
+        x = torch.empty_like(y) if want_x else None
     with torch.cuda.device(dev):
         _lib.check(lib.nf_synth_patches(int(seed) & ((1 << 64) - 1), int(first_patch), int(count), height, width,
                                         float(nlf[0]), float(nlf[1]), y.data_ptr(),

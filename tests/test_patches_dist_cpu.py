@@ -107,3 +107,71 @@ def test_evaluate_sharded_single_process_detects_miscount():
     sums = torch.zeros(3, dtype=torch.float64)
     with pytest.raises(RuntimeError):
         evaluate_sharded(lambda a, n, s: s.add_(torch.tensor([0.0, 0.0, n - 1.0], dtype=torch.float64)), 10, 4, 0, 1, sums)
+
+
+def _timed_worker(rank, world, port, n_total, chunk, steps, warmup, q):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from noise_flow_amd.dist import timed_sharded_evaluations
+    from oracle import philox
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    calls = {"chunks": 0, "finish": 0, "events": []}
+
+    def eval_chunk(first, count, acc):
+        calls["chunks"] += 1
+        x, y = philox.synth_patches(7, first, count, 8, 8)
+        acc += torch.tensor([float((x.astype(np.float64) ** 2).sum()), float(y.astype(np.float64).sum()), count],
+                            dtype=torch.float64)
+
+    def finish(acc):
+        calls["finish"] += 1
+    eval_chunk.finish = finish
+    res = timed_sharded_evaluations(eval_chunk, n_total, chunk, rank, world, steps, warmup,
+                                    lambda: torch.zeros(3, dtype=torch.float64),
+                                    on_step=lambda i, what: calls["events"].append((i, what)))
+    q.put((rank, res, calls))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2])
+def test_timed_sharded_evaluations_gloo(world):
+    """The code path of `bench.py --gpus N` (BASELINE configs[3]): K complete evaluations of the sharded patch range,
+    ONE all-reduce each, results identical on every rank and equal to the unsharded statistics."""
+    import torch.multiprocessing as mp
+    from oracle import philox
+    from noise_flow_amd.patches import shard_range
+    n_total, chunk, steps, warmup = 77, 16, 3, 1
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_timed_worker, args=(r, world, port, n_total, chunk, steps, warmup, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=120) for _ in procs]
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    x, y = philox.synth_patches(7, 0, n_total, 8, 8)
+    want = ((x.astype(np.float64) ** 2).sum() / n_total, y.astype(np.float64).sum() / n_total)
+    for rank, out, calls in res:
+        start, stop = shard_range(n_total, rank, world)
+        assert out["shard"] == (start, stop) and out["elapsed"] > 0 and len(out["results"]) == steps
+        for mean, sd, n in out["results"]:
+            assert n == n_total and abs(mean - want[0]) <= 1e-12 * abs(want[0]) and abs(sd - want[1]) <= 1e-12 * abs(want[1])
+        n_chunks = -(-(stop - start) // chunk)
+        assert calls["chunks"] == n_chunks * (steps + warmup) and calls["finish"] == steps + warmup
+        assert calls["events"] == [(i, w) for i in range(steps) for w in ("begin", "end")]   # timed steps only
+
+
+def test_timed_sharded_evaluations_without_process_group():
+    import torch
+    from noise_flow_amd.dist import timed_sharded_evaluations
+    seen = []
+
+    def eval_chunk(first, count, acc):
+        seen.append((first, count))
+        acc += torch.tensor([2.0 * count, 1.0 * count, float(count)], dtype=torch.float64)
+    out = timed_sharded_evaluations(eval_chunk, 10, 4, 0, 1, 2, 0, lambda: torch.zeros(3, dtype=torch.float64))
+    assert seen == [(0, 4), (4, 4), (8, 2)] * 2 and out["results"] == [(2.0, 1.0, 10)] * 2
+    with pytest.raises(RuntimeError):
+        timed_sharded_evaluations(lambda a, n, s: s.add_(torch.tensor([0.0, 0.0, n - 1.0], dtype=torch.float64)), 10, 4, 0, 1, 1, 0,
+                                  lambda: torch.zeros(3, dtype=torch.float64))

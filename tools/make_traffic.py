@@ -1,0 +1,64 @@
+"""profiles/traffic.json from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE need separate passes: the TCC block
+has 4 counter slots, FETCH_SIZE costs 3 and WRITE_SIZE 2 — MI355X_MICROARCH.md).
+
+    python tools/make_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> [kernel-substring] [B]
+
+Per-launch averages over the launches of the named kernel with Grid_Size == B*256 (the headline launch shape);
+gfx950 correction: FETCH_SIZE reports 64 B per 128-B request for wide coalesced 16 B/lane reads -> x2; WRITE_SIZE as
+reported (uncalibrated; < 0.1 MB here).  The record is stamped with the content hash of the kernel sources so that
+bench.py reports it only for the kernel it was measured on."""
+import csv
+import hashlib
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def source_sha():
+    h = hashlib.sha256()
+    for name in ("nf_kernels.hip", "nf_device.h"):
+        with open(os.path.join(ROOT, "noise_flow_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def mean_counter(path, counter, kernel_sub, grid):
+    vals = []
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            if row["Counter_Name"] == counter and kernel_sub in row["Kernel_Name"] and int(row["Grid_Size"]) == grid:
+                vals.append(float(row["Counter_Value"]))
+    if not vals:
+        raise SystemExit("no %s rows for a kernel containing %r with grid %d in %s" % (counter, kernel_sub, grid, path))
+    return sum(vals) / len(vals), len(vals)
+
+
+def main():
+    fetch_csv, write_csv = sys.argv[1], sys.argv[2]
+    kernel_sub = sys.argv[3] if len(sys.argv) > 3 else "nf_flow_kernel<4, 256, 4, false, true, true, 0>"
+    B = int(sys.argv[4]) if len(sys.argv) > 4 else 1024
+    grid = B * 256
+    fetch_kb, n_f = mean_counter(fetch_csv, "FETCH_SIZE", kernel_sub, grid)
+    write_kb, n_w = mean_counter(write_csv, "WRITE_SIZE", kernel_sub, grid)
+    hbm = 2.0 * fetch_kb * 1024.0 + write_kb * 1024.0
+    algo = 2 * 32 * 32 * 4 * 4 * B
+    out = {
+        "kernel": "%s (fused NLL, B=%d 32x32x4 patches per launch)" % (kernel_sub, B),
+        "kernel_source_sha": source_sha(),
+        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) -- python bench.py "
+                  "--no-cpu-baseline --no-extras --steps 20 --warmup 2 --ramp-ms 0; %s (%d launches), %s (%d launches)"
+                  % (os.path.relpath(fetch_csv, ROOT), n_f, os.path.relpath(write_csv, ROOT), n_w),
+        "FETCH_SIZE_KB_reported": fetch_kb, "WRITE_SIZE_KB_reported": write_kb,
+        "correction": "gfx950: FETCH_SIZE counts 128-B requests at 64 B -> x2 for wide coalesced 16 B/lane reads "
+                      "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE as reported (uncalibrated)",
+        "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": algo, "ratio": hbm / algo,
+    }
+    with open(os.path.join(ROOT, "profiles", "traffic.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
