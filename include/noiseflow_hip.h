@@ -243,6 +243,19 @@ int nf_fold_params(const nf_config *cfg, const nf_layer_desc *layers,
                    float *folded, size_t folded_cap, size_t *n_folded,
                    double *ld_const);
 
+/* Which kernel family nf_nll (direction 0) / nf_sample (direction 1) of this handle launch:
+ *   NF_PATH_SCALAR  scalar-weight VALU kernel (any width / shape; also NF_KERNEL=valu)
+ *   NF_PATH_MFMA4   width 4 on v_mfma_f32_4x4x1            NF_PATH_FP16 width 4, fp16 CNN (NF_CFG_FP16_CNN)
+ *   NF_PATH_WIDE32  width 32 on v_mfma_f32_32x32x2_f32     NF_PATH_WIDE16 width 16 on v_mfma_f32_16x16x4_f32
+ * or a negative status.  No reference counterpart (diagnostic; the parity tests use it to make sure the
+ * kernel they mean to check is the one that ran). */
+#define NF_PATH_SCALAR 0
+#define NF_PATH_MFMA4 1
+#define NF_PATH_FP16 2
+#define NF_PATH_WIDE32 3
+#define NF_PATH_WIDE16 4
+int nf_kernel_path(const nf_handle *h, int32_t direction);
+
 /* Host-only: the SDN5 scalars the kernels receive for a given (iso, cam):
  * out[0] = beta1/gain, out[1] = beta2 (cond_utils.py:205-239). */
 int nf_sdn5_scalars(const float *sdn_params /*23 floats*/, const nf_cond *cond, double out[2]);

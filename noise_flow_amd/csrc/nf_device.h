@@ -100,6 +100,39 @@ __host__ __device__ constexpr int nf_cpl_size(int w)   { return 64 + 36 * w + 18
 #define NF3_CPL_W3H 180
 #define NF3_CPL_SIZE 252
 
+// ---- wide-CNN layout (coupling width 32, nf_wide.hip) ------------------------------------------
+// The three convs of a width-32 coupling CNN run on v_mfma_f32_32x32x2_f32 with the PIXELS on the N
+// axis (a tile = 32 consecutive pixels of one image row, lanes n = lane & 31; the two lane halves
+// g = lane >> 5 are the instruction's two K slices) and channels / taps on the M axis.  The D
+// register v of lane half g then holds row  i = 8 (v >> 2) + 4 g + (v & 3)  — call it c(v, g) — so
+// the output of one layer is, register by register, the B operand of the next: K step s of the next
+// layer consumes D[s], its two K slices being the channels c(s, 0) and c(s, 1).  All weights below
+// are stored in exactly the order the lanes fetch them (one A operand per lane per step):
+//   MIX       M [4][4]          row-major [c][k] (scalar loads)
+//   COUPLING  E  [16][4]  @0    border table, raw columns pre-scaled by 2 log2(e)  (as NF2_CPL_E)
+//             S  [4]      @64   rescaling_scale, sc*log2e, -2 sc*log2e, 0
+//             IMG         @68   the LDS image the workgroup copies per coupling:
+//               A1 [3][64][4]   l_1: step = tap (9 used of 12), lane l: W1[tap][ch = l>>5][i = l&31]
+//               B1 [2][16]      l_1 bias by (g, v): b1[c(v, g)]
+//               A2 [4][64][4]   l_2: step s, lane l: W2[in = c(s, l>>5)][out = l&31]
+//               B2 [2][16]
+//               A3 [4][64][4]   l_last as P = W3^T h2: step s, lane l: W3[tap(i)][in = c(s, l>>5)][j = i&3], i = l&31,
+//                               where row i of P is (a = i>>3, g' = (i>>2)&1, j): taps (di,dj) by (a, g'):
+//                               a=0: (0,0)|(2,0)   a=1: (0,2)|(2,2)   a=2: (0,1)|(2,1)   a=3: (1,0)|(1,2)
+//               A3C[4][8][4]    centre tap (1,1) on v_mfma_f32_4x4x1: step s, (g, j): W3[centre][c(s, g)][j]
+#define NF4_CPL_E 0
+#define NF4_CPL_S 64
+#define NF4_CPL_IMG 68
+#define NF4_IMG_A1 0
+#define NF4_IMG_B1 768
+#define NF4_IMG_A2 800
+#define NF4_IMG_B2 1824
+#define NF4_IMG_A3 1856
+#define NF4_IMG_A3C 2880
+#define NF4_IMG_SIZE 3008
+#define NF4_CPL_SIZE (NF4_CPL_IMG + NF4_IMG_SIZE)
+__host__ __device__ constexpr int nf4_chan(int v, int g) { return 8 * (v >> 2) + 4 * g + (v & 3); }
+
 // launch flags
 enum : uint32_t {
     NF_K_PRIOR     = 1u,   // nll = -(logdet + logp(z)); otherwise nll = -logdet

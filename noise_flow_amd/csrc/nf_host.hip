@@ -23,6 +23,7 @@
 #include "nf_internal.h"
 
 hipError_t nf_launch_flow(const NfProgram &prog, const NfLaunch &a, int n_cu, hipStream_t stream, bool matrix_core);
+hipError_t nf_launch_wide(const NfProgram &prog, const NfLaunch &a, int n_cu, int device, hipStream_t stream);
 hipError_t nf_launch_synth(uint64_t seed, int64_t patch_base, int64_t B, int HW, float beta1, float beta2,
                            float *y_out, float *x_out, hipStream_t stream);
 hipError_t nf_launch_sums_reduce(const double *wide, double *out3, bool accumulate, hipStream_t stream);
@@ -257,6 +258,52 @@ void relayout_coupling_v3(const float *v1, float *out)
     }
 }
 
+// Wide-CNN re-layout (nf_device.h, NF4_*; coupling width 32): every weight in the order the lanes of
+// v_mfma_f32_32x32x2_f32 / v_mfma_f32_4x4x1 fetch their A operands (nf_wide.hip).
+void relayout_coupling_wide32(const float *v1, float *out)
+{
+    const int w = 32;
+    const double k2 = 2.0 * 1.4426950408889634, log2e = 1.4426950408889634;
+    for (int m = 0; m < 16; ++m)
+        for (int j = 0; j < 4; ++j) {
+            const double e = v1[nf_cpl_off_E(w) + 4 * m + j];
+            out[NF4_CPL_E + 4 * m + j] = (float)(j >= 2 ? e * k2 : e);   // raw columns feed exp2() directly
+        }
+    const double sc = v1[nf_cpl_off_S(w)];
+    out[NF4_CPL_S + 0] = (float)sc;
+    out[NF4_CPL_S + 1] = (float)(sc * log2e);
+    out[NF4_CPL_S + 2] = (float)(-2.0 * sc * log2e);
+    out[NF4_CPL_S + 3] = 0.0f;
+    float *img = out + NF4_CPL_IMG;
+    const float *W1 = v1 + nf_cpl_off_W1(w), *B1 = v1 + nf_cpl_off_B1(w), *W2 = v1 + nf_cpl_off_W2(w);
+    const float *B2 = v1 + nf_cpl_off_B2(w), *W3 = v1 + nf_cpl_off_W3(w);
+    for (int step = 0; step < 12; ++step)          // l_1: step = tap, K slice = input channel
+        for (int l = 0; l < 64; ++l)
+            img[NF4_IMG_A1 + ((step >> 2) * 64 + l) * 4 + (step & 3)] =
+                step < 9 ? W1[(step * 2 + (l >> 5)) * w + (l & 31)] : 0.0f;
+    for (int g = 0; g < 2; ++g)
+        for (int v = 0; v < 16; ++v) {
+            img[NF4_IMG_B1 + g * 16 + v] = B1[nf4_chan(v, g)];
+            img[NF4_IMG_B2 + g * 16 + v] = B2[nf4_chan(v, g)];
+        }
+    // taps (di,dj) of the 8 off-centre rows groups of P, by (a, g')
+    static const int tap_of[4][2] = {{0 * 3 + 0, 2 * 3 + 0}, {0 * 3 + 2, 2 * 3 + 2}, {0 * 3 + 1, 2 * 3 + 1}, {1 * 3 + 0, 1 * 3 + 2}};
+    for (int s = 0; s < 16; ++s)
+        for (int l = 0; l < 64; ++l) {
+            const int cin = nf4_chan(s, l >> 5), i = l & 31;
+            img[NF4_IMG_A2 + ((s >> 2) * 64 + l) * 4 + (s & 3)] = W2[cin * w + i];
+            const int a = i >> 3, gp = (i >> 2) & 1, j = i & 3;
+            const double wv = W3[(tap_of[a][gp] * w + cin) * 4 + j];
+            img[NF4_IMG_A3 + ((s >> 2) * 64 + l) * 4 + (s & 3)] = (float)(j >= 2 ? wv * k2 : wv);
+        }
+    for (int s = 0; s < 16; ++s)
+        for (int g = 0; g < 2; ++g)
+            for (int j = 0; j < 4; ++j) {
+                const double wv = W3[(4 * w + nf4_chan(s, g)) * 4 + j];   // centre tap (1,1)
+                img[NF4_IMG_A3C + ((s >> 2) * 8 + g * 4 + j) * 4 + (s & 3)] = (float)(j >= 2 ? wv * k2 : wv);
+            }
+}
+
 // ---- sdn5 host scalars (cond_utils.py:205-239) -------------------------------
 int sdn5_scalars(const float *sp, const nf_cond *cond, double out[2])
 {
@@ -328,6 +375,8 @@ struct Built {
     std::vector<float> block2;   // empty when unavailable
     NfProgram prog3;             // fp16-CNN layout (NF_CFG_FP16_CNN), width 4 only
     std::vector<float> block3;
+    NfProgram prog4;             // wide-CNN layout (NF4_*), width 32 only
+    std::vector<float> block4;
     double ld_const = 0.0;
     bool has_sdn = false;      // some op reads the clean image y
 };
@@ -497,6 +546,29 @@ int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float
         if (out.block2.empty()) out.block2.assign(4, 0.0f);
         if (out.block2.size() > NF2_MAX_FLOATS) out.block2.clear();   // too large for LDS: scalar path only
     }
+    out.block4.clear();
+    memset(&out.prog4, 0, sizeof(out.prog4));
+    if (out.prog.width == 32) {
+        out.prog4.width = 32;
+        for (int i = 0; i < out.prog.n_ops; ++i) {
+            const NfOp &src = out.prog.ops[i];
+            NfOp &dst = out.prog4.ops[out.prog4.n_ops++];
+            dst.type = src.type;
+            dst.off = (int32_t)out.block4.size();
+            const float *v1 = out.block.data() + src.off;
+            if (src.type == NF_OP_MIX) {
+                out.block4.insert(out.block4.end(), v1, v1 + 16);
+            } else if (src.type == NF_OP_COUPLING_FWD || src.type == NF_OP_COUPLING_REV) {
+                out.block4.resize(out.block4.size() + NF4_CPL_SIZE);
+                relayout_coupling_wide32(v1, out.block4.data() + dst.off);
+            } else if (src.type == NF_OP_SCALE) {
+                out.block4.insert(out.block4.end(), v1, v1 + 4);
+            } else {
+                dst.off = src.off;   // conditioning slot
+            }
+        }
+        if (out.block4.empty()) out.block4.assign(4, 0.0f);
+    }
     out.block3.clear();
     memset(&out.prog3, 0, sizeof(out.prog3));
     if (out.prog.width == 4 && (cfg->flags & NF_CFG_FP16_CNN)) {
@@ -580,6 +652,8 @@ struct nf_handle {
     float *d_rev2 = nullptr;
     float *d_fwd3 = nullptr;   // fp16-CNN layout (NF_CFG_FP16_CNN)
     float *d_rev3 = nullptr;
+    float *d_fwd4 = nullptr;   // wide-CNN layout (width 32)
+    float *d_rev4 = nullptr;
     // batch-statistics mode (nf_*_batchstats): the raw model and a lazily allocated scratch
     std::vector<nf_layer_desc> layers;
     std::vector<float> raw;
@@ -648,7 +722,7 @@ int nf_create(const nf_config *cfg, const nf_layer_desc *layers, const float *pa
     {   // the two LDS tiles of the scalar-weight kernel must fit one CU (160 KiB)
         const size_t tile_px = ((size_t)(cfg->height + 2) * (cfg->width + 2) + 1) & ~(size_t)1;
         const size_t lds = sizeof(float) * (tile_px * (2 + (size_t)h->fwd.prog.width) + 64);
-        if (lds > 160 * 1024 && h->fwd.block2.empty()) {
+        if (lds > 160 * 1024 && h->fwd.block2.empty() && h->fwd.block4.empty()) {
             const int w = h->fwd.prog.width;
             delete h;
             return fail(NF_EINVAL, "a %dx%d patch with coupling width %d needs %zu KiB of LDS (> 160): unsupported",
@@ -693,9 +767,10 @@ int nf_create(const nf_config *cfg, const nf_layer_desc *layers, const float *pa
             return fail(NF_EINVAL, "NF_CFG_FP16_CNN needs coupling width 4 and full 32x32 or 64x64 patches");
         }
     }
-    for (int d = 0; d < 4; ++d) {
-        const std::vector<float> &b2 = d == 0 ? h->fwd.block2 : d == 1 ? h->rev.block2 : d == 2 ? h->fwd.block3 : h->rev.block3;
-        float **dst = d == 0 ? &h->d_fwd2 : d == 1 ? &h->d_rev2 : d == 2 ? &h->d_fwd3 : &h->d_rev3;
+    for (int d = 0; d < 6; ++d) {
+        const std::vector<float> &b2 = d == 0 ? h->fwd.block2 : d == 1 ? h->rev.block2 : d == 2 ? h->fwd.block3 : d == 3 ? h->rev.block3
+                                       : d == 4 ? h->fwd.block4 : h->rev.block4;
+        float **dst = d == 0 ? &h->d_fwd2 : d == 1 ? &h->d_rev2 : d == 2 ? &h->d_fwd3 : d == 3 ? &h->d_rev3 : d == 4 ? &h->d_fwd4 : &h->d_rev4;
         if (b2.empty()) continue;
         if ((e = hipMalloc((void **)dst, b2.size() * sizeof(float))) != hipSuccess ||
             (e = hipMemcpy(*dst, b2.data(), b2.size() * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) {
@@ -718,6 +793,8 @@ int nf_destroy(nf_handle *h)
     if (h->d_rev2) (void)hipFree(h->d_rev2);
     if (h->d_fwd3) (void)hipFree(h->d_fwd3);
     if (h->d_rev3) (void)hipFree(h->d_rev3);
+    if (h->d_fwd4) (void)hipFree(h->d_fwd4);
+    if (h->d_rev4) (void)hipFree(h->d_rev4);
     if (h->d_bs_params) (void)hipFree(h->d_bs_params);
     if (h->d_bs_stats) (void)hipFree(h->d_bs_stats);
     delete h;
@@ -804,7 +881,15 @@ static int launch_resident(nf_handle *h, int direction, NfLaunch &a, hipStream_t
     float *d1 = direction == 0 ? h->d_fwd : h->d_rev;
     float *d2 = direction == 0 ? h->d_fwd2 : h->d_rev2;
     float *d3 = direction == 0 ? h->d_fwd3 : h->d_rev3;
+    float *d4 = direction == 0 ? h->d_fwd4 : h->d_rev4;
     if (direction == 0) a.ld_const += b.ld_const;
+    if (d4 && use_matrix_core()) {   // width 32: the three convs on v_mfma_f32_32x32x2_f32 (nf_wide.hip)
+        a.params = d4;
+        a.n_params = (int32_t)b.block4.size();
+        hipError_t e = nf_launch_wide(b.prog4, a, h->n_cu, h->device, st);
+        if (e != hipSuccess) return fail_hip(e, what);
+        return NF_OK;
+    }
     const bool mc = d3 || (d2 && use_matrix_core());
     a.params = d1;
     if (d3) {
@@ -818,6 +903,15 @@ static int launch_resident(nf_handle *h, int direction, NfLaunch &a, hipStream_t
     hipError_t e = nf_launch_flow(d3 ? b.prog3 : mc ? b.prog2 : b.prog, a, h->n_cu, st, mc);
     if (e != hipSuccess) return fail_hip(e, what);
     return NF_OK;
+}
+
+int nf_kernel_path(const nf_handle *h, int32_t direction)
+{
+    if (!h || (direction != 0 && direction != 1)) return fail(NF_EINVAL, "bad argument");
+    if ((direction == 0 ? h->d_fwd4 : h->d_rev4) && use_matrix_core()) return NF_PATH_WIDE32;
+    if (direction == 0 ? h->d_fwd3 : h->d_rev3) return NF_PATH_FP16;
+    if ((direction == 0 ? h->d_fwd2 : h->d_rev2) && use_matrix_core()) return NF_PATH_MFMA4;
+    return NF_PATH_SCALAR;
 }
 
 int nf_nll(nf_handle *h, const float *x, const float *y, int64_t B, const nf_cond *cond, float *nll_out, float *sd_out,

@@ -1,0 +1,450 @@
+// Fused Noise Flow stack for the paper-scale coupling CNN (width 32) on the f32 matrix cores of gfx950.
+//
+// Same program, same I/O and same per-patch workgroup as nf_kernels.hip, but the three convolutions of
+// every coupling CNN (layers.py:463-497: 3x3x2->w, 1x1 w->w, 3x3x(w+1)->4; 2.8 kMAC per pixel at w = 32)
+// are GEMMs on v_mfma_f32_32x32x2_f32 — exact fp32, 64 FLOP/clk/SIMD:
+//
+//  * a TILE is 32 consecutive pixels of one image row on the instruction's N axis (lane n = lane & 31);
+//    the two lane halves g = lane >> 5 are its two K slices.  Channels sit on the M axis, so the D
+//    register v of lane half g holds channel c(v, g) = 8 (v >> 2) + 4 g + (v & 3) of the lane's pixel
+//    and IS the B operand of K step v of the next layer: l_1 -> ReLU -> l_2 -> ReLU -> l_last chain through
+//    registers with no data movement at all.  The A operands (weights) are pre-permuted on the host into
+//    fetch order (nf_device.h, NF4_*) and staged in LDS once per coupling.
+//  * l_1 reads its B operand (tap (di,dj), channel g of the pass-through half) from a zero-bordered LDS
+//    tile of z0 — 9 MFMAs per tile.
+//  * l_last is evaluated transposed: P[pixel][tap][j] = sum_c h2[pixel][c] W3[tap][c][j] is one 32-row
+//    GEMM for the 8 off-centre taps (+ the centre tap on v_mfma_f32_4x4x1) straight from the h2 registers;
+//    the output is the shift-add  o[r][c] = sum_tap P[r+di-1][c+dj-1][tap].  The horizontal shifts are
+//    lane shifts inside the tile, the vertical ones stay in registers because a wavefront owns a STRIP of
+//    8 consecutive rows; only strip boundaries (and the column 31|32 seam of 64-wide patches) go through
+//    LDS.  h2 never exists in memory, 'SAME' zero padding falls out of the zero-filled shifts.
+//
+// Replaces (reference, /root/reference): layers.py:251-375 (AffineCoupling), :452-498 (real_nvp_conv_template),
+// :555-613, :651-674 (conv2d / add_edge_padding / conv2d_zeros) at hps.width = 32 (job_noise_flow.sh:19).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <atomic>
+#include "../../include/noiseflow_hip.h"   // NF_SUMS_SLOTS / NF_SUMS_STRIDE
+#include "nf_device.h"
+#include "nf_dev_util.h"
+
+namespace {
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+constexpr int TPW = 8;   // tiles (= rows of a strip) per wavefront
+
+// value of the lane one pixel to the left / right inside the 32-lane tile half (callers mask the ends)
+__device__ __forceinline__ float from_prev(float x, int lane)
+{
+    return __int_as_float(__builtin_amdgcn_ds_bpermute((lane - 1) << 2, __float_as_int(x)));
+}
+__device__ __forceinline__ float from_next(float x, int lane)
+{
+    return __int_as_float(__builtin_amdgcn_ds_bpermute((lane + 1) << 2, __float_as_int(x)));
+}
+// x(lanes 0-31) + x(lanes 32-63) on every lane: the two halves hold partial sums of the same pixel
+__device__ __forceinline__ float half_sum(float x)
+{
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+//   THREADS  64 x number of strips: (rows / 8) x TPR
+//   PHILOX   input = in-kernel Philox/Box-Muller draw
+//   TPR      tiles per image row: 1 (W <= 32) or 2 (W <= 64)
+template <int THREADS, bool PHILOX, int TPR>
+__global__ __launch_bounds__(THREADS) void nf_wide32_kernel(const NfProgram prog, const NfLaunch a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NW = THREADS / 64;
+    const int H = a.H, W = a.W, HW = H * W;
+    const int Wp = W + 2;
+    const int PL = ((H + 2) * Wp + 3) & ~3;             // one channel plane of the z0 tile
+    float *const z0s = smem;                             // [2][PL]
+    float *const wbuf = z0s + 2 * PL;                    // [NF4_IMG_SIZE] weights of the current coupling
+    float *const exch = wbuf + NF4_IMG_SIZE;             // [NW][2][32][4] strip-boundary rows
+    float *const side = exch + NW * 256;                 // TPR == 2: [2][H+2][3][4] column-seam taps
+    float *const red = side + (TPR == 2 ? 2 * (H + 2) * 12 : 0);   // [3][NW] reduction scratch
+
+    const int t = threadIdx.x;
+    const int w = t >> 6, lane = t & 63, n = lane & 31, g = lane >> 5;
+    const int rg = w / TPR, hf = w % TPR;
+    const int row0 = rg * TPW, c = hf * 32 + n;
+    const bool col_on = c < W;
+    const bool has_left = n > 0;                         // the seam neighbour of a 64-wide row arrives through `side`
+    const bool has_right = n < 31 && c + 1 < W;
+    const bool lead = g == 0;                            // one of the two lanes of a pixel does the global I/O and the sums
+
+    for (int i = t; i < 2 * PL + NF4_IMG_SIZE + NW * 256 + (TPR == 2 ? 2 * (H + 2) * 12 : 0); i += THREADS) smem[i] = 0.0f;
+    __syncthreads();
+
+    const int n_ops = prog.n_ops;
+    double acc_nll = 0.0, acc_sd = 0.0;   // thread 0 only
+
+    for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
+        const size_t patch_off = (size_t)b * (size_t)HW * 4u;
+
+        float z[TPW][4];
+#pragma unroll
+        for (int k = 0; k < TPW; ++k) {
+            const int r = row0 + k;
+            const bool act = r < H && col_on;
+            const int gi = act ? r * W + c : 0;
+            if (PHILOX) {
+                philox_normal4(a.seed, a.patch_base + b, (uint32_t)gi, NF_STREAM_SAMP, z[k]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) z[k][q] *= a.in_scale;
+            } else {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (act) v = reinterpret_cast<const float4 *>(a.in + patch_off)[gi];
+                z[k][0] = v.x * a.in_scale;
+                z[k][1] = v.y * a.in_scale;
+                z[k][2] = v.z * a.in_scale;
+                z[k][3] = v.w * a.in_scale;
+            }
+        }
+
+        float ld = 0.0f, ld2 = 0.0f;   // natural-log / log2 parts of this lane's log-det share
+
+        for (int op = 0; op < n_ops; ++op) {
+            const int type = prog.ops[op].type;
+            const cfloat_p P = (cfloat_p)(a.params + prog.ops[op].off);   // wave-uniform, scalar loads
+
+            if (type == NF_OP_MIX) {
+                float m[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) m[i] = P[i];
+#pragma unroll
+                for (int k = 0; k < TPW; ++k) {
+                    float o[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float s = z[k][0] * m[j];
+                        s = fmaf(z[k][1], m[4 + j], s);
+                        s = fmaf(z[k][2], m[8 + j], s);
+                        s = fmaf(z[k][3], m[12 + j], s);
+                        o[j] = s;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) z[k][j] = o[j];
+                }
+            } else if (type == NF_OP_COUPLING_FWD || type == NF_OP_COUPLING_REV) {
+                // ---- phase A: publish the pass-through half, stage this coupling's weights ----
+#pragma unroll
+                for (int k = 0; k < TPW; ++k) {
+                    const int r = row0 + k;
+                    if (r < H && col_on) z0s[g * PL + (r + 1) * Wp + c + 1] = g ? z[k][1] : z[k][0];
+                }
+                {
+                    const float4 *src = reinterpret_cast<const float4 *>(a.params + prog.ops[op].off + NF4_CPL_IMG);
+                    float4 *dst = reinterpret_cast<float4 *>(wbuf);
+                    for (int i = t; i < NF4_IMG_SIZE / 4; i += THREADS) dst[i] = src[i];
+                }
+                __syncthreads();
+
+                // ---- phase B: the CNN on the matrix cores, strip-local shift-add ----
+                const float4 *const wb4 = reinterpret_cast<const float4 *>(wbuf);
+                float cp[TPW][4];
+#pragma unroll
+                for (int k = 0; k < TPW; ++k)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) cp[k][j] = 0.0f;
+#pragma unroll
+                for (int k = 0; k < TPW; ++k) {
+                    const int r = row0 + k;
+                    if (r >= H) continue;   // wave-uniform
+                    // 16 waves per CU leave 128 VGPRs: keep the compiler from holding all 57 A operands live across tiles
+                    if constexpr (THREADS == 1024) asm volatile("" ::: "memory");
+                    v16f d;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 bb = wb4[NF4_IMG_B1 / 4 + g * 4 + q];
+                        d[4 * q + 0] = bb.x; d[4 * q + 1] = bb.y; d[4 * q + 2] = bb.z; d[4 * q + 3] = bb.w;
+                    }
+                    const float *zb = z0s + g * PL + r * Wp + c;   // tap (di,dj) at + di*Wp + dj
+#pragma unroll
+                    for (int grp = 0; grp < 3; ++grp) {
+                        const float4 aw = wb4[NF4_IMG_A1 / 4 + grp * 64 + lane];
+                        const float as[4] = {aw.x, aw.y, aw.z, aw.w};
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) {
+                            const int tap = grp * 4 + s;
+                            if (tap < 9) d = __builtin_amdgcn_mfma_f32_32x32x2f32(as[s], zb[(tap / 3) * Wp + tap % 3], d, 0, 0, 0);
+                        }
+                    }
+                    v16f e;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 bb = wb4[NF4_IMG_B2 / 4 + g * 4 + q];
+                        e[4 * q + 0] = bb.x; e[4 * q + 1] = bb.y; e[4 * q + 2] = bb.z; e[4 * q + 3] = bb.w;
+                    }
+#pragma unroll
+                    for (int grp = 0; grp < 4; ++grp) {
+                        const float4 aw = wb4[NF4_IMG_A2 / 4 + grp * 64 + lane];
+                        const float as[4] = {aw.x, aw.y, aw.z, aw.w};
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
+                            e = __builtin_amdgcn_mfma_f32_32x32x2f32(as[s], nf_relu(d[grp * 4 + s]), e, 0, 0, 0);
+                    }
+                    v16f p;
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) p[v] = 0.0f;
+                    v4f pc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int grp = 0; grp < 4; ++grp) {
+                        const float4 aw = wb4[NF4_IMG_A3 / 4 + grp * 64 + lane];
+                        const float4 ac = wb4[NF4_IMG_A3C / 4 + grp * 8 + g * 4 + (lane & 3)];
+                        const float as[4] = {aw.x, aw.y, aw.z, aw.w};
+                        const float cs[4] = {ac.x, ac.y, ac.z, ac.w};
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) {
+                            const float h = nf_relu(e[grp * 4 + s]);
+                            p = __builtin_amdgcn_mfma_f32_32x32x2f32(as[s], h, p, 0, 0, 0);
+                            pc = __builtin_amdgcn_mfma_f32_4x4x1f32(cs[s], h, pc, 0, 0, 0);
+                        }
+                    }
+                    // horizontal part of the shift-add.  Register group a of lane half g' holds the taps
+                    //   a=0: (0,0)|(2,0) -> from the left   a=1: (0,2)|(2,2) -> from the right
+                    //   a=2: (0,1)|(2,1) -> in place         a=3: (1,0)|(1,2) -> left | right
+                    float rm[4];   // g'=0: R[.][di=0] (goes one row down), g'=1: R[.][di=2] (goes one row up)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float x0 = from_prev(p[j], lane), x1 = from_next(p[4 + j], lane);
+                        const float yl = from_prev(p[12 + j], lane), yr = from_next(p[12 + j], lane);
+                        rm[j] = (has_left ? x0 : 0.0f) + (has_right ? x1 : 0.0f) + p[8 + j];
+                        const float y = g ? (has_right ? yr : 0.0f) : (has_left ? yl : 0.0f);
+                        cp[k][j] += y + pc[j];
+                    }
+                    if (k + 1 < TPW && g == 0) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) cp[k + 1][j] += rm[j];
+                    }
+                    if (k > 0 && g == 1) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) cp[k - 1][j] += rm[j];
+                    }
+                    if (k == 0 && g == 1 && row0 > 0)
+                        *reinterpret_cast<float4 *>(exch + (w * 2 + 1) * 128 + n * 4) = make_float4(rm[0], rm[1], rm[2], rm[3]);
+                    if (k == TPW - 1 && g == 0 && row0 + TPW < H)
+                        *reinterpret_cast<float4 *>(exch + (w * 2 + 0) * 128 + n * 4) = make_float4(rm[0], rm[1], rm[2], rm[3]);
+                    if constexpr (TPR == 2) {
+                        // the column seam 31|32: the taps that cross it, raw, for the neighbour half's phase C
+                        float *sl = side + (0 * (H + 2) + r + 1) * 12, *sr = side + (1 * (H + 2) + r + 1) * 12;
+                        if (hf == 0 && n == 31) {   // (di,0) taps of pixel 31 belong to pixel 32
+                            if (g == 0) {
+                                *reinterpret_cast<float4 *>(sl + 0) = make_float4(p[0], p[1], p[2], p[3]);
+                                *reinterpret_cast<float4 *>(sl + 4) = make_float4(p[12], p[13], p[14], p[15]);
+                            } else {
+                                *reinterpret_cast<float4 *>(sl + 8) = make_float4(p[0], p[1], p[2], p[3]);
+                            }
+                        }
+                        if (hf == 1 && n == 0) {    // (di,2) taps of pixel 32 belong to pixel 31
+                            if (g == 0) {
+                                *reinterpret_cast<float4 *>(sr + 0) = make_float4(p[4], p[5], p[6], p[7]);
+                            } else {
+                                *reinterpret_cast<float4 *>(sr + 8) = make_float4(p[4], p[5], p[6], p[7]);
+                                *reinterpret_cast<float4 *>(sr + 4) = make_float4(p[12], p[13], p[14], p[15]);
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+
+                // ---- phase C: strip-boundary rows, border table, affine ----
+                const float scl = P[NF4_CPL_S + 1], m2scl = P[NF4_CPL_S + 2];
+#pragma unroll
+                for (int k = 0; k < TPW; ++k) {
+                    const int r = row0 + k;
+                    if (r >= H) continue;   // wave-uniform
+                    float o[4] = {cp[k][0], cp[k][1], cp[k][2], cp[k][3]};
+                    if (k == 0 && g == 0 && row0 > 0) {
+                        const float4 v = *reinterpret_cast<const float4 *>(exch + ((w - TPR) * 2 + 0) * 128 + n * 4);
+                        o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w;
+                    }
+                    if (k == TPW - 1 && g == 1 && row0 + TPW < H) {
+                        const float4 v = *reinterpret_cast<const float4 *>(exch + ((w + TPR) * 2 + 1) * 128 + n * 4);
+                        o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w;
+                    }
+                    if constexpr (TPR == 2) {
+                        if (g == 0 && ((hf == 1 && n == 0) || (hf == 0 && n == 31 && c + 1 < W))) {
+                            const float *sb = side + ((hf == 1 ? 0 : 1) * (H + 2) + r) * 12;   // rows r-1, r, r+1 at +0, +12, +24
+#pragma unroll
+                            for (int di = 0; di < 3; ++di) {
+                                const float4 v = *reinterpret_cast<const float4 *>(sb + di * 12 + di * 4);
+                                o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = half_sum(o[j]);
+                    const bool act = col_on;
+                    const int bm = (r == 0 ? 1 : 0) | (r == H - 1 ? 2 : 0) | (c == 0 ? 4 : 0) | (c == W - 1 ? 8 : 0);
+                    const float4 eb = *reinterpret_cast<const float4 *>(a.params + prog.ops[op].off + NF4_CPL_E + 4 * (act ? bm : 0));
+                    o[0] += eb.x; o[1] += eb.y; o[2] += eb.z; o[3] += eb.w;
+                    // raw columns are pre-scaled by 2 log2(e):  t = exp2(raw') = exp(2 raw);
+                    // ls*log2(e) = scl*tanh(raw) = scl - 2 scl/(t + 1); log-det accumulated in log2 units
+                    const float l0 = fmaf(__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(o[2]) + 1.0f), m2scl, scl);
+                    const float l1 = fmaf(__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(o[3]) + 1.0f), m2scl, scl);
+                    if (type == NF_OP_COUPLING_FWD) {
+                        z[k][2] = fmaf(z[k][2], __builtin_amdgcn_exp2f(l0), o[0]);
+                        z[k][3] = fmaf(z[k][3], __builtin_amdgcn_exp2f(l1), o[1]);
+                        if (act && lead) ld2 += l0 + l1;
+                    } else {
+                        z[k][2] = (z[k][2] - o[0]) * __builtin_amdgcn_exp2f(-l0);
+                        z[k][3] = (z[k][3] - o[1]) * __builtin_amdgcn_exp2f(-l1);
+                    }
+                }
+            } else if (type == NF_OP_SDN_DIV || type == NF_OP_SDN_MUL) {
+                // AffineCouplingSdnEx5: scale = sqrt(beta1*y/gain + beta2)  (cond_utils.py:238)
+                const float4 *y4 = reinterpret_cast<const float4 *>(a.y + patch_off);
+                const float ck1 = a.cond_a[prog.ops[op].off & 3], cb2 = a.cond_b[prog.ops[op].off & 3];
+#pragma unroll
+                for (int k = 0; k < TPW; ++k) {
+                    const int r = row0 + k;
+                    const bool act = r < H && col_on;
+                    float4 yv = make_float4(1.f, 1.f, 1.f, 1.f);
+                    if (act) yv = y4[r * W + c];
+                    const float yy[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float v = fmaf(yy[q], ck1, cb2);
+                        if (type == NF_OP_SDN_DIV) {
+                            z[k][q] = z[k][q] * __builtin_amdgcn_rsqf(v);
+                            if (act && lead) ld = fmaf(-0.34657359027997264f, __builtin_amdgcn_logf(v), ld);
+                        } else {
+                            z[k][q] = z[k][q] * __builtin_amdgcn_sqrtf(v);
+                        }
+                    }
+                }
+            } else if (type == NF_OP_SCALE || type == NF_OP_SCALE_COND) {
+                const float s = type == NF_OP_SCALE ? P[0] : a.cond_a[prog.ops[op].off & 3];
+#pragma unroll
+                for (int k = 0; k < TPW; ++k)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) z[k][q] *= s;
+            }
+        }
+
+        // ---- epilogue (as nf_flow_kernel) ----
+        if (a.out) {
+            float4 *out4 = reinterpret_cast<float4 *>(a.out + patch_off);
+#pragma unroll
+            for (int k = 0; k < TPW; ++k) {
+                const int r = row0 + k;
+                if (r < H && col_on && lead) out4[r * W + c] = make_float4(z[k][0], z[k][1], z[k][2], z[k][3]);
+            }
+        }
+        if (a.nll_out || a.sd_out || a.ld_out || a.sums) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < TPW; ++k)
+                if (row0 + k < H && col_on && lead) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        s1 += z[k][q];
+                        s2 = fmaf(z[k][q], z[k][q], s2);
+                    }
+                }
+            float r0 = wave_sum(fmaf(ld2, 0.6931471805599453f, ld)), r1 = wave_sum(s1), r2 = wave_sum(s2);
+            if (lane == 0) {
+                red[w] = r0;
+                red[NW + w] = r1;
+                red[2 * NW + w] = r2;
+            }
+            __syncthreads();
+            if (t == 0) {
+                r0 = 0.f; r1 = 0.f; r2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < NW; ++i) {
+                    r0 += red[i];
+                    r1 += red[NW + i];
+                    r2 += red[2 * NW + i];
+                }
+                const double npx = (double)HW * 4.0;
+                const double logdet = (double)r0 + a.ld_const;
+                double nll = -logdet;   // prior: sum -0.5*(log 2pi + z^2)   (noise_flow_model.py:537-539)
+                if (a.flags & NF_K_PRIOR) nll += 0.5 * npx * 1.8378770664093453 + 0.5 * (double)r2;
+                const double mean = (double)r1 / npx;
+                double var = (double)r2 / npx - mean * mean;   // noise_flow_model.py:477-478
+                var = var > 0.0 ? var : 0.0;
+                const double sd = sqrt(var);
+                if (a.nll_out) a.nll_out[b] = (float)nll;
+                if (a.sd_out) a.sd_out[b] = (float)sd;
+                if (a.ld_out) a.ld_out[b] = (float)logdet;
+                acc_nll += (double)(float)nll;
+                acc_sd += (double)(float)sd;
+            }
+            __syncthreads();   // scratch is reused by the next patch
+        }
+    }
+
+    if (a.sums && t == 0) {
+        double *sp = a.sums;
+        if (a.flags & NF_K_SUMS_WIDE) sp += (size_t)(blockIdx.x & (NF_SUMS_SLOTS - 1)) * NF_SUMS_STRIDE;
+        atomicAdd(&sp[0], acc_nll);
+        atomicAdd(&sp[1], acc_sd);
+        if (blockIdx.x == 0) atomicAdd(&sp[2], (double)a.B);
+    }
+}
+
+size_t wide_lds_bytes(int H, int W, int threads, int tpr)
+{
+    const int Wp = W + 2, PL = ((H + 2) * Wp + 3) & ~3, NW = threads / 64;
+    size_t f = 2 * (size_t)PL + NF4_IMG_SIZE + (size_t)NW * 256 + (tpr == 2 ? 2 * (size_t)(H + 2) * 12 : 0) + ((3 * NW + 3) & ~3);
+    return f * sizeof(float);
+}
+
+template <int THREADS, bool PHILOX, int TPR>
+hipError_t launch_wide(const NfProgram &prog, const NfLaunch &a, int n_cu, int device, hipStream_t stream)
+{
+    const size_t lds = wide_lds_bytes(a.H, a.W, THREADS, TPR);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    const void *fn = reinterpret_cast<const void *>(&nf_wide32_kernel<THREADS, PHILOX, TPR>);
+    // (device << 40 | lds bytes << 8 | resident workgroups per CU) of the last query; racy but idempotent
+    static std::atomic<uint64_t> cache{0};
+    const uint64_t key = ((uint64_t)(device & 0xff) << 40) | ((uint64_t)lds << 8);
+    uint64_t cv = cache.load(std::memory_order_relaxed);
+    int occ;
+    if ((cv & ~(uint64_t)0xff) == key && (cv & 0xff) != 0) {
+        occ = (int)(cv & 0xff);
+    } else {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+        }
+        occ = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, THREADS, lds);
+        if (e != hipSuccess) return e;
+        if (occ < 1) occ = 1;
+        if (occ > 32) occ = 32;
+        cache.store(key | (uint64_t)occ, std::memory_order_relaxed);
+    }
+    int64_t groups = (int64_t)n_cu * occ;
+    if (a.B < groups) groups = a.B;
+    if (groups < 1) groups = 1;
+    hipLaunchKernelGGL((nf_wide32_kernel<THREADS, PHILOX, TPR>), dim3((unsigned)groups), dim3(THREADS), lds, stream, prog, a);
+    return hipGetLastError();
+}
+
+template <bool PHILOX>
+hipError_t dispatch_wide(const NfProgram &prog, const NfLaunch &a, int n_cu, int device, hipStream_t stream)
+{
+    if (a.W <= 32) {
+        if (a.H <= 32) return launch_wide<256, PHILOX, 1>(prog, a, n_cu, device, stream);
+        return launch_wide<512, PHILOX, 1>(prog, a, n_cu, device, stream);
+    }
+    if (a.H <= 32) return launch_wide<512, PHILOX, 2>(prog, a, n_cu, device, stream);
+    return launch_wide<1024, PHILOX, 2>(prog, a, n_cu, device, stream);
+}
+
+}  // namespace
+
+// entry point used by nf_host.hip: programs in the NF4 layout (coupling width 32), patches up to 64x64
+hipError_t nf_launch_wide(const NfProgram &prog, const NfLaunch &a, int n_cu, int device, hipStream_t stream)
+{
+    if (prog.width != 32 || a.H < 1 || a.W < 1 || a.H > 64 || a.W > 64) return hipErrorInvalidValue;
+    if (a.flags & NF_K_PHILOX_IN) return dispatch_wide<true>(prog, a, n_cu, device, stream);
+    return dispatch_wide<false>(prog, a, n_cu, device, stream);
+}

@@ -1,0 +1,88 @@
+"""GPU parity of the wide coupling CNN (hps.width = 32, the paper-scale width of job_noise_flow.sh:19) on the
+f32 matrix cores (csrc/nf_wide.hip: v_mfma_f32_32x32x2_f32, strips of 8 rows per wavefront) against the fp64 oracle:
+full and ragged patch shapes up to 64x64 (one and two tiles per row, partial strips), both directions, in-kernel
+Philox.  Tolerances as everywhere: per-patch NLL 1e-5 relative, tensors 1e-5 of their scale."""
+import numpy as np
+import pytest
+
+from conftest import make_inputs, trained_like_variables
+
+pytestmark = pytest.mark.gpu
+
+NLL_RTOL = 1e-5
+ELEM_RTOL = 1e-5
+ARCH = "sdn5|unc|gain4|unc"
+
+
+def _model(arch, variables, x_shape, width):
+    from noise_flow_amd import NoiseFlow, default_hps
+    return NoiseFlow(list(x_shape), False, default_hps(arch=arch, width=width), variables=variables)
+
+
+def _close_elem(a, ref, rtol=ELEM_RTOL):
+    scale = np.abs(ref).max()
+    err = np.abs(np.asarray(a, np.float64) - ref).max()
+    assert err <= rtol * scale, "max err %.3e > %.1e * %.3e" % (err, rtol, scale)
+
+
+def _path(m, direction=0):
+    return m._flow.lib.nf_kernel_path(m._flow.ptr, direction)
+
+
+@pytest.mark.parametrize("hw", [(32, 32), (64, 64), (20, 28), (40, 50), (33, 64), (64, 33), (8, 32), (1, 1), (9, 33),
+                                (16, 16), (64, 32), (32, 64), (7, 5)])
+def test_wide32_matrix_core_kernel_matches_oracle(hw):
+    from noise_flow_amd import _lib
+    from oracle.nf_oracle import NoiseFlowOracle
+    H, W = hw
+    v = trained_like_variables(ARCH, 32, seed=H * 100 + W)
+    x, y = make_inputs(5, H, W, seed=3)
+    m = _model(ARCH, v, (H, W, 4), 32)
+    assert _path(m, 0) == _lib.NF_PATH_WIDE32 and _path(m, 1) == _lib.NF_PATH_WIDE32
+    o = NoiseFlowOracle(ARCH, v)
+    nll, sd = m._loss(x, y, [0.0], [0.0], [100], [2])
+    ref_nll, ref_sd, ref_z = o.nll(x, y, 100, 2)
+    np.testing.assert_allclose(nll, ref_nll, rtol=NLL_RTOL, atol=1e-4)
+    assert abs(sd - ref_sd) <= 1e-5 * ref_sd
+    z, obj = m.inverse(x, None, y, [0.0], [0.0], [100], [2])
+    _close_elem(z, ref_z)
+    eps = np.random.RandomState(4).randn(5, H, W, 4).astype(np.float32)
+    xs = m.sample(y, 0.8, y, [0.0], [0.0], [100], [2], eps=eps)
+    _close_elem(xs, o.sample(eps, 0.8, y, 100, 2))
+
+
+def test_wide32_full_arch_batch_and_round_trip():
+    """The shipped layer sequence at width 32, a batch larger than the resident grid (persistent stride loop),
+    slotted sums, and sample(nll(x)) = x."""
+    from conftest import FULL_ARCH
+    from oracle.nf_oracle import NoiseFlowOracle
+    v = trained_like_variables(FULL_ARCH, 32, seed=11)
+    for k in v:   # keep the 8-coupling stack as well conditioned at 32 channels as the helper's weights are at 4
+        if k.endswith("l_2/W") or k.endswith("l_last/W"):
+            v[k] = (v[k] * np.float32((4.0 / 32.0) ** 0.5)).astype(np.float32)
+    B = 1100
+    x, y = make_inputs(B, 32, 32, seed=5)
+    m = _model(FULL_ARCH, v, (32, 32, 4), 32)
+    nll, sd = m._loss(x, y, [0.0], [0.0], [100], [2])
+    idx = np.r_[0:8, B - 8:B]
+    ref_nll, _, ref_z = NoiseFlowOracle(FULL_ARCH, v).nll(x[idx], y[idx], 100, 2)
+    np.testing.assert_allclose(nll[idx], ref_nll, rtol=NLL_RTOL, atol=1e-4)
+    mean, _ = m.loss(x, y, [0.0], [0.0], [100], [2])
+    assert abs(float(mean) - float(np.mean(nll.astype(np.float64)))) <= 1e-6 * abs(float(mean))
+    z, _ = m.inverse(x, None, y, [0.0], [0.0], [100], [2])
+    _close_elem(z[idx], ref_z)
+    x2 = m.forward(z, None, y, [0.0], [0.0], [100], [2])
+    assert np.abs(x2 - x).max() <= 1e-5 * np.abs(x).max()
+
+
+def test_wide32_in_kernel_philox_matches_numpy_philox():
+    from oracle import philox
+    from oracle.nf_oracle import NoiseFlowOracle
+    v = trained_like_variables(ARCH, 32, seed=21)
+    H, W, B = 24, 40, 4
+    _, y = make_inputs(B, H, W, seed=9)
+    m = _model(ARCH, v, (H, W, 4), 32)
+    xs = m.sample(y, 0.7, y, [0.0], [0.0], [100], [2], seed=77)
+    eps = philox.sample_eps(77, 0, B, H, W)
+    ref = NoiseFlowOracle(ARCH, v).sample(eps, 0.7, y, 100, 2)
+    _close_elem(xs, ref, rtol=3e-5)   # Box-Muller on the hardware transcendental unit: ~1e-6 absolute on eps
