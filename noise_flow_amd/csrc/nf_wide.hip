@@ -34,31 +34,57 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 
 constexpr int TPW = 8;   // tiles (= rows of a strip) per wavefront
 
-// value of the lane one pixel to the left / right inside the 32-lane tile half (callers mask the ends)
+// tuning knobs (A/B builds): re-read the A operands per tile instead of holding all 57 live; occupancy target
+#ifndef NF_WIDE_CLOBBER
+#define NF_WIDE_CLOBBER 0
+#endif
+#ifndef NF_WIDE_WPE
+#define NF_WIDE_WPE 3
+#endif
+
+// value of the lane one pixel to the left / right (callers multiply the tile ends away: lane 32 receives lane 31's
+// value and vice versa).  NF_WIDE_DPP=1: DPP wave_shr:1 / wave_shl:1 — a VALU operand modifier, no LDS traffic and no
+// address register; 0: ds_bpermute.
+#ifndef NF_WIDE_DPP
+#define NF_WIDE_DPP 1
+#endif
 __device__ __forceinline__ float from_prev(float x, int lane)
 {
+#if NF_WIDE_DPP
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x138, 0xf, 0xf, true));
+#else
     return __int_as_float(__builtin_amdgcn_ds_bpermute((lane - 1) << 2, __float_as_int(x)));
+#endif
 }
 __device__ __forceinline__ float from_next(float x, int lane)
 {
+#if NF_WIDE_DPP
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x130, 0xf, 0xf, true));
+#else
     return __int_as_float(__builtin_amdgcn_ds_bpermute((lane + 1) << 2, __float_as_int(x)));
+#endif
 }
-// x(lanes 0-31) + x(lanes 32-63) on every lane: the two halves hold partial sums of the same pixel
-__device__ __forceinline__ float half_sum(float x)
+// a(lanes 0-31) + a(lanes 32-63) in the low half, b(lanes 0-31) + b(lanes 32-63) in the high half: the two lane
+// halves hold partial sums of the same pixels; the low half finishes tile `a`, the high half tile `b` — one
+// v_permlane32_swap + one add for two tiles
+__device__ __forceinline__ float half_sums(float a, float b)
 {
-    const unsigned u = __float_as_uint(x);
-    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
 //   THREADS  64 x number of strips: (rows / 8) x TPR
 //   PHILOX   input = in-kernel Philox/Box-Muller draw
 //   TPR      tiles per image row: 1 (W <= 32) or 2 (W <= 64)
+// Pixel ownership: the CNN of a tile needs all 64 lanes (lane half g = K slice), everything else is per pixel —
+// so lane half g OWNS the rows row0 + 2m + g (m = 0..3) of its strip: their 4 channel values live in its registers,
+// it does their global I/O, 1x1 mixes, signal-dependent scaling, affine update and log-det.
 template <int THREADS, bool PHILOX, int TPR>
-__global__ __launch_bounds__(THREADS) void nf_wide32_kernel(const NfProgram prog, const NfLaunch a)
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS == 256 ? NF_WIDE_WPE : 1))) void nf_wide32_kernel(const NfProgram prog, const NfLaunch a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NW = THREADS / 64;
+    constexpr int OWN = TPW / 2;
     const int H = a.H, W = a.W, HW = H * W;
     const int Wp = W + 2;
     const int PL = ((H + 2) * Wp + 3) & ~3;             // one channel plane of the z0 tile
@@ -73,9 +99,10 @@ __global__ __launch_bounds__(THREADS) void nf_wide32_kernel(const NfProgram prog
     const int rg = w / TPR, hf = w % TPR;
     const int row0 = rg * TPW, c = hf * 32 + n;
     const bool col_on = c < W;
-    const bool has_left = n > 0;                         // the seam neighbour of a 64-wide row arrives through `side`
-    const bool has_right = n < 31 && c + 1 < W;
-    const bool lead = g == 0;                            // one of the two lanes of a pixel does the global I/O and the sums
+    // 0/1 multipliers: the seam neighbour of a 64-wide row arrives through `side`, not through a lane shift
+    const float ml = n > 0 ? 1.0f : 0.0f, mr = (n < 31 && c + 1 < W) ? 1.0f : 0.0f;
+    const float mg0 = g == 0 ? 1.0f : 0.0f, mg1 = g == 1 ? 1.0f : 0.0f;
+    const float ml0 = ml * mg0, mr1 = mr * mg1;
 
     for (int i = t; i < 2 * PL + NF4_IMG_SIZE + NW * 256 + (TPR == 2 ? 2 * (H + 2) * 12 : 0); i += THREADS) smem[i] = 0.0f;
     __syncthreads();
@@ -86,23 +113,23 @@ __global__ __launch_bounds__(THREADS) void nf_wide32_kernel(const NfProgram prog
     for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
         const size_t patch_off = (size_t)b * (size_t)HW * 4u;
 
-        float z[TPW][4];
+        float z[OWN][4];
 #pragma unroll
-        for (int k = 0; k < TPW; ++k) {
-            const int r = row0 + k;
+        for (int m = 0; m < OWN; ++m) {
+            const int r = row0 + 2 * m + g;
             const bool act = r < H && col_on;
             const int gi = act ? r * W + c : 0;
             if (PHILOX) {
-                philox_normal4(a.seed, a.patch_base + b, (uint32_t)gi, NF_STREAM_SAMP, z[k]);
+                philox_normal4(a.seed, a.patch_base + b, (uint32_t)gi, NF_STREAM_SAMP, z[m]);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) z[k][q] *= a.in_scale;
+                for (int q = 0; q < 4; ++q) z[m][q] *= a.in_scale;
             } else {
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (act) v = reinterpret_cast<const float4 *>(a.in + patch_off)[gi];
-                z[k][0] = v.x * a.in_scale;
-                z[k][1] = v.y * a.in_scale;
-                z[k][2] = v.z * a.in_scale;
-                z[k][3] = v.w * a.in_scale;
+                z[m][0] = v.x * a.in_scale;
+                z[m][1] = v.y * a.in_scale;
+                z[m][2] = v.z * a.in_scale;
+                z[m][3] = v.w * a.in_scale;
             }
         }
 
@@ -113,29 +140,32 @@ __global__ __launch_bounds__(THREADS) void nf_wide32_kernel(const NfProgram prog
             const cfloat_p P = (cfloat_p)(a.params + prog.ops[op].off);   // wave-uniform, scalar loads
 
             if (type == NF_OP_MIX) {
-                float m[16];
+                float mm[16];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) m[i] = P[i];
+                for (int i = 0; i < 16; ++i) mm[i] = P[i];
 #pragma unroll
-                for (int k = 0; k < TPW; ++k) {
+                for (int m = 0; m < OWN; ++m) {
                     float o[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        float s = z[k][0] * m[j];
-                        s = fmaf(z[k][1], m[4 + j], s);
-                        s = fmaf(z[k][2], m[8 + j], s);
-                        s = fmaf(z[k][3], m[12 + j], s);
+                        float s = z[m][0] * mm[j];
+                        s = fmaf(z[m][1], mm[4 + j], s);
+                        s = fmaf(z[m][2], mm[8 + j], s);
+                        s = fmaf(z[m][3], mm[12 + j], s);
                         o[j] = s;
                     }
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) z[k][j] = o[j];
+                    for (int j = 0; j < 4; ++j) z[m][j] = o[j];
                 }
             } else if (type == NF_OP_COUPLING_FWD || type == NF_OP_COUPLING_REV) {
                 // ---- phase A: publish the pass-through half, stage this coupling's weights ----
 #pragma unroll
-                for (int k = 0; k < TPW; ++k) {
-                    const int r = row0 + k;
-                    if (r < H && col_on) z0s[g * PL + (r + 1) * Wp + c + 1] = g ? z[k][1] : z[k][0];
+                for (int m = 0; m < OWN; ++m) {
+                    const int r = row0 + 2 * m + g;
+                    if (r < H && col_on) {
+                        z0s[(r + 1) * Wp + c + 1] = z[m][0];
+                        z0s[PL + (r + 1) * Wp + c + 1] = z[m][1];
+                    }
                 }
                 {
                     const float4 *src = reinterpret_cast<const float4 *>(a.params + prog.ops[op].off + NF4_CPL_IMG);
@@ -155,8 +185,7 @@ __global__ __launch_bounds__(THREADS) void nf_wide32_kernel(const NfProgram prog
                 for (int k = 0; k < TPW; ++k) {
                     const int r = row0 + k;
                     if (r >= H) continue;   // wave-uniform
-                    // 16 waves per CU leave 128 VGPRs: keep the compiler from holding all 57 A operands live across tiles
-                    if constexpr (THREADS == 1024) asm volatile("" ::: "memory");
+                    if constexpr (NF_WIDE_CLOBBER) asm volatile("" ::: "memory");
                     v16f d;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
@@ -211,19 +240,16 @@ __global__ __launch_bounds__(THREADS) void nf_wide32_kernel(const NfProgram prog
                     float rm[4];   // g'=0: R[.][di=0] (goes one row down), g'=1: R[.][di=2] (goes one row up)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float x0 = from_prev(p[j], lane), x1 = from_next(p[4 + j], lane);
-                        const float yl = from_prev(p[12 + j], lane), yr = from_next(p[12 + j], lane);
-                        rm[j] = (has_left ? x0 : 0.0f) + (has_right ? x1 : 0.0f) + p[8 + j];
-                        const float y = g ? (has_right ? yr : 0.0f) : (has_left ? yl : 0.0f);
-                        cp[k][j] += y + pc[j];
+                        rm[j] = fmaf(from_next(p[4 + j], lane), mr, fmaf(from_prev(p[j], lane), ml, p[8 + j]));
+                        cp[k][j] += fmaf(from_next(p[12 + j], lane), mr1, fmaf(from_prev(p[12 + j], lane), ml0, pc[j]));
                     }
-                    if (k + 1 < TPW && g == 0) {
+                    if (k + 1 < TPW) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) cp[k + 1][j] += rm[j];
+                        for (int j = 0; j < 4; ++j) cp[k + 1][j] = fmaf(rm[j], mg0, cp[k + 1][j]);
                     }
-                    if (k > 0 && g == 1) {
+                    if (k > 0) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) cp[k - 1][j] += rm[j];
+                        for (int j = 0; j < 4; ++j) cp[k - 1][j] = fmaf(rm[j], mg1, cp[k - 1][j]);
                     }
                     if (k == 0 && g == 1 && row0 > 0)
                         *reinterpret_cast<float4 *>(exch + (w * 2 + 1) * 128 + n * 4) = make_float4(rm[0], rm[1], rm[2], rm[3]);
@@ -252,34 +278,38 @@ __global__ __launch_bounds__(THREADS) void nf_wide32_kernel(const NfProgram prog
                 }
                 __syncthreads();
 
-                // ---- phase C: strip-boundary rows, border table, affine ----
-                const float scl = P[NF4_CPL_S + 1], m2scl = P[NF4_CPL_S + 2];
+                // ---- phase C: strip-boundary rows, column seam, then each lane half finishes the rows it owns ----
+                if (row0 > 0 && g == 0) {
+                    const float4 v = *reinterpret_cast<const float4 *>(exch + ((w - TPR) * 2 + 0) * 128 + n * 4);
+                    cp[0][0] += v.x; cp[0][1] += v.y; cp[0][2] += v.z; cp[0][3] += v.w;
+                }
+                if (row0 + TPW < H && g == 1) {
+                    const float4 v = *reinterpret_cast<const float4 *>(exch + ((w + TPR) * 2 + 1) * 128 + n * 4);
+                    cp[TPW - 1][0] += v.x; cp[TPW - 1][1] += v.y; cp[TPW - 1][2] += v.z; cp[TPW - 1][3] += v.w;
+                }
+                if constexpr (TPR == 2) {
+                    if (g == 0 && ((hf == 1 && n == 0) || (hf == 0 && n == 31))) {
 #pragma unroll
-                for (int k = 0; k < TPW; ++k) {
-                    const int r = row0 + k;
-                    if (r >= H) continue;   // wave-uniform
-                    float o[4] = {cp[k][0], cp[k][1], cp[k][2], cp[k][3]};
-                    if (k == 0 && g == 0 && row0 > 0) {
-                        const float4 v = *reinterpret_cast<const float4 *>(exch + ((w - TPR) * 2 + 0) * 128 + n * 4);
-                        o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w;
-                    }
-                    if (k == TPW - 1 && g == 1 && row0 + TPW < H) {
-                        const float4 v = *reinterpret_cast<const float4 *>(exch + ((w + TPR) * 2 + 1) * 128 + n * 4);
-                        o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w;
-                    }
-                    if constexpr (TPR == 2) {
-                        if (g == 0 && ((hf == 1 && n == 0) || (hf == 0 && n == 31 && c + 1 < W))) {
+                        for (int k = 0; k < TPW; ++k) {
+                            const int r = row0 + k;
+                            if (r >= H) continue;
                             const float *sb = side + ((hf == 1 ? 0 : 1) * (H + 2) + r) * 12;   // rows r-1, r, r+1 at +0, +12, +24
 #pragma unroll
                             for (int di = 0; di < 3; ++di) {
                                 const float4 v = *reinterpret_cast<const float4 *>(sb + di * 12 + di * 4);
-                                o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w;
+                                cp[k][0] += v.x; cp[k][1] += v.y; cp[k][2] += v.z; cp[k][3] += v.w;
                             }
                         }
                     }
+                }
+                const float scl = P[NF4_CPL_S + 1], m2scl = P[NF4_CPL_S + 2];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = half_sum(o[j]);
-                    const bool act = col_on;
+                for (int m = 0; m < OWN; ++m) {
+                    const int r = row0 + 2 * m + g;
+                    float o[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = half_sums(cp[2 * m][j], cp[2 * m + 1][j]);
+                    const bool act = r < H && col_on;
                     const int bm = (r == 0 ? 1 : 0) | (r == H - 1 ? 2 : 0) | (c == 0 ? 4 : 0) | (c == W - 1 ? 8 : 0);
                     const float4 eb = *reinterpret_cast<const float4 *>(a.params + prog.ops[op].off + NF4_CPL_E + 4 * (act ? bm : 0));
                     o[0] += eb.x; o[1] += eb.y; o[2] += eb.z; o[3] += eb.w;
@@ -288,12 +318,12 @@ __global__ __launch_bounds__(THREADS) void nf_wide32_kernel(const NfProgram prog
                     const float l0 = fmaf(__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(o[2]) + 1.0f), m2scl, scl);
                     const float l1 = fmaf(__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(o[3]) + 1.0f), m2scl, scl);
                     if (type == NF_OP_COUPLING_FWD) {
-                        z[k][2] = fmaf(z[k][2], __builtin_amdgcn_exp2f(l0), o[0]);
-                        z[k][3] = fmaf(z[k][3], __builtin_amdgcn_exp2f(l1), o[1]);
-                        if (act && lead) ld2 += l0 + l1;
+                        z[m][2] = fmaf(z[m][2], __builtin_amdgcn_exp2f(l0), o[0]);
+                        z[m][3] = fmaf(z[m][3], __builtin_amdgcn_exp2f(l1), o[1]);
+                        if (act) ld2 += l0 + l1;
                     } else {
-                        z[k][2] = (z[k][2] - o[0]) * __builtin_amdgcn_exp2f(-l0);
-                        z[k][3] = (z[k][3] - o[1]) * __builtin_amdgcn_exp2f(-l1);
+                        z[m][2] = (z[m][2] - o[0]) * __builtin_amdgcn_exp2f(-l0);
+                        z[m][3] = (z[m][3] - o[1]) * __builtin_amdgcn_exp2f(-l1);
                     }
                 }
             } else if (type == NF_OP_SDN_DIV || type == NF_OP_SDN_MUL) {
@@ -301,8 +331,8 @@ __global__ __launch_bounds__(THREADS) void nf_wide32_kernel(const NfProgram prog
                 const float4 *y4 = reinterpret_cast<const float4 *>(a.y + patch_off);
                 const float ck1 = a.cond_a[prog.ops[op].off & 3], cb2 = a.cond_b[prog.ops[op].off & 3];
 #pragma unroll
-                for (int k = 0; k < TPW; ++k) {
-                    const int r = row0 + k;
+                for (int m = 0; m < OWN; ++m) {
+                    const int r = row0 + 2 * m + g;
                     const bool act = r < H && col_on;
                     float4 yv = make_float4(1.f, 1.f, 1.f, 1.f);
                     if (act) yv = y4[r * W + c];
@@ -311,19 +341,19 @@ __global__ __launch_bounds__(THREADS) void nf_wide32_kernel(const NfProgram prog
                     for (int q = 0; q < 4; ++q) {
                         const float v = fmaf(yy[q], ck1, cb2);
                         if (type == NF_OP_SDN_DIV) {
-                            z[k][q] = z[k][q] * __builtin_amdgcn_rsqf(v);
-                            if (act && lead) ld = fmaf(-0.34657359027997264f, __builtin_amdgcn_logf(v), ld);
+                            z[m][q] = z[m][q] * __builtin_amdgcn_rsqf(v);
+                            if (act) ld = fmaf(-0.34657359027997264f, __builtin_amdgcn_logf(v), ld);
                         } else {
-                            z[k][q] = z[k][q] * __builtin_amdgcn_sqrtf(v);
+                            z[m][q] = z[m][q] * __builtin_amdgcn_sqrtf(v);
                         }
                     }
                 }
             } else if (type == NF_OP_SCALE || type == NF_OP_SCALE_COND) {
                 const float s = type == NF_OP_SCALE ? P[0] : a.cond_a[prog.ops[op].off & 3];
 #pragma unroll
-                for (int k = 0; k < TPW; ++k)
+                for (int m = 0; m < OWN; ++m)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) z[k][q] *= s;
+                    for (int q = 0; q < 4; ++q) z[m][q] *= s;
             }
         }
 
@@ -331,20 +361,20 @@ __global__ __launch_bounds__(THREADS) void nf_wide32_kernel(const NfProgram prog
         if (a.out) {
             float4 *out4 = reinterpret_cast<float4 *>(a.out + patch_off);
 #pragma unroll
-            for (int k = 0; k < TPW; ++k) {
-                const int r = row0 + k;
-                if (r < H && col_on && lead) out4[r * W + c] = make_float4(z[k][0], z[k][1], z[k][2], z[k][3]);
+            for (int m = 0; m < OWN; ++m) {
+                const int r = row0 + 2 * m + g;
+                if (r < H && col_on) out4[r * W + c] = make_float4(z[m][0], z[m][1], z[m][2], z[m][3]);
             }
         }
         if (a.nll_out || a.sd_out || a.ld_out || a.sums) {
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-            for (int k = 0; k < TPW; ++k)
-                if (row0 + k < H && col_on && lead) {
+            for (int m = 0; m < OWN; ++m)
+                if (row0 + 2 * m + g < H && col_on) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        s1 += z[k][q];
-                        s2 = fmaf(z[k][q], z[k][q], s2);
+                        s1 += z[m][q];
+                        s2 = fmaf(z[m][q], z[m][q], s2);
                     }
                 }
             float r0 = wave_sum(fmaf(ld2, 0.6931471805599453f, ld)), r1 = wave_sum(s1), r2 = wave_sum(s2);

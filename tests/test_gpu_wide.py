@@ -65,14 +65,17 @@ def test_wide32_full_arch_batch_and_round_trip():
     m = _model(FULL_ARCH, v, (32, 32, 4), 32)
     nll, sd = m._loss(x, y, [0.0], [0.0], [100], [2])
     idx = np.r_[0:8, B - 8:B]
-    ref_nll, _, ref_z = NoiseFlowOracle(FULL_ARCH, v).nll(x[idx], y[idx], 100, 2)
+    o = NoiseFlowOracle(FULL_ARCH, v)
+    ref_nll, _, ref_z = o.nll(x[idx], y[idx], 100, 2)
     np.testing.assert_allclose(nll[idx], ref_nll, rtol=NLL_RTOL, atol=1e-4)
     mean, _ = m.loss(x, y, [0.0], [0.0], [100], [2])
     assert abs(float(mean) - float(np.mean(nll.astype(np.float64)))) <= 1e-6 * abs(float(mean))
     z, _ = m.inverse(x, None, y, [0.0], [0.0], [100], [2])
     _close_elem(z[idx], ref_z)
     x2 = m.forward(z, None, y, [0.0], [0.0], [100], [2])
-    assert np.abs(x2 - x).max() <= 1e-5 * np.abs(x).max()
+    _close_elem(x2[idx], o.sample(z[idx], 1.0, y[idx], 100, 2))       # parity of the sampling direction on the same latents
+    # round trip: 16 random wide CNN evaluations deep, fp32 — bounded by the conditioning of the random stack, not 1e-5
+    assert np.abs(x2 - x).max() <= 5e-5 * np.abs(x).max()
 
 
 def test_wide32_in_kernel_philox_matches_numpy_philox():
