@@ -103,7 +103,7 @@ def parse_args():
 def _kernel_source_sha() -> str:
     """Content hash of the kernel sources a PMC traffic measurement belongs to (the GPU box has no .git)."""
     h = hashlib.sha256()
-    for name in ("nf_kernels.hip", "nf_device.h"):
+    for name in ("nf_kernels.hip", "nf_device.h", "nf_dev_util.h"):
         with open(os.path.join(ROOT, "noise_flow_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -420,12 +420,12 @@ def _two_streams(ctx, batches, cond, wide):
                         wide2.data_ptr(), _lib.NF_ACCUMULATE | _lib.NF_SUMS_WIDE, int(side[i & 1].cuda_stream))
         if rc != 0:
             _lib.check(rc)
-    for i in range(max(args.warmup, 50)):
+    for i in range(max(args.warmup, 500)):
         step(i)
     torch.cuda.synchronize(dev)
     wide2.zero_()
     torch.cuda.synchronize(dev)
-    K2 = max(K, 200)
+    K2 = max(K, 1000)
     t2 = time.perf_counter()
     for i in range(K2):
         step(i)

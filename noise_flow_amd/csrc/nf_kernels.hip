@@ -29,8 +29,21 @@
 #ifndef NF_PRIO
 #define NF_PRIO 2
 #endif
+// NF_FAIR: progress-based wave priority.  A SIMD arbitrates its resident waves oldest-first, so of the 4 workgroups
+// that share a CU the oldest runs ahead and the youngest starves: at B = 1024 (one patch per workgroup) workgroup
+// lifetimes spread 37..57 us around a 48 us mean and the launch lasts as long as the slowest one (tools/timeline.py).
+// Lowering a wave's priority as it advances through the couplings (3,3,2,2,1,1,0,0) is a negative feedback that keeps
+// co-resident workgroups level.  0 = off (MFMA bursts at NF_PRIO, the round-1 behaviour).
+#ifndef NF_FAIR
+#define NF_FAIR 1
+#endif
+#if NF_FAIR
+#define NF_PRIO_UP()   do { } while (0)
+#define NF_PRIO_DOWN() do { } while (0)
+#else
 #define NF_PRIO_UP()   do { if (NF_PRIO) __builtin_amdgcn_s_setprio(NF_PRIO); } while (0)
 #define NF_PRIO_DOWN() do { if (NF_PRIO) __builtin_amdgcn_s_setprio(0); } while (0)
+#endif
 // occupancy target (waves per SIMD) the register allocator must honour, per geometry
 #ifndef NF_WPE_512
 #define NF_WPE_512 5
@@ -38,7 +51,20 @@
 #ifndef NF_WPE_256
 #define NF_WPE_256 3
 #endif
+// warm-up touches before the LDS set-up: every NF_WARM_STEP-th owned pixel (2x2-blocked lanes: 2 = one per image row)
+#ifndef NF_WARM_STEP
+#define NF_WARM_STEP 2
+#endif
 #define NF_MIN_WAVES(T, P, M) (((T) == 512 && (P) == 2 && (M)) ? NF_WPE_512 : ((T) == 256 && (P) == 4 && (M)) ? NF_WPE_256 : 1)
+
+// Instrumented build (-DNF_TIMELINE, tools/timeline.py only): thread 0 of every workgroup stamps the 100 MHz
+// s_memrealtime counter at the phase boundaries of its MIDDLE patch (the first one when it has one) into NfLaunch::sd_out, reinterpreted as
+// int64[grid][16] (sd_z is not written in this build).
+#ifdef NF_TIMELINE
+#define NF_STAMP(i) do { if (t == 0 && stamp_on) reinterpret_cast<long long *>(a.sd_out)[(size_t)blockIdx.x * 16 + (i)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define NF_STAMP(i) do { } while (0)
+#endif
 
 namespace {
 
@@ -100,6 +126,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
 
     const int t = threadIdx.x;
     const int j4 = t & 3;   // MFMA: which output channel's weights this lane feeds as the A operand
+    [[maybe_unused]] bool stamp_on = true;
+    [[maybe_unused]] int64_t stamp_it = 0;
+    NF_STAMP(0);
 
     // Pixel ownership.
     //  * default: pixel p of the patch belongs to thread p % THREADS (slot p / THREADS);
@@ -143,27 +172,58 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
     // Touch the first patch's inputs before the LDS set-up below: with one patch per workgroup (B = the
     // resident capacity) every workgroup would otherwise sit through the set-up and THEN through the HBM
     // latency of its first loads, all at the same time.  The values are discarded; the real loads hit L2.
-    float4 warm_x = make_float4(0.f, 0.f, 0.f, 0.f), warm_y = warm_x;
-#ifndef NF_NO_WARM
+    // The first patch's x goes straight into registers and y gets one touch per image row of the lane's 2x2 block
+    // (the values are discarded; the real loads of the sdn layer hit L2) — both in flight during the set-up.
+    float warm = 0.0f;
+    float4 zin[PX];   // raw x of the NEXT patch this workgroup evaluates (software prefetch across the patch loop)
+#pragma unroll
+    for (int k = 0; k < PX; ++k) zin[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     if ((int64_t)blockIdx.x < a.B) {
         const size_t off0 = (size_t)blockIdx.x * (size_t)HW;
-        if (!PHILOX && act[0]) warm_x = reinterpret_cast<const float4 *>(a.in)[off0 + gidx[0]];
-        if (a.y && act[0]) warm_y = reinterpret_cast<const float4 *>(a.y)[off0 + gidx[0]];
-    }
+        if constexpr (!PHILOX) {
+#pragma unroll
+            for (int k = 0; k < PX; ++k)
+                if (act[k]) zin[k] = reinterpret_cast<const float4 *>(a.in)[off0 + gidx[k]];
+        }
+#ifndef NF_NO_WARM
+#pragma unroll
+        for (int k = 0; k < PX; k += NF_WARM_STEP)
+            if (a.y && act[k]) warm += reinterpret_cast<const float *>(a.y)[4 * (off0 + gidx[k])];
 #endif
+    }
 
-    // zero both tiles once: the 1-pixel border is never written again
-    for (int i = t; i < tile_px * TILE_WORDS; i += THREADS) smem[i] = 0.0f;
-    if (MFMA)
-        for (int i = t; i < a.n_params; i += THREADS) wl[i] = a.params[i];
+    // zero both tiles once (the 1-pixel border is never written again) and stage the weight image, 16 bytes per lane
+    {
+        const int nz4 = (tile_px * TILE_WORDS) >> 2;
+        float4 *const s4 = reinterpret_cast<float4 *>(smem);
+        for (int i = t; i < nz4; i += THREADS) s4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = (nz4 << 2) + t; i < tile_px * TILE_WORDS; i += THREADS) smem[i] = 0.0f;
+        if (MFMA) {
+            const int np4 = a.n_params >> 2;   // every section of the matrix-core layouts is a multiple of 4 floats
+            const float4 *const p4 = reinterpret_cast<const float4 *>(a.params);
+            float4 *const w4 = reinterpret_cast<float4 *>(wl);
+            for (int i = t; i < np4; i += THREADS) w4[i] = p4[i];
+            for (int i = (np4 << 2) + t; i < a.n_params; i += THREADS) wl[i] = a.params[i];
+        }
+    }
     __syncthreads();
-    asm volatile("" ::"v"(warm_x.x), "v"(warm_x.w), "v"(warm_y.x), "v"(warm_y.w));   // keep the warm-up loads
+    asm volatile("" ::"v"(warm));   // keep the warm-up loads
+    NF_STAMP(1);
 
     const int n_ops = prog.n_ops;
     double acc_nll = 0.0, acc_sd = 0.0;   // thread 0 only
+    [[maybe_unused]] int cpl_total = 0;
+#if NF_FAIR
+    for (int op = 0; op < n_ops; ++op)
+        cpl_total += (prog.ops[op].type == NF_OP_COUPLING_FWD || prog.ops[op].type == NF_OP_COUPLING_REV) ? 1 : 0;
+    if (cpl_total < 1) cpl_total = 1;
+#endif
 
     for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
         const size_t patch_off = (size_t)b * (size_t)HW * 4u;
+#ifdef NF_TIMELINE
+        stamp_on = stamp_it++ == (a.B / gridDim.x) / 2;
+#endif
 
         // ---- prologue: the 4 channels of each owned pixel -> registers ----
         float z[PX][4];
@@ -175,26 +235,28 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
                 for (int c = 0; c < 4; ++c) z[k][c] *= a.in_scale;
             }
         } else {
-            const float4 *in4 = reinterpret_cast<const float4 *>(a.in + patch_off);
 #pragma unroll
             for (int k = 0; k < PX; ++k) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (act[k]) v = in4[gidx[k]];
-                z[k][0] = v.x * a.in_scale;
-                z[k][1] = v.y * a.in_scale;
-                z[k][2] = v.z * a.in_scale;
-                z[k][3] = v.w * a.in_scale;
+                z[k][0] = zin[k].x * a.in_scale;
+                z[k][1] = zin[k].y * a.in_scale;
+                z[k][2] = zin[k].z * a.in_scale;
+                z[k][3] = zin[k].w * a.in_scale;
             }
         }
 
         float ld = 0.0f;    // this thread's share of the data-dependent log-det (natural log)
         float ld2 = 0.0f;   // ... and the part accumulated in log2 units (matrix-core couplings)
+        [[maybe_unused]] int n_cpl = 0;
+        [[maybe_unused]] int cpl_seen = 0;
 
         for (int op = 0; op < n_ops; ++op) {
             const int type = prog.ops[op].type;
             const cfloat_p P = (cfloat_p)(a.params + prog.ops[op].off);   // wave-uniform, scalar loads
 
             if (type == NF_OP_MIX) {
+#ifdef NF_TIMELINE
+                if (n_cpl == 0) { asm volatile("" ::"v"(z[0][0])); NF_STAMP(2); }   // inputs have arrived (first use after the sdn layer)
+#endif
                 // Conv2d1x1: per-pixel z <- z @ M   (layers.py:108-124)
                 if constexpr (MFMA) {
                     const float4 m = *reinterpret_cast<const float4 *>(wl + prog.ops[op].off + 4 * j4);   // M[0..3][j4]
@@ -229,6 +291,16 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
                 }
             } else if (type == NF_OP_COUPLING_FWD || type == NF_OP_COUPLING_REV) {
                 // ---- AffineCoupling (layers.py:275-291 / 355-375) ----
+#if NF_FAIR
+                if constexpr (MFMA) {
+                    const int lvl = (cpl_seen * 4) / cpl_total;   // 0 .. 3, wave-uniform
+                    ++cpl_seen;
+                    if (lvl == 0) __builtin_amdgcn_s_setprio(3);
+                    else if (lvl == 1) __builtin_amdgcn_s_setprio(2);
+                    else if (lvl == 2) __builtin_amdgcn_s_setprio(1);
+                    else __builtin_amdgcn_s_setprio(0);
+                }
+#endif
                 // 1) publish the pass-through half
 #pragma unroll
                 for (int k = 0; k < PX; ++k) {
@@ -608,6 +680,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
                         }
                     }
                 }
+#ifdef NF_TIMELINE
+                asm volatile("" ::"v"(z[0][2]));
+                if (n_cpl < 8) NF_STAMP(3 + n_cpl);
+                ++n_cpl;
+#endif
             } else if (type == NF_OP_SDN_DIV || type == NF_OP_SDN_MUL) {
                 // AffineCouplingSdnEx5: scale = sqrt(beta1*y/gain + beta2)  (cond_utils.py:238)
                 const float4 *y4 = reinterpret_cast<const float4 *>(a.y + patch_off);
@@ -636,6 +713,19 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
                 for (int k = 0; k < PX; ++k)
 #pragma unroll
                     for (int c = 0; c < 4; ++c) z[k][c] *= s;
+            }
+        }
+
+        // next patch's x: in flight during the epilogue
+        if constexpr (!PHILOX) {
+            const int64_t nb = b + gridDim.x;
+            const bool more = nb < a.B;
+            const float4 *in4 = reinterpret_cast<const float4 *>(a.in) + (size_t)(more ? nb : b) * (size_t)HW;
+#pragma unroll
+            for (int k = 0; k < PX; ++k) {   // assigned on every path: zin is dead across the body of the loop
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (more && act[k]) v = in4[gidx[k]];
+                zin[k] = v;
             }
         }
 
@@ -692,14 +782,18 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
                 const double mean = (double)r1 / n;
                 double var = (double)r2 / n - mean * mean;
                 var = var > 0.0 ? var : 0.0;
-                const double sd = sqrt(var);
+                // the result is rounded to fp32 anyway: v_sqrt_f32 (1 ulp) instead of the ~60-instruction fp64 routine
+                const double sd = (double)__builtin_amdgcn_sqrtf((float)var);
                 if (a.nll_out) a.nll_out[b] = (float)nll;
+#ifndef NF_TIMELINE
                 if (a.sd_out) a.sd_out[b] = (float)sd;
+#endif
                 if (a.ld_out) a.ld_out[b] = (float)logdet;
                 acc_nll += (double)(float)nll;
                 acc_sd += (double)(float)sd;
             }
         }
+        NF_STAMP(11);
     }
 
     if (a.sums && t == 0) {
@@ -711,6 +805,10 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
         atomicAdd(&sp[1], acc_sd);
         if (blockIdx.x == 0) atomicAdd(&sp[2], (double)a.B);
     }
+#ifdef NF_TIMELINE
+    stamp_on = true;
+    NF_STAMP(12);
+#endif
 }
 
 // fold the slotted sums into the plain (sum nll, sum sd, count) triple — one wavefront

@@ -1,4 +1,8 @@
-mkdir -p gpurun_out/r2d
-python -m pytest tests/test_gpu_wide.py -q 2>&1 | tail -4
-for v in w3 w2 nodpp; do echo "== $v"; NF_TOOL_LIB=noise_flow_amd/csrc/libnf_$v.so python tools/quick_time_wide.py 32 8192 32 2>&1 | grep nll; done
-echo "== default"; python tools/quick_time_wide.py 32 8192 32 | grep "nll\|sample"; python tools/quick_time_wide.py 32 1024 32 | grep nll;  python tools/quick_time_wide.py 32 1024 64 10 | grep nll
+python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+for i in 1 2; do
+NF_TOOL_LIB=noise_flow_amd/csrc/libnf_base.so python tools/ab_pool.py 1024 2000 | tail -1
+python tools/ab_pool.py 1024 2000 | tail -1
+done
+python tools/ab_pool.py 16384 200 | tail -1
+NF_TOOL_LIB=noise_flow_amd/csrc/libnf_base.so python tools/ab_pool.py 16384 200 | tail -1
+python tools/quick_time.py 4096 50

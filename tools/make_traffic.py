@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def source_sha():
     h = hashlib.sha256()
-    for name in ("nf_kernels.hip", "nf_device.h"):
+    for name in ("nf_kernels.hip", "nf_device.h", "nf_dev_util.h"):
         with open(os.path.join(ROOT, "noise_flow_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
