@@ -18,6 +18,7 @@ enum : int32_t {
     NF_OP_SDN_MUL      = 5,  // sampling: z <- z * sqrt(k1*y + b2)
     NF_OP_SCALE        = 6,  // z <- z * s               (1 float; un-folded gain layer)
     NF_OP_SCALE_COND   = 7,  // z <- z * cond_a[slot]    (per-call scalar: plain `gain` layer)
+    NF_OP_STORE        = 8,  // out <- z                 (checkpoint between the segments of a batch-statistics call)
 };
 
 struct NfOp {
@@ -162,7 +163,8 @@ struct NfLaunch {
     int32_t n_params;      // floats in the parameter block (matrix-core kernel stages it in LDS)
     // batch-statistics pass (scalar-weight kernel only): when `stats` is set the kernel stops at
     // coupling op `stats_op` and adds the per-channel sum / sum of squares of that layer's first
-    // (stage 1) or second (stage 2) pre-normalisation activation to stats[slot][2*width]
+    // (stage 1) or second (stage 2) pre-normalisation activation to stats[slot][2*width];
+    // an NF_OP_STORE before it writes the tensor at that point to `out`
     double *stats;
     int32_t stats_op;
     int32_t stats_stage;

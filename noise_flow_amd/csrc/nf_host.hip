@@ -27,6 +27,9 @@ hipError_t nf_launch_wide(const NfProgram &prog, const NfLaunch &a, int n_cu, in
 hipError_t nf_launch_synth(uint64_t seed, int64_t patch_base, int64_t B, int HW, float beta1, float beta2,
                            float *y_out, float *x_out, hipStream_t stream);
 hipError_t nf_launch_sums_reduce(const double *wide, double *out3, bool accumulate, hipStream_t stream);
+hipError_t nf_launch_bs_finalize(double *stats, int w, double n, float *Wm, int rows, float *Bv, float *mean_out, float *var_out,
+                                 hipStream_t stream);
+hipError_t nf_launch_gather(float *dst, const float *src, const int32_t *pairs, int n, hipStream_t stream);
 
 namespace {
 
@@ -641,6 +644,9 @@ int nf_fail(int code, const char *fmt, ...)
 
 int nf_fail_hip(hipError_t e, const char *what) { return fail_hip(e, what); }
 
+struct nf_bs_state;
+static void nf_bs_destroy(nf_bs_state *s);
+
 struct nf_handle {
     nf_config cfg;
     int device = 0;
@@ -658,9 +664,7 @@ struct nf_handle {
     std::vector<nf_layer_desc> layers;
     std::vector<float> raw;
     std::mutex bs_mu;
-    float *d_bs_params = nullptr;
-    double *d_bs_stats = nullptr;
-    size_t bs_cap = 0;
+    struct nf_bs_state *bs = nullptr;
 };
 
 extern "C" {
@@ -795,8 +799,7 @@ int nf_destroy(nf_handle *h)
     if (h->d_rev3) (void)hipFree(h->d_rev3);
     if (h->d_fwd4) (void)hipFree(h->d_fwd4);
     if (h->d_rev4) (void)hipFree(h->d_rev4);
-    if (h->d_bs_params) (void)hipFree(h->d_bs_params);
-    if (h->d_bs_stats) (void)hipFree(h->d_bs_stats);
+    nf_bs_destroy(h->bs);
     delete h;
     return NF_OK;
 }
@@ -945,117 +948,244 @@ int nf_sample(nf_handle *h, const float *y, const float *eps, uint64_t seed, int
 }
 
 // ---- batch-statistics mode (is_training=True graphs: layers.py:386-398) ----
-// The normalisation of every coupling CNN uses the moments of the CURRENT call's B patches, which
-// couples all patches: the moments of coupling c depend on the outputs of couplings < c under THEIR
-// batch moments.  So the call runs 2 statistics passes per coupling, in execution order (each one
-// re-runs the prefix with the moments found so far and an identity normalisation in the layer under
-// measurement), re-folds, and finishes with one ordinary fused pass.
+// The normalisation of every coupling CNN uses the moments of the CURRENT call's B patches, which couples all
+// patches: the moments of coupling c depend on the outputs of the couplings before it under THEIR batch moments.
+// The call therefore walks the couplings in execution order with the tensor in front of each one RESIDENT in HBM
+// (T_0 = the caller's input, T_c = the output of coupling c-1 in one of two scratch buffers); per coupling c
+//   launch A_c : [segment c-1 = the layers after coupling c-2 up to coupling c-1, with its moments; STORE T_c;] segment c, statistics of its l_1
+//   launch B_c : the same segment from T_c with BN_1 folded, statistics of its l_2
+// each followed by a one-workgroup kernel that turns the sums into moments and re-folds the layer IN PLACE on a
+// device-resident working copy of the parameter block (which starts as the identity-normalised model), and finally
+// one ordinary fused pass over the whole stack with all moments folded in.  2 short launches per coupling instead of
+// re-running the whole prefix, no host round trip until the moments are copied out at the end.
+struct BsPlan {
+    bool ready = false;
+    Built ident;                      // the model folded with an identity normalisation in every coupling CNN
+    float *d_ident = nullptr;         // ... on the device, scalar layout
+    float *d_ident2 = nullptr;        // ... matrix-core layout (null when unavailable)
+    std::vector<int> cpl_ops;         // op index of every coupling in ident.prog, execution order
+    std::vector<int> cpl_row;         // its row in moments_out (NLL layer order)
+    std::vector<NfProgram> progA, progB;
+    int32_t *d_pairs = nullptr;       // (dst in matrix-core block, src in scalar block) of the BN-dependent entries
+    int n_pairs = 0;
+};
+
+struct nf_bs_state {
+    BsPlan plan[2];
+    float *d_work = nullptr, *d_work2 = nullptr;   // working copies of the parameter block (scalar / matrix-core layout)
+    size_t work_cap = 0, work2_cap = 0;
+    double *d_stats = nullptr;
+    float *d_mom = nullptr;            // [couplings][4][w]
+    float *d_T[2] = {nullptr, nullptr};
+    size_t T_cap = 0;                  // floats per scratch tensor
+    ~nf_bs_state()
+    {
+        for (int d = 0; d < 2; ++d) {
+            if (plan[d].d_ident) (void)hipFree(plan[d].d_ident);
+            if (plan[d].d_ident2) (void)hipFree(plan[d].d_ident2);
+            if (plan[d].d_pairs) (void)hipFree(plan[d].d_pairs);
+        }
+        if (d_work) (void)hipFree(d_work);
+        if (d_work2) (void)hipFree(d_work2);
+        if (d_stats) (void)hipFree(d_stats);
+        if (d_mom) (void)hipFree(d_mom);
+        if (d_T[0]) (void)hipFree(d_T[0]);
+        if (d_T[1]) (void)hipFree(d_T[1]);
+    }
+};
+
+static int bs_build_plan(nf_handle *h, int direction, BsPlan &P)
+{
+    // identity normalisation in every coupling: mean 0, var 1 - eps  ->  scale exactly 1
+    std::vector<float> p = h->raw;
+    int n_cpl = 0;
+    for (int i = 0; i < h->cfg.n_layers; ++i) {
+        const nf_layer_desc &L = h->layers[i];
+        if (L.type != NF_LAYER_COUPLING) continue;
+        ++n_cpl;
+        const int w = L.width;
+        float *lp = p.data() + L.param_offset;
+        float *mv[4] = {lp + 19 * w, lp + 20 * w, lp + 22 * w + w * w, lp + 23 * w + w * w};
+        for (int j = 0; j < w; ++j) {
+            mv[0][j] = mv[2][j] = 0.0f;
+            mv[1][j] = mv[3][j] = (float)(1.0 - kBnEps);
+        }
+    }
+    int rc = build_program(&h->cfg, h->layers.data(), p.data(), p.size(), direction, P.ident);
+    if (rc != NF_OK) return rc;
+    const NfProgram &prog = P.ident.prog;
+    P.cpl_ops.clear();
+    for (int i = 0; i < prog.n_ops; ++i)
+        if (prog.ops[i].type == NF_OP_COUPLING_FWD || prog.ops[i].type == NF_OP_COUPLING_REV) P.cpl_ops.push_back(i);
+    if ((int)P.cpl_ops.size() != n_cpl) return fail(NF_EINVAL, "internal: batch-statistics plan mismatch");
+    P.cpl_row.resize(n_cpl);
+    for (int c = 0; c < n_cpl; ++c) P.cpl_row[c] = direction == 0 ? c : n_cpl - 1 - c;
+    P.progA.assign(n_cpl, NfProgram());
+    P.progB.assign(n_cpl, NfProgram());
+    for (int c = 0; c < n_cpl; ++c) {
+        NfProgram &A = P.progA[c], &B = P.progB[c];
+        memset(&A, 0, sizeof(A));
+        memset(&B, 0, sizeof(B));
+        A.width = B.width = prog.width;
+        const int first = c == 0 ? 0 : P.cpl_ops[c - 1] + 1;
+        if (c > 0) {   // segment c-1 (the layers after coupling c-2 up to and including coupling c-1), now with its moments
+            const int prev_first = c == 1 ? 0 : P.cpl_ops[c - 2] + 1;
+            if (P.cpl_ops[c - 1] - prev_first + 2 > NF_MAX_OPS) return fail(NF_EINVAL, "too many layers for the batch-statistics plan");
+            for (int i = prev_first; i <= P.cpl_ops[c - 1]; ++i) A.ops[A.n_ops++] = prog.ops[i];
+            A.ops[A.n_ops].type = NF_OP_STORE;
+            A.ops[A.n_ops++].off = 0;
+        }
+        if (A.n_ops + (P.cpl_ops[c] - first + 1) > NF_MAX_OPS) return fail(NF_EINVAL, "too many layers for the batch-statistics plan");
+        for (int i = first; i <= P.cpl_ops[c]; ++i) {
+            A.ops[A.n_ops++] = prog.ops[i];
+            B.ops[B.n_ops++] = prog.ops[i];
+        }
+    }
+    hipError_t e;
+    const size_t nb = P.ident.block.size() * sizeof(float);
+    if ((e = hipMalloc((void **)&P.d_ident, nb)) != hipSuccess ||
+        (e = hipMemcpy(P.d_ident, P.ident.block.data(), nb, hipMemcpyHostToDevice)) != hipSuccess)
+        return fail_hip(e, "batch-statistics plan upload");
+    if (!P.ident.block2.empty()) {
+        // the normalisation-dependent entries of the matrix-core layout are plain copies of scalar-layout entries
+        std::vector<int32_t> pairs;
+        const int w = 4;
+        for (int i = 0; i < prog.n_ops; ++i) {
+            if (prog.ops[i].type != NF_OP_COUPLING_FWD && prog.ops[i].type != NF_OP_COUPLING_REV) continue;
+            const int o1 = prog.ops[i].off, o2 = P.ident.prog2.ops[i].off;
+            for (int j = 0; j < 4; ++j) {
+                pairs.push_back(o2 + NF2_CPL_B1 + j); pairs.push_back(o1 + nf_cpl_off_B1(w) + j);
+                pairs.push_back(o2 + NF2_CPL_B2 + j); pairs.push_back(o1 + nf_cpl_off_B2(w) + j);
+                for (int di = 0; di < 3; ++di)
+                    for (int q = 0; q < 6; ++q) {
+                        pairs.push_back(o2 + NF2_CPL_W1T + 24 * j + 8 * di + q);
+                        pairs.push_back(o1 + nf_cpl_off_W1(w) + (di * 6 + q) * 4 + j);
+                    }
+                for (int i2 = 0; i2 < 4; ++i2) {
+                    pairs.push_back(o2 + NF2_CPL_W2T + 4 * j + i2);
+                    pairs.push_back(o1 + nf_cpl_off_W2(w) + i2 * 4 + j);
+                }
+            }
+        }
+        P.n_pairs = (int)(pairs.size() / 2);
+        const size_t nb2 = P.ident.block2.size() * sizeof(float);
+        if ((e = hipMalloc((void **)&P.d_ident2, nb2)) != hipSuccess ||
+            (e = hipMemcpy(P.d_ident2, P.ident.block2.data(), nb2, hipMemcpyHostToDevice)) != hipSuccess ||
+            (e = hipMalloc((void **)&P.d_pairs, pairs.size() * sizeof(int32_t))) != hipSuccess ||
+            (e = hipMemcpy(P.d_pairs, pairs.data(), pairs.size() * sizeof(int32_t), hipMemcpyHostToDevice)) != hipSuccess)
+            return fail_hip(e, "batch-statistics plan upload (matrix-core layout)");
+    }
+    P.ready = true;
+    return NF_OK;
+}
+
 static int run_batchstats(nf_handle *h, int direction, NfLaunch a, float *moments_out, hipStream_t st)
 {
     if (h->cfg.flags & NF_CFG_FP16_CNN) return fail(NF_EINVAL, "batch-statistics mode is fp32 only");
     std::lock_guard<std::mutex> lock(h->bs_mu);   // one scratch per handle: calls serialise
-    const size_t need = std::max(std::max(h->fwd.block.size(), h->rev.block.size()),
-                                 std::max(h->fwd.block2.size(), h->rev.block2.size()));
+    if (!h->bs) h->bs = new (std::nothrow) nf_bs_state();
+    if (!h->bs) return fail(NF_ENOMEM, "out of host memory");
+    nf_bs_state &S = *h->bs;
+    BsPlan &P = S.plan[direction];
     hipError_t e;
-    if (!h->d_bs_params &&
-        (e = hipMalloc((void **)&h->d_bs_params, need * sizeof(float))) != hipSuccess) {
-        h->d_bs_params = nullptr;
-        return fail_hip(e, "hipMalloc(batchstats params)");
+    if (!P.ready) {
+        int rc = bs_build_plan(h, direction, P);
+        if (rc != NF_OK) return rc;
     }
-    h->bs_cap = need;
-    if (!h->d_bs_stats &&
-        (e = hipMalloc((void **)&h->d_bs_stats, NF_STATS_SLOTS * 64 * sizeof(double))) != hipSuccess) {
-        h->d_bs_stats = nullptr;
-        return fail_hip(e, "hipMalloc(batchstats accumulators)");
+    const int n_cpl = (int)P.cpl_ops.size();
+    const int w = P.ident.prog.width;
+    const size_t nw1 = P.ident.block.size(), nw2 = P.ident.block2.size();
+    auto grow = [&](float *&ptr, size_t &cap, size_t need) -> hipError_t {
+        if (cap >= need) return hipSuccess;
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+        hipError_t er = hipMalloc((void **)&ptr, need * sizeof(float));
+        if (er == hipSuccess) cap = need;
+        return er;
+    };
+    if ((e = grow(S.d_work, S.work_cap, nw1)) != hipSuccess || (nw2 && (e = grow(S.d_work2, S.work2_cap, nw2)) != hipSuccess))
+        return fail_hip(e, "hipMalloc(batch-statistics parameters)");
+    if (!S.d_stats && (e = hipMalloc((void **)&S.d_stats, NF_STATS_SLOTS * 64 * sizeof(double))) != hipSuccess) {
+        S.d_stats = nullptr;
+        return fail_hip(e, "hipMalloc(batch-statistics accumulators)");
     }
-    std::vector<float> p = h->raw;
-    std::vector<int> cpl;   // coupling layers in execution order
-    for (int i = 0; i < h->cfg.n_layers; ++i)
-        if (h->layers[i].type == NF_LAYER_COUPLING) cpl.push_back(i);
-    if (direction == 1) std::reverse(cpl.begin(), cpl.end());
-    const double n = (double)a.B * a.H * a.W;
-    std::vector<double> acc(NF_STATS_SLOTS * 64);
-    const double ld_call = a.ld_const;
+    if (!S.d_mom && (e = hipMalloc((void **)&S.d_mom, (size_t)std::max(n_cpl, 1) * 4 * 32 * sizeof(float))) != hipSuccess) {
+        S.d_mom = nullptr;
+        return fail_hip(e, "hipMalloc(batch-statistics moments)");
+    }
+    const size_t tensor = (size_t)a.B * a.H * a.W * 4;
+    if (n_cpl > 1 && S.T_cap < tensor) {
+        for (int i = 0; i < 2; ++i) {
+            if (S.d_T[i]) (void)hipFree(S.d_T[i]);
+            S.d_T[i] = nullptr;
+        }
+        S.T_cap = 0;
+        if ((e = hipMalloc((void **)&S.d_T[0], tensor * sizeof(float))) != hipSuccess ||
+            (e = hipMalloc((void **)&S.d_T[1], tensor * sizeof(float))) != hipSuccess)
+            return fail_hip(e, "hipMalloc(batch-statistics scratch tensors)");
+        S.T_cap = tensor;
+    }
+    if ((e = hipMemcpyAsync(S.d_work, P.d_ident, nw1 * sizeof(float), hipMemcpyDeviceToDevice, st)) != hipSuccess ||
+        (nw2 && (e = hipMemcpyAsync(S.d_work2, P.d_ident2, nw2 * sizeof(float), hipMemcpyDeviceToDevice, st)) != hipSuccess) ||
+        (e = hipMemsetAsync(S.d_stats, 0, NF_STATS_SLOTS * 2 * (size_t)w * sizeof(double), st)) != hipSuccess)
+        return fail_hip(e, "batch-statistics set-up");
 
-    for (size_t c = 0; c < cpl.size(); ++c) {
-        const nf_layer_desc &L = h->layers[cpl[c]];
-        const int w = L.width;
-        float *lp = p.data() + L.param_offset;
-        float *mean1 = lp + 19 * w, *var1 = lp + 20 * w;
-        float *mean2 = lp + 22 * w + w * w, *var2 = lp + 23 * w + w * w;
+    const double n = (double)a.B * a.H * a.W;
+    const double ld_call = a.ld_const;
+    const float *const in0 = a.in;
+    const float in_scale0 = a.in_scale;
+    const uint32_t flags0 = a.flags;
+    for (int c = 0; c < n_cpl; ++c) {
+        const int blk = P.ident.prog.ops[P.cpl_ops[c]].off;
+        float *mom = S.d_mom + (size_t)P.cpl_row[c] * 4 * w;
         for (int stage = 1; stage <= 2; ++stage) {
-            float *mean = stage == 1 ? mean1 : mean2, *var = stage == 1 ? var1 : var2;
-            for (int j = 0; j < w; ++j) {
-                mean[j] = 0.0f;
-                var[j] = (float)(1.0 - kBnEps);   // identity: the kernel then sees the raw activation
-            }
-            Built b;
-            int rc = build_program(&h->cfg, h->layers.data(), p.data(), p.size(), direction, b);
-            if (rc != NF_OK) return rc;
-            int op_index = -1, seen = 0;
-            for (int i = 0; i < b.prog.n_ops; ++i)
-                if (b.prog.ops[i].type == NF_OP_COUPLING_FWD || b.prog.ops[i].type == NF_OP_COUPLING_REV)
-                    if (seen++ == (int)c) {
-                        op_index = i;
-                        break;
-                    }
-            if (op_index < 0 || b.block.size() > h->bs_cap) return fail(NF_EINVAL, "internal: batch-statistics program mismatch");
+            const NfProgram &prog = stage == 1 ? P.progA[c] : P.progB[c];
             NfLaunch s = a;
-            s.params = h->d_bs_params;
-            s.out = nullptr;
+            s.params = S.d_work;
+            s.n_params = 0;
             s.nll_out = s.sd_out = s.ld_out = nullptr;
             s.sums = nullptr;
-            s.stats = h->d_bs_stats;
-            s.stats_op = op_index;
+            s.stats = S.d_stats;
+            s.stats_op = prog.n_ops - 1;
             s.stats_stage = stage;
-            if ((e = hipMemcpyAsync(h->d_bs_params, b.block.data(), b.block.size() * sizeof(float), hipMemcpyHostToDevice, st)) != hipSuccess ||
-                (e = hipMemsetAsync(h->d_bs_stats, 0, NF_STATS_SLOTS * 2 * w * sizeof(double), st)) != hipSuccess)
-                return fail_hip(e, "batch-statistics upload");
-            if ((e = nf_launch_flow(b.prog, s, h->n_cu, st, false)) != hipSuccess) return fail_hip(e, "batch-statistics launch");
-            if ((e = hipMemcpyAsync(acc.data(), h->d_bs_stats, NF_STATS_SLOTS * 2 * w * sizeof(double), hipMemcpyDeviceToHost, st)) != hipSuccess ||
-                (e = hipStreamSynchronize(st)) != hipSuccess)
-                return fail_hip(e, "batch-statistics readback");
-            for (int j = 0; j < w; ++j) {
-                double sum = 0.0, sq = 0.0;
-                for (int slot = 0; slot < NF_STATS_SLOTS; ++slot) {
-                    sum += acc[(size_t)slot * 2 * w + j];
-                    sq += acc[(size_t)slot * 2 * w + w + j];
-                }
-                const double m = sum / n;
-                double v = sq / n - m * m;            // tf.nn.moments: population variance
-                if (v < 0.0) v = 0.0;
-                mean[j] = (float)m;
-                var[j] = (float)v;
-            }
-        }
-        if (moments_out) {
-            // rows follow the NLL layer order whatever the direction: [coupling][mean1|var1|mean2|var2][w]
-            size_t row = 0;
-            for (int i = 0; i < cpl[c]; ++i)
-                if (h->layers[i].type == NF_LAYER_COUPLING) ++row;
-            float *dst = moments_out + row * 4 * (size_t)w;
-            memcpy(dst, mean1, w * sizeof(float));
-            memcpy(dst + w, var1, w * sizeof(float));
-            memcpy(dst + 2 * w, mean2, w * sizeof(float));
-            memcpy(dst + 3 * w, var2, w * sizeof(float));
+            // launch A_c reads T_{c-1} (it re-runs coupling c-1), launch B_c reads T_c;  T_0 = the caller's input
+            const int tin = stage == 1 ? (c > 0 ? c - 1 : 0) : c;
+            const bool from_input = tin == 0;
+            s.in = from_input ? in0 : S.d_T[tin & 1];
+            s.in_scale = from_input ? in_scale0 : 1.0f;
+            s.flags = from_input ? flags0 : (flags0 & ~(uint32_t)NF_K_PHILOX_IN);
+            s.out = (stage == 1 && c > 0) ? S.d_T[c & 1] : nullptr;
+            if ((e = nf_launch_flow(prog, s, h->n_cu, st, false)) != hipSuccess) return fail_hip(e, "batch-statistics launch");
+            float *Wm = S.d_work + blk + (stage == 1 ? nf_cpl_off_W1(w) : nf_cpl_off_W2(w));
+            float *Bv = S.d_work + blk + (stage == 1 ? nf_cpl_off_B1(w) : nf_cpl_off_B2(w));
+            if ((e = nf_launch_bs_finalize(S.d_stats, w, n, Wm, stage == 1 ? 18 : w, Bv, mom + (stage == 1 ? 0 : 2 * w),
+                                           mom + (stage == 1 ? w : 3 * w), st)) != hipSuccess)
+                return fail_hip(e, "batch-statistics finalise");
         }
     }
 
-    // final pass with the batch moments folded in
-    Built b;
-    int rc = build_program(&h->cfg, h->layers.data(), p.data(), p.size(), direction, b);
-    if (rc != NF_OK) return rc;
-    const bool mc = !b.block2.empty() && b.block2.size() <= h->bs_cap && use_matrix_core();
-    const std::vector<float> &blk = mc ? b.block2 : b.block;
-    a.params = h->d_bs_params;
-    a.n_params = mc ? (int32_t)blk.size() : 0;
-    a.ld_const = ld_call + (direction == 0 ? b.ld_const : 0.0);
-    if ((e = hipMemcpyAsync(h->d_bs_params, blk.data(), blk.size() * sizeof(float), hipMemcpyHostToDevice, st)) != hipSuccess)
-        return fail_hip(e, "batch-statistics upload");
-    if ((e = nf_launch_flow(mc ? b.prog2 : b.prog, a, h->n_cu, st, mc)) != hipSuccess) return fail_hip(e, "batch-statistics final launch");
+    // final pass over the whole stack with the batch moments folded in
+    const bool mc = nw2 != 0 && use_matrix_core();
+    if (mc && (e = nf_launch_gather(S.d_work2, S.d_work, P.d_pairs, P.n_pairs, st)) != hipSuccess)
+        return fail_hip(e, "batch-statistics re-layout");
+    a.params = mc ? S.d_work2 : S.d_work;
+    a.n_params = mc ? (int32_t)nw2 : 0;
+    a.ld_const = ld_call + (direction == 0 ? P.ident.ld_const : 0.0);
+    if ((e = nf_launch_flow(mc ? P.ident.prog2 : P.ident.prog, a, h->n_cu, st, mc)) != hipSuccess)
+        return fail_hip(e, "batch-statistics final launch");
+    std::vector<float> mom_h((size_t)std::max(n_cpl, 1) * 4 * w);
+    if (moments_out && n_cpl &&
+        (e = hipMemcpyAsync(mom_h.data(), S.d_mom, (size_t)n_cpl * 4 * w * sizeof(float), hipMemcpyDeviceToHost, st)) != hipSuccess) {
+        (void)hipStreamSynchronize(st);
+        return fail_hip(e, "batch-statistics moments readback");
+    }
     if ((e = hipStreamSynchronize(st)) != hipSuccess) return fail_hip(e, "batch-statistics final sync");   // the scratch is reused
+    if (moments_out && n_cpl) memcpy(moments_out, mom_h.data(), (size_t)n_cpl * 4 * w * sizeof(float));
     return NF_OK;
 }
+
+static void nf_bs_destroy(nf_bs_state *s) { delete s; }
 
 int nf_nll_batchstats(nf_handle *h, const float *x, const float *y, int64_t B, const nf_cond *cond, float *nll_out,
                       float *sd_out, float *logdet_out, float *z_out, double *sums_out, uint32_t flags,

@@ -73,12 +73,35 @@ namespace {
 // the call-wide fp64 accumulators stats[0..WIDTH) / stats[WIDTH..2*WIDTH) of this workgroup's slot
 // (NF_STATS_SLOTS slots spread the atomics; the host adds them up)  (layers.py:388-391).
 template <int WIDTH>
-__device__ __forceinline__ void stats_accumulate(const float (&h)[WIDTH], bool active, double *stats, int t)
+__device__ __forceinline__ void stats_accumulate(const float (&h)[WIDTH], bool active, float (&s1)[WIDTH], float (&s2)[WIDTH])
+{
+#pragma unroll
+    for (int j = 0; j < WIDTH; ++j) {
+        const float v = active ? h[j] : 0.0f;
+        s1[j] += v;
+        s2[j] = fmaf(v, v, s2[j]);
+    }
+}
+template <int WIDTH>
+__device__ __forceinline__ void stats_direct(const float (&h)[WIDTH], bool active, double *stats, int t)
 {
 #pragma unroll
     for (int j = 0; j < WIDTH; ++j) {
         const float v = active ? h[j] : 0.0f;
         const float s = wave_sum(v), q = wave_sum(v * v);
+        if ((t & 63) == 0) {
+            atomicAdd(&stats[j], (double)s);
+            atomicAdd(&stats[WIDTH + j], (double)q);
+        }
+    }
+}
+// one wavefront reduction and one pair of fp64 atomics per channel per wavefront per patch
+template <int WIDTH>
+__device__ __forceinline__ void stats_flush(const float (&s1)[WIDTH], const float (&s2)[WIDTH], double *stats, int t)
+{
+#pragma unroll
+    for (int j = 0; j < WIDTH; ++j) {
+        const float s = wave_sum(s1[j]), q = wave_sum(s2[j]);
         if ((t & 63) == 0) {
             atomicAdd(&stats[j], (double)s);
             atomicAdd(&stats[WIDTH + j], (double)q);
@@ -459,9 +482,18 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
                     // under measurement, so h1 / h2 here ARE its pre-normalisation activations
                     const int stats_stage = (a.stats && op == a.stats_op) ? a.stats_stage : 0;
                     double *const stats = a.stats + (blockIdx.x & (NF_STATS_SLOTS - 1)) * (2 * WIDTH);
+                    // several pixels per lane: sum them in registers first (one reduction + atomics per patch, not per pixel)
+                    constexpr int SW = PX > 1 ? WIDTH : 1;
+                    float st1[SW], st2[SW];
+#pragma unroll
+                    for (int j = 0; j < SW; ++j) st1[j] = st2[j] = 0.0f;
 #pragma unroll
                     for (int k = 0; k < PX; ++k) {
-                        if (stats_stage == 1) stats_accumulate<WIDTH>(h1[k], act[k], stats, t);
+                        if constexpr (PX > 1) {
+                            if (stats_stage == 1) stats_accumulate<WIDTH>(h1[k], act[k], st1, st2);
+                        } else {
+                            if (stats_stage == 1) stats_direct<WIDTH>(h1[k], act[k], stats, t);
+                        }
                         float h2[WIDTH];
 #pragma unroll
                         for (int j = 0; j < WIDTH; ++j) h2[j] = B2[j];
@@ -471,7 +503,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
 #pragma unroll
                             for (int j = 0; j < WIDTH; ++j) h2[j] = fmaf(hi, W2[i * WIDTH + j], h2[j]);
                         }
-                        if (stats_stage == 2) stats_accumulate<WIDTH>(h2, act[k], stats, t);
+                        if constexpr (PX > 1) {
+                            if (stats_stage == 2) stats_accumulate<WIDTH>(h2, act[k], st1, st2);
+                        } else {
+                            if (stats_stage == 2) stats_direct<WIDTH>(h2, act[k], stats, t);
+                        }
                         if (act[k]) {
                             float4 *dst = reinterpret_cast<float4 *>(th + (size_t)lidx[k] * WIDTH);
 #pragma unroll
@@ -479,6 +515,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
                                 dst[q] = make_float4(nf_relu(h2[4 * q + 0]), nf_relu(h2[4 * q + 1]),
                                                      nf_relu(h2[4 * q + 2]), nf_relu(h2[4 * q + 3]));
                         }
+                    }
+                    if constexpr (PX > 1) {
+                        if (stats_stage) stats_flush<WIDTH>(st1, st2, stats, t);
                     }
                 }
                 __syncthreads();
@@ -713,6 +752,13 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
                 for (int k = 0; k < PX; ++k)
 #pragma unroll
                     for (int c = 0; c < 4; ++c) z[k][c] *= s;
+            } else if (type == NF_OP_STORE) {
+                if (a.out) {
+                    float4 *out4 = reinterpret_cast<float4 *>(a.out + patch_off);
+#pragma unroll
+                    for (int k = 0; k < PX; ++k)
+                        if (act[k]) out4[gidx[k]] = make_float4(z[k][0], z[k][1], z[k][2], z[k][3]);
+                }
             }
         }
 
@@ -809,6 +855,43 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
     stamp_on = true;
     NF_STAMP(12);
 #endif
+}
+
+// Batch-statistics mode, device side of the re-fold (layers.py:388-391 + the BN-eval folding of fold_coupling):
+// the moments of one normalisation from the slotted sums, then  W[r][j] *= 1/sqrt(var_j + eps),
+// B[j] = (B[j] - mean_j)/sqrt(var_j + eps)  in place on the working copy of the folded block (which holds the
+// identity-normalised layer), and the accumulators are cleared for the next pass.  One workgroup.
+__global__ __launch_bounds__(64) void nf_bs_finalize_kernel(double *__restrict__ stats, int w, double n, float *__restrict__ Wm, int rows,
+                                                            float *__restrict__ Bv, float *__restrict__ mean_out, float *__restrict__ var_out)
+{
+    __shared__ double sc[64];
+    const int j = threadIdx.x;
+    if (j < w) {
+        double sum = 0.0, sq = 0.0;
+        for (int slot = 0; slot < NF_STATS_SLOTS; ++slot) {
+            sum += stats[(size_t)slot * 2 * w + j];
+            sq += stats[(size_t)slot * 2 * w + w + j];
+        }
+        const double m = sum / n;
+        double v = sq / n - m * m;   // tf.nn.moments: population variance
+        if (v < 0.0) v = 0.0;
+        const float mf = (float)m, vf = (float)v;
+        mean_out[j] = mf;
+        var_out[j] = vf;
+        const double s = 1.0 / sqrt((double)vf + 1e-4);   // layers.py:378 (eps), as fold_coupling
+        sc[j] = s;
+        Bv[j] = (float)(((double)Bv[j] - (double)mf) * s);
+    }
+    __syncthreads();
+    for (int i = j; i < rows * w; i += 64) Wm[i] = (float)((double)Wm[i] * sc[i % w]);
+    for (int i = j; i < NF_STATS_SLOTS * 2 * w; i += 64) stats[i] = 0.0;
+}
+
+// dst[pairs[2i]] = src[pairs[2i+1]]: the normalisation-dependent entries of the matrix-core layout from the working scalar layout
+__global__ __launch_bounds__(256) void nf_gather_kernel(float *__restrict__ dst, const float *__restrict__ src, const int32_t *__restrict__ pairs, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[pairs[2 * i]] = src[pairs[2 * i + 1]];
 }
 
 // fold the slotted sums into the plain (sum nll, sum sd, count) triple — one wavefront
@@ -962,6 +1045,20 @@ hipError_t nf_launch_flow(const NfProgram &prog, const NfLaunch &a, int n_cu, hi
     case 32: return dispatch_geom<32, false>(prog, a, n_cu, stream);
     default: return hipErrorInvalidValue;
     }
+}
+
+hipError_t nf_launch_bs_finalize(double *stats, int w, double n, float *Wm, int rows, float *Bv, float *mean_out, float *var_out,
+                                 hipStream_t stream)
+{
+    hipLaunchKernelGGL(nf_bs_finalize_kernel, dim3(1), dim3(64), 0, stream, stats, w, n, Wm, rows, Bv, mean_out, var_out);
+    return hipGetLastError();
+}
+
+hipError_t nf_launch_gather(float *dst, const float *src, const int32_t *pairs, int n, hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(nf_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dst, src, pairs, n);
+    return hipGetLastError();
 }
 
 hipError_t nf_launch_sums_reduce(const double *wide, double *out3, bool accumulate, hipStream_t stream)
