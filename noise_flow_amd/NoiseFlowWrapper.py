@@ -29,7 +29,14 @@ from .noise_flow_model import NoiseFlow
 
 class NoiseFlowWrapper:
     def __init__(self, path, sampling_temperature=0.6, binding="loss_first", device=None, seed=None,
-                 bn_mode="running"):
+                 bn_mode="running", compat=None):
+        if compat not in (None, "reference"):
+            raise ValueError("compat must be None or 'reference'")
+        if compat == "reference":
+            # what borealisflows/NoiseFlowWrapper.py literally builds: only the sampling graph, so the CNN templates
+            # bind in sampling order (:64, quirk Q1), and is_training=True at every call (:86, quirk Q2)
+            binding, bn_mode = "sample_first", "batch"
+        self.compat = compat
         if bn_mode not in ("running", "batch"):
             raise ValueError("bn_mode must be 'running' or 'batch'")
         self.bn_mode = bn_mode

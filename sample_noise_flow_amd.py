@@ -31,6 +31,10 @@ def main():
     ap.add_argument("--cam", type=float, default=2.0, help="0..4 = IP, GP, S6, N6, G4")
     ap.add_argument("--temp", type=float, default=0.6)        # sample_noise_flow.py:36-40
     ap.add_argument("--out", default="samples_amd.npz")
+    ap.add_argument("--seed", type=int, default=None, help="Philox key of the in-kernel N(0,1) draw (default: hps.txt's seed)")
+    ap.add_argument("--compat", default=None, choices=["reference"],
+                    help="'reference': what the upstream wrapper literally builds (sampling-graph-first template binding + "
+                         "batch-statistics BN, quirks Q1/Q2) instead of the trained model's semantics")
     args = ap.parse_args()
 
     from noise_flow_amd import NoiseFlowWrapper
@@ -42,16 +46,18 @@ def main():
     clean = np.load(args.clean).astype(np.float32) if args.clean else np.random.rand(args.n, 32, 32, 4).astype(np.float32)
     b1, b2 = S6_NLF.get(int(args.iso), S6_NLF[100])
     real_noise = np.random.randn(*clean.shape) * np.sqrt(b1 * clean + b2)
-    nf = NoiseFlowWrapper(args.model, sampling_temperature=args.temp)
-    klds, noisy_syn = [], []
+    nf = NoiseFlowWrapper(args.model, sampling_temperature=args.temp, seed=args.seed, compat=args.compat)
+    klds, noisy_syn, noise_syn = [], [], []
     for p in range(clean.shape[0]):                          # batch_size = 1 like the reference demo
         c = clean[p:p + 1]
-        n_syn = np.squeeze(nf.sample_noise_nf(c, 0.0, 0.0, args.iso, args.cam))[1:-1, 1:-1, :]
+        n_full = np.squeeze(nf.sample_noise_nf(c, 0.0, 0.0, args.iso, args.cam))
+        noise_syn.append(n_full)
+        n_syn = n_full[1:-1, 1:-1, :]
         cc = np.squeeze(c)[1:-1, 1:-1, :]
         noisy_syn.append(unpack_raw(np.clip(cc + n_syn, 0.0, 1.0)))
         n_real = real_noise[p, 1:-1, 1:-1, :]
         klds.append(kl_div_3_data(unpack_raw(n_real).ravel(), unpack_raw(n_syn).ravel(), noise_bin_edges(200))[0])
-    np.savez_compressed(args.out, clean=clean, noisy_syn=np.stack(noisy_syn), kld=np.asarray(klds))
+    np.savez_compressed(args.out, clean=clean, noise_syn=np.stack(noise_syn), noisy_syn=np.stack(noisy_syn), kld=np.asarray(klds))
     print("Mean KL divergence = {}".format(np.mean(klds)))
 
 

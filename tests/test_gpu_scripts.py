@@ -1,0 +1,84 @@
+"""The two driver scripts executed end to end, as subprocesses:
+
+* ``sample_noise_flow_amd.py`` — the data-free core of the reference's ``sample_noise_flow.py:27-101`` (wrapper ->
+  sample_noise_nf per patch -> crop 1 px -> clip(clean + noise) -> unpack_raw -> marginal KL).  Its output is held to the
+  oracle evaluated on the SAME Philox epsilon, both with the trained model's semantics and in the literal-reference
+  mode (``--compat reference``: sampling-graph-first binding + batch-statistics BN, quirks Q1/Q2);
+* ``train_noise_flow_amd.py`` — the epoch loop of ``train_noise_flow.py:240-530`` on synthetic patches: log files in the
+  reference's TSV format, ``hps.txt``, TF-bundle checkpoints that reload to the logged test NLL.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import FULL_ARCH, ROOT, SHIPPED_DIR
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(args, timeout=600):
+    out = subprocess.run([sys.executable] + args, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    return out.stdout.decode()
+
+
+@pytest.mark.parametrize("compat", [None, "reference"])
+def test_demo_sampler_script_matches_oracle(tmp_path, shipped_variables, compat):
+    from noise_flow_amd.patches import unpack_raw
+    from oracle import philox
+    from oracle.nf_oracle import NoiseFlowOracle
+    n, iso, cam, temp, seed = 8, 800.0, 2.0, 0.6, 4321
+    out = str(tmp_path / "samples.npz")
+    args = [os.path.join(ROOT, "sample_noise_flow_amd.py"), "--n", str(n), "--iso", str(iso), "--cam", str(cam), "--temp", str(temp),
+            "--seed", str(seed), "--out", out]
+    if compat:
+        args += ["--compat", compat]
+    stdout = _run(args)
+    d = np.load(out)
+    assert d["clean"].shape == (n, 32, 32, 4) and d["noise_syn"].shape == (n, 32, 32, 4) and d["noisy_syn"].shape == (n, 60, 60)
+    assert "Mean KL divergence = " in stdout and abs(float(stdout.split("=")[-1]) - float(d["kld"].mean())) < 1e-9
+    # the script's inputs are reproducible (np.random.seed(12345), sample_noise_flow.py:58)
+    np.random.seed(12345)
+    clean = np.random.rand(n, 32, 32, 4).astype(np.float32)
+    np.testing.assert_array_equal(d["clean"], clean)
+    # oracle on the same epsilon: patch p of the run is Philox patch index p (batch size 1 per call, running counter)
+    eps = philox.sample_eps(seed, 0, n)
+    o = NoiseFlowOracle(FULL_ARCH, shipped_variables, "sample_first" if compat else "loss_first")
+    for p in range(n):
+        ref = o.sample(eps[p:p + 1], temp, clean[p:p + 1], iso, cam, training=bool(compat))[0]
+        scale = np.abs(ref).max()
+        assert np.abs(d["noise_syn"][p] - ref).max() <= 5e-5 * scale      # in-kernel Box-Muller: ~1e-6 absolute on eps
+        want = unpack_raw(np.clip(clean[p, 1:-1, 1:-1, :] + ref[1:-1, 1:-1, :], 0.0, 1.0).astype(np.float32))
+        assert np.abs(d["noisy_syn"][p] - want).max() <= 5e-5 * max(scale, 1e-3)
+    # the trained binding reproduces the camera noise far better than the literal wrapper's reversed binding (quirk Q1)
+    assert np.isfinite(d["kld"]).all()
+    if not compat:
+        assert float(d["kld"].mean()) < 0.5
+
+
+def test_training_script_writes_reference_formats_and_reloads(tmp_path):
+    from noise_flow_amd import NoiseFlow, default_hps, patches
+    from noise_flow_amd.ckpt import load_checkpoint
+    from noise_flow_amd.harness import S6_NLF
+    logdir = str(tmp_path / "run")
+    _run([os.path.join(ROOT, "train_noise_flow_amd.py"), "--logdir", logdir, "--epochs", "2", "--n_train", "276", "--n_test", "138",
+          "--n_batch_train", "138", "--n_batch_test", "138", "--epochs_full_valid", "1", "--lr", "1e-3"])
+    for f in ("train.txt", "test.txt", "hps.txt"):
+        assert os.path.exists(os.path.join(logdir, f)), f
+    rows = [l.rstrip("\n").split("\t") for l in open(os.path.join(logdir, "test.txt"))]
+    assert rows[0][0] == "epoch" and "NLL" in rows[0] and len(rows) >= 3              # header + one row per evaluated epoch
+    col = rows[0].index("NLL")
+    nlls = [float(r[col]) for r in rows[1:]]
+    assert all(np.isfinite(nlls)) and nlls[-1] < nlls[0]                               # it learns
+    # the checkpoint written after the last epoch reloads (TF-bundle reader) and evaluates to the logged test NLL
+    ck = os.path.join(logdir, "ckpt", "model.ckpt-2")
+    assert os.path.exists(ck + ".index") and os.path.exists(os.path.join(logdir, "ckpt", "model.ckpt.best.index"))
+    v = load_checkpoint(ck)
+    m = NoiseFlow([32, 32, 4], False, default_hps(), variables=v)
+    nlf = S6_NLF[800]
+    x, y = patches.synth_patches(0, 276, 138, nlf=nlf)
+    nll, _ = m.loss(x, y, [nlf[0]], [nlf[1]], [800.0], [2.0])
+    assert abs(float(nll) - nlls[-1]) <= 1e-4 * abs(nlls[-1])

@@ -76,8 +76,10 @@ def main():
             out.append({"_x": x, "_y": y, "nlf0": [nlf[0]], "nlf1": [nlf[1]], "iso": [args.iso], "cam": [args.cam]})
         return out
 
-    lo, hi = patches.shard_range(args.n_train, rank, world)
-    train_mbs = minibatches(lo, hi - lo, args.n_batch_train)
+    # every rank must take the SAME number of optimizer steps (one gradient all-reduce per step): equal blocks of
+    # n_train // world patches, the remainder is dropped
+    per_rank = args.n_train // world
+    train_mbs = minibatches(rank * per_rank, per_rank, args.n_batch_train)
     test_mbs = minibatches(args.n_train, args.n_test, args.n_batch_test)     # every rank evaluates the same test set
     # closed-form baselines of the test noise (sidd/PatchStatsCalculator.py:92-123)
     xt = np.concatenate([mb["_x"].cpu().numpy() for mb in test_mbs])
