@@ -213,6 +213,18 @@ int nf_trainer_forward_backward(nf_trainer *t, const float *x, const float *y, i
  * no gradient — the `sidd_cond == 'condSDN'` branch of train_thread (train_noise_flow.py:61-63). */
 int nf_trainer_forward(nf_trainer *t, const float *x, const float *y, int64_t B, const nf_cond *cond,
                        float *loss_out, void *stream);
+/* Cross-rank batch normalisation (the reference's batch_norm takes its moments over the WHOLE minibatch,
+ * layers.py:386-398; under data parallelism that is the union of the ranks' shards).  With a callback installed,
+ * nf_trainer_forward_backward / _forward / _step call
+ *     fn(user, buf, count, stream)
+ * at every point where batch sums are formed (2 per coupling in the forward pass, 2 in the backward pass): `buf`
+ * (= sync_buf, DEVICE, caller-owned, >= 64 doubles) holds this rank's `count` sums, written by work already enqueued
+ * on `stream`; the callback must enqueue a SUM all-reduce of buf[0..count) over the ranks so that work enqueued on
+ * `stream` afterwards sees the totals (RCCL on that stream, or any blocking implementation), and return 0.  Every rank
+ * must call with the same batch size; moments then use world_size x the local pixel count.  The gradient all-reduce
+ * between forward_backward and apply stays the caller's.  fn = NULL removes the hook. */
+typedef int (*nf_allreduce_fn)(void *user, double *buf, int64_t count, void *stream);
+int nf_trainer_set_sync(nf_trainer *t, nf_allreduce_fn fn, void *user, double *sync_buf, int32_t world_size);
 /* One optimizer update from `grads` (DEVICE float[n_params]; NULL = the trainer's own buffer). */
 int nf_trainer_apply(nf_trainer *t, const float *grads, float lr, void *stream);
 /* = nf_trainer_forward_backward(..., NULL, loss_out) + nf_trainer_apply(t, NULL, lr). */

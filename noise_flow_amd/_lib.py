@@ -56,6 +56,9 @@ class NoiseFlowLibError(RuntimeError):
         self.code = code
 
 
+# int fn(void *user, double *buf, int64_t count, void *stream)  — nf_trainer_set_sync
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+
 _lib = None
 
 
@@ -112,6 +115,8 @@ def load() -> C.CDLL:
     lib.nf_trainer_get_params.argtypes = [vp, vp, C.c_size_t, vp]
     lib.nf_trainer_set_params.restype = C.c_int
     lib.nf_trainer_set_params.argtypes = [vp, vp, C.c_size_t, vp]
+    lib.nf_trainer_set_sync.restype = C.c_int
+    lib.nf_trainer_set_sync.argtypes = [vp, ALLREDUCE_FN, vp, vp, i32]
     lib.nf_trainer_steps.restype = i64
     lib.nf_trainer_steps.argtypes = [vp]
     lib.nf_sums_reduce.restype = C.c_int
@@ -143,7 +148,7 @@ EXPORTED_SYMBOLS = (
     "nf_sample", "nf_synth_patches", "nf_fold_params", "nf_sdn5_scalars",
     "nf_nll_batchstats", "nf_sample_batchstats", "nf_sums_reduce", "nf_kernel_path",
     "nf_trainer_create", "nf_trainer_destroy", "nf_trainer_forward_backward", "nf_trainer_forward", "nf_trainer_apply", "nf_trainer_step",
-    "nf_trainer_get_params", "nf_trainer_set_params", "nf_trainer_steps",
+    "nf_trainer_get_params", "nf_trainer_set_params", "nf_trainer_steps", "nf_trainer_set_sync",
 )
 NF_PATH_SCALAR, NF_PATH_MFMA4, NF_PATH_FP16, NF_PATH_WIDE32, NF_PATH_WIDE16 = 0, 1, 2, 3, 4
 NF_OPT_ADAM = 0

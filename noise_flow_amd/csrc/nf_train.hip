@@ -158,6 +158,24 @@ __device__ __forceinline__ void acc_total2(Acc a, Acc b, int nslot, double &sa, 
     }
 }
 
+// Cross-rank batch normalisation (nf_trainer_set_sync): between the kernel that produces a group of slotted sums
+// and the one that consumes it, the per-rank totals go through the caller's all-reduce.  compact: one wavefront per
+// value adds its slots in fp64; scatter: the global total comes back as slot 0 + slot 1 (hi + lo floats, so that the
+// consumers' fp64 slot sum reconstructs it) with every other slot cleared.
+__global__ __launch_bounds__(64) void k_slots_compact(Acc a, int nslot, double *__restrict__ out)
+{
+    const double s = acc_total(a + (int)blockIdx.x, nslot);
+    if (threadIdx.x == 0) out[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(64) void k_slots_scatter(Acc a, int nslot, const double *__restrict__ in)
+{
+    float *d = (a + (int)blockIdx.x).p;
+    const double tot = in[blockIdx.x];
+    const float hi = (float)tot, lo = (float)(tot - (double)hi);
+    for (int k = threadIdx.x; k < nslot; k += 64) d[k] = k == 0 ? hi : k == 1 ? lo : 0.0f;
+}
+
 // per-patch accumulator: wavefronts that sit inside one patch reduce first
 __device__ __forceinline__ void patch_add(float *arr, int b, bool valid, float v)
 {
@@ -1105,6 +1123,12 @@ struct nf_trainer {
     std::vector<void *> owned;
     bool has_sdn = false;
     bool needs_cam = false;         // an SDN5 layer is present: the camera id must be one of 0..4
+    // cross-rank batch normalisation (nf_trainer_set_sync)
+    nf_allreduce_fn sync_fn = nullptr;
+    void *sync_user = nullptr;
+    double *sync_buf = nullptr;     // caller-owned device buffer, >= 64 doubles
+    int sync_world = 1;
+    int sync_rc = 0;                // first non-zero status a callback returned during the current step
 };
 
 namespace {
@@ -1145,6 +1169,16 @@ struct Guard {
     }
 };
 
+// all-reduce `count` slotted sums (a, a+1, ...) over the ranks; no-op without nf_trainer_set_sync
+void sync_slots(nf_trainer *t, Acc a, int count, int nslot, hipStream_t st)
+{
+    if (!t->sync_fn || t->sync_world < 2) return;
+    hipLaunchKernelGGL(k_slots_compact, dim3((unsigned)count), dim3(64), 0, st, a, nslot, t->sync_buf);
+    const int rc = t->sync_fn(t->sync_user, t->sync_buf, (int64_t)count, (void *)st);
+    if (rc != 0 && t->sync_rc == 0) t->sync_rc = rc;
+    hipLaunchKernelGGL(k_slots_scatter, dim3((unsigned)count), dim3(64), 0, st, a, nslot, (const double *)t->sync_buf);
+}
+
 template <int W>
 void coupling_forward(nf_trainer *t, const Geo &g, const TLayer &L, const float *zin, float *zout, Acc ldacc,
                       const float *zpre, const float *A, hipStream_t st)
@@ -1153,7 +1187,7 @@ void coupling_forward(nf_trainer *t, const Geo &g, const TLayer &L, const float 
     const unsigned nb = blocks_for(g.npix);
     const int w = W, off_w1 = L.off, off_m1 = L.off + 19 * w, off_w2 = L.off + 21 * w, off_m2 = L.off + 22 * w + w * w,
               off_w3 = L.off + 24 * w + w * w;
-    const double n = (double)g.npix;
+    const double n = (double)g.npix * t->sync_world;   // the moments are over the GLOBAL minibatch when the ranks are synchronised
     // zpre != null: the preceding Conv2d1x1 is folded into l_1 (which then also writes `zin`)
     if (zpre)
         hipLaunchKernelGGL((k_c1_fwd<W, true>), dim3(nb), dim3(TB), 0, st, g, zpre, A, const_cast<float *>(zin), t->d_params,
@@ -1161,8 +1195,10 @@ void coupling_forward(nf_trainer *t, const Geo &g, const TLayer &L, const float 
     else
         hipLaunchKernelGGL((k_c1_fwd<W, false>), dim3(nb), dim3(TB), 0, st, g, zin, (const float *)nullptr, (float *)nullptr,
                            t->d_params, off_w1, c.h1, t->acc(c.d_st1));
+    sync_slots(t, t->acc(c.d_st1), 2 * w, g.nslot, st);
     hipLaunchKernelGGL(k_c2_fwd<W>, dim3(nb), dim3(TB), 0, st, g, c.h1, t->acc(c.d_st1), n, t->d_params, off_m1,
                        t->d_flt + c.f_bn1, off_w2, c.h2, t->acc(c.d_st2));
+    sync_slots(t, t->acc(c.d_st2), 2 * w, g.nslot, st);
     hipLaunchKernelGGL(k_c3_fwd<W>, dim3(nb), dim3(TB), 0, st, g, zin, c.h2, t->acc(c.d_st2), n, t->d_params, off_m2,
                        t->d_flt + c.f_bn2, off_w3, zout, ldacc);
 }
@@ -1174,7 +1210,7 @@ void coupling_backward(nf_trainer *t, const Geo &g, const TLayer &L, const float
     const Cpl &c = t->cpl[L.aux];
     const unsigned nb = blocks_for(g.npix);
     const int w = W, off_w1 = L.off, off_b1 = L.off + 18 * w, off_w2 = L.off + 21 * w, off_w3 = L.off + 24 * w + w * w;
-    const double n = (double)g.npix;
+    const double n = (double)g.npix * t->sync_world;
     const float *bn1 = t->d_flt + c.f_bn1, *bn2 = t->d_flt + c.f_bn2;
     const Acc G = t->acc(0);
     const unsigned ng = std::min(nb, 96u);   // filter-gradient kernels: grid.y multiplies the workgroup count
@@ -1191,8 +1227,10 @@ void coupling_backward(nf_trainer *t, const Geo &g, const TLayer &L, const float
     }
     hipLaunchKernelGGL(k_c3_bwd<W>, dim3(nb), dim3(TB), 0, st, g, zin, c.h2, bn2, t->d_params, off_w3, invB, t->dz, gu, G);
     hipLaunchKernelGGL(k_c3_dh<W>, dim3(nb), dim3(TB), 0, st, g, c.h2, bn2, t->d_params, off_w3, gu, t1, t->acc(c.d_bs2));
+    sync_slots(t, t->acc(c.d_bs2), 2 * w, g.nslot, st);
     hipLaunchKernelGGL(k_c2_bwd<W>, dim3(nb), dim3(TB), 0, st, g, c.h1, bn1, c.h2, bn2, t->acc(c.d_bs2), n, t->d_params, off_w2,
                        t1, t2, t->acc(c.d_bs1), G);
+    sync_slots(t, t->acc(c.d_bs1), 2 * w, g.nslot, st);
     hipLaunchKernelGGL(k_c1_bwd<W>, dim3(nb), dim3(TB), 0, st, g, c.h1, bn1, t->acc(c.d_bs1), n, off_b1, t2, G);
     // one fork per coupling (every event operation costs host time): all three producers are done
     (void)hipEventRecord(t->ev_fork[0], st);
@@ -1472,7 +1510,8 @@ static int trainer_run(nf_trainer *t, const float *x, const float *y, int64_t B,
     g.npix = B * (int64_t)g.HW;
     g.nloop = (g.npix + 63) & ~(int64_t)63;
     const unsigned nb = blocks_for(g.npix);
-    g.nslot = (int)nb;
+    g.nslot = (t->sync_fn && t->sync_world > 1) ? std::max((int)nb, 2) : (int)nb;   // the synchronised totals occupy slots 0 and 1
+    t->sync_rc = 0;
     const float invB = 1.0f / (float)B;
     const int n = t->cfg.n_layers;
     hipError_t e;
@@ -1515,11 +1554,12 @@ static int trainer_run(nf_trainer *t, const float *x, const float *y, int64_t B,
     }
     hipLaunchKernelGGL(k_prior, dim3(nb), dim3(TB), 0, st, g, t->zs[n], s1, s2);
     if (loss_out)
-        hipLaunchKernelGGL(k_loss, dim3(1), dim3(TB), 0, st, (int)B, (double)g.HW * 4.0, t->acc(t->d_ld0), n, (int)nb, s1, s2,
+        hipLaunchKernelGGL(k_loss, dim3(1), dim3(TB), 0, st, (int)B, (double)g.HW * 4.0, t->acc(t->d_ld0), n, g.nslot, s1, s2,
                            G + t->d_ldc, loss_out);
     if (!backward) {
         t->zs[0] = nullptr;
         if ((e = hipGetLastError()) != hipSuccess) return nf_fail_hip(e, "trainer launch");
+        if (t->sync_rc) return nf_fail(NF_EINVAL, "the all-reduce callback of nf_trainer_set_sync failed (status %d)", t->sync_rc);
         return NF_OK;
     }
     // ---- backward ----
@@ -1558,12 +1598,24 @@ static int trainer_run(nf_trainer *t, const float *x, const float *y, int64_t B,
             (void)hipStreamWaitEvent(st, t->ev_done[par], 0);
             t->done_pending[par] = false;
         }
-    hipLaunchKernelGGL(k_reduce, dim3((unsigned)t->d_ldc), dim3(64), 0, st, t->d_ldc, t->d_part, (int)nb, G);
+    hipLaunchKernelGGL(k_reduce, dim3((unsigned)t->d_ldc), dim3(64), 0, st, t->d_ldc, t->d_part, g.nslot, G);
     hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, st, t->tl, t->d_params, ci, g.HW, G + t->d_dA, G + t->d_dab, G + t->d_dg, G);
     float *gout = grads_out ? grads_out : t->d_gradf;
     hipLaunchKernelGGL(k_grads_out, dim3((t->n_params + TB - 1) / TB), dim3(TB), 0, st, t->n_params, G, t->d_mask, gout);
     t->zs[0] = nullptr;
     if ((e = hipGetLastError()) != hipSuccess) return nf_fail_hip(e, "trainer launch");
+    if (t->sync_rc) return nf_fail(NF_EINVAL, "the all-reduce callback of nf_trainer_set_sync failed (status %d)", t->sync_rc);
+    return NF_OK;
+}
+
+int nf_trainer_set_sync(nf_trainer *t, nf_allreduce_fn fn, void *user, double *sync_buf, int32_t world_size)
+{
+    if (!t) return nf_fail(NF_EINVAL, "trainer is NULL");
+    if (fn && (!sync_buf || world_size < 1)) return nf_fail(NF_EINVAL, "nf_trainer_set_sync needs a device buffer of 64 doubles and world_size >= 1");
+    t->sync_fn = fn;
+    t->sync_user = user;
+    t->sync_buf = fn ? sync_buf : nullptr;
+    t->sync_world = fn ? world_size : 1;
     return NF_OK;
 }
 

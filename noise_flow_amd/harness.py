@@ -143,14 +143,14 @@ def sample_epoch(nf, minibatches: Iterable[dict], temp: float = 1.0, fix_iso: fl
             "sample_time": time.time() - t0}
 
 
-def train_epoch(trainer, minibatches: Iterable[dict], lr: float, group=None):
+def train_epoch(trainer, minibatches: Iterable[dict], lr: float, group=None, sync_bn: bool = False):
     """``train_multithread`` (train_noise_flow.py:27-77, 484-504) → (mean over minibatches of the
     training loss, mean sd_z, per-batch losses).  Steps are enqueued back to back; the losses are
     read once at the end of the epoch (one synchronisation per epoch, not per step)."""
     outs = []
     for mb in minibatches:
         out = trainer.step(mb["_x"], mb["_y"], mb["nlf0"], mb["nlf1"], mb["iso"], mb["cam"], lr=lr, group=group,
-                           sync=False)
+                           sync=False, sync_bn=sync_bn)
         outs.append(out.clone())
     if not outs:
         return float("nan"), float("nan"), []
@@ -165,7 +165,7 @@ def _is_eval_epoch(epoch: int, epochs_full_valid: int) -> bool:
 
 def fit(trainer, nf_eval, train_mbs: Sequence[dict], test_mbs: Sequence[dict], logdir: str, epochs: int, lr: float,
         epochs_full_valid: int = 10, nll_gauss: float = 0.0, nll_sdn: float = 0.0, do_sampling: bool = True,
-        start_epoch: int = 1, group=None, log=None):
+        start_epoch: int = 1, group=None, log=None, sync_bn: bool = False):
     """The epoch loop of ``train_noise_flow.py:379-511``: per epoch test (on the reference's
     schedule; saves ``ckpt/model.ckpt-<epoch>`` and ``ckpt/model.ckpt.best``), sampling, training;
     appends to ``train.txt`` / ``test.txt`` / ``sample.txt`` under ``logdir``.
@@ -202,7 +202,7 @@ def fit(trainer, nf_eval, train_mbs: Sequence[dict], test_mbs: Sequence[dict], l
                                    "sample_time": sr["sample_time"], "KLD_G": 0.0, "KLD_NLF": sr["KLD_NLF"],
                                    "KLD_NF": sr["KLD_NF"], "KLD_R": 0.0})
         t = time.time()
-        nll_tr, sdz_tr, _ = train_epoch(trainer, train_mbs, lr, group)
+        nll_tr, sdz_tr, _ = train_epoch(trainer, train_mbs, lr, group, sync_bn)
         train_time += time.time() - t
         res["train"].append(nll_tr)
         train_logger.log({"epoch": epoch, "train_time": int(train_time), "NLL": nll_tr, "NLL_G": nll_gauss, "NLL_SDN": nll_sdn,

@@ -5,8 +5,11 @@ with ``train_op = get_optimizer(hps, lr, loss)`` (``train_noise_flow.py:187-198`
 ``Trainer`` owns one ``nf_trainer`` (C ABI, ``include/noiseflow_hip.h``): the raw parameters, the
 optimizer slots and the activation workspace live on the GPU; ``step`` only enqueues kernels on
 torch's current stream.  Data-parallel training = ``forward_backward`` → one RCCL all-reduce of
-the 2 433-float gradient → ``apply`` (``step(..., group=...)`` does exactly that); BN moments stay
-per rank (the reference is single-process, SURVEY.md §8e caveat).
+the 2 433-float gradient → ``apply`` (``step(..., group=...)`` does exactly that).  With
+``sync_bn=True`` the batch-normalisation sums are all-reduced as well (2·width doubles at each of
+the 4 points per coupling where the reference's ``batch_norm`` / its gradient reduce over the
+minibatch, ``layers.py:386-398``), so that N ranks on N shards take the SAME step as one rank on
+the concatenated minibatch; without it the moments stay per rank (replicas with local statistics).
 """
 from __future__ import annotations
 
@@ -64,12 +67,43 @@ class Trainer:
         self._grads = torch.zeros((self.n_params,), dtype=torch.float32, device=self._dev.device)
         self._loss = torch.zeros((2,), dtype=torch.float32, device=self._dev.device)
         self.has_sdn = any(L.kind in ("sdn5", "sdn4") for L in self.layers)
+        self._sync = None          # (group key, callback object, buffer): keeps the ctypes thunk alive
 
     # ------------------------------------------------------------------ lifetime
     def close(self):
         if getattr(self, "_h", None):
             self.lib.nf_trainer_destroy(self._h)
             self._h = None
+        self._sync = None
+
+    # ------------------------------------------------------------------ cross-rank batch normalisation
+    def set_sync_bn(self, group=None, enabled: bool = True) -> None:
+        """Install (or remove) the all-reduce hook of ``nf_trainer_set_sync`` for ``group`` (``None`` / ``True`` = the
+        default process group).  Every rank must then call :meth:`step` with the same batch size."""
+        import torch.distributed as dist
+        grp = None if group in (None, True) else group
+        if not enabled or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(grp) < 2:
+            if self._sync is not None:
+                _lib.check(self.lib.nf_trainer_set_sync(self._h, _lib.ALLREDUCE_FN(0), None, None, 1))
+                self._sync = None
+            return
+        key = ("default" if grp is None else id(grp))
+        if self._sync is not None and self._sync[0] == key:
+            return
+        torch = self._dev.torch
+        buf = torch.zeros((64,), dtype=torch.float64, device=self._dev.device)
+        err = []
+
+        def allreduce(user, ptr, count, stream):
+            try:   # `ptr` is buf's storage; the library wrote this rank's sums on torch's current stream
+                dist.all_reduce(buf[:int(count)], op=dist.ReduceOp.SUM, group=grp)
+                return 0
+            except Exception as e:   # never let an exception cross the C frame
+                err.append(e)
+                return 1
+        cb = _lib.ALLREDUCE_FN(allreduce)
+        _lib.check(self.lib.nf_trainer_set_sync(self._h, cb, None, buf.data_ptr(), dist.get_world_size(grp)))
+        self._sync = (key, cb, buf, err)
 
     def __del__(self):
         try:
@@ -122,13 +156,23 @@ class Trainer:
         with dev.torch.cuda.device(dev.device):
             _lib.check(self.lib.nf_trainer_apply(self._h, g.data_ptr(), float(lr), dev.stream_ptr()))
 
-    def step(self, x, y, nlf0=None, nlf1=None, iso=None, cam=None, lr: float = 1e-4, group=None, sync: bool = True):
+    def step(self, x, y, nlf0=None, nlf1=None, iso=None, cam=None, lr: float = 1e-4, group=None, sync: bool = True,
+             sync_bn: bool = False):
         """One ``sess.run([train_op, loss, sd_z])`` → ``(train_loss, sd_z)``.
 
         ``group``: a ``torch.distributed`` process group (or ``True`` for the default group) —
         averages the gradient over ranks with one all-reduce before the update.
-        ``sync=False`` returns the device tensor ``[loss, sd_z]`` without waiting."""
-        grads, loss = self.forward_backward(x, y, nlf0, nlf1, iso, cam)
+        ``sync_bn``: also all-reduce the batch-normalisation sums over ``group`` (see the module docstring): the
+        step then equals the single-process step on the concatenated minibatch; the returned loss stays the
+        rank's own mean.  ``sync=False`` returns the device tensor ``[loss, sd_z]`` without waiting."""
+        if group is not None or self._sync is not None:
+            self.set_sync_bn(group, enabled=bool(sync_bn) and group is not None)
+        try:
+            grads, loss = self.forward_backward(x, y, nlf0, nlf1, iso, cam)
+        except _lib.NoiseFlowLibError:
+            if self._sync is not None and self._sync[3]:
+                raise self._sync[3].pop()
+            raise
         if group is not None:
             import torch.distributed as dist
             grp = None if group is True else group

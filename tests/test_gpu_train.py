@@ -373,6 +373,99 @@ def test_two_rank_data_parallel_training_matches_manual_gradient_averaging(tmp_p
     assert not np.array_equal(p0[~mask], p1[~mask])
 
 
+def _syncbn_worker(rank, world, port, outdir):
+    """One rank of a synchronised-BN data-parallel run: its shard of the global minibatch, group + sync_bn."""
+    import sys
+    import torch.distributed as dist
+    from conftest import ROOT, make_inputs, trained_like_variables
+    sys.path.insert(0, ROOT)
+    from noise_flow_amd import default_hps
+    from noise_flow_amd.train import Trainer
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    v = trained_like_variables(DP_ARCH, 4, seed=9)
+    tr = Trainer([32, 32, 4], default_hps(arch=DP_ARCH), variables=v, max_batch=8)
+    x, y = make_inputs(8 * world, seed=500, b1=0.003696)
+    sl = slice(8 * rank, 8 * rank + 8)
+    # the two halves of step(group=True, sync_bn=True), with the averaged gradient kept for the comparison
+    tr.set_sync_bn(True)
+    g, loss = tr.forward_backward(x[sl], y[sl], [0.0], [0.0], [800], [2])
+    dist.all_reduce(g)
+    g.div_(world)
+    np.save(os.path.join(outdir, "sync_grad_%d.npy" % rank), g.cpu().numpy())
+    np.save(os.path.join(outdir, "sync_loss_%d.npy" % rank), loss.cpu().numpy())
+    tr.apply(1e-3, g)
+    np.save(os.path.join(outdir, "sync_params1_%d.npy" % rank), tr.raw_params())
+    x2, y2 = make_inputs(8 * world, seed=501, b1=0.003696)
+    tr.step(x2[sl], y2[sl], [0.0], [0.0], [800], [2], lr=1e-3, group=True, sync_bn=True)
+    np.save(os.path.join(outdir, "sync_params_%d.npy" % rank), tr.raw_params())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sync_bn_step_equals_one_rank_on_the_concatenated_batch(tmp_path):
+    """SURVEY §8 f-3 'training-mode BN with cross-GPU moment all-reduce': with sync_bn the batch moments (and the two
+    batch means of the BN gradient) are taken over the union of the ranks' shards, so the rank-averaged gradient of
+    2 ranks x 8 patches IS the gradient of one rank on the 16 concatenated patches (layers.py:386-398; up to the order
+    of the fp32 partial sums), the running statistics move identically, and both ranks stay bit-identical over further
+    steps.  Without the hook the same shards give a different gradient."""
+    import socket
+    import torch.multiprocessing as mp
+    from noise_flow_amd import params as P
+    from oracle.nf_grad_oracle import is_trainable
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_syncbn_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    [p.start() for p in procs]
+    [p.join(timeout=300) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    load = lambda n, r: np.load(os.path.join(str(tmp_path), "sync_%s_%d.npy" % (n, r)))   # noqa: E731
+    g0, g1, p0, p1 = load("grad", 0), load("grad", 1), load("params", 0), load("params", 1)
+    assert np.array_equal(g0, g1) and np.array_equal(p0, p1)      # same model on both ranks, running statistics included
+
+    v = trained_like_variables(DP_ARCH, 4, seed=9)
+    x, y = make_inputs(16, seed=500, b1=0.003696)
+    one = _trainer(DP_ARCH, v, max_batch=16)
+    g_one, loss_one = one.forward_backward(x, y, [0.0], [0.0], [800], [2])
+    g_one = g_one.cpu().numpy().copy()
+    ref = one.raw_to_variables(g_one)
+    got = one.raw_to_variables(g0)
+    gmax = max(np.abs(ref[n]).max() for n in ref if is_trainable(n))
+    for name in ref:
+        if not is_trainable(name):
+            continue
+        if name.endswith("l_1/b") or name.endswith("l_2/b"):     # analytically zero (a bias in front of a batch norm)
+            assert np.abs(got[name]).max() <= 1e-5 * gmax and np.abs(ref[name]).max() <= 1e-5 * gmax
+        else:
+            assert np.abs(got[name] - ref[name]).max() <= 2e-4 * max(np.abs(ref[name]).max(), 1e-6 * gmax), name
+    # the global-batch loss is the mean of the two ranks' losses
+    l2 = 0.5 * (load("loss", 0)[0] + load("loss", 1)[0])
+    assert abs(l2 - float(loss_one.cpu().numpy()[0])) <= 1e-5 * abs(l2)
+    # per-rank statistics (no hook) on the same shards: a measurably different gradient
+    a, b = _trainer(DP_ARCH, v, max_batch=8), _trainer(DP_ARCH, v, max_batch=8)
+    ga, _ = a.forward_backward(x[:8], y[:8], [0.0], [0.0], [800], [2])
+    gb, _ = b.forward_backward(x[8:], y[8:], [0.0], [0.0], [800], [2])
+    g_local = one.raw_to_variables(((ga + gb) / 2).cpu().numpy())
+    worst = max(np.abs(g_local[n] - ref[n]).max() / max(np.abs(ref[n]).max(), 1e-6 * gmax) for n in ref
+                if is_trainable(n) and not n.endswith(("l_1/b", "l_2/b")))
+    assert worst > 2e-3, worst        # ten times the tolerance the synchronised gradient meets
+    # BN running statistics after the first step: moved by the GLOBAL moments (later steps inherit Adam's sign
+    # sensitivity on the analytically-zero bias gradients, in one process as in two)
+    r1 = one.raw_params()
+    q0 = load("params1", 0)
+    mask = np.zeros(one.n_params, bool)
+    pos = 0
+    for L in one.layers:
+        for nm in P.layer_variable_names(L, one._tmpl):
+            n = 1 if nm is None else int(np.asarray(v[nm]).size)
+            mask[pos:pos + n] = nm is not None and ("bn_nvp_conv" in nm)
+            pos += n
+    assert mask.any() and np.abs(q0[mask] - r1[mask]).max() <= 1e-5 * np.abs(r1[mask]).max()
+    assert np.abs(q0[mask] - np.asarray(P.pack_layers(one.layers, v, 4, one._tmpl)[2])[mask]).max() > 1e-3   # they did move
+
+
 def test_gradients_with_the_reversed_template_binding():
     """binding='sample_first' (quirk Q1): the coupling CNN variables are bound to the layers in reversed
     order; trainer and oracle must agree on which template each gradient belongs to."""

@@ -14,7 +14,8 @@ writes ``train.txt / test.txt / sample.txt`` (TSV, reference columns), ``hps.txt
 ``ckpt/model.ckpt-<epoch>``, ``ckpt/model.ckpt.best`` (TF-bundle format) under ``--logdir``.
 Multi-GPU: launch under ``python -m torch.distributed.run --nproc-per-node N`` — every rank draws
 its own shard of the training patches and the gradient is averaged with one RCCL all-reduce per
-step.
+step; ``--sync_bn`` also all-reduces the batch-normalisation sums (the ranks then take the step a
+single process would take on the union of their minibatches).
 """
 import argparse
 import os
@@ -42,6 +43,8 @@ def main():
     ap.add_argument("--iso", type=float, default=800.0)
     ap.add_argument("--cam", type=float, default=2.0)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--sync_bn", action="store_true",
+                    help="multi-GPU: batch-norm moments over the GLOBAL minibatch (all ranks take the single-process step)")
     ap.add_argument("--init", default=None, help="checkpoint prefix to start from (default: fresh initialisation)")
     args = ap.parse_args()
 
@@ -95,7 +98,7 @@ def main():
         log("train minibatches/epoch %d x %d patches (rank 0 of %d), test %d x %d; NLL_G %.2f NLL_SDN %.2f" % (
             len(train_mbs), args.n_batch_train, world, len(test_mbs), args.n_batch_test, base_g, base_sdn))
     res = fit(trainer, nf_eval, train_mbs, test_mbs, logdir, args.epochs, args.lr, args.epochs_full_valid,
-              nll_gauss=base_g, nll_sdn=base_sdn, group=group, log=log)
+              nll_gauss=base_g, nll_sdn=base_sdn, group=group, log=log, sync_bn=args.sync_bn)
     if log:
         log("final: train %.4f  test %.4f (first %.4f)" % (res["train"][-1], res["test"][-1], res["test"][0]))
     if world > 1:
