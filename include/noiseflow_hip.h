@@ -58,6 +58,17 @@ extern "C" {
 #define NF_LAYER_GAIN      7   /* AffineCouplingGain.py   + cond_utils.py:319-330 scale = sig(g1) iso + sig(g2);
                                   log|det| = -log(scale) ONCE per patch, exactly as the reference writes it
                                   (AffineCouplingGain.py:113-127 omits the H*W*C factor) */
+/* the rest of noise_flow_arch's vocabulary (noise_flow_model.py:116-223): per-ISO gain tables and other
+ * parameterisations of the same two elementwise forms, scale^2 = a*y + b  /  scale = a */
+#define NF_LAYER_SDN1      8   /* AffineCouplingSdnEx1.py + cond_utils.py:55-98   sqrt(sig(b1) y / r_gain + sig(b2)), r_gain = exp(1e-2 rg[iso]) iso */
+#define NF_LAYER_SDN2      9   /* AffineCouplingSdnEx2.py + cond_utils.py:101-138 sqrt(gain (sig(b1) y / gain + sig(b2))),  gain = exp(0.1 g[iso]) iso */
+#define NF_LAYER_SDN3     10   /* AffineCouplingSdnEx3.py + cond_utils.py:141-175 gain sqrt(sig(b1) y / gain + sig(b2)) */
+#define NF_LAYER_SDN6     11   /* AffineCouplingSdnEx6.py + cond_utils.py:242-276 SDN5 with ONE camera parameter (scales the gain only) */
+#define NF_LAYER_GAIN1    12   /* AffineCouplingGainEx1.py + cond_utils.py:333-350 scale = exp(1e-5 g1) iso + exp(1e-5 g2); log|det| once per patch (as GAIN) */
+#define NF_LAYER_GAIN2    13   /* AffineCouplingGainEx2.py + cond_utils.py:353-392 scale = exp(0.1 g[iso]) iso; log|det| = -H*W*C log(scale) */
+#define NF_LAYER_GAIN3    14   /* AffineCouplingGainEx3.py + cond_utils.py:395-429 scale = exp(1e-5 g[iso]);  log|det| once per patch (as GAIN) */
+/* per-ISO tables hold the entries of ISO 100, 400, 800, 1600, 3200 in that order; any other ISO uses the ISO-800
+ * entry (the tf.cond chains' last branch) — unlike SDN5/SDN4/SDN6, whose empty one-hot selects 0 */
 
 /* Raw (checkpoint-semantics, un-folded) parameter layout of one layer inside the
  * flat `params` array, starting at `param_offset` floats.  C = 4 channels.
@@ -74,6 +85,11 @@ extern "C" {
  *  SDN4      (7 floats)   beta1, beta2, gain_params[5]
  *  SDN       (2 floats)   b1, b2
  *  GAIN      (2 floats)   g1, g2
+ *  SDN1      (7 floats)   b1, b2, r_gain_param[5]
+ *  SDN2/SDN3 (7 floats)   b1, b2, gain_param[5]
+ *  SDN6      (13 floats)  beta1, beta2, gain_params[5], cam_params[1][5], c_i
+ *  GAIN1     (2 floats)   g1, g2
+ *  GAIN2/3   (5 floats)   gain_param[5]
  */
 typedef struct nf_layer_desc {
     int32_t type;          /* NF_LAYER_*                                  */

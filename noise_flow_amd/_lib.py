@@ -18,6 +18,8 @@ NF_LAYER_GAIN4 = 4
 NF_LAYER_SDN4 = 5
 NF_LAYER_SDN = 6
 NF_LAYER_GAIN = 7
+NF_LAYER_SDN1, NF_LAYER_SDN2, NF_LAYER_SDN3, NF_LAYER_SDN6 = 8, 9, 10, 11
+NF_LAYER_GAIN1, NF_LAYER_GAIN2, NF_LAYER_GAIN3 = 12, 13, 14
 
 NF_CFG_FP16_CNN = 1
 

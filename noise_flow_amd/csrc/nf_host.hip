@@ -70,6 +70,13 @@ int64_t layer_param_count(int32_t type, int32_t w)
     case NF_LAYER_SDN4: return 7;
     case NF_LAYER_SDN: return 2;
     case NF_LAYER_GAIN: return 2;
+    case NF_LAYER_SDN1:
+    case NF_LAYER_SDN2:
+    case NF_LAYER_SDN3: return 7;
+    case NF_LAYER_SDN6: return 13;
+    case NF_LAYER_GAIN1: return 2;
+    case NF_LAYER_GAIN2:
+    case NF_LAYER_GAIN3: return 5;
     default: return -1;
     }
 }
@@ -339,6 +346,18 @@ struct CondLayer {
 
 double sigmoid(double x) { return 1.0 / (1.0 + exp(-x)); }
 
+// per-ISO tables of the Ex1-Ex3 layers: nested tf.cond on iso == 100, 400, 800, 1600, 3200 whose last branch is
+// the ISO-800 entry (cond_utils.py:69-88)
+int iso_table_index(float iso)
+{
+    static const float iso_vals[5] = {100.f, 400.f, 800.f, 1600.f, 3200.f};
+    for (int i = 0; i < 5; ++i)
+        if (iso_vals[i] == iso) return i;
+    return 2;
+}
+
+inline bool is_gain_kind(int k) { return k == NF_LAYER_GAIN || k == NF_LAYER_GAIN1 || k == NF_LAYER_GAIN2 || k == NF_LAYER_GAIN3; }
+
 // Per-call scalars of one conditional layer -> (a, b): SDN kinds: scale^2 = a*y + b; GAIN: scale = a.
 int cond_scalars(const CondLayer &L, const nf_cond *cond, double out[2])
 {
@@ -362,6 +381,55 @@ int cond_scalars(const CondLayer &L, const nf_cond *cond, double out[2])
     case NF_LAYER_GAIN:     // cond_utils.py:319-330 with gain = iso (AffineCouplingGain.py:52,113)
         if (!cond) return fail(NF_EINVAL, "model has a GAIN layer but cond is NULL");
         out[0] = sigmoid(L.p[0]) * (double)cond->iso + sigmoid(L.p[1]);
+        out[1] = 0.0;
+        if (!(out[0] > 0.0)) return fail(NF_EINVAL, "gain scale must be > 0");
+        return NF_OK;
+    case NF_LAYER_SDN1:     // cond_utils.py:55-98
+    case NF_LAYER_SDN2:     // cond_utils.py:101-138
+    case NF_LAYER_SDN3: {   // cond_utils.py:141-175
+        if (!cond) return fail(NF_EINVAL, "model has an SDN layer with a per-ISO gain table but cond is NULL");
+        const double c = L.kind == NF_LAYER_SDN1 ? 1e-2 : 1e-1;
+        const double gain = exp(c * (double)L.p[2 + iso_table_index(cond->iso)]) * (double)cond->iso;
+        const double b1 = sigmoid(L.p[0]), b2 = sigmoid(L.p[1]);
+        if (L.kind == NF_LAYER_SDN1) {          // sqrt(b1 y / r_gain + b2)
+            out[0] = b1 / gain;
+            out[1] = b2;
+        } else if (L.kind == NF_LAYER_SDN2) {   // sqrt(gain (b1 y / gain + b2))
+            out[0] = gain * (b1 / gain);
+            out[1] = gain * b2;
+        } else {                                // gain sqrt(b1 y / gain + b2)
+            out[0] = gain * gain * (b1 / gain);
+            out[1] = gain * gain * b2;
+        }
+        return NF_OK;
+    }
+    case NF_LAYER_SDN6: {   // cond_utils.py:242-276: one camera parameter, applied to the gain exponent only
+        if (!cond) return fail(NF_EINVAL, "model has an SDN6 layer but cond is NULL");
+        const double c_i = L.p[12];
+        int cam_idx = -1;
+        for (int i = 0; i < 5; ++i)
+            if ((float)i == cond->cam) cam_idx = i;
+        if (cam_idx < 0) return fail(NF_ECOND, "unknown camera id %g (expected 0..4 = IP,GP,S6,N6,G4)", (double)cond->cam);
+        const double cp = exp(c_i * (double)L.p[7 + cam_idx]);
+        static const float iso_vals[5] = {100.f, 400.f, 800.f, 1600.f, 3200.f};
+        double g = 0.0;   // unknown ISO -> empty one-hot -> 0
+        for (int i = 0; i < 5; ++i)
+            if (iso_vals[i] == cond->iso) g = L.p[2 + i];
+        const double gain = exp(c_i * g * cp) * (double)cond->iso;
+        out[0] = exp(c_i * (double)L.p[0]) / gain;
+        out[1] = exp(c_i * (double)L.p[1]);
+        return NF_OK;
+    }
+    case NF_LAYER_GAIN1:    // cond_utils.py:333-350 with gain = iso
+        if (!cond) return fail(NF_EINVAL, "model has a GAIN1 layer but cond is NULL");
+        out[0] = exp(1e-5 * (double)L.p[0]) * (double)cond->iso + exp(1e-5 * (double)L.p[1]);
+        out[1] = 0.0;
+        return NF_OK;
+    case NF_LAYER_GAIN2:    // cond_utils.py:353-392
+    case NF_LAYER_GAIN3:    // cond_utils.py:395-429
+        if (!cond) return fail(NF_EINVAL, "model has a per-ISO GAIN layer but cond is NULL");
+        if (L.kind == NF_LAYER_GAIN2) out[0] = exp(1e-1 * (double)L.p[iso_table_index(cond->iso)]) * (double)cond->iso;
+        else out[0] = exp(1e-5 * (double)L.p[iso_table_index(cond->iso)]);
         out[1] = 0.0;
         if (!(out[0] > 0.0)) return fail(NF_EINVAL, "gain scale must be > 0");
         return NF_OK;
@@ -440,16 +508,23 @@ int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float
         case NF_LAYER_SDN5:
         case NF_LAYER_SDN4:
         case NF_LAYER_SDN:
-        case NF_LAYER_GAIN: {
+        case NF_LAYER_GAIN:
+        case NF_LAYER_SDN1:
+        case NF_LAYER_SDN2:
+        case NF_LAYER_SDN3:
+        case NF_LAYER_SDN6:
+        case NF_LAYER_GAIN1:
+        case NF_LAYER_GAIN2:
+        case NF_LAYER_GAIN3: {
             if (out.cond.size() >= 4) return fail(NF_EINVAL, "at most 4 conditional (sdn/gain) layers per model");
-            it.type = L.type == NF_LAYER_GAIN ? NF_OP_SCALE_COND : NF_OP_SDN_DIV;
+            it.type = is_gain_kind(L.type) ? NF_OP_SCALE_COND : NF_OP_SDN_DIV;
             it.slot = (int)out.cond.size();
             CondLayer c;
             c.kind = L.type;
             c.p.assign(p, p + cnt);
             if (L.type == NF_LAYER_SDN5) c.p.resize(23);
             out.cond.push_back(c);
-            if (L.type != NF_LAYER_GAIN) out.has_sdn = true;
+            if (!is_gain_kind(L.type)) out.has_sdn = true;
             break;
         }
         case NF_LAYER_GAIN4:
@@ -818,9 +893,11 @@ static int nll_args(nf_handle *h, const float *x, const float *y, int64_t B, con
         double sc[2];
         int rc = cond_scalars(h->fwd.cond[i], cond, sc);
         if (rc != NF_OK) return rc;
-        if (h->fwd.cond[i].kind == NF_LAYER_GAIN) {
+        if (is_gain_kind(h->fwd.cond[i].kind)) {
             ca[i] = (float)(1.0 / sc[0]);            // NLL direction divides
-            ld_call -= log(sc[0]);                   // AffineCouplingGain.py:113-127 (no H*W*C factor)
+            // AffineCouplingGain / GainEx1 / GainEx3 write -log(scale) once per patch (no H*W*C factor, e.g.
+            // AffineCouplingGain.py:113-127); GainEx2 broadcasts the scale first and sums (AffineCouplingGainEx2.py:112-126)
+            ld_call -= (h->fwd.cond[i].kind == NF_LAYER_GAIN2 ? (double)h->cfg.height * h->cfg.width * kC : 1.0) * log(sc[0]);
         } else {
             ca[i] = (float)sc[0];
             cb[i] = (float)sc[1];

@@ -143,7 +143,37 @@ class AffineCouplingGain(_Conditional):
     log|det| = -/+ log(scale) ONCE per patch, as the reference writes it (no H*W*C factor)."""
 
 
-_CLASS = {"sdn4": AffineCouplingSdnEx4, "sdn": AffineCouplingSdn, "gain": AffineCouplingGain, "conv1x1": Conv2d1x1, "coupling": AffineCoupling, "sdn5": AffineCouplingSdnEx5, "gain4": AffineCouplingGainEx4}
+class AffineCouplingSdnEx1(_Conditional):
+    """AffineCouplingSdnEx1.py + cond_utils.py:55-98: sqrt(sig(b1)*y/r_gain + sig(b2)), r_gain = exp(1e-2*rg[iso])*iso."""
+
+
+class AffineCouplingSdnEx2(_Conditional):
+    """AffineCouplingSdnEx2.py + cond_utils.py:101-138: sqrt(gain*(sig(b1)*y/gain + sig(b2))), gain = exp(0.1*g[iso])*iso."""
+
+
+class AffineCouplingSdnEx3(_Conditional):
+    """AffineCouplingSdnEx3.py + cond_utils.py:141-175: gain*sqrt(sig(b1)*y/gain + sig(b2))."""
+
+
+class AffineCouplingSdnEx6(_Conditional):
+    """AffineCouplingSdnEx6.py + cond_utils.py:242-276: SdnEx5 with ONE camera parameter (on the gain exponent)."""
+
+
+class AffineCouplingGainEx1(_Conditional):
+    """AffineCouplingGainEx1.py + cond_utils.py:333-350: exp(1e-5*g1)*iso + exp(1e-5*g2); log|det| once per patch."""
+
+
+class AffineCouplingGainEx2(_Conditional):
+    """AffineCouplingGainEx2.py + cond_utils.py:353-392: exp(0.1*g[iso])*iso; log|det| = -H*W*C*log(scale)."""
+
+
+class AffineCouplingGainEx3(_Conditional):
+    """AffineCouplingGainEx3.py + cond_utils.py:395-429: exp(1e-5*g[iso]); log|det| once per patch."""
+
+
+_CLASS = {"sdn1": AffineCouplingSdnEx1, "sdn2": AffineCouplingSdnEx2, "sdn3": AffineCouplingSdnEx3, "sdn6": AffineCouplingSdnEx6,
+          "gain1": AffineCouplingGainEx1, "gain2": AffineCouplingGainEx2, "gain3": AffineCouplingGainEx3,
+          "sdn4": AffineCouplingSdnEx4, "sdn": AffineCouplingSdn, "gain": AffineCouplingGain, "conv1x1": Conv2d1x1, "coupling": AffineCoupling, "sdn5": AffineCouplingSdnEx5, "gain4": AffineCouplingGainEx4}
 
 
 def bijectors_from_arch(arch: str, variables: Dict[str, np.ndarray], x_shape, width: int,

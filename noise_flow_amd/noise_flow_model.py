@@ -130,7 +130,7 @@ class FlowHandle:
         _lib.check(self.lib.nf_create(C.byref(cfg), descs, flat.ctypes.data_as(C.POINTER(C.c_float)), flat.size,
                                       C.byref(h)))
         self._h = h
-        self.has_sdn = any(L.kind in ("sdn5", "sdn4", "sdn") for L in self.layers)
+        self.has_sdn = any(L.kind.startswith("sdn") for L in self.layers)
         self.width = int(width)
         # template scope of every coupling CNN, NLL layer order (the rows of nf_*_batchstats' moments)
         tb = tmpl if layers is not None else _params.template_binding(self.layers, binding)

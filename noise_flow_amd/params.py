@@ -15,7 +15,13 @@ import numpy as np
 
 from . import _lib
 
-SUPPORTED_LAYERS = ("unc", "sdn5", "gain4", "sdn4", "sdn", "gain")
+SUPPORTED_LAYERS = ("unc", "sdn", "sdn1", "sdn2", "sdn3", "sdn4", "sdn5", "sdn6", "gain", "gain1", "gain2", "gain3", "gain4")
+ISO_TABLE = (100, 400, 800, 1600, 3200)   # per-ISO variables of the Ex1-Ex3 layers (cond_utils.py:62-68)
+_SCALAR_KINDS = {   # arch key -> (NF_LAYER_*, display prefix)   noise_flow_model.py:106-223
+    "sdn1": ("NF_LAYER_SDN1", "sdn"), "sdn2": ("NF_LAYER_SDN2", "sdn"), "sdn3": ("NF_LAYER_SDN3", "sdn"),
+    "sdn6": ("NF_LAYER_SDN6", "sdn"), "gain1": ("NF_LAYER_GAIN1", "gain"), "gain2": ("NF_LAYER_GAIN2", "gain"),
+    "gain3": ("NF_LAYER_GAIN3", "gain"),
+}
 C_I = 1.0   # train_noise_flow.py:207 / NoiseFlowWrapper.py:125
 
 
@@ -48,6 +54,9 @@ def parse_arch(arch: str) -> List[LayerSpec]:
             layers.append(LayerSpec("sdn", "sdn_%d" % i, i, _lib.NF_LAYER_SDN))
         elif lyr == "gain":      # noise_flow_model.py:183-192
             layers.append(LayerSpec("gain", "gain_%d" % i, i, _lib.NF_LAYER_GAIN))
+        elif lyr in _SCALAR_KINDS:   # noise_flow_model.py:116-147, 171-182, 193-223
+            typ, prefix = _SCALAR_KINDS[lyr]
+            layers.append(LayerSpec(lyr, "%s_%d" % (prefix, i), i, getattr(_lib, typ)))
         else:
             raise NotImplementedError(
                 "arch layer %r is not on the MI355X hot path (supported: %s)" % (lyr, "|".join(SUPPORTED_LAYERS)))
@@ -113,6 +122,17 @@ def layer_variable_names(L: LayerSpec, tmpl: Dict[int, int]) -> List[Optional[st
         return ["model/b1", "model/b2"]
     if L.kind == "gain":   # gain_model_params (cond_utils.py:319-330)
         return ["model/g1", "model/g2"]
+    if L.kind == "sdn1":   # sdn_model_params_ex1 (cond_utils.py:55-98)
+        return ["model/b1", "model/b2"] + ["model/r_gain_param_%05d" % iso for iso in ISO_TABLE]
+    if L.kind in ("sdn2", "sdn3"):   # sdn_model_params_ex2 / _ex3 (cond_utils.py:101-175)
+        return ["model/b1", "model/b2"] + ["model/gain_param_%05d" % iso for iso in ISO_TABLE]
+    if L.kind == "sdn6":   # sdn_model_params_ex6 (cond_utils.py:242-276): cam_params is [1, 5]
+        return ["model/sdn_gain/beta1", "model/sdn_gain/beta2", "model/sdn_gain/gain_params",
+                "model/sdn_gain/cam_params", None]
+    if L.kind == "gain1":  # gain_model_params_ex1 (cond_utils.py:333-350)
+        return ["model/g1", "model/g2"]
+    if L.kind in ("gain2", "gain3"):   # gain_model_params_ex2 / _ex3 (cond_utils.py:353-429)
+        return ["model/gain_param_%05d" % iso for iso in ISO_TABLE]
     return ["model/sdn_gain/gain_val"]   # gain4
 
 
@@ -242,11 +262,35 @@ def init_variables(arch: str, width: int = 4, channels: int = 4, seed: int = 0) 
     if any(L.kind == "gain" for L in layers):
         v["model/g1"] = np.full((1,), -3.0, np.float32)     # cond_utils.py:321-324
         v["model/g2"] = np.full((1,), 3.0, np.float32)
+    kinds = {L.kind for L in layers}
+    gain_init = -5.0                                         # hps.gain_init (sidd/ArgParser.py default)
+    if kinds & {"sdn1", "sdn2", "sdn3"}:
+        v["model/b1"] = np.full((1,), -3.0, np.float32)     # cond_utils.py:90-93
+        v["model/b2"] = np.full((1,), 3.0, np.float32)
+    if "sdn1" in kinds:
+        for iso in ISO_TABLE:
+            v["model/r_gain_param_%05d" % iso] = np.zeros((1,), np.float32)               # init / c = 0 (cond_utils.py:60-68)
+    if kinds & {"sdn2", "sdn3", "gain2"}:
+        for iso in ISO_TABLE:
+            v["model/gain_param_%05d" % iso] = np.full((1,), gain_init / 1e-1, np.float32)   # cond_utils.py:102-112, 361-366
+    elif "gain3" in kinds:
+        for iso in ISO_TABLE:
+            v["model/gain_param_%05d" % iso] = np.full((1,), -5.0 / 1e-5, np.float32)      # cond_utils.py:401-405
+    if "gain1" in kinds:
+        v["model/g1"] = np.full((1,), -5.0 / 1e-5, np.float32)                             # cond_utils.py:341-342
+        v["model/g2"] = np.zeros((1,), np.float32)
+    if "sdn6" in kinds:
+        v["model/sdn_gain/beta1"] = np.full((1,), -5.0 / C_I, np.float32)
+        v["model/sdn_gain/beta2"] = np.zeros((1,), np.float32)
+        v["model/sdn_gain/gain_params"] = np.full((5,), -5.0 / C_I, np.float32)
+        v["model/sdn_gain/cam_params"] = np.ones((1, 5), np.float32)                        # one parameter per camera
+        v["model/sdn_gain/gain_val"] = np.ones((1,), np.float32)
     if any(L.kind in ("sdn5", "gain4", "sdn4") for L in layers):
         v["model/sdn_gain/beta1"] = np.full((1,), -5.0 / C_I, np.float32)
         v["model/sdn_gain/beta2"] = np.zeros((1,), np.float32)
         v["model/sdn_gain/gain_params"] = np.full((5,), -5.0 / C_I, np.float32)
-        v["model/sdn_gain/cam_params"] = np.ones((3, 5), np.float32)
+        if "sdn6" not in kinds:   # sdn6 owns the (AUTO_REUSE'd) scope's cam_params as [1, 5]
+            v["model/sdn_gain/cam_params"] = np.ones((3, 5), np.float32)
         v["model/sdn_gain/gain_val"] = np.ones((1,), np.float32)
     return v
 

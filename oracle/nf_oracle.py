@@ -298,6 +298,57 @@ def gain_plain_scale(p, iso, dtype):
     return dtype(_sigmoid(float(np.asarray(p["g1"]).reshape(-1)[0])) * float(iso) + _sigmoid(float(np.asarray(p["g2"]).reshape(-1)[0])))
 
 
+ISO_TABLE = (100, 400, 800, 1600, 3200)
+
+
+def _iso_entry(table, iso):
+    """The nested tf.cond of the Ex1-Ex3 layers (cond_utils.py:69-88): the entry of ISO 100/400/800/1600/3200,
+    any other ISO falls through to the ISO-800 entry."""
+    iso = float(np.asarray(iso).reshape(-1)[0])
+    k = ISO_TABLE.index(int(iso)) if iso in ISO_TABLE else 2
+    return np.asarray(table).reshape(-1)[k]
+
+
+def sdn_ex123_scale(y, p, iso, kind):
+    """sdn_model_params_ex1 / _ex2 / _ex3 (cond_utils.py:55-175)."""
+    dt = y.dtype.type
+    iso_v = dt(float(np.asarray(iso).reshape(-1)[0]))
+    c = dt(1e-2) if kind == "sdn1" else dt(1e-1)
+    gain = np.exp(c * dt(_iso_entry(p["table"], iso))) * iso_v
+    b1 = dt(_sigmoid(float(np.asarray(p["b1"]).reshape(-1)[0])))
+    b2 = dt(_sigmoid(float(np.asarray(p["b2"]).reshape(-1)[0])))
+    if kind == "sdn1":
+        return np.sqrt(b1 * y / gain + b2)
+    if kind == "sdn2":
+        return np.sqrt(gain * (b1 * y / gain + b2))
+    return gain * np.sqrt(b1 * y / gain + b2)
+
+
+def sdn_ex6_scale(y, p, iso, cam, c_i=1.0):
+    """sdn_model_params_ex6 (cond_utils.py:242-276): ONE camera parameter, on the gain exponent only."""
+    dt = y.dtype.type
+    cam = float(np.asarray(cam).reshape(-1)[0])
+    iso_f = float(np.asarray(iso).reshape(-1)[0])
+    if cam not in (0.0, 1.0, 2.0, 3.0, 4.0):
+        raise ValueError("unknown camera id %r" % cam)
+    cp = np.exp(dt(c_i) * dt(np.asarray(p["cam_params"]).reshape(-1)[int(cam)]))
+    g = dt(np.asarray(p["gain_params"]).reshape(-1)[ISO_TABLE.index(int(iso_f))]) if iso_f in ISO_TABLE else dt(0.0)
+    gain = np.exp(dt(c_i) * g * cp) * dt(iso_f)
+    beta1 = np.exp(dt(c_i) * dt(np.asarray(p["beta1"]).reshape(-1)[0]))
+    beta2 = np.exp(dt(c_i) * dt(np.asarray(p["beta2"]).reshape(-1)[0]))
+    return np.sqrt(beta1 * y / gain + beta2)
+
+
+def gain_ex123_scale(p, iso, kind, dtype):
+    """gain_model_params_ex1 / _ex2 / _ex3 (cond_utils.py:333-429); the layers feed gain = iso."""
+    iso_f = float(np.asarray(iso).reshape(-1)[0])
+    if kind == "gain1":
+        return dtype(np.exp(1e-5 * float(np.asarray(p["g1"]).reshape(-1)[0])) * iso_f + np.exp(1e-5 * float(np.asarray(p["g2"]).reshape(-1)[0])))
+    if kind == "gain2":
+        return dtype(np.exp(1e-1 * float(_iso_entry(p["table"], iso))) * iso_f)
+    return dtype(np.exp(1e-5 * float(_iso_entry(p["table"], iso))))
+
+
 def sdn_ex5_inverse(x, y, p, iso, cam):
     """AffineCouplingSdnEx5._inverse_and_log_det_jacobian, AffineCouplingSdnEx5.py:118-132."""
     scale = sdn_ex5_scale(y, p, iso, cam)
@@ -335,8 +386,8 @@ def parse_arch(arch: str) -> List[Tuple[str, int]]:
     """noise_flow_model.py:71-235: 'a|b|c' → [(layer_type, i)], i = position in arch."""
     out = []
     for i, lyr in enumerate(arch.split("|")):
-        if lyr not in ("unc", "sdn5", "gain4", "sdn4", "sdn", "gain"):
-            raise ValueError("oracle supports unc|sdn5|gain4|sdn4|sdn|gain only, got %r" % lyr)
+        if lyr not in ("unc", "sdn", "sdn1", "sdn2", "sdn3", "sdn4", "sdn5", "sdn6", "gain", "gain1", "gain2", "gain3", "gain4"):
+            raise ValueError("oracle supports unc, sdn[1-6], gain[1-4] only, got %r" % lyr)
         out.append((lyr, i))
     return out
 
@@ -347,7 +398,7 @@ def layer_names(arch: str) -> List[str]:
     for lyr, i in parse_arch(arch):
         if lyr == "unc":
             names += ["Conv2d_1x1_%d" % i, "unc_%d" % i]
-        elif lyr in ("sdn5", "sdn4", "sdn"):
+        elif lyr.startswith("sdn"):
             names.append("sdn_%d" % i)
         else:
             names.append("gain_%d" % i)
@@ -403,6 +454,19 @@ def bind_variables(arch: str, variables: Dict[str, np.ndarray], binding: str = "
             layers.append({"type": "sdn", "name": "sdn_%d" % i, "p": {"b1": f(variables["model/b1"]), "b2": f(variables["model/b2"])}})
         elif lyr == "gain":
             layers.append({"type": "gain", "name": "gain_%d" % i, "p": {"g1": f(variables["model/g1"]), "g2": f(variables["model/g2"])}})
+        elif lyr in ("sdn1", "sdn2", "sdn3"):
+            tab = "model/r_gain_param_%05d" if lyr == "sdn1" else "model/gain_param_%05d"
+            p = {"b1": f(variables["model/b1"]), "b2": f(variables["model/b2"]),
+                 "table": np.concatenate([f(variables[tab % iso]).reshape(-1) for iso in ISO_TABLE])}
+            layers.append({"type": lyr, "name": "sdn_%d" % i, "p": p})
+        elif lyr == "sdn6":
+            p = {k: f(variables["model/sdn_gain/" + k]) for k in ("beta1", "beta2", "gain_params", "cam_params")}
+            layers.append({"type": "sdn6", "name": "sdn_%d" % i, "p": p})
+        elif lyr == "gain1":
+            layers.append({"type": "gain1", "name": "gain_%d" % i, "p": {"g1": f(variables["model/g1"]), "g2": f(variables["model/g2"])}})
+        elif lyr in ("gain2", "gain3"):
+            p = {"table": np.concatenate([f(variables["model/gain_param_%05d" % iso]).reshape(-1) for iso in ISO_TABLE])}
+            layers.append({"type": lyr, "name": "gain_%d" % i, "p": p})
         else:
             layers.append({"type": "gain4", "name": "gain_%d" % i, "gain_val": f(variables["model/sdn_gain/gain_val"])})
     return layers
@@ -508,11 +572,18 @@ class NoiseFlowOracle:
             elif L["type"] in ("sdn4", "sdn"):
                 scale = sdn_ex4_scale(y, L["p"], iso) if L["type"] == "sdn4" else sdn_plain_scale(y, L["p"])
                 z, ld = z / scale, -np.log(scale).sum(axis=(1, 2, 3))
-            elif L["type"] == "gain":
-                # AffineCouplingGain.py:113-127: log|det| = -log(scale), a [1]-tensor broadcast over the
-                # batch — the reference omits the H*W*C factor; restated as written
-                g = gain_plain_scale(L["p"], iso, dt)
+            elif L["type"] in ("sdn1", "sdn2", "sdn3", "sdn6"):
+                scale = sdn_ex6_scale(y, L["p"], iso, cam) if L["type"] == "sdn6" else sdn_ex123_scale(y, L["p"], iso, L["type"])
+                z, ld = z / scale, -np.log(scale).sum(axis=(1, 2, 3))
+            elif L["type"] in ("gain", "gain1", "gain3"):
+                # AffineCouplingGain.py:113-127 (and GainEx1 / GainEx3): log|det| = -log(scale), a [1]-tensor
+                # broadcast over the batch — the reference omits the H*W*C factor; restated as written
+                g = gain_plain_scale(L["p"], iso, dt) if L["type"] == "gain" else gain_ex123_scale(L["p"], iso, L["type"], dt)
                 z, ld = z / g, np.full((z.shape[0],), -np.log(g), dtype=z.dtype)
+            elif L["type"] == "gain2":
+                # AffineCouplingGainEx2.py:112-126: scale += y*0 broadcasts first, so the sum runs over H*W*C
+                g = gain_ex123_scale(L["p"], iso, "gain2", dt)
+                z, ld = z / g, np.full((z.shape[0],), -z[0].size * np.log(g), dtype=z.dtype)
             else:
                 z, ld = gain_ex4_inverse(z, L["gain_val"])
             obj = obj + ld
@@ -550,8 +621,14 @@ class NoiseFlowOracle:
                 x = x * sdn_ex4_scale(y, L["p"], iso)
             elif L["type"] == "sdn":
                 x = x * sdn_plain_scale(y, L["p"])
+            elif L["type"] in ("sdn1", "sdn2", "sdn3"):
+                x = x * sdn_ex123_scale(y, L["p"], iso, L["type"])
+            elif L["type"] == "sdn6":
+                x = x * sdn_ex6_scale(y, L["p"], iso, cam)
             elif L["type"] == "gain":
                 x = x * gain_plain_scale(L["p"], iso, dt)
+            elif L["type"] in ("gain1", "gain2", "gain3"):
+                x = x * gain_ex123_scale(L["p"], iso, L["type"], dt)
             else:
                 x = gain_ex4_forward(x, L["gain_val"])
         return x

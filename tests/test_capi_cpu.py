@@ -182,7 +182,8 @@ def test_error_reporting(shipped_variables):
     assert fold(_lib.nf_config(32, 32, 4, len(layers), -1, 0), n=100) == _lib.NF_EINVAL
     assert fold(_lib.nf_config(32, 32, 4, len(layers), -1, 0)) == 0 and n_ops.value == 17
     with pytest.raises(NotImplementedError):
-        params.parse_arch("unc|sdn3")
+        params.parse_arch("unc|sdn7")          # not a key of noise_flow_arch (noise_flow_model.py:79-234)
+    assert [L.kind for L in params.parse_arch("sdn3|gain2")] == ["sdn3", "gain2"]
     with pytest.raises(KeyError):
         params.pack("unc|unc|unc|unc|unc|unc|unc|unc|unc", shipped_variables, 4)   # no 9th template in the ckpt
 

@@ -534,6 +534,54 @@ def test_secondary_layer_variants(arch, iso):
         zz = ref_z
 
 
+@pytest.mark.parametrize("arch,iso,cam", [("sdn1|gain1", 400, 2), ("sdn2|unc|gain2|unc", 1600, 0), ("sdn3|gain3", 100, 4),
+                                          ("sdn6|unc|gain4|unc", 3200, 1), ("sdn1|unc|gain3", 250, 2), ("sdn6|gain2", 250, 3)])
+def test_remaining_arch_vocabulary(arch, iso, cam):
+    """The rest of noise_flow_arch's layer keys (noise_flow_model.py:116-223): sdn1/2/3/6 and gain1/2/3 — per-ISO
+    tables (an ISO outside 100..3200 falls through to the ISO-800 entry; sdn6's one-hot selects 0 instead), one camera
+    parameter (sdn6), GainEx2's full H*W*C log-det against the once-per-patch one of Gain / GainEx1 / GainEx3."""
+    v = trained_like_variables(arch, 4, seed=17)
+    rng = np.random.RandomState(3)
+    kinds = set(arch.split("|"))
+    for k in list(v):
+        if "r_gain_param_" not in k and "gain_param_" in k:    # distinct entry per ISO, the resulting scale stays O(1)
+            if kinds & {"sdn2", "sdn3", "gain2"}:            # gain = exp(0.1 g) iso
+                v[k] = np.asarray([(-np.log(max(iso, 100)) + 0.3 * rng.randn()) / 1e-1], np.float32)
+            else:                                            # gain3: scale = exp(1e-5 g)
+                v[k] = np.asarray([0.3 * rng.randn() / 1e-5], np.float32)
+        elif "r_gain_param_" in k:
+            v[k] = np.asarray([(-np.log(iso) + 0.3 * rng.randn()) / 1e-2], np.float32)
+        elif k in ("model/b1", "model/b2"):
+            v[k] = np.asarray([rng.randn()], np.float32)
+        elif k == "model/g1":
+            v[k] = np.asarray([-np.log(iso) / 1e-5], np.float32)
+        elif k == "model/g2":
+            v[k] = np.asarray([-0.7 / 1e-5], np.float32)
+        elif k == "model/sdn_gain/cam_params":
+            v[k] = (1.0 + 0.2 * rng.randn(*v[k].shape)).astype(np.float32)
+        elif k == "model/sdn_gain/gain_params":
+            v[k] = (-np.log(np.asarray([100, 400, 800, 1600, 3200.0])) * 0.8 + 0.1 * rng.randn(5)).astype(np.float32)
+        elif k in ("model/sdn_gain/beta1", "model/sdn_gain/beta2"):
+            v[k] = np.asarray([-1.0 + 0.3 * rng.randn()], np.float32)
+    x, y = make_inputs(5, seed=int(iso))
+    m = _model(arch, v)
+    o = _oracle(arch, v)
+    nll, sd = m._loss(x, y, [0], [0], [iso], [cam])
+    ref, rsd, rz = o.nll(x, y, iso, cam)
+    np.testing.assert_allclose(nll, ref, rtol=NLL_RTOL)
+    z, obj = m.inverse(x, None, y, [0], [0], [iso], [cam])
+    _close_elem(z, rz)
+    np.testing.assert_allclose(obj, o.inverse(x, y, iso, cam)[1], rtol=NLL_RTOL, atol=1e-3)
+    eps = np.random.RandomState(2).randn(5, 32, 32, 4).astype(np.float32)
+    _close_elem(m.sample(y, 0.7, y, [0], [0], [iso], [cam], eps=eps), o.sample(eps, 0.7, y, iso, cam))
+    assert m.get_layer_names() == [L["name"] for L in o.layers]
+    if "sdn6" in arch:
+        from noise_flow_amd._lib import NoiseFlowLibError, NF_ECOND
+        with pytest.raises(NoiseFlowLibError) as ei:
+            m._loss(x, y, [0], [0], [iso], [7])
+        assert ei.value.code == NF_ECOND
+
+
 def test_full_bench_batch_against_c_oracle(shipped_variables):
     """Every patch of a full configs[1] batch (1024) and a configs[2] batch (4096 eps-supplied
     samples) against the plain-C oracle (fp32, reference op order)."""
