@@ -270,9 +270,10 @@ void relayout_coupling_v3(const float *v1, float *out)
 
 // Wide-CNN re-layout (nf_device.h, NF4_*; coupling width 32): every weight in the order the lanes of
 // v_mfma_f32_32x32x2_f32 / v_mfma_f32_4x4x1 fetch their A operands (nf_wide.hip).
-void relayout_coupling_wide32(const float *v1, float *out)
+// `w` = the coupling's own width (8, 16 or 32): narrower CNNs are zero-padded to 32 hidden channels (exact: a padded
+// channel has zero weights and zero bias in l_1 / l_2, hence zero activation, and zero l_last weights).
+void relayout_coupling_wide32(const float *v1, int w, float *out)
 {
-    const int w = 32;
     const double k2 = 2.0 * 1.4426950408889634, log2e = 1.4426950408889634;
     for (int m = 0; m < 16; ++m)
         for (int j = 0; j < 4; ++j) {
@@ -290,26 +291,27 @@ void relayout_coupling_wide32(const float *v1, float *out)
     for (int step = 0; step < 12; ++step)          // l_1: step = tap, K slice = input channel
         for (int l = 0; l < 64; ++l)
             img[NF4_IMG_A1 + ((step >> 2) * 64 + l) * 4 + (step & 3)] =
-                step < 9 ? W1[(step * 2 + (l >> 5)) * w + (l & 31)] : 0.0f;
+                (step < 9 && (l & 31) < w) ? W1[(step * 2 + (l >> 5)) * w + (l & 31)] : 0.0f;
     for (int g = 0; g < 2; ++g)
         for (int v = 0; v < 16; ++v) {
-            img[NF4_IMG_B1 + g * 16 + v] = B1[nf4_chan(v, g)];
-            img[NF4_IMG_B2 + g * 16 + v] = B2[nf4_chan(v, g)];
+            const int ch = nf4_chan(v, g);
+            img[NF4_IMG_B1 + g * 16 + v] = ch < w ? B1[ch] : 0.0f;
+            img[NF4_IMG_B2 + g * 16 + v] = ch < w ? B2[ch] : 0.0f;
         }
     // taps (di,dj) of the 8 off-centre rows groups of P, by (a, g')
     static const int tap_of[4][2] = {{0 * 3 + 0, 2 * 3 + 0}, {0 * 3 + 2, 2 * 3 + 2}, {0 * 3 + 1, 2 * 3 + 1}, {1 * 3 + 0, 1 * 3 + 2}};
     for (int s = 0; s < 16; ++s)
         for (int l = 0; l < 64; ++l) {
             const int cin = nf4_chan(s, l >> 5), i = l & 31;
-            img[NF4_IMG_A2 + ((s >> 2) * 64 + l) * 4 + (s & 3)] = W2[cin * w + i];
+            img[NF4_IMG_A2 + ((s >> 2) * 64 + l) * 4 + (s & 3)] = (cin < w && i < w) ? W2[cin * w + i] : 0.0f;
             const int a = i >> 3, gp = (i >> 2) & 1, j = i & 3;
-            const double wv = W3[(tap_of[a][gp] * w + cin) * 4 + j];
+            const double wv = cin < w ? W3[(tap_of[a][gp] * w + cin) * 4 + j] : 0.0;
             img[NF4_IMG_A3 + ((s >> 2) * 64 + l) * 4 + (s & 3)] = (float)(j >= 2 ? wv * k2 : wv);
         }
     for (int s = 0; s < 16; ++s)
         for (int g = 0; g < 2; ++g)
             for (int j = 0; j < 4; ++j) {
-                const double wv = W3[(4 * w + nf4_chan(s, g)) * 4 + j];   // centre tap (1,1)
+                const double wv = nf4_chan(s, g) < w ? W3[(4 * w + nf4_chan(s, g)) * 4 + j] : 0.0;   // centre tap (1,1)
                 img[NF4_IMG_A3C + ((s >> 2) * 8 + g * 4 + j) * 4 + (s & 3)] = (float)(j >= 2 ? wv * k2 : wv);
             }
 }
@@ -626,8 +628,14 @@ int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float
     }
     out.block4.clear();
     memset(&out.prog4, 0, sizeof(out.prog4));
-    if (out.prog.width == 32) {
-        out.prog4.width = 32;
+    // width 32: the product path; widths 8 / 16 only where the scalar-weight kernel's LDS tile does not fit (patches
+    // larger than 32x32 at width 16, 48x48 at width 8): zero-padded to 32 channels
+    {
+        const size_t tile_px = ((size_t)(cfg->height + 2) * (cfg->width + 2) + 1) & ~(size_t)1;
+        const bool scalar_fits = sizeof(float) * (tile_px * (2 + (size_t)out.prog.width) + 64) <= 160 * 1024;
+        if (out.prog.width == 32 || ((out.prog.width == 8 || out.prog.width == 16) && !scalar_fits)) out.prog4.width = 32;
+    }
+    if (out.prog4.width == 32) {
         for (int i = 0; i < out.prog.n_ops; ++i) {
             const NfOp &src = out.prog.ops[i];
             NfOp &dst = out.prog4.ops[out.prog4.n_ops++];
@@ -638,7 +646,7 @@ int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float
                 out.block4.insert(out.block4.end(), v1, v1 + 16);
             } else if (src.type == NF_OP_COUPLING_FWD || src.type == NF_OP_COUPLING_REV) {
                 out.block4.resize(out.block4.size() + NF4_CPL_SIZE);
-                relayout_coupling_wide32(v1, out.block4.data() + dst.off);
+                relayout_coupling_wide32(v1, out.prog.width, out.block4.data() + dst.off);
             } else if (src.type == NF_OP_SCALE) {
                 out.block4.insert(out.block4.end(), v1, v1 + 4);
             } else {

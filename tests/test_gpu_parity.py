@@ -483,12 +483,12 @@ def test_fp16_coupling_cnn_mode(shipped_variables, oracle_full, hw, B):
     np.testing.assert_allclose(nll, ref32, rtol=1e-4)
 
 
-def test_oversized_tile_is_rejected_at_create():
+def test_oversized_patch_is_rejected_at_create():
     from noise_flow_amd._lib import NoiseFlowLibError, NF_EINVAL
     v = trained_like_variables("unc", 8)
     with pytest.raises(NoiseFlowLibError) as ei:
-        _model("unc", v, (64, 64, 4), 8)          # 66*66*(2+8)*4 B = 170 KiB of LDS
-    assert ei.value.code == NF_EINVAL and "LDS" in str(ei.value)
+        _model("unc", v, (65, 64, 4), 8)          # patches are at most 64x64 (one workgroup per patch)
+    assert ei.value.code == NF_EINVAL and "64x64" in str(ei.value)
 
 
 def test_fp16_mode_rejects_unsupported_shapes(shipped_variables):

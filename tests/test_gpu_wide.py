@@ -51,6 +51,29 @@ def test_wide32_matrix_core_kernel_matches_oracle(hw):
     _close_elem(xs, o.sample(eps, 0.8, y, 100, 2))
 
 
+@pytest.mark.parametrize("width,hw", [(16, (64, 64)), (8, (64, 64)), (16, (40, 56)), (8, (60, 64))])
+def test_narrower_widths_on_large_patches_use_the_wide_kernel(width, hw):
+    """Widths 8 / 16 beyond the scalar-weight kernel's LDS tile (round 1 rejected them at create): zero-padded to 32
+    hidden channels on the matrix-core kernel — exact, since a padded channel is identically zero."""
+    from noise_flow_amd import _lib
+    from oracle.nf_oracle import NoiseFlowOracle
+    H, W = hw
+    v = trained_like_variables(ARCH, width, seed=H + W + width)
+    x, y = make_inputs(3, H, W, seed=8)
+    m = _model(ARCH, v, (H, W, 4), width)
+    assert _path(m, 0) == _lib.NF_PATH_WIDE32
+    o = NoiseFlowOracle(ARCH, v)
+    nll, sd = m._loss(x, y, [0.0], [0.0], [100], [2])
+    ref_nll, ref_sd, ref_z = o.nll(x, y, 100, 2)
+    np.testing.assert_allclose(nll, ref_nll, rtol=NLL_RTOL, atol=1e-4)
+    z, _ = m.inverse(x, None, y, [0.0], [0.0], [100], [2])
+    _close_elem(z, ref_z)
+    eps = np.random.RandomState(4).randn(3, H, W, 4).astype(np.float32)
+    _close_elem(m.sample(y, 0.8, y, [0.0], [0.0], [100], [2], eps=eps), o.sample(eps, 0.8, y, 100, 2))
+    # a shape the scalar kernel holds stays on it
+    assert _path(_model(ARCH, trained_like_variables(ARCH, width, seed=1), (32, 32, 4), width), 0) == _lib.NF_PATH_SCALAR
+
+
 def test_wide32_full_arch_batch_and_round_trip():
     """The shipped layer sequence at width 32, a batch larger than the resident grid (persistent stride loop),
     slotted sums, and sample(nll(x)) = x."""
