@@ -48,7 +48,8 @@ ARCH_LABEL = "sdn5|unc|unc|unc|unc|gain4|unc|unc|unc|unc"
 ALGO_BYTES_PER_PATCH = 2 * 32 * 32 * 4 * 4          # read x and y once (fp32): 32768 B
 ALGO_FLOP_PER_PATCH = 5.1e6
 HBM_PEAK_GBS = 8000.0                                # MI355X_MICROARCH.md: 8 TB/s spec
-VALU_PEAK_TFLOPS = 157.3                             # fp32 vector peak
+VALU_PEAK_TFLOPS = 157.3                             # fp32 vector peak = fp32-input matrix peak
+FP16_MFMA_PEAK_TFLOPS = 2500.0                       # dense fp16 matrix peak (MI355X_MICROARCH.md)
 
 
 def _usable_cores(threads: int) -> int:
@@ -539,27 +540,32 @@ def _wide_cnn(ctx, batches, cond, wide):
     args, dev = ctx["args"], ctx["dev"]
     x, y = batches[0]
     out = {}
-    for w in (32, 16):
+    for w, dt in ((32, "fp32"), (16, "fp32"), (32, "fp16")):
         hps = default_hps(width=w)
         var = _params.init_variables(hps.arch, w, 4, 1234)
         rng = np.random.RandomState(w)
         for k in list(var):                 # fresh init has a zero last layer: perturb so that every term is live
             if k.endswith("l_last/W") or k.endswith("l_last/b"):
                 var[k] = (0.02 * rng.randn(*var[k].shape)).astype(np.float32)
-        m = NoiseFlow([32, 32, 4], False, hps, variables=var, device=dev.index)
+        m = NoiseFlow([32, 32, 4], False, hps, variables=var, device=dev.index, cnn_dtype=dt)
         kw = max(5, min(args.steps, 20))
         ms, nll = _time_nll(m, x, y, cond, kw, dev)
         flop = wide_flop_per_pixel(w) * 1024 * x.shape[0]
         tfl = flop / (ms * 1e-3) / 1e12
-        out["w%d" % w] = {"width": w, "batch": int(x.shape[0]), "steps": kw, "kernel_ms": ms,
-                          "value": x.shape[0] / (ms * 1e-3), "unit": "patches/s",
-                          "finite": bool(np.isfinite(nll.cpu().numpy()).all()),
-                          "roofline": {"bound": "mfma", "achieved": tfl, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                       "frac": tfl / VALU_PEAK_TFLOPS, "algorithmic_flop_per_launch": flop,
-                                       "mac_per_pixel_per_coupling": 16 + 18 * w + w * w + 36 * (w + 1),
-                                       "dtype": "f32 in / f32 accumulate (exact fp32)"}}
+        peak = VALU_PEAK_TFLOPS if dt == "fp32" else FP16_MFMA_PEAK_TFLOPS
+        path = m._flow.lib.nf_kernel_path(m._flow.ptr, 0)
+        out["w%d%s" % (w, "" if dt == "fp32" else "_fp16")] = {
+            "width": w, "cnn_dtype": dt, "batch": int(x.shape[0]), "steps": kw, "kernel_ms": ms,
+            "value": x.shape[0] / (ms * 1e-3), "unit": "patches/s", "finite": bool(np.isfinite(nll.cpu().numpy()).all()),
+            "kernel_path": {0: "scalar-weight VALU kernel", 3: "nf_wide32_kernel (v_mfma_f32_32x32x2_f32)",
+                            5: "nf_wide32_kernel (v_mfma_f32_32x32x16_f16)"}.get(path, str(path)),
+            "roofline": {"bound": "mfma", "achieved": tfl, "peak": peak, "unit": "TFLOP/s", "frac": tfl / peak,
+                         "algorithmic_flop_per_launch": flop, "mac_per_pixel_per_coupling": 16 + 18 * w + w * w + 36 * (w + 1),
+                         "dtype": "f32 in / f32 accumulate (exact fp32)" if dt == "fp32" else
+                                  "f16 in / f32 accumulate for the three CNN convs; everything else fp32"}}
         del m
-    out["workload"] = "forward NLL, 1024 synthetic 32x32x4 patches, arch %s with coupling-CNN width 32 / 16" % ARCH_LABEL
+    out["workload"] = ("forward NLL, 1024 synthetic 32x32x4 patches, arch %s with coupling-CNN width 32 / 16 (fresh wide CNN weights: "
+                       "no wide checkpoint ships); w32_fp16 = NF_CFG_FP16_CNN" % ARCH_LABEL)
     return out
 
 

@@ -108,8 +108,9 @@ typedef struct nf_config {
 
 /* nf_config.flags */
 #define NF_CFG_FP16_CNN 1   /* coupling CNN convs in fp16 (fp32 accumulate) on the matrix cores;
-                              1x1 mixes, tanh/exp, log-det and prior stay fp32.  Width 4, full
-                              32x32 or 64x64 patches only (BASELINE configs[4]).            */
+                              1x1 mixes, tanh/exp, log-det and prior stay fp32.  Width 4: full
+                              32x32 or 64x64 patches only (BASELINE configs[4]); widths 8 / 16 / 32:
+                              any patch up to 64x64 (v_mfma_f32_32x32x16_f16).               */
 
 /* Per-call conditioning: ONE value per call, not per patch — the reference
  * feeds length-1 lists (MiniBatchSampler.py:61-64, NoiseFlowWrapper.py:85-86).
@@ -282,6 +283,7 @@ int nf_fold_params(const nf_config *cfg, const nf_layer_desc *layers,
 #define NF_PATH_FP16 2
 #define NF_PATH_WIDE32 3
 #define NF_PATH_WIDE16 4
+#define NF_PATH_WIDE32_FP16 5   /* NF_CFG_FP16_CNN at width 8 / 16 / 32: v_mfma_f32_32x32x16_f16 */
 int nf_kernel_path(const nf_handle *h, int32_t direction);
 
 /* Host-only: the SDN5 scalars the kernels receive for a given (iso, cam):

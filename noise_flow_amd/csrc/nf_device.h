@@ -134,6 +134,26 @@ __host__ __device__ constexpr int nf_cpl_size(int w)   { return 64 + 36 * w + 18
 #define NF4_CPL_SIZE (NF4_CPL_IMG + NF4_IMG_SIZE)
 __host__ __device__ constexpr int nf4_chan(int v, int g) { return 8 * (v >> 2) + 4 * g + (v & 3); }
 
+// ---- wide-CNN fp16 layout (NF_CFG_FP16_CNN at coupling width 32) --------------------------------
+// Same kernel structure on v_mfma_f32_32x32x16_f16 (K = 16 per instruction, fp32 accumulate): an A / B operand is 8
+// halves = 4 dwords per lane, the K slice of lane half g being elements 8g .. 8g+7.  Folded weights and the three CNN
+// inputs (z0, relu(h1), relu(h2)) are rounded to half; biases, border table, tanh/exp, log-det stay fp32 (as NF3_*).
+//   COUPLING  E [16][4] @0 (raw columns pre-scaled by 2 log2 e), S [4] @64, IMG16 @68 (dwords):
+//     A1H [2][64][4]  l_1, 2 instructions: #0 element q of lane half g = (tap 4g + q/2, ch q&1); #1: g=0, q<2 = (tap 8, ch q)
+//     B1  [2][16]     fp32, as NF4
+//     A2H [2][64][4]  l_2: instruction m, element q = input channel c(8m + q, g)
+//     B2  [2][16]
+//     A3H [2][64][4]  P rows as NF4_IMG_A3 (NOT pre-scaled: the kernel scales the raw columns in fp32)
+//     A3CH[4][8][2]   centre tap on v_mfma_f32_4x4x4_16b_f16: instruction q, (g, j): channels c(4q .. 4q+3, g)
+#define NF5_IMG_A1H 0
+#define NF5_IMG_B1 512
+#define NF5_IMG_A2H 544
+#define NF5_IMG_B2 1056
+#define NF5_IMG_A3H 1088
+#define NF5_IMG_A3CH 1600
+#define NF5_IMG_SIZE 1664
+#define NF5_CPL_SIZE (NF4_CPL_IMG + NF5_IMG_SIZE)
+
 // launch flags
 enum : uint32_t {
     NF_K_PRIOR     = 1u,   // nll = -(logdet + logp(z)); otherwise nll = -logdet

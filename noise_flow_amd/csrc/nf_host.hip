@@ -316,6 +316,57 @@ void relayout_coupling_wide32(const float *v1, int w, float *out)
             }
 }
 
+// fp16 variant of the wide layout (nf_device.h, NF5_*): folded weights rounded to half, in the fetch order of
+// v_mfma_f32_32x32x16_f16 (8 halves per lane and instruction) / v_mfma_f32_4x4x4_16b_f16 (centre tap).
+void relayout_coupling_wide32_fp16(const float *v1, int w, float *out)
+{
+    const double k2 = 2.0 * 1.4426950408889634, log2e = 1.4426950408889634;
+    for (int m = 0; m < 16; ++m)
+        for (int j = 0; j < 4; ++j) {
+            const double e = v1[nf_cpl_off_E(w) + 4 * m + j];
+            out[NF4_CPL_E + 4 * m + j] = (float)(j >= 2 ? e * k2 : e);
+        }
+    const double sc = v1[nf_cpl_off_S(w)];
+    out[NF4_CPL_S + 0] = (float)sc;
+    out[NF4_CPL_S + 1] = (float)(sc * log2e);
+    out[NF4_CPL_S + 2] = (float)(-2.0 * sc * log2e);
+    out[NF4_CPL_S + 3] = 0.0f;
+    float *img = out + NF4_CPL_IMG;
+    memset(img, 0, NF5_IMG_SIZE * sizeof(float));
+    uint16_t *h = reinterpret_cast<uint16_t *>(img);   // half index = 2 * dword index
+    const float *W1 = v1 + nf_cpl_off_W1(w), *B1 = v1 + nf_cpl_off_B1(w), *W2 = v1 + nf_cpl_off_W2(w);
+    const float *B2 = v1 + nf_cpl_off_B2(w), *W3 = v1 + nf_cpl_off_W3(w);
+    static const int tap_of[4][2] = {{0 * 3 + 0, 2 * 3 + 0}, {0 * 3 + 2, 2 * 3 + 2}, {0 * 3 + 1, 2 * 3 + 1}, {1 * 3 + 0, 1 * 3 + 2}};
+    for (int l = 0; l < 64; ++l) {
+        const int i = l & 31, g = l >> 5;
+        for (int q = 0; q < 8; ++q) {
+            // l_1, instruction 0: taps 4g .. 4g+3; instruction 1: tap 8 on lane half 0
+            const int tap = 4 * g + (q >> 1), ch = q & 1;
+            h[2 * (NF5_IMG_A1H + (0 * 64 + l) * 4) + q] = i < w ? to_half(W1[(tap * 2 + ch) * w + i]) : 0;
+            h[2 * (NF5_IMG_A1H + (1 * 64 + l) * 4) + q] = (i < w && g == 0 && q < 2) ? to_half(W1[(8 * 2 + q) * w + i]) : 0;
+            for (int m = 0; m < 2; ++m) {
+                const int cin = nf4_chan(8 * m + q, g);
+                h[2 * (NF5_IMG_A2H + (m * 64 + l) * 4) + q] = (cin < w && i < w) ? to_half(W2[cin * w + i]) : 0;
+                const int a = i >> 3, gp = (i >> 2) & 1, j = i & 3;
+                h[2 * (NF5_IMG_A3H + (m * 64 + l) * 4) + q] = cin < w ? to_half(W3[(tap_of[a][gp] * w + cin) * 4 + j]) : 0;
+            }
+        }
+    }
+    for (int g = 0; g < 2; ++g)
+        for (int v = 0; v < 16; ++v) {
+            const int ch = nf4_chan(v, g);
+            img[NF5_IMG_B1 + g * 16 + v] = ch < w ? B1[ch] : 0.0f;
+            img[NF5_IMG_B2 + g * 16 + v] = ch < w ? B2[ch] : 0.0f;
+        }
+    for (int q = 0; q < 4; ++q)
+        for (int g = 0; g < 2; ++g)
+            for (int j = 0; j < 4; ++j)
+                for (int r = 0; r < 4; ++r) {
+                    const int cin = nf4_chan(4 * q + r, g);
+                    h[2 * (NF5_IMG_A3CH + (q * 8 + g * 4 + j) * 2) + r] = cin < w ? to_half(W3[(4 * w + cin) * 4 + j]) : 0;   // centre tap
+                }
+}
+
 // ---- sdn5 host scalars (cond_utils.py:205-239) -------------------------------
 int sdn5_scalars(const float *sp, const nf_cond *cond, double out[2])
 {
@@ -448,8 +499,10 @@ struct Built {
     std::vector<float> block2;   // empty when unavailable
     NfProgram prog3;             // fp16-CNN layout (NF_CFG_FP16_CNN), width 4 only
     std::vector<float> block3;
-    NfProgram prog4;             // wide-CNN layout (NF4_*), width 32 only
+    NfProgram prog4;             // wide-CNN layout (NF4_*), width 32 (8 / 16 zero-padded on large patches)
     std::vector<float> block4;
+    NfProgram prog5;             // wide-CNN fp16 layout (NF5_*): NF_CFG_FP16_CNN at widths 8 / 16 / 32
+    std::vector<float> block5;
     double ld_const = 0.0;
     bool has_sdn = false;      // some op reads the clean image y
 };
@@ -655,6 +708,29 @@ int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float
         }
         if (out.block4.empty()) out.block4.assign(4, 0.0f);
     }
+    out.block5.clear();
+    memset(&out.prog5, 0, sizeof(out.prog5));
+    if ((cfg->flags & NF_CFG_FP16_CNN) && (out.prog.width == 8 || out.prog.width == 16 || out.prog.width == 32)) {
+        out.prog5.width = 32;
+        for (int i = 0; i < out.prog.n_ops; ++i) {
+            const NfOp &src = out.prog.ops[i];
+            NfOp &dst = out.prog5.ops[out.prog5.n_ops++];
+            dst.type = src.type;
+            dst.off = (int32_t)out.block5.size();
+            const float *v1 = out.block.data() + src.off;
+            if (src.type == NF_OP_MIX) {
+                out.block5.insert(out.block5.end(), v1, v1 + 16);
+            } else if (src.type == NF_OP_COUPLING_FWD || src.type == NF_OP_COUPLING_REV) {
+                out.block5.resize(out.block5.size() + NF5_CPL_SIZE);
+                relayout_coupling_wide32_fp16(v1, out.prog.width, out.block5.data() + dst.off);
+            } else if (src.type == NF_OP_SCALE) {
+                out.block5.insert(out.block5.end(), v1, v1 + 4);
+            } else {
+                dst.off = src.off;   // conditioning slot
+            }
+        }
+        if (out.block5.empty()) out.block5.assign(4, 0.0f);
+    }
     out.block3.clear();
     memset(&out.prog3, 0, sizeof(out.prog3));
     if (out.prog.width == 4 && (cfg->flags & NF_CFG_FP16_CNN)) {
@@ -743,6 +819,8 @@ struct nf_handle {
     float *d_rev3 = nullptr;
     float *d_fwd4 = nullptr;   // wide-CNN layout (width 32)
     float *d_rev4 = nullptr;
+    float *d_fwd5 = nullptr;   // wide-CNN fp16 layout
+    float *d_rev5 = nullptr;
     // batch-statistics mode (nf_*_batchstats): the raw model and a lazily allocated scratch
     std::vector<nf_layer_desc> layers;
     std::vector<float> raw;
@@ -809,7 +887,7 @@ int nf_create(const nf_config *cfg, const nf_layer_desc *layers, const float *pa
     {   // the two LDS tiles of the scalar-weight kernel must fit one CU (160 KiB)
         const size_t tile_px = ((size_t)(cfg->height + 2) * (cfg->width + 2) + 1) & ~(size_t)1;
         const size_t lds = sizeof(float) * (tile_px * (2 + (size_t)h->fwd.prog.width) + 64);
-        if (lds > 160 * 1024 && h->fwd.block2.empty() && h->fwd.block4.empty()) {
+        if (lds > 160 * 1024 && h->fwd.block2.empty() && h->fwd.block4.empty() && h->fwd.block5.empty()) {
             const int w = h->fwd.prog.width;
             delete h;
             return fail(NF_EINVAL, "a %dx%d patch with coupling width %d needs %zu KiB of LDS (> 160): unsupported",
@@ -849,15 +927,17 @@ int nf_create(const nf_config *cfg, const nf_layer_desc *layers, const float *pa
     }
     if (cfg->flags & NF_CFG_FP16_CNN) {
         const int hw = cfg->height * cfg->width;
-        if (h->fwd.block3.empty() || !((cfg->height == 32 && cfg->width == 32) || (cfg->height == 64 && cfg->width == 64)) || hw == 0) {
+        const bool w4_ok = !h->fwd.block3.empty() && ((cfg->height == 32 && cfg->width == 32) || (cfg->height == 64 && cfg->width == 64));
+        if ((!w4_ok && h->fwd.block5.empty()) || hw == 0) {
             nf_destroy(h);   // the scalar-layout blocks are already on the device
-            return fail(NF_EINVAL, "NF_CFG_FP16_CNN needs coupling width 4 and full 32x32 or 64x64 patches");
+            return fail(NF_EINVAL, "NF_CFG_FP16_CNN needs coupling width 4 with full 32x32 or 64x64 patches, or width 8 / 16 / 32");
         }
     }
-    for (int d = 0; d < 6; ++d) {
+    for (int d = 0; d < 8; ++d) {
         const std::vector<float> &b2 = d == 0 ? h->fwd.block2 : d == 1 ? h->rev.block2 : d == 2 ? h->fwd.block3 : d == 3 ? h->rev.block3
-                                       : d == 4 ? h->fwd.block4 : h->rev.block4;
-        float **dst = d == 0 ? &h->d_fwd2 : d == 1 ? &h->d_rev2 : d == 2 ? &h->d_fwd3 : d == 3 ? &h->d_rev3 : d == 4 ? &h->d_fwd4 : &h->d_rev4;
+                                       : d == 4 ? h->fwd.block4 : d == 5 ? h->rev.block4 : d == 6 ? h->fwd.block5 : h->rev.block5;
+        float **dst = d == 0 ? &h->d_fwd2 : d == 1 ? &h->d_rev2 : d == 2 ? &h->d_fwd3 : d == 3 ? &h->d_rev3 : d == 4 ? &h->d_fwd4
+                      : d == 5 ? &h->d_rev4 : d == 6 ? &h->d_fwd5 : &h->d_rev5;
         if (b2.empty()) continue;
         if ((e = hipMalloc((void **)dst, b2.size() * sizeof(float))) != hipSuccess ||
             (e = hipMemcpy(*dst, b2.data(), b2.size() * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) {
@@ -882,6 +962,8 @@ int nf_destroy(nf_handle *h)
     if (h->d_rev3) (void)hipFree(h->d_rev3);
     if (h->d_fwd4) (void)hipFree(h->d_fwd4);
     if (h->d_rev4) (void)hipFree(h->d_rev4);
+    if (h->d_fwd5) (void)hipFree(h->d_fwd5);
+    if (h->d_rev5) (void)hipFree(h->d_rev5);
     nf_bs_destroy(h->bs);
     delete h;
     return NF_OK;
@@ -970,7 +1052,16 @@ static int launch_resident(nf_handle *h, int direction, NfLaunch &a, hipStream_t
     float *d2 = direction == 0 ? h->d_fwd2 : h->d_rev2;
     float *d3 = direction == 0 ? h->d_fwd3 : h->d_rev3;
     float *d4 = direction == 0 ? h->d_fwd4 : h->d_rev4;
+    float *d5 = direction == 0 ? h->d_fwd5 : h->d_rev5;
     if (direction == 0) a.ld_const += b.ld_const;
+    if (d5) {   // NF_CFG_FP16_CNN at width 8 / 16 / 32: v_mfma_f32_32x32x16_f16
+        a.params = d5;
+        a.n_params = (int32_t)b.block5.size();
+        a.flags |= NF_K_FP16_CNN;
+        hipError_t e = nf_launch_wide(b.prog5, a, h->n_cu, h->device, st);
+        if (e != hipSuccess) return fail_hip(e, what);
+        return NF_OK;
+    }
     if (d4 && use_matrix_core()) {   // width 32: the three convs on v_mfma_f32_32x32x2_f32 (nf_wide.hip)
         a.params = d4;
         a.n_params = (int32_t)b.block4.size();
@@ -996,6 +1087,7 @@ static int launch_resident(nf_handle *h, int direction, NfLaunch &a, hipStream_t
 int nf_kernel_path(const nf_handle *h, int32_t direction)
 {
     if (!h || (direction != 0 && direction != 1)) return fail(NF_EINVAL, "bad argument");
+    if (direction == 0 ? h->d_fwd5 : h->d_rev5) return NF_PATH_WIDE32_FP16;
     if ((direction == 0 ? h->d_fwd4 : h->d_rev4) && use_matrix_core()) return NF_PATH_WIDE32;
     if (direction == 0 ? h->d_fwd3 : h->d_rev3) return NF_PATH_FP16;
     if ((direction == 0 ? h->d_fwd2 : h->d_rev2) && use_matrix_core()) return NF_PATH_MFMA4;

@@ -31,6 +31,20 @@
 namespace {
 
 typedef float v16f __attribute__((ext_vector_type(16)));
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+typedef _Float16 v4hh __attribute__((ext_vector_type(4)));
+typedef _Float16 v2hh __attribute__((ext_vector_type(2)));
+
+// relu(a), relu(b) rounded to half, packed in one dword (v_cvt_pk_f16_f32 + v_pk_max_f16)
+__device__ __forceinline__ uint32_t relu_pack_h2(float a, float b)
+{
+    const v2hh h = __builtin_elementwise_max(v2hh{(_Float16)a, (_Float16)b}, v2hh{0, 0});
+    return __builtin_bit_cast(uint32_t, h);
+}
+__device__ __forceinline__ v8h as_v8h(uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+    return __builtin_bit_cast(v8h, make_uint4(a, b, c, d));
+}
 
 constexpr int TPW = 8;   // tiles (= rows of a strip) per wavefront
 
@@ -76,21 +90,24 @@ __device__ __forceinline__ float half_sums(float a, float b)
 //   THREADS  64 x number of strips: (rows / 8) x TPR
 //   PHILOX   input = in-kernel Philox/Box-Muller draw
 //   TPR      tiles per image row: 1 (W <= 32) or 2 (W <= 64)
+//   PREC     0 = fp32 (v_mfma_f32_32x32x2_f32), 1 = fp16 CNN convs (v_mfma_f32_32x32x16_f16, fp32 accumulate; NF5_* layout)
 // Pixel ownership: the CNN of a tile needs all 64 lanes (lane half g = K slice), everything else is per pixel —
 // so lane half g OWNS the rows row0 + 2m + g (m = 0..3) of its strip: their 4 channel values live in its registers,
 // it does their global I/O, 1x1 mixes, signal-dependent scaling, affine update and log-det.
-template <int THREADS, bool PHILOX, int TPR>
+template <int THREADS, bool PHILOX, int TPR, int PREC>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS == 256 ? NF_WIDE_WPE : 1))) void nf_wide32_kernel(const NfProgram prog, const NfLaunch a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NW = THREADS / 64;
     constexpr int OWN = TPW / 2;
+    constexpr bool H16 = PREC == 1;
+    constexpr int IMG = H16 ? NF5_IMG_SIZE : NF4_IMG_SIZE;
     const int H = a.H, W = a.W, HW = H * W;
     const int Wp = W + 2;
     const int PL = ((H + 2) * Wp + 3) & ~3;             // one channel plane of the z0 tile
-    float *const z0s = smem;                             // [2][PL]
-    float *const wbuf = z0s + 2 * PL;                    // [NF4_IMG_SIZE] weights of the current coupling
-    float *const exch = wbuf + NF4_IMG_SIZE;             // [NW][2][32][4] strip-boundary rows
+    float *const z0s = smem;                             // fp32: [2][PL] channel planes; fp16: [PL] half2 per pixel (+ unused plane)
+    float *const wbuf = z0s + 2 * PL;                    // [IMG] weights of the current coupling
+    float *const exch = wbuf + IMG;                      // [NW][2][32][4] strip-boundary rows
     float *const side = exch + NW * 256;                 // TPR == 2: [2][H+2][3][4] column-seam taps
     float *const red = side + (TPR == 2 ? 2 * (H + 2) * 12 : 0);   // [3][NW] reduction scratch
 
@@ -103,8 +120,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS
     const float ml = n > 0 ? 1.0f : 0.0f, mr = (n < 31 && c + 1 < W) ? 1.0f : 0.0f;
     const float mg0 = g == 0 ? 1.0f : 0.0f, mg1 = g == 1 ? 1.0f : 0.0f;
     const float ml0 = ml * mg0, mr1 = mr * mg1;
+    [[maybe_unused]] int toff[4];   // fp16 l_1: z0-tile offsets of the taps 4g .. 4g+3 this lane half contributes
+#pragma unroll
+    for (int q = 0; q < 4; ++q) toff[q] = ((4 * g + q) / 3) * Wp + (4 * g + q) % 3;
 
-    for (int i = t; i < 2 * PL + NF4_IMG_SIZE + NW * 256 + (TPR == 2 ? 2 * (H + 2) * 12 : 0); i += THREADS) smem[i] = 0.0f;
+    for (int i = t; i < 2 * PL + IMG + NW * 256 + (TPR == 2 ? 2 * (H + 2) * 12 : 0); i += THREADS) smem[i] = 0.0f;
     __syncthreads();
 
     const int n_ops = prog.n_ops;
@@ -163,14 +183,19 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS
                 for (int m = 0; m < OWN; ++m) {
                     const int r = row0 + 2 * m + g;
                     if (r < H && col_on) {
-                        z0s[(r + 1) * Wp + c + 1] = z[m][0];
-                        z0s[PL + (r + 1) * Wp + c + 1] = z[m][1];
+                        if constexpr (H16) {
+                            const v2hh zh = {(_Float16)z[m][0], (_Float16)z[m][1]};
+                            reinterpret_cast<uint32_t *>(z0s)[(r + 1) * Wp + c + 1] = __builtin_bit_cast(uint32_t, zh);
+                        } else {
+                            z0s[(r + 1) * Wp + c + 1] = z[m][0];
+                            z0s[PL + (r + 1) * Wp + c + 1] = z[m][1];
+                        }
                     }
                 }
                 {
                     const float4 *src = reinterpret_cast<const float4 *>(a.params + prog.ops[op].off + NF4_CPL_IMG);
                     float4 *dst = reinterpret_cast<float4 *>(wbuf);
-                    for (int i = t; i < NF4_IMG_SIZE / 4; i += THREADS) dst[i] = src[i];
+                    for (int i = t; i < IMG / 4; i += THREADS) dst[i] = src[i];
                 }
                 __syncthreads();
 
@@ -186,6 +211,51 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS
                     const int r = row0 + k;
                     if (r >= H) continue;   // wave-uniform
                     if constexpr (NF_WIDE_CLOBBER) asm volatile("" ::: "memory");
+                    v16f p;
+                    v4f pc = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr (H16) {
+                        const uint4 *const wq = reinterpret_cast<const uint4 *>(wbuf);
+                        const uint32_t *const zh = reinterpret_cast<const uint32_t *>(z0s) + r * Wp + c;   // tap (di,dj) at + di*Wp + dj
+                        v16f d;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float4 bb = wb4[NF5_IMG_B1 / 4 + g * 4 + q];
+                            d[4 * q + 0] = bb.x; d[4 * q + 1] = bb.y; d[4 * q + 2] = bb.z; d[4 * q + 3] = bb.w;
+                        }
+                        {   // l_1: K = 18 in two instructions; lane half g brings taps 4g .. 4g+3, then (half 0) tap 8
+                            const uint4 a0 = wq[NF5_IMG_A1H / 4 + lane], a1 = wq[NF5_IMG_A1H / 4 + 64 + lane];
+                            const v8h b0 = as_v8h(zh[toff[0]], zh[toff[1]], zh[toff[2]], zh[toff[3]]);
+                            const v8h b1 = as_v8h(zh[2 * Wp + 2], 0u, 0u, 0u);
+                            d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, a0), b0, d, 0, 0, 0);
+                            d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, a1), b1, d, 0, 0, 0);
+                        }
+                        v16f e;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float4 bb = wb4[NF5_IMG_B2 / 4 + g * 4 + q];
+                            e[4 * q + 0] = bb.x; e[4 * q + 1] = bb.y; e[4 * q + 2] = bb.z; e[4 * q + 3] = bb.w;
+                        }
+#pragma unroll
+                        for (int mm = 0; mm < 2; ++mm) {
+                            const uint4 aw = wq[NF5_IMG_A2H / 4 + mm * 64 + lane];
+                            const v8h hb = as_v8h(relu_pack_h2(d[8 * mm + 0], d[8 * mm + 1]), relu_pack_h2(d[8 * mm + 2], d[8 * mm + 3]),
+                                                  relu_pack_h2(d[8 * mm + 4], d[8 * mm + 5]), relu_pack_h2(d[8 * mm + 6], d[8 * mm + 7]));
+                            e = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, aw), hb, e, 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int v = 0; v < 16; ++v) p[v] = 0.0f;
+                        const uint2 *const wc = reinterpret_cast<const uint2 *>(wbuf + NF5_IMG_A3CH);
+#pragma unroll
+                        for (int mm = 0; mm < 2; ++mm) {
+                            const uint4 aw = wq[NF5_IMG_A3H / 4 + mm * 64 + lane];
+                            const uint32_t h0 = relu_pack_h2(e[8 * mm + 0], e[8 * mm + 1]), h1 = relu_pack_h2(e[8 * mm + 2], e[8 * mm + 3]);
+                            const uint32_t h2 = relu_pack_h2(e[8 * mm + 4], e[8 * mm + 5]), h3 = relu_pack_h2(e[8 * mm + 6], e[8 * mm + 7]);
+                            p = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, aw), as_v8h(h0, h1, h2, h3), p, 0, 0, 0);
+                            const uint2 c0 = wc[(2 * mm + 0) * 8 + g * 4 + (lane & 3)], c1 = wc[(2 * mm + 1) * 8 + g * 4 + (lane & 3)];
+                            pc = __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(v4hh, c0), __builtin_bit_cast(v4hh, make_uint2(h0, h1)), pc, 0, 0, 0);
+                            pc = __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(v4hh, c1), __builtin_bit_cast(v4hh, make_uint2(h2, h3)), pc, 0, 0, 0);
+                        }
+                    } else {
                     v16f d;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
@@ -217,10 +287,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS
                         for (int s = 0; s < 4; ++s)
                             e = __builtin_amdgcn_mfma_f32_32x32x2f32(as[s], nf_relu(d[grp * 4 + s]), e, 0, 0, 0);
                     }
-                    v16f p;
 #pragma unroll
                     for (int v = 0; v < 16; ++v) p[v] = 0.0f;
-                    v4f pc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int grp = 0; grp < 4; ++grp) {
                         const float4 aw = wb4[NF4_IMG_A3 / 4 + grp * 64 + lane];
@@ -233,6 +301,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS
                             p = __builtin_amdgcn_mfma_f32_32x32x2f32(as[s], h, p, 0, 0, 0);
                             pc = __builtin_amdgcn_mfma_f32_4x4x1f32(cs[s], h, pc, 0, 0, 0);
                         }
+                    }
                     }
                     // horizontal part of the shift-add.  Register group a of lane half g' holds the taps
                     //   a=0: (0,0)|(2,0) -> from the left   a=1: (0,2)|(2,2) -> from the right
@@ -312,7 +381,13 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS
                     const bool act = r < H && col_on;
                     const int bm = (r == 0 ? 1 : 0) | (r == H - 1 ? 2 : 0) | (c == 0 ? 4 : 0) | (c == W - 1 ? 8 : 0);
                     const float4 eb = *reinterpret_cast<const float4 *>(a.params + prog.ops[op].off + NF4_CPL_E + 4 * (act ? bm : 0));
-                    o[0] += eb.x; o[1] += eb.y; o[2] += eb.z; o[3] += eb.w;
+                    if constexpr (H16) {   // fp16 weights are not pre-scaled (their rounding points are the oracle's); the table is
+                        o[0] += eb.x; o[1] += eb.y;
+                        o[2] = fmaf(o[2], 2.8853900817779268f, eb.z);
+                        o[3] = fmaf(o[3], 2.8853900817779268f, eb.w);
+                    } else {
+                        o[0] += eb.x; o[1] += eb.y; o[2] += eb.z; o[3] += eb.w;
+                    }
                     // raw columns are pre-scaled by 2 log2(e):  t = exp2(raw') = exp(2 raw);
                     // ls*log2(e) = scl*tanh(raw) = scl - 2 scl/(t + 1); log-det accumulated in log2 units
                     const float l0 = fmaf(__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(o[2]) + 1.0f), m2scl, scl);
@@ -419,19 +494,19 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS
     }
 }
 
-size_t wide_lds_bytes(int H, int W, int threads, int tpr)
+size_t wide_lds_bytes(int H, int W, int threads, int tpr, int prec)
 {
     const int Wp = W + 2, PL = ((H + 2) * Wp + 3) & ~3, NW = threads / 64;
-    size_t f = 2 * (size_t)PL + NF4_IMG_SIZE + (size_t)NW * 256 + (tpr == 2 ? 2 * (size_t)(H + 2) * 12 : 0) + ((3 * NW + 3) & ~3);
+    size_t f = 2 * (size_t)PL + (prec ? NF5_IMG_SIZE : NF4_IMG_SIZE) + (size_t)NW * 256 + (tpr == 2 ? 2 * (size_t)(H + 2) * 12 : 0) + ((3 * NW + 3) & ~3);
     return f * sizeof(float);
 }
 
-template <int THREADS, bool PHILOX, int TPR>
-hipError_t launch_wide(const NfProgram &prog, const NfLaunch &a, int n_cu, int device, hipStream_t stream)
+template <int THREADS, bool PHILOX, int TPR, int PREC>
+hipError_t launch_wide_p(const NfProgram &prog, const NfLaunch &a, int n_cu, int device, hipStream_t stream)
 {
-    const size_t lds = wide_lds_bytes(a.H, a.W, THREADS, TPR);
+    const size_t lds = wide_lds_bytes(a.H, a.W, THREADS, TPR, PREC);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    const void *fn = reinterpret_cast<const void *>(&nf_wide32_kernel<THREADS, PHILOX, TPR>);
+    const void *fn = reinterpret_cast<const void *>(&nf_wide32_kernel<THREADS, PHILOX, TPR, PREC>);
     // (device << 40 | lds bytes << 8 | resident workgroups per CU) of the last query; racy but idempotent
     static std::atomic<uint64_t> cache{0};
     const uint64_t key = ((uint64_t)(device & 0xff) << 40) | ((uint64_t)lds << 8);
@@ -454,8 +529,15 @@ hipError_t launch_wide(const NfProgram &prog, const NfLaunch &a, int n_cu, int d
     int64_t groups = (int64_t)n_cu * occ;
     if (a.B < groups) groups = a.B;
     if (groups < 1) groups = 1;
-    hipLaunchKernelGGL((nf_wide32_kernel<THREADS, PHILOX, TPR>), dim3((unsigned)groups), dim3(THREADS), lds, stream, prog, a);
+    hipLaunchKernelGGL((nf_wide32_kernel<THREADS, PHILOX, TPR, PREC>), dim3((unsigned)groups), dim3(THREADS), lds, stream, prog, a);
     return hipGetLastError();
+}
+
+template <int THREADS, bool PHILOX, int TPR>
+hipError_t launch_wide(const NfProgram &prog, const NfLaunch &a, int n_cu, int device, hipStream_t stream)
+{
+    if (a.flags & NF_K_FP16_CNN) return launch_wide_p<THREADS, PHILOX, TPR, 1>(prog, a, n_cu, device, stream);
+    return launch_wide_p<THREADS, PHILOX, TPR, 0>(prog, a, n_cu, device, stream);
 }
 
 template <bool PHILOX>

@@ -119,3 +119,31 @@ def test_wide32_in_kernel_philox_matches_numpy_philox():
     eps = philox.sample_eps(77, 0, B, H, W)
     ref = NoiseFlowOracle(ARCH, v).sample(eps, 0.7, y, 100, 2)
     _close_elem(xs, ref, rtol=3e-5)   # Box-Muller on the hardware transcendental unit: ~1e-6 absolute on eps
+
+
+@pytest.mark.parametrize("width,hw", [(32, (32, 32)), (32, (64, 64)), (32, (20, 28)), (32, (40, 50)), (16, (32, 32)), (8, (24, 24))])
+def test_wide_fp16_cnn_mode(width, hw):
+    """NF_CFG_FP16_CNN at widths 8 / 16 / 32 (v_mfma_f32_32x32x16_f16, fp32 accumulate, fp32 log-det): against the oracle's
+    emulation of the rounding points — BN and exp(3 logs) folded in fp64, THEN the folded weights and the three CNN inputs
+    rounded to half once — 1e-4 relative on the NLL, 2e-3 of scale on tensors (a near-tie at a half-rounding point may flip
+    an activation by one fp16 ulp), and the mode stays within 2e-4 of the all-fp32 model on the NLL."""
+    from noise_flow_amd import NoiseFlow, default_hps, _lib
+    from oracle.nf_oracle import NoiseFlowOracle
+    H, W = hw
+    v = trained_like_variables(ARCH, width, seed=5 + width)
+    for k in v:   # activations of O(1) at every width (the helper's weights are tuned for width 4)
+        if k.endswith("l_2/W") or k.endswith("l_last/W"):
+            v[k] = (v[k] * np.float32((4.0 / width) ** 0.5)).astype(np.float32)
+    x, y = make_inputs(4, H, W, seed=12)
+    m = NoiseFlow([H, W, 4], False, default_hps(arch=ARCH, width=width), variables=v, cnn_dtype="fp16")
+    assert _path(m, 0) == _lib.NF_PATH_WIDE32_FP16 and _path(m, 1) == _lib.NF_PATH_WIDE32_FP16
+    o16 = NoiseFlowOracle(ARCH, v, cnn_dtype="fp16")
+    nll, sd = m._loss(x, y, [0.0], [0.0], [100], [2])
+    ref, rsd, rz = o16.nll(x, y, 100, 2)
+    np.testing.assert_allclose(nll, ref, rtol=1e-4)
+    assert abs(sd - rsd) <= 1e-4 * rsd
+    z, _ = m.inverse(x, None, y, [0.0], [0.0], [100], [2])
+    _close_elem(z, rz, rtol=2e-3)
+    eps = np.random.RandomState(3).randn(4, H, W, 4).astype(np.float32)
+    _close_elem(m.sample(y, 0.6, y, [0.0], [0.0], [100], [2], eps=eps), o16.sample(eps, 0.6, y, 100, 2), rtol=2e-3)
+    np.testing.assert_allclose(nll, NoiseFlowOracle(ARCH, v).nll(x, y, 100, 2)[0], rtol=2e-4)

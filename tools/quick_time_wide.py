@@ -1,4 +1,4 @@
-"""Tuning aid: time the forward NLL / sampling at a coupling-CNN width.  python tools/quick_time_wide.py [width] [B] [H] [iters]"""
+"""Tuning aid: time the forward NLL / sampling at a coupling-CNN width.  python tools/quick_time_wide.py [width] [B] [H] [iters] [fp32|fp16]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -12,13 +12,14 @@ w = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 H = int(sys.argv[3]) if len(sys.argv) > 3 else 32
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 20
+dtype = sys.argv[5] if len(sys.argv) > 5 else "fp32"
 hps = default_hps(width=w)
 var = _params.init_variables(hps.arch, w, 4, 1234)
 rng = np.random.RandomState(w)
 for k in list(var):
     if k.endswith("l_last/W") or k.endswith("l_last/b"):
         var[k] = (0.02 * rng.randn(*var[k].shape)).astype(np.float32)
-m = NoiseFlow([H, H, 4], False, hps, variables=var)
+m = NoiseFlow([H, H, 4], False, hps, variables=var, cnn_dtype=dtype)
 x, y = synth_patches(0, 0, B, H, H)
 eps = torch.randn_like(x)
 print("kernel path", m._flow.lib.nf_kernel_path(m._flow.ptr, 0))
