@@ -160,6 +160,7 @@ enum : uint32_t {
     NF_K_PHILOX_IN = 2u,   // input = Philox normal draw (sampling with in-kernel eps)
     NF_K_FP16_CNN  = 4u,   // parameter block is the fp16-CNN layout (NF3_*)
     NF_K_SUMS_WIDE = 8u,   // `sums` is the slotted layout of NF_SUMS_WIDE (include/noiseflow_hip.h)
+    NF_K_BATCHSTATS = 16u, // matrix-core launch of a batch-statistics call: honours fix_* and stats
 };
 
 struct NfLaunch {
@@ -188,6 +189,14 @@ struct NfLaunch {
     double *stats;
     int32_t stats_op;
     int32_t stats_stage;
+    // matrix-core batch-statistics launches (NF_K_BATCHSTATS, width 4): the re-fold the PREVIOUS statistics pass makes
+    // due — every workgroup applies it to its LDS weight image, workgroup 0 persists it for the next launch
+    const double *fix_stats;   // [NF_STATS_SLOTS][8] sums of that pass, or null
+    double fix_n;              // number of values behind each sum (B*H*W)
+    int32_t fix_off;           // offset of the coupling's block in the matrix-core layout
+    int32_t fix_stage;         // 1: l_1 / BN_1, 2: l_2 / BN_2
+    float *fix_params_out;     // parameter block the next launch reads (n_params floats)
+    float *fix_mom_out;        // mean[4], var[4] of that normalisation
 };
 
 #define NF_STATS_SLOTS 64   // power of two

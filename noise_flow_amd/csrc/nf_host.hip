@@ -1143,6 +1143,7 @@ struct BsPlan {
     std::vector<int> cpl_ops;         // op index of every coupling in ident.prog, execution order
     std::vector<int> cpl_row;         // its row in moments_out (NLL layer order)
     std::vector<NfProgram> progA, progB;
+    std::vector<NfProgram> progA2, progB2;   // the same segments over the matrix-core layout (width 4)
     int32_t *d_pairs = nullptr;       // (dst in matrix-core block, src in scalar block) of the BN-dependent entries
     int n_pairs = 0;
 };
@@ -1150,7 +1151,10 @@ struct BsPlan {
 struct nf_bs_state {
     BsPlan plan[2];
     float *d_work = nullptr, *d_work2 = nullptr;   // working copies of the parameter block (scalar / matrix-core layout)
-    size_t work_cap = 0, work2_cap = 0;
+    float *d_work2b = nullptr;                      // matrix-core path: the launches ping-pong between two copies
+    size_t work_cap = 0, work2_cap = 0, work2b_cap = 0;
+    double *d_stats_mc = nullptr;                   // matrix-core path: one [NF_STATS_SLOTS][8] block per statistics pass
+    size_t stats_mc_passes = 0;
     double *d_stats = nullptr;
     float *d_mom = nullptr;            // [couplings][4][w]
     float *d_T[2] = {nullptr, nullptr};
@@ -1164,6 +1168,8 @@ struct nf_bs_state {
         }
         if (d_work) (void)hipFree(d_work);
         if (d_work2) (void)hipFree(d_work2);
+        if (d_work2b) (void)hipFree(d_work2b);
+        if (d_stats_mc) (void)hipFree(d_stats_mc);
         if (d_stats) (void)hipFree(d_stats);
         if (d_mom) (void)hipFree(d_mom);
         if (d_T[0]) (void)hipFree(d_T[0]);
@@ -1216,6 +1222,26 @@ static int bs_build_plan(nf_handle *h, int direction, BsPlan &P)
         for (int i = first; i <= P.cpl_ops[c]; ++i) {
             A.ops[A.n_ops++] = prog.ops[i];
             B.ops[B.n_ops++] = prog.ops[i];
+        }
+    }
+    if (!P.ident.block2.empty()) {   // same op sequences, offsets of the matrix-core layout
+        auto to_mc = [&](const NfProgram &src) {
+            NfProgram dst = src;
+            for (int i = 0; i < src.n_ops; ++i) {
+                if (src.ops[i].type == NF_OP_STORE) continue;
+                for (int k = 0; k < prog.n_ops; ++k)   // identify the op in the full program by (type, offset)
+                    if (prog.ops[k].type == src.ops[i].type && prog.ops[k].off == src.ops[i].off) {
+                        dst.ops[i].off = P.ident.prog2.ops[k].off;
+                        break;
+                    }
+            }
+            return dst;
+        };
+        P.progA2.resize(n_cpl);
+        P.progB2.resize(n_cpl);
+        for (int c = 0; c < n_cpl; ++c) {
+            P.progA2[c] = to_mc(P.progA[c]);
+            P.progB2[c] = to_mc(P.progB[c]);
         }
     }
     hipError_t e;
@@ -1302,6 +1328,86 @@ static int run_batchstats(nf_handle *h, int direction, NfLaunch a, float *moment
             (e = hipMalloc((void **)&S.d_T[1], tensor * sizeof(float))) != hipSuccess)
             return fail_hip(e, "hipMalloc(batch-statistics scratch tensors)");
         S.T_cap = tensor;
+    }
+    if (nw2 && P.ident.prog.width == 4 && use_matrix_core()) {
+        // ---- width 4: every launch on the matrix-core kernel, the re-fold fused into the consumer's prologue ----
+        // launch k gathers the sums of pass k into its own block of `d_stats_mc`; launch k+1 (every workgroup, in LDS)
+        // turns them into moments and rescales the layer, workgroup 0 writes the patched image to the OTHER working
+        // copy, which launch k+2 reads.  2 launches per coupling + the final fused pass, nothing else on the stream.
+        const size_t passes = 2 * (size_t)n_cpl;
+        if ((e = grow(S.d_work2b, S.work2b_cap, nw2)) != hipSuccess) return fail_hip(e, "hipMalloc(batch-statistics parameters)");
+        if (S.stats_mc_passes < passes) {
+            if (S.d_stats_mc) (void)hipFree(S.d_stats_mc);
+            S.d_stats_mc = nullptr;
+            S.stats_mc_passes = 0;
+            if ((e = hipMalloc((void **)&S.d_stats_mc, passes * NF_STATS_SLOTS * 8 * sizeof(double))) != hipSuccess)
+                return fail_hip(e, "hipMalloc(batch-statistics accumulators)");
+            S.stats_mc_passes = passes;
+        }
+        if ((e = hipMemsetAsync(S.d_stats_mc, 0, passes * NF_STATS_SLOTS * 8 * sizeof(double), st)) != hipSuccess)
+            return fail_hip(e, "batch-statistics set-up");
+        const double n = (double)a.B * a.H * a.W;
+        const float *cur = P.d_ident2;          // parameter block the next launch reads
+        float *bufs[2] = {S.d_work2, S.d_work2b};
+        int nbuf = 0;
+        // the fix a launch has to apply = the pass of the launch before it
+        const double *pend_stats = nullptr;
+        int pend_off = 0, pend_stage = 0;
+        float *pend_mom = nullptr;
+        auto launch = [&](const NfProgram &prog, NfLaunch &s) -> hipError_t {
+            s.params = cur;
+            s.n_params = (int32_t)nw2;
+            s.flags |= NF_K_BATCHSTATS;
+            s.fix_stats = pend_stats;
+            s.fix_n = n;
+            s.fix_off = pend_off;
+            s.fix_stage = pend_stage;
+            s.fix_mom_out = pend_mom;
+            s.fix_params_out = pend_stats ? bufs[nbuf] : nullptr;
+            hipError_t er = nf_launch_flow(prog, s, h->n_cu, st, true);
+            if (pend_stats) {
+                cur = bufs[nbuf];
+                nbuf ^= 1;
+            }
+            return er;
+        };
+        const float *const in0 = a.in;
+        const float in_scale0 = a.in_scale;
+        const uint32_t flags0 = a.flags;
+        for (int c = 0; c < n_cpl; ++c) {
+            float *mom = S.d_mom + (size_t)P.cpl_row[c] * 16;
+            for (int stage = 1; stage <= 2; ++stage) {
+                const NfProgram &prog = stage == 1 ? P.progA2[c] : P.progB2[c];
+                NfLaunch s = a;
+                s.nll_out = s.sd_out = s.ld_out = nullptr;
+                s.sums = nullptr;
+                s.stats = S.d_stats_mc + (size_t)(2 * c + stage - 1) * NF_STATS_SLOTS * 8;
+                s.stats_op = prog.n_ops - 1;
+                s.stats_stage = stage;
+                const int tin = stage == 1 ? (c > 0 ? c - 1 : 0) : c;
+                const bool from_input = tin == 0;
+                s.in = from_input ? in0 : S.d_T[tin & 1];
+                s.in_scale = from_input ? in_scale0 : 1.0f;
+                s.flags = from_input ? flags0 : (flags0 & ~(uint32_t)NF_K_PHILOX_IN);
+                s.out = (stage == 1 && c > 0) ? S.d_T[c & 1] : nullptr;
+                if ((e = launch(prog, s)) != hipSuccess) return fail_hip(e, "batch-statistics launch");
+                pend_stats = s.stats;
+                pend_off = P.ident.prog2.ops[P.cpl_ops[c]].off;
+                pend_stage = stage;
+                pend_mom = mom + (stage == 1 ? 0 : 8);
+            }
+        }
+        a.ld_const = a.ld_const + (direction == 0 ? P.ident.ld_const : 0.0);
+        if ((e = launch(P.ident.prog2, a)) != hipSuccess) return fail_hip(e, "batch-statistics final launch");
+        std::vector<float> mom_h((size_t)std::max(n_cpl, 1) * 16);
+        if (moments_out && n_cpl &&
+            (e = hipMemcpyAsync(mom_h.data(), S.d_mom, (size_t)n_cpl * 16 * sizeof(float), hipMemcpyDeviceToHost, st)) != hipSuccess) {
+            (void)hipStreamSynchronize(st);
+            return fail_hip(e, "batch-statistics moments readback");
+        }
+        if ((e = hipStreamSynchronize(st)) != hipSuccess) return fail_hip(e, "batch-statistics final sync");   // the scratch is reused
+        if (moments_out && n_cpl) memcpy(moments_out, mom_h.data(), (size_t)n_cpl * 16 * sizeof(float));
+        return NF_OK;
     }
     if ((e = hipMemcpyAsync(S.d_work, P.d_ident, nw1 * sizeof(float), hipMemcpyDeviceToDevice, st)) != hipSuccess ||
         (nw2 && (e = hipMemcpyAsync(S.d_work2, P.d_ident2, nw2 * sizeof(float), hipMemcpyDeviceToDevice, st)) != hipSuccess) ||

@@ -118,11 +118,14 @@ __device__ __forceinline__ void stats_flush(const float (&s1)[WIDTH], const floa
 //   MFMA    matrix-core weight delivery (width 4)
 //   FULL    square 32x32 / 64x64 patch filling the workgroup exactly: compile-time geometry, no masks
 //   PREC    0 = all fp32, 1 = fp16 coupling-CNN convs (fp32 accumulate; FULL matrix-core only)
+//   BS      matrix-core kernel of the batch-statistics mode (nf_*_batchstats at width 4): applies the pending
+//           re-fold of NfLaunch::fix_* to its LDS weight image in the prologue and gathers NfLaunch::stats
 // Global I/O is 16 bytes per lane per pixel ([H,W,4] fp32, NHWC).
 // --------------------------------------------------------------------------
-template <int WIDTH, int THREADS, int PX, bool PHILOX, bool MFMA, bool FULL, int PREC>
+template <int WIDTH, int THREADS, int PX, bool PHILOX, bool MFMA, bool FULL, int PREC, bool BS>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_WAVES(THREADS, PX, MFMA)))) void nf_flow_kernel(const NfProgram prog, const NfLaunch a)
 {
+    static_assert(!BS || (MFMA && PREC == 0), "the batch-statistics variant is the fp32 matrix-core kernel");
     static_assert(WIDTH % 4 == 0, "WIDTH must be a multiple of 4");
     static_assert(!MFMA || WIDTH == 4, "the matrix-core path is the width-4 specialisation");
     static_assert(PREC == 0 || (MFMA && FULL && PX == 4), "the fp16-CNN mode exists for full 2x2-blocked patches only");
@@ -146,6 +149,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
     constexpr int TILE_WORDS = H16 ? 3 : 2 + WIDTH;                   // 32-bit words per tile pixel
     float *const red = smem + TILE_WORDS * tile_px;       // reduction scratch [3][THREADS/64] (+pad)
     float *const wl = red + ((3 * (THREADS / 64) + 3) & ~3);   // MFMA: the whole folded model, j-major
+    // BS: [THREADS/64][8] per-wavefront statistics partials, then 8 doubles (scale[4], mean[4]) of the pending re-fold
+    [[maybe_unused]] float *const bs_part = wl + ((a.n_params + 3) & ~3);
 
     const int t = threadIdx.x;
     const int j4 = t & 3;   // MFMA: which output channel's weights this lane feeds as the A operand
@@ -231,6 +236,48 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
     }
     __syncthreads();
     asm volatile("" ::"v"(warm));   // keep the warm-up loads
+    if constexpr (BS) {
+        // Pending re-fold (layers.py:388-391 + the BN-eval folding of fold_coupling): the previous launch of this call
+        // gathered sum / sum of squares of one normalisation's input; every workgroup turns them into moments and
+        // rescales ITS LDS copy of that layer (W[.][j] *= 1/sqrt(var_j + eps), B[j] = (B[j] - mean_j)/sqrt(var_j + eps));
+        // workgroup 0 also writes the patched image to the parameter block the NEXT launch reads, and the moments.
+        if (a.fix_stats) {
+            double *const fsc = reinterpret_cast<double *>(bs_part + (THREADS / 64) * 8);   // [4] scale, then [4] mean
+            if (t < 64) {
+                double v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = a.fix_stats[(size_t)t * 8 + q];   // slot t (NF_STATS_SLOTS == 64)
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) v[q] += __shfl_xor(v[q], o);
+                if (t < 4) {
+                    const double m = v[t] / a.fix_n;
+                    double var = v[4 + t] / a.fix_n - m * m;   // tf.nn.moments: population variance
+                    if (var < 0.0) var = 0.0;
+                    const float mf = (float)m, vf = (float)var;
+                    fsc[t] = 1.0 / sqrt((double)vf + 1e-4);
+                    fsc[4 + t] = (double)mf;
+                    if (blockIdx.x == 0 && a.fix_mom_out) {
+                        a.fix_mom_out[t] = mf;
+                        a.fix_mom_out[4 + t] = vf;
+                    }
+                }
+            }
+            __syncthreads();
+            float *const blk = wl + a.fix_off;
+            if (a.fix_stage == 1) {
+                for (int i = t; i < 96; i += THREADS) blk[NF2_CPL_W1T + i] = (float)((double)blk[NF2_CPL_W1T + i] * fsc[i / 24]);
+                if (t < 4) blk[NF2_CPL_B1 + t] = (float)(((double)blk[NF2_CPL_B1 + t] - fsc[4 + t]) * fsc[t]);
+            } else {
+                for (int i = t; i < 16; i += THREADS) blk[NF2_CPL_W2T + i] = (float)((double)blk[NF2_CPL_W2T + i] * fsc[i / 4]);
+                if (t < 4) blk[NF2_CPL_B2 + t] = (float)(((double)blk[NF2_CPL_B2 + t] - fsc[4 + t]) * fsc[t]);
+            }
+            __syncthreads();
+            if (blockIdx.x == 0 && a.fix_params_out)
+                for (int i = t; i < a.n_params; i += THREADS) a.fix_params_out[i] = wl[i];
+        }
+    }
     NF_STAMP(1);
 
     const int n_ops = prog.n_ops;
@@ -438,16 +485,45 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
                     }
                     }
                     NF_PRIO_DOWN();
+                    [[maybe_unused]] int bs_stage = 0;
+                    [[maybe_unused]] float bs1[4] = {0.f, 0.f, 0.f, 0.f}, bs2[4] = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr (BS) bs_stage = (a.stats && op == a.stats_op) ? a.stats_stage : 0;
 #pragma unroll
                     for (int k = 0; k < PX; ++k) {
+                        if constexpr (BS) {
+                            if (bs_stage == 1) {
+                                const float h1k[4] = {h1[k][0], h1[k][1], h1[k][2], h1[k][3]};
+                                stats_accumulate<4>(h1k, act[k], bs1, bs2);
+                            }
+                        }
                         v4f h2 = {b2.x, b2.y, b2.z, b2.w};
                         h2 = __builtin_amdgcn_mfma_f32_4x4x1f32(w2.x, nf_relu(h1[k][0]), h2, 0, 0, 0);
                         h2 = __builtin_amdgcn_mfma_f32_4x4x1f32(w2.y, nf_relu(h1[k][1]), h2, 0, 0, 0);
                         h2 = __builtin_amdgcn_mfma_f32_4x4x1f32(w2.z, nf_relu(h1[k][2]), h2, 0, 0, 0);
                         h2 = __builtin_amdgcn_mfma_f32_4x4x1f32(w2.w, nf_relu(h1[k][3]), h2, 0, 0, 0);
+                        if constexpr (BS) {
+                            if (bs_stage == 2) {
+                                const float h2k[4] = {h2[0], h2[1], h2[2], h2[3]};
+                                stats_accumulate<4>(h2k, act[k], bs1, bs2);
+                            }
+                        }
                         if (act[k])
                             *reinterpret_cast<float4 *>(th + (size_t)lidx[k] * 4) =
                                 make_float4(nf_relu(h2[0]), nf_relu(h2[1]), nf_relu(h2[2]), nf_relu(h2[3]));
+                    }
+                    if constexpr (BS) {
+                        // wavefront sums -> LDS; after the barrier below 8 lanes add the workgroup's totals to its slot
+                        // (one fp64 atomic per value per WORKGROUP per patch: same-line atomics serialise at ~10 ns)
+                        if (bs_stage) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const float sa = wave_sum(bs1[j]), sb = wave_sum(bs2[j]);
+                                if ((t & 63) == 0) {
+                                    bs_part[(t >> 6) * 8 + j] = sa;
+                                    bs_part[(t >> 6) * 8 + 4 + j] = sb;
+                                }
+                            }
+                        }
                     }
                 } else
                 {
@@ -521,7 +597,15 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
                     }
                 }
                 __syncthreads();
-                if constexpr (!MFMA) {
+                if constexpr (BS) {
+                    if (a.stats && op == a.stats_op && t < 8) {
+                        double tot = 0.0;
+#pragma unroll
+                        for (int wv = 0; wv < THREADS / 64; ++wv) tot += (double)bs_part[wv * 8 + t];
+                        atomicAdd(&a.stats[(blockIdx.x & (NF_STATS_SLOTS - 1)) * 8 + t], tot);
+                    }
+                }
+                if constexpr (!MFMA || BS) {
                     if (a.stats && op == a.stats_op) break;   // statistics gathered: this patch is done
                 }
 
@@ -775,7 +859,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
             }
         }
 
-        if constexpr (!MFMA) {
+        if constexpr (!MFMA || BS) {
             if (a.stats) continue;   // batch-statistics pass: no outputs
         }
 
@@ -936,16 +1020,17 @@ __global__ __launch_bounds__(256) void nf_synth_kernel(uint64_t seed, int64_t pa
     }
 }
 
-template <int WIDTH, int THREADS, int PX, bool PHILOX, bool MFMA, bool FULL, int PREC>
+template <int WIDTH, int THREADS, int PX, bool PHILOX, bool MFMA, bool FULL, int PREC, bool BS = false>
 hipError_t launch_flow_p(const NfProgram &prog, const NfLaunch &a, int n_cu, hipStream_t stream)
 {
     const int tile_px = ((a.H + 2) * (a.W + 2) + 1) & ~1;
     size_t lds_f = (size_t)tile_px * (PREC == 1 ? 3 : 2 + WIDTH) + ((3 * (THREADS / 64) + 3) & ~3);
     if (PREC == 1 && a.H == 32) lds_f = (size_t)(34 * 48) * 3 + ((3 * (THREADS / 64) + 3) & ~3);   // padded row pitch
     if (MFMA) lds_f += (size_t)((a.n_params + 3) & ~3);
+    if (BS) lds_f += (size_t)(THREADS / 64) * 8 + 16;
     const size_t lds = sizeof(float) * lds_f;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    const void *fn = reinterpret_cast<const void *>(&nf_flow_kernel<WIDTH, THREADS, PX, PHILOX, MFMA, FULL, PREC>);
+    const void *fn = reinterpret_cast<const void *>(&nf_flow_kernel<WIDTH, THREADS, PX, PHILOX, MFMA, FULL, PREC, BS>);
     // (lds bytes << 8 | resident workgroups per CU) of the last query; racy but idempotent
     static std::atomic<uint64_t> cache{0};
     uint64_t c = cache.load(std::memory_order_relaxed);
@@ -953,8 +1038,8 @@ hipError_t launch_flow_p(const NfProgram &prog, const NfLaunch &a, int n_cu, hip
     if ((c >> 8) == (uint64_t)lds && (c & 0xff) != 0) {
         occ = (int)(c & 0xff);
     } else {
-        if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (lds > 64 * 1024) {   // opt in to exactly what this launch needs (a variant may also own static LDS)
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
         occ = 0;
@@ -968,7 +1053,7 @@ hipError_t launch_flow_p(const NfProgram &prog, const NfLaunch &a, int n_cu, hip
     int64_t groups = (int64_t)n_cu * occ;
     if (a.B < groups) groups = a.B;
     if (groups < 1) groups = 1;
-    hipLaunchKernelGGL((nf_flow_kernel<WIDTH, THREADS, PX, PHILOX, MFMA, FULL, PREC>), dim3((unsigned)groups), dim3(THREADS), lds,
+    hipLaunchKernelGGL((nf_flow_kernel<WIDTH, THREADS, PX, PHILOX, MFMA, FULL, PREC, BS>), dim3((unsigned)groups), dim3(THREADS), lds,
                        stream, prog, a);
     return hipGetLastError();
 }
@@ -980,6 +1065,9 @@ hipError_t launch_flow_f(const NfProgram &prog, const NfLaunch &a, int n_cu, hip
         if (a.flags & NF_K_FP16_CNN) return launch_flow_p<WIDTH, THREADS, PX, PHILOX, MFMA, FULL, 1>(prog, a, n_cu, stream);
     }
     if (a.flags & NF_K_FP16_CNN) return hipErrorInvalidValue;
+    if constexpr (MFMA) {   // batch-statistics launches of the width-4 model: the variant with the fused finaliser
+        if (a.flags & NF_K_BATCHSTATS) return launch_flow_p<WIDTH, THREADS, PX, PHILOX, MFMA, FULL, 0, true>(prog, a, n_cu, stream);
+    }
     return launch_flow_p<WIDTH, THREADS, PX, PHILOX, MFMA, FULL, 0>(prog, a, n_cu, stream);
 }
 

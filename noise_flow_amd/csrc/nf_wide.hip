@@ -516,7 +516,7 @@ hipError_t launch_wide_p(const NfProgram &prog, const NfLaunch &a, int n_cu, int
         occ = (int)(cv & 0xff);
     } else {
         if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
         occ = 0;
