@@ -161,7 +161,11 @@ int nf_destroy(nf_handle *h);
  *   logdet_out[B]  per-patch sum of log|det J| over all layers (or NULL)
  *   z_out     [B,H,W,4] latent (or NULL)
  *   sums_out  double[3] on the DEVICE: sum_b nll, sum_b sd, B (or NULL); with NF_SUMS_WIDE the
- *             slotted layout above
+ *             slotted layout above.  Must be ordinary (coarse-grained) hipMalloc memory: the kernels add to
+ *             it with hardware fp64 atomics (the library is built with -munsafe-fp-atomics), which fine-grained /
+ *             host-coherent allocations do not support.
+ * Every tensor pointer (x, y, z_out; y, eps, x_out of nf_sample) must be 16-byte aligned — a pixel is one float4
+ * access — and belong to the handle's device; misaligned pointers are rejected with NF_EINVAL.
  */
 int nf_nll(nf_handle *h, const float *x, const float *y, int64_t B, const nf_cond *cond,
            float *nll_out, float *sd_out, float *logdet_out, float *z_out,

@@ -969,6 +969,8 @@ int nf_destroy(nf_handle *h)
     return NF_OK;
 }
 
+static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
 // ---- argument checking + NfLaunch assembly shared by the resident and the batch-statistics paths ----
 static int nll_args(nf_handle *h, const float *x, const float *y, int64_t B, const nf_cond *cond, float *nll_out,
                     float *sd_out, float *logdet_out, float *z_out, double *sums_out, uint32_t flags, NfLaunch &a)
@@ -977,6 +979,8 @@ static int nll_args(nf_handle *h, const float *x, const float *y, int64_t B, con
     if (B < 0) return fail(NF_EINVAL, "B must be >= 0");
     if (B > 0 && !x) return fail(NF_EINVAL, "x is NULL");
     if (h->fwd.has_sdn && B > 0 && !y) return fail(NF_EINVAL, "model has a signal-dependent layer but y is NULL");
+    if (!aligned16(x) || !aligned16(y) || !aligned16(z_out))
+        return fail(NF_EINVAL, "x, y and z_out must be 16-byte aligned (every pixel is one float4 access)");
     float ca[4] = {0.f, 0.f, 0.f, 0.f}, cb[4] = {1.f, 1.f, 1.f, 1.f};
     double ld_call = 0.0;   // per-call part of the constant log-det (plain `gain` layers)
     for (size_t i = 0; i < h->fwd.cond.size(); ++i) {
@@ -1020,6 +1024,8 @@ static int sample_args(nf_handle *h, const float *y, const float *eps, uint64_t 
     if (B < 0) return fail(NF_EINVAL, "B must be >= 0");
     if (B > 0 && !x_out) return fail(NF_EINVAL, "x_out is NULL");
     if (h->rev.has_sdn && B > 0 && !y) return fail(NF_EINVAL, "model has a signal-dependent layer but y is NULL");
+    if (!aligned16(y) || !aligned16(eps) || !aligned16(x_out))
+        return fail(NF_EINVAL, "y, eps and x_out must be 16-byte aligned (every pixel is one float4 access)");
     float ca[4] = {0.f, 0.f, 0.f, 0.f}, cb[4] = {1.f, 1.f, 1.f, 1.f};
     for (size_t i = 0; i < h->rev.cond.size(); ++i) {
         double sc[2];

@@ -1031,14 +1031,18 @@ hipError_t launch_flow_p(const NfProgram &prog, const NfLaunch &a, int n_cu, hip
     const size_t lds = sizeof(float) * lds_f;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const void *fn = reinterpret_cast<const void *>(&nf_flow_kernel<WIDTH, THREADS, PX, PHILOX, MFMA, FULL, PREC, BS>);
-    // (lds bytes << 8 | resident workgroups per CU) of the last query; racy but idempotent
+    // (device << 40 | lds bytes << 8 | resident workgroups per CU) of the last query; racy but idempotent.  The
+    // >64 KiB opt-in is a per-device function attribute, so the device is part of the key.
+    int dev = 0;
+    (void)hipGetDevice(&dev);
     static std::atomic<uint64_t> cache{0};
+    const uint64_t key = ((uint64_t)(dev & 0xff) << 40) | ((uint64_t)lds << 8);
     uint64_t c = cache.load(std::memory_order_relaxed);
     int occ;
-    if ((c >> 8) == (uint64_t)lds && (c & 0xff) != 0) {
+    if ((c & ~(uint64_t)0xff) == key && (c & 0xff) != 0) {
         occ = (int)(c & 0xff);
     } else {
-        if (lds > 64 * 1024) {   // opt in to exactly what this launch needs (a variant may also own static LDS)
+        if (lds > 64 * 1024) {   // opt in to exactly what this launch needs
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
@@ -1047,7 +1051,7 @@ hipError_t launch_flow_p(const NfProgram &prog, const NfLaunch &a, int n_cu, hip
         if (e != hipSuccess) return e;
         if (occ < 1) occ = 1;
         if (occ > 32) occ = 32;
-        cache.store(((uint64_t)lds << 8) | (uint64_t)occ, std::memory_order_relaxed);
+        cache.store(key | (uint64_t)occ, std::memory_order_relaxed);
     }
     // persistent grid: exactly the resident capacity, each workgroup strides over patches
     int64_t groups = (int64_t)n_cu * occ;

@@ -166,6 +166,24 @@ def test_unknown_iso_and_camera(shipped_variables, oracle_full):
     assert ei.value.code == NF_ECOND
 
 
+def test_misaligned_tensor_pointers_are_rejected(shipped_variables):
+    """Every pixel is one 16-byte access: a pointer that is not 16-byte aligned is an argument error, not a fault."""
+    import ctypes as C
+    import torch
+    from noise_flow_amd import _lib
+    m = _model(FULL_ARCH, shipped_variables)
+    lib = _lib.load()
+    buf = torch.zeros(2 * 32 * 32 * 4 + 4, device="cuda")
+    nll = torch.empty(2, device="cuda")
+    cond = _lib.nf_cond(100.0, 2.0, 0.0, 0.0)
+    rc = lib.nf_nll(m._flow.ptr, buf.data_ptr() + 4, buf.data_ptr(), 2, C.byref(cond), nll.data_ptr(), None, None, None, None, 0, None)
+    assert rc == _lib.NF_EINVAL and b"16-byte aligned" in lib.nf_last_error()
+    rc = lib.nf_sample(m._flow.ptr, buf.data_ptr(), None, 0, 0, 1.0, 2, C.byref(cond), buf.data_ptr() + 8, None)
+    assert rc == _lib.NF_EINVAL and b"16-byte aligned" in lib.nf_last_error()
+    assert lib.nf_nll(m._flow.ptr, buf.data_ptr(), buf.data_ptr(), 2, C.byref(cond), nll.data_ptr(), None, None, None, None, 0, None) == 0
+    torch.cuda.synchronize()
+
+
 def test_empty_and_ragged_batches(shipped_variables, oracle_full):
     m = _model(FULL_ARCH, shipped_variables)
     x, y = make_inputs(0)
