@@ -272,7 +272,7 @@ def sharded_leg(ctx):
                                "non_kernel_share = 1 - (slowest rank's kernel time / step time)"},
         "roofline": {"bound": "mfma", "achieved": tfl, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": tfl / VALU_PEAK_TFLOPS, "traffic": None, "scope": "per GPU, slowest rank's kernel time",
-                     "kernel": "nf_flow_kernel<4,256,4,false,true,true,0>", "kernel_ms": kernel_ms,
+                     "kernel": "nf_flow_kernel<4,256,4,false,true,true,0,false>", "kernel_ms": kernel_ms,
                      "algorithmic_flop_per_launch": ALGO_FLOP_PER_PATCH * n_total / world,
                      "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                              "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PATCH * n_total / world}},
@@ -390,7 +390,7 @@ def single_gpu_leg(ctx):
                      "frac": tfl / VALU_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                      "time_base": "wall-clock ms_per_step",
                      "dtype": "f32 (v_mfma_f32_4x4x1_16b_f32, exact fp32; shares the fp32 datapath with VALU)",
-                     "kernel": "nf_flow_kernel<4,256,4,false,true,true,0>", "kernel_ms": kernel_ms,
+                     "kernel": "nf_flow_kernel<4,256,4,false,true,true,0,false>", "kernel_ms": kernel_ms,
                      "frac_from_kernel_ms": ALGO_FLOP_PER_PATCH * B / (kernel_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS,
                      "algorithmic_flop_per_launch": ALGO_FLOP_PER_PATCH * B,
                      "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,

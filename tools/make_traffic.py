@@ -37,7 +37,7 @@ def mean_counter(path, counter, kernel_sub, grid):
 
 def main():
     fetch_csv, write_csv = sys.argv[1], sys.argv[2]
-    kernel_sub = sys.argv[3] if len(sys.argv) > 3 else "nf_flow_kernel<4, 256, 4, false, true, true, 0>"
+    kernel_sub = sys.argv[3] if len(sys.argv) > 3 else "nf_flow_kernel<4, 256, 4, false, true, true, 0, false>"
     B = int(sys.argv[4]) if len(sys.argv) > 4 else 1024
     grid = B * 256
     fetch_kb, n_f = mean_counter(fetch_csv, "FETCH_SIZE", kernel_sub, grid)
