@@ -206,7 +206,19 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
     float4 zin[PX];   // raw x of the NEXT patch this workgroup evaluates (software prefetch across the patch loop)
 #pragma unroll
     for (int k = 0; k < PX; ++k) zin[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if ((int64_t)blockIdx.x < a.B) {
+    // NF_STAGGER: a one-round launch (B = the resident capacity) would request all its 32 MiB of inputs in the same
+    // microsecond and compute nothing until the last byte arrives (tools/timeline.py).  Only the first quarter of the
+    // grid — with round-robin dispatch the first workgroup of every CU — asks before its LDS set-up; the second quarter
+    // asks after it, the third and fourth NF_STAGGER_SLEEP x 64 cycles later each: the early ones compute while the late
+    // ones load (53.3 -> 49.8 us per 1 024 patches together with the progress-based priority; neutral in steady state)
+#ifndef NF_STAGGER
+#define NF_STAGGER 2
+#endif
+#ifndef NF_STAGGER_SLEEP
+#define NF_STAGGER_SLEEP 16
+#endif
+    const bool early = !NF_STAGGER || PHILOX || blockIdx.x < (NF_STAGGER >= 2 ? (gridDim.x >> 2) : (gridDim.x >> 1));
+    if ((int64_t)blockIdx.x < a.B && early) {
         const size_t off0 = (size_t)blockIdx.x * (size_t)HW;
         if constexpr (!PHILOX) {
 #pragma unroll
@@ -236,6 +248,21 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
     }
     __syncthreads();
     asm volatile("" ::"v"(warm));   // keep the warm-up loads
+    if (NF_STAGGER && !early && (int64_t)blockIdx.x < a.B) {
+#if NF_STAGGER >= 2
+        {   // quarters of the grid = the 4 workgroups of a CU: the 3rd and 4th wait a little longer still
+            const int q = (int)((blockIdx.x * 4u) / gridDim.x);
+            if (q == 2) __builtin_amdgcn_s_sleep(NF_STAGGER_SLEEP);
+            if (q == 3) { __builtin_amdgcn_s_sleep(NF_STAGGER_SLEEP); __builtin_amdgcn_s_sleep(NF_STAGGER_SLEEP); }
+        }
+#endif
+        const size_t off0 = (size_t)blockIdx.x * (size_t)HW;
+        if constexpr (!PHILOX) {
+#pragma unroll
+            for (int k = 0; k < PX; ++k)
+                if (act[k]) zin[k] = reinterpret_cast<const float4 *>(a.in)[off0 + gidx[k]];
+        }
+    }
     if constexpr (BS) {
         // Pending re-fold (layers.py:388-391 + the BN-eval folding of fold_coupling): the previous launch of this call
         // gathered sum / sum of squares of one normalisation's input; every workgroup turns them into moments and
