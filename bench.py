@@ -534,7 +534,8 @@ def wide_flop_per_pixel(width: int, n_couplings: int = 8) -> float:
 
 def _wide_cnn(ctx, batches, cond, wide):
     """Paper-scale coupling CNN (job_noise_flow.sh:19: width 32; also 16): same layer sequence, fresh wide CNN weights
-    (no wide checkpoint ships), forward NLL at B = 1024, 32x32x4 — f32 matrix cores (v_mfma_f32_32x32x2_f32)."""
+    (no wide checkpoint ships), forward NLL at B = 1024, 32x32x4 — f32 matrix cores (v_mfma_f32_32x32x2_f32 at width 32,
+    v_mfma_f32_16x16x4_f32 at width 16) and the fp16 CNN mode (v_mfma_f32_32x32x16_f16)."""
     import numpy as np
     from noise_flow_amd import NoiseFlow, default_hps, params as _params
     args, dev = ctx["args"], ctx["dev"]
@@ -558,6 +559,7 @@ def _wide_cnn(ctx, batches, cond, wide):
             "width": w, "cnn_dtype": dt, "batch": int(x.shape[0]), "steps": kw, "kernel_ms": ms,
             "value": x.shape[0] / (ms * 1e-3), "unit": "patches/s", "finite": bool(np.isfinite(nll.cpu().numpy()).all()),
             "kernel_path": {0: "scalar-weight VALU kernel", 3: "nf_wide32_kernel (v_mfma_f32_32x32x2_f32)",
+                            4: "nf_wide16_kernel (v_mfma_f32_16x16x4_f32)",
                             5: "nf_wide32_kernel (v_mfma_f32_32x32x16_f16)"}.get(path, str(path)),
             "roofline": {"bound": "mfma", "achieved": tfl, "peak": peak, "unit": "TFLOP/s", "frac": tfl / peak,
                          "algorithmic_flop_per_launch": flop, "mac_per_pixel_per_coupling": 16 + 18 * w + w * w + 36 * (w + 1),

@@ -134,6 +134,26 @@ __host__ __device__ constexpr int nf_cpl_size(int w)   { return 64 + 36 * w + 18
 #define NF4_CPL_SIZE (NF4_CPL_IMG + NF4_IMG_SIZE)
 __host__ __device__ constexpr int nf4_chan(int v, int g) { return 8 * (v >> 2) + 4 * g + (v & 3); }
 
+// ---- width-16 layout (nf_wide16.hip, v_mfma_f32_16x16x4_f32) ----------------------------------------
+// Tile = 16 pixels (lane n = lane & 15), four K slices g = lane >> 4; D register v of group g = channel 4 g + v.
+//   COUPLING  E [16][4] @0, S [4] @64 (as NF4), IMG6 @68:
+//     A1  [64][4] + [64]   l_1: K step s, lane l: W1[(tap, ch)][i = l&15] with 2 tap + ch = 4 s + (l>>4) (< 18, else 0)
+//     B1  [4][4]           bias by (g, v)
+//     A2  [64][4]          l_2: step s, lane l: W2[in = 4 (l>>4) + s][out = l&15]
+//     B2  [4][4]
+//     A3A [64][4]          P chain A: row i = l&15 = (g' = i>>2, j = i&3), taps (0,0) (1,0) (2,0) (0,1) by g'; in = 4 (l>>4) + s
+//     A3B [64][4]          P chain B: taps (0,2) (1,2) (2,2) (2,1)
+//     A3C [16][4]          centre tap on v_mfma_f32_4x4x1: (g, j): W3[centre][4 g + s][j], s = 0..3
+#define NF6_IMG_A1 0
+#define NF6_IMG_B1 320
+#define NF6_IMG_A2 336
+#define NF6_IMG_B2 592
+#define NF6_IMG_A3A 608
+#define NF6_IMG_A3B 864
+#define NF6_IMG_A3C 1120
+#define NF6_IMG_SIZE 1184
+#define NF6_CPL_SIZE (NF4_CPL_IMG + NF6_IMG_SIZE)
+
 // ---- wide-CNN fp16 layout (NF_CFG_FP16_CNN at coupling width 32) --------------------------------
 // Same kernel structure on v_mfma_f32_32x32x16_f16 (K = 16 per instruction, fp32 accumulate): an A / B operand is 8
 // halves = 4 dwords per lane, the K slice of lane half g being elements 8g .. 8g+7.  Folded weights and the three CNN

@@ -24,6 +24,7 @@
 
 hipError_t nf_launch_flow(const NfProgram &prog, const NfLaunch &a, int n_cu, hipStream_t stream, bool matrix_core);
 hipError_t nf_launch_wide(const NfProgram &prog, const NfLaunch &a, int n_cu, int device, hipStream_t stream);
+hipError_t nf_launch_wide16(const NfProgram &prog, const NfLaunch &a, int n_cu, int device, hipStream_t stream);
 hipError_t nf_launch_synth(uint64_t seed, int64_t patch_base, int64_t B, int HW, float beta1, float beta2,
                            float *y_out, float *x_out, hipStream_t stream);
 hipError_t nf_launch_sums_reduce(const double *wide, double *out3, bool accumulate, hipStream_t stream);
@@ -316,6 +317,54 @@ void relayout_coupling_wide32(const float *v1, int w, float *out)
             }
 }
 
+// Width-16 re-layout (nf_device.h, NF6_*; `w` = 16, or 8 zero-padded): fetch order of v_mfma_f32_16x16x4_f32.
+void relayout_coupling_wide16(const float *v1, int w, float *out)
+{
+    const double k2 = 2.0 * 1.4426950408889634, log2e = 1.4426950408889634;
+    for (int m = 0; m < 16; ++m)
+        for (int j = 0; j < 4; ++j) {
+            const double e = v1[nf_cpl_off_E(w) + 4 * m + j];
+            out[NF4_CPL_E + 4 * m + j] = (float)(j >= 2 ? e * k2 : e);
+        }
+    const double sc = v1[nf_cpl_off_S(w)];
+    out[NF4_CPL_S + 0] = (float)sc;
+    out[NF4_CPL_S + 1] = (float)(sc * log2e);
+    out[NF4_CPL_S + 2] = (float)(-2.0 * sc * log2e);
+    out[NF4_CPL_S + 3] = 0.0f;
+    float *img = out + NF4_CPL_IMG;
+    memset(img, 0, NF6_IMG_SIZE * sizeof(float));
+    const float *W1 = v1 + nf_cpl_off_W1(w), *B1 = v1 + nf_cpl_off_B1(w), *W2 = v1 + nf_cpl_off_W2(w);
+    const float *B2 = v1 + nf_cpl_off_B2(w), *W3 = v1 + nf_cpl_off_W3(w);
+    static const int tapA[4] = {0 * 3 + 0, 1 * 3 + 0, 2 * 3 + 0, 0 * 3 + 1}, tapB[4] = {0 * 3 + 2, 1 * 3 + 2, 2 * 3 + 2, 2 * 3 + 1};
+    for (int l = 0; l < 64; ++l) {
+        const int i = l & 15, g = l >> 4;
+        for (int s = 0; s < 5; ++s) {
+            const int kk = 4 * s + g;
+            const float v = (kk < 18 && i < w) ? W1[kk * w + i] : 0.0f;   // kk = tap * 2 + ch
+            if (s < 4) img[NF6_IMG_A1 + l * 4 + s] = v;
+            else img[NF6_IMG_A1 + 256 + l] = v;
+        }
+        for (int s = 0; s < 4; ++s) {
+            const int cin = 4 * g + s;
+            img[NF6_IMG_A2 + l * 4 + s] = (cin < w && i < w) ? W2[cin * w + i] : 0.0f;
+            const int gp = i >> 2, j = i & 3;
+            const double wa = cin < w ? W3[(tapA[gp] * w + cin) * 4 + j] : 0.0, wb = cin < w ? W3[(tapB[gp] * w + cin) * 4 + j] : 0.0;
+            img[NF6_IMG_A3A + l * 4 + s] = (float)(j >= 2 ? wa * k2 : wa);
+            img[NF6_IMG_A3B + l * 4 + s] = (float)(j >= 2 ? wb * k2 : wb);
+        }
+    }
+    for (int g = 0; g < 4; ++g)
+        for (int v = 0; v < 4; ++v) {
+            const int ch = 4 * g + v;
+            img[NF6_IMG_B1 + g * 4 + v] = ch < w ? B1[ch] : 0.0f;
+            img[NF6_IMG_B2 + g * 4 + v] = ch < w ? B2[ch] : 0.0f;
+            for (int j = 0; j < 4; ++j) {   // here v plays the K step s
+                const double wv = ch < w ? W3[(4 * w + ch) * 4 + j] : 0.0;
+                img[NF6_IMG_A3C + (g * 4 + j) * 4 + v] = (float)(j >= 2 ? wv * k2 : wv);
+            }
+        }
+}
+
 // fp16 variant of the wide layout (nf_device.h, NF5_*): folded weights rounded to half, in the fetch order of
 // v_mfma_f32_32x32x16_f16 (8 halves per lane and instruction) / v_mfma_f32_4x4x4_16b_f16 (centre tap).
 void relayout_coupling_wide32_fp16(const float *v1, int w, float *out)
@@ -503,6 +552,8 @@ struct Built {
     std::vector<float> block4;
     NfProgram prog5;             // wide-CNN fp16 layout (NF5_*): NF_CFG_FP16_CNN at widths 8 / 16 / 32
     std::vector<float> block5;
+    NfProgram prog6;             // width-16 layout (NF6_*)
+    std::vector<float> block6;
     double ld_const = 0.0;
     bool has_sdn = false;      // some op reads the clean image y
 };
@@ -681,12 +732,12 @@ int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float
     }
     out.block4.clear();
     memset(&out.prog4, 0, sizeof(out.prog4));
-    // width 32: the product path; widths 8 / 16 only where the scalar-weight kernel's LDS tile does not fit (patches
-    // larger than 32x32 at width 16, 48x48 at width 8): zero-padded to 32 channels
+    // width 32: the product path; width 8 only where the scalar-weight kernel's LDS tile does not fit (patches larger
+    // than 48x48): zero-padded to 32 channels.  Width 16 has its own kernel (prog6).
     {
         const size_t tile_px = ((size_t)(cfg->height + 2) * (cfg->width + 2) + 1) & ~(size_t)1;
         const bool scalar_fits = sizeof(float) * (tile_px * (2 + (size_t)out.prog.width) + 64) <= 160 * 1024;
-        if (out.prog.width == 32 || ((out.prog.width == 8 || out.prog.width == 16) && !scalar_fits)) out.prog4.width = 32;
+        if (out.prog.width == 32 || (out.prog.width == 8 && !scalar_fits)) out.prog4.width = 32;
     }
     if (out.prog4.width == 32) {
         for (int i = 0; i < out.prog.n_ops; ++i) {
@@ -707,6 +758,29 @@ int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float
             }
         }
         if (out.block4.empty()) out.block4.assign(4, 0.0f);
+    }
+    out.block6.clear();
+    memset(&out.prog6, 0, sizeof(out.prog6));
+    if (out.prog.width == 16) {
+        out.prog6.width = 16;
+        for (int i = 0; i < out.prog.n_ops; ++i) {
+            const NfOp &src = out.prog.ops[i];
+            NfOp &dst = out.prog6.ops[out.prog6.n_ops++];
+            dst.type = src.type;
+            dst.off = (int32_t)out.block6.size();
+            const float *v1 = out.block.data() + src.off;
+            if (src.type == NF_OP_MIX) {
+                out.block6.insert(out.block6.end(), v1, v1 + 16);
+            } else if (src.type == NF_OP_COUPLING_FWD || src.type == NF_OP_COUPLING_REV) {
+                out.block6.resize(out.block6.size() + NF6_CPL_SIZE);
+                relayout_coupling_wide16(v1, out.prog.width, out.block6.data() + dst.off);
+            } else if (src.type == NF_OP_SCALE) {
+                out.block6.insert(out.block6.end(), v1, v1 + 4);
+            } else {
+                dst.off = src.off;   // conditioning slot
+            }
+        }
+        if (out.block6.empty()) out.block6.assign(4, 0.0f);
     }
     out.block5.clear();
     memset(&out.prog5, 0, sizeof(out.prog5));
@@ -821,6 +895,8 @@ struct nf_handle {
     float *d_rev4 = nullptr;
     float *d_fwd5 = nullptr;   // wide-CNN fp16 layout
     float *d_rev5 = nullptr;
+    float *d_fwd6 = nullptr;   // width-16 layout
+    float *d_rev6 = nullptr;
     // batch-statistics mode (nf_*_batchstats): the raw model and a lazily allocated scratch
     std::vector<nf_layer_desc> layers;
     std::vector<float> raw;
@@ -887,7 +963,7 @@ int nf_create(const nf_config *cfg, const nf_layer_desc *layers, const float *pa
     {   // the two LDS tiles of the scalar-weight kernel must fit one CU (160 KiB)
         const size_t tile_px = ((size_t)(cfg->height + 2) * (cfg->width + 2) + 1) & ~(size_t)1;
         const size_t lds = sizeof(float) * (tile_px * (2 + (size_t)h->fwd.prog.width) + 64);
-        if (lds > 160 * 1024 && h->fwd.block2.empty() && h->fwd.block4.empty() && h->fwd.block5.empty()) {
+        if (lds > 160 * 1024 && h->fwd.block2.empty() && h->fwd.block4.empty() && h->fwd.block5.empty() && h->fwd.block6.empty()) {
             const int w = h->fwd.prog.width;
             delete h;
             return fail(NF_EINVAL, "a %dx%d patch with coupling width %d needs %zu KiB of LDS (> 160): unsupported",
@@ -933,11 +1009,12 @@ int nf_create(const nf_config *cfg, const nf_layer_desc *layers, const float *pa
             return fail(NF_EINVAL, "NF_CFG_FP16_CNN needs coupling width 4 with full 32x32 or 64x64 patches, or width 8 / 16 / 32");
         }
     }
-    for (int d = 0; d < 8; ++d) {
+    for (int d = 0; d < 10; ++d) {
         const std::vector<float> &b2 = d == 0 ? h->fwd.block2 : d == 1 ? h->rev.block2 : d == 2 ? h->fwd.block3 : d == 3 ? h->rev.block3
-                                       : d == 4 ? h->fwd.block4 : d == 5 ? h->rev.block4 : d == 6 ? h->fwd.block5 : h->rev.block5;
+                                       : d == 4 ? h->fwd.block4 : d == 5 ? h->rev.block4 : d == 6 ? h->fwd.block5 : d == 7 ? h->rev.block5
+                                       : d == 8 ? h->fwd.block6 : h->rev.block6;
         float **dst = d == 0 ? &h->d_fwd2 : d == 1 ? &h->d_rev2 : d == 2 ? &h->d_fwd3 : d == 3 ? &h->d_rev3 : d == 4 ? &h->d_fwd4
-                      : d == 5 ? &h->d_rev4 : d == 6 ? &h->d_fwd5 : &h->d_rev5;
+                      : d == 5 ? &h->d_rev4 : d == 6 ? &h->d_fwd5 : d == 7 ? &h->d_rev5 : d == 8 ? &h->d_fwd6 : &h->d_rev6;
         if (b2.empty()) continue;
         if ((e = hipMalloc((void **)dst, b2.size() * sizeof(float))) != hipSuccess ||
             (e = hipMemcpy(*dst, b2.data(), b2.size() * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) {
@@ -964,6 +1041,8 @@ int nf_destroy(nf_handle *h)
     if (h->d_rev4) (void)hipFree(h->d_rev4);
     if (h->d_fwd5) (void)hipFree(h->d_fwd5);
     if (h->d_rev5) (void)hipFree(h->d_rev5);
+    if (h->d_fwd6) (void)hipFree(h->d_fwd6);
+    if (h->d_rev6) (void)hipFree(h->d_rev6);
     nf_bs_destroy(h->bs);
     delete h;
     return NF_OK;
@@ -1068,6 +1147,14 @@ static int launch_resident(nf_handle *h, int direction, NfLaunch &a, hipStream_t
         if (e != hipSuccess) return fail_hip(e, what);
         return NF_OK;
     }
+    float *d6 = direction == 0 ? h->d_fwd6 : h->d_rev6;
+    if (d6 && use_matrix_core()) {   // width 16: v_mfma_f32_16x16x4_f32 (nf_wide16.hip)
+        a.params = d6;
+        a.n_params = (int32_t)b.block6.size();
+        hipError_t e = nf_launch_wide16(b.prog6, a, h->n_cu, h->device, st);
+        if (e != hipSuccess) return fail_hip(e, what);
+        return NF_OK;
+    }
     if (d4 && use_matrix_core()) {   // width 32: the three convs on v_mfma_f32_32x32x2_f32 (nf_wide.hip)
         a.params = d4;
         a.n_params = (int32_t)b.block4.size();
@@ -1094,6 +1181,7 @@ int nf_kernel_path(const nf_handle *h, int32_t direction)
 {
     if (!h || (direction != 0 && direction != 1)) return fail(NF_EINVAL, "bad argument");
     if (direction == 0 ? h->d_fwd5 : h->d_rev5) return NF_PATH_WIDE32_FP16;
+    if ((direction == 0 ? h->d_fwd6 : h->d_rev6) && use_matrix_core()) return NF_PATH_WIDE16;
     if ((direction == 0 ? h->d_fwd4 : h->d_rev4) && use_matrix_core()) return NF_PATH_WIDE32;
     if (direction == 0 ? h->d_fwd3 : h->d_rev3) return NF_PATH_FP16;
     if ((direction == 0 ? h->d_fwd2 : h->d_rev2) && use_matrix_core()) return NF_PATH_MFMA4;
