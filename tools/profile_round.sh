@@ -24,14 +24,18 @@ for pass in 1 2; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/sq_fp32/p$pass -- python $R/tools/prof_nll.py 16384 4 32 fp32 > $OUT/sq_fp32_p$pass.log 2>&1
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/sq_fp16/p$pass -- python $R/tools/prof_nll.py 2048 4 64 fp16 > $OUT/sq_fp16_p$pass.log 2>&1
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/sq_w32/p$pass -- python $R/tools/quick_time_wide.py 32 8192 32 4 > $OUT/sq_w32_p$pass.log 2>&1
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/sq_w16/p$pass -- python $R/tools/quick_time_wide.py 16 8192 32 4 > $OUT/sq_w16_p$pass.log 2>&1
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/sq_w32h/p$pass -- python $R/tools/quick_time_wide.py 32 8192 32 4 fp16 > $OUT/sq_w32h_p$pass.log 2>&1
 done
 cd $R
 python tools/pmc_report.py $OUT/sq_fp32 "nf_flow_kernel<4, 256, 4, false, true, true, 0, false>" 100000 > $OUT/sq_fp32_report.txt 2>&1
 python tools/pmc_report.py $OUT/sq_fp16 "nf_flow_kernel<4, 1024, 4, false, true, true, 1, false>" 100000 > $OUT/sq_fp16_report.txt 2>&1
 python tools/pmc_report.py $OUT/sq_w32 "nf_wide32_kernel" 100000 > $OUT/sq_w32_report.txt 2>&1
+python tools/pmc_report.py $OUT/sq_w16 "nf_wide16_kernel" 100000 > $OUT/sq_w16_report.txt 2>&1
+python tools/pmc_report.py $OUT/sq_w32h "nf_wide32_kernel" 100000 > $OUT/sq_w32h_report.txt 2>&1
 F=$(find $OUT/pmc_fetch -name "*counter_collection.csv" | head -1); W=$(find $OUT/pmc_write -name "*counter_collection.csv" | head -1)
 python tools/make_traffic.py $F $W > $OUT/traffic.log 2>&1 && cp profiles/traffic.json $OUT/traffic.json
 K=$(find $OUT/kt -name "*kernel_stats.csv" | head -1); cp $K $OUT/kernel_stats.csv 2>/dev/null
 K=$(find $OUT/kt_full -name "*kernel_stats.csv" | head -1); cp $K $OUT/kernel_stats_all_sections.csv 2>/dev/null
 cp $F $OUT/pmc_fetch_counter_collection.csv; cp $W $OUT/pmc_write_counter_collection.csv
-for f in $OUT/sq_fp32_report.txt $OUT/sq_fp16_report.txt $OUT/sq_w32_report.txt; do tail -n 3 $f; done; head -c 600 $OUT/bench.json; echo; tail -5 $OUT/traffic.log; head -8 $OUT/kernel_stats.csv
+for f in $OUT/sq_fp32_report.txt $OUT/sq_fp16_report.txt $OUT/sq_w32_report.txt $OUT/sq_w16_report.txt $OUT/sq_w32h_report.txt; do tail -n 3 $f; done; head -c 600 $OUT/bench.json; echo; tail -5 $OUT/traffic.log; head -8 $OUT/kernel_stats.csv
