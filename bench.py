@@ -147,6 +147,10 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: no GPU visible and there is no CPU fallback")
+    # NF_BENCH_ONE_GPU=1 (test aid): every rank uses GPU 0 — with NF_BENCH_BACKEND=gloo this runs the N > 1 leg end to
+    # end on a single-GPU box (RCCL refuses two ranks on one device)
+    if os.environ.get("NF_BENCH_ONE_GPU"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # NF_BENCH_FORCE_DIST=1 runs the N > 1 leg (configs[3] + RCCL) on a single rank too (validation aid)
@@ -154,7 +158,11 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
+        backend = os.environ.get("NF_BENCH_BACKEND", "nccl")                                   # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     from noise_flow_amd import NoiseFlow, default_hps
     from noise_flow_amd.ckpt import load_checkpoint
@@ -258,6 +266,7 @@ def sharded_leg(ctx):
                                % (n_total, ARCH_LABEL, world),
                    "total_patches": n_total, "global_batch": n_total, "patches_per_gpu": n_total // world, "patch": "32x32x4",
                    "launch_chunk": chunk, "inputs": "resident in HBM (%.1f GB per GPU)" % (shard.nbytes / 1e9),
+                   "backend": dist.get_backend(),
                    "parallelism": "dp%d: patch-index sharding, %s" % (
                        world, "one RCCL all-reduce of 3 fp64 scalars per evaluation" if world > 1 else
                        "single rank (NF_BENCH_FORCE_DIST: the RCCL call is issued on a 1-rank group)")},

@@ -32,3 +32,38 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     # the parity leg ran (rank 0, N = 1): GPU mean NLL within tolerance of the fp64 oracle
     assert d["nll_check"]["max_rel_err_per_patch"] <= d["nll_check"]["tolerance"]
     assert d["sampling"]["value"] > 0 and d["training"]["value"] > 0 and d["two_streams"]["value"] > 0
+
+
+def test_bench_multi_rank_leg_under_torchrun_on_one_gpu():
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank) — on this one-GPU box with
+    both ranks on GPU 0 and gloo carrying the all-reduce (RCCL refuses two ranks on one device): the N > 1 leg (BASELINE
+    configs[3]: sharded resident patch range, one all-reduce per evaluation) runs end to end and prints the contract line."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, NF_BENCH_BACKEND="gloo", NF_BENCH_ONE_GPU="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--total-patches", "65536", "--ramp-ms", "0"], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    lines = [l for l in out.stdout.decode().split("\n") if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout.decode()[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "strong" and d["unit"] == "patches/s"
+    assert d["config"]["total_patches"] == 65536 and d["config"]["patches_per_gpu"] == 32768
+    assert abs(d["value"] - 65536 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    assert len(d["per_rank"]["kernel_ms_per_step"]) == 2 and d["mean_nll_identical_across_steps"] is True
+    assert d["roofline"]["frac"] > 0 and d["collective"]["per_step"] == 1
+    # the sharded mean equals the single-process evaluation of the same patch range (any sharding holds the same data)
+    import torch
+    from conftest import SHIPPED_CKPT
+    from noise_flow_amd import NoiseFlow, default_hps
+    from noise_flow_amd.ckpt import load_checkpoint
+    from noise_flow_amd.dist import ResidentShard, evaluate_sharded
+    m = NoiseFlow([32, 32, 4], False, default_hps(), variables=load_checkpoint(SHIPPED_CKPT))
+    shard = ResidentShard(m, 0, 65536, 0, 1)
+    mean, sd, n = evaluate_sharded(shard.eval_chunk(), 65536, 65536, 0, 1, torch.zeros(3, dtype=torch.float64, device="cuda"))
+    assert n == 65536 and abs(mean - d["mean_nll"]) <= 1e-9 * abs(mean) and abs(sd - d["sd_z"]) <= 1e-9 * sd
