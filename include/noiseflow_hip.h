@@ -67,6 +67,13 @@ extern "C" {
 #define NF_LAYER_GAIN1    12   /* AffineCouplingGainEx1.py + cond_utils.py:333-350 scale = exp(1e-5 g1) iso + exp(1e-5 g2); log|det| once per patch (as GAIN) */
 #define NF_LAYER_GAIN2    13   /* AffineCouplingGainEx2.py + cond_utils.py:353-392 scale = exp(0.1 g[iso]) iso; log|det| = -H*W*C log(scale) */
 #define NF_LAYER_GAIN3    14   /* AffineCouplingGainEx3.py + cond_utils.py:395-429 scale = exp(1e-5 g[iso]);  log|det| once per patch (as GAIN) */
+/* the other settings of hps.flow_permutation / hps.decomp (noise_flow_model.py:80-92, matrix_param.py:191-193).  They fold to
+ * the same 4x4 channel-mixing op as CONV1X1; flow_permutation values other than 0 / 1 simply emit no layer. */
+#define NF_LAYER_CONV1X1_NONE 15 /* layers.py:74-145 Conv2d1x1, decomp = NONE (matrix_param.py:23-29): A is the variable,
+                                    A^-1 and log|det A| by pivoted elimination in double */
+#define NF_LAYER_CONV1X1_LU2  16 /* decomp = LU2 (matrix_param.py:143-188): full-matrix L / U variables masked to their
+                                    strict triangles, float64 evaluation */
+#define NF_LAYER_PERMUTE      17 /* flow_permutation = 0: tfb.Permute(channels reversed), log|det| = 0, no parameters */
 /* per-ISO tables hold the entries of ISO 100, 400, 800, 1600, 3200 in that order; any other ISO uses the ISO-800
  * entry (the tf.cond chains' last branch) — unlike SDN5/SDN4/SDN6, whose empty one-hot selects 0 */
 
@@ -75,6 +82,9 @@ extern "C" {
  *
  *  CONV1X1   (36 floats)  P[4][4] row-major, sign_S[4], log_S[4], L_vec[6], U_vec[6]
  *                         (matrix_param.py:100-140; vectors in tfdist.fill_triangular order)
+ *  CONV1X1_NONE (16)      A[4][4] row-major
+ *  CONV1X1_LU2  (56)      P[4][4], L[4][4] (only j<i read), sign_S[4], log_S[4], U[4][4] (only j>i read)
+ *  PERMUTE      (0)       —
  *  COUPLING  (width w)    l_1/W[3][3][2][w], l_1/b[w], bn1_mean[w], bn1_var[w],
  *                         l_2/W[w][w],       l_2/b[w], bn2_mean[w], bn2_var[w],
  *                         l_last/W[3][3][w+1][4], l_last/b[4], l_last/logs[4],

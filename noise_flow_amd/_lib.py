@@ -20,6 +20,7 @@ NF_LAYER_SDN = 6
 NF_LAYER_GAIN = 7
 NF_LAYER_SDN1, NF_LAYER_SDN2, NF_LAYER_SDN3, NF_LAYER_SDN6 = 8, 9, 10, 11
 NF_LAYER_GAIN1, NF_LAYER_GAIN2, NF_LAYER_GAIN3 = 12, 13, 14
+NF_LAYER_CONV1X1_NONE, NF_LAYER_CONV1X1_LU2, NF_LAYER_PERMUTE = 15, 16, 17
 
 NF_CFG_FP16_CNN = 1
 

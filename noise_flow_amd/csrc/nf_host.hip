@@ -60,6 +60,9 @@ int64_t layer_param_count(int32_t type, int32_t w)
 {
     switch (type) {
     case NF_LAYER_CONV1X1: return 16 + 4 + 4 + 6 + 6;
+    case NF_LAYER_CONV1X1_NONE: return 16;
+    case NF_LAYER_CONV1X1_LU2: return 16 + 16 + 4 + 4 + 16;
+    case NF_LAYER_PERMUTE: return 0;
     case NF_LAYER_COUPLING:
         if (w <= 0) return -1;
         return 9 * 2 * (int64_t)w + w + w + w      // l_1/W, l_1/b, bn1 mean, var
@@ -137,6 +140,68 @@ void fold_conv1x1(const float *p, Mat4 &A, Mat4 &Ainv, double &log_abs_det)
             for (int k = i + 1; k < 4; ++k) s -= U.m[i][k] * Ainv.m[k][c];
             Ainv.m[i][c] = s / U.m[i][i];
         }
+}
+
+// General 4x4 inverse + log|det| by Gauss-Jordan with partial pivoting, in double (tf.matrix_inverse / tf.linalg.slogdet
+// of matrix_param.py:26-27, :177-179).  false = singular.
+bool invert4(const Mat4 &M, Mat4 &inv, double &log_abs_det)
+{
+    double a[4][8];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            a[i][j] = M.m[i][j];
+            a[i][4 + j] = i == j ? 1.0 : 0.0;
+        }
+    log_abs_det = 0.0;
+    for (int c = 0; c < 4; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < 4; ++r)
+            if (fabs(a[r][c]) > fabs(a[piv][c])) piv = r;
+        if (!(fabs(a[piv][c]) > 0.0)) return false;
+        if (piv != c)
+            for (int j = 0; j < 8; ++j) std::swap(a[piv][j], a[c][j]);
+        const double d = a[c][c];
+        log_abs_det += log(fabs(d));
+        for (int j = 0; j < 8; ++j) a[c][j] /= d;
+        for (int r = 0; r < 4; ++r) {
+            if (r == c) continue;
+            const double f = a[r][c];
+            if (f != 0.0)
+                for (int j = 0; j < 8; ++j) a[r][j] -= f * a[c][j];
+        }
+    }
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) inv.m[i][j] = a[i][4 + j];
+    return true;
+}
+
+// decomp = 'NONE' (matrix_param.py:23-29): the matrix is the variable.
+bool fold_conv1x1_none(const float *p, Mat4 &A, Mat4 &Ainv, double &log_abs_det)
+{
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) A.m[i][j] = p[i * 4 + j];
+    return invert4(A, Ainv, log_abs_det);
+}
+
+// decomp = 'LU2' (matrix_param.py:143-188): full-matrix L / U variables masked to their strict triangles, evaluated in
+// float64; A^-1 = U^-1 L^-1 P^-1 from the three separate inverses, as the reference forms it (:177-180).
+bool fold_conv1x1_lu2(const float *p, Mat4 &A, Mat4 &Ainv, double &log_abs_det)
+{
+    const float *P = p, *Lf = p + 16, *sign_s = p + 32, *log_s = p + 36, *Uf = p + 40;
+    Mat4 Pm, L, U, Pi, Li, Ui;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            Pm.m[i][j] = P[i * 4 + j];
+            L.m[i][j] = j < i ? (double)Lf[i * 4 + j] : (i == j ? 1.0 : 0.0);
+            U.m[i][j] = j > i ? (double)Uf[i * 4 + j] : (i == j ? (double)sign_s[i] * exp((double)log_s[i]) : 0.0);
+        }
+    log_abs_det = 0.0;
+    for (int i = 0; i < 4; ++i) log_abs_det += (double)log_s[i];           // :187
+    A = matmul(Pm, matmul(L, U));
+    double d;
+    if (!invert4(Pm, Pi, d) || !invert4(L, Li, d) || !invert4(U, Ui, d)) return false;
+    Ainv = matmul(Ui, matmul(Li, Pi));
+    return true;
 }
 
 // ---- coupling CNN folding ---------------------------------------------------
@@ -600,6 +665,21 @@ int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float
             out.ld_const += HW * lad;                       // layers.py:129-130
             break;
         }
+        case NF_LAYER_CONV1X1_NONE:
+        case NF_LAYER_CONV1X1_LU2: {
+            double lad;
+            const bool ok = L.type == NF_LAYER_CONV1X1_NONE ? fold_conv1x1_none(p, it.A, it.Ainv, lad)
+                                                            : fold_conv1x1_lu2(p, it.A, it.Ainv, lad);
+            if (!ok) return fail(NF_EINVAL, "layer %d: the 1x1 matrix is singular", li);
+            it.type = NF_OP_MIX;
+            out.ld_const += HW * lad;
+            break;
+        }
+        case NF_LAYER_PERMUTE:                              // tfb.Permute(channels reversed), noise_flow_model.py:80-84
+            for (int r = 0; r < 4; ++r)
+                for (int c = 0; c < 4; ++c) it.A.m[r][c] = it.Ainv.m[r][c] = (r + c == 3) ? 1.0 : 0.0;
+            it.type = NF_OP_MIX;
+            break;
         case NF_LAYER_COUPLING: {
             if (L.width != 4 && L.width != 8 && L.width != 16 && L.width != 32)
                 return fail(NF_EINVAL, "layer %d: coupling width %d unsupported (4, 8, 16, 32)", li, L.width);

@@ -118,6 +118,18 @@ class Conv2d1x1(_Unconditional):
     ``_forward`` = x @ A⁻¹, constant log|det| = H·W·Σ log_S."""
 
 
+class Conv2d1x1LU2(Conv2d1x1):
+    """decomp='LU2' (matrix_param.py:143-188): full-matrix L / U variables, float64 evaluation."""
+
+
+class Conv2d1x1Dense(Conv2d1x1):
+    """decomp='NONE' (matrix_param.py:23-29): A is the variable; A⁻¹ and log|det A| computed from it."""
+
+
+class Permute(_Unconditional):
+    """``tfb.Permute(permutation=[3, 2, 1, 0])`` of flow_permutation = 0 (noise_flow_model.py:80-84): log|det| = 0."""
+
+
 class AffineCoupling(_Unconditional):
     """layers.py:251-375 with ``real_nvp_conv_template`` (layers.py:452-498)."""
 
@@ -173,13 +185,13 @@ class AffineCouplingGainEx3(_Conditional):
 
 _CLASS = {"sdn1": AffineCouplingSdnEx1, "sdn2": AffineCouplingSdnEx2, "sdn3": AffineCouplingSdnEx3, "sdn6": AffineCouplingSdnEx6,
           "gain1": AffineCouplingGainEx1, "gain2": AffineCouplingGainEx2, "gain3": AffineCouplingGainEx3,
-          "sdn4": AffineCouplingSdnEx4, "sdn": AffineCouplingSdn, "gain": AffineCouplingGain, "conv1x1": Conv2d1x1, "coupling": AffineCoupling, "sdn5": AffineCouplingSdnEx5, "gain4": AffineCouplingGainEx4}
+          "sdn4": AffineCouplingSdnEx4, "sdn": AffineCouplingSdn, "gain": AffineCouplingGain, "conv1x1": Conv2d1x1, "conv1x1_lu2": Conv2d1x1LU2, "conv1x1_none": Conv2d1x1Dense, "permute": Permute, "coupling": AffineCoupling, "sdn5": AffineCouplingSdnEx5, "gain4": AffineCouplingGainEx4}
 
 
 def bijectors_from_arch(arch: str, variables: Dict[str, np.ndarray], x_shape, width: int,
-                        binding: str = "loss_first", device=None) -> List[_Bijector]:
+                        binding: str = "loss_first", device=None, flow_permutation: int = 1, decomp: str = "LU") -> List[_Bijector]:
     """The bijector list ``NoiseFlow.noise_flow_arch`` would build
     (noise_flow_model.py:71-235), each bound to its checkpoint variables."""
-    specs = _params.parse_arch(arch)
+    specs = _params.parse_arch(arch, flow_permutation, decomp)
     tmpl = _params.template_binding(specs, binding)
     return [_CLASS[s.kind](s, variables, x_shape, width, tmpl, device) for s in specs]

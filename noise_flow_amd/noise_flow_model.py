@@ -114,10 +114,10 @@ class FlowHandle:
 
     def __init__(self, arch, variables: Dict[str, np.ndarray], x_shape, width: int,
                  binding: str = "loss_first", device: Optional[int] = None, layers=None, tmpl=None,
-                 cnn_dtype: str = "fp32"):
+                 cnn_dtype: str = "fp32", flow_permutation: int = 1, decomp: str = "LU"):
         self.lib = _lib.load()
         if layers is None:
-            self.layers, descs, flat = _params.pack(arch, variables, width, binding)
+            self.layers, descs, flat = _params.pack(arch, variables, width, binding, flow_permutation, decomp)
         else:   # an explicit sub-list of bijectors (noise_flow_amd.layers)
             self.layers, descs, flat = _params.pack_layers(layers, variables, width, tmpl or {})
         H, W, Cc = (int(v) for v in x_shape)
@@ -189,10 +189,10 @@ class NoiseFlow(object):
             raise NotImplementedError("n_levels > 1 (split2d) is outside the hot path (shipped: n_levels = 1)")
         if int(getattr(hps, "squeeze_factor", 1)) != 1:
             raise NotImplementedError("squeeze_factor != 1 is outside the hot path (shipped: 1)")
-        if int(getattr(hps, "flow_permutation", 1)) != 1:
-            raise NotImplementedError("flow_permutation must be 1 (Conv2d1x1), as shipped")
-        if str(getattr(hps, "decomp", "LU")) != "LU":
-            raise NotImplementedError("decomp must be 'LU', as shipped (hps.txt:67)")
+        # noise_flow_model.py:80-92 / matrix_param.py:191-193: 1 = Conv2d1x1 (shipped; decomp LU | LU2 | NONE), 0 = channel-reversing
+        # tfb.Permute, anything else = no mixing layer
+        self.flow_permutation = int(getattr(hps, "flow_permutation", 1))
+        self.decomp = str(getattr(hps, "decomp", "LU"))
         self.arch = hps.arch
         self.width = int(getattr(hps, "width", 4))
         self._dev = _Dev(device)
@@ -200,13 +200,13 @@ class NoiseFlow(object):
         self._draws = 0
         self._lock = threading.Lock()
         self._variables = dict(variables) if variables is not None else _params.init_variables(
-            self.arch, self.width, self.x_shape[-1], self._seed)
-        self.model = [_params.parse_arch(self.arch)]   # bijector list per level (define_flow_structure)
+            self.arch, self.width, self.x_shape[-1], self._seed, self.flow_permutation, self.decomp)
+        self.model = [_params.parse_arch(self.arch, self.flow_permutation, self.decomp)]   # bijector list per level (define_flow_structure)
         # 'fp16': coupling-CNN convs in half precision on the matrix cores, everything else fp32
         # (BASELINE configs[4]); also selectable as hps.cnn_dtype.  Default: all fp32.
         self.cnn_dtype = cnn_dtype or str(getattr(hps, "cnn_dtype", "fp32"))
         self._flow = FlowHandle(self.arch, self._variables, self.x_shape, self.width, binding, self._dev.device.index,
-                                cnn_dtype=self.cnn_dtype)
+                                cnn_dtype=self.cnn_dtype, flow_permutation=self.flow_permutation, decomp=self.decomp)
 
     # ------------------------------------------------------------------ variables
     @property
@@ -223,7 +223,8 @@ class NoiseFlow(object):
         self._variables = dict(variables)
         old = self._flow
         self._flow = FlowHandle(self.arch, self._variables, self.x_shape, self.width, self.binding,
-                                self._dev.device.index, cnn_dtype=self.cnn_dtype)
+                                self._dev.device.index, cnn_dtype=self.cnn_dtype, flow_permutation=self.flow_permutation,
+                                decomp=self.decomp)
         old.close()
 
     def restore(self, ckpt_prefix: str, binding: Optional[str] = None) -> None:

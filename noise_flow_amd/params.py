@@ -34,15 +34,26 @@ class LayerSpec:
     width: int = 0
 
 
-def parse_arch(arch: str) -> List[LayerSpec]:
-    """noise_flow_model.py:71-235 with flow_permutation = 1 (Conv2d1x1 before every
-    AffineCoupling, noise_flow_model.py:85-90)."""
+_CONV1X1_KINDS = {"LU": ("conv1x1", "NF_LAYER_CONV1X1"), "LU2": ("conv1x1_lu2", "NF_LAYER_CONV1X1_LU2"),
+                  "NONE": ("conv1x1_none", "NF_LAYER_CONV1X1_NONE")}     # matrix_param.py:191-193
+
+
+def parse_arch(arch: str, flow_permutation: int = 1, decomp: str = "LU") -> List[LayerSpec]:
+    """noise_flow_model.py:71-235.  ``flow_permutation`` = 1 (shipped): a Conv2d1x1 parameterised by ``decomp`` before
+    every AffineCoupling (:85-90); 0: tfb.Permute reversing the channels (:80-84); anything else: no mixing layer
+    (:91-92)."""
+    if decomp not in _CONV1X1_KINDS:
+        raise ValueError("hps.decomp must be one of %s (matrix_param.py:191-193), got %r" % (sorted(_CONV1X1_KINDS), decomp))
     if not arch:
         raise ValueError("hps.arch must be a non-empty 'a|b|c' string (revnet2d stacks are out of scope)")
     layers: List[LayerSpec] = []
     for i, lyr in enumerate(arch.split("|")):
         if lyr == "unc":
-            layers.append(LayerSpec("conv1x1", "Conv2d_1x1_%d" % i, i, _lib.NF_LAYER_CONV1X1))
+            if int(flow_permutation) == 1:
+                kind, typ = _CONV1X1_KINDS[decomp]
+                layers.append(LayerSpec(kind, "Conv2d_1x1_%d" % i, i, getattr(_lib, typ)))
+            elif int(flow_permutation) == 0:
+                layers.append(LayerSpec("permute", "permute", i, _lib.NF_LAYER_PERMUTE))
             layers.append(LayerSpec("coupling", "unc_%d" % i, i, _lib.NF_LAYER_COUPLING))
         elif lyr == "sdn5":
             layers.append(LayerSpec("sdn5", "sdn_%d" % i, i, _lib.NF_LAYER_SDN5))
@@ -84,20 +95,27 @@ def template_binding(layers: List[LayerSpec], binding: str) -> Dict[int, int]:
     return {i: k for k, i in enumerate(ids)}
 
 
-def conv1x1_names(i: int) -> Dict[str, str]:
+def conv1x1_names(i: int, decomp: str = "LU") -> Dict[str, str]:
+    """Variable names per decomposition (matrix_param.py:24, :109-123, :151-161), under the layer's scope."""
     pre = "level0/bijector%d/Conv2d_1x1_%d/" % (i, i)
-    sfx = "_matpar_lu_conv2d_1x1_%d_0" % i
-    return {k: pre + k + sfx for k in ("P", "sign_S", "log_S", "L_vec", "U_vec")}
+    nm = "conv2d_1x1_%d_0" % i
+    if decomp == "LU2":
+        return {"P": pre + "P_" + nm, "L": pre + "L_filters_" + nm, "sign_S": pre + "sign_S_" + nm,
+                "log_S": pre + "log_S_filters_" + nm, "U": pre + "U_filters_" + nm}
+    if decomp == "NONE":
+        return {"A": pre + "A_matpar_none_" + nm}
+    return {k: pre + k + "_matpar_lu_" + nm for k in ("P", "sign_S", "log_S", "L_vec", "U_vec")}
 
 
 def _f32(a) -> np.ndarray:
     return np.asarray(a, dtype=np.float32).reshape(-1)
 
 
-def pack(arch: str, variables: Dict[str, np.ndarray], width: int, binding: str = "loss_first"):
+def pack(arch: str, variables: Dict[str, np.ndarray], width: int, binding: str = "loss_first", flow_permutation: int = 1,
+         decomp: str = "LU"):
     """→ (layers, descs ctypes array, params float32 ndarray) in the canonical raw
     layout documented in include/noiseflow_hip.h."""
-    layers = parse_arch(arch)
+    layers = parse_arch(arch, flow_permutation, decomp)
     return pack_layers(layers, variables, width, template_binding(layers, binding))
 
 
@@ -107,6 +125,13 @@ def layer_variable_names(L: LayerSpec, tmpl: Dict[int, int]) -> List[Optional[st
     if L.kind == "conv1x1":
         n = conv1x1_names(L.arch_index)
         return [n["P"], n["sign_S"], n["log_S"], n["L_vec"], n["U_vec"]]
+    if L.kind == "conv1x1_lu2":
+        n = conv1x1_names(L.arch_index, "LU2")
+        return [n["P"], n["L"], n["sign_S"], n["log_S"], n["U"]]
+    if L.kind == "conv1x1_none":
+        return [conv1x1_names(L.arch_index, "NONE")["A"]]
+    if L.kind == "permute":
+        return []
     if L.kind == "coupling":
         t = template_scope(tmpl[L.arch_index]) + "/"
         return [t + "l_1/W", t + "l_1/b", t + "bn_nvp_conv_1/mean", t + "bn_nvp_conv_1/var",
@@ -155,7 +180,8 @@ def pack_layers(layers: List[LayerSpec], variables: Dict[str, np.ndarray], width
             w1 = np.asarray(need(t + "l_1/W"), np.float32)
             if w1.shape != (3, 3, 2, width):
                 raise ValueError("%sl_1/W has shape %s, expected (3,3,2,%d)" % (t, w1.shape, width))
-        blk = np.concatenate([_f32(need(nm)) if nm is not None else np.asarray([C_I], np.float32)
+        blk = np.concatenate([np.zeros((0,), np.float32)] +
+                             [_f32(need(nm)) if nm is not None else np.asarray([C_I], np.float32)
                               for nm in layer_variable_names(L, tmpl)])
         expect = _lib.load().nf_layer_param_count(L.nf_type, L.width)
         if blk.size != expect:
@@ -216,7 +242,8 @@ def stricttri2vec(mat: np.ndarray, upper: bool) -> np.ndarray:
     return out
 
 
-def init_variables(arch: str, width: int = 4, channels: int = 4, seed: int = 0) -> Dict[str, np.ndarray]:
+def init_variables(arch: str, width: int = 4, channels: int = 4, seed: int = 0, flow_permutation: int = 1,
+                   decomp: str = "LU") -> Dict[str, np.ndarray]:
     """Fresh variables under the reference's names with the reference's
     initialisers: QR-orthogonal 1x1 matrix → scipy LU (layers.py:95,
     matrix_param.py:100-123); l_1/l_2 ~ N(0, (width/512·0.05)²), zero biases
@@ -225,14 +252,27 @@ def init_variables(arch: str, width: int = 4, channels: int = 4, seed: int = 0) 
     sdn/gain parameters of train_noise_flow.py:201-214 and cond_utils.py:438."""
     import scipy.linalg as sla
     rng = np.random.RandomState(seed)
-    layers = parse_arch(arch)
+    layers = parse_arch(arch, flow_permutation, decomp)
     v: Dict[str, np.ndarray] = {}
     c2 = channels // 2
     k = 0
     for L in layers:
-        if L.kind != "conv1x1":
+        if not L.kind.startswith("conv1x1") and L.kind != "permute":
             v["level0/bijector%d/rescaling_scale0" % L.arch_index] = np.float32(1e-4)
-        if L.kind == "conv1x1":
+        if L.kind in ("conv1x1_none", "conv1x1_lu2"):
+            q = sla.qr(rng.randn(channels, channels))[0].astype(np.float32)
+            if L.kind == "conv1x1_none":
+                v[conv1x1_names(L.arch_index, "NONE")["A"]] = q
+            else:                                                        # matrix_param.py:145-161
+                p, l, u = sla.lu(q)
+                s = np.diag(u)
+                n = conv1x1_names(L.arch_index, "LU2")
+                v[n["P"]] = p.astype(np.float32)
+                v[n["L"]] = l.astype(np.float32)
+                v[n["sign_S"]] = np.sign(s).astype(np.float32)
+                v[n["log_S"]] = np.log(np.abs(s)).astype(np.float32)
+                v[n["U"]] = np.triu(u, 1).astype(np.float32)
+        elif L.kind == "conv1x1":
             q = sla.qr(rng.randn(channels, channels))[0].astype(np.float32)
             p, l, u = sla.lu(q)
             s = np.diag(u)

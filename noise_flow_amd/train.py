@@ -44,6 +44,9 @@ class Trainer:
         self.width = int(getattr(hps, "width", 4))
         self.binding = binding
         self._dev = _Dev(device)
+        if int(getattr(hps, "flow_permutation", 1)) != 1 or str(getattr(hps, "decomp", "LU")) != "LU":
+            raise NotImplementedError("the training step covers the shipped parameterisation (flow_permutation = 1, decomp = 'LU'); "
+                                      "the other settings are served by the likelihood / sampling paths only")
         seed = int(getattr(hps, "seed", 0) or 0)
         self._variables = dict(variables) if variables is not None else _params.init_variables(
             self.arch, self.width, self.x_shape[-1], seed)

@@ -100,6 +100,66 @@ def matrix_param_lu(P, sign_S, log_S, L_vec, U_vec, dtype=np.float64):
     return A.astype(dtype), A_inv.astype(dtype), dtype(np.sum(log_S))   # :138
 
 
+def matrix_param_none(A, dtype=np.float64):
+    """matrix_param.py:23-29 (decomp 'NONE'): the matrix itself is the variable."""
+    A = np.asarray(A, dtype)
+    sign, lad = np.linalg.slogdet(A.astype(np.float64))
+    return A, np.linalg.inv(A.astype(np.float64)).astype(dtype), dtype(lad)
+
+
+def matrix_param_lu2(P, L, sign_S, log_S, U, dtype=np.float64):
+    """matrix_param.py:143-188 (decomp 'LU2'): full L / U variables masked to their strict
+    triangles, everything evaluated in float64 and cast back (``dtype2 = 'float64'``, :164)."""
+    P, L, U = (np.asarray(a, np.float64) for a in (P, L, U))
+    sign_S, log_S = np.asarray(sign_S, np.float64), np.asarray(log_S, np.float64)
+    n = log_S.shape[0]
+    mask = np.tril(np.ones((n, n)), -1)
+    Lm = L * mask + np.eye(n)                                      # :172
+    Um = U * mask.T + np.diag(sign_S * np.exp(log_S))              # :173
+    A = P @ (Lm @ Um)                                              # :174
+    A_inv = np.linalg.inv(Um) @ (np.linalg.inv(Lm) @ np.linalg.inv(P))   # :177-180
+    return A.astype(dtype), A_inv.astype(dtype), dtype(np.sum(log_S))
+
+
+def conv1x1_variable_names(i: int, decomp: str = "LU") -> Dict[str, str]:
+    """Checkpoint names of Conv2d_1x1_i's variables for each ``hps.decomp`` (matrix_param.py:24, :109-123, :151-161)."""
+    pre = "level0/bijector%d/Conv2d_1x1_%d/" % (i, i)
+    nm = "conv2d_1x1_%d_0" % i
+    if decomp == "LU":
+        return {k: pre + k + "_matpar_lu_" + nm for k in ("P", "sign_S", "log_S", "L_vec", "U_vec")}
+    if decomp == "LU2":
+        return {"P": pre + "P_" + nm, "L": pre + "L_filters_" + nm, "sign_S": pre + "sign_S_" + nm,
+                "log_S": pre + "log_S_filters_" + nm, "U": pre + "U_filters_" + nm}
+    if decomp == "NONE":
+        return {"A": pre + "A_matpar_none_" + nm}
+    raise ValueError("hps.decomp must be 'LU', 'LU2' or 'NONE' (matrix_param.py:191-193), got %r" % (decomp,))
+
+
+def conv1x1_from_variables(variables, i: int, decomp: str, dtype):
+    n = conv1x1_variable_names(i, decomp)
+    if decomp == "LU":
+        return matrix_param_lu(variables[n["P"]], variables[n["sign_S"]], variables[n["log_S"]], variables[n["L_vec"]],
+                               variables[n["U_vec"]], dtype)
+    if decomp == "LU2":
+        return matrix_param_lu2(variables[n["P"]], variables[n["L"]], variables[n["sign_S"]], variables[n["log_S"]],
+                                variables[n["U"]], dtype)
+    return matrix_param_none(variables[n["A"]], dtype)
+
+
+def conv1x1_init_variables(q: np.ndarray, i: int, decomp: str) -> Dict[str, np.ndarray]:
+    """Initial variables of Conv2d_1x1_i from its QR-orthogonal start matrix (layers.py:95)."""
+    import scipy.linalg as sla
+    n = conv1x1_variable_names(i, decomp)
+    if decomp == "LU":
+        return {n[k]: a for k, a in lu_init_from_matrix(q).items()}
+    if decomp == "NONE":
+        return {n["A"]: q.astype(np.float32)}
+    p, l, u = sla.lu(q)                                            # matrix_param.py:145-149
+    s = np.diag(u)
+    return {n["P"]: p.astype(np.float32), n["L"]: l.astype(np.float32), n["sign_S"]: np.sign(s).astype(np.float32),
+            n["log_S"]: np.log(np.abs(s)).astype(np.float32), n["U"]: np.triu(u, k=1).astype(np.float32)}
+
+
 def lu_init_from_matrix(A0: np.ndarray) -> Dict[str, np.ndarray]:
     """matrix_param.py:100-123: initial (P, sign_S, log_S, L_vec, U_vec) from a matrix."""
     import scipy.linalg as sla
@@ -409,7 +469,8 @@ def template_name(k: int) -> str:
     return "model/real_nvp_conv_template" + ("" if k == 0 else "_%d" % k)
 
 
-def bind_variables(arch: str, variables: Dict[str, np.ndarray], binding: str = "loss_first", dtype=np.float64):
+def bind_variables(arch: str, variables: Dict[str, np.ndarray], binding: str = "loss_first", dtype=np.float64,
+                   flow_permutation: int = 1, decomp: str = "LU"):
     """Attach checkpoint variables to layers.
 
     ``binding``: tf.make_template scopes are numbered in the
@@ -427,12 +488,13 @@ def bind_variables(arch: str, variables: Dict[str, np.ndarray], binding: str = "
     layers = []
     for lyr, i in arch_l:
         if lyr == "unc":
-            pre = "level0/bijector%d/Conv2d_1x1_%d/" % (i, i)
-            sfx = "_matpar_lu_conv2d_1x1_%d_0" % i
-            A, A_inv, lad = matrix_param_lu(variables[pre + "P" + sfx], variables[pre + "sign_S" + sfx],
-                                            variables[pre + "log_S" + sfx], variables[pre + "L_vec" + sfx],
-                                            variables[pre + "U_vec" + sfx], dtype)
-            layers.append({"type": "conv1x1", "name": "Conv2d_1x1_%d" % i, "A": A, "A_inv": A_inv, "log_abs_det": lad})
+            if flow_permutation == 1:      # noise_flow_model.py:85-90
+                A, A_inv, lad = conv1x1_from_variables(variables, i, decomp, dtype)
+                layers.append({"type": "conv1x1", "name": "Conv2d_1x1_%d" % i, "A": A, "A_inv": A_inv, "log_abs_det": lad})
+            elif flow_permutation == 0:    # noise_flow_model.py:80-84: tfb.Permute(channels reversed), log|det| = 0
+                J = np.eye(4, dtype=dtype)[::-1].copy()
+                layers.append({"type": "conv1x1", "name": "permute", "A": J, "A_inv": J, "log_abs_det": dtype(0.0)})
+            # any other value: "No permutation specified. Not using any." (noise_flow_model.py:91-92)
             t = template_name(tmpl_of[i]) + "/"
             p = {
                 "l_1/W": f(variables[t + "l_1/W"]), "l_1/b": f(variables[t + "l_1/b"]).reshape(-1),
@@ -472,7 +534,8 @@ def bind_variables(arch: str, variables: Dict[str, np.ndarray], binding: str = "
     return layers
 
 
-def fresh_variables(arch: str, width: int = 4, channels: int = 4, seed: int = 0) -> Dict[str, np.ndarray]:
+def fresh_variables(arch: str, width: int = 4, channels: int = 4, seed: int = 0, flow_permutation: int = 1,
+                    decomp: str = "LU") -> Dict[str, np.ndarray]:
     """Fresh-init variables under the reference's names and initialisers:
     QR-orthogonal 1x1 matrix (layers.py:95) decomposed by scipy LU
     (matrix_param.py:100-123); l_1/l_2 ~ N(0, (width/512*0.05)^2), biases 0
@@ -487,12 +550,9 @@ def fresh_variables(arch: str, width: int = 4, channels: int = 4, seed: int = 0)
     for lyr, i in parse_arch(arch):
         v["level0/bijector%d/rescaling_scale0" % i] = np.float32(1e-4)
         if lyr == "unc":
-            q = sla.qr(rng.randn(channels, channels))[0].astype(np.float32)
-            lu = lu_init_from_matrix(q)
-            pre = "level0/bijector%d/Conv2d_1x1_%d/" % (i, i)
-            sfx = "_matpar_lu_conv2d_1x1_%d_0" % i
-            for nm, arr in lu.items():
-                v[pre + nm + sfx] = arr
+            if flow_permutation == 1:
+                q = sla.qr(rng.randn(channels, channels))[0].astype(np.float32)
+                v.update(conv1x1_init_variables(q, i, decomp))
             t = template_name(k) + "/"
             k += 1
             std = width / 512 * 0.05
@@ -540,12 +600,13 @@ class NoiseFlowOracle:
     default.  ``x`` = noise, ``y`` = clean image, ``z`` = latent."""
 
     def __init__(self, arch: str, variables: Dict[str, np.ndarray], binding: str = "loss_first",
-                 dtype=np.float64, sidd_cond: str = "mix", cnn_dtype: str = "fp32"):
+                 dtype=np.float64, sidd_cond: str = "mix", cnn_dtype: str = "fp32", flow_permutation: int = 1,
+                 decomp: str = "LU"):
         self.arch = arch
         self.dtype = dtype
         self.cnn_fp16 = cnn_dtype == "fp16"   # emulate the library's fp16 coupling-CNN mode
         self.sidd_cond = sidd_cond
-        self.layers = bind_variables(arch, variables, binding, dtype)
+        self.layers = bind_variables(arch, variables, binding, dtype, flow_permutation, decomp)
 
     def _record(self, L, training):
         """Training mode: ``last_batch_moments[layer name]`` ← the moments of the latest call."""

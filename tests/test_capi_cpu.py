@@ -12,10 +12,10 @@ from conftest import FULL_ARCH, ROOT, trained_like_variables
 from oracle import nf_oracle as O
 
 
-def _fold(arch, variables, width, direction, hw=(32, 32)):
+def _fold(arch, variables, width, direction, hw=(32, 32), flow_permutation=1, decomp="LU"):
     from noise_flow_amd import _lib, params
     lib = _lib.load()
-    layers, descs, flat = params.pack(arch, variables, width)
+    layers, descs, flat = params.pack(arch, variables, width, "loss_first", flow_permutation, decomp)
     cfg = _lib.nf_config(hw[0], hw[1], 4, len(layers), -1, 0)
     ops = (C.c_int32 * 256)()
     n_ops, nf, ld = C.c_int32(), C.c_size_t(), C.c_double()
@@ -226,3 +226,36 @@ def test_missing_extension_fails_loudly(tmp_path):
             "    print('OK')\n") % (ROOT, os.path.join(str(tmp_path), "libnoiseflow_hip.so"))
     out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert out.returncode == 0 and out.stdout.decode().strip().endswith("OK"), out.stderr.decode()[-1500:]
+
+
+@pytest.mark.parametrize("flow_permutation,decomp", [(1, "NONE"), (1, "LU2"), (0, "LU"), (2, "LU")])
+def test_other_permutation_settings_fold_like_the_oracle(flow_permutation, decomp):
+    """hps.flow_permutation / hps.decomp beyond the shipped (1, 'LU'): noise_flow_model.py:80-92, matrix_param.py:23-29,143-193."""
+    from noise_flow_amd import _lib, params
+    arch = "unc|unc|gain4|unc"
+    v = O.fresh_variables(arch, 4, 4, seed=11, flow_permutation=flow_permutation, decomp=decomp)
+    rng = np.random.RandomState(5)
+    v["model/sdn_gain/gain_val"] = np.asarray([1.7], np.float32)
+    for k in list(v):
+        if "Conv2d_1x1" in k and not ("/P_" in k or "sign_S" in k):
+            v[k] = (np.asarray(v[k]) + 0.2 * rng.randn(*np.shape(v[k]))).astype(np.float32)   # off the orthogonal start
+    assert set(v) == set(params.init_variables(arch, 4, 4, 11, flow_permutation, decomp))
+    layers = O.bind_variables(arch, v, flow_permutation=flow_permutation, decomp=decomp)
+    mixes = [L for L in layers if L["type"] == "conv1x1"]
+    assert len(mixes) == (3 if flow_permutation in (0, 1) else 0)
+    for direction in (0, 1):
+        ops, blk, ld = _fold(arch, v, 4, direction, flow_permutation=flow_permutation, decomp=decomp)
+        got = [blk[off:off + 16].reshape(4, 4).astype(np.float64) for t, off in ops if t == _lib.NF_OP_MIX]
+        assert len(got) == len(mixes)
+        want_ld = sum(1024 * float(L["log_abs_det"]) for L in mixes) - 4096 * np.log(float(v["model/sdn_gain/gain_val"][0]))
+        assert abs(ld - want_ld) < 1e-6 * max(1.0, abs(want_ld))
+        g = float(v["model/sdn_gain/gain_val"][0])
+        for k, (M, L) in enumerate(zip(got if direction == 0 else got[::-1], mixes)):
+            want = L["A"] if direction == 0 else L["A_inv"]
+            if k == 2:          # the gain layer in front of the third mix is folded into it
+                want = want / g if direction == 0 else want * g
+            np.testing.assert_allclose(M, want, rtol=3e-6, atol=3e-7)
+    if flow_permutation == 0:
+        assert [L.name for L in params.parse_arch(arch, 0)] == ["permute", "unc_0", "permute", "unc_1", "gain_2", "permute", "unc_3"]
+    with pytest.raises(ValueError):
+        params.parse_arch(arch, 1, "QR")

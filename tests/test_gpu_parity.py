@@ -600,6 +600,44 @@ def test_remaining_arch_vocabulary(arch, iso, cam):
         assert ei.value.code == NF_ECOND
 
 
+@pytest.mark.parametrize("width", [4, 16])
+@pytest.mark.parametrize("flow_permutation,decomp", [(1, "NONE"), (1, "LU2"), (0, "LU"), (2, "LU")])
+def test_other_permutation_settings(flow_permutation, decomp, width):
+    """hps.flow_permutation = 0 (tfb.Permute), 2 (no mixing layer) and hps.decomp = NONE / LU2 of Conv2d1x1
+    (noise_flow_model.py:80-92, matrix_param.py:23-29,143-193): both directions, eval-mode and batch-statistics BN."""
+    from noise_flow_amd import NoiseFlow, default_hps, params
+    from oracle.nf_oracle import NoiseFlowOracle
+    arch = "sdn4|unc|unc|gain4|unc"
+    v = params.init_variables(arch, width, 4, 23, flow_permutation, decomp)
+    base = trained_like_variables(arch, width, seed=23)
+    rng = np.random.RandomState(9)
+    for k in v:
+        if k in base:
+            v[k] = base[k]
+        elif "Conv2d_1x1" in k and not ("/P_" in k or "sign_S" in k):
+            v[k] = (np.asarray(v[k]) + 0.15 * rng.randn(*np.shape(v[k]))).astype(np.float32)
+        if width == 16 and (k.endswith("l_2/W") or k.endswith("l_last/W")):
+            v[k] = (v[k] * 0.5).astype(np.float32)
+    hps = default_hps(arch=arch, width=width, flow_permutation=flow_permutation, decomp=decomp)
+    o = NoiseFlowOracle(arch, v, flow_permutation=flow_permutation, decomp=decomp)
+    x, y = make_inputs(6, seed=77)
+    eps = np.random.RandomState(2).randn(6, 32, 32, 4).astype(np.float32)
+    m = NoiseFlow([32, 32, 4], False, hps, variables=v)
+    assert m.get_layer_names() == [L["name"] for L in o.layers]
+    nll, sd = m._loss(x, y, [0], [0], [800], [2])
+    ref, rsd, rz = o.nll(x, y, 800, 2)
+    np.testing.assert_allclose(nll, ref, rtol=NLL_RTOL)
+    z, obj = m.inverse(x, None, y, [0], [0], [800], [2])
+    _close_elem(z, rz)
+    _close_elem(m.sample(y, 0.8, y, [0], [0], [800], [2], eps=eps), o.sample(eps, 0.8, y, 800, 2))
+    # batch-statistics BN (is_training=True): statistics chain through whatever sits between the couplings
+    mt = NoiseFlow([32, 32, 4], True, hps, variables=v)
+    nll_t, _ = mt._loss(x, y, [0], [0], [800], [2])
+    ref_t, _, _ = o.nll(x, y, 800, 2, training=True)
+    np.testing.assert_allclose(nll_t, ref_t, rtol=5e-5)
+    _close_elem(mt.sample(y, 0.8, y, [0], [0], [800], [2], eps=eps), o.sample(eps, 0.8, y, 800, 2, training=True), rtol=2e-4)
+
+
 def test_full_bench_batch_against_c_oracle(shipped_variables):
     """Every patch of a full configs[1] batch (1024) and a configs[2] batch (4096 eps-supplied
     samples) against the plain-C oracle (fp32, reference op order)."""

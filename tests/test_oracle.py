@@ -229,3 +229,31 @@ def test_config_c1_unconditional_flow_256_patches_cpu():
     b = O.NoiseFlowOracle("unc", v).nll(x[:32])[0]
     np.testing.assert_allclose(a[:32], b, rtol=5e-6)
     assert np.isfinite(a).all()
+
+
+def test_conv1x1_decompositions_agree():
+    """matrix_param.py:23-29 / :100-140 / :143-188: the three parameterisations of one matrix give the same A, A^-1
+    and log|det A|; tfb.Permute(reversed channels) is an involution with log|det| = 0."""
+    import scipy.linalg as sla
+    from oracle import nf_oracle as O
+    rng = np.random.RandomState(3)
+    q = (sla.qr(rng.randn(4, 4))[0] + 0.2 * rng.randn(4, 4)).astype(np.float32)
+    v = {}
+    for d in ("LU", "LU2", "NONE"):
+        v.update(O.conv1x1_init_variables(q, 0, d))
+    got = {d: O.conv1x1_from_variables(v, 0, d, np.float64) for d in ("LU", "LU2", "NONE")}
+    for d, (A, Ai, lad) in got.items():
+        np.testing.assert_allclose(A, q.astype(np.float64), rtol=0, atol=3e-7, err_msg=d)
+        np.testing.assert_allclose(A @ Ai, np.eye(4), rtol=0, atol=2e-6, err_msg=d)
+        assert abs(lad - np.log(abs(np.linalg.det(q.astype(np.float64))))) < 2e-6, d
+    # LU2 ignores what sits outside the strict triangles of its full-matrix L / U variables (matrix_param.py:171-173)
+    n = O.conv1x1_variable_names(0, "LU2")
+    v2 = dict(v)
+    v2[n["L"]] = v[n["L"]] + np.triu(np.ones((4, 4), np.float32))
+    v2[n["U"]] = v[n["U"]] + np.tril(np.ones((4, 4), np.float32))
+    np.testing.assert_array_equal(O.conv1x1_from_variables(v2, 0, "LU2", np.float64)[0], got["LU2"][0])
+    layers = O.bind_variables("unc", O.fresh_variables("unc", flow_permutation=0), flow_permutation=0)
+    assert [L["name"] for L in layers] == ["permute", "unc_0"] and layers[0]["log_abs_det"] == 0
+    z = rng.randn(1, 2, 2, 4)
+    np.testing.assert_array_equal(O.conv1x1_inverse(z, layers[0]["A"], 0.0)[0], z[..., ::-1])
+    assert [L["name"] for L in O.bind_variables("unc", O.fresh_variables("unc", flow_permutation=2), flow_permutation=2)] == ["unc_0"]
