@@ -99,7 +99,8 @@ __host__ __device__ constexpr int nf_cpl_size(int w)   { return 64 + 36 * w + 18
 #define NF3_CPL_W1H 76
 #define NF3_CPL_W2H 172
 #define NF3_CPL_W3H 180
-#define NF3_CPL_SIZE 252
+#define NF3_W3H_STRIDE 20      // words per lane-of-four: 9 taps x 2 words, padded so that every lane's run is 16-byte aligned
+#define NF3_CPL_SIZE 260
 
 // ---- wide-CNN layout (coupling width 32, nf_wide.hip) ------------------------------------------
 // The three convs of a width-32 coupling CNN run on v_mfma_f32_32x32x2_f32 with the PIXELS on the N

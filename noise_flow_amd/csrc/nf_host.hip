@@ -330,7 +330,7 @@ void relayout_coupling_v3(const float *v1, float *out)
         }
         for (int i = 0; i < 4; ++i) h2[j * 4 + i] = to_half(v1[nf_cpl_off_W2(w) + i * 4 + j]);
         for (int tap = 0; tap < 9; ++tap)
-            for (int i = 0; i < 4; ++i) h3[(j * 9 + tap) * 4 + i] = to_half(v1[nf_cpl_off_W3(w) + (tap * 4 + i) * 4 + j]);
+            for (int i = 0; i < 4; ++i) h3[j * (2 * NF3_W3H_STRIDE) + tap * 4 + i] = to_half(v1[nf_cpl_off_W3(w) + (tap * 4 + i) * 4 + j]);
     }
 }
 

@@ -34,6 +34,9 @@
 // lifetimes spread 37..57 us around a 48 us mean and the launch lasts as long as the slowest one (tools/timeline.py).
 // Lowering a wave's priority as it advances through the couplings (3,3,2,2,1,1,0,0) is a negative feedback that keeps
 // co-resident workgroups level.  0 = off (MFMA bursts at NF_PRIO, the round-1 behaviour).
+#ifndef NF_WAVE_PRIO
+#define NF_WAVE_PRIO 1
+#endif
 #ifndef NF_FAIR
 #define NF_FAIR 1
 #endif
@@ -307,6 +310,17 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
     }
     NF_STAMP(1);
 
+#if NF_WAVE_PRIO
+    if constexpr (MFMA && THREADS == 1024) {
+        // one workgroup per CU, 4 waves per SIMD (waves w, w+4, w+8, w+12), all in the same phase between two barriers:
+        // a fixed, distinct priority per wave of a SIMD lets the leaders' VALU tail run under the followers' MFMA burst
+        const int wq = NF_WAVE_PRIO == 1 ? ((t >> 8) & 3) : NF_WAVE_PRIO == 2 ? ((t >> 8) & 1) : (((t >> 8) & 3) == 0 ? 1 : 0);
+        if (wq == 0) __builtin_amdgcn_s_setprio(0);
+        else if (wq == 1) __builtin_amdgcn_s_setprio(1);
+        else if (wq == 2) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(3);
+    }
+#endif
     const int n_ops = prog.n_ops;
     double acc_nll = 0.0, acc_sd = 0.0;   // thread 0 only
     [[maybe_unused]] int cpl_total = 0;
@@ -389,7 +403,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
             } else if (type == NF_OP_COUPLING_FWD || type == NF_OP_COUPLING_REV) {
                 // ---- AffineCoupling (layers.py:275-291 / 355-375) ----
 #if NF_FAIR
-                if constexpr (MFMA) {
+                if constexpr (MFMA && !(NF_WAVE_PRIO && THREADS == 1024)) {
                     const int lvl = (cpl_seen * 4) / cpl_total;   // 0 .. 3, wave-uniform
                     ++cpl_seen;
                     if (lvl == 0) __builtin_amdgcn_s_setprio(3);
@@ -417,11 +431,16 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
                     const float4 b1 = *reinterpret_cast<const float4 *>(wb + NF3_CPL_B1);
                     const float4 b2 = *reinterpret_cast<const float4 *>(wb + NF3_CPL_B2);
                     v4h w1h[3][4];   // [filter row][group]: this lane's A operands (4 halves each)
+                    // 16-byte LDS reads (two A operands each): ds_read_b128 moves 256 B/clk, the ds_read2_b64 the compiler
+                    // would form from 8-byte reads only 128 B/clk
 #pragma unroll
                     for (int di = 0; di < 3; ++di)
 #pragma unroll
-                        for (int g = 0; g < 4; ++g)
-                            w1h[di][g] = *reinterpret_cast<const v4h *>(wbw + NF3_CPL_W1H + ((j4 * 3 + di) * 4 + g) * 2);
+                        for (int g = 0; g < 4; g += 2) {
+                            const uint4 q = *reinterpret_cast<const uint4 *>(wbw + NF3_CPL_W1H + ((j4 * 3 + di) * 4 + g) * 2);
+                            w1h[di][g] = __builtin_bit_cast(v4h, make_uint2(q.x, q.y));
+                            w1h[di][g + 1] = __builtin_bit_cast(v4h, make_uint2(q.z, q.w));
+                        }
                     const v4h w2h = *reinterpret_cast<const v4h *>(wbw + NF3_CPL_W2H + j4 * 2);
                     v4f h1[PX];
 #pragma unroll
@@ -646,8 +665,12 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
                         sc = 0.0f;
                         v4h w3h[9];
 #pragma unroll
-                        for (int tap = 0; tap < 9; ++tap)
-                            w3h[tap] = *reinterpret_cast<const v4h *>(wbw + NF3_CPL_W3H + (j4 * 9 + tap) * 2);
+                        for (int tap = 0; tap < 8; tap += 2) {
+                            const uint4 q = *reinterpret_cast<const uint4 *>(wbw + NF3_CPL_W3H + j4 * NF3_W3H_STRIDE + tap * 2);
+                            w3h[tap] = __builtin_bit_cast(v4h, make_uint2(q.x, q.y));
+                            w3h[tap + 1] = __builtin_bit_cast(v4h, make_uint2(q.z, q.w));
+                        }
+                        w3h[8] = *reinterpret_cast<const v4h *>(wbw + NF3_CPL_W3H + j4 * NF3_W3H_STRIDE + 16);
                         v4f acc[PX];
 #pragma unroll
                         for (int k = 0; k < PX; ++k) {
