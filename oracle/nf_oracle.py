@@ -275,14 +275,43 @@ def coupling_cnn_fp16(z0: np.ndarray, p: Dict[str, np.ndarray]):
     return o[..., :c2], o[..., c2:]
 
 
+def coupling_cnn_fp16_plain(z0: np.ndarray, p: Dict[str, np.ndarray]):
+    """An independent half-precision evaluation of real_nvp_conv_template (layers.py:463-497), op by op as the reference
+    writes it and WITHOUT the library's folding: every conv takes its input and its RAW weights rounded to fp16 and
+    accumulates in the working dtype; bias, batch norm (stored statistics), ReLU and the exp(3*logs) scaling are applied
+    afterwards, unrounded.  It shares no rounding point with csrc/nf_host.hip's folded weights, so it measures how far
+    ANY fp16 evaluation of this CNN sits from the fp32 one — the yardstick the library's fp16 mode is held to."""
+    dt = z0.dtype.type
+    h = conv2d_nhwc(_h(z0), _h(p["l_1/W"]), True) + p["l_1/b"].reshape(1, 1, 1, -1)
+    h, _, _ = batch_norm(h, p["bn1/mean"], p["bn1/var"], False)
+    h = np.maximum(h, dt(0))
+    h = conv2d_nhwc(_h(h), _h(p["l_2/W"]), True) + p["l_2/b"].reshape(1, 1, 1, -1)
+    h, _, _ = batch_norm(h, p["bn2/mean"], p["bn2/var"], False)
+    h = np.maximum(h, dt(0))
+    w = p["l_2/W"].shape[-1]
+    W3 = p["l_last/W"].copy()
+    W3[:, :, :w, :] = _h(W3[:, :, :w, :])                      # the 0/1 edge channel and its weights stay exact
+    o = conv2d_nhwc(add_edge_padding(_h(h)), W3, False) + p["l_last/b"].reshape(1, 1, 1, -1)
+    o = o * np.exp(p["l_last/logs"].reshape(1, 1, 1, -1) * dt(LOGSCALE_FACTOR))
+    c2 = o.shape[-1] // 2
+    return o[..., :c2], o[..., c2:]
+
+
 # ----------------------------------------------------------------------------
 # bijectors
 # ----------------------------------------------------------------------------
+def _coupling_cnn_any(z0, p, training, cnn_fp16, record):
+    """``cnn_fp16``: False = all working-dtype; True = the library's rounding points; 'plain' = the unfolded fp16 yardstick."""
+    if cnn_fp16 == "plain":
+        return coupling_cnn_fp16_plain(z0, p)
+    return coupling_cnn_fp16(z0, p) if cnn_fp16 else coupling_cnn(z0, p, training, record)
+
+
 def affine_coupling_inverse(z, p, training=False, cnn_fp16=False, record=None):
     """AffineCoupling._inverse_and_log_det_jacobian, layers.py:355-375 (NLL direction)."""
     c2 = z.shape[-1] // 2
     z0, z1 = z[..., :c2], z[..., c2:]
-    shift, raw = coupling_cnn_fp16(z0, p) if cnn_fp16 else coupling_cnn(z0, p, training, record)
+    shift, raw = _coupling_cnn_any(z0, p, training, cnn_fp16, record)
     ls = p["rescaling_scale"] * np.tanh(raw)
     x1 = z1 * np.exp(ls) + shift
     return np.concatenate([z0, x1], axis=-1), ls.sum(axis=(1, 2, 3))
@@ -292,7 +321,7 @@ def affine_coupling_forward(x, p, training=False, cnn_fp16=False, record=None):
     """AffineCoupling._forward, layers.py:275-291 (sampling direction)."""
     c2 = x.shape[-1] // 2
     x0, x1 = x[..., :c2], x[..., c2:]
-    shift, raw = coupling_cnn_fp16(x0, p) if cnn_fp16 else coupling_cnn(x0, p, training, record)
+    shift, raw = _coupling_cnn_any(x0, p, training, cnn_fp16, record)
     ls = p["rescaling_scale"] * np.tanh(raw)
     y1 = (x1 - shift) * np.exp(-ls)
     return np.concatenate([x0, y1], axis=-1)
@@ -604,7 +633,8 @@ class NoiseFlowOracle:
                  decomp: str = "LU"):
         self.arch = arch
         self.dtype = dtype
-        self.cnn_fp16 = cnn_dtype == "fp16"   # emulate the library's fp16 coupling-CNN mode
+        # 'fp16': emulate the library's fp16 coupling-CNN mode;  'fp16_plain': the independent, unfolded fp16 evaluation
+        self.cnn_fp16 = "plain" if cnn_dtype == "fp16_plain" else cnn_dtype == "fp16"
         self.sidd_cond = sidd_cond
         self.layers = bind_variables(arch, variables, binding, dtype, flow_permutation, decomp)
 

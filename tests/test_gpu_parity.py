@@ -501,6 +501,31 @@ def test_fp16_coupling_cnn_mode(shipped_variables, oracle_full, hw, B):
     np.testing.assert_allclose(nll, ref32, rtol=1e-4)
 
 
+def test_fp16_mode_against_an_independent_fp16_evaluation(shipped_variables, oracle_full):
+    """The emulating oracle above shares the library's folding order.  This one does not: `fp16_plain` rounds the RAW
+    weights and each conv input to half and applies bias / BN / exp(3 logs) afterwards, as the reference's op sequence
+    would under mixed precision.  No two fp16 evaluations agree to better than the quantisation noise, so the claim
+    checked is the meaningful one: the library's fp16 mode is no further from the fp32 model than that independent
+    fp16 evaluation is (per-patch NLL and latent), i.e. folding before rounding costs no accuracy."""
+    from noise_flow_amd import NoiseFlow, default_hps
+    from oracle.nf_oracle import NoiseFlowOracle
+    x, y = make_inputs(16, seed=21)
+    m = NoiseFlow([32, 32, 4], False, default_hps(), variables=shipped_variables, cnn_dtype="fp16")
+    plain = NoiseFlowOracle(FULL_ARCH, shipped_variables, cnn_dtype="fp16_plain")
+    nll32, _, z32 = oracle_full.nll(x, y, 800, 2)
+    nll_p, _, z_p = plain.nll(x, y, 800, 2)
+    nll, _ = m._loss(x, y, [0], [0], [800], [2])
+    z, _ = m.inverse(x, None, y, [0], [0], [800], [2])
+    noise_nll = np.abs(nll_p - nll32).max()
+    noise_z = np.abs(z_p - z32).max()
+    assert noise_nll > 0 and noise_z > 0                                  # the yardstick really is a different evaluation
+    assert np.abs(nll - nll32).max() <= 2.0 * noise_nll + 1e-6 * np.abs(nll32).max()
+    assert np.abs(np.asarray(z, np.float64) - z32).max() <= 2.0 * noise_z + 1e-6 * np.abs(z32).max()
+    # and the two fp16 evaluations sit within that same noise of each other
+    assert np.abs(nll - nll_p).max() <= 3.0 * noise_nll
+    np.testing.assert_allclose(nll, nll32, rtol=2.5e-4)
+
+
 def test_oversized_patch_is_rejected_at_create():
     from noise_flow_amd._lib import NoiseFlowLibError, NF_EINVAL
     v = trained_like_variables("unc", 8)
