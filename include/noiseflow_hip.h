@@ -204,7 +204,9 @@ int nf_sample(nf_handle *h, const float *y, const float *eps, uint64_t seed,
  *                (layers.py:392-393, decay 0.1) consumes; applying it is the caller's business.
  * Unlike nf_nll / nf_sample these calls run 2 statistics passes per coupling before the fused pass,
  * SYNCHRONISE `stream`, use a per-handle scratch (allocated on first use; concurrent calls on one
- * handle serialise) and are fp32 only.  B must be >= 1. */
+ * handle serialise) and are fp32 only.  B must be >= 1.  At coupling widths other than 4 the statistics
+ * passes run on the scalar-weight kernel, whose two LDS tiles bound the patch: up to 1024 pixels at
+ * width 32, ~2270 at width 16 (e.g. 45x48), ~4090 at width 8 (e.g. 62x62); larger -> NF_EINVAL. */
 int nf_nll_batchstats(nf_handle *h, const float *x, const float *y, int64_t B, const nf_cond *cond,
                       float *nll_out, float *sd_out, float *logdet_out, float *z_out,
                       double *sums_out, uint32_t flags, float *moments_out, void *stream);

@@ -1583,6 +1583,14 @@ static int run_batchstats(nf_handle *h, int direction, NfLaunch a, float *moment
         if (moments_out && n_cpl) memcpy(moments_out, mom_h.data(), (size_t)n_cpl * 16 * sizeof(float));
         return NF_OK;
     }
+    {   // the generic schedule runs on the scalar-weight kernel: both LDS tiles of a patch on one CU, one pixel per lane at width 32
+        const size_t tile_px = ((size_t)(a.H + 2) * (a.W + 2) + 1) & ~(size_t)1;
+        const size_t lds = sizeof(float) * (tile_px * (2 + (size_t)w) + 64);
+        if (lds > 160 * 1024 || (w >= 32 && a.H * a.W > 1024))
+            return fail(NF_EINVAL, "batch-statistics mode at coupling width %d covers patches of up to %s pixels (%dx%d given); "
+                        "evaluation mode has no such limit", w, w >= 32 ? "1024" : w == 16 ? "~2270 (e.g. 45x48)" : "~4090 (e.g. 62x62)",
+                        a.H, a.W);
+    }
     if ((e = hipMemcpyAsync(S.d_work, P.d_ident, nw1 * sizeof(float), hipMemcpyDeviceToDevice, st)) != hipSuccess ||
         (nw2 && (e = hipMemcpyAsync(S.d_work2, P.d_ident2, nw2 * sizeof(float), hipMemcpyDeviceToDevice, st)) != hipSuccess) ||
         (e = hipMemsetAsync(S.d_stats, 0, NF_STATS_SLOTS * 2 * (size_t)w * sizeof(double), st)) != hipSuccess)

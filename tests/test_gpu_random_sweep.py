@@ -1,0 +1,182 @@
+"""Randomised sweep: architectures drawn from ``noise_flow_arch``'s whole vocabulary, every coupling width, ragged patch
+shapes from 1x1 to 64x64, all settings of ``hps.flow_permutation`` / ``hps.decomp``, ISO in and outside the table — each
+case through both directions of the HIP path (whichever kernel family the shape selects) against the fp64 oracle.
+
+The hand-picked cases of the other files pin the geometry edges; this file looks for what nobody thought of.
+Tolerance: per-patch NLL 1e-5 relative, tensors 1e-5 of their scale — or, where random weights make the stack
+ill-conditioned, twice the distance of the oracle's own float32 flavour from its fp64 one (the kernel may not be
+further from the truth than a plain fp32 evaluation of the reference's op sequence is)."""
+import numpy as np
+import pytest
+
+from conftest import make_inputs, trained_like_variables
+
+pytestmark = pytest.mark.gpu
+
+VOCAB = ["sdn5", "sdn4", "gain4", "sdn", "gain", "sdn1", "sdn2", "sdn3", "sdn6", "gain1", "gain2", "gain3"]
+SETTINGS = [(1, "LU"), (1, "LU"), (1, "LU2"), (1, "NONE"), (0, "LU"), (2, "LU")]
+ISO_TABLE = [100, 400, 800, 1600, 3200]
+
+
+def _draw_case(seed):
+    rng = np.random.RandomState(1000 + seed)
+    width = int(rng.choice([4, 4, 4, 8, 16, 32]))
+    n = int(rng.randint(1, 6))
+    arch, n_cond = [], 0
+    for _ in range(n):
+        lyr = "unc" if rng.rand() < 0.5 else str(rng.choice(VOCAB))
+        if lyr != "unc":
+            if n_cond == 4:        # the C ABI takes at most 4 conditional layers per model
+                lyr = "unc"
+            else:
+                n_cond += 1
+        arch.append(lyr)
+    # one parameter set per family: two sdn-family (or gain-family) layers that read different variable sets may share an
+    # arch, but two layers over the SAME variables must agree on their shapes (sdn5 [3,5] vs sdn6 [1,5] cam_params)
+    if "sdn5" in arch and "sdn6" in arch:
+        arch = [a if a != "sdn6" else "sdn5" for a in arch]
+    if "gain" in arch and "gain1" in arch:       # ... or on their scale (gain: sigmoid(g), gain1: exp(1e-5 g))
+        arch = [a if a != "gain1" else "gain" for a in arch]
+    shape_kind = rng.randint(0, 4)
+    if shape_kind == 0:
+        H, W = int(rng.choice([32, 64])), int(rng.choice([32, 64]))
+    elif shape_kind == 1:
+        H, W = int(rng.randint(1, 12)), int(rng.randint(1, 12))
+    else:
+        H, W = int(rng.randint(1, 65)), int(rng.randint(1, 65))
+    fp, decomp = SETTINGS[rng.randint(len(SETTINGS))]
+    iso = int(rng.choice(ISO_TABLE + [250]))
+    if "sdn1" in arch or "sdn2" in arch or "sdn3" in arch or "gain2" in arch:
+        iso = int(rng.choice(ISO_TABLE))          # per-ISO tables scaled for their own ISO (see _condition)
+    cam = int(rng.randint(0, 5))
+    B = int(rng.choice([1, 2, 5]))
+    return "|".join(arch), width, (H, W), fp, decomp, iso, cam, B
+
+
+def _condition(v, arch, width, iso, rng):
+    """Keep the random model's scales O(1) (as test_remaining_arch_vocabulary does) and the wide CNNs' activations tame."""
+    kinds = set(arch.split("|"))
+    for k in list(v):
+        if "r_gain_param_" in k:
+            v[k] = np.asarray([(-np.log(iso) + 0.3 * rng.randn()) / 1e-2], np.float32)
+        elif "gain_param_" in k:
+            if kinds & {"sdn2", "sdn3", "gain2"}:
+                v[k] = np.asarray([(-np.log(max(iso, 100)) + 0.3 * rng.randn()) / 1e-1], np.float32)
+            else:
+                v[k] = np.asarray([0.3 * rng.randn() / 1e-5], np.float32)
+        elif k in ("model/b1", "model/b2"):
+            v[k] = np.asarray([rng.randn()], np.float32)
+        elif k == "model/g1":
+            v[k] = np.asarray([-np.log(iso) / 1e-5 if "gain1" in kinds else -np.log(iso)], np.float32)
+        elif k == "model/g2":
+            v[k] = np.asarray([-0.7 / 1e-5 if "gain1" in kinds else -0.7], np.float32)
+        elif k == "model/sdn_gain/cam_params":
+            v[k] = (1.0 + 0.2 * rng.randn(*v[k].shape)).astype(np.float32)
+        elif k == "model/sdn_gain/gain_params":
+            v[k] = (-np.log(np.asarray([100, 400, 800, 1600, 3200.0])) * 0.8 + 0.1 * rng.randn(5)).astype(np.float32)
+        elif k in ("model/sdn_gain/beta1", "model/sdn_gain/beta2"):
+            v[k] = np.asarray([-1.0 + 0.3 * rng.randn()], np.float32)
+        elif width > 4 and (k.endswith("l_2/W") or k.endswith("l_last/W")):
+            v[k] = (v[k] * np.float32((4.0 / width) ** 0.5)).astype(np.float32)
+        elif "Conv2d_1x1" in k and not ("/P_" in k or "sign_S" in k) and ("A_matpar_none" in k or "_filters_" in k):
+            v[k] = (np.asarray(v[k]) + 0.1 * rng.randn(*np.shape(v[k]))).astype(np.float32)
+    return v
+
+
+def _within(a, ref64, ref32, floor_rtol):
+    scale = np.abs(ref64).max()
+    tol = max(floor_rtol * scale, 2.0 * np.abs(ref32 - ref64).max())
+    err = np.abs(np.asarray(a, np.float64) - ref64).max()
+    assert err <= tol, "max err %.3e > tol %.3e (scale %.3e)" % (err, tol, scale)
+
+
+@pytest.mark.parametrize("seed", list(range(150)))
+def test_random_model_matches_oracle(seed):
+    from noise_flow_amd import NoiseFlow, default_hps, params
+    from oracle.nf_oracle import NoiseFlowOracle
+    arch, width, (H, W), fp, decomp, iso, cam, B = _draw_case(seed)
+    rng = np.random.RandomState(seed)
+    v = params.init_variables(arch, width, 4, seed, fp, decomp)
+    base = trained_like_variables(arch, width, seed=seed)
+    for k in v:
+        if k in base:
+            v[k] = base[k]
+    v = _condition(v, arch, width, iso, rng)
+    hps = default_hps(arch=arch, width=width, flow_permutation=fp, decomp=decomp)
+    m = NoiseFlow([H, W, 4], False, hps, variables=v)
+    o64 = NoiseFlowOracle(arch, v, flow_permutation=fp, decomp=decomp)
+    o32 = NoiseFlowOracle(arch, v, dtype=np.float32, flow_permutation=fp, decomp=decomp)
+    assert m.get_layer_names() == [L["name"] for L in o64.layers]
+    x, y = make_inputs(B, H, W, seed=seed + 7)
+    case = "arch=%s width=%d %dx%d fp=%d decomp=%s iso=%d cam=%d B=%d" % (arch, width, H, W, fp, decomp, iso, cam, B)
+    yy, args = y, ([0.0], [0.0], [iso], [cam])
+    try:
+        nll, sd = m._loss(x, yy, *args)
+        ref_nll, ref_sd, ref_z = o64.nll(x, yy, iso, cam)
+        nll32, _, z32 = o32.nll(x, yy, iso, cam)
+        tol = np.maximum(1e-5 * np.abs(ref_nll), 2.0 * np.abs(nll32 - ref_nll)) + 1e-4
+        assert (np.abs(nll - ref_nll) <= tol).all(), np.abs(nll - ref_nll).max()
+        z, obj = m.inverse(x, None, yy, *args)
+        _within(z, ref_z, z32, 1e-5)
+        eps = np.random.RandomState(seed + 3).randn(B, H, W, 4).astype(np.float32)
+        xs = m.sample(yy, 0.8, yy, *args, eps=eps)
+        _within(xs, o64.sample(eps, 0.8, yy, iso, cam), o32.sample(eps, 0.8, yy, iso, cam), 1e-5)
+        # the two directions invert each other
+        back = m.forward(np.asarray(z, np.float32), None, yy, *args)
+        back32 = o32.forward(z32, yy, iso, cam)       # how well a plain fp32 evaluation closes the loop on this model
+        tol = max(5e-5 * np.abs(x).max(), 4.0 * np.abs(back32 - x).max())
+        assert np.abs(np.asarray(back) - x).max() <= tol, "round trip %.3e > %.3e" % (np.abs(np.asarray(back) - x).max(), tol)
+    except AssertionError as e:
+        raise AssertionError("%s: %s" % (case, e))
+
+
+@pytest.mark.parametrize("seed", list(range(200, 240)))
+def test_random_model_batch_statistics(seed):
+    """The same draw in the reference's training-mode graph (``is_training=True``, layers.py:386-398): both activations of
+    every coupling CNN normalised with the moments of the call's own patches.  B >= 2 so that the moments are not those
+    of a single patch only; tolerances as tests/test_gpu_batchstats.py."""
+    from noise_flow_amd import NoiseFlow, default_hps, params
+    from oracle.nf_oracle import NoiseFlowOracle
+    arch, width, (H, W), fp, decomp, iso, cam, B = _draw_case(seed)
+    if "unc" not in arch.split("|"):
+        arch = arch + "|unc"
+    B = max(B, 2)
+    if H * W * B < 16:              # the variance of a handful of values is too noisy a denominator for a parity check
+        H, W = H + 4, W + 4
+    scalar_lds = 4 * ((((H + 2) * (W + 2) + 1) & ~1) * (2 + width) + 64)
+    if width != 4 and (scalar_lds > 160 * 1024 or (width >= 32 and H * W > 1024)):
+        # beyond the patch sizes the statistics passes cover at this width (include/noiseflow_hip.h): a clear refusal
+        from noise_flow_amd._lib import NoiseFlowLibError, NF_EINVAL
+        v0 = _condition(trained_like_variables(arch, width, seed=seed), arch, width, iso, np.random.RandomState(seed))
+        if fp == 1 and decomp == "LU":
+            m0 = NoiseFlow([H, W, 4], True, default_hps(arch=arch, width=width), variables=v0)
+            x0, y0 = make_inputs(B, H, W, seed=1)
+            with pytest.raises(NoiseFlowLibError) as ei:
+                m0._loss(x0, y0, [0.0], [0.0], [iso], [cam])
+            assert ei.value.code == NF_EINVAL and "batch-statistics mode at coupling width" in str(ei.value)
+        H, W = min(H, 30), min(W, 30)
+    rng = np.random.RandomState(seed)
+    v = params.init_variables(arch, width, 4, seed, fp, decomp)
+    base = trained_like_variables(arch, width, seed=seed)
+    for k in v:
+        if k in base:
+            v[k] = base[k]
+    v = _condition(v, arch, width, iso, rng)
+    hps = default_hps(arch=arch, width=width, flow_permutation=fp, decomp=decomp)
+    m = NoiseFlow([H, W, 4], True, hps, variables=v)
+    o64 = NoiseFlowOracle(arch, v, flow_permutation=fp, decomp=decomp)
+    o32 = NoiseFlowOracle(arch, v, dtype=np.float32, flow_permutation=fp, decomp=decomp)
+    x, y = make_inputs(B, H, W, seed=seed + 7)
+    case = "arch=%s width=%d %dx%d fp=%d decomp=%s iso=%d cam=%d B=%d" % (arch, width, H, W, fp, decomp, iso, cam, B)
+    args = ([0.0], [0.0], [iso], [cam])
+    try:
+        nll, _ = m._loss(x, y, *args)
+        ref_nll, _, ref_z = o64.nll(x, y, iso, cam, training=True)
+        nll32, _, z32 = o32.nll(x, y, iso, cam, training=True)
+        tol = np.maximum(5e-5 * np.abs(ref_nll), 2.0 * np.abs(nll32 - ref_nll)) + 1e-3
+        assert (np.abs(nll - ref_nll) <= tol).all(), np.abs(nll - ref_nll).max()
+        eps = np.random.RandomState(seed + 3).randn(B, H, W, 4).astype(np.float32)
+        xs = m.sample(y, 0.8, y, *args, eps=eps)
+        _within(xs, o64.sample(eps, 0.8, y, iso, cam, training=True), o32.sample(eps, 0.8, y, iso, cam, training=True), 2e-4)
+    except AssertionError as e:
+        raise AssertionError("%s: %s" % (case, e))
