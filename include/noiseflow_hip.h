@@ -239,6 +239,9 @@ int nf_trainer_destroy(nf_trainer *t);
  *   grads_out  DEVICE float[n_params] in the raw layout, zeros at non-trainable positions, or NULL
  *              to keep the gradient in the trainer (then nf_trainer_apply(t, NULL, ...) uses it).
  *              A data-parallel caller all-reduces this buffer between the two calls.
+ *              A variable the reference shares between layers (its AUTO_REUSE scope 'sdn_gain': two GAIN4 layers have ONE
+ *              gain_val) has one slot per layer here; the caller ties the slots by giving each the SUM of their gradients
+ *              before nf_trainer_apply (noise_flow_amd/train.py does).
  *   loss_out   DEVICE float[2] = (mean_b nll_b, sd_z) or NULL  */
 int nf_trainer_forward_backward(nf_trainer *t, const float *x, const float *y, int64_t B,
                                 const nf_cond *cond, float *grads_out, float *loss_out, void *stream);

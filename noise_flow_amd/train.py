@@ -70,6 +70,19 @@ class Trainer:
         self._grads = torch.zeros((self.n_params,), dtype=torch.float32, device=self._dev.device)
         self._loss = torch.zeros((2,), dtype=torch.float32, device=self._dev.device)
         self.has_sdn = any(L.kind in ("sdn5", "sdn4") for L in self.layers)
+        # Variables shared by several layers (the reference's AUTO_REUSE scope 'sdn_gain': arch "gain4|...|gain4" has ONE
+        # gain_val, "sdn5|...|sdn5" one beta1 / beta2 / gain_params / cam_params) hold one slot PER LAYER in the raw layout.
+        # Their gradient is the sum over the slots; every slot gets that sum, so the copies stay identical under the update.
+        slots: Dict[str, list] = {}
+        pos = 0
+        for L in self.layers:
+            for nm in _params.layer_variable_names(L, self._tmpl):
+                n = 1 if nm is None else int(np.asarray(self._variables[nm]).size)
+                if nm is not None:
+                    slots.setdefault(nm, []).append((pos, n))
+                pos += n
+        self._tied = [torch.tensor([list(range(p0, p0 + n)) for p0, n in lst], dtype=torch.long, device=self._dev.device)
+                      for lst in slots.values() if len(lst) > 1]
         self._sync = None          # (group key, callback object, buffer): keeps the ctypes thunk alive
 
     # ------------------------------------------------------------------ lifetime
@@ -135,6 +148,8 @@ class Trainer:
             _lib.check(self.lib.nf_trainer_forward_backward(
                 self._h, xt.data_ptr(), yt.data_ptr() if yt is not None else None, int(xt.shape[0]), C.byref(cond),
                 self._grads.data_ptr(), self._loss.data_ptr(), dev.stream_ptr()))
+            for idx in self._tied:
+                self._grads[idx] = self._grads[idx].sum(dim=0, keepdim=True).expand(idx.shape[0], -1)
         return self._grads, self._loss
 
     def forward(self, x, y, nlf0=None, nlf1=None, iso=None, cam=None, sync: bool = True):

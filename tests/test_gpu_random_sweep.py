@@ -180,3 +180,70 @@ def test_random_model_batch_statistics(seed):
         _within(xs, o64.sample(eps, 0.8, y, iso, cam, training=True), o32.sample(eps, 0.8, y, iso, cam, training=True), 2e-4)
     except AssertionError as e:
         raise AssertionError("%s: %s" % (case, e))
+
+
+TRAIN_VOCAB = ["unc", "unc", "unc", "sdn5", "sdn4", "gain4"]     # the layers the training step covers (include/noiseflow_hip.h)
+
+
+@pytest.mark.parametrize("seed", list(range(300, 330)))
+def test_random_model_training_gradients(seed):
+    """One forward + backward of the trainer (C ABI ``nf_trainer_*``) on a random draw of the trainable vocabulary against
+    the fp64 autograd oracle: loss, sd_z and every gradient tensor (tolerances of tests/test_gpu_train.py)."""
+    from noise_flow_amd import default_hps
+    from noise_flow_amd.train import Trainer
+    from oracle.nf_grad_oracle import GradOracle, is_trainable
+    from noise_flow_amd import params as P
+    rng = np.random.RandomState(5000 + seed)
+    width = int(rng.choice([4, 4, 8, 16, 32]))
+    arch = [str(rng.choice(TRAIN_VOCAB)) for _ in range(int(rng.randint(1, 6)))]
+    if "sdn5" in arch and "sdn4" in arch:          # both read model/sdn_gain/*: one family per model, as the job scripts have it
+        arch = [a if a != "sdn4" else "sdn5" for a in arch]
+    if "unc" not in arch:
+        arch.append("unc")
+    arch = "|".join(arch)
+    H, W = (int(rng.randint(1, 33)), int(rng.randint(1, 33))) if rng.rand() < 0.7 else (32, 32)
+    B = int(rng.randint(2, 8))
+    if H * W * B < 32:
+        H, W = H + 4, W + 4
+    iso = int(rng.choice(ISO_TABLE + [250]))
+    cam = int(rng.randint(0, 5))
+    v = trained_like_variables(arch, width, seed=seed)
+    if width > 4:
+        for k in list(v):
+            if k.endswith("l_2/W") or k.endswith("l_last/W"):
+                v[k] = (v[k] * np.float32((4.0 / width) ** 0.5)).astype(np.float32)
+    x, y = make_inputs(B, H, W, seed=seed)
+    case = "arch=%s width=%d %dx%d iso=%d cam=%d B=%d" % (arch, width, H, W, iso, cam, B)
+    tr = Trainer([H, W, 4], default_hps(arch=arch, width=width), variables=v, optim="adam", max_batch=8)
+    names = [nm for L in tr.layers for nm in P.layer_variable_names(L, tr._tmpl) if nm is not None]
+    rtol = 2e-4 if width <= 8 else 1e-3          # fp32 activations through randomly weighted 16/32-wide CNNs
+
+    def compare(xv):
+        grads, loss = tr.forward_backward(xv, y, [0.0], [0.0], [iso], [cam])
+        ref_loss, ref_sd, ref_grads, _ = GradOracle(arch, v).loss_and_grads(xv, y, iso, cam)
+        lv = loss.cpu().numpy()
+        assert abs(lv[0] - ref_loss) <= 1e-5 * abs(ref_loss) + 1e-4, "loss %r vs %r" % (lv[0], ref_loss)
+        assert abs(lv[1] - ref_sd) <= 1e-5 * ref_sd, "sd_z"
+        got = tr.raw_to_variables(grads.cpu().numpy())
+        gmax = max(np.abs(ref_grads[nm]).max() for nm in names if is_trainable(nm))
+        for nm in names:
+            if not is_trainable(nm):
+                continue
+            ref = np.asarray(ref_grads[nm], np.float64)
+            g = np.asarray(got[nm], np.float64).reshape(ref.shape)
+            if nm.endswith("l_1/b") or nm.endswith("l_2/b"):      # analytically zero (BN subtracts the batch mean)
+                assert np.abs(g).max() <= 2e-5 * gmax, (nm, np.abs(g).max(), gmax)
+            else:
+                assert np.abs(g - ref).max() <= rtol * max(np.abs(ref).max(), 1e-6 * gmax), (nm, np.abs(g - ref).max(), np.abs(ref).max())
+
+    # The loss is piecewise smooth: an activation within float32 round-off of a ReLU kink takes one branch in the fp64
+    # oracle and the other on the GPU, and the gradients upstream then differ by that one pixel's share (1e-4 .. 1e-2 of a
+    # tensor; measured: the disagreement vanishes, to 1e-6, when the input is moved by 1e-4 of itself, and the ORACLE's own
+    # gradient jumps by the same amount under a 3e-7 perturbation).  Such a draw is re-drawn next to itself, once.
+    try:
+        compare(x)
+    except AssertionError as first:
+        try:
+            compare((x * (1.0 + 1e-4 * np.random.RandomState(seed).randn(*x.shape))).astype(np.float32))
+        except AssertionError as e:
+            raise AssertionError("%s: %s (and next to it: %s)" % (case, first, e))

@@ -518,3 +518,31 @@ def test_training_golden_fixture(shipped_variables):
         if solid.any():
             # first Adam step = lr * g / (|g| + eps'): the bulk must move exactly like the oracle's
             assert np.abs(got[solid] - want[solid]).max() <= 0.02 * lr + 1e-6 * np.abs(want[solid]).max(), k
+
+
+def test_variables_shared_between_layers_receive_the_summed_gradient():
+    """The reference creates the sdn / gain parameters under an AUTO_REUSE scope: arch ``gain4|unc|gain4`` has ONE gain_val
+    and ``sdn4|unc|sdn4`` one beta1 / beta2 / gain_params.  The raw layout holds a slot per layer; the trainer sums the
+    slots' gradients (found by tests/test_gpu_random_sweep.py) and the copies stay identical through the update."""
+    arch = "sdn4|unc|gain4|sdn4|gain4"
+    v = trained_like_variables(arch, 4, seed=12)
+    x, y = make_inputs(5, 16, 16, seed=9)
+    tr = _trainer(arch, v, (16, 16, 4), 4)
+    grads, loss = tr.forward_backward(x, y, [0.0], [0.0], [800], [2])
+    ref_loss, _, ref_grads, _ = _grad_oracle(arch, v).loss_and_grads(x, y, 800, 2)
+    assert abs(loss.cpu().numpy()[0] - ref_loss) <= 1e-5 * abs(ref_loss)
+    _check_grads(tr, grads, ref_grads)
+    for _ in range(3):
+        tr.step(x, y, [0.0], [0.0], [800], [2], lr=1e-3)
+    raw = tr.raw_params()
+    from noise_flow_amd import params as P
+    pos, seen = 0, {}
+    for L in tr.layers:
+        for nm in P.layer_variable_names(L, tr._tmpl):
+            n = 1 if nm is None else int(np.asarray(v[nm]).size)
+            if nm is not None:
+                if nm in seen:
+                    np.testing.assert_array_equal(raw[pos:pos + n], seen[nm])
+                seen[nm] = raw[pos:pos + n].copy()
+            pos += n
+    assert not np.array_equal(seen["model/sdn_gain/gain_val"], np.asarray(v["model/sdn_gain/gain_val"]).reshape(-1))
