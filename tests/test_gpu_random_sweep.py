@@ -247,3 +247,53 @@ def test_random_model_training_gradients(seed):
             compare((x * (1.0 + 1e-4 * np.random.RandomState(seed).randn(*x.shape))).astype(np.float32))
         except AssertionError as e:
             raise AssertionError("%s: %s (and next to it: %s)" % (case, first, e))
+
+
+@pytest.mark.parametrize("seed", list(range(400, 430)))
+def test_random_model_fp16_cnn_mode(seed):
+    """``cnn_dtype='fp16'`` (BASELINE configs[4]) on a random draw: width 4 on full 32x32 / 64x64 patches
+    (v_mfma_f32_4x4x4_16b_f16), widths 8 / 16 / 32 on any shape (v_mfma_f32_32x32x16_f16) — against the oracle's
+    emulation of the rounding points (NLL 1e-4 relative, tensors 2e-3 of scale, as tests/test_gpu_wide.py) and no further
+    from the fp32 model than the quantisation noise of an independent fp16 evaluation explains."""
+    from noise_flow_amd import NoiseFlow, default_hps, params
+    from oracle.nf_oracle import NoiseFlowOracle
+    arch, width, (H, W), fp, decomp, iso, cam, B = _draw_case(seed)
+    if "unc" not in arch.split("|"):
+        arch = "unc|" + arch
+    if width == 4:
+        H = W = 32 if seed % 2 else 64
+    rng = np.random.RandomState(seed)
+    v = params.init_variables(arch, width, 4, seed, fp, decomp)
+    base = trained_like_variables(arch, width, seed=seed)
+    for k in v:
+        if k in base:
+            v[k] = base[k]
+    v = _condition(v, arch, width, iso, rng)
+    hps = default_hps(arch=arch, width=width, flow_permutation=fp, decomp=decomp)
+    m = NoiseFlow([H, W, 4], False, hps, variables=v, cnn_dtype="fp16")
+    o16 = NoiseFlowOracle(arch, v, cnn_dtype="fp16", flow_permutation=fp, decomp=decomp)
+    o32 = NoiseFlowOracle(arch, v, flow_permutation=fp, decomp=decomp)
+    oplain = NoiseFlowOracle(arch, v, cnn_dtype="fp16_plain", flow_permutation=fp, decomp=decomp)
+    x, y = make_inputs(B, H, W, seed=seed + 7)
+    case = "arch=%s width=%d %dx%d fp=%d decomp=%s iso=%d cam=%d B=%d" % (arch, width, H, W, fp, decomp, iso, cam, B)
+    args = ([0.0], [0.0], [iso], [cam])
+    try:
+        nll, _ = m._loss(x, y, *args)
+        ref, _, rz = o16.nll(x, y, iso, cam)
+        n32, _, z32 = o32.nll(x, y, iso, cam)
+        npl, _, zpl = oplain.nll(x, y, iso, cam)
+        noise = np.abs(npl - n32).max()
+        assert (np.abs(nll - ref) <= 1e-4 * np.abs(ref) + 0.05 * noise + 1e-3).all(), "nll vs emulation %.3e (noise %.3e)" % (np.abs(nll - ref).max(), noise)
+        # two fp16 evaluations are two draws of the same quantisation noise (a handful of patches each): the library's
+        # distance from the fp32 model is held to a multiple of the independent evaluation's, or 2e-4 relative (test_gpu_wide)
+        assert np.abs(nll - n32).max() <= max(6.0 * noise, 2e-4 * np.abs(n32).max()) + 1e-3, \
+            "nll vs fp32 %.3e, fp16 noise %.3e, |nll| %.3e" % (np.abs(nll - n32).max(), noise, np.abs(n32).max())
+        z, _ = m.inverse(x, None, y, *args)
+        zs = np.abs(rz).max()
+        assert np.abs(np.asarray(z, np.float64) - rz).max() <= 2e-3 * zs, "z vs emulation"
+        eps = np.random.RandomState(seed + 3).randn(B, H, W, 4).astype(np.float32)
+        xs = m.sample(y, 0.8, y, *args, eps=eps)
+        rx = o16.sample(eps, 0.8, y, iso, cam)
+        assert np.abs(np.asarray(xs, np.float64) - rx).max() <= 2e-3 * np.abs(rx).max(), "sample vs emulation"
+    except AssertionError as e:
+        raise AssertionError("%s: %s" % (case, e))
