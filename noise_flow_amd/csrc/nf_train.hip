@@ -56,11 +56,45 @@ struct TLayers {
     TLayer l[kMaxLayers];
 };
 
+// Wavefront sums, the total in every lane.  Four DPP adds finish the 16-lane rows (xor 1 and xor 2 inside the quads, then
+// the half-row and row mirrors), four v_readlane + three adds join the rows: ~11 VALU/SALU issues.  The __shfl_xor
+// butterfly this replaces is six DEPENDENT ds_bpermute round trips (~60 cycles each): with 8 .. 70 sums at the end of
+// every kernel of the step that was 1.5 - 3.5 us per launch (measured: 0.89 -> 0.82 ms per step at B = 138).
+#define NF_DPP_I(x, CTRL) __builtin_amdgcn_update_dpp(0, (x), (CTRL), 0xf, 0xf, false)
+#define NF_DPP_QX1 0xB1    // quad_perm [1,0,3,2]
+#define NF_DPP_QX2 0x4E    // quad_perm [2,3,0,1]
+#define NF_DPP_HMIR 0x141  // row_half_mirror
+#define NF_DPP_MIR 0x140   // row_mirror
 __device__ __forceinline__ float wsum(float v)
 {
+    v += __int_as_float(NF_DPP_I(__float_as_int(v), NF_DPP_QX1));
+    v += __int_as_float(NF_DPP_I(__float_as_int(v), NF_DPP_QX2));
+    v += __int_as_float(NF_DPP_I(__float_as_int(v), NF_DPP_HMIR));
+    v += __int_as_float(NF_DPP_I(__float_as_int(v), NF_DPP_MIR));   // every lane of a 16-lane row now holds the row's sum
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_get(double v)
+{
+    const int lo = NF_DPP_I(__double2loint(v), CTRL), hi = NF_DPP_I(__double2hiint(v), CTRL);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wsum(double v)
+{
+    v += dpp_get<NF_DPP_QX1>(v);
+    v += dpp_get<NF_DPP_QX2>(v);
+    v += dpp_get<NF_DPP_HMIR>(v);
+    v += dpp_get<NF_DPP_MIR>(v);
+    double r[4];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    for (int k = 0; k < 4; ++k)
+        r[k] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 16 * k), __builtin_amdgcn_readlane(__double2loint(v), 16 * k));
+    return (r[0] + r[1]) + (r[2] + r[3]);
 }
 
 // Reductions over the minibatch (BN moments, parameter gradients) avoid atomics: device-scope
@@ -129,9 +163,7 @@ __device__ __forceinline__ double acc_total(Acc a, int nslot)
     double s = 0.0;
 #pragma unroll
     for (int k = 0; k < NSLOT / 64; ++k) s += (double)x[k];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    return s;
+    return wsum(s);
 }
 
 // two values at once: all 2*NSLOT/64 loads are in flight together (each is a remote-L2 / memory miss)
@@ -151,11 +183,8 @@ __device__ __forceinline__ void acc_total2(Acc a, Acc b, int nslot, double &sa, 
         sa += (double)x[k];
         sb += (double)y[k];
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        sa += __shfl_xor(sa, o);
-        sb += __shfl_xor(sb, o);
-    }
+    sa = wsum(sa);
+    sb = wsum(sb);
 }
 
 // Cross-rank batch normalisation (nf_trainer_set_sync): between the kernel that produces a group of slotted sums
@@ -807,8 +836,7 @@ __global__ void k_reduce(int n, const float *__restrict__ part, int nslot, doubl
     if (i >= n) return;
     double s = 0.0;
     for (int k = threadIdx.x; k < nslot; k += 64) s += (double)part[(size_t)i * NSLOT + k];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    s = wsum(s);
     if (threadIdx.x == 0) G[i] = s;
 }
 
