@@ -85,11 +85,22 @@ __device__ __forceinline__ float nf_relu(float x)
     return __int_as_float(b > 0 ? b : 0);
 }
 
+// Wavefront sum, the total in every lane: four DPP adds finish the 16-lane rows (xor 1 / xor 2 inside the quads, the
+// half-row and row mirrors), four v_readlane + three adds join the rows — ~11 issues instead of the six dependent
+// ds_bpermute round trips of a __shfl_xor butterfly.
 __device__ __forceinline__ float wave_sum(float v)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
+#define NF_WS_DPP(x, CTRL) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), (CTRL), 0xf, 0xf, false))
+    v += NF_WS_DPP(v, 0xB1);    // quad_perm [1,0,3,2]
+    v += NF_WS_DPP(v, 0x4E);    // quad_perm [2,3,0,1]
+    v += NF_WS_DPP(v, 0x141);   // row_half_mirror
+    v += NF_WS_DPP(v, 0x140);   // row_mirror
+#undef NF_WS_DPP
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (r0 + r1) + (r2 + r3);
 }
 
 }  // namespace
