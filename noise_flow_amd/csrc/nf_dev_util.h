@@ -103,4 +103,25 @@ __device__ __forceinline__ float wave_sum(float v)
     return (r0 + r1) + (r2 + r3);
 }
 
+// the same for a double (both halves travel through the DPP / readlane network)
+template <int CTRL>
+__device__ __forceinline__ double dpp_get_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum(double v)
+{
+    v += dpp_get_f64<0xB1>(v);
+    v += dpp_get_f64<0x4E>(v);
+    v += dpp_get_f64<0x141>(v);
+    v += dpp_get_f64<0x140>(v);
+    double r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        r[k] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 16 * k), __builtin_amdgcn_readlane(__double2loint(v), 16 * k));
+    return (r[0] + r[1]) + (r[2] + r[3]);
+}
+
 }  // namespace

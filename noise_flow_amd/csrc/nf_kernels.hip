@@ -278,9 +278,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
 #pragma unroll
                 for (int q = 0; q < 8; ++q) v[q] = a.fix_stats[(size_t)t * 8 + q];   // slot t (NF_STATS_SLOTS == 64)
 #pragma unroll
-                for (int q = 0; q < 8; ++q)
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) v[q] += __shfl_xor(v[q], o);
+                for (int q = 0; q < 8; ++q) v[q] = wave_sum(v[q]);
                 if (t < 4) {
                     const double m = v[t] / a.fix_n;
                     double var = v[4 + t] / a.fix_n - m * m;   // tf.nn.moments: population variance
@@ -1037,9 +1035,7 @@ __global__ __launch_bounds__(64) void nf_sums_reduce_kernel(const double *__rest
     double v[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        v[k] = wide[(size_t)s * NF_SUMS_STRIDE + k];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o);
+        v[k] = wave_sum(wide[(size_t)s * NF_SUMS_STRIDE + k]);
     }
     if (s == 0)
 #pragma unroll
