@@ -601,11 +601,27 @@ def fresh_variables(arch: str, width: int = 4, channels: int = 4, seed: int = 0,
     if any(l == "gain" for l, _ in parse_arch(arch)):
         v["model/g1"] = np.full((1,), -3.0, np.float32)
         v["model/g2"] = np.full((1,), 3.0, np.float32)
-    if any(l in ("sdn5", "gain4", "sdn4") for l, _ in parse_arch(arch)):
+    kinds = {l for l, _ in parse_arch(arch)}
+    if kinds & {"sdn1", "sdn2", "sdn3"}:                       # cond_utils.py:90-93
+        v["model/b1"] = np.full((1,), -3.0, np.float32)
+        v["model/b2"] = np.full((1,), 3.0, np.float32)
+    if "sdn1" in kinds:                                        # cond_utils.py:60-68
+        for iso in ISO_TABLE:
+            v["model/r_gain_param_%05d" % iso] = np.zeros((1,), np.float32)
+    if kinds & {"sdn2", "sdn3", "gain2"}:                      # cond_utils.py:102-112, 361-366 (hps.gain_init = -5)
+        for iso in ISO_TABLE:
+            v["model/gain_param_%05d" % iso] = np.full((1,), -5.0 / 1e-1, np.float32)
+    elif "gain3" in kinds:                                     # cond_utils.py:401-405
+        for iso in ISO_TABLE:
+            v["model/gain_param_%05d" % iso] = np.full((1,), -5.0 / 1e-5, np.float32)
+    if "gain1" in kinds:                                       # cond_utils.py:341-342
+        v["model/g1"] = np.full((1,), -5.0 / 1e-5, np.float32)
+        v["model/g2"] = np.zeros((1,), np.float32)
+    if kinds & {"sdn5", "gain4", "sdn4", "sdn6"}:
         v["model/sdn_gain/beta1"] = np.full((1,), -5.0, np.float32)
         v["model/sdn_gain/beta2"] = np.zeros((1,), np.float32)
         v["model/sdn_gain/gain_params"] = np.full((5,), -5.0, np.float32)
-        v["model/sdn_gain/cam_params"] = np.ones((3, 5), np.float32)
+        v["model/sdn_gain/cam_params"] = np.ones((1, 5) if "sdn6" in kinds else (3, 5), np.float32)   # cond_utils.py:254 / :219
         v["model/sdn_gain/gain_val"] = np.ones((1,), np.float32)
     return v
 

@@ -663,6 +663,29 @@ def test_other_permutation_settings(flow_permutation, decomp, width):
     _close_elem(mt.sample(y, 0.8, y, [0], [0], [800], [2], eps=eps), o.sample(eps, 0.8, y, 800, 2, training=True), rtol=2e-4)
 
 
+def test_golden_arch_variants():
+    """The committed fixture of the rest of the architecture vocabulary (tests/golden/arch_variants.npz, made by
+    tools/make_golden_variants.py from the fp64 oracle): HIP path against the stored numbers, no oracle in the loop."""
+    import json
+    import os
+    from conftest import GOLDEN_DIR
+    from noise_flow_amd import NoiseFlow, default_hps
+    d = np.load(os.path.join(GOLDEN_DIR, "arch_variants.npz"))
+    meta = json.loads(str(d["meta"]))
+    for i, m in enumerate(meta):
+        tag = "c%d_" % i
+        v = {k[len(tag) + 4:]: d[k] for k in d.files if k.startswith(tag + "var:")}
+        hps = default_hps(arch=m["arch"], width=4, flow_permutation=m["flow_permutation"], decomp=m["decomp"])
+        nf = NoiseFlow([8, 8, 4], False, hps, variables=v)
+        assert nf.get_layer_names() == m["layer_names"]
+        x, y, eps = d[tag + "x"], d[tag + "y"], d[tag + "eps"]
+        nll, sd = nf._loss(x, y, [0.0], [0.0], [m["iso"]], [m["cam"]])
+        np.testing.assert_allclose(nll, d[tag + "nll"], rtol=NLL_RTOL, atol=1e-4, err_msg=m["arch"])
+        z, _ = nf.inverse(x, None, y, [0.0], [0.0], [m["iso"]], [m["cam"]])
+        _close_elem(z, d[tag + "z"])
+        _close_elem(nf.sample(y, 0.7, y, [0.0], [0.0], [m["iso"]], [m["cam"]], eps=eps), d[tag + "sample"])
+
+
 def test_full_bench_batch_against_c_oracle(shipped_variables):
     """Every patch of a full configs[1] batch (1024) and a configs[2] batch (4096 eps-supplied
     samples) against the plain-C oracle (fp32, reference op order)."""

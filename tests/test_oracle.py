@@ -257,3 +257,30 @@ def test_conv1x1_decompositions_agree():
     z = rng.randn(1, 2, 2, 4)
     np.testing.assert_array_equal(O.conv1x1_inverse(z, layers[0]["A"], 0.0)[0], z[..., ::-1])
     assert [L["name"] for L in O.bind_variables("unc", O.fresh_variables("unc", flow_permutation=2), flow_permutation=2)] == ["unc_0"]
+
+
+def _variant_cases():
+    import json
+    d = np.load(os.path.join(GOLDEN_DIR, "arch_variants.npz"))
+    meta = json.loads(str(d["meta"]))
+    for i, m in enumerate(meta):
+        tag = "c%d_" % i
+        v = {k[len(tag) + 4:]: d[k] for k in d.files if k.startswith(tag + "var:")}
+        yield m, v, {k: d[tag + k] for k in ("x", "y", "eps", "nll", "sdz", "z", "sample")}
+
+
+def test_golden_arch_variants_freeze_the_oracle():
+    """tests/golden/arch_variants.npz (tools/make_golden_variants.py): every sdn / gain layer key and the other settings of
+    hps.flow_permutation / hps.decomp, 8x8 patches — the oracle still reproduces what it produced when they were committed."""
+    from oracle.nf_oracle import NoiseFlowOracle
+    n = 0
+    for m, v, t in _variant_cases():
+        o = NoiseFlowOracle(m["arch"], v, flow_permutation=m["flow_permutation"], decomp=m["decomp"])
+        assert [L["name"] for L in o.layers] == m["layer_names"]
+        nll, sd, z = o.nll(t["x"], t["y"], m["iso"], m["cam"])
+        np.testing.assert_allclose(nll, t["nll"], rtol=1e-12)
+        np.testing.assert_allclose(z, t["z"], rtol=0, atol=1e-12 * np.abs(t["z"]).max())
+        np.testing.assert_allclose(o.sample(t["eps"], 0.7, t["y"], m["iso"], m["cam"]), t["sample"], rtol=0,
+                                   atol=1e-12 * np.abs(t["sample"]).max())
+        n += 1
+    assert n == 7
