@@ -535,6 +535,8 @@ __global__ void k_c3_fwd(Geo g, const float *__restrict__ zin, const float *__re
     bn_from_slots<W>(stats2, g.nslot, n, bn2, P, off_m2, off_m2 + W, bn2_out);
     const float *W3 = P + off_w3, *b3 = W3 + 36 * (W + 1), *logs = b3 + 4;
     const float sc = logs[4];
+    const float e30 = expf(kLogscale * logs[0]), e31 = expf(kLogscale * logs[1]), e32 = expf(kLogscale * logs[2]),
+                e33 = expf(kLogscale * logs[3]);   // uniform: once per thread, not once per pixel
     float l = 0.0f;
     NF_PIXEL_LOOP(g, p) {
         if (p < g.npix) {
@@ -543,8 +545,8 @@ __global__ void k_c3_fwd(Geo g, const float *__restrict__ zin, const float *__re
             float u[4];
             l_last_u<W>(g, b, r, c, h2, bn2, W3, b3, u);
             const float4 zi = reinterpret_cast<const float4 *>(zin)[p];
-            const float sh0 = u[0] * expf(kLogscale * logs[0]), sh1 = u[1] * expf(kLogscale * logs[1]);
-            const float ls0 = sc * tanhf(u[2] * expf(kLogscale * logs[2])), ls1 = sc * tanhf(u[3] * expf(kLogscale * logs[3]));
+            const float sh0 = u[0] * e30, sh1 = u[1] * e31;
+            const float ls0 = sc * tanhf(u[2] * e32), ls1 = sc * tanhf(u[3] * e33);
             reinterpret_cast<float4 *>(zout)[p] = make_float4(zi.x, zi.y, fmaf(zi.z, expf(ls0), sh0), fmaf(zi.w, expf(ls1), sh1));
             l += ls0 + ls1;
         }
