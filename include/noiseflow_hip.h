@@ -224,9 +224,9 @@ int nf_sample_batchstats(nf_handle *h, const float *y, const float *eps, uint64_
  * slots and an activation workspace sized for `max_batch` patches; a step only enqueues kernels on
  * `stream` — and on an internal side stream forked from and joined back into it with events — with no
  * allocation and no host synchronisation.  One stream at a time per trainer.
- * Layers: CONV1X1, COUPLING (width 4/8/16/32), SDN5, SDN4, GAIN4 — every architecture of
- * job_noise_flow.sh; fp32 (nf_config.flags must be 0).
- * Trainable = everything except P / sign_S of CONV1X1, the BN statistics and c_i of SDN5. */
+ * Layers: every NF_LAYER_* above (COUPLING at width 4/8/16/32) — the whole vocabulary of noise_flow_arch under every
+ * setting of hps.flow_permutation / hps.decomp; fp32 (nf_config.flags must be 0).
+ * Trainable = everything except P / sign_S of CONV1X1 / CONV1X1_LU2, the BN statistics and c_i of SDN5 / SDN6. */
 typedef struct nf_trainer nf_trainer;
 #define NF_OPT_ADAM     0
 #define NF_OPT_MOMENTUM 1

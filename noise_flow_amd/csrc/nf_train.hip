@@ -45,7 +45,8 @@ struct Geo {
 };
 
 struct TLayer {
-    int type;    // NF_LAYER_*
+    int type;    // NF_LAYER_* of the KERNELS that run it: every 1x1-mix kind is CONV1X1, every sdn kind SDN5, every gain kind GAIN4
+    int kind;    // NF_LAYER_* as given: which parameterisation k_prep / k_finish evaluate
     int width;
     int off;     // offset of the layer's raw parameters (floats)
     int aux;     // index among the layers of the same type
@@ -261,14 +262,128 @@ __device__ void sdn5_eval(const float *sp, CondIdx ci, double &a, double &b)
     b = exp(c_i * (double)sp[1] * cp[1]);
 }
 
+// 4x4 inverse and log|det| by Gauss-Jordan with partial pivoting (decomp = NONE: tf.matrix_inverse / tf.linalg.slogdet)
+__device__ void inv4(const double M[4][4], double inv[4][4], double &lad)
+{
+    double a[4][8];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            a[i][j] = M[i][j];
+            a[i][4 + j] = i == j ? 1.0 : 0.0;
+        }
+    lad = 0.0;
+    for (int c = 0; c < 4; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < 4; ++r)
+            if (fabs(a[r][c]) > fabs(a[piv][c])) piv = r;
+        for (int j = 0; j < 8; ++j) {
+            const double t = a[piv][j];
+            a[piv][j] = a[c][j];
+            a[c][j] = t;
+        }
+        const double d = a[c][c];
+        lad += log(fabs(d));
+        for (int j = 0; j < 8; ++j) a[c][j] /= d;
+        for (int r = 0; r < 4; ++r) {
+            if (r == c) continue;
+            const double f = a[r][c];
+            for (int j = 0; j < 8; ++j) a[r][j] -= f * a[c][j];
+        }
+    }
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) inv[i][j] = a[i][4 + j];
+}
+
+// P, L, U of decomp = LU2 (matrix_param.py:143-188): full-matrix variables masked to their strict triangles
+__device__ void lu2_matrices(const float *p, double Pm[4][4], double L[4][4], double U[4][4])
+{
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            Pm[i][j] = p[i * 4 + j];
+            L[i][j] = j < i ? (double)p[16 + i * 4 + j] : (i == j ? 1.0 : 0.0);
+            U[i][j] = j > i ? (double)p[40 + i * 4 + j] : (i == j ? (double)p[32 + i] * exp((double)p[36 + i]) : 0.0);
+        }
+}
+
+__device__ __forceinline__ double sigm(double v) { return 1.0 / (1.0 + exp(-v)); }
+
+// the per-ISO tables of the Ex1-Ex3 layers: any ISO outside 100..3200 takes the ISO-800 entry (cond_utils.py:69-88)
+__device__ __forceinline__ int table_idx(CondIdx ci) { return ci.iso_idx >= 0 ? ci.iso_idx : 2; }
+
+// scale^2 = a y + b of every sdn kind (cond_utils.py:41-276)
+__device__ void sdn_ab(int kind, const float *p, CondIdx ci, double &a, double &b)
+{
+    const double iso = ci.iso;
+    if (kind == NF_LAYER_SDN5) {
+        sdn5_eval(p, ci, a, b);
+    } else if (kind == NF_LAYER_SDN4) {                                    // c = 1, no camera
+        const double gpar = ci.iso_idx >= 0 ? (double)p[2 + ci.iso_idx] : 0.0;
+        a = exp((double)p[0]) / (exp(gpar) * iso);
+        b = exp((double)p[1]);
+    } else if (kind == NF_LAYER_SDN) {
+        a = sigm(p[0]);
+        b = sigm(p[1]);
+    } else if (kind == NF_LAYER_SDN6) {                                    // one camera parameter, on the gain exponent
+        const double c = p[12], cp = exp(c * (double)p[7 + ci.cam_idx]);
+        const double g = ci.iso_idx >= 0 ? (double)p[2 + ci.iso_idx] : 0.0;
+        a = exp(c * (double)p[0]) / (exp(c * g * cp) * iso);
+        b = exp(c * (double)p[1]);
+    } else {                                                               // SDN1 / SDN2 / SDN3
+        const double gain = exp((kind == NF_LAYER_SDN1 ? 1e-2 : 1e-1) * (double)p[2 + table_idx(ci)]) * iso;
+        const double A0 = sigm(p[0]), B0 = sigm(p[1]);
+        if (kind == NF_LAYER_SDN1) { a = A0 / gain; b = B0; }
+        else if (kind == NF_LAYER_SDN2) { a = A0; b = gain * B0; }
+        else { a = gain * A0; b = gain * gain * B0; }
+    }
+}
+
+// scale of every gain kind and the number of log(scale) terms its log-det holds (cond_utils.py:319-440 and the layers:
+// GainEx4 / GainEx2 write the full H*W*C sum, Gain / GainEx1 / GainEx3 -log(scale) once per patch)
+__device__ void gain_s(int kind, const float *p, CondIdx ci, int HW, double &sv, double &K)
+{
+    const double iso = ci.iso;
+    K = 1.0;
+    if (kind == NF_LAYER_GAIN4) { sv = p[0]; K = 4.0 * HW; }
+    else if (kind == NF_LAYER_GAIN) sv = sigm(p[0]) * iso + sigm(p[1]);
+    else if (kind == NF_LAYER_GAIN1) sv = exp(1e-5 * (double)p[0]) * iso + exp(1e-5 * (double)p[1]);
+    else if (kind == NF_LAYER_GAIN2) { sv = exp(1e-1 * (double)p[table_idx(ci)]) * iso; K = 4.0 * HW; }
+    else sv = exp(1e-5 * (double)p[table_idx(ci)]);
+}
+
 __global__ void k_prep(TLayers ls, const float *__restrict__ P, CondIdx ci, int HW, float *__restrict__ Abuf,
-                       float *__restrict__ abbuf, double *__restrict__ ldc)
+                       float *__restrict__ abbuf, float *__restrict__ sbuf, double *__restrict__ ldc)
 {
     const int l = threadIdx.x;
     if (l >= ls.n) return;
     const TLayer L = ls.l[l];
     const float *p = P + L.off;
-    if (L.type == NF_LAYER_CONV1X1) {
+    if (L.kind == NF_LAYER_PERMUTE) {                                      // tfb.Permute(channels reversed), log|det| = 0
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) Abuf[L.aux * 16 + i * 4 + j] = (i + j == 3) ? 1.0f : 0.0f;
+    } else if (L.kind == NF_LAYER_CONV1X1_NONE) {
+        double M[4][4], Mi[4][4], lad;
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) {
+                M[i][j] = p[i * 4 + j];
+                Abuf[L.aux * 16 + i * 4 + j] = p[i * 4 + j];
+            }
+        inv4(M, Mi, lad);
+        atomicAdd(ldc, (double)HW * lad);
+    } else if (L.kind == NF_LAYER_CONV1X1_LU2) {
+        double Pm[4][4], Lm[4][4], Um[4][4];
+        lu2_matrices(p, Pm, Lm, Um);
+        double lad = 0.0;
+        for (int i = 0; i < 4; ++i) {
+            lad += (double)p[36 + i];
+            for (int j = 0; j < 4; ++j) {
+                double sacc = 0.0;
+                for (int k = 0; k < 4; ++k)
+                    for (int m = 0; m < 4; ++m) sacc += Pm[i][k] * Lm[k][m] * Um[m][j];
+                Abuf[L.aux * 16 + i * 4 + j] = (float)sacc;
+            }
+        }
+        atomicAdd(ldc, (double)HW * lad);
+    } else if (L.type == NF_LAYER_CONV1X1) {
         double Pm[4][4], Lm[4][4], Um[4][4], LU[4][4];
         plu_matrices(p, Pm, Lm, Um);
         for (int i = 0; i < 4; ++i)
@@ -289,15 +404,14 @@ __global__ void k_prep(TLayers ls, const float *__restrict__ P, CondIdx ci, int 
         atomicAdd(ldc, (double)HW * lad);                                  // layers.py:129-130
     } else if (L.type == NF_LAYER_SDN5) {
         double a, b;
-        sdn5_eval(p, ci, a, b);
+        sdn_ab(L.kind, p, ci, a, b);
         abbuf[L.aux * 2] = (float)a;
         abbuf[L.aux * 2 + 1] = (float)b;
-    } else if (L.type == NF_LAYER_SDN4) {                                  // cond_utils.py:178-202 (c = 1, no camera)
-        const double gpar = ci.iso_idx >= 0 ? (double)p[2 + ci.iso_idx] : 0.0;
-        abbuf[L.aux * 2] = (float)(exp((double)p[0]) / (exp(gpar) * (double)ci.iso));
-        abbuf[L.aux * 2 + 1] = (float)exp((double)p[1]);
     } else if (L.type == NF_LAYER_GAIN4) {
-        atomicAdd(ldc, -(double)HW * 4.0 * log((double)p[0]));             // AffineCouplingGainEx4.py:114-127
+        double sv, K;
+        gain_s(L.kind, p, ci, HW, sv, K);
+        sbuf[L.aux] = (float)sv;
+        atomicAdd(ldc, -K * log(sv));                                      // AffineCouplingGainEx4.py:114-127 and siblings
     }
 }
 
@@ -1028,7 +1142,38 @@ __global__ void k_finish(TLayers ls, const float *__restrict__ P, CondIdx ci, in
     const TLayer L = ls.l[l];
     const float *p = P + L.off;
     double *gp = G + L.off;
-    if (L.type == NF_LAYER_CONV1X1) {
+    if (L.kind == NF_LAYER_PERMUTE) {
+        // no parameters
+    } else if (L.kind == NF_LAYER_CONV1X1_NONE) {                          // A is the variable: dA - H W A^-T
+        double M[4][4], Mi[4][4], lad;
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) M[i][j] = p[i * 4 + j];
+        inv4(M, Mi, lad);
+        const double *dA = dAbuf + L.aux * 16;
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) gp[i * 4 + j] = dA[i * 4 + j] - (double)HW * Mi[j][i];
+    } else if (L.kind == NF_LAYER_CONV1X1_LU2) {
+        double Pm[4][4], Lm[4][4], Um[4][4], dM[4][4];
+        lu2_matrices(p, Pm, Lm, Um);
+        const double *dA = dAbuf + L.aux * 16;
+        for (int i = 0; i < 4; ++i)          // dM = P^T dA   (A = P M, M = L U)
+            for (int j = 0; j < 4; ++j) {
+                double sacc = 0.0;
+                for (int k = 0; k < 4; ++k) sacc += Pm[k][i] * dA[k * 4 + j];
+                dM[i][j] = sacc;
+            }
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) {
+                double dl = 0.0, du = 0.0;
+                for (int k = 0; k < 4; ++k) {
+                    dl += dM[i][k] * Um[j][k];   // dL = dM U^T
+                    du += Lm[k][i] * dM[k][j];   // dU = L^T dM
+                }
+                gp[16 + i * 4 + j] = j < i ? dl : 0.0;                     // the mask of matrix_param.py:171-173
+                gp[40 + i * 4 + j] = j > i ? du : 0.0;
+                if (i == j) gp[36 + i] = du * Um[i][i] - (double)HW;       // log_S: diagonal + log-det term
+            }
+    } else if (L.type == NF_LAYER_CONV1X1) {
         double Pm[4][4], Lm[4][4], Um[4][4], dM[4][4], dL[4][4], dU[4][4];
         plu_matrices(p, Pm, Lm, Um);
         const double *dA = dAbuf + L.aux * 16;
@@ -1053,7 +1198,54 @@ __global__ void k_finish(TLayers ls, const float *__restrict__ P, CondIdx ci, in
             gp[24 + k] = dL[kLr[k]][kLc[k]];
             gp[30 + k] = dU[kUr[k]][kUc[k]];
         }
-    } else if (L.type == NF_LAYER_SDN5) {
+    } else if (L.kind == NF_LAYER_SDN || L.kind == NF_LAYER_SDN1 || L.kind == NF_LAYER_SDN2 || L.kind == NF_LAYER_SDN3 ||
+               L.kind == NF_LAYER_SDN6) {
+        double a, b;
+        sdn_ab(L.kind, p, ci, a, b);
+        const double ga = dabbuf[L.aux * 2], gb = dabbuf[L.aux * 2 + 1];
+        if (L.kind == NF_LAYER_SDN6) {
+            const double c = p[12], cp = exp(c * (double)p[7 + ci.cam_idx]);
+            const double g = ci.iso_idx >= 0 ? (double)p[2 + ci.iso_idx] : 0.0;
+            gp[0] = ga * a * c;
+            gp[1] = gb * b * c;
+            if (ci.iso_idx >= 0) gp[2 + ci.iso_idx] = -ga * a * c * cp;
+            gp[7 + ci.cam_idx] = -ga * a * c * c * g * cp;
+        } else {
+            const double A0 = sigm(p[0]), B0 = sigm(p[1]), dA0 = A0 * (1.0 - A0), dB0 = B0 * (1.0 - B0);
+            const int k = 2 + table_idx(ci);
+            if (L.kind == NF_LAYER_SDN) {
+                gp[0] = ga * dA0;
+                gp[1] = gb * dB0;
+            } else if (L.kind == NF_LAYER_SDN1) {                          // a = A0 / gain, b = B0, gain = exp(1e-2 t) iso
+                gp[0] = ga * a * (1.0 - A0);
+                gp[1] = gb * dB0;
+                gp[k] = -ga * a * 1e-2;
+            } else if (L.kind == NF_LAYER_SDN2) {                          // a = A0, b = gain B0, gain = exp(1e-1 t) iso
+                gp[0] = ga * dA0;
+                gp[1] = gb * b * (1.0 - B0);
+                gp[k] = gb * b * 1e-1;
+            } else {                                                       // SDN3: a = gain A0, b = gain^2 B0
+                gp[0] = ga * a * (1.0 - A0);
+                gp[1] = gb * b * (1.0 - B0);
+                gp[k] = (ga * a + 2.0 * gb * b) * 1e-1;
+            }
+        }
+    } else if (L.kind == NF_LAYER_GAIN || L.kind == NF_LAYER_GAIN1 || L.kind == NF_LAYER_GAIN2 || L.kind == NF_LAYER_GAIN3) {
+        double sv, K;
+        gain_s(L.kind, p, ci, HW, sv, K);
+        const double gs = dgbuf[L.aux] + K / sv;                            // data path + the log-det term
+        const double iso = ci.iso;
+        if (L.kind == NF_LAYER_GAIN) {
+            const double A0 = sigm(p[0]), B0 = sigm(p[1]);
+            gp[0] = gs * iso * A0 * (1.0 - A0);
+            gp[1] = gs * B0 * (1.0 - B0);
+        } else if (L.kind == NF_LAYER_GAIN1) {
+            gp[0] = gs * iso * exp(1e-5 * (double)p[0]) * 1e-5;
+            gp[1] = gs * exp(1e-5 * (double)p[1]) * 1e-5;
+        } else {
+            gp[table_idx(ci)] = gs * sv * (L.kind == NF_LAYER_GAIN2 ? 1e-1 : 1e-5);
+        }
+    } else if (L.kind == NF_LAYER_SDN5) {
         double a, b;
         sdn5_eval(p, ci, a, b);
         const double ga = dabbuf[L.aux * 2], gb = dabbuf[L.aux * 2 + 1];
@@ -1068,14 +1260,14 @@ __global__ void k_finish(TLayers ls, const float *__restrict__ P, CondIdx ci, in
         gp[7 + 0 * 5 + ci.cam_idx] = ga * a * c_i * c_i * beta1 * cp[0];
         gp[7 + 1 * 5 + ci.cam_idx] = gb * b * c_i * c_i * beta2 * cp[1];
         gp[7 + 2 * 5 + ci.cam_idx] = -ga * a * c_i * c_i * gpar * cp[2];
-    } else if (L.type == NF_LAYER_SDN4) {
+    } else if (L.kind == NF_LAYER_SDN4) {
         const double gpar = ci.iso_idx >= 0 ? (double)p[2 + ci.iso_idx] : 0.0;
         const double a = exp((double)p[0]) / (exp(gpar) * (double)ci.iso), b = exp((double)p[1]);
         const double ga = dabbuf[L.aux * 2], gb = dabbuf[L.aux * 2 + 1];
         gp[0] = ga * a;
         gp[1] = gb * b;
         if (ci.iso_idx >= 0) gp[2 + ci.iso_idx] = -ga * a;
-    } else if (L.type == NF_LAYER_GAIN4) {
+    } else if (L.kind == NF_LAYER_GAIN4) {
         gp[0] = dgbuf[L.aux] + (double)HW * 4.0 / (double)p[0];
     }
 }
@@ -1141,7 +1333,7 @@ struct nf_trainer {
     int d_dA = 0, d_dab = 0, d_dg = 0, d_ld0 = 0, d_ldc = 0;
     float *d_flt = nullptr;         // A matrices, sdn5 (a,b), BN scalars
     size_t n_flt = 0;
-    int f_A = 0, f_ab = 0;
+    int f_A = 0, f_ab = 0, f_s = 0;
     float *d_patch = nullptr;       // ld[B], s1[B], s2[B]
     std::vector<float *> zs;        // zs[l] = input of layer l (zs[0] is the caller's x), zs[n] = latent
     // backward temporaries, double-buffered by coupling parity: the filter-gradient kernels of one
@@ -1152,7 +1344,8 @@ struct nf_trainer {
     bool done_pending[2] = {false, false};
     std::vector<void *> owned;
     bool has_sdn = false;
-    bool needs_cam = false;         // an SDN5 layer is present: the camera id must be one of 0..4
+    bool needs_cam = false;         // an SDN5 / SDN6 layer is present: the camera id must be one of 0..4
+    bool needs_cond = false;        // a gain layer that reads the ISO is present: cond must be given
     // cross-rank batch normalisation (nf_trainer_set_sync)
     nf_allreduce_fn sync_fn = nullptr;
     void *sync_user = nullptr;
@@ -1363,6 +1556,7 @@ int nf_trainer_create(const nf_config *cfg, const nf_layer_desc *layers, const f
         }
         TLayer &T = t->tl.l[i];
         T.type = L.type;
+        T.kind = L.type;
         T.width = L.width;
         T.off = (int)L.param_offset;
         uint8_t *mk = mask.data() + L.param_offset;
@@ -1394,6 +1588,7 @@ int nf_trainer_create(const nf_config *cfg, const nf_layer_desc *layers, const f
             t->needs_cam = true;
             break;
         case NF_LAYER_SDN4:
+            T.type = NF_LAYER_SDN5;
             T.aux = n_sdn++;
             for (int k = 0; k < 7; ++k) mk[k] = 1;
             t->has_sdn = true;
@@ -1402,9 +1597,45 @@ int nf_trainer_create(const nf_config *cfg, const nf_layer_desc *layers, const f
             T.aux = n_gain++;
             mk[0] = 1;
             break;
+        // the other parameterisations run on the same kernels (TLayer::type) and differ in k_prep / k_finish (TLayer::kind)
+        case NF_LAYER_CONV1X1_NONE:
+            T.type = NF_LAYER_CONV1X1;
+            T.aux = n_mix++;
+            for (int k = 0; k < 16; ++k) mk[k] = 1;
+            break;
+        case NF_LAYER_CONV1X1_LU2:
+            T.type = NF_LAYER_CONV1X1;
+            T.aux = n_mix++;
+            for (int k = 16; k < 32; ++k) mk[k] = 1;   // L (P, sign_S are constants)
+            for (int k = 36; k < 56; ++k) mk[k] = 1;   // log_S, U
+            break;
+        case NF_LAYER_PERMUTE:
+            T.type = NF_LAYER_CONV1X1;
+            T.aux = n_mix++;
+            break;
+        case NF_LAYER_SDN:
+        case NF_LAYER_SDN1:
+        case NF_LAYER_SDN2:
+        case NF_LAYER_SDN3:
+        case NF_LAYER_SDN6:
+            T.type = NF_LAYER_SDN5;
+            T.aux = n_sdn++;
+            for (int64_t k = 0; k < (L.type == NF_LAYER_SDN6 ? 12 : cnt); ++k) mk[k] = 1;   // SDN6: c_i is a constant
+            t->has_sdn = true;
+            if (L.type == NF_LAYER_SDN6) t->needs_cam = true;
+            break;
+        case NF_LAYER_GAIN:
+        case NF_LAYER_GAIN1:
+        case NF_LAYER_GAIN2:
+        case NF_LAYER_GAIN3:
+            T.type = NF_LAYER_GAIN4;
+            T.aux = n_gain++;
+            for (int64_t k = 0; k < cnt; ++k) mk[k] = 1;
+            t->needs_cond = true;
+            break;
         default:
             delete t;
-            return nf_fail(NF_EINVAL, "layer %d: training covers CONV1X1, COUPLING, SDN5, SDN4 and GAIN4 layers (type %d given)", i, L.type);
+            return nf_fail(NF_EINVAL, "layer %d: unknown layer type %d", i, L.type);
         }
     }
 
@@ -1443,6 +1674,7 @@ int nf_trainer_create(const nf_config *cfg, const nf_layer_desc *layers, const f
     size_t nf = 0;
     t->f_A = (int)nf; nf += 16 * (size_t)n_mix;
     t->f_ab = (int)nf; nf += 2 * (size_t)n_sdn;
+    t->f_s = (int)nf; nf += (size_t)n_gain;
     for (Cpl &c : t->cpl) {
         c.f_bn1 = (int)nf; nf += 2 * w;
         c.f_bn2 = (int)nf; nf += 2 * w;
@@ -1526,7 +1758,7 @@ static int trainer_run(nf_trainer *t, const float *x, const float *y, int64_t B,
     if (!x) return nf_fail(NF_EINVAL, "x is NULL");
     if (t->has_sdn && !y) return nf_fail(NF_EINVAL, "model has a signal-dependent layer but y is NULL");
     CondIdx ci;
-    int rc = cond_index(cond, t->has_sdn, t->needs_cam, ci);
+    int rc = cond_index(cond, t->has_sdn || t->needs_cond, t->needs_cam, ci);
     if (rc != NF_OK) return rc;
     Guard guard;
     if ((rc = guard.enter(t->device)) != NF_OK) return rc;
@@ -1551,7 +1783,7 @@ static int trainer_run(nf_trainer *t, const float *x, const float *y, int64_t B,
     float *s1 = t->d_patch, *s2 = s1 + t->max_batch;
     double *G = t->d_dbl;
 
-    hipLaunchKernelGGL(k_prep, dim3(1), dim3(64), 0, st, t->tl, t->d_params, ci, g.HW, t->d_flt + t->f_A, t->d_flt + t->f_ab,
+    hipLaunchKernelGGL(k_prep, dim3(1), dim3(64), 0, st, t->tl, t->d_params, ci, g.HW, t->d_flt + t->f_A, t->d_flt + t->f_ab, t->d_flt + t->f_s,
                        G + t->d_ldc);
     // ---- forward ----
     t->zs[0] = const_cast<float *>(x);
@@ -1565,7 +1797,7 @@ static int trainer_run(nf_trainer *t, const float *x, const float *y, int64_t B,
             hipLaunchKernelGGL(k_sdn_fwd, dim3(nb), dim3(TB), 0, st, g, zin, y, t->d_flt + t->f_ab + 2 * L.aux, zout, t->acc(t->d_ld0 + l));
             break;
         case NF_LAYER_GAIN4:
-            hipLaunchKernelGGL(k_scale_fwd, dim3(nb), dim3(TB), 0, st, g, zin, t->d_params + L.off, zout);
+            hipLaunchKernelGGL(k_scale_fwd, dim3(nb), dim3(TB), 0, st, g, zin, t->d_flt + t->f_s + L.aux, zout);
             break;
         case NF_LAYER_CONV1X1:
             if (l + 1 < n && t->tl.l[l + 1].type == NF_LAYER_COUPLING) break;   // folded into the coupling's l_1 kernel
@@ -1603,7 +1835,7 @@ static int trainer_run(nf_trainer *t, const float *x, const float *y, int64_t B,
                                t->acc(t->d_dab + 2 * L.aux));
             break;
         case NF_LAYER_GAIN4:
-            hipLaunchKernelGGL(k_scale_bwd, dim3(nb), dim3(TB), 0, st, g, t->zs[l + 1], t->d_params + L.off, t->dz,
+            hipLaunchKernelGGL(k_scale_bwd, dim3(nb), dim3(TB), 0, st, g, t->zs[l + 1], t->d_flt + t->f_s + L.aux, t->dz,
                                t->acc(t->d_dg + L.aux));
             break;
         case NF_LAYER_CONV1X1:

@@ -44,13 +44,12 @@ class Trainer:
         self.width = int(getattr(hps, "width", 4))
         self.binding = binding
         self._dev = _Dev(device)
-        if int(getattr(hps, "flow_permutation", 1)) != 1 or str(getattr(hps, "decomp", "LU")) != "LU":
-            raise NotImplementedError("the training step covers the shipped parameterisation (flow_permutation = 1, decomp = 'LU'); "
-                                      "the other settings are served by the likelihood / sampling paths only")
+        self.flow_permutation = int(getattr(hps, "flow_permutation", 1))
+        self.decomp = str(getattr(hps, "decomp", "LU"))
         seed = int(getattr(hps, "seed", 0) or 0)
         self._variables = dict(variables) if variables is not None else _params.init_variables(
-            self.arch, self.width, self.x_shape[-1], seed)
-        self.layers = _params.parse_arch(self.arch)
+            self.arch, self.width, self.x_shape[-1], seed, self.flow_permutation, self.decomp)
+        self.layers = _params.parse_arch(self.arch, self.flow_permutation, self.decomp)
         self._tmpl = _params.template_binding(self.layers, binding)
         self.layers, descs, flat = _params.pack_layers(self.layers, self._variables, self.width, self._tmpl)
         self.n_params = int(flat.size)
@@ -69,7 +68,7 @@ class Trainer:
         torch = self._dev.torch
         self._grads = torch.zeros((self.n_params,), dtype=torch.float32, device=self._dev.device)
         self._loss = torch.zeros((2,), dtype=torch.float32, device=self._dev.device)
-        self.has_sdn = any(L.kind in ("sdn5", "sdn4") for L in self.layers)
+        self.has_sdn = any(L.kind.startswith("sdn") for L in self.layers)
         # Variables shared by several layers (the reference's AUTO_REUSE scope 'sdn_gain': arch "gain4|...|gain4" has ONE
         # gain_val, "sdn5|...|sdn5" one beta1 / beta2 / gain_params / cam_params) hold one slot PER LAYER in the raw layout.
         # Their gradient is the sum over the slots; every slot gets that sum, so the copies stay identical under the update.

@@ -38,6 +38,8 @@ LOGSCALE_FACTOR = O.LOGSCALE_FACTOR
 def is_trainable(name: str) -> bool:
     """train_noise_flow.py:309-312 / tf.trainable_variables(): P and sign_S are created with
     trainable=False (matrix_param.py:113-118), BN statistics too (layers.py:380-385)."""
+    if "/P_conv2d_1x1" in name or "/sign_S_conv2d_1x1" in name:       # decomp = LU2 (matrix_param.py:151-157)
+        return False
     return not ("/P_matpar" in name or "/sign_S_matpar" in name or name.endswith("/mean") or name.endswith("/var"))
 
 
@@ -55,9 +57,12 @@ def _tri_positions(n: int, upper: bool):
 
 
 class GradOracle:
-    def __init__(self, arch: str, variables: Dict[str, np.ndarray], binding: str = "loss_first", c_i: float = 1.0):
+    def __init__(self, arch: str, variables: Dict[str, np.ndarray], binding: str = "loss_first", c_i: float = 1.0,
+                 flow_permutation: int = 1, decomp: str = "LU"):
         self.arch = arch
         self.binding = binding
+        self.flow_permutation = int(flow_permutation)
+        self.decomp = decomp
         self.c_i = float(c_i)
         self.names = list(variables.keys())
         self.shapes = {k: np.asarray(v).shape for k, v in variables.items()}
@@ -71,6 +76,25 @@ class GradOracle:
 
     # -- pieces -----------------------------------------------------------------------------
     def _A(self, i):
+        """(A, log|det A|) of the mixing layer in front of coupling i for hps.flow_permutation / hps.decomp, or None."""
+        if self.flow_permutation == 0:                                    # tfb.Permute(channels reversed)
+            return torch.flip(torch.eye(4, dtype=torch.float64), dims=[1]), torch.zeros((), dtype=torch.float64)
+        if self.flow_permutation != 1:
+            return None
+        n = O.conv1x1_variable_names(i, self.decomp)
+        if self.decomp == "NONE":                                         # matrix_param.py:23-29
+            A = self.t[n["A"]]
+            return A, torch.linalg.slogdet(A)[1]
+        if self.decomp == "LU2":                                          # matrix_param.py:143-188
+            P, L, U = self.t[n["P"]], self.t[n["L"]], self.t[n["U"]]
+            sgn, logS = self.t[n["sign_S"]].reshape(-1), self.t[n["log_S"]].reshape(-1)
+            mask = torch.tril(torch.ones(4, 4, dtype=torch.float64), -1)
+            Lm = L * mask + torch.eye(4, dtype=torch.float64)
+            Um = U * mask.t() + torch.diag(sgn * torch.exp(logS))
+            return P @ (Lm @ Um), logS.sum()
+        return self._A_lu(i)
+
+    def _A_lu(self, i):
         pre = "level0/bijector%d/Conv2d_1x1_%d/" % (i, i)
         sfx = "_matpar_lu_conv2d_1x1_%d_0" % i
         P, sgn, logS = self.t[pre + "P" + sfx], self.t[pre + "sign_S" + sfx], self.t[pre + "log_S" + sfx]
@@ -125,6 +149,46 @@ class GradOracle:
         b2 = torch.exp(c * self.t["model/sdn_gain/beta2"].reshape(-1)[0] * cp[1])
         return torch.sqrt(b1 * y / gain + b2)
 
+    def _table(self, fmt, iso):
+        """Entry of a per-ISO variable table: ISO 100..3200, anything else -> the ISO-800 entry (cond_utils.py:69-88)."""
+        iso = int(iso) if float(iso) in [float(v) for v in O.ISO_TABLE] else 800
+        return self.t[fmt % iso].reshape(-1)[0]
+
+    def _sdn_other_scale(self, kind, y, iso, cam):
+        """sdn_model_params / _ex1 / _ex2 / _ex3 / _ex6 (cond_utils.py:41-175, 242-276) in torch."""
+        if kind == "sdn6":
+            c = self.c_i
+            if float(cam) not in (0.0, 1.0, 2.0, 3.0, 4.0):
+                raise IndexError("unknown camera id %r" % (cam,))
+            cp = torch.exp(c * self.t["model/sdn_gain/cam_params"].reshape(-1)[int(cam)])
+            ks = [k for k, v in enumerate(O.ISO_VALS) if float(v) == float(iso)]
+            g = self.t["model/sdn_gain/gain_params"].reshape(-1)[ks[0]] if ks else torch.zeros((), dtype=torch.float64)
+            gain = torch.exp(c * g * cp) * float(iso)
+            b1 = torch.exp(c * self.t["model/sdn_gain/beta1"].reshape(-1)[0])
+            b2 = torch.exp(c * self.t["model/sdn_gain/beta2"].reshape(-1)[0])
+            return torch.sqrt(b1 * y / gain + b2)
+        b1 = torch.sigmoid(self.t["model/b1"].reshape(-1)[0])
+        b2 = torch.sigmoid(self.t["model/b2"].reshape(-1)[0])
+        if kind == "sdn":
+            return torch.sqrt(b1 * y + b2)
+        if kind == "sdn1":
+            gain = torch.exp(1e-2 * self._table("model/r_gain_param_%05d", iso)) * float(iso)
+            return torch.sqrt(b1 * y / gain + b2)
+        gain = torch.exp(1e-1 * self._table("model/gain_param_%05d", iso)) * float(iso)
+        if kind == "sdn2":
+            return torch.sqrt(gain * (b1 * y / gain + b2))
+        return gain * torch.sqrt(b1 * y / gain + b2)
+
+    def _gain_other_scale(self, kind, iso):
+        """gain_model_params / _ex1 / _ex2 / _ex3 (cond_utils.py:319-429) -> (scale, log-det over the whole patch?)."""
+        if kind == "gain":
+            return torch.sigmoid(self.t["model/g1"].reshape(-1)[0]) * float(iso) + torch.sigmoid(self.t["model/g2"].reshape(-1)[0]), False
+        if kind == "gain1":
+            return torch.exp(1e-5 * self.t["model/g1"].reshape(-1)[0]) * float(iso) + torch.exp(1e-5 * self.t["model/g2"].reshape(-1)[0]), False
+        if kind == "gain2":
+            return torch.exp(1e-1 * self._table("model/gain_param_%05d", iso)) * float(iso), True
+        return torch.exp(1e-5 * self._table("model/gain_param_%05d", iso)), False
+
     # -- the step's forward -----------------------------------------------------------------
     def forward(self, x, y, iso, cam) -> Tuple[torch.Tensor, torch.Tensor, Dict[str, np.ndarray]]:
         """→ (loss, sd_z, new running statistics)."""
@@ -135,9 +199,11 @@ class GradOracle:
         new_running: Dict[str, np.ndarray] = {}
         for lyr, i in self.arch_l:
             if lyr == "unc":
-                A, lad = self._A(i)
-                z = torch.einsum("bchw,ck->bkhw", z, A)                   # layers.py:117-130
-                obj = obj + H * W * lad
+                mix = self._A(i)
+                if mix is not None:
+                    A, lad = mix
+                    z = torch.einsum("bchw,ck->bkhw", z, A)               # layers.py:117-130
+                    obj = obj + H * W * lad
                 c2 = C // 2
                 z0, z1 = z[:, :c2], z[:, c2:]
                 shift, raw = self._cnn(z0, i, new_running)
@@ -160,8 +226,16 @@ class GradOracle:
                 g = self.t["model/sdn_gain/gain_val"].reshape(-1)[0]
                 z = z / g
                 obj = obj - C * H * W * torch.log(g)
+            elif lyr in ("sdn", "sdn1", "sdn2", "sdn3", "sdn6"):
+                scale = self._sdn_other_scale(lyr, yt, iso, cam)
+                z = z / scale
+                obj = obj - torch.log(scale).sum(dim=(1, 2, 3))
+            elif lyr in ("gain", "gain1", "gain2", "gain3"):
+                s, full = self._gain_other_scale(lyr, iso)
+                z = z / s
+                obj = obj - (C * H * W if full else 1) * torch.log(s)     # GainEx2: the full sum; Gain / Ex1 / Ex3: once per patch
             else:
-                raise ValueError("the training oracle covers unc|sdn5|sdn4|gain4, got %r" % lyr)
+                raise ValueError("unknown layer %r" % lyr)
         logp = (-0.5 * (np.log(2 * np.pi) + z * z)).sum(dim=(1, 2, 3))
         nll = -(obj + logp)
         sd_z = torch.sqrt(z.var(dim=(1, 2, 3), unbiased=False)).mean()

@@ -105,3 +105,40 @@ def test_training_golden_fixture_matches_the_oracle(shipped_variables):
     after = adam_step(shipped_variables, grads, {}, float(g["lr"]))
     for k in grads:
         np.testing.assert_allclose(np.asarray(after[k], np.float32), g["adam/" + k], rtol=1e-6, atol=1e-9)
+
+
+def test_autograd_oracle_covers_the_whole_vocabulary_and_every_permutation_setting():
+    """The rest of ``noise_flow_arch``'s layer keys and the other ``hps.flow_permutation`` / ``hps.decomp`` settings in the
+    autograd oracle: the forward value equals the numpy forward oracle's (training-mode BN) and a sample of gradient entries
+    equals central finite differences of it — which is what pins the gradients the trainer is held to."""
+    import json
+    import os
+    from conftest import GOLDEN_DIR
+    from oracle.nf_oracle import NoiseFlowOracle
+    from oracle.nf_grad_oracle import GradOracle, is_trainable
+    d = np.load(os.path.join(GOLDEN_DIR, "arch_variants.npz"))
+    meta = json.loads(str(d["meta"]))
+    rng = np.random.RandomState(1)
+    for i, m in enumerate(meta):
+        tag = "c%d_" % i
+        v = {k[len(tag) + 4:]: d[k] for k in d.files if k.startswith(tag + "var:")}
+        x, y = d[tag + "x"], d[tag + "y"]
+        kw = dict(flow_permutation=m["flow_permutation"], decomp=m["decomp"])
+        f = lambda vv: NoiseFlowOracle(m["arch"], vv, **kw).nll(x, y, m["iso"], m["cam"], training=True)[0].mean()
+        loss, _, grads, _ = GradOracle(m["arch"], v, **kw).loss_and_grads(x, y, m["iso"], m["cam"])
+        assert abs(loss - f(v)) <= 1e-11 * abs(loss), m["arch"]
+        gmax = max(np.abs(g).max() for g in grads.values())
+        names = [k for k in sorted(v) if is_trainable(k) and k in grads and not ("real_nvp_conv_template" in k)]
+        assert names, m["arch"]
+        for k in names:                                  # every scalar-layer / mixing-layer variable, one entry each
+            a = np.asarray(v[k], np.float64)
+            nz = np.argwhere(np.abs(grads[k]) > 0)
+            idx = tuple(nz[rng.randint(len(nz))]) if len(nz) else tuple(0 for _ in a.shape)
+            h = 1e-6 * max(1.0, abs(float(a[idx])))
+            vp, vm = dict(v), dict(v)
+            ap, am = a.copy(), a.copy()
+            ap[idx] += h
+            am[idx] -= h
+            vp[k], vm[k] = ap, am
+            fd = (f(vp) - f(vm)) / (2 * h)
+            assert abs(fd - grads[k][idx]) <= 2e-5 * max(abs(fd), 1e-6 * gmax), (m["arch"], k, fd, grads[k][idx])
