@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--logdir", required=True)
     ap.add_argument("--arch", default="sdn5|unc|unc|unc|unc|gain4|unc|unc|unc|unc")
     ap.add_argument("--width", type=int, default=4)
+    ap.add_argument("--flow_permutation", type=int, default=1)      # sidd/ArgParser.py: 1 = Conv2d1x1, 0 = tfb.Permute, else none
+    ap.add_argument("--decomp", default="LU", choices=["LU", "LU2", "NONE"])
     ap.add_argument("--epochs", type=int, default=20)
     ap.add_argument("--lr", type=float, default=1e-4)                # job_noise_flow.sh:37
     ap.add_argument("--optim", default="adam", choices=["adam", "sgd"])
@@ -65,7 +67,8 @@ def main():
         dist.init_process_group("nccl")
         group = True
 
-    hps = default_hps(arch=args.arch, width=args.width, seed=args.seed, optim=args.optim, lr=args.lr,
+    hps = default_hps(arch=args.arch, width=args.width, flow_permutation=args.flow_permutation, decomp=args.decomp, seed=args.seed,
+                      optim=args.optim, lr=args.lr,
                       n_batch_train=args.n_batch_train, n_batch_test=args.n_batch_test, epochs=args.epochs)
     variables = load_checkpoint(args.init) if args.init else None
     trainer = Trainer([32, 32, 4], hps, variables=variables, max_batch=max(args.n_batch_train, 1))
