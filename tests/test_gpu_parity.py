@@ -686,6 +686,39 @@ def test_golden_arch_variants():
         _close_elem(nf.sample(y, 0.7, y, [0.0], [0.0], [m["iso"]], [m["cam"]], eps=eps), d[tag + "sample"])
 
 
+def test_per_layer_bijectors_of_the_other_settings():
+    """The per-bijector operator surface (noise_flow_amd/layers.py) for the architectures of tests/golden/arch_variants.npz:
+    tfb.Permute, Conv2d1x1 under decomp NONE / LU2, every sdn / gain key — each bijector alone against the oracle's layer."""
+    import json
+    import os
+    from conftest import GOLDEN_DIR
+    from noise_flow_amd.layers import bijectors_from_arch
+    from oracle.nf_oracle import NoiseFlowOracle
+    d = np.load(os.path.join(GOLDEN_DIR, "arch_variants.npz"))
+    meta = json.loads(str(d["meta"]))
+    for i, m in enumerate(meta):
+        tag = "c%d_" % i
+        v = {k[len(tag) + 4:]: d[k] for k in d.files if k.startswith(tag + "var:")}
+        x, y = d[tag + "x"], d[tag + "y"]
+        o = NoiseFlowOracle(m["arch"], v, flow_permutation=m["flow_permutation"], decomp=m["decomp"])
+        _, _, per_layer = o.inverse(x, y, m["iso"], m["cam"], return_layers=True)
+        bij = bijectors_from_arch(m["arch"], v, (8, 8, 4), 4, flow_permutation=m["flow_permutation"], decomp=m["decomp"])
+        assert [b.name for b in bij] == [n for n, _, _ in per_layer] == m["layer_names"]
+        z = x.astype(np.float64)
+        for b, (name, ref_z, ref_ld) in zip(bij, per_layer):
+            zin = z.astype(np.float32)
+            if b.conditional:
+                out, ld = b._inverse_and_log_det_jacobian(zin, y, [0.0], [0.0], [m["iso"]], [m["cam"]])
+                back = b._forward(np.asarray(ref_z, np.float32), y, [0.0], [0.0], [m["iso"]], [m["cam"]])
+            else:
+                out, ld = b._inverse_and_log_det_jacobian(zin)
+                back = b._forward(np.asarray(ref_z, np.float32))
+            _close_elem(out, ref_z)
+            np.testing.assert_allclose(ld, ref_ld, rtol=1e-5, atol=1e-3, err_msg="%s %s" % (m["arch"], name))
+            _close_elem(back, z, rtol=1e-4)      # the input of this direction is the float32-ROUNDED oracle output
+            z = ref_z
+
+
 def test_full_bench_batch_against_c_oracle(shipped_variables):
     """Every patch of a full configs[1] batch (1024) and a configs[2] batch (4096 eps-supplied
     samples) against the plain-C oracle (fp32, reference op order)."""
