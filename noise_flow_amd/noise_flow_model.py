@@ -402,8 +402,29 @@ class NoiseFlow(object):
         Without it ε is generated in-kernel (Philox4x32-10 keyed by ``seed``, a
         running patch counter and the pixel index)."""
         self._check_mode()
-        temp = 1.0 if eps_std is None else _first(eps_std)
         cond = self._cond(nlf0, nlf1, iso, cam)
+        tv = None if eps_std is None else np.asarray(eps_std.detach().cpu() if hasattr(eps_std, "detach") else eps_std,
+                                                     np.float32).reshape(-1)
+        if tv is not None and tv.size > 1 and not np.all(tv == tv[0]):
+            # one temperature PER PATCH (the reference reshapes eps_std to [-1,1,1,1], noise_flow_model.py:501): the draw is
+            # scaled patch by patch here and the kernel runs at temperature 1
+            torch = self._dev.torch
+            B = int(np.shape(y)[0])
+            if tv.size != B:
+                raise ValueError("eps_std holds %d temperatures for %d patches" % (tv.size, B))
+            as_np = eps is not None and not isinstance(eps, torch.Tensor) or eps is None and not isinstance(y, torch.Tensor)
+            if eps is None:
+                gen = torch.Generator(device=self._dev.device)
+                with self._lock:
+                    gen.manual_seed(int(self._seed if seed is None else seed) * 1000003 + self._draws)
+                    self._draws += B
+                e = torch.randn((B,) + tuple(self.x_shape), generator=gen, device=self._dev.device, dtype=torch.float32)
+            else:
+                e = self._dev.to_dev(eps, tuple(self.x_shape))[0]
+            e = e * torch.as_tensor(tv, device=self._dev.device).reshape(-1, 1, 1, 1)
+            out = self._run_sample(e, 1.0, yy, cond, z_is_eps=True)
+            return self._dev.back(out, True) if as_np and isinstance(out, torch.Tensor) else out
+        temp = 1.0 if tv is None else float(tv[0])
         if eps is not None:
             return self._run_sample(eps, temp, yy, cond, z_is_eps=True)
         return self._run_sample(y, temp, yy, cond, z_is_eps=False, seed=seed)

@@ -719,6 +719,23 @@ def test_per_layer_bijectors_of_the_other_settings():
             z = ref_z
 
 
+def test_one_sampling_temperature_per_patch(shipped_variables, oracle_full):
+    """``prior.sample(eps_std)`` reshapes eps_std to [-1,1,1,1] (noise_flow_model.py:499-504): a vector gives every patch its own
+    temperature.  With a supplied epsilon: patch b equals the oracle at temp[b]; without: a fresh N(0,1) draw, finite."""
+    _, y = make_inputs(5, seed=31)
+    eps = np.random.RandomState(8).randn(5, 32, 32, 4).astype(np.float32)
+    temps = np.asarray([1.0, 0.6, 0.3, 0.9, 0.6], np.float32)
+    m = _model(FULL_ARCH, shipped_variables)
+    xs = m.sample(y, temps, y, [0.0], [0.0], [400], [1], eps=eps)
+    assert isinstance(xs, np.ndarray)
+    for b in range(5):
+        _close_elem(xs[b:b + 1], oracle_full.sample(eps[b:b + 1], float(temps[b]), y[b:b + 1], 400, 1))
+    free = m.sample(y, temps, y, [0.0], [0.0], [400], [1])
+    assert free.shape == xs.shape and np.isfinite(free).all() and np.abs(free).max() > 0
+    with pytest.raises(ValueError):
+        m.sample(y, temps[:3], y, [0.0], [0.0], [400], [1], eps=eps)
+
+
 def test_full_bench_batch_against_c_oracle(shipped_variables):
     """Every patch of a full configs[1] batch (1024) and a configs[2] batch (4096 eps-supplied
     samples) against the plain-C oracle (fp32, reference op order)."""
