@@ -34,6 +34,9 @@
 // lifetimes spread 37..57 us around a 48 us mean and the launch lasts as long as the slowest one (tools/timeline.py).
 // Lowering a wave's priority as it advances through the couplings (3,3,2,2,1,1,0,0) is a negative feedback that keeps
 // co-resident workgroups level.  0 = off (MFMA bursts at NF_PRIO, the round-1 behaviour).
+#ifndef NF_BR_SWIZZLE
+#define NF_BR_SWIZZLE 1
+#endif
 #ifndef NF_WAVE_PRIO
 #define NF_WAVE_PRIO 1
 #endif
@@ -176,7 +179,18 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
     int wbase = 0;     // BLK: tile entry of the window origin (r' = 2*br, c' = 2*bc)
     if constexpr (BLK) {
         const int bw = W >> 1;
-        const int br = t / bw, bc = t - br * bw;
+        int br = t / bw, bc = t - br * bw;
+#if NF_BR_SWIZZLE
+        // 32x32, fp32 tiles: a block row is 16 lanes and the tile entries of two neighbouring block rows sit 4*PW = 68 entries
+        // apart, i.e. 4 bank quads (mod 16) — the 16-byte LDS reads of a half-wavefront are served in lane groups that mix
+        // lanes of two block rows ({0-3,12-15,20-27}, ...), and a quad offset of 4 makes a quarter of them collide
+        // (SQ_LDS_BANK_CONFLICT = 19 % of the LDS-active cycles).  Dealing the block rows to the wavefronts with a stride of 4
+        // (rows w, w+4, w+8, w+12) puts the two halves 272 entries = 0 quads apart: conflict-free.
+        if (!H16 && bw == 16) {
+            br = (t >> 6) + 4 * ((t >> 4) & 3);
+            bc = t & 15;
+        }
+#endif
         wbase = H16 ? (2 * br) * Wp + 2 * bc : (2 * br * 2) * PW + bc;
 #pragma unroll
         for (int k = 0; k < PX; ++k) {
