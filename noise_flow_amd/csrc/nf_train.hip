@@ -1814,10 +1814,19 @@ static int trainer_run(nf_trainer *t, const float *x, const float *y, int64_t B,
         }
         }
     }
-    hipLaunchKernelGGL(k_prior, dim3(nb), dim3(TB), 0, st, g, t->zs[n], s1, s2);
+    // The reported loss / sd_z feed nothing in the backward pass: with one to follow they are computed on the side stream
+    // (joined with the filter-gradient work before the step ends) while the main stream starts walking back.
+    hipStream_t ls = st;
+    if (backward && loss_out) {
+        ls = t->side;
+        (void)hipEventRecord(t->ev_fork[1], st);
+        (void)hipStreamWaitEvent(ls, t->ev_fork[1], 0);
+    }
+    hipLaunchKernelGGL(k_prior, dim3(nb), dim3(TB), 0, ls, g, t->zs[n], s1, s2);
     if (loss_out)
-        hipLaunchKernelGGL(k_loss, dim3(1), dim3(TB), 0, st, (int)B, (double)g.HW * 4.0, t->acc(t->d_ld0), n, g.nslot, s1, s2,
+        hipLaunchKernelGGL(k_loss, dim3(1), dim3(TB), 0, ls, (int)B, (double)g.HW * 4.0, t->acc(t->d_ld0), n, g.nslot, s1, s2,
                            G + t->d_ldc, loss_out);
+    if (ls != st) (void)hipEventRecord(t->ev_fork[2], ls);
     if (!backward) {
         t->zs[0] = nullptr;
         if ((e = hipGetLastError()) != hipSuccess) return nf_fail_hip(e, "trainer launch");
@@ -1855,6 +1864,7 @@ static int trainer_run(nf_trainer *t, const float *x, const float *y, int64_t B,
         }
         }
     }
+    if (ls != st) (void)hipStreamWaitEvent(st, t->ev_fork[2], 0);
     for (int par = 0; par < 2; ++par)   // join the side stream: its slots are read next
         if (t->done_pending[par]) {
             (void)hipStreamWaitEvent(st, t->ev_done[par], 0);
