@@ -350,12 +350,9 @@ __device__ void gain_s(int kind, const float *p, CondIdx ci, int HW, double &sv,
     else sv = exp(1e-5 * (double)p[table_idx(ci)]);
 }
 
-__global__ void k_prep(TLayers ls, const float *__restrict__ P, CondIdx ci, int HW, float *__restrict__ Abuf,
-                       float *__restrict__ abbuf, float *__restrict__ sbuf, double *__restrict__ ldc)
+__device__ void k_prep_layer(const TLayer L, const float *__restrict__ P, CondIdx ci, int HW, float *__restrict__ Abuf,
+                             float *__restrict__ abbuf, float *__restrict__ sbuf, double *ldc)
 {
-    const int l = threadIdx.x;
-    if (l >= ls.n) return;
-    const TLayer L = ls.l[l];
     const float *p = P + L.off;
     if (L.kind == NF_LAYER_PERMUTE) {                                      // tfb.Permute(channels reversed), log|det| = 0
         for (int i = 0; i < 4; ++i)
@@ -368,7 +365,7 @@ __global__ void k_prep(TLayers ls, const float *__restrict__ P, CondIdx ci, int 
                 Abuf[L.aux * 16 + i * 4 + j] = p[i * 4 + j];
             }
         inv4(M, Mi, lad);
-        atomicAdd(ldc, (double)HW * lad);
+        *ldc += (double)HW * lad;
     } else if (L.kind == NF_LAYER_CONV1X1_LU2) {
         double Pm[4][4], Lm[4][4], Um[4][4];
         lu2_matrices(p, Pm, Lm, Um);
@@ -382,7 +379,7 @@ __global__ void k_prep(TLayers ls, const float *__restrict__ P, CondIdx ci, int 
                 Abuf[L.aux * 16 + i * 4 + j] = (float)sacc;
             }
         }
-        atomicAdd(ldc, (double)HW * lad);
+        *ldc += (double)HW * lad;
     } else if (L.type == NF_LAYER_CONV1X1) {
         double Pm[4][4], Lm[4][4], Um[4][4], LU[4][4];
         plu_matrices(p, Pm, Lm, Um);
@@ -401,7 +398,7 @@ __global__ void k_prep(TLayers ls, const float *__restrict__ P, CondIdx ci, int 
                 Abuf[L.aux * 16 + i * 4 + j] = (float)s;
             }
         }
-        atomicAdd(ldc, (double)HW * lad);                                  // layers.py:129-130
+        *ldc += (double)HW * lad;                                  // layers.py:129-130
     } else if (L.type == NF_LAYER_SDN5) {
         double a, b;
         sdn_ab(L.kind, p, ci, a, b);
@@ -411,7 +408,26 @@ __global__ void k_prep(TLayers ls, const float *__restrict__ P, CondIdx ci, int 
         double sv, K;
         gain_s(L.kind, p, ci, HW, sv, K);
         sbuf[L.aux] = (float)sv;
-        atomicAdd(ldc, -K * log(sv));                                      // AffineCouplingGainEx4.py:114-127 and siblings
+        *ldc += -K * log(sv);                                      // AffineCouplingGainEx4.py:114-127 and siblings
+    }
+}
+
+// One workgroup of 64 threads, one layer per thread.  Also clears the per-patch accumulators of k_prior and adds the
+// layers' constant log-det terms up serially (no memset launches in front of the step, and a deterministic sum).
+__global__ __launch_bounds__(64) void k_prep(TLayers ls, const float *__restrict__ P, CondIdx ci, int HW, float *__restrict__ Abuf,
+                                             float *__restrict__ abbuf, float *__restrict__ sbuf, double *__restrict__ ldc,
+                                             float *__restrict__ patch_acc, int n_patch_acc)
+{
+    __shared__ double ld_part[kMaxLayers];
+    for (int i = threadIdx.x; i < n_patch_acc; i += 64) patch_acc[i] = 0.0f;
+    const int l = threadIdx.x;
+    ld_part[l] = 0.0;
+    if (l < ls.n) k_prep_layer(ls.l[l], P, ci, HW, Abuf, abbuf, sbuf, &ld_part[l]);
+    __syncthreads();
+    if (l == 0) {
+        double tot = 0.0;
+        for (int i = 0; i < ls.n; ++i) tot += ld_part[i];
+        *ldc = tot;
     }
 }
 
@@ -1777,14 +1793,11 @@ static int trainer_run(nf_trainer *t, const float *x, const float *y, int64_t B,
     const float invB = 1.0f / (float)B;
     const int n = t->cfg.n_layers;
     hipError_t e;
-    if ((e = hipMemsetAsync(t->d_dbl + t->d_ldc, 0, sizeof(double), st)) != hipSuccess ||
-        (e = hipMemsetAsync(t->d_patch, 0, 2 * (size_t)t->max_batch * sizeof(float), st)) != hipSuccess)
-        return nf_fail_hip(e, "hipMemsetAsync(trainer accumulators)");
     float *s1 = t->d_patch, *s2 = s1 + t->max_batch;
     double *G = t->d_dbl;
 
     hipLaunchKernelGGL(k_prep, dim3(1), dim3(64), 0, st, t->tl, t->d_params, ci, g.HW, t->d_flt + t->f_A, t->d_flt + t->f_ab, t->d_flt + t->f_s,
-                       G + t->d_ldc);
+                       G + t->d_ldc, t->d_patch, 2 * (int)t->max_batch);
     // ---- forward ----
     t->zs[0] = const_cast<float *>(x);
     for (int l = 0; l < n; ++l) {
