@@ -685,8 +685,13 @@ __global__ void k_c3_fwd(Geo g, const float *__restrict__ zin, const float *__re
     acc_add_n<1>(ldacc, lv, g.nslot);
 }
 
-__global__ void k_prior(Geo g, const float *__restrict__ z, float *__restrict__ s1, float *__restrict__ s2)
+// Per-patch sum and sum of squares of the latent.  Patches of a multiple of 64 pixels (32x32, 64x64: every wavefront of the
+// pixel loop sits inside one patch): one partial per wavefront, wp[2 w] / wp[2 w + 1] for wavefront w = p / 64 of the batch,
+// added up in a fixed order by k_loss — the reported loss / sd_z are then reproducible bit for bit like the gradients.
+// Other shapes: float atomics into s1 / s2 (cleared by k_prep).
+__global__ void k_prior(Geo g, const float *__restrict__ z, float *__restrict__ s1, float *__restrict__ s2, float *__restrict__ wp)
 {
+    const bool per_wave = (g.HW & 63) == 0;
     NF_PIXEL_LOOP(g, p) {
         const bool valid = p < g.npix;
         const int b = valid ? (int)(p / g.HW) : -1;
@@ -696,14 +701,23 @@ __global__ void k_prior(Geo g, const float *__restrict__ z, float *__restrict__ 
             a = v.x + v.y + v.z + v.w;
             q = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
         }
-        patch_add(s1, b, valid, a);
-        patch_add(s2, b, valid, q);
+        if (per_wave) {
+            const float sa = wsum(a), sq = wsum(q);
+            if ((threadIdx.x & 63) == 0 && valid) {
+                wp[2 * (p >> 6)] = sa;
+                wp[2 * (p >> 6) + 1] = sq;
+            }
+        } else {
+            patch_add(s1, b, valid, a);
+            patch_add(s2, b, valid, q);
+        }
     }
 }
 
 // loss = mean_b nll_b, sd_z = mean_b sqrt(var_hwc z_b)   (noise_flow_model.py:458-484)
 __global__ void k_loss(int B, double n, Acc ld0, int n_layers, int nslot, const float *__restrict__ s1,
-                       const float *__restrict__ s2, const double *__restrict__ ldc, float *__restrict__ out)
+                       const float *__restrict__ s2, const float *__restrict__ wp, int waves_per_patch,
+                       const double *__restrict__ ldc, float *__restrict__ out)
 {
     __shared__ double sh[2][TB];
     __shared__ double shl[TB / 64];
@@ -717,9 +731,20 @@ __global__ void k_loss(int B, double n, Acc ld0, int n_layers, int nslot, const 
     for (int i = 0; i < TB / 64; ++i) ldsum += shl[i];
     double a = 0.0, d = 0.0;
     for (int b = threadIdx.x; b < B; b += TB) {
-        a += 0.5 * n * 1.8378770664093453 + 0.5 * (double)s2[b] - ldc[0];
-        const double m = (double)s1[b] / n;
-        double v = (double)s2[b] / n - m * m;
+        double sum1, sum2;
+        if (waves_per_patch > 0) {          // the wavefront partials of k_prior, in wavefront order
+            sum1 = sum2 = 0.0;
+            for (int w = 0; w < waves_per_patch; ++w) {
+                sum1 += (double)wp[2 * ((size_t)b * waves_per_patch + w)];
+                sum2 += (double)wp[2 * ((size_t)b * waves_per_patch + w) + 1];
+            }
+        } else {
+            sum1 = s1[b];
+            sum2 = s2[b];
+        }
+        a += 0.5 * n * 1.8378770664093453 + 0.5 * sum2 - ldc[0];
+        const double m = sum1 / n;
+        double v = sum2 / n - m * m;
         d += sqrt(v > 0.0 ? v : 0.0);
     }
     sh[0][threadIdx.x] = a;
@@ -1350,7 +1375,8 @@ struct nf_trainer {
     float *d_flt = nullptr;         // A matrices, sdn5 (a,b), BN scalars
     size_t n_flt = 0;
     int f_A = 0, f_ab = 0, f_s = 0;
-    float *d_patch = nullptr;       // ld[B], s1[B], s2[B]
+    float *d_patch = nullptr;       // s1[B], s2[B]
+    float *d_wpart = nullptr;       // per-wavefront (sum z, sum z^2) partials of k_prior (patches of a multiple of 64 pixels)
     std::vector<float *> zs;        // zs[l] = input of layer l (zs[0] is the caller's x), zs[n] = latent
     // backward temporaries, double-buffered by coupling parity: the filter-gradient kernels of one
     // coupling run on `side` while the main stream is already in the next coupling
@@ -1713,6 +1739,7 @@ int nf_trainer_create(const nf_config *cfg, const nf_layer_desc *layers, const f
     NF_TRY(dev_alloc(t, (void **)&t->d_part, (nd - 1) * NSLOT * sizeof(float)));
     NF_TRY(dev_alloc(t, (void **)&t->d_flt, nf * sizeof(float)));
     NF_TRY(dev_alloc(t, (void **)&t->d_patch, 2 * (size_t)max_batch * sizeof(float)));
+    NF_TRY(dev_alloc(t, (void **)&t->d_wpart, 2 * ((act + 63) / 64) * sizeof(float)));
     t->zs.assign(cfg->n_layers + 1, nullptr);
     for (int i = 1; i <= cfg->n_layers; ++i) NF_TRY(dev_alloc(t, (void **)&t->zs[i], act * 4 * sizeof(float)));
     for (Cpl &c : t->cpl) {
@@ -1835,10 +1862,10 @@ static int trainer_run(nf_trainer *t, const float *x, const float *y, int64_t B,
         (void)hipEventRecord(t->ev_fork[1], st);
         (void)hipStreamWaitEvent(ls, t->ev_fork[1], 0);
     }
-    hipLaunchKernelGGL(k_prior, dim3(nb), dim3(TB), 0, ls, g, t->zs[n], s1, s2);
+    hipLaunchKernelGGL(k_prior, dim3(nb), dim3(TB), 0, ls, g, t->zs[n], s1, s2, t->d_wpart);
     if (loss_out)
         hipLaunchKernelGGL(k_loss, dim3(1), dim3(TB), 0, ls, (int)B, (double)g.HW * 4.0, t->acc(t->d_ld0), n, g.nslot, s1, s2,
-                           G + t->d_ldc, loss_out);
+                           t->d_wpart, (g.HW & 63) == 0 ? g.HW / 64 : 0, G + t->d_ldc, loss_out);
     if (ls != st) (void)hipEventRecord(t->ev_fork[2], ls);
     if (!backward) {
         t->zs[0] = nullptr;

@@ -547,3 +547,23 @@ def test_variables_shared_between_layers_receive_the_summed_gradient():
                 seen[nm] = raw[pos:pos + n].copy()
             pos += n
     assert not np.array_equal(seen["model/sdn_gain/gain_val"], np.asarray(v["model/sdn_gain/gain_val"]).reshape(-1))
+
+
+def test_a_training_run_is_reproducible_bit_for_bit(shipped_variables):
+    """Gradients, BN moments and updates come from slot reductions in a fixed order; on patches of a multiple of 64 pixels
+    the reported loss / sd_z do too (one partial per wavefront, summed in order).  Two trainers fed the same minibatches
+    end in identical parameters and identical logged values, to the bit."""
+    import torch
+    outs = []
+    for rep in range(2):
+        tr = _trainer(FULL_ARCH, shipped_variables, max_batch=12)
+        log = []
+        for step in range(4):
+            x, y = make_inputs(12, seed=60 + step, b1=0.003696)
+            loss = tr.step(x, y, [0.0], [0.0], [800], [2], lr=1e-3, sync=False)
+            log.append(loss.clone())
+        torch.cuda.synchronize()
+        outs.append((tr.raw_params(), torch.stack(log).cpu().numpy()))
+        tr.close()
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert np.array_equal(outs[0][1].view(np.uint32), outs[1][1].view(np.uint32))
