@@ -853,8 +853,8 @@ __global__ void k_mix_bwd(Geo g, const float *__restrict__ zin, const float *__r
 template <int W>
 __global__ void k_c3_bwd(Geo g, const float *__restrict__ zin, const float *__restrict__ h2, const float *__restrict__ bn2,
                          const float *__restrict__ P, int off_w3, float invB, float *__restrict__ dz,
-                         float *__restrict__ gu, Acc G)
-{
+                         float *__restrict__ gu, Acc G, const float *__restrict__ zlat)
+{   // zlat != null: this is the first stage of the backward pass; d loss / d latent = latent / B is formed here (k_dz_init)
     const float *W3 = P + off_w3, *b3 = W3 + 36 * (W + 1), *logs = b3 + 4;
     const float sc = logs[4];
     const int off_b3 = off_w3 + 36 * (W + 1);
@@ -868,7 +868,13 @@ __global__ void k_c3_bwd(Geo g, const float *__restrict__ zin, const float *__re
             float u[4];
             l_last_u<W>(g, b, r, c, h2, bn2, W3, b3, u);
             const float4 zi = reinterpret_cast<const float4 *>(zin)[p];
-            float4 d = reinterpret_cast<const float4 *>(dz)[p];
+            float4 d;
+            if (zlat) {
+                const float4 zl = reinterpret_cast<const float4 *>(zlat)[p];
+                d = make_float4(zl.x * invB, zl.y * invB, zl.z * invB, zl.w * invB);
+            } else {
+                d = reinterpret_cast<const float4 *>(dz)[p];
+            }
             const float z1[2] = {zi.z, zi.w}, gx1[2] = {d.z, d.w};
             float go[4], o[4], gz1[2];
 #pragma unroll
@@ -1470,7 +1476,7 @@ void coupling_forward(nf_trainer *t, const Geo &g, const TLayer &L, const float 
 
 template <int W>
 void coupling_backward(nf_trainer *t, const Geo &g, const TLayer &L, const float *zin, float invB, const float *zmix_in,
-                       const float *A, Acc dA, hipStream_t st)
+                       const float *A, Acc dA, hipStream_t st, const float *zlat)
 {
     const Cpl &c = t->cpl[L.aux];
     const unsigned nb = blocks_for(g.npix);
@@ -1490,7 +1496,7 @@ void coupling_backward(nf_trainer *t, const Geo &g, const TLayer &L, const float
         (void)hipStreamWaitEvent(st, t->ev_done[par], 0);
         t->done_pending[par] = false;
     }
-    hipLaunchKernelGGL(k_c3_bwd<W>, dim3(nb), dim3(TB), 0, st, g, zin, c.h2, bn2, t->d_params, off_w3, invB, t->dz, gu, G);
+    hipLaunchKernelGGL(k_c3_bwd<W>, dim3(nb), dim3(TB), 0, st, g, zin, c.h2, bn2, t->d_params, off_w3, invB, t->dz, gu, G, zlat);
     hipLaunchKernelGGL(k_c3_dh<W>, dim3(nb), dim3(TB), 0, st, g, c.h2, bn2, t->d_params, off_w3, gu, t1, t->acc(c.d_bs2));
     sync_slots(t, t->acc(c.d_bs2), 2 * w, g.nslot, st);
     hipLaunchKernelGGL(k_c2_bwd<W>, dim3(nb), dim3(TB), 0, st, g, c.h1, bn1, c.h2, bn2, t->acc(c.d_bs2), n, t->d_params, off_w2,
@@ -1874,7 +1880,9 @@ static int trainer_run(nf_trainer *t, const float *x, const float *y, int64_t B,
         return NF_OK;
     }
     // ---- backward ----
-    hipLaunchKernelGGL(k_dz_init, dim3(nb), dim3(TB), 0, st, g, t->zs[n], invB, t->dz);
+    // d loss / d latent = latent / B: formed inside the first stage when the stack ends in a coupling, else by its own kernel
+    const bool dz_in_first = t->tl.l[n - 1].type == NF_LAYER_COUPLING;
+    if (!dz_in_first) hipLaunchKernelGGL(k_dz_init, dim3(nb), dim3(TB), 0, st, g, t->zs[n], invB, t->dz);
     for (int l = n - 1; l >= 0; --l) {
         const TLayer &L = t->tl.l[l];
         switch (L.type) {
@@ -1896,7 +1904,7 @@ static int trainer_run(nf_trainer *t, const float *x, const float *y, int64_t B,
             const float *zmix_in = fold ? t->zs[l - 1] : nullptr;
             const float *Am = fold ? t->d_flt + t->f_A + 16 * t->tl.l[l - 1].aux : nullptr;
             const Acc dA = t->acc(fold ? t->d_dA + 16 * t->tl.l[l - 1].aux : 0);
-#define NF_CALL(WW) coupling_backward<WW>(t, g, L, t->zs[l], invB, zmix_in, Am, dA, st)
+#define NF_CALL(WW) coupling_backward<WW>(t, g, L, t->zs[l], invB, zmix_in, Am, dA, st, (dz_in_first && l == n - 1) ? t->zs[n] : nullptr)
             NF_WIDTH_SWITCH(L.width, NF_CALL)
 #undef NF_CALL
             if (fold) --l;   // the Conv2d1x1 below was handled by the coupling's last stage
