@@ -1316,6 +1316,7 @@ struct BsPlan {
     float *d_ident2 = nullptr;        // ... matrix-core layout (null when unavailable)
     std::vector<int> cpl_ops;         // op index of every coupling in ident.prog, execution order
     std::vector<int> cpl_row;         // its row in moments_out (NLL layer order)
+    std::vector<float> shift;         // [coupling in NLL layer order][2][width]: the running means the statistics are taken around
     std::vector<NfProgram> progA, progB;
     std::vector<NfProgram> progA2, progB2;   // the same segments over the matrix-core layout (width 4)
     int32_t *d_pairs = nullptr;       // (dst in matrix-core block, src in scalar block) of the BN-dependent entries
@@ -1353,9 +1354,13 @@ struct nf_bs_state {
 
 static int bs_build_plan(nf_handle *h, int direction, BsPlan &P)
 {
-    // identity normalisation in every coupling: mean 0, var 1 - eps  ->  scale exactly 1
+    // unit-scale normalisation in every coupling: var 1 - eps -> scale exactly 1.  The MEAN stays the stored running mean:
+    // the statistics passes then see activations centred near zero, so that their one-pass sum / sum-of-squares does not
+    // cancel when a channel's mean is large against its spread (shipped model: mean^2 / var up to 400); the re-fold
+    // B <- (B - mean') * scale is unchanged, and the reported batch mean is mean' + running mean.
     std::vector<float> p = h->raw;
     int n_cpl = 0;
+    P.shift.clear();
     for (int i = 0; i < h->cfg.n_layers; ++i) {
         const nf_layer_desc &L = h->layers[i];
         if (L.type != NF_LAYER_COUPLING) continue;
@@ -1363,10 +1368,9 @@ static int bs_build_plan(nf_handle *h, int direction, BsPlan &P)
         const int w = L.width;
         float *lp = p.data() + L.param_offset;
         float *mv[4] = {lp + 19 * w, lp + 20 * w, lp + 22 * w + w * w, lp + 23 * w + w * w};
-        for (int j = 0; j < w; ++j) {
-            mv[0][j] = mv[2][j] = 0.0f;
-            mv[1][j] = mv[3][j] = (float)(1.0 - kBnEps);
-        }
+        P.shift.insert(P.shift.end(), mv[0], mv[0] + w);
+        P.shift.insert(P.shift.end(), mv[2], mv[2] + w);
+        for (int j = 0; j < w; ++j) mv[1][j] = mv[3][j] = (float)(1.0 - kBnEps);
     }
     int rc = build_program(&h->cfg, h->layers.data(), p.data(), p.size(), direction, P.ident);
     if (rc != NF_OK) return rc;
@@ -1580,7 +1584,14 @@ static int run_batchstats(nf_handle *h, int direction, NfLaunch a, float *moment
             return fail_hip(e, "batch-statistics moments readback");
         }
         if ((e = hipStreamSynchronize(st)) != hipSuccess) return fail_hip(e, "batch-statistics final sync");   // the scratch is reused
-        if (moments_out && n_cpl) memcpy(moments_out, mom_h.data(), (size_t)n_cpl * 16 * sizeof(float));
+        if (moments_out && n_cpl) {
+            for (int c = 0; c < n_cpl; ++c)          // rows are in NLL layer order, like P.shift
+                for (int j = 0; j < 4; ++j) {
+                    mom_h[(size_t)c * 16 + j] += P.shift[(size_t)c * 8 + j];
+                    mom_h[(size_t)c * 16 + 8 + j] += P.shift[(size_t)c * 8 + 4 + j];
+                }
+            memcpy(moments_out, mom_h.data(), (size_t)n_cpl * 16 * sizeof(float));
+        }
         return NF_OK;
     }
     {   // the generic schedule runs on the scalar-weight kernel: both LDS tiles of a patch on one CU, one pixel per lane at width 32
@@ -1646,7 +1657,14 @@ static int run_batchstats(nf_handle *h, int direction, NfLaunch a, float *moment
         return fail_hip(e, "batch-statistics moments readback");
     }
     if ((e = hipStreamSynchronize(st)) != hipSuccess) return fail_hip(e, "batch-statistics final sync");   // the scratch is reused
-    if (moments_out && n_cpl) memcpy(moments_out, mom_h.data(), (size_t)n_cpl * 4 * w * sizeof(float));
+    if (moments_out && n_cpl) {
+        for (int c = 0; c < n_cpl; ++c)              // [mean1, var1, mean2, var2][w] per coupling, NLL layer order
+            for (int j = 0; j < w; ++j) {
+                mom_h[(size_t)c * 4 * w + j] += P.shift[(size_t)c * 2 * w + j];
+                mom_h[(size_t)c * 4 * w + 2 * w + j] += P.shift[(size_t)c * 2 * w + w + j];
+            }
+        memcpy(moments_out, mom_h.data(), (size_t)n_cpl * 4 * w * sizeof(float));
+    }
     return NF_OK;
 }
 
