@@ -567,3 +567,34 @@ def test_a_training_run_is_reproducible_bit_for_bit(shipped_variables):
         tr.close()
     assert np.array_equal(outs[0][0], outs[1][0])
     assert np.array_equal(outs[0][1].view(np.uint32), outs[1][1].view(np.uint32))
+
+
+@pytest.mark.parametrize("arch,width,hw,B", [(FULL_ARCH, 4, (32, 32), 9),          # 1024 threads per patch
+                                             ("sdn5|unc|unc|gain4|unc", 8, (16, 24), 6),   # 512, width 8
+                                             ("unc|unc|unc", 4, (10, 12), 11),      # 256, threads beyond the patch idle
+                                             ("unc|sdn5|unc|unc", 8, (32, 32), 3),  # a coupling chain cut by another layer
+                                             ("unc|gain4|unc|unc|gain4", 4, (8, 8), 40)])
+def test_tiled_stages_and_layer_kernels_agree(arch, width, hw, B, monkeypatch):
+    """The trainer runs couplings of width <= 8 on patches of <= 1024 pixels through one-workgroup-per-patch tiled stages
+    (two launches per coupling and pass) and everything else through one kernel per layer stage; NF_TRAIN_TILED selects
+    (bit 0 backward, bit 1 forward).  Both must give the oracle's loss and gradients; between themselves they only differ
+    in how the fp32 partial sums are grouped, so the logged loss agrees to 1e-6 and gradients to 1e-4 of their scale."""
+    v = trained_like_variables(arch, width, seed=8)
+    x, y = make_inputs(B, hw[0], hw[1], seed=23)
+    res = {}
+    for mode in ("0", "1", "2", "3"):
+        monkeypatch.setenv("NF_TRAIN_TILED", mode)
+        tr = _trainer(arch, v, (hw[0], hw[1], 4), width)
+        grads, loss = tr.forward_backward(x, y, [0.0], [0.0], [800], [2])
+        res[mode] = (grads.cpu().numpy().copy(), loss.cpu().numpy().copy(), tr.raw_params())
+        if mode == "3":
+            ref_loss, ref_sd, ref_grads, _ = _grad_oracle(arch, v).loss_and_grads(x, y, 800, 2)
+            assert abs(res[mode][1][0] - ref_loss) <= 1e-5 * abs(ref_loss)
+            _check_grads(tr, grads, ref_grads)
+        tr.close()
+    g0, l0, p0 = res["0"]
+    for mode in ("1", "2", "3"):
+        g, l, p = res[mode]
+        assert np.allclose(l, l0, rtol=1e-6, atol=0), (mode, l, l0)
+        assert np.abs(g - g0).max() <= 1e-4 * np.abs(g0).max(), (mode, np.abs(g - g0).max(), np.abs(g0).max())
+        assert np.allclose(p, p0, rtol=1e-5, atol=1e-7), mode      # the BN running moments moved by the forward pass

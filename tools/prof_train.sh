@@ -7,7 +7,7 @@ f=$(find gpurun_out/trprof -name "*kernel_stats.csv" | head -1)
 python - <<PY
 import csv
 rows=list(csv.DictReader(open("$f")))
-for r in rows[:18]:
-    name=r["Name"].split("(")[0].replace("void ","").replace("(anonymous namespace)::","")[:34]
-    print("%-36s calls %5s avg %8.1f us  total %8.1f ms" % (name, r["Calls"], float(r["AverageNs"])/1e3, float(r["TotalDurationNs"])/1e6))
+for r in rows[:24]:
+    name=r["Name"].replace("void ","").replace("(anonymous namespace)::","").split("(")[0][:44]
+    print("%-46s calls %5s avg %8.1f us  total %8.1f ms" % (name, r["Calls"], float(r["AverageNs"])/1e3, float(r["TotalDurationNs"])/1e6))
 PY
