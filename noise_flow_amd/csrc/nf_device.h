@@ -182,6 +182,11 @@ enum : uint32_t {
     NF_K_FP16_CNN  = 4u,   // parameter block is the fp16-CNN layout (NF3_*)
     NF_K_SUMS_WIDE = 8u,   // `sums` is the slotted layout of NF_SUMS_WIDE (include/noiseflow_hip.h)
     NF_K_BATCHSTATS = 16u, // matrix-core launch of a batch-statistics call: honours fix_* and stats
+    // batch-statistics calls: the log-det of the segments already evaluated in their final form travels with the resident
+    // tensor, one float per thread of the patch's workgroup (ld_carry), so that the last launch only runs the last segment
+    NF_K_CARRY_OUT = 32u,  // at NF_OP_STORE: ld_carry <- this thread's log-det so far (+ ld_carry with NF_K_CARRY_ADD)
+    NF_K_CARRY_ADD = 64u,
+    NF_K_CARRY_IN  = 128u, // start from ld_carry instead of 0
 };
 
 struct NfLaunch {
@@ -218,6 +223,7 @@ struct NfLaunch {
     int32_t fix_stage;         // 1: l_1 / BN_1, 2: l_2 / BN_2
     float *fix_params_out;     // parameter block the next launch reads (n_params floats)
     float *fix_mom_out;        // mean[4], var[4] of that normalisation
+    float *ld_carry;           // [B][threads per workgroup] (NF_K_CARRY_*), or null
 };
 
 #define NF_STATS_SLOTS 64   // power of two

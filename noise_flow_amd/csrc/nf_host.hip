@@ -1307,7 +1307,9 @@ int nf_sample(nf_handle *h, const float *y, const float *eps, uint64_t seed, int
 //   launch B_c : the same segment from T_c with BN_1 folded, statistics of its l_2
 // each followed by a one-workgroup kernel that turns the sums into moments and re-folds the layer IN PLACE on a
 // device-resident working copy of the parameter block (which starts as the identity-normalised model), and finally
-// one ordinary fused pass over the whole stack with all moments folded in.  2 short launches per coupling instead of
+// one fused pass over the LAST segment (+ the layers behind the last coupling) from the last resident tensor: every
+// earlier segment already ran in its final form in the launch that stored the tensor behind it, and the log-det it
+// contributed travels with that tensor (NfLaunch::ld_carry, one float per thread of the patch's workgroup).  2 short launches per coupling instead of
 // re-running the whole prefix, no host round trip until the moments are copied out at the end.
 struct BsPlan {
     bool ready = false;
@@ -1319,6 +1321,7 @@ struct BsPlan {
     std::vector<float> shift;         // [coupling in NLL layer order][2][width]: the running means the statistics are taken around
     std::vector<NfProgram> progA, progB;
     std::vector<NfProgram> progA2, progB2;   // the same segments over the matrix-core layout (width 4)
+    NfProgram progF, progF2;          // the last segment + everything behind it (the final launch when there are >= 2 couplings)
     int32_t *d_pairs = nullptr;       // (dst in matrix-core block, src in scalar block) of the BN-dependent entries
     int n_pairs = 0;
 };
@@ -1334,6 +1337,8 @@ struct nf_bs_state {
     float *d_mom = nullptr;            // [couplings][4][w]
     float *d_T[2] = {nullptr, nullptr};
     size_t T_cap = 0;                  // floats per scratch tensor
+    float *d_carry = nullptr;          // [B][1024] per-thread log-det of the segments behind the resident tensor
+    size_t carry_cap = 0;
     ~nf_bs_state()
     {
         for (int d = 0; d < 2; ++d) {
@@ -1349,6 +1354,7 @@ struct nf_bs_state {
         if (d_mom) (void)hipFree(d_mom);
         if (d_T[0]) (void)hipFree(d_T[0]);
         if (d_T[1]) (void)hipFree(d_T[1]);
+        if (d_carry) (void)hipFree(d_carry);
     }
 };
 
@@ -1402,6 +1408,13 @@ static int bs_build_plan(nf_handle *h, int direction, BsPlan &P)
             B.ops[B.n_ops++] = prog.ops[i];
         }
     }
+    memset(&P.progF, 0, sizeof(P.progF));
+    P.progF.width = prog.width;
+    if (n_cpl > 1) {
+        const int first = P.cpl_ops[n_cpl - 2] + 1;
+        if (prog.n_ops - first > NF_MAX_OPS) return fail(NF_EINVAL, "too many layers for the batch-statistics plan");
+        for (int i = first; i < prog.n_ops; ++i) P.progF.ops[P.progF.n_ops++] = prog.ops[i];
+    }
     if (!P.ident.block2.empty()) {   // same op sequences, offsets of the matrix-core layout
         auto to_mc = [&](const NfProgram &src) {
             NfProgram dst = src;
@@ -1421,6 +1434,7 @@ static int bs_build_plan(nf_handle *h, int direction, BsPlan &P)
             P.progA2[c] = to_mc(P.progA[c]);
             P.progB2[c] = to_mc(P.progB[c]);
         }
+        P.progF2 = to_mc(P.progF);
     }
     hipError_t e;
     const size_t nb = P.ident.block.size() * sizeof(float);
@@ -1507,6 +1521,20 @@ static int run_batchstats(nf_handle *h, int direction, NfLaunch a, float *moment
             return fail_hip(e, "hipMalloc(batch-statistics scratch tensors)");
         S.T_cap = tensor;
     }
+    // the log-det only matters to the outputs that contain it
+    const bool carry = n_cpl > 1 && (a.nll_out || a.ld_out || a.sums);
+    if (carry && (e = grow(S.d_carry, S.carry_cap, (size_t)a.B * 1024)) != hipSuccess) return fail_hip(e, "hipMalloc(batch-statistics log-det carry)");
+    // the final launch: from the last resident tensor when there is one
+    auto final_args = [&](NfLaunch &f) {
+        if (n_cpl < 2) return;
+        f.in = S.d_T[(n_cpl - 1) & 1];
+        f.in_scale = 1.0f;
+        f.flags &= ~(uint32_t)NF_K_PHILOX_IN;
+        if (carry) {
+            f.flags |= NF_K_CARRY_IN;
+            f.ld_carry = S.d_carry;
+        }
+    };
     if (nw2 && P.ident.prog.width == 4 && use_matrix_core()) {
         // ---- width 4: every launch on the matrix-core kernel, the re-fold fused into the consumer's prologue ----
         // launch k gathers the sums of pass k into its own block of `d_stats_mc`; launch k+1 (every workgroup, in LDS)
@@ -1568,6 +1596,10 @@ static int run_batchstats(nf_handle *h, int direction, NfLaunch a, float *moment
                 s.in_scale = from_input ? in_scale0 : 1.0f;
                 s.flags = from_input ? flags0 : (flags0 & ~(uint32_t)NF_K_PHILOX_IN);
                 s.out = (stage == 1 && c > 0) ? S.d_T[c & 1] : nullptr;
+                if (carry && s.out) {
+                    s.flags |= NF_K_CARRY_OUT | (c > 1 ? NF_K_CARRY_ADD : 0u);
+                    s.ld_carry = S.d_carry;
+                }
                 if ((e = launch(prog, s)) != hipSuccess) return fail_hip(e, "batch-statistics launch");
                 pend_stats = s.stats;
                 pend_off = P.ident.prog2.ops[P.cpl_ops[c]].off;
@@ -1576,7 +1608,8 @@ static int run_batchstats(nf_handle *h, int direction, NfLaunch a, float *moment
             }
         }
         a.ld_const = a.ld_const + (direction == 0 ? P.ident.ld_const : 0.0);
-        if ((e = launch(P.ident.prog2, a)) != hipSuccess) return fail_hip(e, "batch-statistics final launch");
+        final_args(a);
+        if ((e = launch(n_cpl > 1 ? P.progF2 : P.ident.prog2, a)) != hipSuccess) return fail_hip(e, "batch-statistics final launch");
         std::vector<float> mom_h((size_t)std::max(n_cpl, 1) * 16);
         if (moments_out && n_cpl &&
             (e = hipMemcpyAsync(mom_h.data(), S.d_mom, (size_t)n_cpl * 16 * sizeof(float), hipMemcpyDeviceToHost, st)) != hipSuccess) {
@@ -1632,6 +1665,10 @@ static int run_batchstats(nf_handle *h, int direction, NfLaunch a, float *moment
             s.in_scale = from_input ? in_scale0 : 1.0f;
             s.flags = from_input ? flags0 : (flags0 & ~(uint32_t)NF_K_PHILOX_IN);
             s.out = (stage == 1 && c > 0) ? S.d_T[c & 1] : nullptr;
+            if (carry && s.out) {
+                s.flags |= NF_K_CARRY_OUT | (c > 1 ? NF_K_CARRY_ADD : 0u);
+                s.ld_carry = S.d_carry;
+            }
             if ((e = nf_launch_flow(prog, s, h->n_cu, st, false)) != hipSuccess) return fail_hip(e, "batch-statistics launch");
             float *Wm = S.d_work + blk + (stage == 1 ? nf_cpl_off_W1(w) : nf_cpl_off_W2(w));
             float *Bv = S.d_work + blk + (stage == 1 ? nf_cpl_off_B1(w) : nf_cpl_off_B2(w));
@@ -1641,14 +1678,15 @@ static int run_batchstats(nf_handle *h, int direction, NfLaunch a, float *moment
         }
     }
 
-    // final pass over the whole stack with the batch moments folded in
+    // final pass with the batch moments folded in
     const bool mc = nw2 != 0 && use_matrix_core();
     if (mc && (e = nf_launch_gather(S.d_work2, S.d_work, P.d_pairs, P.n_pairs, st)) != hipSuccess)
         return fail_hip(e, "batch-statistics re-layout");
     a.params = mc ? S.d_work2 : S.d_work;
     a.n_params = mc ? (int32_t)nw2 : 0;
     a.ld_const = ld_call + (direction == 0 ? P.ident.ld_const : 0.0);
-    if ((e = nf_launch_flow(mc ? P.ident.prog2 : P.ident.prog, a, h->n_cu, st, mc)) != hipSuccess)
+    if (!mc) final_args(a);   // (a final pass on the matrix-core kernel maps pixels to threads differently: whole stack, no carry)
+    if ((e = nf_launch_flow(mc ? P.ident.prog2 : n_cpl > 1 ? P.progF : P.ident.prog, a, h->n_cu, st, mc)) != hipSuccess)
         return fail_hip(e, "batch-statistics final launch");
     std::vector<float> mom_h((size_t)std::max(n_cpl, 1) * 4 * w);
     if (moments_out && n_cpl &&

@@ -368,6 +368,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
         }
 
         float ld = 0.0f;    // this thread's share of the data-dependent log-det (natural log)
+        if constexpr (!MFMA || BS) {
+            if (a.flags & NF_K_CARRY_IN) ld = a.ld_carry[(size_t)b * THREADS + t];
+        }
         float ld2 = 0.0f;   // ... and the part accumulated in log2 units (matrix-core couplings)
         [[maybe_unused]] int n_cpl = 0;
         [[maybe_unused]] int cpl_seen = 0;
@@ -904,6 +907,14 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
 #pragma unroll
                     for (int k = 0; k < PX; ++k)
                         if (act[k]) out4[gidx[k]] = make_float4(z[k][0], z[k][1], z[k][2], z[k][3]);
+                }
+                if constexpr (!MFMA || BS) {
+                    if (a.flags & NF_K_CARRY_OUT) {   // the log-det of what ran so far goes with the stored tensor
+                        float *cp = a.ld_carry + (size_t)b * THREADS + t;
+                        float v = fmaf(ld2, 0.6931471805599453f, ld);
+                        if (a.flags & NF_K_CARRY_ADD) v += *cp;
+                        *cp = v;
+                    }
                 }
             }
         }
