@@ -1647,6 +1647,138 @@ __global__ __launch_bounds__(NT) void k_tiled_fwd(Geo g, TiledF3 f3, TiledF1 f1,
     if (HAS_1) stage_flush<NT>(f1.stats1, stg + 1, 2 * W, g.nslot);
 }
 
+// ---------------------------------------------------------------------------------------------
+// width 32 (the paper-scale coupling CNN, job_noise_flow.sh:19): the filter gradients on the matrix cores
+// ---------------------------------------------------------------------------------------------
+// A filter gradient is a GEMM whose K axis is the PIXELS of the minibatch: dW[i][j] = sum_p A[p][i] G[p][j].  One
+// v_mfma_f32_32x32x2_f32 (exact fp32) takes two pixels: lane (i = lane & 31, k = lane >> 5) supplies A[p_k][i] and
+// G[p_k][i'] — with the pixel-major [p][32] tensors that is one coalesced 128-byte row per lane half and operand — and the
+// 32x32 result stays in 16 accumulator registers for the whole pixel loop.  The per-thread-per-pixel kernels above hold
+// W (or 4 W) accumulators per thread and walk 128-byte rows with a 128-byte lane stride: 3.6 ms per coupling for
+// d l_last/W at 1 024 patches, against ~0.1 ms here.
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+// the 32x32 accumulators of the 4 wavefronts of a workgroup -> one slot per value;  value(row, col) = index of D[row][col]
+// relative to `dst`, or -1 for an unused column.  red: [4][16][64] floats.
+template <typename F>
+__device__ __forceinline__ void mfma_tile_to_slots(const v16f &D, float *red, Acc dst, int nslot, F value)
+{
+    const int t = threadIdx.x, wv = t >> 6, ln = t & 63;
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < 16; ++v) red[(wv * 16 + v) * 64 + ln] = D[v];
+    __syncthreads();
+    for (int e = t; e < 1024; e += 256) {
+        const int v = e >> 6, l = e & 63;
+        const float tot = red[e] + red[1024 + e] + red[2048 + e] + red[3072 + e];
+        const int idx = value(8 * (v >> 2) + 4 * (l >> 5) + (v & 3), l & 31);
+        if (idx >= 0) {
+            float *d = dst.p + (size_t)idx * NSLOT;
+            d[blockIdx.x] = tot;
+            for (int q = blockIdx.x + gridDim.x; q < nslot; q += gridDim.x) d[q] = 0.0f;
+        }
+    }
+}
+
+// d l_2/W[i][j] = sum_p relu(bn1(h1))[p][i] * g_h2[p][j]
+__global__ __launch_bounds__(256) void k_w2_grad_mfma32(Geo g, const float *__restrict__ h1, const float *__restrict__ bn1,
+                                                        const float *__restrict__ t1, int off_w2, Acc G)
+{
+    __shared__ float red[4 * 16 * 64];
+    const int t = threadIdx.x, wv = t >> 6, ln = t & 63, col = ln & 31, half = ln >> 5;
+    const float m = bn1[col], rs = bn1[32 + col];
+    v16f D;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) D[v] = 0.0f;
+    const int64_t nsteps = (g.npix + 1) >> 1, stride = (int64_t)gridDim.x * 4;
+    int64_t s = (int64_t)blockIdx.x * 4 + wv;
+    for (; s + 3 * stride < nsteps; s += 4 * stride) {   // four pixel pairs in flight
+        float a[4], b[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t p = 2 * (s + k * stride) + half;
+            const bool in = p < g.npix;
+            a[k] = in ? h1[p * 32 + col] : 0.0f;
+            b[k] = in ? t1[p * 32 + col] : 0.0f;
+            a[k] = in ? fmaxf((a[k] - m) * rs, 0.0f) : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) D = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], b[k], D, 0, 0, 0);
+    }
+    for (; s < nsteps; s += stride) {
+        const int64_t p = 2 * s + half;
+        const bool in = p < g.npix;
+        const float a = in ? fmaxf((h1[p * 32 + col] - m) * rs, 0.0f) : 0.0f, b = in ? t1[p * 32 + col] : 0.0f;
+        D = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, D, 0, 0, 0);
+    }
+    mfma_tile_to_slots(D, red, G + off_w2, g.nslot, [](int i, int j) { return i * 32 + j; });
+}
+
+// d l_last/W[tap][i][q] = sum_p' relu(bn2(h2))[p'][i] * gu[p' - tap][q]  (p' = the pixel the tap reads, inside the patch;
+// gu from a zero-bordered tile of the patch), columns (tap, q): taps 0..7 in one 32-column tile, tap 8 in a second.
+// The indicator channel's gradient, sum over the pixels whose tap falls on the padding ring, is the column sum of ALL of gu
+// (the centre tap's column sum) minus the column sum over the taps that land inside — both fall out of the B operands.
+__global__ __launch_bounds__(256) void k_w3_grad_mfma32(Geo g, const float *__restrict__ h2, const float *__restrict__ bn2,
+                                                        const float *__restrict__ gu, int off_w3, Acc G)
+{
+    extern __shared__ float smem[];   // gu tile [(H+2)(W+2)][4]
+    __shared__ float red[4 * 16 * 64];
+    __shared__ float cs[2][4][64], cst[40];
+    const int t = threadIdx.x, wv = t >> 6, ln = t & 63, col = ln & 31, half = ln >> 5;
+    const int Wp = g.W + 2, tile_px = (g.H + 2) * Wp;
+    const float m = bn2[col], rs = bn2[32 + col];
+    const int tap0 = col >> 2, q = col & 3;
+    const int d0 = (tap0 / 3 - 1) * Wp + (tap0 % 3 - 1), d1 = Wp + 1;   // tile offset of the pixel tap (di, dj) comes from
+    v16f D0, D1;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) D0[v] = D1[v] = 0.0f;
+    float S0 = 0.0f, S1 = 0.0f;
+    for (int i = t; i < tile_px * 4; i += 256) smem[i] = 0.0f;
+    const int npatch = (int)(g.npix / g.HW), nsteps = (g.HW + 1) >> 1;
+    for (int b = blockIdx.x; b < npatch; b += gridDim.x) {
+        __syncthreads();   // the border is zero / the previous patch is done with
+        for (int px = t; px < g.HW; px += 256) {
+            const int r = px / g.W, c = px - r * g.W;
+            reinterpret_cast<float4 *>(smem)[(r + 1) * Wp + c + 1] = reinterpret_cast<const float4 *>(gu)[(int64_t)b * g.HW + px];
+        }
+        __syncthreads();
+        const float *hb = h2 + (int64_t)b * g.HW * 32;
+        for (int s = wv; s < nsteps; s += 4) {
+            const int pp = 2 * s + half;
+            float a = 0.0f, b0 = 0.0f, b1 = 0.0f;
+            if (pp < g.HW) {
+                const int r = pp / g.W, c = pp - r * g.W, tp = (r + 1) * Wp + c + 1;
+                a = fmaxf((hb[pp * 32 + col] - m) * rs, 0.0f);
+                b0 = smem[(tp - d0) * 4 + q];
+                if (col < 4) b1 = smem[(tp - d1) * 4 + q];
+            }
+            S0 += b0;
+            S1 += b1;
+            D0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, D0, 0, 0, 0);
+            D1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, D1, 0, 0, 0);
+        }
+    }
+    const Acc dst = G + off_w3;
+    mfma_tile_to_slots(D0, red, dst, g.nslot, [](int i, int c) { return (c >> 2) * 132 + i * 4 + (c & 3); });
+    mfma_tile_to_slots(D1, red, dst, g.nslot, [](int i, int c) { return c < 4 ? 8 * 132 + i * 4 + c : -1; });
+    cs[0][wv][ln] = S0;
+    cs[1][wv][ln] = S1;
+    __syncthreads();
+    if (t < 36) {   // column sums over the 4 wavefronts and both lane halves: t = tap * 4 + q
+        const int k = t < 32 ? 0 : 1, c = t < 32 ? t : t - 32;
+        float tot = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) tot += cs[k][w][c] + cs[k][w][c + 32];
+        cst[t] = tot;
+    }
+    __syncthreads();
+    if (t < 36) {
+        float *d = dst.p + (size_t)((t >> 2) * 132 + 128 + (t & 3)) * NSLOT;
+        d[blockIdx.x] = cst[16 + (t & 3)] - cst[t];
+        for (int k = blockIdx.x + gridDim.x; k < g.nslot; k += gridDim.x) d[k] = 0.0f;
+    }
+}
+
 // chain rule of the scalar parameterisations: dA -> PLU factors, d(a,b) -> sdn5 variables, gain_val
 __global__ void k_finish(TLayers ls, const float *__restrict__ P, CondIdx ci, int HW, const double *__restrict__ dAbuf,
                          const double *__restrict__ dabbuf, const double *__restrict__ dgbuf, double *__restrict__ G)
@@ -1857,6 +1989,7 @@ struct nf_trainer {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork[3] = {nullptr, nullptr, nullptr}, ev_done[3] = {nullptr, nullptr, nullptr};
     bool done_pending[3] = {false, false, false};
+    int wide_mfma = 255;   // NF_TRAIN_WIDE_MFMA: width-32 stages on the matrix cores (bit 0 filter gradients; 0: layer kernels only)
     int tiled = 3;   // NF_TRAIN_TILED: bit 0 = tiled backward stages, bit 1 = tiled forward stages (0: layer kernels only)
     std::vector<void *> owned;
     bool has_sdn = false;
@@ -1974,8 +2107,16 @@ void coupling_backward(nf_trainer *t, const Geo &g, const TLayer &L, const float
     // one fork per coupling (every event operation costs host time): all three producers are done
     (void)hipEventRecord(t->ev_fork[0], st);
     (void)hipStreamWaitEvent(sd, t->ev_fork[0], 0);
-    hipLaunchKernelGGL(k_w3_grad<W>, dim3(ng, 9), dim3(TB), 0, sd, g, c.h2, bn2, gu, off_w3, G);
-    hipLaunchKernelGGL(k_w2_grad<W>, dim3(ng, w), dim3(TB), 0, sd, g, c.h1, bn1, t1, off_w2, G);
+    if (W == 32 && (t->wide_mfma & 1)) {
+        const unsigned npatch = (unsigned)(g.npix / g.HW), nw = std::min<unsigned>((unsigned)g.nslot, 512u);
+        const size_t tile = (size_t)(g.H + 2) * (g.W + 2) * 4 * sizeof(float);
+        hipLaunchKernelGGL(k_w3_grad_mfma32, dim3(std::min<unsigned>(npatch, (unsigned)g.nslot)), dim3(256), tile, sd, g, c.h2, bn2,
+                           (const float *)gu, off_w3, G);
+        hipLaunchKernelGGL(k_w2_grad_mfma32, dim3(nw), dim3(256), 0, sd, g, c.h1, bn1, (const float *)t1, off_w2, G);
+    } else {
+        hipLaunchKernelGGL(k_w3_grad<W>, dim3(ng, 9), dim3(TB), 0, sd, g, c.h2, bn2, gu, off_w3, G);
+        hipLaunchKernelGGL(k_w2_grad<W>, dim3(ng, w), dim3(TB), 0, sd, g, c.h1, bn1, t1, off_w2, G);
+    }
     hipLaunchKernelGGL(k_w1_grad<W>, dim3(ng, 9), dim3(TB), 0, sd, g, zin, t2, off_w1, G);
     (void)hipEventRecord(t->ev_done[par], sd);
     t->done_pending[par] = true;
@@ -2166,6 +2307,7 @@ int nf_trainer_create(const nf_config *cfg, const nf_layer_desc *layers, const f
     if (!t) return nf_fail(NF_ENOMEM, "out of host memory");
     t->cfg = *cfg;
     if (const char *e = getenv("NF_TRAIN_TILED")) t->tiled = atoi(e);
+    if (const char *e = getenv("NF_TRAIN_WIDE_MFMA")) t->wide_mfma = atoi(e);
     t->max_batch = max_batch;
     t->optimizer = optimizer;
     t->n_params = (int)n_params;
