@@ -548,10 +548,16 @@ __global__ void k_c1_fwd(Geo g, const float *__restrict__ zin, const float *__re
 // BN finalisers, fused into the kernel that consumes them: EVERY workgroup adds up the slot sums
 // (one wavefront per channel, fp64) and keeps (mean, 1/sqrt(var+eps)) in LDS; workgroup 0 also
 // publishes them for the backward pass and moves the running statistics (layers.py:388-393).
+// fin: a finaliser kernel (k_bn_fin, wide couplings) already did all of this; the moments are read from bn_out.
 template <int W>
 __device__ __forceinline__ void bn_from_slots(Acc stats, int nslot, double n, float *sh, float *__restrict__ P,
-                                              int off_mean, int off_var, float *__restrict__ bn_out)
+                                              int off_mean, int off_var, float *__restrict__ bn_out, bool fin = false)
 {
+    if (fin) {
+        if (threadIdx.x < 2 * W) sh[threadIdx.x] = bn_out[threadIdx.x];
+        __syncthreads();
+        return;
+    }
     for (int j = threadIdx.x >> 6; j < W; j += TB / 64) {
         double sm, sq;
         acc_total2(stats + j, stats + W + j, nslot, sm, sq);
@@ -575,8 +581,13 @@ __device__ __forceinline__ void bn_from_slots(Acc stats, int nslot, double n, fl
 
 // the two batch means of the BN backward formula, same scheme
 template <int W>
-__device__ __forceinline__ void bnb_from_slots(Acc bstats, int nslot, double n, float *sh)
+__device__ __forceinline__ void bnb_from_slots(Acc bstats, int nslot, double n, float *sh, const float *__restrict__ pre = nullptr)
 {
+    if (pre) {   // k_bnb_fin already added the slots up
+        if (threadIdx.x < 2 * W) sh[threadIdx.x] = pre[threadIdx.x];
+        __syncthreads();
+        return;
+    }
     for (int j = threadIdx.x >> 6; j < W; j += TB / 64) {
         double a, b;
         acc_total2(bstats + j, bstats + W + j, nslot, a, b);
@@ -588,13 +599,46 @@ __device__ __forceinline__ void bnb_from_slots(Acc bstats, int nslot, double n, 
     __syncthreads();
 }
 
+// Wide couplings: with W channels and up to 1 024 slots, every workgroup adding up the slots itself reads 8 W KB from L2 —
+// 256 KB per workgroup at width 32, as much in total as the activation tensor (measured: 120 of the 240 us of a stage
+// kernel).  There a one-wavefront-per-channel kernel does it once; the extra launch is noise next to 100-us stages.
+__global__ __launch_bounds__(64) void k_bn_fin(Acc stats, int W, int nslot, double n, float *__restrict__ P, int off_mean, int off_var,
+                                               float *__restrict__ bn_out)
+{
+    const int j = blockIdx.x;
+    double sm, sq;
+    acc_total2(stats + j, stats + W + j, nslot, sm, sq);
+    const double m = sm / n;
+    double v = sq / n - m * m;
+    if (v < 0.0) v = 0.0;
+    if (threadIdx.x == 0) {
+        const float mf = (float)m;
+        bn_out[j] = mf;
+        bn_out[W + j] = (float)(1.0 / sqrt(v + (double)kBnEps));
+        P[off_mean + j] -= kBnDecay * (P[off_mean + j] - mf);
+        P[off_var + j] -= kBnDecay * (P[off_var + j] - (float)v);
+    }
+}
+
+__global__ __launch_bounds__(64) void k_bnb_fin(Acc bstats, int W, int nslot, double n, float *__restrict__ out)
+{
+    const int j = blockIdx.x;
+    double a, b;
+    acc_total2(bstats + j, bstats + W + j, nslot, a, b);
+    if (threadIdx.x == 0) {
+        out[j] = (float)(a / n);
+        out[W + j] = (float)(b / n);
+    }
+}
+
 // BN1 + ReLU + l_2 (1x1) + bias; statistics of the result
 template <int W>
 __global__ void k_c2_fwd(Geo g, const float *__restrict__ h1, Acc stats1, double n, float *__restrict__ P, int off_m1,
-                         float *__restrict__ bn1_out, int off_w2, float *__restrict__ h2, Acc stats, const float *__restrict__ Pw)
+                         float *__restrict__ bn1_out, int off_w2, float *__restrict__ h2, Acc stats, const float *__restrict__ Pw,
+                         bool fin)
 {   // Pw = P, read-only view for the filters (see k_tiled_fwd)
     __shared__ float bn1[2 * W];
-    bn_from_slots<W>(stats1, g.nslot, n, bn1, P, off_m1, off_m1 + W, bn1_out);
+    bn_from_slots<W>(stats1, g.nslot, n, bn1, P, off_m1, off_m1 + W, bn1_out, fin);
     const float *W2 = Pw + off_w2, *b2 = W2 + W * W;
     float s[W], q[W];
 #pragma unroll
@@ -660,10 +704,10 @@ __device__ __forceinline__ void l_last_u(const Geo &g, int b, int r, int c, cons
 template <int W>
 __global__ void k_c3_fwd(Geo g, const float *__restrict__ zin, const float *__restrict__ h2, Acc stats2, double n,
                          float *__restrict__ P, int off_m2, float *__restrict__ bn2_out, int off_w3,
-                         float *__restrict__ zout, Acc ldacc, const float *__restrict__ Pw)
-{   // Pw = P, read-only view for the filters (see k_tiled_fwd)
+                         float *__restrict__ zout, Acc ldacc, const float *__restrict__ Pw, bool fin, float *__restrict__ u_out)
+{   // Pw = P, read-only view for the filters (see k_tiled_fwd);  u_out: keep l_last's output for the backward pass (wide couplings)
     __shared__ float bn2[2 * W];
-    bn_from_slots<W>(stats2, g.nslot, n, bn2, P, off_m2, off_m2 + W, bn2_out);
+    bn_from_slots<W>(stats2, g.nslot, n, bn2, P, off_m2, off_m2 + W, bn2_out, fin);
     const float *W3 = Pw + off_w3, *b3 = W3 + 36 * (W + 1), *logs = b3 + 4;
     const float sc = logs[4];
     const float e30 = expf(kLogscale * logs[0]), e31 = expf(kLogscale * logs[1]), e32 = expf(kLogscale * logs[2]),
@@ -675,6 +719,7 @@ __global__ void k_c3_fwd(Geo g, const float *__restrict__ zin, const float *__re
             const int rem = (int)(p - (int64_t)b * g.HW), r = rem / g.W, c = rem - r * g.W;
             float u[4];
             l_last_u<W>(g, b, r, c, h2, bn2, W3, b3, u);
+            if (u_out) reinterpret_cast<float4 *>(u_out)[p] = make_float4(u[0], u[1], u[2], u[3]);
             const float4 zi = reinterpret_cast<const float4 *>(zin)[p];
             const float sh0 = u[0] * e30, sh1 = u[1] * e31;
             const float ls0 = sc * tanhf(u[2] * e32), ls1 = sc * tanhf(u[3] * e33);
@@ -854,8 +899,9 @@ __global__ void k_mix_bwd(Geo g, const float *__restrict__ zin, const float *__r
 template <int W>
 __global__ void k_c3_bwd(Geo g, const float *__restrict__ zin, const float *__restrict__ h2, const float *__restrict__ bn2,
                          const float *__restrict__ P, int off_w3, float invB, float *__restrict__ dz,
-                         float *__restrict__ gu, Acc G, const float *__restrict__ zlat)
+                         float *__restrict__ gu, Acc G, const float *__restrict__ zlat, const float *__restrict__ u_in)
 {   // zlat != null: this is the first stage of the backward pass; d loss / d latent = latent / B is formed here (k_dz_init)
+    // u_in != null: l_last's output was kept by the forward pass (wide couplings: recomputing it is 1 188 MAC per pixel)
     const float *W3 = P + off_w3, *b3 = W3 + 36 * (W + 1), *logs = b3 + 4;
     const float sc = logs[4];
     const int off_b3 = off_w3 + 36 * (W + 1);
@@ -867,7 +913,12 @@ __global__ void k_c3_bwd(Geo g, const float *__restrict__ zin, const float *__re
         if (p < g.npix) {
             const int b = (int)(p / g.HW), rem = (int)(p - (int64_t)b * g.HW), r = rem / g.W, c = rem - r * g.W;
             float u[4];
-            l_last_u<W>(g, b, r, c, h2, bn2, W3, b3, u);
+            if (u_in) {
+                const float4 uv = reinterpret_cast<const float4 *>(u_in)[p];
+                u[0] = uv.x; u[1] = uv.y; u[2] = uv.z; u[3] = uv.w;
+            } else {
+                l_last_u<W>(g, b, r, c, h2, bn2, W3, b3, u);
+            }
             const float4 zi = reinterpret_cast<const float4 *>(zin)[p];
             float4 d;
             if (zlat) {
@@ -1009,10 +1060,10 @@ __global__ void k_reduce(int n, const float *__restrict__ part, int nslot, doubl
 template <int W>
 __global__ void k_c2_bwd(Geo g, const float *__restrict__ h1, const float *__restrict__ bn1, const float *__restrict__ h2,
                          const float *__restrict__ bn2, Acc bstats2, double n, const float *__restrict__ P,
-                         int off_w2, float *__restrict__ t1, float *__restrict__ t2, Acc bstats, Acc G)
+                         int off_w2, float *__restrict__ t1, float *__restrict__ t2, Acc bstats, Acc G, const float *__restrict__ pre)
 {
     __shared__ float bb2[2 * W];
-    bnb_from_slots<W>(bstats2, g.nslot, n, bb2);
+    bnb_from_slots<W>(bstats2, g.nslot, n, bb2, pre);
     const float *W2 = P + off_w2;
     float s[W], q[W], gb[W];
 #pragma unroll
@@ -1073,10 +1124,10 @@ __global__ void k_w2_grad(Geo g, const float *__restrict__ h1, const float *__re
 // coupling, stage 4: BN1 backward -> g_h1 (t2, in place), d l_1/b
 template <int W>
 __global__ void k_c1_bwd(Geo g, const float *__restrict__ h1, const float *__restrict__ bn1, Acc bstats1, double n,
-                         int off_b1, float *__restrict__ t2, Acc G)
+                         int off_b1, float *__restrict__ t2, Acc G, const float *__restrict__ pre)
 {
     __shared__ float bb1[2 * W];
-    bnb_from_slots<W>(bstats1, g.nslot, n, bb1);
+    bnb_from_slots<W>(bstats1, g.nslot, n, bb1, pre);
     float gb[W];
 #pragma unroll
     for (int j = 0; j < W; ++j) gb[j] = 0.0f;
@@ -1092,6 +1143,49 @@ __global__ void k_c1_bwd(Geo g, const float *__restrict__ h1, const float *__res
         }
     }
     acc_add_n<W>(G + off_b1, gb, g.nslot);
+}
+
+// k_c1_bwd for wide couplings: one float4 of the [pixel][W] tensors per thread and step, so that a wavefront touches 1 KB of
+// consecutive memory per load (the per-pixel form walks 128-byte rows with a 128-byte lane stride); the grid stride is a
+// multiple of W / 4, so a thread keeps its 4 channels.
+template <int W>
+__global__ __launch_bounds__(256) void k_c1_bwd_flat(Geo g, const float *__restrict__ h1, const float *__restrict__ bn1,
+                                                     const float *__restrict__ bb1, int off_b1, float *__restrict__ t2, Acc G)
+{
+    __shared__ float red[256 * 4];
+    constexpr int Q = W / 4;
+    const int t = threadIdx.x, cg = t % Q;
+    float m[4], rs[4], ba[4], bq[4], gb[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        m[k] = bn1[4 * cg + k];
+        rs[k] = bn1[W + 4 * cg + k];
+        ba[k] = bb1[4 * cg + k];
+        bq[k] = bb1[W + 4 * cg + k];
+    }
+    const int64_t total = g.npix * Q;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + t; e < total; e += (int64_t)gridDim.x * 256) {
+        const float4 h = reinterpret_cast<const float4 *>(h1)[e], gx = reinterpret_cast<const float4 *>(t2)[e];
+        const float hv[4] = {h.x, h.y, h.z, h.w}, gv[4] = {gx.x, gx.y, gx.z, gx.w};
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float xh = (hv[k] - m[k]) * rs[k];
+            o[k] = rs[k] * (gv[k] - ba[k] - xh * bq[k]);
+            gb[k] += o[k];
+        }
+        reinterpret_cast<float4 *>(t2)[e] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) red[t * 4 + k] = gb[k];
+    __syncthreads();
+    if (t < W) {   // channel t: threads with t' % Q == t / 4, component t % 4
+        float tot = 0.0f;
+        for (int u = t >> 2; u < 256; u += Q) tot += red[u * 4 + (t & 3)];
+        float *d = (G + off_b1 + t).p;
+        d[blockIdx.x] = tot;
+        for (int q = blockIdx.x + gridDim.x; q < g.nslot; q += gridDim.x) d[q] = 0.0f;
+    }
 }
 
 // d l_1/W: one filter tap per blockIdx.y
@@ -1779,6 +1873,164 @@ __global__ __launch_bounds__(256) void k_w3_grad_mfma32(Geo g, const float *__re
     }
 }
 
+// ---- width 32: the 1x1 layer l_2, forward and transposed, as pixel GEMMs -------------------------------------------------
+// 32 consecutive pixels of the batch on the N axis of v_mfma_f32_32x32x2_f32 (lane & 31 = the pixel, both lane halves),
+// the 32 output channels on M, the 32 input channels on K in the order k(step s, lane half h) = 16 h + s: lane (p, h) then
+// feeds the 16 consecutive floats [16 h, 16 h + 16) of its pixel's row — four 16-byte loads per tensor — and owns, in the
+// result, the 16 output channels c(v, h) = 8 (v >> 2) + 4 h + (v & 3), four 16-byte stores.  The layer kernels walk the same
+// rows one pixel per thread with W accumulators each (0.6 ms per coupling for the backward stage at 1 024 patches).
+// Per-channel sums: 16 registers per lane, added up over the 32 lanes of a half and the 4 wavefronts once, at the end.
+
+// red: [4][64][16];  vals[k] of lane (col, half) belongs to channel chan(k, half);  -> dst + chan
+template <typename F>
+__device__ __forceinline__ void lane_sums_to_slots(const float (&vals)[16], float *red, Acc dst, int nslot, F chan)
+{
+    const int t = threadIdx.x, wv = t >> 6, ln = t & 63;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) red[(wv * 64 + ln) * 16 + k] = vals[k];
+    __syncthreads();
+    if (t < 32) {   // t = (half, k)
+        const int half = t >> 4, k = t & 15;
+        float tot = 0.0f;
+        for (int w = 0; w < 4; ++w)
+            for (int c = 0; c < 32; ++c) tot += red[(w * 64 + half * 32 + c) * 16 + k];
+        float *d = dst.p + (size_t)chan(k, half) * NSLOT;
+        d[blockIdx.x] = tot;
+        for (int q = blockIdx.x + gridDim.x; q < nslot; q += gridDim.x) d[q] = 0.0f;
+    }
+}
+
+__device__ __forceinline__ int mfma_row(int v, int half) { return 8 * (v >> 2) + 4 * half + (v & 3); }
+
+// BN1 + ReLU + l_2 + bias; statistics of the result (k_c2_fwd at width 32)
+__global__ __launch_bounds__(256) void k_c2_fwd_mfma32(Geo g, const float *__restrict__ h1, Acc stats1, double n, float *__restrict__ P,
+                                                       int off_m1, float *__restrict__ bn1_out, int off_w2, float *__restrict__ h2,
+                                                       Acc stats, const float *__restrict__ Pw, bool fin)
+{
+    constexpr int W = 32;
+    __shared__ float bn1[2 * W];
+    __shared__ float red[4 * 64 * 16];
+    bn_from_slots<W>(stats1, g.nslot, n, bn1, P, off_m1, off_m1 + W, bn1_out, fin);
+    const float *W2 = Pw + off_w2, *b2 = W2 + W * W;
+    const int t = threadIdx.x, wv = t >> 6, ln = t & 63, col = ln & 31, half = ln >> 5;
+    float a[16];   // A[out = col][k(s, half)] = W2[16 half + s][col]
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a[k] = W2[(16 * half + k) * W + col];
+    float m1[16], r1[16], bo[16], s2[16], q2[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        m1[k] = bn1[16 * half + k];
+        r1[k] = bn1[W + 16 * half + k];
+        bo[k] = b2[mfma_row(k, half)];
+        s2[k] = q2[k] = 0.0f;
+    }
+    const int64_t ntiles = (g.npix + 31) >> 5;
+    for (int64_t T = (int64_t)blockIdx.x * 4 + wv; T < ntiles; T += (int64_t)gridDim.x * 4) {
+        const int64_t p = T * 32 + col;
+        const bool in = p < g.npix;
+        float x[16];
+#pragma unroll
+        for (int k = 0; k < 16; k += 4) {
+            const float4 v = in ? *reinterpret_cast<const float4 *>(h1 + p * W + 16 * half + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            x[k] = v.x; x[k + 1] = v.y; x[k + 2] = v.z; x[k + 3] = v.w;
+        }
+        v16f D;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) D[v] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float b = in ? fmaxf((x[k] - m1[k]) * r1[k], 0.0f) : 0.0f;
+            D = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], b, D, 0, 0, 0);
+        }
+        if (in) {
+#pragma unroll
+            for (int v = 0; v < 16; v += 4) {
+                const float4 o = make_float4(D[v] + bo[v], D[v + 1] + bo[v + 1], D[v + 2] + bo[v + 2], D[v + 3] + bo[v + 3]);
+                *reinterpret_cast<float4 *>(h2 + p * W + mfma_row(v, half)) = o;
+                s2[v] += o.x; s2[v + 1] += o.y; s2[v + 2] += o.z; s2[v + 3] += o.w;
+                q2[v] = fmaf(o.x, o.x, q2[v]); q2[v + 1] = fmaf(o.y, o.y, q2[v + 1]);
+                q2[v + 2] = fmaf(o.z, o.z, q2[v + 2]); q2[v + 3] = fmaf(o.w, o.w, q2[v + 3]);
+            }
+        }
+    }
+    lane_sums_to_slots(s2, red, stats, g.nslot, [](int k, int h) { return mfma_row(k, h); });
+    lane_sums_to_slots(q2, red, stats, g.nslot, [](int k, int h) { return 32 + mfma_row(k, h); });
+}
+
+// BN2 backward -> g_h2 (t1, in place), d l_2/b; transposed l_2 + ReLU mask -> d loss / d xhat1 (t2) and its two batch sums
+// (k_c2_bwd at width 32)
+__global__ __launch_bounds__(256) void k_c2_bwd_mfma32(Geo g, const float *__restrict__ h1, const float *__restrict__ bn1,
+                                                       const float *__restrict__ h2, const float *__restrict__ bn2, Acc bstats2,
+                                                       double n, const float *__restrict__ P, int off_w2, float *__restrict__ t1,
+                                                       float *__restrict__ t2, Acc bstats, Acc G, const float *__restrict__ pre)
+{
+    constexpr int W = 32;
+    __shared__ float bb2[2 * W], sbn2[2 * W], sbn1[2 * W];
+    __shared__ float red[4 * 64 * 16];
+    if (threadIdx.x < 2 * W) {
+        sbn2[threadIdx.x] = bn2[threadIdx.x];
+        sbn1[threadIdx.x] = bn1[threadIdx.x];
+    }
+    bnb_from_slots<W>(bstats2, g.nslot, n, bb2, pre);
+    const float *W2 = P + off_w2;
+    const int t = threadIdx.x, wv = t >> 6, ln = t & 63, col = ln & 31, half = ln >> 5;
+    float a[16];   // A[in = col][k(s, half)] = W2[col][16 half + s]
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a[k] = W2[col * W + 16 * half + k];
+    float gb[16], s1[16], q1[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) gb[k] = s1[k] = q1[k] = 0.0f;
+    const int64_t ntiles = (g.npix + 31) >> 5;
+    for (int64_t T = (int64_t)blockIdx.x * 4 + wv; T < ntiles; T += (int64_t)gridDim.x * 4) {
+        const int64_t p = T * 32 + col;
+        const bool in = p < g.npix;
+        float gx[16], hv[16], x1[16];
+#pragma unroll
+        for (int k = 0; k < 16; k += 4) {
+            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 u = in ? *reinterpret_cast<const float4 *>(t1 + p * W + 16 * half + k) : z4;
+            const float4 v = in ? *reinterpret_cast<const float4 *>(h2 + p * W + 16 * half + k) : z4;
+            const float4 y = in ? *reinterpret_cast<const float4 *>(h1 + p * W + mfma_row(k, half)) : z4;
+            gx[k] = u.x; gx[k + 1] = u.y; gx[k + 2] = u.z; gx[k + 3] = u.w;
+            hv[k] = v.x; hv[k + 1] = v.y; hv[k + 2] = v.z; hv[k + 3] = v.w;
+            x1[k] = y.x; x1[k + 1] = y.y; x1[k + 2] = y.z; x1[k + 3] = y.w;
+        }
+        v16f D;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) D[v] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int j = 16 * half + k;
+            const float rs = sbn2[W + j], xh = (hv[k] - sbn2[j]) * rs;
+            const float gh2 = in ? rs * (gx[k] - bb2[j] - xh * bb2[W + j]) : 0.0f;
+            gx[k] = gh2;
+            gb[k] += gh2;
+            D = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], gh2, D, 0, 0, 0);
+        }
+        if (in) {
+#pragma unroll
+            for (int k = 0; k < 16; k += 4)
+                *reinterpret_cast<float4 *>(t1 + p * W + 16 * half + k) = make_float4(gx[k], gx[k + 1], gx[k + 2], gx[k + 3]);
+            float o[16];
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int i = mfma_row(v, half);
+                const float xh = (x1[v] - sbn1[i]) * sbn1[W + i];
+                o[v] = xh > 0.0f ? D[v] : 0.0f;
+                s1[v] += o[v];
+                q1[v] = fmaf(o[v], xh, q1[v]);
+            }
+#pragma unroll
+            for (int v = 0; v < 16; v += 4)
+                *reinterpret_cast<float4 *>(t2 + p * W + mfma_row(v, half)) = make_float4(o[v], o[v + 1], o[v + 2], o[v + 3]);
+        }
+    }
+    lane_sums_to_slots(s1, red, bstats, g.nslot, [](int k, int h) { return mfma_row(k, h); });
+    lane_sums_to_slots(q1, red, bstats, g.nslot, [](int k, int h) { return 32 + mfma_row(k, h); });
+    lane_sums_to_slots(gb, red, G + off_w2 + W * W, g.nslot, [](int k, int h) { return 16 * h + k; });
+}
+
 // chain rule of the scalar parameterisations: dA -> PLU factors, d(a,b) -> sdn5 variables, gain_val
 __global__ void k_finish(TLayers ls, const float *__restrict__ P, CondIdx ci, int HW, const double *__restrict__ dAbuf,
                          const double *__restrict__ dabbuf, const double *__restrict__ dgbuf, double *__restrict__ G)
@@ -1953,6 +2205,7 @@ __global__ void k_momentum(int n, float *__restrict__ P, const float *__restrict
 
 struct Cpl {      // per-coupling workspace
     float *h1 = nullptr, *h2 = nullptr;
+    float *u = nullptr;                   // l_last's output, kept for the backward pass (wide couplings only)
     int f_bn1, f_bn2, f_bb1, f_bb2;       // offsets into the float scalar buffer
     int d_st1, d_st2, d_bs1, d_bs2;       // offsets into the double buffer
 };
@@ -1989,7 +2242,7 @@ struct nf_trainer {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork[3] = {nullptr, nullptr, nullptr}, ev_done[3] = {nullptr, nullptr, nullptr};
     bool done_pending[3] = {false, false, false};
-    int wide_mfma = 255;   // NF_TRAIN_WIDE_MFMA: width-32 stages on the matrix cores (bit 0 filter gradients; 0: layer kernels only)
+    int wide_mfma = 255;   // NF_TRAIN_WIDE_MFMA: width-32 stages on the matrix cores (bit 0 filter gradients, 1 l_2 forward, 2 l_2 backward, 3 statistics finalisers; 0: layer kernels only)
     int tiled = 3;   // NF_TRAIN_TILED: bit 0 = tiled backward stages, bit 1 = tiled forward stages (0: layer kernels only)
     std::vector<void *> owned;
     bool has_sdn = false;
@@ -2068,11 +2321,23 @@ void coupling_forward(nf_trainer *t, const Geo &g, const TLayer &L, const float 
         hipLaunchKernelGGL((k_c1_fwd<W, false>), dim3(nb), dim3(TB), 0, st, g, zin, (const float *)nullptr, (float *)nullptr,
                            t->d_params, off_w1, c.h1, t->acc(c.d_st1));
     sync_slots(t, t->acc(c.d_st1), 2 * w, g.nslot, st);
-    hipLaunchKernelGGL(k_c2_fwd<W>, dim3(nb), dim3(TB), 0, st, g, c.h1, t->acc(c.d_st1), n, t->d_params, off_m1,
-                       t->d_flt + c.f_bn1, off_w2, c.h2, t->acc(c.d_st2), (const float *)t->d_params);
+    // wide couplings: the slot sums are added up once, by a finaliser kernel, not by every workgroup of the consumer
+    const bool fin = W >= 16 && (t->wide_mfma & 8);
+    if (fin)
+        hipLaunchKernelGGL(k_bn_fin, dim3(w), dim3(64), 0, st, t->acc(c.d_st1), w, g.nslot, n, t->d_params, off_m1, off_m1 + w,
+                           t->d_flt + c.f_bn1);
+    if (W == 32 && (t->wide_mfma & 2))
+        hipLaunchKernelGGL(k_c2_fwd_mfma32, dim3(nb), dim3(256), 0, st, g, (const float *)c.h1, t->acc(c.d_st1), n, t->d_params, off_m1,
+                           t->d_flt + c.f_bn1, off_w2, c.h2, t->acc(c.d_st2), (const float *)t->d_params, fin);
+    else
+        hipLaunchKernelGGL(k_c2_fwd<W>, dim3(nb), dim3(TB), 0, st, g, c.h1, t->acc(c.d_st1), n, t->d_params, off_m1,
+                           t->d_flt + c.f_bn1, off_w2, c.h2, t->acc(c.d_st2), (const float *)t->d_params, fin);
     sync_slots(t, t->acc(c.d_st2), 2 * w, g.nslot, st);
+    if (fin)
+        hipLaunchKernelGGL(k_bn_fin, dim3(w), dim3(64), 0, st, t->acc(c.d_st2), w, g.nslot, n, t->d_params, off_m2, off_m2 + w,
+                           t->d_flt + c.f_bn2);
     hipLaunchKernelGGL(k_c3_fwd<W>, dim3(nb), dim3(TB), 0, st, g, zin, c.h2, t->acc(c.d_st2), n, t->d_params, off_m2,
-                       t->d_flt + c.f_bn2, off_w3, zout, ldacc, (const float *)t->d_params);
+                       t->d_flt + c.f_bn2, off_w3, zout, ldacc, (const float *)t->d_params, fin, c.u);
 }
 
 template <int W>
@@ -2097,13 +2362,25 @@ void coupling_backward(nf_trainer *t, const Geo &g, const TLayer &L, const float
         (void)hipStreamWaitEvent(st, t->ev_done[par], 0);
         t->done_pending[par] = false;
     }
-    hipLaunchKernelGGL(k_c3_bwd<W>, dim3(nb), dim3(TB), 0, st, g, zin, c.h2, bn2, t->d_params, off_w3, invB, t->dz, gu, G, zlat);
+    hipLaunchKernelGGL(k_c3_bwd<W>, dim3(nb), dim3(TB), 0, st, g, zin, c.h2, bn2, t->d_params, off_w3, invB, t->dz, gu, G, zlat,
+                       (const float *)c.u);
     hipLaunchKernelGGL(k_c3_dh<W>, dim3(nb), dim3(TB), 0, st, g, c.h2, bn2, t->d_params, off_w3, gu, t1, t->acc(c.d_bs2));
     sync_slots(t, t->acc(c.d_bs2), 2 * w, g.nslot, st);
-    hipLaunchKernelGGL(k_c2_bwd<W>, dim3(nb), dim3(TB), 0, st, g, c.h1, bn1, c.h2, bn2, t->acc(c.d_bs2), n, t->d_params, off_w2,
-                       t1, t2, t->acc(c.d_bs1), G);
+    const bool fin = W >= 16 && (t->wide_mfma & 8);
+    const float *pre2 = fin ? t->d_flt + c.f_bb2 : nullptr, *pre1 = fin ? t->d_flt + c.f_bb1 : nullptr;
+    if (fin) hipLaunchKernelGGL(k_bnb_fin, dim3(w), dim3(64), 0, st, t->acc(c.d_bs2), w, g.nslot, n, t->d_flt + c.f_bb2);
+    if (W == 32 && (t->wide_mfma & 4))
+        hipLaunchKernelGGL(k_c2_bwd_mfma32, dim3(nb), dim3(256), 0, st, g, (const float *)c.h1, bn1, (const float *)c.h2, bn2,
+                           t->acc(c.d_bs2), n, (const float *)t->d_params, off_w2, t1, t2, t->acc(c.d_bs1), G, pre2);
+    else
+        hipLaunchKernelGGL(k_c2_bwd<W>, dim3(nb), dim3(TB), 0, st, g, c.h1, bn1, c.h2, bn2, t->acc(c.d_bs2), n, t->d_params, off_w2,
+                           t1, t2, t->acc(c.d_bs1), G, pre2);
     sync_slots(t, t->acc(c.d_bs1), 2 * w, g.nslot, st);
-    hipLaunchKernelGGL(k_c1_bwd<W>, dim3(nb), dim3(TB), 0, st, g, c.h1, bn1, t->acc(c.d_bs1), n, off_b1, t2, G);
+    if (fin) hipLaunchKernelGGL(k_bnb_fin, dim3(w), dim3(64), 0, st, t->acc(c.d_bs1), w, g.nslot, n, t->d_flt + c.f_bb1);
+    if (fin && W % 4 == 0 && (256 % (W / 4)) == 0)
+        hipLaunchKernelGGL(k_c1_bwd_flat<(W >= 16 ? W : 16)>, dim3(nb), dim3(256), 0, st, g, (const float *)c.h1, bn1, pre1, off_b1, t2, G);
+    else
+        hipLaunchKernelGGL(k_c1_bwd<W>, dim3(nb), dim3(TB), 0, st, g, c.h1, bn1, t->acc(c.d_bs1), n, off_b1, t2, G, pre1);
     // one fork per coupling (every event operation costs host time): all three producers are done
     (void)hipEventRecord(t->ev_fork[0], st);
     (void)hipStreamWaitEvent(sd, t->ev_fork[0], 0);
@@ -2151,7 +2428,7 @@ void coupling_forward_tiled(nf_trainer *t, const Geo &g, const TLayer &L, const 
     }
     sync_slots(t, t->acc(c.d_st1), 2 * w, g.nslot, st);
     hipLaunchKernelGGL(k_c2_fwd<W>, dim3(nb), dim3(TB), 0, st, g, c.h1, t->acc(c.d_st1), n, t->d_params, off_m1,
-                       t->d_flt + c.f_bn1, off_w2, c.h2, t->acc(c.d_st2), (const float *)t->d_params);
+                       t->d_flt + c.f_bn1, off_w2, c.h2, t->acc(c.d_st2), (const float *)t->d_params, false);
     sync_slots(t, t->acc(c.d_st2), 2 * w, g.nslot, st);
     const TiledF3 f3{zin, c.h2, t->acc(c.d_st2), off_m2, off_w3, t->d_flt + c.f_bn2, zout, ldacc};
     if (nxt) {
@@ -2201,7 +2478,7 @@ void coupling_backward_tiled(nf_trainer *t, const Geo &g, const TLayer &L, const
     }
     sync_slots(t, t->acc(c.d_bs2), 2 * w, g.nslot, st);
     hipLaunchKernelGGL(k_c2_bwd<W>, dim3(nb), dim3(TB), 0, st, g, c.h1, bn1, c.h2, bn2, t->acc(c.d_bs2), n, t->d_params, off_w2,
-                       t1, t2, t->acc(c.d_bs1), G);
+                       t1, t2, t->acc(c.d_bs1), G, (const float *)nullptr);
     sync_slots(t, t->acc(c.d_bs1), 2 * w, g.nslot, st);
     const TiledC cc{zmix_in, A, c.h1, bn1, t2, off_w1, t->acc(c.d_bs1), dA};
     TiledA below{};
@@ -2472,6 +2749,7 @@ int nf_trainer_create(const nf_config *cfg, const nf_layer_desc *layers, const f
     for (Cpl &c : t->cpl) {
         NF_TRY(dev_alloc(t, (void **)&c.h1, act * w * sizeof(float)));
         NF_TRY(dev_alloc(t, (void **)&c.h2, act * w * sizeof(float)));
+        if (w >= 16) NF_TRY(dev_alloc(t, (void **)&c.u, act * 4 * sizeof(float)));
     }
     for (int k = 0; k < 3; ++k) {
         NF_TRY(dev_alloc(t, (void **)&t->t1[k], act * w * sizeof(float)));
