@@ -1774,36 +1774,87 @@ __device__ __forceinline__ void mfma_tile_to_slots(const v16f &D, float *red, Ac
     }
 }
 
+// Operand staging: 32 consecutive rows of a [rows][32] tensor = 4 KB of consecutive memory.  The wavefront fetches them with
+// four 16-byte loads per lane (1 KB of whole cache lines per instruction; one dword per lane and MFMA step left the kernels
+// latency-bound at ~1 TB/s), parks them in its own LDS rows of 36 floats, and each MFMA step reads its two pixels back as
+// one ds_read_b32 per operand.  LDS instructions of one wavefront execute in order, so no barrier — only a compiler fence.
+constexpr int kRowPad = 36;
+struct RowTile {
+    float4 v[4];
+};
+__device__ __forceinline__ void rows_fetch(RowTile &r, const float *__restrict__ src, int64_t row0, int64_t row_end)
+{
+    const int ln = threadIdx.x & 63;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int64_t row = row0 + ((ln + 64 * m) >> 3);
+        r.v[m] = row < row_end ? reinterpret_cast<const float4 *>(src)[row * 8 + (ln & 7)] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// plain copy / BN + ReLU of the lane's 4 channels (4 (ln & 7) ..) on the way into LDS; rows past the end stay zero
+template <bool BNRELU>
+__device__ __forceinline__ void rows_park(const RowTile &r, float *lds, const float (&m)[4], const float (&rs)[4], int64_t row0,
+                                          int64_t row_end)
+{
+    const int ln = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int lr = (ln + 64 * k) >> 3;
+        float4 v = r.v[k];
+        if (BNRELU) {
+            const bool in = row0 + lr < row_end;
+            v.x = in ? fmaxf((v.x - m[0]) * rs[0], 0.0f) : 0.0f;
+            v.y = in ? fmaxf((v.y - m[1]) * rs[1], 0.0f) : 0.0f;
+            v.z = in ? fmaxf((v.z - m[2]) * rs[2], 0.0f) : 0.0f;
+            v.w = in ? fmaxf((v.w - m[3]) * rs[3], 0.0f) : 0.0f;
+        }
+        *reinterpret_cast<float4 *>(lds + lr * kRowPad + 4 * (ln & 7)) = v;
+    }
+}
+
 // d l_2/W[i][j] = sum_p relu(bn1(h1))[p][i] * g_h2[p][j]
 __global__ __launch_bounds__(256) void k_w2_grad_mfma32(Geo g, const float *__restrict__ h1, const float *__restrict__ bn1,
                                                         const float *__restrict__ t1, int off_w2, Acc G)
 {
-    __shared__ float red[4 * 16 * 64];
+    __shared__ float stage[4][2][32 * kRowPad];
+    float *red = &stage[0][0][0];   // [4][16][64], used once the pixel loop is over (mfma_tile_to_slots starts with a barrier)
+    static_assert(sizeof(stage) >= 4 * 16 * 64 * sizeof(float), "the reduction buffer must fit the staging area");
     const int t = threadIdx.x, wv = t >> 6, ln = t & 63, col = ln & 31, half = ln >> 5;
-    const float m = bn1[col], rs = bn1[32 + col];
+    float m[4], rs[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        m[k] = bn1[4 * (ln & 7) + k];
+        rs[k] = bn1[32 + 4 * (ln & 7) + k];
+    }
     v16f D;
 #pragma unroll
     for (int v = 0; v < 16; ++v) D[v] = 0.0f;
-    const int64_t nsteps = (g.npix + 1) >> 1, stride = (int64_t)gridDim.x * 4;
-    int64_t s = (int64_t)blockIdx.x * 4 + wv;
-    for (; s + 3 * stride < nsteps; s += 4 * stride) {   // four pixel pairs in flight
-        float a[4], b[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int64_t p = 2 * (s + k * stride) + half;
-            const bool in = p < g.npix;
-            a[k] = in ? h1[p * 32 + col] : 0.0f;
-            b[k] = in ? t1[p * 32 + col] : 0.0f;
-            a[k] = in ? fmaxf((a[k] - m) * rs, 0.0f) : 0.0f;
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) D = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], b[k], D, 0, 0, 0);
+    float *sa = stage[wv][0], *sb = stage[wv][1];
+    const int64_t ntiles = (g.npix + 31) >> 5, stride = (int64_t)gridDim.x * 4;
+    int64_t T = (int64_t)blockIdx.x * 4 + wv;
+    RowTile ra, rb;
+    if (T < ntiles) {
+        rows_fetch(ra, h1, T * 32, g.npix);
+        rows_fetch(rb, t1, T * 32, g.npix);
     }
-    for (; s < nsteps; s += stride) {
-        const int64_t p = 2 * s + half;
-        const bool in = p < g.npix;
-        const float a = in ? fmaxf((h1[p * 32 + col] - m) * rs, 0.0f) : 0.0f, b = in ? t1[p * 32 + col] : 0.0f;
-        D = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, D, 0, 0, 0);
+    for (; T < ntiles; T += stride) {
+        wave_lds_fence();                                  // the previous tile's reads are issued
+        rows_park<true>(ra, sa, m, rs, T * 32, g.npix);
+        rows_park<false>(rb, sb, m, rs, T * 32, g.npix);
+        if (T + stride < ntiles) {                         // next tile in flight during the MFMAs
+            rows_fetch(ra, h1, (T + stride) * 32, g.npix);
+            rows_fetch(rb, t1, (T + stride) * 32, g.npix);
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2)
+            D = __builtin_amdgcn_mfma_f32_32x32x2f32(sa[(2 * s2 + half) * kRowPad + col], sb[(2 * s2 + half) * kRowPad + col], D, 0, 0, 0);
     }
     mfma_tile_to_slots(D, red, G + off_w2, g.nslot, [](int i, int j) { return i * 32 + j; });
 }
@@ -1815,41 +1866,61 @@ __global__ __launch_bounds__(256) void k_w2_grad_mfma32(Geo g, const float *__re
 __global__ __launch_bounds__(256) void k_w3_grad_mfma32(Geo g, const float *__restrict__ h2, const float *__restrict__ bn2,
                                                         const float *__restrict__ gu, int off_w3, Acc G)
 {
-    extern __shared__ float smem[];   // gu tile [(H+2)(W+2)][4]
-    __shared__ float red[4 * 16 * 64];
+    extern __shared__ float smem[];   // gu tile [(H+2)(W+2)][4], then the tile index of every pixel of a patch (int)
+    __shared__ float stage[4][32 * kRowPad];
+    float *red = &stage[0][0];        // [4][16][64], used once the pixel loop is over
+    static_assert(sizeof(stage) >= 4 * 16 * 64 * sizeof(float), "the reduction buffer must fit the staging area");
     __shared__ float cs[2][4][64], cst[40];
     const int t = threadIdx.x, wv = t >> 6, ln = t & 63, col = ln & 31, half = ln >> 5;
     const int Wp = g.W + 2, tile_px = (g.H + 2) * Wp;
-    const float m = bn2[col], rs = bn2[32 + col];
+    float m[4], rs[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        m[k] = bn2[4 * (ln & 7) + k];
+        rs[k] = bn2[32 + 4 * (ln & 7) + k];
+    }
     const int tap0 = col >> 2, q = col & 3;
     const int d0 = (tap0 / 3 - 1) * Wp + (tap0 % 3 - 1), d1 = Wp + 1;   // tile offset of the pixel tap (di, dj) comes from
     v16f D0, D1;
 #pragma unroll
     for (int v = 0; v < 16; ++v) D0[v] = D1[v] = 0.0f;
     float S0 = 0.0f, S1 = 0.0f;
+    float *sa = stage[wv];
+    int *lut = reinterpret_cast<int *>(smem + tile_px * 4);   // pixel -> its position in the bordered tile (no division per step)
     for (int i = t; i < tile_px * 4; i += 256) smem[i] = 0.0f;
-    const int npatch = (int)(g.npix / g.HW), nsteps = (g.HW + 1) >> 1;
+    for (int px = t; px < g.HW; px += 256) {
+        const int r = px / g.W;
+        lut[px] = (r + 1) * Wp + (px - r * g.W) + 1;
+    }
+    const int npatch = (int)(g.npix / g.HW), ntiles = (g.HW + 31) >> 5;
     for (int b = blockIdx.x; b < npatch; b += gridDim.x) {
-        __syncthreads();   // the border is zero / the previous patch is done with
-        for (int px = t; px < g.HW; px += 256) {
-            const int r = px / g.W, c = px - r * g.W;
-            reinterpret_cast<float4 *>(smem)[(r + 1) * Wp + c + 1] = reinterpret_cast<const float4 *>(gu)[(int64_t)b * g.HW + px];
-        }
-        __syncthreads();
         const float *hb = h2 + (int64_t)b * g.HW * 32;
-        for (int s = wv; s < nsteps; s += 4) {
-            const int pp = 2 * s + half;
-            float a = 0.0f, b0 = 0.0f, b1 = 0.0f;
-            if (pp < g.HW) {
-                const int r = pp / g.W, c = pp - r * g.W, tp = (r + 1) * Wp + c + 1;
-                a = fmaxf((hb[pp * 32 + col] - m) * rs, 0.0f);
-                b0 = smem[(tp - d0) * 4 + q];
-                if (col < 4) b1 = smem[(tp - d1) * 4 + q];
+        RowTile ra;
+        if (wv < ntiles) rows_fetch(ra, hb, wv * 32, g.HW);
+        __syncthreads();   // the border is zero / the previous patch is done with
+        for (int px = t; px < g.HW; px += 256)
+            reinterpret_cast<float4 *>(smem)[lut[px]] = reinterpret_cast<const float4 *>(gu)[(int64_t)b * g.HW + px];
+        __syncthreads();
+        for (int T = wv; T < ntiles; T += 4) {
+            wave_lds_fence();
+            rows_park<true>(ra, sa, m, rs, T * 32, g.HW);
+            if (T + 4 < ntiles) rows_fetch(ra, hb, (T + 4) * 32, g.HW);
+            wave_lds_fence();
+#pragma unroll 4
+            for (int s2 = 0; s2 < 16; ++s2) {
+                const int pp = T * 32 + 2 * s2 + half;
+                float b0 = 0.0f, b1 = 0.0f;
+                if (pp < g.HW) {
+                    const int tp = lut[pp];
+                    b0 = smem[(tp - d0) * 4 + q];
+                    if (col < 4) b1 = smem[(tp - d1) * 4 + q];
+                }
+                const float a = sa[(2 * s2 + half) * kRowPad + col];
+                S0 += b0;
+                S1 += b1;
+                D0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, D0, 0, 0, 0);
+                D1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, D1, 0, 0, 0);
             }
-            S0 += b0;
-            S1 += b1;
-            D0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, D0, 0, 0, 0);
-            D1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, D1, 0, 0, 0);
         }
     }
     const Acc dst = G + off_w3;
@@ -1871,6 +1942,56 @@ __global__ __launch_bounds__(256) void k_w3_grad_mfma32(Geo g, const float *__re
         d[blockIdx.x] = cst[16 + (t & 3)] - cst[t];
         for (int k = blockIdx.x + gridDim.x; k < g.nslot; k += gridDim.x) d[k] = 0.0f;
     }
+}
+
+// d l_1/W[tap][c][j] = sum_p z[p + tap][c] * g_h1[p][j]  (c: the two pass-through channels; z from a zero-bordered tile of the
+// patch): rows (tap, c) = 18 of the 32, columns j, K = the pixels.
+__global__ __launch_bounds__(256) void k_w1_grad_mfma32(Geo g, const float *__restrict__ zin, const float *__restrict__ t2, int off_w1,
+                                                        Acc G)
+{
+    extern __shared__ float smem[];   // z tile [(H+2)(W+2)][2], then the tile index of every pixel of a patch (int)
+    __shared__ float stage[4][32 * kRowPad];
+    float *red = &stage[0][0];        // [4][16][64], used once the pixel loop is over
+    const int t = threadIdx.x, wv = t >> 6, ln = t & 63, col = ln & 31, half = ln >> 5;
+    const int Wp = g.W + 2, tile_px = (g.H + 2) * Wp;
+    const int tap = col >> 1, ch = col & 1;               // row of the result = tap * 2 + ch, valid below 18
+    const int da = (tap / 3 - 1) * Wp + (tap % 3 - 1);
+    const float unused_m[4] = {0.f, 0.f, 0.f, 0.f};
+    v16f D;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) D[v] = 0.0f;
+    float *sb = stage[wv];
+    int *lut = reinterpret_cast<int *>(smem + tile_px * 2);
+    for (int i = t; i < tile_px * 2; i += 256) smem[i] = 0.0f;
+    for (int px = t; px < g.HW; px += 256) {
+        const int r = px / g.W;
+        lut[px] = (r + 1) * Wp + (px - r * g.W) + 1;
+    }
+    const int npatch = (int)(g.npix / g.HW), ntiles = (g.HW + 31) >> 5;
+    for (int b = blockIdx.x; b < npatch; b += gridDim.x) {
+        const float *tb = t2 + (int64_t)b * g.HW * 32;
+        RowTile rb;
+        if (wv < ntiles) rows_fetch(rb, tb, wv * 32, g.HW);
+        __syncthreads();
+        for (int px = t; px < g.HW; px += 256)
+            reinterpret_cast<float2 *>(smem)[lut[px]] = *reinterpret_cast<const float2 *>(zin + ((int64_t)b * g.HW + px) * 4);
+        __syncthreads();
+        for (int T = wv; T < ntiles; T += 4) {
+            wave_lds_fence();
+            rows_park<false>(rb, sb, unused_m, unused_m, T * 32, g.HW);
+            if (T + 4 < ntiles) rows_fetch(rb, tb, (T + 4) * 32, g.HW);
+            wave_lds_fence();
+#pragma unroll 4
+            for (int s2 = 0; s2 < 16; ++s2) {
+                const int pp = T * 32 + 2 * s2 + half;
+                float a = 0.0f;
+                if (pp < g.HW && col < 18) a = smem[(lut[pp] + da) * 2 + ch];
+                D = __builtin_amdgcn_mfma_f32_32x32x2f32(a, sb[(2 * s2 + half) * kRowPad + col], D, 0, 0, 0);
+            }
+        }
+    }
+    // k_w1_grad's layout: [tap][c][j]
+    mfma_tile_to_slots(D, red, G + off_w1, g.nslot, [](int i, int j) { return i < 18 ? (i >> 1) * 64 + (i & 1) * 32 + j : -1; });
 }
 
 // ---- width 32: the 1x1 layer l_2, forward and transposed, as pixel GEMMs -------------------------------------------------
@@ -2384,17 +2505,20 @@ void coupling_backward(nf_trainer *t, const Geo &g, const TLayer &L, const float
     // one fork per coupling (every event operation costs host time): all three producers are done
     (void)hipEventRecord(t->ev_fork[0], st);
     (void)hipStreamWaitEvent(sd, t->ev_fork[0], 0);
-    if (W == 32 && (t->wide_mfma & 1)) {
+    // (the per-patch operand tiles of the matrix-core kernels sit in dynamic LDS: patches of up to ~3 000 pixels)
+    if (W == 32 && (t->wide_mfma & 1) && ((size_t)(g.H + 2) * (g.W + 2) * 4 + g.HW) * sizeof(float) <= 60 * 1024) {
         const unsigned npatch = (unsigned)(g.npix / g.HW), nw = std::min<unsigned>((unsigned)g.nslot, 512u);
-        const size_t tile = (size_t)(g.H + 2) * (g.W + 2) * 4 * sizeof(float);
-        hipLaunchKernelGGL(k_w3_grad_mfma32, dim3(std::min<unsigned>(npatch, (unsigned)g.nslot)), dim3(256), tile, sd, g, c.h2, bn2,
+        const size_t tile = (size_t)(g.H + 2) * (g.W + 2) * 4 * sizeof(float), lut = (size_t)g.HW * sizeof(int);
+        hipLaunchKernelGGL(k_w3_grad_mfma32, dim3(std::min<unsigned>(npatch, (unsigned)g.nslot)), dim3(256), tile + lut, sd, g, c.h2, bn2,
                            (const float *)gu, off_w3, G);
         hipLaunchKernelGGL(k_w2_grad_mfma32, dim3(nw), dim3(256), 0, sd, g, c.h1, bn1, (const float *)t1, off_w2, G);
+        hipLaunchKernelGGL(k_w1_grad_mfma32, dim3(std::min<unsigned>(npatch, (unsigned)g.nslot)), dim3(256), tile / 2 + lut, sd, g, zin,
+                           (const float *)t2, off_w1, G);
     } else {
         hipLaunchKernelGGL(k_w3_grad<W>, dim3(ng, 9), dim3(TB), 0, sd, g, c.h2, bn2, gu, off_w3, G);
         hipLaunchKernelGGL(k_w2_grad<W>, dim3(ng, w), dim3(TB), 0, sd, g, c.h1, bn1, t1, off_w2, G);
+        hipLaunchKernelGGL(k_w1_grad<W>, dim3(ng, 9), dim3(TB), 0, sd, g, zin, t2, off_w1, G);
     }
-    hipLaunchKernelGGL(k_w1_grad<W>, dim3(ng, 9), dim3(TB), 0, sd, g, zin, t2, off_w1, G);
     (void)hipEventRecord(t->ev_done[par], sd);
     t->done_pending[par] = true;
     // zmix_in != null: the backward of the preceding Conv2d1x1 is folded into this last stage
