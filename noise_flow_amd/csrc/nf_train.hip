@@ -2363,6 +2363,7 @@ struct nf_trainer {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork[3] = {nullptr, nullptr, nullptr}, ev_done[3] = {nullptr, nullptr, nullptr};
     bool done_pending[3] = {false, false, false};
+    bool serial = false;   // NF_TRAIN_SERIAL=1: everything on the caller's stream (kernel durations without overlap, for profiling)
     int wide_mfma = 255;   // NF_TRAIN_WIDE_MFMA: width-32 stages on the matrix cores (bit 0 filter gradients, 1 l_2 forward, 2 l_2 backward, 3 statistics finalisers; 0: layer kernels only)
     int tiled = 3;   // NF_TRAIN_TILED: bit 0 = tiled backward stages, bit 1 = tiled forward stages (0: layer kernels only)
     std::vector<void *> owned;
@@ -2478,7 +2479,7 @@ void coupling_backward(nf_trainer *t, const Geo &g, const TLayer &L, const float
     // the main stream waits for the side work of the coupling that used it last.
     const int par = L.aux % 3;
     float *t1 = t->t1[par], *t2 = t->t2[par], *gu = t->gu[par];
-    hipStream_t sd = t->side;
+    hipStream_t sd = t->serial ? st : t->side;
     if (t->done_pending[par]) {
         (void)hipStreamWaitEvent(st, t->ev_done[par], 0);
         t->done_pending[par] = false;
@@ -2585,7 +2586,7 @@ void coupling_backward_tiled(nf_trainer *t, const Geo &g, const TLayer &L, const
     const unsigned ng = std::min(nb, 96u);
     const int set = L.aux % 3;
     float *t1 = t->t1[set], *t2 = t->t2[set], *gu = t->gu[set];
-    hipStream_t sd = t->side;
+    hipStream_t sd = t->serial ? st : t->side;
     const size_t smem = ((size_t)(g.H + 2) * (g.W + 2) * (W + 4) + (W + 16) + (9 + 2 * W) + (NT / 64) * (2 * W > 16 ? 2 * W : 16)) *
                         sizeof(float);
     auto wait_set = [&](int k) {
@@ -2709,6 +2710,7 @@ int nf_trainer_create(const nf_config *cfg, const nf_layer_desc *layers, const f
     t->cfg = *cfg;
     if (const char *e = getenv("NF_TRAIN_TILED")) t->tiled = atoi(e);
     if (const char *e = getenv("NF_TRAIN_WIDE_MFMA")) t->wide_mfma = atoi(e);
+    if (const char *e = getenv("NF_TRAIN_SERIAL")) t->serial = atoi(e) != 0;
     t->max_batch = max_batch;
     t->optimizer = optimizer;
     t->n_params = (int)n_params;
@@ -3007,7 +3009,7 @@ static int trainer_run(nf_trainer *t, const float *x, const float *y, int64_t B,
     // (joined with the filter-gradient work before the step ends) while the main stream starts walking back.
     hipStream_t ls = st;
     if (backward && loss_out) {
-        ls = t->side;
+        ls = t->serial ? st : t->side;
         (void)hipEventRecord(t->ev_fork[1], st);
         (void)hipStreamWaitEvent(ls, t->ev_fork[1], 0);
     }

@@ -598,3 +598,32 @@ def test_tiled_stages_and_layer_kernels_agree(arch, width, hw, B, monkeypatch):
         assert np.allclose(l, l0, rtol=1e-6, atol=0), (mode, l, l0)
         assert np.abs(g - g0).max() <= 1e-4 * np.abs(g0).max(), (mode, np.abs(g - g0).max(), np.abs(g0).max())
         assert np.allclose(p, p0, rtol=1e-5, atol=1e-7), mode      # the BN running moments moved by the forward pass
+
+
+@pytest.mark.parametrize("arch,width,hw,B", [("sdn5|unc|unc|gain4|unc", 32, (32, 32), 5),
+                                             ("unc|unc", 32, (20, 12), 7),          # ragged: tiles of 32 pixels straddle rows
+                                             ("unc", 32, (5, 7), 3),                # a patch smaller than one 64-pixel step
+                                             ("unc|gain4|unc", 32, (64, 64), 2),    # per-patch operand tiles too large for LDS
+                                             ("sdn5|unc|unc", 16, (16, 24), 6)])    # width 16: finalisers + coalesced BN1 backward
+def test_wide_matrix_core_stages_and_layer_kernels_agree(arch, width, hw, B, monkeypatch):
+    """At width 32 the l_2 forward / backward stages and the three filter gradients run as GEMMs on v_mfma_f32_32x32x2_f32
+    (exact fp32), the slot sums are added up by one-pass finaliser kernels and the BN1 backward walks the tensors flat;
+    NF_TRAIN_WIDE_MFMA=0 keeps the one-kernel-per-layer-stage path.  Both give the oracle's gradients and differ from
+    each other only by summation order."""
+    v = trained_like_variables(arch, width, seed=9)
+    x, y = make_inputs(B, hw[0], hw[1], seed=29)
+    res = {}
+    for mode in ("0", "255"):
+        monkeypatch.setenv("NF_TRAIN_WIDE_MFMA", mode)
+        tr = _trainer(arch, v, (hw[0], hw[1], 4), width)
+        grads, loss = tr.forward_backward(x, y, [0.0], [0.0], [400], [1])
+        res[mode] = (grads.cpu().numpy().copy(), loss.cpu().numpy().copy(), tr.raw_params())
+        if mode == "255":
+            ref_loss, ref_sd, ref_grads, _ = _grad_oracle(arch, v).loss_and_grads(x, y, 400, 1)
+            assert abs(res[mode][1][0] - ref_loss) <= 1e-5 * abs(ref_loss)
+            _check_grads(tr, grads, ref_grads)
+        tr.close()
+    (g0, l0, p0), (g1, l1, p1) = res["0"], res["255"]
+    assert np.allclose(l1, l0, rtol=1e-6, atol=0), (l1, l0)
+    assert np.abs(g1 - g0).max() <= 1e-5 * np.abs(g0).max(), (np.abs(g1 - g0).max(), np.abs(g0).max())
+    assert np.allclose(p1, p0, rtol=1e-5, atol=1e-7)      # the BN running moments moved by the forward pass
