@@ -1994,6 +1994,103 @@ __global__ __launch_bounds__(256) void k_w1_grad_mfma32(Geo g, const float *__re
     mfma_tile_to_slots(D, red, G + off_w1, g.nslot, [](int i, int j) { return i < 18 ? (i >> 1) * 64 + (i & 1) * 32 + j : -1; });
 }
 
+// ---- width 32: l_last forward on the matrix cores ----------------------------------------------------------------------
+// u[p][q] = b[q] + sum_tap sum_i relu(bn2(h2))[p + tap][i] W3[tap][i][q] is evaluated transposed, as in the evaluation kernel
+// (nf_wide.hip): P[p][(tap, q)] = sum_i A2[p][i] W3[tap][i][q] is a GEMM over the 32 channels with 36 output rows (taps 0..7 in
+// one 32-row tile, tap 8 in a second), pixels on N, and u is the shift-add u[p][q] = sum_tap P[p + tap][(tap, q)].  One
+// workgroup owns a band of rows of one patch: it computes P for the band and a one-row halo on each side (10 rows for 8 at
+// 32x32: 25 % recomputed) into LDS, then one thread per pixel gathers its 9 taps and finishes the affine transform.
+// The layer kernel does the same 1 188 MAC per pixel on the vector unit, re-normalising each of the 9 neighbours it reads.
+__global__ __launch_bounds__(256) void k_c3_fwd_mfma32(Geo g, const float *__restrict__ zin, const float *__restrict__ h2,
+                                                       const float *__restrict__ bn2, const float *__restrict__ Pw, int off_w3,
+                                                       float *__restrict__ zout, Acc ldacc, float *__restrict__ u_out, int BR)
+{
+    constexpr int W = 32, PS = 36;
+    extern __shared__ float smem[];   // P [pixels of the band + halo][36]
+    __shared__ float stage[4][32 * kRowPad];
+    const float *W3 = Pw + off_w3, *b3 = W3 + 36 * (W + 1), *logs = b3 + 4;
+    const int t = threadIdx.x, wv = t >> 6, ln = t & 63, col = ln & 31, half = ln >> 5;
+    float a0[16], a1[16];             // A[(tap, q) = col][i = 2 s + half]
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int i = 2 * k + half;
+        a0[k] = W3[(col >> 2) * (W + 1) * 4 + i * 4 + (col & 3)];
+        a1[k] = col < 4 ? W3[8 * (W + 1) * 4 + i * 4 + col] : 0.0f;
+    }
+    float m[4], rs[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        m[k] = bn2[4 * (ln & 7) + k];
+        rs[k] = bn2[W + 4 * (ln & 7) + k];
+    }
+    const float sc = logs[4];
+    const float e30 = expf(kLogscale * logs[0]), e31 = expf(kLogscale * logs[1]), e32 = expf(kLogscale * logs[2]),
+                e33 = expf(kLogscale * logs[3]);
+    float *sa = stage[wv];
+    const int npatch = (int)(g.npix / g.HW), nbands = (g.H + BR - 1) / BR, units = npatch * nbands;
+    float l = 0.0f;
+    for (int unit = blockIdx.x; unit < units; unit += gridDim.x) {
+        const int b = unit / nbands, r0 = (unit - b * nbands) * BR, r1 = min(r0 + BR, g.H);
+        const int rlo = max(r0 - 1, 0), rhi = min(r1 + 1, g.H), ntiles = ((rhi - rlo) * g.W + 31) >> 5;
+        const int64_t base = (int64_t)b * g.HW + rlo * g.W, end = (int64_t)b * g.HW + rhi * g.W;
+        RowTile ra;
+        if (wv < ntiles) rows_fetch(ra, h2, base + wv * 32, end);
+        __syncthreads();              // the previous band's gather is over
+        for (int T = wv; T < ntiles; T += 4) {
+            wave_lds_fence();
+            rows_park<true>(ra, sa, m, rs, base + T * 32, end);
+            if (T + 4 < ntiles) rows_fetch(ra, h2, base + (T + 4) * 32, end);
+            wave_lds_fence();
+            v16f D0, D1;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) D0[v] = D1[v] = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const float bv = sa[col * kRowPad + 2 * k + half];
+                D0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[k], bv, D0, 0, 0, 0);
+                D1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[k], bv, D1, 0, 0, 0);
+            }
+            float *pp = smem + (T * 32 + col) * PS;
+#pragma unroll
+            for (int v = 0; v < 16; v += 4)
+                *reinterpret_cast<float4 *>(pp + 2 * v + 4 * half) = make_float4(D0[v], D0[v + 1], D0[v + 2], D0[v + 3]);
+            if (half == 0) *reinterpret_cast<float4 *>(pp + 32) = make_float4(D1[0], D1[1], D1[2], D1[3]);
+        }
+        __syncthreads();
+        for (int px = t; px < (r1 - r0) * g.W; px += 256) {
+            const int rr0 = px / g.W, r = r0 + rr0, c = px - rr0 * g.W;
+            float u[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) u[k] = b3[k];
+#pragma unroll
+            for (int di = 0; di < 3; ++di) {
+                const int rr = r + di - 1;
+#pragma unroll
+                for (int dj = 0; dj < 3; ++dj) {
+                    const int cc = c + dj - 1, tap = di * 3 + dj;
+                    if (rr < 0 || rr >= g.H || cc < 0 || cc >= g.W) {   // on the padding ring: zeros + indicator 1
+                        const float *w = W3 + tap * (W + 1) * 4 + W * 4;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) u[k] += w[k];
+                    } else {
+                        const float4 pv = *reinterpret_cast<const float4 *>(smem + ((rr - rlo) * g.W + cc) * PS + tap * 4);
+                        u[0] += pv.x; u[1] += pv.y; u[2] += pv.z; u[3] += pv.w;
+                    }
+                }
+            }
+            const int64_t p = (int64_t)b * g.HW + r * g.W + c;
+            if (u_out) reinterpret_cast<float4 *>(u_out)[p] = make_float4(u[0], u[1], u[2], u[3]);
+            const float4 zi = reinterpret_cast<const float4 *>(zin)[p];
+            const float sh0 = u[0] * e30, sh1 = u[1] * e31;
+            const float ls0 = sc * tanhf(u[2] * e32), ls1 = sc * tanhf(u[3] * e33);
+            reinterpret_cast<float4 *>(zout)[p] = make_float4(zi.x, zi.y, fmaf(zi.z, expf(ls0), sh0), fmaf(zi.w, expf(ls1), sh1));
+            l += ls0 + ls1;
+        }
+    }
+    const float lv[1] = {l};
+    acc_add_n<1>(ldacc, lv, g.nslot);
+}
+
 // ---- width 32: the 1x1 layer l_2, forward and transposed, as pixel GEMMs -------------------------------------------------
 // 32 consecutive pixels of the batch on the N axis of v_mfma_f32_32x32x2_f32 (lane & 31 = the pixel, both lane halves),
 // the 32 output channels on M, the 32 input channels on K in the order k(step s, lane half h) = 16 h + s: lane (p, h) then
@@ -2364,7 +2461,7 @@ struct nf_trainer {
     hipEvent_t ev_fork[3] = {nullptr, nullptr, nullptr}, ev_done[3] = {nullptr, nullptr, nullptr};
     bool done_pending[3] = {false, false, false};
     bool serial = false;   // NF_TRAIN_SERIAL=1: everything on the caller's stream (kernel durations without overlap, for profiling)
-    int wide_mfma = 255;   // NF_TRAIN_WIDE_MFMA: width-32 stages on the matrix cores (bit 0 filter gradients, 1 l_2 forward, 2 l_2 backward, 3 statistics finalisers; 0: layer kernels only)
+    int wide_mfma = 255;   // NF_TRAIN_WIDE_MFMA: width-32 stages on the matrix cores (bit 0 filter gradients, 1 l_2 forward, 2 l_2 backward, 3 statistics finalisers, 4 l_last forward; 0: layer kernels only)
     int tiled = 3;   // NF_TRAIN_TILED: bit 0 = tiled backward stages, bit 1 = tiled forward stages (0: layer kernels only)
     std::vector<void *> owned;
     bool has_sdn = false;
@@ -2458,8 +2555,17 @@ void coupling_forward(nf_trainer *t, const Geo &g, const TLayer &L, const float 
     if (fin)
         hipLaunchKernelGGL(k_bn_fin, dim3(w), dim3(64), 0, st, t->acc(c.d_st2), w, g.nslot, n, t->d_params, off_m2, off_m2 + w,
                            t->d_flt + c.f_bn2);
-    hipLaunchKernelGGL(k_c3_fwd<W>, dim3(nb), dim3(TB), 0, st, g, zin, c.h2, t->acc(c.d_st2), n, t->d_params, off_m2,
-                       t->d_flt + c.f_bn2, off_w3, zout, ldacc, (const float *)t->d_params, fin, c.u);
+    if (W == 32 && fin && (t->wide_mfma & 16) && 3 * g.W <= 320) {
+        // bands of BR rows: (BR + 2) rows of 36 P values per pixel in LDS
+        const int BR = std::max(1, std::min(g.H, 320 / g.W - 2)), units = (int)(g.npix / g.HW) * ((g.H + BR - 1) / BR);
+        const size_t lds = (size_t)(((BR + 2) * g.W + 31) / 32 * 32) * 36 * sizeof(float);
+        hipLaunchKernelGGL(k_c3_fwd_mfma32, dim3(std::min<unsigned>((unsigned)units, (unsigned)g.nslot)), dim3(256), lds, st, g, zin,
+                           (const float *)c.h2, (const float *)(t->d_flt + c.f_bn2), (const float *)t->d_params, off_w3, zout, ldacc,
+                           c.u, BR);
+    } else {
+        hipLaunchKernelGGL(k_c3_fwd<W>, dim3(nb), dim3(TB), 0, st, g, zin, c.h2, t->acc(c.d_st2), n, t->d_params, off_m2,
+                           t->d_flt + c.f_bn2, off_w3, zout, ldacc, (const float *)t->d_params, fin, c.u);
+    }
 }
 
 template <int W>
