@@ -2176,8 +2176,21 @@ __global__ __launch_bounds__(256) void k_c2_fwd_mfma32(Geo g, const float *__res
     lane_sums_to_slots(q2, red, stats, g.nslot, [](int k, int h) { return 32 + mfma_row(k, h); });
 }
 
+// the reverse of rows_fetch / rows_park: 32 rows parked in LDS (stride kRowPad) -> 4 KB of consecutive memory
+__device__ __forceinline__ void rows_flush(const float *lds, float *__restrict__ dst, int64_t row0, int64_t row_end)
+{
+    const int ln = threadIdx.x & 63;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int lr = (ln + 64 * m) >> 3;
+        if (row0 + lr < row_end)
+            reinterpret_cast<float4 *>(dst)[(row0 + lr) * 8 + (ln & 7)] = *reinterpret_cast<const float4 *>(lds + lr * kRowPad + 4 * (ln & 7));
+    }
+}
+
 // BN2 backward -> g_h2 (t1, in place), d l_2/b; transposed l_2 + ReLU mask -> d loss / d xhat1 (t2) and its two batch sums
-// (k_c2_bwd at width 32)
+// (k_c2_bwd at width 32).  Five passes over [pixels][32] tensors: all of them through wavefront-private LDS tiles, so that
+// every global access is a whole 4 KB tile in 16-byte pieces.
 __global__ __launch_bounds__(256) void k_c2_bwd_mfma32(Geo g, const float *__restrict__ h1, const float *__restrict__ bn1,
                                                        const float *__restrict__ h2, const float *__restrict__ bn2, Acc bstats2,
                                                        double n, const float *__restrict__ P, int off_w2, float *__restrict__ t1,
@@ -2185,7 +2198,9 @@ __global__ __launch_bounds__(256) void k_c2_bwd_mfma32(Geo g, const float *__res
 {
     constexpr int W = 32;
     __shared__ float bb2[2 * W], sbn2[2 * W], sbn1[2 * W];
-    __shared__ float red[4 * 64 * 16];
+    __shared__ float stage[4][3][32 * kRowPad];
+    float *red = &stage[0][0][0];     // [4][64][16], used once the pixel loop is over (lane_sums_to_slots starts with a barrier)
+    static_assert(sizeof(stage) >= 4 * 64 * 16 * sizeof(float), "the reduction buffer must fit the staging area");
     if (threadIdx.x < 2 * W) {
         sbn2[threadIdx.x] = bn2[threadIdx.x];
         sbn1[threadIdx.x] = bn1[threadIdx.x];
@@ -2199,17 +2214,35 @@ __global__ __launch_bounds__(256) void k_c2_bwd_mfma32(Geo g, const float *__res
     float gb[16], s1[16], q1[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) gb[k] = s1[k] = q1[k] = 0.0f;
-    const int64_t ntiles = (g.npix + 31) >> 5;
-    for (int64_t T = (int64_t)blockIdx.x * 4 + wv; T < ntiles; T += (int64_t)gridDim.x * 4) {
+    float *sg = stage[wv][0], *sh = stage[wv][1], *sx = stage[wv][2];
+    const float unused[4] = {0.f, 0.f, 0.f, 0.f};
+    const int64_t ntiles = (g.npix + 31) >> 5, stride = (int64_t)gridDim.x * 4;
+    int64_t T = (int64_t)blockIdx.x * 4 + wv;
+    RowTile rg, rh, rx;
+    if (T < ntiles) {
+        rows_fetch(rg, t1, T * 32, g.npix);
+        rows_fetch(rh, h2, T * 32, g.npix);
+        rows_fetch(rx, h1, T * 32, g.npix);
+    }
+    for (; T < ntiles; T += stride) {
         const int64_t p = T * 32 + col;
         const bool in = p < g.npix;
+        wave_lds_fence();
+        rows_park<false>(rg, sg, unused, unused, T * 32, g.npix);
+        rows_park<false>(rh, sh, unused, unused, T * 32, g.npix);
+        rows_park<false>(rx, sx, unused, unused, T * 32, g.npix);
+        if (T + stride < ntiles) {
+            rows_fetch(rg, t1, (T + stride) * 32, g.npix);
+            rows_fetch(rh, h2, (T + stride) * 32, g.npix);
+            rows_fetch(rx, h1, (T + stride) * 32, g.npix);
+        }
+        wave_lds_fence();
         float gx[16], hv[16], x1[16];
 #pragma unroll
         for (int k = 0; k < 16; k += 4) {
-            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4 u = in ? *reinterpret_cast<const float4 *>(t1 + p * W + 16 * half + k) : z4;
-            const float4 v = in ? *reinterpret_cast<const float4 *>(h2 + p * W + 16 * half + k) : z4;
-            const float4 y = in ? *reinterpret_cast<const float4 *>(h1 + p * W + mfma_row(k, half)) : z4;
+            const float4 u = *reinterpret_cast<const float4 *>(sg + col * kRowPad + 16 * half + k);
+            const float4 v = *reinterpret_cast<const float4 *>(sh + col * kRowPad + 16 * half + k);
+            const float4 y = *reinterpret_cast<const float4 *>(sx + col * kRowPad + mfma_row(k, half));
             gx[k] = u.x; gx[k + 1] = u.y; gx[k + 2] = u.z; gx[k + 3] = u.w;
             hv[k] = v.x; hv[k + 1] = v.y; hv[k + 2] = v.z; hv[k + 3] = v.w;
             x1[k] = y.x; x1[k + 1] = y.y; x1[k + 2] = y.z; x1[k + 3] = y.w;
@@ -2226,23 +2259,24 @@ __global__ __launch_bounds__(256) void k_c2_bwd_mfma32(Geo g, const float *__res
             gb[k] += gh2;
             D = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], gh2, D, 0, 0, 0);
         }
-        if (in) {
+        float o[16];
 #pragma unroll
-            for (int k = 0; k < 16; k += 4)
-                *reinterpret_cast<float4 *>(t1 + p * W + 16 * half + k) = make_float4(gx[k], gx[k + 1], gx[k + 2], gx[k + 3]);
-            float o[16];
-#pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int i = mfma_row(v, half);
-                const float xh = (x1[v] - sbn1[i]) * sbn1[W + i];
-                o[v] = xh > 0.0f ? D[v] : 0.0f;
-                s1[v] += o[v];
-                q1[v] = fmaf(o[v], xh, q1[v]);
-            }
-#pragma unroll
-            for (int v = 0; v < 16; v += 4)
-                *reinterpret_cast<float4 *>(t2 + p * W + mfma_row(v, half)) = make_float4(o[v], o[v + 1], o[v + 2], o[v + 3]);
+        for (int v = 0; v < 16; ++v) {
+            const int i = mfma_row(v, half);
+            const float xh = (x1[v] - sbn1[i]) * sbn1[W + i];
+            o[v] = (in && xh > 0.0f) ? D[v] : 0.0f;
+            s1[v] += o[v];
+            q1[v] = fmaf(o[v], xh, q1[v]);
         }
+        wave_lds_fence();             // every lane has read its inputs: the tiles take the results
+#pragma unroll
+        for (int k = 0; k < 16; k += 4) {
+            *reinterpret_cast<float4 *>(sg + col * kRowPad + 16 * half + k) = make_float4(gx[k], gx[k + 1], gx[k + 2], gx[k + 3]);
+            *reinterpret_cast<float4 *>(sx + col * kRowPad + mfma_row(k, half)) = make_float4(o[k], o[k + 1], o[k + 2], o[k + 3]);
+        }
+        wave_lds_fence();
+        rows_flush(sg, t1, T * 32, g.npix);
+        rows_flush(sx, t2, T * 32, g.npix);
     }
     lane_sums_to_slots(s1, red, bstats, g.nslot, [](int k, int h) { return mfma_row(k, h); });
     lane_sums_to_slots(q1, red, bstats, g.nslot, [](int k, int h) { return 32 + mfma_row(k, h); });
