@@ -2283,6 +2283,88 @@ __global__ __launch_bounds__(256) void k_c2_bwd_mfma32(Geo g, const float *__res
     lane_sums_to_slots(gb, red, G + off_w2 + W * W, g.nslot, [](int k, int h) { return 16 * h + k; });
 }
 
+// transposed l_last + ReLU mask -> d loss / d xhat2 (t1) and the two batch sums of the BN2 backward (k_c3_dh at width 32):
+// g[p][i] = sum_(tap, q) W3[tap][i][q] gu[p - tap][q] — K = 36 = (tap, q), the 32 channels on M, pixels on N; the B operands
+// come from a zero-bordered LDS tile of the patch's gu (K order: step s -> tap s >> 1, q = 2 half + (s & 1), one 8-byte
+// read per tap), the mask from h2 through a staged tile that then takes the result.
+__global__ __launch_bounds__(256) void k_c3_dh_mfma32(Geo g, const float *__restrict__ h2, const float *__restrict__ bn2,
+                                                      const float *__restrict__ P, int off_w3, const float *__restrict__ gu,
+                                                      float *__restrict__ t1, Acc bstats)
+{
+    constexpr int W = 32;
+    extern __shared__ float smem[];   // gu tile [(H+2)(W+2)][4], then the tile index of every pixel of a patch (int)
+    __shared__ float stage[4][32 * kRowPad];
+    __shared__ float sbn2[2 * W];
+    float *red = &stage[0][0];        // [4][64][16], used once the pixel loop is over
+    const float *W3 = P + off_w3;
+    const int t = threadIdx.x, wv = t >> 6, ln = t & 63, col = ln & 31, half = ln >> 5;
+    const int Wp = g.W + 2, tile_px = (g.H + 2) * Wp;
+    if (t < 2 * W) sbn2[t] = bn2[t];
+    float a[18];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) a[k] = W3[(k >> 1) * (W + 1) * 4 + col * 4 + 2 * half + (k & 1)];
+    float s2[16], q2[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s2[k] = q2[k] = 0.0f;
+    float *sx = stage[wv];
+    const float unused[4] = {0.f, 0.f, 0.f, 0.f};
+    int *lut = reinterpret_cast<int *>(smem + tile_px * 4);
+    for (int i = t; i < tile_px * 4; i += 256) smem[i] = 0.0f;
+    for (int px = t; px < g.HW; px += 256) {
+        const int r = px / g.W;
+        lut[px] = (r + 1) * Wp + (px - r * g.W) + 1;
+    }
+    const int npatch = (int)(g.npix / g.HW), ntiles = (g.HW + 31) >> 5;
+    for (int b = blockIdx.x; b < npatch; b += gridDim.x) {
+        const int64_t pb = (int64_t)b * g.HW;
+        RowTile rx;
+        if (wv < ntiles) rows_fetch(rx, h2, pb + wv * 32, pb + g.HW);
+        __syncthreads();              // the border is zero / the previous patch is done with
+        for (int px = t; px < g.HW; px += 256) reinterpret_cast<float4 *>(smem)[lut[px]] = reinterpret_cast<const float4 *>(gu)[pb + px];
+        __syncthreads();
+        for (int T = wv; T < ntiles; T += 4) {
+            const int pp = T * 32 + col;
+            const bool in = pp < g.HW;
+            wave_lds_fence();
+            rows_park<false>(rx, sx, unused, unused, pb + T * 32, pb + g.HW);
+            if (T + 4 < ntiles) rows_fetch(rx, h2, pb + (T + 4) * 32, pb + g.HW);
+            const float *gt = smem + (in ? lut[pp] : 0) * 4 + 2 * half;
+            v16f D;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) D[v] = 0.0f;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const float2 bv = in ? *reinterpret_cast<const float2 *>(gt - ((tap / 3 - 1) * Wp + (tap % 3 - 1)) * 4) : make_float2(0.f, 0.f);
+                D = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * tap], bv.x, D, 0, 0, 0);
+                D = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * tap + 1], bv.y, D, 0, 0, 0);
+            }
+            wave_lds_fence();
+            float o[16];
+#pragma unroll
+            for (int v = 0; v < 16; v += 4) {
+                const float4 y = *reinterpret_cast<const float4 *>(sx + col * kRowPad + mfma_row(v, half));
+                const float hv[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int i = mfma_row(v + k, half);
+                    const float xh = (hv[k] - sbn2[i]) * sbn2[W + i];
+                    o[v + k] = (in && xh > 0.0f) ? D[v + k] : 0.0f;
+                    s2[v + k] += o[v + k];
+                    q2[v + k] = fmaf(o[v + k], xh, q2[v + k]);
+                }
+            }
+            wave_lds_fence();
+#pragma unroll
+            for (int v = 0; v < 16; v += 4)
+                *reinterpret_cast<float4 *>(sx + col * kRowPad + mfma_row(v, half)) = make_float4(o[v], o[v + 1], o[v + 2], o[v + 3]);
+            wave_lds_fence();
+            rows_flush(sx, t1, pb + T * 32, pb + g.HW);
+        }
+    }
+    lane_sums_to_slots(s2, red, bstats, g.nslot, [](int k, int h) { return mfma_row(k, h); });
+    lane_sums_to_slots(q2, red, bstats, g.nslot, [](int k, int h) { return 32 + mfma_row(k, h); });
+}
+
 // chain rule of the scalar parameterisations: dA -> PLU factors, d(a,b) -> sdn5 variables, gain_val
 __global__ void k_finish(TLayers ls, const float *__restrict__ P, CondIdx ci, int HW, const double *__restrict__ dAbuf,
                          const double *__restrict__ dabbuf, const double *__restrict__ dgbuf, double *__restrict__ G)
@@ -2495,7 +2577,7 @@ struct nf_trainer {
     hipEvent_t ev_fork[3] = {nullptr, nullptr, nullptr}, ev_done[3] = {nullptr, nullptr, nullptr};
     bool done_pending[3] = {false, false, false};
     bool serial = false;   // NF_TRAIN_SERIAL=1: everything on the caller's stream (kernel durations without overlap, for profiling)
-    int wide_mfma = 255;   // NF_TRAIN_WIDE_MFMA: width-32 stages on the matrix cores (bit 0 filter gradients, 1 l_2 forward, 2 l_2 backward, 3 statistics finalisers, 4 l_last forward; 0: layer kernels only)
+    int wide_mfma = 255;   // NF_TRAIN_WIDE_MFMA: width-32 stages on the matrix cores (bit 0 filter gradients, 1 l_2 forward, 2 l_2 backward, 3 statistics finalisers, 4 l_last forward, 5 l_last transposed; 0: layer kernels only)
     int tiled = 3;   // NF_TRAIN_TILED: bit 0 = tiled backward stages, bit 1 = tiled forward stages (0: layer kernels only)
     std::vector<void *> owned;
     bool has_sdn = false;
@@ -2626,7 +2708,12 @@ void coupling_backward(nf_trainer *t, const Geo &g, const TLayer &L, const float
     }
     hipLaunchKernelGGL(k_c3_bwd<W>, dim3(nb), dim3(TB), 0, st, g, zin, c.h2, bn2, t->d_params, off_w3, invB, t->dz, gu, G, zlat,
                        (const float *)c.u);
-    hipLaunchKernelGGL(k_c3_dh<W>, dim3(nb), dim3(TB), 0, st, g, c.h2, bn2, t->d_params, off_w3, gu, t1, t->acc(c.d_bs2));
+    const size_t gu_tile = ((size_t)(g.H + 2) * (g.W + 2) * 4 + g.HW) * sizeof(float);   // per-patch operand tile + pixel index
+    if (W == 32 && (t->wide_mfma & 32) && gu_tile <= 60 * 1024)
+        hipLaunchKernelGGL(k_c3_dh_mfma32, dim3(std::min<unsigned>((unsigned)(g.npix / g.HW), (unsigned)g.nslot)), dim3(256), gu_tile, st, g,
+                           (const float *)c.h2, bn2, (const float *)t->d_params, off_w3, (const float *)gu, t1, t->acc(c.d_bs2));
+    else
+        hipLaunchKernelGGL(k_c3_dh<W>, dim3(nb), dim3(TB), 0, st, g, c.h2, bn2, t->d_params, off_w3, gu, t1, t->acc(c.d_bs2));
     sync_slots(t, t->acc(c.d_bs2), 2 * w, g.nslot, st);
     const bool fin = W >= 16 && (t->wide_mfma & 8);
     const float *pre2 = fin ? t->d_flt + c.f_bb2 : nullptr, *pre1 = fin ? t->d_flt + c.f_bb1 : nullptr;
