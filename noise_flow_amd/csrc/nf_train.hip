@@ -2365,6 +2365,94 @@ __global__ __launch_bounds__(256) void k_c3_dh_mfma32(Geo g, const float *__rest
     lane_sums_to_slots(q2, red, bstats, g.nslot, [](int k, int h) { return 32 + mfma_row(k, h); });
 }
 
+// transposed l_1 (k_c1_dz at width 32): d z0[p][c] += sum_tap sum_j W1[tap][c][j] g_h1[p - tap][j], evaluated like the
+// l_last forward: Q[p][(tap, c)] = sum_j W1[tap][c][j] g_h1[p][j] (18 rows of a 32-row tile, K = the 32 channels) for a band
+// of rows + a one-row halo into LDS, then one thread per pixel adds its 9 taps up and runs the folded Conv2d1x1 backward.
+template <bool MIX>
+__global__ __launch_bounds__(256) void k_c1_dz_mfma32(Geo g, const float *__restrict__ t2, const float *__restrict__ P, int off_w1,
+                                                      float *__restrict__ dz, const float *__restrict__ zmix_in,
+                                                      const float *__restrict__ A, Acc dA, int BR)
+{
+    constexpr int W = 32, QS = 20;
+    extern __shared__ float smem[];   // Q [pixels of the band + halo][20]
+    __shared__ float stage[4][32 * kRowPad];
+    const float *W1 = P + off_w1;
+    const int t = threadIdx.x, wv = t >> 6, ln = t & 63, col = ln & 31, half = ln >> 5;
+    float a[16];                      // A[(tap, c) = col][j = 2 s + half]
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a[k] = col < 18 ? W1[(col >> 1) * 2 * W + (col & 1) * W + 2 * k + half] : 0.0f;
+    float mm[16], acc[16];
+    if (MIX) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            mm[i] = A[i];
+            acc[i] = 0.0f;
+        }
+    }
+    const float unused[4] = {0.f, 0.f, 0.f, 0.f};
+    float *sa = stage[wv];
+    const int npatch = (int)(g.npix / g.HW), nbands = (g.H + BR - 1) / BR, units = npatch * nbands;
+    for (int unit = blockIdx.x; unit < units; unit += gridDim.x) {
+        const int b = unit / nbands, r0 = (unit - b * nbands) * BR, r1 = min(r0 + BR, g.H);
+        const int rlo = max(r0 - 1, 0), rhi = min(r1 + 1, g.H), ntiles = ((rhi - rlo) * g.W + 31) >> 5;
+        const int64_t base = (int64_t)b * g.HW + rlo * g.W, end = (int64_t)b * g.HW + rhi * g.W;
+        RowTile ra;
+        if (wv < ntiles) rows_fetch(ra, t2, base + wv * 32, end);
+        __syncthreads();              // the previous band's gather is over
+        for (int T = wv; T < ntiles; T += 4) {
+            wave_lds_fence();
+            rows_park<false>(ra, sa, unused, unused, base + T * 32, end);
+            if (T + 4 < ntiles) rows_fetch(ra, t2, base + (T + 4) * 32, end);
+            wave_lds_fence();
+            v16f D;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) D[v] = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) D = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], sa[col * kRowPad + 2 * k + half], D, 0, 0, 0);
+            float *qp = smem + (T * 32 + col) * QS;   // rows 0..19 of the result (18, 19 are zero)
+            *reinterpret_cast<float4 *>(qp + 4 * half) = make_float4(D[0], D[1], D[2], D[3]);
+            *reinterpret_cast<float4 *>(qp + 8 + 4 * half) = make_float4(D[4], D[5], D[6], D[7]);
+            if (half == 0) *reinterpret_cast<float4 *>(qp + 16) = make_float4(D[8], D[9], D[10], D[11]);
+        }
+        __syncthreads();
+        for (int px = t; px < (r1 - r0) * g.W; px += 256) {
+            const int rr0 = px / g.W, r = r0 + rr0, c = px - rr0 * g.W;
+            float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+            for (int di = 0; di < 3; ++di) {
+                const int qr = r - (di - 1);
+                if (qr < 0 || qr >= g.H) continue;
+#pragma unroll
+                for (int dj = 0; dj < 3; ++dj) {
+                    const int qc = c - (dj - 1);
+                    if (qc < 0 || qc >= g.W) continue;
+                    const float2 qv = *reinterpret_cast<const float2 *>(smem + ((qr - rlo) * g.W + qc) * QS + (di * 3 + dj) * 2);
+                    a0 += qv.x;
+                    a1 += qv.y;
+                }
+            }
+            const int64_t p = (int64_t)b * g.HW + r * g.W + c;
+            if (MIX) {
+                const float4 dv = reinterpret_cast<const float4 *>(dz)[p], zv = reinterpret_cast<const float4 *>(zmix_in)[p];
+                const float d[4] = {dv.x + a0, dv.y + a1, dv.z, dv.w}, zi[4] = {zv.x, zv.y, zv.z, zv.w};
+                float o[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    o[i] = mm[i * 4] * d[0] + mm[i * 4 + 1] * d[1] + mm[i * 4 + 2] * d[2] + mm[i * 4 + 3] * d[3];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i * 4 + j] = fmaf(zi[i], d[j], acc[i * 4 + j]);
+                }
+                reinterpret_cast<float4 *>(dz)[p] = make_float4(o[0], o[1], o[2], o[3]);
+            } else {
+                float2 *d = reinterpret_cast<float2 *>(dz + p * 4);
+                const float2 v = *d;
+                *d = make_float2(v.x + a0, v.y + a1);
+            }
+        }
+    }
+    if (MIX) acc_add_n<16>(dA, acc, g.nslot);
+}
+
 // chain rule of the scalar parameterisations: dA -> PLU factors, d(a,b) -> sdn5 variables, gain_val
 __global__ void k_finish(TLayers ls, const float *__restrict__ P, CondIdx ci, int HW, const double *__restrict__ dAbuf,
                          const double *__restrict__ dabbuf, const double *__restrict__ dgbuf, double *__restrict__ G)
@@ -2577,7 +2665,7 @@ struct nf_trainer {
     hipEvent_t ev_fork[3] = {nullptr, nullptr, nullptr}, ev_done[3] = {nullptr, nullptr, nullptr};
     bool done_pending[3] = {false, false, false};
     bool serial = false;   // NF_TRAIN_SERIAL=1: everything on the caller's stream (kernel durations without overlap, for profiling)
-    int wide_mfma = 255;   // NF_TRAIN_WIDE_MFMA: width-32 stages on the matrix cores (bit 0 filter gradients, 1 l_2 forward, 2 l_2 backward, 3 statistics finalisers, 4 l_last forward, 5 l_last transposed; 0: layer kernels only)
+    int wide_mfma = 255;   // NF_TRAIN_WIDE_MFMA: width-32 stages on the matrix cores (bit 0 filter gradients, 1 l_2 forward, 2 l_2 backward, 3 statistics finalisers, 4 l_last forward, 5 l_last transposed, 6 l_1 transposed; 0: layer kernels only)
     int tiled = 3;   // NF_TRAIN_TILED: bit 0 = tiled backward stages, bit 1 = tiled forward stages (0: layer kernels only)
     std::vector<void *> owned;
     bool has_sdn = false;
@@ -2750,11 +2838,22 @@ void coupling_backward(nf_trainer *t, const Geo &g, const TLayer &L, const float
     (void)hipEventRecord(t->ev_done[par], sd);
     t->done_pending[par] = true;
     // zmix_in != null: the backward of the preceding Conv2d1x1 is folded into this last stage
-    if (zmix_in)
+    if (W == 32 && (t->wide_mfma & 64) && 3 * g.W <= 320) {
+        const int BR = std::max(1, std::min(g.H, 320 / g.W - 2)), units = (int)(g.npix / g.HW) * ((g.H + BR - 1) / BR);
+        const size_t lds = (size_t)(((BR + 2) * g.W + 31) / 32 * 32) * 20 * sizeof(float);
+        const unsigned ngrid = std::min<unsigned>((unsigned)units, (unsigned)g.nslot);
+        if (zmix_in)
+            hipLaunchKernelGGL((k_c1_dz_mfma32<true>), dim3(ngrid), dim3(256), lds, st, g, (const float *)t2, (const float *)t->d_params,
+                               off_w1, t->dz, zmix_in, A, dA, BR);
+        else
+            hipLaunchKernelGGL((k_c1_dz_mfma32<false>), dim3(ngrid), dim3(256), lds, st, g, (const float *)t2, (const float *)t->d_params,
+                               off_w1, t->dz, (const float *)nullptr, (const float *)nullptr, dA, BR);
+    } else if (zmix_in) {
         hipLaunchKernelGGL((k_c1_dz<W, true>), dim3(nb), dim3(TB), 0, st, g, t2, t->d_params, off_w1, t->dz, zmix_in, A, dA);
-    else
+    } else {
         hipLaunchKernelGGL((k_c1_dz<W, false>), dim3(nb), dim3(TB), 0, st, g, t2, t->d_params, off_w1, t->dz,
                            (const float *)nullptr, (const float *)nullptr, dA);
+    }
 }
 
 // The tiled form of coupling_forward (k_tiled_fwd): `f1_done` = this coupling's stage 1 already ran in the launch that
