@@ -2191,6 +2191,9 @@ __device__ __forceinline__ void rows_flush(const float *lds, float *__restrict__
 // BN2 backward -> g_h2 (t1, in place), d l_2/b; transposed l_2 + ReLU mask -> d loss / d xhat1 (t2) and its two batch sums
 // (k_c2_bwd at width 32).  Five passes over [pixels][32] tensors: all of them through wavefront-private LDS tiles, so that
 // every global access is a whole 4 KB tile in 16-byte pieces.
+// WGRAD: d l_2/W = A1^T g_h2 is accumulated here as well — both operands are in the staged tiles at that point (K = the 32
+// pixels of the tile) — instead of by k_w2_grad_mfma32 from a second pass over h1 and a stored g_h2; t1 is then read only.
+template <bool WGRAD>
 __global__ __launch_bounds__(256) void k_c2_bwd_mfma32(Geo g, const float *__restrict__ h1, const float *__restrict__ bn1,
                                                        const float *__restrict__ h2, const float *__restrict__ bn2, Acc bstats2,
                                                        double n, const float *__restrict__ P, int off_w2, float *__restrict__ t1,
@@ -2214,6 +2217,9 @@ __global__ __launch_bounds__(256) void k_c2_bwd_mfma32(Geo g, const float *__res
     float gb[16], s1[16], q1[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) gb[k] = s1[k] = q1[k] = 0.0f;
+    v16f DW;                          // WGRAD: d l_2/W[i][j], lane (j = col), rows i
+#pragma unroll
+    for (int v = 0; v < 16; ++v) DW[v] = 0.0f;
     float *sg = stage[wv][0], *sh = stage[wv][1], *sx = stage[wv][2];
     const float unused[4] = {0.f, 0.f, 0.f, 0.f};
     const int64_t ntiles = (g.npix + 31) >> 5, stride = (int64_t)gridDim.x * 4;
@@ -2270,14 +2276,26 @@ __global__ __launch_bounds__(256) void k_c2_bwd_mfma32(Geo g, const float *__res
         }
         wave_lds_fence();             // every lane has read its inputs: the tiles take the results
 #pragma unroll
-        for (int k = 0; k < 16; k += 4) {
+        for (int k = 0; k < 16; k += 4)
             *reinterpret_cast<float4 *>(sg + col * kRowPad + 16 * half + k) = make_float4(gx[k], gx[k + 1], gx[k + 2], gx[k + 3]);
-            *reinterpret_cast<float4 *>(sx + col * kRowPad + mfma_row(k, half)) = make_float4(o[k], o[k + 1], o[k + 2], o[k + 3]);
+        if (WGRAD) {
+            wave_lds_fence();
+            const float m1 = sbn1[col], r1 = sbn1[W + col];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {   // pixels 2 k + half of the tile: A1[p][i = col] (rows past the end hold g_h2 = 0)
+                const float av = fmaxf((sx[(2 * k + half) * kRowPad + col] - m1) * r1, 0.0f);
+                DW = __builtin_amdgcn_mfma_f32_32x32x2f32(av, sg[(2 * k + half) * kRowPad + col], DW, 0, 0, 0);
+            }
+            wave_lds_fence();
         }
+#pragma unroll
+        for (int k = 0; k < 16; k += 4)
+            *reinterpret_cast<float4 *>(sx + col * kRowPad + mfma_row(k, half)) = make_float4(o[k], o[k + 1], o[k + 2], o[k + 3]);
         wave_lds_fence();
-        rows_flush(sg, t1, T * 32, g.npix);
+        if (!WGRAD) rows_flush(sg, t1, T * 32, g.npix);
         rows_flush(sx, t2, T * 32, g.npix);
     }
+    if (WGRAD) mfma_tile_to_slots(DW, red, G + off_w2, g.nslot, [](int i, int j) { return i * 32 + j; });
     lane_sums_to_slots(s1, red, bstats, g.nslot, [](int k, int h) { return mfma_row(k, h); });
     lane_sums_to_slots(q1, red, bstats, g.nslot, [](int k, int h) { return 32 + mfma_row(k, h); });
     lane_sums_to_slots(gb, red, G + off_w2 + W * W, g.nslot, [](int k, int h) { return 16 * h + k; });
@@ -2287,14 +2305,17 @@ __global__ __launch_bounds__(256) void k_c2_bwd_mfma32(Geo g, const float *__res
 // g[p][i] = sum_(tap, q) W3[tap][i][q] gu[p - tap][q] — K = 36 = (tap, q), the 32 channels on M, pixels on N; the B operands
 // come from a zero-bordered LDS tile of the patch's gu (K order: step s -> tap s >> 1, q = 2 half + (s & 1), one 8-byte
 // read per tap), the mask from h2 through a staged tile that then takes the result.
+// WGRAD: d l_last/W (k_w3_grad_mfma32's sums) is accumulated here too — the h2 tile and the patch's gu tile are both in LDS.
+template <bool WGRAD>
 __global__ __launch_bounds__(256) void k_c3_dh_mfma32(Geo g, const float *__restrict__ h2, const float *__restrict__ bn2,
                                                       const float *__restrict__ P, int off_w3, const float *__restrict__ gu,
-                                                      float *__restrict__ t1, Acc bstats)
+                                                      float *__restrict__ t1, Acc bstats, Acc G)
 {
     constexpr int W = 32;
     extern __shared__ float smem[];   // gu tile [(H+2)(W+2)][4], then the tile index of every pixel of a patch (int)
     __shared__ float stage[4][32 * kRowPad];
     __shared__ float sbn2[2 * W];
+    __shared__ float cs[2][4][64], cst[40];
     float *red = &stage[0][0];        // [4][64][16], used once the pixel loop is over
     const float *W3 = P + off_w3;
     const int t = threadIdx.x, wv = t >> 6, ln = t & 63, col = ln & 31, half = ln >> 5;
@@ -2306,6 +2327,12 @@ __global__ __launch_bounds__(256) void k_c3_dh_mfma32(Geo g, const float *__rest
     float s2[16], q2[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) s2[k] = q2[k] = 0.0f;
+    // WGRAD (see k_w3_grad_mfma32): columns (tap, q), taps 0..7 in D0, tap 8 in D1; S0 / S1 = column sums of the B operands
+    const int wq = col & 3, wd0 = ((col >> 2) / 3 - 1) * Wp + ((col >> 2) % 3 - 1), wd1 = Wp + 1;
+    v16f D0, D1;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) D0[v] = D1[v] = 0.0f;
+    float S0 = 0.0f, S1 = 0.0f;
     float *sx = stage[wv];
     const float unused[4] = {0.f, 0.f, 0.f, 0.f};
     int *lut = reinterpret_cast<int *>(smem + tile_px * 4);
@@ -2339,6 +2366,24 @@ __global__ __launch_bounds__(256) void k_c3_dh_mfma32(Geo g, const float *__rest
                 D = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * tap + 1], bv.y, D, 0, 0, 0);
             }
             wave_lds_fence();
+            if (WGRAD) {
+                const float m2 = sbn2[col], r2 = sbn2[W + col];
+#pragma unroll 4
+                for (int k = 0; k < 16; ++k) {
+                    const int p2 = T * 32 + 2 * k + half;
+                    float b0 = 0.0f, b1 = 0.0f;
+                    if (p2 < g.HW) {
+                        const int tp = lut[p2];
+                        b0 = smem[(tp - wd0) * 4 + wq];
+                        if (col < 4) b1 = smem[(tp - wd1) * 4 + wq];
+                    }
+                    const float av = p2 < g.HW ? fmaxf((sx[(2 * k + half) * kRowPad + col] - m2) * r2, 0.0f) : 0.0f;
+                    S0 += b0;
+                    S1 += b1;
+                    D0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, D0, 0, 0, 0);
+                    D1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, D1, 0, 0, 0);
+                }
+            }
             float o[16];
 #pragma unroll
             for (int v = 0; v < 16; v += 4) {
@@ -2363,6 +2408,27 @@ __global__ __launch_bounds__(256) void k_c3_dh_mfma32(Geo g, const float *__rest
     }
     lane_sums_to_slots(s2, red, bstats, g.nslot, [](int k, int h) { return mfma_row(k, h); });
     lane_sums_to_slots(q2, red, bstats, g.nslot, [](int k, int h) { return 32 + mfma_row(k, h); });
+    if (WGRAD) {
+        const Acc dst = G + off_w3;
+        mfma_tile_to_slots(D0, red, dst, g.nslot, [](int i, int c) { return (c >> 2) * 132 + i * 4 + (c & 3); });
+        mfma_tile_to_slots(D1, red, dst, g.nslot, [](int i, int c) { return c < 4 ? 8 * 132 + i * 4 + c : -1; });
+        cs[0][wv][ln] = S0;
+        cs[1][wv][ln] = S1;
+        __syncthreads();
+        if (t < 36) {   // column sums over the 4 wavefronts and both lane halves: t = tap * 4 + q
+            const int k = t < 32 ? 0 : 1, c = t < 32 ? t : t - 32;
+            float tot = 0.0f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) tot += cs[k][w][c] + cs[k][w][c + 32];
+            cst[t] = tot;
+        }
+        __syncthreads();
+        if (t < 36) {   // indicator channel: the pixels whose tap falls on the padding ring
+            float *d = dst.p + (size_t)((t >> 2) * 132 + 128 + (t & 3)) * NSLOT;
+            d[blockIdx.x] = cst[16 + (t & 3)] - cst[t];
+            for (int k = blockIdx.x + gridDim.x; k < g.nslot; k += gridDim.x) d[k] = 0.0f;
+        }
+    }
 }
 
 // transposed l_1 (k_c1_dz at width 32): d z0[p][c] += sum_tap sum_j W1[tap][c][j] g_h1[p - tap][j], evaluated like the
@@ -2665,7 +2731,7 @@ struct nf_trainer {
     hipEvent_t ev_fork[3] = {nullptr, nullptr, nullptr}, ev_done[3] = {nullptr, nullptr, nullptr};
     bool done_pending[3] = {false, false, false};
     bool serial = false;   // NF_TRAIN_SERIAL=1: everything on the caller's stream (kernel durations without overlap, for profiling)
-    int wide_mfma = 255;   // NF_TRAIN_WIDE_MFMA: width-32 stages on the matrix cores (bit 0 filter gradients, 1 l_2 forward, 2 l_2 backward, 3 statistics finalisers, 4 l_last forward, 5 l_last transposed, 6 l_1 transposed; 0: layer kernels only)
+    int wide_mfma = 255;   // NF_TRAIN_WIDE_MFMA: width-32 stages on the matrix cores (bit 0 filter gradients, 1 l_2 forward, 2 l_2 backward, 3 statistics finalisers, 4 l_last forward, 5 l_last transposed, 6 l_1 transposed, 7 filter gradients inside the stage that holds their operands; 0: layer kernels only)
     int tiled = 3;   // NF_TRAIN_TILED: bit 0 = tiled backward stages, bit 1 = tiled forward stages (0: layer kernels only)
     std::vector<void *> owned;
     bool has_sdn = false;
@@ -2797,17 +2863,29 @@ void coupling_backward(nf_trainer *t, const Geo &g, const TLayer &L, const float
     hipLaunchKernelGGL(k_c3_bwd<W>, dim3(nb), dim3(TB), 0, st, g, zin, c.h2, bn2, t->d_params, off_w3, invB, t->dz, gu, G, zlat,
                        (const float *)c.u);
     const size_t gu_tile = ((size_t)(g.H + 2) * (g.W + 2) * 4 + g.HW) * sizeof(float);   // per-patch operand tile + pixel index
-    if (W == 32 && (t->wide_mfma & 32) && gu_tile <= 60 * 1024)
-        hipLaunchKernelGGL(k_c3_dh_mfma32, dim3(std::min<unsigned>((unsigned)(g.npix / g.HW), (unsigned)g.nslot)), dim3(256), gu_tile, st, g,
-                           (const float *)c.h2, bn2, (const float *)t->d_params, off_w3, (const float *)gu, t1, t->acc(c.d_bs2));
+    const bool mfma_dh = W == 32 && (t->wide_mfma & 32) && gu_tile <= 60 * 1024;
+    // The filter gradients of l_last / l_2 inside the stage kernels (3 tensor passes less: 6.0 -> 5.6 ms per step at 1 024
+    // patches) — but only when the stages fill the GPU: at 138 patches the side stream's kernels run in the CUs the stage
+    // kernels leave idle, and fusing them lengthens the critical path instead (1.67 -> 1.86 ms).
+    const bool fuse = (t->wide_mfma & 1) && (t->wide_mfma & 128) && g.npix >= 400 * 1024;
+    const bool fuse_w3 = mfma_dh && fuse, fuse_w2 = W == 32 && (t->wide_mfma & 4) && fuse;
+    if (mfma_dh && fuse_w3)
+        hipLaunchKernelGGL(k_c3_dh_mfma32<true>, dim3(std::min<unsigned>((unsigned)(g.npix / g.HW), (unsigned)g.nslot)), dim3(256), gu_tile, st, g,
+                           (const float *)c.h2, bn2, (const float *)t->d_params, off_w3, (const float *)gu, t1, t->acc(c.d_bs2), G);
+    else if (mfma_dh)
+        hipLaunchKernelGGL(k_c3_dh_mfma32<false>, dim3(std::min<unsigned>((unsigned)(g.npix / g.HW), (unsigned)g.nslot)), dim3(256), gu_tile, st, g,
+                           (const float *)c.h2, bn2, (const float *)t->d_params, off_w3, (const float *)gu, t1, t->acc(c.d_bs2), G);
     else
         hipLaunchKernelGGL(k_c3_dh<W>, dim3(nb), dim3(TB), 0, st, g, c.h2, bn2, t->d_params, off_w3, gu, t1, t->acc(c.d_bs2));
     sync_slots(t, t->acc(c.d_bs2), 2 * w, g.nslot, st);
     const bool fin = W >= 16 && (t->wide_mfma & 8);
     const float *pre2 = fin ? t->d_flt + c.f_bb2 : nullptr, *pre1 = fin ? t->d_flt + c.f_bb1 : nullptr;
     if (fin) hipLaunchKernelGGL(k_bnb_fin, dim3(w), dim3(64), 0, st, t->acc(c.d_bs2), w, g.nslot, n, t->d_flt + c.f_bb2);
-    if (W == 32 && (t->wide_mfma & 4))
-        hipLaunchKernelGGL(k_c2_bwd_mfma32, dim3(nb), dim3(256), 0, st, g, (const float *)c.h1, bn1, (const float *)c.h2, bn2,
+    if (fuse_w2)
+        hipLaunchKernelGGL(k_c2_bwd_mfma32<true>, dim3(nb), dim3(256), 0, st, g, (const float *)c.h1, bn1, (const float *)c.h2, bn2,
+                           t->acc(c.d_bs2), n, (const float *)t->d_params, off_w2, t1, t2, t->acc(c.d_bs1), G, pre2);
+    else if (W == 32 && (t->wide_mfma & 4))
+        hipLaunchKernelGGL(k_c2_bwd_mfma32<false>, dim3(nb), dim3(256), 0, st, g, (const float *)c.h1, bn1, (const float *)c.h2, bn2,
                            t->acc(c.d_bs2), n, (const float *)t->d_params, off_w2, t1, t2, t->acc(c.d_bs1), G, pre2);
     else
         hipLaunchKernelGGL(k_c2_bwd<W>, dim3(nb), dim3(TB), 0, st, g, c.h1, bn1, c.h2, bn2, t->acc(c.d_bs2), n, t->d_params, off_w2,
@@ -2825,9 +2903,10 @@ void coupling_backward(nf_trainer *t, const Geo &g, const TLayer &L, const float
     if (W == 32 && (t->wide_mfma & 1) && ((size_t)(g.H + 2) * (g.W + 2) * 4 + g.HW) * sizeof(float) <= 60 * 1024) {
         const unsigned npatch = (unsigned)(g.npix / g.HW), nw = std::min<unsigned>((unsigned)g.nslot, 512u);
         const size_t tile = (size_t)(g.H + 2) * (g.W + 2) * 4 * sizeof(float), lut = (size_t)g.HW * sizeof(int);
-        hipLaunchKernelGGL(k_w3_grad_mfma32, dim3(std::min<unsigned>(npatch, (unsigned)g.nslot)), dim3(256), tile + lut, sd, g, c.h2, bn2,
-                           (const float *)gu, off_w3, G);
-        hipLaunchKernelGGL(k_w2_grad_mfma32, dim3(nw), dim3(256), 0, sd, g, c.h1, bn1, (const float *)t1, off_w2, G);
+        if (!fuse_w3)
+            hipLaunchKernelGGL(k_w3_grad_mfma32, dim3(std::min<unsigned>(npatch, (unsigned)g.nslot)), dim3(256), tile + lut, sd, g, c.h2, bn2,
+                               (const float *)gu, off_w3, G);
+        if (!fuse_w2) hipLaunchKernelGGL(k_w2_grad_mfma32, dim3(nw), dim3(256), 0, sd, g, c.h1, bn1, (const float *)t1, off_w2, G);
         hipLaunchKernelGGL(k_w1_grad_mfma32, dim3(std::min<unsigned>(npatch, (unsigned)g.nslot)), dim3(256), tile / 2 + lut, sd, g, zin,
                            (const float *)t2, off_w1, G);
     } else {

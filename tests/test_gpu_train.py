@@ -627,3 +627,25 @@ def test_wide_matrix_core_stages_and_layer_kernels_agree(arch, width, hw, B, mon
     assert np.allclose(l1, l0, rtol=1e-6, atol=0), (l1, l0)
     assert np.abs(g1 - g0).max() <= 1e-5 * np.abs(g0).max(), (np.abs(g1 - g0).max(), np.abs(g0).max())
     assert np.allclose(p1, p0, rtol=1e-5, atol=1e-7)      # the BN running moments moved by the forward pass
+
+
+def test_wide_filter_gradients_fused_into_the_stage_kernels(monkeypatch):
+    """From ~400 patches of 32x32 up (stage kernels that fill the GPU) the width-32 trainer accumulates d l_2/W and d l_last/W
+    inside the backward stage kernels that already hold both operands in LDS (NF_TRAIN_WIDE_MFMA bit 7) instead of in their
+    own kernels on the side stream.  Same sums, other grouping: the three paths agree to 1e-5 of the gradient scale."""
+    arch, width, B = "unc|unc", 32, 416
+    v = trained_like_variables(arch, width, seed=10)
+    x, y = make_inputs(B, 32, 32, seed=31)
+    res = {}
+    for mode in ("0", "127", "255"):
+        monkeypatch.setenv("NF_TRAIN_WIDE_MFMA", mode)
+        tr = _trainer(arch, v, (32, 32, 4), width, max_batch=B)
+        grads, loss = tr.forward_backward(x, y, [0.0], [0.0], [800], [2])
+        res[mode] = (grads.cpu().numpy().copy(), loss.cpu().numpy().copy())
+        tr.close()
+    g0, l0 = res["0"]
+    for mode in ("127", "255"):
+        g, l = res[mode]
+        assert np.allclose(l, l0, rtol=1e-6, atol=0), (mode, l, l0)
+        assert np.abs(g - g0).max() <= 1e-5 * np.abs(g0).max(), (mode, np.abs(g - g0).max(), np.abs(g0).max())
+    assert not np.array_equal(res["127"][0], res["255"][0])      # the fused path really is another code path
