@@ -623,10 +623,26 @@ def _training(ctx, batches, cond, wide):
     torch.cuda.synchronize(dev)
     mst = g0.elapsed_time(g1) / kt
     trn.close()
-    return {"workload": "one training step = forward with batch-statistics BN + backward + BN EMA + Adam "
-                        "(train_noise_flow.py:64-66,187-198), shipped architecture, 138 patches 32x32x4",
-            "batch": TB_, "steps": kt, "ms_per_step": mst, "value": TB_ / (mst * 1e-3), "unit": "patches/s",
-            "bound": "kernel latency: a chain of stream-ordered launches per step (profiles/)"}
+    out = {"workload": "one training step = forward with batch-statistics BN + backward + BN EMA + Adam "
+                       "(train_noise_flow.py:64-66,187-198), shipped architecture, 138 patches 32x32x4",
+           "batch": TB_, "steps": kt, "ms_per_step": mst, "value": TB_ / (mst * 1e-3), "unit": "patches/s",
+           "bound": "kernel latency: a chain of stream-ordered launches per step (profiles/)"}
+    # the same step at the paper-scale coupling width (job_noise_flow.sh:19: "for Noise Flow it is 32"), fresh initialisation:
+    # every dense stage on v_mfma_f32_32x32x2_f32 (DESIGN 4.5 v)
+    trw = Trainer([32, 32, 4], default_hps(width=32), device=dev.index, max_batch=TB_)
+    for _ in range(3):
+        trw.step(xt_, yt_, [0.0], [0.0], [100.0], [2.0], lr=1e-4, sync=False)
+    torch.cuda.synchronize(dev)
+    g0.record(stream)
+    for _ in range(kt):
+        trw.step(xt_, yt_, [0.0], [0.0], [100.0], [2.0], lr=1e-4, sync=False)
+    g1.record(stream)
+    torch.cuda.synchronize(dev)
+    msw = g0.elapsed_time(g1) / kt
+    trw.close()
+    out["width32"] = {"workload": "the same step, coupling width 32 (fresh initialisation), 138 patches 32x32x4", "ms_per_step": msw,
+                      "value": TB_ / (msw * 1e-3), "unit": "patches/s"}
+    return out
 
 
 def _cpu_baseline(args, variables, xc, yc, B):

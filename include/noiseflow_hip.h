@@ -226,7 +226,15 @@ int nf_sample_batchstats(nf_handle *h, const float *y, const float *eps, uint64_
  * allocation and no host synchronisation.  One stream at a time per trainer.
  * Layers: every NF_LAYER_* above (COUPLING at width 4/8/16/32) — the whole vocabulary of noise_flow_arch under every
  * setting of hps.flow_permutation / hps.decomp; fp32 (nf_config.flags must be 0).
- * Trainable = everything except P / sign_S of CONV1X1 / CONV1X1_LU2, the BN statistics and c_i of SDN5 / SDN6. */
+ * Trainable = everything except P / sign_S of CONV1X1 / CONV1X1_LU2, the BN statistics and c_i of SDN5 / SDN6.
+ * Kernel selection (read from the environment by nf_trainer_create; the defaults are the fast paths, the others exist for
+ * A/B tests and profiling — every combination computes the same step up to fp32 summation order):
+ *   NF_TRAIN_TILED      bit 0 / 1: per-patch tiled backward / forward stages (widths 4 and 8, patches <= 1024 pixels,
+ *                       <= 384 patches); 0 = one kernel per layer stage.  Default 3.
+ *   NF_TRAIN_WIDE_MFMA  width 32: bit 0 filter gradients, 1 l_2 forward, 2 l_2 backward, 4 l_last forward, 5 l_last transposed,
+ *                       6 l_1 transposed on v_mfma_f32_32x32x2_f32; 3 one-pass statistics finalisers (widths >= 16);
+ *                       7 filter gradients inside the stage kernels (>= 400k pixels per step).  Default 255.
+ *   NF_TRAIN_SERIAL=1   no side stream: every kernel on the caller's stream (kernel traces without overlap). */
 typedef struct nf_trainer nf_trainer;
 #define NF_OPT_ADAM     0
 #define NF_OPT_MOMENTUM 1
