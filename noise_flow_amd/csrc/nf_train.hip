@@ -2519,6 +2519,87 @@ __global__ __launch_bounds__(256) void k_c1_dz_mfma32(Geo g, const float *__rest
     if (MIX) acc_add_n<16>(dA, acc, g.nslot);
 }
 
+// l_1 (3x3 SAME conv of the pass-through half, folded Conv2d1x1) + bias + statistics at width 32 (k_c1_fwd): K = (tap, c) = 18,
+// step = tap, lane half = c; the B operands from a zero-bordered LDS tile of the patch's (mixed) pass-through channels.
+template <bool MIX>
+__global__ __launch_bounds__(256) void k_c1_fwd_mfma32(Geo g, const float *__restrict__ zin, const float *__restrict__ A,
+                                                       float *__restrict__ zmixed, const float *__restrict__ P, int off,
+                                                       float *__restrict__ h1, Acc stats)
+{
+    constexpr int W = 32;
+    extern __shared__ float smem[];   // z tile [(H+2)(W+2)][2], then the tile index of every pixel of a patch (int)
+    __shared__ float stage[4][32 * kRowPad];
+    float *red = &stage[0][0];        // [4][64][16], used once the pixel loop is over
+    const float *W1 = P + off, *b1 = W1 + 18 * W;
+    const int t = threadIdx.x, wv = t >> 6, ln = t & 63, col = ln & 31, half = ln >> 5;
+    const int Wp = g.W + 2, tile_px = (g.H + 2) * Wp;
+    float a[9], bo[16], s1[16], q1[16];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) a[k] = W1[k * 2 * W + half * W + col];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        bo[k] = b1[mfma_row(k, half)];
+        s1[k] = q1[k] = 0.0f;
+    }
+    float mm[16];
+    if (MIX) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mm[i] = A[i];
+    }
+    float *so = stage[wv];
+    int *lut = reinterpret_cast<int *>(smem + tile_px * 2);
+    for (int i = t; i < tile_px * 2; i += 256) smem[i] = 0.0f;
+    for (int px = t; px < g.HW; px += 256) {
+        const int r = px / g.W;
+        lut[px] = (r + 1) * Wp + (px - r * g.W) + 1;
+    }
+    const int npatch = (int)(g.npix / g.HW), ntiles = (g.HW + 31) >> 5;
+    for (int b = blockIdx.x; b < npatch; b += gridDim.x) {
+        const int64_t pb = (int64_t)b * g.HW;
+        __syncthreads();              // the border is zero / the previous patch is done with
+        for (int px = t; px < g.HW; px += 256) {
+            const float4 u = reinterpret_cast<const float4 *>(zin)[pb + px];
+            float2 v = make_float2(u.x, u.y);
+            if (MIX) {
+                v.x = u.x * mm[0] + u.y * mm[4] + u.z * mm[8] + u.w * mm[12];
+                v.y = u.x * mm[1] + u.y * mm[5] + u.z * mm[9] + u.w * mm[13];
+                reinterpret_cast<float4 *>(zmixed)[pb + px] = make_float4(v.x, v.y, u.x * mm[2] + u.y * mm[6] + u.z * mm[10] + u.w * mm[14],
+                                                                         u.x * mm[3] + u.y * mm[7] + u.z * mm[11] + u.w * mm[15]);
+            }
+            reinterpret_cast<float2 *>(smem)[lut[px]] = v;
+        }
+        __syncthreads();
+        for (int T = wv; T < ntiles; T += 4) {
+            const int pp = T * 32 + col;
+            const bool in = pp < g.HW;
+            const float *zt = smem + (in ? lut[pp] : 0) * 2 + half;
+            v16f D;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) D[v] = 0.0f;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const float bv = in ? zt[((tap / 3 - 1) * Wp + (tap % 3 - 1)) * 2] : 0.0f;
+                D = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tap], bv, D, 0, 0, 0);
+            }
+            wave_lds_fence();         // the previous tile's flush has been issued
+#pragma unroll
+            for (int v = 0; v < 16; v += 4) {
+                const float4 o = make_float4(D[v] + bo[v], D[v + 1] + bo[v + 1], D[v + 2] + bo[v + 2], D[v + 3] + bo[v + 3]);
+                *reinterpret_cast<float4 *>(so + col * kRowPad + mfma_row(v, half)) = o;
+                if (in) {
+                    s1[v] += o.x; s1[v + 1] += o.y; s1[v + 2] += o.z; s1[v + 3] += o.w;
+                    q1[v] = fmaf(o.x, o.x, q1[v]); q1[v + 1] = fmaf(o.y, o.y, q1[v + 1]);
+                    q1[v + 2] = fmaf(o.z, o.z, q1[v + 2]); q1[v + 3] = fmaf(o.w, o.w, q1[v + 3]);
+                }
+            }
+            wave_lds_fence();
+            rows_flush(so, h1, pb + T * 32, pb + g.HW);
+        }
+    }
+    lane_sums_to_slots(s1, red, stats, g.nslot, [](int k, int h) { return mfma_row(k, h); });
+    lane_sums_to_slots(q1, red, stats, g.nslot, [](int k, int h) { return 32 + mfma_row(k, h); });
+}
+
 // chain rule of the scalar parameterisations: dA -> PLU factors, d(a,b) -> sdn5 variables, gain_val
 __global__ void k_finish(TLayers ls, const float *__restrict__ P, CondIdx ci, int HW, const double *__restrict__ dAbuf,
                          const double *__restrict__ dabbuf, const double *__restrict__ dgbuf, double *__restrict__ G)
@@ -2731,7 +2812,7 @@ struct nf_trainer {
     hipEvent_t ev_fork[3] = {nullptr, nullptr, nullptr}, ev_done[3] = {nullptr, nullptr, nullptr};
     bool done_pending[3] = {false, false, false};
     bool serial = false;   // NF_TRAIN_SERIAL=1: everything on the caller's stream (kernel durations without overlap, for profiling)
-    int wide_mfma = 255;   // NF_TRAIN_WIDE_MFMA: width-32 stages on the matrix cores (bit 0 filter gradients, 1 l_2 forward, 2 l_2 backward, 3 statistics finalisers, 4 l_last forward, 5 l_last transposed, 6 l_1 transposed, 7 filter gradients inside the stage that holds their operands; 0: layer kernels only)
+    int wide_mfma = 511;   // NF_TRAIN_WIDE_MFMA: width-32 stages on the matrix cores (bit 0 filter gradients, 1 l_2 forward, 2 l_2 backward, 3 statistics finalisers, 4 l_last forward, 5 l_last transposed, 6 l_1 transposed, 7 filter gradients inside the stage that holds their operands, 8 l_1 forward; 0: layer kernels only)
     int tiled = 3;   // NF_TRAIN_TILED: bit 0 = tiled backward stages, bit 1 = tiled forward stages (0: layer kernels only)
     std::vector<void *> owned;
     bool has_sdn = false;
@@ -2803,12 +2884,22 @@ void coupling_forward(nf_trainer *t, const Geo &g, const TLayer &L, const float 
               off_w3 = L.off + 24 * w + w * w;
     const double n = (double)g.npix * t->sync_world;   // the moments are over the GLOBAL minibatch when the ranks are synchronised
     // zpre != null: the preceding Conv2d1x1 is folded into l_1 (which then also writes `zin`)
-    if (zpre)
+    const size_t z_tile = ((size_t)(g.H + 2) * (g.W + 2) * 2 + g.HW) * sizeof(float);
+    if (W == 32 && (t->wide_mfma & 256) && z_tile <= 60 * 1024) {
+        const unsigned ngrid = std::min<unsigned>((unsigned)(g.npix / g.HW), (unsigned)g.nslot);
+        if (zpre)
+            hipLaunchKernelGGL((k_c1_fwd_mfma32<true>), dim3(ngrid), dim3(256), z_tile, st, g, zpre, A, const_cast<float *>(zin),
+                               (const float *)t->d_params, off_w1, c.h1, t->acc(c.d_st1));
+        else
+            hipLaunchKernelGGL((k_c1_fwd_mfma32<false>), dim3(ngrid), dim3(256), z_tile, st, g, zin, (const float *)nullptr, (float *)nullptr,
+                               (const float *)t->d_params, off_w1, c.h1, t->acc(c.d_st1));
+    } else if (zpre) {
         hipLaunchKernelGGL((k_c1_fwd<W, true>), dim3(nb), dim3(TB), 0, st, g, zpre, A, const_cast<float *>(zin), t->d_params,
                            off_w1, c.h1, t->acc(c.d_st1));
-    else
+    } else {
         hipLaunchKernelGGL((k_c1_fwd<W, false>), dim3(nb), dim3(TB), 0, st, g, zin, (const float *)nullptr, (float *)nullptr,
                            t->d_params, off_w1, c.h1, t->acc(c.d_st1));
+    }
     sync_slots(t, t->acc(c.d_st1), 2 * w, g.nslot, st);
     // wide couplings: the slot sums are added up once, by a finaliser kernel, not by every workgroup of the consumer
     const bool fin = W >= 16 && (t->wide_mfma & 8);
