@@ -2121,61 +2121,6 @@ __device__ __forceinline__ void lane_sums_to_slots(const float (&vals)[16], floa
 
 __device__ __forceinline__ int mfma_row(int v, int half) { return 8 * (v >> 2) + 4 * half + (v & 3); }
 
-// BN1 + ReLU + l_2 + bias; statistics of the result (k_c2_fwd at width 32)
-__global__ __launch_bounds__(256) void k_c2_fwd_mfma32(Geo g, const float *__restrict__ h1, Acc stats1, double n, float *__restrict__ P,
-                                                       int off_m1, float *__restrict__ bn1_out, int off_w2, float *__restrict__ h2,
-                                                       Acc stats, const float *__restrict__ Pw, bool fin)
-{
-    constexpr int W = 32;
-    __shared__ float bn1[2 * W];
-    __shared__ float red[4 * 64 * 16];
-    bn_from_slots<W>(stats1, g.nslot, n, bn1, P, off_m1, off_m1 + W, bn1_out, fin);
-    const float *W2 = Pw + off_w2, *b2 = W2 + W * W;
-    const int t = threadIdx.x, wv = t >> 6, ln = t & 63, col = ln & 31, half = ln >> 5;
-    float a[16];   // A[out = col][k(s, half)] = W2[16 half + s][col]
-#pragma unroll
-    for (int k = 0; k < 16; ++k) a[k] = W2[(16 * half + k) * W + col];
-    float m1[16], r1[16], bo[16], s2[16], q2[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        m1[k] = bn1[16 * half + k];
-        r1[k] = bn1[W + 16 * half + k];
-        bo[k] = b2[mfma_row(k, half)];
-        s2[k] = q2[k] = 0.0f;
-    }
-    const int64_t ntiles = (g.npix + 31) >> 5;
-    for (int64_t T = (int64_t)blockIdx.x * 4 + wv; T < ntiles; T += (int64_t)gridDim.x * 4) {
-        const int64_t p = T * 32 + col;
-        const bool in = p < g.npix;
-        float x[16];
-#pragma unroll
-        for (int k = 0; k < 16; k += 4) {
-            const float4 v = in ? *reinterpret_cast<const float4 *>(h1 + p * W + 16 * half + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-            x[k] = v.x; x[k + 1] = v.y; x[k + 2] = v.z; x[k + 3] = v.w;
-        }
-        v16f D;
-#pragma unroll
-        for (int v = 0; v < 16; ++v) D[v] = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const float b = in ? fmaxf((x[k] - m1[k]) * r1[k], 0.0f) : 0.0f;
-            D = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], b, D, 0, 0, 0);
-        }
-        if (in) {
-#pragma unroll
-            for (int v = 0; v < 16; v += 4) {
-                const float4 o = make_float4(D[v] + bo[v], D[v + 1] + bo[v + 1], D[v + 2] + bo[v + 2], D[v + 3] + bo[v + 3]);
-                *reinterpret_cast<float4 *>(h2 + p * W + mfma_row(v, half)) = o;
-                s2[v] += o.x; s2[v + 1] += o.y; s2[v + 2] += o.z; s2[v + 3] += o.w;
-                q2[v] = fmaf(o.x, o.x, q2[v]); q2[v + 1] = fmaf(o.y, o.y, q2[v + 1]);
-                q2[v + 2] = fmaf(o.z, o.z, q2[v + 2]); q2[v + 3] = fmaf(o.w, o.w, q2[v + 3]);
-            }
-        }
-    }
-    lane_sums_to_slots(s2, red, stats, g.nslot, [](int k, int h) { return mfma_row(k, h); });
-    lane_sums_to_slots(q2, red, stats, g.nslot, [](int k, int h) { return 32 + mfma_row(k, h); });
-}
-
 // the reverse of rows_fetch / rows_park: 32 rows parked in LDS (stride kRowPad) -> 4 KB of consecutive memory
 __device__ __forceinline__ void rows_flush(const float *lds, float *__restrict__ dst, int64_t row0, int64_t row_end)
 {
@@ -2186,6 +2131,72 @@ __device__ __forceinline__ void rows_flush(const float *lds, float *__restrict__
         if (row0 + lr < row_end)
             reinterpret_cast<float4 *>(dst)[(row0 + lr) * 8 + (ln & 7)] = *reinterpret_cast<const float4 *>(lds + lr * kRowPad + 4 * (ln & 7));
     }
+}
+
+// BN1 + ReLU + l_2 + bias; statistics of the result (k_c2_fwd at width 32); tensor tiles staged through LDS
+__global__ __launch_bounds__(256) void k_c2_fwd_mfma32(Geo g, const float *__restrict__ h1, Acc stats1, double n, float *__restrict__ P,
+                                                       int off_m1, float *__restrict__ bn1_out, int off_w2, float *__restrict__ h2,
+                                                       Acc stats, const float *__restrict__ Pw, bool fin)
+{
+    constexpr int W = 32;
+    __shared__ float bn1[2 * W];
+    __shared__ float stage[4][32 * kRowPad];
+    __shared__ float red[4 * 64 * 16];
+    bn_from_slots<W>(stats1, g.nslot, n, bn1, P, off_m1, off_m1 + W, bn1_out, fin);
+    const float *W2 = Pw + off_w2, *b2 = W2 + W * W;
+    const int t = threadIdx.x, wv = t >> 6, ln = t & 63, col = ln & 31, half = ln >> 5;
+    float a[16];   // A[out = col][k(s, half)] = W2[16 half + s][col]
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a[k] = W2[(16 * half + k) * W + col];
+    float m1[4], r1[4], bo[16], s2[16], q2[16];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {   // BN1 + ReLU is applied on the way into LDS: the lane's 4 channels of the 16-byte pieces it moves
+        m1[k] = bn1[4 * (ln & 7) + k];
+        r1[k] = bn1[W + 4 * (ln & 7) + k];
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        bo[k] = b2[mfma_row(k, half)];
+        s2[k] = q2[k] = 0.0f;
+    }
+    float *sx = stage[wv];
+    const int64_t ntiles = (g.npix + 31) >> 5, stride = (int64_t)gridDim.x * 4;
+    int64_t T = (int64_t)blockIdx.x * 4 + wv;
+    RowTile rx;
+    if (T < ntiles) rows_fetch(rx, h1, T * 32, g.npix);
+    for (; T < ntiles; T += stride) {
+        const bool in = T * 32 + col < g.npix;
+        wave_lds_fence();             // the previous tile's flush has been issued
+        rows_park<true>(rx, sx, m1, r1, T * 32, g.npix);
+        if (T + stride < ntiles) rows_fetch(rx, h1, (T + stride) * 32, g.npix);
+        wave_lds_fence();
+        float x[16];
+#pragma unroll
+        for (int k = 0; k < 16; k += 4) {
+            const float4 v = *reinterpret_cast<const float4 *>(sx + col * kRowPad + 16 * half + k);
+            x[k] = v.x; x[k + 1] = v.y; x[k + 2] = v.z; x[k + 3] = v.w;
+        }
+        v16f D;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) D[v] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) D = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], x[k], D, 0, 0, 0);
+        wave_lds_fence();             // every lane has read its inputs: the tile takes the result
+#pragma unroll
+        for (int v = 0; v < 16; v += 4) {
+            const float4 o = make_float4(D[v] + bo[v], D[v + 1] + bo[v + 1], D[v + 2] + bo[v + 2], D[v + 3] + bo[v + 3]);
+            *reinterpret_cast<float4 *>(sx + col * kRowPad + mfma_row(v, half)) = o;
+            if (in) {
+                s2[v] += o.x; s2[v + 1] += o.y; s2[v + 2] += o.z; s2[v + 3] += o.w;
+                q2[v] = fmaf(o.x, o.x, q2[v]); q2[v + 1] = fmaf(o.y, o.y, q2[v + 1]);
+                q2[v + 2] = fmaf(o.z, o.z, q2[v + 2]); q2[v + 3] = fmaf(o.w, o.w, q2[v + 3]);
+            }
+        }
+        wave_lds_fence();
+        rows_flush(sx, h2, T * 32, g.npix);
+    }
+    lane_sums_to_slots(s2, red, stats, g.nslot, [](int k, int h) { return mfma_row(k, h); });
+    lane_sums_to_slots(q2, red, stats, g.nslot, [](int k, int h) { return 32 + mfma_row(k, h); });
 }
 
 // BN2 backward -> g_h2 (t1, in place), d l_2/b; transposed l_2 + ReLU mask -> d loss / d xhat1 (t2) and its two batch sums
