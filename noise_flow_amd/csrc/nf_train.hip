@@ -1864,7 +1864,7 @@ __global__ __launch_bounds__(256) void k_w2_grad_mfma32(Geo g, const float *__re
 // The indicator channel's gradient, sum over the pixels whose tap falls on the padding ring, is the column sum of ALL of gu
 // (the centre tap's column sum) minus the column sum over the taps that land inside — both fall out of the B operands.
 __global__ __launch_bounds__(256) void k_w3_grad_mfma32(Geo g, const float *__restrict__ h2, const float *__restrict__ bn2,
-                                                        const float *__restrict__ gu, int off_w3, Acc G)
+                                                        const float *__restrict__ gu, int off_w3, Acc G, int S)
 {
     extern __shared__ float smem[];   // gu tile [(H+2)(W+2)][4], then the tile index of every pixel of a patch (int)
     __shared__ float stage[4][32 * kRowPad];
@@ -1893,18 +1893,19 @@ __global__ __launch_bounds__(256) void k_w3_grad_mfma32(Geo g, const float *__re
         lut[px] = (r + 1) * Wp + (px - r * g.W) + 1;
     }
     const int npatch = (int)(g.npix / g.HW), ntiles = (g.HW + 31) >> 5;
-    for (int b = blockIdx.x; b < npatch; b += gridDim.x) {
+    for (int unit = blockIdx.x; unit < npatch * S; unit += gridDim.x) {   // S workgroups share a patch's tiles
+        const int b = unit / S, T0 = wv + 4 * (unit - b * S);
         const float *hb = h2 + (int64_t)b * g.HW * 32;
         RowTile ra;
-        if (wv < ntiles) rows_fetch(ra, hb, wv * 32, g.HW);
+        if (T0 < ntiles) rows_fetch(ra, hb, T0 * 32, g.HW);
         __syncthreads();   // the border is zero / the previous patch is done with
         for (int px = t; px < g.HW; px += 256)
             reinterpret_cast<float4 *>(smem)[lut[px]] = reinterpret_cast<const float4 *>(gu)[(int64_t)b * g.HW + px];
         __syncthreads();
-        for (int T = wv; T < ntiles; T += 4) {
+        for (int T = T0; T < ntiles; T += 4 * S) {
             wave_lds_fence();
             rows_park<true>(ra, sa, m, rs, T * 32, g.HW);
-            if (T + 4 < ntiles) rows_fetch(ra, hb, (T + 4) * 32, g.HW);
+            if (T + 4 * S < ntiles) rows_fetch(ra, hb, (T + 4 * S) * 32, g.HW);
             wave_lds_fence();
 #pragma unroll 4
             for (int s2 = 0; s2 < 16; ++s2) {
@@ -1947,7 +1948,7 @@ __global__ __launch_bounds__(256) void k_w3_grad_mfma32(Geo g, const float *__re
 // d l_1/W[tap][c][j] = sum_p z[p + tap][c] * g_h1[p][j]  (c: the two pass-through channels; z from a zero-bordered tile of the
 // patch): rows (tap, c) = 18 of the 32, columns j, K = the pixels.
 __global__ __launch_bounds__(256) void k_w1_grad_mfma32(Geo g, const float *__restrict__ zin, const float *__restrict__ t2, int off_w1,
-                                                        Acc G)
+                                                        Acc G, int S)
 {
     extern __shared__ float smem[];   // z tile [(H+2)(W+2)][2], then the tile index of every pixel of a patch (int)
     __shared__ float stage[4][32 * kRowPad];
@@ -1968,18 +1969,19 @@ __global__ __launch_bounds__(256) void k_w1_grad_mfma32(Geo g, const float *__re
         lut[px] = (r + 1) * Wp + (px - r * g.W) + 1;
     }
     const int npatch = (int)(g.npix / g.HW), ntiles = (g.HW + 31) >> 5;
-    for (int b = blockIdx.x; b < npatch; b += gridDim.x) {
+    for (int unit = blockIdx.x; unit < npatch * S; unit += gridDim.x) {   // S workgroups share a patch's tiles
+        const int b = unit / S, T0 = wv + 4 * (unit - b * S);
         const float *tb = t2 + (int64_t)b * g.HW * 32;
         RowTile rb;
-        if (wv < ntiles) rows_fetch(rb, tb, wv * 32, g.HW);
+        if (T0 < ntiles) rows_fetch(rb, tb, T0 * 32, g.HW);
         __syncthreads();
         for (int px = t; px < g.HW; px += 256)
             reinterpret_cast<float2 *>(smem)[lut[px]] = *reinterpret_cast<const float2 *>(zin + ((int64_t)b * g.HW + px) * 4);
         __syncthreads();
-        for (int T = wv; T < ntiles; T += 4) {
+        for (int T = T0; T < ntiles; T += 4 * S) {
             wave_lds_fence();
             rows_park<false>(rb, sb, unused_m, unused_m, T * 32, g.HW);
-            if (T + 4 < ntiles) rows_fetch(rb, tb, (T + 4) * 32, g.HW);
+            if (T + 4 * S < ntiles) rows_fetch(rb, tb, (T + 4 * S) * 32, g.HW);
             wave_lds_fence();
 #pragma unroll 4
             for (int s2 = 0; s2 < 16; ++s2) {
@@ -2320,7 +2322,7 @@ __global__ __launch_bounds__(256) void k_c2_bwd_mfma32(Geo g, const float *__res
 template <bool WGRAD>
 __global__ __launch_bounds__(256) void k_c3_dh_mfma32(Geo g, const float *__restrict__ h2, const float *__restrict__ bn2,
                                                       const float *__restrict__ P, int off_w3, const float *__restrict__ gu,
-                                                      float *__restrict__ t1, Acc bstats, Acc G)
+                                                      float *__restrict__ t1, Acc bstats, Acc G, int S)
 {
     constexpr int W = 32;
     extern __shared__ float smem[];   // gu tile [(H+2)(W+2)][4], then the tile index of every pixel of a patch (int)
@@ -2353,19 +2355,20 @@ __global__ __launch_bounds__(256) void k_c3_dh_mfma32(Geo g, const float *__rest
         lut[px] = (r + 1) * Wp + (px - r * g.W) + 1;
     }
     const int npatch = (int)(g.npix / g.HW), ntiles = (g.HW + 31) >> 5;
-    for (int b = blockIdx.x; b < npatch; b += gridDim.x) {
+    for (int unit = blockIdx.x; unit < npatch * S; unit += gridDim.x) {   // S workgroups share a patch's tiles
+        const int b = unit / S, T0 = wv + 4 * (unit - b * S);
         const int64_t pb = (int64_t)b * g.HW;
         RowTile rx;
-        if (wv < ntiles) rows_fetch(rx, h2, pb + wv * 32, pb + g.HW);
+        if (T0 < ntiles) rows_fetch(rx, h2, pb + T0 * 32, pb + g.HW);
         __syncthreads();              // the border is zero / the previous patch is done with
         for (int px = t; px < g.HW; px += 256) reinterpret_cast<float4 *>(smem)[lut[px]] = reinterpret_cast<const float4 *>(gu)[pb + px];
         __syncthreads();
-        for (int T = wv; T < ntiles; T += 4) {
+        for (int T = T0; T < ntiles; T += 4 * S) {
             const int pp = T * 32 + col;
             const bool in = pp < g.HW;
             wave_lds_fence();
             rows_park<false>(rx, sx, unused, unused, pb + T * 32, pb + g.HW);
-            if (T + 4 < ntiles) rows_fetch(rx, h2, pb + (T + 4) * 32, pb + g.HW);
+            if (T + 4 * S < ntiles) rows_fetch(rx, h2, pb + (T + 4 * S) * 32, pb + g.HW);
             const float *gt = smem + (in ? lut[pp] : 0) * 4 + 2 * half;
             v16f D;
 #pragma unroll
@@ -2535,7 +2538,7 @@ __global__ __launch_bounds__(256) void k_c1_dz_mfma32(Geo g, const float *__rest
 template <bool MIX>
 __global__ __launch_bounds__(256) void k_c1_fwd_mfma32(Geo g, const float *__restrict__ zin, const float *__restrict__ A,
                                                        float *__restrict__ zmixed, const float *__restrict__ P, int off,
-                                                       float *__restrict__ h1, Acc stats)
+                                                       float *__restrict__ h1, Acc stats, int S)
 {
     constexpr int W = 32;
     extern __shared__ float smem[];   // z tile [(H+2)(W+2)][2], then the tile index of every pixel of a patch (int)
@@ -2565,7 +2568,8 @@ __global__ __launch_bounds__(256) void k_c1_fwd_mfma32(Geo g, const float *__res
         lut[px] = (r + 1) * Wp + (px - r * g.W) + 1;
     }
     const int npatch = (int)(g.npix / g.HW), ntiles = (g.HW + 31) >> 5;
-    for (int b = blockIdx.x; b < npatch; b += gridDim.x) {
+    for (int unit = blockIdx.x; unit < npatch * S; unit += gridDim.x) {   // S workgroups share a patch's tiles
+        const int b = unit / S, part = unit - b * S;
         const int64_t pb = (int64_t)b * g.HW;
         __syncthreads();              // the border is zero / the previous patch is done with
         for (int px = t; px < g.HW; px += 256) {
@@ -2574,13 +2578,14 @@ __global__ __launch_bounds__(256) void k_c1_fwd_mfma32(Geo g, const float *__res
             if (MIX) {
                 v.x = u.x * mm[0] + u.y * mm[4] + u.z * mm[8] + u.w * mm[12];
                 v.y = u.x * mm[1] + u.y * mm[5] + u.z * mm[9] + u.w * mm[13];
-                reinterpret_cast<float4 *>(zmixed)[pb + px] = make_float4(v.x, v.y, u.x * mm[2] + u.y * mm[6] + u.z * mm[10] + u.w * mm[14],
-                                                                         u.x * mm[3] + u.y * mm[7] + u.z * mm[11] + u.w * mm[15]);
+                if (part == 0)
+                    reinterpret_cast<float4 *>(zmixed)[pb + px] = make_float4(v.x, v.y, u.x * mm[2] + u.y * mm[6] + u.z * mm[10] + u.w * mm[14],
+                                                                             u.x * mm[3] + u.y * mm[7] + u.z * mm[11] + u.w * mm[15]);
             }
             reinterpret_cast<float2 *>(smem)[lut[px]] = v;
         }
         __syncthreads();
-        for (int T = wv; T < ntiles; T += 4) {
+        for (int T = wv + 4 * part; T < ntiles; T += 4 * S) {
             const int pp = T * 32 + col;
             const bool in = pp < g.HW;
             const float *zt = smem + (in ? lut[pp] : 0) * 2 + half;
@@ -2885,6 +2890,14 @@ void sync_slots(nf_trainer *t, Acc a, int count, int nslot, hipStream_t st)
     hipLaunchKernelGGL(k_slots_scatter, dim3((unsigned)count), dim3(64), 0, st, a, nslot, (const double *)t->sync_buf);
 }
 
+// per-patch kernels: how many workgroups share one patch's tiles — small minibatches leave CUs idle otherwise (138 patches on
+// 256 CUs); bounded by the slots (one per workgroup)
+inline int patch_split(const Geo &g)
+{
+    const int64_t npatch = g.npix / g.HW;
+    return (int)std::max<int64_t>(1, std::min<int64_t>(4, std::min<int64_t>(g.nslot / npatch, 512 / npatch)));
+}
+
 template <int W>
 void coupling_forward(nf_trainer *t, const Geo &g, const TLayer &L, const float *zin, float *zout, Acc ldacc,
                       const float *zpre, const float *A, hipStream_t st)
@@ -2897,13 +2910,14 @@ void coupling_forward(nf_trainer *t, const Geo &g, const TLayer &L, const float 
     // zpre != null: the preceding Conv2d1x1 is folded into l_1 (which then also writes `zin`)
     const size_t z_tile = ((size_t)(g.H + 2) * (g.W + 2) * 2 + g.HW) * sizeof(float);
     if (W == 32 && (t->wide_mfma & 256) && z_tile <= 60 * 1024) {
-        const unsigned ngrid = std::min<unsigned>((unsigned)(g.npix / g.HW), (unsigned)g.nslot);
+        const int S = patch_split(g);
+        const unsigned ngrid = std::min<unsigned>((unsigned)(g.npix / g.HW) * S, (unsigned)g.nslot);
         if (zpre)
             hipLaunchKernelGGL((k_c1_fwd_mfma32<true>), dim3(ngrid), dim3(256), z_tile, st, g, zpre, A, const_cast<float *>(zin),
-                               (const float *)t->d_params, off_w1, c.h1, t->acc(c.d_st1));
+                               (const float *)t->d_params, off_w1, c.h1, t->acc(c.d_st1), S);
         else
             hipLaunchKernelGGL((k_c1_fwd_mfma32<false>), dim3(ngrid), dim3(256), z_tile, st, g, zin, (const float *)nullptr, (float *)nullptr,
-                               (const float *)t->d_params, off_w1, c.h1, t->acc(c.d_st1));
+                               (const float *)t->d_params, off_w1, c.h1, t->acc(c.d_st1), S);
     } else if (zpre) {
         hipLaunchKernelGGL((k_c1_fwd<W, true>), dim3(nb), dim3(TB), 0, st, g, zpre, A, const_cast<float *>(zin), t->d_params,
                            off_w1, c.h1, t->acc(c.d_st1));
@@ -2971,12 +2985,14 @@ void coupling_backward(nf_trainer *t, const Geo &g, const TLayer &L, const float
     // kernels leave idle, and fusing them lengthens the critical path instead (1.67 -> 1.86 ms).
     const bool fuse = (t->wide_mfma & 1) && (t->wide_mfma & 128) && g.npix >= 400 * 1024;
     const bool fuse_w3 = mfma_dh && fuse, fuse_w2 = W == 32 && (t->wide_mfma & 4) && fuse;
+    const int S = patch_split(g);
+    const unsigned npw = std::min<unsigned>((unsigned)(g.npix / g.HW) * S, (unsigned)g.nslot);   // grid of the per-patch kernels
     if (mfma_dh && fuse_w3)
-        hipLaunchKernelGGL(k_c3_dh_mfma32<true>, dim3(std::min<unsigned>((unsigned)(g.npix / g.HW), (unsigned)g.nslot)), dim3(256), gu_tile, st, g,
-                           (const float *)c.h2, bn2, (const float *)t->d_params, off_w3, (const float *)gu, t1, t->acc(c.d_bs2), G);
+        hipLaunchKernelGGL(k_c3_dh_mfma32<true>, dim3(npw), dim3(256), gu_tile, st, g,
+                           (const float *)c.h2, bn2, (const float *)t->d_params, off_w3, (const float *)gu, t1, t->acc(c.d_bs2), G, S);
     else if (mfma_dh)
-        hipLaunchKernelGGL(k_c3_dh_mfma32<false>, dim3(std::min<unsigned>((unsigned)(g.npix / g.HW), (unsigned)g.nslot)), dim3(256), gu_tile, st, g,
-                           (const float *)c.h2, bn2, (const float *)t->d_params, off_w3, (const float *)gu, t1, t->acc(c.d_bs2), G);
+        hipLaunchKernelGGL(k_c3_dh_mfma32<false>, dim3(npw), dim3(256), gu_tile, st, g,
+                           (const float *)c.h2, bn2, (const float *)t->d_params, off_w3, (const float *)gu, t1, t->acc(c.d_bs2), G, S);
     else
         hipLaunchKernelGGL(k_c3_dh<W>, dim3(nb), dim3(TB), 0, st, g, c.h2, bn2, t->d_params, off_w3, gu, t1, t->acc(c.d_bs2));
     sync_slots(t, t->acc(c.d_bs2), 2 * w, g.nslot, st);
@@ -3003,14 +3019,12 @@ void coupling_backward(nf_trainer *t, const Geo &g, const TLayer &L, const float
     (void)hipStreamWaitEvent(sd, t->ev_fork[0], 0);
     // (the per-patch operand tiles of the matrix-core kernels sit in dynamic LDS: patches of up to ~3 000 pixels)
     if (W == 32 && (t->wide_mfma & 1) && ((size_t)(g.H + 2) * (g.W + 2) * 4 + g.HW) * sizeof(float) <= 60 * 1024) {
-        const unsigned npatch = (unsigned)(g.npix / g.HW), nw = std::min<unsigned>((unsigned)g.nslot, 512u);
+        const unsigned nw = std::min<unsigned>((unsigned)g.nslot, 512u);
         const size_t tile = (size_t)(g.H + 2) * (g.W + 2) * 4 * sizeof(float), lut = (size_t)g.HW * sizeof(int);
         if (!fuse_w3)
-            hipLaunchKernelGGL(k_w3_grad_mfma32, dim3(std::min<unsigned>(npatch, (unsigned)g.nslot)), dim3(256), tile + lut, sd, g, c.h2, bn2,
-                               (const float *)gu, off_w3, G);
+            hipLaunchKernelGGL(k_w3_grad_mfma32, dim3(npw), dim3(256), tile + lut, sd, g, c.h2, bn2, (const float *)gu, off_w3, G, S);
         if (!fuse_w2) hipLaunchKernelGGL(k_w2_grad_mfma32, dim3(nw), dim3(256), 0, sd, g, c.h1, bn1, (const float *)t1, off_w2, G);
-        hipLaunchKernelGGL(k_w1_grad_mfma32, dim3(std::min<unsigned>(npatch, (unsigned)g.nslot)), dim3(256), tile / 2 + lut, sd, g, zin,
-                           (const float *)t2, off_w1, G);
+        hipLaunchKernelGGL(k_w1_grad_mfma32, dim3(npw), dim3(256), tile / 2 + lut, sd, g, zin, (const float *)t2, off_w1, G, S);
     } else {
         hipLaunchKernelGGL(k_w3_grad<W>, dim3(ng, 9), dim3(TB), 0, sd, g, c.h2, bn2, gu, off_w3, G);
         hipLaunchKernelGGL(k_w2_grad<W>, dim3(ng, w), dim3(TB), 0, sd, g, c.h1, bn1, t1, off_w2, G);
