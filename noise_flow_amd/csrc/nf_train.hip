@@ -1778,17 +1778,22 @@ __device__ __forceinline__ void mfma_tile_to_slots(const v16f &D, float *red, Ac
 // four 16-byte loads per lane (1 KB of whole cache lines per instruction; one dword per lane and MFMA step left the kernels
 // latency-bound at ~1 TB/s), parks them in its own LDS rows of 36 floats, and each MFMA step reads its two pixels back as
 // one ds_read_b32 per operand.  LDS instructions of one wavefront execute in order, so no barrier — only a compiler fence.
-constexpr int kRowPad = 36;
+// The same kernels serve width 16 ([rows][16] tensors, 2 KB per 32 rows, LDS rows of 20 floats): the channel GEMMs then use
+// half of the instruction's M or K extent (A rows / K steps beyond the width are absent), the pixel-K GEMMs ignore the rows
+// and columns beyond it.  W / 2 = the K steps of a channel GEMM = the values a lane holds of its pixel's row.
 struct RowTile {
     float4 v[4];
 };
+template <int W>
 __device__ __forceinline__ void rows_fetch(RowTile &r, const float *__restrict__ src, int64_t row0, int64_t row_end)
 {
+    static_assert(W == 16 || W == 32, "matrix-core trainer kernels: widths 16 and 32");
+    constexpr int RQ = W / 4;        // 16-byte pieces per row
     const int ln = threadIdx.x & 63;
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const int64_t row = row0 + ((ln + 64 * m) >> 3);
-        r.v[m] = row < row_end ? reinterpret_cast<const float4 *>(src)[row * 8 + (ln & 7)] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int m = 0; m < W / 8; ++m) {
+        const int64_t row = row0 + (ln + 64 * m) / RQ;
+        r.v[m] = row < row_end ? reinterpret_cast<const float4 *>(src)[row * RQ + ln % RQ] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 __device__ __forceinline__ void wave_lds_fence()
@@ -1797,15 +1802,16 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-// plain copy / BN + ReLU of the lane's 4 channels (4 (ln & 7) ..) on the way into LDS; rows past the end stay zero
-template <bool BNRELU>
+// plain copy / BN + ReLU of the lane's 4 channels (4 (ln % (W / 4)) ..) on the way into LDS; rows past the end stay zero
+template <int W, bool BNRELU>
 __device__ __forceinline__ void rows_park(const RowTile &r, float *lds, const float (&m)[4], const float (&rs)[4], int64_t row0,
                                           int64_t row_end)
 {
+    constexpr int RQ = W / 4, RP = W + 4;
     const int ln = threadIdx.x & 63;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int lr = (ln + 64 * k) >> 3;
+    for (int k = 0; k < W / 8; ++k) {
+        const int lr = (ln + 64 * k) / RQ;
         float4 v = r.v[k];
         if (BNRELU) {
             const bool in = row0 + lr < row_end;
@@ -1814,23 +1820,25 @@ __device__ __forceinline__ void rows_park(const RowTile &r, float *lds, const fl
             v.z = in ? fmaxf((v.z - m[2]) * rs[2], 0.0f) : 0.0f;
             v.w = in ? fmaxf((v.w - m[3]) * rs[3], 0.0f) : 0.0f;
         }
-        *reinterpret_cast<float4 *>(lds + lr * kRowPad + 4 * (ln & 7)) = v;
+        *reinterpret_cast<float4 *>(lds + lr * RP + 4 * (ln % RQ)) = v;
     }
 }
 
 // d l_2/W[i][j] = sum_p relu(bn1(h1))[p][i] * g_h2[p][j]
-__global__ __launch_bounds__(256) void k_w2_grad_mfma32(Geo g, const float *__restrict__ h1, const float *__restrict__ bn1,
-                                                        const float *__restrict__ t1, int off_w2, Acc G)
+template <int W>
+__global__ __launch_bounds__(256) void k_w2_grad_mfma(Geo g, const float *__restrict__ h1, const float *__restrict__ bn1,
+                                                      const float *__restrict__ t1, int off_w2, Acc G)
 {
-    __shared__ float stage[4][2][32 * kRowPad];
+    constexpr int RP = W + 4;
+    __shared__ float stage[4][2][32 * 36];
     float *red = &stage[0][0][0];   // [4][16][64], used once the pixel loop is over (mfma_tile_to_slots starts with a barrier)
     static_assert(sizeof(stage) >= 4 * 16 * 64 * sizeof(float), "the reduction buffer must fit the staging area");
     const int t = threadIdx.x, wv = t >> 6, ln = t & 63, col = ln & 31, half = ln >> 5;
     float m[4], rs[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        m[k] = bn1[4 * (ln & 7) + k];
-        rs[k] = bn1[32 + 4 * (ln & 7) + k];
+        m[k] = bn1[4 * (ln % (W / 4)) + k];
+        rs[k] = bn1[W + 4 * (ln % (W / 4)) + k];
     }
     v16f D;
 #pragma unroll
@@ -1840,34 +1848,37 @@ __global__ __launch_bounds__(256) void k_w2_grad_mfma32(Geo g, const float *__re
     int64_t T = (int64_t)blockIdx.x * 4 + wv;
     RowTile ra, rb;
     if (T < ntiles) {
-        rows_fetch(ra, h1, T * 32, g.npix);
-        rows_fetch(rb, t1, T * 32, g.npix);
+        rows_fetch<W>(ra, h1, T * 32, g.npix);
+        rows_fetch<W>(rb, t1, T * 32, g.npix);
     }
     for (; T < ntiles; T += stride) {
         wave_lds_fence();                                  // the previous tile's reads are issued
-        rows_park<true>(ra, sa, m, rs, T * 32, g.npix);
-        rows_park<false>(rb, sb, m, rs, T * 32, g.npix);
+        rows_park<W, true>(ra, sa, m, rs, T * 32, g.npix);
+        rows_park<W, false>(rb, sb, m, rs, T * 32, g.npix);
         if (T + stride < ntiles) {                         // next tile in flight during the MFMAs
-            rows_fetch(ra, h1, (T + stride) * 32, g.npix);
-            rows_fetch(rb, t1, (T + stride) * 32, g.npix);
+            rows_fetch<W>(ra, h1, (T + stride) * 32, g.npix);
+            rows_fetch<W>(rb, t1, (T + stride) * 32, g.npix);
         }
         wave_lds_fence();
+        const int cw = col < W ? col : 0;   // rows / columns beyond the width are not used
 #pragma unroll
         for (int s2 = 0; s2 < 16; ++s2)
-            D = __builtin_amdgcn_mfma_f32_32x32x2f32(sa[(2 * s2 + half) * kRowPad + col], sb[(2 * s2 + half) * kRowPad + col], D, 0, 0, 0);
+            D = __builtin_amdgcn_mfma_f32_32x32x2f32(sa[(2 * s2 + half) * RP + cw], sb[(2 * s2 + half) * RP + cw], D, 0, 0, 0);
     }
-    mfma_tile_to_slots(D, red, G + off_w2, g.nslot, [](int i, int j) { return i * 32 + j; });
+    mfma_tile_to_slots(D, red, G + off_w2, g.nslot, [](int i, int j) { return i < W && j < W ? i * W + j : -1; });
 }
 
 // d l_last/W[tap][i][q] = sum_p' relu(bn2(h2))[p'][i] * gu[p' - tap][q]  (p' = the pixel the tap reads, inside the patch;
 // gu from a zero-bordered tile of the patch), columns (tap, q): taps 0..7 in one 32-column tile, tap 8 in a second.
 // The indicator channel's gradient, sum over the pixels whose tap falls on the padding ring, is the column sum of ALL of gu
 // (the centre tap's column sum) minus the column sum over the taps that land inside — both fall out of the B operands.
-__global__ __launch_bounds__(256) void k_w3_grad_mfma32(Geo g, const float *__restrict__ h2, const float *__restrict__ bn2,
-                                                        const float *__restrict__ gu, int off_w3, Acc G, int S)
+template <int W>
+__global__ __launch_bounds__(256) void k_w3_grad_mfma(Geo g, const float *__restrict__ h2, const float *__restrict__ bn2,
+                                                      const float *__restrict__ gu, int off_w3, Acc G, int S)
 {
+    constexpr int RP = W + 4;
     extern __shared__ float smem[];   // gu tile [(H+2)(W+2)][4], then the tile index of every pixel of a patch (int)
-    __shared__ float stage[4][32 * kRowPad];
+    __shared__ float stage[4][32 * 36];
     float *red = &stage[0][0];        // [4][16][64], used once the pixel loop is over
     static_assert(sizeof(stage) >= 4 * 16 * 64 * sizeof(float), "the reduction buffer must fit the staging area");
     __shared__ float cs[2][4][64], cst[40];
@@ -1876,10 +1887,10 @@ __global__ __launch_bounds__(256) void k_w3_grad_mfma32(Geo g, const float *__re
     float m[4], rs[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        m[k] = bn2[4 * (ln & 7) + k];
-        rs[k] = bn2[32 + 4 * (ln & 7) + k];
+        m[k] = bn2[4 * (ln % (W / 4)) + k];
+        rs[k] = bn2[W + 4 * (ln % (W / 4)) + k];
     }
-    const int tap0 = col >> 2, q = col & 3;
+    const int tap0 = col >> 2, q = col & 3, cw = col < W ? col : 0;
     const int d0 = (tap0 / 3 - 1) * Wp + (tap0 % 3 - 1), d1 = Wp + 1;   // tile offset of the pixel tap (di, dj) comes from
     v16f D0, D1;
 #pragma unroll
@@ -1895,17 +1906,17 @@ __global__ __launch_bounds__(256) void k_w3_grad_mfma32(Geo g, const float *__re
     const int npatch = (int)(g.npix / g.HW), ntiles = (g.HW + 31) >> 5;
     for (int unit = blockIdx.x; unit < npatch * S; unit += gridDim.x) {   // S workgroups share a patch's tiles
         const int b = unit / S, T0 = wv + 4 * (unit - b * S);
-        const float *hb = h2 + (int64_t)b * g.HW * 32;
+        const float *hb = h2 + (int64_t)b * g.HW * W;
         RowTile ra;
-        if (T0 < ntiles) rows_fetch(ra, hb, T0 * 32, g.HW);
+        if (T0 < ntiles) rows_fetch<W>(ra, hb, T0 * 32, g.HW);
         __syncthreads();   // the border is zero / the previous patch is done with
         for (int px = t; px < g.HW; px += 256)
             reinterpret_cast<float4 *>(smem)[lut[px]] = reinterpret_cast<const float4 *>(gu)[(int64_t)b * g.HW + px];
         __syncthreads();
         for (int T = T0; T < ntiles; T += 4 * S) {
             wave_lds_fence();
-            rows_park<true>(ra, sa, m, rs, T * 32, g.HW);
-            if (T + 4 * S < ntiles) rows_fetch(ra, hb, (T + 4 * S) * 32, g.HW);
+            rows_park<W, true>(ra, sa, m, rs, T * 32, g.HW);
+            if (T + 4 * S < ntiles) rows_fetch<W>(ra, hb, (T + 4 * S) * 32, g.HW);
             wave_lds_fence();
 #pragma unroll 4
             for (int s2 = 0; s2 < 16; ++s2) {
@@ -1916,7 +1927,7 @@ __global__ __launch_bounds__(256) void k_w3_grad_mfma32(Geo g, const float *__re
                     b0 = smem[(tp - d0) * 4 + q];
                     if (col < 4) b1 = smem[(tp - d1) * 4 + q];
                 }
-                const float a = sa[(2 * s2 + half) * kRowPad + col];
+                const float a = sa[(2 * s2 + half) * RP + cw];
                 S0 += b0;
                 S1 += b1;
                 D0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, D0, 0, 0, 0);
@@ -1925,8 +1936,8 @@ __global__ __launch_bounds__(256) void k_w3_grad_mfma32(Geo g, const float *__re
         }
     }
     const Acc dst = G + off_w3;
-    mfma_tile_to_slots(D0, red, dst, g.nslot, [](int i, int c) { return (c >> 2) * 132 + i * 4 + (c & 3); });
-    mfma_tile_to_slots(D1, red, dst, g.nslot, [](int i, int c) { return c < 4 ? 8 * 132 + i * 4 + c : -1; });
+    mfma_tile_to_slots(D0, red, dst, g.nslot, [](int i, int c) { return i < W ? (c >> 2) * (W + 1) * 4 + i * 4 + (c & 3) : -1; });
+    mfma_tile_to_slots(D1, red, dst, g.nslot, [](int i, int c) { return i < W && c < 4 ? 8 * (W + 1) * 4 + i * 4 + c : -1; });
     cs[0][wv][ln] = S0;
     cs[1][wv][ln] = S1;
     __syncthreads();
@@ -1939,7 +1950,7 @@ __global__ __launch_bounds__(256) void k_w3_grad_mfma32(Geo g, const float *__re
     }
     __syncthreads();
     if (t < 36) {
-        float *d = dst.p + (size_t)((t >> 2) * 132 + 128 + (t & 3)) * NSLOT;
+        float *d = dst.p + (size_t)((t >> 2) * (W + 1) * 4 + W * 4 + (t & 3)) * NSLOT;
         d[blockIdx.x] = cst[16 + (t & 3)] - cst[t];
         for (int k = blockIdx.x + gridDim.x; k < g.nslot; k += gridDim.x) d[k] = 0.0f;
     }
@@ -1947,11 +1958,13 @@ __global__ __launch_bounds__(256) void k_w3_grad_mfma32(Geo g, const float *__re
 
 // d l_1/W[tap][c][j] = sum_p z[p + tap][c] * g_h1[p][j]  (c: the two pass-through channels; z from a zero-bordered tile of the
 // patch): rows (tap, c) = 18 of the 32, columns j, K = the pixels.
-__global__ __launch_bounds__(256) void k_w1_grad_mfma32(Geo g, const float *__restrict__ zin, const float *__restrict__ t2, int off_w1,
-                                                        Acc G, int S)
+template <int W>
+__global__ __launch_bounds__(256) void k_w1_grad_mfma(Geo g, const float *__restrict__ zin, const float *__restrict__ t2, int off_w1,
+                                                      Acc G, int S)
 {
+    constexpr int RP = W + 4;
     extern __shared__ float smem[];   // z tile [(H+2)(W+2)][2], then the tile index of every pixel of a patch (int)
-    __shared__ float stage[4][32 * kRowPad];
+    __shared__ float stage[4][32 * 36];
     float *red = &stage[0][0];        // [4][16][64], used once the pixel loop is over
     const int t = threadIdx.x, wv = t >> 6, ln = t & 63, col = ln & 31, half = ln >> 5;
     const int Wp = g.W + 2, tile_px = (g.H + 2) * Wp;
@@ -1971,29 +1984,29 @@ __global__ __launch_bounds__(256) void k_w1_grad_mfma32(Geo g, const float *__re
     const int npatch = (int)(g.npix / g.HW), ntiles = (g.HW + 31) >> 5;
     for (int unit = blockIdx.x; unit < npatch * S; unit += gridDim.x) {   // S workgroups share a patch's tiles
         const int b = unit / S, T0 = wv + 4 * (unit - b * S);
-        const float *tb = t2 + (int64_t)b * g.HW * 32;
+        const float *tb = t2 + (int64_t)b * g.HW * W;
         RowTile rb;
-        if (T0 < ntiles) rows_fetch(rb, tb, T0 * 32, g.HW);
+        if (T0 < ntiles) rows_fetch<W>(rb, tb, T0 * 32, g.HW);
         __syncthreads();
         for (int px = t; px < g.HW; px += 256)
             reinterpret_cast<float2 *>(smem)[lut[px]] = *reinterpret_cast<const float2 *>(zin + ((int64_t)b * g.HW + px) * 4);
         __syncthreads();
         for (int T = T0; T < ntiles; T += 4 * S) {
             wave_lds_fence();
-            rows_park<false>(rb, sb, unused_m, unused_m, T * 32, g.HW);
-            if (T + 4 * S < ntiles) rows_fetch(rb, tb, (T + 4 * S) * 32, g.HW);
+            rows_park<W, false>(rb, sb, unused_m, unused_m, T * 32, g.HW);
+            if (T + 4 * S < ntiles) rows_fetch<W>(rb, tb, (T + 4 * S) * 32, g.HW);
             wave_lds_fence();
 #pragma unroll 4
             for (int s2 = 0; s2 < 16; ++s2) {
                 const int pp = T * 32 + 2 * s2 + half;
                 float a = 0.0f;
                 if (pp < g.HW && col < 18) a = smem[(lut[pp] + da) * 2 + ch];
-                D = __builtin_amdgcn_mfma_f32_32x32x2f32(a, sb[(2 * s2 + half) * kRowPad + col], D, 0, 0, 0);
+                D = __builtin_amdgcn_mfma_f32_32x32x2f32(a, sb[(2 * s2 + half) * RP + (col < W ? col : 0)], D, 0, 0, 0);
             }
         }
     }
     // k_w1_grad's layout: [tap][c][j]
-    mfma_tile_to_slots(D, red, G + off_w1, g.nslot, [](int i, int j) { return i < 18 ? (i >> 1) * 64 + (i & 1) * 32 + j : -1; });
+    mfma_tile_to_slots(D, red, G + off_w1, g.nslot, [](int i, int j) { return i < 18 && j < W ? (i >> 1) * 2 * W + (i & 1) * W + j : -1; });
 }
 
 // ---- width 32: l_last forward on the matrix cores ----------------------------------------------------------------------
@@ -2003,18 +2016,19 @@ __global__ __launch_bounds__(256) void k_w1_grad_mfma32(Geo g, const float *__re
 // workgroup owns a band of rows of one patch: it computes P for the band and a one-row halo on each side (10 rows for 8 at
 // 32x32: 25 % recomputed) into LDS, then one thread per pixel gathers its 9 taps and finishes the affine transform.
 // The layer kernel does the same 1 188 MAC per pixel on the vector unit, re-normalising each of the 9 neighbours it reads.
-__global__ __launch_bounds__(256) void k_c3_fwd_mfma32(Geo g, const float *__restrict__ zin, const float *__restrict__ h2,
+template <int W>
+__global__ __launch_bounds__(256) void k_c3_fwd_mfma(Geo g, const float *__restrict__ zin, const float *__restrict__ h2,
                                                        const float *__restrict__ bn2, const float *__restrict__ Pw, int off_w3,
                                                        float *__restrict__ zout, Acc ldacc, float *__restrict__ u_out, int BR)
 {
-    constexpr int W = 32, PS = 36;
+    constexpr int PS = 36, RP = W + 4, HK = W / 2;
     extern __shared__ float smem[];   // P [pixels of the band + halo][36]
-    __shared__ float stage[4][32 * kRowPad];
+    __shared__ float stage[4][32 * 36];
     const float *W3 = Pw + off_w3, *b3 = W3 + 36 * (W + 1), *logs = b3 + 4;
     const int t = threadIdx.x, wv = t >> 6, ln = t & 63, col = ln & 31, half = ln >> 5;
-    float a0[16], a1[16];             // A[(tap, q) = col][i = 2 s + half]
+    float a0[HK], a1[HK];             // A[(tap, q) = col][i = 2 s + half]
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
+    for (int k = 0; k < HK; ++k) {
         const int i = 2 * k + half;
         a0[k] = W3[(col >> 2) * (W + 1) * 4 + i * 4 + (col & 3)];
         a1[k] = col < 4 ? W3[8 * (W + 1) * 4 + i * 4 + col] : 0.0f;
@@ -2022,8 +2036,8 @@ __global__ __launch_bounds__(256) void k_c3_fwd_mfma32(Geo g, const float *__res
     float m[4], rs[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        m[k] = bn2[4 * (ln & 7) + k];
-        rs[k] = bn2[W + 4 * (ln & 7) + k];
+        m[k] = bn2[4 * (ln % (W / 4)) + k];
+        rs[k] = bn2[W + 4 * (ln % (W / 4)) + k];
     }
     const float sc = logs[4];
     const float e30 = expf(kLogscale * logs[0]), e31 = expf(kLogscale * logs[1]), e32 = expf(kLogscale * logs[2]),
@@ -2036,19 +2050,19 @@ __global__ __launch_bounds__(256) void k_c3_fwd_mfma32(Geo g, const float *__res
         const int rlo = max(r0 - 1, 0), rhi = min(r1 + 1, g.H), ntiles = ((rhi - rlo) * g.W + 31) >> 5;
         const int64_t base = (int64_t)b * g.HW + rlo * g.W, end = (int64_t)b * g.HW + rhi * g.W;
         RowTile ra;
-        if (wv < ntiles) rows_fetch(ra, h2, base + wv * 32, end);
+        if (wv < ntiles) rows_fetch<W>(ra, h2, base + wv * 32, end);
         __syncthreads();              // the previous band's gather is over
         for (int T = wv; T < ntiles; T += 4) {
             wave_lds_fence();
-            rows_park<true>(ra, sa, m, rs, base + T * 32, end);
-            if (T + 4 < ntiles) rows_fetch(ra, h2, base + (T + 4) * 32, end);
+            rows_park<W, true>(ra, sa, m, rs, base + T * 32, end);
+            if (T + 4 < ntiles) rows_fetch<W>(ra, h2, base + (T + 4) * 32, end);
             wave_lds_fence();
             v16f D0, D1;
 #pragma unroll
             for (int v = 0; v < 16; ++v) D0[v] = D1[v] = 0.0f;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const float bv = sa[col * kRowPad + 2 * k + half];
+            for (int k = 0; k < HK; ++k) {
+                const float bv = sa[col * RP + 2 * k + half];
                 D0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[k], bv, D0, 0, 0, 0);
                 D1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[k], bv, D1, 0, 0, 0);
             }
@@ -2102,19 +2116,19 @@ __global__ __launch_bounds__(256) void k_c3_fwd_mfma32(Geo g, const float *__res
 // Per-channel sums: 16 registers per lane, added up over the 32 lanes of a half and the 4 wavefronts once, at the end.
 
 // red: [4][64][16];  vals[k] of lane (col, half) belongs to channel chan(k, half);  -> dst + chan
-template <typename F>
-__device__ __forceinline__ void lane_sums_to_slots(const float (&vals)[16], float *red, Acc dst, int nslot, F chan)
+template <int N, typename F>
+__device__ __forceinline__ void lane_sums_to_slots(const float (&vals)[N], float *red, Acc dst, int nslot, F chan)
 {
     const int t = threadIdx.x, wv = t >> 6, ln = t & 63;
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 16; ++k) red[(wv * 64 + ln) * 16 + k] = vals[k];
+    for (int k = 0; k < N; ++k) red[(wv * 64 + ln) * N + k] = vals[k];
     __syncthreads();
-    if (t < 32) {   // t = (half, k)
-        const int half = t >> 4, k = t & 15;
+    if (t < 2 * N) {   // t = (half, k)
+        const int half = t / N, k = t % N;
         float tot = 0.0f;
         for (int w = 0; w < 4; ++w)
-            for (int c = 0; c < 32; ++c) tot += red[(w * 64 + half * 32 + c) * 16 + k];
+            for (int c = 0; c < 32; ++c) tot += red[(w * 64 + half * 32 + c) * N + k];
         float *d = dst.p + (size_t)chan(k, half) * NSLOT;
         d[blockIdx.x] = tot;
         for (int q = blockIdx.x + gridDim.x; q < nslot; q += gridDim.x) d[q] = 0.0f;
@@ -2123,41 +2137,44 @@ __device__ __forceinline__ void lane_sums_to_slots(const float (&vals)[16], floa
 
 __device__ __forceinline__ int mfma_row(int v, int half) { return 8 * (v >> 2) + 4 * half + (v & 3); }
 
-// the reverse of rows_fetch / rows_park: 32 rows parked in LDS (stride kRowPad) -> 4 KB of consecutive memory
+// the reverse of rows_fetch / rows_park: 32 rows parked in LDS (stride W + 4) -> consecutive memory
+template <int W>
 __device__ __forceinline__ void rows_flush(const float *lds, float *__restrict__ dst, int64_t row0, int64_t row_end)
 {
+    constexpr int RQ = W / 4, RP = W + 4;
     const int ln = threadIdx.x & 63;
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const int lr = (ln + 64 * m) >> 3;
+    for (int m = 0; m < W / 8; ++m) {
+        const int lr = (ln + 64 * m) / RQ;
         if (row0 + lr < row_end)
-            reinterpret_cast<float4 *>(dst)[(row0 + lr) * 8 + (ln & 7)] = *reinterpret_cast<const float4 *>(lds + lr * kRowPad + 4 * (ln & 7));
+            reinterpret_cast<float4 *>(dst)[(row0 + lr) * RQ + ln % RQ] = *reinterpret_cast<const float4 *>(lds + lr * RP + 4 * (ln % RQ));
     }
 }
 
 // BN1 + ReLU + l_2 + bias; statistics of the result (k_c2_fwd at width 32); tensor tiles staged through LDS
-__global__ __launch_bounds__(256) void k_c2_fwd_mfma32(Geo g, const float *__restrict__ h1, Acc stats1, double n, float *__restrict__ P,
+template <int W>
+__global__ __launch_bounds__(256) void k_c2_fwd_mfma(Geo g, const float *__restrict__ h1, Acc stats1, double n, float *__restrict__ P,
                                                        int off_m1, float *__restrict__ bn1_out, int off_w2, float *__restrict__ h2,
                                                        Acc stats, const float *__restrict__ Pw, bool fin)
 {
-    constexpr int W = 32;
+    constexpr int RP = W + 4, HK = W / 2;
     __shared__ float bn1[2 * W];
-    __shared__ float stage[4][32 * kRowPad];
+    __shared__ float stage[4][32 * 36];
     __shared__ float red[4 * 64 * 16];
     bn_from_slots<W>(stats1, g.nslot, n, bn1, P, off_m1, off_m1 + W, bn1_out, fin);
     const float *W2 = Pw + off_w2, *b2 = W2 + W * W;
     const int t = threadIdx.x, wv = t >> 6, ln = t & 63, col = ln & 31, half = ln >> 5;
-    float a[16];   // A[out = col][k(s, half)] = W2[16 half + s][col]
+    float a[HK];   // A[out = col][k(s, half)] = W2[HK half + s][col]; output rows beyond the width do not exist
 #pragma unroll
-    for (int k = 0; k < 16; ++k) a[k] = W2[(16 * half + k) * W + col];
-    float m1[4], r1[4], bo[16], s2[16], q2[16];
+    for (int k = 0; k < HK; ++k) a[k] = col < W ? W2[(HK * half + k) * W + col] : 0.0f;
+    float m1[4], r1[4], bo[HK], s2[HK], q2[HK];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {   // BN1 + ReLU is applied on the way into LDS: the lane's 4 channels of the 16-byte pieces it moves
-        m1[k] = bn1[4 * (ln & 7) + k];
-        r1[k] = bn1[W + 4 * (ln & 7) + k];
+        m1[k] = bn1[4 * (ln % (W / 4)) + k];
+        r1[k] = bn1[W + 4 * (ln % (W / 4)) + k];
     }
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
+    for (int k = 0; k < HK; ++k) {
         bo[k] = b2[mfma_row(k, half)];
         s2[k] = q2[k] = 0.0f;
     }
@@ -2165,29 +2182,29 @@ __global__ __launch_bounds__(256) void k_c2_fwd_mfma32(Geo g, const float *__res
     const int64_t ntiles = (g.npix + 31) >> 5, stride = (int64_t)gridDim.x * 4;
     int64_t T = (int64_t)blockIdx.x * 4 + wv;
     RowTile rx;
-    if (T < ntiles) rows_fetch(rx, h1, T * 32, g.npix);
+    if (T < ntiles) rows_fetch<W>(rx, h1, T * 32, g.npix);
     for (; T < ntiles; T += stride) {
         const bool in = T * 32 + col < g.npix;
         wave_lds_fence();             // the previous tile's flush has been issued
-        rows_park<true>(rx, sx, m1, r1, T * 32, g.npix);
-        if (T + stride < ntiles) rows_fetch(rx, h1, (T + stride) * 32, g.npix);
+        rows_park<W, true>(rx, sx, m1, r1, T * 32, g.npix);
+        if (T + stride < ntiles) rows_fetch<W>(rx, h1, (T + stride) * 32, g.npix);
         wave_lds_fence();
-        float x[16];
+        float x[HK];
 #pragma unroll
-        for (int k = 0; k < 16; k += 4) {
-            const float4 v = *reinterpret_cast<const float4 *>(sx + col * kRowPad + 16 * half + k);
+        for (int k = 0; k < HK; k += 4) {
+            const float4 v = *reinterpret_cast<const float4 *>(sx + col * RP + HK * half + k);
             x[k] = v.x; x[k + 1] = v.y; x[k + 2] = v.z; x[k + 3] = v.w;
         }
         v16f D;
 #pragma unroll
         for (int v = 0; v < 16; ++v) D[v] = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) D = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], x[k], D, 0, 0, 0);
+        for (int k = 0; k < HK; ++k) D = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], x[k], D, 0, 0, 0);
         wave_lds_fence();             // every lane has read its inputs: the tile takes the result
 #pragma unroll
-        for (int v = 0; v < 16; v += 4) {
+        for (int v = 0; v < HK; v += 4) {
             const float4 o = make_float4(D[v] + bo[v], D[v + 1] + bo[v + 1], D[v + 2] + bo[v + 2], D[v + 3] + bo[v + 3]);
-            *reinterpret_cast<float4 *>(sx + col * kRowPad + mfma_row(v, half)) = o;
+            *reinterpret_cast<float4 *>(sx + col * RP + mfma_row(v, half)) = o;
             if (in) {
                 s2[v] += o.x; s2[v + 1] += o.y; s2[v + 2] += o.z; s2[v + 3] += o.w;
                 q2[v] = fmaf(o.x, o.x, q2[v]); q2[v + 1] = fmaf(o.y, o.y, q2[v + 1]);
@@ -2195,26 +2212,26 @@ __global__ __launch_bounds__(256) void k_c2_fwd_mfma32(Geo g, const float *__res
             }
         }
         wave_lds_fence();
-        rows_flush(sx, h2, T * 32, g.npix);
+        rows_flush<W>(sx, h2, T * 32, g.npix);
     }
     lane_sums_to_slots(s2, red, stats, g.nslot, [](int k, int h) { return mfma_row(k, h); });
-    lane_sums_to_slots(q2, red, stats, g.nslot, [](int k, int h) { return 32 + mfma_row(k, h); });
+    lane_sums_to_slots(q2, red, stats, g.nslot, [](int k, int h) { return W + mfma_row(k, h); });
 }
 
 // BN2 backward -> g_h2 (t1, in place), d l_2/b; transposed l_2 + ReLU mask -> d loss / d xhat1 (t2) and its two batch sums
 // (k_c2_bwd at width 32).  Five passes over [pixels][32] tensors: all of them through wavefront-private LDS tiles, so that
 // every global access is a whole 4 KB tile in 16-byte pieces.
 // WGRAD: d l_2/W = A1^T g_h2 is accumulated here as well — both operands are in the staged tiles at that point (K = the 32
-// pixels of the tile) — instead of by k_w2_grad_mfma32 from a second pass over h1 and a stored g_h2; t1 is then read only.
-template <bool WGRAD>
-__global__ __launch_bounds__(256) void k_c2_bwd_mfma32(Geo g, const float *__restrict__ h1, const float *__restrict__ bn1,
+// pixels of the tile) — instead of by k_w2_grad_mfma from a second pass over h1 and a stored g_h2; t1 is then read only.
+template <int W, bool WGRAD>
+__global__ __launch_bounds__(256) void k_c2_bwd_mfma(Geo g, const float *__restrict__ h1, const float *__restrict__ bn1,
                                                        const float *__restrict__ h2, const float *__restrict__ bn2, Acc bstats2,
                                                        double n, const float *__restrict__ P, int off_w2, float *__restrict__ t1,
                                                        float *__restrict__ t2, Acc bstats, Acc G, const float *__restrict__ pre)
 {
-    constexpr int W = 32;
+    constexpr int RP = W + 4, HK = W / 2;
     __shared__ float bb2[2 * W], sbn2[2 * W], sbn1[2 * W];
-    __shared__ float stage[4][3][32 * kRowPad];
+    __shared__ float stage[4][3][32 * 36];
     float *red = &stage[0][0][0];     // [4][64][16], used once the pixel loop is over (lane_sums_to_slots starts with a barrier)
     static_assert(sizeof(stage) >= 4 * 64 * 16 * sizeof(float), "the reduction buffer must fit the staging area");
     if (threadIdx.x < 2 * W) {
@@ -2224,12 +2241,12 @@ __global__ __launch_bounds__(256) void k_c2_bwd_mfma32(Geo g, const float *__res
     bnb_from_slots<W>(bstats2, g.nslot, n, bb2, pre);
     const float *W2 = P + off_w2;
     const int t = threadIdx.x, wv = t >> 6, ln = t & 63, col = ln & 31, half = ln >> 5;
-    float a[16];   // A[in = col][k(s, half)] = W2[col][16 half + s]
+    float a[HK];   // A[in = col][k(s, half)] = W2[col][HK half + s]
 #pragma unroll
-    for (int k = 0; k < 16; ++k) a[k] = W2[col * W + 16 * half + k];
-    float gb[16], s1[16], q1[16];
+    for (int k = 0; k < HK; ++k) a[k] = col < W ? W2[col * W + HK * half + k] : 0.0f;
+    float gb[HK], s1[HK], q1[HK];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) gb[k] = s1[k] = q1[k] = 0.0f;
+    for (int k = 0; k < HK; ++k) gb[k] = s1[k] = q1[k] = 0.0f;
     v16f DW;                          // WGRAD: d l_2/W[i][j], lane (j = col), rows i
 #pragma unroll
     for (int v = 0; v < 16; ++v) DW[v] = 0.0f;
@@ -2239,29 +2256,29 @@ __global__ __launch_bounds__(256) void k_c2_bwd_mfma32(Geo g, const float *__res
     int64_t T = (int64_t)blockIdx.x * 4 + wv;
     RowTile rg, rh, rx;
     if (T < ntiles) {
-        rows_fetch(rg, t1, T * 32, g.npix);
-        rows_fetch(rh, h2, T * 32, g.npix);
-        rows_fetch(rx, h1, T * 32, g.npix);
+        rows_fetch<W>(rg, t1, T * 32, g.npix);
+        rows_fetch<W>(rh, h2, T * 32, g.npix);
+        rows_fetch<W>(rx, h1, T * 32, g.npix);
     }
     for (; T < ntiles; T += stride) {
         const int64_t p = T * 32 + col;
         const bool in = p < g.npix;
         wave_lds_fence();
-        rows_park<false>(rg, sg, unused, unused, T * 32, g.npix);
-        rows_park<false>(rh, sh, unused, unused, T * 32, g.npix);
-        rows_park<false>(rx, sx, unused, unused, T * 32, g.npix);
+        rows_park<W, false>(rg, sg, unused, unused, T * 32, g.npix);
+        rows_park<W, false>(rh, sh, unused, unused, T * 32, g.npix);
+        rows_park<W, false>(rx, sx, unused, unused, T * 32, g.npix);
         if (T + stride < ntiles) {
-            rows_fetch(rg, t1, (T + stride) * 32, g.npix);
-            rows_fetch(rh, h2, (T + stride) * 32, g.npix);
-            rows_fetch(rx, h1, (T + stride) * 32, g.npix);
+            rows_fetch<W>(rg, t1, (T + stride) * 32, g.npix);
+            rows_fetch<W>(rh, h2, (T + stride) * 32, g.npix);
+            rows_fetch<W>(rx, h1, (T + stride) * 32, g.npix);
         }
         wave_lds_fence();
-        float gx[16], hv[16], x1[16];
+        float gx[HK], hv[HK], x1[HK];
 #pragma unroll
-        for (int k = 0; k < 16; k += 4) {
-            const float4 u = *reinterpret_cast<const float4 *>(sg + col * kRowPad + 16 * half + k);
-            const float4 v = *reinterpret_cast<const float4 *>(sh + col * kRowPad + 16 * half + k);
-            const float4 y = *reinterpret_cast<const float4 *>(sx + col * kRowPad + mfma_row(k, half));
+        for (int k = 0; k < HK; k += 4) {
+            const float4 u = *reinterpret_cast<const float4 *>(sg + col * RP + HK * half + k);
+            const float4 v = *reinterpret_cast<const float4 *>(sh + col * RP + HK * half + k);
+            const float4 y = *reinterpret_cast<const float4 *>(sx + col * RP + mfma_row(k, half));
             gx[k] = u.x; gx[k + 1] = u.y; gx[k + 2] = u.z; gx[k + 3] = u.w;
             hv[k] = v.x; hv[k + 1] = v.y; hv[k + 2] = v.z; hv[k + 3] = v.w;
             x1[k] = y.x; x1[k + 1] = y.y; x1[k + 2] = y.z; x1[k + 3] = y.w;
@@ -2270,17 +2287,17 @@ __global__ __launch_bounds__(256) void k_c2_bwd_mfma32(Geo g, const float *__res
 #pragma unroll
         for (int v = 0; v < 16; ++v) D[v] = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int j = 16 * half + k;
+        for (int k = 0; k < HK; ++k) {
+            const int j = HK * half + k;
             const float rs = sbn2[W + j], xh = (hv[k] - sbn2[j]) * rs;
             const float gh2 = in ? rs * (gx[k] - bb2[j] - xh * bb2[W + j]) : 0.0f;
             gx[k] = gh2;
             gb[k] += gh2;
             D = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], gh2, D, 0, 0, 0);
         }
-        float o[16];
+        float o[HK];
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
+        for (int v = 0; v < HK; ++v) {
             const int i = mfma_row(v, half);
             const float xh = (x1[v] - sbn1[i]) * sbn1[W + i];
             o[v] = (in && xh > 0.0f) ? D[v] : 0.0f;
@@ -2289,44 +2306,45 @@ __global__ __launch_bounds__(256) void k_c2_bwd_mfma32(Geo g, const float *__res
         }
         wave_lds_fence();             // every lane has read its inputs: the tiles take the results
 #pragma unroll
-        for (int k = 0; k < 16; k += 4)
-            *reinterpret_cast<float4 *>(sg + col * kRowPad + 16 * half + k) = make_float4(gx[k], gx[k + 1], gx[k + 2], gx[k + 3]);
+        for (int k = 0; k < HK; k += 4)
+            *reinterpret_cast<float4 *>(sg + col * RP + HK * half + k) = make_float4(gx[k], gx[k + 1], gx[k + 2], gx[k + 3]);
         if (WGRAD) {
             wave_lds_fence();
-            const float m1 = sbn1[col], r1 = sbn1[W + col];
+            const int cw = col < W ? col : 0;   // rows / columns beyond the width are not used
+            const float m1 = sbn1[cw], r1 = sbn1[W + cw];
 #pragma unroll
             for (int k = 0; k < 16; ++k) {   // pixels 2 k + half of the tile: A1[p][i = col] (rows past the end hold g_h2 = 0)
-                const float av = fmaxf((sx[(2 * k + half) * kRowPad + col] - m1) * r1, 0.0f);
-                DW = __builtin_amdgcn_mfma_f32_32x32x2f32(av, sg[(2 * k + half) * kRowPad + col], DW, 0, 0, 0);
+                const float av = fmaxf((sx[(2 * k + half) * RP + cw] - m1) * r1, 0.0f);
+                DW = __builtin_amdgcn_mfma_f32_32x32x2f32(av, sg[(2 * k + half) * RP + cw], DW, 0, 0, 0);
             }
             wave_lds_fence();
         }
 #pragma unroll
-        for (int k = 0; k < 16; k += 4)
-            *reinterpret_cast<float4 *>(sx + col * kRowPad + mfma_row(k, half)) = make_float4(o[k], o[k + 1], o[k + 2], o[k + 3]);
+        for (int k = 0; k < HK; k += 4)
+            *reinterpret_cast<float4 *>(sx + col * RP + mfma_row(k, half)) = make_float4(o[k], o[k + 1], o[k + 2], o[k + 3]);
         wave_lds_fence();
-        if (!WGRAD) rows_flush(sg, t1, T * 32, g.npix);
-        rows_flush(sx, t2, T * 32, g.npix);
+        if (!WGRAD) rows_flush<W>(sg, t1, T * 32, g.npix);
+        rows_flush<W>(sx, t2, T * 32, g.npix);
     }
-    if (WGRAD) mfma_tile_to_slots(DW, red, G + off_w2, g.nslot, [](int i, int j) { return i * 32 + j; });
+    if (WGRAD) mfma_tile_to_slots(DW, red, G + off_w2, g.nslot, [](int i, int j) { return i < W && j < W ? i * W + j : -1; });
     lane_sums_to_slots(s1, red, bstats, g.nslot, [](int k, int h) { return mfma_row(k, h); });
-    lane_sums_to_slots(q1, red, bstats, g.nslot, [](int k, int h) { return 32 + mfma_row(k, h); });
-    lane_sums_to_slots(gb, red, G + off_w2 + W * W, g.nslot, [](int k, int h) { return 16 * h + k; });
+    lane_sums_to_slots(q1, red, bstats, g.nslot, [](int k, int h) { return W + mfma_row(k, h); });
+    lane_sums_to_slots(gb, red, G + off_w2 + W * W, g.nslot, [](int k, int h) { return HK * h + k; });
 }
 
 // transposed l_last + ReLU mask -> d loss / d xhat2 (t1) and the two batch sums of the BN2 backward (k_c3_dh at width 32):
 // g[p][i] = sum_(tap, q) W3[tap][i][q] gu[p - tap][q] — K = 36 = (tap, q), the 32 channels on M, pixels on N; the B operands
 // come from a zero-bordered LDS tile of the patch's gu (K order: step s -> tap s >> 1, q = 2 half + (s & 1), one 8-byte
 // read per tap), the mask from h2 through a staged tile that then takes the result.
-// WGRAD: d l_last/W (k_w3_grad_mfma32's sums) is accumulated here too — the h2 tile and the patch's gu tile are both in LDS.
-template <bool WGRAD>
-__global__ __launch_bounds__(256) void k_c3_dh_mfma32(Geo g, const float *__restrict__ h2, const float *__restrict__ bn2,
+// WGRAD: d l_last/W (k_w3_grad_mfma's sums) is accumulated here too — the h2 tile and the patch's gu tile are both in LDS.
+template <int W, bool WGRAD>
+__global__ __launch_bounds__(256) void k_c3_dh_mfma(Geo g, const float *__restrict__ h2, const float *__restrict__ bn2,
                                                       const float *__restrict__ P, int off_w3, const float *__restrict__ gu,
                                                       float *__restrict__ t1, Acc bstats, Acc G, int S)
 {
-    constexpr int W = 32;
+    constexpr int RP = W + 4, HK = W / 2;
     extern __shared__ float smem[];   // gu tile [(H+2)(W+2)][4], then the tile index of every pixel of a patch (int)
-    __shared__ float stage[4][32 * kRowPad];
+    __shared__ float stage[4][32 * 36];
     __shared__ float sbn2[2 * W];
     __shared__ float cs[2][4][64], cst[40];
     float *red = &stage[0][0];        // [4][64][16], used once the pixel loop is over
@@ -2336,12 +2354,12 @@ __global__ __launch_bounds__(256) void k_c3_dh_mfma32(Geo g, const float *__rest
     if (t < 2 * W) sbn2[t] = bn2[t];
     float a[18];
 #pragma unroll
-    for (int k = 0; k < 18; ++k) a[k] = W3[(k >> 1) * (W + 1) * 4 + col * 4 + 2 * half + (k & 1)];
-    float s2[16], q2[16];
+    for (int k = 0; k < 18; ++k) a[k] = col < W ? W3[(k >> 1) * (W + 1) * 4 + col * 4 + 2 * half + (k & 1)] : 0.0f;
+    float s2[HK], q2[HK];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) s2[k] = q2[k] = 0.0f;
-    // WGRAD (see k_w3_grad_mfma32): columns (tap, q), taps 0..7 in D0, tap 8 in D1; S0 / S1 = column sums of the B operands
-    const int wq = col & 3, wd0 = ((col >> 2) / 3 - 1) * Wp + ((col >> 2) % 3 - 1), wd1 = Wp + 1;
+    for (int k = 0; k < HK; ++k) s2[k] = q2[k] = 0.0f;
+    // WGRAD (see k_w3_grad_mfma): columns (tap, q), taps 0..7 in D0, tap 8 in D1; S0 / S1 = column sums of the B operands
+    const int cw = col < W ? col : 0, wq = col & 3, wd0 = ((col >> 2) / 3 - 1) * Wp + ((col >> 2) % 3 - 1), wd1 = Wp + 1;
     v16f D0, D1;
 #pragma unroll
     for (int v = 0; v < 16; ++v) D0[v] = D1[v] = 0.0f;
@@ -2359,7 +2377,7 @@ __global__ __launch_bounds__(256) void k_c3_dh_mfma32(Geo g, const float *__rest
         const int b = unit / S, T0 = wv + 4 * (unit - b * S);
         const int64_t pb = (int64_t)b * g.HW;
         RowTile rx;
-        if (T0 < ntiles) rows_fetch(rx, h2, pb + T0 * 32, pb + g.HW);
+        if (T0 < ntiles) rows_fetch<W>(rx, h2, pb + T0 * 32, pb + g.HW);
         __syncthreads();              // the border is zero / the previous patch is done with
         for (int px = t; px < g.HW; px += 256) reinterpret_cast<float4 *>(smem)[lut[px]] = reinterpret_cast<const float4 *>(gu)[pb + px];
         __syncthreads();
@@ -2367,8 +2385,8 @@ __global__ __launch_bounds__(256) void k_c3_dh_mfma32(Geo g, const float *__rest
             const int pp = T * 32 + col;
             const bool in = pp < g.HW;
             wave_lds_fence();
-            rows_park<false>(rx, sx, unused, unused, pb + T * 32, pb + g.HW);
-            if (T + 4 * S < ntiles) rows_fetch(rx, h2, pb + (T + 4 * S) * 32, pb + g.HW);
+            rows_park<W, false>(rx, sx, unused, unused, pb + T * 32, pb + g.HW);
+            if (T + 4 * S < ntiles) rows_fetch<W>(rx, h2, pb + (T + 4 * S) * 32, pb + g.HW);
             const float *gt = smem + (in ? lut[pp] : 0) * 4 + 2 * half;
             v16f D;
 #pragma unroll
@@ -2381,7 +2399,7 @@ __global__ __launch_bounds__(256) void k_c3_dh_mfma32(Geo g, const float *__rest
             }
             wave_lds_fence();
             if (WGRAD) {
-                const float m2 = sbn2[col], r2 = sbn2[W + col];
+                const float m2 = sbn2[cw], r2 = sbn2[W + cw];
 #pragma unroll 4
                 for (int k = 0; k < 16; ++k) {
                     const int p2 = T * 32 + 2 * k + half;
@@ -2391,17 +2409,17 @@ __global__ __launch_bounds__(256) void k_c3_dh_mfma32(Geo g, const float *__rest
                         b0 = smem[(tp - wd0) * 4 + wq];
                         if (col < 4) b1 = smem[(tp - wd1) * 4 + wq];
                     }
-                    const float av = p2 < g.HW ? fmaxf((sx[(2 * k + half) * kRowPad + col] - m2) * r2, 0.0f) : 0.0f;
+                    const float av = p2 < g.HW ? fmaxf((sx[(2 * k + half) * RP + cw] - m2) * r2, 0.0f) : 0.0f;
                     S0 += b0;
                     S1 += b1;
                     D0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, D0, 0, 0, 0);
                     D1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, D1, 0, 0, 0);
                 }
             }
-            float o[16];
+            float o[HK];
 #pragma unroll
-            for (int v = 0; v < 16; v += 4) {
-                const float4 y = *reinterpret_cast<const float4 *>(sx + col * kRowPad + mfma_row(v, half));
+            for (int v = 0; v < HK; v += 4) {
+                const float4 y = *reinterpret_cast<const float4 *>(sx + col * RP + mfma_row(v, half));
                 const float hv[4] = {y.x, y.y, y.z, y.w};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -2414,18 +2432,18 @@ __global__ __launch_bounds__(256) void k_c3_dh_mfma32(Geo g, const float *__rest
             }
             wave_lds_fence();
 #pragma unroll
-            for (int v = 0; v < 16; v += 4)
-                *reinterpret_cast<float4 *>(sx + col * kRowPad + mfma_row(v, half)) = make_float4(o[v], o[v + 1], o[v + 2], o[v + 3]);
+            for (int v = 0; v < HK; v += 4)
+                *reinterpret_cast<float4 *>(sx + col * RP + mfma_row(v, half)) = make_float4(o[v], o[v + 1], o[v + 2], o[v + 3]);
             wave_lds_fence();
-            rows_flush(sx, t1, pb + T * 32, pb + g.HW);
+            rows_flush<W>(sx, t1, pb + T * 32, pb + g.HW);
         }
     }
     lane_sums_to_slots(s2, red, bstats, g.nslot, [](int k, int h) { return mfma_row(k, h); });
-    lane_sums_to_slots(q2, red, bstats, g.nslot, [](int k, int h) { return 32 + mfma_row(k, h); });
+    lane_sums_to_slots(q2, red, bstats, g.nslot, [](int k, int h) { return W + mfma_row(k, h); });
     if (WGRAD) {
         const Acc dst = G + off_w3;
-        mfma_tile_to_slots(D0, red, dst, g.nslot, [](int i, int c) { return (c >> 2) * 132 + i * 4 + (c & 3); });
-        mfma_tile_to_slots(D1, red, dst, g.nslot, [](int i, int c) { return c < 4 ? 8 * 132 + i * 4 + c : -1; });
+        mfma_tile_to_slots(D0, red, dst, g.nslot, [](int i, int c) { return i < W ? (c >> 2) * (W + 1) * 4 + i * 4 + (c & 3) : -1; });
+        mfma_tile_to_slots(D1, red, dst, g.nslot, [](int i, int c) { return i < W && c < 4 ? 8 * (W + 1) * 4 + i * 4 + c : -1; });
         cs[0][wv][ln] = S0;
         cs[1][wv][ln] = S1;
         __syncthreads();
@@ -2438,7 +2456,7 @@ __global__ __launch_bounds__(256) void k_c3_dh_mfma32(Geo g, const float *__rest
         }
         __syncthreads();
         if (t < 36) {   // indicator channel: the pixels whose tap falls on the padding ring
-            float *d = dst.p + (size_t)((t >> 2) * 132 + 128 + (t & 3)) * NSLOT;
+            float *d = dst.p + (size_t)((t >> 2) * (W + 1) * 4 + W * 4 + (t & 3)) * NSLOT;
             d[blockIdx.x] = cst[16 + (t & 3)] - cst[t];
             for (int k = blockIdx.x + gridDim.x; k < g.nslot; k += gridDim.x) d[k] = 0.0f;
         }
@@ -2448,19 +2466,19 @@ __global__ __launch_bounds__(256) void k_c3_dh_mfma32(Geo g, const float *__rest
 // transposed l_1 (k_c1_dz at width 32): d z0[p][c] += sum_tap sum_j W1[tap][c][j] g_h1[p - tap][j], evaluated like the
 // l_last forward: Q[p][(tap, c)] = sum_j W1[tap][c][j] g_h1[p][j] (18 rows of a 32-row tile, K = the 32 channels) for a band
 // of rows + a one-row halo into LDS, then one thread per pixel adds its 9 taps up and runs the folded Conv2d1x1 backward.
-template <bool MIX>
-__global__ __launch_bounds__(256) void k_c1_dz_mfma32(Geo g, const float *__restrict__ t2, const float *__restrict__ P, int off_w1,
+template <int W, bool MIX>
+__global__ __launch_bounds__(256) void k_c1_dz_mfma(Geo g, const float *__restrict__ t2, const float *__restrict__ P, int off_w1,
                                                       float *__restrict__ dz, const float *__restrict__ zmix_in,
                                                       const float *__restrict__ A, Acc dA, int BR)
 {
-    constexpr int W = 32, QS = 20;
+    constexpr int QS = 20, RP = W + 4, HK = W / 2;
     extern __shared__ float smem[];   // Q [pixels of the band + halo][20]
-    __shared__ float stage[4][32 * kRowPad];
+    __shared__ float stage[4][32 * 36];
     const float *W1 = P + off_w1;
     const int t = threadIdx.x, wv = t >> 6, ln = t & 63, col = ln & 31, half = ln >> 5;
-    float a[16];                      // A[(tap, c) = col][j = 2 s + half]
+    float a[HK];                      // A[(tap, c) = col][j = 2 s + half]
 #pragma unroll
-    for (int k = 0; k < 16; ++k) a[k] = col < 18 ? W1[(col >> 1) * 2 * W + (col & 1) * W + 2 * k + half] : 0.0f;
+    for (int k = 0; k < HK; ++k) a[k] = col < 18 ? W1[(col >> 1) * 2 * W + (col & 1) * W + 2 * k + half] : 0.0f;
     float mm[16], acc[16];
     if (MIX) {
 #pragma unroll
@@ -2477,18 +2495,18 @@ __global__ __launch_bounds__(256) void k_c1_dz_mfma32(Geo g, const float *__rest
         const int rlo = max(r0 - 1, 0), rhi = min(r1 + 1, g.H), ntiles = ((rhi - rlo) * g.W + 31) >> 5;
         const int64_t base = (int64_t)b * g.HW + rlo * g.W, end = (int64_t)b * g.HW + rhi * g.W;
         RowTile ra;
-        if (wv < ntiles) rows_fetch(ra, t2, base + wv * 32, end);
+        if (wv < ntiles) rows_fetch<W>(ra, t2, base + wv * 32, end);
         __syncthreads();              // the previous band's gather is over
         for (int T = wv; T < ntiles; T += 4) {
             wave_lds_fence();
-            rows_park<false>(ra, sa, unused, unused, base + T * 32, end);
-            if (T + 4 < ntiles) rows_fetch(ra, t2, base + (T + 4) * 32, end);
+            rows_park<W, false>(ra, sa, unused, unused, base + T * 32, end);
+            if (T + 4 < ntiles) rows_fetch<W>(ra, t2, base + (T + 4) * 32, end);
             wave_lds_fence();
             v16f D;
 #pragma unroll
             for (int v = 0; v < 16; ++v) D[v] = 0.0f;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) D = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], sa[col * kRowPad + 2 * k + half], D, 0, 0, 0);
+            for (int k = 0; k < HK; ++k) D = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], sa[col * RP + 2 * k + half], D, 0, 0, 0);
             float *qp = smem + (T * 32 + col) * QS;   // rows 0..19 of the result (18, 19 are zero)
             *reinterpret_cast<float4 *>(qp + 4 * half) = make_float4(D[0], D[1], D[2], D[3]);
             *reinterpret_cast<float4 *>(qp + 8 + 4 * half) = make_float4(D[4], D[5], D[6], D[7]);
@@ -2535,23 +2553,23 @@ __global__ __launch_bounds__(256) void k_c1_dz_mfma32(Geo g, const float *__rest
 
 // l_1 (3x3 SAME conv of the pass-through half, folded Conv2d1x1) + bias + statistics at width 32 (k_c1_fwd): K = (tap, c) = 18,
 // step = tap, lane half = c; the B operands from a zero-bordered LDS tile of the patch's (mixed) pass-through channels.
-template <bool MIX>
-__global__ __launch_bounds__(256) void k_c1_fwd_mfma32(Geo g, const float *__restrict__ zin, const float *__restrict__ A,
+template <int W, bool MIX>
+__global__ __launch_bounds__(256) void k_c1_fwd_mfma(Geo g, const float *__restrict__ zin, const float *__restrict__ A,
                                                        float *__restrict__ zmixed, const float *__restrict__ P, int off,
                                                        float *__restrict__ h1, Acc stats, int S)
 {
-    constexpr int W = 32;
+    constexpr int RP = W + 4, HK = W / 2;
     extern __shared__ float smem[];   // z tile [(H+2)(W+2)][2], then the tile index of every pixel of a patch (int)
-    __shared__ float stage[4][32 * kRowPad];
+    __shared__ float stage[4][32 * 36];
     float *red = &stage[0][0];        // [4][64][16], used once the pixel loop is over
     const float *W1 = P + off, *b1 = W1 + 18 * W;
     const int t = threadIdx.x, wv = t >> 6, ln = t & 63, col = ln & 31, half = ln >> 5;
     const int Wp = g.W + 2, tile_px = (g.H + 2) * Wp;
-    float a[9], bo[16], s1[16], q1[16];
+    float a[9], bo[HK], s1[HK], q1[HK];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) a[k] = W1[k * 2 * W + half * W + col];
+    for (int k = 0; k < 9; ++k) a[k] = col < W ? W1[k * 2 * W + half * W + col] : 0.0f;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
+    for (int k = 0; k < HK; ++k) {
         bo[k] = b1[mfma_row(k, half)];
         s1[k] = q1[k] = 0.0f;
     }
@@ -2599,9 +2617,9 @@ __global__ __launch_bounds__(256) void k_c1_fwd_mfma32(Geo g, const float *__res
             }
             wave_lds_fence();         // the previous tile's flush has been issued
 #pragma unroll
-            for (int v = 0; v < 16; v += 4) {
+            for (int v = 0; v < HK; v += 4) {
                 const float4 o = make_float4(D[v] + bo[v], D[v + 1] + bo[v + 1], D[v + 2] + bo[v + 2], D[v + 3] + bo[v + 3]);
-                *reinterpret_cast<float4 *>(so + col * kRowPad + mfma_row(v, half)) = o;
+                *reinterpret_cast<float4 *>(so + col * RP + mfma_row(v, half)) = o;
                 if (in) {
                     s1[v] += o.x; s1[v + 1] += o.y; s1[v + 2] += o.z; s1[v + 3] += o.w;
                     q1[v] = fmaf(o.x, o.x, q1[v]); q1[v + 1] = fmaf(o.y, o.y, q1[v + 1]);
@@ -2609,11 +2627,11 @@ __global__ __launch_bounds__(256) void k_c1_fwd_mfma32(Geo g, const float *__res
                 }
             }
             wave_lds_fence();
-            rows_flush(so, h1, pb + T * 32, pb + g.HW);
+            rows_flush<W>(so, h1, pb + T * 32, pb + g.HW);
         }
     }
     lane_sums_to_slots(s1, red, stats, g.nslot, [](int k, int h) { return mfma_row(k, h); });
-    lane_sums_to_slots(q1, red, stats, g.nslot, [](int k, int h) { return 32 + mfma_row(k, h); });
+    lane_sums_to_slots(q1, red, stats, g.nslot, [](int k, int h) { return W + mfma_row(k, h); });
 }
 
 // chain rule of the scalar parameterisations: dA -> PLU factors, d(a,b) -> sdn5 variables, gain_val
@@ -2909,14 +2927,16 @@ void coupling_forward(nf_trainer *t, const Geo &g, const TLayer &L, const float 
     const double n = (double)g.npix * t->sync_world;   // the moments are over the GLOBAL minibatch when the ranks are synchronised
     // zpre != null: the preceding Conv2d1x1 is folded into l_1 (which then also writes `zin`)
     const size_t z_tile = ((size_t)(g.H + 2) * (g.W + 2) * 2 + g.HW) * sizeof(float);
-    if (W == 32 && (t->wide_mfma & 256) && z_tile <= 60 * 1024) {
+    constexpr bool kWide = W == 16 || W == 32;   // widths with matrix-core stage kernels
+    constexpr int WM = kWide ? W : 32;           // (only instantiated for the widths they exist for)
+    if (kWide && (t->wide_mfma & 256) && z_tile <= 60 * 1024) {
         const int S = patch_split(g);
         const unsigned ngrid = std::min<unsigned>((unsigned)(g.npix / g.HW) * S, (unsigned)g.nslot);
         if (zpre)
-            hipLaunchKernelGGL((k_c1_fwd_mfma32<true>), dim3(ngrid), dim3(256), z_tile, st, g, zpre, A, const_cast<float *>(zin),
+            hipLaunchKernelGGL((k_c1_fwd_mfma<WM, true>), dim3(ngrid), dim3(256), z_tile, st, g, zpre, A, const_cast<float *>(zin),
                                (const float *)t->d_params, off_w1, c.h1, t->acc(c.d_st1), S);
         else
-            hipLaunchKernelGGL((k_c1_fwd_mfma32<false>), dim3(ngrid), dim3(256), z_tile, st, g, zin, (const float *)nullptr, (float *)nullptr,
+            hipLaunchKernelGGL((k_c1_fwd_mfma<WM, false>), dim3(ngrid), dim3(256), z_tile, st, g, zin, (const float *)nullptr, (float *)nullptr,
                                (const float *)t->d_params, off_w1, c.h1, t->acc(c.d_st1), S);
     } else if (zpre) {
         hipLaunchKernelGGL((k_c1_fwd<W, true>), dim3(nb), dim3(TB), 0, st, g, zpre, A, const_cast<float *>(zin), t->d_params,
@@ -2931,8 +2951,8 @@ void coupling_forward(nf_trainer *t, const Geo &g, const TLayer &L, const float 
     if (fin)
         hipLaunchKernelGGL(k_bn_fin, dim3(w), dim3(64), 0, st, t->acc(c.d_st1), w, g.nslot, n, t->d_params, off_m1, off_m1 + w,
                            t->d_flt + c.f_bn1);
-    if (W == 32 && (t->wide_mfma & 2))
-        hipLaunchKernelGGL(k_c2_fwd_mfma32, dim3(nb), dim3(256), 0, st, g, (const float *)c.h1, t->acc(c.d_st1), n, t->d_params, off_m1,
+    if (kWide && (t->wide_mfma & 2))
+        hipLaunchKernelGGL(k_c2_fwd_mfma<WM>, dim3(nb), dim3(256), 0, st, g, (const float *)c.h1, t->acc(c.d_st1), n, t->d_params, off_m1,
                            t->d_flt + c.f_bn1, off_w2, c.h2, t->acc(c.d_st2), (const float *)t->d_params, fin);
     else
         hipLaunchKernelGGL(k_c2_fwd<W>, dim3(nb), dim3(TB), 0, st, g, c.h1, t->acc(c.d_st1), n, t->d_params, off_m1,
@@ -2941,11 +2961,11 @@ void coupling_forward(nf_trainer *t, const Geo &g, const TLayer &L, const float 
     if (fin)
         hipLaunchKernelGGL(k_bn_fin, dim3(w), dim3(64), 0, st, t->acc(c.d_st2), w, g.nslot, n, t->d_params, off_m2, off_m2 + w,
                            t->d_flt + c.f_bn2);
-    if (W == 32 && fin && (t->wide_mfma & 16) && 3 * g.W <= 320) {
+    if (kWide && fin && (t->wide_mfma & 16) && 3 * g.W <= 320) {
         // bands of BR rows: (BR + 2) rows of 36 P values per pixel in LDS
         const int BR = std::max(1, std::min(g.H, 320 / g.W - 2)), units = (int)(g.npix / g.HW) * ((g.H + BR - 1) / BR);
         const size_t lds = (size_t)(((BR + 2) * g.W + 31) / 32 * 32) * 36 * sizeof(float);
-        hipLaunchKernelGGL(k_c3_fwd_mfma32, dim3(std::min<unsigned>((unsigned)units, (unsigned)g.nslot)), dim3(256), lds, st, g, zin,
+        hipLaunchKernelGGL(k_c3_fwd_mfma<WM>, dim3(std::min<unsigned>((unsigned)units, (unsigned)g.nslot)), dim3(256), lds, st, g, zin,
                            (const float *)c.h2, (const float *)(t->d_flt + c.f_bn2), (const float *)t->d_params, off_w3, zout, ldacc,
                            c.u, BR);
     } else {
@@ -2979,19 +2999,21 @@ void coupling_backward(nf_trainer *t, const Geo &g, const TLayer &L, const float
     hipLaunchKernelGGL(k_c3_bwd<W>, dim3(nb), dim3(TB), 0, st, g, zin, c.h2, bn2, t->d_params, off_w3, invB, t->dz, gu, G, zlat,
                        (const float *)c.u);
     const size_t gu_tile = ((size_t)(g.H + 2) * (g.W + 2) * 4 + g.HW) * sizeof(float);   // per-patch operand tile + pixel index
-    const bool mfma_dh = W == 32 && (t->wide_mfma & 32) && gu_tile <= 60 * 1024;
+    constexpr bool kWide = W == 16 || W == 32;
+    constexpr int WM = kWide ? W : 32;
+    const bool mfma_dh = kWide && (t->wide_mfma & 32) && gu_tile <= 60 * 1024;
     // The filter gradients of l_last / l_2 inside the stage kernels (3 tensor passes less: 6.0 -> 5.6 ms per step at 1 024
     // patches) — but only when the stages fill the GPU: at 138 patches the side stream's kernels run in the CUs the stage
     // kernels leave idle, and fusing them lengthens the critical path instead (1.67 -> 1.86 ms).
     const bool fuse = (t->wide_mfma & 1) && (t->wide_mfma & 128) && g.npix >= 400 * 1024;
-    const bool fuse_w3 = mfma_dh && fuse, fuse_w2 = W == 32 && (t->wide_mfma & 4) && fuse;
+    const bool fuse_w3 = mfma_dh && fuse, fuse_w2 = kWide && (t->wide_mfma & 4) && fuse;
     const int S = patch_split(g);
     const unsigned npw = std::min<unsigned>((unsigned)(g.npix / g.HW) * S, (unsigned)g.nslot);   // grid of the per-patch kernels
     if (mfma_dh && fuse_w3)
-        hipLaunchKernelGGL(k_c3_dh_mfma32<true>, dim3(npw), dim3(256), gu_tile, st, g,
+        hipLaunchKernelGGL((k_c3_dh_mfma<WM, true>), dim3(npw), dim3(256), gu_tile, st, g,
                            (const float *)c.h2, bn2, (const float *)t->d_params, off_w3, (const float *)gu, t1, t->acc(c.d_bs2), G, S);
     else if (mfma_dh)
-        hipLaunchKernelGGL(k_c3_dh_mfma32<false>, dim3(npw), dim3(256), gu_tile, st, g,
+        hipLaunchKernelGGL((k_c3_dh_mfma<WM, false>), dim3(npw), dim3(256), gu_tile, st, g,
                            (const float *)c.h2, bn2, (const float *)t->d_params, off_w3, (const float *)gu, t1, t->acc(c.d_bs2), G, S);
     else
         hipLaunchKernelGGL(k_c3_dh<W>, dim3(nb), dim3(TB), 0, st, g, c.h2, bn2, t->d_params, off_w3, gu, t1, t->acc(c.d_bs2));
@@ -3000,10 +3022,10 @@ void coupling_backward(nf_trainer *t, const Geo &g, const TLayer &L, const float
     const float *pre2 = fin ? t->d_flt + c.f_bb2 : nullptr, *pre1 = fin ? t->d_flt + c.f_bb1 : nullptr;
     if (fin) hipLaunchKernelGGL(k_bnb_fin, dim3(w), dim3(64), 0, st, t->acc(c.d_bs2), w, g.nslot, n, t->d_flt + c.f_bb2);
     if (fuse_w2)
-        hipLaunchKernelGGL(k_c2_bwd_mfma32<true>, dim3(nb), dim3(256), 0, st, g, (const float *)c.h1, bn1, (const float *)c.h2, bn2,
+        hipLaunchKernelGGL((k_c2_bwd_mfma<WM, true>), dim3(nb), dim3(256), 0, st, g, (const float *)c.h1, bn1, (const float *)c.h2, bn2,
                            t->acc(c.d_bs2), n, (const float *)t->d_params, off_w2, t1, t2, t->acc(c.d_bs1), G, pre2);
-    else if (W == 32 && (t->wide_mfma & 4))
-        hipLaunchKernelGGL(k_c2_bwd_mfma32<false>, dim3(nb), dim3(256), 0, st, g, (const float *)c.h1, bn1, (const float *)c.h2, bn2,
+    else if (kWide && (t->wide_mfma & 4))
+        hipLaunchKernelGGL((k_c2_bwd_mfma<WM, false>), dim3(nb), dim3(256), 0, st, g, (const float *)c.h1, bn1, (const float *)c.h2, bn2,
                            t->acc(c.d_bs2), n, (const float *)t->d_params, off_w2, t1, t2, t->acc(c.d_bs1), G, pre2);
     else
         hipLaunchKernelGGL(k_c2_bwd<W>, dim3(nb), dim3(TB), 0, st, g, c.h1, bn1, c.h2, bn2, t->acc(c.d_bs2), n, t->d_params, off_w2,
@@ -3018,13 +3040,13 @@ void coupling_backward(nf_trainer *t, const Geo &g, const TLayer &L, const float
     (void)hipEventRecord(t->ev_fork[0], st);
     (void)hipStreamWaitEvent(sd, t->ev_fork[0], 0);
     // (the per-patch operand tiles of the matrix-core kernels sit in dynamic LDS: patches of up to ~3 000 pixels)
-    if (W == 32 && (t->wide_mfma & 1) && ((size_t)(g.H + 2) * (g.W + 2) * 4 + g.HW) * sizeof(float) <= 60 * 1024) {
+    if (kWide && (t->wide_mfma & 1) && ((size_t)(g.H + 2) * (g.W + 2) * 4 + g.HW) * sizeof(float) <= 60 * 1024) {
         const unsigned nw = std::min<unsigned>((unsigned)g.nslot, 512u);
         const size_t tile = (size_t)(g.H + 2) * (g.W + 2) * 4 * sizeof(float), lut = (size_t)g.HW * sizeof(int);
         if (!fuse_w3)
-            hipLaunchKernelGGL(k_w3_grad_mfma32, dim3(npw), dim3(256), tile + lut, sd, g, c.h2, bn2, (const float *)gu, off_w3, G, S);
-        if (!fuse_w2) hipLaunchKernelGGL(k_w2_grad_mfma32, dim3(nw), dim3(256), 0, sd, g, c.h1, bn1, (const float *)t1, off_w2, G);
-        hipLaunchKernelGGL(k_w1_grad_mfma32, dim3(npw), dim3(256), tile / 2 + lut, sd, g, zin, (const float *)t2, off_w1, G, S);
+            hipLaunchKernelGGL(k_w3_grad_mfma<WM>, dim3(npw), dim3(256), tile + lut, sd, g, c.h2, bn2, (const float *)gu, off_w3, G, S);
+        if (!fuse_w2) hipLaunchKernelGGL(k_w2_grad_mfma<WM>, dim3(nw), dim3(256), 0, sd, g, c.h1, bn1, (const float *)t1, off_w2, G);
+        hipLaunchKernelGGL(k_w1_grad_mfma<WM>, dim3(npw), dim3(256), tile / 2 + lut, sd, g, zin, (const float *)t2, off_w1, G, S);
     } else {
         hipLaunchKernelGGL(k_w3_grad<W>, dim3(ng, 9), dim3(TB), 0, sd, g, c.h2, bn2, gu, off_w3, G);
         hipLaunchKernelGGL(k_w2_grad<W>, dim3(ng, w), dim3(TB), 0, sd, g, c.h1, bn1, t1, off_w2, G);
@@ -3033,15 +3055,15 @@ void coupling_backward(nf_trainer *t, const Geo &g, const TLayer &L, const float
     (void)hipEventRecord(t->ev_done[par], sd);
     t->done_pending[par] = true;
     // zmix_in != null: the backward of the preceding Conv2d1x1 is folded into this last stage
-    if (W == 32 && (t->wide_mfma & 64) && 3 * g.W <= 320) {
+    if (kWide && (t->wide_mfma & 64) && 3 * g.W <= 320) {
         const int BR = std::max(1, std::min(g.H, 320 / g.W - 2)), units = (int)(g.npix / g.HW) * ((g.H + BR - 1) / BR);
         const size_t lds = (size_t)(((BR + 2) * g.W + 31) / 32 * 32) * 20 * sizeof(float);
         const unsigned ngrid = std::min<unsigned>((unsigned)units, (unsigned)g.nslot);
         if (zmix_in)
-            hipLaunchKernelGGL((k_c1_dz_mfma32<true>), dim3(ngrid), dim3(256), lds, st, g, (const float *)t2, (const float *)t->d_params,
+            hipLaunchKernelGGL((k_c1_dz_mfma<WM, true>), dim3(ngrid), dim3(256), lds, st, g, (const float *)t2, (const float *)t->d_params,
                                off_w1, t->dz, zmix_in, A, dA, BR);
         else
-            hipLaunchKernelGGL((k_c1_dz_mfma32<false>), dim3(ngrid), dim3(256), lds, st, g, (const float *)t2, (const float *)t->d_params,
+            hipLaunchKernelGGL((k_c1_dz_mfma<WM, false>), dim3(ngrid), dim3(256), lds, st, g, (const float *)t2, (const float *)t->d_params,
                                off_w1, t->dz, (const float *)nullptr, (const float *)nullptr, dA, BR);
     } else if (zmix_in) {
         hipLaunchKernelGGL((k_c1_dz<W, true>), dim3(nb), dim3(TB), 0, st, g, t2, t->d_params, off_w1, t->dz, zmix_in, A, dA);

@@ -89,12 +89,29 @@ def test_gradients_other_widths_and_shapes(arch, width, hw, B, iso, cam):
     v = trained_like_variables(arch, width, seed=6)
     x, y = make_inputs(B, hw[0], hw[1], seed=17)
     tr = _trainer(arch, v, (hw[0], hw[1], 4), width)
-    grads, loss = tr.forward_backward(x, y, [0.0], [0.0], [iso], [cam])
-    ref_loss, ref_sd, ref_grads, _ = _grad_oracle(arch, v).loss_and_grads(x, y, iso, cam)
-    lv = loss.cpu().numpy()
-    assert abs(lv[0] - ref_loss) <= 1e-5 * abs(ref_loss)
-    assert abs(lv[1] - ref_sd) <= 1e-5 * ref_sd
-    _check_grads(tr, grads, ref_grads)
+    _oracle_check_next_to_kinks(tr, arch, v, x, y, iso, cam, width)
+
+
+def _oracle_check_next_to_kinks(tr, arch, v, x, y, iso, cam, width, rtol=GRAD_RTOL):
+    """Loss, sd_z and every gradient tensor against the fp64 oracle.  The loss is piecewise smooth: at widths >= 16 (W channels
+    x pixels x 2 normalisations per coupling) an activation can sit within float32 round-off of its ReLU kink, the fp64
+    oracle and an fp32 evaluation then take different branches and the gradients differ by that one pixel's share — which
+    branch the GPU takes depends on the summation order of the kernel that produced the activation.  As in
+    tests/test_gpu_random_sweep.py such an input is re-drawn next to itself (1e-4 of itself), twice at most."""
+    errors = []
+    for attempt in range(1 if width <= 8 else 3):
+        xv = x if attempt == 0 else (x * (1.0 + 1e-4 * np.random.RandomState(100 + attempt).randn(*x.shape))).astype(np.float32)
+        grads, loss = tr.forward_backward(xv, y, [0.0], [0.0], [iso], [cam])
+        ref_loss, ref_sd, ref_grads, _ = _grad_oracle(arch, v).loss_and_grads(xv, y, iso, cam)
+        lv = loss.cpu().numpy()
+        assert abs(lv[0] - ref_loss) <= 1e-5 * abs(ref_loss)
+        assert abs(lv[1] - ref_sd) <= 1e-5 * ref_sd
+        try:
+            _check_grads(tr, grads, ref_grads, rtol=rtol)
+            return
+        except AssertionError as e:
+            errors.append(str(e)[:300])
+    raise AssertionError(" | next to it: ".join(errors))
 
 
 def test_optimizer_kernels_match_float32_restatement(shipped_variables):
@@ -619,12 +636,7 @@ def test_wide_matrix_core_stages_and_layer_kernels_agree(arch, width, hw, B, mon
         grads, loss = tr.forward_backward(x, y, [0.0], [0.0], [400], [1])
         res[mode] = (grads.cpu().numpy().copy(), loss.cpu().numpy().copy(), tr.raw_params())
         if mode == "511":
-            ref_loss, ref_sd, ref_grads, _ = _grad_oracle(arch, v).loss_and_grads(x, y, 400, 1)
-            assert abs(res[mode][1][0] - ref_loss) <= 1e-5 * abs(ref_loss)
-            # wide couplings: with 32 channels x pixels x 2 normalisations per coupling some activation sits within fp32
-            # round-off of its ReLU kink, and the fp64 oracle and ANY fp32 evaluation take different branches there
-            # (tests/test_gpu_random_sweep.py has the measurements); what matters here is the cross-path agreement below
-            _check_grads(tr, grads, ref_grads, rtol=max(1e-3, min(8.0 / (B * hw[0] * hw[1]), 2e-2)))
+            _oracle_check_next_to_kinks(tr, arch, v, x, y, 400, 1, width, rtol=1e-3)
         tr.close()
     (g0, l0, p0), (g1, l1, p1) = res["0"], res["511"]
     assert np.allclose(l1, l0, rtol=1e-6, atol=0), (l1, l0)
