@@ -391,7 +391,7 @@ def test_two_rank_data_parallel_training_matches_manual_gradient_averaging(tmp_p
     assert not np.array_equal(p0[~mask], p1[~mask])
 
 
-def _syncbn_worker(rank, world, port, outdir):
+def _syncbn_worker(rank, world, port, outdir, width=4, hw=32, per=8):
     """One rank of a synchronised-BN data-parallel run: its shard of the global minibatch, group + sync_bn."""
     import sys
     import torch.distributed as dist
@@ -400,10 +400,10 @@ def _syncbn_worker(rank, world, port, outdir):
     from noise_flow_amd import default_hps
     from noise_flow_amd.train import Trainer
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
-    v = trained_like_variables(DP_ARCH, 4, seed=9)
-    tr = Trainer([32, 32, 4], default_hps(arch=DP_ARCH), variables=v, max_batch=8)
-    x, y = make_inputs(8 * world, seed=500, b1=0.003696)
-    sl = slice(8 * rank, 8 * rank + 8)
+    v = trained_like_variables(DP_ARCH, width, seed=9)
+    tr = Trainer([hw, hw, 4], default_hps(arch=DP_ARCH, width=width), variables=v, max_batch=per)
+    x, y = make_inputs(per * world, hw, hw, seed=500, b1=0.003696)
+    sl = slice(per * rank, per * rank + per)
     # the two halves of step(group=True, sync_bn=True), with the averaged gradient kept for the comparison
     tr.set_sync_bn(True)
     g, loss = tr.forward_backward(x[sl], y[sl], [0.0], [0.0], [800], [2])
@@ -413,7 +413,7 @@ def _syncbn_worker(rank, world, port, outdir):
     np.save(os.path.join(outdir, "sync_loss_%d.npy" % rank), loss.cpu().numpy())
     tr.apply(1e-3, g)
     np.save(os.path.join(outdir, "sync_params1_%d.npy" % rank), tr.raw_params())
-    x2, y2 = make_inputs(8 * world, seed=501, b1=0.003696)
+    x2, y2 = make_inputs(per * world, hw, hw, seed=501, b1=0.003696)
     tr.step(x2[sl], y2[sl], [0.0], [0.0], [800], [2], lr=1e-3, group=True, sync_bn=True)
     np.save(os.path.join(outdir, "sync_params_%d.npy" % rank), tr.raw_params())
     dist.barrier()
@@ -482,6 +482,46 @@ def test_two_rank_sync_bn_step_equals_one_rank_on_the_concatenated_batch(tmp_pat
             pos += n
     assert mask.any() and np.abs(q0[mask] - r1[mask]).max() <= 1e-5 * np.abs(r1[mask]).max()
     assert np.abs(q0[mask] - np.asarray(P.pack_layers(one.layers, v, 4, one._tmpl)[2])[mask]).max() > 1e-3   # they did move
+
+
+def test_two_rank_sync_bn_at_width_32(tmp_path):
+    """The same property on the matrix-core stage kernels (width 32): behind a cross-rank all-reduce the statistics are
+    finalised by k_bn_fin / k_bnb_fin from the scattered totals; 2 ranks x 6 patches of 16x16 = 1 rank on the 12."""
+    import socket
+    import torch.multiprocessing as mp
+    from oracle.nf_grad_oracle import is_trainable
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_syncbn_worker, args=(r, 2, port, str(tmp_path), 32, 16, 6)) for r in range(2)]
+    [p.start() for p in procs]
+    [p.join(timeout=300) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    load = lambda n, r: np.load(os.path.join(str(tmp_path), "sync_%s_%d.npy" % (n, r)))   # noqa: E731
+    g0, g1 = load("grad", 0), load("grad", 1)
+    assert np.array_equal(g0, g1) and np.array_equal(load("params", 0), load("params", 1))
+    v = trained_like_variables(DP_ARCH, 32, seed=9)
+    x, y = make_inputs(12, 16, 16, seed=500, b1=0.003696)
+    one = _trainer(DP_ARCH, v, (16, 16, 4), 32, max_batch=12)
+    g_one, loss_one = one.forward_backward(x, y, [0.0], [0.0], [800], [2])
+    ref, got = one.raw_to_variables(g_one.cpu().numpy().copy()), one.raw_to_variables(g0)
+    gmax = max(np.abs(ref[n]).max() for n in ref if is_trainable(n))
+    tol = 8.0 / (12 * 256)            # a few pixels' worth: ReLU kinks under a different summation order (wide couplings)
+    for name in ref:
+        if is_trainable(name) and not name.endswith(("l_1/b", "l_2/b")):
+            assert np.abs(got[name] - ref[name]).max() <= tol * max(np.abs(ref[name]).max(), 1e-6 * gmax), name
+    l2 = 0.5 * (load("loss", 0)[0] + load("loss", 1)[0])
+    assert abs(l2 - float(loss_one.cpu().numpy()[0])) <= 1e-5 * abs(l2)
+    # per-rank statistics on the same shards: a different gradient
+    a, b = _trainer(DP_ARCH, v, (16, 16, 4), 32, max_batch=6), _trainer(DP_ARCH, v, (16, 16, 4), 32, max_batch=6)
+    ga, _ = a.forward_backward(x[:6], y[:6], [0.0], [0.0], [800], [2])
+    gb, _ = b.forward_backward(x[6:], y[6:], [0.0], [0.0], [800], [2])
+    g_local = one.raw_to_variables(((ga + gb) / 2).cpu().numpy())
+    worst = max(np.abs(g_local[n] - ref[n]).max() / max(np.abs(ref[n]).max(), 1e-6 * gmax) for n in ref
+                if is_trainable(n) and not n.endswith(("l_1/b", "l_2/b")))
+    assert worst > 4 * tol, worst
 
 
 def test_gradients_with_the_reversed_template_binding():
