@@ -2845,6 +2845,7 @@ struct nf_trainer {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork[3] = {nullptr, nullptr, nullptr}, ev_done[3] = {nullptr, nullptr, nullptr};
     bool done_pending[3] = {false, false, false};
+    int band_cap = 320;        // pixels (rows x width, halo included) a band kernel keeps in LDS
     bool serial = false;   // NF_TRAIN_SERIAL=1: everything on the caller's stream (kernel durations without overlap, for profiling)
     int wide_mfma = 511;   // NF_TRAIN_WIDE_MFMA: width-32 stages on the matrix cores (bit 0 filter gradients, 1 l_2 forward, 2 l_2 backward, 3 statistics finalisers, 4 l_last forward, 5 l_last transposed, 6 l_1 transposed, 7 filter gradients inside the stage that holds their operands, 8 l_1 forward; 0: layer kernels only)
     int tiled = 3;   // NF_TRAIN_TILED: bit 0 = tiled backward stages, bit 1 = tiled forward stages (0: layer kernels only)
@@ -2961,9 +2962,9 @@ void coupling_forward(nf_trainer *t, const Geo &g, const TLayer &L, const float 
     if (fin)
         hipLaunchKernelGGL(k_bn_fin, dim3(w), dim3(64), 0, st, t->acc(c.d_st2), w, g.nslot, n, t->d_params, off_m2, off_m2 + w,
                            t->d_flt + c.f_bn2);
-    if (kWide && fin && (t->wide_mfma & 16) && 3 * g.W <= 320) {
+    if (kWide && fin && (t->wide_mfma & 16) && 3 * g.W <= t->band_cap) {
         // bands of BR rows: (BR + 2) rows of 36 P values per pixel in LDS
-        const int BR = std::max(1, std::min(g.H, 320 / g.W - 2)), units = (int)(g.npix / g.HW) * ((g.H + BR - 1) / BR);
+        const int BR = std::max(1, std::min(g.H, t->band_cap / g.W - 2)), units = (int)(g.npix / g.HW) * ((g.H + BR - 1) / BR);
         const size_t lds = (size_t)(((BR + 2) * g.W + 31) / 32 * 32) * 36 * sizeof(float);
         hipLaunchKernelGGL(k_c3_fwd_mfma<WM>, dim3(std::min<unsigned>((unsigned)units, (unsigned)g.nslot)), dim3(256), lds, st, g, zin,
                            (const float *)c.h2, (const float *)(t->d_flt + c.f_bn2), (const float *)t->d_params, off_w3, zout, ldacc,
@@ -3055,8 +3056,11 @@ void coupling_backward(nf_trainer *t, const Geo &g, const TLayer &L, const float
     (void)hipEventRecord(t->ev_done[par], sd);
     t->done_pending[par] = true;
     // zmix_in != null: the backward of the preceding Conv2d1x1 is folded into this last stage
-    if (kWide && (t->wide_mfma & 64) && 3 * g.W <= 320) {
-        const int BR = std::max(1, std::min(g.H, 320 / g.W - 2)), units = (int)(g.npix / g.HW) * ((g.H + BR - 1) / BR);
+    if (kWide && (t->wide_mfma & 64) && 3 * g.W <= t->band_cap) {
+        // (measured at 32x32, width 32: 46 us with 6-row bands = 8 tiles = two rounds of the 4 wavefronts, 55 us with 8-row bands;
+        // the l_last forward, twice the MFMA work per tile, is better off with the smaller halo share of 8-row bands)
+        const int cap = std::max(3 * g.W, std::min(t->band_cap, 256));
+        const int BR = std::max(1, std::min(g.H, cap / g.W - 2)), units = (int)(g.npix / g.HW) * ((g.H + BR - 1) / BR);
         const size_t lds = (size_t)(((BR + 2) * g.W + 31) / 32 * 32) * 20 * sizeof(float);
         const unsigned ngrid = std::min<unsigned>((unsigned)units, (unsigned)g.nslot);
         if (zmix_in)
@@ -3254,6 +3258,7 @@ int nf_trainer_create(const nf_config *cfg, const nf_layer_desc *layers, const f
     if (const char *e = getenv("NF_TRAIN_TILED")) t->tiled = atoi(e);
     if (const char *e = getenv("NF_TRAIN_WIDE_MFMA")) t->wide_mfma = atoi(e);
     if (const char *e = getenv("NF_TRAIN_SERIAL")) t->serial = atoi(e) != 0;
+    if (const char *e = getenv("NF_TRAIN_BAND")) t->band_cap = std::min(320, std::max(96, atoi(e)));
     t->max_batch = max_batch;
     t->optimizer = optimizer;
     t->n_params = (int)n_params;
