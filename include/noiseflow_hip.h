@@ -233,7 +233,8 @@ int nf_sample_batchstats(nf_handle *h, const float *y, const float *eps, uint64_
  *                       <= 384 patches); 0 = one kernel per layer stage.  Default 3.
  *   NF_TRAIN_WIDE_MFMA  widths 16 and 32: bit 0 filter gradients, 1 l_2 forward, 2 l_2 backward, 4 l_last forward, 5 l_last transposed,
  *                       6 l_1 transposed (8: l_1 forward) on v_mfma_f32_32x32x2_f32; 3 one-pass statistics finalisers (widths >= 16);
- *                       7 filter gradients inside the stage kernels (>= 400k pixels per step), 8 l_1 forward.  Default 511.
+ *                       7 filter gradients inside the stage kernels (>= 400k pixels per step), 8 l_1 forward,
+ *                       11 affine / tanh backward inside the transposed l_last kernel.  Default 4095.
  *   NF_TRAIN_SERIAL=1   no side stream: every kernel on the caller's stream (kernel traces without overlap). */
 typedef struct nf_trainer nf_trainer;
 #define NF_OPT_ADAM     0

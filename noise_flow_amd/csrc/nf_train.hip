@@ -1224,8 +1224,8 @@ __global__ void k_w1_grad(Geo g, const float *__restrict__ zin, const float *__r
 // MIX = the backward of the preceding Conv2d1x1 is folded in (per pixel: dA += z_in^T d, d <- d A^T).
 template <int W, bool MIX>
 __global__ void k_c1_dz(Geo g, const float *__restrict__ t2, const float *__restrict__ P, int off_w1, float *__restrict__ dz,
-                        const float *__restrict__ zmix_in, const float *__restrict__ A, Acc dA)
-{
+                        const float *__restrict__ zmix_in, const float *__restrict__ A, Acc dA, const float *__restrict__ dz_in)
+{   // dz_in != null: d loss / d z is read from there (k_c3_dh_mfma's second buffer) and written to dz
     const float *W1 = P + off_w1;
     float m[16], acc[16];
     if (MIX) {
@@ -1255,7 +1255,7 @@ __global__ void k_c1_dz(Geo g, const float *__restrict__ t2, const float *__rest
                 }
             }
             if (MIX) {
-                const float4 dv = reinterpret_cast<const float4 *>(dz)[p], zv = reinterpret_cast<const float4 *>(zmix_in)[p];
+                const float4 dv = reinterpret_cast<const float4 *>(dz_in ? dz_in : dz)[p], zv = reinterpret_cast<const float4 *>(zmix_in)[p];
                 const float d[4] = {dv.x + a0, dv.y + a1, dv.z, dv.w}, zi[4] = {zv.x, zv.y, zv.z, zv.w};
                 float o[4];
 #pragma unroll
@@ -1266,9 +1266,14 @@ __global__ void k_c1_dz(Geo g, const float *__restrict__ t2, const float *__rest
                 }
                 reinterpret_cast<float4 *>(dz)[p] = make_float4(o[0], o[1], o[2], o[3]);
             } else {
-                float2 *d = reinterpret_cast<float2 *>(dz + p * 4);
-                const float2 v = *d;
-                *d = make_float2(v.x + a0, v.y + a1);
+                if (dz_in) {
+                    const float4 v = reinterpret_cast<const float4 *>(dz_in)[p];
+                    reinterpret_cast<float4 *>(dz)[p] = make_float4(v.x + a0, v.y + a1, v.z, v.w);
+                } else {
+                    float2 *d = reinterpret_cast<float2 *>(dz + p * 4);
+                    const float2 v = *d;
+                    *d = make_float2(v.x + a0, v.y + a1);
+                }
             }
         }
     }
@@ -2337,10 +2342,19 @@ __global__ __launch_bounds__(256) void k_c2_bwd_mfma(Geo g, const float *__restr
 // come from a zero-bordered LDS tile of the patch's gu (K order: step s -> tap s >> 1, q = 2 half + (s & 1), one 8-byte
 // read per tap), the mask from h2 through a staged tile that then takes the result.
 // WGRAD: d l_last/W (k_w3_grad_mfma's sums) is accumulated here too — the h2 tile and the patch's gu tile are both in LDS.
+// c3b.u != null: the elementwise stage in front of it (k_c3_bwd: affine transform / tanh / exp(3 logs) backward, from the kept
+// l_last output u) runs while the gu tile is filled — one launch and one round trip of gu less; the first of the S workgroups
+// of a patch also stores gu (for k_w3_grad_mfma), the updated dz and the 9 scalar sums.
+struct C3Bwd {
+    const float *u, *zin, *zlat;   // zlat != null: first stage of the backward pass (d loss / d latent = latent / B)
+    const float *dz;               // d loss / d (coupling output), read by EVERY workgroup of the patch ...
+    float *dz_out, *gu_out;        // ... so the updated one goes to a second buffer (the coupling's last stage reads it from there)
+    float invB;
+};
 template <int W, bool WGRAD>
 __global__ __launch_bounds__(256) void k_c3_dh_mfma(Geo g, const float *__restrict__ h2, const float *__restrict__ bn2,
                                                       const float *__restrict__ P, int off_w3, const float *__restrict__ gu,
-                                                      float *__restrict__ t1, Acc bstats, Acc G, int S)
+                                                      float *__restrict__ t1, Acc bstats, Acc G, int S, C3Bwd c3b)
 {
     constexpr int RP = W + 4, HK = W / 2;
     extern __shared__ float smem[];   // gu tile [(H+2)(W+2)][4], then the tile index of every pixel of a patch (int)
@@ -2366,6 +2380,12 @@ __global__ __launch_bounds__(256) void k_c3_dh_mfma(Geo g, const float *__restri
     float S0 = 0.0f, S1 = 0.0f;
     float *sx = stage[wv];
     const float unused[4] = {0.f, 0.f, 0.f, 0.f};
+    // the elementwise stage (c3b.u): d l_last/b (4), d logs (4), d rescale — adjacent in the raw layout
+    const float *b3 = W3 + 36 * (W + 1), *logs = b3 + 4;
+    const float sc = logs[4];
+    float e3[4], tail[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) e3[k] = expf(kLogscale * logs[k]);
     int *lut = reinterpret_cast<int *>(smem + tile_px * 4);
     for (int i = t; i < tile_px * 4; i += 256) smem[i] = 0.0f;
     for (int px = t; px < g.HW; px += 256) {
@@ -2379,7 +2399,51 @@ __global__ __launch_bounds__(256) void k_c3_dh_mfma(Geo g, const float *__restri
         RowTile rx;
         if (T0 < ntiles) rows_fetch<W>(rx, h2, pb + T0 * 32, pb + g.HW);
         __syncthreads();              // the border is zero / the previous patch is done with
-        for (int px = t; px < g.HW; px += 256) reinterpret_cast<float4 *>(smem)[lut[px]] = reinterpret_cast<const float4 *>(gu)[pb + px];
+        if (c3b.u) {
+            const bool first = unit == b * S;
+            for (int px = t; px < g.HW; px += 256) {
+                const int64_t p = pb + px;
+                const float4 uv = reinterpret_cast<const float4 *>(c3b.u)[p], zi = reinterpret_cast<const float4 *>(c3b.zin)[p];
+                float4 d;
+                if (c3b.zlat) {
+                    const float4 zl = reinterpret_cast<const float4 *>(c3b.zlat)[p];
+                    d = make_float4(zl.x * c3b.invB, zl.y * c3b.invB, zl.z * c3b.invB, zl.w * c3b.invB);
+                } else {
+                    d = reinterpret_cast<const float4 *>(c3b.dz)[p];
+                }
+                const float uu[4] = {uv.x, uv.y, uv.z, uv.w}, z1[2] = {zi.z, zi.w}, gx1[2] = {d.z, d.w};
+                float go[4], o[4], guv[4], gz1[2];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = uu[k] * e3[k];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const float th = tanhf(o[2 + k]), E = expf(sc * th);
+                    gz1[k] = gx1[k] * E;
+                    const float gls = gx1[k] * z1[k] * E - c3b.invB;   // loss = mean(-(sum ls + ...))
+                    if (first) tail[8] = fmaf(gls, th, tail[8]);
+                    go[k] = gx1[k];                                  // shift
+                    go[2 + k] = gls * sc * (1.0f - th * th);         // raw
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    guv[k] = go[k] * e3[k];
+                    if (first) {
+                        tail[4 + k] = fmaf(kLogscale * go[k], o[k], tail[4 + k]);
+                        tail[k] += guv[k];
+                    }
+                }
+                const float4 gv = make_float4(guv[0], guv[1], guv[2], guv[3]);
+                reinterpret_cast<float4 *>(smem)[lut[px]] = gv;
+                if (first) {
+                    reinterpret_cast<float4 *>(c3b.gu_out)[p] = gv;
+                    d.z = gz1[0];
+                    d.w = gz1[1];
+                    reinterpret_cast<float4 *>(c3b.dz_out)[p] = d;
+                }
+            }
+        } else {
+            for (int px = t; px < g.HW; px += 256) reinterpret_cast<float4 *>(smem)[lut[px]] = reinterpret_cast<const float4 *>(gu)[pb + px];
+        }
         __syncthreads();
         for (int T = T0; T < ntiles; T += 4 * S) {
             const int pp = T * 32 + col;
@@ -2440,6 +2504,7 @@ __global__ __launch_bounds__(256) void k_c3_dh_mfma(Geo g, const float *__restri
     }
     lane_sums_to_slots(s2, red, bstats, g.nslot, [](int k, int h) { return mfma_row(k, h); });
     lane_sums_to_slots(q2, red, bstats, g.nslot, [](int k, int h) { return W + mfma_row(k, h); });
+    if (c3b.u) acc_add_n<9>(G + off_w3 + 36 * (W + 1), tail, g.nslot);
     if (WGRAD) {
         const Acc dst = G + off_w3;
         mfma_tile_to_slots(D0, red, dst, g.nslot, [](int i, int c) { return i < W ? (c >> 2) * (W + 1) * 4 + i * 4 + (c & 3) : -1; });
@@ -2469,7 +2534,7 @@ __global__ __launch_bounds__(256) void k_c3_dh_mfma(Geo g, const float *__restri
 template <int W, bool MIX>
 __global__ __launch_bounds__(256) void k_c1_dz_mfma(Geo g, const float *__restrict__ t2, const float *__restrict__ P, int off_w1,
                                                       float *__restrict__ dz, const float *__restrict__ zmix_in,
-                                                      const float *__restrict__ A, Acc dA, int BR)
+                                                      const float *__restrict__ A, Acc dA, int BR, const float *__restrict__ dz_in)
 {
     constexpr int QS = 20, RP = W + 4, HK = W / 2;
     extern __shared__ float smem[];   // Q [pixels of the band + halo][20]
@@ -2531,7 +2596,7 @@ __global__ __launch_bounds__(256) void k_c1_dz_mfma(Geo g, const float *__restri
             }
             const int64_t p = (int64_t)b * g.HW + r * g.W + c;
             if (MIX) {
-                const float4 dv = reinterpret_cast<const float4 *>(dz)[p], zv = reinterpret_cast<const float4 *>(zmix_in)[p];
+                const float4 dv = reinterpret_cast<const float4 *>(dz_in ? dz_in : dz)[p], zv = reinterpret_cast<const float4 *>(zmix_in)[p];
                 const float d[4] = {dv.x + a0, dv.y + a1, dv.z, dv.w}, zi[4] = {zv.x, zv.y, zv.z, zv.w};
                 float o[4];
 #pragma unroll
@@ -2542,9 +2607,14 @@ __global__ __launch_bounds__(256) void k_c1_dz_mfma(Geo g, const float *__restri
                 }
                 reinterpret_cast<float4 *>(dz)[p] = make_float4(o[0], o[1], o[2], o[3]);
             } else {
-                float2 *d = reinterpret_cast<float2 *>(dz + p * 4);
-                const float2 v = *d;
-                *d = make_float2(v.x + a0, v.y + a1);
+                if (dz_in) {
+                    const float4 v = reinterpret_cast<const float4 *>(dz_in)[p];
+                    reinterpret_cast<float4 *>(dz)[p] = make_float4(v.x + a0, v.y + a1, v.z, v.w);
+                } else {
+                    float2 *d = reinterpret_cast<float2 *>(dz + p * 4);
+                    const float2 v = *d;
+                    *d = make_float2(v.x + a0, v.y + a1);
+                }
             }
         }
     }
@@ -2841,13 +2911,14 @@ struct nf_trainer {
     std::vector<float *> zs;        // zs[l] = input of layer l (zs[0] is the caller's x), zs[n] = latent
     // backward temporaries, double-buffered by coupling parity: the filter-gradient kernels of one
     // coupling run on `side` while the main stream is already in the next coupling
-    float *t1[3] = {nullptr, nullptr, nullptr}, *t2[3] = {nullptr, nullptr, nullptr}, *gu[3] = {nullptr, nullptr, nullptr}, *dz = nullptr;
+    float *t1[3] = {nullptr, nullptr, nullptr}, *t2[3] = {nullptr, nullptr, nullptr}, *gu[3] = {nullptr, nullptr, nullptr}, *dz = nullptr,
+          *dz2 = nullptr;   // second d loss / d z buffer (wide couplings: k_c3_dh_mfma writes there what every workgroup of a patch still reads from dz)
     hipStream_t side = nullptr;
     hipEvent_t ev_fork[3] = {nullptr, nullptr, nullptr}, ev_done[3] = {nullptr, nullptr, nullptr};
     bool done_pending[3] = {false, false, false};
     int band_cap = 320;        // pixels (rows x width, halo included) a band kernel keeps in LDS
     bool serial = false;   // NF_TRAIN_SERIAL=1: everything on the caller's stream (kernel durations without overlap, for profiling)
-    int wide_mfma = 511;   // NF_TRAIN_WIDE_MFMA: width-32 stages on the matrix cores (bit 0 filter gradients, 1 l_2 forward, 2 l_2 backward, 3 statistics finalisers, 4 l_last forward, 5 l_last transposed, 6 l_1 transposed, 7 filter gradients inside the stage that holds their operands, 8 l_1 forward; 0: layer kernels only)
+    int wide_mfma = 4095;   // NF_TRAIN_WIDE_MFMA: width-32 stages on the matrix cores (bit 0 filter gradients, 1 l_2 forward, 2 l_2 backward, 3 statistics finalisers, 4 l_last forward, 5 l_last transposed, 6 l_1 transposed, 7 filter gradients inside the stage that holds their operands, 8 l_1 forward, 11 affine/tanh backward inside the transposed l_last; 0: layer kernels only)
     int tiled = 3;   // NF_TRAIN_TILED: bit 0 = tiled backward stages, bit 1 = tiled forward stages (0: layer kernels only)
     std::vector<void *> owned;
     bool has_sdn = false;
@@ -2997,12 +3068,17 @@ void coupling_backward(nf_trainer *t, const Geo &g, const TLayer &L, const float
         (void)hipStreamWaitEvent(st, t->ev_done[par], 0);
         t->done_pending[par] = false;
     }
-    hipLaunchKernelGGL(k_c3_bwd<W>, dim3(nb), dim3(TB), 0, st, g, zin, c.h2, bn2, t->d_params, off_w3, invB, t->dz, gu, G, zlat,
-                       (const float *)c.u);
     const size_t gu_tile = ((size_t)(g.H + 2) * (g.W + 2) * 4 + g.HW) * sizeof(float);   // per-patch operand tile + pixel index
     constexpr bool kWide = W == 16 || W == 32;
     constexpr int WM = kWide ? W : 32;
     const bool mfma_dh = kWide && (t->wide_mfma & 32) && gu_tile <= 60 * 1024;
+    // the elementwise stage in front of the transposed l_last runs inside it when that is the matrix-core kernel
+    const bool c3b_in = mfma_dh && c.u && (t->wide_mfma & 2048);
+    const C3Bwd c3b{c3b_in ? c.u : nullptr, zin, zlat, t->dz, t->dz2, gu, invB};
+    const float *dz_src = c3b_in ? t->dz2 : nullptr;   // where the coupling's last stage finds d loss / d z (null: in t->dz)
+    if (!c3b_in)
+        hipLaunchKernelGGL(k_c3_bwd<W>, dim3(nb), dim3(TB), 0, st, g, zin, c.h2, bn2, t->d_params, off_w3, invB, t->dz, gu, G, zlat,
+                           (const float *)c.u);
     // The filter gradients of l_last / l_2 inside the stage kernels (3 tensor passes less: 6.0 -> 5.6 ms per step at 1 024
     // patches) — but only when the stages fill the GPU: at 138 patches the side stream's kernels run in the CUs the stage
     // kernels leave idle, and fusing them lengthens the critical path instead (1.67 -> 1.86 ms).
@@ -3012,10 +3088,10 @@ void coupling_backward(nf_trainer *t, const Geo &g, const TLayer &L, const float
     const unsigned npw = std::min<unsigned>((unsigned)(g.npix / g.HW) * S, (unsigned)g.nslot);   // grid of the per-patch kernels
     if (mfma_dh && fuse_w3)
         hipLaunchKernelGGL((k_c3_dh_mfma<WM, true>), dim3(npw), dim3(256), gu_tile, st, g,
-                           (const float *)c.h2, bn2, (const float *)t->d_params, off_w3, (const float *)gu, t1, t->acc(c.d_bs2), G, S);
+                           (const float *)c.h2, bn2, (const float *)t->d_params, off_w3, (const float *)gu, t1, t->acc(c.d_bs2), G, S, c3b);
     else if (mfma_dh)
         hipLaunchKernelGGL((k_c3_dh_mfma<WM, false>), dim3(npw), dim3(256), gu_tile, st, g,
-                           (const float *)c.h2, bn2, (const float *)t->d_params, off_w3, (const float *)gu, t1, t->acc(c.d_bs2), G, S);
+                           (const float *)c.h2, bn2, (const float *)t->d_params, off_w3, (const float *)gu, t1, t->acc(c.d_bs2), G, S, c3b);
     else
         hipLaunchKernelGGL(k_c3_dh<W>, dim3(nb), dim3(TB), 0, st, g, c.h2, bn2, t->d_params, off_w3, gu, t1, t->acc(c.d_bs2));
     sync_slots(t, t->acc(c.d_bs2), 2 * w, g.nslot, st);
@@ -3065,15 +3141,15 @@ void coupling_backward(nf_trainer *t, const Geo &g, const TLayer &L, const float
         const unsigned ngrid = std::min<unsigned>((unsigned)units, (unsigned)g.nslot);
         if (zmix_in)
             hipLaunchKernelGGL((k_c1_dz_mfma<WM, true>), dim3(ngrid), dim3(256), lds, st, g, (const float *)t2, (const float *)t->d_params,
-                               off_w1, t->dz, zmix_in, A, dA, BR);
+                               off_w1, t->dz, zmix_in, A, dA, BR, dz_src);
         else
             hipLaunchKernelGGL((k_c1_dz_mfma<WM, false>), dim3(ngrid), dim3(256), lds, st, g, (const float *)t2, (const float *)t->d_params,
-                               off_w1, t->dz, (const float *)nullptr, (const float *)nullptr, dA, BR);
+                               off_w1, t->dz, (const float *)nullptr, (const float *)nullptr, dA, BR, dz_src);
     } else if (zmix_in) {
-        hipLaunchKernelGGL((k_c1_dz<W, true>), dim3(nb), dim3(TB), 0, st, g, t2, t->d_params, off_w1, t->dz, zmix_in, A, dA);
+        hipLaunchKernelGGL((k_c1_dz<W, true>), dim3(nb), dim3(TB), 0, st, g, t2, t->d_params, off_w1, t->dz, zmix_in, A, dA, dz_src);
     } else {
         hipLaunchKernelGGL((k_c1_dz<W, false>), dim3(nb), dim3(TB), 0, st, g, t2, t->d_params, off_w1, t->dz,
-                           (const float *)nullptr, (const float *)nullptr, dA);
+                           (const float *)nullptr, (const float *)nullptr, dA, dz_src);
     }
 }
 
@@ -3431,6 +3507,7 @@ int nf_trainer_create(const nf_config *cfg, const nf_layer_desc *layers, const f
         NF_TRY(dev_alloc(t, (void **)&t->gu[k], act * 4 * sizeof(float)));
     }
     NF_TRY(dev_alloc(t, (void **)&t->dz, act * 4 * sizeof(float)));
+    if (w >= 16) NF_TRY(dev_alloc(t, (void **)&t->dz2, act * 4 * sizeof(float)));
 #undef NF_TRY
     if ((e = hipMemcpy(t->d_params, params, n_params * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess ||
         (e = hipMemcpy(t->d_mask, mask.data(), n_params, hipMemcpyHostToDevice)) != hipSuccess ||

@@ -670,15 +670,15 @@ def test_wide_matrix_core_stages_and_layer_kernels_agree(arch, width, hw, B, mon
     v = trained_like_variables(arch, width, seed=9)
     x, y = make_inputs(B, hw[0], hw[1], seed=29)
     res = {}
-    for mode in ("0", "511"):
+    for mode in ("0", "4095"):
         monkeypatch.setenv("NF_TRAIN_WIDE_MFMA", mode)
         tr = _trainer(arch, v, (hw[0], hw[1], 4), width)
         grads, loss = tr.forward_backward(x, y, [0.0], [0.0], [400], [1])
         res[mode] = (grads.cpu().numpy().copy(), loss.cpu().numpy().copy(), tr.raw_params())
-        if mode == "511":
+        if mode == "4095":
             _oracle_check_next_to_kinks(tr, arch, v, x, y, 400, 1, width, rtol=1e-3)
         tr.close()
-    (g0, l0, p0), (g1, l1, p1) = res["0"], res["511"]
+    (g0, l0, p0), (g1, l1, p1) = res["0"], res["4095"]
     assert np.allclose(l1, l0, rtol=1e-6, atol=0), (l1, l0)
     # other summation order only — unless an activation within round-off of its ReLU kink takes the other branch in one of
     # the two paths: a few pixels' worth of gradient (the bound of tests/test_gpu_random_sweep.py for wide couplings)
@@ -695,15 +695,15 @@ def test_wide_filter_gradients_fused_into_the_stage_kernels(monkeypatch):
     v = trained_like_variables(arch, width, seed=10)
     x, y = make_inputs(B, 32, 32, seed=31)
     res = {}
-    for mode in ("0", "127", "511"):
+    for mode in ("0", "127", "511", "4095"):
         monkeypatch.setenv("NF_TRAIN_WIDE_MFMA", mode)
         tr = _trainer(arch, v, (32, 32, 4), width, max_batch=B)
         grads, loss = tr.forward_backward(x, y, [0.0], [0.0], [800], [2])
         res[mode] = (grads.cpu().numpy().copy(), loss.cpu().numpy().copy())
         tr.close()
     g0, l0 = res["0"]
-    for mode in ("127", "511"):
+    for mode in ("127", "511", "4095"):
         g, l = res[mode]
         assert np.allclose(l, l0, rtol=1e-6, atol=0), (mode, l, l0)
         assert np.abs(g - g0).max() <= 1e-5 * np.abs(g0).max(), (mode, np.abs(g - g0).max(), np.abs(g0).max())
-    assert not np.array_equal(res["127"][0], res["511"][0])      # the fused path really is another code path
+    assert not np.array_equal(res["127"][0], res["4095"][0])      # the fused path really is another code path

@@ -14,17 +14,17 @@ v = trained_like_variables(ARCH, width, seed=int(sys.argv[3]) if len(sys.argv) >
 for (H, W, B) in [(32, 32, 16), (20, 12, 7), (16, 16, 7), (8, 8, 9), (5, 7, 3)]:
     x, y = patches.synth_patches(0, 0, B, height=H, width=W, nlf=(0.003696, 2e-6))
     out = {}
-    for mode in ("0", "511"):
+    for mode in ("0", "4095"):
         os.environ["NF_TRAIN_WIDE_MFMA"] = mode
         tr = Trainer([H, W, 4], default_hps(width=width, arch=ARCH), variables=v, max_batch=B)
         grads, loss = tr.forward_backward(x, y, [0], [0], [800], [2])
         out[mode] = (grads.cpu().numpy().copy(), loss.cpu().numpy().copy())
         tr.close()
-    g0, g1 = out["0"][0], out["511"][0]
+    g0, g1 = out["0"][0], out["4095"][0]
     d = np.abs(g0 - g1)
-    print("shape", (H, W, B), "loss", out["0"][1], out["511"][1], "max|dg| / max|g| = %.3e" % (d.max() / np.abs(g0).max()),
+    print("shape", (H, W, B), "loss", out["0"][1], out["4095"][1], "max|dg| / max|g| = %.3e" % (d.max() / np.abs(g0).max()),
           "worst index", int(d.argmax()), "of", g0.size, "g0", g0.reshape(-1)[d.argmax()], "g1", g1.reshape(-1)[d.argmax()])
-for mode in ("0", "511"):
+for mode in ("0", "4095"):
     os.environ["NF_TRAIN_WIDE_MFMA"] = mode
     for B in (138, 1024):
         x, y = patches.synth_patches(0, 0, B, nlf=(0.003696, 2e-6))
