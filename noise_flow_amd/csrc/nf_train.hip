@@ -1747,7 +1747,8 @@ __global__ __launch_bounds__(NT) void k_tiled_fwd(Geo g, TiledF3 f3, TiledF1 f1,
 }
 
 // ---------------------------------------------------------------------------------------------
-// width 32 (the paper-scale coupling CNN, job_noise_flow.sh:19): the filter gradients on the matrix cores
+// widths 16 and 32 (32 = the paper-scale coupling CNN, job_noise_flow.sh:19): the filter gradients on the matrix cores
+// (written for width 32 — the comments below count in its numbers; templates on the width, see RowTile)
 // ---------------------------------------------------------------------------------------------
 // A filter gradient is a GEMM whose K axis is the PIXELS of the minibatch: dW[i][j] = sum_p A[p][i] G[p][j].  One
 // v_mfma_f32_32x32x2_f32 (exact fp32) takes two pixels: lane (i = lane & 31, k = lane >> 5) supplies A[p_k][i] and
@@ -2014,7 +2015,7 @@ __global__ __launch_bounds__(256) void k_w1_grad_mfma(Geo g, const float *__rest
     mfma_tile_to_slots(D, red, G + off_w1, g.nslot, [](int i, int j) { return i < 18 && j < W ? (i >> 1) * 2 * W + (i & 1) * W + j : -1; });
 }
 
-// ---- width 32: l_last forward on the matrix cores ----------------------------------------------------------------------
+// ---- widths 16 / 32: l_last forward on the matrix cores ----------------------------------------------------------------------
 // u[p][q] = b[q] + sum_tap sum_i relu(bn2(h2))[p + tap][i] W3[tap][i][q] is evaluated transposed, as in the evaluation kernel
 // (nf_wide.hip): P[p][(tap, q)] = sum_i A2[p][i] W3[tap][i][q] is a GEMM over the 32 channels with 36 output rows (taps 0..7 in
 // one 32-row tile, tap 8 in a second), pixels on N, and u is the shift-add u[p][q] = sum_tap P[p + tap][(tap, q)].  One
@@ -2112,7 +2113,7 @@ __global__ __launch_bounds__(256) void k_c3_fwd_mfma(Geo g, const float *__restr
     acc_add_n<1>(ldacc, lv, g.nslot);
 }
 
-// ---- width 32: the 1x1 layer l_2, forward and transposed, as pixel GEMMs -------------------------------------------------
+// ---- widths 16 / 32: the 1x1 layer l_2, forward and transposed, as pixel GEMMs -------------------------------------------------
 // 32 consecutive pixels of the batch on the N axis of v_mfma_f32_32x32x2_f32 (lane & 31 = the pixel, both lane halves),
 // the 32 output channels on M, the 32 input channels on K in the order k(step s, lane half h) = 16 h + s: lane (p, h) then
 // feeds the 16 consecutive floats [16 h, 16 h + 16) of its pixel's row — four 16-byte loads per tensor — and owns, in the
@@ -2156,7 +2157,7 @@ __device__ __forceinline__ void rows_flush(const float *lds, float *__restrict__
     }
 }
 
-// BN1 + ReLU + l_2 + bias; statistics of the result (k_c2_fwd at width 32); tensor tiles staged through LDS
+// BN1 + ReLU + l_2 + bias; statistics of the result (k_c2_fwd at widths 16 / 32); tensor tiles staged through LDS
 template <int W>
 __global__ __launch_bounds__(256) void k_c2_fwd_mfma(Geo g, const float *__restrict__ h1, Acc stats1, double n, float *__restrict__ P,
                                                        int off_m1, float *__restrict__ bn1_out, int off_w2, float *__restrict__ h2,
@@ -2224,7 +2225,7 @@ __global__ __launch_bounds__(256) void k_c2_fwd_mfma(Geo g, const float *__restr
 }
 
 // BN2 backward -> g_h2 (t1, in place), d l_2/b; transposed l_2 + ReLU mask -> d loss / d xhat1 (t2) and its two batch sums
-// (k_c2_bwd at width 32).  Five passes over [pixels][32] tensors: all of them through wavefront-private LDS tiles, so that
+// (k_c2_bwd at widths 16 / 32).  Five passes over [pixels][W] tensors: all of them through wavefront-private LDS tiles, so that
 // every global access is a whole 4 KB tile in 16-byte pieces.
 // WGRAD: d l_2/W = A1^T g_h2 is accumulated here as well — both operands are in the staged tiles at that point (K = the 32
 // pixels of the tile) — instead of by k_w2_grad_mfma from a second pass over h1 and a stored g_h2; t1 is then read only.
@@ -2337,7 +2338,7 @@ __global__ __launch_bounds__(256) void k_c2_bwd_mfma(Geo g, const float *__restr
     lane_sums_to_slots(gb, red, G + off_w2 + W * W, g.nslot, [](int k, int h) { return HK * h + k; });
 }
 
-// transposed l_last + ReLU mask -> d loss / d xhat2 (t1) and the two batch sums of the BN2 backward (k_c3_dh at width 32):
+// transposed l_last + ReLU mask -> d loss / d xhat2 (t1) and the two batch sums of the BN2 backward (k_c3_dh at widths 16 / 32):
 // g[p][i] = sum_(tap, q) W3[tap][i][q] gu[p - tap][q] — K = 36 = (tap, q), the 32 channels on M, pixels on N; the B operands
 // come from a zero-bordered LDS tile of the patch's gu (K order: step s -> tap s >> 1, q = 2 half + (s & 1), one 8-byte
 // read per tap), the mask from h2 through a staged tile that then takes the result.
@@ -2528,7 +2529,7 @@ __global__ __launch_bounds__(256) void k_c3_dh_mfma(Geo g, const float *__restri
     }
 }
 
-// transposed l_1 (k_c1_dz at width 32): d z0[p][c] += sum_tap sum_j W1[tap][c][j] g_h1[p - tap][j], evaluated like the
+// transposed l_1 (k_c1_dz at widths 16 / 32): d z0[p][c] += sum_tap sum_j W1[tap][c][j] g_h1[p - tap][j], evaluated like the
 // l_last forward: Q[p][(tap, c)] = sum_j W1[tap][c][j] g_h1[p][j] (18 rows of a 32-row tile, K = the 32 channels) for a band
 // of rows + a one-row halo into LDS, then one thread per pixel adds its 9 taps up and runs the folded Conv2d1x1 backward.
 template <int W, bool MIX>
@@ -2621,7 +2622,7 @@ __global__ __launch_bounds__(256) void k_c1_dz_mfma(Geo g, const float *__restri
     if (MIX) acc_add_n<16>(dA, acc, g.nslot);
 }
 
-// l_1 (3x3 SAME conv of the pass-through half, folded Conv2d1x1) + bias + statistics at width 32 (k_c1_fwd): K = (tap, c) = 18,
+// l_1 (3x3 SAME conv of the pass-through half, folded Conv2d1x1) + bias + statistics at widths 16 / 32 (k_c1_fwd): K = (tap, c) = 18,
 // step = tap, lane half = c; the B operands from a zero-bordered LDS tile of the patch's (mixed) pass-through channels.
 template <int W, bool MIX>
 __global__ __launch_bounds__(256) void k_c1_fwd_mfma(Geo g, const float *__restrict__ zin, const float *__restrict__ A,
