@@ -11,7 +11,7 @@ from conftest import trained_like_variables
 width = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 ARCH = sys.argv[2] if len(sys.argv) > 2 else "sdn5|unc|unc|gain4|unc"
 v = trained_like_variables(ARCH, width, seed=int(sys.argv[3]) if len(sys.argv) > 3 else 6)
-for (H, W, B) in [(32, 32, 16), (20, 12, 7), (16, 16, 7), (8, 8, 9), (5, 7, 3)]:
+for (H, W, B) in [(32, 32, 16), (20, 12, 7), (16, 16, 7), (8, 8, 9), (5, 7, 3), (48, 48, 2), (40, 56, 2), (56, 40, 3)]:
     x, y = patches.synth_patches(0, 0, B, height=H, width=W, nlf=(0.003696, 2e-6))
     out = {}
     for mode in ("0", "4095"):
