@@ -1,0 +1,468 @@
+// nf_train_tiled.h — part of nf_train.hip (included inside its anonymous namespace; not a standalone header).
+// The per-patch tiled stages of the trainer: couplings of width 4 / 8 on patches of up to 1 024 pixels.
+// ---------------------------------------------------------------------------------------------
+// tiled backward stages: ONE workgroup per patch, the 3x3 neighbourhoods through zero-bordered LDS tiles
+// ---------------------------------------------------------------------------------------------
+// On the main stream the backward of a coupling is a chain of five layer kernels (k_c3_bwd -> k_c3_dh -> k_c2_bwd ->
+// k_c1_bwd -> k_c1_dz); only the two batch reductions of the BN backward formula really separate them.  For couplings of
+// width <= 8 on patches of up to 1024 pixels the chain is cut at exactly those two points:
+//   A' = k_c3_bwd + k_c3_dh   |   k_c2_bwd   |   C' = k_c1_bwd + k_c1_dz (+ the folded Conv2d1x1)
+// and C' of one coupling shares its launch with A' of the coupling below it: 2 launches per coupling on the critical path
+// instead of 5.  The three filter-gradient kernels stay what they are, on the side stream, fed by the tensors these
+// stages leave in HBM (gu, t1, t2) — fusing THEM in was measured to cost more than it saves (their ~290 value sums per
+// coupling multiply with the wavefront count).  One thread per pixel, NT = 256 / 512 / 1024 threads by patch size.
+template <int N, int NT>
+__device__ __forceinline__ void stage_add_n(float *dst, const float (&v)[N], float *part /* [NT/64][N] */)
+{
+    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    __syncthreads();                       // the previous use of `part` is over
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const float sv = wsum(v[k]);
+        if (ln == 0) part[wv * N + k] = sv;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < N; k += NT) {
+        float tot = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NT / 64; ++i) tot += part[i * N + k];
+        dst[k] = tot;
+    }
+}
+
+// staged[0..n) -> this workgroup's slot of n consecutive accumulator values (call after a barrier)
+template <int NT>
+__device__ __forceinline__ void stage_flush(Acc dst, const float *staged, int n, int nslot)
+{
+    for (int k = threadIdx.x; k < n; k += NT) {
+        float *d = dst.p + (size_t)k * NSLOT;
+        d[blockIdx.x] = staged[k];
+        for (int q = blockIdx.x + gridDim.x; q < nslot; q += gridDim.x) d[q] = 0.0f;
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void zero_floats(float *p, int n)
+{
+    for (int i = threadIdx.x; i < n; i += NT) p[i] = 0.0f;
+}
+
+template <int W, int NT>
+__device__ __forceinline__ void bnb_from_slots_nt(Acc bstats, int nslot, double n, float *sh)
+{
+    for (int j = threadIdx.x >> 6; j < W; j += NT / 64) {
+        double a, b;
+        acc_total2(bstats + j, bstats + W + j, nslot, a, b);
+        if ((threadIdx.x & 63) == 0) {
+            sh[j] = (float)(a / n);
+            sh[W + j] = (float)(b / n);
+        }
+    }
+    __syncthreads();
+}
+
+// A'.  dz: d loss / d (coupling output) of the owned pixel in, with its second half replaced by d loss / d z1 out.
+//   stg: [9] d l_last/b, d l_last/logs, d rescale (adjacent in the raw layout), then [2 W] BN2 sums
+template <int W, int NT>
+__device__ __forceinline__ void tiled_phase_A(const Geo &g, int b, int r, int c, bool ok, float (&dz)[4], const float4 zi,
+                                              const float (&h2v)[W], const float *__restrict__ bn2,
+                                              const float *__restrict__ P, int off_w3, float invB,
+                                              float *__restrict__ gu, float *__restrict__ t1, float *stg, float *part, float *TH,
+                                              float *TU)
+{
+    const int Wp = g.W + 2, tile_px = (g.H + 2) * Wp;
+    const float *W3 = P + off_w3, *b3 = W3 + 36 * (W + 1), *logs = b3 + 4;
+    const float sc = logs[4];
+    const int64_t gp = (int64_t)b * g.HW + threadIdx.x;   // this thread's pixel in the batch tensors
+    const int tp = (r + 1) * Wp + c + 1;                  // ... in the tiles
+    zero_floats<NT>(TH, tile_px * W);
+    zero_floats<NT>(TU, tile_px * 4);
+    __syncthreads();
+    if (ok) {
+#pragma unroll
+        for (int i = 0; i < W; ++i) TH[tp * W + i] = fmaxf((h2v[i] - bn2[i]) * bn2[W + i], 0.0f);
+    }
+    __syncthreads();
+    float tail[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // d b (4), d logs (4), d rescale
+    if (ok) {
+        float u[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) u[q] = b3[q];
+#pragma unroll
+        for (int di = 0; di < 3; ++di) {
+            const int rr = r + di - 1;
+#pragma unroll
+            for (int dj = 0; dj < 3; ++dj) {
+                const int cc = c + dj - 1;
+                const float *w = W3 + (di * 3 + dj) * (W + 1) * 4;
+                if (rr < 0 || rr >= g.H || cc < 0 || cc >= g.W) {   // padding ring: zeros + indicator 1
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) u[q] += w[W * 4 + q];
+                } else {
+                    const float *hp = TH + (tp + (di - 1) * Wp + (dj - 1)) * W;
+#pragma unroll
+                    for (int i = 0; i < W; ++i) {
+                        const float a = hp[i];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) u[q] = fmaf(a, w[i * 4 + q], u[q]);
+                    }
+                }
+            }
+        }
+        const float z1[2] = {zi.z, zi.w}, gx1[2] = {dz[2], dz[3]};
+        float go[4], o[4], e3[4], guv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            e3[q] = expf(kLogscale * logs[q]);
+            o[q] = u[q] * e3[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float t = tanhf(o[2 + q]), E = expf(sc * t);
+            dz[2 + q] = gx1[q] * E;
+            const float gls = gx1[q] * z1[q] * E - invB;   // loss = mean(-(sum ls + ...))
+            tail[8] = fmaf(gls, t, tail[8]);
+            go[q] = gx1[q];                                // shift
+            go[2 + q] = gls * sc * (1.0f - t * t);         // raw
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            tail[4 + q] = kLogscale * go[q] * o[q];
+            guv[q] = go[q] * e3[q];
+            tail[q] = guv[q];
+        }
+        const float4 gv = make_float4(guv[0], guv[1], guv[2], guv[3]);
+        *reinterpret_cast<float4 *>(TU + tp * 4) = gv;
+        reinterpret_cast<float4 *>(gu)[gp] = gv;           // k_w3_grad reads it on the side stream
+    }
+    __syncthreads();
+    // transposed l_last + ReLU mask -> d loss / d xhat2 (t1) and the two batch sums of the BN backward formula
+    float sq[2 * W];
+#pragma unroll
+    for (int j = 0; j < 2 * W; ++j) sq[j] = 0.0f;
+    if (ok) {
+        float gh[W];
+#pragma unroll
+        for (int i = 0; i < W; ++i) gh[i] = 0.0f;
+#pragma unroll
+        for (int di = 0; di < 3; ++di)
+#pragma unroll
+            for (int dj = 0; dj < 3; ++dj) {
+                const float4 gv = *reinterpret_cast<const float4 *>(TU + (tp - (di - 1) * Wp - (dj - 1)) * 4);
+                const float *w = W3 + (di * 3 + dj) * (W + 1) * 4;
+#pragma unroll
+                for (int i = 0; i < W; ++i)
+                    gh[i] += w[i * 4] * gv.x + w[i * 4 + 1] * gv.y + w[i * 4 + 2] * gv.z + w[i * 4 + 3] * gv.w;
+            }
+#pragma unroll
+        for (int i = 0; i < W; ++i) {
+            const float xh = TH[tp * W + i];                 // relu(xhat2): equals xhat2 wherever the mask lets gx through
+            const float gx = xh > 0.0f ? gh[i] : 0.0f;
+            t1[gp * W + i] = gx;
+            sq[i] = gx;
+            sq[W + i] = gx * xh;
+        }
+    }
+    stage_add_n<2 * W, NT>(stg + 9, sq, part);
+    stage_add_n<9, NT>(stg, tail, part);
+}
+
+// C'.  dz: the A' result of this coupling (read back from HBM) in, d loss / d (input of the layer below) out.
+//   stg: [W] d l_1/b, then [16] d A
+template <int W, int NT, bool MIX>
+__device__ __forceinline__ void tiled_phase_C(const Geo &g, int b, int r, int c, bool ok, float (&dz)[4], const float4 zv,
+                                              const float *__restrict__ A, const float (&h1v)[W], const float (&t2v)[W],
+                                              const float *__restrict__ bn1, const float *bb1,
+                                              const float *__restrict__ P, int off_w1, float *__restrict__ t2, float *stg,
+                                              float *part, float *TG)
+{
+    const int Wp = g.W + 2, tile_px = (g.H + 2) * Wp;
+    const float *W1 = P + off_w1;
+    const int64_t gp = (int64_t)b * g.HW + threadIdx.x;
+    const int tp = (r + 1) * Wp + c + 1;
+    zero_floats<NT>(TG, tile_px * W);
+    __syncthreads();
+    float gh[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) gh[j] = 0.0f;
+    if (ok) {
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            const float xh = (h1v[j] - bn1[j]) * bn1[W + j];
+            gh[j] = bn1[W + j] * (t2v[j] - bb1[j] - xh * bb1[W + j]);
+            TG[tp * W + j] = gh[j];
+            t2[gp * W + j] = gh[j];                          // k_w1_grad reads it on the side stream
+        }
+    }
+    __syncthreads();
+    float accA[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accA[i] = 0.0f;
+    if (ok) {
+        float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+        for (int di = 0; di < 3; ++di)
+#pragma unroll
+            for (int dj = 0; dj < 3; ++dj) {
+                const float *gq = TG + (tp - (di - 1) * Wp - (dj - 1)) * W;
+                const float *w = W1 + (di * 3 + dj) * 2 * W;
+#pragma unroll
+                for (int j = 0; j < W; ++j) {
+                    a0 = fmaf(w[j], gq[j], a0);
+                    a1 = fmaf(w[W + j], gq[j], a1);
+                }
+            }
+        const float d[4] = {dz[0] + a0, dz[1] + a1, dz[2], dz[3]};
+        if (MIX) {
+            const float zi[4] = {zv.x, zv.y, zv.z, zv.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                dz[i] = A[i * 4] * d[0] + A[i * 4 + 1] * d[1] + A[i * 4 + 2] * d[2] + A[i * 4 + 3] * d[3];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) accA[i * 4 + j] = zi[i] * d[j];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dz[i] = d[i];
+        }
+    }
+    stage_add_n<W, NT>(stg, gh, part);
+    if (MIX) stage_add_n<16, NT>(stg + W, accA, part);
+}
+
+struct TiledA {   // operands of a stage A'
+    const float *zin, *h2, *bn2;
+    int off_w3;
+    float *gu, *t1;
+    Acc bstats2;
+};
+
+struct TiledC {   // operands of a stage C'
+    const float *zpre, *A, *h1, *bn1;
+    float *t2;
+    int off_w1;
+    Acc bstats1, dA;
+};
+
+// C' of one coupling (skipped for the first launch of the pass: HAS_C = false) and A' of the coupling below it (NEXT_A)
+template <int W, int NT, bool HAS_C, bool MIX, bool NEXT_A>
+__global__ __launch_bounds__(NT) void k_tiled_CA(Geo g, TiledC cc, TiledA a, double n, const float *__restrict__ P, float invB,
+                                                 float *__restrict__ dz, const float *__restrict__ zlat, Acc G)
+{
+    extern __shared__ float smem[];
+    __shared__ float bb1[2 * W];
+    const int tile_px = (g.H + 2) * (g.W + 2);
+    float *stgC = smem + tile_px * (W + 4), *stgA = stgC + W + 16, *part = stgA + 9 + 2 * W;
+    const bool ok = (int)threadIdx.x < g.HW;
+    const int r = ok ? (int)threadIdx.x / g.W : 0, c = ok ? (int)threadIdx.x - r * g.W : 0;
+    const int b = blockIdx.x;
+    const int64_t gp = (int64_t)b * g.HW + threadIdx.x;
+    // every global operand of this pixel is requested up front: the stages below are a chain of short LDS phases, and one
+    // exposed memory latency per stage (5 of them) was most of the kernel's time
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f), zv = v, zi = v;
+    float h1v[W], t2v[W], h2v[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) h1v[j] = t2v[j] = h2v[j] = 0.0f;
+    if (ok) {
+        if (zlat) {                                        // first stage of the pass: d loss / d latent = latent / B
+            const float4 zl = reinterpret_cast<const float4 *>(zlat)[gp];
+            v = make_float4(zl.x * invB, zl.y * invB, zl.z * invB, zl.w * invB);
+        } else {
+            v = reinterpret_cast<const float4 *>(dz)[gp];
+        }
+        if (HAS_C) {
+#pragma unroll
+            for (int j = 0; j < W; j += 4) {
+                *reinterpret_cast<float4 *>(h1v + j) = *reinterpret_cast<const float4 *>(cc.h1 + gp * W + j);
+                *reinterpret_cast<float4 *>(t2v + j) = *reinterpret_cast<const float4 *>(cc.t2 + gp * W + j);
+            }
+            if (MIX) zv = reinterpret_cast<const float4 *>(cc.zpre)[gp];
+        }
+        if (NEXT_A) {
+#pragma unroll
+            for (int j = 0; j < W; j += 4) *reinterpret_cast<float4 *>(h2v + j) = *reinterpret_cast<const float4 *>(a.h2 + gp * W + j);
+            zi = reinterpret_cast<const float4 *>(a.zin)[gp];
+        }
+    }
+    if (HAS_C) bnb_from_slots_nt<W, NT>(cc.bstats1, g.nslot, n, bb1);
+    float d[4] = {v.x, v.y, v.z, v.w};
+    if (HAS_C) tiled_phase_C<W, NT, MIX>(g, b, r, c, ok, d, zv, cc.A, h1v, t2v, cc.bn1, bb1, P, cc.off_w1, cc.t2, stgC, part, smem);
+    if (NEXT_A)
+        tiled_phase_A<W, NT>(g, b, r, c, ok, d, zi, h2v, a.bn2, P, a.off_w3, invB, a.gu, a.t1, stgA, part, smem, smem + tile_px * W);
+    if (ok) reinterpret_cast<float4 *>(dz)[gp] = make_float4(d[0], d[1], d[2], d[3]);
+    __syncthreads();
+    if (HAS_C) {
+        stage_flush<NT>(G + cc.off_w1 + 18 * W, stgC, W, g.nslot);            // d l_1/b
+        if (MIX) stage_flush<NT>(cc.dA, stgC + W, 16, g.nslot);
+    }
+    if (NEXT_A) {
+        stage_flush<NT>(G + a.off_w3 + 36 * (W + 1), stgA, 9, g.nslot);       // d l_last/b, d logs, d rescale
+        stage_flush<NT>(a.bstats2, stgA + 9, 2 * W, g.nslot);
+    }
+}
+
+// ---- the forward pass, same idea: stage 3 of one coupling (BN2 + ReLU + l_last + affine) and stage 1 of the coupling above
+// it (folded Conv2d1x1 + l_1 + its statistics) share a launch; k_c2_fwd stays between the two batch reductions.  The
+// per-pixel arithmetic keeps the order of k_c1_fwd / l_last_u (the zero border of the tiles adds exact zeros), so h1, u and
+// z are bit-identical to the layer kernels'; only the grouping of the fp32 partial sums of the statistics differs.
+template <int W, int NT>
+__device__ __forceinline__ void bn_from_slots_nt(Acc stats, int nslot, double n, float *sh, float *__restrict__ P, int off_mean,
+                                                 int off_var, float *__restrict__ bn_out)
+{
+    for (int j = threadIdx.x >> 6; j < W; j += NT / 64) {
+        double sm, sq;
+        acc_total2(stats + j, stats + W + j, nslot, sm, sq);
+        const double m = sm / n;
+        double v = sq / n - m * m;
+        if (v < 0.0) v = 0.0;
+        if ((threadIdx.x & 63) == 0) {
+            const float mf = (float)m, rf = (float)(1.0 / sqrt(v + (double)kBnEps));
+            sh[j] = mf;
+            sh[W + j] = rf;
+            if (blockIdx.x == 0) {
+                bn_out[j] = mf;
+                bn_out[W + j] = rf;
+                P[off_mean + j] -= kBnDecay * (P[off_mean + j] - mf);
+                P[off_var + j] -= kBnDecay * (P[off_var + j] - (float)v);
+            }
+        }
+    }
+    __syncthreads();
+}
+
+struct TiledF3 {   // operands of stage 3 of a coupling
+    const float *zin, *h2;
+    Acc stats2;
+    int off_m2, off_w3;
+    float *bn2_out, *zout;
+    Acc ldacc;
+};
+
+struct TiledF1 {   // operands of stage 1 of a coupling (A / zmixed: the folded Conv2d1x1)
+    const float *A;
+    float *zmixed;
+    int off_w1;
+    float *h1;
+    Acc stats1;
+};
+
+template <int W, int NT, bool HAS_3, bool MIX, bool HAS_1>
+__global__ __launch_bounds__(NT) void k_tiled_fwd(Geo g, TiledF3 f3, TiledF1 f1, const float *__restrict__ zsrc, double n,
+                                                  float *__restrict__ P, const float *__restrict__ Pw)
+{   // Pw = P.  The filters are read through their own read-only pointer: behind the pointer the running moments are written
+    // through, the compiler cannot prove them unclobbered and fetches every (wavefront-uniform) weight with a vector load
+    // instead of a scalar one — 76 extra vector loads per thread in this kernel.
+    extern __shared__ float smem[];
+    __shared__ float bn2[2 * W];
+    const int Wp = g.W + 2, tile_px = (g.H + 2) * Wp;
+    float *TH = smem, *TZ = smem + tile_px * W, *stg = TZ + tile_px * 2, *part = stg + 1 + 2 * W;
+    const bool ok = (int)threadIdx.x < g.HW;
+    const int r = ok ? (int)threadIdx.x / g.W : 0, c = ok ? (int)threadIdx.x - r * g.W : 0;
+    const int b = blockIdx.x, tp = (r + 1) * Wp + c + 1;
+    const int64_t gp = (int64_t)b * g.HW + threadIdx.x;
+    // the pixel's global operands are requested before the statistics are added up (see k_tiled_CA)
+    float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    float h2v[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) h2v[j] = 0.0f;
+    if (ok) {
+        if (HAS_3) {
+#pragma unroll
+            for (int j = 0; j < W; j += 4) *reinterpret_cast<float4 *>(h2v + j) = *reinterpret_cast<const float4 *>(f3.h2 + gp * W + j);
+            z = reinterpret_cast<const float4 *>(f3.zin)[gp];
+        } else {
+            z = reinterpret_cast<const float4 *>(zsrc)[gp];
+        }
+    }
+    zero_floats<NT>(smem, tile_px * (W + 2));
+    if (HAS_3) bn_from_slots_nt<W, NT>(f3.stats2, g.nslot, n, bn2, P, f3.off_m2, f3.off_m2 + W, f3.bn2_out);
+    __syncthreads();
+    if (HAS_3) {
+        const float *W3 = Pw + f3.off_w3, *b3 = W3 + 36 * (W + 1), *logs = b3 + 4;
+        if (ok) {
+#pragma unroll
+            for (int i = 0; i < W; ++i) TH[tp * W + i] = fmaxf((h2v[i] - bn2[i]) * bn2[W + i], 0.0f);
+        }
+        __syncthreads();
+        float lv[1] = {0.0f};
+        if (ok) {
+            float u[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) u[k] = b3[k];
+#pragma unroll
+            for (int di = 0; di < 3; ++di) {
+                const int rr = r + di - 1;
+#pragma unroll
+                for (int dj = 0; dj < 3; ++dj) {
+                    const int cc = c + dj - 1;
+                    const float *w = W3 + (di * 3 + dj) * (W + 1) * 4;
+                    if (rr < 0 || rr >= g.H || cc < 0 || cc >= g.W) {   // on the padding ring: zeros + indicator 1
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) u[k] += w[W * 4 + k];
+                    } else {
+                        const float *hp = TH + (tp + (di - 1) * Wp + (dj - 1)) * W;
+#pragma unroll
+                        for (int i = 0; i < W; ++i) {
+                            const float a = hp[i];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) u[k] = fmaf(a, w[i * 4 + k], u[k]);
+                        }
+                    }
+                }
+            }
+            const float sc = logs[4];
+            const float4 zi = z;
+            const float sh0 = u[0] * expf(kLogscale * logs[0]), sh1 = u[1] * expf(kLogscale * logs[1]);
+            const float ls0 = sc * tanhf(u[2] * expf(kLogscale * logs[2])), ls1 = sc * tanhf(u[3] * expf(kLogscale * logs[3]));
+            z = make_float4(zi.x, zi.y, fmaf(zi.z, expf(ls0), sh0), fmaf(zi.w, expf(ls1), sh1));
+            reinterpret_cast<float4 *>(f3.zout)[gp] = z;
+            lv[0] = ls0 + ls1;
+        }
+        stage_add_n<1, NT>(stg, lv, part);
+    }
+    if (HAS_1) {
+        const float *W1 = Pw + f1.off_w1, *b1 = W1 + 18 * W;
+        if (ok) {
+            float2 v = make_float2(z.x, z.y);
+            if (MIX) {
+                const float *m = f1.A;
+                v.x = z.x * m[0] + z.y * m[4] + z.z * m[8] + z.w * m[12];
+                v.y = z.x * m[1] + z.y * m[5] + z.z * m[9] + z.w * m[13];
+                reinterpret_cast<float4 *>(f1.zmixed)[gp] = make_float4(v.x, v.y, z.x * m[2] + z.y * m[6] + z.z * m[10] + z.w * m[14],
+                                                                        z.x * m[3] + z.y * m[7] + z.z * m[11] + z.w * m[15]);
+            }
+            *reinterpret_cast<float2 *>(TZ + tp * 2) = v;
+        }
+        __syncthreads();
+        float sq[2 * W];
+#pragma unroll
+        for (int j = 0; j < 2 * W; ++j) sq[j] = 0.0f;
+        if (ok) {
+            float h[W];
+#pragma unroll
+            for (int j = 0; j < W; ++j) h[j] = b1[j];
+#pragma unroll
+            for (int di = 0; di < 3; ++di)
+#pragma unroll
+                for (int dj = 0; dj < 3; ++dj) {
+                    const int rr = r + di - 1, cc = c + dj - 1;
+                    if (rr < 0 || rr >= g.H || cc < 0 || cc >= g.W) continue;
+                    const float2 v = *reinterpret_cast<const float2 *>(TZ + (tp + (di - 1) * Wp + (dj - 1)) * 2);
+                    const float *w = W1 + (di * 3 + dj) * 2 * W;
+#pragma unroll
+                    for (int j = 0; j < W; ++j) h[j] = fmaf(v.x, w[j], fmaf(v.y, w[W + j], h[j]));
+                }
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+                f1.h1[gp * W + j] = h[j];
+                sq[j] = h[j];
+                sq[W + j] = h[j] * h[j];
+            }
+        }
+        stage_add_n<2 * W, NT>(stg + 1, sq, part);
+    }
+    __syncthreads();
+    if (HAS_3) stage_flush<NT>(f3.ldacc, stg, 1, g.nslot);
+    if (HAS_1) stage_flush<NT>(f1.stats1, stg + 1, 2 * W, g.nslot);
+}
+
