@@ -235,6 +235,7 @@ int nf_sample_batchstats(nf_handle *h, const float *y, const float *eps, uint64_
  *                       6 l_1 transposed (8: l_1 forward) on v_mfma_f32_32x32x2_f32; 3 one-pass statistics finalisers (widths >= 16);
  *                       7 filter gradients inside the stage kernels (>= 400k pixels per step), 8 l_1 forward,
  *                       11 affine / tanh backward inside the transposed l_last kernel.  Default 4095.
+ *   NF_TRAIN_BAND       pixels (rows x patch width, halo included; 96..320, default 320) a band kernel keeps in LDS.
  *   NF_TRAIN_SERIAL=1   no side stream: every kernel on the caller's stream (kernel traces without overlap). */
 typedef struct nf_trainer nf_trainer;
 #define NF_OPT_ADAM     0
