@@ -28,7 +28,8 @@ Rank 0 prints ONE JSON line.  Besides the contract keys it carries
   fp16_cnn_64x64  BASELINE configs[4] shape (64x64x4, fp16 coupling CNN / fp32 log-det)
   wide_cnn      the paper-scale coupling CNN (width 32 / 16) on the f32 matrix cores, own roofline
   sharded_1m    configs[3] on this one GPU (2^20 resident patches, no process group)
-  training      one training step (fwd batch-BN + bwd + EMA + Adam) at the reference's minibatch of 138
+  training      one training step (fwd batch-BN + bwd + EMA + Adam) at the reference's minibatch of 138: the shipped
+                architecture (width 4) and, nested as `width32`, the paper-scale coupling width on the matrix cores
   two_streams   the headline workload with consecutive steps alternating between two HIP streams
 """
 from __future__ import annotations
