@@ -661,7 +661,8 @@ def test_tiled_stages_and_layer_kernels_agree(arch, width, hw, B, monkeypatch):
                                              ("unc|unc", 32, (20, 12), 7),          # ragged: tiles of 32 pixels straddle rows
                                              ("unc", 32, (5, 7), 3),                # a patch smaller than one 64-pixel step
                                              ("unc|gain4|unc", 32, (64, 64), 2),    # per-patch operand tiles too large for LDS
-                                             ("sdn5|unc|unc", 16, (16, 24), 6)])    # width 16: finalisers + coalesced BN1 backward
+                                             ("sdn5|unc|unc", 16, (16, 24), 6),     # width 16: the same templates
+                                             ("unc|unc", 32, (8, 8), 1100)])        # more patches than slots: the persistent loops
 def test_wide_matrix_core_stages_and_layer_kernels_agree(arch, width, hw, B, monkeypatch):
     """At width 32 the l_2 forward / backward stages and the three filter gradients run as GEMMs on v_mfma_f32_32x32x2_f32
     (exact fp32), the slot sums are added up by one-pass finaliser kernels and the BN1 backward walks the tensors flat;
@@ -672,7 +673,7 @@ def test_wide_matrix_core_stages_and_layer_kernels_agree(arch, width, hw, B, mon
     res = {}
     for mode in ("0", "4095"):
         monkeypatch.setenv("NF_TRAIN_WIDE_MFMA", mode)
-        tr = _trainer(arch, v, (hw[0], hw[1], 4), width)
+        tr = _trainer(arch, v, (hw[0], hw[1], 4), width, max_batch=max(64, B))
         grads, loss = tr.forward_backward(x, y, [0.0], [0.0], [400], [1])
         res[mode] = (grads.cpu().numpy().copy(), loss.cpu().numpy().copy(), tr.raw_params())
         if mode == "4095":
