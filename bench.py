@@ -2,7 +2,8 @@
 """Benchmark of the Noise Flow hot path on MI355X — driver contract.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: either under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...`, or plain
+    `python bench.py --gpus N`, which then launches its own N ranks that way on a free local port)
 
 N = 1 (the headline, BASELINE configs[1] — the configuration the metric is quoted on): a "step" is one
 pass of the fused likelihood-direction kernel (per-patch NLL written to HBM + log|det J| + batch sums)
@@ -14,7 +15,10 @@ N > 1 (BASELINE configs[3]): a "step" is one COMPLETE evaluation of the 2^20-pat
 contiguous blocks of the patch index over the ranks (strong scaling: the total work is fixed).  Every
 rank keeps its block resident in HBM (34 GB / N), evaluates it with the persistent fused kernel and the
 evaluation ends with ONE RCCL all-reduce of (sum nll, sum sd_z, count) — 24 bytes, the only collective;
-no barrier and no read-back inside the timed region.  NF_BENCH_FORCE_DIST=1 runs this leg on one rank.
+no barrier and no read-back inside the timed region.  NF_BENCH_FORCE_DIST=1 runs this leg on one rank.  The same line
+carries BASELINE configs[4] (2^18 patches of 64x64x4, fp16 coupling CNN / fp32 log-det, sharded the same way) as the nested
+section `fp16_cnn_64x64_sharded` with its own roofline; `--config c5` makes it the headline instead.  `cpu_baseline` is timed
+on rank 0 after the timed regions.
 
 Patches are a pure function of (seed, global patch index), so any sharding evaluates the same data.
 Rank 0 prints ONE JSON line.  Besides the contract keys it carries
@@ -86,8 +90,12 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--batch", type=int, default=1024, help="N = 1: patches per step (configs[1]: 1024)")
-    ap.add_argument("--total-patches", type=int, default=1 << 20,
-                    help="N > 1: size of the patch range one step evaluates, sharded over the ranks (configs[3]: 2^20)")
+    ap.add_argument("--total-patches", type=int, default=0,
+                    help="N > 1: size of the patch range one step evaluates, sharded over the ranks (0 = the workload's own: "
+                         "configs[3] 2^20 patches of 32x32x4, configs[4] 2^18 patches of 64x64x4 — 34 GB either way)")
+    ap.add_argument("--config", choices=("auto", "c4", "c5"), default="auto",
+                    help="N > 1 headline: c4 = BASELINE configs[3] (32x32x4, fp32; the default) with configs[4] nested as "
+                         "`fp16_cnn_64x64_sharded`; c5 = BASELINE configs[4] (64x64x4, fp16 coupling CNN) as the headline")
     ap.add_argument("--shard-chunk", type=int, default=0,
                     help="N > 1: patches per kernel launch inside a rank's block (0 = the whole block in one launch)")
     ap.add_argument("--sample-batch", type=int, default=4096, help="sampling-direction batch (configs[2]: 4096)")
@@ -126,6 +134,25 @@ def _traffic():
         return None, "no traffic record: %s" % e
 
 
+def rank_launch_command(n: int, port: int, argv) -> list:
+    """The command `python bench.py --gpus N` turns itself into when it was not started under torch.distributed.run
+    (the launch line the driver's contract names, with a free port)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(n)),
+            "--master-addr", "127.0.0.1", "--master-port", str(int(port)), os.path.abspath(__file__)] + list(argv)
+
+
+def _launch_ranks(n: int) -> int:
+    import socket
+    import subprocess
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    return subprocess.call(rank_launch_command(n, port, sys.argv[1:]), env=env)
+
+
 def main():
     args = parse_args()
     # stdout carries exactly ONE line, the JSON, written last: native libraries (RCCL prints a version
@@ -137,11 +164,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                     % (args.gpus, args.gpus))
-        args.gpus = world
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: become the launcher — one process per GPU under torch.distributed.run on a
+        # free local port; the ranks inherit this stdout, so rank 0's JSON line is this command's one line
+        os.dup2(json_fd, 1)
+        os.close(json_fd)
+        sys.exit(_launch_ranks(args.gpus))
+    args.gpus = world
 
     import torch
     import torch.distributed as dist
@@ -202,15 +231,45 @@ def _clock_ramp(step, ramp_ms, dev):
 
 
 # ---------------------------------------------------------------------------------------------------------
-# N > 1: BASELINE configs[3] — 2^20 patches sharded by patch index, ONE all-reduce per evaluation
+# N > 1: BASELINE configs[3] (and configs[4]) — a patch range sharded by patch index, ONE all-reduce per evaluation
 # ---------------------------------------------------------------------------------------------------------
-def sharded_leg(ctx):
+SHARDED_WORKLOADS = {
+    # BASELINE configs[3]: forward NLL over 2^20 synthetic 32x32x4 patches, exact fp32
+    "c4": dict(label="configs[3]", height=32, width=32, cnn_dtype="fp32", total=1 << 20, dtype="f32",
+               kernel="nf_flow_kernel<4,256,4,false,true,true,0,false>", flop_per_patch=ALGO_FLOP_PER_PATCH,
+               peak=VALU_PEAK_TFLOPS, peak_name="dense fp32 matrix/vector peak"),
+    # BASELINE configs[4]: 64x64x4 patches, fp16 coupling CNN / fp32 log-det; 2^18 patches = the same 34 GB of input
+    "c5": dict(label="configs[4]", height=64, width=64, cnn_dtype="fp16", total=1 << 18, dtype="f16 CNN / f32 log-det",
+               kernel="nf_flow_kernel<4,1024,4,false,true,true,1,false>", flop_per_patch=4 * ALGO_FLOP_PER_PATCH,
+               peak=FP16_MFMA_PEAK_TFLOPS, peak_name="dense fp16 matrix peak"),
+}
+
+
+def sharded_workload(name: str, total_patches: int = 0) -> dict:
+    """The sharded workload `name` ("c4" | "c5") with its patch range (0 = the workload's own size)."""
+    w = dict(SHARDED_WORKLOADS[name], name=name)
+    if total_patches > 0:
+        w["total"] = int(total_patches)
+    w["bytes_per_patch"] = 2 * w["height"] * w["width"] * 4 * 4
+    return w
+
+
+def _run_sharded(ctx, spec, K, Wm):
+    """K timed complete evaluations of spec's patch range on this rank's resident block (+ the one all-reduce each);
+    returns this rank's measurements and, gathered, every rank's."""
     import torch
     import torch.distributed as dist
+    from noise_flow_amd import NoiseFlow, default_hps
     from noise_flow_amd.dist import ResidentShard, timed_sharded_evaluations
-    args, rank, world, dev, model = ctx["args"], ctx["rank"], ctx["world"], ctx["dev"], ctx["model"]
-    K, Wm, n_total = args.steps, args.warmup, args.total_patches
-    shard = ResidentShard(model, args.seed, n_total, rank, world)
+    args, rank, world, dev = ctx["args"], ctx["rank"], ctx["world"], ctx["dev"]
+    if spec["name"] == "c4":
+        model = ctx["model"]
+    else:
+        model = NoiseFlow([spec["height"], spec["width"], 4], False, default_hps(), variables=ctx["variables"],
+                          device=ctx["local_rank"], cnn_dtype=spec["cnn_dtype"])
+    n_total = spec["total"]
+    shard = ResidentShard(model, args.seed, n_total, rank, world, spec["height"], spec["width"],
+                          fill_chunk=max(1, (1 << 25) // (spec["height"] * spec["width"])))
     n_local = shard.stop - shard.start
     chunk = args.shard_chunk if args.shard_chunk > 0 else max(1, n_local)
     eval_chunk = shard.eval_chunk()
@@ -222,13 +281,12 @@ def sharded_leg(ctx):
         ev[i][0 if what == "begin" else 1].record(stream)
 
     if args.ramp_ms > 0:             # untimed clock ramp on a slice of the resident block
-        nb = min(1024, n_local)
+        nb = min(max(1, (1 << 20) // (spec["height"] * spec["width"])), n_local)
         scratch = model.new_sums()
         _clock_ramp(lambda i: model.nll_sums(shard.x[:nb], shard.y[:nb], [0.0], [0.0], [100.0], [2.0], scratch),
                     args.ramp_ms, dev)
     res = timed_sharded_evaluations(eval_chunk, n_total, chunk, rank, world, K, Wm, new_sums,
                                     sync=lambda: torch.cuda.synchronize(dev), on_step=on_step)
-    elapsed_local = res["elapsed"]
     kernel_ms_local = sum(a.elapsed_time(b) for a, b in ev) / K
 
     # the all-reduce on its own (untimed diagnostic): 24-byte message, pure latency
@@ -243,51 +301,97 @@ def sharded_leg(ctx):
     torch.cuda.synchronize(dev)
     allreduce_us = (time.perf_counter() - t_a) / n_probe * 1e6
 
-    stats = torch.tensor([elapsed_local, kernel_ms_local, allreduce_us], dtype=torch.float64, device=dev)
+    stats = torch.tensor([res["elapsed"], kernel_ms_local, allreduce_us], dtype=torch.float64, device=dev)
     gathered = [torch.zeros_like(stats) for _ in range(world)]
     dist.all_gather(gathered, stats)
     per_rank = [g.cpu().tolist() for g in gathered]
+    nbytes = shard.nbytes
+    del shard, eval_chunk
+    torch.cuda.empty_cache()
+    return dict(res=res, per_rank=per_rank, chunk=chunk, nbytes=nbytes)
+
+
+def _sharded_record(spec, run, world, K, Wm, backend):
+    """The JSON fields of one sharded workload (rank 0)."""
+    res, per_rank, n_total = run["res"], run["per_rank"], spec["total"]
     elapsed = max(p[0] for p in per_rank)
-    if rank != 0:
-        return None
     means = [r[0] for r in res["results"]]
-    value = n_total * K / elapsed
     ms_step = 1e3 * elapsed / K
     kernel_ms = max(p[1] for p in per_rank)
-    gbs = ALGO_BYTES_PER_PATCH * (n_total / world) / (kernel_ms * 1e-3) / 1e9       # per GPU
-    tfl = ALGO_FLOP_PER_PATCH * (n_total / world) / (kernel_ms * 1e-3) / 1e12
+    gbs = spec["bytes_per_patch"] * (n_total / world) / (kernel_ms * 1e-3) / 1e9       # per GPU
+    tfl = spec["flop_per_patch"] * (n_total / world) / (kernel_ms * 1e-3) / 1e12
+    patch = "%dx%dx4" % (spec["height"], spec["width"])
     return {
-        "metric": "patches/sec (32x32x4) fwd-NLL and inverse-sample; mean NLL vs CPU ref",
-        "value": value, "unit": "patches/s", "n_gpus": world, "steps": K, "warmup": Wm,
-        "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "configs[3]: forward NLL over %d synthetic 32x32x4 patches (full arch %s, shipped checkpoint, "
-                               "ISO 100 / cam S6), patch range sharded in contiguous blocks over %d GPU(s); one step = one "
-                               "complete evaluation ending in ONE all-reduce of (sum nll, sum sd_z, count)"
-                               % (n_total, ARCH_LABEL, world),
-                   "total_patches": n_total, "global_batch": n_total, "patches_per_gpu": n_total // world, "patch": "32x32x4",
-                   "launch_chunk": chunk, "inputs": "resident in HBM (%.1f GB per GPU)" % (shard.nbytes / 1e9),
-                   "backend": dist.get_backend(),
+        "value": n_total * K / elapsed, "unit": "patches/s", "n_gpus": world, "steps": K, "warmup": Wm,
+        "ms_per_step": ms_step, "scaling": "strong", "dtype": spec["dtype"],
+        "config": {"workload": "%s: forward NLL over %d synthetic %s patches (full arch %s, shipped checkpoint, ISO 100 / cam S6%s), "
+                               "patch range sharded in contiguous blocks over %d GPU(s); one step = one complete evaluation "
+                               "ending in ONE all-reduce of (sum nll, sum sd_z, count)"
+                               % (spec["label"], n_total, patch, ARCH_LABEL,
+                                  ", fp16 coupling CNN with fp32 log-det accumulation" if spec["cnn_dtype"] == "fp16" else "", world),
+                   "total_patches": n_total, "global_batch": n_total, "patches_per_gpu": n_total // world, "patch": patch,
+                   "launch_chunk": run["chunk"], "inputs": "resident in HBM (%.1f GB per GPU)" % (run["nbytes"] / 1e9),
+                   "backend": backend,
                    "parallelism": "dp%d: patch-index sharding, %s" % (
                        world, "one RCCL all-reduce of 3 fp64 scalars per evaluation" if world > 1 else
-                       "single rank (NF_BENCH_FORCE_DIST: the RCCL call is issued on a 1-rank group)")},
+                       "single rank (NF_BENCH_FORCE_DIST: the collective is issued on a 1-rank group)")},
         "mean_nll": means[-1], "sd_z": res["results"][-1][1],
         "mean_nll_identical_across_steps": bool(max(means) - min(means) <= 1e-9 * abs(means[0])),
-        "per_rank": {"elapsed_s": [p[0] for p in per_rank], "kernel_ms_per_step": [p[1] for p in per_rank],
+        "per_rank": {"ranks": world, "elapsed_s": [p[0] for p in per_rank], "kernel_ms_per_step": [p[1] for p in per_rank],
                      "allreduce_us": [p[2] for p in per_rank]},
         "collective": {"allreduce_us": max(p[2] for p in per_rank), "per_step": 1,
                        "share_of_step": max(p[2] for p in per_rank) * 1e-3 / ms_step,
                        "non_kernel_share_of_step": max(0.0, 1.0 - kernel_ms / ms_step),
                        "note": "allreduce_us = one all-reduce + device sync, timed alone after the run; "
                                "non_kernel_share = 1 - (slowest rank's kernel time / step time)"},
-        "roofline": {"bound": "mfma", "achieved": tfl, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": tfl / VALU_PEAK_TFLOPS, "traffic": None, "scope": "per GPU, slowest rank's kernel time",
-                     "kernel": "nf_flow_kernel<4,256,4,false,true,true,0,false>", "kernel_ms": kernel_ms,
-                     "algorithmic_flop_per_launch": ALGO_FLOP_PER_PATCH * n_total / world,
+        "roofline": {"bound": "mfma", "achieved": tfl, "peak": spec["peak"], "unit": "TFLOP/s",
+                     "frac": tfl / spec["peak"], "traffic": None, "scope": "per GPU, slowest rank's kernel time",
+                     "peak_is": spec["peak_name"], "kernel": spec["kernel"], "kernel_ms": kernel_ms,
+                     "algorithmic_flop_per_launch": spec["flop_per_patch"] * n_total / world,
                      "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                             "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PATCH * n_total / world}},
-        "cpu_baseline": None, "clock_ramp_ms": args.ramp_ms,
+                             "algorithmic_bytes_per_launch": spec["bytes_per_patch"] * n_total / world}},
     }
+
+
+def sharded_leg(ctx):
+    import torch.distributed as dist
+    args, rank, world = ctx["args"], ctx["rank"], ctx["world"]
+    K, Wm = args.steps, args.warmup
+    head = "c5" if args.config == "c5" else "c4"
+    spec = sharded_workload(head, args.total_patches)
+    run = _run_sharded(ctx, spec, K, Wm)
+    nested = None
+    if head == "c4":                                   # BASELINE configs[4] rides along as a nested section
+        spec5 = sharded_workload("c5", max(0, args.total_patches // 4))
+        k5 = max(1, min(K, 10))
+        try:
+            nested = (spec5, _run_sharded(ctx, spec5, k5, min(Wm, 2)), k5)
+        except Exception as e:                         # the headline must not depend on the nested section
+            nested = e
+    if rank != 0:
+        return None
+    out = {"metric": "patches/sec (32x32x4) fwd-NLL and inverse-sample; mean NLL vs CPU ref"}
+    out.update(_sharded_record(spec, run, world, K, Wm, dist.get_backend()))
+    out.update({"higher_is_better": True, "vs_baseline": None, "data": "synthetic", "clock_ramp_ms": args.ramp_ms})
+    if head == "c4":
+        traffic, traffic_src = _traffic()
+        if traffic is not None:                        # PMC bytes of a 1024-patch launch of the same kernel, per patch x patches per launch
+            out["roofline"]["traffic"] = traffic / 1024.0 * (spec["total"] / world)
+            out["roofline"]["traffic_source"] = traffic_src + ", scaled from the measured 1024-patch launch to this launch's patch count"
+    if isinstance(nested, tuple):
+        sec = _sharded_record(nested[0], nested[1], world, nested[2], min(Wm, 2), dist.get_backend())
+        sec["roofline"]["hbm"]["achievable_frac"] = sec["roofline"]["hbm"]["achieved"] / 6290.0     # guide: 6.29 TB/s achievable
+        out["fp16_cnn_64x64_sharded"] = sec
+    elif nested is not None:
+        out["fp16_cnn_64x64_sharded"] = {"error": "%s: %s" % (type(nested).__name__, nested)}
+    # CPU baseline: rank 0 only, AFTER the timed regions (the other ranks wait in main()'s closing barrier)
+    out["cpu_baseline"] = None
+    if not args.no_cpu_baseline:
+        from noise_flow_amd.patches import synth_patches
+        xs, ys = synth_patches(args.seed, 0, 1024, device=ctx["local_rank"])       # patches [0, 1024) of configs[3]'s range
+        out["cpu_baseline"] = _cpu_baseline(args, ctx["variables"], xs.cpu().numpy(), ys.cpu().numpy(), 1024)
+        out["cpu_baseline"]["workload_note"] = "32x32x4 fp32 forward NLL (the per-patch work of configs[1] / configs[3])"
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -586,7 +690,7 @@ def _sharded_1m(ctx, batches, cond, wide):
     import torch
     from noise_flow_amd.dist import ResidentShard, timed_sharded_evaluations
     args, dev, model = ctx["args"], ctx["dev"], ctx["model"]
-    n_total = args.total_patches
+    n_total = args.total_patches or (1 << 20)
     shard = ResidentShard(model, args.seed, n_total, 0, 1)
     ks = 3
     res = timed_sharded_evaluations(shard.eval_chunk(), n_total, n_total, 0, 1, ks, 1,

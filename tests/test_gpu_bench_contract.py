@@ -67,3 +67,48 @@ def test_bench_multi_rank_leg_under_torchrun_on_one_gpu():
     shard = ResidentShard(m, 0, 65536, 0, 1)
     mean, sd, n = evaluate_sharded(shard.eval_chunk(), 65536, 65536, 0, 1, torch.zeros(3, dtype=torch.float64, device="cuda"))
     assert n == 65536 and abs(mean - d["mean_nll"]) <= 1e-9 * abs(mean) and abs(sd - d["sd_z"]) <= 1e-9 * sd
+
+
+def test_bench_multi_rank_leg_without_torchrun_self_spawns():
+    """Plain `python bench.py --gpus 2` (no torch.distributed.run, no WORLD_SIZE): bench.py launches its own two ranks.  On this
+    one-GPU box both ranks share GPU 0 and gloo carries the all-reduce.  The line carries configs[3] as the headline, configs[4]
+    (64x64, fp16 CNN, sharded the same way) as a nested section with its own roofline, and rank 0's CPU baseline."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(NF_BENCH_BACKEND="gloo", NF_BENCH_ONE_GPU="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--total-patches", "32768", "--ramp-ms", "0", "--cpu-seconds", "2"], cwd=ROOT, env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    lines = [l for l in out.stdout.decode().split("\n") if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout.decode()[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["total_patches"] == 32768
+    assert d["per_rank"]["ranks"] == 2 and len(d["per_rank"]["kernel_ms_per_step"]) == 2
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
+    c5 = d["fp16_cnn_64x64_sharded"]
+    assert "error" not in c5, c5
+    assert c5["config"]["patch"] == "64x64x4" and c5["config"]["total_patches"] == 8192 and c5["config"]["patches_per_gpu"] == 4096
+    assert c5["roofline"]["peak"] == 2500.0 and c5["roofline"]["frac"] > 0 and c5["roofline"]["hbm"]["frac"] > 0
+    assert c5["mean_nll_identical_across_steps"] is True and c5["value"] > 0
+    # the fp16-CNN mean NLL of the sharded 64x64 range is the model's own answer on the same patches
+    import torch
+    from conftest import SHIPPED_CKPT
+    from noise_flow_amd import NoiseFlow, default_hps
+    from noise_flow_amd.ckpt import load_checkpoint
+    from noise_flow_amd.dist import ResidentShard, evaluate_sharded
+    m = NoiseFlow([64, 64, 4], False, default_hps(), variables=load_checkpoint(SHIPPED_CKPT), cnn_dtype="fp16")
+    shard = ResidentShard(m, 0, 8192, 0, 1, 64, 64)
+    mean, sd, n = evaluate_sharded(shard.eval_chunk(), 8192, 8192, 0, 1, torch.zeros(3, dtype=torch.float64, device="cuda"))
+    assert n == 8192 and abs(mean - c5["mean_nll"]) <= 1e-9 * abs(mean)
+
+
+def test_bench_c5_headline_on_one_rank():
+    """`--config c5` makes BASELINE configs[4] the headline of the sharded leg (here: one rank, NF_BENCH_FORCE_DIST)."""
+    env = dict(os.environ, NF_BENCH_FORCE_DIST="1", NF_BENCH_BACKEND="gloo")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--config", "c5",
+                          "--total-patches", "4096", "--ramp-ms", "0", "--no-cpu-baseline"], cwd=ROOT, env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    d = json.loads([l for l in out.stdout.decode().split("\n") if l.strip().startswith("{")][0])
+    assert d["config"]["patch"] == "64x64x4" and d["config"]["total_patches"] == 4096 and d["dtype"].startswith("f16")
+    assert d["roofline"]["peak"] == 2500.0 and "fp16_cnn_64x64_sharded" not in d

@@ -175,3 +175,96 @@ def test_timed_sharded_evaluations_without_process_group():
     with pytest.raises(RuntimeError):
         timed_sharded_evaluations(lambda a, n, s: s.add_(torch.tensor([0.0, 0.0, n - 1.0], dtype=torch.float64)), 10, 4, 0, 1, 1, 0,
                                   lambda: torch.zeros(3, dtype=torch.float64))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# bench.py's multi-GPU legs: launch convention and the configs[4] (64x64, fp16 CNN) sharded workload
+# ---------------------------------------------------------------------------------------------------------
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("nf_bench", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_bench_launches_its_own_ranks_when_not_under_torchrun():
+    """`python bench.py --gpus N` without WORLD_SIZE must become the torch.distributed.run launcher (it used to exit)."""
+    bench = _bench_module()
+    cmd = bench.rank_launch_command(8, 12345, ["--gpus", "8", "--steps", "3", "--warmup", "1"])
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "12345"
+    assert cmd[-7] == os.path.join(ROOT, "bench.py") and cmd[-6:] == ["--gpus", "8", "--steps", "3", "--warmup", "1"]
+    # end to end on this GPU-less container: the launcher starts 2 ranks, every rank refuses to run without a GPU
+    # (no CPU fallback), the launcher hands the failure on and prints no JSON line
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    import torch
+    if not torch.cuda.is_available():
+        assert out.returncode != 0
+        assert "needs an MI355X" in out.stderr.decode()
+        assert not [l for l in out.stdout.decode().split("\n") if l.strip().startswith("{")]
+
+
+def test_sharded_workload_specs():
+    bench = _bench_module()
+    c4, c5 = bench.sharded_workload("c4"), bench.sharded_workload("c5")
+    assert (c4["height"], c4["width"], c4["cnn_dtype"], c4["total"]) == (32, 32, "fp32", 1 << 20)
+    assert (c5["height"], c5["width"], c5["cnn_dtype"], c5["total"]) == (64, 64, "fp16", 1 << 18)
+    assert c4["bytes_per_patch"] == 32768 and c5["bytes_per_patch"] == 131072
+    assert c4["bytes_per_patch"] * c4["total"] == c5["bytes_per_patch"] * c5["total"]       # the same 34 GB of input
+    assert bench.sharded_workload("c5", 4096)["total"] == 4096
+
+
+def _c5_worker(rank, world, port, n_total, q):
+    """One rank of the configs[4] leg with the fp64 oracle (fp16-CNN emulation) standing in for the HIP kernel: the same
+    `timed_sharded_evaluations` loop, `shard_range` blocks and (seed, global patch index) data contract bench.py uses."""
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from noise_flow_amd.ckpt import load_checkpoint
+    from noise_flow_amd.dist import timed_sharded_evaluations
+    from oracle import philox
+    from oracle.nf_oracle import NoiseFlowOracle
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    orc = NoiseFlowOracle("sdn5|unc|unc|unc|unc|gain4|unc|unc|unc|unc",
+                          load_checkpoint(os.path.join(ROOT, "models", "NoiseFlow", "ckpt", "model.ckpt.best")), cnn_dtype="fp16")
+    seen = []
+
+    def eval_chunk(first, count, acc):
+        seen.append((first, count))
+        x, y = philox.synth_patches(0, first, count, 64, 64)
+        nll, sd, _ = orc.nll(x, y, 100.0, 2.0)
+        acc += torch.tensor([float(np.sum(nll)), float(sd) * count, float(count)], dtype=torch.float64)
+    res = timed_sharded_evaluations(eval_chunk, n_total, n_total, rank, world, 1, 0, lambda: torch.zeros(3, dtype=torch.float64))
+    q.put((rank, res["results"][0], seen))
+    dist.destroy_process_group()
+
+
+def test_c5_leg_sharding_gloo():
+    """BASELINE configs[4] sharded over 2 ranks = the unsharded evaluation of the same 64x64 patch range."""
+    import torch.multiprocessing as mp
+    from noise_flow_amd.ckpt import load_checkpoint
+    from noise_flow_amd.patches import shard_range
+    from oracle import philox
+    from oracle.nf_oracle import NoiseFlowOracle
+    n_total, world = 5, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_c5_worker, args=(r, world, port, n_total, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=300) for _ in procs]
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    orc = NoiseFlowOracle("sdn5|unc|unc|unc|unc|gain4|unc|unc|unc|unc",
+                          load_checkpoint(os.path.join(ROOT, "models", "NoiseFlow", "ckpt", "model.ckpt.best")), cnn_dtype="fp16")
+    x, y = philox.synth_patches(0, 0, n_total, 64, 64)
+    nll, sd, _ = orc.nll(x, y, 100.0, 2.0)
+    for rank, (mean, msd, n), seen in res:
+        a, b = shard_range(n_total, rank, world)
+        assert seen == [(a, b - a)] and n == n_total
+        assert abs(mean - float(np.mean(nll))) <= 1e-9 * abs(float(np.mean(nll)))
