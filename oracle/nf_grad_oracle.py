@@ -73,6 +73,9 @@ class GradOracle:
         order = unc_ids if binding == "loss_first" else unc_ids[::-1]
         self.tmpl_of = {i: k for k, i in enumerate(order)}
         self.arch_l = arch_l
+        self.kink_ulps = 32.0          # see _relu
+        self.kinks = []                # filled by forward(): activations within kink_ulps of their ReLU kink
+        self.relu_flips = set()        # {(site, flat index)}: take the other ReLU branch there
 
     # -- pieces -----------------------------------------------------------------------------
     def _A(self, i):
@@ -115,15 +118,52 @@ class GradOracle:
             new_running[key] = (old - BN_DECAY * (old - val.detach())).numpy().reshape(self.shapes[key])
         return (h - m[None, :, None, None]) / torch.sqrt(v[None, :, None, None] + BN_EPS)
 
+    def _relu(self, hn, h, amp, site, err_in=None):
+        """ReLU written as a constant 0/1 gate, so that a test can ask what the gradient would be with the OTHER branch at
+        activations that no float32 evaluation can place on one side of the kink.
+
+        An activation is "on its kink" when |h - batch mean| < kink_ulps * u, u = 2^-24 * (amp + |batch mean|) + err_in:
+        amp = sum |input| * |weight| + |bias| is the magnitude of the terms whose rounded sum an fp32 evaluation compares
+        with the mean, err_in the round-off its inputs already carry (per ulp; for l_2 that is l_1's u / sqrt(var + eps)
+        pushed through |W2| — it dominates when a batch variance is far below BN's epsilon and the normalised activations
+        are differences of nearly equal numbers).  So the margin is below the round-off of ANY fp32 summation order.  Those
+        are recorded in self.kinks as (site, flat index, margin / u); `self.relu_flips` = set of (site, flat index) inverts
+        the gate there (the forward value moves by the activation itself, i.e. by less than its own round-off).
+        Returns (relu(hn), round-off unit of the output)."""
+        with torch.no_grad():
+            gate = (hn > 0)
+            m = h.mean(dim=(0, 2, 3))
+            v = h.var(dim=(0, 2, 3), unbiased=False)
+            u = 2.0 ** -24 * (amp + m.abs()[None, :, None, None])
+            if err_in is not None:
+                u = u + err_in
+            margin = (h - m[None, :, None, None]).abs() / (u + 1e-300)
+            idx = torch.nonzero(margin.reshape(-1) < self.kink_ulps).reshape(-1)
+            for k in idx.tolist():
+                self.kinks.append((site, k, float(margin.reshape(-1)[k])))
+            if self.relu_flips:
+                flat = gate.reshape(-1).clone()
+                for (st, k) in self.relu_flips:
+                    if st == site:
+                        flat[k] = ~flat[k]
+                gate = flat.reshape(gate.shape)
+            err_out = u / torch.sqrt(v[None, :, None, None] + BN_EPS)
+        return hn * gate.to(hn.dtype), err_out
+
     def _cnn(self, z0, i, new_running):
         t = O.template_name(self.tmpl_of[i]) + "/"
         g = lambda k: self.t[t + k]
         w1 = g("l_1/W").permute(3, 2, 0, 1)
         h = F.conv2d(z0, w1, g("l_1/b").reshape(-1), padding=1)           # layers.py:469
-        h = torch.relu(self._bn_train(h, t, 1, new_running))
+        with torch.no_grad():
+            amp = F.conv2d(z0.abs(), w1.abs(), g("l_1/b").reshape(-1).abs(), padding=1)
+        a1, err1 = self._relu(self._bn_train(h, t, 1, new_running), h, amp, (i, 1))
         w2 = g("l_2/W").reshape(g("l_2/W").shape[-2], g("l_2/W").shape[-1]).t()[:, :, None, None]
-        h = F.conv2d(h, w2, g("l_2/b").reshape(-1))                       # :480
-        h = torch.relu(self._bn_train(h, t, 2, new_running))
+        h = F.conv2d(a1, w2, g("l_2/b").reshape(-1))                      # :480
+        with torch.no_grad():
+            amp = F.conv2d(a1.abs(), w2.abs(), g("l_2/b").reshape(-1).abs())
+            err2 = F.conv2d(err1, w2.abs())
+        h, _ = self._relu(self._bn_train(h, t, 2, new_running), h, amp, (i, 2), err2)
         hp = F.pad(h, (1, 1, 1, 1))                                       # add_edge_padding, :555-583
         e = torch.zeros_like(hp[:, :1])
         e[:, :, 0, :] = 1
@@ -241,8 +281,11 @@ class GradOracle:
         sd_z = torch.sqrt(z.var(dim=(1, 2, 3), unbiased=False)).mean()
         return nll.mean(), sd_z, new_running
 
-    def loss_and_grads(self, x, y, iso, cam):
-        """→ (loss, sd_z, {name: d loss / d variable} for trainables, new running statistics)."""
+    def loss_and_grads(self, x, y, iso, cam, relu_flips=()):
+        """→ (loss, sd_z, {name: d loss / d variable} for trainables, new running statistics).  `self.kinks` afterwards lists
+        the activations that sit on their ReLU kink (see _relu); `relu_flips` takes the other branch at some of them."""
+        self.relu_flips = set((tuple(s), int(k)) for s, k in relu_flips)
+        self.kinks = []
         for v in self.t.values():
             if v.grad is not None:
                 v.grad = None

@@ -209,10 +209,9 @@ def test_random_model_training_gradients(seed):
     case = "arch=%s width=%d %dx%d fp=%d decomp=%s iso=%d cam=%d B=%d" % (arch, width, H, W, fp, decomp, iso, cam, B)
     tr = Trainer([H, W, 4], default_hps(arch=arch, width=width, flow_permutation=fp, decomp=decomp), variables=v, optim="adam", max_batch=16)
     names = [nm for L in tr.layers for nm in P.layer_variable_names(L, tr._tmpl) if nm is not None]
-    # width <= 8: 2e-4 of a tensor's scale.  Wider: a BN-normalised pre-activation sits within float32 round-off of its ReLU
-    # kink in a sizeable share of draws (32 channels x pixels x 2 normalisations per coupling), and the branch the GPU takes
-    # then differs from the fp64 oracle's for that ONE pixel — a few pixels' share of the gradient is the resolution there.
-    rtol = 2e-4 if width <= 8 else max(1e-3, min(8.0 / (B * H * W), 2e-2))
+    # 2e-4 of a tensor's scale at widths <= 8, 5e-4 beyond (longer fp32 sums).  Activations on a ReLU kink are handled exactly
+    # below (grads_match_up_to_kinks), not by a loose tolerance.
+    rtol = 2e-4 if width <= 8 else 5e-4
     # A draw whose coupling CNN sees a nearly constant input (a random sdn stack can shrink z by orders of magnitude) has batch
     # variances far below BN's epsilon: the normalised activations are then ~1e-2 small, float32 resolves them to ~1e-4 of
     # themselves and dozens of them sit on their ReLU kink — for ANY fp32 evaluation, the reference's included.  Such draws
@@ -224,13 +223,13 @@ def test_random_model_training_gradients(seed):
     if min_var < 1e-6:
         rtol = 5e-2
 
-    def compare(xv):
-        grads, loss = tr.forward_backward(xv, y, [0.0], [0.0], [iso], [cam])
-        ref_loss, ref_sd, ref_grads, _ = GradOracle(arch, v, flow_permutation=fp, decomp=decomp).loss_and_grads(xv, y, iso, cam)
-        lv = loss.cpu().numpy()
+    grads, loss = tr.forward_backward(x, y, [0.0], [0.0], [iso], [cam])
+    lv = loss.cpu().numpy()
+    got = tr.raw_to_variables(grads.cpu().numpy())
+
+    def compare(ref_loss, ref_sd, ref_grads):
         assert abs(lv[0] - ref_loss) <= 1e-5 * abs(ref_loss) + 1e-4, "loss %r vs %r" % (lv[0], ref_loss)
         assert abs(lv[1] - ref_sd) <= 1e-5 * ref_sd, "sd_z"
-        got = tr.raw_to_variables(grads.cpu().numpy())
         gmax = max(np.abs(ref_grads[nm]).max() for nm in names if is_trainable(nm))
         for nm in names:
             if not is_trainable(nm):
@@ -243,18 +242,16 @@ def test_random_model_training_gradients(seed):
                 assert np.abs(g - ref).max() <= rtol * max(np.abs(ref).max(), 1e-6 * gmax), (nm, np.abs(g - ref).max(), np.abs(ref).max())
 
     # The loss is piecewise smooth: an activation within float32 round-off of a ReLU kink takes one branch in the fp64
-    # oracle and the other on the GPU, and the gradients upstream then differ by that one pixel's share (1e-4 .. 1e-2 of a
-    # tensor; measured: the disagreement vanishes, to 1e-6, when the input is moved by 1e-4 of itself, and the ORACLE's own
-    # gradient jumps by the same amount under a 3e-7 perturbation).  Such a draw is re-drawn next to itself, twice at most.
-    errors = []
-    for attempt in range(3):
-        xv = x if attempt == 0 else (x * (1.0 + 1e-4 * np.random.RandomState(seed + attempt).randn(*x.shape))).astype(np.float32)
-        try:
-            compare(xv)
-            return
-        except AssertionError as e:
-            errors.append(str(e))
-    raise AssertionError("%s: %s" % (case, " | next to it: ".join(errors)))
+    # oracle and possibly the other on the GPU, and the gradients upstream then differ by that one activation's path.  ONE
+    # evaluation, no re-draws: the oracle reports exactly the activations whose margin is below 32 units of the round-off
+    # of the sum that produced them, and only the other branch at (a subset of) those is accepted — conftest.py.
+    from conftest import grads_match_up_to_kinks
+    try:
+        excused = grads_match_up_to_kinks(GradOracle(arch, v, flow_permutation=fp, decomp=decomp), x, y, iso, cam, compare,
+                                          max_kinks=48 if min_var >= 1e-6 else 0, got=got)
+    except AssertionError as e:
+        raise AssertionError("%s: %s" % (case, e))
+    assert excused <= 12, (case, excused)
 
 
 @pytest.mark.parametrize("seed", list(range(400, 430)))

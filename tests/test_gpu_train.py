@@ -93,25 +93,22 @@ def test_gradients_other_widths_and_shapes(arch, width, hw, B, iso, cam):
 
 
 def _oracle_check_next_to_kinks(tr, arch, v, x, y, iso, cam, width, rtol=GRAD_RTOL):
-    """Loss, sd_z and every gradient tensor against the fp64 oracle.  The loss is piecewise smooth: at widths >= 16 (W channels
-    x pixels x 2 normalisations per coupling) an activation can sit within float32 round-off of its ReLU kink, the fp64
-    oracle and an fp32 evaluation then take different branches and the gradients differ by that one pixel's share — which
-    branch the GPU takes depends on the summation order of the kernel that produced the activation.  As in
-    tests/test_gpu_random_sweep.py such an input is re-drawn next to itself (1e-4 of itself), twice at most."""
-    errors = []
-    for attempt in range(1 if width <= 8 else 3):
-        xv = x if attempt == 0 else (x * (1.0 + 1e-4 * np.random.RandomState(100 + attempt).randn(*x.shape))).astype(np.float32)
-        grads, loss = tr.forward_backward(xv, y, [0.0], [0.0], [iso], [cam])
-        ref_loss, ref_sd, ref_grads, _ = _grad_oracle(arch, v).loss_and_grads(xv, y, iso, cam)
-        lv = loss.cpu().numpy()
+    """Loss, sd_z and every gradient tensor against the fp64 oracle — ONE evaluation, no re-draws.  The loss is piecewise
+    smooth: an activation within float32 round-off of its ReLU kink may take one branch in the fp64 oracle and the other on
+    the GPU.  The oracle names exactly those activations (margin < 32 units of the round-off of the sum that produced them)
+    and `grads_match_up_to_kinks` accepts the other branch at those and nowhere else; the number it had to excuse is
+    returned (0 on almost every input)."""
+    from conftest import grads_match_up_to_kinks
+    grads, loss = tr.forward_backward(x, y, [0.0], [0.0], [iso], [cam])
+    lv = loss.cpu().numpy()
+
+    def compare(ref_loss, ref_sd, ref_grads):
         assert abs(lv[0] - ref_loss) <= 1e-5 * abs(ref_loss)
         assert abs(lv[1] - ref_sd) <= 1e-5 * ref_sd
-        try:
-            _check_grads(tr, grads, ref_grads, rtol=rtol)
-            return
-        except AssertionError as e:
-            errors.append(str(e)[:300])
-    raise AssertionError(" | next to it: ".join(errors))
+        _check_grads(tr, grads, ref_grads, rtol=rtol)
+    excused = grads_match_up_to_kinks(_grad_oracle(arch, v), x, y, iso, cam, compare)
+    assert excused <= 1, excused
+    return excused
 
 
 def test_optimizer_kernels_match_float32_restatement(shipped_variables):

@@ -142,3 +142,56 @@ def test_autograd_oracle_covers_the_whole_vocabulary_and_every_permutation_setti
             vp[k], vm[k] = ap, am
             fd = (f(vp) - f(vm)) / (2 * h)
             assert abs(fd - grads[k][idx]) <= 2e-5 * max(abs(fd), 1e-6 * gmax), (m["arch"], k, fd, grads[k][idx])
+
+
+def test_relu_kinks_are_reported_and_can_be_flipped():
+    """The deterministic replacement of 're-draw the input next to a kink' (tests/conftest.py::grads_match_up_to_kinks)."""
+    import pytest
+    from conftest import grads_match_up_to_kinks
+    from oracle.nf_grad_oracle import GradOracle
+    v, x, y = _setup(B=2, hw=(8, 8))
+    o = GradOracle(ARCH, v)
+    loss, sd, g0, _ = o.loss_and_grads(x, y, 800, 2)
+    assert o.kinks == []                                   # a generic input has no activation within 32 ulp of a kink
+    o.kink_ulps = 8e3                                      # widen the band artificially to get candidates
+    o.loss_and_grads(x, y, 800, 2)
+    cands = [(s, k) for s, k, _ in o.kinks]
+    assert 1 <= len(cands) <= 8, len(cands)
+    assert all(m < 8e3 for _, _, m in o.kinks)
+    loss1, sd1, g1, _ = o.loss_and_grads(x, y, 800, 2, relu_flips=[cands[0]])
+    assert abs(loss1 - loss) <= 1e-5 * abs(loss)           # the forward value moves by the (tiny) activation only
+    diff = max(np.abs(g1[k] - g0[k]).max() / max(np.abs(g0[k]).max(), 1e-30) for k in g0)
+    assert diff > 1e-6                                     # ... but the gradient jumps: the branch matters
+    # an evaluation that took the other branch at candidate 0 is explained by exactly one flip, and by nothing else
+    def compare_to(target):
+        def compare(l, s, g):
+            for k in target:
+                assert np.abs(g[k] - target[k]).max() <= 1e-9 * max(np.abs(target[k]).max(), 1e-30), k
+        return compare
+    assert grads_match_up_to_kinks(o, x, y, 800, 2, compare_to(g0)) == 0
+    assert grads_match_up_to_kinks(o, x, y, 800, 2, compare_to(g1)) == 1
+    bogus = {k: a * 1.01 for k, a in g0.items()}
+    with pytest.raises(AssertionError):
+        grads_match_up_to_kinks(o, x, y, 800, 2, compare_to(bogus))
+    o.kink_ulps = 32.0
+    with pytest.raises(AssertionError, match="nothing to excuse"):
+        grads_match_up_to_kinks(o, x, y, 800, 2, compare_to(g1))
+
+
+def test_many_kinks_are_solved_for_not_searched():
+    """More than 6 candidates: the flipped subset is fitted by least squares in the candidates' gradient moves, rounded,
+    and verified by an exact re-evaluation (tests/conftest.py::grads_match_up_to_kinks)."""
+    from conftest import grads_match_up_to_kinks
+    from oracle.nf_grad_oracle import GradOracle
+    v, x, y = _setup(B=2, hw=(8, 8))
+    o = GradOracle(ARCH, v)
+    o.kink_ulps = 1.2e4
+    o.loss_and_grads(x, y, 800, 2)
+    c = [(s, k) for s, k, _ in o.kinks]
+    assert len(c) > 6
+    tgt = o.loss_and_grads(x, y, 800, 2, relu_flips=[c[1], c[4], c[7]])[2]
+
+    def compare(l, s, g):
+        for k in tgt:
+            assert np.abs(g[k] - tgt[k]).max() <= 1e-9 * max(np.abs(tgt[k]).max(), 1e-30), k
+    assert grads_match_up_to_kinks(o, x, y, 800, 2, compare, max_kinks=48, got=tgt) == 3
