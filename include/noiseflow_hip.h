@@ -301,6 +301,15 @@ int nf_fold_params(const nf_config *cfg, const nf_layer_desc *layers,
                    float *folded, size_t folded_cap, size_t *n_folded,
                    double *ld_const);
 
+/* Host-only: the parameter block of ONE kernel family's layout (`path` = NF_PATH_*; csrc/nf_device.h documents each), i.e.
+ * what nf_create uploads for that family — so that a test can un-permute a layout and hold it to the folded model without a
+ * GPU.  `layout_width` = the coupling width the layout is padded to.  Fails with NF_EINVAL when the model has no block
+ * for that family (e.g. NF_PATH_GEMM at widths <= 32).  No reference counterpart (diagnostic). */
+int nf_fold_layout(const nf_config *cfg, const nf_layer_desc *layers,
+                   const float *params, size_t n_params, int32_t direction, int32_t path,
+                   int32_t *ops_out, int32_t ops_cap, int32_t *n_ops, int32_t *layout_width,
+                   float *folded, size_t folded_cap, size_t *n_folded);
+
 /* Which kernel family nf_nll (direction 0) / nf_sample (direction 1) of this handle launch:
  *   NF_PATH_SCALAR  scalar-weight VALU kernel (any width / shape; also NF_KERNEL=valu)
  *   NF_PATH_MFMA4   width 4 on v_mfma_f32_4x4x1            NF_PATH_FP16 width 4, fp16 CNN (NF_CFG_FP16_CNN)
@@ -313,6 +322,7 @@ int nf_fold_params(const nf_config *cfg, const nf_layer_desc *layers,
 #define NF_PATH_WIDE32 3
 #define NF_PATH_WIDE16 4
 #define NF_PATH_WIDE32_FP16 5   /* NF_CFG_FP16_CNN at width 8 / 16 / 32: v_mfma_f32_32x32x16_f16 */
+#define NF_PATH_GEMM 6          /* widths 33 .. 512: LDS-staged GEMM on v_mfma_f32_32x32x2_f32 (csrc/nf_gemm.hip) */
 int nf_kernel_path(const nf_handle *h, int32_t direction);
 
 /* Host-only: the SDN5 scalars the kernels receive for a given (iso, cam):

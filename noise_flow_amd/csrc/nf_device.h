@@ -175,6 +175,33 @@ __host__ __device__ constexpr int nf4_chan(int v, int g) { return 8 * (v >> 2) +
 #define NF5_IMG_SIZE 1664
 #define NF5_CPL_SIZE (NF4_CPL_IMG + NF5_IMG_SIZE)
 
+// ---- GEMM layout (coupling widths 33 .. 512, nf_gemm.hip) -------------------------------------------
+// WP = the width zero-padded to 64 / 128 / 256 / 512, MT = WP / 32 channel tiles.  Same tile convention as NF4_* (a tile =
+// 32 pixels on the N axis of v_mfma_f32_32x32x2_f32, channels on M, D register v of lane half g = channel c(v, g) of its
+// tile); the hidden activations of a band of NB = 32768 / WP pixels live in LDS, the weights are streamed from L2 by the
+// wavefront that consumes them, in exactly its fetch order:
+//   COUPLING  E [16][4] @0, S [4] @64 (as NF4), IMG7 @68:
+//     A1 [MT][3][64][4]      l_1 of output tile m: step = tap (9 used of 12), lane l: W1[tap][ch = l>>5][32 m + (l&31)]
+//     B1 [MT][2][16]         l_1 bias by (m, g, v): b1[32 m + c(v, g)]
+//     B2 [MT][2][16]
+//     A2 [MT][WP/8][64][4]   l_2 of output tile m: K step kk = 4 kc + s consumes input tile kk / 16, register kk % 16:
+//                            lane l: W2[in = 32 (kk/16) + c(kk%16, l>>5)][out = 32 m + (l&31)]
+//     A3 [2][MT][4][64][4]   l_last as P = W3^T h2, P tile pt: row i = 32 pt + (l&31) = 4 tap + j (36 rows used); step v of
+//                            input tile mi: W3[tap][in = 32 mi + c(v, l>>5)][j]   (raw columns j >= 2 pre-scaled by 2 log2 e)
+#define NF7_CPL_E 0
+#define NF7_CPL_S 64
+#define NF7_CPL_IMG 68
+__host__ __device__ constexpr int nf7_pad_width(int w) { return w <= 64 ? 64 : w <= 128 ? 128 : w <= 256 ? 256 : 512; }
+__host__ __device__ constexpr int nf7_img_A1(int) { return 0; }
+__host__ __device__ constexpr int nf7_img_B1(int wp) { return (wp / 32) * 768; }
+__host__ __device__ constexpr int nf7_img_B2(int wp) { return (wp / 32) * 800; }
+__host__ __device__ constexpr int nf7_img_A2(int wp) { return (wp / 32) * 832; }
+__host__ __device__ constexpr int nf7_img_A3(int wp) { return (wp / 32) * 832 + wp * wp; }
+__host__ __device__ constexpr int nf7_img_size(int wp) { return (wp / 32) * 832 + wp * wp + 2 * (wp / 32) * 1024; }
+__host__ __device__ constexpr int nf7_cpl_size(int wp) { return NF7_CPL_IMG + nf7_img_size(wp); }
+#define NF7_BAND_FLOATS 32768   // hidden activations of one band: WP channels x NB pixels (128 KiB of LDS)
+#define NF7_MAX_PIXELS 2048     // pixels per patch the GEMM kernel holds (4 per thread)
+
 // launch flags
 enum : uint32_t {
     NF_K_PRIOR     = 1u,   // nll = -(logdet + logp(z)); otherwise nll = -logdet

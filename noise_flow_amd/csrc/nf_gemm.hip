@@ -1,0 +1,458 @@
+// Fused Noise Flow stack for WIDE coupling CNNs (hps.width 33 .. 512) as LDS-staged GEMMs on the f32 matrix cores of gfx950.
+//
+// sidd/ArgParser.py:43 defaults --width to Glow's 512 and layers.py:452-498 accepts any width.  At w = 512 a coupling CNN is
+// 290 kMAC per pixel, 90 % of it the 1x1 convolution l_2: [pixels x w] . [w x w] — the one place this model is a real GEMM.
+// Same program, same I/O, same per-patch workgroup and epilogue as nf_kernels.hip / nf_wide.hip; what changes is where the
+// hidden activations live.  A 32x32 patch at w = 512 has 2 MiB of them per layer: neither registers nor LDS hold a patch,
+// so the CNN is evaluated BAND by band:
+//
+//  * a band = NB = 32768 / WP consecutive pixels (row-major), WP = w zero-padded to 64 / 128 / 256 / 512 (exact: a padded
+//    channel has zero weights and bias, hence zero activation).  h1 of the band — WP x NB floats = 128 KiB — sits in LDS in
+//    MFMA B-operand order; 512 threads = 8 wavefronts, one workgroup per CU.
+//  * tiles as in nf_wide.hip: 32 pixels on the N axis of v_mfma_f32_32x32x2_f32 (exact fp32), channels on M; D register v of
+//    lane half g = channel c(v, g) of its tile, which is register by register the B operand of the next layer's K step v.
+//  * l_1 (K = 18): B operands from a zero-bordered LDS tile of the pass-through half; its 32 output tiles are dealt 4 per
+//    wavefront; ReLU'd results are parked in LDS as [K chunk of 8 channels][lane half][pixel][4] — the lane that will need
+//    them as B operands of l_2 reads back one ds_read_b128 per 4 K steps.
+//  * l_2: every wavefront owns 2 output-channel tiles x 2 pixel tiles (4 accumulator tiles, 64 VGPRs) over the whole K.  Its
+//    A operands (the w x w weights, 1 MiB at w = 512) are NOT staged in LDS: each weight is consumed by exactly one wavefront
+//    of the workgroup, so that wavefront streams them straight from L2 in fetch order (one coalesced 16-byte load per lane
+//    per 4 K steps, software-pipelined one chunk ahead).  Per workgroup and band the whole weight set crosses L2 -> CU
+//    once; all workgroups of an XCD walk the couplings in step, so the 1.2 MiB of a coupling stay L2-resident.
+//  * l_last is evaluated transposed, as in nf_wide.hip: P[pixel][tap][j] = sum_c h2[pixel][c] W3[tap][c][j] straight from
+//    the ReLU'd l_2 accumulators (h2 never exists in memory).  A wavefront only holds its own 64 channels, so the WM = WP/64
+//    partial P tiles of a pixel meet in LDS (the h1 region is dead by then), and every thread then gathers the 9 taps of the
+//    output pixels it owns:  o[r][c] += sum_taps P[r+di-1][c+dj-1][tap] over the pixels of THIS band.  'SAME' padding falls
+//    out of the bounds checks, the edge-indicator channel is the 16-entry border table of the other kernels.
+//
+// Replaces (reference, /root/reference): layers.py:251-375 (AffineCoupling), :452-498 (real_nvp_conv_template), :555-613,
+// :651-674 (conv2d / add_edge_padding / conv2d_zeros) at hps.width > 32 (sidd/ArgParser.py:43: default 512).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <atomic>
+#include "../../include/noiseflow_hip.h"   // NF_SUMS_SLOTS / NF_SUMS_STRIDE
+#include "nf_device.h"
+#include "nf_dev_util.h"
+
+namespace {
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+constexpr int GT = 512;          // threads per workgroup
+constexpr int GW = GT / 64;      // wavefronts
+
+__device__ __forceinline__ float4 ldg4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+
+//   WP      padded coupling width: 64, 128, 256, 512
+//   PHILOX  input = in-kernel Philox/Box-Muller draw
+//   OWN     pixels per thread: 2 (patches <= 1024 pixels) or 4 (<= 2048)
+template <int WP, bool PHILOX, int OWN>
+__global__ __launch_bounds__(GT) void nf_gemm_kernel(const NfProgram prog, const NfLaunch a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int MT = WP / 32;            // channel tiles
+    constexpr int NB = NF7_BAND_FLOATS / WP;   // pixels per band
+    constexpr int NT = NB / 32;            // pixel tiles per band
+    constexpr int WM = MT / 2;             // wavefronts along the channel axis of l_2 (2 tiles each)
+    constexpr int WN = GW / WM;            // wavefronts along the pixel axis (2 tiles each)
+    constexpr int KC = WP / 8;             // chunks of 4 K steps (8 input channels)
+    static_assert(MT * NT == 32 && WM * WN == GW && NT == 2 * WN, "tile split");
+    const int H = a.H, W = a.W, HW = H * W;
+    const int Wp = W + 2;
+    const int PL = ((H + 2) * Wp + 3) & ~3;            // one channel plane of the z0 tile
+    float *const h1 = smem;                             // [KC][2][NB][4]; later the partial P tiles [WM][NB][36]
+    float *const z0s = smem + NF7_BAND_FLOATS;          // [2][PL]
+    float *const red = z0s + 2 * PL;                    // [3][GW]
+
+    const int t = threadIdx.x;
+    const int wv = t >> 6, lane = t & 63, n = lane & 31, g = lane >> 5;
+    const int wm = wv / WN, wn = wv % WN;
+
+    for (int i = t; i < 2 * PL; i += GT) z0s[i] = 0.0f;
+    __syncthreads();
+
+    // the pixels this thread owns: p = t + GT m
+    int pr[OWN], pc[OWN];
+    bool act[OWN];
+#pragma unroll
+    for (int m = 0; m < OWN; ++m) {
+        const int p = t + GT * m;
+        act[m] = p < HW;
+        pr[m] = act[m] ? p / W : 0;
+        pc[m] = act[m] ? p - pr[m] * W : 0;
+    }
+
+    const int n_ops = prog.n_ops;
+    const int n_bands = (HW + NB - 1) / NB;
+    double acc_nll = 0.0, acc_sd = 0.0;   // thread 0 only
+
+    for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
+        const size_t patch_off = (size_t)b * (size_t)HW * 4u;
+
+        float z[OWN][4];
+#pragma unroll
+        for (int m = 0; m < OWN; ++m) {
+            const int gi = act[m] ? t + GT * m : 0;
+            if (PHILOX) {
+                philox_normal4(a.seed, a.patch_base + b, (uint32_t)gi, NF_STREAM_SAMP, z[m]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) z[m][q] *= a.in_scale;
+            } else {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (act[m]) v = reinterpret_cast<const float4 *>(a.in + patch_off)[gi];
+                z[m][0] = v.x * a.in_scale;
+                z[m][1] = v.y * a.in_scale;
+                z[m][2] = v.z * a.in_scale;
+                z[m][3] = v.w * a.in_scale;
+            }
+        }
+
+        float ld = 0.0f, ld2 = 0.0f;   // natural-log / log2 parts of this thread's log-det share
+
+        for (int op = 0; op < n_ops; ++op) {
+            const int type = prog.ops[op].type;
+            const cfloat_p P = (cfloat_p)(a.params + prog.ops[op].off);   // wave-uniform, scalar loads
+
+            if (type == NF_OP_MIX) {
+                float mm[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) mm[i] = P[i];
+#pragma unroll
+                for (int m = 0; m < OWN; ++m) {
+                    float o[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float s = z[m][0] * mm[j];
+                        s = fmaf(z[m][1], mm[4 + j], s);
+                        s = fmaf(z[m][2], mm[8 + j], s);
+                        s = fmaf(z[m][3], mm[12 + j], s);
+                        o[j] = s;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) z[m][j] = o[j];
+                }
+            } else if (type == NF_OP_COUPLING_FWD || type == NF_OP_COUPLING_REV) {
+                const float *const img = a.params + prog.ops[op].off + NF7_CPL_IMG;
+                // ---- publish the pass-through half ----
+#pragma unroll
+                for (int m = 0; m < OWN; ++m)
+                    if (act[m]) {
+                        z0s[(pr[m] + 1) * Wp + pc[m] + 1] = z[m][0];
+                        z0s[PL + (pr[m] + 1) * Wp + pc[m] + 1] = z[m][1];
+                    }
+                float o[OWN][4];
+#pragma unroll
+                for (int m = 0; m < OWN; ++m)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[m][j] = 0.0f;
+                __syncthreads();
+
+                for (int band = 0; band < n_bands; ++band) {
+                    const int p0 = band * NB;
+                    // ---- l_1: 32 tiles of h1 = relu(W1 z0 + b1), 4 per wavefront, into LDS in B-operand order ----
+#pragma unroll 1
+                    for (int i = 0; i < 4; ++i) {
+                        const int tt = wv * 4 + i, m = tt / NT, nt = tt % NT;
+                        int p = p0 + 32 * nt + n;
+                        p = p < HW ? p : HW - 1;   // columns past the patch: never gathered
+                        const int r = p / W, c = p - r * W;
+                        const float *zb = z0s + g * PL + r * Wp + c;   // tap (di,dj) at + di*Wp + dj
+                        v16f d;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float4 bb = ldg4(img + nf7_img_B1(WP) + m * 32 + g * 16 + 4 * q);
+                            d[4 * q + 0] = bb.x; d[4 * q + 1] = bb.y; d[4 * q + 2] = bb.z; d[4 * q + 3] = bb.w;
+                        }
+#pragma unroll
+                        for (int grp = 0; grp < 3; ++grp) {
+                            const float4 aw = ldg4(img + nf7_img_A1(WP) + ((m * 3 + grp) * 64 + lane) * 4);
+                            const float as[4] = {aw.x, aw.y, aw.z, aw.w};
+#pragma unroll
+                            for (int s = 0; s < 4; ++s) {
+                                const int tap = grp * 4 + s;
+                                if (tap < 9) d = __builtin_amdgcn_mfma_f32_32x32x2f32(as[s], zb[(tap / 3) * Wp + tap % 3], d, 0, 0, 0);
+                            }
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            *reinterpret_cast<float4 *>(h1 + ((((m * 4 + q) * 2 + g) * NB) + 32 * nt + n) * 4) =
+                                make_float4(nf_relu(d[4 * q + 0]), nf_relu(d[4 * q + 1]), nf_relu(d[4 * q + 2]), nf_relu(d[4 * q + 3]));
+                    }
+                    __syncthreads();
+
+                    // ---- l_2: 2 x 2 accumulator tiles per wavefront over the whole K; weights streamed from L2 ----
+                    v16f acc[2][2];
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float4 bb = ldg4(img + nf7_img_B2(WP) + (2 * wm + mi) * 32 + g * 16 + 4 * q);
+#pragma unroll
+                            for (int ni = 0; ni < 2; ++ni) {
+                                acc[mi][ni][4 * q + 0] = bb.x; acc[mi][ni][4 * q + 1] = bb.y;
+                                acc[mi][ni][4 * q + 2] = bb.z; acc[mi][ni][4 * q + 3] = bb.w;
+                            }
+                        }
+                    }
+                    {
+                        const float *ap0 = img + nf7_img_A2(WP) + ((size_t)(2 * wm + 0) * KC * 64 + lane) * 4;
+                        const float *ap1 = img + nf7_img_A2(WP) + ((size_t)(2 * wm + 1) * KC * 64 + lane) * 4;
+                        const float *bp0 = h1 + (g * NB + 32 * (2 * wn + 0) + n) * 4;
+                        const float *bp1 = h1 + (g * NB + 32 * (2 * wn + 1) + n) * 4;
+                        float4 a0 = ldg4(ap0), a1 = ldg4(ap1);
+                        float4 b0 = *reinterpret_cast<const float4 *>(bp0), b1 = *reinterpret_cast<const float4 *>(bp1);
+#pragma unroll 2
+                        for (int kc = 0; kc < KC; ++kc) {
+                            const int kn = kc + 1 < KC ? kc + 1 : kc;
+                            const float4 na0 = ldg4(ap0 + (size_t)kn * 256), na1 = ldg4(ap1 + (size_t)kn * 256);
+                            const float4 nb0 = *reinterpret_cast<const float4 *>(bp0 + (size_t)kn * 2 * NB * 4);
+                            const float4 nb1 = *reinterpret_cast<const float4 *>(bp1 + (size_t)kn * 2 * NB * 4);
+                            const float as0[4] = {a0.x, a0.y, a0.z, a0.w}, as1[4] = {a1.x, a1.y, a1.z, a1.w};
+                            const float bs0[4] = {b0.x, b0.y, b0.z, b0.w}, bs1[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                            for (int s = 0; s < 4; ++s) {
+                                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(as0[s], bs0[s], acc[0][0], 0, 0, 0);
+                                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(as0[s], bs1[s], acc[0][1], 0, 0, 0);
+                                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(as1[s], bs0[s], acc[1][0], 0, 0, 0);
+                                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(as1[s], bs1[s], acc[1][1], 0, 0, 0);
+                            }
+                            a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+                        }
+                    }
+                    // ---- P = W3^T relu(h2): this wavefront's 64 channels, both P tiles (36 of 64 rows used) ----
+                    v16f pa[2][2];
+#pragma unroll
+                    for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                            for (int v = 0; v < 16; ++v) pa[pt][ni][v] = 0.0f;
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+                        for (int grp = 0; grp < 4; ++grp) {
+                            const float4 w0 = ldg4(img + nf7_img_A3(WP) + ((((0 * MT + 2 * wm + mi) * 4 + grp) * 64) + lane) * 4);
+                            const float4 w1 = ldg4(img + nf7_img_A3(WP) + ((((1 * MT + 2 * wm + mi) * 4 + grp) * 64) + lane) * 4);
+                            const float ws0[4] = {w0.x, w0.y, w0.z, w0.w}, ws1[4] = {w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+                            for (int s = 0; s < 4; ++s) {
+                                const float hA = nf_relu(acc[mi][0][grp * 4 + s]), hB = nf_relu(acc[mi][1][grp * 4 + s]);
+                                pa[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws0[s], hA, pa[0][0], 0, 0, 0);
+                                pa[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws0[s], hB, pa[0][1], 0, 0, 0);
+                                pa[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws1[s], hA, pa[1][0], 0, 0, 0);
+                                pa[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws1[s], hB, pa[1][1], 0, 0, 0);
+                            }
+                        }
+                    }
+                    __syncthreads();   // every wavefront is done with h1: the region becomes the partial P tiles
+
+                    // rows 4 tap + j of P: register group a of lane half g of tile pt holds tap 8 pt + 2 a + g (j = 0..3)
+                    float *const pp = h1;   // [WM][NB][36]
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) {
+                        float *dst = pp + ((size_t)(wm * NB + 32 * (2 * wn + ni) + n)) * 36;
+#pragma unroll
+                        for (int aa = 0; aa < 4; ++aa)
+                            *reinterpret_cast<float4 *>(dst + (2 * aa + g) * 4) =
+                                make_float4(pa[0][ni][4 * aa + 0], pa[0][ni][4 * aa + 1], pa[0][ni][4 * aa + 2], pa[0][ni][4 * aa + 3]);
+                        if (g == 0)
+                            *reinterpret_cast<float4 *>(dst + 8 * 4) = make_float4(pa[1][ni][0], pa[1][ni][1], pa[1][ni][2], pa[1][ni][3]);
+                    }
+                    __syncthreads();
+
+                    // ---- gather: the taps of this band's pixels that fall on the output pixels this thread owns ----
+#pragma unroll
+                    for (int m = 0; m < OWN; ++m) {
+                        const int q = t + GT * m;
+                        if (!act[m] || q + W + 1 < p0 || q >= p0 + NB + W + 1) continue;
+#pragma unroll
+                        for (int di = 0; di < 3; ++di) {
+                            const int rr = pr[m] + di - 1;
+                            if (rr < 0 || rr >= H) continue;
+#pragma unroll
+                            for (int dj = 0; dj < 3; ++dj) {
+                                const int cc = pc[m] + dj - 1;
+                                const int src = rr * W + cc - p0;
+                                if (cc < 0 || cc >= W || src < 0 || src >= NB) continue;
+#pragma unroll
+                                for (int k = 0; k < WM; ++k) {
+                                    const float4 v = *reinterpret_cast<const float4 *>(pp + ((size_t)(k * NB + src)) * 36 + (di * 3 + dj) * 4);
+                                    o[m][0] += v.x; o[m][1] += v.y; o[m][2] += v.z; o[m][3] += v.w;
+                                }
+                            }
+                        }
+                    }
+                    __syncthreads();   // the next band's l_1 overwrites the region
+                }
+
+                // ---- finish the coupling on the owned pixels ----
+                const float scl = P[NF7_CPL_S + 1], m2scl = P[NF7_CPL_S + 2];
+#pragma unroll
+                for (int m = 0; m < OWN; ++m) {
+                    const int r = pr[m], c = pc[m];
+                    const int bm = (r == 0 ? 1 : 0) | (r == H - 1 ? 2 : 0) | (c == 0 ? 4 : 0) | (c == W - 1 ? 8 : 0);
+                    const float4 eb = *reinterpret_cast<const float4 *>(a.params + prog.ops[op].off + NF7_CPL_E + 4 * (act[m] ? bm : 0));
+                    o[m][0] += eb.x; o[m][1] += eb.y; o[m][2] += eb.z; o[m][3] += eb.w;
+                    // raw columns are pre-scaled by 2 log2(e):  t = exp2(raw') = exp(2 raw);
+                    // ls*log2(e) = scl*tanh(raw) = scl - 2 scl/(t + 1); log-det accumulated in log2 units
+                    const float l0 = fmaf(__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(o[m][2]) + 1.0f), m2scl, scl);
+                    const float l1 = fmaf(__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(o[m][3]) + 1.0f), m2scl, scl);
+                    if (type == NF_OP_COUPLING_FWD) {
+                        z[m][2] = fmaf(z[m][2], __builtin_amdgcn_exp2f(l0), o[m][0]);
+                        z[m][3] = fmaf(z[m][3], __builtin_amdgcn_exp2f(l1), o[m][1]);
+                        if (act[m]) ld2 += l0 + l1;
+                    } else {
+                        z[m][2] = (z[m][2] - o[m][0]) * __builtin_amdgcn_exp2f(-l0);
+                        z[m][3] = (z[m][3] - o[m][1]) * __builtin_amdgcn_exp2f(-l1);
+                    }
+                }
+            } else if (type == NF_OP_SDN_DIV || type == NF_OP_SDN_MUL) {
+                // AffineCouplingSdnEx5: scale = sqrt(beta1*y/gain + beta2)  (cond_utils.py:238)
+                const float4 *y4 = reinterpret_cast<const float4 *>(a.y + patch_off);
+                const float ck1 = a.cond_a[prog.ops[op].off & 3], cb2 = a.cond_b[prog.ops[op].off & 3];
+#pragma unroll
+                for (int m = 0; m < OWN; ++m) {
+                    float4 yv = make_float4(1.f, 1.f, 1.f, 1.f);
+                    if (act[m]) yv = y4[t + GT * m];
+                    const float yy[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float v = fmaf(yy[q], ck1, cb2);
+                        if (type == NF_OP_SDN_DIV) {
+                            z[m][q] = z[m][q] * __builtin_amdgcn_rsqf(v);
+                            if (act[m]) ld = fmaf(-0.34657359027997264f, __builtin_amdgcn_logf(v), ld);
+                        } else {
+                            z[m][q] = z[m][q] * __builtin_amdgcn_sqrtf(v);
+                        }
+                    }
+                }
+            } else if (type == NF_OP_SCALE || type == NF_OP_SCALE_COND) {
+                const float s = type == NF_OP_SCALE ? P[0] : a.cond_a[prog.ops[op].off & 3];
+#pragma unroll
+                for (int m = 0; m < OWN; ++m)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) z[m][q] *= s;
+            }
+        }
+
+        // ---- epilogue (as nf_flow_kernel) ----
+        if (a.out) {
+            float4 *out4 = reinterpret_cast<float4 *>(a.out + patch_off);
+#pragma unroll
+            for (int m = 0; m < OWN; ++m)
+                if (act[m]) out4[t + GT * m] = make_float4(z[m][0], z[m][1], z[m][2], z[m][3]);
+        }
+        if (a.nll_out || a.sd_out || a.ld_out || a.sums) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int m = 0; m < OWN; ++m)
+                if (act[m]) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        s1 += z[m][q];
+                        s2 = fmaf(z[m][q], z[m][q], s2);
+                    }
+                }
+            float r0 = wave_sum(fmaf(ld2, 0.6931471805599453f, ld)), r1 = wave_sum(s1), r2 = wave_sum(s2);
+            if (lane == 0) {
+                red[wv] = r0;
+                red[GW + wv] = r1;
+                red[2 * GW + wv] = r2;
+            }
+            __syncthreads();
+            if (t == 0) {
+                r0 = 0.f; r1 = 0.f; r2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < GW; ++i) {
+                    r0 += red[i];
+                    r1 += red[GW + i];
+                    r2 += red[2 * GW + i];
+                }
+                const double npx = (double)HW * 4.0;
+                const double logdet = (double)r0 + a.ld_const;
+                double nll = -logdet;   // prior: sum -0.5*(log 2pi + z^2)   (noise_flow_model.py:537-539)
+                if (a.flags & NF_K_PRIOR) nll += 0.5 * npx * 1.8378770664093453 + 0.5 * (double)r2;
+                const double mean = (double)r1 / npx;
+                double var = (double)r2 / npx - mean * mean;   // noise_flow_model.py:477-478
+                var = var > 0.0 ? var : 0.0;
+                const double sd = sqrt(var);
+                if (a.nll_out) a.nll_out[b] = (float)nll;
+                if (a.sd_out) a.sd_out[b] = (float)sd;
+                if (a.ld_out) a.ld_out[b] = (float)logdet;
+                acc_nll += (double)(float)nll;
+                acc_sd += (double)(float)sd;
+            }
+            __syncthreads();   // scratch is reused by the next patch
+        }
+    }
+
+    if (a.sums && t == 0) {
+        double *sp = a.sums;
+        if (a.flags & NF_K_SUMS_WIDE) sp += (size_t)(blockIdx.x & (NF_SUMS_SLOTS - 1)) * NF_SUMS_STRIDE;
+        atomicAdd(&sp[0], acc_nll);
+        atomicAdd(&sp[1], acc_sd);
+        if (blockIdx.x == 0) atomicAdd(&sp[2], (double)a.B);
+    }
+}
+
+size_t gemm_lds_bytes(int H, int W)
+{
+    const int Wp = W + 2, PL = ((H + 2) * Wp + 3) & ~3;
+    return ((size_t)NF7_BAND_FLOATS + 2 * (size_t)PL + 3 * GW + 8) * sizeof(float);
+}
+
+template <int WP, bool PHILOX, int OWN>
+hipError_t launch_gemm(const NfProgram &prog, const NfLaunch &a, int n_cu, int device, hipStream_t stream)
+{
+    const size_t lds = gemm_lds_bytes(a.H, a.W);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    const void *fn = reinterpret_cast<const void *>(&nf_gemm_kernel<WP, PHILOX, OWN>);
+    // largest dynamic-LDS size this instantiation was enabled for, per device (racy but idempotent)
+    static std::atomic<size_t> lds_set[16];
+    std::atomic<size_t> &cur = lds_set[device & 15];
+    if (lds > cur.load(std::memory_order_relaxed) || device > 15) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        cur.store(lds, std::memory_order_relaxed);
+    }
+    int64_t groups = n_cu;   // one 512-thread workgroup with > 128 KiB of LDS per CU
+    if (a.B < groups) groups = a.B;
+    if (groups < 1) groups = 1;
+    hipLaunchKernelGGL((nf_gemm_kernel<WP, PHILOX, OWN>), dim3((unsigned)groups), dim3(GT), lds, stream, prog, a);
+    return hipGetLastError();
+}
+
+template <int WP, bool PHILOX>
+hipError_t dispatch_own(const NfProgram &prog, const NfLaunch &a, int n_cu, int device, hipStream_t stream)
+{
+    if (a.H * a.W <= 2 * GT) return launch_gemm<WP, PHILOX, 2>(prog, a, n_cu, device, stream);
+    return launch_gemm<WP, PHILOX, 4>(prog, a, n_cu, device, stream);
+}
+
+template <bool PHILOX>
+hipError_t dispatch_gemm(const NfProgram &prog, const NfLaunch &a, int n_cu, int device, hipStream_t stream)
+{
+    switch (prog.width) {
+    case 64: return dispatch_own<64, PHILOX>(prog, a, n_cu, device, stream);
+    case 128: return dispatch_own<128, PHILOX>(prog, a, n_cu, device, stream);
+    case 256: return dispatch_own<256, PHILOX>(prog, a, n_cu, device, stream);
+    case 512: return dispatch_own<512, PHILOX>(prog, a, n_cu, device, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace
+
+// whether a patch shape fits the GEMM kernel (nf_create asks before accepting a width > 32)
+bool nf_gemm_shape_ok(int H, int W)
+{
+    return H >= 1 && W >= 1 && H * W <= NF7_MAX_PIXELS && gemm_lds_bytes(H, W) <= 160 * 1024;
+}
+
+// entry point used by nf_host.hip: programs in the NF7 layout (coupling width padded to 64 / 128 / 256 / 512)
+hipError_t nf_launch_gemm(const NfProgram &prog, const NfLaunch &a, int n_cu, int device, hipStream_t stream)
+{
+    if (!nf_gemm_shape_ok(a.H, a.W)) return hipErrorInvalidValue;
+    if (a.flags & NF_K_PHILOX_IN) return dispatch_gemm<true>(prog, a, n_cu, device, stream);
+    return dispatch_gemm<false>(prog, a, n_cu, device, stream);
+}

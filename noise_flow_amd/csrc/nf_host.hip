@@ -25,6 +25,8 @@
 hipError_t nf_launch_flow(const NfProgram &prog, const NfLaunch &a, int n_cu, hipStream_t stream, bool matrix_core);
 hipError_t nf_launch_wide(const NfProgram &prog, const NfLaunch &a, int n_cu, int device, hipStream_t stream);
 hipError_t nf_launch_wide16(const NfProgram &prog, const NfLaunch &a, int n_cu, int device, hipStream_t stream);
+hipError_t nf_launch_gemm(const NfProgram &prog, const NfLaunch &a, int n_cu, int device, hipStream_t stream);
+bool nf_gemm_shape_ok(int H, int W);
 hipError_t nf_launch_synth(uint64_t seed, int64_t patch_base, int64_t B, int HW, float beta1, float beta2,
                            float *y_out, float *x_out, hipStream_t stream);
 hipError_t nf_launch_sums_reduce(const double *wide, double *out3, bool accumulate, hipStream_t stream);
@@ -382,6 +384,60 @@ void relayout_coupling_wide32(const float *v1, int w, float *out)
             }
 }
 
+// GEMM re-layout (nf_device.h, NF7_*; widths 33 .. 512 zero-padded to wp = 64 / 128 / 256 / 512): every weight in the order the
+// wavefront that consumes it fetches it from L2 (nf_gemm.hip).
+void relayout_coupling_gemm(const float *v1, int w, int wp, float *out)
+{
+    const double k2 = 2.0 * 1.4426950408889634, log2e = 1.4426950408889634;
+    const int MT = wp / 32, KC = wp / 8;
+    for (int m = 0; m < 16; ++m)
+        for (int j = 0; j < 4; ++j) {
+            const double e = v1[nf_cpl_off_E(w) + 4 * m + j];
+            out[NF7_CPL_E + 4 * m + j] = (float)(j >= 2 ? e * k2 : e);   // raw columns feed exp2() directly
+        }
+    const double sc = v1[nf_cpl_off_S(w)];
+    out[NF7_CPL_S + 0] = (float)sc;
+    out[NF7_CPL_S + 1] = (float)(sc * log2e);
+    out[NF7_CPL_S + 2] = (float)(-2.0 * sc * log2e);
+    out[NF7_CPL_S + 3] = 0.0f;
+    float *img = out + NF7_CPL_IMG;
+    const float *W1 = v1 + nf_cpl_off_W1(w), *B1 = v1 + nf_cpl_off_B1(w), *W2 = v1 + nf_cpl_off_W2(w);
+    const float *B2 = v1 + nf_cpl_off_B2(w), *W3 = v1 + nf_cpl_off_W3(w);
+    for (int m = 0; m < MT; ++m) {
+        for (int step = 0; step < 12; ++step)          // l_1: step = tap, K slice = input channel
+            for (int l = 0; l < 64; ++l) {
+                const int oc = 32 * m + (l & 31);
+                img[nf7_img_A1(wp) + ((m * 3 + (step >> 2)) * 64 + l) * 4 + (step & 3)] =
+                    (step < 9 && oc < w) ? W1[(step * 2 + (l >> 5)) * w + oc] : 0.0f;
+            }
+        for (int g = 0; g < 2; ++g)
+            for (int v = 0; v < 16; ++v) {
+                const int ch = 32 * m + nf4_chan(v, g);
+                img[nf7_img_B1(wp) + m * 32 + g * 16 + v] = ch < w ? B1[ch] : 0.0f;
+                img[nf7_img_B2(wp) + m * 32 + g * 16 + v] = ch < w ? B2[ch] : 0.0f;
+            }
+        for (int kc = 0; kc < KC; ++kc)                // l_2: K step kk = 4 kc + s consumes input tile kk / 16, register kk % 16
+            for (int l = 0; l < 64; ++l)
+                for (int s2 = 0; s2 < 4; ++s2) {
+                    const int kk = 4 * kc + s2, cin = 32 * (kk / 16) + nf4_chan(kk % 16, l >> 5), oc = 32 * m + (l & 31);
+                    img[nf7_img_A2(wp) + (((size_t)m * KC + kc) * 64 + l) * 4 + s2] = (cin < w && oc < w) ? W2[(size_t)cin * w + oc] : 0.0f;
+                }
+    }
+    for (int pt = 0; pt < 2; ++pt)                     // P = W3^T h2: row 32 pt + i = 4 tap + j
+        for (int mi = 0; mi < MT; ++mi)
+            for (int v = 0; v < 16; ++v)
+                for (int l = 0; l < 64; ++l) {
+                    const int row = 32 * pt + (l & 31), cin = 32 * mi + nf4_chan(v, l >> 5);
+                    double wv = 0.0;
+                    if (row < 36 && cin < w) {
+                        const int tap = row >> 2, j = row & 3;
+                        wv = W3[((size_t)tap * w + cin) * 4 + j];
+                        if (j >= 2) wv *= k2;
+                    }
+                    img[nf7_img_A3(wp) + ((((size_t)pt * MT + mi) * 4 + (v >> 2)) * 64 + l) * 4 + (v & 3)] = (float)wv;
+                }
+}
+
 // Width-16 re-layout (nf_device.h, NF6_*; `w` = 16, or 8 zero-padded): fetch order of v_mfma_f32_16x16x4_f32.
 void relayout_coupling_wide16(const float *v1, int w, float *out)
 {
@@ -619,6 +675,8 @@ struct Built {
     std::vector<float> block5;
     NfProgram prog6;             // width-16 layout (NF6_*)
     std::vector<float> block6;
+    NfProgram prog7;             // GEMM layout (NF7_*): widths 33 .. 512, zero-padded to 64 / 128 / 256 / 512
+    std::vector<float> block7;
     double ld_const = 0.0;
     bool has_sdn = false;      // some op reads the clean image y
 };
@@ -681,8 +739,13 @@ int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float
             it.type = NF_OP_MIX;
             break;
         case NF_LAYER_COUPLING: {
-            if (L.width != 4 && L.width != 8 && L.width != 16 && L.width != 32)
-                return fail(NF_EINVAL, "layer %d: coupling width %d unsupported (4, 8, 16, 32)", li, L.width);
+            if (L.width != 4 && L.width != 8 && L.width != 16 && !(L.width >= 32 && L.width <= 512))
+                return fail(NF_EINVAL, "layer %d: coupling width %d unsupported (4, 8, 16, 32 .. 512)", li, L.width);
+            if (L.width > 32 && (cfg->flags & NF_CFG_FP16_CNN))
+                return fail(NF_EINVAL, "layer %d: NF_CFG_FP16_CNN covers coupling widths 4 / 8 / 16 / 32 (width %d runs exact fp32)", li, L.width);
+            if (L.width > 32 && !nf_gemm_shape_ok(cfg->height, cfg->width))
+                return fail(NF_EINVAL, "layer %d: coupling width %d covers patches of up to %d pixels (%dx%d given)", li, L.width,
+                            NF7_MAX_PIXELS, cfg->height, cfg->width);
             if (width && width != L.width) return fail(NF_EINVAL, "all coupling layers must share one width");
             width = L.width;
             it.type = NF_OP_COUPLING_FWD;
@@ -862,6 +925,30 @@ int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float
         }
         if (out.block6.empty()) out.block6.assign(4, 0.0f);
     }
+    out.block7.clear();
+    memset(&out.prog7, 0, sizeof(out.prog7));
+    if (out.prog.width > 32) {
+        const int wp = nf7_pad_width(out.prog.width);
+        out.prog7.width = wp;
+        for (int i = 0; i < out.prog.n_ops; ++i) {
+            const NfOp &src = out.prog.ops[i];
+            NfOp &dst = out.prog7.ops[out.prog7.n_ops++];
+            dst.type = src.type;
+            dst.off = (int32_t)out.block7.size();
+            const float *v1 = out.block.data() + src.off;
+            if (src.type == NF_OP_MIX) {
+                out.block7.insert(out.block7.end(), v1, v1 + 16);
+            } else if (src.type == NF_OP_COUPLING_FWD || src.type == NF_OP_COUPLING_REV) {
+                out.block7.resize(out.block7.size() + nf7_cpl_size(wp));
+                relayout_coupling_gemm(v1, out.prog.width, wp, out.block7.data() + dst.off);
+            } else if (src.type == NF_OP_SCALE) {
+                out.block7.insert(out.block7.end(), v1, v1 + 4);
+            } else {
+                dst.off = src.off;   // conditioning slot
+            }
+        }
+        if (out.block7.empty()) out.block7.assign(4, 0.0f);
+    }
     out.block5.clear();
     memset(&out.prog5, 0, sizeof(out.prog5));
     if ((cfg->flags & NF_CFG_FP16_CNN) && (out.prog.width == 8 || out.prog.width == 16 || out.prog.width == 32)) {
@@ -977,6 +1064,9 @@ struct nf_handle {
     float *d_rev5 = nullptr;
     float *d_fwd6 = nullptr;   // width-16 layout
     float *d_rev6 = nullptr;
+    float *d_fwd7 = nullptr;   // GEMM layout (widths 33 .. 512)
+    float *d_rev7 = nullptr;
+    bool scalar_ok = true;     // the scalar-weight kernel's LDS tiles fit this patch shape / width
     // batch-statistics mode (nf_*_batchstats): the raw model and a lazily allocated scratch
     std::vector<nf_layer_desc> layers;
     std::vector<float> raw;
@@ -1019,6 +1109,44 @@ int nf_fold_params(const nf_config *cfg, const nf_layer_desc *layers, const floa
     return NF_OK;
 }
 
+int nf_fold_layout(const nf_config *cfg, const nf_layer_desc *layers, const float *params, size_t n_params, int32_t direction,
+                   int32_t path, int32_t *ops_out, int32_t ops_cap, int32_t *n_ops, int32_t *layout_width, float *folded,
+                   size_t folded_cap, size_t *n_folded)
+{
+    if (direction != 0 && direction != 1) return fail(NF_EINVAL, "direction must be 0 or 1");
+    Built b;
+    int rc = build_program(cfg, layers, params, n_params, direction, b);
+    if (rc != NF_OK) return rc;
+    const NfProgram *pg = nullptr;
+    const std::vector<float> *blk = nullptr;
+    switch (path) {
+    case NF_PATH_SCALAR: pg = &b.prog; blk = &b.block; break;
+    case NF_PATH_MFMA4: pg = &b.prog2; blk = &b.block2; break;
+    case NF_PATH_FP16: pg = &b.prog3; blk = &b.block3; break;
+    case NF_PATH_WIDE32: pg = &b.prog4; blk = &b.block4; break;
+    case NF_PATH_WIDE32_FP16: pg = &b.prog5; blk = &b.block5; break;
+    case NF_PATH_WIDE16: pg = &b.prog6; blk = &b.block6; break;
+    case NF_PATH_GEMM: pg = &b.prog7; blk = &b.block7; break;
+    default: return fail(NF_EINVAL, "unknown kernel path %d", path);
+    }
+    if (blk->empty()) return fail(NF_EINVAL, "this model has no parameter block for kernel path %d", path);
+    if (n_ops) *n_ops = pg->n_ops;
+    if (layout_width) *layout_width = pg->width;
+    if (n_folded) *n_folded = blk->size();
+    if (ops_out) {
+        if (ops_cap < pg->n_ops) return fail(NF_EINVAL, "ops_cap too small");
+        for (int i = 0; i < pg->n_ops; ++i) {
+            ops_out[2 * i] = pg->ops[i].type;
+            ops_out[2 * i + 1] = pg->ops[i].off;
+        }
+    }
+    if (folded) {
+        if (folded_cap < blk->size()) return fail(NF_EINVAL, "folded_cap too small");
+        memcpy(folded, blk->data(), blk->size() * sizeof(float));
+    }
+    return NF_OK;
+}
+
 int nf_sdn5_scalars(const float *sdn_params, const nf_cond *cond, double out[2])
 {
     if (!sdn_params || !out) return fail(NF_EINVAL, "null argument");
@@ -1043,7 +1171,9 @@ int nf_create(const nf_config *cfg, const nf_layer_desc *layers, const float *pa
     {   // the two LDS tiles of the scalar-weight kernel must fit one CU (160 KiB)
         const size_t tile_px = ((size_t)(cfg->height + 2) * (cfg->width + 2) + 1) & ~(size_t)1;
         const size_t lds = sizeof(float) * (tile_px * (2 + (size_t)h->fwd.prog.width) + 64);
-        if (lds > 160 * 1024 && h->fwd.block2.empty() && h->fwd.block4.empty() && h->fwd.block5.empty() && h->fwd.block6.empty()) {
+        h->scalar_ok = lds <= 160 * 1024 && h->fwd.prog.width <= 32;
+        if (lds > 160 * 1024 && h->fwd.block2.empty() && h->fwd.block4.empty() && h->fwd.block5.empty() && h->fwd.block6.empty() &&
+            h->fwd.block7.empty()) {
             const int w = h->fwd.prog.width;
             delete h;
             return fail(NF_EINVAL, "a %dx%d patch with coupling width %d needs %zu KiB of LDS (> 160): unsupported",
@@ -1089,12 +1219,13 @@ int nf_create(const nf_config *cfg, const nf_layer_desc *layers, const float *pa
             return fail(NF_EINVAL, "NF_CFG_FP16_CNN needs coupling width 4 with full 32x32 or 64x64 patches, or width 8 / 16 / 32");
         }
     }
-    for (int d = 0; d < 10; ++d) {
+    for (int d = 0; d < 12; ++d) {
         const std::vector<float> &b2 = d == 0 ? h->fwd.block2 : d == 1 ? h->rev.block2 : d == 2 ? h->fwd.block3 : d == 3 ? h->rev.block3
                                        : d == 4 ? h->fwd.block4 : d == 5 ? h->rev.block4 : d == 6 ? h->fwd.block5 : d == 7 ? h->rev.block5
-                                       : d == 8 ? h->fwd.block6 : h->rev.block6;
+                                       : d == 8 ? h->fwd.block6 : d == 9 ? h->rev.block6 : d == 10 ? h->fwd.block7 : h->rev.block7;
         float **dst = d == 0 ? &h->d_fwd2 : d == 1 ? &h->d_rev2 : d == 2 ? &h->d_fwd3 : d == 3 ? &h->d_rev3 : d == 4 ? &h->d_fwd4
-                      : d == 5 ? &h->d_rev4 : d == 6 ? &h->d_fwd5 : d == 7 ? &h->d_rev5 : d == 8 ? &h->d_fwd6 : &h->d_rev6;
+                      : d == 5 ? &h->d_rev4 : d == 6 ? &h->d_fwd5 : d == 7 ? &h->d_rev5 : d == 8 ? &h->d_fwd6 : d == 9 ? &h->d_rev6
+                      : d == 10 ? &h->d_fwd7 : &h->d_rev7;
         if (b2.empty()) continue;
         if ((e = hipMalloc((void **)dst, b2.size() * sizeof(float))) != hipSuccess ||
             (e = hipMemcpy(*dst, b2.data(), b2.size() * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) {
@@ -1123,6 +1254,8 @@ int nf_destroy(nf_handle *h)
     if (h->d_rev5) (void)hipFree(h->d_rev5);
     if (h->d_fwd6) (void)hipFree(h->d_fwd6);
     if (h->d_rev6) (void)hipFree(h->d_rev6);
+    if (h->d_fwd7) (void)hipFree(h->d_fwd7);
+    if (h->d_rev7) (void)hipFree(h->d_rev7);
     nf_bs_destroy(h->bs);
     delete h;
     return NF_OK;
@@ -1227,15 +1360,25 @@ static int launch_resident(nf_handle *h, int direction, NfLaunch &a, hipStream_t
         if (e != hipSuccess) return fail_hip(e, what);
         return NF_OK;
     }
+    float *d7 = direction == 0 ? h->d_fwd7 : h->d_rev7;
+    if (d7) {   // widths 33 .. 512: LDS-staged GEMMs on v_mfma_f32_32x32x2_f32 (nf_gemm.hip); no other kernel holds these widths
+        a.params = d7;
+        a.n_params = (int32_t)b.block7.size();
+        hipError_t e = nf_launch_gemm(b.prog7, a, h->n_cu, h->device, st);
+        if (e != hipSuccess) return fail_hip(e, what);
+        return NF_OK;
+    }
+    // NF_KERNEL=valu (A/B aid) selects the scalar-weight kernel only where that kernel can hold the patch
+    const bool mcore = use_matrix_core() || !h->scalar_ok;
     float *d6 = direction == 0 ? h->d_fwd6 : h->d_rev6;
-    if (d6 && use_matrix_core()) {   // width 16: v_mfma_f32_16x16x4_f32 (nf_wide16.hip)
+    if (d6 && mcore) {   // width 16: v_mfma_f32_16x16x4_f32 (nf_wide16.hip)
         a.params = d6;
         a.n_params = (int32_t)b.block6.size();
         hipError_t e = nf_launch_wide16(b.prog6, a, h->n_cu, h->device, st);
         if (e != hipSuccess) return fail_hip(e, what);
         return NF_OK;
     }
-    if (d4 && use_matrix_core()) {   // width 32: the three convs on v_mfma_f32_32x32x2_f32 (nf_wide.hip)
+    if (d4 && mcore) {   // width 32: the three convs on v_mfma_f32_32x32x2_f32 (nf_wide.hip)
         a.params = d4;
         a.n_params = (int32_t)b.block4.size();
         hipError_t e = nf_launch_wide(b.prog4, a, h->n_cu, h->device, st);
@@ -1261,8 +1404,10 @@ int nf_kernel_path(const nf_handle *h, int32_t direction)
 {
     if (!h || (direction != 0 && direction != 1)) return fail(NF_EINVAL, "bad argument");
     if (direction == 0 ? h->d_fwd5 : h->d_rev5) return NF_PATH_WIDE32_FP16;
-    if ((direction == 0 ? h->d_fwd6 : h->d_rev6) && use_matrix_core()) return NF_PATH_WIDE16;
-    if ((direction == 0 ? h->d_fwd4 : h->d_rev4) && use_matrix_core()) return NF_PATH_WIDE32;
+    if (direction == 0 ? h->d_fwd7 : h->d_rev7) return NF_PATH_GEMM;
+    const bool mcore = use_matrix_core() || !h->scalar_ok;
+    if ((direction == 0 ? h->d_fwd6 : h->d_rev6) && mcore) return NF_PATH_WIDE16;
+    if ((direction == 0 ? h->d_fwd4 : h->d_rev4) && mcore) return NF_PATH_WIDE32;
     if (direction == 0 ? h->d_fwd3 : h->d_rev3) return NF_PATH_FP16;
     if ((direction == 0 ? h->d_fwd2 : h->d_rev2) && use_matrix_core()) return NF_PATH_MFMA4;
     return NF_PATH_SCALAR;

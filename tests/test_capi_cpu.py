@@ -259,3 +259,116 @@ def test_other_permutation_settings_fold_like_the_oracle(flow_permutation, decom
         assert [L.name for L in params.parse_arch(arch, 0)] == ["permute", "unc_0", "permute", "unc_1", "gain_2", "permute", "unc_3"]
     with pytest.raises(ValueError):
         params.parse_arch(arch, 1, "QR")
+
+
+# ---------------------------------------------------------------------------------------------------------
+# GEMM layout (widths 33 .. 512, csrc/nf_gemm.hip): numpy emulation of the kernel's dataflow from the uploaded block
+# ---------------------------------------------------------------------------------------------------------
+def _fold_layout(arch, variables, width, direction, path, hw=(32, 32)):
+    from noise_flow_amd import _lib, params
+    lib = _lib.load()
+    layers, descs, flat = params.pack(arch, variables, width, "loss_first", 1, "LU")
+    cfg = _lib.nf_config(hw[0], hw[1], 4, len(layers), -1, 0)
+    ops = (C.c_int32 * 256)()
+    n_ops, lw, nf = C.c_int32(), C.c_int32(), C.c_size_t()
+    args = (C.byref(cfg), descs, flat.ctypes.data_as(C.POINTER(C.c_float)), flat.size, direction, path, ops, 128, C.byref(n_ops),
+            C.byref(lw))
+    _lib.check(lib.nf_fold_layout(*args, None, 0, C.byref(nf)))
+    folded = np.zeros(nf.value, np.float32)
+    _lib.check(lib.nf_fold_layout(*args, folded.ctypes.data_as(C.POINTER(C.c_float)), folded.size, C.byref(nf)))
+    return [(ops[2 * i], ops[2 * i + 1]) for i in range(n_ops.value)], folded, lw.value
+
+
+def _chan(v, g):
+    return 8 * (v >> 2) + 4 * g + (v & 3)
+
+
+def _mfma_32x32x2(A, B, D):
+    """v_mfma_f32_32x32x2_f32 as the kernels use it: A[lane] = A-matrix[i = lane & 31][k = lane >> 5], B[lane] =
+    B-matrix[k = lane >> 5][n = lane & 31]; D[v][lane] holds row c(v, lane >> 5), column lane & 31."""
+    Am = np.zeros((32, 2)); Bm = np.zeros((2, 32))
+    for l in range(64):
+        Am[l & 31, l >> 5] = A[l]
+        Bm[l >> 5, l & 31] = B[l]
+    Cm = Am @ Bm
+    out = D.copy()
+    for v in range(16):
+        for l in range(64):
+            out[v, l] += Cm[_chan(v, l >> 5), l & 31]
+    return out
+
+
+@pytest.mark.parametrize("width", [64, 96])
+def test_gemm_layout_emulated_lane_by_lane_matches_the_oracle_cnn(width):
+    """The NF7 block nf_create uploads at widths > 32, consumed exactly as csrc/nf_gemm.hip consumes it (tile / lane / register
+    indices, K-step order, the P rows of the transposed l_last, the 9-tap gather) in a numpy model of v_mfma_f32_32x32x2_f32 —
+    against the oracle's coupling CNN on a small patch.  Catches layout / indexing mistakes without a GPU."""
+    from noise_flow_amd import _lib
+    arch = "unc"
+    H, W = 5, 9            # 45 pixels: two pixel tiles, the second one ragged
+    v = trained_like_variables(arch, width, seed=width)
+    ops, blk, wp = _fold_layout(arch, v, width, 0, _lib.NF_PATH_GEMM, (H, W))
+    assert wp == (64 if width <= 64 else 128)
+    (t0, off0), (t1, off) = ops
+    assert (t0, t1) == (1, 2)
+    MT, KC = wp // 32, wp // 8
+    img = blk[off + 68:]
+    A1 = img[0:MT * 768].reshape(MT, 3, 64, 4)
+    B1 = img[MT * 768:MT * 800].reshape(MT, 2, 16)
+    B2 = img[MT * 800:MT * 832].reshape(MT, 2, 16)
+    A2 = img[MT * 832:MT * 832 + wp * wp].reshape(MT, KC, 64, 4)
+    A3 = img[MT * 832 + wp * wp:MT * 832 + wp * wp + 2 * MT * 1024].reshape(2, MT, 4, 64, 4)
+    E = blk[off:off + 64].reshape(16, 4)
+    rng = np.random.RandomState(1)
+    z0 = rng.randn(H, W, 2)
+    z0p = np.zeros((H + 2, W + 2, 2)); z0p[1:-1, 1:-1] = z0
+    HW = H * W
+    NTILES = (HW + 31) // 32
+    P = np.zeros((NTILES * 32, 36))
+    for nt in range(NTILES):
+        pix = [min(nt * 32 + n, HW - 1) for n in range(32)]
+        # l_1
+        h1 = np.zeros((MT, 16, 64))
+        for m in range(MT):
+            d = np.zeros((16, 64))
+            for l in range(64):
+                d[:, l] = B1[m, l >> 5]
+            for tap in range(9):
+                Bv = np.array([z0p[pix[l & 31] // W + tap // 3, pix[l & 31] % W + tap % 3, l >> 5] for l in range(64)])
+                d = _mfma_32x32x2(A1[m, tap >> 2, :, tap & 3], Bv, d)
+            h1[m] = np.maximum(d, 0)
+        # l_2: K step kk consumes register kk % 16 of input tile kk // 16
+        h2 = np.zeros((MT, 16, 64))
+        for m in range(MT):
+            d = np.zeros((16, 64))
+            for l in range(64):
+                d[:, l] = B2[m, l >> 5]
+            for kk in range(wp // 2):
+                d = _mfma_32x32x2(A2[m, kk >> 2, :, kk & 3], h1[kk // 16, kk % 16], d)
+            h2[m] = np.maximum(d, 0)
+        # P tiles
+        for pt in range(2):
+            d = np.zeros((16, 64))
+            for mi in range(MT):
+                for vv in range(16):
+                    d = _mfma_32x32x2(A3[pt, mi, vv >> 2, :, vv & 3], h2[mi, vv], d)
+            for vv in range(16):
+                for l in range(64):
+                    row = 32 * pt + _chan(vv, l >> 5)
+                    if row < 36:
+                        P[nt * 32 + (l & 31), row] = d[vv, l]
+    o = np.zeros((H, W, 4))
+    for r in range(H):
+        for c in range(W):
+            for di in range(3):
+                for dj in range(3):
+                    rr, cc = r + di - 1, c + dj - 1
+                    if 0 <= rr < H and 0 <= cc < W:
+                        o[r, c] += P[rr * W + cc, (di * 3 + dj) * 4:(di * 3 + dj) * 4 + 4]
+            bm = (r == 0) | (r == H - 1) << 1 | (c == 0) << 2 | (c == W - 1) << 3
+            o[r, c] += E[bm]
+    o[..., 2:] /= 2.0 * 1.4426950408889634          # raw columns are pre-scaled by 2 log2 e
+    cp = [L["p"] for L in O.bind_variables(arch, v) if L["type"] == "coupling"][0]
+    shift, raw = O.coupling_cnn(z0[None], cp)
+    ref = np.concatenate([shift[0], raw[0]], -1)
+    assert np.abs(o - ref).max() <= 2e-5 * np.abs(ref).max(), np.abs(o - ref).max() / np.abs(ref).max()
