@@ -647,7 +647,8 @@ def wide_flop_per_pixel(width: int, n_couplings: int = 8) -> float:
 
 
 def _wide_cnn(ctx, batches, cond, wide):
-    """Paper-scale coupling CNN (job_noise_flow.sh:19: width 32; also 16): same layer sequence, fresh wide CNN weights
+    """Paper-scale coupling CNN (job_noise_flow.sh:19: width 32; also 16) and Glow's default width 512 (sidd/ArgParser.py:43; also
+    128) on the GEMM kernel: same layer sequence, fresh wide CNN weights
     (no wide checkpoint ships), forward NLL at B = 1024, 32x32x4 — f32 matrix cores (v_mfma_f32_32x32x2_f32 at width 32,
     v_mfma_f32_16x16x4_f32 at width 16) and the fp16 CNN mode (v_mfma_f32_32x32x16_f16)."""
     import numpy as np
@@ -655,33 +656,36 @@ def _wide_cnn(ctx, batches, cond, wide):
     args, dev = ctx["args"], ctx["dev"]
     x, y = batches[0]
     out = {}
-    for w, dt in ((32, "fp32"), (16, "fp32"), (32, "fp16")):
+    for w, dt in ((32, "fp32"), (16, "fp32"), (32, "fp16"), (512, "fp32"), (128, "fp32")):
         hps = default_hps(width=w)
         var = _params.init_variables(hps.arch, w, 4, 1234)
         rng = np.random.RandomState(w)
         for k in list(var):                 # fresh init has a zero last layer: perturb so that every term is live
             if k.endswith("l_last/W") or k.endswith("l_last/b"):
-                var[k] = (0.02 * rng.randn(*var[k].shape)).astype(np.float32)
+                var[k] = (0.02 * rng.randn(*var[k].shape) * min(1.0, (32.0 / w) ** 0.5)).astype(np.float32)
         m = NoiseFlow([32, 32, 4], False, hps, variables=var, device=dev.index, cnn_dtype=dt)
-        kw = max(5, min(args.steps, 20))
-        ms, nll = _time_nll(m, x, y, cond, kw, dev)
-        flop = wide_flop_per_pixel(w) * 1024 * x.shape[0]
+        nb = x.shape[0] if w <= 32 else 512          # width 512 is 4.7 GFLOP per patch: 512 patches = 2 rounds of the 256 CUs
+        kw = max(5, min(args.steps, 20 if w <= 32 else 5))
+        ms, nll = _time_nll(m, x[:nb], y[:nb], cond, kw, dev)
+        flop = wide_flop_per_pixel(w) * 1024 * nb
         tfl = flop / (ms * 1e-3) / 1e12
         peak = VALU_PEAK_TFLOPS if dt == "fp32" else FP16_MFMA_PEAK_TFLOPS
         path = m._flow.lib.nf_kernel_path(m._flow.ptr, 0)
         out["w%d%s" % (w, "" if dt == "fp32" else "_fp16")] = {
-            "width": w, "cnn_dtype": dt, "batch": int(x.shape[0]), "steps": kw, "kernel_ms": ms,
-            "value": x.shape[0] / (ms * 1e-3), "unit": "patches/s", "finite": bool(np.isfinite(nll.cpu().numpy()).all()),
+            "width": w, "cnn_dtype": dt, "batch": int(nb), "steps": kw, "kernel_ms": ms,
+            "value": nb / (ms * 1e-3), "unit": "patches/s", "finite": bool(np.isfinite(nll.cpu().numpy()).all()),
             "kernel_path": {0: "scalar-weight VALU kernel", 3: "nf_wide32_kernel (v_mfma_f32_32x32x2_f32)",
                             4: "nf_wide16_kernel (v_mfma_f32_16x16x4_f32)",
-                            5: "nf_wide32_kernel (v_mfma_f32_32x32x16_f16)"}.get(path, str(path)),
+                            5: "nf_wide32_kernel (v_mfma_f32_32x32x16_f16)",
+                            6: "nf_gemm_kernel (v_mfma_f32_32x32x2_f32, LDS-staged GEMM, weights streamed from L2)"}.get(path, str(path)),
             "roofline": {"bound": "mfma", "achieved": tfl, "peak": peak, "unit": "TFLOP/s", "frac": tfl / peak,
                          "algorithmic_flop_per_launch": flop, "mac_per_pixel_per_coupling": 16 + 18 * w + w * w + 36 * (w + 1),
                          "dtype": "f32 in / f32 accumulate (exact fp32)" if dt == "fp32" else
                                   "f16 in / f32 accumulate for the three CNN convs; everything else fp32"}}
         del m
-    out["workload"] = ("forward NLL, 1024 synthetic 32x32x4 patches, arch %s with coupling-CNN width 32 / 16 (fresh wide CNN weights: "
-                       "no wide checkpoint ships); w32_fp16 = NF_CFG_FP16_CNN" % ARCH_LABEL)
+    out["workload"] = ("forward NLL, synthetic 32x32x4 patches (1024 at widths <= 32, 512 beyond), arch %s with coupling-CNN width 32 / 16 "
+                       "and, on the LDS-staged GEMM kernel, 512 (sidd/ArgParser.py:43 default) / 128 (fresh wide CNN weights: no wide "
+                       "checkpoint ships); w32_fp16 = NF_CFG_FP16_CNN" % ARCH_LABEL)
     return out
 
 

@@ -9,8 +9,8 @@ hot path, with the reference's call pattern and on-disk formats.
   minibatch dict, epoch NLL = mean over minibatches of the per-minibatch means
   (quirk Q12), sd_z likewise.
 * ``sample_epoch``  — ``sample_thread`` (reference ``train_noise_flow.py:139-184``):
-  fixed ISO 100 / camera S6, sample, marginal KL vs the real noise, NLL of the
-  sample.
+  fixed ISO 100 / camera S6, sample, NLL of the sample, and the reference's marginal-KL
+  recipe ``calc_kldiv_mb`` (``sidd/sidd_utils.py:995-1058``) → KLD_G / KLD_NLF / KLD_NF / KLD_R.
 
 * ``train_epoch`` / ``fit`` — ``train_multithread`` / ``train_thread`` and the epoch loop of
   ``main`` (reference ``train_noise_flow.py:27-77, 379-511``): one training step per minibatch
@@ -31,7 +31,6 @@ from typing import Iterable, List, Sequence
 
 import numpy as np
 
-from .metrics import kl_div_3_data, noise_bin_edges
 
 
 def _np(a) -> np.ndarray:
@@ -115,31 +114,36 @@ S6_NLF = {100: (0.000479, 0.000002), 400: (0.001774, 0.000002), 800: (0.003696, 
 
 
 def sample_epoch(nf, minibatches: Iterable[dict], temp: float = 1.0, fix_iso: float = 100.0, fix_cam: float = 2.0,
-                 n_threads: int = 1, kl_edges=None, seed=None):
-    """→ dict(NLL, sdz, KLD_NF, KLD_NLF, sample_time): sample with fixed ISO / camera,
-    marginal KL of the synthesised noise (and of a camera-NLF draw) against the real
-    noise of the minibatch, NLL of the sample under the model."""
+                 n_threads: int = 1, sc_sd: float = 1.0, vis_dir=None, seed=None):
+    """``sample_multithread`` / ``sample_thread`` (train_noise_flow.py:119-184) → dict(NLL, sdz, KLD_G, KLD_NLF, KLD_NF,
+    KLD_R, sample_time).  Per minibatch: sample with the camera / ISO FIXED to S6 / 100 (``is_fix``; the fed ``nlf1`` is the
+    reference's ``nlf_s6[..][0]``, quirk Q4 — inert for sdn5), NLL of the sample under the model, and the marginal-KL
+    recipe ``calc_kldiv_mb`` (every 5th patch, four noise models against the minibatch's real noise; ``sc_sd`` = the
+    training set's noise standard deviation, ``pat_stats['sc_in_sd']``).  The KL draws use the global numpy RNG, like the
+    reference; they are taken on the calling thread in minibatch order after the device work, so a seeded epoch is
+    reproducible for any ``n_threads`` (``seed``: seed that RNG first)."""
+    from .metrics import calc_kldiv_mb
     mbs = list(minibatches)
-    edges = noise_bin_edges() if kl_edges is None else kl_edges
-    nlf0, nlf1 = S6_NLF.get(int(fix_iso), S6_NLF[100])
-    rng = np.random.RandomState(0 if seed is None else seed)
+    nlf0 = S6_NLF.get(int(fix_iso), S6_NLF[100])[0]
+    nlf1 = nlf0                                                  # train_noise_flow.py:158-159 (index 0 twice)
     t0 = time.time()
 
     def one(mb):
         y = mb["_y"]
         xs = nf.sample(y, temp, y, [nlf0], [nlf1], [fix_iso], [fix_cam])
-        kl_nf = kl_div_3_data(_np(mb["_x"]).ravel(), _np(xs).ravel(), edges)[0]
         loss, sd_z = nf.loss(xs, y, [nlf0], [nlf1], [fix_iso], [fix_cam])
-        return kl_nf, float(loss), float(sd_z)
+        return _np(xs), float(loss), float(sd_z)
 
     res = _run_threads(one, mbs, n_threads)
-    kl_nlf = []
-    for mb in mbs:   # the camera-NLF baseline draw (host side, like kldiv_patch_set)
-        y = _np(mb["_y"]).astype(np.float64)
-        nl = np.sqrt(nlf0 * y + nlf1) * rng.standard_normal(y.shape)
-        kl_nlf.append(kl_div_3_data(_np(mb["_x"]).ravel(), nl.ravel(), edges)[0])
+    if seed is not None:
+        np.random.seed(seed)
+    kld = np.zeros(4)
+    for mb, r in zip(mbs, res):
+        host = dict(mb, _x=_np(mb["_x"]), _y=_np(mb["_y"]), pid=mb.get("pid", np.arange(len(r[0]))), fn=mb.get("fn", ""))
+        kld += calc_kldiv_mb(host, r[0], vis_dir, sc_sd)
+    kld /= max(len(mbs), 1)
     return {"NLL": float(np.mean([r[1] for r in res])), "sdz": float(np.mean([r[2] for r in res])),
-            "KLD_NF": float(np.mean([r[0] for r in res])), "KLD_NLF": float(np.mean(kl_nlf)),
+            "KLD_G": float(kld[0]), "KLD_NLF": float(kld[1]), "KLD_NF": float(kld[2]), "KLD_R": float(kld[3]),
             "sample_time": time.time() - t0}
 
 
@@ -165,7 +169,7 @@ def _is_eval_epoch(epoch: int, epochs_full_valid: int) -> bool:
 
 def fit(trainer, nf_eval, train_mbs: Sequence[dict], test_mbs: Sequence[dict], logdir: str, epochs: int, lr: float,
         epochs_full_valid: int = 10, nll_gauss: float = 0.0, nll_sdn: float = 0.0, do_sampling: bool = True,
-        start_epoch: int = 1, group=None, log=None, sync_bn: bool = False):
+        start_epoch: int = 1, group=None, log=None, sync_bn: bool = False, sc_sd: float = 1.0):
     """The epoch loop of ``train_noise_flow.py:379-511``: per epoch test (on the reference's
     schedule; saves ``ckpt/model.ckpt-<epoch>`` and ``ckpt/model.ckpt.best``), sampling, training;
     appends to ``train.txt`` / ``test.txt`` / ``sample.txt`` under ``logdir``.
@@ -196,11 +200,11 @@ def fit(trainer, nf_eval, train_mbs: Sequence[dict], test_mbs: Sequence[dict], l
                 trainer.save(ckpt_path + ".best")
             test_logger.log({"epoch": epoch, "NLL": nll, "NLL_G": nll_gauss, "NLL_SDN": nll_sdn, "sdz": sdz, "msg": is_best})
             if do_sampling:
-                sr = sample_epoch(nf_eval, test_mbs, temp=1.0)
+                sr = sample_epoch(nf_eval, test_mbs, temp=1.0, sc_sd=sc_sd)
                 res["sample"].append(sr["NLL"])
                 sample_logger.log({"epoch": epoch, "NLL": sr["NLL"], "NLL_G": nll_gauss, "NLL_SDN": nll_sdn, "sdz": sr["sdz"],
-                                   "sample_time": sr["sample_time"], "KLD_G": 0.0, "KLD_NLF": sr["KLD_NLF"],
-                                   "KLD_NF": sr["KLD_NF"], "KLD_R": 0.0})
+                                   "sample_time": sr["sample_time"], "KLD_G": sr["KLD_G"], "KLD_NLF": sr["KLD_NLF"],
+                                   "KLD_NF": sr["KLD_NF"], "KLD_R": sr["KLD_R"]})
         t = time.time()
         nll_tr, sdz_tr, _ = train_epoch(trainer, train_mbs, lr, group, sync_bn)
         train_time += time.time() - t

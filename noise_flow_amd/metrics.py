@@ -41,6 +41,63 @@ def kl_div_3_data(p_data, q_data, bin_edges=None, left_edge=0.0, right_edge=1.0,
     return fwd, inv, (fwd + inv) / 2.0
 
 
+def kl_div_forward(p, q):
+    """sum p log(p / q) over the bins where both histograms are finite and positive (sidd_utils.py:1202-1209)."""
+    p, q = np.asarray(p), np.asarray(q)
+    ok = ~(np.isnan(p) | np.isinf(p) | np.isnan(q) | np.isinf(q))
+    p, q = p[ok], q[ok]
+    ok = (p > 0) & (q > 0)
+    p, q = p[ok], q[ok]
+    return np.sum(p * np.log(p / q))
+
+
+def kldiv_patch_set(i, mb, x_samples, sc_sd, subdir=None):
+    """The four marginal KL divergences of ONE patch of a minibatch against its real noise — the sampling-epoch metric of
+    the reference's training driver (``sidd_utils.py:1011-1058``): the noise of patch ``i`` under (0) an i.i.d. Gaussian of
+    standard deviation ``sc_sd``, (1) the camera NLF ``sqrt(nlf0 y + nlf1)``, (2) the flow's sample ``x_samples[i]``, (3) the
+    real noise itself (= 0), each unpacked to the Bayer mosaic and binned on ``[-1000, -0.1 : 0.2/64 : 0.1, 1000]``.
+    The two random draws use the GLOBAL numpy RNG in the reference's order (Gaussian first, then the NLF draw).
+    ``subdir``: also write the reference's per-patch ``.mat`` dumps there (scipy)."""
+    from .patches import unpack_raw
+    y = unpack_raw(np.asarray(mb['_y'])[i, :, :, :])
+    nlf_sd = np.sqrt(mb['nlf0'] * y + mb['nlf1'])          # Camera NLF
+    ng = np.random.normal(0, sc_sd, y.shape)               # Gaussian
+    ns = unpack_raw(np.asarray(x_samples)[i, :, :, :])     # NF-sampled
+    nl = nlf_sd * np.random.normal(0, 1, y.shape)          # Camera NLF
+    n = unpack_raw(np.asarray(mb['_x'])[i, :, :, :])       # Real
+    noise_pats_raw = (ng, nl, ns, n)
+    bw = 0.2 / 64
+    bin_edges = np.concatenate(([-1000.0], np.arange(-0.1, 0.1 + 1e-9, bw), [1000.0]), axis=0)
+    hists = [get_histogram(pat, bin_edges=bin_edges)[0] for pat in noise_pats_raw]
+    klds = np.asarray([kl_div_forward(hists[-1], h) for h in hists], np.float64)
+    if subdir is not None:
+        from scipy.io import savemat
+        import os
+        pid = mb['pid'][i]
+        xs, xg, xl, x = (np.clip(y + v, 0.0, 1.0) for v in (ns, ng, nl, n))
+        for name, val in (('y', y), ('ng', ng), ('nl', nl), ('ns', ns), ('n', n), ('xg', xg), ('xl', xl), ('xs', xs), ('x', x),
+                          ('kl_ng', klds[0]), ('kl_nl', klds[1]), ('kl_ns', klds[2])):
+            savemat(os.path.join(subdir, '%s_%04d.mat' % (name, pid)), {'x': val})
+    return klds
+
+
+def calc_kldiv_mb(mb, x_samples, vis_dir=None, sc_sd=1.0):
+    """``sidd_utils.py:995-1008``: :func:`kldiv_patch_set` on every 5th patch of the minibatch, averaged →
+    ``[KLD_G, KLD_NLF, KLD_NF, KLD_R]``.  ``vis_dir``: write the reference's ``.mat`` dumps under ``vis_dir/<fn>``."""
+    subdir = None
+    if vis_dir is not None:
+        import os
+        subdir = os.path.join(vis_dir, str(mb['fn']).split('|')[0])
+        os.makedirs(subdir, exist_ok=True)
+    step = 5
+    klds_avg = np.zeros(4)
+    cnt = 0
+    for i in range(0, np.asarray(mb['_x']).shape[0], step):
+        klds_avg += kldiv_patch_set(i, mb, x_samples, sc_sd, subdir)
+        cnt += 1
+    return klds_avg / cnt
+
+
 def noise_bin_edges(n_bins=1000, lo=-0.25, hi=0.25):
     """Symmetric edges for NOISE values (the reference's default [0,1] range suits
     clipped images; raw noise is centred at 0)."""

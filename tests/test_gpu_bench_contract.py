@@ -32,6 +32,8 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     # the parity leg ran (rank 0, N = 1): GPU mean NLL within tolerance of the fp64 oracle
     assert d["nll_check"]["max_rel_err_per_patch"] <= d["nll_check"]["tolerance"]
     assert d["sampling"]["value"] > 0 and d["training"]["value"] > 0 and d["two_streams"]["value"] > 0
+    w512 = d["wide_cnn"]["w512"]     # Glow's default width (sidd/ArgParser.py:43) on the LDS-staged GEMM kernel
+    assert w512["finite"] and w512["value"] > 0 and "nf_gemm_kernel" in w512["kernel_path"] and w512["roofline"]["frac"] > 0.3
 
 
 def test_bench_multi_rank_leg_under_torchrun_on_one_gpu():

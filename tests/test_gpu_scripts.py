@@ -82,3 +82,17 @@ def test_training_script_writes_reference_formats_and_reloads(tmp_path):
     x, y = patches.synth_patches(0, 276, 138, nlf=nlf)
     nll, _ = m.loss(x, y, [nlf[0]], [nlf[1]], [800.0], [2.0])
     assert abs(float(nll) - nlls[-1]) <= 1e-4 * abs(nlls[-1])
+
+
+def test_training_script_consumes_the_sampler_queues(tmp_path):
+    """`--pipeline queues`: image tuples -> PatchSampler -> MiniBatchSampler queues (the reference's host pipeline) feed float64
+    minibatch dicts to the trainer; sample.txt carries the four KLD columns of the reference's recipe."""
+    logdir = str(tmp_path / "runq")
+    _run([os.path.join(ROOT, "train_noise_flow_amd.py"), "--logdir", logdir, "--epochs", "2", "--n_train", "128", "--n_test", "64",
+          "--n_batch_train", "32", "--n_batch_test", "32", "--epochs_full_valid", "1", "--lr", "1e-3", "--pipeline", "queues"])
+    rows = [l.rstrip("\n").split("\t") for l in open(os.path.join(logdir, "train.txt"))]
+    assert len(rows) == 3 and all(np.isfinite(float(r[rows[0].index("NLL")])) for r in rows[1:])
+    srows = [l.rstrip("\n").split("\t") for l in open(os.path.join(logdir, "sample.txt"))]
+    assert srows[0][-4:] == ["KLD_G", "KLD_NLF", "KLD_NF", "KLD_R"] and len(srows) == 3
+    g, nlf, nf, r = (float(v) for v in srows[-1][-4:])
+    assert r == 0.0 and g > 0 and nlf > 0 and nf > 0

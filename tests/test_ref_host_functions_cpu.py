@@ -107,3 +107,70 @@ def test_fresh_sdn_gain_initialisation_matches_reference(ref):
     assert np.all(np.asarray(v["model/sdn_gain/beta2"], np.float64) == float(ref["init_beta2"]))
     assert np.array_equal(np.asarray(v["model/sdn_gain/gain_params"], np.float64).reshape(-1), ref["init_gain_params"])
     assert np.array_equal(np.asarray(v["model/sdn_gain/cam_params"], np.float64), ref["init_cam_params"])
+
+
+def test_random_and_shuffled_patch_origins_match_reference(ref):
+    """sample_indices_random / the shuffled sample_indices_uniform draw from the GLOBAL numpy RNG; a seeded run reproduces the
+    reference's origins (sidd_utils.py:830-858; the shuffle is sklearn.utils.shuffle's)."""
+    from noise_flow_amd.samplers import sample_indices_random, sample_indices_uniform
+    np.random.seed(1234)
+    ii, jj = sample_indices_random(100, 80, 32, 32, 7)
+    assert [list(map(int, ii)), list(map(int, jj))] == ref["rand_origins"].tolist()
+    np.random.seed(4321)
+    ii, jj, n_p = sample_indices_uniform(100, 140, 32, 32, True, None)
+    assert n_p == 12 and [list(map(int, ii)), list(map(int, jj))] == ref["shuf_origins"].tolist()
+
+
+@pytest.mark.parametrize("mode,kw,seed", [("uniform", dict(sampling="uniform", n_pat_per_im=4, shuffle=False), None),
+                                          ("shuffled", dict(sampling="uniform", n_pat_per_im=4, shuffle=True), 99),
+                                          ("random", dict(sampling="random", n_pat_per_im=4), 77)])
+def test_patch_and_minibatch_samplers_match_reference(ref, mode, kw, seed):
+    """Image tuples -> PatchSampler -> MiniBatchSampler (one worker each: queue order), against what the reference's own
+    classes put on their queues for the same tuples and seed (sidd/PatchSampler.py, sidd/MiniBatchSampler.py)."""
+    import queue
+    from noise_flow_amd.samplers import MiniBatchSampler, PatchSampler
+    ims = [{"in": ref["samp_in"][k][None], "gt": ref["samp_gt"][k][None], "nlf0": 0.001 * (k + 1), "nlf1": 1e-6 * (k + 1),
+            "iso": [100.0, 400.0, 800.0][k], "cam": float(k), "fn": "img%d|x" % k, "metadata": None} for k in range(3)]
+    imq = queue.Queue()
+    if seed is not None:
+        np.random.seed(seed)
+    ps = PatchSampler(imq, patch_height=16, max_queue_size=64, n_threads=1, **kw)
+    for im in ims:
+        imq.put(im)
+    pats = [ps.get_queue().get(timeout=30) for _ in range(12)]
+    ps.close()
+    assert [p["pid"] for p in pats] == ref["samp_%s_pid" % mode].tolist()
+    assert [p["iso"] for p in pats] == ref["samp_%s_iso" % mode].tolist()
+    assert set(pats[0]) == {"in", "gt", "vr", "nlf0", "nlf1", "iso", "cam", "fn", "metadata", "pid"} and pats[0]["vr"] == []
+    pq = queue.Queue()
+    ms = MiniBatchSampler(pq, minibatch_size=6, max_queue_size=4, n_threads=1)
+    for p in pats:
+        pq.put(p)
+    mbs = [ms.get_queue().get(timeout=30) for _ in range(2)]
+    ms.close()
+    for k, mb in enumerate(mbs):
+        assert mb["_x"].dtype == np.float64 and mb["_y"].dtype == np.float64 and mb["pid"].dtype == np.float64
+        assert np.array_equal(mb["_x"], ref["mb_%s_%d_x" % (mode, k)]) and np.array_equal(mb["_y"], ref["mb_%s_%d_y" % (mode, k)])
+        assert np.array_equal(mb["pid"], ref["mb_%s_%d_pid" % (mode, k)])
+        assert [mb["nlf0"][0], mb["nlf1"][0], mb["iso"][0], mb["cam"][0]] == ref["mb_%s_%d_cond" % (mode, k)].tolist()
+        assert mb["fn"] == str(ref["mb_%s_%d_fn" % (mode, k)]) and mb["metadata"] is None
+        assert set(mb) == {"_x", "_y", "pid", "nlf0", "nlf1", "iso", "cam", "fn", "metadata"}
+    # a patch count that differs from n_pat_per_im is an error (the reference drops into pdb)
+    ps2 = PatchSampler(queue.Queue(), patch_height=16, n_threads=0, n_pat_per_im=5)
+    with pytest.raises(ValueError):
+        ps2.patches_of(ims[0])
+
+
+def test_sampling_epoch_kl_recipe_matches_reference(ref, tmp_path):
+    """calc_kldiv_mb / kldiv_patch_set (sidd_utils.py:995-1058): every 5th patch, Gaussian / camera-NLF / flow / real noise
+    against the real noise on the reference's bin edges, the two draws on the global numpy RNG in the reference's order."""
+    from noise_flow_amd.metrics import calc_kldiv_mb
+    mb = {"_y": ref["kld_y"], "_x": ref["kld_x"], "nlf0": [0.003696], "nlf1": [2e-6], "pid": np.arange(12.0), "fn": "0001_001_S6_00800|p"}
+    np.random.seed(2024)
+    got = calc_kldiv_mb(mb, ref["kld_xs"], None, float(ref["kld_sc_sd"]))
+    np.testing.assert_allclose(got, ref["kld_avg"], rtol=1e-13, atol=0)
+    assert got[3] == 0.0 and (got[:3] > 0).all()
+    np.random.seed(2024)
+    got2 = calc_kldiv_mb(mb, ref["kld_xs"], str(tmp_path), float(ref["kld_sc_sd"]))          # with the .mat dumps
+    np.testing.assert_allclose(got2, ref["kld_avg"], rtol=1e-13, atol=0)
+    assert sorted(os.listdir(os.path.join(str(tmp_path), "0001_001_S6_00800"))) == ref["kld_mat_files"].tolist()

@@ -9,8 +9,10 @@ and stores inputs + outputs as data.  The committed .npz holds no reference sour
 
     python tools/make_golden_ref_host.py        (needs /root/reference)
 
-Pinned: pack_raw / unpack_raw, sample_indices_uniform, get_histogram, kl_div_3_data
-(sidd/sidd_utils.py:732-764, 830-846, 1247-1274), NoiseFlowWrapper.hps_loader on the shipped hps.txt
+Pinned: pack_raw / unpack_raw, sample_indices_uniform (also shuffled), sample_indices_random, get_histogram, kl_div_3_data,
+kl_div_forward / kldiv_patch_set / calc_kldiv_mb (sidd/sidd_utils.py:732-764, 830-858, 995-1058, 1202-1274), PatchSampler and
+MiniBatchSampler on in-memory image tuples (sidd/PatchSampler.py:20-79, sidd/MiniBatchSampler.py:19-78; their `Thread` is given
+as a daemon subclass so that this script can end), NoiseFlowWrapper.hps_loader on the shipped hps.txt
 (borealisflows/NoiseFlowWrapper.py:96-138), ResultLogger / hps_logger / hps_loader
 (borealisflows/utils.py:90-135), the Gaussian / camera-NLF baseline formulas of
 PatchStatsCalculator.calc_baselines (sidd/PatchStatsCalculator.py:92-123), the initial sdn / gain
@@ -163,6 +165,72 @@ def main():
     c_i, b1, b2, gp, cp = h1.param_inits
     out["init_c_i"], out["init_beta1"], out["init_beta2"] = np.asarray(c_i), np.asarray(b1), np.asarray(b2)
     out["init_gain_params"], out["init_cam_params"] = np.asarray(gp), np.asarray(cp)
+
+    # ---- sidd_utils: random / shuffled patch origins (global numpy RNG) ------------------------------
+    from sklearn.utils import shuffle as sk_shuffle                      # what sidd_utils imports as `shuffle`
+    ns = {"np": np, "gc": gc, "shuffle": sk_shuffle}
+    take("sidd/sidd_utils.py", ["sample_indices_uniform", "sample_indices_random"], ns)
+    np.random.seed(1234)
+    ii, jj = ns["sample_indices_random"](100, 80, 32, 32, 7)
+    out["rand_origins"] = np.asarray([list(map(int, ii)), list(map(int, jj))], np.int64)
+    np.random.seed(4321)
+    ii, jj, n_p = ns["sample_indices_uniform"](100, 140, 32, 32, True, None)
+    out["shuf_origins"] = np.asarray([list(map(int, ii)), list(map(int, jj))], np.int64)
+
+    # ---- PatchSampler / MiniBatchSampler on in-memory image tuples (one worker thread each: queue order) ------
+    import threading
+
+    class DaemonThread(threading.Thread):                                  # the reference's workers never return
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            self.daemon = True
+    ns = {"np": np, "queue": queue, "Thread": DaemonThread, "time": __import__("time"), "random": __import__("random"),
+          "sample_indices_uniform": ns["sample_indices_uniform"], "sample_indices_random": ns["sample_indices_random"]}
+    take("sidd/PatchSampler.py", ["PatchSampler"], ns)
+    take("sidd/MiniBatchSampler.py", ["MiniBatchSampler"], ns)
+    ims = []
+    for k in range(3):
+        gt = rng.rand(1, 38, 38, 4)
+        ims.append({"in": gt + rng.randn(1, 38, 38, 4) * 0.01, "gt": gt, "nlf0": 0.001 * (k + 1), "nlf1": 1e-6 * (k + 1),
+                    "iso": [100.0, 400.0, 800.0][k], "cam": float(k), "fn": "img%d|x" % k, "metadata": None})
+    out["samp_in"] = np.stack([im["in"][0] for im in ims])
+    out["samp_gt"] = np.stack([im["gt"][0] for im in ims])
+    for mode, kw, seed in (("uniform", dict(sampling="uniform", n_pat_per_im=4, shuffle=False), None),
+                           ("shuffled", dict(sampling="uniform", n_pat_per_im=4, shuffle=True), 99),
+                           ("random", dict(sampling="random", n_pat_per_im=4), 77)):
+        imq = queue.Queue()
+        if seed is not None:
+            np.random.seed(seed)
+        ps = ns["PatchSampler"](imq, patch_height=16, max_queue_size=64, n_threads=1, **kw)
+        for im in ims:
+            imq.put(im)
+        pats = [ps.get_queue().get(timeout=30) for _ in range(12)]
+        out["samp_%s_pid" % mode] = np.asarray([p["pid"] for p in pats], np.int64)
+        out["samp_%s_iso" % mode] = np.asarray([p["iso"] for p in pats])
+        pq = queue.Queue()
+        ms = ns["MiniBatchSampler"](pq, minibatch_size=6, max_queue_size=4, n_threads=1)
+        for p in pats:
+            pq.put(p)
+        mbs = [ms.get_queue().get(timeout=30) for _ in range(2)]
+        for k, mb in enumerate(mbs):
+            assert mb["_x"].dtype == np.float64
+            out["mb_%s_%d_x" % (mode, k)], out["mb_%s_%d_y" % (mode, k)], out["mb_%s_%d_pid" % (mode, k)] = mb["_x"], mb["_y"], mb["pid"]
+            out["mb_%s_%d_cond" % (mode, k)] = np.asarray([mb["nlf0"][0], mb["nlf1"][0], mb["iso"][0], mb["cam"][0]])
+            out["mb_%s_%d_fn" % (mode, k)] = np.asarray(mb["fn"])
+
+    # ---- calc_kldiv_mb / kldiv_patch_set: the sampling-epoch KL recipe of the training driver ---------------------
+    from scipy.io import savemat
+    ns = {"np": np, "os": os, "queue": queue, "savemat": savemat}
+    take("sidd/sidd_utils.py", ["unpack_raw", "get_histogram", "kl_div_forward", "kldiv_patch_set", "calc_kldiv_mb"], ns)
+    yk = rng.rand(12, 16, 16, 4)
+    mbk = {"_y": yk, "_x": rng.randn(12, 16, 16, 4) * np.sqrt(0.003696 * yk + 2e-6), "nlf0": [0.003696], "nlf1": [2e-6],
+           "pid": np.arange(12.0), "fn": "0001_001_S6_00800|p"}
+    xsk = rng.randn(12, 16, 16, 4) * np.sqrt(0.0042 * yk + 3e-6)
+    np.random.seed(2024)
+    out["kld_avg"] = np.asarray(ns["calc_kldiv_mb"](mbk, xsk, os.path.join(tmp, "vis"), 0.035))
+    out["kld_y"], out["kld_x"], out["kld_xs"] = mbk["_y"], mbk["_x"], xsk
+    out["kld_sc_sd"] = np.asarray(0.035)
+    out["kld_mat_files"] = np.asarray(sorted(os.listdir(os.path.join(tmp, "vis", "0001_001_S6_00800"))))
 
     path = os.path.join(ROOT, "tests", "golden", "ref_host_functions.npz")
     np.savez_compressed(path, **out)

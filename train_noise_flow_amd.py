@@ -48,6 +48,10 @@ def main():
     ap.add_argument("--sync_bn", action="store_true",
                     help="multi-GPU: batch-norm moments over the GLOBAL minibatch (all ranks take the single-process step)")
     ap.add_argument("--init", default=None, help="checkpoint prefix to start from (default: fresh initialisation)")
+    ap.add_argument("--pipeline", default="resident", choices=["resident", "queues"],
+                    help="resident: training minibatches generated once on the GPU; queues: the reference's host pipeline — image "
+                         "tuples -> PatchSampler -> MiniBatchSampler queues (sidd/PatchSampler.py, sidd/MiniBatchSampler.py), numpy "
+                         "float64 minibatch dicts fed per step")
     args = ap.parse_args()
 
     import torch
@@ -85,7 +89,27 @@ def main():
     # every rank must take the SAME number of optimizer steps (one gradient all-reduce per step): equal blocks of
     # n_train // world patches, the remainder is dropped
     per_rank = args.n_train // world
-    train_mbs = minibatches(rank * per_rank, per_rank, args.n_batch_train)
+    stages = []
+    if args.pipeline == "queues":
+        # the reference's host pipeline on in-memory image tuples: every "image" is a 4 x 4 mosaic of this rank's synthetic
+        # 32x32 patches ('in' = the noise layer, sidd_utils.py:264-265); patches are drawn on the grid in shuffled order and
+        # collated into float64 minibatch dicts by the sampler threads
+        from noise_flow_amd.samplers import ImageTupleFeeder, MiniBatchSampler, PatchSampler, QueueEpoch
+        np.random.seed(args.seed + rank)
+        n_img = max(1, per_rank // 16)
+        tuples = []
+        for k in range(n_img):
+            x, y = patches.synth_patches(args.seed, rank * per_rank + 16 * k, 16, nlf=nlf)
+            mosaic = lambda t: t.cpu().numpy().astype(np.float64).reshape(4, 4, 32, 32, 4).transpose(0, 2, 1, 3, 4).reshape(1, 128, 128, 4)   # noqa: E731
+            tuples.append({"in": mosaic(x), "gt": mosaic(y), "nlf0": nlf[0], "nlf1": nlf[1], "iso": args.iso, "cam": args.cam,
+                           "fn": "synth_%04d" % k, "metadata": None})
+        feeder = ImageTupleFeeder(tuples)
+        ps = PatchSampler(feeder.get_queue(), patch_height=32, sampling="uniform", n_threads=1, n_pat_per_im=16, shuffle=True)
+        ms = MiniBatchSampler(ps.get_queue(), minibatch_size=args.n_batch_train, n_threads=1)
+        stages = [ms, ps, feeder]
+        train_mbs = QueueEpoch(ms.get_queue(), max(1, (n_img * 16) // args.n_batch_train))
+    else:
+        train_mbs = minibatches(rank * per_rank, per_rank, args.n_batch_train)
     test_mbs = minibatches(args.n_train, args.n_test, args.n_batch_test)     # every rank evaluates the same test set
     # closed-form baselines of the test noise (sidd/PatchStatsCalculator.py:92-123)
     xt = np.concatenate([mb["_x"].cpu().numpy() for mb in test_mbs])
@@ -101,7 +125,10 @@ def main():
         log("train minibatches/epoch %d x %d patches (rank 0 of %d), test %d x %d; NLL_G %.2f NLL_SDN %.2f" % (
             len(train_mbs), args.n_batch_train, world, len(test_mbs), args.n_batch_test, base_g, base_sdn))
     res = fit(trainer, nf_eval, train_mbs, test_mbs, logdir, args.epochs, args.lr, args.epochs_full_valid,
-              nll_gauss=base_g, nll_sdn=base_sdn, group=group, log=log, sync_bn=args.sync_bn)
+              nll_gauss=base_g, nll_sdn=base_sdn, group=group, log=log, sync_bn=args.sync_bn,
+              sc_sd=float(xt.std()))        # pat_stats['sc_in_sd'] of the reference: the KLD_G model of sample.txt
+    for st in stages:
+        st.close()
     if log:
         log("final: train %.4f  test %.4f (first %.4f)" % (res["train"][-1], res["test"][-1], res["test"][0]))
     if world > 1:
