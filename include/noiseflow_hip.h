@@ -195,6 +195,27 @@ int nf_sample(nf_handle *h, const float *y, const float *eps, uint64_t seed,
               int64_t patch_index_base, float temp, int64_t B, const nf_cond *cond,
               float *x_out, void *stream);
 
+/* Host-fed variants: the call pattern of the reference's drivers — `sess.run(..., feed_dict={x: numpy, y: numpy})` with the
+ * float64 minibatches of sidd/MiniBatchSampler.py:54-55 (train_noise_flow.py:112-113) and
+ * NoiseFlowWrapper.sample_noise_nf(batch_x, ...) (NoiseFlowWrapper.py:81-87): every tensor pointer is HOST memory (pageable
+ * or pinned, no alignment requirement), results are in the caller's host buffers when the call returns.
+ *   x, y / y     [B,H,W,4] float32 (NF_HOST_F32) or float64 (NF_HOST_F64; narrowed to float32 exactly as the feed does)
+ *   eps          [B,H,W,4] float32 or NULL (in-kernel Philox keyed by (seed, patch_index_base + b, pixel))
+ *   nll_out, sd_out, logdet_out [B], z_out / x_out [B,H,W,4]: float32 host buffers (each optional except x_out)
+ *   sums_out     HOST double[3] = (sum nll, sum sd, B), or NULL; NF_ACCUMULATE adds to it.  flags: NF_NO_PRIOR, NF_ACCUMULATE.
+ * The call is a chunked pipeline owned by the handle (created on first use, freed by nf_destroy): worker threads narrow /
+ * copy a chunk into pinned staging while the previous chunks cross PCIe and run on three internal streams; patches are
+ * independent, so every per-patch output is bit-identical to nf_nll / nf_sample on the same data.  Evaluation mode only
+ * (running BN statistics).  Calls on one handle serialise.  Environment: NF_HOSTFED_THREADS (default: the CPUs this
+ * process may use, at most 32), NF_HOSTFED_CHUNK (patches per chunk; default 8 MiB of one tensor). */
+#define NF_HOST_F32 0
+#define NF_HOST_F64 1
+int nf_nll_host(nf_handle *h, const void *x, const void *y, int32_t dtype, int64_t B, const nf_cond *cond,
+                float *nll_out, float *sd_out, float *logdet_out, float *z_out,
+                double *sums_out, uint32_t flags);
+int nf_sample_host(nf_handle *h, const void *y, int32_t y_dtype, const float *eps, uint64_t seed,
+                   int64_t patch_index_base, float temp, int64_t B, const nf_cond *cond, float *x_out);
+
 /* Batch-statistics variants = the reference's `is_training=True` graphs (layers.py:386-398; what
  * NoiseFlowWrapper.py:49 builds): every batch_norm of the coupling CNNs normalises with the moments
  * of the CURRENT call's B patches over (N,H,W) instead of the stored running statistics, so the

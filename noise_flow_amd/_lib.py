@@ -130,6 +130,10 @@ def load() -> C.CDLL:
     lib.nf_fold_params.argtypes = [C.POINTER(nf_config), C.POINTER(nf_layer_desc), C.POINTER(C.c_float), C.c_size_t,
                                    i32, C.POINTER(i32), i32, C.POINTER(i32), C.POINTER(C.c_float), C.c_size_t,
                                    C.POINTER(C.c_size_t), C.POINTER(C.c_double)]
+    lib.nf_nll_host.restype = C.c_int
+    lib.nf_nll_host.argtypes = [vp, vp, vp, i32, i64, C.POINTER(nf_cond), vp, vp, vp, vp, vp, u32]
+    lib.nf_sample_host.restype = C.c_int
+    lib.nf_sample_host.argtypes = [vp, vp, i32, vp, u64, i64, f32, i64, C.POINTER(nf_cond), vp]
     lib.nf_fold_layout.restype = C.c_int
     lib.nf_fold_layout.argtypes = [C.POINTER(nf_config), C.POINTER(nf_layer_desc), C.POINTER(C.c_float), C.c_size_t,
                                    i32, i32, C.POINTER(i32), i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(C.c_float), C.c_size_t,
@@ -152,11 +156,12 @@ def check(rc: int) -> None:
 
 EXPORTED_SYMBOLS = (
     "nf_abi_version", "nf_last_error", "nf_layer_param_count", "nf_create", "nf_destroy", "nf_nll",
-    "nf_sample", "nf_synth_patches", "nf_fold_params", "nf_fold_layout", "nf_sdn5_scalars",
+    "nf_sample", "nf_nll_host", "nf_sample_host", "nf_synth_patches", "nf_fold_params", "nf_fold_layout", "nf_sdn5_scalars",
     "nf_nll_batchstats", "nf_sample_batchstats", "nf_sums_reduce", "nf_kernel_path",
     "nf_trainer_create", "nf_trainer_destroy", "nf_trainer_forward_backward", "nf_trainer_forward", "nf_trainer_apply", "nf_trainer_step",
     "nf_trainer_get_params", "nf_trainer_set_params", "nf_trainer_steps", "nf_trainer_set_sync",
 )
 NF_PATH_SCALAR, NF_PATH_MFMA4, NF_PATH_FP16, NF_PATH_WIDE32, NF_PATH_WIDE16, NF_PATH_WIDE32_FP16, NF_PATH_GEMM = 0, 1, 2, 3, 4, 5, 6
+NF_HOST_F32, NF_HOST_F64 = 0, 1
 NF_OPT_ADAM = 0
 NF_OPT_MOMENTUM = 1

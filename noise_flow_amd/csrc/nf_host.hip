@@ -1074,6 +1074,15 @@ struct nf_handle {
     struct nf_bs_state *bs = nullptr;
 };
 
+int nf_handle_geometry(const nf_handle *h, int32_t *H, int32_t *W, int32_t *device)
+{
+    if (!h) return fail(NF_EINVAL, "handle is NULL");
+    *H = h->cfg.height;
+    *W = h->cfg.width;
+    *device = h->device;
+    return NF_OK;
+}
+
 extern "C" {
 
 int nf_destroy(nf_handle *h);
@@ -1240,6 +1249,7 @@ int nf_create(const nf_config *cfg, const nf_layer_desc *layers, const float *pa
 int nf_destroy(nf_handle *h)
 {
     if (!h) return NF_OK;
+    nf_hostpipe_release(h);
     DeviceGuard guard;
     (void)guard.enter(h->device);
     if (h->d_fwd) (void)hipFree(h->d_fwd);

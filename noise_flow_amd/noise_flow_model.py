@@ -67,6 +67,27 @@ def _to_float32(a) -> np.ndarray:
     return out
 
 
+def _host_out(torch, shape):
+    """float32 host array for a result.  Large ones come from torch's caching PINNED host allocator: the library then copies
+    D2H straight into them (no staging copy), and — unlike a fresh ``np.empty`` — a recycled block has no first-touch page
+    faults (64 MiB of fresh pages cost ~6 ms, more than the whole sampling call).  The array keeps its block alive."""
+    n = int(np.prod(shape))
+    if n < (1 << 20):
+        return np.empty(shape, np.float32)
+    return torch.empty(tuple(shape), dtype=torch.float32, device="cpu", pin_memory=True).numpy()
+
+
+def _host_tensor(a, shape_tail):
+    """A host array as the host-fed C ABI takes it: C-contiguous float32 or float64 [B, *shape_tail] → (array, dtype code)."""
+    a = np.asarray(a)
+    if a.dtype != np.float32 and a.dtype != np.float64:
+        a = a.astype(np.float32)
+    a = np.ascontiguousarray(a)
+    if shape_tail is not None and tuple(a.shape[1:]) != tuple(shape_tail):
+        raise ValueError("expected tensor of shape [B,%s], got %s" % (",".join(map(str, shape_tail)), tuple(a.shape)))
+    return a, (_lib.NF_HOST_F64 if a.dtype == np.float64 else _lib.NF_HOST_F32)
+
+
 class _Dev:
     """Device plumbing (torch is used ONLY for HBM allocations and streams)."""
 
@@ -102,6 +123,8 @@ class _Dev:
         owns that block until it is garbage-collected."""
         if not as_numpy:
             return t
+        if t.device.type == "cpu":    # the host-fed path already delivered into host memory
+            return t.numpy()
         if t.numel() < (1 << 23):     # below 32 MiB the pageable path is as fast (measured) and has no set-up cost
             return t.cpu().numpy()
         h = self.torch.empty(t.shape, dtype=t.dtype, device="cpu", pin_memory=True)
@@ -264,9 +287,37 @@ class NoiseFlow(object):
                     old = np.asarray(self._variables[key], np.float32)
                     self._variables[key] = (old - decay * (old - moments[row, k].reshape(old.shape))).astype(np.float32)
 
+    def _run_nll_host(self, x, y, cond, want_z: bool, flags: int, want_sums: bool):
+        """numpy in → numpy out through ``nf_nll_host``: the float64 → float32 narrowing, H2D, the kernel and D2H of
+        consecutive chunks overlap inside the library (what a ``sess.run(feed_dict=numpy)`` caller of the reference gets).
+        Returns CPU torch tensors that alias the numpy results, so that the callers' arithmetic is the device path's."""
+        torch = self._dev.torch
+        tail = tuple(self.x_shape)
+        xa, dt = _host_tensor(x, tail)
+        ya = None
+        if y is not None:
+            ya, dty = _host_tensor(y, tail)
+            if ya.shape[0] != xa.shape[0]:
+                raise ValueError("x and y batch sizes differ")
+            if dty != dt:                      # one dtype per call: narrow the float64 one here (rare)
+                xa, ya, dt = xa.astype(np.float32, copy=False), ya.astype(np.float32, copy=False), _lib.NF_HOST_F32
+        B = int(xa.shape[0])
+        nll, sd, ld = (np.empty((B,), np.float32) for _ in range(3))
+        z = _host_out(torch, xa.shape) if want_z else None
+        sums = np.zeros(3, np.float64) if want_sums else None
+        with torch.cuda.device(self._dev.device):
+            _lib.check(self._flow.lib.nf_nll_host(self._flow.ptr, xa.ctypes.data, ya.ctypes.data if ya is not None else None, dt, B,
+                                                  C.byref(cond), nll.ctypes.data, sd.ctypes.data, ld.ctypes.data,
+                                                  z.ctypes.data if z is not None else None,
+                                                  sums.ctypes.data if sums is not None else None, flags))
+        t = torch.from_numpy
+        return t(nll), t(sd), t(ld), (t(z) if z is not None else None), (t(sums) if sums is not None else None), True
+
     def _run_nll(self, x, y, cond, want_z: bool, flags: int = 0, want_sums: bool = False):
         dev = self._dev
         tail = tuple(self.x_shape)
+        if not self._is_training and not isinstance(x, dev.torch.Tensor) and not isinstance(y, dev.torch.Tensor):
+            return self._run_nll_host(x, y, cond, want_z, flags, want_sums)
         xt, was_np = dev.to_dev(x, tail)
         yt = None
         if y is not None:
@@ -434,6 +485,27 @@ class NoiseFlow(object):
         tail = tuple(self.x_shape)
         if yy is None and self._flow.has_sdn:
             raise ValueError("this architecture has a signal-dependent layer: the clean image yy is required")
+        if not self._is_training and not isinstance(z_or_y, dev.torch.Tensor) and not isinstance(yy, dev.torch.Tensor):
+            # numpy in → numpy out through nf_sample_host (chunked, full duplex: y goes down while x comes up)
+            za, zdt = _host_tensor(z_or_y, tail)
+            B = int(za.shape[0])
+            ya, ydt = _host_tensor(yy, tail) if yy is not None else (None, _lib.NF_HOST_F32)
+            if ya is not None and ya.shape[0] != B:
+                raise ValueError("batch sizes differ")
+            eps = np.ascontiguousarray(za, dtype=np.float32) if z_is_eps else None
+            if z_is_eps:
+                base, sd = 0, 0
+            else:
+                sd = self._seed if seed is None else int(seed)
+                with self._lock:
+                    base = self._draws
+                    self._draws += B
+            out = _host_out(dev.torch, za.shape)
+            with dev.torch.cuda.device(dev.device):
+                _lib.check(self._flow.lib.nf_sample_host(self._flow.ptr, ya.ctypes.data if ya is not None else None, ydt,
+                                                         eps.ctypes.data if eps is not None else None, sd & _U64, base, float(temp), B,
+                                                         C.byref(cond), out.ctypes.data))
+            return out
         zt, was_np = dev.to_dev(z_or_y, tail)
         yt = dev.to_dev(yy, tail)[0] if yy is not None else None
         B = int(zt.shape[0])

@@ -82,3 +82,51 @@ def test_standalone_c_training_client(tmp_path):
         assert abs(loss - losses[k][0]) <= 1e-6 * abs(loss) and abs(sd - losses[k][1]) <= 1e-6 * sd
     assert np.array_equal(tr.raw_params(), trained)
     assert losses[-1][0] < losses[0][0]
+
+
+def test_host_fed_entries_equal_the_device_resident_path(shipped_variables):
+    """nf_nll_host / nf_sample_host (host pointers, float64 or float32, chunked over three streams with pinned staging) give
+    per-patch results BIT-identical to nf_nll / nf_sample on device tensors: multi-chunk batches (NF_HOSTFED_CHUNK-sized
+    pieces + a ragged tail), both dtypes, every optional output, in-kernel Philox with a patch base that crosses chunks."""
+    import torch
+    from conftest import FULL_ARCH, make_inputs
+    from noise_flow_amd import NoiseFlow, default_hps
+    os.environ["NF_HOSTFED_CHUNK"] = "96"
+    try:
+        m = NoiseFlow([32, 32, 4], False, default_hps(), variables=shipped_variables)
+        B = 96 * 3 + 41
+        x, y = make_inputs(B, seed=9)
+        xd, yd = torch.tensor(x).cuda(), torch.tensor(y).cuda()
+        for cast in (np.float64, np.float32):
+            nll_h, sd_h = m._loss(x.astype(cast), y.astype(cast), [0.0], [0.0], [800], [3])
+            nll_d, sd_d = m._loss(xd, yd, [0.0], [0.0], [800], [3])
+            assert isinstance(nll_h, np.ndarray) and np.array_equal(nll_h, nll_d.cpu().numpy())
+            assert abs(sd_h - float(sd_d)) <= 1e-6 * sd_h
+            z_h, obj_h = m.inverse(x.astype(cast), None, y.astype(cast), [0.0], [0.0], [800], [3])
+            z_d, obj_d = m.inverse(xd, None, yd, [0.0], [0.0], [800], [3])
+            assert np.array_equal(z_h, z_d.cpu().numpy()) and np.array_equal(obj_h, obj_d.cpu().numpy())
+            mean_h, msd_h = m.loss(x.astype(cast), y.astype(cast), [0.0], [0.0], [800], [3])
+            mean_d, msd_d = m.loss(xd, yd, [0.0], [0.0], [800], [3])
+            assert abs(float(mean_h) - float(mean_d)) <= 1e-6 * abs(float(mean_d)) and abs(float(msd_h) - float(msd_d)) <= 1e-6
+            eps = np.random.RandomState(2).randn(B, 32, 32, 4).astype(np.float32)
+            xs_h = m.sample(y.astype(cast), 0.7, y.astype(cast), [0.0], [0.0], [800], [3], eps=eps)
+            xs_d = m.sample(yd, 0.7, yd, [0.0], [0.0], [800], [3], eps=torch.tensor(eps).cuda())
+            assert np.array_equal(xs_h, xs_d.cpu().numpy())
+            m._draws = 1000
+            p_h = m.sample(y.astype(cast), 0.7, y.astype(cast), [0.0], [0.0], [800], [3], seed=11)
+            m._draws = 1000
+            p_d = m.sample(yd, 0.7, yd, [0.0], [0.0], [800], [3], seed=11)
+            assert np.array_equal(p_h, p_d.cpu().numpy()) and m._draws == 1000 + B
+        # an empty batch and a model without signal-dependent layers (y = NULL)
+        nll0, _ = m._loss(x[:0].astype(np.float64), y[:0].astype(np.float64), [0.0], [0.0], [800], [3])
+        assert nll0.shape == (0,)
+        from conftest import trained_like_variables
+        mu = NoiseFlow([16, 16, 4], False, default_hps(arch="unc|unc"), variables=trained_like_variables("unc|unc", 4, seed=2))
+        xu, _ = make_inputs(150, 16, 16, seed=3)
+        hps_u = mu.hps
+        hps_u.sidd_cond = "uncond"
+        nu_h, _ = mu._loss(xu.astype(np.float64), None)
+        nu_d, _ = mu._loss(torch.tensor(xu).cuda(), None)
+        assert np.array_equal(nu_h, nu_d.cpu().numpy())
+    finally:
+        del os.environ["NF_HOSTFED_CHUNK"]
