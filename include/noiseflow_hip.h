@@ -195,6 +195,13 @@ int nf_sample(nf_handle *h, const float *y, const float *eps, uint64_t seed,
               int64_t patch_index_base, float temp, int64_t B, const nf_cond *cond,
               float *x_out, void *stream);
 
+/* The N(0,1) draw nf_sample makes in-kernel when eps = NULL, written to eps_out [B,H,W,4] (device): Philox4x32-10 keyed
+ * (seed, patch_index_base + b, pixel), bit-identical to the in-kernel values.  For callers that post-process the draw before
+ * the flow — e.g. one temperature PER PATCH, which the reference's prior supports (eps_std reshaped to [-1,1,1,1],
+ * noise_flow_model.py:499-504) — and hand it back as `eps`. */
+int nf_sample_eps(uint64_t seed, int64_t patch_index_base, int64_t B, int32_t height, int32_t width,
+                  float *eps_out, void *stream);
+
 /* Host-fed variants: the call pattern of the reference's drivers — `sess.run(..., feed_dict={x: numpy, y: numpy})` with the
  * float64 minibatches of sidd/MiniBatchSampler.py:54-55 (train_noise_flow.py:112-113) and
  * NoiseFlowWrapper.sample_noise_nf(batch_x, ...) (NoiseFlowWrapper.py:81-87): every tensor pointer is HOST memory (pageable

@@ -29,6 +29,7 @@ hipError_t nf_launch_gemm(const NfProgram &prog, const NfLaunch &a, int n_cu, in
 bool nf_gemm_shape_ok(int H, int W);
 hipError_t nf_launch_synth(uint64_t seed, int64_t patch_base, int64_t B, int HW, float beta1, float beta2,
                            float *y_out, float *x_out, hipStream_t stream);
+hipError_t nf_launch_eps(uint64_t seed, int64_t patch_base, int64_t B, int HW, float *eps_out, hipStream_t stream);
 hipError_t nf_launch_sums_reduce(const double *wide, double *out3, bool accumulate, hipStream_t stream);
 hipError_t nf_launch_bs_finalize(double *stats, int w, double n, float *Wm, int rows, float *Bv, float *mean_out, float *var_out,
                                  hipStream_t stream);
@@ -1899,6 +1900,15 @@ int nf_sums_reduce(const double *wide, double *out3, uint32_t flags, void *strea
     if (!wide || !out3) return fail(NF_EINVAL, "null argument");
     hipError_t e = nf_launch_sums_reduce(wide, out3, (flags & NF_ACCUMULATE) != 0, (hipStream_t)stream);
     if (e != hipSuccess) return fail_hip(e, "nf_sums_reduce launch");
+    return NF_OK;
+}
+
+int nf_sample_eps(uint64_t seed, int64_t patch_index_base, int64_t B, int32_t height, int32_t width, float *eps_out, void *stream)
+{
+    if (B < 0 || height < 1 || width < 1) return fail(NF_EINVAL, "bad shape");
+    if (!eps_out || !aligned16(eps_out)) return fail(NF_EINVAL, "eps_out must be a 16-byte aligned device pointer");
+    hipError_t e = nf_launch_eps(seed, patch_index_base, B, height * width, eps_out, (hipStream_t)stream);
+    if (e != hipSuccess) return fail_hip(e, "nf_sample_eps launch");
     return NF_OK;
 }
 

@@ -1091,6 +1091,18 @@ __global__ __launch_bounds__(256) void nf_synth_kernel(uint64_t seed, int64_t pa
     }
 }
 
+// the N(0,1) draw the flow kernels make in-kernel for sampling (stream NF_STREAM_SAMP), written out (nf_sample_eps)
+__global__ __launch_bounds__(256) void nf_eps_kernel(uint64_t seed, int64_t patch_base, int64_t B, int HW, float *__restrict__ eps_out)
+{
+    const int64_t total = B * (int64_t)HW;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / HW;
+        float e[4];
+        philox_normal4(seed, patch_base + b, (uint32_t)(i - b * HW), NF_STREAM_SAMP, e);
+        reinterpret_cast<float4 *>(eps_out)[i] = make_float4(e[0], e[1], e[2], e[3]);
+    }
+}
+
 template <int WIDTH, int THREADS, int PX, bool PHILOX, bool MFMA, bool FULL, int PREC, bool BS = false>
 hipError_t launch_flow_p(const NfProgram &prog, const NfLaunch &a, int n_cu, hipStream_t stream)
 {
@@ -1227,6 +1239,15 @@ hipError_t nf_launch_gather(float *dst, const float *src, const int32_t *pairs, 
 hipError_t nf_launch_sums_reduce(const double *wide, double *out3, bool accumulate, hipStream_t stream)
 {
     hipLaunchKernelGGL(nf_sums_reduce_kernel, dim3(1), dim3(64), 0, stream, wide, out3, accumulate ? 1 : 0);
+    return hipGetLastError();
+}
+
+hipError_t nf_launch_eps(uint64_t seed, int64_t patch_base, int64_t B, int HW, float *eps_out, hipStream_t stream)
+{
+    if (B <= 0) return hipSuccess;
+    int64_t blocks = (B * (int64_t)HW + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(nf_eps_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, seed, patch_base, B, HW, eps_out);
     return hipGetLastError();
 }
 

@@ -223,7 +223,8 @@ class NoiseFlow(object):
         self._draws = 0
         self._lock = threading.Lock()
         self._variables = dict(variables) if variables is not None else _params.init_variables(
-            self.arch, self.width, self.x_shape[-1], self._seed, self.flow_permutation, self.decomp)
+            self.arch, self.width, self.x_shape[-1], self._seed, self.flow_permutation, self.decomp,
+            float(getattr(hps, "gain_init", -5.0)))
         self.model = [_params.parse_arch(self.arch, self.flow_permutation, self.decomp)]   # bijector list per level (define_flow_structure)
         # 'fp16': coupling-CNN convs in half precision on the matrix cores, everything else fp32
         # (BASELINE configs[4]); also selectable as hps.cnn_dtype.  Default: all fp32.
@@ -465,11 +466,15 @@ class NoiseFlow(object):
                 raise ValueError("eps_std holds %d temperatures for %d patches" % (tv.size, B))
             as_np = eps is not None and not isinstance(eps, torch.Tensor) or eps is None and not isinstance(y, torch.Tensor)
             if eps is None:
-                gen = torch.Generator(device=self._dev.device)
+                # the draw the kernel would make for these patches (same Philox key: seed, running patch counter, pixel), so
+                # that a seed gives the same noise whether the temperature is one number or one per patch
                 with self._lock:
-                    gen.manual_seed(int(self._seed if seed is None else seed) * 1000003 + self._draws)
+                    base = self._draws
                     self._draws += B
-                e = torch.randn((B,) + tuple(self.x_shape), generator=gen, device=self._dev.device, dtype=torch.float32)
+                e = torch.empty((B,) + tuple(self.x_shape), device=self._dev.device, dtype=torch.float32)
+                with torch.cuda.device(self._dev.device):
+                    _lib.check(self._flow.lib.nf_sample_eps(int(self._seed if seed is None else seed) & _U64, base, B, self.x_shape[0],
+                                                            self.x_shape[1], e.data_ptr(), self._dev.stream_ptr()))
             else:
                 e = self._dev.to_dev(eps, tuple(self.x_shape))[0]
             e = e * torch.as_tensor(tv, device=self._dev.device).reshape(-1, 1, 1, 1)

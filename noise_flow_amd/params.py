@@ -243,7 +243,7 @@ def stricttri2vec(mat: np.ndarray, upper: bool) -> np.ndarray:
 
 
 def init_variables(arch: str, width: int = 4, channels: int = 4, seed: int = 0, flow_permutation: int = 1,
-                   decomp: str = "LU") -> Dict[str, np.ndarray]:
+                   decomp: str = "LU", gain_init: float = -5.0) -> Dict[str, np.ndarray]:
     """Fresh variables under the reference's names with the reference's
     initialisers: QR-orthogonal 1x1 matrix → scipy LU (layers.py:95,
     matrix_param.py:100-123); l_1/l_2 ~ N(0, (width/512·0.05)²), zero biases
@@ -303,7 +303,7 @@ def init_variables(arch: str, width: int = 4, channels: int = 4, seed: int = 0, 
         v["model/g1"] = np.full((1,), -3.0, np.float32)     # cond_utils.py:321-324
         v["model/g2"] = np.full((1,), 3.0, np.float32)
     kinds = {L.kind for L in layers}
-    gain_init = -5.0                                         # hps.gain_init (sidd/ArgParser.py default)
+    gain_init = float(gain_init)                             # hps.gain_init (sidd/ArgParser.py default -5.0): sdn2 / sdn3 / gain2
     if kinds & {"sdn1", "sdn2", "sdn3"}:
         v["model/b1"] = np.full((1,), -3.0, np.float32)     # cond_utils.py:90-93
         v["model/b2"] = np.full((1,), 3.0, np.float32)

@@ -48,7 +48,8 @@ class Trainer:
         self.decomp = str(getattr(hps, "decomp", "LU"))
         seed = int(getattr(hps, "seed", 0) or 0)
         self._variables = dict(variables) if variables is not None else _params.init_variables(
-            self.arch, self.width, self.x_shape[-1], seed, self.flow_permutation, self.decomp)
+            self.arch, self.width, self.x_shape[-1], seed, self.flow_permutation, self.decomp,
+            float(getattr(hps, "gain_init", -5.0)))
         self.layers = _params.parse_arch(self.arch, self.flow_permutation, self.decomp)
         self._tmpl = _params.template_binding(self.layers, binding)
         self.layers, descs, flat = _params.pack_layers(self.layers, self._variables, self.width, self._tmpl)
@@ -184,6 +185,8 @@ class Trainer:
         rank's own mean.  ``sync=False`` returns the device tensor ``[loss, sd_z]`` without waiting."""
         if group is not None or self._sync is not None:
             self.set_sync_bn(group, enabled=bool(sync_bn) and group is not None)
+        if self._sync is not None:
+            self._check_equal_shards(int(np.shape(x)[0]), None if group is True else group)
         try:
             grads, loss = self.forward_backward(x, y, nlf0, nlf1, iso, cam)
         except _lib.NoiseFlowLibError:
@@ -199,7 +202,39 @@ class Trainer:
         if not sync:
             return loss
         v = loss.cpu().numpy()
+        self._drain_shard_checks(wait=True)
         return np.float32(v[0]), np.float32(v[1])
+
+    def _drain_shard_checks(self, wait: bool):
+        pend = getattr(self, "_shard_checks", None)
+        if pend is None:
+            pend = self._shard_checks = []
+        while pend and (wait or pend[0][0].query()):
+            ev, host, step_no = pend.pop(0)
+            ev.synchronize()
+            hi, neg_lo = float(host[0]), float(host[1])
+            if hi != -neg_lo:
+                pend.clear()
+                raise ValueError("sync_bn needs the same number of patches on every rank (step %d: between %d and %d): the batch "
+                                 "moments are formed with world x the local pixel count" % (step_no, int(-neg_lo), int(hi)))
+
+    def _check_equal_shards(self, B: int, grp):
+        """Synchronised batch normalisation takes its moments over world x the LOCAL pixel count (the library's ``n``), which
+        is the global count only when every rank feeds the same number of patches.  One 16-byte MAX all-reduce of (B, -B) per
+        step, read back WITHOUT stalling the step: the result of step k is looked at when its copy has landed (a step or two
+        later) and a mismatch raises there — before more updates are taken with wrong moments."""
+        import torch.distributed as dist
+        torch = self._dev.torch
+        self._drain_shard_checks(wait=False)
+        pend = self._shard_checks
+        dev = self._dev.device
+        t = torch.tensor([float(B), -float(B)], dtype=torch.float64).pin_memory().to(dev, non_blocking=True)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=grp)
+        host = torch.empty(2, dtype=torch.float64, pin_memory=True)
+        host.copy_(t, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        pend.append((ev, host, self.steps))
 
     # ------------------------------------------------------------------ parameters
     @property
@@ -217,6 +252,7 @@ class Trainer:
     def variables(self) -> Dict[str, np.ndarray]:
         """The current variables under the reference's checkpoint names (trained values and the
         EMA-updated BN statistics); synchronises."""
+        self._drain_shard_checks(wait=True)
         self._variables = _params.unpack_layers(self.layers, self.raw_params(), self._variables, self._tmpl)
         return self._variables
 

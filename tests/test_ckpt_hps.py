@@ -83,3 +83,13 @@ def test_hps_logger_round_trip(tmp_path):
     assert lines[:3] == ["sdn_0", "Conv2d_1x1_1", "unc_1"] and lines[18] == "2433"
     back = hps_loader(p)
     assert back.arch == FULL_ARCH and back.width == 4 and back.do_sample is True and back.name == "x"
+
+
+def test_fresh_initialisation_honours_hps_gain_init():
+    """cond_utils.py:102-112, 361-366: the per-ISO gain tables of sdn2 / sdn3 / gain2 start at hps.gain_init / 0.1 (sidd/ArgParser.py:
+    --gain_init, default -5.0), not at a hard-coded -5."""
+    from noise_flow_amd import params
+    v = params.init_variables("sdn2|unc|gain2", 4, 4, 0)
+    assert float(v["model/gain_param_00800"][0]) == -50.0
+    v = params.init_variables("sdn2|unc|gain2", 4, 4, 0, gain_init=-3.0)
+    assert all(float(v["model/gain_param_%05d" % iso][0]) == -30.0 for iso in (100, 400, 800, 1600, 3200))

@@ -784,3 +784,21 @@ def test_extreme_inputs_stay_finite_and_match(shipped_variables, oracle_full):
     # 6-sigma latents are amplified ~1000x through the eight inverse 1x1 / coupling pairs: fp32 round-off
     # of the intermediate values (not of the output scale) sets the error here, 3.4e-5 measured
     _close_elem(xs, oracle_full.sample(eps, 1.0, y, 100, 2), rtol=1e-4)
+
+
+def test_per_patch_temperature_draws_the_kernels_own_philox_stream(shipped_variables):
+    """eps_std with one temperature PER PATCH (the reference reshapes it to [-1,1,1,1], noise_flow_model.py:499-504): the draw
+    is the library's Philox stream (nf_sample_eps), keyed like the in-kernel one — so a seed gives the same noise whether the
+    temperature is one number or the same number per patch, and the running patch counter advances identically."""
+    m = _model(FULL_ARCH, shipped_variables)
+    _, y = make_inputs(6, seed=21)
+    m._draws = 40
+    a = m.sample(y, 0.7, y, [0.0], [0.0], [100], [2], seed=13)
+    assert m._draws == 46
+    m._draws = 40
+    b = m.sample(y, np.full(6, 0.7, np.float32), y, [0.0], [0.0], [100], [2], seed=13)
+    assert m._draws == 46 and isinstance(b, np.ndarray)
+    m._draws = 40
+    c = m.sample(y, np.asarray([0.7, 0.7, 0.7, 0.2, 0.7, 0.7], np.float32), y, [0.0], [0.0], [100], [2], seed=13)
+    assert np.array_equal(a, b)
+    assert np.array_equal(a[[0, 1, 2, 4, 5]], c[[0, 1, 2, 4, 5]]) and np.abs(c[3]).max() < np.abs(a[3]).max()

@@ -481,6 +481,46 @@ def test_two_rank_sync_bn_step_equals_one_rank_on_the_concatenated_batch(tmp_pat
     assert np.abs(q0[mask] - np.asarray(P.pack_layers(one.layers, v, 4, one._tmpl)[2])[mask]).max() > 1e-3   # they did move
 
 
+def _unequal_worker(rank, world, port, outdir):
+    import sys
+    import torch.distributed as dist
+    from conftest import ROOT, make_inputs, trained_like_variables
+    sys.path.insert(0, ROOT)
+    from noise_flow_amd import default_hps
+    from noise_flow_amd.train import Trainer
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    tr = Trainer([16, 16, 4], default_hps(arch=DP_ARCH), variables=trained_like_variables(DP_ARCH, 4, seed=9), max_batch=8)
+    n = 8 - rank                                        # 8 patches on rank 0, 7 on rank 1
+    x, y = make_inputs(n, 16, 16, seed=3 + rank, b1=0.003696)
+    msg = ""
+    try:
+        tr.step(x, y, [0.0], [0.0], [800], [2], lr=1e-3, group=True, sync_bn=True, sync=True)
+    except ValueError as e:
+        msg = str(e)
+    open(os.path.join(outdir, "unequal_%d.txt" % rank), "w").write(msg)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sync_bn_rejects_unequal_shards(tmp_path):
+    """Synchronised BN forms the global moments with world x the LOCAL pixel count: ranks that feed different numbers of
+    patches would silently get wrong moments and gradients — the step reports it instead (one 16-byte MAX all-reduce)."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_unequal_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    [p.start() for p in procs]
+    [p.join(timeout=300) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    for r in range(2):
+        msg = open(os.path.join(str(tmp_path), "unequal_%d.txt" % r)).read()
+        assert "same number of patches on every rank" in msg and "between 7 and 8" in msg, msg
+
+
 def test_two_rank_sync_bn_at_width_32(tmp_path):
     """The same property on the matrix-core stage kernels (width 32): behind a cross-rank all-reduce the statistics are
     finalised by k_bn_fin / k_bnb_fin from the scattered totals; 2 ranks x 6 patches of 16x16 = 1 rank on the 12."""
