@@ -242,6 +242,17 @@ int nf_sample_batchstats(nf_handle *h, const float *y, const float *eps, uint64_
                          int64_t patch_index_base, float temp, int64_t B, const nf_cond *cond,
                          float *x_out, float *moments_out, void *stream);
 
+/* Cross-rank batch statistics for nf_nll_batchstats / nf_sample_batchstats: the reference's batch_norm takes its moments over
+ * the WHOLE minibatch (layers.py:386-398), which under data parallelism is the union of the ranks' shards.  With a callback
+ * installed the library calls fn(user, sync_buf, count, stream) after every statistics pass (2 per coupling): sync_buf (DEVICE,
+ * caller-owned, >= 64 doubles) holds this rank's `count` sums, written by work already enqueued on `stream`; the callback must
+ * enqueue a SUM all-reduce over the ranks so that later work on `stream` sees the totals, and return 0 (the contract of
+ * nf_trainer_set_sync, declared below with nf_allreduce_fn).  Every rank must call with the same B; the moments then use
+ * world_size x the local pixel count, and every rank normalises with the same, global moments — N ranks x B patches evaluate
+ * exactly like one rank on the N*B concatenated patches.  fn = NULL removes the hook. */
+typedef int (*nf_allreduce_fn)(void *user, double *buf, int64_t count, void *stream);
+int nf_set_sync(nf_handle *h, nf_allreduce_fn fn, void *user, double *sync_buf, int32_t world_size);
+
 /* ---- Training step ------------------------------------------------------
  * Replaces `sess.run([train_op, loss, sd_z], {..., is_training: True})` (train_noise_flow.py:64-66)
  * with `train_op = AdamOptimizer(lr, 0.9, 0.999, 1e-8).minimize(loss)` or
@@ -297,7 +308,6 @@ int nf_trainer_forward(nf_trainer *t, const float *x, const float *y, int64_t B,
  * `stream` afterwards sees the totals (RCCL on that stream, or any blocking implementation), and return 0.  Every rank
  * must call with the same batch size; moments then use world_size x the local pixel count.  The gradient all-reduce
  * between forward_backward and apply stays the caller's.  fn = NULL removes the hook. */
-typedef int (*nf_allreduce_fn)(void *user, double *buf, int64_t count, void *stream);
 int nf_trainer_set_sync(nf_trainer *t, nf_allreduce_fn fn, void *user, double *sync_buf, int32_t world_size);
 /* One optimizer update from `grads` (DEVICE float[n_params]; NULL = the trainer's own buffer). */
 int nf_trainer_apply(nf_trainer *t, const float *grads, float lr, void *stream);

@@ -30,6 +30,8 @@ bool nf_gemm_shape_ok(int H, int W);
 hipError_t nf_launch_synth(uint64_t seed, int64_t patch_base, int64_t B, int HW, float beta1, float beta2,
                            float *y_out, float *x_out, hipStream_t stream);
 hipError_t nf_launch_eps(uint64_t seed, int64_t patch_base, int64_t B, int HW, float *eps_out, hipStream_t stream);
+hipError_t nf_launch_stats_compact(const double *stats, int nvals, double *buf, hipStream_t stream);
+hipError_t nf_launch_stats_scatter(double *stats, int nvals, const double *buf, hipStream_t stream);
 hipError_t nf_launch_sums_reduce(const double *wide, double *out3, bool accumulate, hipStream_t stream);
 hipError_t nf_launch_bs_finalize(double *stats, int w, double n, float *Wm, int rows, float *Bv, float *mean_out, float *var_out,
                                  hipStream_t stream);
@@ -1073,6 +1075,11 @@ struct nf_handle {
     std::vector<float> raw;
     std::mutex bs_mu;
     struct nf_bs_state *bs = nullptr;
+    // cross-rank batch statistics of nf_*_batchstats (nf_set_sync)
+    nf_allreduce_fn sync_fn = nullptr;
+    void *sync_user = nullptr;
+    double *sync_buf = nullptr;
+    int sync_world = 1;
 };
 
 int nf_handle_geometry(const nf_handle *h, int32_t *H, int32_t *W, int32_t *device)
@@ -1630,6 +1637,20 @@ static int bs_build_plan(nf_handle *h, int direction, BsPlan &P)
     return NF_OK;
 }
 
+// all-reduce the `nvals` slotted sums of one statistics pass over the ranks (no-op without nf_set_sync): the totals come
+// back as slot 0, so the consumer — the next launch's prologue or nf_bs_finalize — needs no other change than n x world
+static int bs_sync(nf_handle *h, double *stats, int nvals, hipStream_t st)
+{
+    if (!h->sync_fn || h->sync_world < 2) return NF_OK;
+    if (nvals > 64) return fail(NF_EINVAL, "cross-rank batch statistics cover coupling widths up to 32");
+    hipError_t e = nf_launch_stats_compact(stats, nvals, h->sync_buf, st);
+    if (e != hipSuccess) return fail_hip(e, "batch-statistics compaction");
+    const int rc = h->sync_fn(h->sync_user, h->sync_buf, (int64_t)nvals, (void *)st);
+    if (rc != 0) return fail(NF_EINVAL, "the all-reduce callback of nf_set_sync failed (status %d)", rc);
+    if ((e = nf_launch_stats_scatter(stats, nvals, h->sync_buf, st)) != hipSuccess) return fail_hip(e, "batch-statistics scatter");
+    return NF_OK;
+}
+
 static int run_batchstats(nf_handle *h, int direction, NfLaunch a, float *moments_out, hipStream_t st)
 {
     if (h->cfg.flags & NF_CFG_FP16_CNN) return fail(NF_EINVAL, "batch-statistics mode is fp32 only");
@@ -1708,7 +1729,7 @@ static int run_batchstats(nf_handle *h, int direction, NfLaunch a, float *moment
         }
         if ((e = hipMemsetAsync(S.d_stats_mc, 0, passes * NF_STATS_SLOTS * 8 * sizeof(double), st)) != hipSuccess)
             return fail_hip(e, "batch-statistics set-up");
-        const double n = (double)a.B * a.H * a.W;
+        const double n = (double)a.B * a.H * a.W * h->sync_world;   // with nf_set_sync the moments are over all ranks' patches
         const float *cur = P.d_ident2;          // parameter block the next launch reads
         float *bufs[2] = {S.d_work2, S.d_work2b};
         int nbuf = 0;
@@ -1757,6 +1778,10 @@ static int run_batchstats(nf_handle *h, int direction, NfLaunch a, float *moment
                     s.ld_carry = S.d_carry;
                 }
                 if ((e = launch(prog, s)) != hipSuccess) return fail_hip(e, "batch-statistics launch");
+                {
+                    const int rc = bs_sync(h, s.stats, 8, st);
+                    if (rc != NF_OK) return rc;
+                }
                 pend_stats = s.stats;
                 pend_off = P.ident.prog2.ops[P.cpl_ops[c]].off;
                 pend_stage = stage;
@@ -1796,7 +1821,7 @@ static int run_batchstats(nf_handle *h, int direction, NfLaunch a, float *moment
         (e = hipMemsetAsync(S.d_stats, 0, NF_STATS_SLOTS * 2 * (size_t)w * sizeof(double), st)) != hipSuccess)
         return fail_hip(e, "batch-statistics set-up");
 
-    const double n = (double)a.B * a.H * a.W;
+    const double n = (double)a.B * a.H * a.W * h->sync_world;
     const double ld_call = a.ld_const;
     const float *const in0 = a.in;
     const float in_scale0 = a.in_scale;
@@ -1826,6 +1851,10 @@ static int run_batchstats(nf_handle *h, int direction, NfLaunch a, float *moment
                 s.ld_carry = S.d_carry;
             }
             if ((e = nf_launch_flow(prog, s, h->n_cu, st, false)) != hipSuccess) return fail_hip(e, "batch-statistics launch");
+            {
+                const int rc = bs_sync(h, S.d_stats, 2 * w, st);
+                if (rc != NF_OK) return rc;
+            }
             float *Wm = S.d_work + blk + (stage == 1 ? nf_cpl_off_W1(w) : nf_cpl_off_W2(w));
             float *Bv = S.d_work + blk + (stage == 1 ? nf_cpl_off_B1(w) : nf_cpl_off_B2(w));
             if ((e = nf_launch_bs_finalize(S.d_stats, w, n, Wm, stage == 1 ? 18 : w, Bv, mom + (stage == 1 ? 0 : 2 * w),
@@ -1893,6 +1922,18 @@ int nf_sample_batchstats(nf_handle *h, const float *y, const float *eps, uint64_
     DeviceGuard guard;
     if ((rc = guard.enter(h->device)) != NF_OK) return rc;
     return run_batchstats(h, 1, a, moments_out, (hipStream_t)stream);
+}
+
+int nf_set_sync(nf_handle *h, nf_allreduce_fn fn, void *user, double *sync_buf, int32_t world_size)
+{
+    if (!h) return fail(NF_EINVAL, "handle is NULL");
+    if (fn && (!sync_buf || world_size < 1)) return fail(NF_EINVAL, "nf_set_sync needs a device buffer of 64 doubles and world_size >= 1");
+    std::lock_guard<std::mutex> lock(h->bs_mu);
+    h->sync_fn = fn;
+    h->sync_user = user;
+    h->sync_buf = fn ? sync_buf : nullptr;
+    h->sync_world = fn ? world_size : 1;
+    return NF_OK;
 }
 
 int nf_sums_reduce(const double *wide, double *out3, uint32_t flags, void *stream)

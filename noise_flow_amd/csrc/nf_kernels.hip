@@ -1091,6 +1091,24 @@ __global__ __launch_bounds__(256) void nf_synth_kernel(uint64_t seed, int64_t pa
     }
 }
 
+// cross-rank batch statistics (nf_set_sync): slotted fp64 sums [NF_STATS_SLOTS][nvals] -> totals in `buf`, and back as
+// slot 0 = the all-reduced total, every other slot 0 (the consumers add the slots up)
+__global__ __launch_bounds__(64) void nf_stats_compact_kernel(const double *__restrict__ stats, int nvals, double *__restrict__ buf)
+{
+    const int j = threadIdx.x;
+    if (j >= nvals) return;
+    double s = 0.0;
+    for (int k = 0; k < NF_STATS_SLOTS; ++k) s += stats[(size_t)k * nvals + j];
+    buf[j] = s;
+}
+__global__ __launch_bounds__(64) void nf_stats_scatter_kernel(double *__restrict__ stats, int nvals, const double *__restrict__ buf)
+{
+    const int j = threadIdx.x;
+    if (j >= nvals) return;
+    stats[j] = buf[j];
+    for (int k = 1; k < NF_STATS_SLOTS; ++k) stats[(size_t)k * nvals + j] = 0.0;
+}
+
 // the N(0,1) draw the flow kernels make in-kernel for sampling (stream NF_STREAM_SAMP), written out (nf_sample_eps)
 __global__ __launch_bounds__(256) void nf_eps_kernel(uint64_t seed, int64_t patch_base, int64_t B, int HW, float *__restrict__ eps_out)
 {
@@ -1239,6 +1257,17 @@ hipError_t nf_launch_gather(float *dst, const float *src, const int32_t *pairs, 
 hipError_t nf_launch_sums_reduce(const double *wide, double *out3, bool accumulate, hipStream_t stream)
 {
     hipLaunchKernelGGL(nf_sums_reduce_kernel, dim3(1), dim3(64), 0, stream, wide, out3, accumulate ? 1 : 0);
+    return hipGetLastError();
+}
+
+hipError_t nf_launch_stats_compact(const double *stats, int nvals, double *buf, hipStream_t stream)
+{
+    hipLaunchKernelGGL(nf_stats_compact_kernel, dim3(1), dim3(64), 0, stream, stats, nvals, buf);
+    return hipGetLastError();
+}
+hipError_t nf_launch_stats_scatter(double *stats, int nvals, const double *buf, hipStream_t stream)
+{
+    hipLaunchKernelGGL(nf_stats_scatter_kernel, dim3(1), dim3(64), 0, stream, stats, nvals, buf);
     return hipGetLastError();
 }
 

@@ -250,6 +250,40 @@ class NoiseFlow(object):
                                 self._dev.device.index, cnn_dtype=self.cnn_dtype, flow_permutation=self.flow_permutation,
                                 decomp=self.decomp)
         old.close()
+        if getattr(self, "_sync", None) is not None:
+            self._install_sync()
+
+    # ------------------------------------------------------------------ cross-rank batch statistics (is_training=True)
+    def set_sync_bn(self, group=None, enabled: bool = True) -> None:
+        """Batch-statistics calls (``is_training=True``) across ranks: the reference's ``batch_norm`` takes its moments over the
+        whole minibatch (layers.py:386-398), which under data parallelism is the union of the ranks' shards.  Installs the
+        all-reduce hook of ``nf_set_sync`` for ``group`` (``None`` / ``True`` = the default process group): every statistics
+        pass (2 per coupling) all-reduces its sums, so N ranks x B patches evaluate exactly like one rank on the N*B
+        concatenated patches — same moments, same running-statistics EMA on every rank.  Every rank must call with the same B."""
+        import torch.distributed as dist
+        grp = None if group in (None, True) else group
+        self._sync = None
+        if enabled and dist.is_available() and dist.is_initialized() and dist.get_world_size(grp) > 1:
+            torch = self._dev.torch
+            buf = torch.zeros((64,), dtype=torch.float64, device=self._dev.device)
+            err = []
+
+            def allreduce(user, ptr, count, stream):
+                try:   # `ptr` is buf's storage; the library wrote this rank's sums on torch's current stream
+                    dist.all_reduce(buf[:int(count)], op=dist.ReduceOp.SUM, group=grp)
+                    return 0
+                except Exception as e:   # never let an exception cross the C frame
+                    err.append(e)
+                    return 1
+            self._sync = (_lib.ALLREDUCE_FN(allreduce), buf, dist.get_world_size(grp), err)
+        self._install_sync()
+
+    def _install_sync(self):
+        sync = getattr(self, "_sync", None)
+        if sync is None:
+            _lib.check(self._flow.lib.nf_set_sync(self._flow.ptr, _lib.ALLREDUCE_FN(0), None, None, 1))
+        else:
+            _lib.check(self._flow.lib.nf_set_sync(self._flow.ptr, sync[0], None, sync[1].data_ptr(), sync[2]))
 
     def restore(self, ckpt_prefix: str, binding: Optional[str] = None) -> None:
         """``saver.restore(sess, prefix)`` (NoiseFlowWrapper.py:77) on a TF bundle, without TF."""

@@ -173,3 +173,68 @@ def test_batchstats_c_abi_errors(shipped_variables):
     assert rc == 0
     torch.cuda.synchronize()
     assert torch.isfinite(out).all()
+
+
+def _bs_sync_worker(rank, world, port, outdir, arch, width, hw, per):
+    """One rank of a batch-statistics evaluation with cross-rank moments (NoiseFlow.set_sync_bn -> nf_set_sync)."""
+    import os
+    import sys
+    import torch.distributed as dist
+    from conftest import ROOT, make_inputs, trained_like_variables
+    sys.path.insert(0, ROOT)
+    from noise_flow_amd import NoiseFlow, default_hps
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    v = trained_like_variables(arch, width, seed=4)
+    m = NoiseFlow([hw, hw, 4], True, default_hps(arch=arch, width=width), variables=v)
+    m.set_sync_bn(True)
+    x, y = make_inputs(per * world, hw, hw, seed=31, b1=0.003696)
+    sl = slice(per * rank, per * rank + per)
+    nll, sd = m._loss(x[sl], y[sl], [0.0], [0.0], [800], [2])
+    eps = np.random.RandomState(5).randn(per * world, hw, hw, 4).astype(np.float32)
+    xs = m.sample(y[sl], 0.8, y[sl], [0.0], [0.0], [800], [2], eps=eps[sl])
+    np.save(os.path.join(outdir, "bs_nll_%d.npy" % rank), nll)
+    np.save(os.path.join(outdir, "bs_xs_%d.npy" % rank), xs)
+    np.savez(os.path.join(outdir, "bs_bn_%d.npz" % rank), **{k.replace("/", "!"): a for k, a in m.variables.items() if "bn_nvp_conv" in k})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("arch,width,hw,per", [("sdn5|unc|unc|gain4|unc", 4, 32, 6), ("sdn5|unc|gain4|unc", 16, 16, 5)])
+def test_two_rank_batch_statistics_evaluation_equals_one_rank_on_the_union(tmp_path, arch, width, hw, per):
+    """`is_training=True` forward / sampling across ranks (layers.py:386-398: the moments are those of the whole minibatch):
+    with the nf_set_sync hook, 2 ranks x `per` patches give per-patch NLLs, samples and running-statistics updates equal to
+    one rank on the 2*per concatenated patches — on the fused width-4 path and on the generic (width 16) path."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_bs_sync_worker, args=(r, 2, port, str(tmp_path), arch, width, hw, per)) for r in range(2)]
+    [p.start() for p in procs]
+    [p.join(timeout=300) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    v = trained_like_variables(arch, width, seed=4)
+    x, y = make_inputs(per * 2, hw, hw, seed=31, b1=0.003696)
+    one = _model(arch, v, (hw, hw, 4), width)
+    nll1, _ = one._loss(x, y, [0.0], [0.0], [800], [2])
+    bn_after_nll = {k: np.array(a) for k, a in one.variables.items() if "bn_nvp_conv" in k}
+    eps = np.random.RandomState(5).randn(per * 2, hw, hw, 4).astype(np.float32)
+    xs1 = one.sample(y, 0.8, y, [0.0], [0.0], [800], [2], eps=eps)
+    nll2 = np.concatenate([np.load(str(tmp_path / ("bs_nll_%d.npy" % r))) for r in range(2)])
+    xs2 = np.concatenate([np.load(str(tmp_path / ("bs_xs_%d.npy" % r))) for r in range(2)])
+    np.testing.assert_allclose(nll2, nll1, rtol=NLL_RTOL)
+    _close_elem(xs2, xs1.astype(np.float64))
+    # without the hook the shards normalise with their own moments: measurably different
+    half = _model(arch, v, (hw, hw, 4), width)
+    nll_h, _ = half._loss(x[:per], y[:per], [0.0], [0.0], [800], [2])
+    assert np.abs(nll_h - nll1[:per]).max() > 1e-4 * np.abs(nll1).max()
+    # both ranks moved their running statistics identically, by the GLOBAL moments (2 EMA steps: _loss, then sample)
+    bn0, bn1 = (np.load(str(tmp_path / ("bs_bn_%d.npz" % r))) for r in range(2))
+    final = {k: np.array(a) for k, a in one.variables.items() if "bn_nvp_conv" in k}
+    for k, a in final.items():
+        kk = k.replace("/", "!")
+        assert np.array_equal(bn0[kk], bn1[kk]), k
+        assert np.abs(bn0[kk] - a).max() <= 1e-5 * max(np.abs(a).max(), 1e-3), k
+        assert np.abs(a - bn_after_nll[k]).max() > 0 or "var" in k
