@@ -186,8 +186,9 @@ __host__ __device__ constexpr int nf4_chan(int v, int g) { return 8 * (v >> 2) +
 //     B2 [MT][2][16]
 //     A2 [MT][WP/8][64][4]   l_2 of output tile m: K step kk = 4 kc + s consumes input tile kk / 16, register kk % 16:
 //                            lane l: W2[in = 32 (kk/16) + c(kk%16, l>>5)][out = 32 m + (l&31)]
-//     A3 [2][MT][4][64][4]   l_last as P = W3^T h2, P tile pt: row i = 32 pt + (l&31) = 4 tap + j (36 rows used); step v of
-//                            input tile mi: W3[tap][in = 32 mi + c(v, l>>5)][j]   (raw columns j >= 2 pre-scaled by 2 log2 e)
+//     A3 [MT][4][64][4]      l_last as P = W3^T h2, taps 0 .. 7: row i = l&31 = 4 tap + j; step v of input tile mi:
+//                            W3[tap][in = 32 mi + c(v, l>>5)][j]   (raw columns j >= 2 pre-scaled by 2 log2 e)
+//     A3C[MT][4][8][4]       tap 8 on v_mfma_f32_4x4x1: step v = 4 grp + s of input tile mi, (g, j): W3[8][32 mi + c(v, g)][j]
 #define NF7_CPL_E 0
 #define NF7_CPL_S 64
 #define NF7_CPL_IMG 68
@@ -197,7 +198,9 @@ __host__ __device__ constexpr int nf7_img_B1(int wp) { return (wp / 32) * 768; }
 __host__ __device__ constexpr int nf7_img_B2(int wp) { return (wp / 32) * 800; }
 __host__ __device__ constexpr int nf7_img_A2(int wp) { return (wp / 32) * 832; }
 __host__ __device__ constexpr int nf7_img_A3(int wp) { return (wp / 32) * 832 + wp * wp; }
-__host__ __device__ constexpr int nf7_img_size(int wp) { return (wp / 32) * 832 + wp * wp + 2 * (wp / 32) * 1024; }
+__host__ __device__ constexpr int nf7_img_A3C(int wp) { return (wp / 32) * 832 + wp * wp + (wp / 32) * 1024; }
+__host__ __device__ constexpr int nf7_img_size(int wp) { return (wp / 32) * 832 + wp * wp + (wp / 32) * (1024 + 128); }
+#define NF7_P_STRIDE 44          // floats per pixel of a partial P tile in LDS: 8 taps x 4, tap 8 of lane half 0 / 1, pad (conflict-free)
 __host__ __device__ constexpr int nf7_cpl_size(int wp) { return NF7_CPL_IMG + nf7_img_size(wp); }
 #define NF7_BAND_FLOATS 32768   // hidden activations of one band: WP channels x NB pixels (128 KiB of LDS)
 #define NF7_MAX_PIXELS 2048     // pixels per patch the GEMM kernel holds (4 per thread)

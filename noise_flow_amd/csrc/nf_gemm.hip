@@ -56,11 +56,12 @@ __global__ __launch_bounds__(GT) void nf_gemm_kernel(const NfProgram prog, const
     constexpr int WM = MT / 2;             // wavefronts along the channel axis of l_2 (2 tiles each)
     constexpr int WN = GW / WM;            // wavefronts along the pixel axis (2 tiles each)
     constexpr int KC = WP / 8;             // chunks of 4 K steps (8 input channels)
-    static_assert(MT * NT == 32 && WM * WN == GW && NT == 2 * WN, "tile split");
+    static_assert(MT * NT == 32 && WM * WN == GW && NT == 2 * WN && KC % 2 == 0, "tile split");
+    static_assert(WM * NB * NF7_P_STRIDE <= NF7_BAND_FLOATS, "the partial P tiles reuse the h1 region");
     const int H = a.H, W = a.W, HW = H * W;
     const int Wp = W + 2;
     const int PL = ((H + 2) * Wp + 3) & ~3;            // one channel plane of the z0 tile
-    float *const h1 = smem;                             // [KC][2][NB][4]; later the partial P tiles [WM][NB][36]
+    float *const h1 = smem;                             // [KC][2][NB][4]; later the partial P tiles [WM][NB][NF7_P_STRIDE]
     float *const z0s = smem + NF7_BAND_FLOATS;          // [2][PL]
     float *const red = z0s + 2 * PL;                    // [3][GW]
 
@@ -199,64 +200,83 @@ __global__ __launch_bounds__(GT) void nf_gemm_kernel(const NfProgram prog, const
                         const float *ap1 = img + nf7_img_A2(WP) + ((size_t)(2 * wm + 1) * KC * 64 + lane) * 4;
                         const float *bp0 = h1 + (g * NB + 32 * (2 * wn + 0) + n) * 4;
                         const float *bp1 = h1 + (g * NB + 32 * (2 * wn + 1) + n) * 4;
-                        float4 a0 = ldg4(ap0), a1 = ldg4(ap1);
-                        float4 b0 = *reinterpret_cast<const float4 *>(bp0), b1 = *reinterpret_cast<const float4 *>(bp1);
-#pragma unroll 2
-                        for (int kc = 0; kc < KC; ++kc) {
-                            const int kn = kc + 1 < KC ? kc + 1 : kc;
-                            const float4 na0 = ldg4(ap0 + (size_t)kn * 256), na1 = ldg4(ap1 + (size_t)kn * 256);
-                            const float4 nb0 = *reinterpret_cast<const float4 *>(bp0 + (size_t)kn * 2 * NB * 4);
-                            const float4 nb1 = *reinterpret_cast<const float4 *>(bp1 + (size_t)kn * 2 * NB * 4);
-                            const float as0[4] = {a0.x, a0.y, a0.z, a0.w}, as1[4] = {a1.x, a1.y, a1.z, a1.w};
-                            const float bs0[4] = {b0.x, b0.y, b0.z, b0.w}, bs1[4] = {b1.x, b1.y, b1.z, b1.w};
-#pragma unroll
-                            for (int s = 0; s < 4; ++s) {
-                                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(as0[s], bs0[s], acc[0][0], 0, 0, 0);
-                                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(as0[s], bs1[s], acc[0][1], 0, 0, 0);
-                                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(as1[s], bs0[s], acc[1][0], 0, 0, 0);
-                                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(as1[s], bs1[s], acc[1][1], 0, 0, 0);
-                            }
-                            a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+                        // Software pipeline over K chunks of 4 steps, two operand sets in ping-pong: the loads of chunk kc + 1 are
+                        // ISSUED before the 16 MFMAs of chunk kc.  The scheduling barriers keep it that way — left alone, the
+                        // machine scheduler sinks every load to just before its first use (measured: 0.72 of peak with the loads
+                        // 4 MFMAs ahead of their use, an L2 hit being ~20 MFMAs away).
+                        float4 xa0 = ldg4(ap0), xa1 = ldg4(ap1);
+                        float4 xb0 = *reinterpret_cast<const float4 *>(bp0), xb1 = *reinterpret_cast<const float4 *>(bp1);
+                        float4 ya0, ya1, yb0, yb1;
+#define NF_GEMM_CHUNK(A0, A1, B0, B1)                                                                              \
+    {                                                                                                              \
+        const float as0[4] = {A0.x, A0.y, A0.z, A0.w}, as1[4] = {A1.x, A1.y, A1.z, A1.w};                          \
+        const float bs0[4] = {B0.x, B0.y, B0.z, B0.w}, bs1[4] = {B1.x, B1.y, B1.z, B1.w};                          \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                              \
+        {                                                                                                          \
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(as0[s], bs0[s], acc[0][0], 0, 0, 0);                  \
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(as0[s], bs1[s], acc[0][1], 0, 0, 0);                  \
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(as1[s], bs0[s], acc[1][0], 0, 0, 0);                  \
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(as1[s], bs1[s], acc[1][1], 0, 0, 0);                  \
+        }                                                                                                          \
+    }
+#pragma unroll 1
+                        for (int kc = 0; kc < KC; kc += 2) {
+                            const int k1 = kc + 1, k2 = kc + 2 < KC ? kc + 2 : KC - 1;
+                            ya0 = ldg4(ap0 + (size_t)k1 * 256);
+                            ya1 = ldg4(ap1 + (size_t)k1 * 256);
+                            yb0 = *reinterpret_cast<const float4 *>(bp0 + (size_t)k1 * 2 * NB * 4);
+                            yb1 = *reinterpret_cast<const float4 *>(bp1 + (size_t)k1 * 2 * NB * 4);
+                            __builtin_amdgcn_sched_barrier(0);
+                            NF_GEMM_CHUNK(xa0, xa1, xb0, xb1)
+                            __builtin_amdgcn_sched_barrier(0);
+                            xa0 = ldg4(ap0 + (size_t)k2 * 256);
+                            xa1 = ldg4(ap1 + (size_t)k2 * 256);
+                            xb0 = *reinterpret_cast<const float4 *>(bp0 + (size_t)k2 * 2 * NB * 4);
+                            xb1 = *reinterpret_cast<const float4 *>(bp1 + (size_t)k2 * 2 * NB * 4);
+                            __builtin_amdgcn_sched_barrier(0);
+                            NF_GEMM_CHUNK(ya0, ya1, yb0, yb1)
+                            __builtin_amdgcn_sched_barrier(0);
                         }
+#undef NF_GEMM_CHUNK
                     }
-                    // ---- P = W3^T relu(h2): this wavefront's 64 channels, both P tiles (36 of 64 rows used) ----
-                    v16f pa[2][2];
+                    // ---- P = W3^T relu(h2): this wavefront's 64 channels; taps 0 .. 7 as one 32-row tile, tap 8 on 4x4x1 ----
+                    v16f pa[2];
+                    v4f p8[2];
 #pragma unroll
-                    for (int pt = 0; pt < 2; ++pt)
+                    for (int ni = 0; ni < 2; ++ni) {
 #pragma unroll
-                        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                            for (int v = 0; v < 16; ++v) pa[pt][ni][v] = 0.0f;
+                        for (int v = 0; v < 16; ++v) pa[ni][v] = 0.0f;
+                        p8[ni] = v4f{0.f, 0.f, 0.f, 0.f};
+                    }
 #pragma unroll
                     for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
                         for (int grp = 0; grp < 4; ++grp) {
-                            const float4 w0 = ldg4(img + nf7_img_A3(WP) + ((((0 * MT + 2 * wm + mi) * 4 + grp) * 64) + lane) * 4);
-                            const float4 w1 = ldg4(img + nf7_img_A3(WP) + ((((1 * MT + 2 * wm + mi) * 4 + grp) * 64) + lane) * 4);
-                            const float ws0[4] = {w0.x, w0.y, w0.z, w0.w}, ws1[4] = {w1.x, w1.y, w1.z, w1.w};
+                            const float4 w0 = ldg4(img + nf7_img_A3(WP) + ((((2 * wm + mi) * 4 + grp) * 64) + lane) * 4);
+                            const float4 wc = ldg4(img + nf7_img_A3C(WP) + ((((2 * wm + mi) * 4 + grp) * 8) + g * 4 + (lane & 3)) * 4);
+                            const float ws0[4] = {w0.x, w0.y, w0.z, w0.w}, wcs[4] = {wc.x, wc.y, wc.z, wc.w};
 #pragma unroll
                             for (int s = 0; s < 4; ++s) {
                                 const float hA = nf_relu(acc[mi][0][grp * 4 + s]), hB = nf_relu(acc[mi][1][grp * 4 + s]);
-                                pa[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws0[s], hA, pa[0][0], 0, 0, 0);
-                                pa[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws0[s], hB, pa[0][1], 0, 0, 0);
-                                pa[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws1[s], hA, pa[1][0], 0, 0, 0);
-                                pa[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws1[s], hB, pa[1][1], 0, 0, 0);
+                                pa[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws0[s], hA, pa[0], 0, 0, 0);
+                                pa[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws0[s], hB, pa[1], 0, 0, 0);
+                                p8[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(wcs[s], hA, p8[0], 0, 0, 0);
+                                p8[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wcs[s], hB, p8[1], 0, 0, 0);
                             }
                         }
                     }
                     __syncthreads();   // every wavefront is done with h1: the region becomes the partial P tiles
 
-                    // rows 4 tap + j of P: register group a of lane half g of tile pt holds tap 8 pt + 2 a + g (j = 0..3)
-                    float *const pp = h1;   // [WM][NB][36]
+                    // per pixel [tap 0..7][j] (register group a of lane half g holds tap 2 a + g), then tap 8 of lane half 0 / 1
+                    float *const pp = h1;   // [WM][NB][NF7_P_STRIDE]
 #pragma unroll
                     for (int ni = 0; ni < 2; ++ni) {
-                        float *dst = pp + ((size_t)(wm * NB + 32 * (2 * wn + ni) + n)) * 36;
+                        float *dst = pp + ((size_t)(wm * NB + 32 * (2 * wn + ni) + n)) * NF7_P_STRIDE;
 #pragma unroll
                         for (int aa = 0; aa < 4; ++aa)
                             *reinterpret_cast<float4 *>(dst + (2 * aa + g) * 4) =
-                                make_float4(pa[0][ni][4 * aa + 0], pa[0][ni][4 * aa + 1], pa[0][ni][4 * aa + 2], pa[0][ni][4 * aa + 3]);
-                        if (g == 0)
-                            *reinterpret_cast<float4 *>(dst + 8 * 4) = make_float4(pa[1][ni][0], pa[1][ni][1], pa[1][ni][2], pa[1][ni][3]);
+                                make_float4(pa[ni][4 * aa + 0], pa[ni][4 * aa + 1], pa[ni][4 * aa + 2], pa[ni][4 * aa + 3]);
+                        *reinterpret_cast<float4 *>(dst + 32 + 4 * g) = make_float4(p8[ni][0], p8[ni][1], p8[ni][2], p8[ni][3]);
                     }
                     __syncthreads();
 
@@ -276,7 +296,12 @@ __global__ __launch_bounds__(GT) void nf_gemm_kernel(const NfProgram prog, const
                                 if (cc < 0 || cc >= W || src < 0 || src >= NB) continue;
 #pragma unroll
                                 for (int k = 0; k < WM; ++k) {
-                                    const float4 v = *reinterpret_cast<const float4 *>(pp + ((size_t)(k * NB + src)) * 36 + (di * 3 + dj) * 4);
+                                    const float *rec = pp + ((size_t)(k * NB + src)) * NF7_P_STRIDE;
+                                    float4 v = *reinterpret_cast<const float4 *>(rec + (di * 3 + dj) * 4);
+                                    if (di * 3 + dj == 8) {   // tap 8: the two lane halves' partial sums
+                                        const float4 u = *reinterpret_cast<const float4 *>(rec + 36);
+                                        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+                                    }
                                     o[m][0] += v.x; o[m][1] += v.y; o[m][2] += v.z; o[m][3] += v.w;
                                 }
                             }

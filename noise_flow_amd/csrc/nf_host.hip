@@ -426,18 +426,26 @@ void relayout_coupling_gemm(const float *v1, int w, int wp, float *out)
                     img[nf7_img_A2(wp) + (((size_t)m * KC + kc) * 64 + l) * 4 + s2] = (cin < w && oc < w) ? W2[(size_t)cin * w + oc] : 0.0f;
                 }
     }
-    for (int pt = 0; pt < 2; ++pt)                     // P = W3^T h2: row 32 pt + i = 4 tap + j
-        for (int mi = 0; mi < MT; ++mi)
-            for (int v = 0; v < 16; ++v)
-                for (int l = 0; l < 64; ++l) {
-                    const int row = 32 * pt + (l & 31), cin = 32 * mi + nf4_chan(v, l >> 5);
-                    double wv = 0.0;
-                    if (row < 36 && cin < w) {
-                        const int tap = row >> 2, j = row & 3;
-                        wv = W3[((size_t)tap * w + cin) * 4 + j];
-                        if (j >= 2) wv *= k2;
-                    }
-                    img[nf7_img_A3(wp) + ((((size_t)pt * MT + mi) * 4 + (v >> 2)) * 64 + l) * 4 + (v & 3)] = (float)wv;
+    for (int mi = 0; mi < MT; ++mi)                    // P = W3^T h2: taps 0 .. 7 as one 32-row GEMM (row i = 4 tap + j) ...
+        for (int v = 0; v < 16; ++v)
+            for (int l = 0; l < 64; ++l) {
+                const int row = l & 31, cin = 32 * mi + nf4_chan(v, l >> 5);
+                double wv = 0.0;
+                if (cin < w) {
+                    const int tap = row >> 2, j = row & 3;
+                    wv = W3[((size_t)tap * w + cin) * 4 + j];
+                    if (j >= 2) wv *= k2;
+                }
+                img[nf7_img_A3(wp) + (((size_t)mi * 4 + (v >> 2)) * 64 + l) * 4 + (v & 3)] = (float)wv;
+            }
+    for (int mi = 0; mi < MT; ++mi)                    // ... and tap 8 on v_mfma_f32_4x4x1 (4 rows, not a 32-row tile)
+        for (int v = 0; v < 16; ++v)
+            for (int g = 0; g < 2; ++g)
+                for (int j = 0; j < 4; ++j) {
+                    const int cin = 32 * mi + nf4_chan(v, g);
+                    double wv = cin < w ? (double)W3[((size_t)8 * w + cin) * 4 + j] : 0.0;
+                    if (j >= 2) wv *= k2;
+                    img[nf7_img_A3C(wp) + (((size_t)mi * 4 + (v >> 2)) * 8 + g * 4 + j) * 4 + (v & 3)] = (float)wv;
                 }
 }
 

@@ -317,7 +317,8 @@ def test_gemm_layout_emulated_lane_by_lane_matches_the_oracle_cnn(width):
     B1 = img[MT * 768:MT * 800].reshape(MT, 2, 16)
     B2 = img[MT * 800:MT * 832].reshape(MT, 2, 16)
     A2 = img[MT * 832:MT * 832 + wp * wp].reshape(MT, KC, 64, 4)
-    A3 = img[MT * 832 + wp * wp:MT * 832 + wp * wp + 2 * MT * 1024].reshape(2, MT, 4, 64, 4)
+    A3 = img[MT * 832 + wp * wp:MT * 832 + wp * wp + MT * 1024].reshape(MT, 4, 64, 4)
+    A3C = img[MT * 832 + wp * wp + MT * 1024:MT * 832 + wp * wp + MT * 1152].reshape(MT, 4, 8, 4)
     E = blk[off:off + 64].reshape(16, 4)
     rng = np.random.RandomState(1)
     z0 = rng.randn(H, W, 2)
@@ -346,17 +347,21 @@ def test_gemm_layout_emulated_lane_by_lane_matches_the_oracle_cnn(width):
             for kk in range(wp // 2):
                 d = _mfma_32x32x2(A2[m, kk >> 2, :, kk & 3], h1[kk // 16, kk % 16], d)
             h2[m] = np.maximum(d, 0)
-        # P tiles
-        for pt in range(2):
-            d = np.zeros((16, 64))
-            for mi in range(MT):
-                for vv in range(16):
-                    d = _mfma_32x32x2(A3[pt, mi, vv >> 2, :, vv & 3], h2[mi, vv], d)
+        # P: taps 0 .. 7 as one 32-row tile; tap 8 on v_mfma_f32_4x4x1 (lane l: D[v] += A[lane 4 (l // 4) + v] * B[l])
+        d = np.zeros((16, 64))
+        p8 = np.zeros((4, 64))
+        for mi in range(MT):
             for vv in range(16):
+                d = _mfma_32x32x2(A3[mi, vv >> 2, :, vv & 3], h2[mi, vv], d)
+                Av = np.array([A3C[mi, vv >> 2, (l >> 5) * 4 + (l & 3), vv & 3] for l in range(64)])
                 for l in range(64):
-                    row = 32 * pt + _chan(vv, l >> 5)
-                    if row < 36:
-                        P[nt * 32 + (l & 31), row] = d[vv, l]
+                    for v4 in range(4):
+                        p8[v4, l] += Av[4 * (l // 4) + v4] * h2[mi, vv, l]
+        for vv in range(16):
+            for l in range(64):
+                P[nt * 32 + (l & 31), _chan(vv, l >> 5)] = d[vv, l]
+        for l in range(64):
+            P[nt * 32 + (l & 31), 32:36] += p8[:, l]          # the two lane halves' partial sums of tap 8
     o = np.zeros((H, W, 4))
     for r in range(H):
         for c in range(W):
