@@ -3,7 +3,7 @@
 # Writes everything under gpurun_out/<tag>/; copy the summaries you want judged into profiles/.
 # Every counter pass is its own run with --kernel-trace only (never combined with other trace domains).
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
@@ -26,16 +26,25 @@ for pass in 1 2; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/sq_w32/p$pass -- python $R/tools/quick_time_wide.py 32 8192 32 4 > $OUT/sq_w32_p$pass.log 2>&1
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/sq_w16/p$pass -- python $R/tools/quick_time_wide.py 16 8192 32 4 > $OUT/sq_w16_p$pass.log 2>&1
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/sq_w32h/p$pass -- python $R/tools/quick_time_wide.py 32 8192 32 4 fp16 > $OUT/sq_w32h_p$pass.log 2>&1
+  B=512 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/sq_gemm512/p$pass -- python $R/tools/check_gemm.py 512 > $OUT/sq_gemm512_p$pass.log 2>&1
+  B=512 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/sq_gemm128/p$pass -- python $R/tools/check_gemm.py 128 > $OUT/sq_gemm128_p$pass.log 2>&1
 done
+# HBM traffic of the GEMM kernel at width 512 (weights are re-read per band from L2, not from HBM)
+B=512 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/gemm512_fetch -- python $R/tools/check_gemm.py 512 > $OUT/gemm512_fetch.log 2>&1
+B=512 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/gemm512_write -- python $R/tools/check_gemm.py 512 > $OUT/gemm512_write.log 2>&1
 cd $R
 python tools/pmc_report.py $OUT/sq_fp32 "nf_flow_kernel<4, 256, 4, false, true, true, 0, false>" 100000 > $OUT/sq_fp32_report.txt 2>&1
 python tools/pmc_report.py $OUT/sq_fp16 "nf_flow_kernel<4, 1024, 4, false, true, true, 1, false>" 100000 > $OUT/sq_fp16_report.txt 2>&1
 python tools/pmc_report.py $OUT/sq_w32 "nf_wide32_kernel" 100000 > $OUT/sq_w32_report.txt 2>&1
 python tools/pmc_report.py $OUT/sq_w16 "nf_wide16_kernel" 100000 > $OUT/sq_w16_report.txt 2>&1
 python tools/pmc_report.py $OUT/sq_w32h "nf_wide32_kernel" 100000 > $OUT/sq_w32h_report.txt 2>&1
+python tools/pmc_report.py $OUT/sq_gemm512 "nf_gemm_kernel<512" 100000 > $OUT/sq_gemm512_report.txt 2>&1
+python tools/pmc_report.py $OUT/sq_gemm128 "nf_gemm_kernel<128" 100000 > $OUT/sq_gemm128_report.txt 2>&1
+python tools/pmc_report.py $OUT/gemm512_fetch "nf_gemm_kernel<512" 100000 > $OUT/gemm512_traffic.txt 2>&1
+python tools/pmc_report.py $OUT/gemm512_write "nf_gemm_kernel<512" 100000 >> $OUT/gemm512_traffic.txt 2>&1
 F=$(find $OUT/pmc_fetch -name "*counter_collection.csv" | head -1); W=$(find $OUT/pmc_write -name "*counter_collection.csv" | head -1)
 python tools/make_traffic.py $F $W > $OUT/traffic.log 2>&1 && cp profiles/traffic.json $OUT/traffic.json
 K=$(find $OUT/kt -name "*kernel_stats.csv" | head -1); cp $K $OUT/kernel_stats.csv 2>/dev/null
 K=$(find $OUT/kt_full -name "*kernel_stats.csv" | head -1); cp $K $OUT/kernel_stats_all_sections.csv 2>/dev/null
 cp $F $OUT/pmc_fetch_counter_collection.csv; cp $W $OUT/pmc_write_counter_collection.csv
-for f in $OUT/sq_fp32_report.txt $OUT/sq_fp16_report.txt $OUT/sq_w32_report.txt $OUT/sq_w16_report.txt $OUT/sq_w32h_report.txt; do tail -n 3 $f; done; head -c 600 $OUT/bench.json; echo; tail -5 $OUT/traffic.log; head -8 $OUT/kernel_stats.csv
+for f in $OUT/sq_fp32_report.txt $OUT/sq_fp16_report.txt $OUT/sq_w32_report.txt $OUT/sq_w16_report.txt $OUT/sq_w32h_report.txt $OUT/sq_gemm512_report.txt $OUT/sq_gemm128_report.txt $OUT/gemm512_traffic.txt; do tail -n 3 $f; done; head -c 600 $OUT/bench.json; echo; tail -5 $OUT/traffic.log; head -8 $OUT/kernel_stats.csv
