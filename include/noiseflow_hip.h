@@ -361,6 +361,7 @@ int nf_fold_layout(const nf_config *cfg, const nf_layer_desc *layers,
 #define NF_PATH_WIDE16 4
 #define NF_PATH_WIDE32_FP16 5   /* NF_CFG_FP16_CNN at width 8 / 16 / 32: v_mfma_f32_32x32x16_f16 */
 #define NF_PATH_GEMM 6          /* widths 33 .. 512: LDS-staged GEMM on v_mfma_f32_32x32x2_f32 (csrc/nf_gemm.hip) */
+#define NF_PATH_GEMM_FP16 7     /* NF_CFG_FP16_CNN at widths 33 .. 512: the same on v_mfma_f32_32x32x16_f16 (csrc/nf_gemm16.hip) */
 int nf_kernel_path(const nf_handle *h, int32_t direction);
 
 /* Host-only: the SDN5 scalars the kernels receive for a given (iso, cam):

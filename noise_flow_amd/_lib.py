@@ -165,7 +165,7 @@ EXPORTED_SYMBOLS = (
     "nf_trainer_create", "nf_trainer_destroy", "nf_trainer_forward_backward", "nf_trainer_forward", "nf_trainer_apply", "nf_trainer_step",
     "nf_trainer_get_params", "nf_trainer_set_params", "nf_trainer_steps", "nf_trainer_set_sync",
 )
-NF_PATH_SCALAR, NF_PATH_MFMA4, NF_PATH_FP16, NF_PATH_WIDE32, NF_PATH_WIDE16, NF_PATH_WIDE32_FP16, NF_PATH_GEMM = 0, 1, 2, 3, 4, 5, 6
+NF_PATH_SCALAR, NF_PATH_MFMA4, NF_PATH_FP16, NF_PATH_WIDE32, NF_PATH_WIDE16, NF_PATH_WIDE32_FP16, NF_PATH_GEMM, NF_PATH_GEMM_FP16 = 0, 1, 2, 3, 4, 5, 6, 7
 NF_HOST_F32, NF_HOST_F64 = 0, 1
 NF_OPT_ADAM = 0
 NF_OPT_MOMENTUM = 1

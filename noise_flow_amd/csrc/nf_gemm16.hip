@@ -1,0 +1,475 @@
+// fp16-CNN variant of the GEMM kernel (nf_gemm.hip): NF_CFG_FP16_CNN at coupling widths 33 .. 512 on v_mfma_f32_32x32x16_f16.
+//
+// Same band structure, tile convention, transposed l_last and 9-tap gather as nf_gemm.hip; what changes with K = 16 per
+// instruction and 16 x the MAC rate:
+//  * the three CNN inputs are half precision (the rounding points of the oracle's cnn_dtype='fp16': folded weights, z0,
+//    relu(h1), relu(h2), each rounded once; biases, border table, tanh / exp and the log-det stay fp32), so a band holds
+//    NB = 65536 / WP pixels (128 at width 512) in the same 128 KiB of LDS, one ds_read_b128 per B operand;
+//  * an MFMA lasts 32 cycles and needs 1 KiB of weights: streamed per wavefront as in the fp32 kernel the weight traffic would
+//    be 64 B/clk/CU — the whole L2 link.  Every wavefront therefore owns 2 channel tiles x FOUR pixel tiles (8 accumulator
+//    tiles, 128 VGPRs): one weight operand feeds 4 MFMAs (32 B/clk/CU), and the B operands cost 64 B/clk/CU of LDS;
+//  * the partial P tiles of a band's 1024 / WM pixels x WM wavefronts no longer fit the dead h1 region at once: the transposed
+//    l_last + gather run in two halves of the pixel tiles.
+//
+// Replaces (reference, /root/reference): layers.py:251-375, :452-498, :555-613, :651-674 at hps.width > 32, with the coupling-CNN
+// convolutions in half precision (BASELINE configs[4] names that mode for width 4; no reference counterpart).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <atomic>
+#include "../../include/noiseflow_hip.h"   // NF_SUMS_SLOTS / NF_SUMS_STRIDE
+#include "nf_device.h"
+#include "nf_gemm_layout.h"
+#include "nf_dev_util.h"
+
+namespace {
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+typedef _Float16 v4hh __attribute__((ext_vector_type(4)));
+typedef _Float16 v2hh __attribute__((ext_vector_type(2)));
+
+constexpr int GT = 512;          // threads per workgroup
+constexpr int GW = GT / 64;      // wavefronts
+constexpr int PSTR = 44;         // floats per pixel of a partial P tile (as NF7_P_STRIDE)
+
+// relu(a), relu(b) rounded to half, packed in one dword (v_cvt_pk_f16_f32 + v_pk_max_f16)
+__device__ __forceinline__ uint32_t relu_pack_h2(float a, float b)
+{
+    const v2hh h = __builtin_elementwise_max(v2hh{(_Float16)a, (_Float16)b}, v2hh{0, 0});
+    return __builtin_bit_cast(uint32_t, h);
+}
+__device__ __forceinline__ v8h as_v8h(uint4 q) { return __builtin_bit_cast(v8h, q); }
+__device__ __forceinline__ uint4 ldg4u(const float *p) { return *reinterpret_cast<const uint4 *>(p); }
+__device__ __forceinline__ float4 ldg4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+
+//   WP      padded coupling width: 64, 128, 256, 512
+//   PHILOX  input = in-kernel Philox/Box-Muller draw
+//   OWN     pixels per thread: 2 (patches <= 1024 pixels) or 4 (<= 2048)
+template <int WP, bool PHILOX, int OWN>
+__global__ __launch_bounds__(GT) void nf_gemm16_kernel(const NfProgram prog, const NfLaunch a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int MT = WP / 32;                // channel tiles
+    constexpr int NB = NF8_BAND_HALVES / WP;   // pixels per band
+    constexpr int NT = NB / 32;                // pixel tiles per band
+    constexpr int WM = MT / 2;                 // wavefronts along the channel axis (2 tiles each)
+    constexpr int WN = GW / WM;                // wavefronts along the pixel axis (4 tiles each)
+    constexpr int KS = WP / 16;                // K steps of l_2
+    constexpr int NBH = NB / 2;                // pixels of one half of the P stage
+    static_assert(MT * NT == 64 && WM * WN == GW && NT == 4 * WN && KS % 2 == 0, "tile split");
+    static_assert(WM * NBH * PSTR <= NF8_BAND_HALVES / 2, "the partial P tiles reuse the h1 region");
+    const int H = a.H, W = a.W, HW = H * W;
+    const int Wp = W + 2;
+    const int PL = ((H + 2) * Wp + 3) & ~3;            // the z0 tile: one half2 per pixel
+    uint32_t *const h1 = reinterpret_cast<uint32_t *>(smem);           // [KS][2][NB][4] dwords; later the partial P tiles
+    uint32_t *const z0h = h1 + NF8_BAND_HALVES / 2;                    // [PL] half2
+    float *const red = smem + NF8_BAND_HALVES / 2 + PL;                // [3][GW]
+
+    const int t = threadIdx.x;
+    const int wv = t >> 6, lane = t & 63, n = lane & 31, g = lane >> 5;
+    const int wm = wv / WN, wn = wv % WN;
+    int toff[4];   // l_1: z0-tile offsets of the taps 4g .. 4g+3 this lane half contributes
+#pragma unroll
+    for (int q = 0; q < 4; ++q) toff[q] = ((4 * g + q) / 3) * Wp + (4 * g + q) % 3;
+
+    for (int i = t; i < PL; i += GT) z0h[i] = 0u;
+    __syncthreads();
+    // the pixels this thread owns: p = t + GT m
+    int pr[OWN], pc[OWN];
+    bool act[OWN];
+#pragma unroll
+    for (int m = 0; m < OWN; ++m) {
+        const int p = t + GT * m;
+        act[m] = p < HW;
+        pr[m] = act[m] ? p / W : 0;
+        pc[m] = act[m] ? p - pr[m] * W : 0;
+    }
+
+    const int n_ops = prog.n_ops;
+    const int n_bands = (HW + NB - 1) / NB;
+    double acc_nll = 0.0, acc_sd = 0.0;   // thread 0 only
+
+    for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
+        const size_t patch_off = (size_t)b * (size_t)HW * 4u;
+
+        float z[OWN][4];
+#pragma unroll
+        for (int m = 0; m < OWN; ++m) {
+            const int gi = act[m] ? t + GT * m : 0;
+            if (PHILOX) {
+                philox_normal4(a.seed, a.patch_base + b, (uint32_t)gi, NF_STREAM_SAMP, z[m]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) z[m][q] *= a.in_scale;
+            } else {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (act[m]) v = reinterpret_cast<const float4 *>(a.in + patch_off)[gi];
+                z[m][0] = v.x * a.in_scale;
+                z[m][1] = v.y * a.in_scale;
+                z[m][2] = v.z * a.in_scale;
+                z[m][3] = v.w * a.in_scale;
+            }
+        }
+
+        float ld = 0.0f, ld2 = 0.0f;   // natural-log / log2 parts of this thread's log-det share
+
+        for (int op = 0; op < n_ops; ++op) {
+            const int type = prog.ops[op].type;
+            const cfloat_p P = (cfloat_p)(a.params + prog.ops[op].off);   // wave-uniform, scalar loads
+
+            if (type == NF_OP_MIX) {
+                float mm[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) mm[i] = P[i];
+#pragma unroll
+                for (int m = 0; m < OWN; ++m) {
+                    float o[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float s = z[m][0] * mm[j];
+                        s = fmaf(z[m][1], mm[4 + j], s);
+                        s = fmaf(z[m][2], mm[8 + j], s);
+                        s = fmaf(z[m][3], mm[12 + j], s);
+                        o[j] = s;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) z[m][j] = o[j];
+                }
+            } else if (type == NF_OP_COUPLING_FWD || type == NF_OP_COUPLING_REV) {
+                const float *const img = a.params + prog.ops[op].off + NF8_CPL_IMG;
+                // ---- publish the pass-through half (rounded to half: a CNN input) ----
+#pragma unroll
+                for (int m = 0; m < OWN; ++m)
+                    if (act[m]) {
+                        const v2hh zh = {(_Float16)z[m][0], (_Float16)z[m][1]};
+                        z0h[(pr[m] + 1) * Wp + pc[m] + 1] = __builtin_bit_cast(uint32_t, zh);
+                    }
+                float o[OWN][4];
+#pragma unroll
+                for (int m = 0; m < OWN; ++m)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[m][j] = 0.0f;
+                __syncthreads();
+
+                for (int band = 0; band < n_bands; ++band) {
+                    const int p0 = band * NB;
+                    // ---- l_1: 64 tiles of relu(W1 z0 + b1) -> half, 8 per wavefront, into LDS in B-operand order ----
+#pragma unroll 1
+                    for (int i = 0; i < 8; ++i) {
+                        const int tt = wv * 8 + i, m = tt / NT, nt = tt % NT;
+                        int p = p0 + 32 * nt + n;
+                        p = p < HW ? p : HW - 1;   // columns past the patch: never gathered
+                        const int r = p / W, c = p - r * W;
+                        const uint32_t *zb = z0h + r * Wp + c;   // tap (di,dj) at + di*Wp + dj
+                        v16f d;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float4 bb = ldg4(img + nf8_img_B1(WP) + m * 32 + g * 16 + 4 * q);
+                            d[4 * q + 0] = bb.x; d[4 * q + 1] = bb.y; d[4 * q + 2] = bb.z; d[4 * q + 3] = bb.w;
+                        }
+                        const uint4 a0 = ldg4u(img + nf8_img_A1H(WP) + ((m * 2 + 0) * 64 + lane) * 4);
+                        const uint4 a1 = ldg4u(img + nf8_img_A1H(WP) + ((m * 2 + 1) * 64 + lane) * 4);
+                        const uint4 b0 = make_uint4(zb[toff[0]], zb[toff[1]], zb[toff[2]], zb[toff[3]]);
+                        const uint4 b1 = make_uint4(g == 0 ? zb[2 * Wp + 2] : 0u, 0u, 0u, 0u);
+                        d = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_v8h(a0), as_v8h(b0), d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_v8h(a1), as_v8h(b1), d, 0, 0, 0);
+#pragma unroll
+                        for (int m2 = 0; m2 < 2; ++m2)
+                            *reinterpret_cast<uint4 *>(h1 + ((size_t)(((m * 2 + m2) * 2 + g) * NB) + 32 * nt + n) * 4) =
+                                make_uint4(relu_pack_h2(d[8 * m2 + 0], d[8 * m2 + 1]), relu_pack_h2(d[8 * m2 + 2], d[8 * m2 + 3]),
+                                           relu_pack_h2(d[8 * m2 + 4], d[8 * m2 + 5]), relu_pack_h2(d[8 * m2 + 6], d[8 * m2 + 7]));
+                    }
+                    __syncthreads();
+
+                    // ---- l_2: 2 x 4 accumulator tiles per wavefront over the whole K; weights streamed from L2 ----
+                    v16f acc[2][4];
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float4 bb = ldg4(img + nf8_img_B2(WP) + (2 * wm + mi) * 32 + g * 16 + 4 * q);
+#pragma unroll
+                            for (int ni = 0; ni < 4; ++ni) {
+                                acc[mi][ni][4 * q + 0] = bb.x; acc[mi][ni][4 * q + 1] = bb.y;
+                                acc[mi][ni][4 * q + 2] = bb.z; acc[mi][ni][4 * q + 3] = bb.w;
+                            }
+                        }
+                    }
+                    {
+                        const float *ap0 = img + nf8_img_A2H(WP) + ((size_t)(2 * wm + 0) * KS * 64 + lane) * 4;
+                        const float *ap1 = img + nf8_img_A2H(WP) + ((size_t)(2 * wm + 1) * KS * 64 + lane) * 4;
+                        const uint32_t *bp = h1 + ((size_t)(g * NB) + 32 * (4 * wn) + n) * 4;
+                        // software pipeline over K steps, two operand sets in ping-pong; the scheduling barriers keep the loads of
+                        // step ks + 1 in front of the 8 MFMAs of step ks (nf_gemm.hip)
+                        uint4 xa0 = ldg4u(ap0), xa1 = ldg4u(ap1), xb[4], ya0, ya1, yb[4];
+#pragma unroll
+                        for (int ni = 0; ni < 4; ++ni) xb[ni] = *reinterpret_cast<const uint4 *>(bp + 32 * ni * 4);
+#define NF_GEMM16_STEP(A0, A1, B)                                                                                              \
+    _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                                           \
+    {                                                                                                                          \
+        acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_v8h(A0), as_v8h(B[ni]), acc[0][ni], 0, 0, 0);                   \
+        acc[1][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_v8h(A1), as_v8h(B[ni]), acc[1][ni], 0, 0, 0);                   \
+    }
+#pragma unroll 1
+                        for (int ks = 0; ks < KS; ks += 2) {
+                            const int k1 = ks + 1, k2 = ks + 2 < KS ? ks + 2 : KS - 1;
+                            ya0 = ldg4u(ap0 + (size_t)k1 * 256);
+                            ya1 = ldg4u(ap1 + (size_t)k1 * 256);
+#pragma unroll
+                            for (int ni = 0; ni < 4; ++ni) yb[ni] = *reinterpret_cast<const uint4 *>(bp + ((size_t)k1 * 2 * NB + 32 * ni) * 4);
+                            __builtin_amdgcn_sched_barrier(0);
+                            NF_GEMM16_STEP(xa0, xa1, xb)
+                            __builtin_amdgcn_sched_barrier(0);
+                            xa0 = ldg4u(ap0 + (size_t)k2 * 256);
+                            xa1 = ldg4u(ap1 + (size_t)k2 * 256);
+#pragma unroll
+                            for (int ni = 0; ni < 4; ++ni) xb[ni] = *reinterpret_cast<const uint4 *>(bp + ((size_t)k2 * 2 * NB + 32 * ni) * 4);
+                            __builtin_amdgcn_sched_barrier(0);
+                            NF_GEMM16_STEP(ya0, ya1, yb)
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+#undef NF_GEMM16_STEP
+                    }
+                    float *const pp = reinterpret_cast<float *>(h1);   // [WM][NBH][PSTR] partial P tiles of one half
+                    // ---- P = W3^T relu(h2) + gather, pixel tiles {0, 1} then {2, 3} of this wavefront ----
+#pragma unroll
+                    for (int hN = 0; hN < 2; ++hN) {
+                        v16f pa[2];
+                        v4f p8[2];
+#pragma unroll
+                        for (int nj = 0; nj < 2; ++nj) {
+#pragma unroll
+                            for (int v = 0; v < 16; ++v) pa[nj][v] = 0.0f;
+                            p8[nj] = v4f{0.f, 0.f, 0.f, 0.f};
+                        }
+#pragma unroll
+                        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+                            for (int m2 = 0; m2 < 2; ++m2) {
+                                const uint4 w0 = ldg4u(img + nf8_img_A3H(WP) + (((2 * wm + mi) * 2 + m2) * 64 + lane) * 4);
+                                const uint2 c0 = *reinterpret_cast<const uint2 *>(img + nf8_img_A3CH(WP) + (((2 * wm + mi) * 4 + 2 * m2 + 0) * 8 + g * 4 + (lane & 3)) * 2);
+                                const uint2 c1 = *reinterpret_cast<const uint2 *>(img + nf8_img_A3CH(WP) + (((2 * wm + mi) * 4 + 2 * m2 + 1) * 8 + g * 4 + (lane & 3)) * 2);
+#pragma unroll
+                                for (int nj = 0; nj < 2; ++nj) {
+                                    const v16f &e = acc[mi][2 * hN + nj];
+                                    const uint32_t q0 = relu_pack_h2(e[8 * m2 + 0], e[8 * m2 + 1]), q1 = relu_pack_h2(e[8 * m2 + 2], e[8 * m2 + 3]);
+                                    const uint32_t q2 = relu_pack_h2(e[8 * m2 + 4], e[8 * m2 + 5]), q3 = relu_pack_h2(e[8 * m2 + 6], e[8 * m2 + 7]);
+                                    pa[nj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_v8h(w0), as_v8h(make_uint4(q0, q1, q2, q3)), pa[nj], 0, 0, 0);
+                                    p8[nj] = __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(v4hh, c0), __builtin_bit_cast(v4hh, make_uint2(q0, q1)), p8[nj], 0, 0, 0);
+                                    p8[nj] = __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(v4hh, c1), __builtin_bit_cast(v4hh, make_uint2(q2, q3)), p8[nj], 0, 0, 0);
+                                }
+                            }
+                        }
+                        __syncthreads();   // first half: every wavefront is done with h1; second: with the first half's records
+
+                        // per pixel [tap 0..7][j] (register group a of lane half g holds tap 2 a + g), then tap 8 of lane half 0 / 1
+#pragma unroll
+                        for (int nj = 0; nj < 2; ++nj) {
+                            float *dst = pp + ((size_t)(wm * NBH + 32 * (2 * wn + nj) + n)) * PSTR;
+#pragma unroll
+                            for (int aa = 0; aa < 4; ++aa)
+                                *reinterpret_cast<float4 *>(dst + (2 * aa + g) * 4) =
+                                    make_float4(pa[nj][4 * aa + 0], pa[nj][4 * aa + 1], pa[nj][4 * aa + 2], pa[nj][4 * aa + 3]);
+                            *reinterpret_cast<float4 *>(dst + 32 + 4 * g) = make_float4(p8[nj][0], p8[nj][1], p8[nj][2], p8[nj][3]);
+                        }
+                        __syncthreads();
+
+                        // gather: the taps of this half's pixels that fall on the output pixels this thread owns
+#pragma unroll
+                        for (int m = 0; m < OWN; ++m) {
+                            const int q = t + GT * m;
+                            if (!act[m] || q + W + 1 < p0 || q >= p0 + NB + W + 1) continue;
+#pragma unroll
+                            for (int di = 0; di < 3; ++di) {
+                                const int rr = pr[m] + di - 1;
+                                if (rr < 0 || rr >= H) continue;
+#pragma unroll
+                                for (int dj = 0; dj < 3; ++dj) {
+                                    const int cc = pc[m] + dj - 1;
+                                    const int src = rr * W + cc - p0;
+                                    if (cc < 0 || cc >= W || src < 0 || src >= NB) continue;
+                                    const int nt = src >> 5;                      // pixel tile nt belongs to wavefront column nt / 4,
+                                    if (((nt >> 1) & 1) != hN) continue;          // ... and to its half (nt / 2) & 1
+                                    const int rec = 32 * (2 * (nt >> 2) + (nt & 1)) + (src & 31);
+#pragma unroll
+                                    for (int k = 0; k < WM; ++k) {
+                                        const float *rp = pp + ((size_t)(k * NBH + rec)) * PSTR;
+                                        float4 v = *reinterpret_cast<const float4 *>(rp + (di * 3 + dj) * 4);
+                                        if (di * 3 + dj == 8) {   // tap 8: the two lane halves' partial sums
+                                            const float4 u = *reinterpret_cast<const float4 *>(rp + 36);
+                                            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+                                        }
+                                        o[m][0] += v.x; o[m][1] += v.y; o[m][2] += v.z; o[m][3] += v.w;
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    __syncthreads();   // the next band's l_1 overwrites the region
+                }
+
+                // ---- finish the coupling on the owned pixels ----
+                const float scl = P[NF8_CPL_S + 1], m2scl = P[NF8_CPL_S + 2];
+#pragma unroll
+                for (int m = 0; m < OWN; ++m) {
+                    const int r = pr[m], c = pc[m];
+                    const int bm = (r == 0 ? 1 : 0) | (r == H - 1 ? 2 : 0) | (c == 0 ? 4 : 0) | (c == W - 1 ? 8 : 0);
+                    const float4 eb = *reinterpret_cast<const float4 *>(a.params + prog.ops[op].off + NF8_CPL_E + 4 * (act[m] ? bm : 0));
+                    // fp16 weights are not pre-scaled (their rounding points are the oracle's); the table is
+                    o[m][0] += eb.x; o[m][1] += eb.y;
+                    o[m][2] = fmaf(o[m][2], 2.8853900817779268f, eb.z);
+                    o[m][3] = fmaf(o[m][3], 2.8853900817779268f, eb.w);
+                    const float l0 = fmaf(__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(o[m][2]) + 1.0f), m2scl, scl);
+                    const float l1 = fmaf(__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(o[m][3]) + 1.0f), m2scl, scl);
+                    if (type == NF_OP_COUPLING_FWD) {
+                        z[m][2] = fmaf(z[m][2], __builtin_amdgcn_exp2f(l0), o[m][0]);
+                        z[m][3] = fmaf(z[m][3], __builtin_amdgcn_exp2f(l1), o[m][1]);
+                        if (act[m]) ld2 += l0 + l1;
+                    } else {
+                        z[m][2] = (z[m][2] - o[m][0]) * __builtin_amdgcn_exp2f(-l0);
+                        z[m][3] = (z[m][3] - o[m][1]) * __builtin_amdgcn_exp2f(-l1);
+                    }
+                }
+            } else if (type == NF_OP_SDN_DIV || type == NF_OP_SDN_MUL) {
+                // AffineCouplingSdnEx5: scale = sqrt(beta1*y/gain + beta2)  (cond_utils.py:238)
+                const float4 *y4 = reinterpret_cast<const float4 *>(a.y + patch_off);
+                const float ck1 = a.cond_a[prog.ops[op].off & 3], cb2 = a.cond_b[prog.ops[op].off & 3];
+#pragma unroll
+                for (int m = 0; m < OWN; ++m) {
+                    float4 yv = make_float4(1.f, 1.f, 1.f, 1.f);
+                    if (act[m]) yv = y4[t + GT * m];
+                    const float yy[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float v = fmaf(yy[q], ck1, cb2);
+                        if (type == NF_OP_SDN_DIV) {
+                            z[m][q] = z[m][q] * __builtin_amdgcn_rsqf(v);
+                            if (act[m]) ld = fmaf(-0.34657359027997264f, __builtin_amdgcn_logf(v), ld);
+                        } else {
+                            z[m][q] = z[m][q] * __builtin_amdgcn_sqrtf(v);
+                        }
+                    }
+                }
+            } else if (type == NF_OP_SCALE || type == NF_OP_SCALE_COND) {
+                const float s = type == NF_OP_SCALE ? P[0] : a.cond_a[prog.ops[op].off & 3];
+#pragma unroll
+                for (int m = 0; m < OWN; ++m)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) z[m][q] *= s;
+            }
+        }
+
+        // ---- epilogue (as nf_flow_kernel) ----
+        if (a.out) {
+            float4 *out4 = reinterpret_cast<float4 *>(a.out + patch_off);
+#pragma unroll
+            for (int m = 0; m < OWN; ++m)
+                if (act[m]) out4[t + GT * m] = make_float4(z[m][0], z[m][1], z[m][2], z[m][3]);
+        }
+        if (a.nll_out || a.sd_out || a.ld_out || a.sums) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int m = 0; m < OWN; ++m)
+                if (act[m]) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        s1 += z[m][q];
+                        s2 = fmaf(z[m][q], z[m][q], s2);
+                    }
+                }
+            float r0 = wave_sum(fmaf(ld2, 0.6931471805599453f, ld)), r1 = wave_sum(s1), r2 = wave_sum(s2);
+            if (lane == 0) {
+                red[wv] = r0;
+                red[GW + wv] = r1;
+                red[2 * GW + wv] = r2;
+            }
+            __syncthreads();
+            if (t == 0) {
+                r0 = 0.f; r1 = 0.f; r2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < GW; ++i) {
+                    r0 += red[i];
+                    r1 += red[GW + i];
+                    r2 += red[2 * GW + i];
+                }
+                const double npx = (double)HW * 4.0;
+                const double logdet = (double)r0 + a.ld_const;
+                double nll = -logdet;   // prior: sum -0.5*(log 2pi + z^2)   (noise_flow_model.py:537-539)
+                if (a.flags & NF_K_PRIOR) nll += 0.5 * npx * 1.8378770664093453 + 0.5 * (double)r2;
+                const double mean = (double)r1 / npx;
+                double var = (double)r2 / npx - mean * mean;   // noise_flow_model.py:477-478
+                var = var > 0.0 ? var : 0.0;
+                const double sd = sqrt(var);
+                if (a.nll_out) a.nll_out[b] = (float)nll;
+                if (a.sd_out) a.sd_out[b] = (float)sd;
+                if (a.ld_out) a.ld_out[b] = (float)logdet;
+                acc_nll += (double)(float)nll;
+                acc_sd += (double)(float)sd;
+            }
+            __syncthreads();   // scratch is reused by the next patch
+        }
+    }
+
+    if (a.sums && t == 0) {
+        double *sp = a.sums;
+        if (a.flags & NF_K_SUMS_WIDE) sp += (size_t)(blockIdx.x & (NF_SUMS_SLOTS - 1)) * NF_SUMS_STRIDE;
+        atomicAdd(&sp[0], acc_nll);
+        atomicAdd(&sp[1], acc_sd);
+        if (blockIdx.x == 0) atomicAdd(&sp[2], (double)a.B);
+    }
+}
+
+size_t gemm16_lds_bytes(int H, int W)
+{
+    const int Wp = W + 2, PL = ((H + 2) * Wp + 3) & ~3;
+    return ((size_t)NF8_BAND_HALVES / 2 + (size_t)PL + 3 * GW + 8) * sizeof(float);
+}
+
+template <int WP, bool PHILOX, int OWN>
+hipError_t launch_gemm16(const NfProgram &prog, const NfLaunch &a, int n_cu, int device, hipStream_t stream)
+{
+    const size_t lds = gemm16_lds_bytes(a.H, a.W);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    const void *fn = reinterpret_cast<const void *>(&nf_gemm16_kernel<WP, PHILOX, OWN>);
+    // largest dynamic-LDS size this instantiation was enabled for, per device (racy but idempotent)
+    static std::atomic<size_t> lds_set[16];
+    std::atomic<size_t> &cur = lds_set[device & 15];
+    if (lds > cur.load(std::memory_order_relaxed) || device > 15) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        cur.store(lds, std::memory_order_relaxed);
+    }
+    int64_t groups = n_cu;   // one 512-thread workgroup with > 128 KiB of LDS per CU
+    if (a.B < groups) groups = a.B;
+    if (groups < 1) groups = 1;
+    hipLaunchKernelGGL((nf_gemm16_kernel<WP, PHILOX, OWN>), dim3((unsigned)groups), dim3(GT), lds, stream, prog, a);
+    return hipGetLastError();
+}
+
+template <int WP, bool PHILOX>
+hipError_t dispatch_own16(const NfProgram &prog, const NfLaunch &a, int n_cu, int device, hipStream_t stream)
+{
+    if (a.H * a.W <= 2 * GT) return launch_gemm16<WP, PHILOX, 2>(prog, a, n_cu, device, stream);
+    return launch_gemm16<WP, PHILOX, 4>(prog, a, n_cu, device, stream);
+}
+
+template <bool PHILOX>
+hipError_t dispatch_gemm16(const NfProgram &prog, const NfLaunch &a, int n_cu, int device, hipStream_t stream)
+{
+    switch (prog.width) {
+    case 64: return dispatch_own16<64, PHILOX>(prog, a, n_cu, device, stream);
+    case 128: return dispatch_own16<128, PHILOX>(prog, a, n_cu, device, stream);
+    case 256: return dispatch_own16<256, PHILOX>(prog, a, n_cu, device, stream);
+    case 512: return dispatch_own16<512, PHILOX>(prog, a, n_cu, device, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace
+
+// entry point used by nf_host.hip: programs in the NF8 layout (NF_CFG_FP16_CNN, coupling width padded to 64 / 128 / 256 / 512)
+hipError_t nf_launch_gemm16(const NfProgram &prog, const NfLaunch &a, int n_cu, int device, hipStream_t stream)
+{
+    if (a.H < 1 || a.W < 1 || a.H * a.W > NF7_MAX_PIXELS || gemm16_lds_bytes(a.H, a.W) > 160 * 1024) return hipErrorInvalidValue;
+    if (a.flags & NF_K_PHILOX_IN) return dispatch_gemm16<true>(prog, a, n_cu, device, stream);
+    return dispatch_gemm16<false>(prog, a, n_cu, device, stream);
+}

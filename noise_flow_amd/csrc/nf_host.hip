@@ -20,12 +20,14 @@
 
 #include "../../include/noiseflow_hip.h"
 #include "nf_device.h"
+#include "nf_gemm_layout.h"
 #include "nf_internal.h"
 
 hipError_t nf_launch_flow(const NfProgram &prog, const NfLaunch &a, int n_cu, hipStream_t stream, bool matrix_core);
 hipError_t nf_launch_wide(const NfProgram &prog, const NfLaunch &a, int n_cu, int device, hipStream_t stream);
 hipError_t nf_launch_wide16(const NfProgram &prog, const NfLaunch &a, int n_cu, int device, hipStream_t stream);
 hipError_t nf_launch_gemm(const NfProgram &prog, const NfLaunch &a, int n_cu, int device, hipStream_t stream);
+hipError_t nf_launch_gemm16(const NfProgram &prog, const NfLaunch &a, int n_cu, int device, hipStream_t stream);
 bool nf_gemm_shape_ok(int H, int W);
 hipError_t nf_launch_synth(uint64_t seed, int64_t patch_base, int64_t B, int HW, float beta1, float beta2,
                            float *y_out, float *x_out, hipStream_t stream);
@@ -449,6 +451,63 @@ void relayout_coupling_gemm(const float *v1, int w, int wp, float *out)
                 }
 }
 
+// fp16-CNN GEMM re-layout (nf_gemm_layout.h, NF8_*; NF_CFG_FP16_CNN at widths 33 .. 512): fetch order of v_mfma_f32_32x32x16_f16,
+// folded weights rounded to half once (the oracle's rounding points), biases / border table fp32.
+void relayout_coupling_gemm16(const float *v1, int w, int wp, float *out)
+{
+    const double k2 = 2.0 * 1.4426950408889634, log2e = 1.4426950408889634;
+    const int MT = wp / 32, KS = wp / 16;
+    for (int m = 0; m < 16; ++m)
+        for (int j = 0; j < 4; ++j) {
+            const double e = v1[nf_cpl_off_E(w) + 4 * m + j];
+            out[NF8_CPL_E + 4 * m + j] = (float)(j >= 2 ? e * k2 : e);
+        }
+    const double sc = v1[nf_cpl_off_S(w)];
+    out[NF8_CPL_S + 0] = (float)sc;
+    out[NF8_CPL_S + 1] = (float)(sc * log2e);
+    out[NF8_CPL_S + 2] = (float)(-2.0 * sc * log2e);
+    out[NF8_CPL_S + 3] = 0.0f;
+    float *img = out + NF8_CPL_IMG;
+    memset(img, 0, (size_t)nf8_img_size(wp) * sizeof(float));
+    uint16_t *h = reinterpret_cast<uint16_t *>(img);   // half index = 2 * dword index
+    const float *W1 = v1 + nf_cpl_off_W1(w), *B1 = v1 + nf_cpl_off_B1(w), *W2 = v1 + nf_cpl_off_W2(w);
+    const float *B2 = v1 + nf_cpl_off_B2(w), *W3 = v1 + nf_cpl_off_W3(w);
+    for (int m = 0; m < MT; ++m) {
+        for (int l = 0; l < 64; ++l) {
+            const int oc = 32 * m + (l & 31), g = l >> 5;
+            for (int q = 0; q < 8; ++q) {
+                // l_1, instruction 0: taps 4g .. 4g+3; instruction 1: tap 8 on lane half 0
+                const int tap = 4 * g + (q >> 1), ch = q & 1;
+                h[2 * ((size_t)nf8_img_A1H(wp) + ((m * 2 + 0) * 64 + l) * 4) + q] = oc < w ? to_half(W1[(tap * 2 + ch) * w + oc]) : 0;
+                h[2 * ((size_t)nf8_img_A1H(wp) + ((m * 2 + 1) * 64 + l) * 4) + q] = (oc < w && g == 0 && q < 2) ? to_half(W1[(8 * 2 + q) * w + oc]) : 0;
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int cin = 32 * (ks >> 1) + nf4_chan(8 * (ks & 1) + q, g);
+                    h[2 * ((size_t)nf8_img_A2H(wp) + (((size_t)m * KS + ks) * 64 + l) * 4) + q] =
+                        (cin < w && oc < w) ? to_half(W2[(size_t)cin * w + oc]) : 0;
+                }
+                for (int m2 = 0; m2 < 2; ++m2) {       // P rows of taps 0 .. 7 from INPUT tile m
+                    const int cin = 32 * m + nf4_chan(8 * m2 + q, g), row = l & 31, tap = row >> 2, j = row & 3;
+                    h[2 * ((size_t)nf8_img_A3H(wp) + ((m * 2 + m2) * 64 + l) * 4) + q] = cin < w ? to_half(W3[((size_t)tap * w + cin) * 4 + j]) : 0;
+                }
+            }
+        }
+        for (int g = 0; g < 2; ++g)
+            for (int v = 0; v < 16; ++v) {
+                const int ch = 32 * m + nf4_chan(v, g);
+                img[nf8_img_B1(wp) + m * 32 + g * 16 + v] = ch < w ? B1[ch] : 0.0f;
+                img[nf8_img_B2(wp) + m * 32 + g * 16 + v] = ch < w ? B2[ch] : 0.0f;
+            }
+        for (int q4 = 0; q4 < 4; ++q4)                 // tap 8 on v_mfma_f32_4x4x4_16b_f16
+            for (int g = 0; g < 2; ++g)
+                for (int j = 0; j < 4; ++j)
+                    for (int r = 0; r < 4; ++r) {
+                        const int cin = 32 * m + nf4_chan(4 * q4 + r, g);
+                        h[2 * ((size_t)nf8_img_A3CH(wp) + ((m * 4 + q4) * 8 + g * 4 + j) * 2) + r] =
+                            cin < w ? to_half(W3[((size_t)8 * w + cin) * 4 + j]) : 0;
+                    }
+    }
+}
+
 // Width-16 re-layout (nf_device.h, NF6_*; `w` = 16, or 8 zero-padded): fetch order of v_mfma_f32_16x16x4_f32.
 void relayout_coupling_wide16(const float *v1, int w, float *out)
 {
@@ -688,6 +747,8 @@ struct Built {
     std::vector<float> block6;
     NfProgram prog7;             // GEMM layout (NF7_*): widths 33 .. 512, zero-padded to 64 / 128 / 256 / 512
     std::vector<float> block7;
+    NfProgram prog8;             // fp16-CNN GEMM layout (NF8_*): NF_CFG_FP16_CNN at widths 33 .. 512
+    std::vector<float> block8;
     double ld_const = 0.0;
     bool has_sdn = false;      // some op reads the clean image y
 };
@@ -752,8 +813,6 @@ int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float
         case NF_LAYER_COUPLING: {
             if (L.width != 4 && L.width != 8 && L.width != 16 && !(L.width >= 32 && L.width <= 512))
                 return fail(NF_EINVAL, "layer %d: coupling width %d unsupported (4, 8, 16, 32 .. 512)", li, L.width);
-            if (L.width > 32 && (cfg->flags & NF_CFG_FP16_CNN))
-                return fail(NF_EINVAL, "layer %d: NF_CFG_FP16_CNN covers coupling widths 4 / 8 / 16 / 32 (width %d runs exact fp32)", li, L.width);
             if (L.width > 32 && !nf_gemm_shape_ok(cfg->height, cfg->width))
                 return fail(NF_EINVAL, "layer %d: coupling width %d covers patches of up to %d pixels (%dx%d given)", li, L.width,
                             NF7_MAX_PIXELS, cfg->height, cfg->width);
@@ -936,9 +995,33 @@ int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float
         }
         if (out.block6.empty()) out.block6.assign(4, 0.0f);
     }
+    out.block8.clear();
+    memset(&out.prog8, 0, sizeof(out.prog8));
+    if (out.prog.width > 32 && (cfg->flags & NF_CFG_FP16_CNN)) {
+        const int wp = nf7_pad_width(out.prog.width);
+        out.prog8.width = wp;
+        for (int i = 0; i < out.prog.n_ops; ++i) {
+            const NfOp &src = out.prog.ops[i];
+            NfOp &dst = out.prog8.ops[out.prog8.n_ops++];
+            dst.type = src.type;
+            dst.off = (int32_t)out.block8.size();
+            const float *v1 = out.block.data() + src.off;
+            if (src.type == NF_OP_MIX) {
+                out.block8.insert(out.block8.end(), v1, v1 + 16);
+            } else if (src.type == NF_OP_COUPLING_FWD || src.type == NF_OP_COUPLING_REV) {
+                out.block8.resize(out.block8.size() + nf8_cpl_size(wp));
+                relayout_coupling_gemm16(v1, out.prog.width, wp, out.block8.data() + dst.off);
+            } else if (src.type == NF_OP_SCALE) {
+                out.block8.insert(out.block8.end(), v1, v1 + 4);
+            } else {
+                dst.off = src.off;   // conditioning slot
+            }
+        }
+        if (out.block8.empty()) out.block8.assign(4, 0.0f);
+    }
     out.block7.clear();
     memset(&out.prog7, 0, sizeof(out.prog7));
-    if (out.prog.width > 32) {
+    if (out.prog.width > 32 && !(cfg->flags & NF_CFG_FP16_CNN)) {
         const int wp = nf7_pad_width(out.prog.width);
         out.prog7.width = wp;
         for (int i = 0; i < out.prog.n_ops; ++i) {
@@ -1077,6 +1160,8 @@ struct nf_handle {
     float *d_rev6 = nullptr;
     float *d_fwd7 = nullptr;   // GEMM layout (widths 33 .. 512)
     float *d_rev7 = nullptr;
+    float *d_fwd8 = nullptr;   // fp16-CNN GEMM layout
+    float *d_rev8 = nullptr;
     bool scalar_ok = true;     // the scalar-weight kernel's LDS tiles fit this patch shape / width
     // batch-statistics mode (nf_*_batchstats): the raw model and a lazily allocated scratch
     std::vector<nf_layer_desc> layers;
@@ -1152,6 +1237,7 @@ int nf_fold_layout(const nf_config *cfg, const nf_layer_desc *layers, const floa
     case NF_PATH_WIDE32_FP16: pg = &b.prog5; blk = &b.block5; break;
     case NF_PATH_WIDE16: pg = &b.prog6; blk = &b.block6; break;
     case NF_PATH_GEMM: pg = &b.prog7; blk = &b.block7; break;
+    case NF_PATH_GEMM_FP16: pg = &b.prog8; blk = &b.block8; break;
     default: return fail(NF_EINVAL, "unknown kernel path %d", path);
     }
     if (blk->empty()) return fail(NF_EINVAL, "this model has no parameter block for kernel path %d", path);
@@ -1198,7 +1284,7 @@ int nf_create(const nf_config *cfg, const nf_layer_desc *layers, const float *pa
         const size_t lds = sizeof(float) * (tile_px * (2 + (size_t)h->fwd.prog.width) + 64);
         h->scalar_ok = lds <= 160 * 1024 && h->fwd.prog.width <= 32;
         if (lds > 160 * 1024 && h->fwd.block2.empty() && h->fwd.block4.empty() && h->fwd.block5.empty() && h->fwd.block6.empty() &&
-            h->fwd.block7.empty()) {
+            h->fwd.block7.empty() && h->fwd.block8.empty()) {
             const int w = h->fwd.prog.width;
             delete h;
             return fail(NF_EINVAL, "a %dx%d patch with coupling width %d needs %zu KiB of LDS (> 160): unsupported",
@@ -1239,18 +1325,19 @@ int nf_create(const nf_config *cfg, const nf_layer_desc *layers, const float *pa
     if (cfg->flags & NF_CFG_FP16_CNN) {
         const int hw = cfg->height * cfg->width;
         const bool w4_ok = !h->fwd.block3.empty() && ((cfg->height == 32 && cfg->width == 32) || (cfg->height == 64 && cfg->width == 64));
-        if ((!w4_ok && h->fwd.block5.empty()) || hw == 0) {
+        if ((!w4_ok && h->fwd.block5.empty() && h->fwd.block8.empty()) || hw == 0) {
             nf_destroy(h);   // the scalar-layout blocks are already on the device
             return fail(NF_EINVAL, "NF_CFG_FP16_CNN needs coupling width 4 with full 32x32 or 64x64 patches, or width 8 / 16 / 32");
         }
     }
-    for (int d = 0; d < 12; ++d) {
+    for (int d = 0; d < 14; ++d) {
         const std::vector<float> &b2 = d == 0 ? h->fwd.block2 : d == 1 ? h->rev.block2 : d == 2 ? h->fwd.block3 : d == 3 ? h->rev.block3
                                        : d == 4 ? h->fwd.block4 : d == 5 ? h->rev.block4 : d == 6 ? h->fwd.block5 : d == 7 ? h->rev.block5
-                                       : d == 8 ? h->fwd.block6 : d == 9 ? h->rev.block6 : d == 10 ? h->fwd.block7 : h->rev.block7;
+                                       : d == 8 ? h->fwd.block6 : d == 9 ? h->rev.block6 : d == 10 ? h->fwd.block7 : d == 11 ? h->rev.block7
+                                       : d == 12 ? h->fwd.block8 : h->rev.block8;
         float **dst = d == 0 ? &h->d_fwd2 : d == 1 ? &h->d_rev2 : d == 2 ? &h->d_fwd3 : d == 3 ? &h->d_rev3 : d == 4 ? &h->d_fwd4
                       : d == 5 ? &h->d_rev4 : d == 6 ? &h->d_fwd5 : d == 7 ? &h->d_rev5 : d == 8 ? &h->d_fwd6 : d == 9 ? &h->d_rev6
-                      : d == 10 ? &h->d_fwd7 : &h->d_rev7;
+                      : d == 10 ? &h->d_fwd7 : d == 11 ? &h->d_rev7 : d == 12 ? &h->d_fwd8 : &h->d_rev8;
         if (b2.empty()) continue;
         if ((e = hipMalloc((void **)dst, b2.size() * sizeof(float))) != hipSuccess ||
             (e = hipMemcpy(*dst, b2.data(), b2.size() * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) {
@@ -1282,6 +1369,8 @@ int nf_destroy(nf_handle *h)
     if (h->d_rev6) (void)hipFree(h->d_rev6);
     if (h->d_fwd7) (void)hipFree(h->d_fwd7);
     if (h->d_rev7) (void)hipFree(h->d_rev7);
+    if (h->d_fwd8) (void)hipFree(h->d_fwd8);
+    if (h->d_rev8) (void)hipFree(h->d_rev8);
     nf_bs_destroy(h->bs);
     delete h;
     return NF_OK;
@@ -1386,6 +1475,15 @@ static int launch_resident(nf_handle *h, int direction, NfLaunch &a, hipStream_t
         if (e != hipSuccess) return fail_hip(e, what);
         return NF_OK;
     }
+    float *d8 = direction == 0 ? h->d_fwd8 : h->d_rev8;
+    if (d8) {   // NF_CFG_FP16_CNN at widths 33 .. 512: the GEMM kernel on v_mfma_f32_32x32x16_f16 (nf_gemm16.hip)
+        a.params = d8;
+        a.n_params = (int32_t)b.block8.size();
+        a.flags |= NF_K_FP16_CNN;
+        hipError_t e = nf_launch_gemm16(b.prog8, a, h->n_cu, h->device, st);
+        if (e != hipSuccess) return fail_hip(e, what);
+        return NF_OK;
+    }
     float *d7 = direction == 0 ? h->d_fwd7 : h->d_rev7;
     if (d7) {   // widths 33 .. 512: LDS-staged GEMMs on v_mfma_f32_32x32x2_f32 (nf_gemm.hip); no other kernel holds these widths
         a.params = d7;
@@ -1430,6 +1528,7 @@ int nf_kernel_path(const nf_handle *h, int32_t direction)
 {
     if (!h || (direction != 0 && direction != 1)) return fail(NF_EINVAL, "bad argument");
     if (direction == 0 ? h->d_fwd5 : h->d_rev5) return NF_PATH_WIDE32_FP16;
+    if (direction == 0 ? h->d_fwd8 : h->d_rev8) return NF_PATH_GEMM_FP16;
     if (direction == 0 ? h->d_fwd7 : h->d_rev7) return NF_PATH_GEMM;
     const bool mcore = use_matrix_core() || !h->scalar_ok;
     if ((direction == 0 ? h->d_fwd6 : h->d_rev6) && mcore) return NF_PATH_WIDE16;

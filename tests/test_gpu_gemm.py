@@ -105,8 +105,36 @@ def test_gemm_width_512_full_arch():
 
 def test_gemm_width_limits_are_reported():
     from noise_flow_amd import NoiseFlow, default_hps
-    for width, hw, dt in ((64, (64, 64), "fp32"), (513, (32, 32), "fp32"), (64, (32, 32), "fp16")):
+    for width, hw, dt in ((64, (64, 64), "fp32"), (513, (32, 32), "fp32"), (64, (64, 64), "fp16")):
         v = trained_like_variables(ARCH, width, seed=1)
         with pytest.raises(Exception) as ei:
             NoiseFlow([hw[0], hw[1], 4], False, default_hps(arch=ARCH, width=width), variables=v, cnn_dtype=dt)
         assert "width" in str(ei.value)
+
+
+@pytest.mark.parametrize("width,hw", [(64, (32, 32)), (128, (32, 32)), (256, (32, 32)), (512, (32, 32)), (96, (20, 28)), (512, (24, 40)),
+                                      (64, (45, 45)), (200, (7, 5)), (160, (33, 31))])
+def test_gemm_fp16_cnn_mode(width, hw):
+    """NF_CFG_FP16_CNN at widths 33 .. 512 (csrc/nf_gemm16.hip: v_mfma_f32_32x32x16_f16, fp32 accumulate, fp32 log-det): against
+    the oracle's emulation of the rounding points — BN and exp(3 logs) folded in fp64, THEN the folded weights and the three
+    CNN inputs rounded to half once — 1e-4 relative on the NLL, 2e-3 of scale on tensors (a near-tie at a half-rounding point
+    may flip an activation by one fp16 ulp), and the mode stays within 2e-4 of the all-fp32 model on the NLL
+    (the tolerances of tests/test_gpu_wide.py::test_wide_fp16_cnn_mode)."""
+    from noise_flow_amd import NoiseFlow, default_hps, _lib
+    from oracle.nf_oracle import NoiseFlowOracle
+    H, W = hw
+    B = 3
+    v = _variables(ARCH, width, seed=7 + width + H)
+    x, y = make_inputs(B, H, W, seed=12)
+    m = NoiseFlow([H, W, 4], False, default_hps(arch=ARCH, width=width), variables=v, cnn_dtype="fp16")
+    assert _path(m, 0) == _lib.NF_PATH_GEMM_FP16 and _path(m, 1) == _lib.NF_PATH_GEMM_FP16
+    o16 = NoiseFlowOracle(ARCH, v, cnn_dtype="fp16")
+    nll, sd = m._loss(x, y, [0.0], [0.0], [100], [2])
+    ref, rsd, rz = o16.nll(x, y, 100, 2)
+    np.testing.assert_allclose(nll, ref, rtol=1e-4)
+    assert abs(sd - rsd) <= 1e-4 * rsd
+    z, _ = m.inverse(x, None, y, [0.0], [0.0], [100], [2])
+    _close_elem(z, rz, rtol=2e-3)
+    eps = np.random.RandomState(3).randn(B, H, W, 4).astype(np.float32)
+    _close_elem(m.sample(y, 0.6, y, [0.0], [0.0], [100], [2], eps=eps), o16.sample(eps, 0.6, y, 100, 2), rtol=2e-3)
+    np.testing.assert_allclose(nll, NoiseFlowOracle(ARCH, v).nll(x, y, 100, 2)[0], rtol=2e-4)
