@@ -656,7 +656,7 @@ def _wide_cnn(ctx, batches, cond, wide):
     args, dev = ctx["args"], ctx["dev"]
     x, y = batches[0]
     out = {}
-    for w, dt in ((32, "fp32"), (16, "fp32"), (32, "fp16"), (512, "fp32"), (128, "fp32")):
+    for w, dt in ((32, "fp32"), (16, "fp32"), (32, "fp16"), (512, "fp32"), (128, "fp32"), (512, "fp16")):
         hps = default_hps(width=w)
         var = _params.init_variables(hps.arch, w, 4, 1234)
         rng = np.random.RandomState(w)
@@ -677,7 +677,8 @@ def _wide_cnn(ctx, batches, cond, wide):
             "kernel_path": {0: "scalar-weight VALU kernel", 3: "nf_wide32_kernel (v_mfma_f32_32x32x2_f32)",
                             4: "nf_wide16_kernel (v_mfma_f32_16x16x4_f32)",
                             5: "nf_wide32_kernel (v_mfma_f32_32x32x16_f16)",
-                            6: "nf_gemm_kernel (v_mfma_f32_32x32x2_f32, LDS-staged GEMM, weights streamed from L2)"}.get(path, str(path)),
+                            6: "nf_gemm_kernel (v_mfma_f32_32x32x2_f32, LDS-staged GEMM, weights streamed from L2)",
+                            7: "nf_gemm16_kernel (v_mfma_f32_32x32x16_f16, LDS-staged GEMM, weights streamed from L2)"}.get(path, str(path)),
             "roofline": {"bound": "mfma", "achieved": tfl, "peak": peak, "unit": "TFLOP/s", "frac": tfl / peak,
                          "algorithmic_flop_per_launch": flop, "mac_per_pixel_per_coupling": 16 + 18 * w + w * w + 36 * (w + 1),
                          "dtype": "f32 in / f32 accumulate (exact fp32)" if dt == "fp32" else

@@ -92,9 +92,29 @@ def _within(a, ref64, ref32, floor_rtol):
 
 @pytest.mark.parametrize("seed", list(range(150)))
 def test_random_model_matches_oracle(seed):
+    _check_case(seed, _draw_case(seed))
+
+
+@pytest.mark.parametrize("seed", list(range(600, 616)))
+def test_random_model_wide_couplings_match_oracle(seed):
+    """The same sweep at coupling widths BEYOND 32 (sidd/ArgParser.py:43 defaults --width to 512): the LDS-staged GEMM kernel
+    (csrc/nf_gemm.hip) — widths that are and are not one of its padded sizes, ragged patches of up to 2 048 pixels."""
+    from noise_flow_amd import _lib
+    arch, _, (H, W), fp, decomp, iso, cam, B = _draw_case(seed)
+    rng = np.random.RandomState(seed)
+    width = int(rng.choice([33, 48, 64, 96, 128, 200, 256, 320]))
+    if "unc" not in arch.split("|"):
+        arch = "unc|" + arch
+    while H * W > 2048:
+        H, W = max(1, H // 2), W
+    m = _check_case(seed, (arch, width, (H, W), fp, decomp, iso, cam, min(B, 2)))
+    assert m._flow.lib.nf_kernel_path(m._flow.ptr, 0) == _lib.NF_PATH_GEMM
+
+
+def _check_case(seed, case_tuple):
     from noise_flow_amd import NoiseFlow, default_hps, params
     from oracle.nf_oracle import NoiseFlowOracle
-    arch, width, (H, W), fp, decomp, iso, cam, B = _draw_case(seed)
+    arch, width, (H, W), fp, decomp, iso, cam, B = case_tuple
     rng = np.random.RandomState(seed)
     v = params.init_variables(arch, width, 4, seed, fp, decomp)
     base = trained_like_variables(arch, width, seed=seed)
@@ -128,6 +148,7 @@ def test_random_model_matches_oracle(seed):
         assert np.abs(np.asarray(back) - x).max() <= tol, "round trip %.3e > %.3e" % (np.abs(np.asarray(back) - x).max(), tol)
     except AssertionError as e:
         raise AssertionError("%s: %s" % (case, e))
+    return m
 
 
 @pytest.mark.parametrize("seed", list(range(200, 240)))
