@@ -418,6 +418,394 @@ __global__ __launch_bounds__(GT) void nf_gemm16_kernel(const NfProgram prog, con
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Variant B: pixel tiles, not channel tiles, per wavefront.  Every wavefront owns ONE tile of 32 pixels per round (8 wavefronts =
+// 256 pixels) and computes ALL channels for it: its h1 never leaves its registers (WP / 4 dwords of packed halves per lane — 128
+// VGPRs at width 512), the l_2 accumulators of an output tile are consumed by the transposed l_last the moment they are complete
+// (no cross-wavefront partial P sums), and the WEIGHTS come through LDS: one slab per output tile (nf_gemm_layout.h, NF9_*: the
+// l_2 rows of the tile, its l_last columns, its bias), ALL slabs of a coupling staged once per patch and resident for its 4
+// rounds — which is what limits this variant to widths <= 128 (42 KiB of slabs).  The weights cross L2 -> CU once per patch
+// and coupling instead of once per band, and the operand every wavefront needs sits in LDS (1 KiB per MFMA and wavefront =
+// 128 of the 256 B/clk ds_read_b128 delivers).  A streamed version for 256 / 512 (slabs double-buffered behind the previous
+// tile's MFMAs, one barrier per tile) was measured below variant A (599 against 795 TFLOP/s at 512) and is not kept.
+template <int WP, bool PHILOX, int OWN>
+__global__ __launch_bounds__(GT) void nf_gemm16b_kernel(const NfProgram prog, const NfLaunch a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int MT = WP / 32;                // channel tiles
+    constexpr int KS = WP / 16;                // K steps of l_2
+    constexpr int RND = 32 * GW;               // pixels per round
+    constexpr int SLAB = nf9_slab_dwords(WP);
+    static_assert(MT * SLAB * 4 <= 64 * 1024, "variant B keeps every slab of the coupling resident in LDS (widths <= 128)");
+    constexpr int NBUF = MT;
+    const int H = a.H, W = a.W, HW = H * W;
+    const int Wp = W + 2;
+    const int PL = ((H + 2) * Wp + 3) & ~3;            // the z0 tile: one half2 per pixel
+    uint32_t *const wb = reinterpret_cast<uint32_t *>(smem);            // [NBUF][SLAB] weight slabs
+    float *const prec = smem + NBUF * SLAB;                             // [RND][PSTR] P records of the round
+    uint32_t *const z0h = reinterpret_cast<uint32_t *>(prec + RND * PSTR);   // [PL] half2
+    float *const red = reinterpret_cast<float *>(z0h + PL);            // [3][GW]
+
+    const int t = threadIdx.x;
+    const int wv = t >> 6, lane = t & 63, n = lane & 31, g = lane >> 5;
+    int toff[4];   // l_1: z0-tile offsets of the taps 4g .. 4g+3 this lane half contributes
+#pragma unroll
+    for (int q = 0; q < 4; ++q) toff[q] = ((4 * g + q) / 3) * Wp + (4 * g + q) % 3;
+
+    for (int i = t; i < PL; i += GT) z0h[i] = 0u;
+    __syncthreads();
+    // the pixels this thread owns: p = t + GT m
+    int pr[OWN], pc[OWN];
+    bool act[OWN];
+#pragma unroll
+    for (int m = 0; m < OWN; ++m) {
+        const int p = t + GT * m;
+        act[m] = p < HW;
+        pr[m] = act[m] ? p / W : 0;
+        pc[m] = act[m] ? p - pr[m] * W : 0;
+    }
+
+    const int n_ops = prog.n_ops;
+    const int n_rounds = (HW + RND - 1) / RND;
+    double acc_nll = 0.0, acc_sd = 0.0;   // thread 0 only
+
+    for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
+        const size_t patch_off = (size_t)b * (size_t)HW * 4u;
+
+        float z[OWN][4];
+#pragma unroll
+        for (int m = 0; m < OWN; ++m) {
+            const int gi = act[m] ? t + GT * m : 0;
+            if (PHILOX) {
+                philox_normal4(a.seed, a.patch_base + b, (uint32_t)gi, NF_STREAM_SAMP, z[m]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) z[m][q] *= a.in_scale;
+            } else {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (act[m]) v = reinterpret_cast<const float4 *>(a.in + patch_off)[gi];
+                z[m][0] = v.x * a.in_scale;
+                z[m][1] = v.y * a.in_scale;
+                z[m][2] = v.z * a.in_scale;
+                z[m][3] = v.w * a.in_scale;
+            }
+        }
+
+        float ld = 0.0f, ld2 = 0.0f;   // natural-log / log2 parts of this thread's log-det share
+
+        for (int op = 0; op < n_ops; ++op) {
+            const int type = prog.ops[op].type;
+            const cfloat_p P = (cfloat_p)(a.params + prog.ops[op].off);   // wave-uniform, scalar loads
+
+            if (type == NF_OP_MIX) {
+                float mm[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) mm[i] = P[i];
+#pragma unroll
+                for (int m = 0; m < OWN; ++m) {
+                    float o[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float s = z[m][0] * mm[j];
+                        s = fmaf(z[m][1], mm[4 + j], s);
+                        s = fmaf(z[m][2], mm[8 + j], s);
+                        s = fmaf(z[m][3], mm[12 + j], s);
+                        o[j] = s;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) z[m][j] = o[j];
+                }
+            } else if (type == NF_OP_COUPLING_FWD || type == NF_OP_COUPLING_REV) {
+                const float *const img = a.params + prog.ops[op].off + NF8_CPL_IMG;
+                const float *const slabs = img + nf9_img_SLAB(WP);
+                // ---- publish the pass-through half (rounded to half: a CNN input) ----
+#pragma unroll
+                for (int m = 0; m < OWN; ++m)
+                    if (act[m]) {
+                        const v2hh zh = {(_Float16)z[m][0], (_Float16)z[m][1]};
+                        z0h[(pr[m] + 1) * Wp + pc[m] + 1] = __builtin_bit_cast(uint32_t, zh);
+                    }
+                float o[OWN][4];
+#pragma unroll
+                for (int m = 0; m < OWN; ++m)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[m][j] = 0.0f;
+                // this coupling's slabs
+                for (int i = t; i < MT * (SLAB / 4); i += GT)
+                    reinterpret_cast<uint4 *>(wb)[i] = reinterpret_cast<const uint4 *>(slabs)[i];
+                __syncthreads();
+
+                for (int rnd = 0; rnd < n_rounds; ++rnd) {
+                    const int p0 = rnd * RND;
+                    // ---- l_1: relu(W1 z0 + b1) -> half for this wavefront's 32 pixels, all channels, into registers ----
+                    uint32_t hr[MT][8];
+                    {
+                        int p = p0 + 32 * wv + n;
+                        p = p < HW ? p : HW - 1;   // columns past the patch: never gathered
+                        const int r = p / W, c = p - r * W;
+                        const uint32_t *zb = z0h + r * Wp + c;   // tap (di,dj) at + di*Wp + dj
+                        const uint4 b0 = make_uint4(zb[toff[0]], zb[toff[1]], zb[toff[2]], zb[toff[3]]);
+                        const uint4 b1 = make_uint4(g == 0 ? zb[2 * Wp + 2] : 0u, 0u, 0u, 0u);
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) {
+                            v16f d;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const float4 bb = ldg4(img + nf8_img_B1(WP) + m * 32 + g * 16 + 4 * q);
+                                d[4 * q + 0] = bb.x; d[4 * q + 1] = bb.y; d[4 * q + 2] = bb.z; d[4 * q + 3] = bb.w;
+                            }
+                            const uint4 a0 = ldg4u(img + nf8_img_A1H(WP) + ((m * 2 + 0) * 64 + lane) * 4);
+                            const uint4 a1 = ldg4u(img + nf8_img_A1H(WP) + ((m * 2 + 1) * 64 + lane) * 4);
+                            d = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_v8h(a0), as_v8h(b0), d, 0, 0, 0);
+                            d = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_v8h(a1), as_v8h(b1), d, 0, 0, 0);
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) hr[m][i] = relu_pack_h2(d[2 * i], d[2 * i + 1]);
+                            __builtin_amdgcn_sched_barrier(0);   // keep the tiles' operand loads from being hoisted on top of each other
+                        }
+                    }
+                    // ---- per output tile: l_2 over the whole K from the slab in LDS, then its share of P = W3^T relu(h2) ----
+                    v16f pa;
+                    v4f p8 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) pa[v] = 0.0f;
+#pragma unroll 1
+                    for (int m = 0; m < MT; ++m) {
+                        const uint32_t *sl = wb + m * SLAB;
+                        v16f acc0;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float4 bb = *reinterpret_cast<const float4 *>(sl + nf9_slab_B2(WP) + g * 16 + 4 * q);
+                            acc0[4 * q + 0] = bb.x; acc0[4 * q + 1] = bb.y; acc0[4 * q + 2] = bb.z; acc0[4 * q + 3] = bb.w;
+                        }
+                        const uint4 *ap = reinterpret_cast<const uint4 *>(sl) + lane;   // K step ks at + 64 ks
+                        // pairs of K steps; the LDS reads of the next pair are issued before the MFMAs of this one (one accumulator
+                        // chain: the SIMD's other wavefront fills the dependent-issue gaps; a second chain costs 16 VGPRs this kernel
+                        // does not have at width 512)
+                        uint4 ca[2], na[2];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) ca[u] = ap[64 * u];
+#pragma unroll
+                        for (int kg = 0; kg < KS; kg += 2) {
+                            if (kg + 2 < KS) {
+#pragma unroll
+                                for (int u = 0; u < 2; ++u) na[u] = ap[64 * (kg + 2 + u)];
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) {
+                                const int ks = kg + u;
+                                const uint4 bq = make_uint4(hr[ks >> 1][4 * (ks & 1) + 0], hr[ks >> 1][4 * (ks & 1) + 1],
+                                                            hr[ks >> 1][4 * (ks & 1) + 2], hr[ks >> 1][4 * (ks & 1) + 3]);
+                                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_v8h(ca[u]), as_v8h(bq), acc0, 0, 0, 0);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) ca[u] = na[u];
+                        }
+                        // h2 tile m complete: relu, round to half, and straight into P (taps 0 .. 7: one 32-row tile; tap 8: 4x4x4)
+#pragma unroll
+                        for (int m2 = 0; m2 < 2; ++m2) {
+                            const uint4 w0 = *reinterpret_cast<const uint4 *>(sl + nf9_slab_A3H(WP) + (m2 * 64 + lane) * 4);
+                            const uint2 c0 = *reinterpret_cast<const uint2 *>(sl + nf9_slab_A3CH(WP) + ((2 * m2 + 0) * 8 + g * 4 + (lane & 3)) * 2);
+                            const uint2 c1 = *reinterpret_cast<const uint2 *>(sl + nf9_slab_A3CH(WP) + ((2 * m2 + 1) * 8 + g * 4 + (lane & 3)) * 2);
+                            uint32_t q[4];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                q[i] = relu_pack_h2(acc0[8 * m2 + 2 * i], acc0[8 * m2 + 2 * i + 1]);
+                            pa = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_v8h(w0), as_v8h(make_uint4(q[0], q[1], q[2], q[3])), pa, 0, 0, 0);
+                            p8 = __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(v4hh, c0), __builtin_bit_cast(v4hh, make_uint2(q[0], q[1])), p8, 0, 0, 0);
+                            p8 = __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(v4hh, c1), __builtin_bit_cast(v4hh, make_uint2(q[2], q[3])), p8, 0, 0, 0);
+                        }
+                    }
+                    // ---- P records of the round: per pixel [tap 0..7][j] (register group a of lane half g = tap 2 a + g), tap 8 of half 0 / 1 ----
+                    {
+                        float *dst = prec + (size_t)(32 * wv + n) * PSTR;
+#pragma unroll
+                        for (int aa = 0; aa < 4; ++aa)
+                            *reinterpret_cast<float4 *>(dst + (2 * aa + g) * 4) = make_float4(pa[4 * aa + 0], pa[4 * aa + 1], pa[4 * aa + 2], pa[4 * aa + 3]);
+                        *reinterpret_cast<float4 *>(dst + 32 + 4 * g) = make_float4(p8[0], p8[1], p8[2], p8[3]);
+                    }
+                    __syncthreads();
+                    // gather: the taps of this round's pixels that fall on the output pixels this thread owns
+#pragma unroll
+                    for (int m = 0; m < OWN; ++m) {
+                        const int q = t + GT * m;
+                        if (!act[m] || q + W + 1 < p0 || q >= p0 + RND + W + 1) continue;
+#pragma unroll
+                        for (int di = 0; di < 3; ++di) {
+                            const int rr = pr[m] + di - 1;
+                            if (rr < 0 || rr >= H) continue;
+#pragma unroll
+                            for (int dj = 0; dj < 3; ++dj) {
+                                const int cc = pc[m] + dj - 1;
+                                const int src = rr * W + cc - p0;
+                                if (cc < 0 || cc >= W || src < 0 || src >= RND) continue;
+                                const float *rp = prec + (size_t)src * PSTR;
+                                float4 v = *reinterpret_cast<const float4 *>(rp + (di * 3 + dj) * 4);
+                                if (di * 3 + dj == 8) {   // tap 8: the two lane halves' partial sums
+                                    const float4 u = *reinterpret_cast<const float4 *>(rp + 36);
+                                    v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+                                }
+                                o[m][0] += v.x; o[m][1] += v.y; o[m][2] += v.z; o[m][3] += v.w;
+                            }
+                        }
+                    }
+                    __syncthreads();   // the next round overwrites the records
+                }
+
+                // ---- finish the coupling on the owned pixels ----
+                const float scl = P[NF8_CPL_S + 1], m2scl = P[NF8_CPL_S + 2];
+#pragma unroll
+                for (int m = 0; m < OWN; ++m) {
+                    const int r = pr[m], c = pc[m];
+                    const int bm = (r == 0 ? 1 : 0) | (r == H - 1 ? 2 : 0) | (c == 0 ? 4 : 0) | (c == W - 1 ? 8 : 0);
+                    const float4 eb = *reinterpret_cast<const float4 *>(a.params + prog.ops[op].off + NF8_CPL_E + 4 * (act[m] ? bm : 0));
+                    o[m][0] += eb.x; o[m][1] += eb.y;
+                    o[m][2] = fmaf(o[m][2], 2.8853900817779268f, eb.z);
+                    o[m][3] = fmaf(o[m][3], 2.8853900817779268f, eb.w);
+                    const float l0 = fmaf(__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(o[m][2]) + 1.0f), m2scl, scl);
+                    const float l1 = fmaf(__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(o[m][3]) + 1.0f), m2scl, scl);
+                    if (type == NF_OP_COUPLING_FWD) {
+                        z[m][2] = fmaf(z[m][2], __builtin_amdgcn_exp2f(l0), o[m][0]);
+                        z[m][3] = fmaf(z[m][3], __builtin_amdgcn_exp2f(l1), o[m][1]);
+                        if (act[m]) ld2 += l0 + l1;
+                    } else {
+                        z[m][2] = (z[m][2] - o[m][0]) * __builtin_amdgcn_exp2f(-l0);
+                        z[m][3] = (z[m][3] - o[m][1]) * __builtin_amdgcn_exp2f(-l1);
+                    }
+                }
+            } else if (type == NF_OP_SDN_DIV || type == NF_OP_SDN_MUL) {
+                // AffineCouplingSdnEx5: scale = sqrt(beta1*y/gain + beta2)  (cond_utils.py:238)
+                const float4 *y4 = reinterpret_cast<const float4 *>(a.y + patch_off);
+                const float ck1 = a.cond_a[prog.ops[op].off & 3], cb2 = a.cond_b[prog.ops[op].off & 3];
+#pragma unroll
+                for (int m = 0; m < OWN; ++m) {
+                    float4 yv = make_float4(1.f, 1.f, 1.f, 1.f);
+                    if (act[m]) yv = y4[t + GT * m];
+                    const float yy[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float v = fmaf(yy[q], ck1, cb2);
+                        if (type == NF_OP_SDN_DIV) {
+                            z[m][q] = z[m][q] * __builtin_amdgcn_rsqf(v);
+                            if (act[m]) ld = fmaf(-0.34657359027997264f, __builtin_amdgcn_logf(v), ld);
+                        } else {
+                            z[m][q] = z[m][q] * __builtin_amdgcn_sqrtf(v);
+                        }
+                    }
+                }
+            } else if (type == NF_OP_SCALE || type == NF_OP_SCALE_COND) {
+                const float s = type == NF_OP_SCALE ? P[0] : a.cond_a[prog.ops[op].off & 3];
+#pragma unroll
+                for (int m = 0; m < OWN; ++m)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) z[m][q] *= s;
+            }
+        }
+
+        // ---- epilogue (as nf_flow_kernel) ----
+        if (a.out) {
+            float4 *out4 = reinterpret_cast<float4 *>(a.out + patch_off);
+#pragma unroll
+            for (int m = 0; m < OWN; ++m)
+                if (act[m]) out4[t + GT * m] = make_float4(z[m][0], z[m][1], z[m][2], z[m][3]);
+        }
+        if (a.nll_out || a.sd_out || a.ld_out || a.sums) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int m = 0; m < OWN; ++m)
+                if (act[m]) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        s1 += z[m][q];
+                        s2 = fmaf(z[m][q], z[m][q], s2);
+                    }
+                }
+            float r0 = wave_sum(fmaf(ld2, 0.6931471805599453f, ld)), r1 = wave_sum(s1), r2 = wave_sum(s2);
+            if (lane == 0) {
+                red[wv] = r0;
+                red[GW + wv] = r1;
+                red[2 * GW + wv] = r2;
+            }
+            __syncthreads();
+            if (t == 0) {
+                r0 = 0.f; r1 = 0.f; r2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < GW; ++i) {
+                    r0 += red[i];
+                    r1 += red[GW + i];
+                    r2 += red[2 * GW + i];
+                }
+                const double npx = (double)HW * 4.0;
+                const double logdet = (double)r0 + a.ld_const;
+                double nll = -logdet;   // prior: sum -0.5*(log 2pi + z^2)   (noise_flow_model.py:537-539)
+                if (a.flags & NF_K_PRIOR) nll += 0.5 * npx * 1.8378770664093453 + 0.5 * (double)r2;
+                const double mean = (double)r1 / npx;
+                double var = (double)r2 / npx - mean * mean;   // noise_flow_model.py:477-478
+                var = var > 0.0 ? var : 0.0;
+                const double sd = sqrt(var);
+                if (a.nll_out) a.nll_out[b] = (float)nll;
+                if (a.sd_out) a.sd_out[b] = (float)sd;
+                if (a.ld_out) a.ld_out[b] = (float)logdet;
+                acc_nll += (double)(float)nll;
+                acc_sd += (double)(float)sd;
+            }
+            __syncthreads();   // scratch is reused by the next patch
+        }
+    }
+
+    if (a.sums && t == 0) {
+        double *sp = a.sums;
+        if (a.flags & NF_K_SUMS_WIDE) sp += (size_t)(blockIdx.x & (NF_SUMS_SLOTS - 1)) * NF_SUMS_STRIDE;
+        atomicAdd(&sp[0], acc_nll);
+        atomicAdd(&sp[1], acc_sd);
+        if (blockIdx.x == 0) atomicAdd(&sp[2], (double)a.B);
+    }
+}
+
+size_t gemm16b_lds_bytes(int wp, int H, int W)
+{
+    const int Wp = W + 2, PL = ((H + 2) * Wp + 3) & ~3, MT = wp / 32, SLAB = nf9_slab_dwords(wp);
+    return ((size_t)MT * SLAB + (size_t)32 * GW * PSTR + (size_t)PL + 3 * GW + 8) * sizeof(float);
+}
+
+template <int WP, bool PHILOX, int OWN>
+hipError_t launch_gemm16b(const NfProgram &prog, const NfLaunch &a, int n_cu, int device, hipStream_t stream)
+{
+    const size_t lds = gemm16b_lds_bytes(WP, a.H, a.W);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    const void *fn = reinterpret_cast<const void *>(&nf_gemm16b_kernel<WP, PHILOX, OWN>);
+    static std::atomic<size_t> lds_set[16];
+    std::atomic<size_t> &cur = lds_set[device & 15];
+    if (lds > cur.load(std::memory_order_relaxed) || device > 15) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        cur.store(lds, std::memory_order_relaxed);
+    }
+    int64_t groups = n_cu;
+    if (a.B < groups) groups = a.B;
+    if (groups < 1) groups = 1;
+    hipLaunchKernelGGL((nf_gemm16b_kernel<WP, PHILOX, OWN>), dim3((unsigned)groups), dim3(GT), lds, stream, prog, a);
+    return hipGetLastError();
+}
+
+template <int WP, bool PHILOX>
+hipError_t dispatch_own16b(const NfProgram &prog, const NfLaunch &a, int n_cu, int device, hipStream_t stream)
+{
+    if (a.H * a.W <= 2 * GT) return launch_gemm16b<WP, PHILOX, 2>(prog, a, n_cu, device, stream);
+    return launch_gemm16b<WP, PHILOX, 4>(prog, a, n_cu, device, stream);
+}
+
+template <bool PHILOX>
+hipError_t dispatch_gemm16b(const NfProgram &prog, const NfLaunch &a, int n_cu, int device, hipStream_t stream)
+{
+    switch (prog.width) {
+    case 64: return dispatch_own16b<64, PHILOX>(prog, a, n_cu, device, stream);
+    case 128: return dispatch_own16b<128, PHILOX>(prog, a, n_cu, device, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
 size_t gemm16_lds_bytes(int H, int W)
 {
     const int Wp = W + 2, PL = ((H + 2) * Wp + 3) & ~3;
@@ -465,6 +853,14 @@ hipError_t dispatch_gemm16(const NfProgram &prog, const NfLaunch &a, int n_cu, i
 }
 
 }  // namespace
+
+// variant B: programs in the NF9 layout
+hipError_t nf_launch_gemm16b(const NfProgram &prog, const NfLaunch &a, int n_cu, int device, hipStream_t stream)
+{
+    if (a.H < 1 || a.W < 1 || a.H * a.W > NF7_MAX_PIXELS || gemm16b_lds_bytes(prog.width, a.H, a.W) > 160 * 1024) return hipErrorInvalidValue;
+    if (a.flags & NF_K_PHILOX_IN) return dispatch_gemm16b<true>(prog, a, n_cu, device, stream);
+    return dispatch_gemm16b<false>(prog, a, n_cu, device, stream);
+}
 
 // entry point used by nf_host.hip: programs in the NF8 layout (NF_CFG_FP16_CNN, coupling width padded to 64 / 128 / 256 / 512)
 hipError_t nf_launch_gemm16(const NfProgram &prog, const NfLaunch &a, int n_cu, int device, hipStream_t stream)

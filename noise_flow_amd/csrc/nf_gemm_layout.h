@@ -30,3 +30,17 @@ __host__ __device__ constexpr int nf8_img_A3CH(int wp) { return (wp / 32) * 576 
 __host__ __device__ constexpr int nf8_img_size(int wp) { return (wp / 32) * (576 + 512 + 64) + wp * wp / 2; }
 __host__ __device__ constexpr int nf8_cpl_size(int wp) { return NF8_CPL_IMG + nf8_img_size(wp); }
 #define NF8_BAND_HALVES 65536   // hidden activations of one band: WP channels x NB pixels, half precision (128 KiB of LDS)
+
+// ---- variant B (pixel tiles per wavefront, weights through LDS): one contiguous SLAB per channel tile m ----------------------------
+//   IMG9 @68:  A1H [MT][2][64][4] and B1 [MT][2][16] as NF8 (same offsets), then
+//     SLAB [MT] x { A2H(m) [WP/16][64][4]   the l_2 rows of OUTPUT tile m, K step ks at + 64 ks (16 bytes per lane)
+//                   A3H(m) [2][64][4]        the l_last columns (taps 0 .. 7) of INPUT tile m
+//                   A3CH(m)[4][8][2]         tap 8
+//                   B2(m)  [2][16] }         fp32 bias of l_2's output tile m
+__host__ __device__ constexpr int nf9_slab_dwords(int wp) { return (wp / 16) * 256 + 512 + 64 + 32; }
+__host__ __device__ constexpr int nf9_slab_A3H(int wp) { return (wp / 16) * 256; }
+__host__ __device__ constexpr int nf9_slab_A3CH(int wp) { return (wp / 16) * 256 + 512; }
+__host__ __device__ constexpr int nf9_slab_B2(int wp) { return (wp / 16) * 256 + 512 + 64; }
+__host__ __device__ constexpr int nf9_img_SLAB(int wp) { return (wp / 32) * 544; }
+__host__ __device__ constexpr int nf9_img_size(int wp) { return (wp / 32) * 544 + (wp / 32) * nf9_slab_dwords(wp); }
+__host__ __device__ constexpr int nf9_cpl_size(int wp) { return NF8_CPL_IMG + nf9_img_size(wp); }

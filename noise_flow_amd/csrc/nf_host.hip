@@ -28,6 +28,7 @@ hipError_t nf_launch_wide(const NfProgram &prog, const NfLaunch &a, int n_cu, in
 hipError_t nf_launch_wide16(const NfProgram &prog, const NfLaunch &a, int n_cu, int device, hipStream_t stream);
 hipError_t nf_launch_gemm(const NfProgram &prog, const NfLaunch &a, int n_cu, int device, hipStream_t stream);
 hipError_t nf_launch_gemm16(const NfProgram &prog, const NfLaunch &a, int n_cu, int device, hipStream_t stream);
+hipError_t nf_launch_gemm16b(const NfProgram &prog, const NfLaunch &a, int n_cu, int device, hipStream_t stream);
 bool nf_gemm_shape_ok(int H, int W);
 hipError_t nf_launch_synth(uint64_t seed, int64_t patch_base, int64_t B, int HW, float beta1, float beta2,
                            float *y_out, float *x_out, hipStream_t stream);
@@ -508,6 +509,24 @@ void relayout_coupling_gemm16(const float *v1, int w, int wp, float *out)
     }
 }
 
+// Variant B of the fp16-CNN GEMM layout (NF9_*): the same values, one contiguous slab per channel tile.
+void relayout_coupling_gemm16b(const float *v1, int w, int wp, float *out)
+{
+    std::vector<float> a(nf8_cpl_size(wp));
+    relayout_coupling_gemm16(v1, w, wp, a.data());
+    const int MT = wp / 32, KS = wp / 16;
+    memcpy(out, a.data(), (size_t)(NF8_CPL_IMG + MT * 544) * sizeof(float));      // E, S, A1H, B1 (same offsets)
+    const float *ia = a.data() + NF8_CPL_IMG;
+    float *io = out + NF8_CPL_IMG;
+    for (int m = 0; m < MT; ++m) {
+        float *sl = io + nf9_img_SLAB(wp) + (size_t)m * nf9_slab_dwords(wp);
+        memcpy(sl, ia + nf8_img_A2H(wp) + (size_t)m * KS * 256, (size_t)KS * 256 * sizeof(float));
+        memcpy(sl + nf9_slab_A3H(wp), ia + nf8_img_A3H(wp) + (size_t)m * 512, 512 * sizeof(float));
+        memcpy(sl + nf9_slab_A3CH(wp), ia + nf8_img_A3CH(wp) + (size_t)m * 64, 64 * sizeof(float));
+        memcpy(sl + nf9_slab_B2(wp), ia + nf8_img_B2(wp) + (size_t)m * 32, 32 * sizeof(float));
+    }
+}
+
 // Width-16 re-layout (nf_device.h, NF6_*; `w` = 16, or 8 zero-padded): fetch order of v_mfma_f32_16x16x4_f32.
 void relayout_coupling_wide16(const float *v1, int w, float *out)
 {
@@ -749,6 +768,7 @@ struct Built {
     std::vector<float> block7;
     NfProgram prog8;             // fp16-CNN GEMM layout (NF8_*): NF_CFG_FP16_CNN at widths 33 .. 512
     std::vector<float> block8;
+    bool gemm16_b = false;       // block8 is in the variant-B layout (NF9_*: widths <= 128)
     double ld_const = 0.0;
     bool has_sdn = false;      // some op reads the clean image y
 };
@@ -1000,6 +1020,10 @@ int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float
     if (out.prog.width > 32 && (cfg->flags & NF_CFG_FP16_CNN)) {
         const int wp = nf7_pad_width(out.prog.width);
         out.prog8.width = wp;
+        {   // variant B (weights resident in LDS, pixel tiles per wavefront) where its slabs fit: widths <= 128; NF_GEMM16=a: A/B aid
+            const char *e = getenv("NF_GEMM16");
+            out.gemm16_b = wp <= 128 && !(e && e[0] == 'a');
+        }
         for (int i = 0; i < out.prog.n_ops; ++i) {
             const NfOp &src = out.prog.ops[i];
             NfOp &dst = out.prog8.ops[out.prog8.n_ops++];
@@ -1009,8 +1033,9 @@ int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float
             if (src.type == NF_OP_MIX) {
                 out.block8.insert(out.block8.end(), v1, v1 + 16);
             } else if (src.type == NF_OP_COUPLING_FWD || src.type == NF_OP_COUPLING_REV) {
-                out.block8.resize(out.block8.size() + nf8_cpl_size(wp));
-                relayout_coupling_gemm16(v1, out.prog.width, wp, out.block8.data() + dst.off);
+                out.block8.resize(out.block8.size() + (out.gemm16_b ? nf9_cpl_size(wp) : nf8_cpl_size(wp)));
+                if (out.gemm16_b) relayout_coupling_gemm16b(v1, out.prog.width, wp, out.block8.data() + dst.off);
+                else relayout_coupling_gemm16(v1, out.prog.width, wp, out.block8.data() + dst.off);
             } else if (src.type == NF_OP_SCALE) {
                 out.block8.insert(out.block8.end(), v1, v1 + 4);
             } else {
@@ -1480,7 +1505,7 @@ static int launch_resident(nf_handle *h, int direction, NfLaunch &a, hipStream_t
         a.params = d8;
         a.n_params = (int32_t)b.block8.size();
         a.flags |= NF_K_FP16_CNN;
-        hipError_t e = nf_launch_gemm16(b.prog8, a, h->n_cu, h->device, st);
+        hipError_t e = b.gemm16_b ? nf_launch_gemm16b(b.prog8, a, h->n_cu, h->device, st) : nf_launch_gemm16(b.prog8, a, h->n_cu, h->device, st);
         if (e != hipSuccess) return fail_hip(e, what);
         return NF_OK;
     }
