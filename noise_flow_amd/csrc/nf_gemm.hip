@@ -32,6 +32,7 @@
 #include <atomic>
 #include "../../include/noiseflow_hip.h"   // NF_SUMS_SLOTS / NF_SUMS_STRIDE
 #include "nf_device.h"
+#include "nf_gemm_layout.h"
 #include "nf_dev_util.h"
 
 namespace {
@@ -420,6 +421,367 @@ __global__ __launch_bounds__(GT) void nf_gemm_kernel(const NfProgram prog, const
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Variant B (widths <= 128): pixel tiles, not channel tiles, per wavefront.  Every wavefront owns ONE tile of 32 pixels per round
+// (8 wavefronts = 256 pixels) and computes ALL channels for it: its h1 stays in its registers (WP / 2 floats per lane), the l_2
+// accumulators of an output tile go straight into the transposed l_last (no cross-wavefront partial P sums), and the weights come
+// through LDS — one slab per output tile (nf_gemm_layout.h, NF10_*), all slabs of a coupling staged once per patch and resident
+// for its rounds (85 KiB at width 128).  Nothing is re-streamed per band and the band bookkeeping of variant A (4 barriers, a
+// partial-sum gather over WM wavefronts) shrinks to 2 barriers per round.  Beyond 128 the slabs do not fit and variant A runs.
+template <int WP, bool PHILOX, int OWN>
+__global__ __launch_bounds__(GT) void nf_gemmb_kernel(const NfProgram prog, const NfLaunch a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int MT = WP / 32;                // channel tiles
+    constexpr int KC = WP / 8;                 // chunks of 4 K steps of l_2
+    constexpr int RND = 32 * GW;               // pixels per round
+    constexpr int SLAB = nf10_slab_floats(WP);
+    static_assert(MT * SLAB * 4 <= 96 * 1024, "variant B keeps every slab of the coupling resident in LDS (widths <= 128)");
+    const int H = a.H, W = a.W, HW = H * W;
+    const int Wp = W + 2;
+    const int PL = ((H + 2) * Wp + 3) & ~3;            // one channel plane of the z0 tile
+    float *const wb = smem;                             // [MT][SLAB] weight slabs
+    float *const prec = wb + MT * SLAB;                 // [RND][NF7_P_STRIDE] P records of the round
+    float *const z0s = prec + RND * NF7_P_STRIDE;       // [2][PL]
+    float *const red = z0s + 2 * PL;                    // [3][GW]
+
+    const int t = threadIdx.x;
+    const int wv = t >> 6, lane = t & 63, n = lane & 31, g = lane >> 5;
+
+    for (int i = t; i < 2 * PL; i += GT) z0s[i] = 0.0f;
+    __syncthreads();
+    // the pixels this thread owns: p = t + GT m
+    int pr[OWN], pc[OWN];
+    bool act[OWN];
+#pragma unroll
+    for (int m = 0; m < OWN; ++m) {
+        const int p = t + GT * m;
+        act[m] = p < HW;
+        pr[m] = act[m] ? p / W : 0;
+        pc[m] = act[m] ? p - pr[m] * W : 0;
+    }
+
+    const int n_ops = prog.n_ops;
+    const int n_rounds = (HW + RND - 1) / RND;
+    double acc_nll = 0.0, acc_sd = 0.0;   // thread 0 only
+
+    for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
+        const size_t patch_off = (size_t)b * (size_t)HW * 4u;
+
+        float z[OWN][4];
+#pragma unroll
+        for (int m = 0; m < OWN; ++m) {
+            const int gi = act[m] ? t + GT * m : 0;
+            if (PHILOX) {
+                philox_normal4(a.seed, a.patch_base + b, (uint32_t)gi, NF_STREAM_SAMP, z[m]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) z[m][q] *= a.in_scale;
+            } else {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (act[m]) v = reinterpret_cast<const float4 *>(a.in + patch_off)[gi];
+                z[m][0] = v.x * a.in_scale;
+                z[m][1] = v.y * a.in_scale;
+                z[m][2] = v.z * a.in_scale;
+                z[m][3] = v.w * a.in_scale;
+            }
+        }
+
+        float ld = 0.0f, ld2 = 0.0f;   // natural-log / log2 parts of this thread's log-det share
+
+        for (int op = 0; op < n_ops; ++op) {
+            const int type = prog.ops[op].type;
+            const cfloat_p P = (cfloat_p)(a.params + prog.ops[op].off);   // wave-uniform, scalar loads
+
+            if (type == NF_OP_MIX) {
+                float mm[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) mm[i] = P[i];
+#pragma unroll
+                for (int m = 0; m < OWN; ++m) {
+                    float o[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float s = z[m][0] * mm[j];
+                        s = fmaf(z[m][1], mm[4 + j], s);
+                        s = fmaf(z[m][2], mm[8 + j], s);
+                        s = fmaf(z[m][3], mm[12 + j], s);
+                        o[j] = s;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) z[m][j] = o[j];
+                }
+            } else if (type == NF_OP_COUPLING_FWD || type == NF_OP_COUPLING_REV) {
+                const float *const img = a.params + prog.ops[op].off + NF7_CPL_IMG;
+                // ---- publish the pass-through half, stage this coupling's slabs ----
+#pragma unroll
+                for (int m = 0; m < OWN; ++m)
+                    if (act[m]) {
+                        z0s[(pr[m] + 1) * Wp + pc[m] + 1] = z[m][0];
+                        z0s[PL + (pr[m] + 1) * Wp + pc[m] + 1] = z[m][1];
+                    }
+                float o[OWN][4];
+#pragma unroll
+                for (int m = 0; m < OWN; ++m)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[m][j] = 0.0f;
+                for (int i = t; i < MT * (SLAB / 4); i += GT)
+                    reinterpret_cast<float4 *>(wb)[i] = reinterpret_cast<const float4 *>(img + nf10_img_SLAB(WP))[i];
+                __syncthreads();
+
+                for (int rnd = 0; rnd < n_rounds; ++rnd) {
+                    const int p0 = rnd * RND;
+                    // ---- l_1: relu(W1 z0 + b1) for this wavefront's 32 pixels, all channels, into registers ----
+                    float hr[MT][16];
+                    {
+                        int p = p0 + 32 * wv + n;
+                        p = p < HW ? p : HW - 1;   // columns past the patch: never gathered
+                        const int r = p / W, c = p - r * W;
+                        const float *zb = z0s + g * PL + r * Wp + c;   // tap (di,dj) at + di*Wp + dj
+                        float bt[9];
+#pragma unroll
+                        for (int tap = 0; tap < 9; ++tap) bt[tap] = zb[(tap / 3) * Wp + tap % 3];
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) {
+                            v16f d;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const float4 bb = ldg4(img + nf7_img_B1(WP) + m * 32 + g * 16 + 4 * q);
+                                d[4 * q + 0] = bb.x; d[4 * q + 1] = bb.y; d[4 * q + 2] = bb.z; d[4 * q + 3] = bb.w;
+                            }
+#pragma unroll
+                            for (int grp = 0; grp < 3; ++grp) {
+                                const float4 aw = ldg4(img + nf7_img_A1(WP) + ((m * 3 + grp) * 64 + lane) * 4);
+                                const float as[4] = {aw.x, aw.y, aw.z, aw.w};
+#pragma unroll
+                                for (int s = 0; s < 4; ++s)
+                                    if (grp * 4 + s < 9) d = __builtin_amdgcn_mfma_f32_32x32x2f32(as[s], bt[grp * 4 + s], d, 0, 0, 0);
+                            }
+#pragma unroll
+                            for (int v = 0; v < 16; ++v) hr[m][v] = nf_relu(d[v]);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                    // ---- per output tile: l_2 over the whole K from the slab in LDS, then its share of P = W3^T relu(h2) ----
+                    v16f pa;
+                    v4f p8 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) pa[v] = 0.0f;
+#pragma unroll 1
+                    for (int m = 0; m < MT; ++m) {
+                        const float *sl = wb + m * SLAB;
+                        v16f acc;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float4 bb = *reinterpret_cast<const float4 *>(sl + nf10_slab_B2(WP) + g * 16 + 4 * q);
+                            acc[4 * q + 0] = bb.x; acc[4 * q + 1] = bb.y; acc[4 * q + 2] = bb.z; acc[4 * q + 3] = bb.w;
+                        }
+                        const float4 *ap = reinterpret_cast<const float4 *>(sl) + lane;   // chunk kc (K steps 4 kc .. 4 kc + 3) at + 64 kc
+                        float4 ca = ap[0], na = ca;
+#pragma unroll
+                        for (int kc = 0; kc < KC; ++kc) {
+                            if (kc + 1 < KC) na = ap[64 * (kc + 1)];
+                            __builtin_amdgcn_sched_barrier(0);
+                            const float as[4] = {ca.x, ca.y, ca.z, ca.w};
+#pragma unroll
+                            for (int s = 0; s < 4; ++s) {
+                                const int kk = 4 * kc + s;   // consumes register kk % 16 of input tile kk / 16
+                                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(as[s], hr[kk >> 4][kk & 15], acc, 0, 0, 0);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                            ca = na;
+                        }
+                        // h2 tile m complete: ReLU and straight into P (taps 0 .. 7: one 32-row tile; tap 8: 4x4x1)
+#pragma unroll
+                        for (int grp = 0; grp < 4; ++grp) {
+                            const float4 w0 = *reinterpret_cast<const float4 *>(sl + nf10_slab_A3(WP) + (grp * 64 + lane) * 4);
+                            const float4 wc = *reinterpret_cast<const float4 *>(sl + nf10_slab_A3C(WP) + (grp * 8 + g * 4 + (lane & 3)) * 4);
+                            const float ws0[4] = {w0.x, w0.y, w0.z, w0.w}, wcs[4] = {wc.x, wc.y, wc.z, wc.w};
+#pragma unroll
+                            for (int s = 0; s < 4; ++s) {
+                                const float h = nf_relu(acc[grp * 4 + s]);
+                                pa = __builtin_amdgcn_mfma_f32_32x32x2f32(ws0[s], h, pa, 0, 0, 0);
+                                p8 = __builtin_amdgcn_mfma_f32_4x4x1f32(wcs[s], h, p8, 0, 0, 0);
+                            }
+                        }
+                    }
+                    // ---- P records of the round ----
+                    {
+                        float *dst = prec + (size_t)(32 * wv + n) * NF7_P_STRIDE;
+#pragma unroll
+                        for (int aa = 0; aa < 4; ++aa)
+                            *reinterpret_cast<float4 *>(dst + (2 * aa + g) * 4) = make_float4(pa[4 * aa + 0], pa[4 * aa + 1], pa[4 * aa + 2], pa[4 * aa + 3]);
+                        *reinterpret_cast<float4 *>(dst + 32 + 4 * g) = make_float4(p8[0], p8[1], p8[2], p8[3]);
+                    }
+                    __syncthreads();
+                    // gather: the taps of this round's pixels that fall on the output pixels this thread owns
+#pragma unroll
+                    for (int m = 0; m < OWN; ++m) {
+                        const int q = t + GT * m;
+                        if (!act[m] || q + W + 1 < p0 || q >= p0 + RND + W + 1) continue;
+#pragma unroll
+                        for (int di = 0; di < 3; ++di) {
+                            const int rr = pr[m] + di - 1;
+                            if (rr < 0 || rr >= H) continue;
+#pragma unroll
+                            for (int dj = 0; dj < 3; ++dj) {
+                                const int cc = pc[m] + dj - 1;
+                                const int src = rr * W + cc - p0;
+                                if (cc < 0 || cc >= W || src < 0 || src >= RND) continue;
+                                const float *rp = prec + (size_t)src * NF7_P_STRIDE;
+                                float4 v = *reinterpret_cast<const float4 *>(rp + (di * 3 + dj) * 4);
+                                if (di * 3 + dj == 8) {   // tap 8: the two lane halves' partial sums
+                                    const float4 u = *reinterpret_cast<const float4 *>(rp + 36);
+                                    v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+                                }
+                                o[m][0] += v.x; o[m][1] += v.y; o[m][2] += v.z; o[m][3] += v.w;
+                            }
+                        }
+                    }
+                    __syncthreads();   // the next round overwrites the records
+                }
+
+                // ---- finish the coupling on the owned pixels ----
+                const float scl = P[NF7_CPL_S + 1], m2scl = P[NF7_CPL_S + 2];
+#pragma unroll
+                for (int m = 0; m < OWN; ++m) {
+                    const int r = pr[m], c = pc[m];
+                    const int bm = (r == 0 ? 1 : 0) | (r == H - 1 ? 2 : 0) | (c == 0 ? 4 : 0) | (c == W - 1 ? 8 : 0);
+                    const float4 eb = *reinterpret_cast<const float4 *>(a.params + prog.ops[op].off + NF7_CPL_E + 4 * (act[m] ? bm : 0));
+                    o[m][0] += eb.x; o[m][1] += eb.y; o[m][2] += eb.z; o[m][3] += eb.w;
+                    const float l0 = fmaf(__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(o[m][2]) + 1.0f), m2scl, scl);
+                    const float l1 = fmaf(__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(o[m][3]) + 1.0f), m2scl, scl);
+                    if (type == NF_OP_COUPLING_FWD) {
+                        z[m][2] = fmaf(z[m][2], __builtin_amdgcn_exp2f(l0), o[m][0]);
+                        z[m][3] = fmaf(z[m][3], __builtin_amdgcn_exp2f(l1), o[m][1]);
+                        if (act[m]) ld2 += l0 + l1;
+                    } else {
+                        z[m][2] = (z[m][2] - o[m][0]) * __builtin_amdgcn_exp2f(-l0);
+                        z[m][3] = (z[m][3] - o[m][1]) * __builtin_amdgcn_exp2f(-l1);
+                    }
+                }
+            } else if (type == NF_OP_SDN_DIV || type == NF_OP_SDN_MUL) {
+                // AffineCouplingSdnEx5: scale = sqrt(beta1*y/gain + beta2)  (cond_utils.py:238)
+                const float4 *y4 = reinterpret_cast<const float4 *>(a.y + patch_off);
+                const float ck1 = a.cond_a[prog.ops[op].off & 3], cb2 = a.cond_b[prog.ops[op].off & 3];
+#pragma unroll
+                for (int m = 0; m < OWN; ++m) {
+                    float4 yv = make_float4(1.f, 1.f, 1.f, 1.f);
+                    if (act[m]) yv = y4[t + GT * m];
+                    const float yy[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float v = fmaf(yy[q], ck1, cb2);
+                        if (type == NF_OP_SDN_DIV) {
+                            z[m][q] = z[m][q] * __builtin_amdgcn_rsqf(v);
+                            if (act[m]) ld = fmaf(-0.34657359027997264f, __builtin_amdgcn_logf(v), ld);
+                        } else {
+                            z[m][q] = z[m][q] * __builtin_amdgcn_sqrtf(v);
+                        }
+                    }
+                }
+            } else if (type == NF_OP_SCALE || type == NF_OP_SCALE_COND) {
+                const float s = type == NF_OP_SCALE ? P[0] : a.cond_a[prog.ops[op].off & 3];
+#pragma unroll
+                for (int m = 0; m < OWN; ++m)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) z[m][q] *= s;
+            }
+        }
+
+        // ---- epilogue (as nf_flow_kernel) ----
+        if (a.out) {
+            float4 *out4 = reinterpret_cast<float4 *>(a.out + patch_off);
+#pragma unroll
+            for (int m = 0; m < OWN; ++m)
+                if (act[m]) out4[t + GT * m] = make_float4(z[m][0], z[m][1], z[m][2], z[m][3]);
+        }
+        if (a.nll_out || a.sd_out || a.ld_out || a.sums) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int m = 0; m < OWN; ++m)
+                if (act[m]) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        s1 += z[m][q];
+                        s2 = fmaf(z[m][q], z[m][q], s2);
+                    }
+                }
+            float r0 = wave_sum(fmaf(ld2, 0.6931471805599453f, ld)), r1 = wave_sum(s1), r2 = wave_sum(s2);
+            if (lane == 0) {
+                red[wv] = r0;
+                red[GW + wv] = r1;
+                red[2 * GW + wv] = r2;
+            }
+            __syncthreads();
+            if (t == 0) {
+                r0 = 0.f; r1 = 0.f; r2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < GW; ++i) {
+                    r0 += red[i];
+                    r1 += red[GW + i];
+                    r2 += red[2 * GW + i];
+                }
+                const double npx = (double)HW * 4.0;
+                const double logdet = (double)r0 + a.ld_const;
+                double nll = -logdet;   // prior: sum -0.5*(log 2pi + z^2)   (noise_flow_model.py:537-539)
+                if (a.flags & NF_K_PRIOR) nll += 0.5 * npx * 1.8378770664093453 + 0.5 * (double)r2;
+                const double mean = (double)r1 / npx;
+                double var = (double)r2 / npx - mean * mean;   // noise_flow_model.py:477-478
+                var = var > 0.0 ? var : 0.0;
+                const double sd = sqrt(var);
+                if (a.nll_out) a.nll_out[b] = (float)nll;
+                if (a.sd_out) a.sd_out[b] = (float)sd;
+                if (a.ld_out) a.ld_out[b] = (float)logdet;
+                acc_nll += (double)(float)nll;
+                acc_sd += (double)(float)sd;
+            }
+            __syncthreads();   // scratch is reused by the next patch
+        }
+    }
+
+    if (a.sums && t == 0) {
+        double *sp = a.sums;
+        if (a.flags & NF_K_SUMS_WIDE) sp += (size_t)(blockIdx.x & (NF_SUMS_SLOTS - 1)) * NF_SUMS_STRIDE;
+        atomicAdd(&sp[0], acc_nll);
+        atomicAdd(&sp[1], acc_sd);
+        if (blockIdx.x == 0) atomicAdd(&sp[2], (double)a.B);
+    }
+}
+
+size_t gemmb_lds_bytes(int wp, int H, int W)
+{
+    const int Wp = W + 2, PL = ((H + 2) * Wp + 3) & ~3;
+    return ((size_t)(wp / 32) * nf10_slab_floats(wp) + (size_t)32 * GW * NF7_P_STRIDE + 2 * (size_t)PL + 3 * GW + 8) * sizeof(float);
+}
+
+template <int WP, bool PHILOX, int OWN>
+hipError_t launch_gemmb(const NfProgram &prog, const NfLaunch &a, int n_cu, int device, hipStream_t stream)
+{
+    const size_t lds = gemmb_lds_bytes(WP, a.H, a.W);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    const void *fn = reinterpret_cast<const void *>(&nf_gemmb_kernel<WP, PHILOX, OWN>);
+    static std::atomic<size_t> lds_set[16];
+    std::atomic<size_t> &cur = lds_set[device & 15];
+    if (lds > cur.load(std::memory_order_relaxed) || device > 15) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        cur.store(lds, std::memory_order_relaxed);
+    }
+    int64_t groups = n_cu;
+    if (a.B < groups) groups = a.B;
+    if (groups < 1) groups = 1;
+    hipLaunchKernelGGL((nf_gemmb_kernel<WP, PHILOX, OWN>), dim3((unsigned)groups), dim3(GT), lds, stream, prog, a);
+    return hipGetLastError();
+}
+
+template <int WP, bool PHILOX>
+hipError_t dispatch_ownb(const NfProgram &prog, const NfLaunch &a, int n_cu, int device, hipStream_t stream)
+{
+    if (a.H * a.W <= 2 * GT) return launch_gemmb<WP, PHILOX, 2>(prog, a, n_cu, device, stream);
+    return launch_gemmb<WP, PHILOX, 4>(prog, a, n_cu, device, stream);
+}
+
 size_t gemm_lds_bytes(int H, int W)
 {
     const int Wp = W + 2, PL = ((H + 2) * Wp + 3) & ~3;
@@ -467,6 +829,19 @@ hipError_t dispatch_gemm(const NfProgram &prog, const NfLaunch &a, int n_cu, int
 }
 
 }  // namespace
+
+// variant B: programs in the NF10 layout (widths <= 128)
+bool nf_gemmb_shape_ok(int wp, int H, int W)
+{
+    return wp <= 128 && H >= 1 && W >= 1 && H * W <= NF7_MAX_PIXELS && gemmb_lds_bytes(wp, H, W) <= 160 * 1024;
+}
+hipError_t nf_launch_gemmb(const NfProgram &prog, const NfLaunch &a, int n_cu, int device, hipStream_t stream)
+{
+    if (!nf_gemmb_shape_ok(prog.width, a.H, a.W)) return hipErrorInvalidValue;
+    const bool ph = (a.flags & NF_K_PHILOX_IN) != 0;
+    if (prog.width == 64) return ph ? dispatch_ownb<64, true>(prog, a, n_cu, device, stream) : dispatch_ownb<64, false>(prog, a, n_cu, device, stream);
+    return ph ? dispatch_ownb<128, true>(prog, a, n_cu, device, stream) : dispatch_ownb<128, false>(prog, a, n_cu, device, stream);
+}
 
 // whether a patch shape fits the GEMM kernel (nf_create asks before accepting a width > 32)
 bool nf_gemm_shape_ok(int H, int W)

@@ -44,3 +44,17 @@ __host__ __device__ constexpr int nf9_slab_B2(int wp) { return (wp / 16) * 256 +
 __host__ __device__ constexpr int nf9_img_SLAB(int wp) { return (wp / 32) * 544; }
 __host__ __device__ constexpr int nf9_img_size(int wp) { return (wp / 32) * 544 + (wp / 32) * nf9_slab_dwords(wp); }
 __host__ __device__ constexpr int nf9_cpl_size(int wp) { return NF8_CPL_IMG + nf9_img_size(wp); }
+
+// ---- exact-fp32 variant B (nf_gemm.hip, widths <= 128): the NF7_* values, one contiguous SLAB per channel tile m ---------------------
+//   IMG10 @68:  A1 [MT][3][64][4], B1 [MT][2][16] as NF7 (same offsets; NF7's B2 block stays where it is, unused), then at
+//   nf10_img_SLAB:  SLAB [MT] x { A2(m) [WP/8][64][4]   l_2 rows of OUTPUT tile m, chunk kc (4 K steps) at + 256 kc floats
+//                                 A3(m) [4][64][4]       l_last columns (taps 0 .. 7) of INPUT tile m
+//                                 A3C(m)[4][8][4]        tap 8 (v_mfma_f32_4x4x1)
+//                                 B2(m) [2][16] }
+__host__ __device__ constexpr int nf10_slab_floats(int wp) { return 32 * wp + 1024 + 128 + 32; }
+__host__ __device__ constexpr int nf10_slab_A3(int wp) { return 32 * wp; }
+__host__ __device__ constexpr int nf10_slab_A3C(int wp) { return 32 * wp + 1024; }
+__host__ __device__ constexpr int nf10_slab_B2(int wp) { return 32 * wp + 1024 + 128; }
+__host__ __device__ constexpr int nf10_img_SLAB(int wp) { return (wp / 32) * 832; }
+__host__ __device__ constexpr int nf10_img_size(int wp) { return (wp / 32) * 832 + (wp / 32) * nf10_slab_floats(wp); }
+__host__ __device__ constexpr int nf10_cpl_size(int wp) { return 68 + nf10_img_size(wp); }

@@ -30,6 +30,8 @@ hipError_t nf_launch_gemm(const NfProgram &prog, const NfLaunch &a, int n_cu, in
 hipError_t nf_launch_gemm16(const NfProgram &prog, const NfLaunch &a, int n_cu, int device, hipStream_t stream);
 hipError_t nf_launch_gemm16b(const NfProgram &prog, const NfLaunch &a, int n_cu, int device, hipStream_t stream);
 bool nf_gemm_shape_ok(int H, int W);
+hipError_t nf_launch_gemmb(const NfProgram &prog, const NfLaunch &a, int n_cu, int device, hipStream_t stream);
+bool nf_gemmb_shape_ok(int wp, int H, int W);
 hipError_t nf_launch_synth(uint64_t seed, int64_t patch_base, int64_t B, int HW, float beta1, float beta2,
                            float *y_out, float *x_out, hipStream_t stream);
 hipError_t nf_launch_eps(uint64_t seed, int64_t patch_base, int64_t B, int HW, float *eps_out, hipStream_t stream);
@@ -452,6 +454,24 @@ void relayout_coupling_gemm(const float *v1, int w, int wp, float *out)
                 }
 }
 
+// Variant B of the GEMM layout (NF10_*, widths <= 128): the NF7 values, one contiguous slab per channel tile.
+void relayout_coupling_gemmb(const float *v1, int w, int wp, float *out)
+{
+    std::vector<float> a(nf7_cpl_size(wp));
+    relayout_coupling_gemm(v1, w, wp, a.data());
+    const int MT = wp / 32, KC = wp / 8;
+    memcpy(out, a.data(), (size_t)(NF7_CPL_IMG + MT * 832) * sizeof(float));      // E, S, A1, B1 (+ NF7's B2 block, unused)
+    const float *ia = a.data() + NF7_CPL_IMG;
+    float *io = out + NF7_CPL_IMG;
+    for (int m = 0; m < MT; ++m) {
+        float *sl = io + nf10_img_SLAB(wp) + (size_t)m * nf10_slab_floats(wp);
+        memcpy(sl, ia + nf7_img_A2(wp) + (size_t)m * KC * 256, (size_t)KC * 256 * sizeof(float));
+        memcpy(sl + nf10_slab_A3(wp), ia + nf7_img_A3(wp) + (size_t)m * 1024, 1024 * sizeof(float));
+        memcpy(sl + nf10_slab_A3C(wp), ia + nf7_img_A3C(wp) + (size_t)m * 128, 128 * sizeof(float));
+        memcpy(sl + nf10_slab_B2(wp), ia + nf7_img_B2(wp) + (size_t)m * 32, 32 * sizeof(float));
+    }
+}
+
 // fp16-CNN GEMM re-layout (nf_gemm_layout.h, NF8_*; NF_CFG_FP16_CNN at widths 33 .. 512): fetch order of v_mfma_f32_32x32x16_f16,
 // folded weights rounded to half once (the oracle's rounding points), biases / border table fp32.
 void relayout_coupling_gemm16(const float *v1, int w, int wp, float *out)
@@ -766,6 +786,7 @@ struct Built {
     std::vector<float> block6;
     NfProgram prog7;             // GEMM layout (NF7_*): widths 33 .. 512, zero-padded to 64 / 128 / 256 / 512
     std::vector<float> block7;
+    bool gemm_b = false;         // block7 is in the variant-B layout (NF10_*: widths <= 128, weights resident in LDS)
     NfProgram prog8;             // fp16-CNN GEMM layout (NF8_*): NF_CFG_FP16_CNN at widths 33 .. 512
     std::vector<float> block8;
     bool gemm16_b = false;       // block8 is in the variant-B layout (NF9_*: widths <= 128)
@@ -1049,6 +1070,10 @@ int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float
     if (out.prog.width > 32 && !(cfg->flags & NF_CFG_FP16_CNN)) {
         const int wp = nf7_pad_width(out.prog.width);
         out.prog7.width = wp;
+        {   // variant B where its slabs fit beside the patch's tiles; NF_GEMM=a: A/B aid
+            const char *e = getenv("NF_GEMM");
+            out.gemm_b = nf_gemmb_shape_ok(wp, cfg->height, cfg->width) && !(e && e[0] == 'a');
+        }
         for (int i = 0; i < out.prog.n_ops; ++i) {
             const NfOp &src = out.prog.ops[i];
             NfOp &dst = out.prog7.ops[out.prog7.n_ops++];
@@ -1058,8 +1083,9 @@ int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float
             if (src.type == NF_OP_MIX) {
                 out.block7.insert(out.block7.end(), v1, v1 + 16);
             } else if (src.type == NF_OP_COUPLING_FWD || src.type == NF_OP_COUPLING_REV) {
-                out.block7.resize(out.block7.size() + nf7_cpl_size(wp));
-                relayout_coupling_gemm(v1, out.prog.width, wp, out.block7.data() + dst.off);
+                out.block7.resize(out.block7.size() + (out.gemm_b ? nf10_cpl_size(wp) : nf7_cpl_size(wp)));
+                if (out.gemm_b) relayout_coupling_gemmb(v1, out.prog.width, wp, out.block7.data() + dst.off);
+                else relayout_coupling_gemm(v1, out.prog.width, wp, out.block7.data() + dst.off);
             } else if (src.type == NF_OP_SCALE) {
                 out.block7.insert(out.block7.end(), v1, v1 + 4);
             } else {
@@ -1513,7 +1539,7 @@ static int launch_resident(nf_handle *h, int direction, NfLaunch &a, hipStream_t
     if (d7) {   // widths 33 .. 512: LDS-staged GEMMs on v_mfma_f32_32x32x2_f32 (nf_gemm.hip); no other kernel holds these widths
         a.params = d7;
         a.n_params = (int32_t)b.block7.size();
-        hipError_t e = nf_launch_gemm(b.prog7, a, h->n_cu, h->device, st);
+        hipError_t e = b.gemm_b ? nf_launch_gemmb(b.prog7, a, h->n_cu, h->device, st) : nf_launch_gemm(b.prog7, a, h->n_cu, h->device, st);
         if (e != hipSuccess) return fail_hip(e, what);
         return NF_OK;
     }

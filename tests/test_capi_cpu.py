@@ -298,8 +298,8 @@ def _mfma_32x32x2(A, B, D):
     return out
 
 
-@pytest.mark.parametrize("width", [64, 96])
-def test_gemm_layout_emulated_lane_by_lane_matches_the_oracle_cnn(width):
+@pytest.mark.parametrize("width,variant", [(64, "a"), (96, "a"), (64, "b"), (96, "b")])
+def test_gemm_layout_emulated_lane_by_lane_matches_the_oracle_cnn(width, variant, monkeypatch):
     """The NF7 block nf_create uploads at widths > 32, consumed exactly as csrc/nf_gemm.hip consumes it (tile / lane / register
     indices, K-step order, the P rows of the transposed l_last, the 9-tap gather) in a numpy model of v_mfma_f32_32x32x2_f32 —
     against the oracle's coupling CNN on a small patch.  Catches layout / indexing mistakes without a GPU."""
@@ -307,6 +307,8 @@ def test_gemm_layout_emulated_lane_by_lane_matches_the_oracle_cnn(width):
     arch = "unc"
     H, W = 5, 9            # 45 pixels: two pixel tiles, the second one ragged
     v = trained_like_variables(arch, width, seed=width)
+    if variant == "a":     # widths <= 128 default to variant B (weights resident in LDS, one slab per channel tile)
+        monkeypatch.setenv("NF_GEMM", "a")
     ops, blk, wp = _fold_layout(arch, v, width, 0, _lib.NF_PATH_GEMM, (H, W))
     assert wp == (64 if width <= 64 else 128)
     (t0, off0), (t1, off) = ops
@@ -315,10 +317,18 @@ def test_gemm_layout_emulated_lane_by_lane_matches_the_oracle_cnn(width):
     img = blk[off + 68:]
     A1 = img[0:MT * 768].reshape(MT, 3, 64, 4)
     B1 = img[MT * 768:MT * 800].reshape(MT, 2, 16)
-    B2 = img[MT * 800:MT * 832].reshape(MT, 2, 16)
-    A2 = img[MT * 832:MT * 832 + wp * wp].reshape(MT, KC, 64, 4)
-    A3 = img[MT * 832 + wp * wp:MT * 832 + wp * wp + MT * 1024].reshape(MT, 4, 64, 4)
-    A3C = img[MT * 832 + wp * wp + MT * 1024:MT * 832 + wp * wp + MT * 1152].reshape(MT, 4, 8, 4)
+    if variant == "a":     # NF7_*: one section per operand kind
+        B2 = img[MT * 800:MT * 832].reshape(MT, 2, 16)
+        A2 = img[MT * 832:MT * 832 + wp * wp].reshape(MT, KC, 64, 4)
+        A3 = img[MT * 832 + wp * wp:MT * 832 + wp * wp + MT * 1024].reshape(MT, 4, 64, 4)
+        A3C = img[MT * 832 + wp * wp + MT * 1024:MT * 832 + wp * wp + MT * 1152].reshape(MT, 4, 8, 4)
+    else:                  # NF10_*: one contiguous slab per channel tile
+        slab = 32 * wp + 1024 + 128 + 32
+        sl = img[MT * 832:MT * 832 + MT * slab].reshape(MT, slab)
+        A2 = sl[:, :32 * wp].reshape(MT, KC, 64, 4)
+        A3 = sl[:, 32 * wp:32 * wp + 1024].reshape(MT, 4, 64, 4)
+        A3C = sl[:, 32 * wp + 1024:32 * wp + 1152].reshape(MT, 4, 8, 4)
+        B2 = sl[:, 32 * wp + 1152:].reshape(MT, 2, 16)
     E = blk[off:off + 64].reshape(16, 4)
     rng = np.random.RandomState(1)
     z0 = rng.randn(H, W, 2)
