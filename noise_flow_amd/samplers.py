@@ -198,3 +198,90 @@ class QueueEpoch:
     def __iter__(self):
         for _ in range(self.n_its):
             yield self.queue.get(timeout=self.timeout)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the stage in front of PatchSampler: filename tuples -> image tuples (sidd/ImageLoader.py, sidd_utils.py:224-283)
+# ---------------------------------------------------------------------------------------------------------
+SIDD_CAMERAS = ['IP', 'GP', 'S6', 'N6', 'G4']   # sidd_utils.py:262
+
+
+def _read_raw_mat(path):
+    """The first (only) dataset of a MATLAB v7.3 file — what ``load_one_tuple_images`` reads with h5py.  h5py is not part of
+    this project's environment: without it the caller must hand a reader to :func:`load_one_tuple_images`."""
+    try:
+        import h5py
+    except ImportError as e:   # pragma: no cover
+        raise ImportError("reading SIDD .MAT files needs h5py (pass read_raw= to load_one_tuple_images otherwise)") from e
+    with h5py.File(path, 'r') as f:
+        return np.asarray(f[list(f.keys())[0]])
+
+
+def _read_metadata_mat(path):
+    """``load_metadata`` (sidd_utils.py:718-723)."""
+    from scipy.io import loadmat
+    return loadmat(path)['metadata'][0, 0]
+
+
+def get_nlf(metadata):
+    """``get_nlf`` (sidd_utils.py:726-729): the camera's two NLF parameters out of the DNG tags."""
+    return metadata['UnknownTags'][7, 0][2][0][0:2]
+
+
+def load_one_tuple_images(filepath_tuple, read_raw=None, read_metadata=None):
+    """``load_one_tuple_images`` (sidd_utils.py:224-283): (noisy path, clean path, variance path, metadata path) →
+    ``(noise, gt, var, nlf0, nlf1, iso, cam, metadata)``.  Both images are Bayer-packed to [1, h/2, w/2, 4], NaNs zeroed,
+    clipped to [0, 1]; the first output is the NOISE LAYER (noisy − clean, "crucial step"); non-positive NLF parameters are
+    floored at 1e-6; ISO and camera come from the scene directory name (``…/0001_001_S6_00100_00060_3200_L/…`` → 100.0,
+    ``SIDD_CAMERAS.index('S6')``).  ``read_raw(path)`` / ``read_metadata(path)`` default to the h5py / scipy readers."""
+    from .patches import pack_raw
+    in_path, gt_path, _var_path, meta_path = filepath_tuple[0], filepath_tuple[1], filepath_tuple[2], filepath_tuple[3]
+    read_raw = read_raw or _read_raw_mat
+    read_metadata = read_metadata or _read_metadata_mat
+
+    def packed(path):
+        im = np.expand_dims(pack_raw(np.asarray(read_raw(path))), axis=0)
+        return np.clip(np.nan_to_num(im), 0.0, 1.0)
+    input_image, gt_image = packed(in_path), packed(gt_path)
+    metadata = read_metadata(meta_path)
+    nlf0, nlf1 = get_nlf(metadata)
+    fparts = in_path.split('/')
+    sdir = fparts[-3]
+    if len(sdir) != 30:
+        sdir = fparts[-2]   # if subdirectory does not exist
+    iso = float(sdir[12:17])
+    cam = float(SIDD_CAMERAS.index(sdir[9:11]))
+    input_image = input_image - gt_image   # the noise layer instead of the noisy image
+    nlf0 = 1e-6 if nlf0 <= 0 else nlf0
+    nlf1 = 1e-6 if nlf1 <= 0 else nlf1
+    return input_image, gt_image, [], nlf0, nlf1, iso, cam, metadata
+
+
+class ImageLoader(_Stage):
+    """``sidd/ImageLoader.py:16-80``: filename tuples → image dicts ``{in, gt, vr, nlf0, nlf1, iso, cam, fn, metadata}`` with
+    ``fn = <scene dir>|<file name>``; with ``requeue`` the filename tuples go round again for further epochs (the reference
+    swaps two queues when the first runs empty and waits for the image queue to drain; here every consumed tuple is put back
+    behind the others, which yields the same epoch order with one worker).  ``loader`` = :func:`load_one_tuple_images` or any
+    callable with its result."""
+
+    def __init__(self, filename_tuple_queue, max_queue_size=4, n_threads=4, requeue=True, loader=None):
+        self.filename_tuple_queue = filename_tuple_queue
+        self.requeue = requeue
+        self.loader = loader or load_one_tuple_images
+        super().__init__(max_queue_size, n_threads, self.load_image_tuple_thread)
+
+    def load_image_tuple_thread(self, thread_id):
+        try:
+            while True:
+                filename_tuple = self._get(self.filename_tuple_queue)
+                parts = str.split(filename_tuple[0], '/')
+                fn = parts[-3] + '|' + parts[-1]
+                noise, gt, var, nlf0, nlf1, iso, cam, metadata = self.loader(filename_tuple)
+                self._put({'in': noise, 'gt': gt, 'vr': var, 'nlf0': nlf0, 'nlf1': nlf1, 'iso': iso, 'cam': cam, 'fn': fn,
+                           'metadata': metadata})
+                if self.requeue:
+                    self.filename_tuple_queue.put(filename_tuple)
+                elif self.filename_tuple_queue.empty():
+                    return
+        except _Stopped:
+            return

@@ -268,3 +268,54 @@ def test_c5_leg_sharding_gloo():
         a, b = shard_range(n_total, rank, world)
         assert seen == [(a, b - a)] and n == n_total
         assert abs(mean - float(np.mean(nll))) <= 1e-9 * abs(float(np.mean(nll)))
+
+
+def test_image_loader_stage_and_tuple_post_processing():
+    """sidd/ImageLoader.py + sidd_utils.load_one_tuple_images on in-memory 'files' (the h5py reader is replaceable): Bayer
+    packing, NaN / clip clean-up, the NOISE layer as 'in', the NLF floor, ISO / camera from the scene directory name, the
+    fn key, and the requeue of filename tuples for further epochs — feeding PatchSampler / MiniBatchSampler downstream."""
+    import queue
+    from noise_flow_amd.patches import pack_raw
+    from noise_flow_amd.samplers import ImageLoader, MiniBatchSampler, PatchSampler, load_one_tuple_images
+    rng = np.random.RandomState(3)
+    files = {}
+    tuples = []
+    for k, (cam, iso) in enumerate((("S6", 100), ("GP", 3200))):
+        sdir = "%04d_%03d_%s_%05d_00060_3200_L" % (k + 1, k + 1, cam, iso)
+        assert len(sdir) == 30
+        base = "/data/SIDD_Medium_Raw/Data/%s/%s" % (sdir, "raw/" if k == 0 else "")     # with and without the sub-directory level
+        gt = rng.rand(64, 64)
+        noisy = gt + 0.01 * rng.randn(64, 64)
+        noisy[0, 0] = np.nan
+        noisy[1, 1] = 1.7
+        files[base + "NOISY_RAW_010.MAT"] = noisy
+        files[base + "GT_RAW_010.MAT"] = gt
+        tuples.append((base + "NOISY_RAW_010.MAT", base + "GT_RAW_010.MAT", "", base + "METADATA_RAW_010.MAT"))
+
+    def read_meta(path):
+        tags = np.empty((8, 1), object)
+        tags[7, 0] = (None, None, [np.asarray([0.0012, -3.0, 9.9])])      # get_nlf: UnknownTags[7, 0][2][0][0:2]
+        return {"UnknownTags": tags}
+    loader = lambda ft: load_one_tuple_images(ft, read_raw=files.__getitem__, read_metadata=read_meta)   # noqa: E731
+    noise, gt, var, nlf0, nlf1, iso, cam, meta = loader(tuples[1])
+    assert noise.shape == (1, 32, 32, 4) and gt.shape == (1, 32, 32, 4) and var == []
+    assert (iso, cam) == (3200.0, 1.0) and nlf0 == 0.0012 and nlf1 == 1e-6              # non-positive NLF -> 1e-6
+    want_gt = np.clip(pack_raw(files[tuples[1][1]]), 0, 1)
+    want_in = np.clip(np.nan_to_num(pack_raw(files[tuples[1][0]])), 0, 1)
+    assert np.array_equal(gt[0], want_gt) and np.array_equal(noise[0], want_in - want_gt)
+    n0 = loader(tuples[0])[0]
+    assert n0[0, 0, 0, 0] == -loader(tuples[0])[1][0, 0, 0, 0]                          # NaN -> 0 before the subtraction
+    fq = queue.Queue()
+    for ft in tuples:
+        fq.put(ft)
+    il = ImageLoader(fq, max_queue_size=4, n_threads=1, requeue=True, loader=loader)
+    ims = [il.get_queue().get(timeout=30) for _ in range(5)]                            # 2.5 epochs
+    assert [im["fn"] for im in ims] == ["%s|NOISY_RAW_010.MAT" % t[0].split("/")[-3] for t in (tuples * 3)[:5]]   # parts[-3] | parts[-1]
+    assert ims[0]["fn"].startswith("0001_001_S6_00100") and ims[1]["fn"].startswith("Data|") and ims[0]["cam"] == 2.0
+    assert set(ims[0]) == {"in", "gt", "vr", "nlf0", "nlf1", "iso", "cam", "fn", "metadata"} and ims[1]["iso"] == 3200.0
+    ps = PatchSampler(il.get_queue(), patch_height=16, sampling="uniform", n_threads=1, n_pat_per_im=4, shuffle=False)
+    ms = MiniBatchSampler(ps.get_queue(), minibatch_size=4, n_threads=1)
+    mb = ms.get_queue().get(timeout=30)
+    assert mb["_x"].shape == (4, 16, 16, 4) and mb["_x"].dtype == np.float64 and len(mb["iso"]) == 1
+    for st in (ms, ps, il):
+        st.close()
