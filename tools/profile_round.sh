@@ -28,6 +28,8 @@ for pass in 1 2; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/sq_w32h/p$pass -- python $R/tools/quick_time_wide.py 32 8192 32 4 fp16 > $OUT/sq_w32h_p$pass.log 2>&1
   B=512 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/sq_gemm512/p$pass -- python $R/tools/check_gemm.py 512 > $OUT/sq_gemm512_p$pass.log 2>&1
   B=512 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/sq_gemm128/p$pass -- python $R/tools/check_gemm.py 128 > $OUT/sq_gemm128_p$pass.log 2>&1
+  B=512 DTYPE=fp16 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/sq_gemm512h/p$pass -- python $R/tools/check_gemm.py 512 > $OUT/sq_gemm512h_p$pass.log 2>&1
+  B=512 DTYPE=fp16 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/sq_gemm128h/p$pass -- python $R/tools/check_gemm.py 128 > $OUT/sq_gemm128h_p$pass.log 2>&1
 done
 # HBM traffic of the GEMM kernel at width 512 (weights are re-read per band from L2, not from HBM)
 B=512 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/gemm512_fetch -- python $R/tools/check_gemm.py 512 > $OUT/gemm512_fetch.log 2>&1
@@ -39,7 +41,9 @@ python tools/pmc_report.py $OUT/sq_w32 "nf_wide32_kernel" 100000 > $OUT/sq_w32_r
 python tools/pmc_report.py $OUT/sq_w16 "nf_wide16_kernel" 100000 > $OUT/sq_w16_report.txt 2>&1
 python tools/pmc_report.py $OUT/sq_w32h "nf_wide32_kernel" 100000 > $OUT/sq_w32h_report.txt 2>&1
 python tools/pmc_report.py $OUT/sq_gemm512 "nf_gemm_kernel<512" 100000 > $OUT/sq_gemm512_report.txt 2>&1
-python tools/pmc_report.py $OUT/sq_gemm128 "nf_gemm_kernel<128" 100000 > $OUT/sq_gemm128_report.txt 2>&1
+python tools/pmc_report.py $OUT/sq_gemm128 "nf_gemmb_kernel<128" 100000 > $OUT/sq_gemm128_report.txt 2>&1
+python tools/pmc_report.py $OUT/sq_gemm512h "nf_gemm16_kernel<512" 100000 > $OUT/sq_gemm512_fp16_report.txt 2>&1
+python tools/pmc_report.py $OUT/sq_gemm128h "nf_gemm16b_kernel<128" 100000 > $OUT/sq_gemm128_fp16_report.txt 2>&1
 python tools/pmc_report.py $OUT/gemm512_fetch "nf_gemm_kernel<512" 100000 > $OUT/gemm512_traffic.txt 2>&1
 python tools/pmc_report.py $OUT/gemm512_write "nf_gemm_kernel<512" 100000 >> $OUT/gemm512_traffic.txt 2>&1
 F=$(find $OUT/pmc_fetch -name "*counter_collection.csv" | head -1); W=$(find $OUT/pmc_write -name "*counter_collection.csv" | head -1)
@@ -47,4 +51,4 @@ python tools/make_traffic.py $F $W > $OUT/traffic.log 2>&1 && cp profiles/traffi
 K=$(find $OUT/kt -name "*kernel_stats.csv" | head -1); cp $K $OUT/kernel_stats.csv 2>/dev/null
 K=$(find $OUT/kt_full -name "*kernel_stats.csv" | head -1); cp $K $OUT/kernel_stats_all_sections.csv 2>/dev/null
 cp $F $OUT/pmc_fetch_counter_collection.csv; cp $W $OUT/pmc_write_counter_collection.csv
-for f in $OUT/sq_fp32_report.txt $OUT/sq_fp16_report.txt $OUT/sq_w32_report.txt $OUT/sq_w16_report.txt $OUT/sq_w32h_report.txt $OUT/sq_gemm512_report.txt $OUT/sq_gemm128_report.txt $OUT/gemm512_traffic.txt; do tail -n 3 $f; done; head -c 600 $OUT/bench.json; echo; tail -5 $OUT/traffic.log; head -8 $OUT/kernel_stats.csv
+for f in $OUT/sq_fp32_report.txt $OUT/sq_fp16_report.txt $OUT/sq_w32_report.txt $OUT/sq_w16_report.txt $OUT/sq_w32h_report.txt $OUT/sq_gemm512_report.txt $OUT/sq_gemm128_report.txt $OUT/sq_gemm512_fp16_report.txt $OUT/sq_gemm128_fp16_report.txt $OUT/gemm512_traffic.txt; do tail -n 3 $f; done; head -c 600 $OUT/bench.json; echo; tail -5 $OUT/traffic.log; head -8 $OUT/kernel_stats.csv
