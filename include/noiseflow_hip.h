@@ -118,9 +118,10 @@ typedef struct nf_config {
 
 /* nf_config.flags */
 #define NF_CFG_FP16_CNN 1   /* coupling CNN convs in fp16 (fp32 accumulate) on the matrix cores;
-                              1x1 mixes, tanh/exp, log-det and prior stay fp32.  Width 4: full
-                              32x32 or 64x64 patches only (BASELINE configs[4]); widths 8 / 16 / 32:
-                              any patch up to 64x64 (v_mfma_f32_32x32x16_f16).               */
+                              1x1 mixes, tanh/exp, log-det and prior stay fp32.  Width 4: its own kernel
+                              for full 32x32 / 64x64 patches (BASELINE configs[4]), any other shape on
+                              the width-32 kernel, zero-padded; widths 8 / 16 / 32: any patch up to 64x64
+                              (v_mfma_f32_32x32x16_f16); widths 33 .. 512: patches of up to 2048 pixels. */
 
 /* Per-call conditioning: ONE value per call, not per patch — the reference
  * feeds length-1 lists (MiniBatchSampler.py:61-64, NoiseFlowWrapper.py:85-86).
@@ -359,7 +360,7 @@ int nf_fold_layout(const nf_config *cfg, const nf_layer_desc *layers,
 #define NF_PATH_FP16 2
 #define NF_PATH_WIDE32 3
 #define NF_PATH_WIDE16 4
-#define NF_PATH_WIDE32_FP16 5   /* NF_CFG_FP16_CNN at width 8 / 16 / 32: v_mfma_f32_32x32x16_f16 */
+#define NF_PATH_WIDE32_FP16 5   /* NF_CFG_FP16_CNN at width 8 / 16 / 32 (and width 4 off the full shapes): v_mfma_f32_32x32x16_f16 */
 #define NF_PATH_GEMM 6          /* widths 33 .. 512: LDS-staged GEMM on v_mfma_f32_32x32x2_f32 (csrc/nf_gemm.hip) */
 #define NF_PATH_GEMM_FP16 7     /* NF_CFG_FP16_CNN at widths 33 .. 512: the same on v_mfma_f32_32x32x16_f16 (csrc/nf_gemm16.hip) */
 int nf_kernel_path(const nf_handle *h, int32_t direction);

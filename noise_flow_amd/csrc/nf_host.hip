@@ -1096,7 +1096,11 @@ int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float
     }
     out.block5.clear();
     memset(&out.prog5, 0, sizeof(out.prog5));
-    if ((cfg->flags & NF_CFG_FP16_CNN) && (out.prog.width == 8 || out.prog.width == 16 || out.prog.width == 32)) {
+    // width 4 has its own fp16 kernel for the two full shapes (nf_kernels.hip); on any other shape it runs here, zero-padded
+    // to 32 channels (exact: same rounding points, a padded channel is identically zero)
+    const bool w4_full = (cfg->height == 32 && cfg->width == 32) || (cfg->height == 64 && cfg->width == 64);
+    if ((cfg->flags & NF_CFG_FP16_CNN) &&
+        (out.prog.width == 8 || out.prog.width == 16 || out.prog.width == 32 || (out.prog.width == 4 && !w4_full))) {
         out.prog5.width = 32;
         for (int i = 0; i < out.prog.n_ops; ++i) {
             const NfOp &src = out.prog.ops[i];
@@ -1378,7 +1382,7 @@ int nf_create(const nf_config *cfg, const nf_layer_desc *layers, const float *pa
         const bool w4_ok = !h->fwd.block3.empty() && ((cfg->height == 32 && cfg->width == 32) || (cfg->height == 64 && cfg->width == 64));
         if ((!w4_ok && h->fwd.block5.empty() && h->fwd.block8.empty()) || hw == 0) {
             nf_destroy(h);   // the scalar-layout blocks are already on the device
-            return fail(NF_EINVAL, "NF_CFG_FP16_CNN needs coupling width 4 with full 32x32 or 64x64 patches, or width 8 / 16 / 32");
+            return fail(NF_EINVAL, "NF_CFG_FP16_CNN: no half-precision kernel for this width / patch shape");
         }
     }
     for (int d = 0; d < 14; ++d) {

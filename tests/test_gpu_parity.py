@@ -540,11 +540,26 @@ def test_oversized_patch_is_rejected_at_create():
     assert ei.value.code == NF_EINVAL and "64x64" in str(ei.value)
 
 
-def test_fp16_mode_rejects_unsupported_shapes(shipped_variables):
-    from noise_flow_amd import NoiseFlow, default_hps
-    from noise_flow_amd._lib import NoiseFlowLibError
-    with pytest.raises(NoiseFlowLibError):
-        NoiseFlow([16, 16, 4], False, default_hps(), variables=shipped_variables, cnn_dtype="fp16")
+@pytest.mark.parametrize("hw", [(16, 16), (20, 28), (40, 50), (33, 64), (7, 5)])
+def test_fp16_mode_at_width_4_on_other_patch_shapes(shipped_variables, hw):
+    """The width-4 fp16 kernel exists for full 32x32 / 64x64 patches; every other shape (rejected until round 3) runs on the
+    32x32x16_f16 kernel of nf_wide.hip zero-padded to 32 channels — the same rounding points, so the same oracle emulation."""
+    from noise_flow_amd import NoiseFlow, default_hps, _lib
+    from oracle.nf_oracle import NoiseFlowOracle
+    H, W = hw
+    x, y = make_inputs(5, H, W, seed=18)
+    m = NoiseFlow([H, W, 4], False, default_hps(), variables=shipped_variables, cnn_dtype="fp16")
+    assert m._flow.lib.nf_kernel_path(m._flow.ptr, 0) == _lib.NF_PATH_WIDE32_FP16
+    o16 = NoiseFlowOracle(FULL_ARCH, shipped_variables, cnn_dtype="fp16")
+    nll, sd = m._loss(x, y, [0], [0], [100], [2])
+    ref, rsd, rz = o16.nll(x, y, 100, 2)
+    np.testing.assert_allclose(nll, ref, rtol=1e-4)
+    z, _ = m.inverse(x, None, y, [0], [0], [100], [2])
+    _close_elem(z, rz, rtol=2e-3)
+    eps = np.random.RandomState(3).randn(5, H, W, 4).astype(np.float32)
+    _close_elem(m.sample(y, 0.6, y, [0], [0], [100], [2], eps=eps), o16.sample(eps, 0.6, y, 100, 2), rtol=2e-3)
+    full = NoiseFlow([32, 32, 4], False, default_hps(), variables=shipped_variables, cnn_dtype="fp16")
+    assert full._flow.lib.nf_kernel_path(full._flow.ptr, 0) == _lib.NF_PATH_FP16          # the full shapes keep their own kernel
 
 
 @pytest.mark.parametrize("arch,iso", [("sdn4|gain4", 800), ("sdn4|unc|gain4|unc", 100), ("sdn|unc|gain|unc", 400),
