@@ -363,6 +363,9 @@ int nf_fold_layout(const nf_config *cfg, const nf_layer_desc *layers,
 #define NF_PATH_WIDE32_FP16 5   /* NF_CFG_FP16_CNN at width 8 / 16 / 32 (and width 4 off the full shapes): v_mfma_f32_32x32x16_f16 */
 #define NF_PATH_GEMM 6          /* widths 33 .. 512: LDS-staged GEMM on v_mfma_f32_32x32x2_f32 (csrc/nf_gemm.hip) */
 #define NF_PATH_GEMM_FP16 7     /* NF_CFG_FP16_CNN at widths 33 .. 512: the same on v_mfma_f32_32x32x16_f16 (csrc/nf_gemm16.hip) */
+/* Both GEMM families have two variants, picked by nf_create from the padded width: weights resident in LDS with one pixel tile per
+ * wavefront (<= 128) or bands of pixels with the weights streamed from L2 (256 / 512); the environment variables NF_GEMM=a /
+ * NF_GEMM16=a (read at nf_create) force the band variant everywhere — an A/B aid, like NF_KERNEL=valu. */
 int nf_kernel_path(const nf_handle *h, int32_t direction);
 
 /* Host-only: the SDN5 scalars the kernels receive for a given (iso, cam):
