@@ -58,7 +58,12 @@ def _tri_positions(n: int, upper: bool):
 
 class GradOracle:
     def __init__(self, arch: str, variables: Dict[str, np.ndarray], binding: str = "loss_first", c_i: float = 1.0,
-                 flow_permutation: int = 1, decomp: str = "LU"):
+                 flow_permutation: int = 1, decomp: str = "LU", dtype=torch.float64):
+        """``dtype=torch.float32`` gives the SAME op sequence in single precision — not a second oracle but a yardstick: how far a
+        plain fp32 evaluation of the reference's graph is from the fp64 one on this input (gradients that are sums of large
+        cancelling terms lose relative accuracy in ANY fp32 evaluation; the tests allow the kernels that much)."""
+        self.dt = dtype
+        self.npdt = np.float64 if dtype == torch.float64 else np.float32
         self.arch = arch
         self.binding = binding
         self.flow_permutation = int(flow_permutation)
@@ -66,7 +71,7 @@ class GradOracle:
         self.c_i = float(c_i)
         self.names = list(variables.keys())
         self.shapes = {k: np.asarray(v).shape for k, v in variables.items()}
-        self.t = {k: torch.tensor(np.asarray(v, np.float64), dtype=torch.float64, requires_grad=is_trainable(k))
+        self.t = {k: torch.tensor(np.asarray(v, self.npdt), dtype=self.dt, requires_grad=is_trainable(k))
                   for k, v in variables.items()}
         arch_l = O.parse_arch(arch)
         unc_ids = [i for lyr, i in arch_l if lyr == "unc"]
@@ -81,7 +86,7 @@ class GradOracle:
     def _A(self, i):
         """(A, log|det A|) of the mixing layer in front of coupling i for hps.flow_permutation / hps.decomp, or None."""
         if self.flow_permutation == 0:                                    # tfb.Permute(channels reversed)
-            return torch.flip(torch.eye(4, dtype=torch.float64), dims=[1]), torch.zeros((), dtype=torch.float64)
+            return torch.flip(torch.eye(4, dtype=self.dt), dims=[1]), torch.zeros((), dtype=self.dt)
         if self.flow_permutation != 1:
             return None
         n = O.conv1x1_variable_names(i, self.decomp)
@@ -91,8 +96,8 @@ class GradOracle:
         if self.decomp == "LU2":                                          # matrix_param.py:143-188
             P, L, U = self.t[n["P"]], self.t[n["L"]], self.t[n["U"]]
             sgn, logS = self.t[n["sign_S"]].reshape(-1), self.t[n["log_S"]].reshape(-1)
-            mask = torch.tril(torch.ones(4, 4, dtype=torch.float64), -1)
-            Lm = L * mask + torch.eye(4, dtype=torch.float64)
+            mask = torch.tril(torch.ones(4, 4, dtype=self.dt), -1)
+            Lm = L * mask + torch.eye(4, dtype=self.dt)
             Um = U * mask.t() + torch.diag(sgn * torch.exp(logS))
             return P @ (Lm @ Um), logS.sum()
         return self._A_lu(i)
@@ -105,7 +110,7 @@ class GradOracle:
         n = logS.numel()
         lr, lc = _tri_positions(n, False)
         ur, uc = _tri_positions(n, True)
-        L = torch.eye(n, dtype=torch.float64).index_put((lr, lc), Lv)
+        L = torch.eye(n, dtype=self.dt).index_put((lr, lc), Lv)
         U = torch.diag(sgn.reshape(-1) * torch.exp(logS.reshape(-1))).index_put((ur, uc), Uv)
         return P @ (L @ U), logS.sum()                                    # matrix_param.py:130,138
 
@@ -183,7 +188,7 @@ class GradOracle:
             raise IndexError("unknown camera id %r" % (cam,))
         cp = torch.exp(c * self.t["model/sdn_gain/cam_params"][:, cam_idx])
         ks = [k for k, v in enumerate(O.ISO_VALS) if float(v) == float(iso)]
-        g = self.t["model/sdn_gain/gain_params"].reshape(-1)[ks[0]] if ks else torch.zeros((), dtype=torch.float64)
+        g = self.t["model/sdn_gain/gain_params"].reshape(-1)[ks[0]] if ks else torch.zeros((), dtype=self.dt)
         gain = torch.exp(c * g * cp[2]) * float(iso)
         b1 = torch.exp(c * self.t["model/sdn_gain/beta1"].reshape(-1)[0] * cp[0])
         b2 = torch.exp(c * self.t["model/sdn_gain/beta2"].reshape(-1)[0] * cp[1])
@@ -202,7 +207,7 @@ class GradOracle:
                 raise IndexError("unknown camera id %r" % (cam,))
             cp = torch.exp(c * self.t["model/sdn_gain/cam_params"].reshape(-1)[int(cam)])
             ks = [k for k, v in enumerate(O.ISO_VALS) if float(v) == float(iso)]
-            g = self.t["model/sdn_gain/gain_params"].reshape(-1)[ks[0]] if ks else torch.zeros((), dtype=torch.float64)
+            g = self.t["model/sdn_gain/gain_params"].reshape(-1)[ks[0]] if ks else torch.zeros((), dtype=self.dt)
             gain = torch.exp(c * g * cp) * float(iso)
             b1 = torch.exp(c * self.t["model/sdn_gain/beta1"].reshape(-1)[0])
             b2 = torch.exp(c * self.t["model/sdn_gain/beta2"].reshape(-1)[0])
@@ -232,10 +237,10 @@ class GradOracle:
     # -- the step's forward -----------------------------------------------------------------
     def forward(self, x, y, iso, cam) -> Tuple[torch.Tensor, torch.Tensor, Dict[str, np.ndarray]]:
         """→ (loss, sd_z, new running statistics)."""
-        z = torch.tensor(np.asarray(x, np.float64)).permute(0, 3, 1, 2)
-        yt = torch.tensor(np.asarray(y, np.float64)).permute(0, 3, 1, 2) if y is not None else None
+        z = torch.tensor(np.asarray(x, self.npdt)).permute(0, 3, 1, 2)
+        yt = torch.tensor(np.asarray(y, self.npdt)).permute(0, 3, 1, 2) if y is not None else None
         B, C, H, W = z.shape
-        obj = torch.zeros(B, dtype=torch.float64)
+        obj = torch.zeros(B, dtype=self.dt)
         new_running: Dict[str, np.ndarray] = {}
         for lyr, i in self.arch_l:
             if lyr == "unc":
@@ -256,7 +261,7 @@ class GradOracle:
                 obj = obj - torch.log(scale).sum(dim=(1, 2, 3))
             elif lyr == "sdn4":                                           # cond_utils.py:178-202
                 ks = [k for k, v in enumerate(O.ISO_VALS) if float(v) == float(iso)]
-                gp = self.t["model/sdn_gain/gain_params"].reshape(-1)[ks[0]] if ks else torch.zeros((), dtype=torch.float64)
+                gp = self.t["model/sdn_gain/gain_params"].reshape(-1)[ks[0]] if ks else torch.zeros((), dtype=self.dt)
                 gain = torch.exp(gp) * float(iso)
                 scale = torch.sqrt(torch.exp(self.t["model/sdn_gain/beta1"].reshape(-1)[0]) * yt / gain
                                    + torch.exp(self.t["model/sdn_gain/beta2"].reshape(-1)[0]))
@@ -277,6 +282,7 @@ class GradOracle:
             else:
                 raise ValueError("unknown layer %r" % lyr)
         logp = (-0.5 * (np.log(2 * np.pi) + z * z)).sum(dim=(1, 2, 3))
+        self._parts = (-(obj.mean()), -(logp.mean()))     # loss = (- log-det part) + (- prior part)
         nll = -(obj + logp)
         sd_z = torch.sqrt(z.var(dim=(1, 2, 3), unbiased=False)).mean()
         return nll.mean(), sd_z, new_running
@@ -290,12 +296,22 @@ class GradOracle:
             if v.grad is not None:
                 v.grad = None
         loss, sd_z, new_running = self.forward(x, y, iso, cam)
-        loss.backward()
-        grads = {}
+        # d loss / d theta = (gradient of the log-det part) + (gradient of the prior part).  Near the optimum the two cancel
+        # (that IS the optimality condition: e.g. d/d gain of  -sum log s  against  sum z^2 / 2), so a gradient can be 1e-4 of
+        # the terms it is the sum of — and no fp32 evaluation resolves it better than ~1e-7 of THOSE.  self.grad_terms[name] =
+        # max |part a| + |part b| gives the comparison that scale.
+        leaves = [v for v in self.t.values() if v.requires_grad]
+        ga = torch.autograd.grad(self._parts[0], leaves, retain_graph=True, allow_unused=True)
+        gb = torch.autograd.grad(self._parts[1], leaves, allow_unused=True)
+        grads, self.grad_terms = {}, {}
+        it = iter(zip(ga, gb))
         for k, v in self.t.items():
             if v.requires_grad:
-                g = v.grad if v.grad is not None else torch.zeros_like(v)
-                grads[k] = g.numpy().reshape(self.shapes[k]).copy()
+                a, b = next(it)
+                a = torch.zeros_like(v) if a is None else a
+                b = torch.zeros_like(v) if b is None else b
+                grads[k] = (a + b).numpy().reshape(self.shapes[k]).copy()
+                self.grad_terms[k] = float((a.abs() + b.abs()).max())
         return float(loss.detach()), float(sd_z.detach()), grads, new_running
 
 

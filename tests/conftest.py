@@ -143,3 +143,29 @@ def grads_match_up_to_kinks(oracle, x, y, iso, cam, compare, max_kinks=8, got=No
         raise AssertionError("%s  [%d on-kink activations; least-squares branch fit %s -> flips %r still fails: %s]"
                              % (first, len(kinks), np.round(c, 2).tolist(), subset, str(e)[:300]))
     return len(subset)
+
+
+def other_kernel_path_gradients(make_trainer, x, y, iso, cam):
+    """The same training step on the trainer's OTHER kernel paths (layer kernels instead of the tiled / matrix-core stages:
+    NF_TRAIN_TILED=0, NF_TRAIN_WIDE_MFMA=0, read by nf_trainer_create) → ``{name: gradient}``: the same arithmetic in a
+    different fp32 summation order, on the same hardware.
+
+    Why the gradient tests need it: a gradient can be the small remainder of large cancelling terms — at a gain layer near its
+    optimum d loss / d s is 1e-4 of the per-element terms it sums — and then NO fp32 evaluation resolves it to 2e-4 of itself
+    (measured on one such draw: the kernels are 2e-7 of the TERMS away from the fp64 oracle, which is 5e-3 of the gradient,
+    and the two kernel paths differ from each other by as much).  The distance between two summation orders is the
+    yardstick for exactly that; a wrong kernel is wrong by more than its own rounding noise and is not excused by it."""
+    import os
+    old = {k: os.environ.get(k) for k in ("NF_TRAIN_TILED", "NF_TRAIN_WIDE_MFMA")}
+    os.environ["NF_TRAIN_TILED"] = "0"
+    os.environ["NF_TRAIN_WIDE_MFMA"] = "0"
+    try:
+        tr = make_trainer()
+    finally:
+        for k, val in old.items():
+            if val is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = val
+    grads, _ = tr.forward_backward(x, y, [0.0], [0.0], [iso], [cam])
+    return tr.raw_to_variables(grads.cpu().numpy())

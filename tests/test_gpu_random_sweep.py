@@ -247,10 +247,16 @@ def test_random_model_training_gradients(seed):
     grads, loss = tr.forward_backward(x, y, [0.0], [0.0], [iso], [cam])
     lv = loss.cpu().numpy()
     got = tr.raw_to_variables(grads.cpu().numpy())
+    # the step's own fp32 summation-order noise on this input: the same step on the other kernel paths (conftest.py)
+    from conftest import other_kernel_path_gradients
+    alt = other_kernel_path_gradients(lambda: Trainer([H, W, 4], default_hps(arch=arch, width=width, flow_permutation=fp, decomp=decomp),
+                                                      variables=v, optim="adam", max_batch=16), x, y, iso, cam)
+    noise = {nm: float(np.abs(np.asarray(alt[nm], np.float64) - np.asarray(got[nm], np.float64)).max()) for nm in names}
+    sd_rtol = 1e-5 if min_var >= 1e-6 else 5e-5     # sd_z = sqrt(E z^2 - (E z)^2) of nearly constant latents cancels too
 
     def compare(ref_loss, ref_sd, ref_grads):
         assert abs(lv[0] - ref_loss) <= 1e-5 * abs(ref_loss) + 1e-4, "loss %r vs %r" % (lv[0], ref_loss)
-        assert abs(lv[1] - ref_sd) <= 1e-5 * ref_sd, "sd_z"
+        assert abs(lv[1] - ref_sd) <= sd_rtol * ref_sd, "sd_z"
         gmax = max(np.abs(ref_grads[nm]).max() for nm in names if is_trainable(nm))
         for nm in names:
             if not is_trainable(nm):
@@ -260,7 +266,8 @@ def test_random_model_training_gradients(seed):
             if nm.endswith("l_1/b") or nm.endswith("l_2/b"):      # analytically zero (BN subtracts the batch mean)
                 assert np.abs(g).max() <= 2e-5 * gmax, (nm, np.abs(g).max(), gmax)
             else:
-                assert np.abs(g - ref).max() <= rtol * max(np.abs(ref).max(), 1e-6 * gmax), (nm, np.abs(g - ref).max(), np.abs(ref).max())
+                tol = max(rtol * max(np.abs(ref).max(), 1e-6 * gmax), 4.0 * noise[nm])
+                assert np.abs(g - ref).max() <= tol, (nm, np.abs(g - ref).max(), np.abs(ref).max(), noise[nm])
 
     # The loss is piecewise smooth: an activation within float32 round-off of a ReLU kink takes one branch in the fp64
     # oracle and possibly the other on the GPU, and the gradients upstream then differ by that one activation's path.  ONE

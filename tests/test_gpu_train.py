@@ -31,7 +31,9 @@ def _grad_oracle(arch, variables):
     return GradOracle(arch, variables)
 
 
-def _check_grads(tr, grads_dev, ref_grads, loss_scale=1.0, rtol=GRAD_RTOL):
+def _check_grads(tr, grads_dev, ref_grads, loss_scale=1.0, rtol=GRAD_RTOL, noise=None):
+    """`noise` (optional, {name: float}): the step's own fp32 summation-order noise on this input (conftest.py::
+    other_kernel_path_gradients); a tensor may be 4 x that away from the oracle when that exceeds rtol of its scale."""
     got = tr.raw_to_variables(grads_dev.cpu().numpy())
     from oracle.nf_grad_oracle import is_trainable
     from noise_flow_amd import params as P
@@ -50,7 +52,8 @@ def _check_grads(tr, grads_dev, ref_grads, loss_scale=1.0, rtol=GRAD_RTOL):
             assert np.abs(g).max() <= 1e-5 * gmax, (nm, np.abs(g).max(), gmax)
         else:
             floor = 1e-6 * gmax
-            assert np.abs(g - ref).max() <= rtol * max(scale, floor), (nm, np.abs(g - ref).max(), scale)
+            tol = max(rtol * max(scale, floor), 4.0 * (noise or {}).get(nm, 0.0))
+            assert np.abs(g - ref).max() <= tol, (nm, np.abs(g - ref).max(), scale)
         checked += ref.size
     return checked
 
@@ -98,14 +101,17 @@ def _oracle_check_next_to_kinks(tr, arch, v, x, y, iso, cam, width, rtol=GRAD_RT
     the GPU.  The oracle names exactly those activations (margin < 32 units of the round-off of the sum that produced them)
     and `grads_match_up_to_kinks` accepts the other branch at those and nowhere else; the number it had to excuse is
     returned (0 on almost every input)."""
-    from conftest import grads_match_up_to_kinks
+    from conftest import grads_match_up_to_kinks, other_kernel_path_gradients
     grads, loss = tr.forward_backward(x, y, [0.0], [0.0], [iso], [cam])
     lv = loss.cpu().numpy()
+    got = tr.raw_to_variables(grads.cpu().numpy())
+    alt = other_kernel_path_gradients(lambda: _trainer(arch, v, tuple(tr.x_shape), width), x, y, iso, cam)
+    noise = {nm: float(np.abs(np.asarray(alt[nm], np.float64) - np.asarray(got[nm], np.float64)).max()) for nm in got if nm in alt}
 
     def compare(ref_loss, ref_sd, ref_grads):
         assert abs(lv[0] - ref_loss) <= 1e-5 * abs(ref_loss)
         assert abs(lv[1] - ref_sd) <= 1e-5 * ref_sd
-        _check_grads(tr, grads, ref_grads, rtol=rtol)
+        _check_grads(tr, grads, ref_grads, rtol=rtol, noise=noise)
     excused = grads_match_up_to_kinks(_grad_oracle(arch, v), x, y, iso, cam, compare)
     assert excused <= 1, excused
     return excused
