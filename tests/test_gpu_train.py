@@ -105,7 +105,7 @@ def _oracle_check_next_to_kinks(tr, arch, v, x, y, iso, cam, width, rtol=GRAD_RT
     grads, loss = tr.forward_backward(x, y, [0.0], [0.0], [iso], [cam])
     lv = loss.cpu().numpy()
     got = tr.raw_to_variables(grads.cpu().numpy())
-    alt = other_kernel_path_gradients(lambda: _trainer(arch, v, tuple(tr.x_shape), width), x, y, iso, cam)
+    alt = other_kernel_path_gradients(lambda: _trainer(arch, v, tuple(tr.x_shape), width, max_batch=max(64, len(x))), x, y, iso, cam)
     noise = {nm: float(np.abs(np.asarray(alt[nm], np.float64) - np.asarray(got[nm], np.float64)).max()) for nm in got if nm in alt}
 
     def compare(ref_loss, ref_sd, ref_grads):
