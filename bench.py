@@ -677,8 +677,13 @@ def _wide_cnn(ctx, batches, cond, wide):
             "kernel_path": {0: "scalar-weight VALU kernel", 3: "nf_wide32_kernel (v_mfma_f32_32x32x2_f32)",
                             4: "nf_wide16_kernel (v_mfma_f32_16x16x4_f32)",
                             5: "nf_wide32_kernel (v_mfma_f32_32x32x16_f16)",
-                            6: "nf_gemm_kernel (v_mfma_f32_32x32x2_f32, LDS-staged GEMM, weights streamed from L2)",
-                            7: "nf_gemm16_kernel (v_mfma_f32_32x32x16_f16, LDS-staged GEMM, weights streamed from L2)"}.get(path, str(path)),
+                            6: ("nf_gemmb_kernel (v_mfma_f32_32x32x2_f32, pixel tile per wavefront, weights resident in LDS)"
+                                if w <= 128 and os.environ.get("NF_GEMM", "") != "a" else
+                                "nf_gemm_kernel (v_mfma_f32_32x32x2_f32, LDS-staged GEMM, weights streamed from L2)"),
+                            7: ("nf_gemm16b_kernel (v_mfma_f32_32x32x16_f16, pixel tile per wavefront, weights resident in LDS)"
+                                if w <= 128 and os.environ.get("NF_GEMM16", "") != "a" else
+                                "nf_gemm16_kernel (v_mfma_f32_32x32x16_f16, LDS-staged GEMM, weights streamed from L2)"),
+                            }.get(path, str(path)),
             "roofline": {"bound": "mfma", "achieved": tfl, "peak": peak, "unit": "TFLOP/s", "frac": tfl / peak,
                          "algorithmic_flop_per_launch": flop, "mac_per_pixel_per_coupling": 16 + 18 * w + w * w + 36 * (w + 1),
                          "dtype": "f32 in / f32 accumulate (exact fp32)" if dt == "fp32" else
