@@ -107,9 +107,16 @@ typedef struct nf_layer_desc {
     int64_t param_offset;  /* offset in floats into `params`              */
 } nf_layer_desc;
 
+/* Patch sizes.  Up to 64x64 a patch is held whole by one workgroup (every width and mode).  Beyond that — the reference
+ * leaves --patch_height free (sidd/ArgParser.py:72-73) — nf_nll / nf_sample and their host-fed variants evaluate the image
+ * as overlapping 64-pixel tiles: a coupling reads a 5x5 neighbourhood, so a tile is exact 2 x (number of couplings) pixels
+ * inside every tile border that is not an image border, and only that core is reported (nf_tile_plan below).  Coupling
+ * width 4, fp32, at most 14 coupling layers; batch-statistics mode and the trainer's tiled stages stay at <= 64x64. */
+#define NF_MAX_IMAGE_SIDE 4096
+
 typedef struct nf_config {
-    int32_t height;        /* patch H (<= 64)                             */
-    int32_t width;         /* patch W (<= 64), H*W <= 4096                */
+    int32_t height;        /* patch H (1 .. NF_MAX_IMAGE_SIDE)            */
+    int32_t width;         /* patch W (1 .. NF_MAX_IMAGE_SIDE)            */
     int32_t channels;      /* must be 4 (packed Bayer raw)                */
     int32_t n_layers;      /* number of nf_layer_desc entries, NLL order  */
     int32_t device;        /* HIP device ordinal, -1 = current device     */
@@ -202,6 +209,13 @@ int nf_sample(nf_handle *h, const float *y, const float *eps, uint64_t seed,
  * noise_flow_model.py:499-504) — and hand it back as `eps`. */
 int nf_sample_eps(uint64_t seed, int64_t patch_index_base, int64_t B, int32_t height, int32_t width,
                   float *eps_out, void *stream);
+
+/* The tile plan of one image axis (see "Patch sizes"): `size` pixels, tiles of `tile` = min(size, 64) pixels, `halo` =
+ * 2 x the number of coupling layers.  Returns the number of tiles n (or a negative NF_E* code) and, for i < min(n, cap),
+ * the tile's first pixel origin[i] and the window [core0[i], core1[i]) it reports — a partition of [0, size) with
+ * core0[i] >= origin[i] + halo and core1[i] <= origin[i] + tile - halo wherever the tile border is not the image border.
+ * Pure host arithmetic (no device needed); the kernels use the same formulas (csrc/nf_device.h). */
+int nf_tile_plan(int32_t size, int32_t tile, int32_t halo, int32_t *origin, int32_t *core0, int32_t *core1, int32_t cap);
 
 /* Host-fed variants: the call pattern of the reference's drivers — `sess.run(..., feed_dict={x: numpy, y: numpy})` with the
  * float64 minibatches of sidd/MiniBatchSampler.py:54-55 (train_noise_flow.py:112-113) and

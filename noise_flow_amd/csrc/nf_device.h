@@ -217,7 +217,33 @@ enum : uint32_t {
     NF_K_CARRY_OUT = 32u,  // at NF_OP_STORE: ld_carry <- this thread's log-det so far (+ ld_carry with NF_K_CARRY_ADD)
     NF_K_CARRY_ADD = 64u,
     NF_K_CARRY_IN  = 128u, // start from ld_carry instead of 0
+    // images larger than one workgroup's tile (H or W > 64): every "patch" of the launch is one H x W TILE of an
+    // img_H x img_W image, see NfLaunch::tile_* below
+    NF_K_TILED     = 256u,
 };
+
+// ---- images beyond 64 x 64: overlapping tiles -------------------------------------------------------
+// A coupling reads a 5 x 5 neighbourhood (3x3, 1x1, 3x3 convs), so a tile evaluated on its own (zero padding at ITS
+// border) is exact `halo` = 2 x (number of couplings) pixels away from every tile border that is not an image border.
+// Along one axis of extent S, tiles of t pixels start at origin(i) = min(i * (t - 2 halo), S - t), i = 0 .. n-1, and
+// tile i REPORTS (stores its output, adds its log-det / prior terms for) the pixels [core0(i), core1(i)):
+// core0(0) = 0, core0(i) = origin(i) + halo, core1(i) = core0(i + 1), core1(n - 1) = S — a partition of [0, S).
+__host__ __device__ constexpr int nf_tile_count(int S, int t, int halo)
+{
+    return S <= t ? 1 : (S - t + (t - 2 * halo) - 1) / (t - 2 * halo) + 1;
+}
+__host__ __device__ constexpr int nf_tile_origin(int i, int S, int t, int halo)
+{
+    return i * (t - 2 * halo) < S - t ? i * (t - 2 * halo) : (S - t > 0 ? S - t : 0);
+}
+__host__ __device__ constexpr int nf_tile_core0(int i, int S, int t, int halo)
+{
+    return i == 0 ? 0 : nf_tile_origin(i, S, t, halo) + halo;
+}
+__host__ __device__ constexpr int nf_tile_core1(int i, int n, int S, int t, int halo)
+{
+    return i == n - 1 ? S : nf_tile_origin(i + 1, S, t, halo) + halo;
+}
 
 struct NfLaunch {
     const float *params;   // folded parameter block (device)
@@ -254,6 +280,15 @@ struct NfLaunch {
     float *fix_params_out;     // parameter block the next launch reads (n_params floats)
     float *fix_mom_out;        // mean[4], var[4] of that normalisation
     float *ld_carry;           // [B][threads per workgroup] (NF_K_CARRY_*), or null
+    // NF_K_TILED (fused kernel, masked instantiations): in / y / out are [B / (tile_ny tile_nx)][img_H][img_W][4]; patch b
+    // of the launch is tile (b % (tile_ny tile_nx)) of image b / (tile_ny tile_nx), H x W pixels at
+    // (nf_tile_origin(ty, img_H, H, tile_halo), nf_tile_origin(tx, img_W, W, tile_halo)).  Border masks follow the IMAGE
+    // border; outputs, log-det and prior sums cover the tile's core window only and go, per tile, to tile_part[b][4] =
+    // (data log-det, sum z, sum z^2, -) instead of nll_out / sd_out / ld_out / sums (nf_tile_combine_kernel adds them up)
+    int32_t img_H, img_W;
+    int32_t tile_ny, tile_nx;
+    int32_t tile_halo;
+    float *tile_part;
 };
 
 #define NF_STATS_SLOTS 64   // power of two

@@ -40,6 +40,8 @@ hipError_t nf_launch_stats_scatter(double *stats, int nvals, const double *buf, 
 hipError_t nf_launch_sums_reduce(const double *wide, double *out3, bool accumulate, hipStream_t stream);
 hipError_t nf_launch_bs_finalize(double *stats, int w, double n, float *Wm, int rows, float *Bv, float *mean_out, float *var_out,
                                  hipStream_t stream);
+hipError_t nf_launch_tile_combine(const float *part, int nt, int64_t B, double n, double ld_const, uint32_t flags, float *nll_out,
+                                  float *sd_out, float *ld_out, double *sums, hipStream_t stream);
 hipError_t nf_launch_gather(float *dst, const float *src, const int32_t *pairs, int n, hipStream_t stream);
 
 namespace {
@@ -792,6 +794,9 @@ struct Built {
     bool gemm16_b = false;       // block8 is in the variant-B layout (NF9_*: widths <= 128)
     double ld_const = 0.0;
     bool has_sdn = false;      // some op reads the clean image y
+    // images beyond 64x64 (nf_device.h, NF_K_TILED): the kernels run on overlapping tile_h x tile_w tiles
+    bool tiled = false;
+    int tile_h = 0, tile_w = 0, tile_ny = 1, tile_nx = 1, tile_halo = 0;
 };
 
 int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float *params, size_t n_params,
@@ -799,8 +804,16 @@ int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float
 {
     if (!cfg || !layers || !params) return fail(NF_EINVAL, "null argument");
     if (cfg->channels != kC) return fail(NF_EINVAL, "channels must be 4 (packed raw), got %d", cfg->channels);
-    if (cfg->height < 1 || cfg->width < 1 || cfg->height * cfg->width > 4096 || cfg->height > 64 || cfg->width > 64)
-        return fail(NF_EINVAL, "patch size %dx%d unsupported (max 64x64)", cfg->height, cfg->width);
+    if (cfg->height < 1 || cfg->width < 1 || cfg->height > NF_MAX_IMAGE_SIDE || cfg->width > NF_MAX_IMAGE_SIDE)
+        return fail(NF_EINVAL, "patch size %dx%d unsupported (1 .. %d per side)", cfg->height, cfg->width, NF_MAX_IMAGE_SIDE);
+    // one workgroup holds up to 64x64 pixels; larger images are evaluated as overlapping tiles of th x tw pixels, and every
+    // kernel-shape decision below is about the tile
+    const int th = cfg->height < 64 ? cfg->height : 64, tw = cfg->width < 64 ? cfg->width : 64;
+    out.tiled = cfg->height > 64 || cfg->width > 64;
+    out.tile_h = th;
+    out.tile_w = tw;
+    out.tile_ny = out.tile_nx = 1;
+    out.tile_halo = 0;
     if (cfg->n_layers < 1) return fail(NF_EINVAL, "n_layers must be >= 1");
     if (cfg->flags & ~NF_CFG_FP16_CNN) return fail(NF_EINVAL, "nf_config.flags has unknown bits set");
     const double HW = (double)cfg->height * cfg->width;
@@ -854,7 +867,7 @@ int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float
         case NF_LAYER_COUPLING: {
             if (L.width != 4 && L.width != 8 && L.width != 16 && !(L.width >= 32 && L.width <= 512))
                 return fail(NF_EINVAL, "layer %d: coupling width %d unsupported (4, 8, 16, 32 .. 512)", li, L.width);
-            if (L.width > 32 && !nf_gemm_shape_ok(cfg->height, cfg->width))
+            if (L.width > 32 && !nf_gemm_shape_ok(th, tw))
                 return fail(NF_EINVAL, "layer %d: coupling width %d covers patches of up to %d pixels (%dx%d given)", li, L.width,
                             NF7_MAX_PIXELS, cfg->height, cfg->width);
             if (width && width != L.width) return fail(NF_EINVAL, "all coupling layers must share one width");
@@ -895,6 +908,19 @@ int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float
             break;
         }
         items.push_back(it);
+    }
+
+    if (out.tiled) {
+        int n_cpl = 0;
+        for (const Item &it : items) n_cpl += it.type == NF_OP_COUPLING_FWD ? 1 : 0;
+        if (n_cpl > 0 && (width != 4 || (cfg->flags & NF_CFG_FP16_CNN)))
+            return fail(NF_EINVAL, "patches beyond 64x64 (%dx%d given) are evaluated at coupling width 4 in fp32 only", cfg->height, cfg->width);
+        // every coupling widens the dependence of a pixel by 2 (3x3, 1x1, 3x3): nf_device.h, "overlapping tiles"
+        out.tile_halo = 2 * n_cpl;
+        if (64 - 2 * out.tile_halo < 8)
+            return fail(NF_EINVAL, "patches beyond 64x64: %d coupling layers leave no core in a 64-pixel tile (at most 14)", n_cpl);
+        out.tile_ny = nf_tile_count(cfg->height, th, out.tile_halo);
+        out.tile_nx = nf_tile_count(cfg->width, tw, out.tile_halo);
     }
 
     // Fold every gain into a neighbouring 1x1 matrix (NLL: z/g then z@A == z@(A/g)).
@@ -989,7 +1015,7 @@ int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float
     // width 32: the product path; width 8 only where the scalar-weight kernel's LDS tile does not fit (patches larger
     // than 48x48): zero-padded to 32 channels.  Width 16 has its own kernel (prog6).
     {
-        const size_t tile_px = ((size_t)(cfg->height + 2) * (cfg->width + 2) + 1) & ~(size_t)1;
+        const size_t tile_px = ((size_t)(th + 2) * (tw + 2) + 1) & ~(size_t)1;
         const bool scalar_fits = sizeof(float) * (tile_px * (2 + (size_t)out.prog.width) + 64) <= 160 * 1024;
         if (out.prog.width == 32 || (out.prog.width == 8 && !scalar_fits)) out.prog4.width = 32;
     }
@@ -1072,7 +1098,7 @@ int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float
         out.prog7.width = wp;
         {   // variant B where its slabs fit beside the patch's tiles; NF_GEMM=a: A/B aid
             const char *e = getenv("NF_GEMM");
-            out.gemm_b = nf_gemmb_shape_ok(wp, cfg->height, cfg->width) && !(e && e[0] == 'a');
+            out.gemm_b = nf_gemmb_shape_ok(wp, th, tw) && !(e && e[0] == 'a');
         }
         for (int i = 0; i < out.prog.n_ops; ++i) {
             const NfOp &src = out.prog.ops[i];
@@ -1098,7 +1124,7 @@ int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float
     memset(&out.prog5, 0, sizeof(out.prog5));
     // width 4 has its own fp16 kernel for the two full shapes (nf_kernels.hip); on any other shape it runs here, zero-padded
     // to 32 channels (exact: same rounding points, a padded channel is identically zero)
-    const bool w4_full = (cfg->height == 32 && cfg->width == 32) || (cfg->height == 64 && cfg->width == 64);
+    const bool w4_full = (th == 32 && tw == 32) || (th == 64 && tw == 64);
     if ((cfg->flags & NF_CFG_FP16_CNN) &&
         (out.prog.width == 8 || out.prog.width == 16 || out.prog.width == 32 || (out.prog.width == 4 && !w4_full))) {
         out.prog5.width = 32;
@@ -1335,7 +1361,7 @@ int nf_create(const nf_config *cfg, const nf_layer_desc *layers, const float *pa
     h->layers.assign(layers, layers + cfg->n_layers);
     h->raw.assign(params, params + n_params);
     {   // the two LDS tiles of the scalar-weight kernel must fit one CU (160 KiB)
-        const size_t tile_px = ((size_t)(cfg->height + 2) * (cfg->width + 2) + 1) & ~(size_t)1;
+        const size_t tile_px = ((size_t)(h->fwd.tile_h + 2) * (h->fwd.tile_w + 2) + 1) & ~(size_t)1;
         const size_t lds = sizeof(float) * (tile_px * (2 + (size_t)h->fwd.prog.width) + 64);
         h->scalar_ok = lds <= 160 * 1024 && h->fwd.prog.width <= 32;
         if (lds > 160 * 1024 && h->fwd.block2.empty() && h->fwd.block4.empty() && h->fwd.block5.empty() && h->fwd.block6.empty() &&
@@ -1512,6 +1538,51 @@ static int sample_args(nf_handle *h, const float *y, const float *eps, uint64_t 
     return NF_OK;
 }
 
+// Images beyond 64x64 (nf_device.h, "overlapping tiles"): one launch of the fused width-4 kernel over B x tiles tile-sized
+// "patches" that reads and writes the caller's image tensors in place, then — in the NLL direction — a one-lane-per-image
+// kernel that adds the tiles' sums up.  The per-tile sums live in a stream-ordered allocation, so concurrent calls on one
+// handle (different streams) never share scratch.
+static int launch_tiled(nf_handle *h, int direction, NfLaunch &a, hipStream_t st, const char *what)
+{
+    const Built &b = direction == 0 ? h->fwd : h->rev;
+    float *d1 = direction == 0 ? h->d_fwd : h->d_rev;
+    float *d2 = direction == 0 ? h->d_fwd2 : h->d_rev2;
+    const int nt = b.tile_ny * b.tile_nx;
+    const int64_t B = a.B;
+    if (B > INT64_MAX / nt) return fail(NF_EINVAL, "B too large");
+    NfLaunch t = a;
+    t.B = B * nt;
+    t.H = b.tile_h;
+    t.W = b.tile_w;
+    t.img_H = h->cfg.height;
+    t.img_W = h->cfg.width;
+    t.tile_ny = b.tile_ny;
+    t.tile_nx = b.tile_nx;
+    t.tile_halo = b.tile_halo;
+    t.flags |= NF_K_TILED;
+    t.nll_out = t.sd_out = t.ld_out = nullptr;
+    t.sums = nullptr;
+    const bool want = direction == 0 && (a.nll_out || a.sd_out || a.ld_out || a.sums);
+    hipError_t e;
+    if (want) {
+        e = hipMallocAsync((void **)&t.tile_part, (size_t)t.B * 4 * sizeof(float), st);
+        if (e != hipSuccess) return fail_hip(e, "hipMallocAsync(tile sums)");
+    }
+    const bool mc = d2 && (use_matrix_core() || !h->scalar_ok);
+    t.params = mc ? d2 : d1;
+    if (mc) t.n_params = (int32_t)b.block2.size();
+    e = nf_launch_flow(mc ? b.prog2 : b.prog, t, h->n_cu, st, mc);
+    if (e == hipSuccess && want)
+        e = nf_launch_tile_combine(t.tile_part, nt, B, (double)h->cfg.height * h->cfg.width * kC, a.ld_const, a.flags, a.nll_out, a.sd_out,
+                                   a.ld_out, a.sums, st);
+    if (want) {
+        hipError_t e2 = hipFreeAsync(t.tile_part, st);
+        if (e == hipSuccess) e = e2;
+    }
+    if (e != hipSuccess) return fail_hip(e, what);
+    return NF_OK;
+}
+
 // launch on the handle's resident (running-statistics) programs
 static int launch_resident(nf_handle *h, int direction, NfLaunch &a, hipStream_t st, const char *what)
 {
@@ -1522,6 +1593,7 @@ static int launch_resident(nf_handle *h, int direction, NfLaunch &a, hipStream_t
     float *d4 = direction == 0 ? h->d_fwd4 : h->d_rev4;
     float *d5 = direction == 0 ? h->d_fwd5 : h->d_rev5;
     if (direction == 0) a.ld_const += b.ld_const;
+    if (b.tiled) return launch_tiled(h, direction, a, st, what);
     if (d5) {   // NF_CFG_FP16_CNN at width 8 / 16 / 32: v_mfma_f32_32x32x16_f16
         a.params = d5;
         a.n_params = (int32_t)b.block5.size();
@@ -1816,6 +1888,8 @@ static int bs_sync(nf_handle *h, double *stats, int nvals, hipStream_t st)
 static int run_batchstats(nf_handle *h, int direction, NfLaunch a, float *moments_out, hipStream_t st)
 {
     if (h->cfg.flags & NF_CFG_FP16_CNN) return fail(NF_EINVAL, "batch-statistics mode is fp32 only");
+    if (h->fwd.tiled)
+        return fail(NF_EINVAL, "batch-statistics mode covers patches of up to 64x64 pixels (%dx%d given)", h->cfg.height, h->cfg.width);
     std::lock_guard<std::mutex> lock(h->bs_mu);   // one scratch per handle: calls serialise
     if (!h->bs) h->bs = new (std::nothrow) nf_bs_state();
     if (!h->bs) return fail(NF_ENOMEM, "out of host memory");
@@ -2104,6 +2178,19 @@ int nf_sums_reduce(const double *wide, double *out3, uint32_t flags, void *strea
     hipError_t e = nf_launch_sums_reduce(wide, out3, (flags & NF_ACCUMULATE) != 0, (hipStream_t)stream);
     if (e != hipSuccess) return fail_hip(e, "nf_sums_reduce launch");
     return NF_OK;
+}
+
+int nf_tile_plan(int32_t size, int32_t tile, int32_t halo, int32_t *origin, int32_t *core0, int32_t *core1, int32_t cap)
+{
+    if (size < 1 || tile < 1 || halo < 0 || tile > size) return fail(NF_EINVAL, "bad tile plan (size %d, tile %d, halo %d)", size, tile, halo);
+    if (size > tile && tile - 2 * halo < 1) return fail(NF_EINVAL, "a %d-pixel tile has no core with a halo of %d", tile, halo);
+    const int n = nf_tile_count(size, tile, halo);
+    for (int i = 0; i < n && i < cap; ++i) {
+        if (origin) origin[i] = nf_tile_origin(i, size, tile, halo);
+        if (core0) core0[i] = nf_tile_core0(i, size, tile, halo);
+        if (core1) core1[i] = nf_tile_core1(i, n, size, tile, halo);
+    }
+    return n;
 }
 
 int nf_sample_eps(uint64_t seed, int64_t patch_index_base, int64_t B, int32_t height, int32_t width, float *eps_out, void *stream)

@@ -176,6 +176,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
     int gidx[PX];      // index of the pixel inside the patch (float4 units)
     int bmask[PX];     // border mask: top | bottom<<1 | left<<2 | right<<3
     bool act[PX];
+    bool own[PX];      // pixels whose results this workgroup reports: act[k], narrowed to the tile's core window by NF_K_TILED launches
+    [[maybe_unused]] int prow[PX], pcol[PX];   // masked instantiations: row / column of the pixel inside the patch (tile)
     int wbase = 0;     // BLK: tile entry of the window origin (r' = 2*br, c' = 2*bc)
     if constexpr (BLK) {
         const int bw = W >> 1;
@@ -197,6 +199,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
             const int dy = k >> 1, dx = k & 1;
             const int r = 2 * br + dy, c = 2 * bc + dx;
             act[k] = true;
+            own[k] = true;
             gidx[k] = r * W + c;
             lidx[k] = H16 ? (r + 1) * Wp + (c + 1) : wbase + ((dy + 1) * 2 + ((dx + 1) & 1)) * PW + ((dx + 1) >> 1);
             bmask[k] = (r == 0 ? 1 : 0) | (r == H - 1 ? 2 : 0) | (c == 0 ? 4 : 0) | (c == W - 1 ? 8 : 0);
@@ -206,8 +209,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
         for (int k = 0; k < PX; ++k) {
             const int p = t + THREADS * k;
             act[k] = FULL || p < HW;   // FULL: the patch fills the workgroup exactly -> no masking code at all
+            own[k] = act[k];
             const int pp = act[k] ? p : 0;
             const int r = pp / W, c = pp - r * W;
+            prow[k] = r;
+            pcol[k] = c;
             gidx[k] = pp;
             lidx[k] = (r + 1) * Wp + (c + 1);
             bmask[k] = (r == 0 ? 1 : 0) | (r == H - 1 ? 2 : 0) | (c == 0 ? 4 : 0) | (c == W - 1 ? 8 : 0);
@@ -235,7 +241,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
 #define NF_STAGGER_SLEEP 16
 #endif
     const bool early = !NF_STAGGER || PHILOX || blockIdx.x < (NF_STAGGER >= 2 ? (gridDim.x >> 2) : (gridDim.x >> 1));
-    if ((int64_t)blockIdx.x < a.B && early) {
+    // NF_K_TILED (nf_device.h): the pixel -> address map changes from tile to tile, so the loads sit at the top of the
+    // patch loop instead of one patch ahead
+    bool tiled = false;
+    if constexpr (!FULL) tiled = (a.flags & NF_K_TILED) != 0;
+    if ((int64_t)blockIdx.x < a.B && early && !tiled) {
         const size_t off0 = (size_t)blockIdx.x * (size_t)HW;
         if constexpr (!PHILOX) {
 #pragma unroll
@@ -265,7 +275,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
     }
     __syncthreads();
     asm volatile("" ::"v"(warm));   // keep the warm-up loads
-    if (NF_STAGGER && !early && (int64_t)blockIdx.x < a.B) {
+    if (NF_STAGGER && !early && (int64_t)blockIdx.x < a.B && !tiled) {
 #if NF_STAGGER >= 2
         {   // quarters of the grid = the 4 workgroups of a CU: the 3rd and 4th wait a little longer still
             const int q = (int)((blockIdx.x * 4u) / gridDim.x);
@@ -343,17 +353,47 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
 #endif
 
     for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
-        const size_t patch_off = (size_t)b * (size_t)HW * 4u;
+        size_t patch_off = (size_t)b * (size_t)HW * 4u;
+        [[maybe_unused]] int64_t patch_id = b;   // Philox key of the patch (NF_K_TILED: of the image the tile belongs to)
 #ifdef NF_TIMELINE
         stamp_on = stamp_it++ == (a.B / gridDim.x) / 2;
 #endif
+        if constexpr (!FULL) {
+            if (tiled) {
+                const int nt = a.tile_ny * a.tile_nx;
+                const int64_t img = b / nt;
+                const int ti = (int)(b - img * nt);
+                const int ty = ti / a.tile_nx, tx = ti - ty * a.tile_nx;
+                const int oy = nf_tile_origin(ty, a.img_H, H, a.tile_halo), ox = nf_tile_origin(tx, a.img_W, W, a.tile_halo);
+                const int cy0 = nf_tile_core0(ty, a.img_H, H, a.tile_halo), cy1 = nf_tile_core1(ty, a.tile_ny, a.img_H, H, a.tile_halo);
+                const int cx0 = nf_tile_core0(tx, a.img_W, W, a.tile_halo), cx1 = nf_tile_core1(tx, a.tile_nx, a.img_W, W, a.tile_halo);
+                patch_off = (size_t)img * (size_t)a.img_H * (size_t)a.img_W * 4u;
+                patch_id = img;
+#pragma unroll
+                for (int k = 0; k < PX; ++k) {
+                    const int r = oy + prow[k], c = ox + pcol[k];
+                    gidx[k] = act[k] ? r * a.img_W + c : 0;
+                    bmask[k] = (r == 0 ? 1 : 0) | (r == a.img_H - 1 ? 2 : 0) | (c == 0 ? 4 : 0) | (c == a.img_W - 1 ? 8 : 0);
+                    own[k] = act[k] && r >= cy0 && r < cy1 && c >= cx0 && c < cx1;
+                }
+                if constexpr (!PHILOX) {
+                    const float4 *in4 = reinterpret_cast<const float4 *>(a.in + patch_off);
+#pragma unroll
+                    for (int k = 0; k < PX; ++k) {
+                        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (act[k]) v = in4[gidx[k]];
+                        zin[k] = v;
+                    }
+                }
+            }
+        }
 
         // ---- prologue: the 4 channels of each owned pixel -> registers ----
         float z[PX][4];
         if (PHILOX) {
 #pragma unroll
             for (int k = 0; k < PX; ++k) {
-                philox_normal4(a.seed, a.patch_base + b, (uint32_t)gidx[k], NF_STREAM_SAMP, z[k]);
+                philox_normal4(a.seed, a.patch_base + patch_id, (uint32_t)gidx[k], NF_STREAM_SAMP, z[k]);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) z[k][c] *= a.in_scale;
             }
@@ -841,7 +881,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
                                 const float l1 = fmaf(__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(o[k][3]) + 1.0f), m2scl, scl);
                                 z[k][2] = fmaf(z[k][2], __builtin_amdgcn_exp2f(l0), o[k][0]);
                                 z[k][3] = fmaf(z[k][3], __builtin_amdgcn_exp2f(l1), o[k][1]);
-                                if (act[k]) ld2 += l0 + l1;
+                                if (own[k]) ld2 += l0 + l1;
                             }
                         } else {
 #pragma unroll
@@ -860,7 +900,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
                             if (type == NF_OP_COUPLING_FWD) {
                                 z[k][2] = fmaf(z[k][2], nf_exp(ls0), o[k][0]);
                                 z[k][3] = fmaf(z[k][3], nf_exp(ls1), o[k][1]);
-                                if (act[k]) ld += ls0 + ls1;
+                                if (own[k]) ld += ls0 + ls1;
                             } else {
                                 z[k][2] = (z[k][2] - o[k][0]) * nf_exp(-ls0);
                                 z[k][3] = (z[k][3] - o[k][1]) * nf_exp(-ls1);
@@ -889,7 +929,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
                         const float v = fmaf(yy[c], ck1, cb2);
                         if (type == NF_OP_SDN_DIV) {
                             z[k][c] = z[k][c] * __builtin_amdgcn_rsqf(v);
-                            if (act[k]) ld = fmaf(-0.34657359027997264f, __builtin_amdgcn_logf(v), ld);
+                            if (own[k]) ld = fmaf(-0.34657359027997264f, __builtin_amdgcn_logf(v), ld);
                         } else {
                             z[k][c] = z[k][c] * __builtin_amdgcn_sqrtf(v);
                         }
@@ -920,7 +960,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
         }
 
         // next patch's x: in flight during the epilogue
-        if constexpr (!PHILOX) {
+        if (!PHILOX && !tiled) {
             const int64_t nb = b + gridDim.x;
             const bool more = nb < a.B;
             const float4 *in4 = reinterpret_cast<const float4 *>(a.in) + (size_t)(more ? nb : b) * (size_t)HW;
@@ -941,13 +981,13 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
             float4 *out4 = reinterpret_cast<float4 *>(a.out + patch_off);
 #pragma unroll
             for (int k = 0; k < PX; ++k)
-                if (act[k]) out4[gidx[k]] = make_float4(z[k][0], z[k][1], z[k][2], z[k][3]);
+                if (own[k]) out4[gidx[k]] = make_float4(z[k][0], z[k][1], z[k][2], z[k][3]);
         }
-        if (a.nll_out || a.sd_out || a.ld_out || a.sums) {
+        if (a.nll_out || a.sd_out || a.ld_out || a.sums || (tiled && a.tile_part)) {
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int k = 0; k < PX; ++k)
-                if (act[k]) {
+                if (own[k]) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         s1 += z[k][c];
@@ -975,7 +1015,10 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
                 }
                 __syncthreads();   // scratch is reused by the next patch
             }
-            if (t == 0) {
+            if (tiled) {
+                // the tile's share of its image's sums; nf_tile_combine_kernel forms nll / sd / log-det per image
+                if (t == 0) *reinterpret_cast<float4 *>(a.tile_part + (size_t)b * 4u) = make_float4(r0, r1, r2, 0.f);
+            } else if (t == 0) {
                 const double n = (double)HW * 4.0;
                 const double logdet = (double)r0 + a.ld_const;
                 // prior: sum -0.5*(log 2pi + z^2)   (noise_flow_model.py:537-539)
@@ -999,7 +1042,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
         NF_STAMP(11);
     }
 
-    if (a.sums && t == 0) {
+    if (a.sums && t == 0 && !tiled) {
         // device-scope atomics on ONE cache line serialise at ~10 ns each (2 per workgroup = 5.6 us of a
         // 55 us launch at B = 1024); the slotted layout spreads them over NF_SUMS_SLOTS lines
         double *sp = a.sums;
@@ -1065,6 +1108,50 @@ __global__ __launch_bounds__(64) void nf_sums_reduce_kernel(const double *__rest
     if (s == 0)
 #pragma unroll
         for (int k = 0; k < 3; ++k) out3[k] = (accumulate ? out3[k] : 0.0) + v[k];
+}
+
+// NF_K_TILED launches (nf_device.h): per image, the sums its tiles left in tile_part[image][tile][4] -> nll / sd / log-det
+// exactly as the fused kernel's epilogue forms them for a patch it holds whole (tiles added in index order, in double),
+// and the call's (sum nll, sum sd, count) accumulators.  One lane per image.
+__global__ __launch_bounds__(64) void nf_tile_combine_kernel(const float *__restrict__ part, int nt, int64_t B, double n, double ld_const,
+                                                             uint32_t flags, float *__restrict__ nll_out, float *__restrict__ sd_out,
+                                                             float *__restrict__ ld_out, double *__restrict__ sums)
+{
+    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    double a_nll = 0.0, a_sd = 0.0;
+    if (i < B) {
+        double r0 = 0.0, r1 = 0.0, r2 = 0.0;
+        const float4 *p4 = reinterpret_cast<const float4 *>(part) + (size_t)i * nt;
+        for (int k = 0; k < nt; ++k) {
+            const float4 v = p4[k];
+            r0 += (double)v.x;
+            r1 += (double)v.y;
+            r2 += (double)v.z;
+        }
+        const double logdet = r0 + ld_const;
+        double nll = -logdet;
+        if (flags & NF_K_PRIOR) nll += 0.5 * n * 1.8378770664093453 + 0.5 * r2;
+        const double mean = r1 / n;
+        double var = r2 / n - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        const double sd = (double)__builtin_amdgcn_sqrtf((float)var);
+        if (nll_out) nll_out[i] = (float)nll;
+        if (sd_out) sd_out[i] = (float)sd;
+        if (ld_out) ld_out[i] = (float)logdet;
+        a_nll = (double)(float)nll;
+        a_sd = (double)(float)sd;
+    }
+    if (sums) {
+        a_nll = wave_sum(a_nll);
+        a_sd = wave_sum(a_sd);
+        if (threadIdx.x == 0) {
+            double *sp = sums;
+            if (flags & NF_K_SUMS_WIDE) sp += (size_t)(blockIdx.x & (NF_SUMS_SLOTS - 1)) * NF_SUMS_STRIDE;
+            atomicAdd(&sp[0], a_nll);
+            atomicAdd(&sp[1], a_sd);
+            if (blockIdx.x == 0) atomicAdd(&sp[2], (double)B);
+        }
+    }
 }
 
 // --------------------------------------------------------------------------
@@ -1181,7 +1268,7 @@ hipError_t launch_flow_v(const NfProgram &prog, const NfLaunch &a, int n_cu, hip
 {
     // full-patch specialisation only for the production shapes (32x32, 64x64) to bound code size
     if constexpr (THREADS * PX == 1024 || THREADS * PX == 4096) {
-        if (a.H == a.W && a.H * a.W == THREADS * PX)
+        if (a.H == a.W && a.H * a.W == THREADS * PX && !(a.flags & NF_K_TILED))
             return launch_flow_f<WIDTH, THREADS, PX, PHILOX, MFMA, true>(prog, a, n_cu, stream);
     }
     return launch_flow_f<WIDTH, THREADS, PX, PHILOX, MFMA, false>(prog, a, n_cu, stream);
@@ -1257,6 +1344,15 @@ hipError_t nf_launch_gather(float *dst, const float *src, const int32_t *pairs, 
 hipError_t nf_launch_sums_reduce(const double *wide, double *out3, bool accumulate, hipStream_t stream)
 {
     hipLaunchKernelGGL(nf_sums_reduce_kernel, dim3(1), dim3(64), 0, stream, wide, out3, accumulate ? 1 : 0);
+    return hipGetLastError();
+}
+
+hipError_t nf_launch_tile_combine(const float *part, int nt, int64_t B, double n, double ld_const, uint32_t flags, float *nll_out,
+                                  float *sd_out, float *ld_out, double *sums, hipStream_t stream)
+{
+    if (B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(nf_tile_combine_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, stream, part, nt, B, n, ld_const, flags,
+                       nll_out, sd_out, ld_out, sums);
     return hipGetLastError();
 }
 

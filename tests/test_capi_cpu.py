@@ -178,7 +178,9 @@ def test_error_reporting(shipped_variables):
         return lib.nf_fold_params(C.byref(cfg), descs, flat.ctypes.data_as(C.POINTER(C.c_float)), n, 0, None, 0,
                                   C.byref(n_ops), None, 0, None, None)
     assert fold(_lib.nf_config(32, 32, 3, len(layers), -1, 0)) == _lib.NF_EINVAL and b"channels" in lib.nf_last_error()
-    assert fold(_lib.nf_config(128, 128, 4, len(layers), -1, 0)) == _lib.NF_EINVAL
+    assert fold(_lib.nf_config(5000, 128, 4, len(layers), -1, 0)) == _lib.NF_EINVAL and b"per side" in lib.nf_last_error()
+    assert fold(_lib.nf_config(128, 128, 4, len(layers), -1, 0)) == 0          # beyond 64x64: overlapping tiles (width 4, fp32)
+    assert fold(_lib.nf_config(128, 128, 4, len(layers), -1, _lib.NF_CFG_FP16_CNN)) == _lib.NF_EINVAL and b"fp32 only" in lib.nf_last_error()
     assert fold(_lib.nf_config(32, 32, 4, len(layers), -1, 0), n=100) == _lib.NF_EINVAL
     assert fold(_lib.nf_config(32, 32, 4, len(layers), -1, 0)) == 0 and n_ops.value == 17
     with pytest.raises(NotImplementedError):
@@ -387,3 +389,62 @@ def test_gemm_layout_emulated_lane_by_lane_matches_the_oracle_cnn(width, variant
     shift, raw = O.coupling_cnn(z0[None], cp)
     ref = np.concatenate([shift[0], raw[0]], -1)
     assert np.abs(o - ref).max() <= 2e-5 * np.abs(ref).max(), np.abs(o - ref).max() / np.abs(ref).max()
+
+
+def _tile_plan(lib, size, tile, halo):
+    o, a, b = (C.c_int32 * 512)(), (C.c_int32 * 512)(), (C.c_int32 * 512)()
+    n = lib.nf_tile_plan(size, tile, halo, o, a, b, 512)
+    return n, list(o[:max(n, 0)]), list(a[:max(n, 0)]), list(b[:max(n, 0)])
+
+
+def test_tile_plan_partitions_the_axis_and_keeps_the_halo():
+    """Patches beyond 64x64 (include/noiseflow_hip.h "Patch sizes"): along each axis the reported windows partition
+    [0, size), every tile lies inside the image, and a window stays `halo` pixels away from every tile border that is not
+    the image border — the distance beyond which the zero padding at a tile border cannot be seen (2 pixels per coupling:
+    3x3 -> 1x1 -> 3x3, layers.py:452-498)."""
+    from noise_flow_amd import _lib
+    lib = _lib.load()
+    assert _tile_plan(lib, 64, 64, 16) == (1, [0], [0], [64])
+    assert _tile_plan(lib, 128, 64, 16) == (3, [0, 32, 64], [0, 48, 80], [48, 80, 128])
+    assert _tile_plan(lib, 65, 64, 16) == (2, [0, 1], [0, 17], [17, 65])
+    for size in list(range(1, 400)) + [1000, 4096]:
+        for halo in (0, 2, 8, 16, 28):
+            tile = min(size, 64)
+            n, o, a, b = _tile_plan(lib, size, tile, halo)
+            assert n >= 1 and a[0] == 0 and b[-1] == size
+            assert n == 1 or n == -(-(size - tile) // (tile - 2 * halo)) + 1
+            for i in range(n):
+                assert 0 <= o[i] and o[i] + tile <= size and a[i] < b[i]
+                if i > 0:
+                    assert a[i] == b[i - 1] and a[i] >= o[i] + halo and o[i] > o[i - 1]
+                if i < n - 1:
+                    assert b[i] <= o[i] + tile - halo
+    assert lib.nf_tile_plan(100, 64, 32, None, None, None, 0) == _lib.NF_EINVAL and b"no core" in lib.nf_last_error()
+    assert lib.nf_tile_plan(10, 64, 2, None, None, None, 0) == _lib.NF_EINVAL
+    assert lib.nf_tile_plan(200, 64, 16, None, None, None, 0) == 6          # counting only
+
+
+def test_tiled_evaluation_equals_whole_image_evaluation_in_the_oracle():
+    """The claim the tile kernels rest on, checked on the CPU with the fp64 oracle itself: evaluating a 64-pixel tile with
+    zero padding at ITS border and keeping the plan's window gives the whole-image latent and per-pixel log-det terms."""
+    from noise_flow_amd import _lib
+    from oracle.nf_oracle import NoiseFlowOracle
+    from conftest import make_inputs, trained_like_variables
+    lib = _lib.load()
+    arch = "sdn5|unc|unc|gain4|unc"
+    v = trained_like_variables(arch, 4, seed=9)
+    o = NoiseFlowOracle(arch, v, "loss_first")
+    H, W, halo = 80, 70, 6
+    x, y = make_inputs(1, H, W, seed=2)
+    z_ref, ld_ref = o.inverse(x, y, 100, 2)
+    ny, oy, ay, by = _tile_plan(lib, H, 64, halo)
+    nx, ox, ax, bx = _tile_plan(lib, W, 64, halo)
+    z = np.full_like(z_ref, np.nan)
+    for i in range(ny):
+        for j in range(nx):
+            ys, xs = slice(oy[i], oy[i] + 64), slice(ox[j], ox[j] + 64)
+            zt, _ = o.inverse(x[:, ys, xs], y[:, ys, xs], 100, 2)
+            # interior tile borders are NOT image borders: the oracle pads them like one, which is what the halo absorbs —
+            # except where the border IS the image's (first / last tile), where the padding is the image's own
+            z[:, ay[i]:by[i], ax[j]:bx[j]] = zt[:, ay[i] - oy[i]:by[i] - oy[i], ax[j] - ox[j]:bx[j] - ox[j]]
+    np.testing.assert_allclose(z, z_ref, rtol=0, atol=1e-12 * np.abs(z_ref).max())

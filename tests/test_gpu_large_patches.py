@@ -1,0 +1,88 @@
+"""GPU parity for patches beyond 64x64: the overlapping-tile evaluation (csrc/nf_device.h "overlapping tiles",
+`nf_tile_plan`) against the fp64 oracle on the WHOLE image.  The reference leaves --patch_height free
+(sidd/ArgParser.py:72-73); a coupling is 3x3 -> 1x1 -> 3x3 (layers.py:452-498), so a pixel of the output depends on a
+5x5 neighbourhood per coupling, and a tile that keeps 2 x couplings pixels of margin reproduces the image-wide result."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import FULL_ARCH, make_inputs, trained_like_variables
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def _assert_ok(r):
+    assert r["ok"], json.dumps(r)
+
+
+@pytest.mark.parametrize("hw,B,arch", [((65, 64), 3, None), ((64, 65), 2, None), ((96, 80), 2, None), ((128, 128), 2, None),
+                                       ((32, 200), 2, None), ((130, 70), 2, "sdn5|unc|unc|gain4|unc"), ((200, 9), 2, "unc|unc"),
+                                       ((72, 72), 1, "sdn4|unc|gain4|unc|unc|unc|unc|unc|unc|unc|unc|unc|unc|unc")])
+def test_large_patches_match_the_oracle(hw, B, arch):
+    """NLL, sd_z, log-det, latent, round trip, sampling with supplied and in-kernel eps; host-fed == resident.  The last case
+    has 12 couplings (halo 24: a 64-pixel tile reports a 16-pixel core)."""
+    from check_large_patches import check
+    _assert_ok(check(hw[0], hw[1], B, arch))
+
+
+def test_large_patches_with_the_shipped_checkpoint(shipped_variables):
+    """The model that ships (S6 checkpoint, 8 couplings: halo 16) on 128x96 images, every tolerance as in
+    tests/test_gpu_parity.py — no conditioning allowance."""
+    from check_large_patches import check
+    _assert_ok(check(128, 96, 3, FULL_ARCH, variables=shipped_variables, strict=True))
+
+
+def test_large_patches_on_the_scalar_weight_kernel():
+    """NF_KERNEL=valu is read once per process: the same check in a child process."""
+    env = dict(os.environ, NF_KERNEL="valu")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_large_patches.py"), "96", "100", "2"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    r = json.loads(p.stdout.strip().splitlines()[-1])
+    assert r["ok"] and r["kernel_path"] == 0, r
+
+
+def test_tile_results_do_not_depend_on_the_batch():
+    """Per-image results are bit-identical whatever else shares the launch (tile index arithmetic, per-image sums added up
+    in tile order by nf_tile_combine_kernel)."""
+    from noise_flow_amd import NoiseFlow, default_hps
+    v = trained_like_variables(FULL_ARCH, 4, seed=5)
+    x, y = make_inputs(5, 96, 64, seed=3)
+    m = NoiseFlow([96, 64, 4], False, default_hps(arch=FULL_ARCH, width=4), variables=v)
+    nll, _ = m._loss(x, y, [0.0], [0.0], [100], [2])
+    for i in range(5):
+        one, _ = m._loss(x[i:i + 1], y[i:i + 1], [0.0], [0.0], [100], [2])
+        assert np.array_equal(one, nll[i:i + 1])
+    z, _ = m.inverse(x, None, y, [0.0], [0.0], [100], [2])
+    z3, _ = m.inverse(x[3:4], None, y[3:4], [0.0], [0.0], [100], [2])
+    assert np.array_equal(z3[0], z[3])
+
+
+def test_large_patches_limits():
+    from noise_flow_amd import NoiseFlow, default_hps
+    from noise_flow_amd._lib import NoiseFlowLibError, NF_EINVAL
+    v8 = trained_like_variables("unc", 8)
+    with pytest.raises(NoiseFlowLibError) as ei:
+        NoiseFlow([80, 80, 4], False, default_hps(arch="unc", width=8), variables=v8)
+    assert ei.value.code == NF_EINVAL and "width 4" in str(ei.value)
+    v4 = trained_like_variables("unc", 4)
+    with pytest.raises(NoiseFlowLibError) as ei:
+        NoiseFlow([80, 80, 4], False, default_hps(arch="unc", width=4), variables=v4, cnn_dtype="fp16")
+    assert ei.value.code == NF_EINVAL
+    deep = "|".join(["unc"] * 15)
+    with pytest.raises(NoiseFlowLibError) as ei:
+        NoiseFlow([80, 80, 4], False, default_hps(arch=deep, width=4), variables=trained_like_variables(deep, 4))
+    assert ei.value.code == NF_EINVAL and "no core" in str(ei.value)
+    # batch-statistics mode keeps a patch per workgroup
+    m = NoiseFlow([80, 80, 4], True, default_hps(arch="unc", width=4), variables=v4)
+    x, y = make_inputs(2, 80, 80, seed=1)
+    with pytest.raises(NoiseFlowLibError) as ei:
+        m._loss(x, y, [0.0], [0.0], [100], [2])
+    assert ei.value.code == NF_EINVAL and "64x64" in str(ei.value)
