@@ -110,8 +110,8 @@ typedef struct nf_layer_desc {
 /* Patch sizes.  Up to 64x64 a patch is held whole by one workgroup (every width and mode).  Beyond that — the reference
  * leaves --patch_height free (sidd/ArgParser.py:72-73) — nf_nll / nf_sample and their host-fed variants evaluate the image
  * as overlapping 64-pixel tiles: a coupling reads a 5x5 neighbourhood, so a tile is exact 2 x (number of couplings) pixels
- * inside every tile border that is not an image border, and only that core is reported (nf_tile_plan below).  Coupling
- * width 4, fp32, at most 14 coupling layers; batch-statistics mode and the trainer's tiled stages stay at <= 64x64. */
+ * inside every tile border that is not an image border, and only that core is reported (nf_tile_plan, nf_tile_segments
+ * below).  Coupling width 4, fp32; batch-statistics mode stays at <= 64x64. */
 #define NF_MAX_IMAGE_SIDE 4096
 
 typedef struct nf_config {
@@ -216,6 +216,15 @@ int nf_sample_eps(uint64_t seed, int64_t patch_index_base, int64_t B, int32_t he
  * core0[i] >= origin[i] + halo and core1[i] <= origin[i] + tile - halo wherever the tile border is not the image border.
  * Pure host arithmetic (no device needed); the kernels use the same formulas (csrc/nf_device.h). */
 int nf_tile_plan(int32_t size, int32_t tile, int32_t halo, int32_t *origin, int32_t *core0, int32_t *core1, int32_t cap);
+
+/* How a model on patches beyond 64x64 is cut into tiled launches: deep stacks leave a small core per tile (8 couplings: 32 of
+ * 64 pixels per axis), so the program is split after a coupling into segments, each its own tiled launch with a halo of
+ * 2 x ITS couplings, the tensor between two segments resident in HBM; the number of segments minimises tiles x (couplings +
+ * per-tile overhead).  Returns the number of segments (0: the patch is held whole; negative: NF_E*), and for i < cap
+ * out5[5 i ..] = first op, one-past-last op (indices into nf_fold_params' op list), halo, tiles along H, tiles along W.
+ * Host arithmetic only.  NF_TILE_SEGMENTS=<n> in the environment forces the count (A/B aid). */
+int nf_tile_segments(const nf_config *cfg, const nf_layer_desc *layers, const float *params, size_t n_params,
+                     int32_t direction, int32_t *out5, int32_t cap);
 
 /* Host-fed variants: the call pattern of the reference's drivers — `sess.run(..., feed_dict={x: numpy, y: numpy})` with the
  * float64 minibatches of sidd/MiniBatchSampler.py:54-55 (train_noise_flow.py:112-113) and

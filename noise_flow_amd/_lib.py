@@ -136,6 +136,9 @@ def load() -> C.CDLL:
     lib.nf_sample_eps.argtypes = [u64, i64, i64, i32, i32, vp, vp]
     lib.nf_tile_plan.restype = C.c_int
     lib.nf_tile_plan.argtypes = [i32, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), i32]
+    lib.nf_tile_segments.restype = C.c_int
+    lib.nf_tile_segments.argtypes = [C.POINTER(nf_config), C.POINTER(nf_layer_desc), C.POINTER(C.c_float), C.c_size_t, i32,
+                                     C.POINTER(i32), i32]
     lib.nf_nll_host.restype = C.c_int
     lib.nf_nll_host.argtypes = [vp, vp, vp, i32, i64, C.POINTER(nf_cond), vp, vp, vp, vp, vp, u32]
     lib.nf_sample_host.restype = C.c_int
@@ -162,7 +165,7 @@ def check(rc: int) -> None:
 
 EXPORTED_SYMBOLS = (
     "nf_abi_version", "nf_last_error", "nf_layer_param_count", "nf_create", "nf_destroy", "nf_nll",
-    "nf_sample", "nf_set_sync", "nf_sample_eps", "nf_tile_plan", "nf_nll_host", "nf_sample_host", "nf_synth_patches", "nf_fold_params", "nf_fold_layout", "nf_sdn5_scalars",
+    "nf_sample", "nf_set_sync", "nf_sample_eps", "nf_tile_plan", "nf_tile_segments", "nf_nll_host", "nf_sample_host", "nf_synth_patches", "nf_fold_params", "nf_fold_layout", "nf_sdn5_scalars",
     "nf_nll_batchstats", "nf_sample_batchstats", "nf_sums_reduce", "nf_kernel_path",
     "nf_trainer_create", "nf_trainer_destroy", "nf_trainer_forward_backward", "nf_trainer_forward", "nf_trainer_apply", "nf_trainer_step",
     "nf_trainer_get_params", "nf_trainer_set_params", "nf_trainer_steps", "nf_trainer_set_sync",

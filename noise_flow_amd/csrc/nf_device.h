@@ -228,6 +228,15 @@ enum : uint32_t {
 // Along one axis of extent S, tiles of t pixels start at origin(i) = min(i * (t - 2 halo), S - t), i = 0 .. n-1, and
 // tile i REPORTS (stores its output, adds its log-det / prior terms for) the pixels [core0(i), core1(i)):
 // core0(0) = 0, core0(i) = origin(i) + halo, core1(i) = core0(i + 1), core1(n - 1) = S — a partition of [0, S).
+// Deep stacks would leave a small core (8 couplings: 32 of 64 pixels per axis, i.e. 4 x the work on a large image), so the host
+// may cut the program after a coupling into up to NF_MAX_TILE_SEGS SEGMENTS, each its own tiled launch with its own, smaller
+// halo, the tensor between two segments resident in HBM (32 B per pixel and segment: nothing next to the recomputation saved).
+#define NF_MAX_TILE_SEGS 16
+struct NfTileParts {            // where the per-tile sums of a call's segments sit (nf_tile_combine_kernel)
+    int32_t n_seg;
+    int32_t nt[NF_MAX_TILE_SEGS];    // tiles per image in segment s
+    int64_t off[NF_MAX_TILE_SEGS];   // first float4 of segment s in the array ([image][tile] inside a segment)
+};
 __host__ __device__ constexpr int nf_tile_count(int S, int t, int halo)
 {
     return S <= t ? 1 : (S - t + (t - 2 * halo) - 1) / (t - 2 * halo) + 1;
@@ -284,7 +293,8 @@ struct NfLaunch {
     // of the launch is tile (b % (tile_ny tile_nx)) of image b / (tile_ny tile_nx), H x W pixels at
     // (nf_tile_origin(ty, img_H, H, tile_halo), nf_tile_origin(tx, img_W, W, tile_halo)).  Border masks follow the IMAGE
     // border; outputs, log-det and prior sums cover the tile's core window only and go, per tile, to tile_part[b][4] =
-    // (data log-det, sum z, sum z^2, -) instead of nll_out / sd_out / ld_out / sums (nf_tile_combine_kernel adds them up)
+    // (data log-det of THIS launch's ops, sum z, sum z^2, -) instead of nll_out / sd_out / ld_out / sums (nf_tile_combine_kernel
+    // adds them up: the log-det over every segment, the moments of z from the last one)
     int32_t img_H, img_W;
     int32_t tile_ny, tile_nx;
     int32_t tile_halo;

@@ -40,8 +40,8 @@ hipError_t nf_launch_stats_scatter(double *stats, int nvals, const double *buf, 
 hipError_t nf_launch_sums_reduce(const double *wide, double *out3, bool accumulate, hipStream_t stream);
 hipError_t nf_launch_bs_finalize(double *stats, int w, double n, float *Wm, int rows, float *Bv, float *mean_out, float *var_out,
                                  hipStream_t stream);
-hipError_t nf_launch_tile_combine(const float *part, int nt, int64_t B, double n, double ld_const, uint32_t flags, float *nll_out,
-                                  float *sd_out, float *ld_out, double *sums, hipStream_t stream);
+hipError_t nf_launch_tile_combine(const float *part, const NfTileParts &tp, int64_t B, double n, double ld_const, uint32_t flags,
+                                  float *nll_out, float *sd_out, float *ld_out, double *sums, hipStream_t stream);
 hipError_t nf_launch_gather(float *dst, const float *src, const int32_t *pairs, int n, hipStream_t stream);
 
 namespace {
@@ -794,10 +794,65 @@ struct Built {
     bool gemm16_b = false;       // block8 is in the variant-B layout (NF9_*: widths <= 128)
     double ld_const = 0.0;
     bool has_sdn = false;      // some op reads the clean image y
-    // images beyond 64x64 (nf_device.h, NF_K_TILED): the kernels run on overlapping tile_h x tile_w tiles
+    // images beyond 64x64 (nf_device.h, NF_K_TILED): the kernels run on overlapping tile_h x tile_w tiles, the program cut
+    // into segments (ops [op0, op1) each, its own halo and tile counts)
     bool tiled = false;
-    int tile_h = 0, tile_w = 0, tile_ny = 1, tile_nx = 1, tile_halo = 0;
+    int tile_h = 0, tile_w = 0;
+    struct TileSeg {
+        int op0, op1, halo, ny, nx;
+    };
+    std::vector<TileSeg> segs;
 };
+
+// Cut a tiled program into segments (nf_device.h): the couplings dealt as evenly as possible to S consecutive groups, a
+// segment ending right after its last coupling (the pointwise ops behind the last coupling stay with the last segment), S
+// chosen for the least estimated work, in units of one coupling on one tile: tiles of a segment x (its couplings + 0.75 for the
+// tile's load / store / set-up and the pointwise layers) + 1 per 4096 image pixels and segment boundary (32 B per pixel
+// through HBM) — fitted to tools/time_large_patches.py at 256^2 and 1024^2.  NF_TILE_SEGMENTS=<n> forces S (A/B and test aid).
+static int plan_tile_segments(const NfProgram &prog, int H, int W, int th, int tw, std::vector<Built::TileSeg> &segs)
+{
+    std::vector<int> cpl;
+    for (int i = 0; i < prog.n_ops; ++i)
+        if (prog.ops[i].type == NF_OP_COUPLING_FWD || prog.ops[i].type == NF_OP_COUPLING_REV) cpl.push_back(i);
+    const int n_cpl = (int)cpl.size();
+    const char *e = getenv("NF_TILE_SEGMENTS");
+    const int forced = e ? atoi(e) : 0;
+    double best = 0.0;
+    segs.clear();
+    const int s_max = n_cpl < 1 ? 1 : n_cpl < NF_MAX_TILE_SEGS ? n_cpl : NF_MAX_TILE_SEGS;
+    const int s_only = forced > 0 ? (forced < s_max ? forced : s_max) : 0;
+    for (int S = 1; S <= s_max; ++S) {
+        if (s_only && S != s_only) continue;
+        std::vector<Built::TileSeg> cand;
+        double cost = 0.0;
+        bool ok = true;
+        int c0 = 0, op0 = 0;
+        for (int sgm = 0; sgm < S; ++sgm) {
+            const int nc = n_cpl / S + (sgm < n_cpl % S ? 1 : 0);
+            Built::TileSeg t;
+            t.op0 = op0;
+            t.op1 = sgm == S - 1 ? prog.n_ops : cpl[c0 + nc - 1] + 1;
+            t.halo = 2 * nc;
+            if ((H > th || W > tw) && 64 - 2 * t.halo < 8) ok = false;   // no core left in a 64-pixel tile
+            if (!ok) break;
+            t.ny = nf_tile_count(H, th, t.halo);
+            t.nx = nf_tile_count(W, tw, t.halo);
+            cost += (double)t.ny * t.nx * (nc + 0.75);
+            if (sgm > 0) cost += (double)H * W / 4096.0;   // the tensor between two segments: ~ one tile-coupling per 4096 pixels
+            cand.push_back(t);
+            c0 += nc;
+            op0 = t.op1;
+        }
+        if (!ok) continue;
+        if (segs.empty() || cost < best) {
+            best = cost;
+            segs.swap(cand);
+        }
+    }
+    if (segs.empty()) return fail(NF_EINVAL, "patches beyond 64x64: %d coupling layers cannot be cut into at most %d tiled segments", n_cpl, NF_MAX_TILE_SEGS);
+    return NF_OK;
+}
+
 
 int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float *params, size_t n_params,
                   int direction, Built &out)
@@ -812,8 +867,7 @@ int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float
     out.tiled = cfg->height > 64 || cfg->width > 64;
     out.tile_h = th;
     out.tile_w = tw;
-    out.tile_ny = out.tile_nx = 1;
-    out.tile_halo = 0;
+    out.segs.clear();
     if (cfg->n_layers < 1) return fail(NF_EINVAL, "n_layers must be >= 1");
     if (cfg->flags & ~NF_CFG_FP16_CNN) return fail(NF_EINVAL, "nf_config.flags has unknown bits set");
     const double HW = (double)cfg->height * cfg->width;
@@ -915,12 +969,6 @@ int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float
         for (const Item &it : items) n_cpl += it.type == NF_OP_COUPLING_FWD ? 1 : 0;
         if (n_cpl > 0 && (width != 4 || (cfg->flags & NF_CFG_FP16_CNN)))
             return fail(NF_EINVAL, "patches beyond 64x64 (%dx%d given) are evaluated at coupling width 4 in fp32 only", cfg->height, cfg->width);
-        // every coupling widens the dependence of a pixel by 2 (3x3, 1x1, 3x3): nf_device.h, "overlapping tiles"
-        out.tile_halo = 2 * n_cpl;
-        if (64 - 2 * out.tile_halo < 8)
-            return fail(NF_EINVAL, "patches beyond 64x64: %d coupling layers leave no core in a 64-pixel tile (at most 14)", n_cpl);
-        out.tile_ny = nf_tile_count(cfg->height, th, out.tile_halo);
-        out.tile_nx = nf_tile_count(cfg->width, tw, out.tile_halo);
     }
 
     // Fold every gain into a neighbouring 1x1 matrix (NLL: z/g then z@A == z@(A/g)).
@@ -1171,6 +1219,11 @@ int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float
         }
         if (out.block3.empty()) out.block3.assign(4, 0.0f);
         if (out.block3.size() > NF2_MAX_FLOATS) return fail(NF_EINVAL, "model too large for the fp16-CNN LDS image");
+    }
+    if (out.tiled) {
+        // every coupling widens the dependence of a pixel by 2 (3x3, 1x1, 3x3): nf_device.h, "overlapping tiles"
+        int rc = plan_tile_segments(out.prog, cfg->height, cfg->width, th, tw, out.segs);
+        if (rc != NF_OK) return rc;
     }
     return NF_OK;
 }
@@ -1538,47 +1591,75 @@ static int sample_args(nf_handle *h, const float *y, const float *eps, uint64_t 
     return NF_OK;
 }
 
-// Images beyond 64x64 (nf_device.h, "overlapping tiles"): one launch of the fused width-4 kernel over B x tiles tile-sized
-// "patches" that reads and writes the caller's image tensors in place, then — in the NLL direction — a one-lane-per-image
-// kernel that adds the tiles' sums up.  The per-tile sums live in a stream-ordered allocation, so concurrent calls on one
-// handle (different streams) never share scratch.
+// Images beyond 64x64 (nf_device.h, "overlapping tiles"): per segment of the program one launch of the fused width-4 kernel
+// over B x tiles tile-sized "patches" that reads and writes image-shaped tensors in place (the caller's, and between two
+// segments a scratch tensor), then — in the NLL direction — a one-lane-per-image kernel that adds the tiles' sums up.  Scratch
+// is stream-ordered (hipMallocAsync), so concurrent calls on one handle (different streams) never share it.
 static int launch_tiled(nf_handle *h, int direction, NfLaunch &a, hipStream_t st, const char *what)
 {
     const Built &b = direction == 0 ? h->fwd : h->rev;
     float *d1 = direction == 0 ? h->d_fwd : h->d_rev;
     float *d2 = direction == 0 ? h->d_fwd2 : h->d_rev2;
-    const int nt = b.tile_ny * b.tile_nx;
     const int64_t B = a.B;
-    if (B > INT64_MAX / nt) return fail(NF_EINVAL, "B too large");
-    NfLaunch t = a;
-    t.B = B * nt;
-    t.H = b.tile_h;
-    t.W = b.tile_w;
-    t.img_H = h->cfg.height;
-    t.img_W = h->cfg.width;
-    t.tile_ny = b.tile_ny;
-    t.tile_nx = b.tile_nx;
-    t.tile_halo = b.tile_halo;
-    t.flags |= NF_K_TILED;
-    t.nll_out = t.sd_out = t.ld_out = nullptr;
-    t.sums = nullptr;
+    const int S = (int)b.segs.size();
     const bool want = direction == 0 && (a.nll_out || a.sd_out || a.ld_out || a.sums);
-    hipError_t e;
-    if (want) {
-        e = hipMallocAsync((void **)&t.tile_part, (size_t)t.B * 4 * sizeof(float), st);
-        if (e != hipSuccess) return fail_hip(e, "hipMallocAsync(tile sums)");
+    NfTileParts tp;
+    memset(&tp, 0, sizeof(tp));
+    tp.n_seg = S;
+    int64_t part4 = 0;   // float4 entries
+    for (int s = 0; s < S; ++s) {
+        tp.nt[s] = b.segs[s].ny * b.segs[s].nx;
+        tp.off[s] = part4;
+        if (B > (INT64_MAX / 64) / tp.nt[s]) return fail(NF_EINVAL, "B too large");
+        part4 += B * tp.nt[s];
     }
+    const size_t img_bytes = (size_t)B * h->cfg.height * h->cfg.width * kC * sizeof(float);
+    float *part = nullptr, *scratch[2] = {nullptr, nullptr};
+    hipError_t e = hipSuccess;
+    if (want) e = hipMallocAsync((void **)&part, (size_t)part4 * 4 * sizeof(float), st);
+    for (int i = 0; i < 2 && i < S - 1 && e == hipSuccess; ++i) e = hipMallocAsync((void **)&scratch[i], img_bytes, st);
     const bool mc = d2 && (use_matrix_core() || !h->scalar_ok);
-    t.params = mc ? d2 : d1;
-    if (mc) t.n_params = (int32_t)b.block2.size();
-    e = nf_launch_flow(mc ? b.prog2 : b.prog, t, h->n_cu, st, mc);
-    if (e == hipSuccess && want)
-        e = nf_launch_tile_combine(t.tile_part, nt, B, (double)h->cfg.height * h->cfg.width * kC, a.ld_const, a.flags, a.nll_out, a.sd_out,
-                                   a.ld_out, a.sums, st);
-    if (want) {
-        hipError_t e2 = hipFreeAsync(t.tile_part, st);
-        if (e == hipSuccess) e = e2;
+    const NfProgram &full = mc ? b.prog2 : b.prog;
+    const float *cur = a.in;
+    for (int s = 0; s < S && e == hipSuccess; ++s) {
+        const Built::TileSeg &g = b.segs[s];
+        NfProgram sp;
+        memset(&sp, 0, sizeof(sp));
+        sp.width = full.width;
+        sp.n_ops = g.op1 - g.op0;
+        memcpy(sp.ops, full.ops + g.op0, sizeof(NfOp) * (size_t)sp.n_ops);
+        NfLaunch t = a;
+        t.B = B * tp.nt[s];
+        t.H = b.tile_h;
+        t.W = b.tile_w;
+        t.img_H = h->cfg.height;
+        t.img_W = h->cfg.width;
+        t.tile_ny = g.ny;
+        t.tile_nx = g.nx;
+        t.tile_halo = g.halo;
+        t.flags |= NF_K_TILED;
+        if (s > 0) {   // only the first segment draws / scales the input
+            t.flags &= ~(uint32_t)NF_K_PHILOX_IN;
+            t.in_scale = 1.0f;
+        }
+        t.in = cur;
+        t.out = s == S - 1 ? a.out : scratch[s & 1];
+        t.nll_out = t.sd_out = t.ld_out = nullptr;
+        t.sums = nullptr;
+        t.tile_part = want ? part + tp.off[s] * 4 : nullptr;
+        t.params = mc ? d2 : d1;
+        if (mc) t.n_params = (int32_t)b.block2.size();
+        e = nf_launch_flow(sp, t, h->n_cu, st, mc);
+        cur = t.out;
     }
+    if (e == hipSuccess && want)
+        e = nf_launch_tile_combine(part, tp, B, (double)h->cfg.height * h->cfg.width * kC, a.ld_const, a.flags, a.nll_out, a.sd_out, a.ld_out,
+                                   a.sums, st);
+    for (float *p : {part, scratch[0], scratch[1]})
+        if (p) {
+            hipError_t e2 = hipFreeAsync(p, st);
+            if (e == hipSuccess) e = e2;
+        }
     if (e != hipSuccess) return fail_hip(e, what);
     return NF_OK;
 }
@@ -2178,6 +2259,22 @@ int nf_sums_reduce(const double *wide, double *out3, uint32_t flags, void *strea
     hipError_t e = nf_launch_sums_reduce(wide, out3, (flags & NF_ACCUMULATE) != 0, (hipStream_t)stream);
     if (e != hipSuccess) return fail_hip(e, "nf_sums_reduce launch");
     return NF_OK;
+}
+
+int nf_tile_segments(const nf_config *cfg, const nf_layer_desc *layers, const float *params, size_t n_params, int32_t direction,
+                     int32_t *out5, int32_t cap)
+{
+    if (direction != 0 && direction != 1) return fail(NF_EINVAL, "direction must be 0 or 1");
+    Built b;
+    int rc = build_program(cfg, layers, params, n_params, direction, b);
+    if (rc != NF_OK) return rc;
+    if (!b.tiled) return 0;
+    for (int i = 0; i < (int)b.segs.size() && i < cap && out5; ++i) {
+        const Built::TileSeg &g = b.segs[i];
+        const int32_t v[5] = {g.op0, g.op1, g.halo, g.ny, g.nx};
+        memcpy(out5 + 5 * i, v, sizeof(v));
+    }
+    return (int)b.segs.size();
 }
 
 int nf_tile_plan(int32_t size, int32_t tile, int32_t halo, int32_t *origin, int32_t *core0, int32_t *core1, int32_t cap)

@@ -128,10 +128,13 @@ __device__ __forceinline__ void stats_flush(const float (&s1)[WIDTH], const floa
 //           re-fold of NfLaunch::fix_* to its LDS weight image in the prologue and gathers NfLaunch::stats
 // Global I/O is 16 bytes per lane per pixel ([H,W,4] fp32, NHWC).
 // --------------------------------------------------------------------------
-template <int WIDTH, int THREADS, int PX, bool PHILOX, bool MFMA, bool FULL, int PREC, bool BS>
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_WAVES(THREADS, PX, MFMA)))) void nf_flow_kernel(const NfProgram prog, const NfLaunch a)
+//   TF      NF_K_TILED launches whose tiles are full 64x64 blocks (FULL geometry, per-tile addresses and border masks);
+//           masked (!FULL) instantiations take tiled launches of any tile shape at run time
+template <int WIDTH, int THREADS, int PX, bool PHILOX, bool MFMA, bool FULL, int PREC, bool BS, bool TF>
+__device__ __forceinline__ void nf_flow_body(const NfProgram &prog, const NfLaunch &a)
 {
     static_assert(!BS || (MFMA && PREC == 0), "the batch-statistics variant is the fp32 matrix-core kernel");
+    static_assert(!TF || (FULL && MFMA && PX == 4 && PREC == 0 && !BS), "tiled full-geometry launches: the fp32 matrix-core kernel");
     static_assert(WIDTH % 4 == 0, "WIDTH must be a multiple of 4");
     static_assert(!MFMA || WIDTH == 4, "the matrix-core path is the width-4 specialisation");
     static_assert(PREC == 0 || (MFMA && FULL && PX == 4), "the fp16-CNN mode exists for full 2x2-blocked patches only");
@@ -200,6 +203,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
             const int r = 2 * br + dy, c = 2 * bc + dx;
             act[k] = true;
             own[k] = true;
+            prow[k] = r;
+            pcol[k] = c;
             gidx[k] = r * W + c;
             lidx[k] = H16 ? (r + 1) * Wp + (c + 1) : wbase + ((dy + 1) * 2 + ((dx + 1) & 1)) * PW + ((dx + 1) >> 1);
             bmask[k] = (r == 0 ? 1 : 0) | (r == H - 1 ? 2 : 0) | (c == 0 ? 4 : 0) | (c == W - 1 ? 8 : 0);
@@ -243,7 +248,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
     const bool early = !NF_STAGGER || PHILOX || blockIdx.x < (NF_STAGGER >= 2 ? (gridDim.x >> 2) : (gridDim.x >> 1));
     // NF_K_TILED (nf_device.h): the pixel -> address map changes from tile to tile, so the loads sit at the top of the
     // patch loop instead of one patch ahead
-    bool tiled = false;
+    bool tiled = TF;
     if constexpr (!FULL) tiled = (a.flags & NF_K_TILED) != 0;
     if ((int64_t)blockIdx.x < a.B && early && !tiled) {
         const size_t off0 = (size_t)blockIdx.x * (size_t)HW;
@@ -358,7 +363,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
 #ifdef NF_TIMELINE
         stamp_on = stamp_it++ == (a.B / gridDim.x) / 2;
 #endif
-        if constexpr (!FULL) {
+        if constexpr (!FULL || TF) {
             if (tiled) {
                 const int nt = a.tile_ny * a.tile_nx;
                 const int64_t img = b / nt;
@@ -1057,6 +1062,19 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
 #endif
 }
 
+template <int WIDTH, int THREADS, int PX, bool PHILOX, bool MFMA, bool FULL, int PREC, bool BS>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_WAVES(THREADS, PX, MFMA)))) void nf_flow_kernel(const NfProgram prog, const NfLaunch a)
+{
+    nf_flow_body<WIDTH, THREADS, PX, PHILOX, MFMA, FULL, PREC, BS, false>(prog, a);
+}
+
+// NF_K_TILED launches over full 64x64 tiles: the 2x2-blocked matrix-core geometry of nf_flow_kernel<4, 1024, 4, ., true, true, 0, false>
+template <bool PHILOX>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(NF_MIN_WAVES(1024, 4, true)))) void nf_flow_tile64_kernel(const NfProgram prog, const NfLaunch a)
+{
+    nf_flow_body<4, 1024, 4, PHILOX, true, true, 0, false, true>(prog, a);
+}
+
 // Batch-statistics mode, device side of the re-fold (layers.py:388-391 + the BN-eval folding of fold_coupling):
 // the moments of one normalisation from the slotted sums, then  W[r][j] *= 1/sqrt(var_j + eps),
 // B[j] = (B[j] - mean_j)/sqrt(var_j + eps)  in place on the working copy of the folded block (which holds the
@@ -1110,24 +1128,34 @@ __global__ __launch_bounds__(64) void nf_sums_reduce_kernel(const double *__rest
         for (int k = 0; k < 3; ++k) out3[k] = (accumulate ? out3[k] : 0.0) + v[k];
 }
 
-// NF_K_TILED launches (nf_device.h): per image, the sums its tiles left in tile_part[image][tile][4] -> nll / sd / log-det
-// exactly as the fused kernel's epilogue forms them for a patch it holds whole (tiles added in index order, in double),
-// and the call's (sum nll, sum sd, count) accumulators.  One lane per image.
-__global__ __launch_bounds__(64) void nf_tile_combine_kernel(const float *__restrict__ part, int nt, int64_t B, double n, double ld_const,
-                                                             uint32_t flags, float *__restrict__ nll_out, float *__restrict__ sd_out,
-                                                             float *__restrict__ ld_out, double *__restrict__ sums)
+// NF_K_TILED launches (nf_device.h): per image, the sums the tiles of every segment left in `part` -> nll / sd / log-det exactly as
+// the fused kernel's epilogue forms them for a patch it holds whole (the log-det over all segments, the moments of z from the
+// last one), and the call's (sum nll, sum sd, count) accumulators.  One wavefront per image: lane l adds up tiles l, l + 64, ...
+// of every segment in double, then the fixed-order wavefront sum — the same bits whatever else is in the batch.
+__global__ __launch_bounds__(64) void nf_tile_combine_kernel(const float *__restrict__ part, const NfTileParts tp, int64_t B, double n,
+                                                             double ld_const, uint32_t flags, float *__restrict__ nll_out,
+                                                             float *__restrict__ sd_out, float *__restrict__ ld_out, double *__restrict__ sums)
 {
-    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    double a_nll = 0.0, a_sd = 0.0;
-    if (i < B) {
-        double r0 = 0.0, r1 = 0.0, r2 = 0.0;
-        const float4 *p4 = reinterpret_cast<const float4 *>(part) + (size_t)i * nt;
-        for (int k = 0; k < nt; ++k) {
+    const int64_t i = blockIdx.x;
+    const int lane = threadIdx.x;
+    double r0 = 0.0, r1 = 0.0, r2 = 0.0;
+    for (int sgm = 0; sgm < tp.n_seg; ++sgm) {
+        const int nt = tp.nt[sgm];
+        const float4 *p4 = reinterpret_cast<const float4 *>(part) + tp.off[sgm] + (size_t)i * nt;
+        const bool last = sgm == tp.n_seg - 1;
+        for (int k = lane; k < nt; k += 64) {
             const float4 v = p4[k];
             r0 += (double)v.x;
-            r1 += (double)v.y;
-            r2 += (double)v.z;
+            if (last) {
+                r1 += (double)v.y;
+                r2 += (double)v.z;
+            }
         }
+    }
+    r0 = wave_sum(r0);
+    r1 = wave_sum(r1);
+    r2 = wave_sum(r2);
+    if (lane == 0) {
         const double logdet = r0 + ld_const;
         double nll = -logdet;
         if (flags & NF_K_PRIOR) nll += 0.5 * n * 1.8378770664093453 + 0.5 * r2;
@@ -1138,17 +1166,11 @@ __global__ __launch_bounds__(64) void nf_tile_combine_kernel(const float *__rest
         if (nll_out) nll_out[i] = (float)nll;
         if (sd_out) sd_out[i] = (float)sd;
         if (ld_out) ld_out[i] = (float)logdet;
-        a_nll = (double)(float)nll;
-        a_sd = (double)(float)sd;
-    }
-    if (sums) {
-        a_nll = wave_sum(a_nll);
-        a_sd = wave_sum(a_sd);
-        if (threadIdx.x == 0) {
+        if (sums) {
             double *sp = sums;
             if (flags & NF_K_SUMS_WIDE) sp += (size_t)(blockIdx.x & (NF_SUMS_SLOTS - 1)) * NF_SUMS_STRIDE;
-            atomicAdd(&sp[0], a_nll);
-            atomicAdd(&sp[1], a_sd);
+            atomicAdd(&sp[0], (double)(float)nll);
+            atomicAdd(&sp[1], (double)(float)sd);
             if (blockIdx.x == 0) atomicAdd(&sp[2], (double)B);
         }
     }
@@ -1208,7 +1230,13 @@ __global__ __launch_bounds__(256) void nf_eps_kernel(uint64_t seed, int64_t patc
     }
 }
 
-template <int WIDTH, int THREADS, int PX, bool PHILOX, bool MFMA, bool FULL, int PREC, bool BS = false>
+inline int env_int(const char *name)
+{
+    const char *e = getenv(name);
+    return e ? atoi(e) : 0;
+}
+
+template <int WIDTH, int THREADS, int PX, bool PHILOX, bool MFMA, bool FULL, int PREC, bool BS = false, bool TF = false>
 hipError_t launch_flow_p(const NfProgram &prog, const NfLaunch &a, int n_cu, hipStream_t stream)
 {
     const int tile_px = ((a.H + 2) * (a.W + 2) + 1) & ~1;
@@ -1218,7 +1246,11 @@ hipError_t launch_flow_p(const NfProgram &prog, const NfLaunch &a, int n_cu, hip
     if (BS) lds_f += (size_t)(THREADS / 64) * 8 + 16;
     const size_t lds = sizeof(float) * lds_f;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    const void *fn = reinterpret_cast<const void *>(&nf_flow_kernel<WIDTH, THREADS, PX, PHILOX, MFMA, FULL, PREC, BS>);
+    void (*const kern)(const NfProgram, const NfLaunch) = [] {
+        if constexpr (TF) return &nf_flow_tile64_kernel<PHILOX>;
+        else return &nf_flow_kernel<WIDTH, THREADS, PX, PHILOX, MFMA, FULL, PREC, BS>;
+    }();
+    const void *fn = reinterpret_cast<const void *>(kern);
     // (device << 40 | lds bytes << 8 | resident workgroups per CU) of the last query; racy but idempotent.  The
     // >64 KiB opt-in is a per-device function attribute, so the device is part of the key.
     int dev = 0;
@@ -1245,8 +1277,7 @@ hipError_t launch_flow_p(const NfProgram &prog, const NfLaunch &a, int n_cu, hip
     int64_t groups = (int64_t)n_cu * occ;
     if (a.B < groups) groups = a.B;
     if (groups < 1) groups = 1;
-    hipLaunchKernelGGL((nf_flow_kernel<WIDTH, THREADS, PX, PHILOX, MFMA, FULL, PREC, BS>), dim3((unsigned)groups), dim3(THREADS), lds,
-                       stream, prog, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3(THREADS), lds, stream, prog, a);
     return hipGetLastError();
 }
 
@@ -1268,8 +1299,14 @@ hipError_t launch_flow_v(const NfProgram &prog, const NfLaunch &a, int n_cu, hip
 {
     // full-patch specialisation only for the production shapes (32x32, 64x64) to bound code size
     if constexpr (THREADS * PX == 1024 || THREADS * PX == 4096) {
-        if (a.H == a.W && a.H * a.W == THREADS * PX && !(a.flags & NF_K_TILED))
-            return launch_flow_f<WIDTH, THREADS, PX, PHILOX, MFMA, true>(prog, a, n_cu, stream);
+        if (a.H == a.W && a.H * a.W == THREADS * PX) {
+            if (!(a.flags & NF_K_TILED)) return launch_flow_f<WIDTH, THREADS, PX, PHILOX, MFMA, true>(prog, a, n_cu, stream);
+            // tiled launches: full 64x64 tiles have their own instantiation of the blocked geometry, everything else is masked
+            if constexpr (MFMA && WIDTH == 4 && THREADS == 1024 && PX == 4) {
+                static const bool masked = env_int("NF_TILE_MASKED") != 0;   // A/B aid
+                if (!masked) return launch_flow_p<WIDTH, THREADS, PX, PHILOX, MFMA, true, 0, false, true>(prog, a, n_cu, stream);
+            }
+        }
     }
     return launch_flow_f<WIDTH, THREADS, PX, PHILOX, MFMA, false>(prog, a, n_cu, stream);
 }
@@ -1281,12 +1318,6 @@ hipError_t launch_flow(const NfProgram &prog, const NfLaunch &a, int n_cu, hipSt
     // registers and libm code never burden the likelihood path
     if (a.flags & NF_K_PHILOX_IN) return launch_flow_v<WIDTH, THREADS, PX, true, MFMA>(prog, a, n_cu, stream);
     return launch_flow_v<WIDTH, THREADS, PX, false, MFMA>(prog, a, n_cu, stream);
-}
-
-inline int env_int(const char *name)
-{
-    const char *e = getenv(name);
-    return e ? atoi(e) : 0;
 }
 
 template <int WIDTH, bool MFMA>
@@ -1347,11 +1378,12 @@ hipError_t nf_launch_sums_reduce(const double *wide, double *out3, bool accumula
     return hipGetLastError();
 }
 
-hipError_t nf_launch_tile_combine(const float *part, int nt, int64_t B, double n, double ld_const, uint32_t flags, float *nll_out,
-                                  float *sd_out, float *ld_out, double *sums, hipStream_t stream)
+hipError_t nf_launch_tile_combine(const float *part, const NfTileParts &tp, int64_t B, double n, double ld_const, uint32_t flags,
+                                  float *nll_out, float *sd_out, float *ld_out, double *sums, hipStream_t stream)
 {
     if (B <= 0) return hipSuccess;
-    hipLaunchKernelGGL(nf_tile_combine_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, stream, part, nt, B, n, ld_const, flags,
+    if (B > 0x7fffffff) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(nf_tile_combine_kernel, dim3((unsigned)B), dim3(64), 0, stream, part, tp, B, n, ld_const, flags,
                        nll_out, sd_out, ld_out, sums);
     return hipGetLastError();
 }

@@ -448,3 +448,46 @@ def test_tiled_evaluation_equals_whole_image_evaluation_in_the_oracle():
             # except where the border IS the image's (first / last tile), where the padding is the image's own
             z[:, ay[i]:by[i], ax[j]:bx[j]] = zt[:, ay[i] - oy[i]:by[i] - oy[i], ax[j] - ox[j]:bx[j] - ox[j]]
     np.testing.assert_allclose(z, z_ref, rtol=0, atol=1e-12 * np.abs(z_ref).max())
+
+
+def test_tile_segment_plan(monkeypatch):
+    """nf_tile_segments: segments partition the op list, end right after a coupling, carry a halo of 2 x their couplings and
+    the tile counts of nf_tile_plan; deeper stacks / larger images get more segments; NF_TILE_SEGMENTS forces the count."""
+    from noise_flow_amd import _lib, params
+    from conftest import trained_like_variables
+    lib = _lib.load()
+
+    def plan(arch, H, W, direction=0):
+        v = trained_like_variables(arch, 4)
+        layers, descs, flat = params.pack(arch, v, 4)
+        cfg = _lib.nf_config(H, W, 4, len(layers), -1, 0)
+        fp = flat.ctypes.data_as(C.POINTER(C.c_float))
+        out = (C.c_int32 * 80)()
+        n = lib.nf_tile_segments(C.byref(cfg), descs, fp, flat.size, direction, out, 16)
+        ops = (C.c_int32 * 128)()
+        n_ops = C.c_int32()
+        assert lib.nf_fold_params(C.byref(cfg), descs, fp, flat.size, direction, ops, 64, C.byref(n_ops), None, 0, None, None) == 0
+        types = [ops[2 * i] for i in range(n_ops.value)]
+        return n, [tuple(out[5 * i:5 * i + 5]) for i in range(max(n, 0))], types
+
+    monkeypatch.delenv("NF_TILE_SEGMENTS", raising=False)
+    assert plan(FULL_ARCH, 64, 64)[0] == 0 and plan(FULL_ARCH, 32, 32)[0] == 0
+    counts = {}
+    for H, W in ((65, 64), (128, 128), (256, 256), (1024, 1024), (32, 200)):
+        for direction in (0, 1):
+            n, segs, types = plan(FULL_ARCH, H, W, direction)
+            counts[(H, W)] = n
+            assert n >= 1 and segs[0][0] == 0 and segs[-1][1] == len(types)
+            for i, (op0, op1, halo, ny, nx) in enumerate(segs):
+                ncpl = sum(1 for t in types[op0:op1] if t in (2, 3))          # NF_OP_COUPLING_FWD / _REV
+                assert halo == 2 * ncpl and 64 - 2 * halo >= 8
+                assert i == 0 or op0 == segs[i - 1][1]
+                assert i == n - 1 or types[op1 - 1] in (2, 3)
+                assert ny == lib.nf_tile_plan(H, min(H, 64), halo, None, None, None, 0)
+                assert nx == lib.nf_tile_plan(W, min(W, 64), halo, None, None, None, 0)
+            assert sum(s[2] for s in segs) == 16                               # 8 couplings in all
+    assert counts[(65, 64)] == 1 and counts[(1024, 1024)] > counts[(128, 128)]
+    assert plan("|".join(["unc"] * 16), 100, 100)[0] >= 2                      # halo 32 would leave no core
+    monkeypatch.setenv("NF_TILE_SEGMENTS", "3")
+    n, segs, _ = plan(FULL_ARCH, 128, 128)
+    assert n == 3 and [s[2] for s in segs] == [6, 6, 4]
