@@ -87,7 +87,8 @@ def test_gradients_full_arch_shipped(shipped_variables):
                                                      ("sdn4|gain4", 4, (32, 32), 4, 800, 9),            # job_noise_flow.sh "S-G"
                                                      ("sdn4|unc|gain4", 4, (16, 16), 4, 123, 2),
                                                      ("sdn5|gain4", 4, (32, 32), 4, 3200, 4),           # "S-G-CAM"
-                                                     ("unc|unc|unc|unc", 4, (32, 32), 3, 100, 2)])      # "Ax4"
+                                                     ("unc|unc|unc|unc", 4, (32, 32), 3, 100, 2),       # "Ax4"
+                                                     ("sdn5|unc|gain4|unc", 4, (72, 80), 2, 400, 2)])   # beyond 64x64: layer kernels
 def test_gradients_other_widths_and_shapes(arch, width, hw, B, iso, cam):
     v = trained_like_variables(arch, width, seed=6)
     x, y = make_inputs(B, hw[0], hw[1], seed=17)
