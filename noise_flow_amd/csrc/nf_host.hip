@@ -921,6 +921,9 @@ int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float
         case NF_LAYER_COUPLING: {
             if (L.width != 4 && L.width != 8 && L.width != 16 && !(L.width >= 32 && L.width <= 512))
                 return fail(NF_EINVAL, "layer %d: coupling width %d unsupported (4, 8, 16, 32 .. 512)", li, L.width);
+            if (L.width > 32 && out.tiled)
+                return fail(NF_EINVAL, "layer %d: patches beyond 64x64 (%dx%d given) are evaluated at coupling widths up to 32", li, cfg->height,
+                            cfg->width);
             if (L.width > 32 && !nf_gemm_shape_ok(th, tw))
                 return fail(NF_EINVAL, "layer %d: coupling width %d covers patches of up to %d pixels (%dx%d given)", li, L.width,
                             NF7_MAX_PIXELS, cfg->height, cfg->width);
@@ -962,13 +965,6 @@ int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float
             break;
         }
         items.push_back(it);
-    }
-
-    if (out.tiled) {
-        int n_cpl = 0;
-        for (const Item &it : items) n_cpl += it.type == NF_OP_COUPLING_FWD ? 1 : 0;
-        if (n_cpl > 0 && (width != 4 || (cfg->flags & NF_CFG_FP16_CNN)))
-            return fail(NF_EINVAL, "patches beyond 64x64 (%dx%d given) are evaluated at coupling width 4 in fp32 only", cfg->height, cfg->width);
     }
 
     // Fold every gain into a neighbouring 1x1 matrix (NLL: z/g then z@A == z@(A/g)).
@@ -1066,6 +1062,8 @@ int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float
         const size_t tile_px = ((size_t)(th + 2) * (tw + 2) + 1) & ~(size_t)1;
         const bool scalar_fits = sizeof(float) * (tile_px * (2 + (size_t)out.prog.width) + 64) <= 160 * 1024;
         if (out.prog.width == 32 || (out.prog.width == 8 && !scalar_fits)) out.prog4.width = 32;
+        // tiled images (nf_device.h): widths 8 / 16 run zero-padded on the width-32 kernel, the wide family with a tiled mode
+        if (out.tiled && (out.prog.width == 8 || out.prog.width == 16)) out.prog4.width = 32;
     }
     if (out.prog4.width == 32) {
         for (int i = 0; i < out.prog.n_ops; ++i) {
@@ -1172,7 +1170,7 @@ int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float
     memset(&out.prog5, 0, sizeof(out.prog5));
     // width 4 has its own fp16 kernel for the two full shapes (nf_kernels.hip); on any other shape it runs here, zero-padded
     // to 32 channels (exact: same rounding points, a padded channel is identically zero)
-    const bool w4_full = (th == 32 && tw == 32) || (th == 64 && tw == 64);
+    const bool w4_full = ((th == 32 && tw == 32) || (th == 64 && tw == 64)) && !out.tiled;   // tiled: the width-32 fp16 kernel
     if ((cfg->flags & NF_CFG_FP16_CNN) &&
         (out.prog.width == 8 || out.prog.width == 16 || out.prog.width == 32 || (out.prog.width == 4 && !w4_full))) {
         out.prog5.width = 32;
@@ -1618,8 +1616,13 @@ static int launch_tiled(nf_handle *h, int direction, NfLaunch &a, hipStream_t st
     hipError_t e = hipSuccess;
     if (want) e = hipMallocAsync((void **)&part, (size_t)part4 * 4 * sizeof(float), st);
     for (int i = 0; i < 2 && i < S - 1 && e == hipSuccess; ++i) e = hipMallocAsync((void **)&scratch[i], img_bytes, st);
+    // kernel family: fp16-CNN mode and widths 8 / 16 / 32 on the width-32 matrix-core kernel (zero-padded), width 4 in fp32 on
+    // the fused width-4 kernels
+    float *d4 = direction == 0 ? h->d_fwd4 : h->d_rev4;
+    float *d5 = direction == 0 ? h->d_fwd5 : h->d_rev5;
+    const int wide = d5 ? 2 : (d4 && b.prog.width > 4) ? 1 : 0;
     const bool mc = d2 && (use_matrix_core() || !h->scalar_ok);
-    const NfProgram &full = mc ? b.prog2 : b.prog;
+    const NfProgram &full = wide == 2 ? b.prog5 : wide == 1 ? b.prog4 : mc ? b.prog2 : b.prog;
     const float *cur = a.in;
     for (int s = 0; s < S && e == hipSuccess; ++s) {
         const Built::TileSeg &g = b.segs[s];
@@ -1647,9 +1650,16 @@ static int launch_tiled(nf_handle *h, int direction, NfLaunch &a, hipStream_t st
         t.nll_out = t.sd_out = t.ld_out = nullptr;
         t.sums = nullptr;
         t.tile_part = want ? part + tp.off[s] * 4 : nullptr;
-        t.params = mc ? d2 : d1;
-        if (mc) t.n_params = (int32_t)b.block2.size();
-        e = nf_launch_flow(sp, t, h->n_cu, st, mc);
+        if (wide) {
+            t.params = wide == 2 ? d5 : d4;
+            t.n_params = (int32_t)(wide == 2 ? b.block5.size() : b.block4.size());
+            if (wide == 2) t.flags |= NF_K_FP16_CNN;
+            e = nf_launch_wide(sp, t, h->n_cu, h->device, st);
+        } else {
+            t.params = mc ? d2 : d1;
+            if (mc) t.n_params = (int32_t)b.block2.size();
+            e = nf_launch_flow(sp, t, h->n_cu, st, mc);
+        }
         cur = t.out;
     }
     if (e == hipSuccess && want)
@@ -1736,6 +1746,10 @@ int nf_kernel_path(const nf_handle *h, int32_t direction)
 {
     if (!h || (direction != 0 && direction != 1)) return fail(NF_EINVAL, "bad argument");
     if (direction == 0 ? h->d_fwd5 : h->d_rev5) return NF_PATH_WIDE32_FP16;
+    if (h->fwd.tiled) {   // images beyond 64x64: launch_tiled's choice
+        if ((direction == 0 ? h->d_fwd4 : h->d_rev4) && h->fwd.prog.width > 4) return NF_PATH_WIDE32;
+        return (direction == 0 ? h->d_fwd2 : h->d_rev2) && (use_matrix_core() || !h->scalar_ok) ? NF_PATH_MFMA4 : NF_PATH_SCALAR;
+    }
     if (direction == 0 ? h->d_fwd8 : h->d_rev8) return NF_PATH_GEMM_FP16;
     if (direction == 0 ? h->d_fwd7 : h->d_rev7) return NF_PATH_GEMM;
     const bool mcore = use_matrix_core() || !h->scalar_ok;

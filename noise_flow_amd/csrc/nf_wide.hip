@@ -94,8 +94,10 @@ __device__ __forceinline__ float half_sums(float a, float b)
 // Pixel ownership: the CNN of a tile needs all 64 lanes (lane half g = K slice), everything else is per pixel —
 // so lane half g OWNS the rows row0 + 2m + g (m = 0..3) of its strip: their 4 channel values live in its registers,
 // it does their global I/O, 1x1 mixes, signal-dependent scaling, affine update and log-det.
-template <int THREADS, bool PHILOX, int TPR, int PREC>
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS == 256 ? NF_WIDE_WPE : 1))) void nf_wide32_kernel(const NfProgram prog, const NfLaunch a)
+//   TILED    NF_K_TILED launches (nf_device.h): its own kernels (nf_wide32_tiled_kernel), so that the per-tile geometry costs
+//            the whole-patch kernels neither scalar registers nor instructions
+template <int THREADS, bool PHILOX, int TPR, int PREC, bool TILED>
+__device__ __forceinline__ void nf_wide32_body(const NfProgram &prog, const NfLaunch &a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NW = THREADS / 64;
@@ -131,16 +133,41 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS
     double acc_nll = 0.0, acc_sd = 0.0;   // thread 0 only
 
     for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
-        const size_t patch_off = (size_t)b * (size_t)HW * 4u;
+        // Where this "patch" sits: on its own ([B,H,W,4] tensors), or — NF_K_TILED (nf_device.h, "overlapping tiles") — as
+        // tile b % tiles of image b / tiles: pixel (r, c) of the tile is pixel (oy + r, ox + c) of an IH x IW image, border
+        // masks follow the image border, and results are reported for the core window [cy0, cy1) x [cx0, cx1) only.
+        size_t patch_off = (size_t)b * (size_t)HW * 4u;
+        int64_t patch_id = b;
+        int oy = 0, ox = 0, IH = H, IW = W, cy0 = 0, cy1 = H, cx0 = 0, cx1 = W;
+        constexpr bool tiled = TILED;
+        if constexpr (TILED) {
+            const int nt = a.tile_ny * a.tile_nx;
+            const int64_t img = b / nt;
+            const int ti = (int)(b - img * nt);
+            const int ty = ti / a.tile_nx, tx = ti - ty * a.tile_nx;
+            IH = a.img_H;
+            IW = a.img_W;
+            oy = nf_tile_origin(ty, IH, H, a.tile_halo);
+            ox = nf_tile_origin(tx, IW, W, a.tile_halo);
+            cy0 = nf_tile_core0(ty, IH, H, a.tile_halo);
+            cy1 = nf_tile_core1(ty, a.tile_ny, IH, H, a.tile_halo);
+            cx0 = nf_tile_core0(tx, IW, W, a.tile_halo);
+            cx1 = nf_tile_core1(tx, a.tile_nx, IW, W, a.tile_halo);
+            patch_off = (size_t)img * (size_t)IH * (size_t)IW * 4u;
+            patch_id = img;
+        }
+        const int C = ox + c;                                               // image column of this lane's pixels
+        const bool col_own = col_on && C >= cx0 && C < cx1;
+        const int cmask = (C == 0 ? 4 : 0) | (C == IW - 1 ? 8 : 0);
 
         float z[OWN][4];
 #pragma unroll
         for (int m = 0; m < OWN; ++m) {
             const int r = row0 + 2 * m + g;
             const bool act = r < H && col_on;
-            const int gi = act ? r * W + c : 0;
+            const int gi = act ? (oy + r) * IW + C : 0;
             if (PHILOX) {
-                philox_normal4(a.seed, a.patch_base + b, (uint32_t)gi, NF_STREAM_SAMP, z[m]);
+                philox_normal4(a.seed, a.patch_base + patch_id, (uint32_t)gi, NF_STREAM_SAMP, z[m]);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) z[m][q] *= a.in_scale;
             } else {
@@ -379,7 +406,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS
 #pragma unroll
                     for (int j = 0; j < 4; ++j) o[j] = half_sums(cp[2 * m][j], cp[2 * m + 1][j]);
                     const bool act = r < H && col_on;
-                    const int bm = (r == 0 ? 1 : 0) | (r == H - 1 ? 2 : 0) | (c == 0 ? 4 : 0) | (c == W - 1 ? 8 : 0);
+                    const int R = oy + r;
+                    const bool own = r < H && col_own && R >= cy0 && R < cy1;
+                    const int bm = (R == 0 ? 1 : 0) | (R == IH - 1 ? 2 : 0) | cmask;
                     const float4 eb = *reinterpret_cast<const float4 *>(a.params + prog.ops[op].off + NF4_CPL_E + 4 * (act ? bm : 0));
                     if constexpr (H16) {   // fp16 weights are not pre-scaled (their rounding points are the oracle's); the table is
                         o[0] += eb.x; o[1] += eb.y;
@@ -395,7 +424,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS
                     if (type == NF_OP_COUPLING_FWD) {
                         z[m][2] = fmaf(z[m][2], __builtin_amdgcn_exp2f(l0), o[0]);
                         z[m][3] = fmaf(z[m][3], __builtin_amdgcn_exp2f(l1), o[1]);
-                        if (act) ld2 += l0 + l1;
+                        if (own) ld2 += l0 + l1;
                     } else {
                         z[m][2] = (z[m][2] - o[0]) * __builtin_amdgcn_exp2f(-l0);
                         z[m][3] = (z[m][3] - o[1]) * __builtin_amdgcn_exp2f(-l1);
@@ -409,15 +438,17 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS
                 for (int m = 0; m < OWN; ++m) {
                     const int r = row0 + 2 * m + g;
                     const bool act = r < H && col_on;
+                    const int R = oy + r;
+                    const bool own = r < H && col_own && R >= cy0 && R < cy1;
                     float4 yv = make_float4(1.f, 1.f, 1.f, 1.f);
-                    if (act) yv = y4[r * W + c];
+                    if (act) yv = y4[R * IW + C];
                     const float yy[4] = {yv.x, yv.y, yv.z, yv.w};
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const float v = fmaf(yy[q], ck1, cb2);
                         if (type == NF_OP_SDN_DIV) {
                             z[m][q] = z[m][q] * __builtin_amdgcn_rsqf(v);
-                            if (act) ld = fmaf(-0.34657359027997264f, __builtin_amdgcn_logf(v), ld);
+                            if (own) ld = fmaf(-0.34657359027997264f, __builtin_amdgcn_logf(v), ld);
                         } else {
                             z[m][q] = z[m][q] * __builtin_amdgcn_sqrtf(v);
                         }
@@ -437,15 +468,15 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS
             float4 *out4 = reinterpret_cast<float4 *>(a.out + patch_off);
 #pragma unroll
             for (int m = 0; m < OWN; ++m) {
-                const int r = row0 + 2 * m + g;
-                if (r < H && col_on) out4[r * W + c] = make_float4(z[m][0], z[m][1], z[m][2], z[m][3]);
+                const int r = row0 + 2 * m + g, R = oy + r;
+                if (r < H && col_own && R >= cy0 && R < cy1) out4[R * IW + C] = make_float4(z[m][0], z[m][1], z[m][2], z[m][3]);
             }
         }
-        if (a.nll_out || a.sd_out || a.ld_out || a.sums) {
+        if (a.nll_out || a.sd_out || a.ld_out || a.sums || (tiled && a.tile_part)) {
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int m = 0; m < OWN; ++m)
-                if (row0 + 2 * m + g < H && col_on) {
+                if (row0 + 2 * m + g < H && col_own && oy + row0 + 2 * m + g >= cy0 && oy + row0 + 2 * m + g < cy1) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         s1 += z[m][q];
@@ -467,6 +498,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS
                     r1 += red[NW + i];
                     r2 += red[2 * NW + i];
                 }
+            }
+            if (t == 0 && tiled) {
+                // the tile's share of its image's sums (nf_tile_combine_kernel forms nll / sd / log-det per image)
+                *reinterpret_cast<float4 *>(a.tile_part + (size_t)b * 4u) = make_float4(r0, r1, r2, 0.f);
+            } else if (t == 0) {
                 const double npx = (double)HW * 4.0;
                 const double logdet = (double)r0 + a.ld_const;
                 double nll = -logdet;   // prior: sum -0.5*(log 2pi + z^2)   (noise_flow_model.py:537-539)
@@ -485,13 +521,25 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS
         }
     }
 
-    if (a.sums && t == 0) {
+    if (a.sums && t == 0 && !TILED) {
         double *sp = a.sums;
         if (a.flags & NF_K_SUMS_WIDE) sp += (size_t)(blockIdx.x & (NF_SUMS_SLOTS - 1)) * NF_SUMS_STRIDE;
         atomicAdd(&sp[0], acc_nll);
         atomicAdd(&sp[1], acc_sd);
         if (blockIdx.x == 0) atomicAdd(&sp[2], (double)a.B);
     }
+}
+
+template <int THREADS, bool PHILOX, int TPR, int PREC>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS == 256 ? NF_WIDE_WPE : 1))) void nf_wide32_kernel(const NfProgram prog, const NfLaunch a)
+{
+    nf_wide32_body<THREADS, PHILOX, TPR, PREC, false>(prog, a);
+}
+
+template <int THREADS, bool PHILOX, int TPR, int PREC>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS == 256 ? NF_WIDE_WPE : 1))) void nf_wide32_tiled_kernel(const NfProgram prog, const NfLaunch a)
+{
+    nf_wide32_body<THREADS, PHILOX, TPR, PREC, true>(prog, a);
 }
 
 size_t wide_lds_bytes(int H, int W, int threads, int tpr, int prec)
@@ -506,10 +554,13 @@ hipError_t launch_wide_p(const NfProgram &prog, const NfLaunch &a, int n_cu, int
 {
     const size_t lds = wide_lds_bytes(a.H, a.W, THREADS, TPR, PREC);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    const void *fn = reinterpret_cast<const void *>(&nf_wide32_kernel<THREADS, PHILOX, TPR, PREC>);
-    // (device << 40 | lds bytes << 8 | resident workgroups per CU) of the last query; racy but idempotent
+    const bool tiled = (a.flags & NF_K_TILED) != 0;
+    void (*const kern)(const NfProgram, const NfLaunch) =
+        tiled ? &nf_wide32_tiled_kernel<THREADS, PHILOX, TPR, PREC> : &nf_wide32_kernel<THREADS, PHILOX, TPR, PREC>;
+    const void *fn = reinterpret_cast<const void *>(kern);
+    // (tiled << 48 | device << 40 | lds bytes << 8 | resident workgroups per CU) of the last query; racy but idempotent
     static std::atomic<uint64_t> cache{0};
-    const uint64_t key = ((uint64_t)(device & 0xff) << 40) | ((uint64_t)lds << 8);
+    const uint64_t key = ((uint64_t)(tiled ? 1 : 0) << 48) | ((uint64_t)(device & 0xff) << 40) | ((uint64_t)lds << 8);
     uint64_t cv = cache.load(std::memory_order_relaxed);
     int occ;
     if ((cv & ~(uint64_t)0xff) == key && (cv & 0xff) != 0) {
@@ -529,7 +580,7 @@ hipError_t launch_wide_p(const NfProgram &prog, const NfLaunch &a, int n_cu, int
     int64_t groups = (int64_t)n_cu * occ;
     if (a.B < groups) groups = a.B;
     if (groups < 1) groups = 1;
-    hipLaunchKernelGGL((nf_wide32_kernel<THREADS, PHILOX, TPR, PREC>), dim3((unsigned)groups), dim3(THREADS), lds, stream, prog, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3(THREADS), lds, stream, prog, a);
     return hipGetLastError();
 }
 

@@ -84,18 +84,30 @@ def test_tile_results_do_not_depend_on_the_batch():
     assert np.array_equal(z3[0], z[3])
 
 
+@pytest.mark.parametrize("width,cnn_dtype,hw,arch,path", [(32, "fp32", (100, 72), "sdn5|unc|gain4|unc|unc", 3),
+                                                          (16, "fp32", (70, 130), "sdn5|unc|unc|gain4|unc", 3),
+                                                          (8, "fp32", (65, 65), "unc|unc", 3),
+                                                          (32, "fp16", (96, 96), "sdn5|unc|gain4|unc", 5),
+                                                          (4, "fp16", (128, 80), None, 5),
+                                                          (32, "fp32", (40, 150), "unc|unc|unc", 3)])
+def test_large_patches_on_the_width_32_kernel(width, cnn_dtype, hw, arch, path):
+    """Coupling widths 8 / 16 / 32 and the fp16-CNN mode (any width up to 32) run their tiles on the width-32 matrix-core
+    kernel (narrower CNNs zero-padded: exact, a padded channel is identically zero)."""
+    from check_large_patches import check
+    r = check(hw[0], hw[1], 2, arch, width=width, cnn_dtype=cnn_dtype)
+    assert r["kernel_path"] == path, r
+    _assert_ok(r)
+
+
 def test_large_patches_limits():
     from noise_flow_amd import NoiseFlow, default_hps
     from noise_flow_amd._lib import NoiseFlowLibError, NF_EINVAL
-    v8 = trained_like_variables("unc", 8)
+    v64 = trained_like_variables("unc", 64)
     with pytest.raises(NoiseFlowLibError) as ei:
-        NoiseFlow([80, 80, 4], False, default_hps(arch="unc", width=8), variables=v8)
-    assert ei.value.code == NF_EINVAL and "width 4" in str(ei.value)
-    v4 = trained_like_variables("unc", 4)
-    with pytest.raises(NoiseFlowLibError) as ei:
-        NoiseFlow([80, 80, 4], False, default_hps(arch="unc", width=4), variables=v4, cnn_dtype="fp16")
-    assert ei.value.code == NF_EINVAL
+        NoiseFlow([80, 80, 4], False, default_hps(arch="unc", width=64), variables=v64)
+    assert ei.value.code == NF_EINVAL and "up to 32" in str(ei.value)
     # batch-statistics mode keeps a patch per workgroup
+    v4 = trained_like_variables("unc", 4)
     m = NoiseFlow([80, 80, 4], True, default_hps(arch="unc", width=4), variables=v4)
     x, y = make_inputs(2, 80, 80, seed=1)
     with pytest.raises(NoiseFlowLibError) as ei:
