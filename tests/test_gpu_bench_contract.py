@@ -34,6 +34,8 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert d["sampling"]["value"] > 0 and d["training"]["value"] > 0 and d["two_streams"]["value"] > 0
     w512 = d["wide_cnn"]["w512"]     # Glow's default width (sidd/ArgParser.py:43) on the LDS-staged GEMM kernel
     assert w512["finite"] and w512["value"] > 0 and "nf_gemm_kernel" in w512["kernel_path"] and w512["roofline"]["frac"] > 0.3
+    lp = d["large_patches"]          # 256x256 images as overlapping tiles
+    assert lp["finite"] and lp["segments"] >= 1 and lp["pixels_per_s"] > 1e9, lp
 
 
 def test_bench_multi_rank_leg_under_torchrun_on_one_gpu():

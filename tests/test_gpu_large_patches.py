@@ -99,6 +99,39 @@ def test_large_patches_on_the_width_32_kernel(width, cnn_dtype, hw, arch, path):
     _assert_ok(r)
 
 
+def test_tiled_calls_from_concurrent_streams_share_one_handle(shipped_variables):
+    """Scratch of a tiled call (per-tile sums, the tensor between two segments) is a stream-ordered allocation of THAT call:
+    8 threads on their own streams, one handle, 256x256 images in two segments."""
+    import threading
+    import torch
+    from noise_flow_amd import NoiseFlow, default_hps
+    m = NoiseFlow([256, 256, 4], False, default_hps(arch=FULL_ARCH, width=4), variables=shipped_variables)
+    x, y = make_inputs(3, 256, 256, seed=8)
+    xt, yt = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    ref, _ = m._loss(xt, yt, [0], [0], [100], [2])
+    zref, _ = m.inverse(xt, None, yt, [0], [0], [100], [2])
+    ref, zref = ref.cpu().numpy(), zref.cpu().numpy()
+    torch.cuda.synchronize()
+    errs = []
+
+    def work(i):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for _ in range(6):
+                    nll, _ = m._loss(xt, yt, [0], [0], [100], [2])
+                    z, _ = m.inverse(xt, None, yt, [0], [0], [100], [2])
+                st.synchronize()
+            assert np.array_equal(nll.cpu().numpy(), ref) and np.array_equal(z.cpu().numpy(), zref)
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(8)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs[0]
+
+
 def test_large_patches_limits():
     from noise_flow_amd import NoiseFlow, default_hps
     from noise_flow_amd._lib import NoiseFlowLibError, NF_EINVAL
