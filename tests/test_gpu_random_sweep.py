@@ -1,5 +1,5 @@
 """Randomised sweep: architectures drawn from ``noise_flow_arch``'s whole vocabulary, every coupling width, ragged patch
-shapes from 1x1 to 64x64, all settings of ``hps.flow_permutation`` / ``hps.decomp``, ISO in and outside the table — each
+shapes from 1x1 to 64x64 (and, tiled, up to 160x160), all settings of ``hps.flow_permutation`` / ``hps.decomp``, ISO in and outside the table — each
 case through both directions of the HIP path (whichever kernel family the shape selects) against the fp64 oracle.
 
 The hand-picked cases of the other files pin the geometry edges; this file looks for what nobody thought of.
@@ -109,6 +109,24 @@ def test_random_model_wide_couplings_match_oracle(seed):
         H, W = max(1, H // 2), W
     m = _check_case(seed, (arch, width, (H, W), fp, decomp, iso, cam, min(B, 2)))
     assert m._flow.lib.nf_kernel_path(m._flow.ptr, 0) == _lib.NF_PATH_GEMM
+
+
+def _large_shape(seed):
+    rng = np.random.RandomState(5000 + seed)
+    kind = rng.randint(0, 4)
+    if kind == 0:
+        return int(rng.randint(65, 161)), int(rng.randint(1, 65))
+    if kind == 1:
+        return int(rng.randint(1, 65)), int(rng.randint(65, 161))
+    return int(rng.randint(65, 161)), int(rng.randint(65, 161))
+
+
+@pytest.mark.parametrize("seed", list(range(800, 824)))
+def test_random_model_large_patches(seed):
+    """The same sweep on patches BEYOND 64x64 (overlapping tiles): whole vocabulary, widths 4 .. 32, every
+    permutation / decomposition setting, one or both sides beyond 64, against the oracle on the whole image."""
+    arch, width, _, fp, decomp, iso, cam, B = _draw_case(seed)
+    _check_case(seed, (arch, width, _large_shape(seed), fp, decomp, iso, cam, min(B, 2)))
 
 
 def _check_case(seed, case_tuple):
