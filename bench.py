@@ -643,6 +643,7 @@ def _fp16_cnn(ctx, batches, cond, wide):
 def _large_patches(ctx, batches, cond, wide):
     """Patches beyond 64x64: 256x256x4 images as overlapping 64-pixel tiles, shipped model, forward NLL."""
     import ctypes
+    import numpy as np
     from noise_flow_amd import NoiseFlow, default_hps, _lib, params
     from noise_flow_amd.patches import synth_patches
     args, dev = ctx["args"], ctx["dev"]
