@@ -1983,8 +1983,17 @@ static int bs_sync(nf_handle *h, double *stats, int nvals, hipStream_t st)
 static int run_batchstats(nf_handle *h, int direction, NfLaunch a, float *moments_out, hipStream_t st)
 {
     if (h->cfg.flags & NF_CFG_FP16_CNN) return fail(NF_EINVAL, "batch-statistics mode is fp32 only");
-    if (h->fwd.tiled)
-        return fail(NF_EINVAL, "batch-statistics mode covers patches of up to 64x64 pixels (%dx%d given)", h->cfg.height, h->cfg.width);
+    // images beyond 64x64 (nf_device.h, "overlapping tiles"): the width-4 matrix-core schedule below, every launch tiled with
+    // ONE halo for the whole call — 3 = the deepest launch (re-run coupling c-1, then l_1 of coupling c for its statistics) —
+    // so that the tile grid, and with it the per-thread log-det carry, is the same in every launch
+    const bool tiled = h->fwd.tiled;
+    if (tiled && !(h->fwd.prog.width == 4 && !h->fwd.block2.empty() && use_matrix_core()))
+        return fail(NF_EINVAL, "batch-statistics mode beyond 64x64 pixels (%dx%d given) runs on the width-4 matrix-core kernels only",
+                    h->cfg.height, h->cfg.width);
+    const int bs_halo = 3;
+    const int bs_ny = tiled ? nf_tile_count(h->cfg.height, h->fwd.tile_h, bs_halo) : 1;
+    const int bs_nx = tiled ? nf_tile_count(h->cfg.width, h->fwd.tile_w, bs_halo) : 1;
+    const int bs_nt = bs_ny * bs_nx;
     std::lock_guard<std::mutex> lock(h->bs_mu);   // one scratch per handle: calls serialise
     if (!h->bs) h->bs = new (std::nothrow) nf_bs_state();
     if (!h->bs) return fail(NF_ENOMEM, "out of host memory");
@@ -2031,7 +2040,7 @@ static int run_batchstats(nf_handle *h, int direction, NfLaunch a, float *moment
     }
     // the log-det only matters to the outputs that contain it
     const bool carry = n_cpl > 1 && (a.nll_out || a.ld_out || a.sums);
-    if (carry && (e = grow(S.d_carry, S.carry_cap, (size_t)a.B * 1024)) != hipSuccess) return fail_hip(e, "hipMalloc(batch-statistics log-det carry)");
+    if (carry && (e = grow(S.d_carry, S.carry_cap, (size_t)a.B * bs_nt * 1024)) != hipSuccess) return fail_hip(e, "hipMalloc(batch-statistics log-det carry)");
     // the final launch: from the last resident tensor when there is one
     auto final_args = [&](NfLaunch &f) {
         if (n_cpl < 2) return;
@@ -2072,6 +2081,17 @@ static int run_batchstats(nf_handle *h, int direction, NfLaunch a, float *moment
             s.params = cur;
             s.n_params = (int32_t)nw2;
             s.flags |= NF_K_BATCHSTATS;
+            if (tiled) {   // every "patch" of the launch is one tile of an image (tensors stay image-shaped)
+                s.flags |= NF_K_TILED;
+                s.img_H = h->cfg.height;
+                s.img_W = h->cfg.width;
+                s.H = h->fwd.tile_h;
+                s.W = h->fwd.tile_w;
+                s.tile_ny = bs_ny;
+                s.tile_nx = bs_nx;
+                s.tile_halo = bs_halo;
+                s.B = a.B * bs_nt;
+            }
             s.fix_stats = pend_stats;
             s.fix_n = n;
             s.fix_off = pend_off;
@@ -2121,7 +2141,31 @@ static int run_batchstats(nf_handle *h, int direction, NfLaunch a, float *moment
         }
         a.ld_const = a.ld_const + (direction == 0 ? P.ident.ld_const : 0.0);
         final_args(a);
-        if ((e = launch(n_cpl > 1 ? P.progF2 : P.ident.prog2, a)) != hipSuccess) return fail_hip(e, "batch-statistics final launch");
+        if (tiled) {
+            // the final launch leaves per-tile sums; one more kernel forms the per-image results (as launch_tiled)
+            const bool want = direction == 0 && (a.nll_out || a.sd_out || a.ld_out || a.sums);
+            NfLaunch f = a;
+            f.nll_out = f.sd_out = f.ld_out = nullptr;
+            f.sums = nullptr;
+            float *part = nullptr;
+            if (want && (e = hipMallocAsync((void **)&part, (size_t)a.B * bs_nt * 4 * sizeof(float), st)) != hipSuccess)
+                return fail_hip(e, "hipMallocAsync(tile sums)");
+            f.tile_part = part;
+            e = launch(n_cpl > 1 ? P.progF2 : P.ident.prog2, f);
+            if (e == hipSuccess && want) {
+                NfTileParts tp;
+                memset(&tp, 0, sizeof(tp));
+                tp.n_seg = 1;
+                tp.nt[0] = bs_nt;
+                e = nf_launch_tile_combine(part, tp, a.B, (double)h->cfg.height * h->cfg.width * kC, a.ld_const, a.flags, a.nll_out, a.sd_out,
+                                           a.ld_out, a.sums, st);
+            }
+            if (part) {
+                hipError_t e2 = hipFreeAsync(part, st);
+                if (e == hipSuccess) e = e2;
+            }
+            if (e != hipSuccess) return fail_hip(e, "batch-statistics final launch");
+        } else if ((e = launch(n_cpl > 1 ? P.progF2 : P.ident.prog2, a)) != hipSuccess) return fail_hip(e, "batch-statistics final launch");
         std::vector<float> mom_h((size_t)std::max(n_cpl, 1) * 16);
         if (moments_out && n_cpl &&
             (e = hipMemcpyAsync(mom_h.data(), S.d_mom, (size_t)n_cpl * 16 * sizeof(float), hipMemcpyDeviceToHost, st)) != hipSuccess) {

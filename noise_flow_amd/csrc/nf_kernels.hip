@@ -599,7 +599,7 @@ __device__ __forceinline__ void nf_flow_body(const NfProgram &prog, const NfLaun
                         if constexpr (BS) {
                             if (bs_stage == 1) {
                                 const float h1k[4] = {h1[k][0], h1[k][1], h1[k][2], h1[k][3]};
-                                stats_accumulate<4>(h1k, act[k], bs1, bs2);
+                                stats_accumulate<4>(h1k, own[k], bs1, bs2);
                             }
                         }
                         v4f h2 = {b2.x, b2.y, b2.z, b2.w};
@@ -610,7 +610,7 @@ __device__ __forceinline__ void nf_flow_body(const NfProgram &prog, const NfLaun
                         if constexpr (BS) {
                             if (bs_stage == 2) {
                                 const float h2k[4] = {h2[0], h2[1], h2[2], h2[3]};
-                                stats_accumulate<4>(h2k, act[k], bs1, bs2);
+                                stats_accumulate<4>(h2k, own[k], bs1, bs2);
                             }
                         }
                         if (act[k])
@@ -672,9 +672,9 @@ __device__ __forceinline__ void nf_flow_body(const NfProgram &prog, const NfLaun
 #pragma unroll
                     for (int k = 0; k < PX; ++k) {
                         if constexpr (PX > 1) {
-                            if (stats_stage == 1) stats_accumulate<WIDTH>(h1[k], act[k], st1, st2);
+                            if (stats_stage == 1) stats_accumulate<WIDTH>(h1[k], own[k], st1, st2);
                         } else {
-                            if (stats_stage == 1) stats_direct<WIDTH>(h1[k], act[k], stats, t);
+                            if (stats_stage == 1) stats_direct<WIDTH>(h1[k], own[k], stats, t);
                         }
                         float h2[WIDTH];
 #pragma unroll
@@ -686,9 +686,9 @@ __device__ __forceinline__ void nf_flow_body(const NfProgram &prog, const NfLaun
                             for (int j = 0; j < WIDTH; ++j) h2[j] = fmaf(hi, W2[i * WIDTH + j], h2[j]);
                         }
                         if constexpr (PX > 1) {
-                            if (stats_stage == 2) stats_accumulate<WIDTH>(h2, act[k], st1, st2);
+                            if (stats_stage == 2) stats_accumulate<WIDTH>(h2, own[k], st1, st2);
                         } else {
-                            if (stats_stage == 2) stats_direct<WIDTH>(h2, act[k], stats, t);
+                            if (stats_stage == 2) stats_direct<WIDTH>(h2, own[k], stats, t);
                         }
                         if (act[k]) {
                             float4 *dst = reinterpret_cast<float4 *>(th + (size_t)lidx[k] * WIDTH);
@@ -951,7 +951,7 @@ __device__ __forceinline__ void nf_flow_body(const NfProgram &prog, const NfLaun
                     float4 *out4 = reinterpret_cast<float4 *>(a.out + patch_off);
 #pragma unroll
                     for (int k = 0; k < PX; ++k)
-                        if (act[k]) out4[gidx[k]] = make_float4(z[k][0], z[k][1], z[k][2], z[k][3]);
+                        if (own[k]) out4[gidx[k]] = make_float4(z[k][0], z[k][1], z[k][2], z[k][3]);
                 }
                 if constexpr (!MFMA || BS) {
                     if (a.flags & NF_K_CARRY_OUT) {   // the log-det of what ran so far goes with the stored tensor
@@ -1304,7 +1304,7 @@ hipError_t launch_flow_v(const NfProgram &prog, const NfLaunch &a, int n_cu, hip
             // tiled launches: full 64x64 tiles have their own instantiation of the blocked geometry, everything else is masked
             if constexpr (MFMA && WIDTH == 4 && THREADS == 1024 && PX == 4) {
                 static const bool masked = env_int("NF_TILE_MASKED") != 0;   // A/B aid
-                if (!masked) return launch_flow_p<WIDTH, THREADS, PX, PHILOX, MFMA, true, 0, false, true>(prog, a, n_cu, stream);
+                if (!masked && !(a.flags & NF_K_BATCHSTATS)) return launch_flow_p<WIDTH, THREADS, PX, PHILOX, MFMA, true, 0, false, true>(prog, a, n_cu, stream);
             }
         }
     }

@@ -139,10 +139,44 @@ def test_large_patches_limits():
     with pytest.raises(NoiseFlowLibError) as ei:
         NoiseFlow([80, 80, 4], False, default_hps(arch="unc", width=64), variables=v64)
     assert ei.value.code == NF_EINVAL and "up to 32" in str(ei.value)
-    # batch-statistics mode keeps a patch per workgroup
-    v4 = trained_like_variables("unc", 4)
-    m = NoiseFlow([80, 80, 4], True, default_hps(arch="unc", width=4), variables=v4)
+    # batch-statistics mode beyond 64x64: the width-4 matrix-core schedule only
+    v8 = trained_like_variables("unc", 8)
+    m = NoiseFlow([80, 80, 4], True, default_hps(arch="unc", width=8), variables=v8)
     x, y = make_inputs(2, 80, 80, seed=1)
     with pytest.raises(NoiseFlowLibError) as ei:
         m._loss(x, y, [0.0], [0.0], [100], [2])
     assert ei.value.code == NF_EINVAL and "64x64" in str(ei.value)
+
+
+@pytest.mark.parametrize("hw,B,arch", [((96, 80), 3, None), ((65, 130), 2, "sdn5|unc|gain4|unc|unc"), ((128, 40), 4, "unc|unc|unc")])
+def test_batch_statistics_mode_on_large_patches(shipped_variables, hw, B, arch):
+    """`is_training=True` graphs (layers.py:386-398; what the upstream wrapper feeds, quirk Q2) beyond 64x64: every launch of the
+    batch-statistics schedule tiled with one halo, the moments taken over the core windows (= every pixel once) — NLL, sd_z,
+    latent, the EMA'd running statistics and sampling against the oracle in training mode on the whole images."""
+    from noise_flow_amd import NoiseFlow, default_hps
+    from oracle.nf_oracle import NoiseFlowOracle
+    H, W = hw
+    arch = arch or FULL_ARCH
+    v = shipped_variables if arch == FULL_ARCH else trained_like_variables(arch, 4, seed=H + W)
+    x, y = make_inputs(B, H, W, seed=31, b1=0.003696)
+    o = NoiseFlowOracle(arch, v, "loss_first")
+    ref_nll, ref_sd, ref_z = o.nll(x, y, 800, 2, training=True)
+    m = NoiseFlow([H, W, 4], True, default_hps(arch=arch, width=4), variables=v)
+    nll, sd = m._loss(x, y, [0.0], [0.0], [800], [2])
+    np.testing.assert_allclose(nll, ref_nll, rtol=1e-5)
+    assert abs(sd - ref_sd) <= 1e-5 * ref_sd
+    names = [L["name"] for L in o.layers if L["type"] == "coupling"]
+    for scope, lname in zip(m._flow.coupling_scopes, names):
+        rec = o.last_batch_moments[lname]
+        for bn, key in (("bn_nvp_conv_1/mean", "new_mean1"), ("bn_nvp_conv_1/var", "new_var1"),
+                        ("bn_nvp_conv_2/mean", "new_mean2"), ("bn_nvp_conv_2/var", "new_var2")):
+            want = rec[key]
+            assert np.abs(m.variables[scope + "/" + bn] - want).max() <= 1e-5 * max(np.abs(want).max(), 1e-3), (scope, bn)
+    m2 = NoiseFlow([H, W, 4], True, default_hps(arch=arch, width=4), variables=v)
+    z, _ = m2.inverse(x, None, y, [0.0], [0.0], [800], [2])
+    assert np.abs(z - ref_z).max() <= 1e-5 * np.abs(ref_z).max()
+    eps = np.random.RandomState(3).randn(B, H, W, 4).astype(np.float32)
+    m3 = NoiseFlow([H, W, 4], True, default_hps(arch=arch, width=4), variables=v)
+    xs = m3.sample(y, 0.7, y, [0.0], [0.0], [800], [2], eps=eps)
+    ref_x = o.sample(eps, 0.7, y, 800, 2, training=True)
+    assert np.abs(xs - ref_x).max() <= 2e-5 * np.abs(ref_x).max()
