@@ -266,10 +266,40 @@ __device__ __forceinline__ void nf_flow_body(const NfProgram &prog, const NfLaun
 
     // zero both tiles once (the 1-pixel border is never written again) and stage the weight image, 16 bytes per lane
     {
+#ifndef NF_ZERO_BORDER
+#define NF_ZERO_BORDER 0
+#endif
+        if constexpr (NF_ZERO_BORDER && BLK && !H16) {
+            // blocked fp32 tiles: every interior entry has an owner that writes it (z0 / h2 of each coupling) before anyone
+            // reads it, so only the 2 (W + 2) + 2 H border entries need the zero — 3 KiB instead of 27 KiB of LDS stores per
+            // 32x32 workgroup.  Measured and left OFF: back-to-back launches over a few rotating batches gain 0.7 % (49.46 ->
+            // 49.10 us, tools/ab_headline.py), but bench.py's regime — every launch reads a batch nothing has touched
+            // before — loses 2 - 5 % (49.8 -> 50.8 us, tools/ab_bench.sh, two boxes): the shorter set-up lets three quarters
+            // of the grid ask for their first, cold inputs almost at once, which is what NF_STAGGER exists to prevent
+            const int nb = 2 * (W + 2) + 2 * H;
+            for (int i = t; i < nb; i += THREADS) {
+                int rp, cp;
+                if (i < W + 2) {
+                    rp = 0;
+                    cp = i;
+                } else if (i < 2 * (W + 2)) {
+                    rp = H + 1;
+                    cp = i - (W + 2);
+                } else {
+                    const int j = i - 2 * (W + 2);
+                    rp = 1 + (j >> 1);
+                    cp = (j & 1) ? W + 1 : 0;
+                }
+                const int e = (rp * 2 + (cp & 1)) * PW + (cp >> 1);
+                t0[e] = make_float2(0.f, 0.f);
+                *reinterpret_cast<float4 *>(th + (size_t)e * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {
         const int nz4 = (tile_px * TILE_WORDS) >> 2;
         float4 *const s4 = reinterpret_cast<float4 *>(smem);
         for (int i = t; i < nz4; i += THREADS) s4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int i = (nz4 << 2) + t; i < tile_px * TILE_WORDS; i += THREADS) smem[i] = 0.0f;
+        }
         if (MFMA) {
             const int np4 = a.n_params >> 2;   // every section of the matrix-core layouts is a multiple of 4 floats
             const float4 *const p4 = reinterpret_cast<const float4 *>(a.params);

@@ -28,15 +28,20 @@ from noise_flow_amd import NoiseFlow, default_hps, params
 from noise_flow_amd.patches import synth_patches
 hps = default_hps()
 m = NoiseFlow([32, 32, 4], False, hps, variables=params.init_variables(hps.arch, 4, 4, 1234))
-x, y = synth_patches(0, 0, 1024, 32, 32)
+R = int(os.environ.get("NF_AB_ROTATE", "12"))   # rotating input batches: 12 x 34 MB does not fit the 256 MB Infinity Cache (as bench.py)
+xy = [synth_patches(0, 1024 * r, 1024, 32, 32) for r in range(R)]
 lib = _lib.load()
 cond = _lib.nf_cond(100, 2, 0, 0)
 acc = torch.zeros(_lib.NF_SUMS_SLOTS * _lib.NF_SUMS_STRIDE, dtype=torch.float64, device="cuda")
+nll = torch.empty(1024, dtype=torch.float32, device="cuda")
 st = torch.cuda.current_stream()
+it = [0]
 
 
 def step():
-    rc = lib.nf_nll(m._flow.ptr, x.data_ptr(), y.data_ptr(), 1024, ctypes.byref(cond), None, None, None, None, acc.data_ptr(),
+    x, y = xy[it[0] % R]
+    it[0] += 1
+    rc = lib.nf_nll(m._flow.ptr, x.data_ptr(), y.data_ptr(), 1024, ctypes.byref(cond), nll.data_ptr(), None, None, None, acc.data_ptr(),
                     _lib.NF_ACCUMULATE | _lib.NF_SUMS_WIDE, int(st.cuda_stream))
     assert rc == 0
 
@@ -53,4 +58,8 @@ for rep in range(5):
     e1.record(st)
     torch.cuda.synchronize()
     best.append(e0.elapsed_time(e1) / n * 1e3)
-print("%s: %s us per launch (median %.2f)" % (os.path.basename(path), " ".join("%.2f" % b for b in best), sorted(best)[2]))
+it[0] = 0
+step()
+torch.cuda.synchronize()
+print("%s: %s us per launch (median %.2f)  nll checksum %.9e" % (os.path.basename(path), " ".join("%.2f" % b for b in best), sorted(best)[2],
+                                                               float(nll.double().sum())))
