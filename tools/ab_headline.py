@@ -27,7 +27,13 @@ import torch
 from noise_flow_amd import NoiseFlow, default_hps, params
 from noise_flow_amd.patches import synth_patches
 hps = default_hps()
-m = NoiseFlow([32, 32, 4], False, hps, variables=params.init_variables(hps.arch, 4, 4, 1234))
+if os.environ.get("NF_AB_WEIGHTS", "shipped") == "shipped":   # the bench's model; "init": fresh initialisation (l_last = 0)
+    from noise_flow_amd.ckpt import load_checkpoint
+    var = load_checkpoint(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "models", "NoiseFlow", "ckpt", "model.ckpt.best"))
+else:
+    var = params.init_variables(hps.arch, 4, 4, 1234)
+m = NoiseFlow([32, 32, 4], False, hps, variables=var)
+BLOCK = int(os.environ.get("NF_AB_BLOCK", "0"))   # > 0: synchronise after every BLOCK launches (bench.py times blocks of 20)
 R = int(os.environ.get("NF_AB_ROTATE", "12"))   # rotating input batches: 12 x 34 MB does not fit the 256 MB Infinity Cache (as bench.py)
 xy = [synth_patches(0, 1024 * r, 1024, 32, 32) for r in range(R)]
 lib = _lib.load()
@@ -53,6 +59,18 @@ best = []
 for rep in range(5):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(st)
+    if BLOCK:
+        tot = 0.0
+        for _ in range(n // BLOCK):
+            b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            b0.record(st)
+            for _ in range(BLOCK):
+                step()
+            b1.record(st)
+            torch.cuda.synchronize()
+            tot += b0.elapsed_time(b1)
+        best.append(tot / (n // BLOCK * BLOCK) * 1e3)
+        continue
     for _ in range(n):
         step()
     e1.record(st)
