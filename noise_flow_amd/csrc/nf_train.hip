@@ -80,6 +80,18 @@ __device__ __forceinline__ float wsum(float v)
     return (r0 + r1) + (r2 + r3);
 }
 
+// the first half of wsum: every lane of a 16-lane DPP row ends up with its row's sum (4 issues).  Reductions of MANY values stop
+// here and let one lane per row park the row sums in LDS — the 7 readlane / add issues per value that join the four rows of a
+// wavefront are then paid once, by the few threads that add the partials up, not by every wavefront for every value
+__device__ __forceinline__ float row_sum16(float v)
+{
+    v += __int_as_float(NF_DPP_I(__float_as_int(v), NF_DPP_QX1));
+    v += __int_as_float(NF_DPP_I(__float_as_int(v), NF_DPP_QX2));
+    v += __int_as_float(NF_DPP_I(__float_as_int(v), NF_DPP_HMIR));
+    v += __int_as_float(NF_DPP_I(__float_as_int(v), NF_DPP_MIR));
+    return v;
+}
+
 template <int CTRL>
 __device__ __forceinline__ double dpp_get(double v)
 {
@@ -133,19 +145,20 @@ __device__ __forceinline__ void acc_add(Acc dst, float v, int nslot)
 template <int N>
 __device__ __forceinline__ void acc_add_n(Acc dst, const float (&v)[N], int nslot)
 {
-    __shared__ float part[TB / 64][N];
-    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    __shared__ float part[TB / 16][N];     // one partial per 16-lane row (row_sum16)
+    const int row = threadIdx.x >> 4;
     __syncthreads();                       // the previous use of `part` is over
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-        const float s = wsum(v[k]);
-        if (ln == 0) part[wv][k] = s;
+        const float s = row_sum16(v[k]);
+        if ((threadIdx.x & 15) == 0) part[row][k] = s;
     }
     __syncthreads();
     for (int k = threadIdx.x; k < N; k += TB) {
         float tot = 0.0f;
 #pragma unroll
-        for (int i = 0; i < TB / 64; ++i) tot += part[i][k];
+        for (int i = 0; i < TB / 64; ++i)   // wavefront by wavefront, its four rows joined as wsum joins them
+            tot += (part[4 * i][k] + part[4 * i + 1][k]) + (part[4 * i + 2][k] + part[4 * i + 3][k]);
         float *d = dst.p + (size_t)k * NSLOT;
         d[blockIdx.x] = tot;
         for (int q = blockIdx.x + gridDim.x; q < nslot; q += gridDim.x) d[q] = 0.0f;
@@ -1745,7 +1758,7 @@ void coupling_forward_tiled(nf_trainer *t, const Geo &g, const TLayer &L, const 
     const int w = W, off_w1 = L.off, off_m1 = L.off + 19 * w, off_w2 = L.off + 21 * w, off_m2 = L.off + 22 * w + w * w,
               off_w3 = L.off + 24 * w + w * w;
     const double n = (double)g.npix * t->sync_world;
-    const size_t smem = ((size_t)(g.H + 2) * (g.W + 2) * (W + 2) + 1 + 2 * W + (NT / 64) * 2 * W) * sizeof(float);
+    const size_t smem = ((size_t)(g.H + 2) * (g.W + 2) * (W + 2) + 1 + 2 * W + (NT / 16) * 2 * W) * sizeof(float);
     if (!f1_done) {
         const TiledF1 f1{A, const_cast<float *>(zin), off_w1, c.h1, t->acc(c.d_st1)};
         if (zpre)
@@ -1789,7 +1802,7 @@ void coupling_backward_tiled(nf_trainer *t, const Geo &g, const TLayer &L, const
     const int set = L.aux % 3;
     float *t1 = t->t1[set], *t2 = t->t2[set], *gu = t->gu[set];
     hipStream_t sd = t->serial ? st : t->side;
-    const size_t smem = ((size_t)(g.H + 2) * (g.W + 2) * (W + 4) + (W + 16) + (9 + 2 * W) + (NT / 64) * (2 * W > 16 ? 2 * W : 16)) *
+    const size_t smem = ((size_t)(g.H + 2) * (g.W + 2) * (W + 4) + (W + 16) + (9 + 2 * W) + (NT / 16) * (2 * W > 16 ? 2 * W : 16)) *
                         sizeof(float);
     auto wait_set = [&](int k) {
         if (t->done_pending[k]) {

@@ -12,20 +12,23 @@
 // stages leave in HBM (gu, t1, t2) — fusing THEM in was measured to cost more than it saves (their ~290 value sums per
 // coupling multiply with the wavefront count).  One thread per pixel, NT = 256 / 512 / 1024 threads by patch size.
 template <int N, int NT>
-__device__ __forceinline__ void stage_add_n(float *dst, const float (&v)[N], float *part /* [NT/64][N] */)
+__device__ __forceinline__ void stage_add_n(float *dst, const float (&v)[N], float *part /* [NT/16][N]: one partial per 16-lane row */)
 {
-    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    const int row = threadIdx.x >> 4;
     __syncthreads();                       // the previous use of `part` is over
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-        const float sv = wsum(v[k]);
-        if (ln == 0) part[wv * N + k] = sv;
+        const float sv = row_sum16(v[k]);  // 4 issues per value instead of wsum's 11: the rows are joined below, once
+        if ((threadIdx.x & 15) == 0) part[row * N + k] = sv;
     }
     __syncthreads();
     for (int k = threadIdx.x; k < N; k += NT) {
         float tot = 0.0f;
 #pragma unroll
-        for (int i = 0; i < NT / 64; ++i) tot += part[i * N + k];
+        for (int i = 0; i < NT / 64; ++i) {   // wavefront by wavefront, its four rows joined as wsum joins them (same bits)
+            const float *q = part + (4 * i) * N + k;
+            tot += (q[0] + q[N]) + (q[2 * N] + q[3 * N]);
+        }
         dst[k] = tot;
     }
 }

@@ -2,6 +2,9 @@
 import json, os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from noise_flow_amd import _lib as _nf_lib
+if os.environ.get("NF_TOOL_LIB"):   # A/B a differently-built library (this tool only)
+    _nf_lib.LIB_PATH = os.path.abspath(os.environ["NF_TOOL_LIB"])
 from noise_flow_amd import default_hps, patches
 from noise_flow_amd.train import Trainer
 
@@ -12,7 +15,7 @@ for B in [int(b) for b in (sys.argv[2] if len(sys.argv) > 2 else "138").split(",
     for _ in range(3):
         tr.step(x, y, [0], [0], [800], [2], lr=1e-4, sync=False)
     torch.cuda.synchronize()
-    steps = 30
+    steps = int(os.environ.get("NF_TOOL_STEPS", "30"))
     t = time.perf_counter()
     for _ in range(steps):
         tr.step(x, y, [0], [0], [800], [2], lr=1e-4, sync=False)
