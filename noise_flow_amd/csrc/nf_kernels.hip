@@ -272,10 +272,10 @@ __device__ __forceinline__ void nf_flow_body(const NfProgram &prog, const NfLaun
         if constexpr (NF_ZERO_BORDER && BLK && !H16) {
             // blocked fp32 tiles: every interior entry has an owner that writes it (z0 / h2 of each coupling) before anyone
             // reads it, so only the 2 (W + 2) + 2 H border entries need the zero — 3 KiB instead of 27 KiB of LDS stores per
-            // 32x32 workgroup.  Measured and left OFF: back-to-back launches over a few rotating batches gain 0.7 % (49.46 ->
-            // 49.10 us, tools/ab_headline.py), but bench.py's regime — every launch reads a batch nothing has touched
-            // before — loses 2 - 5 % (49.8 -> 50.8 us, tools/ab_bench.sh, two boxes): the shorter set-up lets three quarters
-            // of the grid ask for their first, cold inputs almost at once, which is what NF_STAGGER exists to prevent
+            // 32x32 workgroup.  Measured and left OFF: + 0.7 % with a freshly initialised model (49.46 ->
+            // 49.10 us per launch), - 2 .. 5 % with the shipped checkpoint, i.e. through bench.py (50.0 -> 52.5 us;
+            // tools/ab_headline.py, tools/ab_bench.sh): the shorter set-up lets three quarters of the grid ask for their
+            // first inputs almost at once, which is what NF_STAGGER exists to prevent
             const int nb = 2 * (W + 2) + 2 * H;
             for (int i = t; i < nb; i += THREADS) {
                 int rp, cp;

@@ -9,6 +9,21 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $R/bench.py --steps 20 --warmup 5"
+if [ "${2:-all}" = "traffic" ]; then
+  # bash tools/profile_round.sh <tag> traffic: only the HBM-traffic passes of the headline kernel + the bench line that quotes
+  # them (after a change to the kernel sources that cannot have changed the other evidence, e.g. a comment)
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- $BENCH --no-cpu-baseline --no-extras --ramp-ms 0 > $OUT/pmc_fetch.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- $BENCH --no-cpu-baseline --no-extras --ramp-ms 0 > $OUT/pmc_write.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- $BENCH --no-cpu-baseline --no-extras > $OUT/kt.log 2>&1
+  cd $R
+  F=$(find $OUT/pmc_fetch -name "*counter_collection.csv" | head -1); W=$(find $OUT/pmc_write -name "*counter_collection.csv" | head -1)
+  python tools/make_traffic.py $F $W > $OUT/traffic.log 2>&1 && cp profiles/traffic.json $OUT/traffic.json
+  cp $F $OUT/pmc_fetch_counter_collection.csv; cp $W $OUT/pmc_write_counter_collection.csv
+  K=$(find $OUT/kt -name "*kernel_stats.csv" | head -1); cp $K $OUT/kernel_stats.csv 2>/dev/null
+  $BENCH > $OUT/bench.json 2> $OUT/bench.err
+  tail -5 $OUT/traffic.log; head -3 $OUT/kernel_stats.csv; head -c 400 $OUT/bench.json; echo
+  exit 0
+fi
 # 1. the driver's command, plain (the JSON line) and under the kernel trace
 $BENCH > $OUT/bench.json 2> $OUT/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- $BENCH --no-cpu-baseline --no-extras > $OUT/kt.log 2>&1
