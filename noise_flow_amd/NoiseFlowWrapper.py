@@ -29,7 +29,7 @@ from .noise_flow_model import NoiseFlow
 
 class NoiseFlowWrapper:
     def __init__(self, path, sampling_temperature=0.6, binding="loss_first", device=None, seed=None,
-                 bn_mode="running", compat=None):
+                 bn_mode="running", compat=None, patch_shape=None):
         if compat not in (None, "reference"):
             raise ValueError("compat must be None or 'reference'")
         if compat == "reference":
@@ -45,6 +45,9 @@ class NoiseFlowWrapper:
         self.nf_model = None
         self.is_cond = True
         self.temp = sampling_temperature
+        # the reference fixes 32x32 (NoiseFlowWrapper.py:47); any (H, W) up to 4096 per side here — beyond 64x64 the patches are
+        # evaluated as overlapping tiles, same numbers as a kernel that held them whole
+        self.patch_shape = (32, 32) if patch_shape is None else (int(patch_shape[0]), int(patch_shape[1]))
         self.binding = binding
         self.device = device
         self.hps = self.hps_loader(os.path.join(self.nf_path, "hps.txt"))
@@ -55,7 +58,7 @@ class NoiseFlowWrapper:
         self.load_noise_flow_model()
 
     def load_noise_flow_model(self):
-        self.x_shape = [None, 32, 32, 4]                       # NoiseFlowWrapper.py:47 (quirk Q8)
+        self.x_shape = [None, self.patch_shape[0], self.patch_shape[1], 4]   # NoiseFlowWrapper.py:47 fixes 32x32 (quirk Q8)
         if not hasattr(self.hps, "x_shape") or isinstance(self.hps.x_shape, str):
             setattr(self.hps, "x_shape", self.x_shape)
         self.logger.info("Building Noise Flow")

@@ -132,6 +132,25 @@ def test_tiled_calls_from_concurrent_streams_share_one_handle(shipped_variables)
     assert not errs, errs[0]
 
 
+@pytest.mark.parametrize("compat", [None, "reference"])
+def test_wrapper_samples_large_patches(compat):
+    """`NoiseFlowWrapper(..., patch_shape=(H, W))`: the shipped model on 96x80 clean patches, in the trained model's semantics
+    and in the upstream wrapper's literal mode (sampling-order binding, is_training=True: batch statistics on tiles)."""
+    from noise_flow_amd import NoiseFlowWrapper
+    from noise_flow_amd.ckpt import load_checkpoint
+    from oracle import philox
+    from oracle.nf_oracle import NoiseFlowOracle
+    from conftest import SHIPPED_CKPT, SHIPPED_DIR
+    nf = NoiseFlowWrapper(SHIPPED_DIR, sampling_temperature=0.6, seed=11, compat=compat, patch_shape=(96, 80))
+    _, y = make_inputs(3, 96, 80, seed=12)
+    xs = nf.sample_noise_nf(y, 0.0, 0.0, 800, 2)
+    assert xs.shape == (3, 96, 80, 4) and xs.dtype == np.float32
+    o = NoiseFlowOracle(FULL_ARCH, load_checkpoint(SHIPPED_CKPT), "sample_first" if compat else "loss_first")
+    eps = philox.sample_eps(11, 0, 3, 96, 80)
+    ref = o.sample(eps, 0.6, y, 800, 2, training=bool(compat))
+    assert np.abs(xs - ref).max() <= 5e-5 * np.abs(ref).max()
+
+
 def test_large_patches_limits():
     from noise_flow_amd import NoiseFlow, default_hps
     from noise_flow_amd._lib import NoiseFlowLibError, NF_EINVAL
