@@ -1590,8 +1590,8 @@ static int sample_args(nf_handle *h, const float *y, const float *eps, uint64_t 
 }
 
 // Images beyond 64x64 (nf_device.h, "overlapping tiles"): per segment of the program one launch of the fused width-4 kernel
-// over B x tiles tile-sized "patches" that reads and writes image-shaped tensors in place (the caller's, and between two
-// segments a scratch tensor), then — in the NLL direction — a one-lane-per-image kernel that adds the tiles' sums up.  Scratch
+// (or, at widths 8 / 16 / 32 and in fp16-CNN mode, of the width-32 matrix-core kernel) over B x tiles tile-sized "patches" that reads and writes image-shaped tensors in place (the caller's, and between two
+// segments a scratch tensor), then — in the NLL direction — a one-wavefront-per-image kernel that adds the tiles' sums up.  Scratch
 // is stream-ordered (hipMallocAsync), so concurrent calls on one handle (different streams) never share it.
 static int launch_tiled(nf_handle *h, int direction, NfLaunch &a, hipStream_t st, const char *what)
 {
