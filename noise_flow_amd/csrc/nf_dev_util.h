@@ -13,6 +13,7 @@ namespace {
 typedef const float __attribute__((address_space(4))) *cfloat_p;
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef _Float16 v4h __attribute__((ext_vector_type(4)));
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 typedef _Float16 v2h __attribute__((ext_vector_type(2)));
 
 // --------------------------------------------------------------------------

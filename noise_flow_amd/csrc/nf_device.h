@@ -102,6 +102,39 @@ __host__ __device__ constexpr int nf_cpl_size(int w)   { return 64 + 36 * w + 18
 #define NF3_W3H_STRIDE 20      // words per lane-of-four: 9 taps x 2 words, padded so that every lane's run is 16-byte aligned
 #define NF3_CPL_SIZE 260
 
+// ---- fp16-CNN layout on the 1-issue matrix instruction (width 4, full 32x32 / 64x64 patches) ---------------------------
+// v_mfma_f32_4x4x4_16b_f16 is a 2-pass instruction that owns the SIMD's issue port, so the 64 of them a lane needs per
+// coupling and 4 pixels add to its VALU work instead of hiding under it.  v_mfma_f32_16x16x32_f16 issues once for 4 passes
+// (16 cycles) and fits the width-4 CNN when the 2x2 OUTPUT BLOCK of a lane column sits on M and its 4x4 INPUT WINDOW on K:
+//   unit   = 2 image rows x 32 columns = 64 pixels, one per lane: lane l = 16 g + n owns pixel (row 2u + (g >> 1), column
+//            32 q + 2 n + (g & 1)); g = 2 a + p is the M slot of the output pixel (a, p) of the 2x2 block of lane column n
+//   D      : lane (g, n), register v = output channel v of that pixel            (M row 4 g + v, N column n)
+//   l_1    : K = 32 = 4 window rows x 4 window columns x 2 channels: ONE instruction per unit.  K slot gk = lane >> 4 of
+//            the B operand reads window row nf11_l1_row(gk), columns 2n .. 2n+3 of the half2 tile (two 8-byte reads);
+//            element e = 2 wc + c
+//   l_last : K = 64 = 4 x 4 x 4 channels: TWO chained instructions m3 = 0, 1.  K slot gk reads window row
+//            nf11_l3_row(gk, m3), column pair gk >> 1 (columns 2n + 2 (gk >> 1) + {0, 1}) of the 4 x half tile — one aligned
+//            16-byte read; element e = 4 px + c
+//   A      : lane (gk = l >> 4, m = l & 15) holds the 8 halves A[m][8 gk .. 8 gk + 7], m = 4 (2a + p) + j:
+//            W[di = window row - a][dj = window column - p][c][j], zero where a tap index falls outside 0 .. 2
+//   (56 % of the multiplies are useful; the window-row order of the K slots is chosen so that the lane groups that share an
+//    LDS access cycle sit 128 B (8-byte reads) / 0 B (16-byte reads) apart modulo 256 B at the tile pitches below)
+// Offsets in 32-bit words:
+//   COUPLING  E [16][4] fp32 @0, B1 [4] @64, B2 [4] @68, S [4] @72 (as NF3_*), W2h [4][2w] @76 (as NF3_CPL_W2H),
+//             A1 [64][4w] @84, A3 [2][64][4w] @340
+#define NF11_CPL_E 0
+#define NF11_CPL_B1 64
+#define NF11_CPL_B2 68
+#define NF11_CPL_S 72
+#define NF11_CPL_W2H 76
+#define NF11_CPL_A1 84
+#define NF11_CPL_A3 340
+#define NF11_CPL_SIZE 852
+#define NF11_MAX_FLOATS 12288   // 48 KiB of LDS for the whole model's weights in this layout
+__host__ __device__ constexpr int nf11_l1_row(int gk) { return 2 * (gk & 1) + (gk >> 1); }
+__host__ __device__ constexpr int nf11_l3_row(int gk, int m3) { return 2 * (gk & 1) + m3; }
+__host__ __device__ constexpr int nf11_pitch(int side) { return side == 64 ? 80 : 48; }   // tile row pitch in pixels
+
 // ---- wide-CNN layout (coupling width 32, nf_wide.hip) ------------------------------------------
 // The three convs of a width-32 coupling CNN run on v_mfma_f32_32x32x2_f32 with the PIXELS on the N
 // axis (a tile = 32 consecutive pixels of one image row, lanes n = lane & 31; the two lane halves
@@ -220,6 +253,7 @@ enum : uint32_t {
     // images larger than one workgroup's tile (H or W > 64): every "patch" of the launch is one H x W TILE of an
     // img_H x img_W image, see NfLaunch::tile_* below
     NF_K_TILED     = 256u,
+    NF_K_FP16_BIG  = 512u, // with NF_K_FP16_CNN: the parameter block is the NF11_* layout (v_mfma_f32_16x16x32_f16)
 };
 
 // ---- images beyond 64 x 64: overlapping tiles -------------------------------------------------------

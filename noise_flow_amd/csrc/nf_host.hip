@@ -346,6 +346,40 @@ void relayout_coupling_v3(const float *v1, float *out)
     }
 }
 
+// fp16-CNN re-layout for v_mfma_f32_16x16x32_f16 (nf_device.h, NF11_*): the A operands in the order the lanes fetch them.
+void relayout_coupling_v11(const float *v1, float *out)
+{
+    const int w = 4;
+    const double log2e = 1.4426950408889634;
+    memcpy(out + NF11_CPL_E, v1 + nf_cpl_off_E(w), 64 * sizeof(float));
+    memcpy(out + NF11_CPL_B1, v1 + nf_cpl_off_B1(w), 4 * sizeof(float));
+    memcpy(out + NF11_CPL_B2, v1 + nf_cpl_off_B2(w), 4 * sizeof(float));
+    const double sc = v1[nf_cpl_off_S(w)];
+    out[NF11_CPL_S + 0] = (float)sc;
+    out[NF11_CPL_S + 1] = (float)(sc * log2e);
+    out[NF11_CPL_S + 2] = (float)(-2.0 * sc * log2e);
+    out[NF11_CPL_S + 3] = 0.0f;
+    uint16_t *h2 = reinterpret_cast<uint16_t *>(out + NF11_CPL_W2H);
+    uint16_t *a1 = reinterpret_cast<uint16_t *>(out + NF11_CPL_A1);
+    uint16_t *a3 = reinterpret_cast<uint16_t *>(out + NF11_CPL_A3);
+    for (int j = 0; j < 4; ++j)
+        for (int i = 0; i < 4; ++i) h2[j * 4 + i] = to_half(v1[nf_cpl_off_W2(w) + i * 4 + j]);
+    auto tap_ok = [](int d) { return d >= 0 && d <= 2; };
+    for (int l = 0; l < 64; ++l) {
+        const int gk = l >> 4, m = l & 15, a = m >> 3, p = (m >> 2) & 1, j = m & 3;
+        for (int e = 0; e < 8; ++e) {
+            {   // l_1: element e = 2 wc + c of window row nf11_l1_row(gk)
+                const int wc = e >> 1, c = e & 1, di = nf11_l1_row(gk) - a, dj = wc - p;
+                a1[l * 8 + e] = tap_ok(di) && tap_ok(dj) ? to_half(v1[nf_cpl_off_W1(w) + ((di * 3 + dj) * 2 + c) * 4 + j]) : (uint16_t)0;
+            }
+            for (int m3 = 0; m3 < 2; ++m3) {   // l_last: element e = 4 px + c of window row nf11_l3_row(gk, m3), column pair gk >> 1
+                const int wc = 2 * (gk >> 1) + (e >> 2), c = e & 3, di = nf11_l3_row(gk, m3) - a, dj = wc - p;
+                a3[(m3 * 64 + l) * 8 + e] = tap_ok(di) && tap_ok(dj) ? to_half(v1[nf_cpl_off_W3(w) + ((di * 3 + dj) * 4 + c) * 4 + j]) : (uint16_t)0;
+            }
+        }
+    }
+}
+
 // Wide-CNN re-layout (nf_device.h, NF4_*; coupling width 32): every weight in the order the lanes of
 // v_mfma_f32_32x32x2_f32 / v_mfma_f32_4x4x1 fetch their A operands (nf_wide.hip).
 // `w` = the coupling's own width (8, 16 or 32): narrower CNNs are zero-padded to 32 hidden channels (exact: a padded
@@ -780,6 +814,7 @@ struct Built {
     std::vector<float> block2;   // empty when unavailable
     NfProgram prog3;             // fp16-CNN layout (NF_CFG_FP16_CNN), width 4 only
     std::vector<float> block3;
+    bool fp16_big = false;       // block3 is the NF11_* layout (v_mfma_f32_16x16x32_f16) instead of NF3_* (4x4x4)
     NfProgram prog4;             // wide-CNN layout (NF4_*), width 32 (8 / 16 zero-padded on large patches)
     std::vector<float> block4;
     NfProgram prog5;             // wide-CNN fp16 layout (NF5_*): NF_CFG_FP16_CNN at widths 8 / 16 / 32
@@ -1197,6 +1232,9 @@ int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float
     memset(&out.prog3, 0, sizeof(out.prog3));
     if (out.prog.width == 4 && (cfg->flags & NF_CFG_FP16_CNN)) {
         out.prog3.width = 4;
+        // NF_H16=4x4 (read at nf_create) keeps the v_mfma_f32_4x4x4_16b_f16 formulation — an A/B aid, like NF_KERNEL=valu
+        const char *h16 = getenv("NF_H16");
+        out.fp16_big = !(h16 && strcmp(h16, "4x4") == 0);
         for (int i = 0; i < out.prog.n_ops; ++i) {
             const NfOp &src = out.prog.ops[i];
             NfOp &dst = out.prog3.ops[out.prog3.n_ops++];
@@ -1207,8 +1245,9 @@ int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float
                 for (int j = 0; j < 4; ++j)
                     for (int c = 0; c < 4; ++c) out.block3.push_back(v1[c * 4 + j]);
             } else if (src.type == NF_OP_COUPLING_FWD || src.type == NF_OP_COUPLING_REV) {
-                out.block3.resize(out.block3.size() + NF3_CPL_SIZE);
-                relayout_coupling_v3(v1, out.block3.data() + dst.off);
+                out.block3.resize(out.block3.size() + (out.fp16_big ? NF11_CPL_SIZE : NF3_CPL_SIZE));
+                if (out.fp16_big) relayout_coupling_v11(v1, out.block3.data() + dst.off);
+                else relayout_coupling_v3(v1, out.block3.data() + dst.off);
             } else if (src.type == NF_OP_SCALE) {
                 out.block3.insert(out.block3.end(), v1, v1 + 4);
             } else {
@@ -1216,7 +1255,7 @@ int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float
             }
         }
         if (out.block3.empty()) out.block3.assign(4, 0.0f);
-        if (out.block3.size() > NF2_MAX_FLOATS) return fail(NF_EINVAL, "model too large for the fp16-CNN LDS image");
+        if (out.block3.size() > (size_t)(out.fp16_big ? NF11_MAX_FLOATS : NF2_MAX_FLOATS)) return fail(NF_EINVAL, "model too large for the fp16-CNN LDS image");
     }
     if (out.tiled) {
         // every coupling widens the dependence of a pixel by 2 (3x3, 1x1, 3x3): nf_device.h, "overlapping tiles"
@@ -1732,7 +1771,7 @@ static int launch_resident(nf_handle *h, int direction, NfLaunch &a, hipStream_t
     if (d3) {
         a.params = d3;
         a.n_params = (int32_t)b.block3.size();
-        a.flags |= NF_K_FP16_CNN;
+        a.flags |= NF_K_FP16_CNN | (b.fp16_big ? NF_K_FP16_BIG : 0u);
     } else if (mc) {
         a.params = d2;
         a.n_params = (int32_t)b.block2.size();

@@ -138,7 +138,9 @@ __device__ __forceinline__ void nf_flow_body(const NfProgram &prog, const NfLaun
     static_assert(WIDTH % 4 == 0, "WIDTH must be a multiple of 4");
     static_assert(!MFMA || WIDTH == 4, "the matrix-core path is the width-4 specialisation");
     static_assert(PREC == 0 || (MFMA && FULL && PX == 4), "the fp16-CNN mode exists for full 2x2-blocked patches only");
-    constexpr bool H16 = PREC == 1;   // coupling-CNN convs on fp16 matrix cores (fp32 accumulate)
+    constexpr bool H16 = PREC == 1;   // coupling-CNN convs on fp16 matrix cores (fp32 accumulate): v_mfma_f32_4x4x4_16b_f16
+    constexpr bool HB = PREC == 2;    // the same on v_mfma_f32_16x16x32_f16 (nf_device.h, NF11_*)
+    constexpr bool HALF = PREC != 0;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     // FULL = square patch that fills the workgroup exactly (32x32 or 64x64): the geometry is a
@@ -148,14 +150,14 @@ __device__ __forceinline__ void nf_flow_body(const NfProgram &prog, const NfLaun
     const int H = FULL ? SIDE : a.H, W = FULL ? SIDE : a.W, HW = H * W;
     // row pitch of the plain row-major tiles; fp16 mode at 32x32: 48 entries so that the next
     // block row (2 tile rows down) starts a multiple of 128 B (half2) / 256 B (4 x half) away
-    const int Wp = (H16 && SIDE == 32) ? 48 : W + 2;
+    const int Wp = HB ? nf11_pitch(SIDE) : (H16 && SIDE == 32) ? 48 : W + 2;
     const int tile_px = ((H + 2) * Wp + 1) & ~1;         // even -> 16-byte aligned sections
     float2 *const t0 = reinterpret_cast<float2 *>(smem);  // z0 tile  [tile_px] float2
     float *const th = smem + 2 * tile_px;                 // h2 tile  [tile_px][WIDTH]
     // fp16-CNN mode: the same two tiles hold half2 / 4 x half per pixel, plain row-major
     uint32_t *const t0h = reinterpret_cast<uint32_t *>(smem);         // [tile_px] half2
     uint2 *const thh = reinterpret_cast<uint2 *>(smem + tile_px);     // [tile_px] 4 x half
-    constexpr int TILE_WORDS = H16 ? 3 : 2 + WIDTH;                   // 32-bit words per tile pixel
+    constexpr int TILE_WORDS = HALF ? 3 : 2 + WIDTH;                  // 32-bit words per tile pixel
     float *const red = smem + TILE_WORDS * tile_px;       // reduction scratch [3][THREADS/64] (+pad)
     float *const wl = red + ((3 * (THREADS / 64) + 3) & ~3);   // MFMA: the whole folded model, j-major
     // BS: [THREADS/64][8] per-wavefront statistics partials, then 8 doubles (scale[4], mean[4]) of the pending re-fold
@@ -182,7 +184,27 @@ __device__ __forceinline__ void nf_flow_body(const NfProgram &prog, const NfLaun
     bool own[PX];      // pixels whose results this workgroup reports: act[k], narrowed to the tile's core window by NF_K_TILED launches
     [[maybe_unused]] int prow[PX], pcol[PX];   // masked instantiations: row / column of the pixel inside the patch (tile)
     int wbase = 0;     // BLK: tile entry of the window origin (r' = 2*br, c' = 2*bc)
-    if constexpr (BLK) {
+    [[maybe_unused]] int wbase3 = 0;   // HB: first entry of this lane's l_last B operand (unit 0, instruction 0)
+    if constexpr (HB) {
+        // nf_device.h, NF11_*: a wavefront owns 8 rows x 32 columns = 4 units of 2 rows; lane 16 g + n is pixel
+        // (a, p) = (g >> 1, g & 1) of the 2x2 block of lane column n in each of them
+        const int wv = t >> 6, g = (t >> 4) & 3, n = t & 15;
+        const int q = SIDE == 64 ? (wv & 1) : 0, band = SIDE == 64 ? (wv >> 1) : wv;
+        const int c = 32 * q + 2 * n + (g & 1);
+        wbase = (band * 8 + nf11_l1_row(g)) * Wp + 32 * q + 2 * n;
+        wbase3 = (band * 8 + nf11_l3_row(g, 0)) * Wp + 32 * q + 2 * n + 2 * (g >> 1);
+#pragma unroll
+        for (int k = 0; k < PX; ++k) {
+            const int r = band * 8 + 2 * k + (g >> 1);
+            act[k] = true;
+            own[k] = true;
+            prow[k] = r;
+            pcol[k] = c;
+            gidx[k] = r * W + c;
+            lidx[k] = (r + 1) * Wp + (c + 1);
+            bmask[k] = (r == 0 ? 1 : 0) | (r == H - 1 ? 2 : 0) | (c == 0 ? 4 : 0) | (c == W - 1 ? 8 : 0);
+        }
+    } else if constexpr (BLK) {
         const int bw = W >> 1;
         int br = t / bw, bc = t - br * bw;
 #if NF_BR_SWIZZLE
@@ -269,7 +291,7 @@ __device__ __forceinline__ void nf_flow_body(const NfProgram &prog, const NfLaun
 #ifndef NF_ZERO_BORDER
 #define NF_ZERO_BORDER 0
 #endif
-        if constexpr (NF_ZERO_BORDER && BLK && !H16) {
+        if constexpr (NF_ZERO_BORDER && BLK && !HALF) {
             // blocked fp32 tiles: every interior entry has an owner that writes it (z0 / h2 of each coupling) before anyone
             // reads it, so only the 2 (W + 2) + 2 H border entries need the zero — 3 KiB instead of 27 KiB of LDS stores per
             // 32x32 workgroup.  Measured and left OFF: + 0.7 % with a freshly initialised model (49.46 ->
@@ -505,7 +527,7 @@ __device__ __forceinline__ void nf_flow_body(const NfProgram &prog, const NfLaun
                 // 1) publish the pass-through half
 #pragma unroll
                 for (int k = 0; k < PX; ++k) {
-                    if constexpr (H16) {
+                    if constexpr (HALF) {
                         const v2h zh = {(_Float16)z[k][0], (_Float16)z[k][1]};
                         t0h[lidx[k]] = __builtin_bit_cast(uint32_t, zh);
                     } else {
@@ -515,7 +537,43 @@ __device__ __forceinline__ void nf_flow_body(const NfProgram &prog, const NfLaun
                 __syncthreads();
 
                 // 2) l_1 (3x3 SAME, BN folded) -> ReLU -> l_2 (1x1, BN folded) -> ReLU
-                if constexpr (H16) {
+                if constexpr (HB) {
+                    const float *wb = wl + prog.ops[op].off;
+                    const uint32_t *wbw = reinterpret_cast<const uint32_t *>(wb);
+                    const float4 b1 = *reinterpret_cast<const float4 *>(wb + NF11_CPL_B1);
+                    const float4 b2 = *reinterpret_cast<const float4 *>(wb + NF11_CPL_B2);
+                    const v8h a1 = __builtin_bit_cast(v8h, *reinterpret_cast<const uint4 *>(wbw + NF11_CPL_A1 + (t & 63) * 4));
+                    const v4h w2h = *reinterpret_cast<const v4h *>(wbw + NF11_CPL_W2H + j4 * 2);
+                    // the four units of the wavefront side by side: every stage's dependent latency (LDS, the 4-pass MFMA, the
+                    // conversions) is covered by the same stage of the other three
+                    v8h bop[PX];
+#pragma unroll
+                    for (int k = 0; k < PX; ++k) {
+                        // this lane's K slot: one window row, 4 columns x 2 channels (two 8-byte reads, 8-byte aligned)
+                        const uint2 lo = *reinterpret_cast<const uint2 *>(t0h + wbase + 2 * k * Wp);
+                        const uint2 hi = *reinterpret_cast<const uint2 *>(t0h + wbase + 2 * k * Wp + 2);
+                        bop[k] = __builtin_bit_cast(v8h, make_uint4(lo.x, lo.y, hi.x, hi.y));
+                    }
+                    v4f h1[PX];
+#pragma unroll
+                    for (int k = 0; k < PX; ++k)
+                        h1[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bop[k], v4f{b1.x, b1.y, b1.z, b1.w}, 0, 0, 0);
+                    v4h r1[PX];
+#pragma unroll
+                    for (int k = 0; k < PX; ++k)
+                        r1[k] = __builtin_elementwise_max(
+                            v4h{(_Float16)h1[k][0], (_Float16)h1[k][1], (_Float16)h1[k][2], (_Float16)h1[k][3]}, v4h{0, 0, 0, 0});
+                    v4f h2[PX];
+#pragma unroll
+                    for (int k = 0; k < PX; ++k)
+                        h2[k] = __builtin_amdgcn_mfma_f32_4x4x4f16(w2h, r1[k], v4f{b2.x, b2.y, b2.z, b2.w}, 0, 0, 0);
+#pragma unroll
+                    for (int k = 0; k < PX; ++k) {
+                        const v4h r2 = __builtin_elementwise_max(
+                            v4h{(_Float16)h2[k][0], (_Float16)h2[k][1], (_Float16)h2[k][2], (_Float16)h2[k][3]}, v4h{0, 0, 0, 0});
+                        thh[lidx[k]] = __builtin_bit_cast(uint2, r2);
+                    }
+                } else if constexpr (H16) {
                     const float *wb = wl + prog.ops[op].off;
                     const uint32_t *wbw = reinterpret_cast<const uint32_t *>(wb);
                     const float4 b1 = *reinterpret_cast<const float4 *>(wb + NF3_CPL_B1);
@@ -749,7 +807,24 @@ __device__ __forceinline__ void nf_flow_body(const NfProgram &prog, const NfLaun
                 {
                     float o[PX][4];
                     float sc;
-                    if constexpr (H16) {
+                    if constexpr (HB) {
+                        const float *wb = wl + prog.ops[op].off;
+                        const uint32_t *wbw = reinterpret_cast<const uint32_t *>(wb);
+                        sc = 0.0f;
+                        const v8h a3a = __builtin_bit_cast(v8h, *reinterpret_cast<const uint4 *>(wbw + NF11_CPL_A3 + (t & 63) * 4));
+                        const v8h a3b = __builtin_bit_cast(v8h, *reinterpret_cast<const uint4 *>(wbw + NF11_CPL_A3 + 256 + (t & 63) * 4));
+#pragma unroll
+                        for (int k = 0; k < PX; ++k) {
+                            const float4 e = *reinterpret_cast<const float4 *>(wb + NF11_CPL_E + 4 * bmask[k]);
+                            // K slot of this lane: two adjacent window pixels x 4 channels = one aligned 16-byte read per instruction
+                            const uint4 q0 = *reinterpret_cast<const uint4 *>(thh + wbase3 + 2 * k * Wp);
+                            const uint4 q1 = *reinterpret_cast<const uint4 *>(thh + wbase3 + (2 * k + 1) * Wp);
+                            v4f acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a3a, __builtin_bit_cast(v8h, q0), v4f{e.x, e.y, e.z, e.w}, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a3b, __builtin_bit_cast(v8h, q1), acc, 0, 0, 0);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) o[k][j] = acc[j];
+                        }
+                    } else if constexpr (H16) {
                         const float *wb = wl + prog.ops[op].off;
                         const uint32_t *wbw = reinterpret_cast<const uint32_t *>(wb);
                         sc = 0.0f;
@@ -902,7 +977,7 @@ __device__ __forceinline__ void nf_flow_body(const NfProgram &prog, const NfLaun
                         // and the log-det is accumulated in log2 units (ld2), converted once per patch.
                         const float scl = wl[prog.ops[op].off + NF2_CPL_S + 1];     // (NF3_CPL_S == NF2_CPL_S)
                         const float m2scl = wl[prog.ops[op].off + NF2_CPL_S + 2];
-                        if constexpr (H16) {
+                        if constexpr (HALF) {
 #pragma unroll
                             for (int k = 0; k < PX; ++k) {
                                 o[k][2] *= 2.8853900817779268f;   // fp16 weights are not pre-scaled by 2*log2(e)
@@ -1270,8 +1345,9 @@ template <int WIDTH, int THREADS, int PX, bool PHILOX, bool MFMA, bool FULL, int
 hipError_t launch_flow_p(const NfProgram &prog, const NfLaunch &a, int n_cu, hipStream_t stream)
 {
     const int tile_px = ((a.H + 2) * (a.W + 2) + 1) & ~1;
-    size_t lds_f = (size_t)tile_px * (PREC == 1 ? 3 : 2 + WIDTH) + ((3 * (THREADS / 64) + 3) & ~3);
+    size_t lds_f = (size_t)tile_px * (PREC != 0 ? 3 : 2 + WIDTH) + ((3 * (THREADS / 64) + 3) & ~3);
     if (PREC == 1 && a.H == 32) lds_f = (size_t)(34 * 48) * 3 + ((3 * (THREADS / 64) + 3) & ~3);   // padded row pitch
+    if (PREC == 2) lds_f = (size_t)((a.H + 2) * nf11_pitch(a.H)) * 3 + ((3 * (THREADS / 64) + 3) & ~3);
     if (MFMA) lds_f += (size_t)((a.n_params + 3) & ~3);
     if (BS) lds_f += (size_t)(THREADS / 64) * 8 + 16;
     const size_t lds = sizeof(float) * lds_f;
@@ -1315,6 +1391,7 @@ template <int WIDTH, int THREADS, int PX, bool PHILOX, bool MFMA, bool FULL>
 hipError_t launch_flow_f(const NfProgram &prog, const NfLaunch &a, int n_cu, hipStream_t stream)
 {
     if constexpr (MFMA && FULL && PX == 4) {
+        if (a.flags & NF_K_FP16_BIG) return launch_flow_p<WIDTH, THREADS, PX, PHILOX, MFMA, FULL, 2>(prog, a, n_cu, stream);
         if (a.flags & NF_K_FP16_CNN) return launch_flow_p<WIDTH, THREADS, PX, PHILOX, MFMA, FULL, 1>(prog, a, n_cu, stream);
     }
     if (a.flags & NF_K_FP16_CNN) return hipErrorInvalidValue;

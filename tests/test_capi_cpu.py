@@ -269,11 +269,11 @@ def test_other_permutation_settings_fold_like_the_oracle(flow_permutation, decom
 # ---------------------------------------------------------------------------------------------------------
 # GEMM layout (widths 33 .. 512, csrc/nf_gemm.hip): numpy emulation of the kernel's dataflow from the uploaded block
 # ---------------------------------------------------------------------------------------------------------
-def _fold_layout(arch, variables, width, direction, path, hw=(32, 32)):
+def _fold_layout(arch, variables, width, direction, path, hw=(32, 32), flags=0):
     from noise_flow_amd import _lib, params
     lib = _lib.load()
     layers, descs, flat = params.pack(arch, variables, width, "loss_first", 1, "LU")
-    cfg = _lib.nf_config(hw[0], hw[1], 4, len(layers), -1, 0)
+    cfg = _lib.nf_config(hw[0], hw[1], 4, len(layers), -1, flags)
     ops = (C.c_int32 * 256)()
     n_ops, lw, nf = C.c_int32(), C.c_int32(), C.c_size_t()
     args = (C.byref(cfg), descs, flat.ctypes.data_as(C.POINTER(C.c_float)), flat.size, direction, path, ops, 128, C.byref(n_ops),
@@ -392,6 +392,94 @@ def test_gemm_layout_emulated_lane_by_lane_matches_the_oracle_cnn(width, variant
     shift, raw = O.coupling_cnn(z0[None], cp)
     ref = np.concatenate([shift[0], raw[0]], -1)
     assert np.abs(o - ref).max() <= 2e-5 * np.abs(ref).max(), np.abs(o - ref).max() / np.abs(ref).max()
+
+
+def _mfma_16x16x32(A, B, D):
+    """v_mfma_f32_16x16x32_f16: A[lane][e] = A-matrix[m = lane & 15][k = 8 (lane >> 4) + e], B[lane][e] = B-matrix[k][n = lane & 15];
+    D[v][lane] holds row 4 (lane >> 4) + v, column lane & 15."""
+    Am = np.zeros((16, 32)); Bm = np.zeros((32, 16))
+    for l in range(64):
+        Am[l & 15, 8 * (l >> 4):8 * (l >> 4) + 8] = A[l]
+        Bm[8 * (l >> 4):8 * (l >> 4) + 8, l & 15] = B[l]
+    Cm = Am @ Bm
+    out = D.copy()
+    for v in range(4):
+        for l in range(64):
+            out[v, l] += Cm[4 * (l >> 4) + v, l & 15]
+    return out
+
+
+@pytest.mark.parametrize("side", [32, 64])
+def test_fp16_big_mfma_layout_emulated_lane_by_lane_matches_the_oracle_cnn(side):
+    """The NF11 block nf_create uploads for NF_CFG_FP16_CNN at width 4, consumed exactly as nf_flow_kernel<.., PREC = 2> consumes
+    it — pixel ownership of the lanes, the K slots' window rows / column pairs read from the two LDS tiles, the A operands in
+    lane order, the 2x2 output block on M — in a numpy model of v_mfma_f32_16x16x32_f16, against the oracle's fp16-CNN
+    emulation on a whole patch.  Catches layout / indexing mistakes without a GPU."""
+    from noise_flow_amd import _lib
+    arch = "unc"
+    v = trained_like_variables(arch, 4, seed=11)
+    ops, blk, _ = _fold_layout(arch, v, 4, 0, _lib.NF_PATH_FP16, (side, side), flags=_lib.NF_CFG_FP16_CNN)
+    (t0, _), (t1, off) = ops
+    assert (t0, t1) == (1, 2)
+    words = blk.view(np.uint32)
+    halves = lambda a, n: words[a:a + n].view(np.float16).astype(np.float64)
+    E = blk[off:off + 64].reshape(16, 4).astype(np.float64)
+    B1, B2 = blk[off + 64:off + 68].astype(np.float64), blk[off + 68:off + 72].astype(np.float64)
+    W2h = halves(off + 76, 8).reshape(4, 4)                 # [j][i]
+    A1 = halves(off + 84, 256).reshape(64, 8)
+    A3 = halves(off + 340, 512).reshape(2, 64, 8)
+    Wp = 80 if side == 64 else 48
+    l1_row = lambda g: 2 * (g & 1) + (g >> 1)
+    l3_row = lambda g, m3: 2 * (g & 1) + m3
+    rng = np.random.RandomState(3)
+    z0 = rng.randn(side, side, 2)
+    h16 = lambda a: np.asarray(a).astype(np.float16).astype(np.float64)
+    t0h = np.zeros(((side + 2) * Wp, 2)); thh = np.zeros(((side + 2) * Wp, 4))
+    for r in range(side):
+        t0h[(r + 1) * Wp + 1:(r + 1) * Wp + 1 + side] = h16(z0[r])
+    n_waves = 16 if side == 64 else 4
+    o = np.zeros((side, side, 4))
+    own = {}
+    for phase in (0, 1):
+        for wv in range(n_waves):
+            q, band = (wv & 1, wv >> 1) if side == 64 else (0, wv)
+            for k in range(4):
+                lanes = range(64)
+                g = [l >> 4 for l in lanes]; n = [l & 15 for l in lanes]
+                rr = [band * 8 + 2 * k + (g[l] >> 1) for l in lanes]
+                cc = [32 * q + 2 * n[l] + (g[l] & 1) for l in lanes]
+                lidx = [(rr[l] + 1) * Wp + cc[l] + 1 for l in lanes]
+                if phase == 0:
+                    Bop = np.zeros((64, 8))
+                    for l in lanes:
+                        base = (band * 8 + l1_row(g[l])) * Wp + 32 * q + 2 * n[l] + 2 * k * Wp
+                        Bop[l] = t0h[base:base + 4].reshape(-1)
+                    d = _mfma_16x16x32(A1, Bop, np.repeat(B1[:, None], 64, 1))
+                    r1 = h16(np.maximum(d, 0))
+                    h2 = B2[:, None] + W2h @ r1                 # 4x4x4: D[j][pixel] = sum_i W2h[j][i] r1[i][pixel]
+                    r2 = h16(np.maximum(h2, 0))
+                    for l in lanes:
+                        thh[lidx[l]] = r2[:, l]
+                        assert (rr[l], cc[l]) not in own
+                        own[(rr[l], cc[l])] = 1
+                else:
+                    d = np.zeros((4, 64))
+                    for l in lanes:
+                        bm = (rr[l] == 0) | (rr[l] == side - 1) << 1 | (cc[l] == 0) << 2 | (cc[l] == side - 1) << 3
+                        d[:, l] = E[bm]
+                    for m3 in (0, 1):
+                        Bop = np.zeros((64, 8))
+                        for l in lanes:
+                            base = (band * 8 + l3_row(g[l], 0)) * Wp + 32 * q + 2 * n[l] + 2 * (g[l] >> 1) + (2 * k + m3) * Wp
+                            Bop[l] = thh[base:base + 2].reshape(-1)
+                        d = _mfma_16x16x32(A3[m3], Bop, d)
+                    for l in lanes:
+                        o[rr[l], cc[l]] = d[:, l]
+    assert len(own) == side * side
+    cp = [L["p"] for L in O.bind_variables(arch, v) if L["type"] == "coupling"][0]
+    shift, raw = O.coupling_cnn_fp16(z0[None], cp)
+    ref = np.concatenate([shift[0], raw[0]], -1)
+    assert np.abs(o - ref).max() <= 1e-5 * np.abs(ref).max(), np.abs(o - ref).max() / np.abs(ref).max()
 
 
 def _tile_plan(lib, size, tile, halo):

@@ -14,7 +14,7 @@ iters = int(sys.argv[3]) if len(sys.argv) > 3 else 50
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 v = load_checkpoint(os.path.join(root, "models/NoiseFlow/ckpt/model.ckpt.best"))
 x, y = synth_patches(0, 0, B, H, H)
-for mode in ("fp32", "fp16"):
+for mode in os.environ.get("MODES", "fp32,fp16").split(","):
     m = NoiseFlow([H, H, 4], False, default_hps(), variables=v, cnn_dtype=mode)
     for name, fn in (("nll", lambda: m.nll_sums(x, y, [0], [0], [100], [2])), ("sample", lambda: m.sample(y, 1.0, y, [0], [0], [100], [2]))):
         for _ in range(5):
