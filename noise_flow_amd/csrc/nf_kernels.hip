@@ -472,28 +472,42 @@ __device__ __forceinline__ void nf_flow_body(const NfProgram &prog, const NfLaun
         [[maybe_unused]] int n_cpl = 0;
         [[maybe_unused]] int cpl_seen = 0;
 
+        // Conv2d1x1 on the matrix cores: per-pixel z <- z @ M   (layers.py:108-124)
+        [[maybe_unused]] auto mix_mfma = [&](int mop) {
+            const float4 m = *reinterpret_cast<const float4 *>(wl + prog.ops[mop].off + 4 * j4);   // M[0..3][j4]
+#pragma unroll
+            for (int k = 0; k < PX; ++k) {
+                v4f acc = {0.f, 0.f, 0.f, 0.f};
+                acc = __builtin_amdgcn_mfma_f32_4x4x1f32(m.x, z[k][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_4x4x1f32(m.y, z[k][1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_4x4x1f32(m.z, z[k][2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_4x4x1f32(m.w, z[k][3], acc, 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) z[k][j] = acc[j];
+            }
+        };
+
         for (int op = 0; op < n_ops; ++op) {
-            const int type = prog.ops[op].type;
-            const cfloat_p P = (cfloat_p)(a.params + prog.ops[op].off);   // wave-uniform, scalar loads
+            int type = prog.ops[op].type;
+            if constexpr (MFMA) {
+                if (type == NF_OP_MIX) {
+#ifdef NF_TIMELINE
+                    if (n_cpl == 0) { asm volatile("" ::"v"(z[0][0])); NF_STAMP(2); }   // inputs have arrived (first use after the sdn layer)
+#endif
+                    mix_mfma(op);
+                    // the coupling behind a mix (an `unc` layer is Conv2d1x1 + AffineCoupling, noise_flow_model.py:79-104) runs in
+                    // the same trip of this loop
+                    const int nt = op + 1 < n_ops ? prog.ops[op + 1].type : 0;
+                    if (nt != NF_OP_COUPLING_FWD && nt != NF_OP_COUPLING_REV) continue;
+                    ++op;
+                    type = nt;
+                }
+            }
+            cfloat_p P = (cfloat_p)(a.params + prog.ops[op].off);   // wave-uniform, scalar loads
 
             if (type == NF_OP_MIX) {
-#ifdef NF_TIMELINE
-                if (n_cpl == 0) { asm volatile("" ::"v"(z[0][0])); NF_STAMP(2); }   // inputs have arrived (first use after the sdn layer)
-#endif
-                // Conv2d1x1: per-pixel z <- z @ M   (layers.py:108-124)
-                if constexpr (MFMA) {
-                    const float4 m = *reinterpret_cast<const float4 *>(wl + prog.ops[op].off + 4 * j4);   // M[0..3][j4]
-#pragma unroll
-                    for (int k = 0; k < PX; ++k) {
-                        v4f acc = {0.f, 0.f, 0.f, 0.f};
-                        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(m.x, z[k][0], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(m.y, z[k][1], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(m.z, z[k][2], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(m.w, z[k][3], acc, 0, 0, 0);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) z[k][j] = acc[j];
-                    }
-                } else {
+                // Conv2d1x1 on the scalar-weight kernel
+                if constexpr (!MFMA) {
                     float m[16];
 #pragma unroll
                     for (int i = 0; i < 16; ++i) m[i] = P[i];
@@ -514,6 +528,12 @@ __device__ __forceinline__ void nf_flow_body(const NfProgram &prog, const NfLaun
                 }
             } else if (type == NF_OP_COUPLING_FWD || type == NF_OP_COUPLING_REV) {
                 // ---- AffineCoupling (layers.py:275-291 / 355-375) ----
+                // A run of couplings with a mix in front of each (unc | unc | ...) stays in this inner loop: with the pointwise
+                // layers' code paths out of the way z has ONE set of registers across the run — the mix accumulates into it, the
+                // coupling updates its transformed half in place — instead of being copied between the loop-carried set and a
+                // working set around every op (28 v_mov_b64 per mix + coupling, a fifth of the VALU instructions)
+                bool patch_done = false;
+                for (;;) {
 #if NF_FAIR
                 if constexpr (MFMA && !(NF_WAVE_PRIO && THREADS == 1024)) {
                     const int lvl = (cpl_seen * 4) / cpl_total;   // 0 .. 3, wave-uniform
@@ -800,7 +820,10 @@ __device__ __forceinline__ void nf_flow_body(const NfProgram &prog, const NfLaun
                     }
                 }
                 if constexpr (!MFMA || BS) {
-                    if (a.stats && op == a.stats_op) break;   // statistics gathered: this patch is done
+                    if (a.stats && op == a.stats_op) {   // statistics gathered: this patch is done
+                        patch_done = true;
+                        break;
+                    }
                 }
 
                 // 3) l_last (zero pad + border-indicator channel, 3x3 VALID, *exp(3 logs) folded)
@@ -1023,6 +1046,19 @@ __device__ __forceinline__ void nf_flow_body(const NfProgram &prog, const NfLaun
                 if (n_cpl < 8) NF_STAMP(3 + n_cpl);
                 ++n_cpl;
 #endif
+                if constexpr (!MFMA) {
+                    break;
+                } else {
+                    if (op + 2 >= n_ops || prog.ops[op + 1].type != NF_OP_MIX ||
+                        (prog.ops[op + 2].type != NF_OP_COUPLING_FWD && prog.ops[op + 2].type != NF_OP_COUPLING_REV))
+                        break;
+                    mix_mfma(op + 1);
+                    op += 2;
+                    type = prog.ops[op].type;
+                    P = (cfloat_p)(a.params + prog.ops[op].off);
+                }
+                }   // run of couplings
+                if (patch_done) break;
             } else if (type == NF_OP_SDN_DIV || type == NF_OP_SDN_MUL) {
                 // AffineCouplingSdnEx5: scale = sqrt(beta1*y/gain + beta2)  (cond_utils.py:238)
                 const float4 *y4 = reinterpret_cast<const float4 *>(a.y + patch_off);
