@@ -104,6 +104,18 @@ __device__ __forceinline__ float wave_sum(float v)
     return (r0 + r1) + (r2 + r3);
 }
 
+// every lane of a 16-lane DPP row gets its row's sum (the first four issues of wave_sum)
+__device__ __forceinline__ float row16_sum(float v)
+{
+#define NF_WS_DPP(x, CTRL) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), (CTRL), 0xf, 0xf, false))
+    v += NF_WS_DPP(v, 0xB1);    // quad_perm [1,0,3,2]
+    v += NF_WS_DPP(v, 0x4E);    // quad_perm [2,3,0,1]
+    v += NF_WS_DPP(v, 0x141);   // row_half_mirror
+    v += NF_WS_DPP(v, 0x140);   // row_mirror
+#undef NF_WS_DPP
+    return v;
+}
+
 // the same for a double (both halves travel through the DPP / readlane network)
 template <int CTRL>
 __device__ __forceinline__ double dpp_get_f64(double v)

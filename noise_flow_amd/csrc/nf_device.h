@@ -133,7 +133,10 @@ __host__ __device__ constexpr int nf_cpl_size(int w)   { return 64 + 36 * w + 18
 #define NF11_MAX_FLOATS 12288   // 48 KiB of LDS for the whole model's weights in this layout
 __host__ __device__ constexpr int nf11_l1_row(int gk) { return 2 * (gk & 1) + (gk >> 1); }
 __host__ __device__ constexpr int nf11_l3_row(int gk, int m3) { return 2 * (gk & 1) + m3; }
-__host__ __device__ constexpr int nf11_pitch(int side) { return side == 64 ? 80 : 48; }   // tile row pitch in pixels
+#ifndef NF11_PITCH64
+#define NF11_PITCH64 80
+#endif
+__host__ __device__ constexpr int nf11_pitch(int side) { return side == 64 ? NF11_PITCH64 : 48; }   // tile row pitch in pixels
 
 // ---- wide-CNN layout (coupling width 32, nf_wide.hip) ------------------------------------------
 // The three convs of a width-32 coupling CNN run on v_mfma_f32_32x32x2_f32 with the PIXELS on the N

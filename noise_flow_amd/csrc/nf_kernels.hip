@@ -158,8 +158,8 @@ __device__ __forceinline__ void nf_flow_body(const NfProgram &prog, const NfLaun
     uint32_t *const t0h = reinterpret_cast<uint32_t *>(smem);         // [tile_px] half2
     uint2 *const thh = reinterpret_cast<uint2 *>(smem + tile_px);     // [tile_px] 4 x half
     constexpr int TILE_WORDS = HALF ? 3 : 2 + WIDTH;                  // 32-bit words per tile pixel
-    float *const red = smem + TILE_WORDS * tile_px;       // reduction scratch [3][THREADS/64] (+pad)
-    float *const wl = red + ((3 * (THREADS / 64) + 3) & ~3);   // MFMA: the whole folded model, j-major
+    float *const red = smem + TILE_WORDS * tile_px;       // reduction scratch [2][3][THREADS/64] (+pad), alternating by patch
+    float *const wl = red + ((6 * (THREADS / 64) + 3) & ~3);   // MFMA: the whole folded model, j-major
     // BS: [THREADS/64][8] per-wavefront statistics partials, then 8 doubles (scale[4], mean[4]) of the pending re-fold
     [[maybe_unused]] float *const bs_part = wl + ((a.n_params + 3) & ~3);
 
@@ -256,6 +256,19 @@ __device__ __forceinline__ void nf_flow_body(const NfProgram &prog, const NfLaun
     float4 zin[PX];   // raw x of the NEXT patch this workgroup evaluates (software prefetch across the patch loop)
 #pragma unroll
     for (int k = 0; k < PX; ++k) zin[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // YPF — one 1024-thread workgroup per CU (64x64 patches): nothing else on the CU covers the HBM latency of the clean image
+    // the leading sdn layer reads (tools/timeline.py: 2.3 us between two patches, 12 % of a patch), so y of the next patch
+    // travels with its x, and the leading sdn layer is peeled off the op loop so that these registers are dead inside it
+#ifndef NF_YPF
+#define NF_YPF 1
+#endif
+    constexpr bool YPF = NF_YPF && MFMA && FULL && !PHILOX && THREADS == 1024 && !TF && !BS && (PREC != 0 || NF_YPF > 1);   // fp32 at 64x64 has no 16 registers to spare
+    [[maybe_unused]] float4 yin[YPF ? PX : 1];
+    [[maybe_unused]] const bool sdn_first = YPF && a.y && prog.n_ops > 0 && prog.ops[0].type == NF_OP_SDN_DIV;
+    if constexpr (YPF) {
+#pragma unroll
+        for (int k = 0; k < PX; ++k) yin[k] = make_float4(1.f, 1.f, 1.f, 1.f);
+    }
     // NF_STAGGER: a one-round launch (B = the resident capacity) would request all its 32 MiB of inputs in the same
     // microsecond and compute nothing until the last byte arrives (tools/timeline.py).  Only the first quarter of the
     // grid — with round-robin dispatch the first workgroup of every CU — asks before its LDS set-up; the second quarter
@@ -279,17 +292,27 @@ __device__ __forceinline__ void nf_flow_body(const NfProgram &prog, const NfLaun
             for (int k = 0; k < PX; ++k)
                 if (act[k]) zin[k] = reinterpret_cast<const float4 *>(a.in)[off0 + gidx[k]];
         }
+        if constexpr (YPF) {
+            if (sdn_first) {
+#pragma unroll
+                for (int k = 0; k < PX; ++k) yin[k] = reinterpret_cast<const float4 *>(a.y)[off0 + gidx[k]];
+            }
+        } else {
 #ifndef NF_NO_WARM
 #pragma unroll
         for (int k = 0; k < PX; k += NF_WARM_STEP)
             if (a.y && act[k]) warm += reinterpret_cast<const float *>(a.y)[4 * (off0 + gidx[k])];
 #endif
+        }
     }
 
     // zero both tiles once (the 1-pixel border is never written again) and stage the weight image, 16 bytes per lane
     {
 #ifndef NF_ZERO_BORDER
 #define NF_ZERO_BORDER 0
+#endif
+#ifndef NF_HB_ZB
+#define NF_HB_ZB 1
 #endif
         if constexpr (NF_ZERO_BORDER && BLK && !HALF) {
             // blocked fp32 tiles: every interior entry has an owner that writes it (z0 / h2 of each coupling) before anyone
@@ -315,6 +338,26 @@ __device__ __forceinline__ void nf_flow_body(const NfProgram &prog, const NfLaun
                 const int e = (rp * 2 + (cp & 1)) * PW + (cp >> 1);
                 t0[e] = make_float2(0.f, 0.f);
                 *reinterpret_cast<float4 *>(th + (size_t)e * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else if constexpr (NF_HB_ZB && HB) {
+            // every interior entry of both tiles has an owner that writes it before anyone reads it, and no operand read reaches
+            // beyond column W + 1 of the padded rows: only the border ring needs the zero (3.5 KiB instead of 63 KiB at 64x64)
+            const int nb = 2 * (W + 2) + 2 * H;
+            for (int i = t; i < nb; i += THREADS) {
+                int rp, cp;
+                if (i < W + 2) {
+                    rp = 0;
+                    cp = i;
+                } else if (i < 2 * (W + 2)) {
+                    rp = H + 1;
+                    cp = i - (W + 2);
+                } else {
+                    const int j = i - 2 * (W + 2);
+                    rp = 1 + (j >> 1);
+                    cp = (j & 1) ? W + 1 : 0;
+                }
+                t0h[rp * Wp + cp] = 0u;
+                thh[rp * Wp + cp] = make_uint2(0u, 0u);
             }
         } else {
         const int nz4 = (tile_px * TILE_WORDS) >> 2;
@@ -345,6 +388,12 @@ __device__ __forceinline__ void nf_flow_body(const NfProgram &prog, const NfLaun
 #pragma unroll
             for (int k = 0; k < PX; ++k)
                 if (act[k]) zin[k] = reinterpret_cast<const float4 *>(a.in)[off0 + gidx[k]];
+        }
+        if constexpr (YPF) {
+            if (sdn_first) {
+#pragma unroll
+                for (int k = 0; k < PX; ++k) yin[k] = reinterpret_cast<const float4 *>(a.y)[off0 + gidx[k]];
+            }
         }
     }
     if constexpr (BS) {
@@ -402,6 +451,8 @@ __device__ __forceinline__ void nf_flow_body(const NfProgram &prog, const NfLaun
 #endif
     const int n_ops = prog.n_ops;
     double acc_nll = 0.0, acc_sd = 0.0;   // thread 0 only
+    const double inv_n = 1.0 / ((double)HW * 4.0);   // once per launch: two fp64 divisions per patch were a third of the epilogue
+    [[maybe_unused]] int red_sel = 0;
     [[maybe_unused]] int cpl_total = 0;
 #if NF_FAIR
     for (int op = 0; op < n_ops; ++op)
@@ -487,7 +538,38 @@ __device__ __forceinline__ void nf_flow_body(const NfProgram &prog, const NfLaun
             }
         };
 
-        for (int op = 0; op < n_ops; ++op) {
+        // AffineCouplingSdnEx5 and its relatives: scale = sqrt(beta1*y/gain + beta2)  (cond_utils.py:238)
+        auto sdn_apply = [&](int stype, int slot, const float4 (&yv)[PX]) {
+            const float ck1 = a.cond_a[slot & 3], cb2 = a.cond_b[slot & 3];
+#pragma unroll
+            for (int k = 0; k < PX; ++k) {
+                const float yy[4] = {yv[k].x, yv[k].y, yv[k].z, yv[k].w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    // scale = sqrt(v), v = beta1*y/gain + beta2 > 0: z/scale = z*rsq(v), log scale = ln2/2*log2(v)
+                    // (v_rsq_f32 / v_log_f32: 1 ulp; once per element per patch)
+                    const float v = fmaf(yy[c], ck1, cb2);
+                    if (stype == NF_OP_SDN_DIV) {
+                        z[k][c] = z[k][c] * __builtin_amdgcn_rsqf(v);
+                        if (own[k]) ld = fmaf(-0.34657359027997264f, __builtin_amdgcn_logf(v), ld);
+                    } else {
+                        z[k][c] = z[k][c] * __builtin_amdgcn_sqrtf(v);
+                    }
+                }
+            }
+        };
+        int op_begin = 0;
+        if constexpr (YPF) {
+            if (sdn_first) {   // the leading sdn layer on the prefetched clean image
+                float4 yv[PX];
+#pragma unroll
+                for (int k = 0; k < PX; ++k) yv[k] = yin[k];
+                sdn_apply(NF_OP_SDN_DIV, prog.ops[0].off, yv);
+                op_begin = 1;
+            }
+        }
+
+        for (int op = op_begin; op < n_ops; ++op) {
             int type = prog.ops[op].type;
             if constexpr (MFMA) {
                 if (type == NF_OP_MIX) {
@@ -544,6 +626,24 @@ __device__ __forceinline__ void nf_flow_body(const NfProgram &prog, const NfLaun
                     else __builtin_amdgcn_s_setprio(0);
                 }
 #endif
+                // HB: every weight operand of the coupling is requested before the barriers, so that after a barrier only the
+                // tile reads stand between a wavefront and its matrix instructions (NF_HB_EARLY=0: at first use, A/B aid)
+#ifndef NF_HB_EARLY
+#define NF_HB_EARLY 1
+#endif
+                [[maybe_unused]] v8h hb_a1, hb_a3a, hb_a3b;
+                [[maybe_unused]] v4h hb_w2h;
+                [[maybe_unused]] float4 hb_b1, hb_b2, hb_e[PX];
+                if constexpr (HB) {
+                    const float *wb = wl + prog.ops[op].off;
+                    const uint32_t *wbw = reinterpret_cast<const uint32_t *>(wb);
+                    if (NF_HB_EARLY) {
+                        hb_b1 = *reinterpret_cast<const float4 *>(wb + NF11_CPL_B1);
+                        hb_b2 = *reinterpret_cast<const float4 *>(wb + NF11_CPL_B2);
+                        hb_a1 = __builtin_bit_cast(v8h, *reinterpret_cast<const uint4 *>(wbw + NF11_CPL_A1 + (t & 63) * 4));
+                        hb_w2h = *reinterpret_cast<const v4h *>(wbw + NF11_CPL_W2H + j4 * 2);
+                    }
+                }
                 // 1) publish the pass-through half
 #pragma unroll
                 for (int k = 0; k < PX; ++k) {
@@ -560,10 +660,15 @@ __device__ __forceinline__ void nf_flow_body(const NfProgram &prog, const NfLaun
                 if constexpr (HB) {
                     const float *wb = wl + prog.ops[op].off;
                     const uint32_t *wbw = reinterpret_cast<const uint32_t *>(wb);
-                    const float4 b1 = *reinterpret_cast<const float4 *>(wb + NF11_CPL_B1);
-                    const float4 b2 = *reinterpret_cast<const float4 *>(wb + NF11_CPL_B2);
-                    const v8h a1 = __builtin_bit_cast(v8h, *reinterpret_cast<const uint4 *>(wbw + NF11_CPL_A1 + (t & 63) * 4));
-                    const v4h w2h = *reinterpret_cast<const v4h *>(wbw + NF11_CPL_W2H + j4 * 2);
+                    if (!NF_HB_EARLY) {
+                        hb_b1 = *reinterpret_cast<const float4 *>(wb + NF11_CPL_B1);
+                        hb_b2 = *reinterpret_cast<const float4 *>(wb + NF11_CPL_B2);
+                        hb_a1 = __builtin_bit_cast(v8h, *reinterpret_cast<const uint4 *>(wbw + NF11_CPL_A1 + (t & 63) * 4));
+                        hb_w2h = *reinterpret_cast<const v4h *>(wbw + NF11_CPL_W2H + j4 * 2);
+                    }
+                    const float4 b1 = hb_b1, b2 = hb_b2;
+                    const v8h a1 = hb_a1;
+                    const v4h w2h = hb_w2h;
                     // the four units of the wavefront side by side: every stage's dependent latency (LDS, the 4-pass MFMA, the
                     // conversions) is covered by the same stage of the other three
                     v8h bop[PX];
@@ -592,6 +697,12 @@ __device__ __forceinline__ void nf_flow_body(const NfProgram &prog, const NfLaun
                         const v4h r2 = __builtin_elementwise_max(
                             v4h{(_Float16)h2[k][0], (_Float16)h2[k][1], (_Float16)h2[k][2], (_Float16)h2[k][3]}, v4h{0, 0, 0, 0});
                         thh[lidx[k]] = __builtin_bit_cast(uint2, r2);
+                    }
+                    if (NF_HB_EARLY) {   // l_last's weights and border-table rows: in flight across the barrier
+                        hb_a3a = __builtin_bit_cast(v8h, *reinterpret_cast<const uint4 *>(wbw + NF11_CPL_A3 + (t & 63) * 4));
+                        hb_a3b = __builtin_bit_cast(v8h, *reinterpret_cast<const uint4 *>(wbw + NF11_CPL_A3 + 256 + (t & 63) * 4));
+#pragma unroll
+                        for (int k = 0; k < PX; ++k) hb_e[k] = *reinterpret_cast<const float4 *>(wb + NF11_CPL_E + 4 * bmask[k]);
                     }
                 } else if constexpr (H16) {
                     const float *wb = wl + prog.ops[op].off;
@@ -834,11 +945,16 @@ __device__ __forceinline__ void nf_flow_body(const NfProgram &prog, const NfLaun
                         const float *wb = wl + prog.ops[op].off;
                         const uint32_t *wbw = reinterpret_cast<const uint32_t *>(wb);
                         sc = 0.0f;
-                        const v8h a3a = __builtin_bit_cast(v8h, *reinterpret_cast<const uint4 *>(wbw + NF11_CPL_A3 + (t & 63) * 4));
-                        const v8h a3b = __builtin_bit_cast(v8h, *reinterpret_cast<const uint4 *>(wbw + NF11_CPL_A3 + 256 + (t & 63) * 4));
+                        if (!NF_HB_EARLY) {
+                            hb_a3a = __builtin_bit_cast(v8h, *reinterpret_cast<const uint4 *>(wbw + NF11_CPL_A3 + (t & 63) * 4));
+                            hb_a3b = __builtin_bit_cast(v8h, *reinterpret_cast<const uint4 *>(wbw + NF11_CPL_A3 + 256 + (t & 63) * 4));
+#pragma unroll
+                            for (int k = 0; k < PX; ++k) hb_e[k] = *reinterpret_cast<const float4 *>(wb + NF11_CPL_E + 4 * bmask[k]);
+                        }
+                        const v8h a3a = hb_a3a, a3b = hb_a3b;
 #pragma unroll
                         for (int k = 0; k < PX; ++k) {
-                            const float4 e = *reinterpret_cast<const float4 *>(wb + NF11_CPL_E + 4 * bmask[k]);
+                            const float4 e = hb_e[k];
                             // K slot of this lane: two adjacent window pixels x 4 channels = one aligned 16-byte read per instruction
                             const uint4 q0 = *reinterpret_cast<const uint4 *>(thh + wbase3 + 2 * k * Wp);
                             const uint4 q1 = *reinterpret_cast<const uint4 *>(thh + wbase3 + (2 * k + 1) * Wp);
@@ -1060,27 +1176,14 @@ __device__ __forceinline__ void nf_flow_body(const NfProgram &prog, const NfLaun
                 }   // run of couplings
                 if (patch_done) break;
             } else if (type == NF_OP_SDN_DIV || type == NF_OP_SDN_MUL) {
-                // AffineCouplingSdnEx5: scale = sqrt(beta1*y/gain + beta2)  (cond_utils.py:238)
                 const float4 *y4 = reinterpret_cast<const float4 *>(a.y + patch_off);
-                const float ck1 = a.cond_a[prog.ops[op].off & 3], cb2 = a.cond_b[prog.ops[op].off & 3];
+                float4 yv[PX];
 #pragma unroll
                 for (int k = 0; k < PX; ++k) {
-                    float4 yv = make_float4(1.f, 1.f, 1.f, 1.f);
-                    if (act[k]) yv = y4[gidx[k]];
-                    const float yy[4] = {yv.x, yv.y, yv.z, yv.w};
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        // scale = sqrt(v), v = beta1*y/gain + beta2 > 0: z/scale = z*rsq(v), log scale = ln2/2*log2(v)
-                        // (v_rsq_f32 / v_log_f32: 1 ulp; once per element per patch)
-                        const float v = fmaf(yy[c], ck1, cb2);
-                        if (type == NF_OP_SDN_DIV) {
-                            z[k][c] = z[k][c] * __builtin_amdgcn_rsqf(v);
-                            if (own[k]) ld = fmaf(-0.34657359027997264f, __builtin_amdgcn_logf(v), ld);
-                        } else {
-                            z[k][c] = z[k][c] * __builtin_amdgcn_sqrtf(v);
-                        }
-                    }
+                    yv[k] = make_float4(1.f, 1.f, 1.f, 1.f);
+                    if (act[k]) yv[k] = y4[gidx[k]];
                 }
+                sdn_apply(type, prog.ops[op].off, yv);
             } else if (type == NF_OP_SCALE || type == NF_OP_SCALE_COND) {
                 const float s = type == NF_OP_SCALE ? P[0] : a.cond_a[prog.ops[op].off & 3];
 #pragma unroll
@@ -1116,6 +1219,15 @@ __device__ __forceinline__ void nf_flow_body(const NfProgram &prog, const NfLaun
                 if (more && act[k]) v = in4[gidx[k]];
                 zin[k] = v;
             }
+            if constexpr (YPF) {
+                const float4 *y4n = reinterpret_cast<const float4 *>(a.y) + (size_t)(more ? nb : b) * (size_t)HW;
+#pragma unroll
+                for (int k = 0; k < PX; ++k) {
+                    float4 v = make_float4(1.f, 1.f, 1.f, 1.f);
+                    if (more && sdn_first) v = y4n[gidx[k]];
+                    yin[k] = v;
+                }
+            }
         }
 
         if constexpr (!MFMA || BS) {
@@ -1143,23 +1255,23 @@ __device__ __forceinline__ void nf_flow_body(const NfProgram &prog, const NfLaun
             float r0 = wave_sum(fmaf(ld2, 0.6931471805599453f, ld)), r1 = wave_sum(s1), r2 = wave_sum(s2);
             constexpr int NW = THREADS / 64;
             if (NW > 1) {
+                // two scratch sets, alternating by patch: thread 0 finishes this patch (the fp64 tail below) while the other
+                // wavefronts are already in the next one — the next barrier any of them reaches comes after its reads
+                float *const rd = red + (red_sel ? 3 * NW : 0);
+                red_sel ^= 1;
                 const int wv = t >> 6;
                 if ((t & 63) == 0) {
-                    red[wv] = r0;
-                    red[NW + wv] = r1;
-                    red[2 * NW + wv] = r2;
+                    rd[wv] = r0;
+                    rd[NW + wv] = r1;
+                    rd[2 * NW + wv] = r2;
                 }
                 __syncthreads();
-                if (t == 0) {
-                    r0 = 0.f; r1 = 0.f; r2 = 0.f;
-#pragma unroll
-                    for (int i = 0; i < NW; ++i) {
-                        r0 += red[i];
-                        r1 += red[NW + i];
-                        r2 += red[2 * NW + i];
-                    }
+                if (t < 16) {   // one DPP row adds the wavefronts' partials: 3 reads + 12 adds instead of thread 0's chain of 3 NW
+                    static_assert(NW <= 16, "one lane per wavefront");
+                    r0 = row16_sum(t < NW ? rd[t] : 0.f);
+                    r1 = row16_sum(t < NW ? rd[NW + t] : 0.f);
+                    r2 = row16_sum(t < NW ? rd[2 * NW + t] : 0.f);
                 }
-                __syncthreads();   // scratch is reused by the next patch
             }
             if (tiled) {
                 // the tile's share of its image's sums; nf_tile_combine_kernel forms nll / sd / log-det per image
@@ -1171,8 +1283,8 @@ __device__ __forceinline__ void nf_flow_body(const NfProgram &prog, const NfLaun
                 double nll = -logdet;
                 if (a.flags & NF_K_PRIOR) nll += 0.5 * n * 1.8378770664093453 + 0.5 * (double)r2;
                 // sd of the base measure: population variance over the patch (noise_flow_model.py:477-478)
-                const double mean = (double)r1 / n;
-                double var = (double)r2 / n - mean * mean;
+                const double mean = (double)r1 * inv_n;
+                double var = (double)r2 * inv_n - mean * mean;
                 var = var > 0.0 ? var : 0.0;
                 // the result is rounded to fp32 anyway: v_sqrt_f32 (1 ulp) instead of the ~60-instruction fp64 routine
                 const double sd = (double)__builtin_amdgcn_sqrtf((float)var);
@@ -1381,9 +1493,9 @@ template <int WIDTH, int THREADS, int PX, bool PHILOX, bool MFMA, bool FULL, int
 hipError_t launch_flow_p(const NfProgram &prog, const NfLaunch &a, int n_cu, hipStream_t stream)
 {
     const int tile_px = ((a.H + 2) * (a.W + 2) + 1) & ~1;
-    size_t lds_f = (size_t)tile_px * (PREC != 0 ? 3 : 2 + WIDTH) + ((3 * (THREADS / 64) + 3) & ~3);
-    if (PREC == 1 && a.H == 32) lds_f = (size_t)(34 * 48) * 3 + ((3 * (THREADS / 64) + 3) & ~3);   // padded row pitch
-    if (PREC == 2) lds_f = (size_t)((a.H + 2) * nf11_pitch(a.H)) * 3 + ((3 * (THREADS / 64) + 3) & ~3);
+    size_t lds_f = (size_t)tile_px * (PREC != 0 ? 3 : 2 + WIDTH) + ((6 * (THREADS / 64) + 3) & ~3);
+    if (PREC == 1 && a.H == 32) lds_f = (size_t)(34 * 48) * 3 + ((6 * (THREADS / 64) + 3) & ~3);   // padded row pitch
+    if (PREC == 2) lds_f = (size_t)((a.H + 2) * nf11_pitch(a.H)) * 3 + ((6 * (THREADS / 64) + 3) & ~3);
     if (MFMA) lds_f += (size_t)((a.n_params + 3) & ~3);
     if (BS) lds_f += (size_t)(THREADS / 64) * 8 + 16;
     const size_t lds = sizeof(float) * lds_f;

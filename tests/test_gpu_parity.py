@@ -477,14 +477,19 @@ def test_epoch_harness_matches_oracle_and_sampler_statistics(shipped_variables, 
     assert -3.2 < out["NLL"] / 4096 < -2.5
 
 
+@pytest.mark.parametrize("formulation", ["16x16x32", "4x4x4"])
 @pytest.mark.parametrize("hw,B", [((32, 32), 12), ((64, 64), 5)])
-def test_fp16_coupling_cnn_mode(shipped_variables, oracle_full, hw, B):
+def test_fp16_coupling_cnn_mode(shipped_variables, oracle_full, hw, B, formulation, monkeypatch):
     """BASELINE configs[4]: fp16 coupling CNN (fp32 accumulate, fp32 log-det) on the matrix
     cores.  Checked against the oracle's emulation of the same rounding points (folded
     weights and the three CNN inputs rounded to half); tolerance 1e-4 relative on the NLL,
     2e-3 of the tensor scale elementwise (a near-tie at a half-rounding point may flip one
-    activation by one fp16 ulp).  Also: the mode stays within 1e-4 of the all-fp32 model."""
+    activation by one fp16 ulp).  Also: the mode stays within 1e-4 of the all-fp32 model.
+    Both formulations of the width-4 kernel: v_mfma_f32_16x16x32_f16 with the 2x2 output block on M (the default, nf_device.h
+    NF11_*) and v_mfma_f32_4x4x4_16b_f16 with a pixel per lane (NF_H16=4x4, kept as the A/B partner of tools/ab_fp16.sh)."""
     from noise_flow_amd import NoiseFlow, default_hps
+    if formulation == "4x4x4":
+        monkeypatch.setenv("NF_H16", "4x4")     # read by nf_create
     H, W = hw
     x, y = make_inputs(B, H, W, seed=16)
     m = NoiseFlow([H, W, 4], False, default_hps(), variables=shipped_variables, cnn_dtype="fp16")

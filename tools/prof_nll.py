@@ -3,6 +3,9 @@ rocprofv3 ... -- python tools/prof_nll.py [B] [n] [H] [cnn_dtype]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from noise_flow_amd import _lib as _nf_lib
+if os.environ.get("NF_TOOL_LIB"):
+    _nf_lib.LIB_PATH = os.environ["NF_TOOL_LIB"]
 from noise_flow_amd import NoiseFlow, default_hps
 from noise_flow_amd.ckpt import load_checkpoint
 from noise_flow_amd.patches import synth_patches

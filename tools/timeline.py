@@ -4,7 +4,8 @@ Needs a library built with -DNF_TIMELINE (csrc/nf_kernels.hip: thread 0 of every
 s_memrealtime counter at the phase boundaries of its first patch into the sd_out buffer):
 
     hipcc ... -DNF_TIMELINE -c nf_kernels.hip -o k_tl.o ; hipcc -shared k_tl.o nf_wide.o nf_host.o nf_train.o -o libnf_timeline.so
-    NF_TIMELINE_LIB=noise_flow_amd/csrc/libnf_timeline.so python tools/timeline.py [B] [out.json]
+    NF_TIMELINE_LIB=noise_flow_amd/csrc/libnf_timeline.so python tools/timeline.py [B] [out.json] [H] [fp32|fp16]
+(bash tools/build_variant.sh tl -DNF_TIMELINE builds one as build/variants/lib_tl.so)
 
 Stamps: 0 entry, 1 after LDS set-up (+weight image) and the first barrier, 2 inputs arrived (after the sdn layer),
 3..10 after each of the 8 couplings, 11 after the epilogue — of the workgroup's MIDDLE patch (its first when B <= grid) —, 12 kernel exit.  The library is
@@ -25,10 +26,13 @@ from noise_flow_amd.ckpt import load_checkpoint
 from noise_flow_amd.patches import synth_patches
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-out_path = sys.argv[2] if len(sys.argv) > 2 else None
+out_path = sys.argv[2] if len(sys.argv) > 2 and sys.argv[2] != "-" else None
+H = int(sys.argv[3]) if len(sys.argv) > 3 else 32
+mode = sys.argv[4] if len(sys.argv) > 4 else "fp32"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-m = NoiseFlow([32, 32, 4], False, default_hps(), variables=load_checkpoint(os.path.join(root, "models/NoiseFlow/ckpt/model.ckpt.best")))
-x, y = synth_patches(0, 0, B)
+m = NoiseFlow([H, H, 4], False, default_hps(), variables=load_checkpoint(os.path.join(root, "models/NoiseFlow/ckpt/model.ckpt.best")),
+              cnn_dtype=mode)
+x, y = synth_patches(0, 0, B, H, H)
 lib = _lib.load()
 grid = min(B, 1024)
 dbg = torch.zeros(grid * 16, dtype=torch.int64, device="cuda")
