@@ -55,6 +55,7 @@ ALGO_BYTES_PER_PATCH = 2 * 32 * 32 * 4 * 4          # read x and y once (fp32): 
 ALGO_FLOP_PER_PATCH = 5.1e6
 HBM_PEAK_GBS = 8000.0                                # MI355X_MICROARCH.md: 8 TB/s spec
 VALU_PEAK_TFLOPS = 157.3                             # fp32 vector peak = fp32-input matrix peak
+FP16_SHAPE_PEAK_TFLOPS = 248.0 / (216.0 / 512 + 16.0 / 128 + 16.0 / 32) * 2 * 1024 * 2.4e9 / 1e12   # see _fp16_cnn
 FP16_MFMA_PEAK_TFLOPS = 2500.0                       # dense fp16 matrix peak (MI355X_MICROARCH.md)
 
 
@@ -120,13 +121,18 @@ def _kernel_source_sha() -> str:
     return h.hexdigest()[:16]
 
 
-def _traffic():
+def _traffic(entry=None):
     """HBM bytes per launch from the committed PMC passes (profiles/traffic.json) — only when that file was
-    measured on THIS kernel source; otherwise null (a replayed number must not outlive its kernel)."""
+    measured on THIS kernel source; otherwise null (a replayed number must not outlive its kernel).
+    `entry` names one of the other measured launches (`configs` in the file: "sampling", "fp16_cnn_64x64")."""
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(tpath) as f:
             t = json.load(f)
+        if entry is not None:
+            t = t.get("configs", {}).get(entry)
+            if t is None:
+                return None, "profiles/traffic.json has no entry %r" % entry
         if t.get("kernel_source_sha") != _kernel_source_sha():
             return None, "profiles/traffic.json was measured on a different nf_kernels.hip (sha %s): not reported" % t.get(
                 "kernel_source_sha")
@@ -588,9 +594,20 @@ def _sampling(ctx, batches, cond, wide):
     e1.record(stream)
     torch.cuda.synchronize(dev)
     ts = time.perf_counter() - ts
+    kms = e0.elapsed_time(e1) / ks
+    tfl = ALGO_FLOP_PER_PATCH * SB / (kms * 1e-3) / 1e12
+    sbytes = 2 * 32 * 32 * 4 * 4 * SB              # reads y, writes x (eps is drawn in-kernel)
+    traffic, traffic_src = _traffic("sampling")
     return {"value": SB * ks / ts, "unit": "patches/s", "batch": SB, "steps": ks,
-            "ms_per_step": 1e3 * ts / ks, "kernel_ms": e0.elapsed_time(e1) / ks, "temp": 1.0,
-            "eps": "in-kernel Philox4x32-10", "workload": "configs[2]: inverse sampling, clean patch + fixed cam/ISO"}
+            "ms_per_step": 1e3 * ts / ks, "kernel_ms": kms, "temp": 1.0,
+            "eps": "in-kernel Philox4x32-10", "workload": "configs[2]: inverse sampling, clean patch + fixed cam/ISO",
+            # same arithmetic as the NLL direction (the Philox / Box-Muller draw is not counted): fp32 matrix = vector peak
+            "roofline": {"bound": "mfma", "achieved": tfl, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / VALU_PEAK_TFLOPS,
+                         "traffic": traffic, "traffic_source": traffic_src, "time_base": "HIP events over the timed launches",
+                         "kernel": "nf_flow_kernel<4,256,4,true,true,true,0,false>", "kernel_ms": kms,
+                         "algorithmic_flop_per_launch": ALGO_FLOP_PER_PATCH * SB,
+                         "hbm": {"achieved": sbytes / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": sbytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": sbytes}}}
 
 
 def _time_nll(model, x, y, cond, n, dev):
@@ -632,10 +649,26 @@ def _fp16_cnn(ctx, batches, cond, wide):
     ms16, _ = _time_nll(m16, x16, y16, cond, k16, dev)
     bytes16 = 2 * 64 * 64 * 4 * 4 * B16
     flop16 = 4 * ALGO_FLOP_PER_PATCH * B16
+    tfl16 = flop16 / (ms16 * 1e-3) / 1e12
+    traffic, traffic_src = _traffic("fp16_cnn_64x64")
+    old = os.environ.get("NF_H16") == "4x4"
     return {"workload": "configs[4] shape: forward NLL, 64x64x4 patches, fp16 coupling CNN "
-                        "(v_mfma_f32_4x4x4_16b_f16, fp32 accumulate + fp32 log-det), fp32 I/O, 1 GPU",
+                        "(%s, fp32 accumulate + fp32 log-det), fp32 I/O, 1 GPU"
+                        % ("v_mfma_f32_4x4x4_16b_f16" if old else "v_mfma_f32_16x16x32_f16 for the 3x3 convs"),
             "batch": B16, "steps": k16, "kernel_ms": ms16, "value": B16 / (ms16 * 1e-3), "unit": "patches/s",
-            "pixels_per_s": B16 * 4096 / (ms16 * 1e-3), "algorithmic_tflops": flop16 / (ms16 * 1e-3) / 1e12,
+            "pixels_per_s": B16 * 4096 / (ms16 * 1e-3), "algorithmic_tflops": tfl16,
+            "roofline": {"bound": "mfma", "achieved": tfl16, "peak": FP16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl16 / FP16_MFMA_PEAK_TFLOPS,
+                         "traffic": traffic, "traffic_source": traffic_src, "time_base": "HIP events over the timed launches",
+                         "kernel": "nf_flow_kernel<4,1024,4,false,true,true,%d,false>" % (1 if old else 2), "kernel_ms": ms16,
+                         "algorithmic_flop_per_launch": flop16,
+                         # the peak of the instructions this kernel actually issues: per pixel and coupling 216 MAC (l_1, l_last) on
+                         # v_mfma_f32_16x16x32_f16 (512 MAC/clk/SIMD = the dense fp16 rate), 16 (l_2) on v_mfma_f32_4x4x4_16b_f16 (128),
+                         # 16 (the fp32 1x1 mix) on v_mfma_f32_4x4x1_16b_f32 (32): 248 MAC in 1.047 clk
+                         "shape_peak": {"peak": FP16_SHAPE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl16 / FP16_SHAPE_PEAK_TFLOPS,
+                                        "note": "MAC-weighted rate of the three matrix instructions of the kernel at 1024 SIMDs x 2.4 GHz; "
+                                                "the fp32 mix alone is half of that time"},
+                         "hbm": {"achieved": bytes16 / (ms16 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": bytes16 / (ms16 * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bytes16}},
             "hbm": {"achieved": bytes16 / (ms16 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": bytes16 / (ms16 * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bytes16}}
 

@@ -815,6 +815,7 @@ struct Built {
     NfProgram prog3;             // fp16-CNN layout (NF_CFG_FP16_CNN), width 4 only
     std::vector<float> block3;
     bool fp16_big = false;       // block3 is the NF11_* layout (v_mfma_f32_16x16x32_f16) instead of NF3_* (4x4x4)
+    int raw_width = 4;           // coupling width of the model's variables; prog.width is the (zero-padded) width the kernels run
     NfProgram prog4;             // wide-CNN layout (NF4_*), width 32 (8 / 16 zero-padded on large patches)
     std::vector<float> block4;
     NfProgram prog5;             // wide-CNN fp16 layout (NF5_*): NF_CFG_FP16_CNN at widths 8 / 16 / 32
@@ -917,7 +918,7 @@ int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float
         int slot = 0;           // conditioning slot of SDN / SCALE_COND items
     };
     std::vector<Item> items;
-    int width = 0;
+    int width = 0, raw_width = 0;   // width of the kernels' layouts / of the model's variables (differ when zero-padded)
     out.ld_const = 0.0;
     out.has_sdn = false;
     out.cond.clear();
@@ -954,20 +955,43 @@ int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float
             it.type = NF_OP_MIX;
             break;
         case NF_LAYER_COUPLING: {
-            if (L.width != 4 && L.width != 8 && L.width != 16 && !(L.width >= 32 && L.width <= 512))
-                return fail(NF_EINVAL, "layer %d: coupling width %d unsupported (4, 8, 16, 32 .. 512)", li, L.width);
+            if (L.width < 1 || L.width > 512)
+                return fail(NF_EINVAL, "layer %d: coupling width %d unsupported (1 .. 512)", li, L.width);
+            // layers.py:452-498 takes any width; the kernels exist for 4 / 8 / 16 / 32 and, zero-padded inside their layouts, 33 .. 512.
+            // Widths in between run on the next kernel up, zero-padded HERE: a hidden channel with zero weights and zero bias is
+            // relu(0) = 0 in both hidden layers and contributes nothing to l_2 / l_last — exact.
+            const int wk = L.width > 32 ? L.width : L.width <= 4 ? 4 : L.width <= 8 ? 8 : L.width <= 16 ? 16 : 32;
             if (L.width > 32 && out.tiled)
                 return fail(NF_EINVAL, "layer %d: patches beyond 64x64 (%dx%d given) are evaluated at coupling widths up to 32", li, cfg->height,
                             cfg->width);
             if (L.width > 32 && !nf_gemm_shape_ok(th, tw))
                 return fail(NF_EINVAL, "layer %d: coupling width %d covers patches of up to %d pixels (%dx%d given)", li, L.width,
                             NF7_MAX_PIXELS, cfg->height, cfg->width);
-            if (width && width != L.width) return fail(NF_EINVAL, "all coupling layers must share one width");
-            width = L.width;
+            if (raw_width && raw_width != L.width) return fail(NF_EINVAL, "all coupling layers must share one width");
+            raw_width = L.width;
+            width = wk;
             it.type = NF_OP_COUPLING_FWD;
-            it.w = L.width;
-            it.blk.assign(nf_cpl_size(L.width), 0.0f);
-            fold_coupling(p, L.width, it.blk.data());
+            it.w = wk;
+            it.blk.assign(nf_cpl_size(wk), 0.0f);
+            if (wk == L.width) {
+                fold_coupling(p, L.width, it.blk.data());
+            } else {
+                const int w = L.width;
+                std::vector<float> f(nf_cpl_size(w));
+                fold_coupling(p, w, f.data());
+                float *o = it.blk.data();
+                memcpy(o + nf_cpl_off_E(wk), f.data() + nf_cpl_off_E(w), 64 * sizeof(float));
+                for (int tap = 0; tap < 9; ++tap) {
+                    memcpy(o + nf_cpl_off_W3(wk) + tap * wk * 4, f.data() + nf_cpl_off_W3(w) + tap * w * 4, (size_t)w * 4 * sizeof(float));
+                    for (int c = 0; c < 2; ++c)
+                        memcpy(o + nf_cpl_off_W1(wk) + (tap * 2 + c) * wk, f.data() + nf_cpl_off_W1(w) + (tap * 2 + c) * w, (size_t)w * sizeof(float));
+                }
+                memcpy(o + nf_cpl_off_B1(wk), f.data() + nf_cpl_off_B1(w), (size_t)w * sizeof(float));
+                memcpy(o + nf_cpl_off_B2(wk), f.data() + nf_cpl_off_B2(w), (size_t)w * sizeof(float));
+                for (int i = 0; i < w; ++i)
+                    memcpy(o + nf_cpl_off_W2(wk) + i * wk, f.data() + nf_cpl_off_W2(w) + i * w, (size_t)w * sizeof(float));
+                memcpy(o + nf_cpl_off_S(wk), f.data() + nf_cpl_off_S(w), 4 * sizeof(float));
+            }
             break;
         }
         case NF_LAYER_SDN5:
@@ -1026,6 +1050,7 @@ int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float
 
     memset(&out.prog, 0, sizeof(out.prog));
     out.prog.width = width ? width : 4;
+    out.raw_width = raw_width ? raw_width : 4;
     out.block.clear();
     for (Item *it : order) {
         NfOp &op = out.prog.ops[out.prog.n_ops++];
@@ -2022,6 +2047,8 @@ static int bs_sync(nf_handle *h, double *stats, int nvals, hipStream_t st)
 static int run_batchstats(nf_handle *h, int direction, NfLaunch a, float *moments_out, hipStream_t st)
 {
     if (h->cfg.flags & NF_CFG_FP16_CNN) return fail(NF_EINVAL, "batch-statistics mode is fp32 only");
+    if (h->fwd.raw_width != h->fwd.prog.width)
+        return fail(NF_EINVAL, "batch-statistics mode covers the coupling widths 4 / 8 / 16 / 32 (the model has %d)", h->fwd.raw_width);
     // images beyond 64x64 (nf_device.h, "overlapping tiles"): the width-4 matrix-core schedule below, every launch tiled with
     // ONE halo for the whole call — 3 = the deepest launch (re-run coupling c-1, then l_1 of coupling c for its statistics) —
     // so that the tile grid, and with it the per-thread log-det carry, is the same in every launch

@@ -81,6 +81,18 @@ class GradOracle:
         self.kink_ulps = 32.0          # see _relu
         self.kinks = []                # filled by forward(): activations within kink_ulps of their ReLU kink
         self.relu_flips = set()        # {(site, flat index)}: take the other ReLU branch there
+        self._bcasts = []              # (u, u expanded) of every broadcast parameter-derived value (see _bc)
+        self._convs = []               # (weight name, bias name, |input|, conv output, padding) of every convolution
+
+    def _bc(self, u, like):
+        """`u` (a value computed from variables: a scalar, a per-channel vector (1,C,1,1), a 4x4 matrix) broadcast against
+        `like`, as an explicit expanded tensor whose gradient can be asked for: element e of that gradient is the TERM the
+        element contributes to d loss / d u, and sum_e |term_e| is what the round-off of any fp32 evaluation of that sum
+        scales with (loss_and_grads -> grad_abs_terms).  Numerically the identity."""
+        shape = like if isinstance(like, (tuple, list, torch.Size)) else like.shape
+        ue = u.expand(*shape)
+        self._bcasts.append((u, ue))
+        return ue
 
     # -- pieces -----------------------------------------------------------------------------
     def _A(self, i):
@@ -160,11 +172,13 @@ class GradOracle:
         g = lambda k: self.t[t + k]
         w1 = g("l_1/W").permute(3, 2, 0, 1)
         h = F.conv2d(z0, w1, g("l_1/b").reshape(-1), padding=1)           # layers.py:469
+        self._convs.append((t + "l_1/W", t + "l_1/b", z0.detach().abs(), h, 1))
         with torch.no_grad():
             amp = F.conv2d(z0.abs(), w1.abs(), g("l_1/b").reshape(-1).abs(), padding=1)
         a1, err1 = self._relu(self._bn_train(h, t, 1, new_running), h, amp, (i, 1))
         w2 = g("l_2/W").reshape(g("l_2/W").shape[-2], g("l_2/W").shape[-1]).t()[:, :, None, None]
         h = F.conv2d(a1, w2, g("l_2/b").reshape(-1))                      # :480
+        self._convs.append((t + "l_2/W", t + "l_2/b", a1.detach().abs(), h, 0))
         with torch.no_grad():
             amp = F.conv2d(a1.abs(), w2.abs(), g("l_2/b").reshape(-1).abs())
             err2 = F.conv2d(err1, w2.abs())
@@ -177,7 +191,8 @@ class GradOracle:
         e[:, :, :, -1] = 1
         w3 = g("l_last/W").permute(3, 2, 0, 1)
         o = F.conv2d(torch.cat([hp, e], 1), w3, g("l_last/b").reshape(-1))   # :665-670
-        o = o * torch.exp(g("l_last/logs").reshape(1, -1, 1, 1) * LOGSCALE_FACTOR)   # :671-673
+        self._convs.append((t + "l_last/W", t + "l_last/b", torch.cat([hp, e], 1).detach().abs(), o, 0))
+        o = o * self._bc(torch.exp(g("l_last/logs").reshape(1, -1, 1, 1) * LOGSCALE_FACTOR), o)   # :671-673
         c2 = o.shape[1] // 2
         return o[:, :c2], o[:, c2:]
 
@@ -192,7 +207,7 @@ class GradOracle:
         gain = torch.exp(c * g * cp[2]) * float(iso)
         b1 = torch.exp(c * self.t["model/sdn_gain/beta1"].reshape(-1)[0] * cp[0])
         b2 = torch.exp(c * self.t["model/sdn_gain/beta2"].reshape(-1)[0] * cp[1])
-        return torch.sqrt(b1 * y / gain + b2)
+        return torch.sqrt(self._bc(b1, y) * y / self._bc(gain, y) + self._bc(b2, y))
 
     def _table(self, fmt, iso):
         """Entry of a per-ISO variable table: ISO 100..3200, anything else -> the ISO-800 entry (cond_utils.py:69-88)."""
@@ -211,15 +226,16 @@ class GradOracle:
             gain = torch.exp(c * g * cp) * float(iso)
             b1 = torch.exp(c * self.t["model/sdn_gain/beta1"].reshape(-1)[0])
             b2 = torch.exp(c * self.t["model/sdn_gain/beta2"].reshape(-1)[0])
-            return torch.sqrt(b1 * y / gain + b2)
+            return torch.sqrt(self._bc(b1, y) * y / self._bc(gain, y) + self._bc(b2, y))
         b1 = torch.sigmoid(self.t["model/b1"].reshape(-1)[0])
         b2 = torch.sigmoid(self.t["model/b2"].reshape(-1)[0])
+        b1, b2 = self._bc(b1, y), self._bc(b2, y)
         if kind == "sdn":
             return torch.sqrt(b1 * y + b2)
         if kind == "sdn1":
-            gain = torch.exp(1e-2 * self._table("model/r_gain_param_%05d", iso)) * float(iso)
+            gain = self._bc(torch.exp(1e-2 * self._table("model/r_gain_param_%05d", iso)) * float(iso), y)
             return torch.sqrt(b1 * y / gain + b2)
-        gain = torch.exp(1e-1 * self._table("model/gain_param_%05d", iso)) * float(iso)
+        gain = self._bc(torch.exp(1e-1 * self._table("model/gain_param_%05d", iso)) * float(iso), y)
         if kind == "sdn2":
             return torch.sqrt(gain * (b1 * y / gain + b2))
         return gain * torch.sqrt(b1 * y / gain + b2)
@@ -247,12 +263,12 @@ class GradOracle:
                 mix = self._A(i)
                 if mix is not None:
                     A, lad = mix
-                    z = torch.einsum("bchw,ck->bkhw", z, A)               # layers.py:117-130
-                    obj = obj + H * W * lad
+                    z = torch.einsum("bchw,bhwck->bkhw", z, self._bc(A, (B, H, W, C, C)))   # layers.py:117-130
+                    obj = obj + H * W * self._bc(lad, obj)
                 c2 = C // 2
                 z0, z1 = z[:, :c2], z[:, c2:]
                 shift, raw = self._cnn(z0, i, new_running)
-                ls = self.t["level0/bijector%d/rescaling_scale0" % i].reshape(()) * torch.tanh(raw)
+                ls = self._bc(self.t["level0/bijector%d/rescaling_scale0" % i].reshape(()), raw) * torch.tanh(raw)
                 z = torch.cat([z0, z1 * torch.exp(ls) + shift], 1)        # layers.py:355-375
                 obj = obj + ls.sum(dim=(1, 2, 3))
             elif lyr == "sdn5":
@@ -262,23 +278,23 @@ class GradOracle:
             elif lyr == "sdn4":                                           # cond_utils.py:178-202
                 ks = [k for k, v in enumerate(O.ISO_VALS) if float(v) == float(iso)]
                 gp = self.t["model/sdn_gain/gain_params"].reshape(-1)[ks[0]] if ks else torch.zeros((), dtype=self.dt)
-                gain = torch.exp(gp) * float(iso)
-                scale = torch.sqrt(torch.exp(self.t["model/sdn_gain/beta1"].reshape(-1)[0]) * yt / gain
-                                   + torch.exp(self.t["model/sdn_gain/beta2"].reshape(-1)[0]))
+                gain = self._bc(torch.exp(gp) * float(iso), yt)
+                scale = torch.sqrt(self._bc(torch.exp(self.t["model/sdn_gain/beta1"].reshape(-1)[0]), yt) * yt / gain
+                                   + self._bc(torch.exp(self.t["model/sdn_gain/beta2"].reshape(-1)[0]), yt))
                 z = z / scale
                 obj = obj - torch.log(scale).sum(dim=(1, 2, 3))
             elif lyr == "gain4":
                 g = self.t["model/sdn_gain/gain_val"].reshape(-1)[0]
-                z = z / g
-                obj = obj - C * H * W * torch.log(g)
+                z = z / self._bc(g, z)
+                obj = obj - C * H * W * torch.log(self._bc(g, obj))
             elif lyr in ("sdn", "sdn1", "sdn2", "sdn3", "sdn6"):
                 scale = self._sdn_other_scale(lyr, yt, iso, cam)
                 z = z / scale
                 obj = obj - torch.log(scale).sum(dim=(1, 2, 3))
             elif lyr in ("gain", "gain1", "gain2", "gain3"):
                 s, full = self._gain_other_scale(lyr, iso)
-                z = z / s
-                obj = obj - (C * H * W if full else 1) * torch.log(s)     # GainEx2: the full sum; Gain / Ex1 / Ex3: once per patch
+                z = z / self._bc(s, z)
+                obj = obj - (C * H * W if full else 1) * torch.log(self._bc(s, obj))     # GainEx2: the full sum; Gain / Ex1 / Ex3: once per patch
             else:
                 raise ValueError("unknown layer %r" % lyr)
         logp = (-0.5 * (np.log(2 * np.pi) + z * z)).sum(dim=(1, 2, 3))
@@ -292,26 +308,63 @@ class GradOracle:
         the activations that sit on their ReLU kink (see _relu); `relu_flips` takes the other branch at some of them."""
         self.relu_flips = set((tuple(s), int(k)) for s, k in relu_flips)
         self.kinks = []
+        self._bcasts, self._convs = [], []
         for v in self.t.values():
             if v.grad is not None:
                 v.grad = None
         loss, sd_z, new_running = self.forward(x, y, iso, cam)
         # d loss / d theta = (gradient of the log-det part) + (gradient of the prior part).  Near the optimum the two cancel
         # (that IS the optimality condition: e.g. d/d gain of  -sum log s  against  sum z^2 / 2), so a gradient can be 1e-4 of
-        # the terms it is the sum of — and no fp32 evaluation resolves it better than ~1e-7 of THOSE.  self.grad_terms[name] =
-        # max |part a| + |part b| gives the comparison that scale.
-        leaves = [v for v in self.t.values() if v.requires_grad]
-        ga = torch.autograd.grad(self._parts[0], leaves, retain_graph=True, allow_unused=True)
-        gb = torch.autograd.grad(self._parts[1], leaves, allow_unused=True)
-        grads, self.grad_terms = {}, {}
-        it = iter(zip(ga, gb))
-        for k, v in self.t.items():
-            if v.requires_grad:
-                a, b = next(it)
-                a = torch.zeros_like(v) if a is None else a
-                b = torch.zeros_like(v) if b is None else b
-                grads[k] = (a + b).numpy().reshape(self.shapes[k]).copy()
-                self.grad_terms[k] = float((a.abs() + b.abs()).max())
+        # the terms it is the sum of — and no fp32 evaluation resolves it better than ~1e-7 of THOSE.
+        #   self.grad_abs_terms[name]  = per entry, sum_e |term_e| over the batch x pixel elements whose contributions the
+        #                                entry is the sum of, the two parts counted separately: the scale the round-off of ANY
+        #                                fp32 evaluation of that sum goes with, computed here in fp64 from the model and the
+        #                                input alone (the tests' noise allowance: c * 2^-24 * this — nothing a kernel computes)
+        #   self.grad_terms[name]      = max |part a| + |part b| (coarser, kept for reference)
+        names = [k for k, v in self.t.items() if v.requires_grad]
+        leaves = [self.t[k] for k in names]
+        self._bcasts = [(u, ue) for u, ue in self._bcasts if ue.requires_grad]     # constants (a channel permutation) have no terms
+        probes = [ue for _, ue in self._bcasts] + [o for (_, _, _, o, _) in self._convs]
+        nb = len(self._bcasts)
+        ga_all = torch.autograd.grad(self._parts[0], leaves + probes, retain_graph=True, allow_unused=True)
+        gb_all = torch.autograd.grad(self._parts[1], leaves + probes, retain_graph=True, allow_unused=True)
+        zero = lambda g, ref: torch.zeros_like(ref) if g is None else g   # noqa: E731
+        terms = {k: torch.zeros_like(v) for k, v in zip(names, leaves)}
+        # (i) broadcast values: |d u_i / d theta| x sum_e |term_e(u_i)|
+        for j, (u, ue) in enumerate(self._bcasts):
+            ta = zero(ga_all[len(leaves) + j], ue).abs() + zero(gb_all[len(leaves) + j], ue).abs()
+            while ta.dim() > u.dim():                       # sum over the broadcast dimensions: leading ones first ...
+                ta = ta.sum(dim=0)
+            for d in range(u.dim()):                        # ... then the size-1 dimensions of u
+                if u.shape[d] == 1 and ta.shape[d] != 1:
+                    ta = ta.sum(dim=d, keepdim=True)
+            if not u.requires_grad:
+                continue
+            uf, tf = u.reshape(-1), ta.reshape(-1)
+            for i in range(uf.numel()):
+                if float(tf[i]) == 0.0:
+                    continue
+                gi = torch.autograd.grad(uf[i], leaves, retain_graph=True, allow_unused=True)
+                for k, g in zip(names, gi):
+                    if g is not None:
+                        terms[k] = terms[k] + g.abs() * tf[i]
+        # (ii) convolutions: d/dW[k][j] = sum_{b,p} in[b, p + tap, k] * gout[b, p, j]  ->  the same sum over |in| |gout|
+        for c, (wn, bn, ain, o, pad) in enumerate(self._convs):
+            gout = zero(ga_all[len(leaves) + nb + c], o).abs() + zero(gb_all[len(leaves) + nb + c], o).abs()
+            W = self.t[wn]
+            kh, kw = (W.shape[0], W.shape[1]) if W.dim() == 4 else (1, 1)
+            tw = torch.nn.grad.conv2d_weight(ain, (gout.shape[1], ain.shape[1], kh, kw), gout, padding=pad)   # [out, in, kh, kw]
+            if W.dim() == 4:
+                terms[wn] = terms[wn] + tw.permute(2, 3, 1, 0).reshape(W.shape)
+            else:
+                terms[wn] = terms[wn] + tw[:, :, 0, 0].t().reshape(W.shape)
+            terms[bn] = terms[bn] + gout.sum(dim=(0, 2, 3)).reshape(self.t[bn].shape)
+        grads, self.grad_terms, self.grad_abs_terms = {}, {}, {}
+        for k, v, a, b in zip(names, leaves, ga_all, gb_all):
+            a, b = zero(a, v), zero(b, v)
+            grads[k] = (a + b).detach().numpy().reshape(self.shapes[k]).copy()
+            self.grad_terms[k] = float((a.abs() + b.abs()).max())
+            self.grad_abs_terms[k] = terms[k].detach().numpy().reshape(self.shapes[k]).copy()
         return float(loss.detach()), float(sd_z.detach()), grads, new_running
 
 

@@ -125,6 +125,35 @@ def test_folding_matches_oracle(shipped_variables, width):
             np.testing.assert_allclose(blk_r[off:off + 16].reshape(4, 4), L["A_inv"] * gain_before[L["name"]], rtol=2e-7, atol=1e-9)
 
 
+@pytest.mark.parametrize("width,padded", [(1, 4), (3, 4), (5, 8), (12, 16), (24, 32), (31, 32)])
+def test_in_between_widths_fold_zero_padded_onto_the_next_kernel_width(width, padded):
+    """layers.py:452-498 takes any width; the kernels exist for 4 / 8 / 16 / 32: a width in between is folded into the next
+    layout up with zero weights / biases for the extra hidden channels (relu(0) = 0 in both hidden layers: exact).  The
+    padded block must equal the fold of the same model with its variables zero-extended to the padded width."""
+    arch = "unc|gain4|unc|sdn5"
+    v = trained_like_variables(arch, width, seed=3 * width)
+    ops, blk, ld = _fold(arch, v, width, 0)
+    vp = {}
+    for k, a in v.items():
+        a = np.asarray(a)
+        if k.endswith("l_1/W"):
+            b = np.zeros(a.shape[:3] + (padded,), np.float32); b[..., :width] = a
+        elif k.endswith("l_2/W"):
+            b = np.zeros(a.shape[:2] + (padded, padded), np.float32); b[..., :width, :width] = a
+        elif k.endswith("l_last/W"):
+            b = np.zeros(a.shape[:2] + (padded + 1, 4), np.float32); b[:, :, :width] = a[:, :, :width]; b[:, :, padded] = a[:, :, width]
+        elif (k.endswith("l_1/b") or k.endswith("l_2/b") or k.endswith("/mean")) and a.shape[-1] == width:
+            b = np.zeros(padded, np.float32); b[:width] = a
+        elif k.endswith("/var") and a.shape[-1] == width:
+            b = np.ones(padded, np.float32); b[:width] = a
+        else:
+            b = a
+        vp[k] = b
+    ops_p, blk_p, ld_p = _fold(arch, vp, padded, 0)
+    assert ops == ops_p and ld == ld_p and blk.shape == blk_p.shape
+    np.testing.assert_array_equal(blk, blk_p)
+
+
 def test_secondary_layers_fold_to_conditional_slots():
     from noise_flow_amd import _lib
     v = trained_like_variables("sdn4|unc|gain|sdn", 4)

@@ -32,6 +32,13 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     # the parity leg ran (rank 0, N = 1): GPU mean NLL within tolerance of the fp64 oracle
     assert d["nll_check"]["max_rel_err_per_patch"] <= d["nll_check"]["tolerance"]
     assert d["sampling"]["value"] > 0 and d["training"]["value"] > 0 and d["two_streams"]["value"] > 0
+    # every measured BASELINE config carries the same roofline block as the headline (configs[2] sampling, configs[4] fp16 CNN)
+    for sec in ("sampling", "fp16_cnn_64x64"):
+        rr = d[sec]["roofline"]
+        for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "kernel_ms", "traffic", "hbm"):
+            assert k in rr, (sec, k)
+        assert abs(rr["frac"] - rr["achieved"] / rr["peak"]) < 1e-9 and 0 < rr["hbm"]["frac"] < 1
+    assert d["fp16_cnn_64x64"]["roofline"]["peak"] == 2500.0 and d["fp16_cnn_64x64"]["roofline"]["shape_peak"]["frac"] > 0
     w512 = d["wide_cnn"]["w512"]     # Glow's default width (sidd/ArgParser.py:43) on the LDS-staged GEMM kernel
     assert w512["finite"] and w512["value"] > 0 and "nf_gemm_kernel" in w512["kernel_path"] and w512["roofline"]["frac"] > 0.3
     lp = d["large_patches"]          # 256x256 images as overlapping tiles

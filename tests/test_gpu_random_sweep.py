@@ -265,11 +265,8 @@ def test_random_model_training_gradients(seed):
     grads, loss = tr.forward_backward(x, y, [0.0], [0.0], [iso], [cam])
     lv = loss.cpu().numpy()
     got = tr.raw_to_variables(grads.cpu().numpy())
-    # the step's own fp32 summation-order noise on this input: the same step on the other kernel paths (conftest.py)
-    from conftest import other_kernel_path_gradients
-    alt = other_kernel_path_gradients(lambda: Trainer([H, W, 4], default_hps(arch=arch, width=width, flow_permutation=fp, decomp=decomp),
-                                                      variables=v, optim="adam", max_batch=16), x, y, iso, cam)
-    noise = {nm: float(np.abs(np.asarray(alt[nm], np.float64) - np.asarray(got[nm], np.float64)).max()) for nm in names}
+    go = GradOracle(arch, v, flow_permutation=fp, decomp=decomp)
+    from conftest import grad_noise_allowance
     sd_rtol = 1e-5 if min_var >= 1e-6 else 5e-5     # sd_z = sqrt(E z^2 - (E z)^2) of nearly constant latents cancels too
 
     def compare(ref_loss, ref_sd, ref_grads):
@@ -284,8 +281,10 @@ def test_random_model_training_gradients(seed):
             if nm.endswith("l_1/b") or nm.endswith("l_2/b"):      # analytically zero (BN subtracts the batch mean)
                 assert np.abs(g).max() <= 2e-5 * gmax, (nm, np.abs(g).max(), gmax)
             else:
-                tol = max(rtol * max(np.abs(ref).max(), 1e-6 * gmax), 4.0 * noise[nm])
-                assert np.abs(g - ref).max() <= tol, (nm, np.abs(g - ref).max(), np.abs(ref).max(), noise[nm])
+                # rtol of the tensor's scale, or the round-off allowance of the sum the entry is — computed by the fp64 oracle
+                # for the evaluation being compared (conftest.py::grad_noise_allowance), not by a second GPU run
+                tol = np.maximum(rtol * max(np.abs(ref).max(), 1e-6 * gmax), grad_noise_allowance(go, nm).reshape(ref.shape))
+                assert (np.abs(g - ref) <= tol).all(), (nm, np.abs(g - ref).max(), np.abs(ref).max(), float(np.max(tol)))
 
     # The loss is piecewise smooth: an activation within float32 round-off of a ReLU kink takes one branch in the fp64
     # oracle and possibly the other on the GPU, and the gradients upstream then differ by that one activation's path.  ONE
@@ -293,7 +292,7 @@ def test_random_model_training_gradients(seed):
     # of the sum that produced them, and only the other branch at (a subset of) those is accepted — conftest.py.
     from conftest import grads_match_up_to_kinks
     try:
-        excused = grads_match_up_to_kinks(GradOracle(arch, v, flow_permutation=fp, decomp=decomp), x, y, iso, cam, compare,
+        excused = grads_match_up_to_kinks(go, x, y, iso, cam, compare,
                                           max_kinks=48 if min_var >= 1e-6 else 0, got=got)
     except AssertionError as e:
         raise AssertionError("%s: %s" % (case, e))

@@ -31,9 +31,10 @@ def _grad_oracle(arch, variables):
     return GradOracle(arch, variables)
 
 
-def _check_grads(tr, grads_dev, ref_grads, loss_scale=1.0, rtol=GRAD_RTOL, noise=None):
-    """`noise` (optional, {name: float}): the step's own fp32 summation-order noise on this input (conftest.py::
-    other_kernel_path_gradients); a tensor may be 4 x that away from the oracle when that exceeds rtol of its scale."""
+def _check_grads(tr, grads_dev, ref_grads, loss_scale=1.0, rtol=GRAD_RTOL, oracle=None):
+    """`oracle` (optional): the GradOracle whose evaluation `ref_grads` is; an entry may then also be within the round-off
+    allowance of the sum it is (conftest.py::grad_noise_allowance — a bound the fp64 oracle computes, not a second GPU run)."""
+    from conftest import grad_noise_allowance
     got = tr.raw_to_variables(grads_dev.cpu().numpy())
     from oracle.nf_grad_oracle import is_trainable
     from noise_flow_amd import params as P
@@ -52,8 +53,10 @@ def _check_grads(tr, grads_dev, ref_grads, loss_scale=1.0, rtol=GRAD_RTOL, noise
             assert np.abs(g).max() <= 1e-5 * gmax, (nm, np.abs(g).max(), gmax)
         else:
             floor = 1e-6 * gmax
-            tol = max(rtol * max(scale, floor), 4.0 * (noise or {}).get(nm, 0.0))
-            assert np.abs(g - ref).max() <= tol, (nm, np.abs(g - ref).max(), scale)
+            tol = rtol * max(scale, floor)
+            if oracle is not None:
+                tol = np.maximum(tol, grad_noise_allowance(oracle, nm).reshape(ref.shape))
+            assert (np.abs(g - ref) <= tol).all(), (nm, np.abs(g - ref).max(), scale, np.max(tol))
         checked += ref.size
     return checked
 
@@ -102,18 +105,16 @@ def _oracle_check_next_to_kinks(tr, arch, v, x, y, iso, cam, width, rtol=GRAD_RT
     the GPU.  The oracle names exactly those activations (margin < 32 units of the round-off of the sum that produced them)
     and `grads_match_up_to_kinks` accepts the other branch at those and nowhere else; the number it had to excuse is
     returned (0 on almost every input)."""
-    from conftest import grads_match_up_to_kinks, other_kernel_path_gradients
+    from conftest import grads_match_up_to_kinks
     grads, loss = tr.forward_backward(x, y, [0.0], [0.0], [iso], [cam])
     lv = loss.cpu().numpy()
-    got = tr.raw_to_variables(grads.cpu().numpy())
-    alt = other_kernel_path_gradients(lambda: _trainer(arch, v, tuple(tr.x_shape), width, max_batch=max(64, len(x))), x, y, iso, cam)
-    noise = {nm: float(np.abs(np.asarray(alt[nm], np.float64) - np.asarray(got[nm], np.float64)).max()) for nm in got if nm in alt}
+    o = _grad_oracle(arch, v)
 
     def compare(ref_loss, ref_sd, ref_grads):
         assert abs(lv[0] - ref_loss) <= 1e-5 * abs(ref_loss)
         assert abs(lv[1] - ref_sd) <= 1e-5 * ref_sd
-        _check_grads(tr, grads, ref_grads, rtol=rtol, noise=noise)
-    excused = grads_match_up_to_kinks(_grad_oracle(arch, v), x, y, iso, cam, compare)
+        _check_grads(tr, grads, ref_grads, rtol=rtol, oracle=o)     # o.grad_abs_terms belongs to the evaluation being compared
+    excused = grads_match_up_to_kinks(o, x, y, iso, cam, compare)
     assert excused <= 1, excused
     return excused
 
@@ -752,3 +753,32 @@ def test_wide_filter_gradients_fused_into_the_stage_kernels(monkeypatch):
         assert np.allclose(l, l0, rtol=1e-6, atol=0), (mode, l, l0)
         assert np.abs(g - g0).max() <= 1e-5 * np.abs(g0).max(), (mode, np.abs(g - g0).max(), np.abs(g0).max())
     assert not np.array_equal(res["127"][0], res["4095"][0])      # the fused path really is another code path
+
+
+def test_round_off_allowance_where_a_gradient_cancels():
+    """The one place the gradient comparison needs more than a relative tolerance, and what grants it: a gain layer AT its
+    optimum (gain_val solved for on the fp64 oracle), where d loss / d gain = 0.016 is the remainder of per-element terms that
+    add up to 6.8e5 in magnitude.  No fp32 evaluation resolves that to 2e-4 of itself; it is resolved to a few 2^-24 of the
+    terms.  The allowance (conftest.py::grad_noise_allowance) is computed by the fp64 oracle alone.  Checked here: both kernel
+    paths of the trainer are within it, so is their distance from each other (two summation orders of the same arithmetic), and
+    it is not vacuous — within three orders of magnitude of the distances actually observed."""
+    from conftest import grad_noise_allowance, other_kernel_path_gradients
+    arch, key = "sdn5|gain4|unc", "model/sdn_gain/gain_val"
+    v = trained_like_variables(arch, 4, seed=2)
+    v[key] = np.asarray([0.016486794], np.float32)
+    x, y = make_inputs(8, 32, 32, seed=5)
+    o = _grad_oracle(arch, v)
+    ref_loss, _, ref_grads, _ = o.loss_and_grads(x, y, 800, 2)
+    ref = float(np.asarray(ref_grads[key]).reshape(-1)[0])
+    terms = float(np.asarray(o.grad_abs_terms[key]).reshape(-1)[0])
+    allow = float(grad_noise_allowance(o, key).reshape(-1)[0])
+    assert abs(ref) < 1e-6 * terms and allow < 2e-6 * terms           # the case is what it is meant to be
+    tr = _trainer(arch, v, (32, 32, 4), 4)
+    grads, loss = tr.forward_backward(x, y, [0.0], [0.0], [800], [2])
+    a = float(np.asarray(tr.raw_to_variables(grads.cpu().numpy())[key]).reshape(-1)[0])
+    b = float(np.asarray(other_kernel_path_gradients(lambda: _trainer(arch, v, (32, 32, 4), 4), x, y, 800, 2)[key]).reshape(-1)[0])
+    assert abs(loss.cpu().numpy()[0] - ref_loss) <= 1e-5 * abs(ref_loss)
+    seen = max(abs(a - ref), abs(b - ref), abs(a - b))
+    assert abs(a - ref) <= allow and abs(b - ref) <= allow and abs(a - b) <= allow, (a, b, ref, allow)
+    assert seen > 0 and allow <= 1000.0 * seen, (a, b, ref, allow, seen)
+    _check_grads(tr, grads, ref_grads, oracle=o)                      # and every other tensor of the step at the usual tolerance

@@ -173,3 +173,34 @@ def test_wide_fp16_cnn_mode(width, hw):
     eps = np.random.RandomState(3).randn(4, H, W, 4).astype(np.float32)
     _close_elem(m.sample(y, 0.6, y, [0.0], [0.0], [100], [2], eps=eps), o16.sample(eps, 0.6, y, 100, 2), rtol=2e-3)
     np.testing.assert_allclose(nll, NoiseFlowOracle(ARCH, v).nll(x, y, 100, 2)[0], rtol=2e-4)
+
+
+@pytest.mark.parametrize("width,hw,dt", [(1, (8, 8), "fp32"), (3, (32, 32), "fp32"), (5, (32, 32), "fp32"), (6, (20, 28), "fp32"),
+                                         (12, (32, 32), "fp32"), (24, (32, 32), "fp32"), (24, (64, 64), "fp32"), (31, (40, 50), "fp32"),
+                                         (24, (32, 32), "fp16"), (5, (32, 32), "fp16"), (12, (100, 70), "fp32")])
+def test_coupling_widths_between_the_kernel_widths(width, hw, dt):
+    """layers.py:452-498 takes any width; the kernels exist for 4 / 8 / 16 / 32 (and 33 .. 512): a width in between runs on the
+    next one up with the extra hidden channels zero-padded at nf_create (exact: relu(0) = 0 in both hidden layers).  Every
+    kernel family the padding lands on, fp32 and the fp16-CNN mode, whole patches and a tiled image; the batch-statistics mode
+    (its moments are per variable channel) and the trainer say that they do not take such widths."""
+    from noise_flow_amd import NoiseFlow, default_hps
+    from oracle.nf_oracle import NoiseFlowOracle
+    H, W = hw
+    v = trained_like_variables(ARCH, width, seed=7 * width + H)
+    x, y = make_inputs(3, H, W, seed=21)
+    m = NoiseFlow([H, W, 4], False, default_hps(arch=ARCH, width=width), variables=v, cnn_dtype=dt)
+    o = NoiseFlowOracle(ARCH, v, cnn_dtype=dt)
+    nll, sd = m._loss(x, y, [0.0], [0.0], [100], [2])
+    ref_nll, ref_sd, ref_z = o.nll(x, y, 100, 2)
+    rt, et = (NLL_RTOL, ELEM_RTOL) if dt == "fp32" else (1e-4, 2e-3)
+    np.testing.assert_allclose(nll, ref_nll, rtol=rt, atol=1e-4)
+    z, _ = m.inverse(x, None, y, [0.0], [0.0], [100], [2])
+    _close_elem(z, ref_z, rtol=et)
+    eps = np.random.RandomState(4).randn(3, H, W, 4).astype(np.float32)
+    xs = m.sample(y, 0.8, y, [0.0], [0.0], [100], [2], eps=eps)
+    _close_elem(xs, o.sample(eps, 0.8, y, 100, 2), rtol=et)
+    if dt == "fp32" and max(H, W) <= 64:
+        mt = NoiseFlow([H, W, 4], True, default_hps(arch=ARCH, width=width), variables=v)
+        with pytest.raises(Exception) as ei:
+            mt._loss(x, y, [0.0], [0.0], [100], [2])
+        assert "width" in str(ei.value)

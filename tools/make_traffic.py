@@ -2,6 +2,8 @@
 has 4 counter slots, FETCH_SIZE costs 3 and WRITE_SIZE 2 — MI355X_MICROARCH.md).
 
     python tools/make_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> [kernel-substring] [B]
+    python tools/make_traffic.py <fetch.csv> <write.csv> <kernel-substring> <B> <entry> <threads> <bytes-per-patch>
+        -> the record of ANOTHER measured launch (bench.py sections "sampling", "fp16_cnn_64x64") under "configs"[entry]
 
 Per-launch averages over the launches of the named kernel with Grid_Size == B*256 (the headline launch shape);
 gfx950 correction: FETCH_SIZE reports 64 B per 128-B request for wide coalesced 16 B/lane reads -> x2; WRITE_SIZE as
@@ -39,13 +41,16 @@ def main():
     fetch_csv, write_csv = sys.argv[1], sys.argv[2]
     kernel_sub = sys.argv[3] if len(sys.argv) > 3 else "nf_flow_kernel<4, 256, 4, false, true, true, 0, false>"
     B = int(sys.argv[4]) if len(sys.argv) > 4 else 1024
-    grid = B * 256
+    entry = sys.argv[5] if len(sys.argv) > 5 else None
+    threads = int(sys.argv[6]) if len(sys.argv) > 6 else 256
+    patch_bytes = int(sys.argv[7]) if len(sys.argv) > 7 else 2 * 32 * 32 * 4 * 4
+    grid = min(B, 256 * (4 if threads == 256 else 1)) * threads if entry else B * 256
     fetch_kb, n_f = mean_counter(fetch_csv, "FETCH_SIZE", kernel_sub, grid)
     write_kb, n_w = mean_counter(write_csv, "WRITE_SIZE", kernel_sub, grid)
     hbm = 2.0 * fetch_kb * 1024.0 + write_kb * 1024.0
-    algo = 2 * 32 * 32 * 4 * 4 * B
+    algo = patch_bytes * B
     out = {
-        "kernel": "%s (fused NLL, B=%d 32x32x4 patches per launch)" % (kernel_sub, B),
+        "kernel": "%s (B=%d patches per launch)" % (kernel_sub, B) if entry else "%s (fused NLL, B=%d 32x32x4 patches per launch)" % (kernel_sub, B),
         "kernel_source_sha": source_sha(),
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) -- python bench.py "
                   "--no-cpu-baseline --no-extras --steps 20 --warmup 2 --ramp-ms 0; %s (%d launches), %s (%d launches)"
@@ -55,8 +60,22 @@ def main():
                       "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE as reported (uncalibrated)",
         "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": algo, "ratio": hbm / algo,
     }
-    with open(os.path.join(ROOT, "profiles", "traffic.json"), "w") as f:
-        json.dump(out, f, indent=1)
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(tpath) as f:
+            prev = json.load(f)
+    except Exception:
+        prev = {}
+    if entry:
+        out["source"] = "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only); %s (%d launches), %s (%d launches)" % (
+            os.path.relpath(fetch_csv, ROOT), n_f, os.path.relpath(write_csv, ROOT), n_w)
+        prev.setdefault("configs", {})[entry] = out
+        full = prev
+    else:
+        out["configs"] = prev.get("configs", {})
+        full = out
+    with open(tpath, "w") as f:
+        json.dump(full, f, indent=1)
     print(json.dumps(out, indent=1))
 
 

@@ -1,5 +1,5 @@
 """Profiling target: a handful of launches of the fused NLL kernel.
-rocprofv3 ... -- python tools/prof_nll.py [B] [n] [H] [cnn_dtype]"""
+rocprofv3 ... -- python tools/prof_nll.py [B] [n] [H] [cnn_dtype] [nll|sample]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -17,6 +17,10 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 v = load_checkpoint(os.path.join(root, "models/NoiseFlow/ckpt/model.ckpt.best"))
 m = NoiseFlow([H, H, 4], False, default_hps(), variables=v, cnn_dtype=mode)
 x, y = synth_patches(0, 0, B, H, H)
-for _ in range(n):
-    m.nll_sums(x, y, [0], [0], [100], [2])
+what = sys.argv[5] if len(sys.argv) > 5 else "nll"
+for i in range(n):
+    if what == "sample":      # in-kernel Philox eps (BASELINE configs[2])
+        m.sample(y, 1.0, y, [0], [0], [100], [2], seed=i)
+    else:
+        m.nll_sums(x, y, [0], [0], [100], [2])
 torch.cuda.synchronize()

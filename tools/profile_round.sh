@@ -3,7 +3,7 @@
 # Writes everything under gpurun_out/<tag>/; copy the summaries you want judged into profiles/.
 # Every counter pass is its own run with --kernel-trace only (never combined with other trace domains).
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
@@ -31,6 +31,14 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_full -- $BENCH -
 # 2. HBM traffic of the headline kernel: FETCH_SIZE and WRITE_SIZE in separate passes (headline only: --no-extras)
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- $BENCH --no-cpu-baseline --no-extras --ramp-ms 0 > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- $BENCH --no-cpu-baseline --no-extras --ramp-ms 0 > $OUT/pmc_write.log 2>&1
+# 2b. HBM traffic of the other measured BASELINE configs: configs[4] shape (64x64, fp16 CNN, B = 1024) and configs[2] (sampling, B = 4096)
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_fp16_$c -- python $R/tools/prof_nll.py 1024 20 64 fp16 > $OUT/pmc_fp16_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_samp_$c -- python $R/tools/prof_nll.py 4096 20 32 fp32 sample > $OUT/pmc_samp_$c.log 2>&1
+done
+# per-config kernel stats
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_fp16 -- python $R/tools/prof_nll.py 1024 200 64 fp16 > $OUT/kt_fp16.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_samp -- python $R/tools/prof_nll.py 4096 100 32 fp32 sample > $OUT/kt_samp.log 2>&1
 # 3. SQ counters: headline kernel at B = 16384, fp16-CNN 64x64, wide CNN width 32
 SQ1="SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU GRBM_GUI_ACTIVE"
 SQ2="SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE"
@@ -51,7 +59,7 @@ B=512 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/gemm
 B=512 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/gemm512_write -- python $R/tools/check_gemm.py 512 > $OUT/gemm512_write.log 2>&1
 cd $R
 python tools/pmc_report.py $OUT/sq_fp32 "nf_flow_kernel<4, 256, 4, false, true, true, 0, false>" 100000 > $OUT/sq_fp32_report.txt 2>&1
-python tools/pmc_report.py $OUT/sq_fp16 "nf_flow_kernel<4, 1024, 4, false, true, true, 1, false>" 100000 > $OUT/sq_fp16_report.txt 2>&1
+python tools/pmc_report.py $OUT/sq_fp16 "nf_flow_kernel<4, 1024, 4, false, true, true, 2, false>" 100000 > $OUT/sq_fp16_report.txt 2>&1
 python tools/pmc_report.py $OUT/sq_w32 "nf_wide32_kernel" 100000 > $OUT/sq_w32_report.txt 2>&1
 python tools/pmc_report.py $OUT/sq_w16 "nf_wide16_kernel" 100000 > $OUT/sq_w16_report.txt 2>&1
 python tools/pmc_report.py $OUT/sq_w32h "nf_wide32_kernel" 100000 > $OUT/sq_w32h_report.txt 2>&1
@@ -62,8 +70,17 @@ python tools/pmc_report.py $OUT/sq_gemm128h "nf_gemm16b_kernel<128" 100000 > $OU
 python tools/pmc_report.py $OUT/gemm512_fetch "nf_gemm_kernel<512" 100000 > $OUT/gemm512_traffic.txt 2>&1
 python tools/pmc_report.py $OUT/gemm512_write "nf_gemm_kernel<512" 100000 >> $OUT/gemm512_traffic.txt 2>&1
 F=$(find $OUT/pmc_fetch -name "*counter_collection.csv" | head -1); W=$(find $OUT/pmc_write -name "*counter_collection.csv" | head -1)
-python tools/make_traffic.py $F $W > $OUT/traffic.log 2>&1 && cp profiles/traffic.json $OUT/traffic.json
+python tools/make_traffic.py $F $W > $OUT/traffic.log 2>&1
+F2=$(find $OUT/pmc_fp16_FETCH_SIZE -name "*counter_collection.csv" | head -1); W2=$(find $OUT/pmc_fp16_WRITE_SIZE -name "*counter_collection.csv" | head -1)
+python tools/make_traffic.py $F2 $W2 "nf_flow_kernel<4, 1024, 4, false, true, true, 2, false>" 1024 fp16_cnn_64x64 1024 131072 >> $OUT/traffic.log 2>&1
+F3=$(find $OUT/pmc_samp_FETCH_SIZE -name "*counter_collection.csv" | head -1); W3=$(find $OUT/pmc_samp_WRITE_SIZE -name "*counter_collection.csv" | head -1)
+python tools/make_traffic.py $F3 $W3 "nf_flow_kernel<4, 256, 4, true, true, true, 0, false>" 4096 sampling 256 32768 >> $OUT/traffic.log 2>&1
+cp profiles/traffic.json $OUT/traffic.json
+cp $F2 $OUT/pmc_fp16_fetch_counter_collection.csv; cp $W2 $OUT/pmc_fp16_write_counter_collection.csv
+cp $F3 $OUT/pmc_sampling_fetch_counter_collection.csv; cp $W3 $OUT/pmc_sampling_write_counter_collection.csv
 K=$(find $OUT/kt -name "*kernel_stats.csv" | head -1); cp $K $OUT/kernel_stats.csv 2>/dev/null
+K=$(find $OUT/kt_fp16 -name "*kernel_stats.csv" | head -1); cp $K $OUT/kernel_stats_fp16_cnn_64x64.csv 2>/dev/null
+K=$(find $OUT/kt_samp -name "*kernel_stats.csv" | head -1); cp $K $OUT/kernel_stats_sampling.csv 2>/dev/null
 K=$(find $OUT/kt_full -name "*kernel_stats.csv" | head -1); cp $K $OUT/kernel_stats_all_sections.csv 2>/dev/null
 cp $F $OUT/pmc_fetch_counter_collection.csv; cp $W $OUT/pmc_write_counter_collection.csv
 for f in $OUT/sq_fp32_report.txt $OUT/sq_fp16_report.txt $OUT/sq_w32_report.txt $OUT/sq_w16_report.txt $OUT/sq_w32h_report.txt $OUT/sq_gemm512_report.txt $OUT/sq_gemm128_report.txt $OUT/sq_gemm512_fp16_report.txt $OUT/sq_gemm128_fp16_report.txt $OUT/gemm512_traffic.txt; do tail -n 3 $f; done; head -c 600 $OUT/bench.json; echo; tail -5 $OUT/traffic.log; head -8 $OUT/kernel_stats.csv
