@@ -239,7 +239,7 @@ __host__ __device__ constexpr int nf7_img_size(int wp) { return (wp / 32) * 832 
 #define NF7_P_STRIDE 44          // floats per pixel of a partial P tile in LDS: 8 taps x 4, tap 8 of lane half 0 / 1, pad (conflict-free)
 __host__ __device__ constexpr int nf7_cpl_size(int wp) { return NF7_CPL_IMG + nf7_img_size(wp); }
 #define NF7_BAND_FLOATS 32768   // hidden activations of one band: WP channels x NB pixels (128 KiB of LDS)
-#define NF7_MAX_PIXELS 2048     // pixels per patch the GEMM kernel holds (4 per thread)
+#define NF7_MAX_PIXELS 4096     // pixels per patch the GEMM kernels hold (8 per thread): up to 64x64
 
 // launch flags
 enum : uint32_t {

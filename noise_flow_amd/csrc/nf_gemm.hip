@@ -46,8 +46,10 @@ __device__ __forceinline__ float4 ldg4(const float *p) { return *reinterpret_cas
 
 //   WP      padded coupling width: 64, 128, 256, 512
 //   PHILOX  input = in-kernel Philox/Box-Muller draw
-//   OWN     pixels per thread: 2 (patches <= 1024 pixels) or 4 (<= 2048)
-template <int WP, bool PHILOX, int OWN>
+//   OWN     pixels per thread: 2 (patches <= 1024 pixels), 4 (<= 2048) or 8 (<= 4096: 64x64)
+//   BRD     the pass-through tile carries a zero border ('SAME' padding by construction).  Beside the 128 KiB band a bordered
+//           64x64 tile does not fit the 160 KiB of a CU by 2 KiB: !BRD keeps the bare H x W planes and masks the taps instead
+template <int WP, bool PHILOX, int OWN, bool BRD>
 __global__ __launch_bounds__(GT) void nf_gemm_kernel(const NfProgram prog, const NfLaunch a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -60,11 +62,12 @@ __global__ __launch_bounds__(GT) void nf_gemm_kernel(const NfProgram prog, const
     static_assert(MT * NT == 32 && WM * WN == GW && NT == 2 * WN && KC % 2 == 0, "tile split");
     static_assert(WM * NB * NF7_P_STRIDE <= NF7_BAND_FLOATS, "the partial P tiles reuse the h1 region");
     const int H = a.H, W = a.W, HW = H * W;
-    const int Wp = W + 2;
-    const int PL = ((H + 2) * Wp + 3) & ~3;            // one channel plane of the z0 tile
+    const int Wp = BRD ? W + 2 : W;
+    const int PL = ((BRD ? (H + 2) * Wp : HW) + 3) & ~3;   // one channel plane of the z0 tile
     float *const h1 = smem;                             // [KC][2][NB][4]; later the partial P tiles [WM][NB][NF7_P_STRIDE]
     float *const z0s = smem + NF7_BAND_FLOATS;          // [2][PL]
-    float *const red = z0s + 2 * PL;                    // [3][GW]
+    float *const red = BRD ? z0s + 2 * PL : h1;         // [3][GW]  (!BRD: every byte counts — the band region is idle in the epilogue)
+    constexpr int ZB = BRD ? 1 : 0;                     // tile coordinates = pixel coordinates + ZB
 
     const int t = threadIdx.x;
     const int wv = t >> 6, lane = t & 63, n = lane & 31, g = lane >> 5;
@@ -139,8 +142,8 @@ __global__ __launch_bounds__(GT) void nf_gemm_kernel(const NfProgram prog, const
 #pragma unroll
                 for (int m = 0; m < OWN; ++m)
                     if (act[m]) {
-                        z0s[(pr[m] + 1) * Wp + pc[m] + 1] = z[m][0];
-                        z0s[PL + (pr[m] + 1) * Wp + pc[m] + 1] = z[m][1];
+                        z0s[(pr[m] + ZB) * Wp + pc[m] + ZB] = z[m][0];
+                        z0s[PL + (pr[m] + ZB) * Wp + pc[m] + ZB] = z[m][1];
                     }
                 float o[OWN][4];
 #pragma unroll
@@ -158,7 +161,8 @@ __global__ __launch_bounds__(GT) void nf_gemm_kernel(const NfProgram prog, const
                         int p = p0 + 32 * nt + n;
                         p = p < HW ? p : HW - 1;   // columns past the patch: never gathered
                         const int r = p / W, c = p - r * W;
-                        const float *zb = z0s + g * PL + r * Wp + c;   // tap (di,dj) at + di*Wp + dj
+                        const float *zb = z0s + g * PL + r * Wp + c;   // BRD: tap (di,dj) at + di*Wp + dj
+                        [[maybe_unused]] const bool rok[3] = {r > 0, true, r + 1 < H}, cok[3] = {c > 0, true, c + 1 < W};
                         v16f d;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
@@ -172,7 +176,17 @@ __global__ __launch_bounds__(GT) void nf_gemm_kernel(const NfProgram prog, const
 #pragma unroll
                             for (int s = 0; s < 4; ++s) {
                                 const int tap = grp * 4 + s;
-                                if (tap < 9) d = __builtin_amdgcn_mfma_f32_32x32x2f32(as[s], zb[(tap / 3) * Wp + tap % 3], d, 0, 0, 0);
+                                if (tap < 9) {
+                                    float zv;
+                                    if constexpr (BRD) {
+                                        zv = zb[(tap / 3) * Wp + tap % 3];
+                                    } else {   // bare planes: the taps outside the patch are the zeros of 'SAME' padding
+                                        const bool ok = rok[tap / 3] && cok[tap % 3];
+                                        zv = zb[ok ? (tap / 3 - 1) * Wp + tap % 3 - 1 : 0];
+                                        zv = ok ? zv : 0.0f;
+                                    }
+                                    d = __builtin_amdgcn_mfma_f32_32x32x2f32(as[s], zv, d, 0, 0, 0);
+                                }
                             }
                         }
 #pragma unroll
@@ -779,21 +793,22 @@ template <int WP, bool PHILOX>
 hipError_t dispatch_ownb(const NfProgram &prog, const NfLaunch &a, int n_cu, int device, hipStream_t stream)
 {
     if (a.H * a.W <= 2 * GT) return launch_gemmb<WP, PHILOX, 2>(prog, a, n_cu, device, stream);
-    return launch_gemmb<WP, PHILOX, 4>(prog, a, n_cu, device, stream);
+    if (a.H * a.W <= 4 * GT) return launch_gemmb<WP, PHILOX, 4>(prog, a, n_cu, device, stream);
+    return launch_gemmb<WP, PHILOX, 8>(prog, a, n_cu, device, stream);
 }
 
-size_t gemm_lds_bytes(int H, int W)
+size_t gemm_lds_bytes(int H, int W, bool bordered = true)
 {
-    const int Wp = W + 2, PL = ((H + 2) * Wp + 3) & ~3;
-    return ((size_t)NF7_BAND_FLOATS + 2 * (size_t)PL + 3 * GW + 8) * sizeof(float);
+    const int Wp = W + 2, PL = ((bordered ? (H + 2) * Wp : H * W) + 3) & ~3;
+    return ((size_t)NF7_BAND_FLOATS + 2 * (size_t)PL + (bordered ? 3 * GW + 8 : 0)) * sizeof(float);
 }
 
-template <int WP, bool PHILOX, int OWN>
+template <int WP, bool PHILOX, int OWN, bool BRD = true>
 hipError_t launch_gemm(const NfProgram &prog, const NfLaunch &a, int n_cu, int device, hipStream_t stream)
 {
-    const size_t lds = gemm_lds_bytes(a.H, a.W);
+    const size_t lds = gemm_lds_bytes(a.H, a.W, BRD);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    const void *fn = reinterpret_cast<const void *>(&nf_gemm_kernel<WP, PHILOX, OWN>);
+    const void *fn = reinterpret_cast<const void *>(&nf_gemm_kernel<WP, PHILOX, OWN, BRD>);
     // largest dynamic-LDS size this instantiation was enabled for, per device (racy but idempotent)
     static std::atomic<size_t> lds_set[16];
     std::atomic<size_t> &cur = lds_set[device & 15];
@@ -805,7 +820,7 @@ hipError_t launch_gemm(const NfProgram &prog, const NfLaunch &a, int n_cu, int d
     int64_t groups = n_cu;   // one 512-thread workgroup with > 128 KiB of LDS per CU
     if (a.B < groups) groups = a.B;
     if (groups < 1) groups = 1;
-    hipLaunchKernelGGL((nf_gemm_kernel<WP, PHILOX, OWN>), dim3((unsigned)groups), dim3(GT), lds, stream, prog, a);
+    hipLaunchKernelGGL((nf_gemm_kernel<WP, PHILOX, OWN, BRD>), dim3((unsigned)groups), dim3(GT), lds, stream, prog, a);
     return hipGetLastError();
 }
 
@@ -813,7 +828,10 @@ template <int WP, bool PHILOX>
 hipError_t dispatch_own(const NfProgram &prog, const NfLaunch &a, int n_cu, int device, hipStream_t stream)
 {
     if (a.H * a.W <= 2 * GT) return launch_gemm<WP, PHILOX, 2>(prog, a, n_cu, device, stream);
-    return launch_gemm<WP, PHILOX, 4>(prog, a, n_cu, device, stream);
+    if (a.H * a.W <= 4 * GT) return launch_gemm<WP, PHILOX, 4>(prog, a, n_cu, device, stream);
+    // up to 64x64: 8 pixels per thread; the bordered tile of the largest shapes does not fit beside the band
+    if (gemm_lds_bytes(a.H, a.W, true) <= 160 * 1024) return launch_gemm<WP, PHILOX, 8>(prog, a, n_cu, device, stream);
+    return launch_gemm<WP, PHILOX, 8, false>(prog, a, n_cu, device, stream);
 }
 
 template <bool PHILOX>
@@ -846,7 +864,7 @@ hipError_t nf_launch_gemmb(const NfProgram &prog, const NfLaunch &a, int n_cu, i
 // whether a patch shape fits the GEMM kernel (nf_create asks before accepting a width > 32)
 bool nf_gemm_shape_ok(int H, int W)
 {
-    return H >= 1 && W >= 1 && H * W <= NF7_MAX_PIXELS && gemm_lds_bytes(H, W) <= 160 * 1024;
+    return H >= 1 && W >= 1 && H * W <= NF7_MAX_PIXELS && gemm_lds_bytes(H, W, false) <= 160 * 1024;
 }
 
 // entry point used by nf_host.hip: programs in the NF7 layout (coupling width padded to 64 / 128 / 256 / 512)

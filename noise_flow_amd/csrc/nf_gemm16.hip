@@ -44,7 +44,7 @@ __device__ __forceinline__ float4 ldg4(const float *p) { return *reinterpret_cas
 
 //   WP      padded coupling width: 64, 128, 256, 512
 //   PHILOX  input = in-kernel Philox/Box-Muller draw
-//   OWN     pixels per thread: 2 (patches <= 1024 pixels) or 4 (<= 2048)
+//   OWN     pixels per thread: 2 (patches <= 1024 pixels), 4 (<= 2048) or 8 (<= 4096: 64x64)
 template <int WP, bool PHILOX, int OWN>
 __global__ __launch_bounds__(GT) void nf_gemm16_kernel(const NfProgram prog, const NfLaunch a)
 {
@@ -793,7 +793,8 @@ template <int WP, bool PHILOX>
 hipError_t dispatch_own16b(const NfProgram &prog, const NfLaunch &a, int n_cu, int device, hipStream_t stream)
 {
     if (a.H * a.W <= 2 * GT) return launch_gemm16b<WP, PHILOX, 2>(prog, a, n_cu, device, stream);
-    return launch_gemm16b<WP, PHILOX, 4>(prog, a, n_cu, device, stream);
+    if (a.H * a.W <= 4 * GT) return launch_gemm16b<WP, PHILOX, 4>(prog, a, n_cu, device, stream);
+    return launch_gemm16b<WP, PHILOX, 8>(prog, a, n_cu, device, stream);
 }
 
 template <bool PHILOX>
@@ -837,7 +838,8 @@ template <int WP, bool PHILOX>
 hipError_t dispatch_own16(const NfProgram &prog, const NfLaunch &a, int n_cu, int device, hipStream_t stream)
 {
     if (a.H * a.W <= 2 * GT) return launch_gemm16<WP, PHILOX, 2>(prog, a, n_cu, device, stream);
-    return launch_gemm16<WP, PHILOX, 4>(prog, a, n_cu, device, stream);
+    if (a.H * a.W <= 4 * GT) return launch_gemm16<WP, PHILOX, 4>(prog, a, n_cu, device, stream);
+    return launch_gemm16<WP, PHILOX, 8>(prog, a, n_cu, device, stream);
 }
 
 template <bool PHILOX>

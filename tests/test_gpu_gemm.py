@@ -40,12 +40,15 @@ def _path(m, direction=0):
 
 @pytest.mark.parametrize("width,hw", [(64, (32, 32)), (128, (32, 32)), (256, (32, 32)), (512, (32, 32)),
                                       (64, (20, 28)), (512, (24, 40)), (96, (32, 32)), (48, (16, 16)), (200, (7, 5)),
-                                      (64, (1, 1)), (128, (33, 31)), (64, (32, 64)), (512, (45, 45)), (160, (9, 33))])
+                                      (64, (1, 1)), (128, (33, 31)), (64, (32, 64)), (512, (45, 45)), (160, (9, 33)),
+                                      # up to 64x64 (8 pixels per thread; the configs[4] geometry at the reference's default width): the
+                                      # slab kernel (64), the band kernel with the bare pass-through tile (128, 512), ragged shapes
+                                      (64, (64, 64)), (128, (64, 64)), (512, (64, 64)), (256, (56, 63)), (96, (64, 40))])
 def test_gemm_kernel_matches_oracle(width, hw):
     from noise_flow_amd import _lib
     from oracle.nf_oracle import NoiseFlowOracle
     H, W = hw
-    B = 3
+    B = 3 if H * W <= 2048 else 2
     v = _variables(ARCH, width, seed=H * 100 + W + width)
     x, y = make_inputs(B, H, W, seed=3)
     m = _model(ARCH, v, (H, W, 4), width)
@@ -105,7 +108,7 @@ def test_gemm_width_512_full_arch():
 
 def test_gemm_width_limits_are_reported():
     from noise_flow_amd import NoiseFlow, default_hps
-    for width, hw, dt in ((64, (64, 64), "fp32"), (513, (32, 32), "fp32"), (64, (64, 64), "fp16")):
+    for width, hw, dt in ((64, (65, 64), "fp32"), (513, (32, 32), "fp32"), (64, (64, 96), "fp16")):
         v = trained_like_variables(ARCH, width, seed=1)
         with pytest.raises(Exception) as ei:
             NoiseFlow([hw[0], hw[1], 4], False, default_hps(arch=ARCH, width=width), variables=v, cnn_dtype=dt)
@@ -113,7 +116,8 @@ def test_gemm_width_limits_are_reported():
 
 
 @pytest.mark.parametrize("width,hw", [(64, (32, 32)), (128, (32, 32)), (256, (32, 32)), (512, (32, 32)), (96, (20, 28)), (512, (24, 40)),
-                                      (64, (45, 45)), (200, (7, 5)), (160, (33, 31))])
+                                      (64, (45, 45)), (200, (7, 5)), (160, (33, 31)),
+                                      (64, (64, 64)), (512, (64, 64)), (256, (60, 64))])     # BASELINE configs[4]'s geometry
 def test_gemm_fp16_cnn_mode(width, hw):
     """NF_CFG_FP16_CNN at widths 33 .. 512 (csrc/nf_gemm16.hip: v_mfma_f32_32x32x16_f16, fp32 accumulate, fp32 log-det): against
     the oracle's emulation of the rounding points — BN and exp(3 logs) folded in fp64, THEN the folded weights and the three
