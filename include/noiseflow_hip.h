@@ -22,8 +22,10 @@
  *   - a handle is immutable after nf_create: nf_nll / nf_sample are re-entrant
  *     and may be called concurrently from many host threads (the reference's
  *     16-32 Python threads sharing one tf.Session, job_noise_flow.sh:36,
- *     train_dncnn_noiseflow.py:195); they never allocate and never synchronise
- *     (the nf_*_batchstats variants are the documented exception).
+ *     train_dncnn_noiseflow.py:195); they never synchronise and — patches of
+ *     up to 64x64 — never allocate; images beyond 64x64 use scratch the handle
+ *     owns (nf_reserve_workspace; grown on demand otherwise).  The
+ *     nf_*_batchstats variants are the documented exception.
  */
 #ifndef NOISEFLOW_HIP_H
 #define NOISEFLOW_HIP_H
@@ -130,7 +132,7 @@ typedef struct nf_config {
                               1x1 mixes, tanh/exp, log-det and prior stay fp32.  Width 4: its own kernel
                               for full 32x32 / 64x64 patches (BASELINE configs[4]), any other shape on
                               the width-32 kernel, zero-padded; widths 8 / 16 / 32: any patch up to 64x64
-                              (v_mfma_f32_32x32x16_f16); widths 33 .. 512: patches of up to 2048 pixels. */
+                              (v_mfma_f32_32x32x16_f16); widths 33 .. 512: any patch up to 64x64. */
 
 /* Per-call conditioning: ONE value per call, not per patch — the reference
  * feeds length-1 lists (MiniBatchSampler.py:61-64, NoiseFlowWrapper.py:85-86).
@@ -236,11 +238,16 @@ int nf_tile_segments(const nf_config *cfg, const nf_layer_desc *layers, const fl
  *   eps          [B,H,W,4] float32 or NULL (in-kernel Philox keyed by (seed, patch_index_base + b, pixel))
  *   nll_out, sd_out, logdet_out [B], z_out / x_out [B,H,W,4]: float32 host buffers (each optional except x_out)
  *   sums_out     HOST double[3] = (sum nll, sum sd, B), or NULL; NF_ACCUMULATE adds to it.  flags: NF_NO_PRIOR, NF_ACCUMULATE.
- * The call is a chunked pipeline owned by the handle (created on first use, freed by nf_destroy): worker threads narrow /
- * copy a chunk into pinned staging while the previous chunks cross PCIe and run on three internal streams; patches are
- * independent, so every per-patch output is bit-identical to nf_nll / nf_sample on the same data.  Evaluation mode only
- * (running BN statistics).  Calls on one handle serialise.  Environment: NF_HOSTFED_THREADS (default: the CPUs this
- * process may use, at most 32), NF_HOSTFED_CHUNK (patches per chunk; default 8 MiB of one tensor). */
+ * The call is a chunked pipeline (created on first use, freed by nf_destroy): a chunk is narrowed / copied into pinned staging
+ * while the previous chunks cross PCIe and run on three internal streams; patches are independent, so every per-patch output
+ * is bit-identical to nf_nll / nf_sample on the same data.  Evaluation mode only (running BN statistics).
+ * Re-entrant like nf_nll: any number of host threads may call on one handle at once (the reference's 16 queue workers each
+ * call sess.run on their own, train_noise_flow.py:30-47, job_noise_flow.sh:36) — up to 4 calls are in flight at a time
+ * (NF_HOSTFED_PIPES), each on a pipeline of its own, so one caller's narrowing overlaps another's DMA and kernel, and further
+ * callers wait their turn; a lone caller's narrowing is spread over a process-wide worker pool instead.  A tensor result is stored by the kernel straight into the caller's buffer when that is page-locked over its
+ * whole length and 16-byte aligned, through pinned staging otherwise.  Not fork-safe while a call is in flight; a forked child
+ * starts with a fresh worker pool.  Environment: NF_HOSTFED_THREADS (default: the CPUs this process may use, at most 32),
+ * NF_HOSTFED_CHUNK (patches per chunk; default 8 MiB of one tensor). */
 #define NF_HOST_F32 0
 #define NF_HOST_F64 1
 int nf_nll_host(nf_handle *h, const void *x, const void *y, int32_t dtype, int64_t B, const nf_cond *cond,
@@ -392,6 +399,15 @@ int nf_fold_layout(const nf_config *cfg, const nf_layer_desc *layers,
  * wavefront (<= 128) or bands of pixels with the weights streamed from L2 (256 / 512); the environment variables NF_GEMM=a /
  * NF_GEMM16=a (read at nf_create) force the band variant everywhere — an A/B aid, like NF_KERNEL=valu. */
 int nf_kernel_path(const nf_handle *h, int32_t direction);
+
+/* Device scratch of calls on images beyond 64x64 (evaluated as overlapping tiles: the per-tile sums and the tensors between two
+ * segments of the program).  The handle owns a small set of buffers, one per call in flight; nf_nll / nf_sample allocate only
+ * when a call needs more than any earlier call did or when more calls are in flight than ever before.  nf_workspace_bytes says
+ * what one call of B images needs (0 for patches of up to 64x64: they need none); nf_reserve_workspace allocates that for
+ * `calls_in_flight` concurrent calls up front (synchronous; at nf_create time, so to speak), after which no call of up to B
+ * images allocates anything.  No reference counterpart (TF sizes its arena inside sess.run). */
+int64_t nf_workspace_bytes(const nf_handle *h, int32_t direction, int64_t B);
+int nf_reserve_workspace(nf_handle *h, int64_t B, int32_t calls_in_flight);
 
 /* Host-only: the SDN5 scalars the kernels receive for a given (iso, cam):
  * out[0] = beta1/gain, out[1] = beta2 (cond_utils.py:205-239). */

@@ -149,6 +149,10 @@ def load() -> C.CDLL:
                                    C.POINTER(C.c_size_t)]
     lib.nf_kernel_path.restype = C.c_int
     lib.nf_kernel_path.argtypes = [vp, i32]
+    lib.nf_workspace_bytes.restype = i64
+    lib.nf_workspace_bytes.argtypes = [vp, i32, i64]
+    lib.nf_reserve_workspace.restype = C.c_int
+    lib.nf_reserve_workspace.argtypes = [vp, i64, i32]
     lib.nf_sdn5_scalars.restype = C.c_int
     lib.nf_sdn5_scalars.argtypes = [C.POINTER(C.c_float), C.POINTER(nf_cond), C.POINTER(C.c_double)]
     if lib.nf_abi_version() != 1:
@@ -166,7 +170,7 @@ def check(rc: int) -> None:
 EXPORTED_SYMBOLS = (
     "nf_abi_version", "nf_last_error", "nf_layer_param_count", "nf_create", "nf_destroy", "nf_nll",
     "nf_sample", "nf_set_sync", "nf_sample_eps", "nf_tile_plan", "nf_tile_segments", "nf_nll_host", "nf_sample_host", "nf_synth_patches", "nf_fold_params", "nf_fold_layout", "nf_sdn5_scalars",
-    "nf_nll_batchstats", "nf_sample_batchstats", "nf_sums_reduce", "nf_kernel_path",
+    "nf_nll_batchstats", "nf_sample_batchstats", "nf_sums_reduce", "nf_kernel_path", "nf_workspace_bytes", "nf_reserve_workspace",
     "nf_trainer_create", "nf_trainer_destroy", "nf_trainer_forward_backward", "nf_trainer_forward", "nf_trainer_apply", "nf_trainer_step",
     "nf_trainer_get_params", "nf_trainer_set_params", "nf_trainer_steps", "nf_trainer_set_sync",
 )

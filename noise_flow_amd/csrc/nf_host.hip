@@ -1359,6 +1359,18 @@ struct nf_handle {
     float *d_fwd8 = nullptr;   // fp16-CNN GEMM layout
     float *d_rev8 = nullptr;
     bool scalar_ok = true;     // the scalar-weight kernel's LDS tiles fit this patch shape / width
+    // scratch of the tiled calls (images beyond 64x64): the per-tile sums and the tensors between two segments.  A small set of
+    // device buffers owned by the handle, one per call in flight; a call takes a free one (waiting, on ITS stream, for the work
+    // that last used it), so nf_nll / nf_sample allocate only when a call needs more than any earlier one did, or when more
+    // calls are in flight than ever before — nf_reserve_workspace sizes it up front
+    struct Workspace {
+        char *p = nullptr;
+        size_t bytes = 0;
+        hipEvent_t ev = nullptr;   // recorded behind the last launch that used the buffer
+        bool busy = false;         // a host thread is enqueueing on it
+    };
+    std::mutex ws_mu;
+    std::vector<Workspace *> ws;
     // batch-statistics mode (nf_*_batchstats): the raw model and a lazily allocated scratch
     std::vector<nf_layer_desc> layers;
     std::vector<float> raw;
@@ -1568,6 +1580,14 @@ int nf_destroy(nf_handle *h)
     if (h->d_fwd8) (void)hipFree(h->d_fwd8);
     if (h->d_rev8) (void)hipFree(h->d_rev8);
     nf_bs_destroy(h->bs);
+    for (nf_handle::Workspace *w : h->ws) {
+        if (w->ev) {
+            (void)hipEventSynchronize(w->ev);
+            (void)hipEventDestroy(w->ev);
+        }
+        if (w->p) (void)hipFree(w->p);
+        delete w;
+    }
     delete h;
     return NF_OK;
 }
@@ -1653,10 +1673,67 @@ static int sample_args(nf_handle *h, const float *y, const float *eps, uint64_t 
     return NF_OK;
 }
 
+// ---- workspace of the tiled calls -------------------------------------------------------------------------------------
+static size_t tiled_workspace_bytes(const nf_handle *h, int direction, int64_t B, bool want_sums)
+{
+    const Built &b = direction == 0 ? h->fwd : h->rev;
+    if (!b.tiled || B <= 0) return 0;
+    const int S = (int)b.segs.size();
+    size_t part4 = 0;
+    for (int s = 0; s < S; ++s) part4 += (size_t)B * b.segs[s].ny * b.segs[s].nx;
+    const size_t img = (((size_t)B * h->cfg.height * h->cfg.width * kC * sizeof(float)) + 255) & ~(size_t)255;
+    const size_t part = want_sums ? ((part4 * 4 * sizeof(float) + 255) & ~(size_t)255) : 0;
+    return part + img * (size_t)(S - 1 < 2 ? (S - 1 < 0 ? 0 : S - 1) : 2);
+}
+
+// a buffer of >= bytes that no other call is enqueueing on; work the stream `st` enqueues is ordered behind its last user
+static int ws_acquire(nf_handle *h, size_t bytes, hipStream_t st, nf_handle::Workspace **out)
+{
+    *out = nullptr;
+    if (bytes == 0) return NF_OK;
+    std::lock_guard<std::mutex> lk(h->ws_mu);
+    nf_handle::Workspace *w = nullptr;
+    for (nf_handle::Workspace *c : h->ws)      // smallest free buffer that is large enough, else the largest free one (to grow)
+        if (!c->busy && (!w || (c->bytes >= bytes ? (w->bytes < bytes || c->bytes < w->bytes) : (w->bytes < bytes && c->bytes > w->bytes)))) w = c;
+    hipError_t e = hipSuccess;
+    if (!w) {
+        w = new (std::nothrow) nf_handle::Workspace();
+        if (!w) return fail(NF_ENOMEM, "out of host memory");
+        if ((e = hipEventCreateWithFlags(&w->ev, hipEventDisableTiming)) != hipSuccess) {
+            delete w;
+            return fail_hip(e, "hipEventCreate");
+        }
+        h->ws.push_back(w);
+    }
+    if (w->bytes < bytes) {                    // grow: the only allocation a call can make (the first one of its size)
+        if (w->p) {
+            (void)hipEventSynchronize(w->ev);
+            (void)hipFree(w->p);
+            w->p = nullptr;
+            w->bytes = 0;
+        }
+        if ((e = hipMalloc((void **)&w->p, bytes)) != hipSuccess) return fail_hip(e, "hipMalloc(tiled workspace)");
+        w->bytes = bytes;
+    } else if ((e = hipStreamWaitEvent(st, w->ev, 0)) != hipSuccess) {
+        return fail_hip(e, "hipStreamWaitEvent");
+    }
+    w->busy = true;
+    *out = w;
+    return NF_OK;
+}
+
+static void ws_release(nf_handle *h, nf_handle::Workspace *w, hipStream_t st)
+{
+    if (!w) return;
+    (void)hipEventRecord(w->ev, st);
+    std::lock_guard<std::mutex> lk(h->ws_mu);
+    w->busy = false;
+}
+
 // Images beyond 64x64 (nf_device.h, "overlapping tiles"): per segment of the program one launch of the fused width-4 kernel
 // (or, at widths 8 / 16 / 32 and in fp16-CNN mode, of the width-32 matrix-core kernel) over B x tiles tile-sized "patches" that reads and writes image-shaped tensors in place (the caller's, and between two
 // segments a scratch tensor), then — in the NLL direction — a one-wavefront-per-image kernel that adds the tiles' sums up.  Scratch
-// is stream-ordered (hipMallocAsync), so concurrent calls on one handle (different streams) never share it.
+// comes from the handle's workspace set (above): one buffer per call in flight, so concurrent calls on one handle never share it.
 static int launch_tiled(nf_handle *h, int direction, NfLaunch &a, hipStream_t st, const char *what)
 {
     const Built &b = direction == 0 ? h->fwd : h->rev;
@@ -1675,11 +1752,20 @@ static int launch_tiled(nf_handle *h, int direction, NfLaunch &a, hipStream_t st
         if (B > (INT64_MAX / 64) / tp.nt[s]) return fail(NF_EINVAL, "B too large");
         part4 += B * tp.nt[s];
     }
-    const size_t img_bytes = (size_t)B * h->cfg.height * h->cfg.width * kC * sizeof(float);
+    const size_t img_bytes = (((size_t)B * h->cfg.height * h->cfg.width * kC * sizeof(float)) + 255) & ~(size_t)255;
     float *part = nullptr, *scratch[2] = {nullptr, nullptr};
     hipError_t e = hipSuccess;
-    if (want) e = hipMallocAsync((void **)&part, (size_t)part4 * 4 * sizeof(float), st);
-    for (int i = 0; i < 2 && i < S - 1 && e == hipSuccess; ++i) e = hipMallocAsync((void **)&scratch[i], img_bytes, st);
+    nf_handle::Workspace *wsp = nullptr;
+    {
+        const int rc = ws_acquire(h, tiled_workspace_bytes(h, direction, B, want), st, &wsp);
+        if (rc != NF_OK) return rc;
+        char *q = wsp ? wsp->p : nullptr;
+        if (want) {
+            part = reinterpret_cast<float *>(q);
+            q += ((size_t)part4 * 4 * sizeof(float) + 255) & ~(size_t)255;
+        }
+        for (int i = 0; i < 2 && i < S - 1; ++i, q += img_bytes) scratch[i] = reinterpret_cast<float *>(q);
+    }
     // kernel family: fp16-CNN mode and widths 8 / 16 / 32 on the width-32 matrix-core kernel (zero-padded), width 4 in fp32 on
     // the fused width-4 kernels
     float *d4 = direction == 0 ? h->d_fwd4 : h->d_rev4;
@@ -1729,11 +1815,7 @@ static int launch_tiled(nf_handle *h, int direction, NfLaunch &a, hipStream_t st
     if (e == hipSuccess && want)
         e = nf_launch_tile_combine(part, tp, B, (double)h->cfg.height * h->cfg.width * kC, a.ld_const, a.flags, a.nll_out, a.sd_out, a.ld_out,
                                    a.sums, st);
-    for (float *p : {part, scratch[0], scratch[1]})
-        if (p) {
-            hipError_t e2 = hipFreeAsync(p, st);
-            if (e == hipSuccess) e = e2;
-        }
+    ws_release(h, wsp, st);
     if (e != hipSuccess) return fail_hip(e, what);
     return NF_OK;
 }
@@ -1804,6 +1886,30 @@ static int launch_resident(nf_handle *h, int direction, NfLaunch &a, hipStream_t
     hipError_t e = nf_launch_flow(d3 ? b.prog3 : mc ? b.prog2 : b.prog, a, h->n_cu, st, mc);
     if (e != hipSuccess) return fail_hip(e, what);
     return NF_OK;
+}
+
+int64_t nf_workspace_bytes(const nf_handle *h, int32_t direction, int64_t B)
+{
+    if (!h || (direction != 0 && direction != 1) || B < 0) return fail(NF_EINVAL, "bad argument");
+    return (int64_t)tiled_workspace_bytes(h, direction, B, direction == 0);
+}
+
+int nf_reserve_workspace(nf_handle *h, int64_t B, int32_t calls_in_flight)
+{
+    if (!h || B < 0 || calls_in_flight < 1 || calls_in_flight > 64) return fail(NF_EINVAL, "bad argument");
+    const size_t need = std::max(tiled_workspace_bytes(h, 0, B, true), tiled_workspace_bytes(h, 1, B, false));
+    if (need == 0) return NF_OK;
+    DeviceGuard guard;
+    int rc = guard.enter(h->device);
+    if (rc != NF_OK) return rc;
+    std::vector<nf_handle::Workspace *> got;
+    for (int i = 0; i < calls_in_flight && rc == NF_OK; ++i) {
+        nf_handle::Workspace *w = nullptr;
+        rc = ws_acquire(h, need, nullptr, &w);   // marks it busy, so that the next iteration takes (or makes) another one
+        if (w) got.push_back(w);
+    }
+    for (nf_handle::Workspace *w : got) ws_release(h, w, nullptr);
+    return rc;
 }
 
 int nf_kernel_path(const nf_handle *h, int32_t direction)

@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
+#include <pthread.h>
 #include <sched.h>
 #include <unistd.h>
 #include <immintrin.h>
@@ -55,6 +56,7 @@ public:
     // fn(part, parts) on every worker; returns when all are done
     void run(const std::function<void(int, int)> &fn)
     {
+        std::lock_guard<std::mutex> one(run_mu_);   // one job at a time (the pool is shared by every handle of the process)
         std::unique_lock<std::mutex> lk(mu_);
         fn_ = &fn;
         pending_ = n_;
@@ -86,7 +88,7 @@ private:
     }
     int n_;
     std::vector<std::thread> th_;
-    std::mutex mu_;
+    std::mutex mu_, run_mu_;
     std::condition_variable cv_, done_;
     const std::function<void(int, int)> *fn_ = nullptr;
     uint64_t gen_ = 0;
@@ -111,6 +113,26 @@ int usable_threads()
     }
     if (const char *e = getenv("NF_HOSTFED_THREADS")) n = atoi(e);
     return std::max(1, std::min(n, 32));
+}
+
+// ONE pool per process (every handle's host-fed calls share it; a handle used to keep up to 32 threads of its own alive).  Created
+// on first use; a fork()ed child has none of the parent's threads, so the child starts over with a fresh pool (pthread_atfork) —
+// the parent's pool object is abandoned in the child, never joined.
+std::mutex g_pool_mu;
+Pool *g_pool = nullptr;
+void pool_forget_in_child() { g_pool = nullptr; new (&g_pool_mu) std::mutex(); }
+Pool &shared_pool()
+{
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    if (!g_pool) {
+        static bool hooked = false;
+        if (!hooked) {
+            (void)pthread_atfork(nullptr, nullptr, pool_forget_in_child);
+            hooked = true;
+        }
+        g_pool = new Pool(usable_threads());
+    }
+    return *g_pool;
 }
 
 // float64 -> float32 with NON-TEMPORAL stores: the destination is pinned staging that only the DMA engine reads next, so
@@ -144,12 +166,12 @@ void narrow_base(float *dst, const double *src, size_t n)
 }
 
 // dst[0, n) <- src[0, n) as float32 (src float32 or float64), split over the pool
-void stage_in(Pool &pool, float *dst, const void *src, int dtype, size_t n)
+// `inline_only`: on the calling thread — when several callers feed one handle at once (the reference's 16 / 32 sess.run threads,
+// job_noise_flow.sh:36) THEY are the parallelism, and queueing each of their small chunks on the shared pool would serialise them
+void stage_in(float *dst, const void *src, int dtype, size_t n, bool inline_only)
 {
     static const bool avx2 = __builtin_cpu_supports("avx2");
-    pool.run([&](int part, int parts) {
-        const size_t per = ((n + parts - 1) / parts + 15) & ~(size_t)15;
-        const size_t a = std::min(n, per * part), b = std::min(n, a + per);
+    auto piece = [&](size_t a, size_t b) {
         if (a >= b) return;
         if (dtype == NF_HOST_F64) {
             if (avx2) narrow_avx2(dst + a, (const double *)src + a, b - a);
@@ -159,28 +181,42 @@ void stage_in(Pool &pool, float *dst, const void *src, int dtype, size_t n)
         } else {
             memcpy(dst + a, (const float *)src + a, (b - a) * sizeof(float));
         }
+    };
+    if (inline_only || n < (1u << 17)) {
+        piece(0, n);
+        return;
+    }
+    shared_pool().run([&](int part, int parts) {
+        const size_t per = ((n + parts - 1) / parts + 15) & ~(size_t)15;
+        const size_t a = std::min(n, per * part);
+        piece(a, std::min(n, a + per));
     });
 }
 
-// is this host pointer page-locked memory the DMA engines can address directly (hipHostMalloc / hipHostRegister)?
-bool is_pinned(const void *p)
+// can the kernel store its tensor result straight into [p, p + bytes)?  Page-locked memory the device addresses directly
+// (hipHostMalloc / hipHostRegister) — at BOTH ends of the range (a buffer registered in part would fault under the kernel) — and
+// 16-byte aligned, as the kernels' float4 stores need; anything else goes through the slot's staging
+bool is_pinned(const void *p, size_t bytes)
 {
-    if (!p) return false;
-    hipPointerAttribute_t at;
-    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
-        (void)hipGetLastError();   // ordinary pageable memory: not an error for us
-        return false;
+    if (!p || bytes == 0 || (reinterpret_cast<uintptr_t>(p) & 15u) != 0) return false;
+    for (const char *q : {(const char *)p, (const char *)p + bytes - 1}) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, q) != hipSuccess) {
+            (void)hipGetLastError();   // ordinary pageable memory: not an error for us
+            return false;
+        }
+        if (at.type != hipMemoryTypeHost) return false;
     }
-    return at.type == hipMemoryTypeHost;
+    return true;
 }
 
-void stage_out(Pool &pool, float *dst, const float *src, size_t n)
+void stage_out(float *dst, const float *src, size_t n, bool inline_only)
 {
-    if (n < (1u << 16)) {
+    if (inline_only || n < (1u << 17)) {
         memcpy(dst, src, n * sizeof(float));
         return;
     }
-    pool.run([&](int part, int parts) {
+    shared_pool().run([&](int part, int parts) {
         const size_t per = ((n + parts - 1) / parts + 15) & ~(size_t)15;
         const size_t a = std::min(n, per * part), b = std::min(n, a + per);
         if (a < b) memcpy(dst + a, src + a, (b - a) * sizeof(float));
@@ -206,14 +242,29 @@ struct nf_hostpipe {
     Slot s[kSlots];
     double *d_sums = nullptr;
     double *h_sums = nullptr;   // pinned
-    Pool *pool = nullptr;
-    std::mutex mu;              // calls on one pipe serialise
+    bool busy = false;          // a call is on this pipe (guarded by g_pipes_mu)
 };
 
 namespace {
 
+// handle -> its pipes (the handle type is opaque here).  A call takes a pipe that no other call is on, or makes one — so the
+// host threads that share a handle (train_noise_flow.py:30-47: every queue worker calls sess.run on its own) overlap one
+// caller's narrowing with another's DMA and kernel instead of queueing on one pipe.  At most max_pipes() calls are in flight on a
+// handle, further callers wait their turn (asleep): measured with 138-patch float64 minibatches, 4 calls in flight give 1.8 x
+// the single caller's rate, 16 give 0.8 x — 16 threads polling events and taking turns on the HIP runtime's locks cost more
+// than the overlap they add (tools/host_fed.py).  NF_HOSTFED_PIPES overrides (1 .. 16).
+int max_pipes()
+{
+    static const int n = [] {
+        const char *e = getenv("NF_HOSTFED_PIPES");
+        const int v = e ? atoi(e) : 4;
+        return v < 1 ? 1 : v > 16 ? 16 : v;
+    }();
+    return n;
+}
 std::mutex g_pipes_mu;
-std::vector<std::pair<nf_handle *, nf_hostpipe *>> g_pipes;   // handle -> pipe (the handle type is opaque here)
+std::condition_variable g_pipes_cv;
+std::vector<std::pair<nf_handle *, nf_hostpipe *>> g_pipes;
 
 void pipe_free(nf_hostpipe *p)
 {
@@ -236,20 +287,33 @@ void pipe_free(nf_hostpipe *p)
     }
     if (p->d_sums) (void)hipFree(p->d_sums);
     if (p->h_sums) (void)hipHostFree(p->h_sums);
-    delete p->pool;
     delete p;
     if (prev >= 0) (void)hipSetDevice(prev);
 }
 
-// the handle's pipe, created on first use (device buffers + pinned staging for kSlots chunks)
-int pipe_get(nf_handle *h, int H, int W, int device, nf_hostpipe **out)
+// a pipe of the handle that no call is on — created on demand (device buffers + pinned staging for kSlots chunks) —, marked busy;
+// `others` = how many other calls are on the handle's pipes right now
+int pipe_get(nf_handle *h, int H, int W, int device, nf_hostpipe **out, int *others)
 {
-    std::lock_guard<std::mutex> lk(g_pipes_mu);
-    for (auto &kv : g_pipes)
-        if (kv.first == h) {
-            *out = kv.second;
+    std::unique_lock<std::mutex> lk(g_pipes_mu);
+    for (;;) {
+        int mine = 0, busy = 0;
+        nf_hostpipe *free_pipe = nullptr;
+        for (auto &kv : g_pipes)
+            if (kv.first == h) {
+                ++mine;
+                if (kv.second->busy) ++busy;
+                else if (!free_pipe) free_pipe = kv.second;
+            }
+        *others = busy;
+        if (free_pipe) {
+            free_pipe->busy = true;
+            *out = free_pipe;
             return NF_OK;
         }
+        if (mine < max_pipes()) break;
+        g_pipes_cv.wait(lk);
+    }
     nf_hostpipe *p = new (std::nothrow) nf_hostpipe();
     if (!p) return nf_fail(NF_ENOMEM, "out of host memory");
     p->device = device;
@@ -270,11 +334,24 @@ int pipe_get(nf_handle *h, int H, int W, int device, nf_hostpipe **out)
         pipe_free(p);
         return nf_fail_hip(e, "host-fed pipeline allocation");
     }
-    p->pool = new Pool(usable_threads());
+    p->busy = true;
     g_pipes.emplace_back(h, p);
     *out = p;
     return NF_OK;
 }
+
+struct PipeLease {   // hands the pipe back when the call returns
+    nf_hostpipe *p = nullptr;
+    ~PipeLease()
+    {
+        if (!p) return;
+        {
+            std::lock_guard<std::mutex> lk(g_pipes_mu);
+            p->busy = false;
+        }
+        g_pipes_cv.notify_one();
+    }
+};
 
 // slot buffers for chunks of up to min(need, chunk) patches (a wrapper that samples one patch at a time never pins 72 MiB)
 int pipe_reserve(nf_hostpipe *p, int64_t need)
@@ -337,17 +414,18 @@ struct DevGuard {
 // called by nf_destroy (nf_host.hip)
 void nf_hostpipe_release(nf_handle *h)
 {
-    nf_hostpipe *p = nullptr;
+    std::vector<nf_hostpipe *> mine;
     {
         std::lock_guard<std::mutex> lk(g_pipes_mu);
-        for (size_t i = 0; i < g_pipes.size(); ++i)
+        for (size_t i = 0; i < g_pipes.size();)
             if (g_pipes[i].first == h) {
-                p = g_pipes[i].second;
+                mine.push_back(g_pipes[i].second);
                 g_pipes.erase(g_pipes.begin() + i);
-                break;
+            } else {
+                ++i;
             }
     }
-    pipe_free(p);
+    for (nf_hostpipe *p : mine) pipe_free(p);
 }
 
 extern "C" {
@@ -365,12 +443,15 @@ int nf_nll_host(nf_handle *h, const void *x, const void *y, int32_t dtype, int64
     DevGuard guard;
     if ((rc = guard.enter(device)) != NF_OK) return rc;
     nf_hostpipe *p = nullptr;
-    if ((rc = pipe_get(h, H, W, device, &p)) != NF_OK) return rc;
-    std::lock_guard<std::mutex> lk(p->mu);
+    int others = 0;
+    if ((rc = pipe_get(h, H, W, device, &p, &others)) != NF_OK) return rc;
+    PipeLease lease;
+    lease.p = p;
+    const bool solo = others == 0;   // no other caller on this handle: the shared pool narrows; else this thread does
     if ((rc = pipe_reserve(p, B)) != NF_OK) return rc;
     const int64_t CH = pipe_chunk(p, B);
     const size_t px = p->px, esz = dtype == NF_HOST_F64 ? 8 : 4;
-    const bool z_direct = is_pinned(z_out);   // page-locked caller memory: D2H straight into it
+    const bool z_direct = is_pinned(z_out, (size_t)B * px * sizeof(float));   // page-locked caller memory: the kernel stores straight into it
     hipError_t e;
     if (sums_out && (e = hipMemsetAsync(p->d_sums, 0, 3 * sizeof(double), p->s[0].st)) != hipSuccess) return nf_fail_hip(e, "hipMemsetAsync");
     if (sums_out && (e = hipStreamSynchronize(p->s[0].st)) != hipSuccess) return nf_fail_hip(e, "hipStreamSynchronize");
@@ -383,7 +464,7 @@ int nf_nll_host(nf_handle *h, const void *x, const void *y, int32_t dtype, int64
         if (nll_out) memcpy(nll_out + s.first, s.h_s, n * sizeof(float));
         if (sd_out) memcpy(sd_out + s.first, s.h_s + CH, n * sizeof(float));
         if (logdet_out) memcpy(logdet_out + s.first, s.h_s + 2 * CH, n * sizeof(float));
-        if (z_out && !z_direct) stage_out(*p->pool, z_out + (size_t)s.first * px, s.h_t, n * px);
+        if (z_out && !z_direct) stage_out(z_out + (size_t)s.first * px, s.h_t, n * px, !solo);
         s.count = 0;
         return NF_OK;
     };
@@ -393,8 +474,8 @@ int nf_nll_host(nf_handle *h, const void *x, const void *y, int32_t dtype, int64
         Slot &s = p->s[c % kSlots];
         if ((rc = retire(s)) != NF_OK) break;
         const int64_t n = std::min(CH, B - first);
-        stage_in(*p->pool, s.h_a, (const char *)x + (size_t)first * px * esz, dtype, (size_t)n * px);
-        if (y) stage_in(*p->pool, s.h_b, (const char *)y + (size_t)first * px * esz, dtype, (size_t)n * px);
+        stage_in(s.h_a, (const char *)x + (size_t)first * px * esz, dtype, (size_t)n * px, !solo);
+        if (y) stage_in(s.h_b, (const char *)y + (size_t)first * px * esz, dtype, (size_t)n * px, !solo);
         if ((e = hipMemcpyAsync(s.d_a, s.h_a, (size_t)n * px * 4, hipMemcpyHostToDevice, s.st)) != hipSuccess ||
             (y && (e = hipMemcpyAsync(s.d_b, s.h_b, (size_t)n * px * 4, hipMemcpyHostToDevice, s.st)) != hipSuccess)) {
             rc = nf_fail_hip(e, "hipMemcpyAsync(H2D)");
@@ -441,19 +522,22 @@ int nf_sample_host(nf_handle *h, const void *y, int32_t y_dtype, const float *ep
     DevGuard guard;
     if ((rc = guard.enter(device)) != NF_OK) return rc;
     nf_hostpipe *p = nullptr;
-    if ((rc = pipe_get(h, H, W, device, &p)) != NF_OK) return rc;
-    std::lock_guard<std::mutex> lk(p->mu);
+    int others = 0;
+    if ((rc = pipe_get(h, H, W, device, &p, &others)) != NF_OK) return rc;
+    PipeLease lease;
+    lease.p = p;
+    const bool solo = others == 0;
     if ((rc = pipe_reserve(p, B)) != NF_OK) return rc;
     const int64_t CH = pipe_chunk(p, B);
     const size_t px = p->px, esz = y_dtype == NF_HOST_F64 ? 8 : 4;
-    const bool x_direct = is_pinned(x_out);   // page-locked caller memory: D2H straight into it
+    const bool x_direct = is_pinned(x_out, (size_t)B * px * sizeof(float));   // page-locked caller memory: the kernel stores straight into it
     hipError_t e;
 
     auto retire = [&](Slot &s) -> int {
         if (s.count == 0) return NF_OK;
         hipError_t er = hipEventSynchronize(s.ev);
         if (er != hipSuccess) return nf_fail_hip(er, "host-fed chunk");
-        if (!x_direct) stage_out(*p->pool, x_out + (size_t)s.first * px, s.h_t, (size_t)s.count * px);
+        if (!x_direct) stage_out(x_out + (size_t)s.first * px, s.h_t, (size_t)s.count * px, !solo);
         s.count = 0;
         return NF_OK;
     };
@@ -463,8 +547,8 @@ int nf_sample_host(nf_handle *h, const void *y, int32_t y_dtype, const float *ep
         Slot &s = p->s[c % kSlots];
         if ((rc = retire(s)) != NF_OK) break;
         const int64_t n = std::min(CH, B - first);
-        if (y) stage_in(*p->pool, s.h_b, (const char *)y + (size_t)first * px * esz, y_dtype, (size_t)n * px);
-        if (eps) stage_in(*p->pool, s.h_a, eps + (size_t)first * px, NF_HOST_F32, (size_t)n * px);
+        if (y) stage_in(s.h_b, (const char *)y + (size_t)first * px * esz, y_dtype, (size_t)n * px, !solo);
+        if (eps) stage_in(s.h_a, eps + (size_t)first * px, NF_HOST_F32, (size_t)n * px, !solo);
         if ((y && (e = hipMemcpyAsync(s.d_b, s.h_b, (size_t)n * px * 4, hipMemcpyHostToDevice, s.st)) != hipSuccess) ||
             (eps && (e = hipMemcpyAsync(s.d_a, s.h_a, (size_t)n * px * 4, hipMemcpyHostToDevice, s.st)) != hipSuccess)) {
             rc = nf_fail_hip(e, "hipMemcpyAsync(H2D)");

@@ -100,8 +100,8 @@ def test_large_patches_on_the_width_32_kernel(width, cnn_dtype, hw, arch, path):
 
 
 def test_tiled_calls_from_concurrent_streams_share_one_handle(shipped_variables):
-    """Scratch of a tiled call (per-tile sums, the tensor between two segments) is a stream-ordered allocation of THAT call:
-    8 threads on their own streams, one handle, 256x256 images in two segments."""
+    """Scratch of a tiled call (per-tile sums, the tensor between two segments) is a buffer of the handle's workspace set that
+    no other call in flight uses: 8 threads on their own streams, one handle, 256x256 images in two segments."""
     import threading
     import torch
     from noise_flow_amd import NoiseFlow, default_hps
@@ -130,6 +130,36 @@ def test_tiled_calls_from_concurrent_streams_share_one_handle(shipped_variables)
     [t.start() for t in th]
     [t.join() for t in th]
     assert not errs, errs[0]
+
+
+def test_tiled_workspace_is_owned_by_the_handle_and_reservable(shipped_variables):
+    """SURVEY 8b: no allocation inside nf_nll / nf_sample.  Patches up to 64x64 need no scratch (nf_workspace_bytes = 0);
+    beyond that nf_workspace_bytes says what a call of B images needs, nf_reserve_workspace sets it aside for n calls in
+    flight, and calls after that run with the device's free memory unchanged (no hipMalloc of any kind in them)."""
+    import torch
+    from noise_flow_amd import NoiseFlow, default_hps
+    small = NoiseFlow([32, 32, 4], False, default_hps(), variables=shipped_variables)
+    assert small._flow.lib.nf_workspace_bytes(small._flow.ptr, 0, 1024) == 0
+    m = NoiseFlow([192, 160, 4], False, default_hps(arch=FULL_ARCH, width=4), variables=shipped_variables)
+    lib, B = m._flow.lib, 4
+    need = lib.nf_workspace_bytes(m._flow.ptr, 0, B)
+    assert need >= B * 192 * 160 * 16 and lib.nf_workspace_bytes(m._flow.ptr, 1, B) <= need      # >= one tensor between two segments
+    from noise_flow_amd import _lib
+    _lib.check(lib.nf_reserve_workspace(m._flow.ptr, B, 2))
+    x, y = make_inputs(B, 192, 160, seed=4)
+    xt, yt = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    nll0, _ = m._loss(xt, yt, [0], [0], [100], [2])          # also warms torch's own caching allocator for the outputs
+    z0, _ = m.inverse(xt, None, yt, [0], [0], [100], [2])
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(5):
+        nll, _ = m._loss(xt, yt, [0], [0], [100], [2])
+        z, _ = m.inverse(xt, None, yt, [0], [0], [100], [2])
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free0
+    assert torch.equal(nll, nll0) and torch.equal(z, z0)
+    with pytest.raises(Exception):
+        _lib.check(lib.nf_reserve_workspace(m._flow.ptr, B, 0))
 
 
 @pytest.mark.parametrize("compat", [None, "reference"])

@@ -32,3 +32,31 @@ for B in (64, 1024, 4096):
             fn()
         dt = (time.perf_counter() - t) / n
         print("B=%5d %-24s %.3f ms/call  %.3e patches/s" % (B, name, dt * 1e3, B / dt), flush=True)
+
+# ---- many callers on one handle (the reference's queue workers: job_noise_flow.sh:36 runs 16 threads, each calling sess.run
+#      on its own minibatch of 138 float64 patches, train_noise_flow.py:30-47): aggregate rate, 1 thread vs 16
+import threading
+Bm = 138
+ym = rng.rand(Bm, 32, 32, 4)
+xm = rng.randn(Bm, 32, 32, 4) * 0.02
+ref, _ = m._loss(xm, ym, [0], [0], [100], [2])
+for nthreads in (1, 4, 16):
+    calls = 200
+    outs = [None] * nthreads
+
+    def work(i):
+        for _ in range(calls // nthreads):
+            outs[i] = m._loss(xm, ym, [0], [0], [100], [2])[0]
+    for i in range(nthreads):
+        work(i)                                    # warm-up: every thread's pipe exists
+    th = [threading.Thread(target=work, args=(i,)) for i in range(nthreads)]
+    t = time.perf_counter()
+    for k in th:
+        k.start()
+    for k in th:
+        k.join()
+    dt = time.perf_counter() - t
+    done = (calls // nthreads) * nthreads
+    same = all(np.array_equal(o, ref) for o in outs)
+    print("host-fed _loss(float64), B=%d per call, %2d threads on ONE handle: %.3e patches/s aggregate, identical results: %s"
+          % (Bm, nthreads, done * Bm / dt, same), flush=True)
