@@ -269,14 +269,29 @@ def _run_sharded(ctx, spec, K, Wm):
     from noise_flow_amd import NoiseFlow, default_hps
     from noise_flow_amd.dist import ResidentShard, timed_sharded_evaluations
     args, rank, world, dev = ctx["args"], ctx["rank"], ctx["world"], ctx["dev"]
-    if spec["name"] == "c4":
-        model = ctx["model"]
-    else:
-        model = NoiseFlow([spec["height"], spec["width"], 4], False, default_hps(), variables=ctx["variables"],
-                          device=ctx["local_rank"], cnn_dtype=spec["cnn_dtype"])
+    # Everything that can fail on ONE rank alone (model creation, the rank's share of the resident block: 34 GB / N) happens
+    # before the first collective of this workload, and the ranks agree on the outcome: a rank that raised while the others
+    # entered the all-reduce of the first evaluation would leave them waiting forever — and with them the headline line.
+    model = shard = None
+    err = None
+    try:
+        if spec["name"] == "c4":
+            model = ctx["model"]
+        else:
+            model = NoiseFlow([spec["height"], spec["width"], 4], False, default_hps(), variables=ctx["variables"],
+                              device=ctx["local_rank"], cnn_dtype=spec["cnn_dtype"])
+        shard = ResidentShard(model, args.seed, spec["total"], rank, world, spec["height"], spec["width"],
+                              fill_chunk=max(1, (1 << 25) // (spec["height"] * spec["width"])))
+    except Exception as e:
+        err = e
+    ok = torch.tensor([0.0 if err is not None else 1.0], dtype=torch.float64, device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if float(ok.item()) < 1.0:
+        del shard
+        torch.cuda.empty_cache()
+        raise RuntimeError("set-up of the sharded workload %r failed on %s" % (
+            spec["name"], "this rank: %s: %s" % (type(err).__name__, err) if err is not None else "another rank"))
     n_total = spec["total"]
-    shard = ResidentShard(model, args.seed, n_total, rank, world, spec["height"], spec["width"],
-                          fill_chunk=max(1, (1 << 25) // (spec["height"] * spec["width"])))
     n_local = shard.stop - shard.start
     chunk = args.shard_chunk if args.shard_chunk > 0 else max(1, n_local)
     eval_chunk = shard.eval_chunk()

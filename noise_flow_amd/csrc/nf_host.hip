@@ -1230,7 +1230,11 @@ int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float
     memset(&out.prog5, 0, sizeof(out.prog5));
     // width 4 has its own fp16 kernel for the two full shapes (nf_kernels.hip); on any other shape it runs here, zero-padded
     // to 32 channels (exact: same rounding points, a padded channel is identically zero)
-    const bool w4_full = ((th == 32 && tw == 32) || (th == 64 && tw == 64)) && !out.tiled;   // tiled: the width-32 fp16 kernel
+    // NF_H16=4x4 (read at nf_create) keeps the v_mfma_f32_4x4x4_16b_f16 formulation of the width-4 fp16 kernel — an A/B aid
+    const bool fp16_big = [] { const char *e = getenv("NF_H16"); return !(e && strcmp(e, "4x4") == 0); }();
+    // width 4 in fp16-CNN mode has its own kernel for full 32x32 / 64x64 patches — and, on v_mfma_f32_16x16x32_f16, for images
+    // tiled into full 64x64 tiles; everything else rides the width-32 fp16 kernel zero-padded
+    const bool w4_full = ((th == 32 && tw == 32) || (th == 64 && tw == 64)) && (!out.tiled || (fp16_big && th == 64 && tw == 64));
     if ((cfg->flags & NF_CFG_FP16_CNN) &&
         (out.prog.width == 8 || out.prog.width == 16 || out.prog.width == 32 || (out.prog.width == 4 && !w4_full))) {
         out.prog5.width = 32;
@@ -1257,9 +1261,7 @@ int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float
     memset(&out.prog3, 0, sizeof(out.prog3));
     if (out.prog.width == 4 && (cfg->flags & NF_CFG_FP16_CNN)) {
         out.prog3.width = 4;
-        // NF_H16=4x4 (read at nf_create) keeps the v_mfma_f32_4x4x4_16b_f16 formulation — an A/B aid, like NF_KERNEL=valu
-        const char *h16 = getenv("NF_H16");
-        out.fp16_big = !(h16 && strcmp(h16, "4x4") == 0);
+        out.fp16_big = fp16_big;
         for (int i = 0; i < out.prog.n_ops; ++i) {
             const NfOp &src = out.prog.ops[i];
             NfOp &dst = out.prog3.ops[out.prog3.n_ops++];
@@ -1532,7 +1534,8 @@ int nf_create(const nf_config *cfg, const nf_layer_desc *layers, const float *pa
     }
     if (cfg->flags & NF_CFG_FP16_CNN) {
         const int hw = cfg->height * cfg->width;
-        const bool w4_ok = !h->fwd.block3.empty() && ((cfg->height == 32 && cfg->width == 32) || (cfg->height == 64 && cfg->width == 64));
+        const bool w4_ok = !h->fwd.block3.empty() && ((cfg->height == 32 && cfg->width == 32) || (cfg->height == 64 && cfg->width == 64) ||
+                                                      (h->fwd.tiled && h->fwd.fp16_big && h->fwd.tile_h == 64 && h->fwd.tile_w == 64));
         if ((!w4_ok && h->fwd.block5.empty() && h->fwd.block8.empty()) || hw == 0) {
             nf_destroy(h);   // the scalar-layout blocks are already on the device
             return fail(NF_EINVAL, "NF_CFG_FP16_CNN: no half-precision kernel for this width / patch shape");
@@ -1770,9 +1773,11 @@ static int launch_tiled(nf_handle *h, int direction, NfLaunch &a, hipStream_t st
     // the fused width-4 kernels
     float *d4 = direction == 0 ? h->d_fwd4 : h->d_rev4;
     float *d5 = direction == 0 ? h->d_fwd5 : h->d_rev5;
-    const int wide = d5 ? 2 : (d4 && b.prog.width > 4) ? 1 : 0;
-    const bool mc = d2 && (use_matrix_core() || !h->scalar_ok);
-    const NfProgram &full = wide == 2 ? b.prog5 : wide == 1 ? b.prog4 : mc ? b.prog2 : b.prog;
+    float *d3 = direction == 0 ? h->d_fwd3 : h->d_rev3;
+    const bool hb = d3 && b.fp16_big && !d5;   // width 4, fp16 CNN, full 64x64 tiles: the fused kernel on v_mfma_f32_16x16x32_f16
+    const int wide = hb ? 0 : d5 ? 2 : (d4 && b.prog.width > 4) ? 1 : 0;
+    const bool mc = hb || (d2 && (use_matrix_core() || !h->scalar_ok));
+    const NfProgram &full = hb ? b.prog3 : wide == 2 ? b.prog5 : wide == 1 ? b.prog4 : mc ? b.prog2 : b.prog;
     const float *cur = a.in;
     for (int s = 0; s < S && e == hipSuccess; ++s) {
         const Built::TileSeg &g = b.segs[s];
@@ -1806,8 +1811,13 @@ static int launch_tiled(nf_handle *h, int direction, NfLaunch &a, hipStream_t st
             if (wide == 2) t.flags |= NF_K_FP16_CNN;
             e = nf_launch_wide(sp, t, h->n_cu, h->device, st);
         } else {
-            t.params = mc ? d2 : d1;
-            if (mc) t.n_params = (int32_t)b.block2.size();
+            t.params = hb ? d3 : mc ? d2 : d1;
+            if (hb) {
+                t.n_params = (int32_t)b.block3.size();
+                t.flags |= NF_K_FP16_CNN | NF_K_FP16_BIG;
+            } else if (mc) {
+                t.n_params = (int32_t)b.block2.size();
+            }
             e = nf_launch_flow(sp, t, h->n_cu, st, mc);
         }
         cur = t.out;
@@ -1917,6 +1927,7 @@ int nf_kernel_path(const nf_handle *h, int32_t direction)
     if (!h || (direction != 0 && direction != 1)) return fail(NF_EINVAL, "bad argument");
     if (direction == 0 ? h->d_fwd5 : h->d_rev5) return NF_PATH_WIDE32_FP16;
     if (h->fwd.tiled) {   // images beyond 64x64: launch_tiled's choice
+        if ((direction == 0 ? h->d_fwd3 : h->d_rev3) && h->fwd.fp16_big) return NF_PATH_FP16;
         if ((direction == 0 ? h->d_fwd4 : h->d_rev4) && h->fwd.prog.width > 4) return NF_PATH_WIDE32;
         return (direction == 0 ? h->d_fwd2 : h->d_rev2) && (use_matrix_core() || !h->scalar_ok) ? NF_PATH_MFMA4 : NF_PATH_SCALAR;
     }

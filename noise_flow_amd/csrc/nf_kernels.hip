@@ -134,7 +134,7 @@ template <int WIDTH, int THREADS, int PX, bool PHILOX, bool MFMA, bool FULL, int
 __device__ __forceinline__ void nf_flow_body(const NfProgram &prog, const NfLaunch &a)
 {
     static_assert(!BS || (MFMA && PREC == 0), "the batch-statistics variant is the fp32 matrix-core kernel");
-    static_assert(!TF || (FULL && MFMA && PX == 4 && PREC == 0 && !BS), "tiled full-geometry launches: the fp32 matrix-core kernel");
+    static_assert(!TF || (FULL && MFMA && PX == 4 && PREC != 1 && !BS), "tiled full-geometry launches: the fp32 matrix-core kernel and the fp16-CNN kernel on v_mfma_f32_16x16x32_f16");
     static_assert(WIDTH % 4 == 0, "WIDTH must be a multiple of 4");
     static_assert(!MFMA || WIDTH == 4, "the matrix-core path is the width-4 specialisation");
     static_assert(PREC == 0 || (MFMA && FULL && PX == 4), "the fp16-CNN mode exists for full 2x2-blocked patches only");
@@ -1321,11 +1321,12 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NF_MIN_
     nf_flow_body<WIDTH, THREADS, PX, PHILOX, MFMA, FULL, PREC, BS, false>(prog, a);
 }
 
-// NF_K_TILED launches over full 64x64 tiles: the 2x2-blocked matrix-core geometry of nf_flow_kernel<4, 1024, 4, ., true, true, 0, false>
-template <bool PHILOX>
+// NF_K_TILED launches over full 64x64 tiles: the full-patch matrix-core geometry of nf_flow_kernel<4, 1024, 4, ., true, true, PREC, false>
+// (PREC = 0: fp32, 2x2-blocked lanes; PREC = 2: fp16 CNN on v_mfma_f32_16x16x32_f16)
+template <bool PHILOX, int PREC>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(NF_MIN_WAVES(1024, 4, true)))) void nf_flow_tile64_kernel(const NfProgram prog, const NfLaunch a)
 {
-    nf_flow_body<4, 1024, 4, PHILOX, true, true, 0, false, true>(prog, a);
+    nf_flow_body<4, 1024, 4, PHILOX, true, true, PREC, false, true>(prog, a);
 }
 
 // Batch-statistics mode, device side of the re-fold (layers.py:388-391 + the BN-eval folding of fold_coupling):
@@ -1501,7 +1502,7 @@ hipError_t launch_flow_p(const NfProgram &prog, const NfLaunch &a, int n_cu, hip
     const size_t lds = sizeof(float) * lds_f;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     void (*const kern)(const NfProgram, const NfLaunch) = [] {
-        if constexpr (TF) return &nf_flow_tile64_kernel<PHILOX>;
+        if constexpr (TF) return &nf_flow_tile64_kernel<PHILOX, PREC>;
         else return &nf_flow_kernel<WIDTH, THREADS, PX, PHILOX, MFMA, FULL, PREC, BS>;
     }();
     const void *fn = reinterpret_cast<const void *>(kern);
@@ -1558,6 +1559,7 @@ hipError_t launch_flow_v(const NfProgram &prog, const NfLaunch &a, int n_cu, hip
             if (!(a.flags & NF_K_TILED)) return launch_flow_f<WIDTH, THREADS, PX, PHILOX, MFMA, true>(prog, a, n_cu, stream);
             // tiled launches: full 64x64 tiles have their own instantiation of the blocked geometry, everything else is masked
             if constexpr (MFMA && WIDTH == 4 && THREADS == 1024 && PX == 4) {
+                if (a.flags & NF_K_FP16_BIG) return launch_flow_p<WIDTH, THREADS, PX, PHILOX, MFMA, true, 2, false, true>(prog, a, n_cu, stream);
                 static const bool masked = env_int("NF_TILE_MASKED") != 0;   // A/B aid
                 if (!masked && !(a.flags & NF_K_BATCHSTATS)) return launch_flow_p<WIDTH, THREADS, PX, PHILOX, MFMA, true, 0, false, true>(prog, a, n_cu, stream);
             }

@@ -269,14 +269,31 @@ class NoiseFlow(object):
             err = []
 
             def allreduce(user, ptr, count, stream):
-                try:   # `ptr` is buf's storage; the library wrote this rank's sums on torch's current stream
-                    dist.all_reduce(buf[:int(count)], op=dist.ReduceOp.SUM, group=grp)
+                try:   # `ptr` is buf's storage; the library wrote this rank's sums on `stream` and reads them back there
+                    with torch.cuda.stream(torch.cuda.ExternalStream(int(stream or 0), device=self._dev.device)):
+                        dist.all_reduce(buf[:int(count)], op=dist.ReduceOp.SUM, group=grp)
                     return 0
                 except Exception as e:   # never let an exception cross the C frame
                     err.append(e)
                     return 1
-            self._sync = (_lib.ALLREDUCE_FN(allreduce), buf, dist.get_world_size(grp), err)
+            self._sync = (_lib.ALLREDUCE_FN(allreduce), buf, dist.get_world_size(grp), err, grp)
         self._install_sync()
+
+    def _check_equal_shards(self, B: int) -> None:
+        """The library forms the synchronised moments with n = world x the LOCAL pixel count (nf_set_sync), i.e. every rank must
+        feed the same number of patches to an ``is_training=True`` call; a MAX all-reduce of (B, -B) says so before the call
+        (these calls synchronise anyway: nf_*_batchstats end in a stream synchronise)."""
+        sync = getattr(self, "_sync", None)
+        if sync is None:
+            return
+        import torch.distributed as dist
+        torch = self._dev.torch
+        t = torch.tensor([float(B), -float(B)], dtype=torch.float64, device=self._dev.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=sync[4])
+        hi, neg_lo = (float(v) for v in t.cpu())
+        if hi != -neg_lo:
+            raise ValueError("set_sync_bn needs the same number of patches on every rank (between %d and %d here): the batch "
+                             "moments are formed with world x the local pixel count" % (int(-neg_lo), int(hi)))
 
     def _install_sync(self):
         sync = getattr(self, "_sync", None)
@@ -375,6 +392,7 @@ class NoiseFlow(object):
         with torch.cuda.device(dev.device):
             if self._is_training:
                 mom = self._moments_buffer()
+                self._check_equal_shards(int(xt.shape[0]))
                 _lib.check(self._flow.lib.nf_nll_batchstats(*args, mom.ctypes.data, dev.stream_ptr()))
                 self._apply_bn_ema(mom)
             else:
@@ -443,6 +461,7 @@ class NoiseFlow(object):
         with torch.cuda.device(dev.device):
             if self._is_training:
                 mom = self._moments_buffer()
+                self._check_equal_shards(int(xt.shape[0]))
                 _lib.check(self._flow.lib.nf_nll_batchstats(*args, mom.ctypes.data, dev.stream_ptr()))
                 self._apply_bn_ema(mom)
             else:
@@ -561,6 +580,7 @@ class NoiseFlow(object):
         with dev.torch.cuda.device(dev.device):
             if self._is_training:
                 mom = self._moments_buffer()
+                self._check_equal_shards(B)
                 _lib.check(self._flow.lib.nf_sample_batchstats(*args, mom.ctypes.data, dev.stream_ptr()))
                 self._apply_bn_ema(mom)
             else:

@@ -210,31 +210,46 @@ class Trainer:
         if pend is None:
             pend = self._shard_checks = []
         while pend and (wait or pend[0][0].query()):
-            ev, host, step_no = pend.pop(0)
+            ev, host, step_no, src = pend.pop(0)
             ev.synchronize()
             hi, neg_lo = float(host[0]), float(host[1])
+            self._shard_pool.append((src, host, ev))
             if hi != -neg_lo:
                 pend.clear()
+                self._shard_verified_B = None
                 raise ValueError("sync_bn needs the same number of patches on every rank (step %d: between %d and %d): the batch "
                                  "moments are formed with world x the local pixel count" % (step_no, int(-neg_lo), int(hi)))
 
     def _check_equal_shards(self, B: int, grp):
         """Synchronised batch normalisation takes its moments over world x the LOCAL pixel count (the library's ``n``), which
-        is the global count only when every rank feeds the same number of patches.  One 16-byte MAX all-reduce of (B, -B) per
-        step, read back WITHOUT stalling the step: the result of step k is looked at when its copy has landed (a step or two
-        later) and a mismatch raises there — before more updates are taken with wrong moments."""
+        is the global count only when every rank feeds the same number of patches.  One 16-byte MAX all-reduce of (B, -B).
+        The FIRST step, and every step whose B differs from the last verified one, waits for the answer before any kernel of
+        the step runs — no update is ever taken with wrong moments; a step whose B equals the last verified one (every step of
+        a normal run) only enqueues the check and looks at it when its copy has landed, without stalling (another rank may
+        have changed ITS B).  Pinned buffers and events are allocated once per trainer and recycled."""
         import torch.distributed as dist
         torch = self._dev.torch
         self._drain_shard_checks(wait=False)
         pend = self._shard_checks
         dev = self._dev.device
-        t = torch.tensor([float(B), -float(B)], dtype=torch.float64).pin_memory().to(dev, non_blocking=True)
+        pool = getattr(self, "_shard_pool", None)
+        if pool is None:
+            pool = self._shard_pool = []
+        if pool:
+            src, host, ev = pool.pop()
+        else:
+            src = torch.empty(2, dtype=torch.float64, pin_memory=True)
+            host = torch.empty(2, dtype=torch.float64, pin_memory=True)
+            ev = torch.cuda.Event()
+        src[0], src[1] = float(B), -float(B)
+        t = src.to(dev, non_blocking=True)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=grp)
-        host = torch.empty(2, dtype=torch.float64, pin_memory=True)
         host.copy_(t, non_blocking=True)
-        ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))
-        pend.append((ev, host, self.steps))
+        pend.append((ev, host, self.steps, src))
+        if getattr(self, "_shard_verified_B", None) != B:
+            self._drain_shard_checks(wait=True)          # raises on a mismatch, before forward_backward
+            self._shard_verified_B = B
 
     # ------------------------------------------------------------------ parameters
     @property

@@ -88,11 +88,14 @@ def test_tile_results_do_not_depend_on_the_batch():
                                                           (16, "fp32", (70, 130), "sdn5|unc|unc|gain4|unc", 3),
                                                           (8, "fp32", (65, 65), "unc|unc", 3),
                                                           (32, "fp16", (96, 96), "sdn5|unc|gain4|unc", 5),
-                                                          (4, "fp16", (128, 80), None, 5),
+                                                          (4, "fp16", (128, 80), None, 2),      # full 64x64 tiles: the width-4 fp16 kernel
+                                                          (4, "fp16", (256, 96), "sdn5|unc|unc|gain4|unc|unc", 2),
+                                                          (4, "fp16", (150, 40), None, 5),      # 64x40 tiles: zero-padded on the width-32 kernel
                                                           (32, "fp32", (40, 150), "unc|unc|unc", 3)])
 def test_large_patches_on_the_width_32_kernel(width, cnn_dtype, hw, arch, path):
     """Coupling widths 8 / 16 / 32 and the fp16-CNN mode (any width up to 32) run their tiles on the width-32 matrix-core
-    kernel (narrower CNNs zero-padded: exact, a padded channel is identically zero)."""
+    kernel (narrower CNNs zero-padded: exact, a padded channel is identically zero) — except width 4 in fp16-CNN mode on images
+    of at least 64 pixels per side, whose full 64x64 tiles run on the width-4 fp16 kernel (v_mfma_f32_16x16x32_f16)."""
     from check_large_patches import check
     r = check(hw[0], hw[1], 2, arch, width=width, cnn_dtype=cnn_dtype)
     assert r["kernel_path"] == path, r

@@ -30,10 +30,10 @@ def mean_counter(path, counter, kernel_sub, grid):
     vals = []
     with open(path) as f:
         for row in csv.DictReader(f):
-            if row["Counter_Name"] == counter and kernel_sub in row["Kernel_Name"] and int(row["Grid_Size"]) == grid:
+            if row["Counter_Name"] == counter and kernel_sub in row["Kernel_Name"] and (grid is None or int(row["Grid_Size"]) == grid):
                 vals.append(float(row["Counter_Value"]))
     if not vals:
-        raise SystemExit("no %s rows for a kernel containing %r with grid %d in %s" % (counter, kernel_sub, grid, path))
+        raise SystemExit("no %s rows for a kernel containing %r with grid %r in %s" % (counter, kernel_sub, grid, path))
     return sum(vals) / len(vals), len(vals)
 
 
@@ -44,7 +44,7 @@ def main():
     entry = sys.argv[5] if len(sys.argv) > 5 else None
     threads = int(sys.argv[6]) if len(sys.argv) > 6 else 256
     patch_bytes = int(sys.argv[7]) if len(sys.argv) > 7 else 2 * 32 * 32 * 4 * 4
-    grid = min(B, 256 * (4 if threads == 256 else 1)) * threads if entry else B * 256
+    grid = None if entry else B * 256      # an entry's profiling run launches nothing else under that kernel name
     fetch_kb, n_f = mean_counter(fetch_csv, "FETCH_SIZE", kernel_sub, grid)
     write_kb, n_w = mean_counter(write_csv, "WRITE_SIZE", kernel_sub, grid)
     hbm = 2.0 * fetch_kb * 1024.0 + write_kb * 1024.0
