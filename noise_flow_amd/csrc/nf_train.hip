@@ -1470,6 +1470,7 @@ __global__ void k_momentum(int n, float *__restrict__ P, const float *__restrict
 
 struct Cpl {      // per-coupling workspace
     float *h1 = nullptr, *h2 = nullptr;
+    float *a1 = nullptr, *a2 = nullptr;   // relu(bn(h)) of both hidden layers, kept for the backward pass (widths beyond 32: nf_train_gemm.h)
     float *u = nullptr;                   // l_last's output, kept for the backward pass (wide couplings only)
     int f_bn1, f_bn2, f_bb1, f_bb2;       // offsets into the float scalar buffer
     int d_st1, d_st2, d_bs1, d_bs2;       // offsets into the double buffer
@@ -1522,6 +1523,11 @@ struct nf_trainer {
     double *sync_buf = nullptr;     // caller-owned device buffer, >= 64 doubles
     int sync_world = 1;
     int sync_rc = 0;                // first non-zero status a callback returned during the current step
+    // coupling widths beyond 32 (nf_train_gemm.h): rocBLAS handle and the operands of its GEMMs
+    void *blas = nullptr;
+    float *gz18 = nullptr, *gp36 = nullptr, *gq18 = nullptr, *gw3r = nullptr;   // [pixels][18] windows, [pixels][36] taps, [pixels][18], [w][36]
+    float *gdw = nullptr;           // filter gradients of every coupling as the split GEMMs leave them: 3 per coupling x gemm_part_floats(w)
+    int gnp[3 * kMaxLayers] = {};   // how many partial products each of them holds (this step)
 };
 
 namespace {
@@ -1566,10 +1572,13 @@ struct Guard {
 void sync_slots(nf_trainer *t, Acc a, int count, int nslot, hipStream_t st)
 {
     if (!t->sync_fn || t->sync_world < 2) return;
-    hipLaunchKernelGGL(k_slots_compact, dim3((unsigned)count), dim3(64), 0, st, a, nslot, t->sync_buf);
-    const int rc = t->sync_fn(t->sync_user, t->sync_buf, (int64_t)count, (void *)st);
-    if (rc != 0 && t->sync_rc == 0) t->sync_rc = rc;
-    hipLaunchKernelGGL(k_slots_scatter, dim3((unsigned)count), dim3(64), 0, st, a, nslot, (const double *)t->sync_buf);
+    for (int c0 = 0; c0 < count; c0 += 64) {   // the caller's buffer holds 64 doubles (wide couplings have up to 1 024 sums per group)
+        const int cn = count - c0 < 64 ? count - c0 : 64;
+        hipLaunchKernelGGL(k_slots_compact, dim3((unsigned)cn), dim3(64), 0, st, a + c0, nslot, t->sync_buf);
+        const int rc = t->sync_fn(t->sync_user, t->sync_buf, (int64_t)cn, (void *)st);
+        if (rc != 0 && t->sync_rc == 0) t->sync_rc = rc;
+        hipLaunchKernelGGL(k_slots_scatter, dim3((unsigned)cn), dim3(64), 0, st, a + c0, nslot, (const double *)t->sync_buf);
+    }
 }
 
 // per-patch kernels: how many workgroups share one patch's tiles — small minibatches leave CUs idle otherwise (138 patches on
@@ -1579,6 +1588,10 @@ inline int patch_split(const Geo &g)
     const int64_t npatch = g.npix / g.HW;
     return (int)std::max<int64_t>(1, std::min<int64_t>(4, std::min<int64_t>(g.nslot / npatch, 512 / npatch)));
 }
+
+}  // namespace
+#include "nf_train_gemm.h"    // widths 33 .. 512: library GEMMs + pixel kernels of run-time width
+namespace {
 
 template <int W>
 void coupling_forward(nf_trainer *t, const Geo &g, const TLayer &L, const float *zin, float *zout, Acc ldacc,
@@ -1902,6 +1915,7 @@ int nf_trainer_destroy(nf_trainer *t)
     for (hipEvent_t ev : t->ev_done)
         if (ev) (void)hipEventDestroy(ev);
     for (void *p : t->owned) (void)hipFree(p);
+    if (t->blas && rocblas_api()) (void)rocblas_api()->destroy((rocblas_handle)t->blas);
     delete t;
     return NF_OK;
 }
@@ -1955,9 +1969,13 @@ int nf_trainer_create(const nf_config *cfg, const nf_layer_desc *layers, const f
             break;
         case NF_LAYER_COUPLING: {
             const int w = L.width;
-            if (w != 4 && w != 8 && w != 16 && w != 32) {
+            if (w != 4 && w != 8 && w != 16 && w != 32 && !(w > 32 && w <= 512)) {
                 delete t;
-                return nf_fail(NF_EINVAL, "layer %d: coupling width %d unsupported (4, 8, 16, 32)", i, w);
+                return nf_fail(NF_EINVAL, "layer %d: the trainer takes the coupling widths 4, 8, 16 and 32 .. 512 (%d given)", i, w);
+            }
+            if (w > 32 && !rocblas_api()) {
+                delete t;
+                return nf_fail(NF_EINVAL, "layer %d: training at coupling width %d runs its dense products on rocBLAS, which could not be loaded (librocblas.so.5)", i, w);
             }
             if (t->width && t->width != w) {
                 delete t;
@@ -2092,8 +2110,25 @@ int nf_trainer_create(const nf_config *cfg, const nf_layer_desc *layers, const f
         NF_TRY(dev_alloc(t, (void **)&c.h1, act * w * sizeof(float)));
         NF_TRY(dev_alloc(t, (void **)&c.h2, act * w * sizeof(float)));
         if (w >= 16) NF_TRY(dev_alloc(t, (void **)&c.u, act * 4 * sizeof(float)));
+        if (w > 32) {
+            NF_TRY(dev_alloc(t, (void **)&c.a1, act * w * sizeof(float)));
+            NF_TRY(dev_alloc(t, (void **)&c.a2, act * w * sizeof(float)));
+        }
     }
-    for (int k = 0; k < 3; ++k) {
+    if (w > 32 && n_cpl > 0) {   // nf_train_gemm.h
+        NF_TRY(dev_alloc(t, (void **)&t->gz18, act * 18 * sizeof(float)));
+        NF_TRY(dev_alloc(t, (void **)&t->gp36, act * 36 * sizeof(float)));
+        NF_TRY(dev_alloc(t, (void **)&t->gq18, act * 18 * sizeof(float)));
+        NF_TRY(dev_alloc(t, (void **)&t->gw3r, (size_t)w * 36 * sizeof(float)));
+        NF_TRY(dev_alloc(t, (void **)&t->gdw, (size_t)n_cpl * 3 * gemm_part_floats(w) * sizeof(float)));
+        rocblas_handle bh = nullptr;
+        if (rocblas_api()->create(&bh) != rocblas_status_success) {
+            nf_trainer_destroy(t);
+            return nf_fail(NF_EHIP, "rocblas_create_handle failed");
+        }
+        t->blas = bh;
+    }
+    for (int k = 0; k < (w > 32 ? 1 : 3); ++k) {
         NF_TRY(dev_alloc(t, (void **)&t->t1[k], act * w * sizeof(float)));
         NF_TRY(dev_alloc(t, (void **)&t->t2[k], act * w * sizeof(float)));
         NF_TRY(dev_alloc(t, (void **)&t->gu[k], act * 4 * sizeof(float)));
@@ -2165,6 +2200,7 @@ static int trainer_run(nf_trainer *t, const float *x, const float *y, int64_t B,
     const unsigned nb = blocks_for(g.npix);
     g.nslot = (t->sync_fn && t->sync_world > 1) ? std::max((int)nb, 2) : (int)nb;   // the synchronised totals occupy slots 0 and 1
     t->sync_rc = 0;
+    bool blas_failed = false;
     const float invB = 1.0f / (float)B;
     const int n = t->cfg.n_layers;
     hipError_t e;
@@ -2213,6 +2249,8 @@ static int trainer_run(nf_trainer *t, const float *x, const float *y, int64_t B,
                 if (L.width == 4) NF_CALL(4); else NF_CALL(8);
 #undef NF_CALL
                 f1_done = nxt != nullptr;
+            } else if (L.width > 32) {
+                if (!coupling_forward_gemm(t, g, L, zin, zout, t->acc(t->d_ld0 + l), zpre, Am, st)) blas_failed = true;
             } else {
 #define NF_CALL(WW) coupling_forward<WW>(t, g, L, zin, zout, t->acc(t->d_ld0 + l), zpre, Am, st)
                 NF_WIDTH_SWITCH(L.width, NF_CALL)
@@ -2281,6 +2319,8 @@ static int trainer_run(nf_trainer *t, const float *x, const float *y, int64_t B,
                 if (L.width == 4) NF_CALL(4); else NF_CALL(8);
 #undef NF_CALL
                 a_done = nxt != nullptr;
+            } else if (L.width > 32) {
+                if (!coupling_backward_gemm(t, g, L, t->zs[l], invB, zmix_in, Am, dA, st, zlat)) blas_failed = true;
             } else {
 #define NF_CALL(WW) coupling_backward<WW>(t, g, L, t->zs[l], invB, zmix_in, Am, dA, st, zlat)
                 NF_WIDTH_SWITCH(L.width, NF_CALL)
@@ -2297,12 +2337,42 @@ static int trainer_run(nf_trainer *t, const float *x, const float *y, int64_t B,
             (void)hipStreamWaitEvent(st, t->ev_done[par], 0);
             t->done_pending[par] = false;
         }
-    hipLaunchKernelGGL(k_reduce, dim3((unsigned)t->d_ldc), dim3(64), 0, st, t->d_ldc, t->d_part, g.nslot, G);
+    if (t->width > 32) {
+        // the filters of wide couplings get their gradients whole from the GEMMs: the slotted sums are added up for every other
+        // value only (the runs between the filters), then the GEMM results are stored next to them
+        int lo = 0;
+        auto reduce_run = [&](int a, int b) {
+            if (b > a) hipLaunchKernelGGL(k_reduce, dim3((unsigned)(b - a)), dim3(64), 0, st, b - a, t->d_part + (size_t)a * NSLOT, g.nslot, G + a);
+        };
+        for (int l = 0; l < n; ++l) {
+            const TLayer &L = t->tl.l[l];
+            if (L.type != NF_LAYER_COUPLING) continue;
+            const int w = L.width, off_w2 = L.off + 21 * w, off_w3 = L.off + 24 * w + w * w;
+            reduce_run(lo, L.off);                  // ... up to l_1/W
+            reduce_run(L.off + 18 * w, off_w2);     // l_1/b (and the BN statistics, masked out)
+            lo = off_w2 + w * w;                    // behind l_2/W: l_2/b, BN, l_last/W (edge rows), b, logs, scale
+            const float *gdw = t->gdw + (size_t)(3 * L.aux) * gemm_part_floats(w);
+            store_grad(st, 18 * w, w, 0, gdw, t->gnp[3 * L.aux], G, L.off);
+            store_grad(st, w * w, w, 0, gdw + gemm_part_floats(w), t->gnp[3 * L.aux + 1], G, off_w2);
+            (void)off_w3;
+        }
+        reduce_run(lo, t->d_ldc);
+        for (int l = 0; l < n; ++l) {               // l_last/W: after the run that holds its edge rows was reduced
+            const TLayer &L = t->tl.l[l];
+            if (L.type != NF_LAYER_COUPLING) continue;
+            const int w = L.width;
+            const float *gdw = t->gdw + (size_t)(3 * L.aux + 2) * gemm_part_floats(w);
+            store_grad(st, 36 * w, w, 1, gdw, t->gnp[3 * L.aux + 2], G, L.off + 24 * w + w * w);
+        }
+    } else {
+        hipLaunchKernelGGL(k_reduce, dim3((unsigned)t->d_ldc), dim3(64), 0, st, t->d_ldc, t->d_part, g.nslot, G);
+    }
     hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, st, t->tl, t->d_params, ci, g.HW, G + t->d_dA, G + t->d_dab, G + t->d_dg, G);
     float *gout = grads_out ? grads_out : t->d_gradf;
     hipLaunchKernelGGL(k_grads_out, dim3((t->n_params + TB - 1) / TB), dim3(TB), 0, st, t->n_params, G, t->d_mask, gout);
     t->zs[0] = nullptr;
     if ((e = hipGetLastError()) != hipSuccess) return nf_fail_hip(e, "trainer launch");
+    if (blas_failed) return nf_fail(NF_EHIP, "a rocBLAS GEMM of the wide-coupling training step failed");
     if (t->sync_rc) return nf_fail(NF_EINVAL, "the all-reduce callback of nf_trainer_set_sync failed (status %d)", t->sync_rc);
     return NF_OK;
 }

@@ -782,3 +782,37 @@ def test_round_off_allowance_where_a_gradient_cancels():
     assert abs(a - ref) <= allow and abs(b - ref) <= allow and abs(a - b) <= allow, (a, b, ref, allow)
     assert seen > 0 and allow <= 1000.0 * seen, (a, b, ref, allow, seen)
     _check_grads(tr, grads, ref_grads, oracle=o)                      # and every other tensor of the step at the usual tolerance
+
+
+@pytest.mark.parametrize("arch,width,hw,B,iso,cam", [("sdn5|unc|gain4|unc", 128, (8, 8), 3, 800, 2),
+                                                     ("unc|unc", 64, (12, 10), 4, 100, 1),
+                                                     ("sdn5|unc|unc|gain4|unc", 50, (9, 7), 5, 400, 0),      # not a multiple of 4
+                                                     ("unc", 512, (6, 6), 2, 1600, 3),                        # the reference's default width
+                                                     ("unc|unc", 96, (32, 32), 6, 800, 2)])
+def test_gradients_at_coupling_widths_beyond_32(arch, width, hw, B, iso, cam):
+    """sidd/ArgParser.py:43 defaults --width to 512 and train_noise_flow.py:50-77 trains at whatever width is set: beyond 32 the
+    step's dense products are library GEMMs (rocBLAS sgemm) between hand-written kernels over [pixel][w] tensors of run-time
+    width (csrc/nf_train_gemm.h).  Loss, sd_z, every gradient tensor and the BN running statistics against the fp64 autograd
+    oracle; one Adam step against the float32 restatement of TF's update rule."""
+    from oracle.nf_grad_oracle import adam_step
+    v = trained_like_variables(arch, width, seed=width)
+    for k in v:     # activations of O(1) at every width (the helper's weights are tuned for width 4)
+        if k.endswith("l_2/W") or k.endswith("l_last/W"):
+            v[k] = (v[k] * np.float32((4.0 / width) ** 0.5)).astype(np.float32)
+    x, y = make_inputs(B, hw[0], hw[1], seed=19)
+    tr = _trainer(arch, v, (hw[0], hw[1], 4), width)
+    _oracle_check_next_to_kinks(tr, arch, v, x, y, iso, cam, width, rtol=1e-3)
+    o = _grad_oracle(arch, v)
+    _, _, ref_grads, new_running = o.loss_and_grads(x, y, iso, cam)
+    got = tr.variables
+    for k, want in new_running.items():          # BN running statistics moved by the EMA of the batch moments (layers.py:392-393)
+        assert np.abs(np.asarray(got[k], np.float64).reshape(want.shape) - want).max() <= 1e-5 * max(np.abs(want).max(), 1e-3), k
+    tr.step(x, y, [0.0], [0.0], [iso], [cam], lr=1e-3)
+    after = tr.variables
+    want = adam_step({k: np.asarray(a, np.float32) for k, a in v.items()}, ref_grads, {}, 1e-3, dtype=np.float32)
+    for k in ref_grads:
+        if k.endswith("l_1/b") or k.endswith("l_2/b"):
+            continue                             # analytically zero gradients: Adam normalises round-off to +-lr
+        a, b = np.asarray(after[k], np.float64).reshape(-1), np.asarray(want[k], np.float64).reshape(-1)
+        moved = np.abs(b - np.asarray(v[k], np.float64).reshape(-1)) > 0
+        assert (np.abs(a - b)[moved] <= 2.5e-3).all(), k       # a step is +-lr wherever the gradient is resolved; sign flips only at its noise floor
