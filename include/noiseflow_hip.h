@@ -296,7 +296,9 @@ int nf_set_sync(nf_handle *h, nf_allreduce_fn fn, void *user, double *sync_buf, 
  * slots and an activation workspace sized for `max_batch` patches; a step only enqueues kernels on
  * `stream` — and on an internal side stream forked from and joined back into it with events — with no
  * allocation and no host synchronisation.  One stream at a time per trainer.
- * Layers: every NF_LAYER_* above (COUPLING at width 4/8/16/32) — the whole vocabulary of noise_flow_arch under every
+ * Layers: every NF_LAYER_* above (COUPLING at width 4/8/16 and 32..512; beyond 32 the dense products run on rocBLAS sgemm,
+ * loaded with dlopen when such a trainer is created — NF_EINVAL with a message if librocblas cannot be loaded) — the whole
+ * vocabulary of noise_flow_arch under every
  * setting of hps.flow_permutation / hps.decomp; fp32 (nf_config.flags must be 0).
  * Trainable = everything except P / sign_S of CONV1X1 / CONV1X1_LU2, the BN statistics and c_i of SDN5 / SDN6.
  * Kernel selection (read from the environment by nf_trainer_create; the defaults are the fast paths, the others exist for
