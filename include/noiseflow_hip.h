@@ -296,7 +296,7 @@ int nf_set_sync(nf_handle *h, nf_allreduce_fn fn, void *user, double *sync_buf, 
  * slots and an activation workspace sized for `max_batch` patches; a step only enqueues kernels on
  * `stream` — and on an internal side stream forked from and joined back into it with events — with no
  * allocation and no host synchronisation.  One stream at a time per trainer.
- * Layers: every NF_LAYER_* above (COUPLING at width 4/8/16 and 32..512; beyond 32 the dense products run on rocBLAS sgemm,
+ * Layers: every NF_LAYER_* above (COUPLING at any width 1..512: 4/8/16/32 on kernels of their own, at every other width the dense products run on rocBLAS sgemm,
  * loaded with dlopen when such a trainer is created — NF_EINVAL with a message if librocblas cannot be loaded) — the whole
  * vocabulary of noise_flow_arch under every
  * setting of hps.flow_permutation / hps.decomp; fp32 (nf_config.flags must be 0).
@@ -310,6 +310,7 @@ int nf_set_sync(nf_handle *h, nf_allreduce_fn fn, void *user, double *sync_buf, 
  *                       7 filter gradients inside the stage kernels (>= 400k pixels per step), 8 l_1 forward,
  *                       11 affine / tanh backward inside the transposed l_last kernel.  Default 4095.
  *   NF_TRAIN_BAND       pixels (rows x patch width, halo included; 96..320, default 320) a band kernel keeps in LDS.
+ *   NF_TRAIN_GEMM=1     widths 4/8/16/32 on the library-GEMM path of the other widths as well.
  *   NF_TRAIN_SERIAL=1   no side stream: every kernel on the caller's stream (kernel traces without overlap). */
 typedef struct nf_trainer nf_trainer;
 #define NF_OPT_ADAM     0

@@ -1969,11 +1969,11 @@ int nf_trainer_create(const nf_config *cfg, const nf_layer_desc *layers, const f
             break;
         case NF_LAYER_COUPLING: {
             const int w = L.width;
-            if (w != 4 && w != 8 && w != 16 && w != 32 && !(w > 32 && w <= 512)) {
+            if (w < 1 || w > 512) {
                 delete t;
-                return nf_fail(NF_EINVAL, "layer %d: the trainer takes the coupling widths 4, 8, 16 and 32 .. 512 (%d given)", i, w);
+                return nf_fail(NF_EINVAL, "layer %d: the trainer takes the coupling widths 1 .. 512 (%d given)", i, w);
             }
-            if (w > 32 && !rocblas_api()) {
+            if (gemm_width(w) && !rocblas_api()) {
                 delete t;
                 return nf_fail(NF_EINVAL, "layer %d: training at coupling width %d runs its dense products on rocBLAS, which could not be loaded (librocblas.so.5)", i, w);
             }
@@ -2109,13 +2109,13 @@ int nf_trainer_create(const nf_config *cfg, const nf_layer_desc *layers, const f
     for (Cpl &c : t->cpl) {
         NF_TRY(dev_alloc(t, (void **)&c.h1, act * w * sizeof(float)));
         NF_TRY(dev_alloc(t, (void **)&c.h2, act * w * sizeof(float)));
-        if (w >= 16) NF_TRY(dev_alloc(t, (void **)&c.u, act * 4 * sizeof(float)));
-        if (w > 32) {
+        if (w >= 16 || gemm_width(w)) NF_TRY(dev_alloc(t, (void **)&c.u, act * 4 * sizeof(float)));
+        if (gemm_width(w)) {
             NF_TRY(dev_alloc(t, (void **)&c.a1, act * w * sizeof(float)));
             NF_TRY(dev_alloc(t, (void **)&c.a2, act * w * sizeof(float)));
         }
     }
-    if (w > 32 && n_cpl > 0) {   // nf_train_gemm.h
+    if (gemm_width(w) && n_cpl > 0) {   // nf_train_gemm.h
         NF_TRY(dev_alloc(t, (void **)&t->gz18, act * 18 * sizeof(float)));
         NF_TRY(dev_alloc(t, (void **)&t->gp36, act * 36 * sizeof(float)));
         NF_TRY(dev_alloc(t, (void **)&t->gq18, act * 18 * sizeof(float)));
@@ -2128,7 +2128,7 @@ int nf_trainer_create(const nf_config *cfg, const nf_layer_desc *layers, const f
         }
         t->blas = bh;
     }
-    for (int k = 0; k < (w > 32 ? 1 : 3); ++k) {
+    for (int k = 0; k < (gemm_width(w) ? 1 : 3); ++k) {
         NF_TRY(dev_alloc(t, (void **)&t->t1[k], act * w * sizeof(float)));
         NF_TRY(dev_alloc(t, (void **)&t->t2[k], act * w * sizeof(float)));
         NF_TRY(dev_alloc(t, (void **)&t->gu[k], act * 4 * sizeof(float)));
@@ -2249,7 +2249,7 @@ static int trainer_run(nf_trainer *t, const float *x, const float *y, int64_t B,
                 if (L.width == 4) NF_CALL(4); else NF_CALL(8);
 #undef NF_CALL
                 f1_done = nxt != nullptr;
-            } else if (L.width > 32) {
+            } else if (gemm_width(L.width)) {
                 if (!coupling_forward_gemm(t, g, L, zin, zout, t->acc(t->d_ld0 + l), zpre, Am, st)) blas_failed = true;
             } else {
 #define NF_CALL(WW) coupling_forward<WW>(t, g, L, zin, zout, t->acc(t->d_ld0 + l), zpre, Am, st)
@@ -2319,7 +2319,7 @@ static int trainer_run(nf_trainer *t, const float *x, const float *y, int64_t B,
                 if (L.width == 4) NF_CALL(4); else NF_CALL(8);
 #undef NF_CALL
                 a_done = nxt != nullptr;
-            } else if (L.width > 32) {
+            } else if (gemm_width(L.width)) {
                 if (!coupling_backward_gemm(t, g, L, t->zs[l], invB, zmix_in, Am, dA, st, zlat)) blas_failed = true;
             } else {
 #define NF_CALL(WW) coupling_backward<WW>(t, g, L, t->zs[l], invB, zmix_in, Am, dA, st, zlat)
@@ -2337,7 +2337,7 @@ static int trainer_run(nf_trainer *t, const float *x, const float *y, int64_t B,
             (void)hipStreamWaitEvent(st, t->ev_done[par], 0);
             t->done_pending[par] = false;
         }
-    if (t->width > 32) {
+    if (gemm_width(t->width)) {
         // the filters of wide couplings get their gradients whole from the GEMMs: the slotted sums are added up for every other
         // value only (the runs between the filters), then the GEMM results are stored next to them
         int lo = 0;

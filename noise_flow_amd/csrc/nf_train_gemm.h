@@ -36,6 +36,14 @@
 
 namespace {
 
+// the widths with kernels of their own (nf_train.hip, nf_train_tiled.h, nf_train_wide.h); every other width 1 .. 512 runs here
+// (NF_TRAIN_GEMM=1 in the environment sends those four here as well: an A/B switch for tests and profiles)
+inline bool gemm_width(int w)
+{
+    static const bool all = [] { const char *e = getenv("NF_TRAIN_GEMM"); return e && atoi(e) != 0; }();
+    return all || (w != 4 && w != 8 && w != 16 && w != 32);
+}
+
 struct RocBlas {
     void *lib = nullptr;
     rocblas_status (*create)(rocblas_handle *) = nullptr;
@@ -198,15 +206,15 @@ __global__ __launch_bounds__(256) void k_g_bias_stats_slow(Geo g, int w, float *
     const int64_t per = (g.npix + gridDim.x - 1) / gridDim.x, p0 = per * blockIdx.x, p1 = p0 + per < g.npix ? p0 + per : g.npix;
     for (int j = threadIdx.x; j < w; j += 256) {
         const float bj = bias[j];
-        float s = 0.0f, q = 0.0f;
+        double s = 0.0, q = 0.0;   // one thread walks the whole run: a float sum of `per` values would cost the mean its last bits
         for (int64_t p = p0; p < p1; ++p) {
             const float v = h[p * w + j] + bj;
             h[p * w + j] = v;
-            s += v;
-            q = fmaf(v, v, q);
+            s += (double)v;
+            q += (double)v * (double)v;
         }
-        (stats + j).p[blockIdx.x] = s;
-        (stats + (w + j)).p[blockIdx.x] = q;
+        (stats + j).p[blockIdx.x] = (float)s;
+        (stats + (w + j)).p[blockIdx.x] = (float)q;
     }
 }
 
@@ -389,16 +397,16 @@ __global__ __launch_bounds__(256) void k_g_mask_stats_slow(Geo g, int w, float *
 {
     const int64_t per = (g.npix + gridDim.x - 1) / gridDim.x, p0 = per * blockIdx.x, p1 = p0 + per < g.npix ? p0 + per : g.npix;
     for (int j = threadIdx.x; j < w; j += 256) {
-        float s = 0.0f, q = 0.0f;
+        double s = 0.0, q = 0.0;
         for (int64_t p = p0; p < p1; ++p) {
             const float av = a[p * w + j];
             const float gx = av > 0.0f ? ga[p * w + j] : 0.0f;
             ga[p * w + j] = gx;
-            s += gx;
-            q = fmaf(gx, av, q);
+            s += (double)gx;
+            q += (double)gx * (double)av;
         }
-        (bstats + j).p[blockIdx.x] = s;
-        (bstats + (w + j)).p[blockIdx.x] = q;
+        (bstats + j).p[blockIdx.x] = (float)s;
+        (bstats + (w + j)).p[blockIdx.x] = (float)q;
     }
 }
 
@@ -440,14 +448,14 @@ __global__ __launch_bounds__(256) void k_g_bn_bwd_slow(Geo g, int w, float *__re
     const int64_t per = (g.npix + gridDim.x - 1) / gridDim.x, p0 = per * blockIdx.x, p1 = p0 + per < g.npix ? p0 + per : g.npix;
     for (int j = threadIdx.x; j < w; j += 256) {
         const float m = bn[j], rs = bn[w + j], ba = bb[j], bq = bb[w + j];
-        float s = 0.0f;
+        double s = 0.0;
         for (int64_t p = p0; p < p1; ++p) {
             const float xh = (h[p * w + j] - m) * rs;
             const float o = rs * (gx[p * w + j] - ba - xh * bq);
             gx[p * w + j] = o;
-            s += o;
+            s += (double)o;
         }
-        (Gb + j).p[blockIdx.x] = s;
+        (Gb + j).p[blockIdx.x] = (float)s;
     }
 }
 
