@@ -33,7 +33,8 @@ Rank 0 prints ONE JSON line.  Besides the contract keys it carries
   wide_cnn      the paper-scale coupling CNN (width 32 / 16) on the f32 matrix cores, own roofline
   sharded_1m    configs[3] on this one GPU (2^20 resident patches, no process group)
   training      one training step (fwd batch-BN + bwd + EMA + Adam) at the reference's minibatch of 138: the shipped
-                architecture (width 4) and, nested as `width32`, the paper-scale coupling width on the matrix cores
+                architecture (width 4) and, nested as `width32`, the paper-scale coupling width on the matrix cores;
+                `width512`: the reference's default width (library GEMMs between run-time-width kernels)
   two_streams   the headline workload with consecutive steps alternating between two HIP streams
   large_patches 256x256x4 images (beyond the 64x64 a workgroup holds): overlapping tiles, DESIGN 4.8
 """
@@ -836,6 +837,28 @@ def _training(ctx, batches, cond, wide):
     trw.close()
     out["width32"] = {"workload": "the same step, coupling width 32 (fresh initialisation), 138 patches 32x32x4", "ms_per_step": msw,
                       "value": TB_ / (msw * 1e-3), "unit": "patches/s"}
+    # ... and at the width the reference's flags default to (sidd/ArgParser.py:43: 512): the dense products of a step are library
+    # GEMMs (rocBLAS sgemm, exact fp32) between hand-written kernels of run-time width (csrc/nf_train_gemm.h)
+    try:
+        trg = Trainer([32, 32, 4], default_hps(width=512), device=dev.index, max_batch=TB_)
+        for _ in range(2):
+            trg.step(xt_, yt_, [0.0], [0.0], [100.0], [2.0], lr=1e-4, sync=False)
+        torch.cuda.synchronize(dev)
+        kg = 5
+        g0.record(stream)
+        for _ in range(kg):
+            trg.step(xt_, yt_, [0.0], [0.0], [100.0], [2.0], lr=1e-4, sync=False)
+        g1.record(stream)
+        torch.cuda.synchronize(dev)
+        msg = g0.elapsed_time(g1) / kg
+        trg.close()
+        flop = 3.0 * 2.0 * (18 * 512 + 512 * 512 + 512 * 36) * 8 * TB_ * 1024      # forward + two transposed products per filter
+        out["width512"] = {"workload": "the same step, coupling width 512 (the reference's default flag; fresh initialisation), "
+                                       "138 patches 32x32x4", "steps": kg, "ms_per_step": msg, "value": TB_ / (msg * 1e-3), "unit": "patches/s",
+                           "dense_tflops": flop / (msg * 1e-3) / 1e12,
+                           "note": "fp32 products on rocBLAS sgemm (f32 matrix peak 157.3 TFLOP/s)"}
+    except Exception as ex:    # e.g. librocblas missing on the box: reported, the other sections stand
+        out["width512"] = {"error": str(ex)[:300]}
     return out
 
 

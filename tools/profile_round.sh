@@ -76,6 +76,9 @@ python tools/make_traffic.py $F2 $W2 "nf_flow_kernel<4, 1024, 4, false, true, tr
 F3=$(find $OUT/pmc_samp_FETCH_SIZE -name "*counter_collection.csv" | head -1); W3=$(find $OUT/pmc_samp_WRITE_SIZE -name "*counter_collection.csv" | head -1)
 python tools/make_traffic.py $F3 $W3 "nf_flow_kernel<4, 256, 4, true, true, true, 0, false>" 4096 sampling 256 32768 >> $OUT/traffic.log 2>&1
 cp profiles/traffic.json $OUT/traffic.json
+# the bench line once more, now that profiles/traffic.json belongs to these kernel sources (roofline.traffic is quoted from it)
+mv $OUT/bench.json $OUT/bench_before_traffic.json
+(cd /tmp && $BENCH > $OUT/bench.json 2> $OUT/bench.err)
 cp $F2 $OUT/pmc_fp16_fetch_counter_collection.csv; cp $W2 $OUT/pmc_fp16_write_counter_collection.csv
 cp $F3 $OUT/pmc_sampling_fetch_counter_collection.csv; cp $W3 $OUT/pmc_sampling_write_counter_collection.csv
 K=$(find $OUT/kt -name "*kernel_stats.csv" | head -1); cp $K $OUT/kernel_stats.csv 2>/dev/null
