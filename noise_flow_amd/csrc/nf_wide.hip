@@ -9,7 +9,8 @@
 //    register v of lane half g holds channel c(v, g) = 8 (v >> 2) + 4 g + (v & 3) of the lane's pixel
 //    and IS the B operand of K step v of the next layer: l_1 -> ReLU -> l_2 -> ReLU -> l_last chain through
 //    registers with no data movement at all.  The A operands (weights) are pre-permuted on the host into
-//    fetch order (nf_device.h, NF4_*) and staged in LDS once per coupling.
+//    fetch order (nf_device.h, NF4_*) and staged in LDS once per coupling: by LDS-DMA into the other half of a double
+//    buffer while the current coupling's CNN runs.
 //  * l_1 reads its B operand (tap (di,dj), channel g of the pass-through half) from a zero-bordered LDS
 //    tile of z0 — 9 MFMAs per tile.
 //  * l_last is evaluated transposed: P[pixel][tap][j] = sum_c h2[pixel][c] W3[tap][c][j] is one 32-row
@@ -27,6 +28,16 @@
 #include "../../include/noiseflow_hip.h"   // NF_SUMS_SLOTS / NF_SUMS_STRIDE
 #include "nf_device.h"
 #include "nf_dev_util.h"
+
+// Instrumented build (-DNF_TIMELINE, tools/timeline_wide.py only): thread 0 of every workgroup stamps the 100 MHz s_memrealtime
+// counter at the phase boundaries of its MIDDLE patch into NfLaunch::sd_out, reinterpreted as int64[grid][64] (sd_z is not written
+// in this build): 0 patch start, 1 inputs in registers, per coupling c: 2+4c weights staged (after the barrier of phase A), +1 phase B
+// done (this wavefront), +2 every wavefront's phase B done (barrier), +3 phase C done; 40 outputs written, 41 patch done.
+#ifdef NF_TIMELINE
+#define NF_WSTAMP(i) do { if (t == 0 && stamp_on) reinterpret_cast<long long *>(a.sd_out)[(size_t)blockIdx.x * 64 + (i)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define NF_WSTAMP(i) do { } while (0)
+#endif
 
 namespace {
 
@@ -108,8 +119,13 @@ __device__ __forceinline__ void nf_wide32_body(const NfProgram &prog, const NfLa
     const int Wp = W + 2;
     const int PL = ((H + 2) * Wp + 3) & ~3;             // one channel plane of the z0 tile
     float *const z0s = smem;                             // fp32: [2][PL] channel planes; fp16: [PL] half2 per pixel (+ unused plane)
-    float *const wbuf = z0s + 2 * PL;                    // [IMG] weights of the current coupling
-    float *const exch = wbuf + IMG;                      // [NW][2][32][4] strip-boundary rows
+    // [2][CPLB]: the parameter block (border table, scale, weight image) of the current coupling and, arriving by LDS-DMA while
+    // this one's CNN runs, of the next one (the first coupling of the next patch behind the last one)
+    constexpr int CPLF = NF4_CPL_IMG + IMG;              // floats of a block
+    constexpr int CHUNKS = (CPLF + 255) / 256;           // global_load_lds_dwordx4 moves 1 KiB per wavefront instruction
+    constexpr int CPLB = CHUNKS * 256;
+    float *const wbuf0 = z0s + 2 * PL;
+    float *const exch = wbuf0 + 2 * CPLB;                // [NW][2][32][4] strip-boundary rows
     float *const side = exch + NW * 256;                 // TPR == 2: [2][H+2][3][4] column-seam taps
     float *const red = side + (TPR == 2 ? 2 * (H + 2) * 12 : 0);   // [3][NW] reduction scratch
 
@@ -126,13 +142,35 @@ __device__ __forceinline__ void nf_wide32_body(const NfProgram &prog, const NfLa
 #pragma unroll
     for (int q = 0; q < 4; ++q) toff[q] = ((4 * g + q) / 3) * Wp + (4 * g + q) % 3;
 
-    for (int i = t; i < 2 * PL + IMG + NW * 256 + (TPR == 2 ? 2 * (H + 2) * 12 : 0); i += THREADS) smem[i] = 0.0f;
+    for (int i = t; i < 2 * PL + 2 * CPLB + NW * 256 + (TPR == 2 ? 2 * (H + 2) * 12 : 0); i += THREADS) smem[i] = 0.0f;
     __syncthreads();
 
     const int n_ops = prog.n_ops;
+    // LDS-DMA of one coupling's block: LDS address = wavefront-uniform base + 16 B x lane, global address per lane (the lanes
+    // behind the block's end re-read its start into the padding of the last KiB)
+    auto stage = [&](int off, int buf) {
+        for (int ch = w; ch < CHUNKS; ch += NW) {
+            const int fo = ch * 256 + lane * 4;
+            const float *src = a.params + off + (fo < CPLF ? fo : 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(wbuf0 + buf * CPLB + ch * 256), 16, 0, 0);
+        }
+    };
+    int first_cpl = -1;
+    for (int op = n_ops - 1; op >= 0; --op)
+        if (prog.ops[op].type == NF_OP_COUPLING_FWD || prog.ops[op].type == NF_OP_COUPLING_REV) first_cpl = op;
+    int cur = 0;   // which half of wbuf0 the next coupling reads
+    if (first_cpl >= 0 && (int64_t)blockIdx.x < a.B) stage(prog.ops[first_cpl].off, 0);
     double acc_nll = 0.0, acc_sd = 0.0;   // thread 0 only
 
+    [[maybe_unused]] bool stamp_on = false;
+    [[maybe_unused]] int64_t stamp_it = 0;
     for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
+#ifdef NF_TIMELINE
+        stamp_on = stamp_it++ == (a.B / gridDim.x) / 2;
+        int n_cpl = 0;
+        NF_WSTAMP(0);
+#endif
         // Where this "patch" sits: on its own ([B,H,W,4] tensors), or — NF_K_TILED (nf_device.h, "overlapping tiles") — as
         // tile b % tiles of image b / tiles: pixel (r, c) of the tile is pixel (oy + r, ox + c) of an IH x IW image, border
         // masks follow the image border, and results are reported for the core window [cy0, cy1) x [cx0, cx1) only.
@@ -181,6 +219,10 @@ __device__ __forceinline__ void nf_wide32_body(const NfProgram &prog, const NfLa
         }
 
         float ld = 0.0f, ld2 = 0.0f;   // natural-log / log2 parts of this lane's log-det share
+#ifdef NF_TIMELINE
+        asm volatile("" ::"v"(z[0][0]));
+        NF_WSTAMP(1);
+#endif
 
         for (int op = 0; op < n_ops; ++op) {
             const int type = prog.ops[op].type;
@@ -205,7 +247,7 @@ __device__ __forceinline__ void nf_wide32_body(const NfProgram &prog, const NfLa
                     for (int j = 0; j < 4; ++j) z[m][j] = o[j];
                 }
             } else if (type == NF_OP_COUPLING_FWD || type == NF_OP_COUPLING_REV) {
-                // ---- phase A: publish the pass-through half, stage this coupling's weights ----
+                // ---- phase A: publish the pass-through half; this coupling's weights arrive (requested during the previous CNN phase) ----
 #pragma unroll
                 for (int m = 0; m < OWN; ++m) {
                     const int r = row0 + 2 * m + g;
@@ -219,12 +261,22 @@ __device__ __forceinline__ void nf_wide32_body(const NfProgram &prog, const NfLa
                         }
                     }
                 }
-                {
-                    const float4 *src = reinterpret_cast<const float4 *>(a.params + prog.ops[op].off + NF4_CPL_IMG);
-                    float4 *dst = reinterpret_cast<float4 *>(wbuf);
-                    for (int i = t; i < IMG / 4; i += THREADS) dst[i] = src[i];
-                }
+                // this coupling's block was requested a whole CNN phase ago: every wavefront retires its own pieces, the barrier
+                // publishes them (and the z0 tile)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
+                const float *const wblk = wbuf0 + cur * CPLB;      // [E][S][image] as in global memory (nf_device.h, NF4_CPL_*)
+                const float *const wbuf = wblk + NF4_CPL_IMG;
+                {   // request the next coupling's block into the other half (last read two barriers ago)
+                    int nx = op + 1;
+                    while (nx < n_ops && prog.ops[nx].type != NF_OP_COUPLING_FWD && prog.ops[nx].type != NF_OP_COUPLING_REV) ++nx;
+                    if (nx >= n_ops) nx = b + (int64_t)gridDim.x < a.B ? first_cpl : -1;
+                    if (nx >= 0) stage(prog.ops[nx].off, cur ^ 1);
+                }
+                cur ^= 1;
+#ifdef NF_TIMELINE
+                if (n_cpl < 8) NF_WSTAMP(2 + 4 * n_cpl);
+#endif
 
                 // ---- phase B: the CNN on the matrix cores, strip-local shift-add ----
                 const float4 *const wb4 = reinterpret_cast<const float4 *>(wbuf);
@@ -372,7 +424,14 @@ __device__ __forceinline__ void nf_wide32_body(const NfProgram &prog, const NfLa
                         }
                     }
                 }
+#ifdef NF_TIMELINE
+                asm volatile("" ::"v"(cp[0][0]), "v"(cp[TPW - 1][3]));
+                if (n_cpl < 8) NF_WSTAMP(3 + 4 * n_cpl);
+#endif
                 __syncthreads();
+#ifdef NF_TIMELINE
+                if (n_cpl < 8) NF_WSTAMP(4 + 4 * n_cpl);
+#endif
 
                 // ---- phase C: strip-boundary rows, column seam, then each lane half finishes the rows it owns ----
                 if (row0 > 0 && g == 0) {
@@ -409,7 +468,7 @@ __device__ __forceinline__ void nf_wide32_body(const NfProgram &prog, const NfLa
                     const int R = oy + r;
                     const bool own = r < H && col_own && R >= cy0 && R < cy1;
                     const int bm = (R == 0 ? 1 : 0) | (R == IH - 1 ? 2 : 0) | cmask;
-                    const float4 eb = *reinterpret_cast<const float4 *>(a.params + prog.ops[op].off + NF4_CPL_E + 4 * (act ? bm : 0));
+                    const float4 eb = *reinterpret_cast<const float4 *>(wblk + NF4_CPL_E + 4 * (act ? bm : 0));
                     if constexpr (H16) {   // fp16 weights are not pre-scaled (their rounding points are the oracle's); the table is
                         o[0] += eb.x; o[1] += eb.y;
                         o[2] = fmaf(o[2], 2.8853900817779268f, eb.z);
@@ -430,6 +489,11 @@ __device__ __forceinline__ void nf_wide32_body(const NfProgram &prog, const NfLa
                         z[m][3] = (z[m][3] - o[1]) * __builtin_amdgcn_exp2f(-l1);
                     }
                 }
+#ifdef NF_TIMELINE
+                asm volatile("" ::"v"(z[0][2]));
+                if (n_cpl < 8) NF_WSTAMP(5 + 4 * n_cpl);
+                ++n_cpl;
+#endif
             } else if (type == NF_OP_SDN_DIV || type == NF_OP_SDN_MUL) {
                 // AffineCouplingSdnEx5: scale = sqrt(beta1*y/gain + beta2)  (cond_utils.py:238)
                 const float4 *y4 = reinterpret_cast<const float4 *>(a.y + patch_off);
@@ -472,6 +536,7 @@ __device__ __forceinline__ void nf_wide32_body(const NfProgram &prog, const NfLa
                 if (r < H && col_own && R >= cy0 && R < cy1) out4[R * IW + C] = make_float4(z[m][0], z[m][1], z[m][2], z[m][3]);
             }
         }
+        NF_WSTAMP(40);
         if (a.nll_out || a.sd_out || a.ld_out || a.sums || (tiled && a.tile_part)) {
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -512,13 +577,16 @@ __device__ __forceinline__ void nf_wide32_body(const NfProgram &prog, const NfLa
                 var = var > 0.0 ? var : 0.0;
                 const double sd = sqrt(var);
                 if (a.nll_out) a.nll_out[b] = (float)nll;
+#ifndef NF_TIMELINE
                 if (a.sd_out) a.sd_out[b] = (float)sd;
+#endif
                 if (a.ld_out) a.ld_out[b] = (float)logdet;
                 acc_nll += (double)(float)nll;
                 acc_sd += (double)(float)sd;
             }
             __syncthreads();   // scratch is reused by the next patch
         }
+        NF_WSTAMP(41);
     }
 
     if (a.sums && t == 0 && !TILED) {
@@ -545,7 +613,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS
 size_t wide_lds_bytes(int H, int W, int threads, int tpr, int prec)
 {
     const int Wp = W + 2, PL = ((H + 2) * Wp + 3) & ~3, NW = threads / 64;
-    size_t f = 2 * (size_t)PL + (prec ? NF5_IMG_SIZE : NF4_IMG_SIZE) + (size_t)NW * 256 + (tpr == 2 ? 2 * (size_t)(H + 2) * 12 : 0) + ((3 * NW + 3) & ~3);
+    const size_t cplb = ((size_t)(NF4_CPL_IMG + (prec ? NF5_IMG_SIZE : NF4_IMG_SIZE)) + 255) / 256 * 256;   // as CPLB in the kernel
+    size_t f = 2 * (size_t)PL + 2 * cplb + (size_t)NW * 256 + (tpr == 2 ? 2 * (size_t)(H + 2) * 12 : 0) + ((3 * NW + 3) & ~3);
     return f * sizeof(float);
 }
 

@@ -1,11 +1,21 @@
 #!/bin/bash
-# Tuning aid: an alternative build of nf_kernels.hip linked with the other objects of the library:
-#   bash tools/build_variant.sh <name> [-DFLAG=..]...   ->  build/variants/lib_<name>.so   (use with NF_TOOL_LIB=...)
+# Tuning aid: an alternative build of ONE object of the library, linked with the product's other objects:
+#   [OBJ=nf_wide] [SRC=path.hip] bash tools/build_variant.sh <name> [-DFLAG=..]...   ->  build/variants/lib_<name>.so
+# OBJ names the object that is replaced (default nf_kernels; nf_wide, nf_wide16, nf_gemm, nf_gemm16, nf_train ...), SRC the source
+# it is compiled from (default csrc/$OBJ.hip; a patched copy must sit where its includes resolve, or be compiled with -I).
+# Use with NF_TOOL_LIB=build/variants/lib_<name>.so (tools/ only — the product loads csrc/libnoiseflow_hip.so).
 set -e
 NAME=$1; shift
 R=$(cd "$(dirname "$0")/.." && pwd)
 C=$R/noise_flow_amd/csrc
+OBJ=${OBJ:-nf_kernels}
 mkdir -p $R/build/variants
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -Wall -Wno-unused-function "$@" -c ${SRC:-$C/nf_kernels.hip} -o $R/build/variants/nf_kernels_$NAME.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $R/build/variants/nf_kernels_$NAME.o $C/nf_wide.o $C/nf_wide16.o $C/nf_gemm.o $C/nf_gemm16.o $C/nf_host.o $C/nf_hostfed.o $C/nf_train.o -lpthread -o $R/build/variants/lib_$NAME.so
+EXTRA=""
+[ "$OBJ" != "nf_kernels" ] && EXTRA="-mllvm -amdgpu-mfma-vgpr-form"
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -Wall -Wno-unused-function $EXTRA -I$C "$@" -c ${SRC:-$C/$OBJ.hip} -o $R/build/variants/${OBJ}_$NAME.o
+OBJS=""
+for o in nf_kernels nf_wide nf_wide16 nf_gemm nf_gemm16 nf_host nf_hostfed nf_train; do
+  if [ "$o" = "$OBJ" ]; then OBJS="$OBJS $R/build/variants/${OBJ}_$NAME.o"; else OBJS="$OBJS $C/$o.o"; fi
+done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -lpthread -o $R/build/variants/lib_$NAME.so
 echo built $R/build/variants/lib_$NAME.so
