@@ -9,17 +9,17 @@
 //
 //   forward   Z18 = the 3x3 x 2-channel windows of the pass-through half            k_g_gather18
 //             h1 = Z18 . W1 (K = 18)                                                sgemm
-//             + b1, batch sums of h1 (slotted, as everywhere in the trainer)        k_g_bias_stats   -> k_bn_fin (moments, EMA)
-//             a1 = relu(bn1(h1))                                                    k_g_bn_relu
+//             batch sums of h1 + b1 (slotted; h1 stays without its bias in memory)  k_g_bias_stats   -> k_bn_fin (moments, EMA)
+//             a1 = relu(bn1(h1 + b1))                                               k_g_bn_relu
 //             h2 = a1 . W2                                                          sgemm
-//             + b2, batch sums; a2 = relu(bn2(h2))                                  k_g_bias_stats, k_bn_fin, k_g_bn_relu
+//             batch sums of h2 + b2; a2 = relu(bn2(h2 + b2))                        k_g_bias_stats, k_bn_fin, k_g_bn_relu
 //             P = a2 . W3r  (W3r[i][tap*4+k] = l_last/W[tap][i][k], 36 columns)     k_g_pack_w3, sgemm
 //             u = gather of the 9 taps of P + edge channel + b3; affine transform   k_g_c3_fwd
 //   backward  affine / tanh / exp(3 logs) backward -> gu, d b3, d logs, d scale     k_g_c3_bwd
 //             G36[p][tap*4+k] = gu[p - tap][k]; d edge-channel weights              k_g_gather36
 //             d l_last/W = a2^T . G36 ;  g_a2 = G36 . W3r^T                         sgemm x 2
-//             ReLU mask + the two batch sums of BN2's backward                      k_g_mask_stats   -> k_bnb_fin
-//             g_h2 = BN2 backward; d b2                                             k_g_bn_bwd
+//             the two batch sums of BN2's backward (mask from h2, read-only)        k_g_mask_stats   -> k_bnb_fin
+//             g_h2 = BN2 backward of the masked g_a2; d b2                          k_g_bn_bwd
 //             d l_2/W = a1^T . g_h2 ;  g_a1 = g_h2 . W2^T                           sgemm x 2
 //             mask + sums, g_h1 = BN1 backward, d b1                                k_g_mask_stats, k_bnb_fin, k_g_bn_bwd
 //             d l_1/W = Z18^T . g_h1 ;  Q = g_h1 . W1^T (18 columns)                sgemm x 2
@@ -181,8 +181,14 @@ __device__ __forceinline__ void flat_store(const float (&v)[4], float *red, cons
     }
 }
 
-// h += bias (in place) and the slotted batch sums of the result (sum, sum of squares per channel)
-__global__ __launch_bounds__(256) void k_g_bias_stats(Geo g, int w, float *__restrict__ h, const float *__restrict__ bias, Acc stats)
+// The GEMM's output h stays WITHOUT its bias in memory: every consumer adds it on the fly (g_xhat), which saves this kernel the
+// write pass over the tensor.
+// normalised activation of one value (layers.py:378-401 with the batch moments): the expression every kernel below shares, so
+// that the ReLU mask the backward pass re-derives from h is bit for bit the forward's
+__device__ __forceinline__ float g_xhat(float h, float b, float m, float rs) { return ((h + b) - m) * rs; }
+
+// the slotted batch sums of h + bias (sum, sum of squares per channel)
+__global__ __launch_bounds__(256) void k_g_bias_stats(Geo g, int w, const float *__restrict__ h, const float *__restrict__ bias, Acc stats)
 {
     __shared__ float red[256 * 4];
     const FlatWalk f = flat_walk(g.npix, w);
@@ -191,9 +197,8 @@ __global__ __launch_bounds__(256) void k_g_bias_stats(Geo g, int w, float *__res
     if (t < f.TBq) {
         const float b4[4] = {bias[4 * cg], bias[4 * cg + 1], bias[4 * cg + 2], bias[4 * cg + 3]};
         for (int64_t e = (int64_t)blockIdx.x * f.TBq + t; e < f.total; e += f.stride) {
-            float4 v = reinterpret_cast<float4 *>(h)[e];
+            float4 v = reinterpret_cast<const float4 *>(h)[e];
             v.x += b4[0]; v.y += b4[1]; v.z += b4[2]; v.w += b4[3];
-            reinterpret_cast<float4 *>(h)[e] = v;
             s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
             q[0] = fmaf(v.x, v.x, q[0]); q[1] = fmaf(v.y, v.y, q[1]); q[2] = fmaf(v.z, v.z, q[2]); q[3] = fmaf(v.w, v.w, q[3]);
         }
@@ -201,7 +206,7 @@ __global__ __launch_bounds__(256) void k_g_bias_stats(Geo g, int w, float *__res
     flat_store(s, red, f, w, stats);
     flat_store(q, red, f, w, stats + w);
 }
-__global__ __launch_bounds__(256) void k_g_bias_stats_slow(Geo g, int w, float *__restrict__ h, const float *__restrict__ bias, Acc stats)
+__global__ __launch_bounds__(256) void k_g_bias_stats_slow(Geo g, int w, const float *__restrict__ h, const float *__restrict__ bias, Acc stats)
 {
     const int64_t per = (g.npix + gridDim.x - 1) / gridDim.x, p0 = per * blockIdx.x, p1 = p0 + per < g.npix ? p0 + per : g.npix;
     for (int j = threadIdx.x; j < w; j += 256) {
@@ -209,7 +214,6 @@ __global__ __launch_bounds__(256) void k_g_bias_stats_slow(Geo g, int w, float *
         double s = 0.0, q = 0.0;   // one thread walks the whole run: a float sum of `per` values would cost the mean its last bits
         for (int64_t p = p0; p < p1; ++p) {
             const float v = h[p * w + j] + bj;
-            h[p * w + j] = v;
             s += (double)v;
             q += (double)v * (double)v;
         }
@@ -218,20 +222,22 @@ __global__ __launch_bounds__(256) void k_g_bias_stats_slow(Geo g, int w, float *
     }
 }
 
-// a = relu((h - mean) * rstd)   (layers.py:378-401 with the batch moments, then :478 / :489).  V = 4: four channels per thread
-// (widths that are a multiple of 4), else one
+// a = relu((h + bias - mean) * rstd)   (layers.py:378-401 with the batch moments, then :478 / :489).  V = 4: four channels per
+// thread (widths that are a multiple of 4), else one
 template <int V>
-__global__ void k_g_bn_relu(int64_t nv, int wv, const float *__restrict__ h, const float *__restrict__ bn, float *__restrict__ a)
+__global__ void k_g_bn_relu(int64_t nv, int wv, const float *__restrict__ h, const float *__restrict__ bias, const float *__restrict__ bn,
+                            float *__restrict__ a)
 {
     const int w = V * wv;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nv; e += (int64_t)gridDim.x * blockDim.x) {
         const int j = (int)(e % wv) * V;
         if constexpr (V == 4) {
             const float4 v = reinterpret_cast<const float4 *>(h)[e];
-            reinterpret_cast<float4 *>(a)[e] = make_float4(fmaxf((v.x - bn[j]) * bn[w + j], 0.f), fmaxf((v.y - bn[j + 1]) * bn[w + j + 1], 0.f),
-                                                            fmaxf((v.z - bn[j + 2]) * bn[w + j + 2], 0.f), fmaxf((v.w - bn[j + 3]) * bn[w + j + 3], 0.f));
+            reinterpret_cast<float4 *>(a)[e] =
+                make_float4(fmaxf(g_xhat(v.x, bias[j], bn[j], bn[w + j]), 0.f), fmaxf(g_xhat(v.y, bias[j + 1], bn[j + 1], bn[w + j + 1]), 0.f),
+                            fmaxf(g_xhat(v.z, bias[j + 2], bn[j + 2], bn[w + j + 2]), 0.f), fmaxf(g_xhat(v.w, bias[j + 3], bn[j + 3], bn[w + j + 3]), 0.f));
         } else {
-            a[e] = fmaxf((h[e] - bn[j]) * bn[w + j], 0.f);
+            a[e] = fmaxf(g_xhat(h[e], bias[j], bn[j], bn[w + j]), 0.f);
         }
     }
 }
@@ -372,56 +378,71 @@ __global__ void k_g_gather36(Geo g, int w, const float *__restrict__ gu, float *
     }
 }
 
-// gx = g_a where the activation is positive (in place), and the two batch sums BN's backward needs: sum gx, sum gx * xhat
-// (xhat = a wherever it counts: a = relu(xhat))
-__global__ __launch_bounds__(256) void k_g_mask_stats(Geo g, int w, float *__restrict__ ga, const float *__restrict__ a, Acc bstats)
+// The two batch sums BN's backward needs — sum gx, sum gx * xhat with gx = g_a where the activation is positive — from a
+// read-only pass: the mask is re-derived from h (xhat > 0 <=> the forward's relu kept the value; same expression, same bits) and
+// applied again by k_g_bn_bwd, so the masked gradient is never written.
+__global__ __launch_bounds__(256) void k_g_mask_stats(Geo g, int w, const float *__restrict__ ga, const float *__restrict__ h,
+                                                      const float *__restrict__ bias, const float *__restrict__ bn, Acc bstats)
 {
     __shared__ float red[256 * 4];
     const FlatWalk f = flat_walk(g.npix, w);
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, cg = t % f.Q;
     float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
     if (t < f.TBq) {
+        float b[4], m[4], rs[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            b[k] = bias[4 * cg + k];
+            m[k] = bn[4 * cg + k];
+            rs[k] = bn[w + 4 * cg + k];
+        }
         for (int64_t e = (int64_t)blockIdx.x * f.TBq + t; e < f.total; e += f.stride) {
-            const float4 av = reinterpret_cast<const float4 *>(a)[e];
-            float4 gv = reinterpret_cast<float4 *>(ga)[e];
-            gv.x = av.x > 0.f ? gv.x : 0.f; gv.y = av.y > 0.f ? gv.y : 0.f; gv.z = av.z > 0.f ? gv.z : 0.f; gv.w = av.w > 0.f ? gv.w : 0.f;
-            reinterpret_cast<float4 *>(ga)[e] = gv;
-            s[0] += gv.x; s[1] += gv.y; s[2] += gv.z; s[3] += gv.w;
-            q[0] = fmaf(gv.x, av.x, q[0]); q[1] = fmaf(gv.y, av.y, q[1]); q[2] = fmaf(gv.z, av.z, q[2]); q[3] = fmaf(gv.w, av.w, q[3]);
+            const float4 hv4 = reinterpret_cast<const float4 *>(h)[e], gv4 = reinterpret_cast<const float4 *>(ga)[e];
+            const float hv[4] = {hv4.x, hv4.y, hv4.z, hv4.w}, gv[4] = {gv4.x, gv4.y, gv4.z, gv4.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float xh = g_xhat(hv[k], b[k], m[k], rs[k]);
+                const float gx = xh > 0.f ? gv[k] : 0.f;
+                s[k] += gx;
+                q[k] = fmaf(gx, xh, q[k]);
+            }
         }
     }
     flat_store(s, red, f, w, bstats);
     flat_store(q, red, f, w, bstats + w);
 }
-__global__ __launch_bounds__(256) void k_g_mask_stats_slow(Geo g, int w, float *__restrict__ ga, const float *__restrict__ a, Acc bstats)
+__global__ __launch_bounds__(256) void k_g_mask_stats_slow(Geo g, int w, const float *__restrict__ ga, const float *__restrict__ h,
+                                                           const float *__restrict__ bias, const float *__restrict__ bn, Acc bstats)
 {
     const int64_t per = (g.npix + gridDim.x - 1) / gridDim.x, p0 = per * blockIdx.x, p1 = p0 + per < g.npix ? p0 + per : g.npix;
     for (int j = threadIdx.x; j < w; j += 256) {
+        const float b = bias[j], m = bn[j], rs = bn[w + j];
         double s = 0.0, q = 0.0;
         for (int64_t p = p0; p < p1; ++p) {
-            const float av = a[p * w + j];
-            const float gx = av > 0.0f ? ga[p * w + j] : 0.0f;
-            ga[p * w + j] = gx;
+            const float xh = g_xhat(h[p * w + j], b, m, rs);
+            const float gx = xh > 0.0f ? ga[p * w + j] : 0.0f;
             s += (double)gx;
-            q += (double)gx * (double)av;
+            q += (double)gx * (double)xh;
         }
         (bstats + j).p[blockIdx.x] = (float)s;
         (bstats + (w + j)).p[blockIdx.x] = (float)q;
     }
 }
 
-// BN backward (in place): g_h = rstd * (gx - mean(gx) - xhat * mean(gx * xhat)); and d bias = sum of g_h
-__global__ __launch_bounds__(256) void k_g_bn_bwd(Geo g, int w, float *__restrict__ gx, const float *__restrict__ h, const float *__restrict__ bn,
-                                                  const float *__restrict__ bb, Acc Gb)
+// BN backward (in place, on the UNMASKED g_a): gx = g_a where xhat > 0, g_h = rstd * (gx - mean(gx) - xhat * mean(gx * xhat));
+// and d bias = sum of g_h
+__global__ __launch_bounds__(256) void k_g_bn_bwd(Geo g, int w, float *__restrict__ gx, const float *__restrict__ h, const float *__restrict__ bias,
+                                                  const float *__restrict__ bn, const float *__restrict__ bb, Acc Gb)
 {
     __shared__ float red[256 * 4];
     const FlatWalk f = flat_walk(g.npix, w);
     const int t = threadIdx.x, cg = t % f.Q;
     float s[4] = {0.f, 0.f, 0.f, 0.f};
     if (t < f.TBq) {
-        float m[4], rs[4], ba[4], bq[4];
+        float b[4], m[4], rs[4], ba[4], bq[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
+            b[k] = bias[4 * cg + k];
             m[k] = bn[4 * cg + k];
             rs[k] = bn[w + 4 * cg + k];
             ba[k] = bb[4 * cg + k];
@@ -433,8 +454,8 @@ __global__ __launch_bounds__(256) void k_g_bn_bwd(Geo g, int w, float *__restric
             float o[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float xh = (hv[k] - m[k]) * rs[k];
-                o[k] = rs[k] * (gv[k] - ba[k] - xh * bq[k]);
+                const float xh = g_xhat(hv[k], b[k], m[k], rs[k]);
+                o[k] = rs[k] * ((xh > 0.f ? gv[k] : 0.f) - ba[k] - xh * bq[k]);
                 s[k] += o[k];
             }
             reinterpret_cast<float4 *>(gx)[e] = make_float4(o[0], o[1], o[2], o[3]);
@@ -443,15 +464,16 @@ __global__ __launch_bounds__(256) void k_g_bn_bwd(Geo g, int w, float *__restric
     flat_store(s, red, f, w, Gb);
 }
 __global__ __launch_bounds__(256) void k_g_bn_bwd_slow(Geo g, int w, float *__restrict__ gx, const float *__restrict__ h,
-                                                       const float *__restrict__ bn, const float *__restrict__ bb, Acc Gb)
+                                                       const float *__restrict__ bias, const float *__restrict__ bn,
+                                                       const float *__restrict__ bb, Acc Gb)
 {
     const int64_t per = (g.npix + gridDim.x - 1) / gridDim.x, p0 = per * blockIdx.x, p1 = p0 + per < g.npix ? p0 + per : g.npix;
     for (int j = threadIdx.x; j < w; j += 256) {
-        const float m = bn[j], rs = bn[w + j], ba = bb[j], bq = bb[w + j];
+        const float b = bias[j], m = bn[j], rs = bn[w + j], ba = bb[j], bq = bb[w + j];
         double s = 0.0;
         for (int64_t p = p0; p < p1; ++p) {
-            const float xh = (h[p * w + j] - m) * rs;
-            const float o = rs * (gx[p * w + j] - ba - xh * bq);
+            const float xh = g_xhat(h[p * w + j], b, m, rs);
+            const float o = rs * ((xh > 0.0f ? gx[p * w + j] : 0.0f) - ba - xh * bq);
             gx[p * w + j] = o;
             s += (double)o;
         }
@@ -551,24 +573,24 @@ bool coupling_forward_gemm(nf_trainer *t, const Geo &g, const TLayer &L, const f
     const int V = w % 4 == 0 ? 4 : 1;
     const int64_t nv = g.npix * (w / V);
     const unsigned ne = (unsigned)std::min<int64_t>((nv + 255) / 256, 256 * 32);
-    auto bn_relu = [&](const float *h, const float *bn, float *a) {
-        if (V == 4) hipLaunchKernelGGL(k_g_bn_relu<4>, dim3(ne), dim3(256), 0, st, nv, w / 4, h, bn, a);
-        else hipLaunchKernelGGL(k_g_bn_relu<1>, dim3(ne), dim3(256), 0, st, nv, w, h, bn, a);
+    auto bn_relu = [&](const float *h, const float *bias, const float *bn, float *a) {
+        if (V == 4) hipLaunchKernelGGL(k_g_bn_relu<4>, dim3(ne), dim3(256), 0, st, nv, w / 4, h, bias, bn, a);
+        else hipLaunchKernelGGL(k_g_bn_relu<1>, dim3(ne), dim3(256), 0, st, nv, w, h, bias, bn, a);
     };
     if (zpre) hipLaunchKernelGGL(k_mix_fwd, dim3(nb), dim3(TB), 0, st, g, zpre, A, const_cast<float *>(zin));
     hipLaunchKernelGGL(k_g_gather18, dim3(nb), dim3(TB), 0, st, g, zin, t->gz18);
     bool ok = gemm_rm(t, st, false, false, g.npix, w, 18, t->gz18, 18, P + off_w1, w, c.h1, w);
-    if (V == 4) hipLaunchKernelGGL(k_g_bias_stats, dim3(ns), dim3(256), 0, st, g, w, c.h1, P + off_b1, t->acc(c.d_st1));
-    else hipLaunchKernelGGL(k_g_bias_stats_slow, dim3(ns), dim3(256), 0, st, g, w, c.h1, P + off_b1, t->acc(c.d_st1));
+    if (V == 4) hipLaunchKernelGGL(k_g_bias_stats, dim3(ns), dim3(256), 0, st, g, w, (const float *)c.h1, P + off_b1, t->acc(c.d_st1));
+    else hipLaunchKernelGGL(k_g_bias_stats_slow, dim3(ns), dim3(256), 0, st, g, w, (const float *)c.h1, P + off_b1, t->acc(c.d_st1));
     sync_slots(t, t->acc(c.d_st1), 2 * w, g.nslot, st);
     hipLaunchKernelGGL(k_bn_fin, dim3(w), dim3(64), 0, st, t->acc(c.d_st1), w, g.nslot, n, t->d_params, off_m1, off_m1 + w, t->d_flt + c.f_bn1);
-    bn_relu(c.h1, t->d_flt + c.f_bn1, c.a1);
+    bn_relu(c.h1, P + off_b1, t->d_flt + c.f_bn1, c.a1);
     ok = ok && gemm_rm(t, st, false, false, g.npix, w, w, c.a1, w, P + off_w2, w, c.h2, w);
-    if (V == 4) hipLaunchKernelGGL(k_g_bias_stats, dim3(ns), dim3(256), 0, st, g, w, c.h2, P + off_b2, t->acc(c.d_st2));
-    else hipLaunchKernelGGL(k_g_bias_stats_slow, dim3(ns), dim3(256), 0, st, g, w, c.h2, P + off_b2, t->acc(c.d_st2));
+    if (V == 4) hipLaunchKernelGGL(k_g_bias_stats, dim3(ns), dim3(256), 0, st, g, w, (const float *)c.h2, P + off_b2, t->acc(c.d_st2));
+    else hipLaunchKernelGGL(k_g_bias_stats_slow, dim3(ns), dim3(256), 0, st, g, w, (const float *)c.h2, P + off_b2, t->acc(c.d_st2));
     sync_slots(t, t->acc(c.d_st2), 2 * w, g.nslot, st);
     hipLaunchKernelGGL(k_bn_fin, dim3(w), dim3(64), 0, st, t->acc(c.d_st2), w, g.nslot, n, t->d_params, off_m2, off_m2 + w, t->d_flt + c.f_bn2);
-    bn_relu(c.h2, t->d_flt + c.f_bn2, c.a2);
+    bn_relu(c.h2, P + off_b2, t->d_flt + c.f_bn2, c.a2);
     hipLaunchKernelGGL(k_g_pack_w3, dim3((w * 36 + 255) / 256), dim3(256), 0, st, w, P + off_w3, t->gw3r);
     ok = ok && gemm_rm(t, st, false, false, g.npix, 36, w, c.a2, w, t->gw3r, 36, t->gp36, 36);
     hipLaunchKernelGGL(k_g_c3_fwd, dim3(nb), dim3(TB), 0, st, g, w, zin, (const float *)t->gp36, P, off_w3, zout, ldacc, c.u);
@@ -595,17 +617,19 @@ bool coupling_backward_gemm(nf_trainer *t, const Geo &g, const TLayer &L, const 
     bool ok = (np[2] = gemm_atb_split(t, st, w, 36, g.npix, c.a2, w, t->gp36, 36, dW3r)) > 0;         // d l_last/W = a2^T . G36
     ok = ok && gemm_rm(t, st, false, true, g.npix, w, 36, t->gp36, 36, t->gw3r, 36, t1, w);          // g_a2 = G36 . W3r^T
     const bool flat = w % 4 == 0;
-    hipLaunchKernelGGL(flat ? k_g_mask_stats : k_g_mask_stats_slow, dim3(ns), dim3(256), 0, st, g, w, t1, (const float *)c.a2, t->acc(c.d_bs2));
+    hipLaunchKernelGGL(flat ? k_g_mask_stats : k_g_mask_stats_slow, dim3(ns), dim3(256), 0, st, g, w, (const float *)t1, (const float *)c.h2,
+                       P + off_b2, bn2, t->acc(c.d_bs2));
     sync_slots(t, t->acc(c.d_bs2), 2 * w, g.nslot, st);
     hipLaunchKernelGGL(k_bnb_fin, dim3(w), dim3(64), 0, st, t->acc(c.d_bs2), w, g.nslot, n, t->d_flt + c.f_bb2);
-    hipLaunchKernelGGL(flat ? k_g_bn_bwd : k_g_bn_bwd_slow, dim3(ns), dim3(256), 0, st, g, w, t1, (const float *)c.h2, bn2,
+    hipLaunchKernelGGL(flat ? k_g_bn_bwd : k_g_bn_bwd_slow, dim3(ns), dim3(256), 0, st, g, w, t1, (const float *)c.h2, P + off_b2, bn2,
                        (const float *)(t->d_flt + c.f_bb2), G + off_b2);
     ok = ok && (np[1] = gemm_atb_split(t, st, w, w, g.npix, c.a1, w, t1, w, dW2)) > 0;                 // d l_2/W = a1^T . g_h2
     ok = ok && gemm_rm(t, st, false, true, g.npix, w, w, t1, w, P + off_w2, w, t2, w);               // g_a1 = g_h2 . W2^T
-    hipLaunchKernelGGL(flat ? k_g_mask_stats : k_g_mask_stats_slow, dim3(ns), dim3(256), 0, st, g, w, t2, (const float *)c.a1, t->acc(c.d_bs1));
+    hipLaunchKernelGGL(flat ? k_g_mask_stats : k_g_mask_stats_slow, dim3(ns), dim3(256), 0, st, g, w, (const float *)t2, (const float *)c.h1,
+                       P + off_b1, bn1, t->acc(c.d_bs1));
     sync_slots(t, t->acc(c.d_bs1), 2 * w, g.nslot, st);
     hipLaunchKernelGGL(k_bnb_fin, dim3(w), dim3(64), 0, st, t->acc(c.d_bs1), w, g.nslot, n, t->d_flt + c.f_bb1);
-    hipLaunchKernelGGL(flat ? k_g_bn_bwd : k_g_bn_bwd_slow, dim3(ns), dim3(256), 0, st, g, w, t2, (const float *)c.h1, bn1,
+    hipLaunchKernelGGL(flat ? k_g_bn_bwd : k_g_bn_bwd_slow, dim3(ns), dim3(256), 0, st, g, w, t2, (const float *)c.h1, P + off_b1, bn1,
                        (const float *)(t->d_flt + c.f_bb1), G + off_b1);
     hipLaunchKernelGGL(k_g_gather18, dim3(nb), dim3(TB), 0, st, g, zin, t->gz18);
     ok = ok && (np[0] = gemm_atb_split(t, st, 18, w, g.npix, t->gz18, 18, t2, w, dW1)) > 0;            // d l_1/W = Z18^T . g_h1
