@@ -538,9 +538,11 @@ def test_sync_bn_rejects_unequal_shards(tmp_path):
         assert "same number of patches on every rank" in msg and "between 7 and 8" in msg, msg
 
 
-def test_two_rank_sync_bn_at_width_32(tmp_path):
-    """The same property on the matrix-core stage kernels (width 32): behind a cross-rank all-reduce the statistics are
-    finalised by k_bn_fin / k_bnb_fin from the scattered totals; 2 ranks x 6 patches of 16x16 = 1 rank on the 12."""
+@pytest.mark.parametrize("width", [32, 96])
+def test_two_rank_sync_bn_at_width_32(tmp_path, width):
+    """The same property on the matrix-core stage kernels (width 32) and on the library-GEMM path of the widths beyond (96;
+    csrc/nf_train_gemm.h): behind a cross-rank all-reduce the statistics are finalised by k_bn_fin / k_bnb_fin from the scattered
+    totals; 2 ranks x 6 patches of 16x16 = 1 rank on the 12."""
     import socket
     import torch.multiprocessing as mp
     from oracle.nf_grad_oracle import is_trainable
@@ -549,16 +551,16 @@ def test_two_rank_sync_bn_at_width_32(tmp_path):
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_syncbn_worker, args=(r, 2, port, str(tmp_path), 32, 16, 6)) for r in range(2)]
+    procs = [ctx.Process(target=_syncbn_worker, args=(r, 2, port, str(tmp_path), width, 16, 6)) for r in range(2)]
     [p.start() for p in procs]
     [p.join(timeout=300) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
     load = lambda n, r: np.load(os.path.join(str(tmp_path), "sync_%s_%d.npy" % (n, r)))   # noqa: E731
     g0, g1 = load("grad", 0), load("grad", 1)
     assert np.array_equal(g0, g1) and np.array_equal(load("params", 0), load("params", 1))
-    v = trained_like_variables(DP_ARCH, 32, seed=9)
+    v = trained_like_variables(DP_ARCH, width, seed=9)
     x, y = make_inputs(12, 16, 16, seed=500, b1=0.003696)
-    one = _trainer(DP_ARCH, v, (16, 16, 4), 32, max_batch=12)
+    one = _trainer(DP_ARCH, v, (16, 16, 4), width, max_batch=12)
     g_one, loss_one = one.forward_backward(x, y, [0.0], [0.0], [800], [2])
     ref, got = one.raw_to_variables(g_one.cpu().numpy().copy()), one.raw_to_variables(g0)
     gmax = max(np.abs(ref[n]).max() for n in ref if is_trainable(n))
@@ -569,7 +571,7 @@ def test_two_rank_sync_bn_at_width_32(tmp_path):
     l2 = 0.5 * (load("loss", 0)[0] + load("loss", 1)[0])
     assert abs(l2 - float(loss_one.cpu().numpy()[0])) <= 1e-5 * abs(l2)
     # per-rank statistics on the same shards: a different gradient
-    a, b = _trainer(DP_ARCH, v, (16, 16, 4), 32, max_batch=6), _trainer(DP_ARCH, v, (16, 16, 4), 32, max_batch=6)
+    a, b = _trainer(DP_ARCH, v, (16, 16, 4), width, max_batch=6), _trainer(DP_ARCH, v, (16, 16, 4), width, max_batch=6)
     ga, _ = a.forward_backward(x[:6], y[:6], [0.0], [0.0], [800], [2])
     gb, _ = b.forward_backward(x[6:], y[6:], [0.0], [0.0], [800], [2])
     g_local = one.raw_to_variables(((ga + gb) / 2).cpu().numpy())
