@@ -2044,11 +2044,14 @@ static int bs_build_plan(nf_handle *h, int direction, BsPlan &P)
         const nf_layer_desc &L = h->layers[i];
         if (L.type != NF_LAYER_COUPLING) continue;
         ++n_cpl;
-        const int w = L.width;
+        const int w = L.width, wk = h->fwd.prog.width;   // width of the variables / of the kernels' layout (zero-padded channels:
+                                                          // activation 0 on every pixel, batch moments 0, weights and bias stay 0)
         float *lp = p.data() + L.param_offset;
         float *mv[4] = {lp + 19 * w, lp + 20 * w, lp + 22 * w + w * w, lp + 23 * w + w * w};
         P.shift.insert(P.shift.end(), mv[0], mv[0] + w);
+        P.shift.insert(P.shift.end(), (size_t)(wk - w), 0.0f);
         P.shift.insert(P.shift.end(), mv[2], mv[2] + w);
+        P.shift.insert(P.shift.end(), (size_t)(wk - w), 0.0f);
         for (int j = 0; j < w; ++j) mv[1][j] = mv[3][j] = (float)(1.0 - kBnEps);
     }
     int rc = build_program(&h->cfg, h->layers.data(), p.data(), p.size(), direction, P.ident);
@@ -2164,8 +2167,9 @@ static int bs_sync(nf_handle *h, double *stats, int nvals, hipStream_t st)
 static int run_batchstats(nf_handle *h, int direction, NfLaunch a, float *moments_out, hipStream_t st)
 {
     if (h->cfg.flags & NF_CFG_FP16_CNN) return fail(NF_EINVAL, "batch-statistics mode is fp32 only");
-    if (h->fwd.raw_width != h->fwd.prog.width)
-        return fail(NF_EINVAL, "batch-statistics mode covers the coupling widths 4 / 8 / 16 / 32 (the model has %d)", h->fwd.raw_width);
+    if (h->fwd.prog.width > 32)
+        return fail(NF_EINVAL, "batch-statistics mode covers the coupling widths 1 .. 32 (the model has %d)", h->fwd.raw_width);
+    const int wr = h->fwd.raw_width;   // rows of moments_out are [4][wr]; the kernels' rows [4][prog.width] (zero-padded widths)
     // images beyond 64x64 (nf_device.h, "overlapping tiles"): the width-4 matrix-core schedule below, every launch tiled with
     // ONE halo for the whole call — 3 = the deepest launch (re-run coupling c-1, then l_1 of coupling c for its statistics) —
     // so that the tile grid, and with it the per-thread log-det carry, is the same in every launch
@@ -2362,7 +2366,8 @@ static int run_batchstats(nf_handle *h, int direction, NfLaunch a, float *moment
                     mom_h[(size_t)c * 16 + j] += P.shift[(size_t)c * 8 + j];
                     mom_h[(size_t)c * 16 + 8 + j] += P.shift[(size_t)c * 8 + 4 + j];
                 }
-            memcpy(moments_out, mom_h.data(), (size_t)n_cpl * 16 * sizeof(float));
+            for (int c = 0; c < n_cpl; ++c)          // the caller's rows hold the model's own channels
+                for (int q = 0; q < 4; ++q) memcpy(moments_out + ((size_t)c * 4 + q) * wr, mom_h.data() + (size_t)c * 16 + q * 4, (size_t)wr * sizeof(float));
         }
         return NF_OK;
     }
@@ -2444,7 +2449,9 @@ static int run_batchstats(nf_handle *h, int direction, NfLaunch a, float *moment
                 mom_h[(size_t)c * 4 * w + j] += P.shift[(size_t)c * 2 * w + j];
                 mom_h[(size_t)c * 4 * w + 2 * w + j] += P.shift[(size_t)c * 2 * w + w + j];
             }
-        memcpy(moments_out, mom_h.data(), (size_t)n_cpl * 4 * w * sizeof(float));
+        for (int c = 0; c < n_cpl; ++c)              // the caller's rows hold the model's own channels
+            for (int q = 0; q < 4; ++q)
+                memcpy(moments_out + ((size_t)c * 4 + q) * wr, mom_h.data() + ((size_t)c * 4 + q) * w, (size_t)wr * sizeof(float));
     }
     return NF_OK;
 }

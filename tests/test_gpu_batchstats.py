@@ -89,9 +89,13 @@ def test_sampling_batchstats_full_arch(shipped_variables):
 
 
 @pytest.mark.parametrize("arch,width,hw,B", [("unc|unc", 8, (24, 40), 6), ("unc|gain4|unc", 16, (16, 16), 9),
-                                             ("sdn4|unc|gain4|unc", 4, (64, 64), 3)])
+                                             ("sdn4|unc|gain4|unc", 4, (64, 64), 3),
+                                             ("unc|unc", 5, (16, 20), 5), ("sdn5|unc|unc", 12, (16, 16), 4),      # zero-padded onto
+                                             ("unc|gain4|unc", 24, (16, 16), 6), ("unc|unc", 3, (32, 32), 3)])     # 8 / 16 / 32 / 4
 def test_batchstats_other_shapes(arch, width, hw, B):
-    """Scalar-weight final pass (width != 4 / ragged shapes) and the 64x64 matrix-core one."""
+    """Scalar-weight final pass (width != 4 / ragged shapes) and the 64x64 matrix-core one; widths between two kernel widths run
+    zero-padded (a padded channel is 0 on every pixel: batch moments 0, its weights and bias stay 0), the moments the call
+    reports — and the running statistics they move — are the model's own channels."""
     v = trained_like_variables(arch, width, seed=4)
     shape = (hw[0], hw[1], 4)
     x, y = make_inputs(B, hw[0], hw[1], seed=13)
@@ -102,6 +106,18 @@ def test_batchstats_other_shapes(arch, width, hw, B):
     np.testing.assert_allclose(nll, ref, rtol=NLL_RTOL)
     rng = np.random.RandomState(2)
     eps = rng.randn(B, *shape).astype(np.float32)
+    # running statistics after the NLL call: the EMA of the model's own channels (layers.py:392-393)
+    m3 = _model(arch, v, shape, width)
+    m3._loss(x, y, [0.0], [0.0], [400], [1])
+    o.nll(x, y, 400, 1, training=True)
+    names = [L["name"] for L in o.layers if L["type"] == "coupling"]
+    for scope, lname in zip(_coupling_scopes(m3), names):
+        rec = o.last_batch_moments[lname]
+        for bn, key in (("bn_nvp_conv_1/mean", "new_mean1"), ("bn_nvp_conv_1/var", "new_var1"),
+                        ("bn_nvp_conv_2/mean", "new_mean2"), ("bn_nvp_conv_2/var", "new_var2")):
+            got, want = np.asarray(m3.variables[scope + "/" + bn]).reshape(-1), np.asarray(rec[key]).reshape(-1)
+            assert got.shape == want.shape == (width,)
+            assert np.abs(got - want).max() <= 1e-5 * max(np.abs(want).max(), 1e-3), (scope, bn)
     xs = m.sample(y, 1.0, y, [0.0], [0.0], [400], [1], eps=eps)
     _close_elem(xs, o.sample(eps, 1.0, y, 400, 1, training=True))
 
