@@ -6,6 +6,8 @@ The hand-picked cases of the other files pin the geometry edges; this file looks
 Tolerance: per-patch NLL 1e-5 relative, tensors 1e-5 of their scale — or, where random weights make the stack
 ill-conditioned, twice the distance of the oracle's own float32 flavour from its fp64 one (the kernel may not be
 further from the truth than a plain fp32 evaluation of the reference's op sequence is)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -21,6 +23,8 @@ ISO_TABLE = [100, 400, 800, 1600, 3200]
 def _draw_case(seed):
     rng = np.random.RandomState(1000 + seed)
     width = int(rng.choice([4, 4, 4, 8, 16, 32]))
+    if os.environ.get("NF_SWEEP_WIDTHS"):      # one-off sweeps over other widths (tools/oneoff_*.py): same draw otherwise
+        width = int(np.random.RandomState(77 + seed).choice([int(w) for w in os.environ["NF_SWEEP_WIDTHS"].split(",")]))
     n = int(rng.randint(1, 6))
     arch, n_cond = [], 0
     for _ in range(n):
@@ -233,7 +237,8 @@ def test_random_model_training_gradients(seed):
     arch, width, (H, W), fp, decomp, iso, cam, B = _draw_case(5000 + seed)
     if "unc" not in arch.split("|"):
         arch = arch + "|unc"
-    H, W = min(H, 32), min(W, 32)
+    hw_max = int(os.environ.get("NF_SWEEP_MAXHW", "32"))    # one-off sweeps at large widths: fewer activations, fewer of them on a kink
+    H, W = min(H, hw_max), min(W, hw_max)
     B = max(B, 2) + seed % 4
     if H * W * B < 32:
         H, W = H + 4, W + 4
@@ -279,7 +284,8 @@ def test_random_model_training_gradients(seed):
             ref = np.asarray(ref_grads[nm], np.float64)
             g = np.asarray(got[nm], np.float64).reshape(ref.shape)
             if nm.endswith("l_1/b") or nm.endswith("l_2/b"):      # analytically zero (BN subtracts the batch mean)
-                assert np.abs(g).max() <= 2e-5 * gmax, (nm, np.abs(g).max(), gmax)
+                tol0 = np.maximum(2e-5 * gmax, grad_noise_allowance(go, nm).reshape(ref.shape))
+                assert (np.abs(g) <= tol0).all(), (nm, np.abs(g).max(), gmax)
             else:
                 # rtol of the tensor's scale, or the round-off allowance of the sum the entry is — computed by the fp64 oracle
                 # for the evaluation being compared (conftest.py::grad_noise_allowance), not by a second GPU run
@@ -293,7 +299,7 @@ def test_random_model_training_gradients(seed):
     from conftest import grads_match_up_to_kinks
     try:
         excused = grads_match_up_to_kinks(go, x, y, iso, cam, compare,
-                                          max_kinks=48 if min_var >= 1e-6 else 0, got=got)
+                                          max_kinks=int(os.environ.get("NF_SWEEP_MAXKINKS", "48")) if min_var >= 1e-6 else 0, got=got)
     except AssertionError as e:
         raise AssertionError("%s: %s" % (case, e))
     assert excused <= 12, (case, excused)
