@@ -92,14 +92,41 @@ __global__ __launch_bounds__(GT) void nf_gemm_kernel(const NfProgram prog, const
     double acc_nll = 0.0, acc_sd = 0.0;   // thread 0 only
 
     for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
-        const size_t patch_off = (size_t)b * (size_t)HW * 4u;
+        // Where this "patch" sits: on its own ([B,H,W,4] tensors), or — NF_K_TILED (nf_device.h, "overlapping tiles") — as tile
+        // b % tiles of image b / tiles: pixel (r, c) of the tile is pixel (oy + r, ox + c) of an IH x IW image, border masks
+        // follow the image border, and results are reported for the core window [cy0, cy1) x [cx0, cx1) only.
+        size_t patch_off = (size_t)b * (size_t)HW * 4u;
+        int64_t patch_id = b;
+        int oy = 0, ox = 0, IH = H, IW = W, cy0 = 0, cy1 = H, cx0 = 0, cx1 = W;
+        const bool tiled = (a.flags & NF_K_TILED) != 0;
+        if (tiled) {
+            const int nt = a.tile_ny * a.tile_nx;
+            const int64_t img = b / nt;
+            const int ti = (int)(b - img * nt);
+            const int ty = ti / a.tile_nx, tx = ti - ty * a.tile_nx;
+            IH = a.img_H;
+            IW = a.img_W;
+            oy = nf_tile_origin(ty, IH, H, a.tile_halo);
+            ox = nf_tile_origin(tx, IW, W, a.tile_halo);
+            cy0 = nf_tile_core0(ty, IH, H, a.tile_halo);
+            cy1 = nf_tile_core1(ty, a.tile_ny, IH, H, a.tile_halo);
+            cx0 = nf_tile_core0(tx, IW, W, a.tile_halo);
+            cx1 = nf_tile_core1(tx, a.tile_nx, IW, W, a.tile_halo);
+            patch_off = (size_t)img * (size_t)IH * (size_t)IW * 4u;
+            patch_id = img;
+        }
+        auto gi_of = [&](int m) { return act[m] ? (oy + pr[m]) * IW + ox + pc[m] : 0; };        // pixel index in the tensors
+        auto own_of = [&](int m) {                                                             // this launch reports the pixel
+            const int R = oy + pr[m], C = ox + pc[m];
+            return act[m] && R >= cy0 && R < cy1 && C >= cx0 && C < cx1;
+        };
 
         float z[OWN][4];
 #pragma unroll
         for (int m = 0; m < OWN; ++m) {
-            const int gi = act[m] ? t + GT * m : 0;
+            const int gi = gi_of(m);
             if (PHILOX) {
-                philox_normal4(a.seed, a.patch_base + b, (uint32_t)gi, NF_STREAM_SAMP, z[m]);
+                philox_normal4(a.seed, a.patch_base + patch_id, (uint32_t)gi, NF_STREAM_SAMP, z[m]);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) z[m][q] *= a.in_scale;
             } else {
@@ -330,7 +357,7 @@ __global__ __launch_bounds__(GT) void nf_gemm_kernel(const NfProgram prog, const
 #pragma unroll
                 for (int m = 0; m < OWN; ++m) {
                     const int r = pr[m], c = pc[m];
-                    const int bm = (r == 0 ? 1 : 0) | (r == H - 1 ? 2 : 0) | (c == 0 ? 4 : 0) | (c == W - 1 ? 8 : 0);
+                    const int bm = (oy + r == 0 ? 1 : 0) | (oy + r == IH - 1 ? 2 : 0) | (ox + c == 0 ? 4 : 0) | (ox + c == IW - 1 ? 8 : 0);
                     const float4 eb = *reinterpret_cast<const float4 *>(a.params + prog.ops[op].off + NF7_CPL_E + 4 * (act[m] ? bm : 0));
                     o[m][0] += eb.x; o[m][1] += eb.y; o[m][2] += eb.z; o[m][3] += eb.w;
                     // raw columns are pre-scaled by 2 log2(e):  t = exp2(raw') = exp(2 raw);
@@ -340,7 +367,7 @@ __global__ __launch_bounds__(GT) void nf_gemm_kernel(const NfProgram prog, const
                     if (type == NF_OP_COUPLING_FWD) {
                         z[m][2] = fmaf(z[m][2], __builtin_amdgcn_exp2f(l0), o[m][0]);
                         z[m][3] = fmaf(z[m][3], __builtin_amdgcn_exp2f(l1), o[m][1]);
-                        if (act[m]) ld2 += l0 + l1;
+                        if (own_of(m)) ld2 += l0 + l1;
                     } else {
                         z[m][2] = (z[m][2] - o[m][0]) * __builtin_amdgcn_exp2f(-l0);
                         z[m][3] = (z[m][3] - o[m][1]) * __builtin_amdgcn_exp2f(-l1);
@@ -353,14 +380,14 @@ __global__ __launch_bounds__(GT) void nf_gemm_kernel(const NfProgram prog, const
 #pragma unroll
                 for (int m = 0; m < OWN; ++m) {
                     float4 yv = make_float4(1.f, 1.f, 1.f, 1.f);
-                    if (act[m]) yv = y4[t + GT * m];
+                    if (act[m]) yv = y4[gi_of(m)];
                     const float yy[4] = {yv.x, yv.y, yv.z, yv.w};
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const float v = fmaf(yy[q], ck1, cb2);
                         if (type == NF_OP_SDN_DIV) {
                             z[m][q] = z[m][q] * __builtin_amdgcn_rsqf(v);
-                            if (act[m]) ld = fmaf(-0.34657359027997264f, __builtin_amdgcn_logf(v), ld);
+                            if (own_of(m)) ld = fmaf(-0.34657359027997264f, __builtin_amdgcn_logf(v), ld);
                         } else {
                             z[m][q] = z[m][q] * __builtin_amdgcn_sqrtf(v);
                         }
@@ -380,13 +407,13 @@ __global__ __launch_bounds__(GT) void nf_gemm_kernel(const NfProgram prog, const
             float4 *out4 = reinterpret_cast<float4 *>(a.out + patch_off);
 #pragma unroll
             for (int m = 0; m < OWN; ++m)
-                if (act[m]) out4[t + GT * m] = make_float4(z[m][0], z[m][1], z[m][2], z[m][3]);
+                if (own_of(m)) out4[gi_of(m)] = make_float4(z[m][0], z[m][1], z[m][2], z[m][3]);
         }
-        if (a.nll_out || a.sd_out || a.ld_out || a.sums) {
+        if (a.nll_out || a.sd_out || a.ld_out || a.sums || (tiled && a.tile_part)) {
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int m = 0; m < OWN; ++m)
-                if (act[m]) {
+                if (own_of(m)) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         s1 += z[m][q];
@@ -408,6 +435,11 @@ __global__ __launch_bounds__(GT) void nf_gemm_kernel(const NfProgram prog, const
                     r1 += red[GW + i];
                     r2 += red[2 * GW + i];
                 }
+            }
+            if (t == 0 && tiled) {
+                // the tile's share of its image's sums (nf_tile_combine_kernel forms nll / sd / log-det per image)
+                *reinterpret_cast<float4 *>(a.tile_part + (size_t)b * 4u) = make_float4(r0, r1, r2, 0.f);
+            } else if (t == 0) {
                 const double npx = (double)HW * 4.0;
                 const double logdet = (double)r0 + a.ld_const;
                 double nll = -logdet;   // prior: sum -0.5*(log 2pi + z^2)   (noise_flow_model.py:537-539)
@@ -426,7 +458,7 @@ __global__ __launch_bounds__(GT) void nf_gemm_kernel(const NfProgram prog, const
         }
     }
 
-    if (a.sums && t == 0) {
+    if (a.sums && t == 0 && !(a.flags & NF_K_TILED)) {
         double *sp = a.sums;
         if (a.flags & NF_K_SUMS_WIDE) sp += (size_t)(blockIdx.x & (NF_SUMS_SLOTS - 1)) * NF_SUMS_STRIDE;
         atomicAdd(&sp[0], acc_nll);
@@ -481,14 +513,41 @@ __global__ __launch_bounds__(GT) void nf_gemmb_kernel(const NfProgram prog, cons
     double acc_nll = 0.0, acc_sd = 0.0;   // thread 0 only
 
     for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
-        const size_t patch_off = (size_t)b * (size_t)HW * 4u;
+        // Where this "patch" sits: on its own ([B,H,W,4] tensors), or — NF_K_TILED (nf_device.h, "overlapping tiles") — as tile
+        // b % tiles of image b / tiles: pixel (r, c) of the tile is pixel (oy + r, ox + c) of an IH x IW image, border masks
+        // follow the image border, and results are reported for the core window [cy0, cy1) x [cx0, cx1) only.
+        size_t patch_off = (size_t)b * (size_t)HW * 4u;
+        int64_t patch_id = b;
+        int oy = 0, ox = 0, IH = H, IW = W, cy0 = 0, cy1 = H, cx0 = 0, cx1 = W;
+        const bool tiled = (a.flags & NF_K_TILED) != 0;
+        if (tiled) {
+            const int nt = a.tile_ny * a.tile_nx;
+            const int64_t img = b / nt;
+            const int ti = (int)(b - img * nt);
+            const int ty = ti / a.tile_nx, tx = ti - ty * a.tile_nx;
+            IH = a.img_H;
+            IW = a.img_W;
+            oy = nf_tile_origin(ty, IH, H, a.tile_halo);
+            ox = nf_tile_origin(tx, IW, W, a.tile_halo);
+            cy0 = nf_tile_core0(ty, IH, H, a.tile_halo);
+            cy1 = nf_tile_core1(ty, a.tile_ny, IH, H, a.tile_halo);
+            cx0 = nf_tile_core0(tx, IW, W, a.tile_halo);
+            cx1 = nf_tile_core1(tx, a.tile_nx, IW, W, a.tile_halo);
+            patch_off = (size_t)img * (size_t)IH * (size_t)IW * 4u;
+            patch_id = img;
+        }
+        auto gi_of = [&](int m) { return act[m] ? (oy + pr[m]) * IW + ox + pc[m] : 0; };        // pixel index in the tensors
+        auto own_of = [&](int m) {                                                             // this launch reports the pixel
+            const int R = oy + pr[m], C = ox + pc[m];
+            return act[m] && R >= cy0 && R < cy1 && C >= cx0 && C < cx1;
+        };
 
         float z[OWN][4];
 #pragma unroll
         for (int m = 0; m < OWN; ++m) {
-            const int gi = act[m] ? t + GT * m : 0;
+            const int gi = gi_of(m);
             if (PHILOX) {
-                philox_normal4(a.seed, a.patch_base + b, (uint32_t)gi, NF_STREAM_SAMP, z[m]);
+                philox_normal4(a.seed, a.patch_base + patch_id, (uint32_t)gi, NF_STREAM_SAMP, z[m]);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) z[m][q] *= a.in_scale;
             } else {
@@ -660,7 +719,7 @@ __global__ __launch_bounds__(GT) void nf_gemmb_kernel(const NfProgram prog, cons
 #pragma unroll
                 for (int m = 0; m < OWN; ++m) {
                     const int r = pr[m], c = pc[m];
-                    const int bm = (r == 0 ? 1 : 0) | (r == H - 1 ? 2 : 0) | (c == 0 ? 4 : 0) | (c == W - 1 ? 8 : 0);
+                    const int bm = (oy + r == 0 ? 1 : 0) | (oy + r == IH - 1 ? 2 : 0) | (ox + c == 0 ? 4 : 0) | (ox + c == IW - 1 ? 8 : 0);
                     const float4 eb = *reinterpret_cast<const float4 *>(a.params + prog.ops[op].off + NF7_CPL_E + 4 * (act[m] ? bm : 0));
                     o[m][0] += eb.x; o[m][1] += eb.y; o[m][2] += eb.z; o[m][3] += eb.w;
                     const float l0 = fmaf(__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(o[m][2]) + 1.0f), m2scl, scl);
@@ -668,7 +727,7 @@ __global__ __launch_bounds__(GT) void nf_gemmb_kernel(const NfProgram prog, cons
                     if (type == NF_OP_COUPLING_FWD) {
                         z[m][2] = fmaf(z[m][2], __builtin_amdgcn_exp2f(l0), o[m][0]);
                         z[m][3] = fmaf(z[m][3], __builtin_amdgcn_exp2f(l1), o[m][1]);
-                        if (act[m]) ld2 += l0 + l1;
+                        if (own_of(m)) ld2 += l0 + l1;
                     } else {
                         z[m][2] = (z[m][2] - o[m][0]) * __builtin_amdgcn_exp2f(-l0);
                         z[m][3] = (z[m][3] - o[m][1]) * __builtin_amdgcn_exp2f(-l1);
@@ -681,14 +740,14 @@ __global__ __launch_bounds__(GT) void nf_gemmb_kernel(const NfProgram prog, cons
 #pragma unroll
                 for (int m = 0; m < OWN; ++m) {
                     float4 yv = make_float4(1.f, 1.f, 1.f, 1.f);
-                    if (act[m]) yv = y4[t + GT * m];
+                    if (act[m]) yv = y4[gi_of(m)];
                     const float yy[4] = {yv.x, yv.y, yv.z, yv.w};
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const float v = fmaf(yy[q], ck1, cb2);
                         if (type == NF_OP_SDN_DIV) {
                             z[m][q] = z[m][q] * __builtin_amdgcn_rsqf(v);
-                            if (act[m]) ld = fmaf(-0.34657359027997264f, __builtin_amdgcn_logf(v), ld);
+                            if (own_of(m)) ld = fmaf(-0.34657359027997264f, __builtin_amdgcn_logf(v), ld);
                         } else {
                             z[m][q] = z[m][q] * __builtin_amdgcn_sqrtf(v);
                         }
@@ -708,13 +767,13 @@ __global__ __launch_bounds__(GT) void nf_gemmb_kernel(const NfProgram prog, cons
             float4 *out4 = reinterpret_cast<float4 *>(a.out + patch_off);
 #pragma unroll
             for (int m = 0; m < OWN; ++m)
-                if (act[m]) out4[t + GT * m] = make_float4(z[m][0], z[m][1], z[m][2], z[m][3]);
+                if (own_of(m)) out4[gi_of(m)] = make_float4(z[m][0], z[m][1], z[m][2], z[m][3]);
         }
-        if (a.nll_out || a.sd_out || a.ld_out || a.sums) {
+        if (a.nll_out || a.sd_out || a.ld_out || a.sums || (tiled && a.tile_part)) {
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int m = 0; m < OWN; ++m)
-                if (act[m]) {
+                if (own_of(m)) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         s1 += z[m][q];
@@ -736,6 +795,11 @@ __global__ __launch_bounds__(GT) void nf_gemmb_kernel(const NfProgram prog, cons
                     r1 += red[GW + i];
                     r2 += red[2 * GW + i];
                 }
+            }
+            if (t == 0 && tiled) {
+                // the tile's share of its image's sums (nf_tile_combine_kernel forms nll / sd / log-det per image)
+                *reinterpret_cast<float4 *>(a.tile_part + (size_t)b * 4u) = make_float4(r0, r1, r2, 0.f);
+            } else if (t == 0) {
                 const double npx = (double)HW * 4.0;
                 const double logdet = (double)r0 + a.ld_const;
                 double nll = -logdet;   // prior: sum -0.5*(log 2pi + z^2)   (noise_flow_model.py:537-539)
@@ -754,7 +818,7 @@ __global__ __launch_bounds__(GT) void nf_gemmb_kernel(const NfProgram prog, cons
         }
     }
 
-    if (a.sums && t == 0) {
+    if (a.sums && t == 0 && !(a.flags & NF_K_TILED)) {
         double *sp = a.sums;
         if (a.flags & NF_K_SUMS_WIDE) sp += (size_t)(blockIdx.x & (NF_SUMS_SLOTS - 1)) * NF_SUMS_STRIDE;
         atomicAdd(&sp[0], acc_nll);

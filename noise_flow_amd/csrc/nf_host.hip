@@ -961,9 +961,6 @@ int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float
             // Widths in between run on the next kernel up, zero-padded HERE: a hidden channel with zero weights and zero bias is
             // relu(0) = 0 in both hidden layers and contributes nothing to l_2 / l_last — exact.
             const int wk = L.width > 32 ? L.width : L.width <= 4 ? 4 : L.width <= 8 ? 8 : L.width <= 16 ? 16 : 32;
-            if (L.width > 32 && out.tiled)
-                return fail(NF_EINVAL, "layer %d: patches beyond 64x64 (%dx%d given) are evaluated at coupling widths up to 32", li, cfg->height,
-                            cfg->width);
             if (L.width > 32 && !nf_gemm_shape_ok(th, tw))
                 return fail(NF_EINVAL, "layer %d: coupling width %d covers patches of up to %d pixels (%dx%d given)", li, L.width,
                             NF7_MAX_PIXELS, cfg->height, cfg->width);
@@ -1774,10 +1771,13 @@ static int launch_tiled(nf_handle *h, int direction, NfLaunch &a, hipStream_t st
     float *d4 = direction == 0 ? h->d_fwd4 : h->d_rev4;
     float *d5 = direction == 0 ? h->d_fwd5 : h->d_rev5;
     float *d3 = direction == 0 ? h->d_fwd3 : h->d_rev3;
-    const bool hb = d3 && b.fp16_big && !d5;   // width 4, fp16 CNN, full 64x64 tiles: the fused kernel on v_mfma_f32_16x16x32_f16
-    const int wide = hb ? 0 : d5 ? 2 : (d4 && b.prog.width > 4) ? 1 : 0;
+    float *d7 = direction == 0 ? h->d_fwd7 : h->d_rev7;   // widths 33 .. 512: the GEMM kernels take tiles as they take patches
+    float *d8 = direction == 0 ? h->d_fwd8 : h->d_rev8;
+    const int gemm = d8 ? 2 : d7 ? 1 : 0;
+    const bool hb = !gemm && d3 && b.fp16_big && !d5;   // width 4, fp16 CNN, full 64x64 tiles: the fused kernel on v_mfma_f32_16x16x32_f16
+    const int wide = (hb || gemm) ? 0 : d5 ? 2 : (d4 && b.prog.width > 4) ? 1 : 0;
     const bool mc = hb || (d2 && (use_matrix_core() || !h->scalar_ok));
-    const NfProgram &full = hb ? b.prog3 : wide == 2 ? b.prog5 : wide == 1 ? b.prog4 : mc ? b.prog2 : b.prog;
+    const NfProgram &full = gemm == 2 ? b.prog8 : gemm == 1 ? b.prog7 : hb ? b.prog3 : wide == 2 ? b.prog5 : wide == 1 ? b.prog4 : mc ? b.prog2 : b.prog;
     const float *cur = a.in;
     for (int s = 0; s < S && e == hipSuccess; ++s) {
         const Built::TileSeg &g = b.segs[s];
@@ -1805,7 +1805,16 @@ static int launch_tiled(nf_handle *h, int direction, NfLaunch &a, hipStream_t st
         t.nll_out = t.sd_out = t.ld_out = nullptr;
         t.sums = nullptr;
         t.tile_part = want ? part + tp.off[s] * 4 : nullptr;
-        if (wide) {
+        if (gemm == 2) {
+            t.params = d8;
+            t.n_params = (int32_t)b.block8.size();
+            t.flags |= NF_K_FP16_CNN;
+            e = b.gemm16_b ? nf_launch_gemm16b(sp, t, h->n_cu, h->device, st) : nf_launch_gemm16(sp, t, h->n_cu, h->device, st);
+        } else if (gemm == 1) {
+            t.params = d7;
+            t.n_params = (int32_t)b.block7.size();
+            e = b.gemm_b ? nf_launch_gemmb(sp, t, h->n_cu, h->device, st) : nf_launch_gemm(sp, t, h->n_cu, h->device, st);
+        } else if (wide) {
             t.params = wide == 2 ? d5 : d4;
             t.n_params = (int32_t)(wide == 2 ? b.block5.size() : b.block4.size());
             if (wide == 2) t.flags |= NF_K_FP16_CNN;
@@ -1927,6 +1936,8 @@ int nf_kernel_path(const nf_handle *h, int32_t direction)
     if (!h || (direction != 0 && direction != 1)) return fail(NF_EINVAL, "bad argument");
     if (direction == 0 ? h->d_fwd5 : h->d_rev5) return NF_PATH_WIDE32_FP16;
     if (h->fwd.tiled) {   // images beyond 64x64: launch_tiled's choice
+        if (direction == 0 ? h->d_fwd8 : h->d_rev8) return NF_PATH_GEMM_FP16;
+        if (direction == 0 ? h->d_fwd7 : h->d_rev7) return NF_PATH_GEMM;
         if ((direction == 0 ? h->d_fwd3 : h->d_rev3) && h->fwd.fp16_big) return NF_PATH_FP16;
         if ((direction == 0 ? h->d_fwd4 : h->d_rev4) && h->fwd.prog.width > 4) return NF_PATH_WIDE32;
         return (direction == 0 ? h->d_fwd2 : h->d_rev2) && (use_matrix_core() || !h->scalar_ok) ? NF_PATH_MFMA4 : NF_PATH_SCALAR;

@@ -91,13 +91,26 @@ def test_tile_results_do_not_depend_on_the_batch():
                                                           (4, "fp16", (128, 80), None, 2),      # full 64x64 tiles: the width-4 fp16 kernel
                                                           (4, "fp16", (256, 96), "sdn5|unc|unc|gain4|unc|unc", 2),
                                                           (4, "fp16", (150, 40), None, 5),      # 64x40 tiles: zero-padded on the width-32 kernel
-                                                          (32, "fp32", (40, 150), "unc|unc|unc", 3)])
+                                                          (32, "fp32", (40, 150), "unc|unc|unc", 3),
+                                                          # widths beyond 32: the GEMM kernels take tiles as they take patches
+                                                          (64, "fp32", (80, 100), "sdn5|unc|gain4|unc", 6),      # variant B (weights in LDS)
+                                                          (200, "fp32", (70, 66), "unc|unc", 6),
+                                                          (96, "fp16", (130, 64), "sdn5|unc|unc|gain4", 7),
+                                                          (512, "fp16", (65, 40), "unc", 7)])
 def test_large_patches_on_the_width_32_kernel(width, cnn_dtype, hw, arch, path):
     """Coupling widths 8 / 16 / 32 and the fp16-CNN mode (any width up to 32) run their tiles on the width-32 matrix-core
     kernel (narrower CNNs zero-padded: exact, a padded channel is identically zero) — except width 4 in fp16-CNN mode on images
-    of at least 64 pixels per side, whose full 64x64 tiles run on the width-4 fp16 kernel (v_mfma_f32_16x16x32_f16)."""
+    of at least 64 pixels per side, whose full 64x64 tiles run on the width-4 fp16 kernel (v_mfma_f32_16x16x32_f16).  Widths
+    33 .. 512 run their tiles on the GEMM kernels (nf_gemm.hip / nf_gemm16.hip: a tile is a patch at an offset, border masks
+    from the image, results for the core window)."""
     from check_large_patches import check
-    r = check(hw[0], hw[1], 2, arch, width=width, cnn_dtype=cnn_dtype)
+    v = None
+    if width > 32:      # activations of O(1) at every width (the helper's weights are tuned for width 4): the fp16 cases compare
+        v = trained_like_variables(arch, width, seed=hw[0] * 1000 + hw[1])      # tensors at 2e-3 of their scale
+        for k in v:
+            if k.endswith("l_2/W") or k.endswith("l_last/W"):
+                v[k] = (v[k] * np.float32((4.0 / width) ** 0.5)).astype(np.float32)
+    r = check(hw[0], hw[1], 2, arch, width=width, cnn_dtype=cnn_dtype, variables=v)
     assert r["kernel_path"] == path, r
     _assert_ok(r)
 
@@ -187,10 +200,6 @@ def test_wrapper_samples_large_patches(compat):
 def test_large_patches_limits():
     from noise_flow_amd import NoiseFlow, default_hps
     from noise_flow_amd._lib import NoiseFlowLibError, NF_EINVAL
-    v64 = trained_like_variables("unc", 64)
-    with pytest.raises(NoiseFlowLibError) as ei:
-        NoiseFlow([80, 80, 4], False, default_hps(arch="unc", width=64), variables=v64)
-    assert ei.value.code == NF_EINVAL and "up to 32" in str(ei.value)
     # batch-statistics mode beyond 64x64: the width-4 matrix-core schedule only
     v8 = trained_like_variables("unc", 8)
     m = NoiseFlow([80, 80, 4], True, default_hps(arch="unc", width=8), variables=v8)
