@@ -2127,6 +2127,8 @@ int nf_trainer_create(const nf_config *cfg, const nf_layer_desc *layers, const f
             return nf_fail(NF_EHIP, "rocblas_create_handle failed");
         }
         t->blas = bh;
+        // no atomically accumulated split-K products: a step's gradients are the same bits on every run, as at the other widths
+        if (rocblas_api()->set_atomics) (void)rocblas_api()->set_atomics(bh, rocblas_atomics_not_allowed);
     }
     for (int k = 0; k < (gemm_width(w) ? 1 : 3); ++k) {
         NF_TRY(dev_alloc(t, (void **)&t->t1[k], act * w * sizeof(float)));

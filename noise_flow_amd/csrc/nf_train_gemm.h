@@ -49,6 +49,7 @@ struct RocBlas {
     rocblas_status (*create)(rocblas_handle *) = nullptr;
     rocblas_status (*destroy)(rocblas_handle) = nullptr;
     rocblas_status (*set_stream)(rocblas_handle, hipStream_t) = nullptr;
+    rocblas_status (*set_atomics)(rocblas_handle, rocblas_atomics_mode) = nullptr;   // optional
     rocblas_status (*sgemm)(rocblas_handle, rocblas_operation, rocblas_operation, rocblas_int, rocblas_int, rocblas_int, const float *,
                             const float *, rocblas_int, const float *, rocblas_int, const float *, float *, rocblas_int) = nullptr;
     rocblas_status (*sgemm_sb)(rocblas_handle, rocblas_operation, rocblas_operation, rocblas_int, rocblas_int, rocblas_int, const float *,
@@ -69,6 +70,7 @@ inline const RocBlas *rocblas_api()
             r.create = reinterpret_cast<decltype(r.create)>(dlsym(r.lib, "rocblas_create_handle"));
             r.destroy = reinterpret_cast<decltype(r.destroy)>(dlsym(r.lib, "rocblas_destroy_handle"));
             r.set_stream = reinterpret_cast<decltype(r.set_stream)>(dlsym(r.lib, "rocblas_set_stream"));
+            r.set_atomics = reinterpret_cast<decltype(r.set_atomics)>(dlsym(r.lib, "rocblas_set_atomics_mode"));
             r.sgemm = reinterpret_cast<decltype(r.sgemm)>(dlsym(r.lib, "rocblas_sgemm"));
             r.sgemm_sb = reinterpret_cast<decltype(r.sgemm_sb)>(dlsym(r.lib, "rocblas_sgemm_strided_batched"));
             if (!r.create || !r.destroy || !r.set_stream || !r.sgemm || !r.sgemm_sb) r.lib = nullptr;

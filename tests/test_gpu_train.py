@@ -662,14 +662,16 @@ def test_variables_shared_between_layers_receive_the_summed_gradient():
     assert not np.array_equal(seen["model/sdn_gain/gain_val"], np.asarray(v["model/sdn_gain/gain_val"]).reshape(-1))
 
 
-def test_a_training_run_is_reproducible_bit_for_bit(shipped_variables):
+@pytest.mark.parametrize("width", [4, 64])
+def test_a_training_run_is_reproducible_bit_for_bit(shipped_variables, width):
     """Gradients, BN moments and updates come from slot reductions in a fixed order; on patches of a multiple of 64 pixels
     the reported loss / sd_z do too (one partial per wavefront, summed in order).  Two trainers fed the same minibatches
-    end in identical parameters and identical logged values, to the bit."""
+    end in identical parameters and identical logged values, to the bit — also on the library-GEMM path (width 64: rocBLAS with
+    atomically accumulated products switched off, filter gradients as pixel-split partial products added up in a fixed order)."""
     import torch
     outs = []
     for rep in range(2):
-        tr = _trainer(FULL_ARCH, shipped_variables, max_batch=12)
+        tr = _trainer(FULL_ARCH, shipped_variables if width == 4 else trained_like_variables(FULL_ARCH, width, seed=3), width=width, max_batch=12)
         log = []
         for step in range(4):
             x, y = make_inputs(12, seed=60 + step, b1=0.003696)
