@@ -20,6 +20,7 @@
 #include "nf_device.h"
 #include "nf_gemm_layout.h"
 #include "nf_dev_util.h"
+#include "nf_gemm_common.h"
 
 namespace {
 
@@ -90,52 +91,9 @@ __global__ __launch_bounds__(GT) void nf_gemm16_kernel(const NfProgram prog, con
     double acc_nll = 0.0, acc_sd = 0.0;   // thread 0 only
 
     for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
-        // Where this "patch" sits: on its own ([B,H,W,4] tensors), or — NF_K_TILED (nf_device.h, "overlapping tiles") — as tile
-        // b % tiles of image b / tiles: pixel (r, c) of the tile is pixel (oy + r, ox + c) of an IH x IW image, border masks
-        // follow the image border, and results are reported for the core window [cy0, cy1) x [cx0, cx1) only.
-        size_t patch_off = (size_t)b * (size_t)HW * 4u;
-        int64_t patch_id = b;
-        int oy = 0, ox = 0, IH = H, IW = W, cy0 = 0, cy1 = H, cx0 = 0, cx1 = W;
-        const bool tiled = (a.flags & NF_K_TILED) != 0;
-        if (tiled) {
-            const int nt = a.tile_ny * a.tile_nx;
-            const int64_t img = b / nt;
-            const int ti = (int)(b - img * nt);
-            const int ty = ti / a.tile_nx, tx = ti - ty * a.tile_nx;
-            IH = a.img_H;
-            IW = a.img_W;
-            oy = nf_tile_origin(ty, IH, H, a.tile_halo);
-            ox = nf_tile_origin(tx, IW, W, a.tile_halo);
-            cy0 = nf_tile_core0(ty, IH, H, a.tile_halo);
-            cy1 = nf_tile_core1(ty, a.tile_ny, IH, H, a.tile_halo);
-            cx0 = nf_tile_core0(tx, IW, W, a.tile_halo);
-            cx1 = nf_tile_core1(tx, a.tile_nx, IW, W, a.tile_halo);
-            patch_off = (size_t)img * (size_t)IH * (size_t)IW * 4u;
-            patch_id = img;
-        }
-        auto gi_of = [&](int m) { return act[m] ? (oy + pr[m]) * IW + ox + pc[m] : 0; };        // pixel index in the tensors
-        auto own_of = [&](int m) {                                                             // this launch reports the pixel
-            const int R = oy + pr[m], C = ox + pc[m];
-            return act[m] && R >= cy0 && R < cy1 && C >= cx0 && C < cx1;
-        };
-
+        const GemmTile T = gemm_tile(a, b, H, W);
         float z[OWN][4];
-#pragma unroll
-        for (int m = 0; m < OWN; ++m) {
-            const int gi = gi_of(m);
-            if (PHILOX) {
-                philox_normal4(a.seed, a.patch_base + patch_id, (uint32_t)gi, NF_STREAM_SAMP, z[m]);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) z[m][q] *= a.in_scale;
-            } else {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (act[m]) v = reinterpret_cast<const float4 *>(a.in + patch_off)[gi];
-                z[m][0] = v.x * a.in_scale;
-                z[m][1] = v.y * a.in_scale;
-                z[m][2] = v.z * a.in_scale;
-                z[m][3] = v.w * a.in_scale;
-            }
-        }
+        gemm_input<OWN, PHILOX>(a, T, pr, pc, act, z);
 
         float ld = 0.0f, ld2 = 0.0f;   // natural-log / log2 parts of this thread's log-det share
 
@@ -144,23 +102,7 @@ __global__ __launch_bounds__(GT) void nf_gemm16_kernel(const NfProgram prog, con
             const cfloat_p P = (cfloat_p)(a.params + prog.ops[op].off);   // wave-uniform, scalar loads
 
             if (type == NF_OP_MIX) {
-                float mm[16];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) mm[i] = P[i];
-#pragma unroll
-                for (int m = 0; m < OWN; ++m) {
-                    float o[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float s = z[m][0] * mm[j];
-                        s = fmaf(z[m][1], mm[4 + j], s);
-                        s = fmaf(z[m][2], mm[8 + j], s);
-                        s = fmaf(z[m][3], mm[12 + j], s);
-                        o[j] = s;
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) z[m][j] = o[j];
-                }
+                gemm_mix<OWN>(P, z);
             } else if (type == NF_OP_COUPLING_FWD || type == NF_OP_COUPLING_REV) {
                 const float *const img = a.params + prog.ops[op].off + NF8_CPL_IMG;
                 // ---- publish the pass-through half (rounded to half: a CNN input) ----
@@ -335,119 +277,17 @@ __global__ __launch_bounds__(GT) void nf_gemm16_kernel(const NfProgram prog, con
                 }
 
                 // ---- finish the coupling on the owned pixels ----
-                const float scl = P[NF8_CPL_S + 1], m2scl = P[NF8_CPL_S + 2];
-#pragma unroll
-                for (int m = 0; m < OWN; ++m) {
-                    const int r = pr[m], c = pc[m];
-                    const int bm = (oy + r == 0 ? 1 : 0) | (oy + r == IH - 1 ? 2 : 0) | (ox + c == 0 ? 4 : 0) | (ox + c == IW - 1 ? 8 : 0);
-                    const float4 eb = *reinterpret_cast<const float4 *>(a.params + prog.ops[op].off + NF8_CPL_E + 4 * (act[m] ? bm : 0));
-                    // fp16 weights are not pre-scaled (their rounding points are the oracle's); the table is
-                    o[m][0] += eb.x; o[m][1] += eb.y;
-                    o[m][2] = fmaf(o[m][2], 2.8853900817779268f, eb.z);
-                    o[m][3] = fmaf(o[m][3], 2.8853900817779268f, eb.w);
-                    const float l0 = fmaf(__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(o[m][2]) + 1.0f), m2scl, scl);
-                    const float l1 = fmaf(__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(o[m][3]) + 1.0f), m2scl, scl);
-                    if (type == NF_OP_COUPLING_FWD) {
-                        z[m][2] = fmaf(z[m][2], __builtin_amdgcn_exp2f(l0), o[m][0]);
-                        z[m][3] = fmaf(z[m][3], __builtin_amdgcn_exp2f(l1), o[m][1]);
-                        if (own_of(m)) ld2 += l0 + l1;
-                    } else {
-                        z[m][2] = (z[m][2] - o[m][0]) * __builtin_amdgcn_exp2f(-l0);
-                        z[m][3] = (z[m][3] - o[m][1]) * __builtin_amdgcn_exp2f(-l1);
-                    }
-                }
+                gemm_finish_coupling<OWN, true>(type, a.params + prog.ops[op].off + NF8_CPL_E, P[NF8_CPL_S + 1], P[NF8_CPL_S + 2], T, pr, pc, act, o, z, ld2);
             } else if (type == NF_OP_SDN_DIV || type == NF_OP_SDN_MUL) {
-                // AffineCouplingSdnEx5: scale = sqrt(beta1*y/gain + beta2)  (cond_utils.py:238)
-                const float4 *y4 = reinterpret_cast<const float4 *>(a.y + patch_off);
-                const float ck1 = a.cond_a[prog.ops[op].off & 3], cb2 = a.cond_b[prog.ops[op].off & 3];
-#pragma unroll
-                for (int m = 0; m < OWN; ++m) {
-                    float4 yv = make_float4(1.f, 1.f, 1.f, 1.f);
-                    if (act[m]) yv = y4[gi_of(m)];
-                    const float yy[4] = {yv.x, yv.y, yv.z, yv.w};
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float v = fmaf(yy[q], ck1, cb2);
-                        if (type == NF_OP_SDN_DIV) {
-                            z[m][q] = z[m][q] * __builtin_amdgcn_rsqf(v);
-                            if (own_of(m)) ld = fmaf(-0.34657359027997264f, __builtin_amdgcn_logf(v), ld);
-                        } else {
-                            z[m][q] = z[m][q] * __builtin_amdgcn_sqrtf(v);
-                        }
-                    }
-                }
+                gemm_sdn<OWN>(type, prog.ops[op].off, a, T, pr, pc, act, z, ld);
             } else if (type == NF_OP_SCALE || type == NF_OP_SCALE_COND) {
-                const float s = type == NF_OP_SCALE ? P[0] : a.cond_a[prog.ops[op].off & 3];
-#pragma unroll
-                for (int m = 0; m < OWN; ++m)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) z[m][q] *= s;
+                gemm_scale<OWN>(type == NF_OP_SCALE ? P[0] : a.cond_a[prog.ops[op].off & 3], z);
             }
         }
 
-        // ---- epilogue (as nf_flow_kernel) ----
-        if (a.out) {
-            float4 *out4 = reinterpret_cast<float4 *>(a.out + patch_off);
-#pragma unroll
-            for (int m = 0; m < OWN; ++m)
-                if (own_of(m)) out4[gi_of(m)] = make_float4(z[m][0], z[m][1], z[m][2], z[m][3]);
-        }
-        if (a.nll_out || a.sd_out || a.ld_out || a.sums || (tiled && a.tile_part)) {
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int m = 0; m < OWN; ++m)
-                if (own_of(m)) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        s1 += z[m][q];
-                        s2 = fmaf(z[m][q], z[m][q], s2);
-                    }
-                }
-            float r0 = wave_sum(fmaf(ld2, 0.6931471805599453f, ld)), r1 = wave_sum(s1), r2 = wave_sum(s2);
-            if (lane == 0) {
-                red[wv] = r0;
-                red[GW + wv] = r1;
-                red[2 * GW + wv] = r2;
-            }
-            __syncthreads();
-            if (t == 0) {
-                r0 = 0.f; r1 = 0.f; r2 = 0.f;
-#pragma unroll
-                for (int i = 0; i < GW; ++i) {
-                    r0 += red[i];
-                    r1 += red[GW + i];
-                    r2 += red[2 * GW + i];
-                }
-            }
-            if (t == 0 && tiled) {
-                // the tile's share of its image's sums (nf_tile_combine_kernel forms nll / sd / log-det per image)
-                *reinterpret_cast<float4 *>(a.tile_part + (size_t)b * 4u) = make_float4(r0, r1, r2, 0.f);
-            } else if (t == 0) {
-                const double npx = (double)HW * 4.0;
-                const double logdet = (double)r0 + a.ld_const;
-                double nll = -logdet;   // prior: sum -0.5*(log 2pi + z^2)   (noise_flow_model.py:537-539)
-                if (a.flags & NF_K_PRIOR) nll += 0.5 * npx * 1.8378770664093453 + 0.5 * (double)r2;
-                const double mean = (double)r1 / npx;
-                double var = (double)r2 / npx - mean * mean;   // noise_flow_model.py:477-478
-                var = var > 0.0 ? var : 0.0;
-                const double sd = sqrt(var);
-                if (a.nll_out) a.nll_out[b] = (float)nll;
-                if (a.sd_out) a.sd_out[b] = (float)sd;
-                if (a.ld_out) a.ld_out[b] = (float)logdet;
-                acc_nll += (double)(float)nll;
-                acc_sd += (double)(float)sd;
-            }
-            __syncthreads();   // scratch is reused by the next patch
-        }
+        gemm_epilogue<OWN, GT>(a, T, b, HW, pr, pc, act, z, ld, ld2, red, acc_nll, acc_sd);
     }
-
-    if (a.sums && t == 0 && !(a.flags & NF_K_TILED)) {
-        double *sp = a.sums;
-        if (a.flags & NF_K_SUMS_WIDE) sp += (size_t)(blockIdx.x & (NF_SUMS_SLOTS - 1)) * NF_SUMS_STRIDE;
-        atomicAdd(&sp[0], acc_nll);
-        atomicAdd(&sp[1], acc_sd);
-        if (blockIdx.x == 0) atomicAdd(&sp[2], (double)a.B);
-    }
+    gemm_flush_sums(a, acc_nll, acc_sd);
 }
 
 
@@ -503,52 +343,9 @@ __global__ __launch_bounds__(GT) void nf_gemm16b_kernel(const NfProgram prog, co
     double acc_nll = 0.0, acc_sd = 0.0;   // thread 0 only
 
     for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
-        // Where this "patch" sits: on its own ([B,H,W,4] tensors), or — NF_K_TILED (nf_device.h, "overlapping tiles") — as tile
-        // b % tiles of image b / tiles: pixel (r, c) of the tile is pixel (oy + r, ox + c) of an IH x IW image, border masks
-        // follow the image border, and results are reported for the core window [cy0, cy1) x [cx0, cx1) only.
-        size_t patch_off = (size_t)b * (size_t)HW * 4u;
-        int64_t patch_id = b;
-        int oy = 0, ox = 0, IH = H, IW = W, cy0 = 0, cy1 = H, cx0 = 0, cx1 = W;
-        const bool tiled = (a.flags & NF_K_TILED) != 0;
-        if (tiled) {
-            const int nt = a.tile_ny * a.tile_nx;
-            const int64_t img = b / nt;
-            const int ti = (int)(b - img * nt);
-            const int ty = ti / a.tile_nx, tx = ti - ty * a.tile_nx;
-            IH = a.img_H;
-            IW = a.img_W;
-            oy = nf_tile_origin(ty, IH, H, a.tile_halo);
-            ox = nf_tile_origin(tx, IW, W, a.tile_halo);
-            cy0 = nf_tile_core0(ty, IH, H, a.tile_halo);
-            cy1 = nf_tile_core1(ty, a.tile_ny, IH, H, a.tile_halo);
-            cx0 = nf_tile_core0(tx, IW, W, a.tile_halo);
-            cx1 = nf_tile_core1(tx, a.tile_nx, IW, W, a.tile_halo);
-            patch_off = (size_t)img * (size_t)IH * (size_t)IW * 4u;
-            patch_id = img;
-        }
-        auto gi_of = [&](int m) { return act[m] ? (oy + pr[m]) * IW + ox + pc[m] : 0; };        // pixel index in the tensors
-        auto own_of = [&](int m) {                                                             // this launch reports the pixel
-            const int R = oy + pr[m], C = ox + pc[m];
-            return act[m] && R >= cy0 && R < cy1 && C >= cx0 && C < cx1;
-        };
-
+        const GemmTile T = gemm_tile(a, b, H, W);
         float z[OWN][4];
-#pragma unroll
-        for (int m = 0; m < OWN; ++m) {
-            const int gi = gi_of(m);
-            if (PHILOX) {
-                philox_normal4(a.seed, a.patch_base + patch_id, (uint32_t)gi, NF_STREAM_SAMP, z[m]);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) z[m][q] *= a.in_scale;
-            } else {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (act[m]) v = reinterpret_cast<const float4 *>(a.in + patch_off)[gi];
-                z[m][0] = v.x * a.in_scale;
-                z[m][1] = v.y * a.in_scale;
-                z[m][2] = v.z * a.in_scale;
-                z[m][3] = v.w * a.in_scale;
-            }
-        }
+        gemm_input<OWN, PHILOX>(a, T, pr, pc, act, z);
 
         float ld = 0.0f, ld2 = 0.0f;   // natural-log / log2 parts of this thread's log-det share
 
@@ -557,23 +354,7 @@ __global__ __launch_bounds__(GT) void nf_gemm16b_kernel(const NfProgram prog, co
             const cfloat_p P = (cfloat_p)(a.params + prog.ops[op].off);   // wave-uniform, scalar loads
 
             if (type == NF_OP_MIX) {
-                float mm[16];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) mm[i] = P[i];
-#pragma unroll
-                for (int m = 0; m < OWN; ++m) {
-                    float o[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float s = z[m][0] * mm[j];
-                        s = fmaf(z[m][1], mm[4 + j], s);
-                        s = fmaf(z[m][2], mm[8 + j], s);
-                        s = fmaf(z[m][3], mm[12 + j], s);
-                        o[j] = s;
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) z[m][j] = o[j];
-                }
+                gemm_mix<OWN>(P, z);
             } else if (type == NF_OP_COUPLING_FWD || type == NF_OP_COUPLING_REV) {
                 const float *const img = a.params + prog.ops[op].off + NF8_CPL_IMG;
                 const float *const slabs = img + nf9_img_SLAB(WP);
@@ -713,118 +494,17 @@ __global__ __launch_bounds__(GT) void nf_gemm16b_kernel(const NfProgram prog, co
                 }
 
                 // ---- finish the coupling on the owned pixels ----
-                const float scl = P[NF8_CPL_S + 1], m2scl = P[NF8_CPL_S + 2];
-#pragma unroll
-                for (int m = 0; m < OWN; ++m) {
-                    const int r = pr[m], c = pc[m];
-                    const int bm = (oy + r == 0 ? 1 : 0) | (oy + r == IH - 1 ? 2 : 0) | (ox + c == 0 ? 4 : 0) | (ox + c == IW - 1 ? 8 : 0);
-                    const float4 eb = *reinterpret_cast<const float4 *>(a.params + prog.ops[op].off + NF8_CPL_E + 4 * (act[m] ? bm : 0));
-                    o[m][0] += eb.x; o[m][1] += eb.y;
-                    o[m][2] = fmaf(o[m][2], 2.8853900817779268f, eb.z);
-                    o[m][3] = fmaf(o[m][3], 2.8853900817779268f, eb.w);
-                    const float l0 = fmaf(__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(o[m][2]) + 1.0f), m2scl, scl);
-                    const float l1 = fmaf(__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(o[m][3]) + 1.0f), m2scl, scl);
-                    if (type == NF_OP_COUPLING_FWD) {
-                        z[m][2] = fmaf(z[m][2], __builtin_amdgcn_exp2f(l0), o[m][0]);
-                        z[m][3] = fmaf(z[m][3], __builtin_amdgcn_exp2f(l1), o[m][1]);
-                        if (own_of(m)) ld2 += l0 + l1;
-                    } else {
-                        z[m][2] = (z[m][2] - o[m][0]) * __builtin_amdgcn_exp2f(-l0);
-                        z[m][3] = (z[m][3] - o[m][1]) * __builtin_amdgcn_exp2f(-l1);
-                    }
-                }
+                gemm_finish_coupling<OWN, true>(type, a.params + prog.ops[op].off + NF8_CPL_E, P[NF8_CPL_S + 1], P[NF8_CPL_S + 2], T, pr, pc, act, o, z, ld2);
             } else if (type == NF_OP_SDN_DIV || type == NF_OP_SDN_MUL) {
-                // AffineCouplingSdnEx5: scale = sqrt(beta1*y/gain + beta2)  (cond_utils.py:238)
-                const float4 *y4 = reinterpret_cast<const float4 *>(a.y + patch_off);
-                const float ck1 = a.cond_a[prog.ops[op].off & 3], cb2 = a.cond_b[prog.ops[op].off & 3];
-#pragma unroll
-                for (int m = 0; m < OWN; ++m) {
-                    float4 yv = make_float4(1.f, 1.f, 1.f, 1.f);
-                    if (act[m]) yv = y4[gi_of(m)];
-                    const float yy[4] = {yv.x, yv.y, yv.z, yv.w};
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float v = fmaf(yy[q], ck1, cb2);
-                        if (type == NF_OP_SDN_DIV) {
-                            z[m][q] = z[m][q] * __builtin_amdgcn_rsqf(v);
-                            if (own_of(m)) ld = fmaf(-0.34657359027997264f, __builtin_amdgcn_logf(v), ld);
-                        } else {
-                            z[m][q] = z[m][q] * __builtin_amdgcn_sqrtf(v);
-                        }
-                    }
-                }
+                gemm_sdn<OWN>(type, prog.ops[op].off, a, T, pr, pc, act, z, ld);
             } else if (type == NF_OP_SCALE || type == NF_OP_SCALE_COND) {
-                const float s = type == NF_OP_SCALE ? P[0] : a.cond_a[prog.ops[op].off & 3];
-#pragma unroll
-                for (int m = 0; m < OWN; ++m)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) z[m][q] *= s;
+                gemm_scale<OWN>(type == NF_OP_SCALE ? P[0] : a.cond_a[prog.ops[op].off & 3], z);
             }
         }
 
-        // ---- epilogue (as nf_flow_kernel) ----
-        if (a.out) {
-            float4 *out4 = reinterpret_cast<float4 *>(a.out + patch_off);
-#pragma unroll
-            for (int m = 0; m < OWN; ++m)
-                if (own_of(m)) out4[gi_of(m)] = make_float4(z[m][0], z[m][1], z[m][2], z[m][3]);
-        }
-        if (a.nll_out || a.sd_out || a.ld_out || a.sums || (tiled && a.tile_part)) {
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int m = 0; m < OWN; ++m)
-                if (own_of(m)) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        s1 += z[m][q];
-                        s2 = fmaf(z[m][q], z[m][q], s2);
-                    }
-                }
-            float r0 = wave_sum(fmaf(ld2, 0.6931471805599453f, ld)), r1 = wave_sum(s1), r2 = wave_sum(s2);
-            if (lane == 0) {
-                red[wv] = r0;
-                red[GW + wv] = r1;
-                red[2 * GW + wv] = r2;
-            }
-            __syncthreads();
-            if (t == 0) {
-                r0 = 0.f; r1 = 0.f; r2 = 0.f;
-#pragma unroll
-                for (int i = 0; i < GW; ++i) {
-                    r0 += red[i];
-                    r1 += red[GW + i];
-                    r2 += red[2 * GW + i];
-                }
-            }
-            if (t == 0 && tiled) {
-                // the tile's share of its image's sums (nf_tile_combine_kernel forms nll / sd / log-det per image)
-                *reinterpret_cast<float4 *>(a.tile_part + (size_t)b * 4u) = make_float4(r0, r1, r2, 0.f);
-            } else if (t == 0) {
-                const double npx = (double)HW * 4.0;
-                const double logdet = (double)r0 + a.ld_const;
-                double nll = -logdet;   // prior: sum -0.5*(log 2pi + z^2)   (noise_flow_model.py:537-539)
-                if (a.flags & NF_K_PRIOR) nll += 0.5 * npx * 1.8378770664093453 + 0.5 * (double)r2;
-                const double mean = (double)r1 / npx;
-                double var = (double)r2 / npx - mean * mean;   // noise_flow_model.py:477-478
-                var = var > 0.0 ? var : 0.0;
-                const double sd = sqrt(var);
-                if (a.nll_out) a.nll_out[b] = (float)nll;
-                if (a.sd_out) a.sd_out[b] = (float)sd;
-                if (a.ld_out) a.ld_out[b] = (float)logdet;
-                acc_nll += (double)(float)nll;
-                acc_sd += (double)(float)sd;
-            }
-            __syncthreads();   // scratch is reused by the next patch
-        }
+        gemm_epilogue<OWN, GT>(a, T, b, HW, pr, pc, act, z, ld, ld2, red, acc_nll, acc_sd);
     }
-
-    if (a.sums && t == 0 && !(a.flags & NF_K_TILED)) {
-        double *sp = a.sums;
-        if (a.flags & NF_K_SUMS_WIDE) sp += (size_t)(blockIdx.x & (NF_SUMS_SLOTS - 1)) * NF_SUMS_STRIDE;
-        atomicAdd(&sp[0], acc_nll);
-        atomicAdd(&sp[1], acc_sd);
-        if (blockIdx.x == 0) atomicAdd(&sp[2], (double)a.B);
-    }
+    gemm_flush_sums(a, acc_nll, acc_sd);
 }
 
 size_t gemm16b_lds_bytes(int wp, int H, int W)
