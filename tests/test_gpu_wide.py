@@ -182,7 +182,7 @@ def test_coupling_widths_between_the_kernel_widths(width, hw, dt):
     """layers.py:452-498 takes any width; the kernels exist for 4 / 8 / 16 / 32 (and 33 .. 512): a width in between runs on the
     next one up with the extra hidden channels zero-padded at nf_create (exact: relu(0) = 0 in both hidden layers).  Every
     kernel family the padding lands on, fp32 and the fp16-CNN mode, whole patches and a tiled image; the batch-statistics mode
-    (its moments are per variable channel) and the trainer say that they do not take such widths."""
+    pads the same way (tests/test_gpu_batchstats.py), the trainer runs such widths on its library-GEMM path (tests/test_gpu_train.py)."""
     from noise_flow_amd import NoiseFlow, default_hps
     from oracle.nf_oracle import NoiseFlowOracle
     H, W = hw
@@ -199,8 +199,7 @@ def test_coupling_widths_between_the_kernel_widths(width, hw, dt):
     eps = np.random.RandomState(4).randn(3, H, W, 4).astype(np.float32)
     xs = m.sample(y, 0.8, y, [0.0], [0.0], [100], [2], eps=eps)
     _close_elem(xs, o.sample(eps, 0.8, y, 100, 2), rtol=et)
-    if dt == "fp32" and max(H, W) <= 64:
-        mt = NoiseFlow([H, W, 4], True, default_hps(arch=ARCH, width=width), variables=v)
-        with pytest.raises(Exception) as ei:
-            mt._loss(x, y, [0.0], [0.0], [100], [2])
-        assert "width" in str(ei.value)
+    if dt == "fp32" and H * W <= 1024:      # batch-statistics mode pads the same way (its statistics passes at the padded width
+        mt = NoiseFlow([H, W, 4], True, default_hps(arch=ARCH, width=width), variables=v)      # 32 hold up to 1024 pixels)
+        nll_t, _ = mt._loss(x, y, [0.0], [0.0], [100], [2])
+        np.testing.assert_allclose(nll_t, o.nll(x, y, 100, 2, training=True)[0], rtol=NLL_RTOL, atol=1e-4)
