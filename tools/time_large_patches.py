@@ -3,6 +3,9 @@ tiles, csrc/nf_device.h).  python tools/time_large_patches.py H W B [iters] [wid
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from noise_flow_amd import _lib as _nf_lib
+if os.environ.get("NF_TOOL_LIB"):   # A/B a differently-built library (this tool only)
+    _nf_lib.LIB_PATH = os.path.abspath(os.environ["NF_TOOL_LIB"])
 from noise_flow_amd import NoiseFlow, default_hps, params as _params
 from noise_flow_amd.patches import synth_patches
 H, W, B = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
