@@ -401,9 +401,17 @@ def sharded_leg(ctx):
         if traffic is not None:                        # PMC bytes of a 1024-patch launch of the same kernel, per patch x patches per launch
             out["roofline"]["traffic"] = traffic / 1024.0 * (spec["total"] / world)
             out["roofline"]["traffic_source"] = traffic_src + ", scaled from the measured 1024-patch launch to this launch's patch count"
+    def fp16_traffic(rec, sp):     # the 64x64 fp16 kernel's PMC bytes, measured on a 1024-patch launch, per patch x patches of this launch
+        tr, src = _traffic("fp16_cnn_64x64")
+        if tr is not None:
+            rec["roofline"]["traffic"] = tr / 1024.0 * (sp["total"] / world)
+            rec["roofline"]["traffic_source"] = src + ", scaled from the measured 1024-patch launch to this launch's patch count"
+    if head != "c4":
+        fp16_traffic(out, spec)
     if isinstance(nested, tuple):
         sec = _sharded_record(nested[0], nested[1], world, nested[2], min(Wm, 2), dist.get_backend())
         sec["roofline"]["hbm"]["achievable_frac"] = sec["roofline"]["hbm"]["achieved"] / 6290.0     # guide: 6.29 TB/s achievable
+        fp16_traffic(sec, nested[0])
         out["fp16_cnn_64x64_sharded"] = sec
     elif nested is not None:
         out["fp16_cnn_64x64_sharded"] = {"error": "%s: %s" % (type(nested).__name__, nested)}
