@@ -267,7 +267,9 @@ int nf_sample_host(nf_handle *h, const void *y, int32_t y_dtype, const float *ep
  * SYNCHRONISE `stream`, use a per-handle scratch (allocated on first use; concurrent calls on one
  * handle serialise) and are fp32 only.  B must be >= 1.  At coupling widths other than 4 the statistics
  * passes run on the scalar-weight kernel, whose two LDS tiles bound the patch: up to 1024 pixels at
- * width 32, ~2270 at width 16 (e.g. 45x48), ~4090 at width 8 (e.g. 62x62); larger -> NF_EINVAL. */
+ * width 32, ~2270 at width 16 (e.g. 45x48), ~4090 at width 8 (e.g. 62x62); larger -> NF_EINVAL.  Coupling widths 1 .. 32 (a
+ * width between two kernel widths runs zero-padded on the next one and has that one's limit; moments_out rows keep the model's
+ * own w channels); widths beyond 32 -> NF_EINVAL (nf_trainer_forward evaluates a minibatch's loss under batch statistics there). */
 int nf_nll_batchstats(nf_handle *h, const float *x, const float *y, int64_t B, const nf_cond *cond,
                       float *nll_out, float *sd_out, float *logdet_out, float *z_out,
                       double *sums_out, uint32_t flags, float *moments_out, void *stream);
