@@ -634,6 +634,43 @@ def test_training_golden_fixture(shipped_variables):
             assert np.abs(got[solid] - want[solid]).max() <= 0.02 * lr + 1e-6 * np.abs(want[solid]).max(), k
 
 
+def test_wide_training_golden_fixture():
+    """tests/golden/train_step_width48.npz (tools/make_golden_train.py wide, from the fp64 autograd oracle; the model is part of
+    the fixture): loss, sd_z, every gradient tensor (2e-4 of its scale or the fixture's round-off allowance of the entry) and the
+    BN EMA of a step at width 48 — the trainer's library-GEMM path (csrc/nf_train_gemm.h)."""
+    from conftest import ROOT, GRAD_NOISE_C
+    from oracle.nf_grad_oracle import is_trainable
+    from noise_flow_amd import params as P
+    g = np.load(os.path.join(ROOT, "tests", "golden", "train_step_width48.npz"))
+    arch, width = str(g["arch"]), int(g["width"])
+    v = {k[4:]: g[k] for k in g.files if k.startswith("var/")}
+    x, y = g["x"], g["y"]
+    tr = _trainer(arch, v, (x.shape[1], x.shape[2], 4), width)
+    grads, loss = tr.forward_backward(x, y, [0.0], [0.0], [float(g["iso"])], [float(g["cam"])])
+    lv = loss.cpu().numpy()
+    assert abs(lv[0] - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    assert abs(lv[1] - float(g["sd_z"])) <= 1e-5 * float(g["sd_z"])
+    got = tr.raw_to_variables(grads.cpu().numpy())
+    names = [nm for L in tr.layers for nm in P.layer_variable_names(L, tr._tmpl) if nm is not None and is_trainable(nm)]
+    gmax = max(np.abs(g["grad/" + nm]).max() for nm in names)
+    n = 0
+    for nm in names:
+        ref = np.asarray(g["grad/" + nm], np.float64)
+        allow = GRAD_NOISE_C * 2.0 ** -24 * np.asarray(g["abs/" + nm], np.float64).reshape(ref.shape)
+        a = np.asarray(got[nm], np.float64).reshape(ref.shape)
+        if nm.endswith("l_1/b") or nm.endswith("l_2/b"):
+            assert (np.abs(a) <= np.maximum(1e-5 * gmax, allow)).all(), nm
+        else:
+            assert (np.abs(a - ref) <= np.maximum(GRAD_RTOL * max(np.abs(ref).max(), 1e-6 * gmax), allow)).all(), (nm, np.abs(a - ref).max())
+        n += ref.size
+    assert n > 10000
+    after = tr.variables
+    for k in g.files:
+        if k.startswith("bn/"):
+            want = g[k]
+            assert np.abs(np.asarray(after[k[3:]]).reshape(want.shape) - want).max() <= 1e-5 * max(np.abs(want).max(), 1e-3), k
+
+
 def test_variables_shared_between_layers_receive_the_summed_gradient():
     """The reference creates the sdn / gain parameters under an AUTO_REUSE scope: arch ``gain4|unc|gain4`` has ONE gain_val
     and ``sdn4|unc|sdn4`` one beta1 / beta2 / gain_params.  The raw layout holds a slot per layer; the trainer sums the

@@ -110,6 +110,27 @@ def test_training_golden_fixture_matches_the_oracle(shipped_variables):
         np.testing.assert_allclose(np.asarray(after[k], np.float32), g["adam/" + k], rtol=1e-6, atol=1e-9)
 
 
+def test_wide_training_golden_fixture_matches_the_oracle():
+    """tests/golden/train_step_width48.npz (tools/make_golden_train.py wide): a step at a coupling width the trainer runs on its
+    library-GEMM path; the model is part of the fixture."""
+    import os
+    from conftest import ROOT
+    from oracle.nf_grad_oracle import GradOracle
+    g = np.load(os.path.join(ROOT, "tests", "golden", "train_step_width48.npz"))
+    v = {k[4:]: g[k] for k in g.files if k.startswith("var/")}
+    o = GradOracle(str(g["arch"]), v)
+    loss, sd_z, grads, new_running = o.loss_and_grads(g["x"], g["y"], int(g["iso"]), int(g["cam"]))
+    assert not o.kinks
+    assert abs(loss - float(g["loss"])) <= 1e-10 * abs(loss) and abs(sd_z - float(g["sd_z"])) <= 1e-10 * sd_z
+    gmax = max(float(np.abs(g["grad/" + k]).max()) for k in grads)
+    for k, a in grads.items():
+        ref = g["grad/" + k]
+        assert np.abs(np.asarray(a, np.float32) - ref).max() <= 1e-6 * max(np.abs(ref).max(), 1e-6 * gmax), k
+        np.testing.assert_allclose(np.asarray(o.grad_abs_terms[k], np.float32), g["abs/" + k], rtol=1e-5, atol=1e-12)
+    for k, a in new_running.items():
+        assert np.abs(np.asarray(a, np.float32) - g["bn/" + k]).max() <= 1e-6 * max(np.abs(g["bn/" + k]).max(), 1e-6), k
+
+
 def test_autograd_oracle_covers_the_whole_vocabulary_and_every_permutation_setting():
     """The rest of ``noise_flow_arch``'s layer keys and the other ``hps.flow_permutation`` / ``hps.decomp`` settings in the
     autograd oracle: the forward value equals the numpy forward oracle's (training-mode BN) and a sample of gradient entries
