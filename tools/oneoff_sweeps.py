@@ -64,8 +64,9 @@ def wide_fp16(seed):
     assert np.abs(np.asarray(xs, np.float64) - rx).max() <= 2e-3 * np.abs(rx).max(), "sample vs emulation w=%d" % width
 
 
-run("eval", lambda s: S._check_case(s, S._draw_case(s)), range(20000, 20000 + n_eval))
-run("fp16", S.test_random_model_fp16_cnn_mode, range(21000, 21000 + n_fp16))
-run("batchstats", S.test_random_model_batch_statistics, range(22000, 22000 + n_bs))
-run("wide_fp16", wide_fp16, range(23000, 23000 + n_wf))
+OFF = int(os.environ.get("NF_SWEEP_OFFSET", "0"))      # fresh seeds per round: round 3 ran offset 0, round 4 offset 4000
+run("eval", lambda s: S._check_case(s, S._draw_case(s)), range(20000 + OFF, 20000 + OFF + n_eval))
+run("fp16", S.test_random_model_fp16_cnn_mode, range(21000 + OFF, 21000 + OFF + n_fp16))
+run("batchstats", S.test_random_model_batch_statistics, range(22000 + OFF, 22000 + OFF + n_bs))
+run("wide_fp16", wide_fp16, range(23000 + OFF, 23000 + OFF + n_wf))
 print("done, failures:", bad, flush=True)
