@@ -313,6 +313,7 @@ int nf_set_sync(nf_handle *h, nf_allreduce_fn fn, void *user, double *sync_buf, 
  *                       11 affine / tanh backward inside the transposed l_last kernel.  Default 4095.
  *   NF_TRAIN_BAND       pixels (rows x patch width, halo included; 96..320, default 320) a band kernel keeps in LDS.
  *   NF_TRAIN_GEMM=1     widths 4/8/16/32 on the library-GEMM path of the other widths as well.
+ *   NF_TRAIN_GEMM_C1=0  library-GEMM path: l_1 forward as sgemm + statistics pass instead of the fused kernel.
  *   NF_TRAIN_SERIAL=1   no side stream: every kernel on the caller's stream (kernel traces without overlap). */
 typedef struct nf_trainer nf_trainer;
 #define NF_OPT_ADAM     0

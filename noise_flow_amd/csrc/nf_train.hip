@@ -1528,6 +1528,7 @@ struct nf_trainer {
     float *gz18 = nullptr, *gp36 = nullptr, *gq18 = nullptr, *gw3r = nullptr;   // [pixels][18] windows, [pixels][36] taps, [pixels][18], [w][36]
     float *gdw = nullptr;           // filter gradients of every coupling as the split GEMMs leave them: 3 per coupling x gemm_part_floats(w)
     int gnp[3 * kMaxLayers] = {};   // how many partial products each of them holds (this step)
+    bool gemm_c1_fused = true;      // NF_TRAIN_GEMM_C1=0: l_1 forward as library GEMM + statistics pass (A/B aid)
 };
 
 namespace {
@@ -2127,6 +2128,7 @@ int nf_trainer_create(const nf_config *cfg, const nf_layer_desc *layers, const f
             return nf_fail(NF_EHIP, "rocblas_create_handle failed");
         }
         t->blas = bh;
+        if (const char *ev = getenv("NF_TRAIN_GEMM_C1")) t->gemm_c1_fused = atoi(ev) != 0;
         // no atomically accumulated split-K products: a step's gradients are the same bits on every run, as at the other widths
         if (rocblas_api()->set_atomics) (void)rocblas_api()->set_atomics(bh, rocblas_atomics_not_allowed);
     }

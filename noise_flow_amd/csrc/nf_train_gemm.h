@@ -208,6 +208,48 @@ __global__ __launch_bounds__(256) void k_g_bias_stats(Geo g, int w, const float 
     flat_store(s, red, f, w, stats);
     flat_store(q, red, f, w, stats + w);
 }
+// l_1 itself where the width allows the flat walk (a multiple of 4): h1 = Z18 . W1 has K = 18 — less arithmetic than the write
+// of its own result — so the library GEMM, its read-back for the statistics and their launches collapse into ONE pass: every
+// thread keeps the 18 x 4 filter entries of its four channels in registers, reads a pixel's 18 gathered inputs (the lanes that
+// share a pixel share the cache line), writes its float4 of h1 (without the bias, as everywhere here) and accumulates the batch
+// sums of h1 + bias.
+__global__ __launch_bounds__(256) void k_g_c1_fwd(Geo g, int w, const float *__restrict__ Z18, const float *__restrict__ W1,
+                                                  const float *__restrict__ bias, float *__restrict__ h, Acc stats)
+{
+    __shared__ float red[256 * 4];
+    const FlatWalk f = flat_walk(g.npix, w);
+    const int t = threadIdx.x, cg = t % f.Q;
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+    if (t < f.TBq) {
+        float wk[18][4], b4[4];
+#pragma unroll
+        for (int k = 0; k < 18; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wk[k][j] = W1[k * w + 4 * cg + j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b4[j] = bias[4 * cg + j];
+        for (int64_t e = (int64_t)blockIdx.x * f.TBq + t; e < f.total; e += f.stride) {
+            const int64_t p = e / f.Q;
+            const float2 *zr = reinterpret_cast<const float2 *>(Z18 + p * 18);   // rows of 72 bytes: 8-byte aligned
+            float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k2 = 0; k2 < 9; ++k2) {
+                const float2 zv = zr[k2];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a[j] = fmaf(zv.y, wk[2 * k2 + 1][j], fmaf(zv.x, wk[2 * k2][j], a[j]));
+            }
+            reinterpret_cast<float4 *>(h)[e] = make_float4(a[0], a[1], a[2], a[3]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v = a[j] + b4[j];
+                s[j] += v;
+                q[j] = fmaf(v, v, q[j]);
+            }
+        }
+    }
+    flat_store(s, red, f, w, stats);
+    flat_store(q, red, f, w, stats + w);
+}
 __global__ __launch_bounds__(256) void k_g_bias_stats_slow(Geo g, int w, const float *__restrict__ h, const float *__restrict__ bias, Acc stats)
 {
     const int64_t per = (g.npix + gridDim.x - 1) / gridDim.x, p0 = per * blockIdx.x, p1 = p0 + per < g.npix ? p0 + per : g.npix;
@@ -581,9 +623,14 @@ bool coupling_forward_gemm(nf_trainer *t, const Geo &g, const TLayer &L, const f
     };
     if (zpre) hipLaunchKernelGGL(k_mix_fwd, dim3(nb), dim3(TB), 0, st, g, zpre, A, const_cast<float *>(zin));
     hipLaunchKernelGGL(k_g_gather18, dim3(nb), dim3(TB), 0, st, g, zin, t->gz18);
-    bool ok = gemm_rm(t, st, false, false, g.npix, w, 18, t->gz18, 18, P + off_w1, w, c.h1, w);
-    if (V == 4) hipLaunchKernelGGL(k_g_bias_stats, dim3(ns), dim3(256), 0, st, g, w, (const float *)c.h1, P + off_b1, t->acc(c.d_st1));
-    else hipLaunchKernelGGL(k_g_bias_stats_slow, dim3(ns), dim3(256), 0, st, g, w, (const float *)c.h1, P + off_b1, t->acc(c.d_st1));
+    bool ok = true;
+    if (V == 4 && t->gemm_c1_fused) {
+        hipLaunchKernelGGL(k_g_c1_fwd, dim3(ns), dim3(256), 0, st, g, w, (const float *)t->gz18, P + off_w1, P + off_b1, c.h1, t->acc(c.d_st1));
+    } else {
+        ok = gemm_rm(t, st, false, false, g.npix, w, 18, t->gz18, 18, P + off_w1, w, c.h1, w);
+        if (V == 4) hipLaunchKernelGGL(k_g_bias_stats, dim3(ns), dim3(256), 0, st, g, w, (const float *)c.h1, P + off_b1, t->acc(c.d_st1));
+        else hipLaunchKernelGGL(k_g_bias_stats_slow, dim3(ns), dim3(256), 0, st, g, w, (const float *)c.h1, P + off_b1, t->acc(c.d_st1));
+    }
     sync_slots(t, t->acc(c.d_st1), 2 * w, g.nslot, st);
     hipLaunchKernelGGL(k_bn_fin, dim3(w), dim3(64), 0, st, t->acc(c.d_st1), w, g.nslot, n, t->d_params, off_m1, off_m1 + w, t->d_flt + c.f_bn1);
     bn_relu(c.h1, P + off_b1, t->d_flt + c.f_bn1, c.a1);
