@@ -57,6 +57,16 @@ __device__ __forceinline__ float quad_sums(float x0, float x1, float x2, float x
 #ifndef NF_W16_RELOAD
 #define NF_W16_RELOAD 0
 #endif
+#ifndef NF_W16_PLANE_PAD
+#define NF_W16_PLANE_PAD 1
+#endif
+__host__ __device__ inline int nf_w16_plane(int px)
+{
+    int pl = (px + 3) & ~3;
+    if (NF_W16_PLANE_PAD) pl += (16 - (pl & 31)) & 31;     // pl = 16 (mod 32)
+    return pl;
+}
+
 template <int THREADS, int TPW, bool PHILOX>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS == 512 ? NF_W16_WPE : 1))) void nf_wide16_kernel(const NfProgram prog, const NfLaunch a)
 {
@@ -65,7 +75,10 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS
     constexpr int OWN = TPW / 4;
     const int H = a.H, W = a.W, HW = H * W;
     const int Wp = W + 2;
-    const int PL = ((H + 2) * Wp + 3) & ~3;             // one channel plane of the z0 tile
+    // one channel plane of the z0 tile.  Lane groups 0 / 1 (and 2 / 3) of an l_1 operand read the SAME tap in the two planes, 16
+    // consecutive words each, in one 32-lane pass of ds_read_b32: the planes sit 16 banks (mod 32) apart so that the two groups
+    // do not meet (NF_W16_PLANE_PAD=0: the planes back to back — 2-way conflicts on 12 of 16 banks at 32x32)
+    const int PL = nf_w16_plane((H + 2) * Wp);
     const int TC = (W + 15) >> 4;                        // 16-pixel column blocks per image row
     float *const z0s = smem;                             // [2][PL]
     float *const wbuf = z0s + 2 * PL;                    // [NF6_IMG_SIZE] weights of the current coupling
@@ -376,7 +389,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS
 
 size_t wide16_lds_bytes(int H, int W, int threads)
 {
-    const int Wp = W + 2, PL = ((H + 2) * Wp + 3) & ~3, NW = threads / 64, TC = (W + 15) >> 4;
+    const int Wp = W + 2, PL = nf_w16_plane((H + 2) * Wp), NW = threads / 64, TC = (W + 15) >> 4;
     size_t f = 2 * (size_t)PL + NF6_IMG_SIZE + (size_t)NW * 256 + 2 * (size_t)(H + 2) * TC * 12 + ((3 * NW + 3) & ~3);
     return f * sizeof(float);
 }
