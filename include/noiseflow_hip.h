@@ -113,8 +113,8 @@ typedef struct nf_layer_desc {
  * leaves --patch_height free (sidd/ArgParser.py:72-73) — nf_nll / nf_sample and their host-fed variants evaluate the image
  * as overlapping 64-pixel tiles: a coupling reads a 5x5 neighbourhood, so a tile is exact 2 x (number of couplings) pixels
  * inside every tile border that is not an image border, and only that core is reported (nf_tile_plan, nf_tile_segments
- * below).  Every coupling width, fp32 or NF_CFG_FP16_CNN (width 4 in fp32 on the fused width-4 kernels, the other widths up to
- * 32 on the width-32 matrix-core kernel, zero-padded, widths 33 .. 512 on the GEMM kernels); nf_*_batchstats beyond 64x64: coupling width 4 (every launch of its
+ * below).  Every coupling width, fp32 or NF_CFG_FP16_CNN (width 4 in fp32 on the fused width-4 kernels, width 16 in fp32 on its
+ * own, the other widths up to 32 on the width-32 matrix-core kernel, zero-padded, widths 33 .. 512 on the GEMM kernels); nf_*_batchstats beyond 64x64: coupling width 4 (every launch of its
  * schedule tiled with a halo of 3, statistics over the core windows). */
 #define NF_MAX_IMAGE_SIDE 4096
 

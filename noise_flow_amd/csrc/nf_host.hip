@@ -1119,8 +1119,9 @@ int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float
         const size_t tile_px = ((size_t)(th + 2) * (tw + 2) + 1) & ~(size_t)1;
         const bool scalar_fits = sizeof(float) * (tile_px * (2 + (size_t)out.prog.width) + 64) <= 160 * 1024;
         if (out.prog.width == 32 || (out.prog.width == 8 && !scalar_fits)) out.prog4.width = 32;
-        // tiled images (nf_device.h): widths 8 / 16 run zero-padded on the width-32 kernel, the wide family with a tiled mode
-        if (out.tiled && (out.prog.width == 8 || out.prog.width == 16)) out.prog4.width = 32;
+        // tiled images (nf_device.h): width 8 runs zero-padded on the width-32 kernel; width 16 on its own (fp32; its fp16-CNN
+        // mode is the width-32 fp16 kernel's, tiled or not)
+        if (out.tiled && out.prog.width == 8) out.prog4.width = 32;
     }
     if (out.prog4.width == 32) {
         for (int i = 0; i < out.prog.n_ops; ++i) {
@@ -1774,10 +1775,12 @@ static int launch_tiled(nf_handle *h, int direction, NfLaunch &a, hipStream_t st
     float *d7 = direction == 0 ? h->d_fwd7 : h->d_rev7;   // widths 33 .. 512: the GEMM kernels take tiles as they take patches
     float *d8 = direction == 0 ? h->d_fwd8 : h->d_rev8;
     const int gemm = d8 ? 2 : d7 ? 1 : 0;
+    float *d6 = direction == 0 ? h->d_fwd6 : h->d_rev6;   // width 16 in fp32: nf_wide16.hip takes tiles as well
+    const bool w16 = !gemm && !d5 && d6 && b.prog.width == 16 && (use_matrix_core() || !h->scalar_ok);
     const bool hb = !gemm && d3 && b.fp16_big && !d5;   // width 4, fp16 CNN, full 64x64 tiles: the fused kernel on v_mfma_f32_16x16x32_f16
-    const int wide = (hb || gemm) ? 0 : d5 ? 2 : (d4 && b.prog.width > 4) ? 1 : 0;
+    const int wide = (hb || gemm || w16) ? 0 : d5 ? 2 : (d4 && b.prog.width > 4) ? 1 : 0;
     const bool mc = hb || (d2 && (use_matrix_core() || !h->scalar_ok));
-    const NfProgram &full = gemm == 2 ? b.prog8 : gemm == 1 ? b.prog7 : hb ? b.prog3 : wide == 2 ? b.prog5 : wide == 1 ? b.prog4 : mc ? b.prog2 : b.prog;
+    const NfProgram &full = w16 ? b.prog6 : gemm == 2 ? b.prog8 : gemm == 1 ? b.prog7 : hb ? b.prog3 : wide == 2 ? b.prog5 : wide == 1 ? b.prog4 : mc ? b.prog2 : b.prog;
     const float *cur = a.in;
     for (int s = 0; s < S && e == hipSuccess; ++s) {
         const Built::TileSeg &g = b.segs[s];
@@ -1805,7 +1808,11 @@ static int launch_tiled(nf_handle *h, int direction, NfLaunch &a, hipStream_t st
         t.nll_out = t.sd_out = t.ld_out = nullptr;
         t.sums = nullptr;
         t.tile_part = want ? part + tp.off[s] * 4 : nullptr;
-        if (gemm == 2) {
+        if (w16) {
+            t.params = d6;
+            t.n_params = (int32_t)b.block6.size();
+            e = nf_launch_wide16(sp, t, h->n_cu, h->device, st);
+        } else if (gemm == 2) {
             t.params = d8;
             t.n_params = (int32_t)b.block8.size();
             t.flags |= NF_K_FP16_CNN;
@@ -1939,6 +1946,7 @@ int nf_kernel_path(const nf_handle *h, int32_t direction)
         if (direction == 0 ? h->d_fwd8 : h->d_rev8) return NF_PATH_GEMM_FP16;
         if (direction == 0 ? h->d_fwd7 : h->d_rev7) return NF_PATH_GEMM;
         if ((direction == 0 ? h->d_fwd3 : h->d_rev3) && h->fwd.fp16_big) return NF_PATH_FP16;
+        if ((direction == 0 ? h->d_fwd6 : h->d_rev6) && h->fwd.prog.width == 16 && (use_matrix_core() || !h->scalar_ok)) return NF_PATH_WIDE16;
         if ((direction == 0 ? h->d_fwd4 : h->d_rev4) && h->fwd.prog.width > 4) return NF_PATH_WIDE32;
         return (direction == 0 ? h->d_fwd2 : h->d_rev2) && (use_matrix_core() || !h->scalar_ok) ? NF_PATH_MFMA4 : NF_PATH_SCALAR;
     }

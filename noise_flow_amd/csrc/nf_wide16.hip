@@ -21,6 +21,7 @@
 #include "../../include/noiseflow_hip.h"   // NF_SUMS_SLOTS / NF_SUMS_STRIDE
 #include "nf_device.h"
 #include "nf_dev_util.h"
+#include "nf_gemm_common.h"   // GemmTile: where a patch or, NF_K_TILED, a tile of an image sits
 
 namespace {
 
@@ -110,16 +111,17 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS
     double acc_nll = 0.0, acc_sd = 0.0;   // thread 0 only
 
     for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
-        const size_t patch_off = (size_t)b * (size_t)HW * 4u;
+        const GemmTile T = gemm_tile(a, b, H, W);      // the patch on its own, or (NF_K_TILED) a tile of an image: nf_gemm_common.h
+        const size_t patch_off = T.patch_off;
 
         float z[OWN][4];
 #pragma unroll
         for (int m = 0; m < OWN; ++m) {
             const int r = row0 + 4 * m + g;
             const bool act = r < H && col_on && strip_on;
-            const int gi = act ? r * W + c : 0;
+            const int gi = T.gi(act, r, c);
             if (PHILOX) {
-                philox_normal4(a.seed, a.patch_base + b, (uint32_t)gi, NF_STREAM_SAMP, z[m]);
+                philox_normal4(a.seed, a.patch_base + T.patch_id, (uint32_t)gi, NF_STREAM_SAMP, z[m]);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) z[m][q] *= a.in_scale;
             } else {
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS
 #pragma unroll
                     for (int j = 0; j < 4; ++j) o[j] = quad_sums(cp[4 * m][j], cp[4 * m + 1][j], cp[4 * m + 2][j], cp[4 * m + 3][j]);
                     const bool act = r < H && col_on && strip_on;
-                    const int bm = (r == 0 ? 1 : 0) | (r == H - 1 ? 2 : 0) | (c == 0 ? 4 : 0) | (c == W - 1 ? 8 : 0);
+                    const int bm = T.border(r, c);
                     const float4 eb = *reinterpret_cast<const float4 *>(a.params + prog.ops[op].off + NF4_CPL_E + 4 * (act ? bm : 0));
                     o[0] += eb.x; o[1] += eb.y; o[2] += eb.z; o[3] += eb.w;
                     // raw columns are pre-scaled by 2 log2(e): t = exp2(raw') = exp(2 raw); ls*log2(e) = scl - 2 scl/(t + 1)
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS
                     if (type == NF_OP_COUPLING_FWD) {
                         z[m][2] = fmaf(z[m][2], __builtin_amdgcn_exp2f(l0), o[0]);
                         z[m][3] = fmaf(z[m][3], __builtin_amdgcn_exp2f(l1), o[1]);
-                        if (act) ld2 += l0 + l1;
+                        if (T.own(act, r, c)) ld2 += l0 + l1;
                     } else {
                         z[m][2] = (z[m][2] - o[0]) * __builtin_amdgcn_exp2f(-l0);
                         z[m][3] = (z[m][3] - o[1]) * __builtin_amdgcn_exp2f(-l1);
@@ -303,14 +305,14 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS
                     const int r = row0 + 4 * m + g;
                     const bool act = r < H && col_on && strip_on;
                     float4 yv = make_float4(1.f, 1.f, 1.f, 1.f);
-                    if (act) yv = y4[r * W + c];
+                    if (act) yv = y4[T.gi(act, r, c)];
                     const float yy[4] = {yv.x, yv.y, yv.z, yv.w};
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const float v = fmaf(yy[q], ck1, cb2);
                         if (type == NF_OP_SDN_DIV) {
                             z[m][q] = z[m][q] * __builtin_amdgcn_rsqf(v);
-                            if (act) ld = fmaf(-0.34657359027997264f, __builtin_amdgcn_logf(v), ld);
+                            if (T.own(act, r, c)) ld = fmaf(-0.34657359027997264f, __builtin_amdgcn_logf(v), ld);
                         } else {
                             z[m][q] = z[m][q] * __builtin_amdgcn_sqrtf(v);
                         }
@@ -331,14 +333,15 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS
 #pragma unroll
             for (int m = 0; m < OWN; ++m) {
                 const int r = row0 + 4 * m + g;
-                if (r < H && col_on && strip_on) out4[r * W + c] = make_float4(z[m][0], z[m][1], z[m][2], z[m][3]);
+                const bool act = r < H && col_on && strip_on;
+                if (T.own(act, r, c)) out4[T.gi(act, r, c)] = make_float4(z[m][0], z[m][1], z[m][2], z[m][3]);
             }
         }
-        if (a.nll_out || a.sd_out || a.ld_out || a.sums) {
+        if (a.nll_out || a.sd_out || a.ld_out || a.sums || (T.tiled && a.tile_part)) {
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int m = 0; m < OWN; ++m)
-                if (row0 + 4 * m + g < H && col_on && strip_on) {
+                if (T.own(row0 + 4 * m + g < H && col_on && strip_on, row0 + 4 * m + g, c)) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         s1 += z[m][q];
@@ -360,6 +363,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS
                     r1 += red[NW + i];
                     r2 += red[2 * NW + i];
                 }
+            }
+            if (t == 0 && T.tiled) {
+                // the tile's share of its image's sums (nf_tile_combine_kernel forms nll / sd / log-det per image)
+                *reinterpret_cast<float4 *>(a.tile_part + (size_t)b * 4u) = make_float4(r0, r1, r2, 0.f);
+            } else if (t == 0) {
                 const double npx = (double)HW * 4.0;
                 const double logdet = (double)r0 + a.ld_const;
                 double nll = -logdet;   // prior: sum -0.5*(log 2pi + z^2)   (noise_flow_model.py:537-539)
@@ -378,7 +386,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS
         }
     }
 
-    if (a.sums && t == 0) {
+    if (a.sums && t == 0 && !(a.flags & NF_K_TILED)) {
         double *sp = a.sums;
         if (a.flags & NF_K_SUMS_WIDE) sp += (size_t)(blockIdx.x & (NF_SUMS_SLOTS - 1)) * NF_SUMS_STRIDE;
         atomicAdd(&sp[0], acc_nll);

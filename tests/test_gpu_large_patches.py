@@ -85,7 +85,7 @@ def test_tile_results_do_not_depend_on_the_batch():
 
 
 @pytest.mark.parametrize("width,cnn_dtype,hw,arch,path", [(32, "fp32", (100, 72), "sdn5|unc|gain4|unc|unc", 3),
-                                                          (16, "fp32", (70, 130), "sdn5|unc|unc|gain4|unc", 3),
+                                                          (16, "fp32", (70, 130), "sdn5|unc|unc|gain4|unc", 4),      # width 16: its own kernel takes tiles
                                                           (8, "fp32", (65, 65), "unc|unc", 3),
                                                           (32, "fp16", (96, 96), "sdn5|unc|gain4|unc", 5),
                                                           (4, "fp16", (128, 80), None, 2),      # full 64x64 tiles: the width-4 fp16 kernel
