@@ -44,6 +44,25 @@ __device__ __forceinline__ void stage_flush(Acc dst, const float *staged, int n,
     }
 }
 
+// One pixel's W values of a [pixel][W] LDS tile as 16-byte accesses (W = 4 / 8: the entry is 16-byte aligned).  Scalar accesses
+// put consecutive lanes W words apart — 8 distinct banks for 32 lanes, a 4-way conflict on every read (counters: 56 - 68 % of
+// the LDS-active cycles of these kernels); a 16-byte access per lane is conflict-free.
+template <int W>
+__device__ __forceinline__ void lds_get(const float *p, float (&v)[W])
+{
+#pragma unroll
+    for (int j = 0; j < W; j += 4) {
+        const float4 q = *reinterpret_cast<const float4 *>(p + j);
+        v[j] = q.x; v[j + 1] = q.y; v[j + 2] = q.z; v[j + 3] = q.w;
+    }
+}
+template <int W>
+__device__ __forceinline__ void lds_put(float *p, const float (&v)[W])
+{
+#pragma unroll
+    for (int j = 0; j < W; j += 4) *reinterpret_cast<float4 *>(p + j) = make_float4(v[j], v[j + 1], v[j + 2], v[j + 3]);
+}
+
 template <int NT>
 __device__ __forceinline__ void zero_floats(float *p, int n)
 {
@@ -82,8 +101,10 @@ __device__ __forceinline__ void tiled_phase_A(const Geo &g, int b, int r, int c,
     zero_floats<NT>(TU, tile_px * 4);
     __syncthreads();
     if (ok) {
+        float a2v[W];
 #pragma unroll
-        for (int i = 0; i < W; ++i) TH[tp * W + i] = fmaxf((h2v[i] - bn2[i]) * bn2[W + i], 0.0f);
+        for (int i = 0; i < W; ++i) a2v[i] = fmaxf((h2v[i] - bn2[i]) * bn2[W + i], 0.0f);
+        lds_put<W>(TH + tp * W, a2v);
     }
     __syncthreads();
     float tail[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // d b (4), d logs (4), d rescale
@@ -102,10 +123,11 @@ __device__ __forceinline__ void tiled_phase_A(const Geo &g, int b, int r, int c,
 #pragma unroll
                     for (int q = 0; q < 4; ++q) u[q] += w[W * 4 + q];
                 } else {
-                    const float *hp = TH + (tp + (di - 1) * Wp + (dj - 1)) * W;
+                    float hv[W];
+                    lds_get<W>(TH + (tp + (di - 1) * Wp + (dj - 1)) * W, hv);
 #pragma unroll
                     for (int i = 0; i < W; ++i) {
-                        const float a = hp[i];
+                        const float a = hv[i];
 #pragma unroll
                         for (int q = 0; q < 4; ++q) u[q] = fmaf(a, w[i * 4 + q], u[q]);
                     }
@@ -157,9 +179,11 @@ __device__ __forceinline__ void tiled_phase_A(const Geo &g, int b, int r, int c,
                 for (int i = 0; i < W; ++i)
                     gh[i] += w[i * 4] * gv.x + w[i * 4 + 1] * gv.y + w[i * 4 + 2] * gv.z + w[i * 4 + 3] * gv.w;
             }
+        float xhv[W];
+        lds_get<W>(TH + tp * W, xhv);
 #pragma unroll
         for (int i = 0; i < W; ++i) {
-            const float xh = TH[tp * W + i];                 // relu(xhat2): equals xhat2 wherever the mask lets gx through
+            const float xh = xhv[i];                         // relu(xhat2): equals xhat2 wherever the mask lets gx through
             const float gx = xh > 0.0f ? gh[i] : 0.0f;
             t1[gp * W + i] = gx;
             sq[i] = gx;
@@ -193,9 +217,9 @@ __device__ __forceinline__ void tiled_phase_C(const Geo &g, int b, int r, int c,
         for (int j = 0; j < W; ++j) {
             const float xh = (h1v[j] - bn1[j]) * bn1[W + j];
             gh[j] = bn1[W + j] * (t2v[j] - bb1[j] - xh * bb1[W + j]);
-            TG[tp * W + j] = gh[j];
             t2[gp * W + j] = gh[j];                          // k_w1_grad reads it on the side stream
         }
+        lds_put<W>(TG + tp * W, gh);
     }
     __syncthreads();
     float accA[16];
@@ -207,7 +231,8 @@ __device__ __forceinline__ void tiled_phase_C(const Geo &g, int b, int r, int c,
         for (int di = 0; di < 3; ++di)
 #pragma unroll
             for (int dj = 0; dj < 3; ++dj) {
-                const float *gq = TG + (tp - (di - 1) * Wp - (dj - 1)) * W;
+                float gq[W];
+                lds_get<W>(TG + (tp - (di - 1) * Wp - (dj - 1)) * W, gq);
                 const float *w = W1 + (di * 3 + dj) * 2 * W;
 #pragma unroll
                 for (int j = 0; j < W; ++j) {
@@ -252,7 +277,7 @@ template <int W, int NT, bool HAS_C, bool MIX, bool NEXT_A>
 __global__ __launch_bounds__(NT) void k_tiled_CA(Geo g, TiledC cc, TiledA a, double n, const float *__restrict__ P, float invB,
                                                  float *__restrict__ dz, const float *__restrict__ zlat, Acc G)
 {
-    extern __shared__ float smem[];
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ float bb1[2 * W];
     const int tile_px = (g.H + 2) * (g.W + 2);
     float *stgC = smem + tile_px * (W + 4), *stgA = stgC + W + 16, *part = stgA + 9 + 2 * W;
@@ -355,7 +380,7 @@ __global__ __launch_bounds__(NT) void k_tiled_fwd(Geo g, TiledF3 f3, TiledF1 f1,
 {   // Pw = P.  The filters are read through their own read-only pointer: behind the pointer the running moments are written
     // through, the compiler cannot prove them unclobbered and fetches every (wavefront-uniform) weight with a vector load
     // instead of a scalar one — 76 extra vector loads per thread in this kernel.
-    extern __shared__ float smem[];
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ float bn2[2 * W];
     const int Wp = g.W + 2, tile_px = (g.H + 2) * Wp;
     float *TH = smem, *TZ = smem + tile_px * W, *stg = TZ + tile_px * 2, *part = stg + 1 + 2 * W;
@@ -383,8 +408,10 @@ __global__ __launch_bounds__(NT) void k_tiled_fwd(Geo g, TiledF3 f3, TiledF1 f1,
     if (HAS_3) {
         const float *W3 = Pw + f3.off_w3, *b3 = W3 + 36 * (W + 1), *logs = b3 + 4;
         if (ok) {
+            float a2v[W];
 #pragma unroll
-            for (int i = 0; i < W; ++i) TH[tp * W + i] = fmaxf((h2v[i] - bn2[i]) * bn2[W + i], 0.0f);
+            for (int i = 0; i < W; ++i) a2v[i] = fmaxf((h2v[i] - bn2[i]) * bn2[W + i], 0.0f);
+            lds_put<W>(TH + tp * W, a2v);
         }
         __syncthreads();
         float lv[1] = {0.0f};
@@ -403,10 +430,11 @@ __global__ __launch_bounds__(NT) void k_tiled_fwd(Geo g, TiledF3 f3, TiledF1 f1,
 #pragma unroll
                         for (int k = 0; k < 4; ++k) u[k] += w[W * 4 + k];
                     } else {
-                        const float *hp = TH + (tp + (di - 1) * Wp + (dj - 1)) * W;
+                        float hv[W];
+                        lds_get<W>(TH + (tp + (di - 1) * Wp + (dj - 1)) * W, hv);
 #pragma unroll
                         for (int i = 0; i < W; ++i) {
-                            const float a = hp[i];
+                            const float a = hv[i];
 #pragma unroll
                             for (int k = 0; k < 4; ++k) u[k] = fmaf(a, w[i * 4 + k], u[k]);
                         }
