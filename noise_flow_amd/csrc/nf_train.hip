@@ -1470,7 +1470,6 @@ __global__ void k_momentum(int n, float *__restrict__ P, const float *__restrict
 
 struct Cpl {      // per-coupling workspace
     float *h1 = nullptr, *h2 = nullptr;
-    float *a1 = nullptr, *a2 = nullptr;   // relu(bn(h)) of both hidden layers, kept for the backward pass (widths beyond 32: nf_train_gemm.h)
     float *u = nullptr;                   // l_last's output, kept for the backward pass (wide couplings only)
     int f_bn1, f_bn2, f_bb1, f_bb2;       // offsets into the float scalar buffer
     int d_st1, d_st2, d_bs1, d_bs2;       // offsets into the double buffer
@@ -1523,12 +1522,13 @@ struct nf_trainer {
     double *sync_buf = nullptr;     // caller-owned device buffer, >= 64 doubles
     int sync_world = 1;
     int sync_rc = 0;                // first non-zero status a callback returned during the current step
-    // coupling widths beyond 32 (nf_train_gemm.h): rocBLAS handle and the operands of its GEMMs
-    void *blas = nullptr;
-    float *gz18 = nullptr, *gp36 = nullptr, *gq18 = nullptr, *gw3r = nullptr;   // [pixels][18] windows, [pixels][36] taps, [pixels][18], [w][36]
-    float *gdw = nullptr;           // filter gradients of every coupling as the split GEMMs leave them: 3 per coupling x gemm_part_floats(w)
+    // coupling widths without stage kernels of their own (nf_train_gemm.h): the operands of the matrix-core GEMMs of nf_train_mm.h
+    int n_cu = 256;
+    float *gz18 = nullptr, *gp36 = nullptr, *gq18 = nullptr;   // [pixels][20] windows (18 + 2 zero columns), [pixels][36] taps, [pixels][18]
+    float *gpack = nullptr;         // every coupling's weights in the GEMMs' packed layouts (gemm_pack_floats(w) each; written by the forward pass)
+    float *gdw = nullptr;           // filter gradients of every coupling as the pixel-K GEMMs leave them: 3 per coupling x gemm_part_floats(w)
     int gnp[3 * kMaxLayers] = {};   // how many partial products each of them holds (this step)
-    bool gemm_c1_fused = true;      // NF_TRAIN_GEMM_C1=0: l_1 forward as library GEMM + statistics pass (A/B aid)
+    bool gemm_c1_fused = false;     // NF_TRAIN_GEMM_C1=1: l_1 forward on the VALU kernel k_g_c1_fwd (widths that are a multiple of 4; A/B aid)
 };
 
 namespace {
@@ -1591,7 +1591,7 @@ inline int patch_split(const Geo &g)
 }
 
 }  // namespace
-#include "nf_train_gemm.h"    // widths 33 .. 512: library GEMMs + pixel kernels of run-time width
+#include "nf_train_gemm.h"    // widths without stage kernels of their own: matrix-core GEMMs (nf_train_mm.h) + pixel kernels of run-time width
 namespace {
 
 template <int W>
@@ -1916,7 +1916,6 @@ int nf_trainer_destroy(nf_trainer *t)
     for (hipEvent_t ev : t->ev_done)
         if (ev) (void)hipEventDestroy(ev);
     for (void *p : t->owned) (void)hipFree(p);
-    if (t->blas && rocblas_api()) (void)rocblas_api()->destroy((rocblas_handle)t->blas);
     delete t;
     return NF_OK;
 }
@@ -1973,10 +1972,6 @@ int nf_trainer_create(const nf_config *cfg, const nf_layer_desc *layers, const f
             if (w < 1 || w > 512) {
                 delete t;
                 return nf_fail(NF_EINVAL, "layer %d: the trainer takes the coupling widths 1 .. 512 (%d given)", i, w);
-            }
-            if (gemm_width(w) && !rocblas_api()) {
-                delete t;
-                return nf_fail(NF_EINVAL, "layer %d: training at coupling width %d runs its dense products on rocBLAS, which could not be loaded (librocblas.so.5)", i, w);
             }
             if (t->width && t->width != w) {
                 delete t;
@@ -2111,26 +2106,16 @@ int nf_trainer_create(const nf_config *cfg, const nf_layer_desc *layers, const f
         NF_TRY(dev_alloc(t, (void **)&c.h1, act * w * sizeof(float)));
         NF_TRY(dev_alloc(t, (void **)&c.h2, act * w * sizeof(float)));
         if (w >= 16 || gemm_width(w)) NF_TRY(dev_alloc(t, (void **)&c.u, act * 4 * sizeof(float)));
-        if (gemm_width(w)) {
-            NF_TRY(dev_alloc(t, (void **)&c.a1, act * w * sizeof(float)));
-            NF_TRY(dev_alloc(t, (void **)&c.a2, act * w * sizeof(float)));
-        }
     }
     if (gemm_width(w) && n_cpl > 0) {   // nf_train_gemm.h
-        NF_TRY(dev_alloc(t, (void **)&t->gz18, act * 18 * sizeof(float)));
+        NF_TRY(dev_alloc(t, (void **)&t->gz18, act * kZ18 * sizeof(float)));
         NF_TRY(dev_alloc(t, (void **)&t->gp36, act * 36 * sizeof(float)));
         NF_TRY(dev_alloc(t, (void **)&t->gq18, act * 18 * sizeof(float)));
-        NF_TRY(dev_alloc(t, (void **)&t->gw3r, (size_t)w * 36 * sizeof(float)));
+        NF_TRY(dev_alloc(t, (void **)&t->gpack, (size_t)n_cpl * gemm_pack_floats(w) * sizeof(float)));
         NF_TRY(dev_alloc(t, (void **)&t->gdw, (size_t)n_cpl * 3 * gemm_part_floats(w) * sizeof(float)));
-        rocblas_handle bh = nullptr;
-        if (rocblas_api()->create(&bh) != rocblas_status_success) {
-            nf_trainer_destroy(t);
-            return nf_fail(NF_EHIP, "rocblas_create_handle failed");
-        }
-        t->blas = bh;
         if (const char *ev = getenv("NF_TRAIN_GEMM_C1")) t->gemm_c1_fused = atoi(ev) != 0;
-        // no atomically accumulated split-K products: a step's gradients are the same bits on every run, as at the other widths
-        if (rocblas_api()->set_atomics) (void)rocblas_api()->set_atomics(bh, rocblas_atomics_not_allowed);
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, t->device) == hipSuccess && cus > 0) t->n_cu = cus;
     }
     for (int k = 0; k < (gemm_width(w) ? 1 : 3); ++k) {
         NF_TRY(dev_alloc(t, (void **)&t->t1[k], act * w * sizeof(float)));
@@ -2204,7 +2189,7 @@ static int trainer_run(nf_trainer *t, const float *x, const float *y, int64_t B,
     const unsigned nb = blocks_for(g.npix);
     g.nslot = (t->sync_fn && t->sync_world > 1) ? std::max((int)nb, 2) : (int)nb;   // the synchronised totals occupy slots 0 and 1
     t->sync_rc = 0;
-    bool blas_failed = false;
+    bool mm_failed = false;
     const float invB = 1.0f / (float)B;
     const int n = t->cfg.n_layers;
     hipError_t e;
@@ -2254,7 +2239,7 @@ static int trainer_run(nf_trainer *t, const float *x, const float *y, int64_t B,
 #undef NF_CALL
                 f1_done = nxt != nullptr;
             } else if (gemm_width(L.width)) {
-                if (!coupling_forward_gemm(t, g, L, zin, zout, t->acc(t->d_ld0 + l), zpre, Am, st)) blas_failed = true;
+                if (!coupling_forward_gemm(t, g, L, zin, zout, t->acc(t->d_ld0 + l), zpre, Am, st)) mm_failed = true;
             } else {
 #define NF_CALL(WW) coupling_forward<WW>(t, g, L, zin, zout, t->acc(t->d_ld0 + l), zpre, Am, st)
                 NF_WIDTH_SWITCH(L.width, NF_CALL)
@@ -2324,7 +2309,7 @@ static int trainer_run(nf_trainer *t, const float *x, const float *y, int64_t B,
 #undef NF_CALL
                 a_done = nxt != nullptr;
             } else if (gemm_width(L.width)) {
-                if (!coupling_backward_gemm(t, g, L, t->zs[l], invB, zmix_in, Am, dA, st, zlat)) blas_failed = true;
+                if (!coupling_backward_gemm(t, g, L, t->zs[l], invB, zmix_in, Am, dA, st, zlat)) mm_failed = true;
             } else {
 #define NF_CALL(WW) coupling_backward<WW>(t, g, L, t->zs[l], invB, zmix_in, Am, dA, st, zlat)
                 NF_WIDTH_SWITCH(L.width, NF_CALL)
@@ -2376,7 +2361,7 @@ static int trainer_run(nf_trainer *t, const float *x, const float *y, int64_t B,
     hipLaunchKernelGGL(k_grads_out, dim3((t->n_params + TB - 1) / TB), dim3(TB), 0, st, t->n_params, G, t->d_mask, gout);
     t->zs[0] = nullptr;
     if ((e = hipGetLastError()) != hipSuccess) return nf_fail_hip(e, "trainer launch");
-    if (blas_failed) return nf_fail(NF_EHIP, "a rocBLAS GEMM of the wide-coupling training step failed");
+    if (mm_failed) return nf_fail(NF_EHIP, "a matrix-core GEMM of the wide-coupling training step could not be launched");
     if (t->sync_rc) return nf_fail(NF_EINVAL, "the all-reduce callback of nf_trainer_set_sync failed (status %d)", t->sync_rc);
     return NF_OK;
 }

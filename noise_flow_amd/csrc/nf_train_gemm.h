@@ -1,40 +1,43 @@
-// Training step at coupling widths beyond 32 (part of nf_train.hip).
+// Training step at coupling widths without stage kernels of their own (part of nf_train.hip): 33 .. 512 and 1 .. 31 except 4 / 8 / 16.
 //
 // sidd/ArgParser.py:43 defaults --width to Glow's 512 and train_noise_flow.py:50-77,187-198 trains at whatever width is set.
 // The layer kernels of nf_train.hip keep (w+1)*4 accumulators per thread and the matrix-core stages of nf_train_wide.h hold one
 // 32-channel tile per operand: neither exists beyond width 32.  At these widths a coupling IS GEMM-shaped — l_2 is
-// [pixels x w] . [w x w], 90 % of the arithmetic at 512 — so the dense products of the step run as plain library GEMMs
-// (rocBLAS sgemm, exact fp32; loaded with dlopen when the first wide trainer is created, so the library itself does not depend
-// on it) and everything that is not a plain GEMM is a hand-written kernel over [pixel][w] tensors of run-time width:
+// [pixels x w] . [w x w], 90 % of the arithmetic at 512 — so the dense products of the step are the hand-written fp32
+// matrix-core GEMMs of nf_train_mm.h (k_mm_pix: pixels on M; k_mm_kpix: pixels on K), with batch normalisation + ReLU fused into
+// their operand staging and the batch sums into their epilogues; what is not a dense product is a kernel over [pixel][w]
+// tensors of run-time width below:
 //
-//   forward   Z18 = the 3x3 x 2-channel windows of the pass-through half            k_g_gather18
-//             h1 = Z18 . W1 (K = 18)                                                sgemm
-//             batch sums of h1 + b1 (slotted; h1 stays without its bias in memory)  k_g_bias_stats   -> k_bn_fin (moments, EMA)
-//             a1 = relu(bn1(h1 + b1))                                               k_g_bn_relu
-//             h2 = a1 . W2                                                          sgemm
-//             batch sums of h2 + b2; a2 = relu(bn2(h2 + b2))                        k_g_bias_stats, k_bn_fin, k_g_bn_relu
-//             P = a2 . W3r  (W3r[i][tap*4+k] = l_last/W[tap][i][k], 36 columns)     k_g_pack_w3, sgemm
+//   forward   the coupling's weights in the GEMMs' packed layouts (one launch)     mm::k_mm_pack_all
+//             Z18 = the 3x3 x 2-channel windows of the pass-through half            k_g_gather18
+//             h1 = Z18 . W1 (K = 18) + batch sums of h1 + b1                        k_mm_pix <EPI 1> (NF_TRAIN_GEMM_C1=1: k_g_c1_fwd) -> k_bn_fin
+//             h2 = relu(bn1(h1 + b1)) . W2 + batch sums of h2 + b2                  k_mm_pix <APRO 1, EPI 1>                 -> k_bn_fin
+//             P = relu(bn2(h2 + b2)) . W3r  (W3r[i][tap*4+k] = l_last/W[tap][i][k]) k_mm_pix <APRO 1>
 //             u = gather of the 9 taps of P + edge channel + b3; affine transform   k_g_c3_fwd
 //   backward  affine / tanh / exp(3 logs) backward -> gu, d b3, d logs, d scale     k_g_c3_bwd
 //             G36[p][tap*4+k] = gu[p - tap][k]; d edge-channel weights              k_g_gather36
-//             d l_last/W = a2^T . G36 ;  g_a2 = G36 . W3r^T                         sgemm x 2
-//             the two batch sums of BN2's backward (mask from h2, read-only)        k_g_mask_stats   -> k_bnb_fin
-//             g_h2 = BN2 backward of the masked g_a2; d b2                          k_g_bn_bwd
-//             d l_2/W = a1^T . g_h2 ;  g_a1 = g_h2 . W2^T                           sgemm x 2
-//             mask + sums, g_h1 = BN1 backward, d b1                                k_g_mask_stats, k_bnb_fin, k_g_bn_bwd
-//             d l_1/W = Z18^T . g_h1 ;  Q = g_h1 . W1^T (18 columns)                sgemm x 2
+//             d l_last/W = relu(bn2(h2 + b2))^T . G36                               k_mm_kpix <APRO 1>
+//             the two batch sums of BN2's backward over g_a2 = G36 . W3r^T          k_mm_pix <EPI 4> (nothing stored)        -> k_bnb_fin
+//             g_h2 = BN2 backward of the masked g_a2 (formed again: K = 36); d b2   k_mm_pix <EPI 3>
+//             d l_2/W = relu(bn1(h1 + b1))^T . g_h2                                 k_mm_kpix <APRO 1>
+//             g_a1 = g_h2 . W2^T + the two batch sums of BN1's backward             k_mm_pix <EPI 2>                         -> k_bnb_fin
+//             d l_1/W = Z18^T . g_h1, g_h1 = BN1 backward of the masked g_a1; d b1  k_mm_kpix <BPRO 2>
+//             Q = g_h1 . W1^T (18 columns), g_h1 formed again                       k_mm_pix <APRO 2>
 //             d z0 += gather of Q; the folded Conv2d1x1 backward                    k_g_c1_dz
 //
-// Gradients of the three filters come out of the GEMMs whole and go straight into the fp64 gradient vector (k_g_store_grad);
-// every other reduction of the step keeps the trainer's slotted partial sums, so the batch statistics can be synchronised
-// across ranks exactly as at the other widths.  One stream, no side work: a wide step is tens of milliseconds of GEMMs.
+// The pre-BN activations h1 / h2 stay WITHOUT their bias in memory and are the only [pixel][w] tensors a coupling keeps: the
+// normalised activations are re-formed from them wherever they are an operand (same expression, same bits: mm::xhat = g_xhat).
+// Gradients of the three filters come out of k_mm_kpix as partial products per pixel chunk and go into the fp64 gradient vector
+// (k_g_store_grad); every other reduction of the step keeps the trainer's slotted partial sums, so the batch statistics can be
+// synchronised across ranks exactly as at the other widths.  One stream, no side work: a wide step is milliseconds of GEMMs.
 //
 // Replaces (reference, /root/reference): train_noise_flow.py:64-66 with borealisflows/layers.py:452-498 at hps.width > 32.
 #pragma once
-#include <dlfcn.h>
-#include <rocblas/rocblas.h>   // types and enumerators only: the functions are resolved with dlsym
+#include "nf_train_mm.h"
 
 namespace {
+
+static_assert(mm::kSlotStride == NSLOT, "nf_train_mm.h writes the trainer's slotted accumulators");
 
 // the widths with kernels of their own (nf_train.hip, nf_train_tiled.h, nf_train_wide.h); every other width 1 .. 512 runs here
 // (NF_TRAIN_GEMM=1 in the environment sends those four here as well: an A/B switch for tests and profiles)
@@ -44,98 +47,17 @@ inline bool gemm_width(int w)
     return all || (w != 4 && w != 8 && w != 16 && w != 32);
 }
 
-struct RocBlas {
-    void *lib = nullptr;
-    rocblas_status (*create)(rocblas_handle *) = nullptr;
-    rocblas_status (*destroy)(rocblas_handle) = nullptr;
-    rocblas_status (*set_stream)(rocblas_handle, hipStream_t) = nullptr;
-    rocblas_status (*set_atomics)(rocblas_handle, rocblas_atomics_mode) = nullptr;   // optional
-    rocblas_status (*sgemm)(rocblas_handle, rocblas_operation, rocblas_operation, rocblas_int, rocblas_int, rocblas_int, const float *,
-                            const float *, rocblas_int, const float *, rocblas_int, const float *, float *, rocblas_int) = nullptr;
-    rocblas_status (*sgemm_sb)(rocblas_handle, rocblas_operation, rocblas_operation, rocblas_int, rocblas_int, rocblas_int, const float *,
-                               const float *, rocblas_int, rocblas_stride, const float *, rocblas_int, rocblas_stride, const float *, float *,
-                               rocblas_int, rocblas_stride, rocblas_int) = nullptr;
-};
-
-// process-wide, loaded once (never unloaded)
-inline const RocBlas *rocblas_api()
-{
-    static const RocBlas api = [] {
-        RocBlas r;
-        for (const char *name : {"librocblas.so.5", "librocblas.so", "/opt/rocm/lib/librocblas.so"}) {
-            r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-            if (r.lib) break;
-        }
-        if (r.lib) {
-            r.create = reinterpret_cast<decltype(r.create)>(dlsym(r.lib, "rocblas_create_handle"));
-            r.destroy = reinterpret_cast<decltype(r.destroy)>(dlsym(r.lib, "rocblas_destroy_handle"));
-            r.set_stream = reinterpret_cast<decltype(r.set_stream)>(dlsym(r.lib, "rocblas_set_stream"));
-            r.set_atomics = reinterpret_cast<decltype(r.set_atomics)>(dlsym(r.lib, "rocblas_set_atomics_mode"));
-            r.sgemm = reinterpret_cast<decltype(r.sgemm)>(dlsym(r.lib, "rocblas_sgemm"));
-            r.sgemm_sb = reinterpret_cast<decltype(r.sgemm_sb)>(dlsym(r.lib, "rocblas_sgemm_strided_batched"));
-            if (!r.create || !r.destroy || !r.set_stream || !r.sgemm || !r.sgemm_sb) r.lib = nullptr;
-        }
-        return r;
-    }();
-    return api.lib ? &api : nullptr;
-}
-
-// Row-major C[M x N] = op(A) . op(B) (+ beta C): rocBLAS is column-major, so the call computes C^T = op(B)^T . op(A)^T.
-// ta / tb: the row-major operand is stored transposed ([K x M] / [N x K]).
-inline bool gemm_rm(nf_trainer *t, hipStream_t st, bool ta, bool tb, int64_t M, int64_t N, int64_t K, const float *A, int64_t lda,
-                    const float *B, int64_t ldb, float *C, int64_t ldc)
-{
-    const RocBlas *rb = rocblas_api();
-    const float one = 1.0f, zero = 0.0f;
-    if (!rb || !t->blas) return false;
-    rocblas_handle h = (rocblas_handle)t->blas;
-    if (rb->set_stream(h, st) != rocblas_status_success) return false;
-    return rb->sgemm(h, tb ? rocblas_operation_transpose : rocblas_operation_none, ta ? rocblas_operation_transpose : rocblas_operation_none,
-                     (rocblas_int)N, (rocblas_int)M, (rocblas_int)K, &one, B, (rocblas_int)ldb, A, (rocblas_int)lda, &zero, C,
-                     (rocblas_int)ldc) == rocblas_status_success;
-}
-
-// Filter gradients: row-major C[M x N] = A^T . B with A [K x M], B [K x N] and K = the PIXELS of the minibatch (1e5 .. 1e6) against
-// M, N of 18 .. 512 — one GEMM with a handful of output tiles, i.e. a handful of workgroups on 256 CUs (measured: the library
-// picks a 9-way split at M = N = 64 and the call takes milliseconds).  So the pixels are cut into `S` chunks here, one strided-
-// batched call computes the S partial products (S x tiles workgroups), and k_g_store_grad adds them up in fp64 on their way into
-// the gradient vector.  Returns the number of partials left in `part` ([S][M][N]), 0 on failure.
-constexpr int64_t kGradPartFloats = (int64_t)1 << 22;   // 16 MiB of partial products per filter
-inline int gemm_atb_split(nf_trainer *t, hipStream_t st, int64_t M, int64_t N, int64_t K, const float *A, int64_t lda, const float *B,
-                          int64_t ldb, float *part)
-{
-    const RocBlas *rb = rocblas_api();
-    const float one = 1.0f, zero = 0.0f;
-    if (!rb || !t->blas) return 0;
-    rocblas_handle h = (rocblas_handle)t->blas;
-    if (rb->set_stream(h, st) != rocblas_status_success) return 0;
-    int64_t S = std::max<int64_t>(1, std::min<int64_t>(256, kGradPartFloats / (M * N)));
-    S = std::min<int64_t>(S, std::max<int64_t>(1, K / 512));          // chunks of at least 512 pixels
-    const int64_t Kc = K / S, rem = K - Kc * S;                         // S equal chunks, the remainder as one more partial
-    // column-major view: C^T [N x M] = B^T-chunk [N x Kc] . A-chunk [Kc x M]  ->  op(B) = none (ld = ldb), op(A) = transpose (ld = lda)
-    if (rb->sgemm_sb(h, rocblas_operation_none, rocblas_operation_transpose, (rocblas_int)N, (rocblas_int)M, (rocblas_int)Kc, &one, B,
-                     (rocblas_int)ldb, (rocblas_stride)(Kc * ldb), A, (rocblas_int)lda, (rocblas_stride)(Kc * lda), &zero, part, (rocblas_int)N,
-                     (rocblas_stride)(M * N), (rocblas_int)S) != rocblas_status_success)
-        return 0;
-    if (rem > 0) {
-        if (rb->sgemm(h, rocblas_operation_none, rocblas_operation_transpose, (rocblas_int)N, (rocblas_int)M, (rocblas_int)rem, &one,
-                      B + Kc * S * ldb, (rocblas_int)ldb, A + Kc * S * lda, (rocblas_int)lda, &zero, part + S * M * N,
-                      (rocblas_int)N) != rocblas_status_success)
-            return 0;
-        return (int)S + 1;
-    }
-    return (int)S;
-}
-
 // ---- kernels over [pixel][w] tensors of run-time width ------------------------------------------------------------------
 
-// Z18[p][tap*2 + c] = z0 of pixel p + tap (zero outside the patch): the im2col of l_1 (layers.py:586-613, 'SAME')
+// Z18[p][tap*2 + c] = z0 of pixel p + tap (zero outside the patch): the im2col of l_1 (layers.py:586-613, 'SAME').  Rows of
+// kZ18 = 20 floats (16-byte aligned; the two spare columns are zero, so a GEMM may run K = 20)
+constexpr int kZ18 = 20;
 __global__ void k_g_gather18(Geo g, const float *__restrict__ z, float *__restrict__ Z18)
 {
     NF_PIXEL_LOOP(g, p) {
         if (p < g.npix) {
             const int b = (int)(p / g.HW), rem = (int)(p - (int64_t)b * g.HW), r = rem / g.W, c = rem - r * g.W;
-            float *o = Z18 + p * 18;
+            float *o = Z18 + p * kZ18;
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int rr = r + tap / 3 - 1, cc = c + tap % 3 - 1;
@@ -144,6 +66,8 @@ __global__ void k_g_gather18(Geo g, const float *__restrict__ z, float *__restri
                 o[2 * tap] = v.x;
                 o[2 * tap + 1] = v.y;
             }
+            o[18] = 0.0f;
+            o[19] = 0.0f;
         }
     }
 }
@@ -189,25 +113,6 @@ __device__ __forceinline__ void flat_store(const float (&v)[4], float *red, cons
 // that the ReLU mask the backward pass re-derives from h is bit for bit the forward's
 __device__ __forceinline__ float g_xhat(float h, float b, float m, float rs) { return ((h + b) - m) * rs; }
 
-// the slotted batch sums of h + bias (sum, sum of squares per channel)
-__global__ __launch_bounds__(256) void k_g_bias_stats(Geo g, int w, const float *__restrict__ h, const float *__restrict__ bias, Acc stats)
-{
-    __shared__ float red[256 * 4];
-    const FlatWalk f = flat_walk(g.npix, w);
-    const int t = threadIdx.x, cg = t % f.Q;
-    float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
-    if (t < f.TBq) {
-        const float b4[4] = {bias[4 * cg], bias[4 * cg + 1], bias[4 * cg + 2], bias[4 * cg + 3]};
-        for (int64_t e = (int64_t)blockIdx.x * f.TBq + t; e < f.total; e += f.stride) {
-            float4 v = reinterpret_cast<const float4 *>(h)[e];
-            v.x += b4[0]; v.y += b4[1]; v.z += b4[2]; v.w += b4[3];
-            s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
-            q[0] = fmaf(v.x, v.x, q[0]); q[1] = fmaf(v.y, v.y, q[1]); q[2] = fmaf(v.z, v.z, q[2]); q[3] = fmaf(v.w, v.w, q[3]);
-        }
-    }
-    flat_store(s, red, f, w, stats);
-    flat_store(q, red, f, w, stats + w);
-}
 // l_1 itself where the width allows the flat walk (a multiple of 4): h1 = Z18 . W1 has K = 18 — less arithmetic than the write
 // of its own result — so the library GEMM, its read-back for the statistics and their launches collapse into ONE pass: every
 // thread keeps the 18 x 4 filter entries of its four channels in registers, reads a pixel's 18 gathered inputs (the lanes that
@@ -230,7 +135,7 @@ __global__ __launch_bounds__(256) void k_g_c1_fwd(Geo g, int w, const float *__r
         for (int j = 0; j < 4; ++j) b4[j] = bias[4 * cg + j];
         for (int64_t e = (int64_t)blockIdx.x * f.TBq + t; e < f.total; e += f.stride) {
             const int64_t p = e / f.Q;
-            const float2 *zr = reinterpret_cast<const float2 *>(Z18 + p * 18);   // rows of 72 bytes: 8-byte aligned
+            const float2 *zr = reinterpret_cast<const float2 *>(Z18 + p * kZ18);
             float a[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int k2 = 0; k2 < 9; ++k2) {
@@ -250,51 +155,6 @@ __global__ __launch_bounds__(256) void k_g_c1_fwd(Geo g, int w, const float *__r
     flat_store(s, red, f, w, stats);
     flat_store(q, red, f, w, stats + w);
 }
-__global__ __launch_bounds__(256) void k_g_bias_stats_slow(Geo g, int w, const float *__restrict__ h, const float *__restrict__ bias, Acc stats)
-{
-    const int64_t per = (g.npix + gridDim.x - 1) / gridDim.x, p0 = per * blockIdx.x, p1 = p0 + per < g.npix ? p0 + per : g.npix;
-    for (int j = threadIdx.x; j < w; j += 256) {
-        const float bj = bias[j];
-        double s = 0.0, q = 0.0;   // one thread walks the whole run: a float sum of `per` values would cost the mean its last bits
-        for (int64_t p = p0; p < p1; ++p) {
-            const float v = h[p * w + j] + bj;
-            s += (double)v;
-            q += (double)v * (double)v;
-        }
-        (stats + j).p[blockIdx.x] = (float)s;
-        (stats + (w + j)).p[blockIdx.x] = (float)q;
-    }
-}
-
-// a = relu((h + bias - mean) * rstd)   (layers.py:378-401 with the batch moments, then :478 / :489).  V = 4: four channels per
-// thread (widths that are a multiple of 4), else one
-template <int V>
-__global__ void k_g_bn_relu(int64_t nv, int wv, const float *__restrict__ h, const float *__restrict__ bias, const float *__restrict__ bn,
-                            float *__restrict__ a)
-{
-    const int w = V * wv;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nv; e += (int64_t)gridDim.x * blockDim.x) {
-        const int j = (int)(e % wv) * V;
-        if constexpr (V == 4) {
-            const float4 v = reinterpret_cast<const float4 *>(h)[e];
-            reinterpret_cast<float4 *>(a)[e] =
-                make_float4(fmaxf(g_xhat(v.x, bias[j], bn[j], bn[w + j]), 0.f), fmaxf(g_xhat(v.y, bias[j + 1], bn[j + 1], bn[w + j + 1]), 0.f),
-                            fmaxf(g_xhat(v.z, bias[j + 2], bn[j + 2], bn[w + j + 2]), 0.f), fmaxf(g_xhat(v.w, bias[j + 3], bn[j + 3], bn[w + j + 3]), 0.f));
-        } else {
-            a[e] = fmaxf(g_xhat(h[e], bias[j], bn[j], bn[w + j]), 0.f);
-        }
-    }
-}
-
-// W3r[i][tap*4 + k] = l_last/W[tap][i][k], i < w (the edge-indicator row i = w is handled by the gather kernels)
-__global__ void k_g_pack_w3(int w, const float *__restrict__ W3, float *__restrict__ W3r)
-{
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= w * 36) return;
-    const int i = e / 36, col = e - i * 36, tap = col >> 2, k = col & 3;
-    W3r[e] = W3[(tap * (w + 1) + i) * 4 + k];
-}
-
 // u = sum of the 9 taps of P (+ the edge channel's weight where the tap falls on the padding ring, + b3); the affine transform
 // of the second half (layers.py:355-375, 555-583, 651-674); keeps u for the backward pass
 __global__ void k_g_c3_fwd(Geo g, int w, const float *__restrict__ zin, const float *__restrict__ P36, const float *__restrict__ Pw,
@@ -422,109 +282,6 @@ __global__ void k_g_gather36(Geo g, int w, const float *__restrict__ gu, float *
     }
 }
 
-// The two batch sums BN's backward needs — sum gx, sum gx * xhat with gx = g_a where the activation is positive — from a
-// read-only pass: the mask is re-derived from h (xhat > 0 <=> the forward's relu kept the value; same expression, same bits) and
-// applied again by k_g_bn_bwd, so the masked gradient is never written.
-__global__ __launch_bounds__(256) void k_g_mask_stats(Geo g, int w, const float *__restrict__ ga, const float *__restrict__ h,
-                                                      const float *__restrict__ bias, const float *__restrict__ bn, Acc bstats)
-{
-    __shared__ float red[256 * 4];
-    const FlatWalk f = flat_walk(g.npix, w);
-    const int t = threadIdx.x, cg = t % f.Q;
-    float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
-    if (t < f.TBq) {
-        float b[4], m[4], rs[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            b[k] = bias[4 * cg + k];
-            m[k] = bn[4 * cg + k];
-            rs[k] = bn[w + 4 * cg + k];
-        }
-        for (int64_t e = (int64_t)blockIdx.x * f.TBq + t; e < f.total; e += f.stride) {
-            const float4 hv4 = reinterpret_cast<const float4 *>(h)[e], gv4 = reinterpret_cast<const float4 *>(ga)[e];
-            const float hv[4] = {hv4.x, hv4.y, hv4.z, hv4.w}, gv[4] = {gv4.x, gv4.y, gv4.z, gv4.w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float xh = g_xhat(hv[k], b[k], m[k], rs[k]);
-                const float gx = xh > 0.f ? gv[k] : 0.f;
-                s[k] += gx;
-                q[k] = fmaf(gx, xh, q[k]);
-            }
-        }
-    }
-    flat_store(s, red, f, w, bstats);
-    flat_store(q, red, f, w, bstats + w);
-}
-__global__ __launch_bounds__(256) void k_g_mask_stats_slow(Geo g, int w, const float *__restrict__ ga, const float *__restrict__ h,
-                                                           const float *__restrict__ bias, const float *__restrict__ bn, Acc bstats)
-{
-    const int64_t per = (g.npix + gridDim.x - 1) / gridDim.x, p0 = per * blockIdx.x, p1 = p0 + per < g.npix ? p0 + per : g.npix;
-    for (int j = threadIdx.x; j < w; j += 256) {
-        const float b = bias[j], m = bn[j], rs = bn[w + j];
-        double s = 0.0, q = 0.0;
-        for (int64_t p = p0; p < p1; ++p) {
-            const float xh = g_xhat(h[p * w + j], b, m, rs);
-            const float gx = xh > 0.0f ? ga[p * w + j] : 0.0f;
-            s += (double)gx;
-            q += (double)gx * (double)xh;
-        }
-        (bstats + j).p[blockIdx.x] = (float)s;
-        (bstats + (w + j)).p[blockIdx.x] = (float)q;
-    }
-}
-
-// BN backward (in place, on the UNMASKED g_a): gx = g_a where xhat > 0, g_h = rstd * (gx - mean(gx) - xhat * mean(gx * xhat));
-// and d bias = sum of g_h
-__global__ __launch_bounds__(256) void k_g_bn_bwd(Geo g, int w, float *__restrict__ gx, const float *__restrict__ h, const float *__restrict__ bias,
-                                                  const float *__restrict__ bn, const float *__restrict__ bb, Acc Gb)
-{
-    __shared__ float red[256 * 4];
-    const FlatWalk f = flat_walk(g.npix, w);
-    const int t = threadIdx.x, cg = t % f.Q;
-    float s[4] = {0.f, 0.f, 0.f, 0.f};
-    if (t < f.TBq) {
-        float b[4], m[4], rs[4], ba[4], bq[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            b[k] = bias[4 * cg + k];
-            m[k] = bn[4 * cg + k];
-            rs[k] = bn[w + 4 * cg + k];
-            ba[k] = bb[4 * cg + k];
-            bq[k] = bb[w + 4 * cg + k];
-        }
-        for (int64_t e = (int64_t)blockIdx.x * f.TBq + t; e < f.total; e += f.stride) {
-            const float4 hv4 = reinterpret_cast<const float4 *>(h)[e], gv4 = reinterpret_cast<const float4 *>(gx)[e];
-            const float hv[4] = {hv4.x, hv4.y, hv4.z, hv4.w}, gv[4] = {gv4.x, gv4.y, gv4.z, gv4.w};
-            float o[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float xh = g_xhat(hv[k], b[k], m[k], rs[k]);
-                o[k] = rs[k] * ((xh > 0.f ? gv[k] : 0.f) - ba[k] - xh * bq[k]);
-                s[k] += o[k];
-            }
-            reinterpret_cast<float4 *>(gx)[e] = make_float4(o[0], o[1], o[2], o[3]);
-        }
-    }
-    flat_store(s, red, f, w, Gb);
-}
-__global__ __launch_bounds__(256) void k_g_bn_bwd_slow(Geo g, int w, float *__restrict__ gx, const float *__restrict__ h,
-                                                       const float *__restrict__ bias, const float *__restrict__ bn,
-                                                       const float *__restrict__ bb, Acc Gb)
-{
-    const int64_t per = (g.npix + gridDim.x - 1) / gridDim.x, p0 = per * blockIdx.x, p1 = p0 + per < g.npix ? p0 + per : g.npix;
-    for (int j = threadIdx.x; j < w; j += 256) {
-        const float b = bias[j], m = bn[j], rs = bn[w + j], ba = bb[j], bq = bb[w + j];
-        double s = 0.0;
-        for (int64_t p = p0; p < p1; ++p) {
-            const float xh = g_xhat(h[p * w + j], b, m, rs);
-            const float o = rs * ((xh > 0.0f ? gx[p * w + j] : 0.0f) - ba - xh * bq);
-            gx[p * w + j] = o;
-            s += (double)o;
-        }
-        (Gb + j).p[blockIdx.x] = (float)s;
-    }
-}
-
 // transposed l_1 from Q[p][tap*2 + c] = sum_j g_h1[p][j] W1[tap][c][j]: d z0[q][c] += sum over taps of Q[q - tap][tap][c];
 // MIX: the backward of the preceding Conv2d1x1 folded in (per pixel: dA += z_in^T d, d <- d A^T), as k_c1_dz
 template <bool MIX>
@@ -602,8 +359,10 @@ inline void store_grad(hipStream_t st, int n, int w, int mode, const float *part
 // ---- host side -------------------------------------------------------------------------------------------------------------
 
 inline unsigned gemm_grid(const Geo &g) { return (unsigned)g.nslot; }   // one workgroup per slot: nobody's slot stays stale
-// floats of partial products one filter gradient may leave (up to 257 partials of at most kGradPartFloats / 256 ... w*w floats)
-inline size_t gemm_part_floats(int w) { return (size_t)kGradPartFloats + 2 * (size_t)w * w; }
+// floats of partial products one filter gradient may leave (up to 256 partials of M x N, at least one)
+inline size_t gemm_part_floats(int w) { return (size_t)mm::kGradPartFloats + 2 * (size_t)w * w; }
+// floats of packed weights one coupling's GEMMs read (nf_train_mm.h: pack_layout)
+inline size_t gemm_pack_floats(int w) { return (mm::pack_layout(w).total + 3) & ~(size_t)3; }
 
 bool coupling_forward_gemm(nf_trainer *t, const Geo &g, const TLayer &L, const float *zin, float *zout, Acc ldacc, const float *zpre,
                            const float *A, hipStream_t st)
@@ -614,34 +373,48 @@ bool coupling_forward_gemm(nf_trainer *t, const Geo &g, const TLayer &L, const f
               off_b2 = off_w2 + w * w, off_m2 = L.off + 22 * w + w * w, off_w3 = L.off + 24 * w + w * w;
     const double n = (double)g.npix * t->sync_world;
     const float *P = t->d_params;
-    const int V = w % 4 == 0 ? 4 : 1;
-    const int64_t nv = g.npix * (w / V);
-    const unsigned ne = (unsigned)std::min<int64_t>((nv + 255) / 256, 256 * 32);
-    auto bn_relu = [&](const float *h, const float *bias, const float *bn, float *a) {
-        if (V == 4) hipLaunchKernelGGL(k_g_bn_relu<4>, dim3(ne), dim3(256), 0, st, nv, w / 4, h, bias, bn, a);
-        else hipLaunchKernelGGL(k_g_bn_relu<1>, dim3(ne), dim3(256), 0, st, nv, w, h, bias, bn, a);
-    };
+    const bool v4 = w % 4 == 0;
+    const mm::PackAll pl = mm::pack_layout(w);
+    float *pk = t->gpack + (size_t)L.aux * gemm_pack_floats(w);   // this coupling's packed weights: written here, read again by the backward pass
+    hipLaunchKernelGGL(mm::k_mm_pack_all, dim3((unsigned)((pl.total + 255) / 256)), dim3(256), 0, st, w, pl, P + off_w1, P + off_w2, P + off_w3, pk);
     if (zpre) hipLaunchKernelGGL(k_mix_fwd, dim3(nb), dim3(TB), 0, st, g, zpre, A, const_cast<float *>(zin));
     hipLaunchKernelGGL(k_g_gather18, dim3(nb), dim3(TB), 0, st, g, zin, t->gz18);
+    const mm::Ctx cx{t->n_cu, t->device};
     bool ok = true;
-    if (V == 4 && t->gemm_c1_fused) {
+    mm::PixArgs a{};
+    a.P = g.npix;
+    a.nslot = g.nslot;
+    // ---- l_1: h1 = Z18 . W1 and the batch sums of h1 + b1 ----
+    if (v4 && t->gemm_c1_fused) {
         hipLaunchKernelGGL(k_g_c1_fwd, dim3(ns), dim3(256), 0, st, g, w, (const float *)t->gz18, P + off_w1, P + off_b1, c.h1, t->acc(c.d_st1));
     } else {
-        ok = gemm_rm(t, st, false, false, g.npix, w, 18, t->gz18, 18, P + off_w1, w, c.h1, w);
-        if (V == 4) hipLaunchKernelGGL(k_g_bias_stats, dim3(ns), dim3(256), 0, st, g, w, (const float *)c.h1, P + off_b1, t->acc(c.d_st1));
-        else hipLaunchKernelGGL(k_g_bias_stats_slow, dim3(ns), dim3(256), 0, st, g, w, (const float *)c.h1, P + off_b1, t->acc(c.d_st1));
+        a.N = w; a.K = kZ18;                                   // the two spare columns of Z18 and of the packed W1^T are zero
+        a.A = t->gz18; a.lda = kZ18;
+        a.Bt = pk + pl.o_w1t; a.ldb = 20;
+        a.C = c.h1; a.ldc = w;
+        a.ebias = P + off_b1; a.stats = t->acc(c.d_st1).p;
+        ok = mm::mm_pix<0, 1, 4>(cx, st, a) && ok;
     }
     sync_slots(t, t->acc(c.d_st1), 2 * w, g.nslot, st);
     hipLaunchKernelGGL(k_bn_fin, dim3(w), dim3(64), 0, st, t->acc(c.d_st1), w, g.nslot, n, t->d_params, off_m1, off_m1 + w, t->d_flt + c.f_bn1);
-    bn_relu(c.h1, P + off_b1, t->d_flt + c.f_bn1, c.a1);
-    ok = ok && gemm_rm(t, st, false, false, g.npix, w, w, c.a1, w, P + off_w2, w, c.h2, w);
-    if (V == 4) hipLaunchKernelGGL(k_g_bias_stats, dim3(ns), dim3(256), 0, st, g, w, (const float *)c.h2, P + off_b2, t->acc(c.d_st2));
-    else hipLaunchKernelGGL(k_g_bias_stats_slow, dim3(ns), dim3(256), 0, st, g, w, (const float *)c.h2, P + off_b2, t->acc(c.d_st2));
+    // ---- l_2: h2 = relu(bn1(h1 + b1)) . W2 and the batch sums of h2 + b2 ----
+    a.N = w; a.K = w;
+    a.A = c.h1; a.lda = w;
+    a.Bt = pk + pl.o_w2t; a.ldb = pl.w4;
+    a.C = c.h2; a.ldc = w;
+    a.abias = P + off_b1; a.abn = t->d_flt + c.f_bn1;
+    a.ebias = P + off_b2; a.stats = t->acc(c.d_st2).p;
+    ok = (v4 ? mm::mm_pix<1, 1, 4>(cx, st, a) : mm::mm_pix<1, 1, 1>(cx, st, a)) && ok;
     sync_slots(t, t->acc(c.d_st2), 2 * w, g.nslot, st);
     hipLaunchKernelGGL(k_bn_fin, dim3(w), dim3(64), 0, st, t->acc(c.d_st2), w, g.nslot, n, t->d_params, off_m2, off_m2 + w, t->d_flt + c.f_bn2);
-    bn_relu(c.h2, P + off_b2, t->d_flt + c.f_bn2, c.a2);
-    hipLaunchKernelGGL(k_g_pack_w3, dim3((w * 36 + 255) / 256), dim3(256), 0, st, w, P + off_w3, t->gw3r);
-    ok = ok && gemm_rm(t, st, false, false, g.npix, 36, w, c.a2, w, t->gw3r, 36, t->gp36, 36);
+    // ---- l_last, transposed: P36 = relu(bn2(h2 + b2)) . W3r ----
+    a.N = 36; a.K = w;
+    a.A = c.h2; a.lda = w;
+    a.Bt = pk + pl.o_w3a; a.ldb = pl.w4;
+    a.C = t->gp36; a.ldc = 36;
+    a.abias = P + off_b2; a.abn = t->d_flt + c.f_bn2;
+    a.ebias = nullptr; a.stats = nullptr;
+    ok = (v4 ? mm::mm_pix<1, 0, 4>(cx, st, a) : mm::mm_pix<1, 0, 1>(cx, st, a)) && ok;
     hipLaunchKernelGGL(k_g_c3_fwd, dim3(nb), dim3(TB), 0, st, g, w, zin, (const float *)t->gp36, P, off_w3, zout, ldacc, c.u);
     return ok;
 }
@@ -650,39 +423,82 @@ bool coupling_backward_gemm(nf_trainer *t, const Geo &g, const TLayer &L, const 
                             const float *A, Acc dA, hipStream_t st, const float *zlat)
 {
     const Cpl &c = t->cpl[L.aux];
-    const unsigned nb = blocks_for(g.npix), ns = gemm_grid(g);
+    const unsigned nb = blocks_for(g.npix);
     const int w = L.width, off_w1 = L.off, off_b1 = L.off + 18 * w, off_w2 = L.off + 21 * w, off_b2 = off_w2 + w * w,
               off_w3 = L.off + 24 * w + w * w;
+    (void)off_w1; (void)off_w2;
     const double n = (double)g.npix * t->sync_world;
-    const float *P = t->d_params, *bn1 = t->d_flt + c.f_bn1, *bn2 = t->d_flt + c.f_bn2;
+    const float *P = t->d_params, *bn1 = t->d_flt + c.f_bn1, *bn2 = t->d_flt + c.f_bn2, *bb1 = t->d_flt + c.f_bb1, *bb2 = t->d_flt + c.f_bb2;
     const Acc G = t->acc(0);
     float *t1 = t->t1[0], *t2 = t->t2[0], *gu = t->gu[0];
-    // this coupling's filter gradients: the partial products of the split GEMMs, summed when the step's gradients are assembled
+    const bool v4 = w % 4 == 0;
+    const mm::PackAll pl = mm::pack_layout(w);
+    const float *pk = t->gpack + (size_t)L.aux * gemm_pack_floats(w);   // packed by this step's forward pass
+    // this coupling's filter gradients: the partial products of the pixel-K GEMMs, summed when the step's gradients are assembled
     float *dW1 = t->gdw + (size_t)(3 * L.aux) * gemm_part_floats(w), *dW2 = dW1 + gemm_part_floats(w), *dW3r = dW2 + gemm_part_floats(w);
     int *np = t->gnp + 3 * L.aux;
     hipLaunchKernelGGL(k_g_c3_bwd, dim3(nb), dim3(TB), 0, st, g, w, zin, P, off_w3, invB, t->dz, gu, G, zlat, (const float *)c.u);
     hipLaunchKernelGGL(k_g_gather36, dim3(nb), dim3(TB), 0, st, g, w, (const float *)gu, t->gp36, off_w3, G);
-    hipLaunchKernelGGL(k_g_pack_w3, dim3((w * 36 + 255) / 256), dim3(256), 0, st, w, P + off_w3, t->gw3r);
-    bool ok = (np[2] = gemm_atb_split(t, st, w, 36, g.npix, c.a2, w, t->gp36, 36, dW3r)) > 0;         // d l_last/W = a2^T . G36
-    ok = ok && gemm_rm(t, st, false, true, g.npix, w, 36, t->gp36, 36, t->gw3r, 36, t1, w);          // g_a2 = G36 . W3r^T
-    const bool flat = w % 4 == 0;
-    hipLaunchKernelGGL(flat ? k_g_mask_stats : k_g_mask_stats_slow, dim3(ns), dim3(256), 0, st, g, w, (const float *)t1, (const float *)c.h2,
-                       P + off_b2, bn2, t->acc(c.d_bs2));
+    const mm::Ctx cx{t->n_cu, t->device};
+    bool ok = true;
+    mm::KpixArgs k{};
+    k.npix = g.npix;
+    k.nslot = g.nslot;
+    mm::PixArgs a{};
+    a.P = g.npix;
+    a.nslot = g.nslot;
+    // ---- d l_last/W = relu(bn2(h2 + b2))^T . G36 ----
+    k.M = w; k.N = 36;
+    k.A = c.h2; k.lda = w; k.B = t->gp36; k.ldb = 36; k.part = dW3r;
+    k.abias = P + off_b2; k.abn = bn2;
+    if (w > 64) np[2] = v4 ? mm::mm_kpix_launch<2, 2, 1, 1, 4, 4>(cx, st, k) : mm::mm_kpix_launch<2, 2, 1, 1, 1, 4>(cx, st, k);
+    else np[2] = v4 ? mm::mm_kpix_launch<2, 1, 1, 1, 4, 4>(cx, st, k) : mm::mm_kpix_launch<2, 1, 1, 1, 1, 4>(cx, st, k);
+    ok = ok && np[2] > 0;
+    // ---- g_a2 = G36 . W3r^T is a K = 36 product — cheap enough to form TWICE instead of passing a [pixel][w] tensor through
+    //      memory three more times: pass 1 leaves only the two batch sums of BN2's backward, pass 2 forms it again and stores
+    //      g_h2 = BN2 backward of the masked g_a2 (and adds up d b2)
+    a.N = w; a.K = 36;
+    a.A = t->gp36; a.lda = 36;
+    a.Bt = pk + pl.o_w3b; a.ldb = 36;
+    a.C = t1; a.ldc = w;
+    a.ebias = P + off_b2; a.ebn = bn2; a.eh = c.h2; a.ldh = w; a.stats = t->acc(c.d_bs2).p;
+    ok = mm::mm_pix<0, 4, 4>(cx, st, a) && ok;
     sync_slots(t, t->acc(c.d_bs2), 2 * w, g.nslot, st);
     hipLaunchKernelGGL(k_bnb_fin, dim3(w), dim3(64), 0, st, t->acc(c.d_bs2), w, g.nslot, n, t->d_flt + c.f_bb2);
-    hipLaunchKernelGGL(flat ? k_g_bn_bwd : k_g_bn_bwd_slow, dim3(ns), dim3(256), 0, st, g, w, t1, (const float *)c.h2, P + off_b2, bn2,
-                       (const float *)(t->d_flt + c.f_bb2), G + off_b2);
-    ok = ok && (np[1] = gemm_atb_split(t, st, w, w, g.npix, c.a1, w, t1, w, dW2)) > 0;                 // d l_2/W = a1^T . g_h2
-    ok = ok && gemm_rm(t, st, false, true, g.npix, w, w, t1, w, P + off_w2, w, t2, w);               // g_a1 = g_h2 . W2^T
-    hipLaunchKernelGGL(flat ? k_g_mask_stats : k_g_mask_stats_slow, dim3(ns), dim3(256), 0, st, g, w, (const float *)t2, (const float *)c.h1,
-                       P + off_b1, bn1, t->acc(c.d_bs1));
+    a.ebb = bb2; a.stats = (G + off_b2).p;
+    ok = mm::mm_pix<0, 3, 4>(cx, st, a) && ok;
+    // ---- d l_2/W = relu(bn1(h1 + b1))^T . g_h2 ----
+    k.M = w; k.N = w;
+    k.A = c.h1; k.lda = w; k.B = t1; k.ldb = w; k.part = dW2;
+    k.abias = P + off_b1; k.abn = bn1;
+    if (w > 64) np[1] = v4 ? mm::mm_kpix_launch<2, 2, 2, 1, 4, 4>(cx, st, k) : mm::mm_kpix_launch<2, 2, 2, 1, 1, 1>(cx, st, k);
+    else np[1] = v4 ? mm::mm_kpix_launch<2, 1, 1, 1, 4, 4>(cx, st, k) : mm::mm_kpix_launch<2, 1, 1, 1, 1, 1>(cx, st, k);
+    ok = ok && np[1] > 0;
+    // ---- g_a1 = g_h2 . W2^T and the two batch sums of BN1's backward ----
+    a.N = w; a.K = w;
+    a.A = t1; a.lda = w;
+    a.Bt = pk + pl.o_w2; a.ldb = pl.w4;
+    a.C = t2; a.ldc = w;
+    a.ebias = P + off_b1; a.ebn = bn1; a.eh = c.h1; a.ldh = w; a.ebb = nullptr; a.stats = t->acc(c.d_bs1).p;
+    ok = (v4 ? mm::mm_pix<0, 2, 4>(cx, st, a) : mm::mm_pix<0, 2, 1>(cx, st, a)) && ok;
     sync_slots(t, t->acc(c.d_bs1), 2 * w, g.nslot, st);
     hipLaunchKernelGGL(k_bnb_fin, dim3(w), dim3(64), 0, st, t->acc(c.d_bs1), w, g.nslot, n, t->d_flt + c.f_bb1);
-    hipLaunchKernelGGL(flat ? k_g_bn_bwd : k_g_bn_bwd_slow, dim3(ns), dim3(256), 0, st, g, w, t2, (const float *)c.h1, P + off_b1, bn1,
-                       (const float *)(t->d_flt + c.f_bb1), G + off_b1);
+    // ---- g_h1 = BN1 backward of the masked g_a1 is never stored: both of its consumers form it while they stage their tiles ----
+    // d l_1/W = Z18^T . g_h1 (and d b1 = its column sums) ;  Q = g_h1 . W1^T
     hipLaunchKernelGGL(k_g_gather18, dim3(nb), dim3(TB), 0, st, g, zin, t->gz18);
-    ok = ok && (np[0] = gemm_atb_split(t, st, 18, w, g.npix, t->gz18, 18, t2, w, dW1)) > 0;            // d l_1/W = Z18^T . g_h1
-    ok = ok && gemm_rm(t, st, false, true, g.npix, 18, w, t2, w, P + off_w1, w, t->gq18, 18);        // Q = g_h1 . W1^T
+    k.M = 18; k.N = w;
+    k.A = t->gz18; k.lda = kZ18; k.B = t2; k.ldb = w; k.part = dW1;
+    k.abias = nullptr; k.abn = nullptr;
+    k.B2 = c.h1; k.bbias = P + off_b1; k.bbn = bn1; k.bbb = bb1; k.dbias = (G + off_b1).p;
+    np[0] = v4 ? mm::mm_kpix_launch<1, 1, 2, 0, 1, 4, 2>(cx, st, k) : mm::mm_kpix_launch<1, 1, 2, 0, 1, 1, 2>(cx, st, k);
+    ok = ok && np[0] > 0;
+    a.N = 18; a.K = w;
+    a.A = t2; a.lda = w; a.A2 = c.h1;
+    a.abias = P + off_b1; a.abn = bn1; a.abb = bb1;
+    a.Bt = pk + pl.o_w1; a.ldb = pl.w4;
+    a.C = t->gq18; a.ldc = 18;
+    a.ebias = nullptr; a.ebn = nullptr; a.eh = nullptr; a.stats = nullptr;
+    ok = (v4 ? mm::mm_pix<2, 0, 4>(cx, st, a) : mm::mm_pix<2, 0, 1>(cx, st, a)) && ok;
     if (zmix_in)
         hipLaunchKernelGGL(k_g_c1_dz<true>, dim3(nb), dim3(TB), 0, st, g, (const float *)t->gq18, t->dz, zmix_in, A, dA);
     else

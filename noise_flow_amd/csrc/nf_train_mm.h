@@ -1,0 +1,916 @@
+// Dense products of the training step at coupling widths without stage kernels of their own (1 .. 512 except 4 / 8 / 16 / 32):
+// hand-written fp32 GEMMs on the matrix cores of gfx950 (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulation), with
+// what a library GEMM forces into separate passes over the [pixel][w] tensors fused into their prologues and epilogues.
+//
+//   k_mm_pix    C[pixel][n] = sum_k pro(A)[pixel][k] Bt[n][k]        pixels on the M axis (l_2, the transposed l_2 / l_last / l_1,
+//               l_last as 36 columns, l_1 at widths that are not a multiple of 4)
+//               prologue  APRO 1: A = relu(bn(h + bias)) formed from the pre-BN activation h while the tile is staged — the
+//                         normalised activations a1 / a2 never exist in memory
+//               epilogue  EPI 1: per-channel batch sums (sum, sum of squares) of C + bias       -> the slots k_bn_fin adds up
+//                         EPI 2: the two batch sums of BN's backward (sum gx, sum gx * xhat; gx = C where xhat(h) > 0)
+//   k_mm_kpix   part[s][m][n] = sum_{pixel in chunk s} pro(A)[pixel][m] B[pixel][n]     the filter gradients: K = the PIXELS of
+//               the minibatch, cut into chunks whose partial products k_g_store_grad adds in fp64 (bit-reproducible: no atomics)
+//
+// Tiles.  256 threads = 4 wavefronts; a wavefront owns up to 2 x 2 accumulator tiles of 32 x 32 (64 VGPRs) and per K step of 2
+// feeds 4 MFMAs (256 cycles of the matrix pipe) from 2 + 2 operand registers — one ds_read_b128 per operand tile per 4 K steps
+// in k_mm_pix, one ds_read_b64 per operand pair per step in k_mm_kpix.  Both operands go global -> registers -> (prologue) -> LDS,
+// double-buffered: the loads of K tile t + 1 are issued before the MFMAs of tile t and parked after them, one barrier per tile;
+// 2 workgroups per CU (66 KiB of LDS, <= 128 VGPRs) cover each other's barrier and epilogue.
+//   k_mm_pix LDS layout [k / 4][row (+1)][4]: a lane's float4 = 4 consecutive k of its row = its A / B registers of 4 MFMA steps
+//   (lane half g takes the k4 group 2 c + g of chunk c: the K order inside a chunk is permuted identically on both operands).
+//   The odd row pitch makes the 8-lane groups of ds_write_b128 and the 16-lane groups of ds_read_b128 conflict-free.
+//   k_mm_kpix LDS layout [pixel][channel] = the global layout; tile t of a wavefront takes the channels base + T r + t (r = MFMA
+//   row), so ONE 8-byte read serves both tiles of an operand.
+// Work split.  k_mm_pix: workgroup (n tile, m slot) walks the pixel tiles m slot, m slot + gm, ... and keeps the epilogue's batch
+// sums in registers until the end: one partial per channel and SLOT (the trainer's slotted reductions; every slot < nslot is
+// written).  Workgroup ids are dealt to the 8 XCDs round-robin by the hardware: ids that share an XCD share the A tile (all n
+// tiles of a pixel tile) resp. the pixel chunk (all output tiles of a chunk), so the operand crosses HBM -> L2 once.
+//
+// Replaces (reference, /root/reference): train_noise_flow.py:64-66 (one sess.run of train_op) with borealisflows/layers.py:452-498
+// (real_nvp_conv_template: conv2d -> batch_norm -> relu, twice, conv2d_zeros) and TF's gradients of it, at hps.width
+// (sidd/ArgParser.py:43: default 512).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <algorithm>
+#include <atomic>
+
+namespace {
+namespace mm {
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+constexpr int kSlotStride = 1024;   // floats between two values of a slotted accumulator group (= NSLOT of nf_train.hip)
+constexpr int kT = 256;             // threads per workgroup
+constexpr int kBK = 32;             // K extent of one staged tile (k_mm_pix: channels; k_mm_kpix: pixels)
+constexpr int kBM = 128;            // pixels per tile of k_mm_pix
+
+// normalised activation (layers.py:378-401 with the batch moments): the ONE expression the forward pass, the ReLU masks of the
+// backward pass and the pixel kernels of nf_train_gemm.h share (g_xhat there), so that a mask re-derived from h is the forward's
+__device__ __forceinline__ float xhat(float h, float b, float m, float rs) { return ((h + b) - m) * rs; }
+
+// BN backward of one value (k_g_bn_bwd of nf_train_gemm.h): g = d loss / d relu output, h = the pre-BN activation; ba, bq = the batch
+// means of gx and gx * xhat (gx = g where the forward's relu kept the value)
+__device__ __forceinline__ float bn_bwd(float g, float h, float b, float m, float rs, float ba, float bq)
+{
+    const float xh = xhat(h, b, m, rs);
+    return rs * ((xh > 0.0f ? g : 0.0f) - ba - xh * bq);
+}
+
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+// 4 floats from a 4-byte aligned address (parameter blocks)
+__device__ __forceinline__ float4 ld4u(const float *p) { return make_float4(p[0], p[1], p[2], p[3]); }
+__device__ __forceinline__ float f4c(const float4 &v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+
+// 4 consecutive floats of a row, zero beyond `n`.  V = 4: the row base and `at` are 16-byte aligned and n % 4 == 0
+template <int V>
+__device__ __forceinline__ float4 row4(const float *row, int at, int n)
+{
+    if constexpr (V == 4) {
+        return at < n ? ld4(row + at) : make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+        float4 v;
+        v.x = at + 0 < n ? row[at + 0] : 0.0f;
+        v.y = at + 1 < n ? row[at + 1] : 0.0f;
+        v.z = at + 2 < n ? row[at + 2] : 0.0f;
+        v.w = at + 3 < n ? row[at + 3] : 0.0f;
+        return v;
+    }
+}
+
+// floats of LDS k_mm_pix shares between its operand tiles (2 x 8 x (129 + BN + 1) float4), the finished tile on its way out
+// ([128][BN + 4]) and the final sums
+constexpr int pix_region0_floats(int BN)
+{
+    const int ops = 2 * 8 * (kBM + 1 + BN + 1) * 4, out = kBM * (BN + 4);
+    return ops > out ? ops : out;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct PixArgs {
+    int64_t P;              // pixels (rows of A and C)
+    int N, K;               // output channels, reduction length
+    const float *A;         // [P][lda]
+    int lda;
+    const float *Bt;        // packed weights [N][ldb]: 16-byte aligned, ldb % 4 == 0, zero in the columns K .. ldb - 1
+    int ldb;
+    float *C;               // [P][ldc]
+    int ldc;
+    const float *abias, *abn;        // APRO 1 / 2: bias [K] and (mean [K], rstd [K]) of the batch normalisation in front of A
+    const float *A2, *abb;           // APRO 2: the pre-BN activation [P][lda] beside A = d loss / d relu output, and BN backward's two batch means (ba [K], bq [K])
+    const float *ebias, *ebn, *eh;   // EPI 1: ebias [N].  EPI 2 / 3 / 4: ebias [N], ebn = (mean [N], rstd [N]), eh [P][ldh] = pre-BN activation
+    const float *ebb;                // EPI 3: BN backward's two batch means (ba [N], bq [N])
+    int ldh;
+    float *stats;           // EPI 1 / 2 / 4: value j (j < 2 N: the N sums, then the N second sums) of slot s at stats[j * kSlotStride + s]; EPI 3: N sums
+    int gm, nslot;          // m slots that take tiles (<= nslot); slots gm .. nslot - 1 are cleared
+    int n_tiles, m_tiles;
+};
+
+//   WN     wavefronts along the channel axis (1 or 2); 4 / WN along the pixel axis
+//   TN     32-channel tiles per wavefront: the workgroup's tile is 128 pixels x (32 WN TN) channels
+//   APRO   0: A as stored;  1: A = relu(xhat(A + bias));  2: A = BN backward of (A masked by xhat(A2) > 0)
+//   EPI    0: store;  1: + batch sums of C + bias;  2: + masked batch sums against xhat(eh);  4: those sums WITHOUT the store;
+//          3: store BN backward of the masked C (the batch means are known: second pass over a cheap product) + its column sums
+//   AV     4: A rows are 16-byte aligned and K % 4 == 0 (one global_load_dwordx4 per 4 k);  1: any width / alignment
+//   CV     4: C (and eh) rows are 16-byte aligned and N % 4 == 0: the tile leaves through LDS as whole 16-byte pieces of its rows
+//          (one global_store_dwordx4 / global_load_dwordx4 per 4 channels, 512 contiguous bytes per 32 lanes);  1: D registers
+//          straight to memory, 4 bytes per lane
+template <int WN, int TN, int APRO, int EPI, int AV, int CV>
+__global__ __launch_bounds__(kT) void k_mm_pix(const PixArgs a)
+{
+    constexpr int WM = 4 / WN, TM = kBM / (32 * WM), BN = WN * TN * 32;
+    constexpr int AP = kBM + 1, BP = BN + 1;   // float4 units per k4 row
+    constexpr int NB = BN / 32;                // B-tile float4s per thread
+    extern __shared__ __attribute__((aligned(16))) float mm_smem[];
+    constexpr int SP = BN + 4;                 // row pitch (floats) of the tile on its way out (CV 4)
+    constexpr int R0 = pix_region0_floats(BN); // the operand tiles; between two K loops the finished tile [128][SP]; at the end the sums
+    float4 *const sA = reinterpret_cast<float4 *>(mm_smem);   // [2][8][AP]
+    float4 *const sB = sA + 2 * 8 * AP;                        // [2][8][BP]
+    float *const stg = mm_smem;                                // [kBM][SP]
+    float *const red = mm_smem;                                // [2][WM or kT / (BN / 4)][BN]
+    float *const cst = mm_smem + R0;                           // APRO 1: [3][Kc] (bias, mean, rstd); APRO 2: [5][Kc] (+ ba, bq)
+    const int Kc = (a.K + kBK - 1) / kBK * kBK;
+
+    // ids that share an XCD (id % 8) and are neighbours there share the pixel tile
+    const int id = blockIdx.x, xcd = id & 7, q = id >> 3;
+    const int nt = q % a.n_tiles, ms = (q / a.n_tiles) * 8 + xcd;
+    if (ms >= a.gm) return;
+
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, n = lane & 31, g = lane >> 5;
+    const int wm = wv / WN, wn = wv % WN;
+    const int j = tid & 7, r0 = tid >> 3;      // staging: k4 group j of the rows r0 + 32 i
+    const int n0 = nt * BN;
+
+    if constexpr (APRO != 0) {
+        for (int i = tid; i < Kc; i += kT) {
+            cst[i] = i < a.K ? a.abias[i] : 0.0f;
+            cst[Kc + i] = i < a.K ? a.abn[i] : 0.0f;
+            cst[2 * Kc + i] = i < a.K ? a.abn[a.K + i] : 0.0f;
+            if constexpr (APRO == 2) {
+                cst[3 * Kc + i] = i < a.K ? a.abb[i] : 0.0f;
+                cst[4 * Kc + i] = i < a.K ? a.abb[a.K + i] : 0.0f;
+            }
+        }
+        __syncthreads();
+    }
+
+    // epilogue constants: a lane's channels are n0 + wn TN 32 + tn 32 + n for every tile it ever computes
+    [[maybe_unused]] float s4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};   // CV 4: this thread's 4 channels (n0 + 4 (tid % (BN / 4)) ...)
+    [[maybe_unused]] float eb[TN], em[TN], er[TN], ea[TN], eq[TN], ssum[TN], qsum[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int ch = n0 + (wn * TN + tn) * 32 + n;
+        eb[tn] = (EPI != 0 && ch < a.N) ? a.ebias[ch] : 0.0f;
+        em[tn] = (EPI >= 2 && ch < a.N) ? a.ebn[ch] : 0.0f;
+        er[tn] = (EPI >= 2 && ch < a.N) ? a.ebn[a.N + ch] : 0.0f;
+        ea[tn] = (EPI == 3 && ch < a.N) ? a.ebb[ch] : 0.0f;
+        eq[tn] = (EPI == 3 && ch < a.N) ? a.ebb[a.N + ch] : 0.0f;
+        ssum[tn] = 0.0f;
+        qsum[tn] = 0.0f;
+    }
+
+    // B rows of this workgroup's tile (fixed over the pixel tiles)
+    const float *brow[NB];
+    float bmask[NB];           // rows beyond N: a valid row is loaded and multiplied away (no branch around the load)
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int r = n0 + r0 + 32 * i;
+        bmask[i] = r < a.N ? 1.0f : 0.0f;
+        brow[i] = a.Bt + (size_t)(r < a.N ? r : 0) * a.ldb;
+    }
+    const int nkt = Kc / kBK;
+    const int nkt_full = a.K / kBK;   // K tiles every load of which is in range (ldb >= K)
+
+    for (int64_t mt = ms; mt < a.m_tiles; mt += a.gm) {
+        const int64_t m0 = mt * kBM;
+        const float *arow[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int64_t r = m0 + r0 + 32 * i;
+            r = r < a.P ? r : a.P - 1;        // rows past the end: loaded (valid memory), never stored nor summed
+            arow[i] = a.A + r * a.lda;
+        }
+        v16f acc[TM][TN];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[tm][tn][v] = 0.0f;
+
+        // Staging registers (ONE set: the loads of K tile t + 1 are issued before the MFMAs of tile t and parked after them.  A
+        // second set with two tiles of lead was measured SLOWER, 630 -> 654 us for the plain 512 product: the parking wait is not
+        // what the feed costs — removing the loads altogether gains 10 %, removing the barrier 2 %)
+        struct Stage {
+            float4 ra[4], rb[NB], rh[APRO == 2 ? 4 : 1];
+        };
+        Stage R0;
+        [[maybe_unused]] const float *hrow[4];
+        if constexpr (APRO == 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hrow[i] = a.A2 + (arow[i] - a.A);
+        }
+        auto fetch = [&](int kt, Stage &R) {
+            const int k = kt * kBK + 4 * j;
+            if (kt < nkt_full) {     // workgroup-uniform: the whole tile is inside K, no predicates around the loads
+#pragma unroll
+                for (int i = 0; i < 4; ++i) R.ra[i] = row4<AV>(arow[i], k, k + 4);
+                if constexpr (APRO == 2) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) R.rh[i] = row4<AV>(hrow[i], k, k + 4);
+                }
+#pragma unroll
+                for (int i = 0; i < NB; ++i) R.rb[i] = ld4(brow[i] + k);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) R.ra[i] = row4<AV>(arow[i], k, a.K);
+                if constexpr (APRO == 2) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) R.rh[i] = row4<AV>(hrow[i], k, a.K);
+                }
+#pragma unroll
+                for (int i = 0; i < NB; ++i) R.rb[i] = k < a.ldb ? ld4(brow[i] + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        auto park = [&](int kt, int buf, Stage &R) {
+            if constexpr (APRO == 1) {
+                const int k = kt * kBK + 4 * j;
+                const float4 cb = ld4(cst + k), cm = ld4(cst + Kc + k), cr = ld4(cst + 2 * Kc + k);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    R.ra[i].x = fmaxf(xhat(R.ra[i].x, cb.x, cm.x, cr.x), 0.0f);
+                    R.ra[i].y = fmaxf(xhat(R.ra[i].y, cb.y, cm.y, cr.y), 0.0f);
+                    R.ra[i].z = fmaxf(xhat(R.ra[i].z, cb.z, cm.z, cr.z), 0.0f);
+                    R.ra[i].w = fmaxf(xhat(R.ra[i].w, cb.w, cm.w, cr.w), 0.0f);
+                }
+            } else if constexpr (APRO == 2) {
+                const int k = kt * kBK + 4 * j;
+                const float4 cb = ld4(cst + k), cm = ld4(cst + Kc + k), cr = ld4(cst + 2 * Kc + k), ca = ld4(cst + 3 * Kc + k), cq = ld4(cst + 4 * Kc + k);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    R.ra[i].x = bn_bwd(R.ra[i].x, R.rh[i].x, cb.x, cm.x, cr.x, ca.x, cq.x);
+                    R.ra[i].y = bn_bwd(R.ra[i].y, R.rh[i].y, cb.y, cm.y, cr.y, ca.y, cq.y);
+                    R.ra[i].z = bn_bwd(R.ra[i].z, R.rh[i].z, cb.z, cm.z, cr.z, ca.z, cq.z);
+                    R.ra[i].w = bn_bwd(R.ra[i].w, R.rh[i].w, cb.w, cm.w, cr.w, ca.w, cq.w);
+                }
+            }
+            float4 *da = sA + (buf * 8 + j) * AP + r0, *db = sB + (buf * 8 + j) * BP + r0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) da[32 * i] = R.ra[i];
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+                db[32 * i] = make_float4(R.rb[i].x * bmask[i], R.rb[i].y * bmask[i], R.rb[i].z * bmask[i], R.rb[i].w * bmask[i]);
+        };
+        // the 4 chunks of 8 k of one staged tile.  Every tile runs all of them: beyond K both operands hold zeros (a ragged K costs
+        // MFMA time in the last tile only; guarding the chunks with uniform branches was measured SLOWER — the wait-count pass then
+        // also waits for the prefetched operands at every join).  Operand registers in ping-pong: the LDS reads of chunk c + 1 are
+        // ISSUED before the 16 MFMAs of chunk c (left alone, the machine scheduler sinks them to just before their first use and
+        // every chunk starts with an exposed LDS round trip)
+        auto compute = [&](int buf) {
+            const float4 *pa = sA + (buf * 8 + g) * AP + wm * TM * 32 + n;
+            const float4 *pb = sB + (buf * 8 + g) * BP + wn * TN * 32 + n;
+            float4 af[2][TM], bf[2][TN];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) af[0][tm] = pa[tm * 32];
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) bf[0][tn] = pb[tn * 32];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (c + 1 < 4) {
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm) af[(c + 1) & 1][tm] = pa[2 * (c + 1) * AP + tm * 32];
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) bf[(c + 1) & 1][tn] = pb[2 * (c + 1) * BP + tn * 32];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                        for (int tn = 0; tn < TN; ++tn)
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4c(af[c & 1][tm], s), f4c(bf[c & 1][tn], s), acc[tm][tn], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+
+#ifndef MM_ABL
+#define MM_ABL 0   // tools/probes/mm_probe.hip only: 1 = no barrier in the K loop, 2 = no global loads in it, 4 = no LDS writes in it (timing ablations; results are wrong)
+#endif
+        fetch(0, R0);
+        park(0, 0, R0);
+        __syncthreads();
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < nkt && !(MM_ABL & 2)) fetch(kt + 1, R0);
+            compute(buf);
+            if (kt + 1 < nkt && !(MM_ABL & 4)) park(kt + 1, buf ^ 1, R0);
+            if (!(MM_ABL & 1)) __syncthreads();
+        }
+
+        // ---- epilogue: D register v of lane (n, g) = pixel 8 (v >> 2) + 4 g + (v & 3) of the tile, channel n ----
+        if constexpr (CV == 4) {
+            // through LDS (the operand tiles are dead: every wavefront is past the K loop's last barrier): D registers -> [pixel][SP]
+            // (32 lanes = 32 consecutive channels: conflict-free), then every thread takes 16-byte pieces of the rows — its 4 channels
+            // are the same for every row and every tile, so the batch sums stay in 8 registers until the kernel ends
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    float *d = stg + ((wm * TM + tm) * 32 + 4 * g) * SP + (wn * TN + tn) * 32 + n;
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) d[(8 * (v >> 2) + (v & 3)) * SP] = acc[tm][tn][v];
+                }
+            __syncthreads();
+            constexpr int Q = BN / 4, RS = kT / Q, PASS = kBM / RS;   // float4 per row, rows per pass, passes
+            const int c4 = tid % Q, rr = tid / Q, ch = n0 + 4 * c4;
+            if (ch < a.N) {
+                [[maybe_unused]] float4 kb, km, kr, ka, kq;
+                if constexpr (EPI != 0) kb = ld4u(a.ebias + ch);
+                if constexpr (EPI >= 2) {
+                    km = ld4u(a.ebn + ch);
+                    kr = ld4u(a.ebn + a.N + ch);
+                }
+                if constexpr (EPI == 3) {
+                    ka = ld4u(a.ebb + ch);
+                    kq = ld4u(a.ebb + a.N + ch);
+                }
+                // (loads and stores share one in-order counter: ALL pre-BN activations of the thread's pieces are requested first —
+                // one memory round trip per tile, not one per group of rows)
+                [[maybe_unused]] float4 hv[EPI >= 2 ? PASS : 1];
+                if constexpr (EPI >= 2) {
+#pragma unroll
+                    for (int i = 0; i < PASS; ++i) {
+                        const int64_t p = m0 + rr + RS * i;
+                        hv[i] = p < a.P ? ld4(a.eh + p * a.ldh + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < PASS; ++i) {
+                    const int r = rr + RS * i;
+                    const int64_t p = m0 + r;
+                    if (p >= a.P) continue;
+                    float4 v = *reinterpret_cast<const float4 *>(stg + r * SP + 4 * c4);
+                    if constexpr (EPI == 1) {
+                        const float x0 = v.x + kb.x, x1 = v.y + kb.y, x2 = v.z + kb.z, x3 = v.w + kb.w;
+                        s4[0] += x0; s4[1] += x1; s4[2] += x2; s4[3] += x3;
+                        q4[0] = fmaf(x0, x0, q4[0]); q4[1] = fmaf(x1, x1, q4[1]); q4[2] = fmaf(x2, x2, q4[2]); q4[3] = fmaf(x3, x3, q4[3]);
+                    } else if constexpr (EPI == 2 || EPI == 4) {
+                        const float h0 = xhat(hv[i].x, kb.x, km.x, kr.x), h1 = xhat(hv[i].y, kb.y, km.y, kr.y), h2 = xhat(hv[i].z, kb.z, km.z, kr.z),
+                                    h3 = xhat(hv[i].w, kb.w, km.w, kr.w);
+                        const float g0 = h0 > 0.f ? v.x : 0.f, g1 = h1 > 0.f ? v.y : 0.f, g2 = h2 > 0.f ? v.z : 0.f, g3 = h3 > 0.f ? v.w : 0.f;
+                        s4[0] += g0; s4[1] += g1; s4[2] += g2; s4[3] += g3;
+                        q4[0] = fmaf(g0, h0, q4[0]); q4[1] = fmaf(g1, h1, q4[1]); q4[2] = fmaf(g2, h2, q4[2]); q4[3] = fmaf(g3, h3, q4[3]);
+                    } else if constexpr (EPI == 3) {
+                        v.x = bn_bwd(v.x, hv[i].x, kb.x, km.x, kr.x, ka.x, kq.x);
+                        v.y = bn_bwd(v.y, hv[i].y, kb.y, km.y, kr.y, ka.y, kq.y);
+                        v.z = bn_bwd(v.z, hv[i].z, kb.z, km.z, kr.z, ka.z, kq.z);
+                        v.w = bn_bwd(v.w, hv[i].w, kb.w, km.w, kr.w, ka.w, kq.w);
+                        s4[0] += v.x; s4[1] += v.y; s4[2] += v.z; s4[3] += v.w;
+                    }
+                    if constexpr (EPI != 4) *reinterpret_cast<float4 *>(a.C + p * a.ldc + ch) = v;
+                }
+            }
+            __syncthreads();   // the next tile's operands overwrite the region
+        } else {
+        const bool whole = m0 + kBM <= a.P && n0 + BN <= a.N;   // workgroup-uniform: no per-element predicates
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const int ch = n0 + (wn * TN + tn) * 32 + n;
+                const bool chok = ch < a.N;
+                const int64_t pb0 = m0 + (wm * TM + tm) * 32 + 4 * g;
+                float *const cp = a.C + pb0 * a.ldc + ch;
+                [[maybe_unused]] const float *const hp = EPI >= 2 ? a.eh + pb0 * a.ldh + ch : nullptr;
+                // the 16 pre-BN activations this lane needs, requested together and BEFORE any store of the tile: loads and stores
+                // share one in-order counter (vmcnt), so a load issued behind a store waits for that store's round trip
+                [[maybe_unused]] float hv[EPI >= 2 ? 16 : 1];
+                if constexpr (EPI >= 2) {
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        const int dp = 8 * (v >> 2) + (v & 3);
+                        hv[v] = (whole || (chok && pb0 + dp < a.P)) ? hp[(int64_t)dp * a.ldh] : 0.0f;
+                    }
+                }
+                auto one = [&](int v) {
+                    const int dp = 8 * (v >> 2) + (v & 3);
+                    const float val = acc[tm][tn][v];
+                    if constexpr (EPI <= 2) cp[(int64_t)dp * a.ldc] = val;
+                    if constexpr (EPI == 1) {
+                        const float x = val + eb[tn];
+                        ssum[tn] += x;
+                        qsum[tn] = fmaf(x, x, qsum[tn]);
+                    } else if constexpr (EPI == 2 || EPI == 4) {
+                        const float xh = xhat(hv[v], eb[tn], em[tn], er[tn]);
+                        const float gx = xh > 0.0f ? val : 0.0f;
+                        ssum[tn] += gx;
+                        qsum[tn] = fmaf(gx, xh, qsum[tn]);
+                    } else if constexpr (EPI == 3) {
+                        const float o = bn_bwd(val, hv[v], eb[tn], em[tn], er[tn], ea[tn], eq[tn]);
+                        cp[(int64_t)dp * a.ldc] = o;
+                        ssum[tn] += o;
+                    }
+                };
+                if (whole) {
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) one(v);
+                } else if (chok) {
+#pragma unroll
+                    for (int v = 0; v < 16; ++v)
+                        if (pb0 + 8 * (v >> 2) + (v & 3) < a.P) one(v);
+                }
+            }
+            }
+    }
+
+    if constexpr (EPI != 0 && CV == 4) {
+        // one partial per channel and slot: the kT / (BN / 4) threads that share 4 channels meet in LDS
+        constexpr int Q = BN / 4, RS = kT / Q;
+        const int c4 = tid % Q, rr = tid / Q;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            red[rr * BN + 4 * c4 + i] = s4[i];
+            red[(RS + rr) * BN + 4 * c4 + i] = q4[i];
+        }
+        __syncthreads();
+        for (int c = tid; c < BN; c += kT) {
+            const int ch = n0 + c;
+            if (ch >= a.N) continue;
+            float s = 0.0f, qq = 0.0f;
+#pragma unroll
+            for (int w = 0; w < RS; ++w) {
+                s += red[w * BN + c];
+                qq += red[(RS + w) * BN + c];
+            }
+            float *ps = a.stats + (size_t)ch * kSlotStride, *pq = a.stats + (size_t)(a.N + ch) * kSlotStride;
+            ps[ms] = s;
+            if (EPI != 3) pq[ms] = qq;
+            for (int k = ms + a.gm; k < a.nslot; k += a.gm) {   // the slots nobody owns
+                ps[k] = 0.0f;
+                if (EPI != 3) pq[k] = 0.0f;
+            }
+        }
+    }
+    if constexpr (EPI != 0 && CV != 4) {
+        // one partial per channel and slot: lane halves, then the WM wavefronts that share the channels
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            ssum[tn] += __shfl_xor(ssum[tn], 32);
+            qsum[tn] += __shfl_xor(qsum[tn], 32);
+        }
+        __syncthreads();
+        if (g == 0) {
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                red[wm * BN + (wn * TN + tn) * 32 + n] = ssum[tn];
+                red[(WM + wm) * BN + (wn * TN + tn) * 32 + n] = qsum[tn];
+            }
+        }
+        __syncthreads();
+        for (int c = tid; c < BN; c += kT) {
+            const int ch = n0 + c;
+            if (ch >= a.N) continue;
+            float s = 0.0f, qq = 0.0f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) {
+                s += red[w * BN + c];
+                qq += red[(WM + w) * BN + c];
+            }
+            float *ps = a.stats + (size_t)ch * kSlotStride, *pq = a.stats + (size_t)(a.N + ch) * kSlotStride;
+            ps[ms] = s;
+            if (EPI != 3) pq[ms] = qq;
+            for (int k = ms + a.gm; k < a.nslot; k += a.gm) {   // the slots nobody owns
+                ps[k] = 0.0f;
+                if (EPI != 3) pq[k] = 0.0f;
+            }
+        }
+    }
+}
+
+template <int WN, int TN>
+constexpr size_t pix_lds_bytes(int K, int apro)
+{
+    constexpr int BN = WN * TN * 32;
+    return ((size_t)pix_region0_floats(BN) + (apro == 2 ? 5 : apro ? 3 : 0) * (size_t)((K + kBK - 1) / kBK * kBK)) * sizeof(float);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct KpixArgs {
+    int64_t npix;
+    int M, N;               // output rows (channels of A), columns (channels of B)
+    const float *A;         // [npix][lda]
+    int lda;
+    const float *B;         // [npix][ldb]
+    int ldb;
+    float *part;            // [S][M][N]
+    int64_t chunk;          // pixels per partial product (a multiple of kBK)
+    int S;                  // partial products
+    int m_tiles, n_tiles;
+    const float *abias, *abn;   // APRO 1: bias [M], (mean [M], rstd [M]): A = relu(xhat(A + bias))
+    const float *B2, *bbias, *bbn, *bbb;   // BPRO 2: B = BN backward of (B masked by xhat(B2) > 0): pre-BN activation [npix][ldb], bias [N], (mean, rstd), (ba, bq)
+    float *dbias;               // BPRO 2: the column sums of that B (= d bias) as slotted partials: value n of slot s at dbias[n * kSlotStride + s]
+    int nslot;                  // BPRO 2: S <= nslot; the slots S .. nslot - 1 are cleared
+};
+
+//   WMv       wavefronts along M (1, 2, 4); 4 / WMv along N
+//   TM, TN    32-channel tiles per wavefront along M / N (1 or 2): the workgroup's tile is (32 WMv TM) x (32 (4 / WMv) TN)
+//   AV, BV    4: the operand's rows are 16-byte aligned and its width is a multiple of 4;  1: anything
+//   BPRO      0: B as stored;  2: B = BN backward of the masked B, formed while the tile is staged (and its column sums = d bias)
+template <int WMv, int TM, int TN, int APRO, int AV, int BV, int BPRO = 0>
+__global__ __launch_bounds__(kT) void k_mm_kpix(const KpixArgs a)
+{
+    constexpr int WNv = 4 / WMv, BM = WMv * TM * 32, BN = WNv * TN * 32;
+    extern __shared__ __attribute__((aligned(16))) float mm_smem[];
+    float *const sA = mm_smem;                 // [2][kBK][BM]
+    float *const sB = sA + 2 * kBK * BM;       // [2][kBK][BN]
+
+    const int tiles = a.m_tiles * a.n_tiles;
+    const int id = blockIdx.x, xcd = id & 7, q = id >> 3;
+    const int tile = q % tiles, s = (q / tiles) * 8 + xcd;   // the tiles of one pixel chunk share an XCD
+    if (s >= a.S) return;
+    const int m0 = (tile / a.n_tiles) * BM, n0 = (tile % a.n_tiles) * BN;
+    const int64_t p0 = (int64_t)s * a.chunk, p1 = p0 + a.chunk < a.npix ? p0 + a.chunk : a.npix;
+
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, n = lane & 31, g = lane >> 5;
+    const int wm = wv / WNv, wn = wv % WNv;
+
+    // staging: thread -> a fixed channel group (so the prologue's constants stay in registers), RS pixel rows apart
+    constexpr int AQ = AV == 4 ? BM / 4 : BM, ARS = kT / AQ, APASS = kBK / ARS;
+    constexpr int BQ = BV == 4 ? BN / 4 : BN, BRS = kT / BQ, BPASS = kBK / BRS;
+    static_assert(kT % AQ == 0 && kT % BQ == 0 && kBK % ARS == 0 && kBK % BRS == 0 && APASS >= 1 && BPASS >= 1, "staging split");
+    const int acq = tid % AQ, apr = tid / AQ, bcq = tid % BQ, bpr = tid / BQ;
+    const int ac = m0 + AV * acq, bc = n0 + BV * bcq;      // first channel this thread stages
+    float4 cb = make_float4(0.f, 0.f, 0.f, 0.f), cm = cb, cr = cb;
+    if constexpr (APRO == 1) {
+        float t[12];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool ok = i < AV && ac + i < a.M;
+            t[i] = ok ? a.abias[ac + i] : 0.0f;
+            t[4 + i] = ok ? a.abn[ac + i] : 0.0f;
+            t[8 + i] = ok ? a.abn[a.M + ac + i] : 0.0f;
+        }
+        cb = make_float4(t[0], t[1], t[2], t[3]);
+        cm = make_float4(t[4], t[5], t[6], t[7]);
+        cr = make_float4(t[8], t[9], t[10], t[11]);
+    }
+
+    [[maybe_unused]] float kb[4], km[4], kr[4], ka[4], kq[4], dsum[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (BPRO == 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool ok = i < BV && bc + i < a.N;
+            kb[i] = ok ? a.bbias[bc + i] : 0.0f;
+            km[i] = ok ? a.bbn[bc + i] : 0.0f;
+            kr[i] = ok ? a.bbn[a.N + bc + i] : 0.0f;
+            ka[i] = ok ? a.bbb[bc + i] : 0.0f;
+            kq[i] = ok ? a.bbb[a.N + bc + i] : 0.0f;
+        }
+    }
+    const bool sums = BPRO == 2 && tile / a.n_tiles == 0;   // one workgroup row adds up d bias (every m tile stages the same B)
+
+    v16f acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[tm][tn][v] = 0.0f;
+
+    float4 ra[AV == 4 ? APASS : (APASS + 3) / 4], rb[BV == 4 ? BPASS : (BPASS + 3) / 4];
+    float sa1[AV == 4 ? 1 : APASS], sb1[BV == 4 ? 1 : BPASS];
+    [[maybe_unused]] float4 rh[(BPRO == 2 && BV == 4) ? BPASS : 1];
+    [[maybe_unused]] float sh1[(BPRO == 2 && BV == 1) ? BPASS : 1];
+    [[maybe_unused]] int64_t bpk = 0;   // first pixel of the tile the B registers hold
+    auto fetch = [&](int64_t pk) {
+        if constexpr (AV == 4) {
+#pragma unroll
+            for (int i = 0; i < APASS; ++i) {
+                const int64_t p = pk + apr + ARS * i;
+                ra[i] = (p < p1 && ac < a.M) ? ld4(a.A + p * a.lda + ac) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < APASS; ++i) {
+                const int64_t p = pk + apr + ARS * i;
+                sa1[i] = (p < p1 && ac < a.M) ? a.A[p * a.lda + ac] : 0.0f;
+            }
+        }
+        bpk = pk;
+        if constexpr (BV == 4) {
+#pragma unroll
+            for (int i = 0; i < BPASS; ++i) {
+                const int64_t p = pk + bpr + BRS * i;
+                const bool ok = p < p1 && bc < a.N;
+                rb[i] = ok ? ld4(a.B + p * a.ldb + bc) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (BPRO == 2) rh[i] = ok ? ld4(a.B2 + p * a.ldb + bc) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < BPASS; ++i) {
+                const int64_t p = pk + bpr + BRS * i;
+                const bool ok = p < p1 && bc < a.N;
+                sb1[i] = ok ? a.B[p * a.ldb + bc] : 0.0f;
+                if constexpr (BPRO == 2) sh1[i] = ok ? a.B2[p * a.ldb + bc] : 0.0f;
+            }
+        }
+    };
+    auto park = [&](int buf) {
+        float *da = sA + buf * kBK * BM, *db = sB + buf * kBK * BN;
+        if constexpr (AV == 4) {
+#pragma unroll
+            for (int i = 0; i < APASS; ++i) {
+                float4 v = ra[i];
+                if constexpr (APRO == 1) {
+                    v.x = fmaxf(xhat(v.x, cb.x, cm.x, cr.x), 0.0f);
+                    v.y = fmaxf(xhat(v.y, cb.y, cm.y, cr.y), 0.0f);
+                    v.z = fmaxf(xhat(v.z, cb.z, cm.z, cr.z), 0.0f);
+                    v.w = fmaxf(xhat(v.w, cb.w, cm.w, cr.w), 0.0f);
+                }
+                *reinterpret_cast<float4 *>(da + (apr + ARS * i) * BM + 4 * acq) = v;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < APASS; ++i) {
+                float v = sa1[i];
+                if constexpr (APRO == 1) v = fmaxf(xhat(v, cb.x, cm.x, cr.x), 0.0f);
+                da[(apr + ARS * i) * BM + acq] = v;
+            }
+        }
+        if constexpr (BV == 4) {
+#pragma unroll
+            for (int i = 0; i < BPASS; ++i) {
+                float4 v = rb[i];
+                if constexpr (BPRO == 2) {
+                    const bool in = bpk + bpr + BRS * i < p1 && bc < a.N;     // rows past the chunk stay zero (and out of d bias)
+                    v.x = in ? bn_bwd(v.x, rh[i].x, kb[0], km[0], kr[0], ka[0], kq[0]) : 0.0f;
+                    v.y = in ? bn_bwd(v.y, rh[i].y, kb[1], km[1], kr[1], ka[1], kq[1]) : 0.0f;
+                    v.z = in ? bn_bwd(v.z, rh[i].z, kb[2], km[2], kr[2], ka[2], kq[2]) : 0.0f;
+                    v.w = in ? bn_bwd(v.w, rh[i].w, kb[3], km[3], kr[3], ka[3], kq[3]) : 0.0f;
+                    dsum[0] += v.x; dsum[1] += v.y; dsum[2] += v.z; dsum[3] += v.w;
+                }
+                *reinterpret_cast<float4 *>(db + (bpr + BRS * i) * BN + 4 * bcq) = v;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < BPASS; ++i) {
+                float v = sb1[i];
+                if constexpr (BPRO == 2) {
+                    const bool in = bpk + bpr + BRS * i < p1 && bc < a.N;
+                    v = in ? bn_bwd(v, sh1[i], kb[0], km[0], kr[0], ka[0], kq[0]) : 0.0f;
+                    dsum[0] += v;
+                }
+                db[(bpr + BRS * i) * BN + bcq] = v;
+            }
+        }
+    };
+
+    const int nkt = (int)((p1 - p0 + kBK - 1) / kBK);
+    if (nkt > 0) {
+        fetch(p0);
+        park(0);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nkt) fetch(p0 + (int64_t)(kt + 1) * kBK);
+        const float *pa = sA + buf * kBK * BM + g * BM + wm * TM * 32 + TM * n;
+        const float *pb = sB + buf * kBK * BN + g * BN + wn * TN * 32 + TN * n;
+#pragma unroll
+        for (int st = 0; st < kBK / 2; ++st) {
+            float av[TM], bv[TN];
+            if constexpr (TM == 2) {
+                const float2 t = *reinterpret_cast<const float2 *>(pa + 2 * st * BM);
+                av[0] = t.x;
+                av[1] = t.y;
+            } else {
+                av[0] = pa[2 * st * BM];
+            }
+            if constexpr (TN == 2) {
+                const float2 t = *reinterpret_cast<const float2 *>(pb + 2 * st * BN);
+                bv[0] = t.x;
+                bv[1] = t.y;
+            } else {
+                bv[0] = pb[2 * st * BN];
+            }
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm], bv[tn], acc[tm][tn], 0, 0, 0);
+        }
+        if (kt + 1 < nkt) park(buf ^ 1);
+        __syncthreads();
+    }
+
+    // D register v of lane (n, g): MFMA row r = 8 (v >> 2) + 4 g + (v & 3) -> channel m0 + wm TM 32 + TM r + tm; column n -> n0 + wn TN 32 + TN n + tn
+    float *const out = a.part + (size_t)s * a.M * a.N;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int col = n0 + wn * TN * 32 + TN * n + tn;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int row = m0 + wm * TM * 32 + TM * (8 * (v >> 2) + 4 * g + (v & 3)) + tm;
+                if (row < a.M && col < a.N) out[(size_t)row * a.N + col] = acc[tm][tn][v];
+            }
+        }
+
+    if constexpr (BPRO == 2) {
+        if (!sums) return;                       // workgroup-uniform
+        // the BRS threads that staged the same channels meet in LDS (the tiles are dead); one partial per channel and chunk = slot
+        float *const red = mm_smem;              // [BRS][BN]
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < BV; ++i) red[bpr * BN + BV * bcq + i] = dsum[i];
+        __syncthreads();
+        for (int c = tid; c < BN; c += kT) {
+            const int ch = n0 + c;
+            if (ch >= a.N) continue;
+            float tot = 0.0f;
+            for (int r = 0; r < BRS; ++r) tot += red[r * BN + c];
+            float *pd = a.dbias + (size_t)ch * kSlotStride;
+            pd[s] = tot;
+            for (int k = s + a.S; k < a.nslot; k += a.S) pd[k] = 0.0f;   // the slots nobody owns
+        }
+    }
+}
+
+template <int WMv, int TM, int TN>
+constexpr size_t kpix_lds_bytes()
+{
+    return (size_t)2 * kBK * (WMv * TM * 32 + (4 / WMv) * TN * 32) * sizeof(float);   // (>= the [BRS][BN] floats of the d-bias reduction)
+}
+
+// ---- weights into the layout k_mm_pix reads: dst [rows][ld], ld % 4 == 0, zero beyond `cols` ----------------------------------
+//   mode 0  dst[r][c] = src[r * cols + c]                         (Bt = the matrix as stored)
+//   mode 1  dst[r][c] = src[c * rows + r]                         (Bt = its transpose)
+//   mode 2  dst[tap*4 + k][i] = l_last/W[tap][i][k], i < w        (rows = 36, cols = w: the 36 columns of l_last's transposed evaluation)
+//   mode 3  dst[i][tap*4 + k] = l_last/W[tap][i][k]               (rows = w, cols = 36)
+__global__ void k_mm_pack(int mode, int rows, int cols, int ld, int w, const float *__restrict__ src, float *__restrict__ dst)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= rows * ld) return;
+    const int r = e / ld, c = e - r * ld;
+    float v = 0.0f;
+    if (c < cols) {
+        if (mode == 0) v = src[(size_t)r * cols + c];
+        else if (mode == 1) v = src[(size_t)c * rows + r];
+        else if (mode == 2) v = src[((size_t)(r >> 2) * (w + 1) + c) * 4 + (r & 3)];
+        else v = src[((size_t)(c >> 2) * (w + 1) + r) * 4 + (c & 3)];
+    }
+    dst[e] = v;
+}
+
+// ---- launches (host) ----------------------------------------------------------------------------------------------------------
+struct Ctx {
+    int n_cu, device;
+};
+
+// floats of partial products one filter gradient may leave (k_mm_kpix: S x M x N)
+constexpr int64_t kGradPartFloats = (int64_t)1 << 24;   // 64 MiB per filter
+
+// dynamic LDS beyond 64 KiB has to be enabled per kernel (once per device; racy but idempotent).  `cur` = the caller's static
+// per-instantiation record of what was enabled so far
+inline bool mm_enable_lds(const void *fn, size_t lds, int device, std::atomic<size_t> (&cur)[16])
+{
+    std::atomic<size_t> &c = cur[device & 15];
+    if (lds > c.load(std::memory_order_relaxed) || device > 15) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+        c.store(lds, std::memory_order_relaxed);
+    }
+    return true;
+}
+
+// C[P x N] = pro(A) . Bt^T with the prologue / epilogue of the template (nf_train_mm.h); `a` carries everything but the work split
+template <int WN, int TN, int APRO, int EPI, int AV, int CV>
+inline bool mm_pix_launch(const Ctx &cx, hipStream_t st, PixArgs a)
+{
+    constexpr int BN = WN * TN * 32;
+    a.n_tiles = (a.N + BN - 1) / BN;
+    a.m_tiles = (int)((a.P + kBM - 1) / kBM);
+    // without batch sums: one workgroup per tile, the dispatcher balances.  With them: one SLOT per workgroup, each walking its
+    // share of the pixel tiles — about two workgroups per CU in flight and a whole number of tiles each
+    int gm = a.m_tiles;
+    if (EPI != 0) {
+        const int want = std::max(1, 2 * cx.n_cu / a.n_tiles);
+        gm = std::min(std::min(a.nslot, a.m_tiles), std::max(want, 1));
+        if (gm < 1) gm = 1;
+    }
+    a.gm = gm;
+    const size_t lds = pix_lds_bytes<WN, TN>(a.K, APRO);
+    auto fn = &k_mm_pix<WN, TN, APRO, EPI, AV, CV>;
+    static std::atomic<size_t> enabled[16];
+    if (!mm_enable_lds(reinterpret_cast<const void *>(fn), lds, cx.device, enabled)) return false;
+    const unsigned grid = (unsigned)((gm + 7) / 8 * 8 * a.n_tiles);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(kT), lds, st, a);
+    return true;
+}
+// the tile width follows the channel count: 128 / 64 / 32 columns
+template <int APRO, int EPI, int AV, int CV>
+inline bool mm_pix_cv(const Ctx &cx, hipStream_t st, const PixArgs &a)
+{
+    if (a.N > 64) return mm_pix_launch<2, 2, APRO, EPI, AV, CV>(cx, st, a);
+    if (a.N > 32) return mm_pix_launch<1, 2, APRO, EPI, AV, CV>(cx, st, a);
+    return mm_pix_launch<1, 1, APRO, EPI, AV, CV>(cx, st, a);
+}
+// ... and the way the tile leaves follows the alignment of C (and of the pre-BN activation beside it)
+template <int APRO, int EPI, int AV>
+inline bool mm_pix(const Ctx &cx, hipStream_t st, const PixArgs &a)
+{
+    // (measured: a tile that is only STORED leaves faster straight from the D registers — stores are fire-and-forget, the LDS pass
+    // costs two barriers; one that also READS the pre-BN activation gains from one 16-byte request per 4 channels)
+    const bool vec = EPI >= 2 && a.N % 4 == 0 && (EPI == 4 || (a.ldc % 4 == 0 && (reinterpret_cast<uintptr_t>(a.C) & 15) == 0)) && a.ldh % 4 == 0 &&
+                     (reinterpret_cast<uintptr_t>(a.eh) & 15) == 0;
+    return vec ? mm_pix_cv<APRO, EPI, AV, 4>(cx, st, a) : mm_pix_cv<APRO, EPI, AV, 1>(cx, st, a);
+}
+
+// part[s][M][N] = sum over the pixels of chunk s of pro(A)^T . B; returns the number of partial products (0 on failure)
+template <int WMv, int TM, int TN, int APRO, int AV, int BV, int BPRO = 0>
+inline int mm_kpix_launch(const Ctx &cx, hipStream_t st, KpixArgs a)
+{
+    constexpr int BM = WMv * TM * 32, BN = (4 / WMv) * TN * 32;
+    a.m_tiles = (a.M + BM - 1) / BM;
+    a.n_tiles = (a.N + BN - 1) / BN;
+    const int tiles = a.m_tiles * a.n_tiles;
+    int64_t S = std::max<int64_t>(1, (4 * (int64_t)cx.n_cu + tiles - 1) / tiles);     // ~4 workgroups per CU over the whole launch
+    S = std::min<int64_t>(S, std::min<int64_t>(256, kGradPartFloats / ((int64_t)a.M * a.N)));
+    S = std::min<int64_t>(S, std::max<int64_t>(1, a.npix / (4 * kBK)));            // chunks of at least 128 pixels
+    if (BPRO == 2) S = std::min<int64_t>(S, std::max(1, a.nslot));                     // one d-bias slot per chunk
+    a.chunk = ((a.npix + S - 1) / S + kBK - 1) / kBK * kBK;
+    a.S = (int)((a.npix + a.chunk - 1) / a.chunk);
+    const size_t lds = kpix_lds_bytes<WMv, TM, TN>();
+    auto fn = &k_mm_kpix<WMv, TM, TN, APRO, AV, BV, BPRO>;
+    static std::atomic<size_t> enabled[16];
+    if (!mm_enable_lds(reinterpret_cast<const void *>(fn), lds, cx.device, enabled)) return 0;
+    const unsigned grid = (unsigned)((a.S + 7) / 8 * 8 * tiles);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(kT), lds, st, a);
+    return a.S;
+}
+
+// weights into the packed layout k_mm_pix reads (nf_train_mm.h: k_mm_pack); returns the row pitch
+inline int mm_pack(hipStream_t st, int mode, int rows, int cols, int w, const float *src, float *dst)
+{
+    const int ld = (cols + 3) & ~3;
+    hipLaunchKernelGGL(k_mm_pack, dim3((unsigned)((rows * ld + 255) / 256)), dim3(256), 0, st, mode, rows, cols, ld, w, src, dst);
+    return ld;
+}
+
+
+// every packed layout of one coupling in ONE launch (the weights do not change between a step's forward and backward pass):
+//   [w2t: w x w4 | w2: w x w4 | w3a: 36 x w4 | w3b: w x 36 | w1: 18 x w4 | w1t: w x 20]      (w4 = w rounded up to 4)
+struct PackAll {
+    size_t o_w2t, o_w2, o_w3a, o_w3b, o_w1, o_w1t, total;
+    int w4;
+};
+inline PackAll pack_layout(int w)
+{
+    PackAll L;
+    L.w4 = (w + 3) & ~3;
+    L.o_w2t = 0;
+    L.o_w2 = L.o_w2t + (size_t)w * L.w4;
+    L.o_w3a = L.o_w2 + (size_t)w * L.w4;
+    L.o_w3b = L.o_w3a + 36 * (size_t)L.w4;
+    L.o_w1 = L.o_w3b + (size_t)w * 36;
+    L.o_w1t = L.o_w1 + 18 * (size_t)L.w4;
+    L.total = L.o_w1t + (size_t)w * 20;
+    return L;
+}
+__global__ void k_mm_pack_all(int w, PackAll L, const float *__restrict__ W1, const float *__restrict__ W2, const float *__restrict__ W3,
+                              float *__restrict__ dst)
+{
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= L.total) return;
+    const int w4 = L.w4;
+    float v = 0.0f;
+    if (e < L.o_w2) {                     // Bt[j][i] = W2[i][j]
+        const int r = (int)(e / w4), c = (int)(e - (size_t)r * w4);
+        if (c < w) v = W2[(size_t)c * w + r];
+    } else if (e < L.o_w3a) {             // Bt[i][j] = W2[i][j]
+        const size_t f = e - L.o_w2;
+        const int r = (int)(f / w4), c = (int)(f - (size_t)r * w4);
+        if (c < w) v = W2[(size_t)r * w + c];
+    } else if (e < L.o_w3b) {             // Bt[tap*4+k][i] = l_last/W[tap][i][k]
+        const size_t f = e - L.o_w3a;
+        const int r = (int)(f / w4), c = (int)(f - (size_t)r * w4);
+        if (c < w) v = W3[((size_t)(r >> 2) * (w + 1) + c) * 4 + (r & 3)];
+    } else if (e < L.o_w1) {              // Bt[i][tap*4+k] = l_last/W[tap][i][k]
+        const size_t f = e - L.o_w3b;
+        const int r = (int)(f / 36), c = (int)(f - (size_t)r * 36);
+        v = W3[((size_t)(c >> 2) * (w + 1) + r) * 4 + (c & 3)];
+    } else if (e < L.o_w1t) {             // Bt[tap*2+c][j] = W1[tap*2+c][j]
+        const size_t f = e - L.o_w1;
+        const int r = (int)(f / w4), c = (int)(f - (size_t)r * w4);
+        if (c < w) v = W1[(size_t)r * w + c];
+    } else {                              // Bt[j][tap*2+c] = W1[tap*2+c][j]
+        const size_t f = e - L.o_w1t;
+        const int r = (int)(f / 20), c = (int)(f - (size_t)r * 20);
+        if (c < 18) v = W1[(size_t)c * w + r];
+    }
+    dst[e] = v;
+}
+
+}  // namespace mm
+}  // namespace
