@@ -1866,7 +1866,8 @@ bool tiled_ok(const nf_trainer *t, const Geo &g, int width, int pass /* 1 backwa
     // measured on the shipped model (both passes tiled): 0.61 vs 0.77 ms per step at 138 patches, 0.77 vs 0.88 at 256, break-even
     // near 400 (one 1024-thread workgroup per CU: past one round over the 256 CUs the layer kernels' finer grain wins)
     const int64_t npatch = g.npix / g.HW;
-    return (t->tiled & pass) && (width == 4 || width == 8) && g.HW <= 1024 && npatch <= g.nslot && npatch <= 384;
+    // (NF_TRAIN_GEMM=1 sends widths 4 / 8 down the GEMM path: the create-time allocation and this dispatch share gemm_width())
+    return (t->tiled & pass) && !gemm_width(width) && (width == 4 || width == 8) && g.HW <= 1024 && npatch <= g.nslot && npatch <= 384;
 }
 
 #define NF_WIDTH_SWITCH(w, CALL)            \

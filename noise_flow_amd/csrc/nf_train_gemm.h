@@ -26,7 +26,7 @@
 //             d z0 += gather of Q; the folded Conv2d1x1 backward                    k_g_c1_dz
 //
 // The pre-BN activations h1 / h2 stay WITHOUT their bias in memory and are the only [pixel][w] tensors a coupling keeps: the
-// normalised activations are re-formed from them wherever they are an operand (same expression, same bits: mm::xhat = g_xhat).
+// normalised activations are re-formed from them wherever they are an operand (same expression, same bits: mm::xhat).
 // Gradients of the three filters come out of k_mm_kpix as partial products per pixel chunk and go into the fp64 gradient vector
 // (k_g_store_grad); every other reduction of the step keeps the trainer's slotted partial sums, so the batch statistics can be
 // synchronised across ranks exactly as at the other widths.  One stream, no side work: a wide step is milliseconds of GEMMs.
@@ -107,11 +107,7 @@ __device__ __forceinline__ void flat_store(const float (&v)[4], float *red, cons
     }
 }
 
-// The GEMM's output h stays WITHOUT its bias in memory: every consumer adds it on the fly (g_xhat), which saves this kernel the
-// write pass over the tensor.
-// normalised activation of one value (layers.py:378-401 with the batch moments): the expression every kernel below shares, so
-// that the ReLU mask the backward pass re-derives from h is bit for bit the forward's
-__device__ __forceinline__ float g_xhat(float h, float b, float m, float rs) { return ((h + b) - m) * rs; }
+// The pre-BN activations h stay WITHOUT their bias in memory: every consumer adds it on the fly (mm::xhat).
 
 // l_1 itself where the width allows the flat walk (a multiple of 4): h1 = Z18 . W1 has K = 18 — less arithmetic than the write
 // of its own result — so the library GEMM, its read-back for the statistics and their launches collapse into ONE pass: every

@@ -45,15 +45,19 @@ constexpr int kT = 256;             // threads per workgroup
 constexpr int kBK = 32;             // K extent of one staged tile (k_mm_pix: channels; k_mm_kpix: pixels)
 constexpr int kBM = 128;            // pixels per tile of k_mm_pix
 
-// normalised activation (layers.py:378-401 with the batch moments): the ONE expression the forward pass, the ReLU masks of the
-// backward pass and the pixel kernels of nf_train_gemm.h share (g_xhat there), so that a mask re-derived from h is the forward's
-__device__ __forceinline__ float xhat(float h, float b, float m, float rs) { return ((h + b) - m) * rs; }
+// normalised activation (layers.py:378-401 with the batch moments) of a pre-BN value h stored WITHOUT its bias:
+// ((h + b) - mean) rstd as ONE fma, h rstd + c with c = (b - mean) rstd per channel.  The ONE expression every site shares — the
+// forward operand, the ReLU masks the backward pass re-derives from h, the BN backward — so a re-derived mask is the forward's, bit
+// for bit.  (fp32 VALU work and the MFMA pipe do not overlap on a SIMD: 2 instead of 4 instructions per staged element is
+// matrix-pipe time)
+__device__ __forceinline__ float xhat_c(float b, float m, float rs) { return (b - m) * rs; }
+__device__ __forceinline__ float xhat(float h, float rs, float c) { return fmaf(h, rs, c); }
 
 // BN backward of one value (k_g_bn_bwd of nf_train_gemm.h): g = d loss / d relu output, h = the pre-BN activation; ba, bq = the batch
 // means of gx and gx * xhat (gx = g where the forward's relu kept the value)
-__device__ __forceinline__ float bn_bwd(float g, float h, float b, float m, float rs, float ba, float bq)
+__device__ __forceinline__ float bn_bwd(float g, float h, float rs, float c, float ba, float bq)
 {
-    const float xh = xhat(h, b, m, rs);
+    const float xh = xhat(h, rs, c);
     return rs * ((xh > 0.0f ? g : 0.0f) - ba - xh * bq);
 }
 
@@ -128,7 +132,7 @@ __global__ __launch_bounds__(kT) void k_mm_pix(const PixArgs a)
     float4 *const sB = sA + 2 * 8 * AP;                        // [2][8][BP]
     float *const stg = mm_smem;                                // [kBM][SP]
     float *const red = mm_smem;                                // [2][WM or kT / (BN / 4)][BN]
-    float *const cst = mm_smem + R0;                           // APRO 1: [3][Kc] (bias, mean, rstd); APRO 2: [5][Kc] (+ ba, bq)
+    float *const cst = mm_smem + R0;                           // APRO 1: [2][Kc] (rstd, c = (bias - mean) rstd); APRO 2: [4][Kc] (+ ba, bq)
     const int Kc = (a.K + kBK - 1) / kBK * kBK;
 
     // ids that share an XCD (id % 8) and are neighbours there share the pixel tile
@@ -143,12 +147,12 @@ __global__ __launch_bounds__(kT) void k_mm_pix(const PixArgs a)
 
     if constexpr (APRO != 0) {
         for (int i = tid; i < Kc; i += kT) {
-            cst[i] = i < a.K ? a.abias[i] : 0.0f;
-            cst[Kc + i] = i < a.K ? a.abn[i] : 0.0f;
-            cst[2 * Kc + i] = i < a.K ? a.abn[a.K + i] : 0.0f;
+            const float rs = i < a.K ? a.abn[a.K + i] : 0.0f;
+            cst[i] = rs;
+            cst[Kc + i] = i < a.K ? xhat_c(a.abias[i], a.abn[i], rs) : 0.0f;
             if constexpr (APRO == 2) {
-                cst[3 * Kc + i] = i < a.K ? a.abb[i] : 0.0f;
-                cst[4 * Kc + i] = i < a.K ? a.abb[a.K + i] : 0.0f;
+                cst[2 * Kc + i] = i < a.K ? a.abb[i] : 0.0f;
+                cst[3 * Kc + i] = i < a.K ? a.abb[a.K + i] : 0.0f;
             }
         }
         __syncthreads();
@@ -156,40 +160,123 @@ __global__ __launch_bounds__(kT) void k_mm_pix(const PixArgs a)
 
     // epilogue constants: a lane's channels are n0 + wn TN 32 + tn 32 + n for every tile it ever computes
     [[maybe_unused]] float s4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};   // CV 4: this thread's 4 channels (n0 + 4 (tid % (BN / 4)) ...)
-    [[maybe_unused]] float eb[TN], em[TN], er[TN], ea[TN], eq[TN], ssum[TN], qsum[TN];
+    [[maybe_unused]] float eb[TN], er[TN], ec[TN], ea[TN], eq[TN], ssum[TN], qsum[TN];
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
         const int ch = n0 + (wn * TN + tn) * 32 + n;
         eb[tn] = (EPI != 0 && ch < a.N) ? a.ebias[ch] : 0.0f;
-        em[tn] = (EPI >= 2 && ch < a.N) ? a.ebn[ch] : 0.0f;
         er[tn] = (EPI >= 2 && ch < a.N) ? a.ebn[a.N + ch] : 0.0f;
+        ec[tn] = (EPI >= 2 && ch < a.N) ? xhat_c(eb[tn], a.ebn[ch], er[tn]) : 0.0f;
         ea[tn] = (EPI == 3 && ch < a.N) ? a.ebb[ch] : 0.0f;
         eq[tn] = (EPI == 3 && ch < a.N) ? a.ebb[a.N + ch] : 0.0f;
         ssum[tn] = 0.0f;
         qsum[tn] = 0.0f;
     }
 
-    // B rows of this workgroup's tile (fixed over the pixel tiles)
-    const float *brow[NB];
-    float bmask[NB];           // rows beyond N: a valid row is loaded and multiplied away (no branch around the load)
+    // Operand addresses = a wavefront-UNIFORM base (tile origin + K position: scalar registers, advanced by scalar adds) + a per-lane
+    // 32-bit byte offset that never changes (row within the tile, k4 group): the loads take the scalar-base form and the K loop
+    // spends no vector instruction on addresses.
+    // B rows of this workgroup's tile (fixed over the pixel tiles); rows beyond N: a valid row is loaded and multiplied away
+    const float *const bbase = a.Bt + (size_t)n0 * a.ldb;
+    uint32_t boff[NB];
+    float bmask[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-        const int r = n0 + r0 + 32 * i;
-        bmask[i] = r < a.N ? 1.0f : 0.0f;
-        brow[i] = a.Bt + (size_t)(r < a.N ? r : 0) * a.ldb;
+        const int r = r0 + 32 * i;
+        bmask[i] = n0 + r < a.N ? 1.0f : 0.0f;
+        boff[i] = (uint32_t)((n0 + r < a.N ? r : 0) * a.ldb + 4 * j) * 4u;
     }
+    const bool bragged = n0 + BN > a.N;   // workgroup-uniform
     const int nkt = Kc / kBK;
     const int nkt_full = a.K / kBK;   // K tiles every load of which is in range (ldb >= K)
 
-    for (int64_t mt = ms; mt < a.m_tiles; mt += a.gm) {
+    // the A side of the tile being staged: origin and per-lane offsets (set by `origin`).  (Issuing a tile's FIRST loads before the
+    // previous tile's epilogue — so that the round trip at a tile boundary hides behind the stores — was measured: no gain, the
+    // other workgroup of the CU already covers it, and 38 more live registers)
+    const float *abase = a.A;
+    [[maybe_unused]] const float *hbase = a.A2;
+    uint32_t aoff[4];
+    auto origin = [&](int64_t mt) {
         const int64_t m0 = mt * kBM;
-        const float *arow[4];
+        abase = a.A + m0 * a.lda;
+        if constexpr (APRO == 2) hbase = a.A2 + m0 * a.lda;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            int64_t r = m0 + r0 + 32 * i;
-            r = r < a.P ? r : a.P - 1;        // rows past the end: loaded (valid memory), never stored nor summed
-            arow[i] = a.A + r * a.lda;
+            int r = r0 + 32 * i;
+            r = m0 + r < a.P ? r : (int)(a.P - 1 - m0);   // rows past the end: loaded (valid memory), never stored nor summed
+            aoff[i] = (uint32_t)(r * a.lda + 4 * j) * 4u;
         }
+    };
+    // Staging registers (ONE set: the loads of K tile t + 1 are issued before the MFMAs of tile t and parked after them.  A
+    // second set with two tiles of lead was measured SLOWER, 630 -> 654 us for the plain 512 product: the parking wait is not
+    // what the feed costs — removing the loads altogether gains 10 %, removing the barrier 2 %)
+    struct Stage {
+        float4 ra[4], rb[NB], rh[APRO == 2 ? 4 : 1];
+    };
+    Stage SR;
+    auto at = [](const float *base, uint32_t off) { return reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + off); };
+    auto fetch = [&](int kt, Stage &R) {
+        const float *const ak = abase + kt * kBK, *const bk = bbase + kt * kBK;
+        [[maybe_unused]] const float *const hk = hbase + kt * kBK;
+        if (kt < nkt_full) {     // workgroup-uniform: the whole tile is inside K, no predicates around the loads
+#pragma unroll
+            for (int i = 0; i < 4; ++i) R.ra[i] = row4<AV>(at(ak, aoff[i]), 0, 4);
+            if constexpr (APRO == 2) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) R.rh[i] = row4<AV>(at(hk, aoff[i]), 0, 4);
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) R.rb[i] = ld4(at(bk, boff[i]));
+        } else {
+            const int k = kt * kBK + 4 * j;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) R.ra[i] = row4<AV>(at(ak, aoff[i]), 0, a.K - k);
+            if constexpr (APRO == 2) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) R.rh[i] = row4<AV>(at(hk, aoff[i]), 0, a.K - k);
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) R.rb[i] = k < a.ldb ? ld4(at(bk, boff[i])) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto park = [&](int kt, int buf, Stage &R) {
+        if constexpr (APRO == 1) {
+            const int k = kt * kBK + 4 * j;
+            const float4 cr = ld4(cst + k), cc = ld4(cst + Kc + k);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                R.ra[i].x = fmaxf(xhat(R.ra[i].x, cr.x, cc.x), 0.0f);
+                R.ra[i].y = fmaxf(xhat(R.ra[i].y, cr.y, cc.y), 0.0f);
+                R.ra[i].z = fmaxf(xhat(R.ra[i].z, cr.z, cc.z), 0.0f);
+                R.ra[i].w = fmaxf(xhat(R.ra[i].w, cr.w, cc.w), 0.0f);
+            }
+        } else if constexpr (APRO == 2) {
+            const int k = kt * kBK + 4 * j;
+            const float4 cr = ld4(cst + k), cc = ld4(cst + Kc + k), ca = ld4(cst + 2 * Kc + k), cq = ld4(cst + 3 * Kc + k);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                R.ra[i].x = bn_bwd(R.ra[i].x, R.rh[i].x, cr.x, cc.x, ca.x, cq.x);
+                R.ra[i].y = bn_bwd(R.ra[i].y, R.rh[i].y, cr.y, cc.y, ca.y, cq.y);
+                R.ra[i].z = bn_bwd(R.ra[i].z, R.rh[i].z, cr.z, cc.z, ca.z, cq.z);
+                R.ra[i].w = bn_bwd(R.ra[i].w, R.rh[i].w, cr.w, cc.w, ca.w, cq.w);
+            }
+        }
+        float4 *da = sA + (buf * 8 + j) * AP + r0, *db = sB + (buf * 8 + j) * BP + r0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) da[32 * i] = R.ra[i];
+        if (bragged) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+                db[32 * i] = make_float4(R.rb[i].x * bmask[i], R.rb[i].y * bmask[i], R.rb[i].z * bmask[i], R.rb[i].w * bmask[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) db[32 * i] = R.rb[i];
+        }
+    };
+    for (int64_t mt = ms; mt < a.m_tiles; mt += a.gm) {
+        const int64_t m0 = mt * kBM;
+        origin(mt);
+        fetch(0, SR);
         v16f acc[TM][TN];
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
@@ -198,69 +285,6 @@ __global__ __launch_bounds__(kT) void k_mm_pix(const PixArgs a)
 #pragma unroll
                 for (int v = 0; v < 16; ++v) acc[tm][tn][v] = 0.0f;
 
-        // Staging registers (ONE set: the loads of K tile t + 1 are issued before the MFMAs of tile t and parked after them.  A
-        // second set with two tiles of lead was measured SLOWER, 630 -> 654 us for the plain 512 product: the parking wait is not
-        // what the feed costs — removing the loads altogether gains 10 %, removing the barrier 2 %)
-        struct Stage {
-            float4 ra[4], rb[NB], rh[APRO == 2 ? 4 : 1];
-        };
-        Stage R0;
-        [[maybe_unused]] const float *hrow[4];
-        if constexpr (APRO == 2) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) hrow[i] = a.A2 + (arow[i] - a.A);
-        }
-        auto fetch = [&](int kt, Stage &R) {
-            const int k = kt * kBK + 4 * j;
-            if (kt < nkt_full) {     // workgroup-uniform: the whole tile is inside K, no predicates around the loads
-#pragma unroll
-                for (int i = 0; i < 4; ++i) R.ra[i] = row4<AV>(arow[i], k, k + 4);
-                if constexpr (APRO == 2) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) R.rh[i] = row4<AV>(hrow[i], k, k + 4);
-                }
-#pragma unroll
-                for (int i = 0; i < NB; ++i) R.rb[i] = ld4(brow[i] + k);
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) R.ra[i] = row4<AV>(arow[i], k, a.K);
-                if constexpr (APRO == 2) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) R.rh[i] = row4<AV>(hrow[i], k, a.K);
-                }
-#pragma unroll
-                for (int i = 0; i < NB; ++i) R.rb[i] = k < a.ldb ? ld4(brow[i] + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        };
-        auto park = [&](int kt, int buf, Stage &R) {
-            if constexpr (APRO == 1) {
-                const int k = kt * kBK + 4 * j;
-                const float4 cb = ld4(cst + k), cm = ld4(cst + Kc + k), cr = ld4(cst + 2 * Kc + k);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    R.ra[i].x = fmaxf(xhat(R.ra[i].x, cb.x, cm.x, cr.x), 0.0f);
-                    R.ra[i].y = fmaxf(xhat(R.ra[i].y, cb.y, cm.y, cr.y), 0.0f);
-                    R.ra[i].z = fmaxf(xhat(R.ra[i].z, cb.z, cm.z, cr.z), 0.0f);
-                    R.ra[i].w = fmaxf(xhat(R.ra[i].w, cb.w, cm.w, cr.w), 0.0f);
-                }
-            } else if constexpr (APRO == 2) {
-                const int k = kt * kBK + 4 * j;
-                const float4 cb = ld4(cst + k), cm = ld4(cst + Kc + k), cr = ld4(cst + 2 * Kc + k), ca = ld4(cst + 3 * Kc + k), cq = ld4(cst + 4 * Kc + k);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    R.ra[i].x = bn_bwd(R.ra[i].x, R.rh[i].x, cb.x, cm.x, cr.x, ca.x, cq.x);
-                    R.ra[i].y = bn_bwd(R.ra[i].y, R.rh[i].y, cb.y, cm.y, cr.y, ca.y, cq.y);
-                    R.ra[i].z = bn_bwd(R.ra[i].z, R.rh[i].z, cb.z, cm.z, cr.z, ca.z, cq.z);
-                    R.ra[i].w = bn_bwd(R.ra[i].w, R.rh[i].w, cb.w, cm.w, cr.w, ca.w, cq.w);
-                }
-            }
-            float4 *da = sA + (buf * 8 + j) * AP + r0, *db = sB + (buf * 8 + j) * BP + r0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) da[32 * i] = R.ra[i];
-#pragma unroll
-            for (int i = 0; i < NB; ++i)
-                db[32 * i] = make_float4(R.rb[i].x * bmask[i], R.rb[i].y * bmask[i], R.rb[i].z * bmask[i], R.rb[i].w * bmask[i]);
-        };
         // the 4 chunks of 8 k of one staged tile.  Every tile runs all of them: beyond K both operands hold zeros (a ragged K costs
         // MFMA time in the last tile only; guarding the chunks with uniform branches was measured SLOWER — the wait-count pass then
         // also waits for the prefetched operands at every join).  Operand registers in ping-pong: the LDS reads of chunk c + 1 are
@@ -297,14 +321,13 @@ __global__ __launch_bounds__(kT) void k_mm_pix(const PixArgs a)
 #ifndef MM_ABL
 #define MM_ABL 0   // tools/probes/mm_probe.hip only: 1 = no barrier in the K loop, 2 = no global loads in it, 4 = no LDS writes in it (timing ablations; results are wrong)
 #endif
-        fetch(0, R0);
-        park(0, 0, R0);
+        park(0, 0, SR);
         __syncthreads();
         for (int kt = 0; kt < nkt; ++kt) {
             const int buf = kt & 1;
-            if (kt + 1 < nkt && !(MM_ABL & 2)) fetch(kt + 1, R0);
+            if (kt + 1 < nkt && !(MM_ABL & 2)) fetch(kt + 1, SR);
             compute(buf);
-            if (kt + 1 < nkt && !(MM_ABL & 4)) park(kt + 1, buf ^ 1, R0);
+            if (kt + 1 < nkt && !(MM_ABL & 4)) park(kt + 1, buf ^ 1, SR);
             if (!(MM_ABL & 1)) __syncthreads();
         }
 
@@ -325,29 +348,34 @@ __global__ __launch_bounds__(kT) void k_mm_pix(const PixArgs a)
             constexpr int Q = BN / 4, RS = kT / Q, PASS = kBM / RS;   // float4 per row, rows per pass, passes
             const int c4 = tid % Q, rr = tid / Q, ch = n0 + 4 * c4;
             if (ch < a.N) {
-                [[maybe_unused]] float4 kb, km, kr, ka, kq;
+                [[maybe_unused]] float4 kb, kr, kc, ka, kq;
                 if constexpr (EPI != 0) kb = ld4u(a.ebias + ch);
                 if constexpr (EPI >= 2) {
-                    km = ld4u(a.ebn + ch);
+                    const float4 km = ld4u(a.ebn + ch);
                     kr = ld4u(a.ebn + a.N + ch);
+                    kc = make_float4(xhat_c(kb.x, km.x, kr.x), xhat_c(kb.y, km.y, kr.y), xhat_c(kb.z, km.z, kr.z), xhat_c(kb.w, km.w, kr.w));
                 }
                 if constexpr (EPI == 3) {
                     ka = ld4u(a.ebb + ch);
                     kq = ld4u(a.ebb + a.N + ch);
                 }
-                // (loads and stores share one in-order counter: ALL pre-BN activations of the thread's pieces are requested first —
-                // one memory round trip per tile, not one per group of rows)
-                [[maybe_unused]] float4 hv[EPI >= 2 ? PASS : 1];
+                // (loads and stores share one in-order counter: the pre-BN activations of HALF of the thread's pieces are requested
+                // together, before their stores — two memory round trips per tile; all 16 at once need 64 registers beside the next
+                // tile's staged operands and cost the kernel its second wavefront per SIMD)
+                constexpr int GRP = PASS >= 8 ? PASS / 2 : PASS;
+#pragma unroll
+                for (int i0 = 0; i0 < PASS; i0 += GRP) {
+                [[maybe_unused]] float4 hv[EPI >= 2 ? GRP : 1];
                 if constexpr (EPI >= 2) {
 #pragma unroll
-                    for (int i = 0; i < PASS; ++i) {
-                        const int64_t p = m0 + rr + RS * i;
+                    for (int i = 0; i < GRP; ++i) {
+                        const int64_t p = m0 + rr + RS * (i0 + i);
                         hv[i] = p < a.P ? ld4(a.eh + p * a.ldh + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
                     }
                 }
 #pragma unroll
-                for (int i = 0; i < PASS; ++i) {
-                    const int r = rr + RS * i;
+                for (int i = 0; i < GRP; ++i) {
+                    const int r = rr + RS * (i0 + i);
                     const int64_t p = m0 + r;
                     if (p >= a.P) continue;
                     float4 v = *reinterpret_cast<const float4 *>(stg + r * SP + 4 * c4);
@@ -356,19 +384,19 @@ __global__ __launch_bounds__(kT) void k_mm_pix(const PixArgs a)
                         s4[0] += x0; s4[1] += x1; s4[2] += x2; s4[3] += x3;
                         q4[0] = fmaf(x0, x0, q4[0]); q4[1] = fmaf(x1, x1, q4[1]); q4[2] = fmaf(x2, x2, q4[2]); q4[3] = fmaf(x3, x3, q4[3]);
                     } else if constexpr (EPI == 2 || EPI == 4) {
-                        const float h0 = xhat(hv[i].x, kb.x, km.x, kr.x), h1 = xhat(hv[i].y, kb.y, km.y, kr.y), h2 = xhat(hv[i].z, kb.z, km.z, kr.z),
-                                    h3 = xhat(hv[i].w, kb.w, km.w, kr.w);
+                        const float h0 = xhat(hv[i].x, kr.x, kc.x), h1 = xhat(hv[i].y, kr.y, kc.y), h2 = xhat(hv[i].z, kr.z, kc.z), h3 = xhat(hv[i].w, kr.w, kc.w);
                         const float g0 = h0 > 0.f ? v.x : 0.f, g1 = h1 > 0.f ? v.y : 0.f, g2 = h2 > 0.f ? v.z : 0.f, g3 = h3 > 0.f ? v.w : 0.f;
                         s4[0] += g0; s4[1] += g1; s4[2] += g2; s4[3] += g3;
                         q4[0] = fmaf(g0, h0, q4[0]); q4[1] = fmaf(g1, h1, q4[1]); q4[2] = fmaf(g2, h2, q4[2]); q4[3] = fmaf(g3, h3, q4[3]);
                     } else if constexpr (EPI == 3) {
-                        v.x = bn_bwd(v.x, hv[i].x, kb.x, km.x, kr.x, ka.x, kq.x);
-                        v.y = bn_bwd(v.y, hv[i].y, kb.y, km.y, kr.y, ka.y, kq.y);
-                        v.z = bn_bwd(v.z, hv[i].z, kb.z, km.z, kr.z, ka.z, kq.z);
-                        v.w = bn_bwd(v.w, hv[i].w, kb.w, km.w, kr.w, ka.w, kq.w);
+                        v.x = bn_bwd(v.x, hv[i].x, kr.x, kc.x, ka.x, kq.x);
+                        v.y = bn_bwd(v.y, hv[i].y, kr.y, kc.y, ka.y, kq.y);
+                        v.z = bn_bwd(v.z, hv[i].z, kr.z, kc.z, ka.z, kq.z);
+                        v.w = bn_bwd(v.w, hv[i].w, kr.w, kc.w, ka.w, kq.w);
                         s4[0] += v.x; s4[1] += v.y; s4[2] += v.z; s4[3] += v.w;
                     }
                     if constexpr (EPI != 4) *reinterpret_cast<float4 *>(a.C + p * a.ldc + ch) = v;
+                }
                 }
             }
             __syncthreads();   // the next tile's operands overwrite the region
@@ -402,12 +430,12 @@ __global__ __launch_bounds__(kT) void k_mm_pix(const PixArgs a)
                         ssum[tn] += x;
                         qsum[tn] = fmaf(x, x, qsum[tn]);
                     } else if constexpr (EPI == 2 || EPI == 4) {
-                        const float xh = xhat(hv[v], eb[tn], em[tn], er[tn]);
+                        const float xh = xhat(hv[v], er[tn], ec[tn]);
                         const float gx = xh > 0.0f ? val : 0.0f;
                         ssum[tn] += gx;
                         qsum[tn] = fmaf(gx, xh, qsum[tn]);
                     } else if constexpr (EPI == 3) {
-                        const float o = bn_bwd(val, hv[v], eb[tn], em[tn], er[tn], ea[tn], eq[tn]);
+                        const float o = bn_bwd(val, hv[v], er[tn], ec[tn], ea[tn], eq[tn]);
                         cp[(int64_t)dp * a.ldc] = o;
                         ssum[tn] += o;
                     }
@@ -493,7 +521,7 @@ template <int WN, int TN>
 constexpr size_t pix_lds_bytes(int K, int apro)
 {
     constexpr int BN = WN * TN * 32;
-    return ((size_t)pix_region0_floats(BN) + (apro == 2 ? 5 : apro ? 3 : 0) * (size_t)((K + kBK - 1) / kBK * kBK)) * sizeof(float);
+    return ((size_t)pix_region0_floats(BN) + (apro == 2 ? 4 : apro ? 2 : 0) * (size_t)((K + kBK - 1) / kBK * kBK)) * sizeof(float);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -542,29 +570,26 @@ __global__ __launch_bounds__(kT) void k_mm_kpix(const KpixArgs a)
     static_assert(kT % AQ == 0 && kT % BQ == 0 && kBK % ARS == 0 && kBK % BRS == 0 && APASS >= 1 && BPASS >= 1, "staging split");
     const int acq = tid % AQ, apr = tid / AQ, bcq = tid % BQ, bpr = tid / BQ;
     const int ac = m0 + AV * acq, bc = n0 + BV * bcq;      // first channel this thread stages
-    float4 cb = make_float4(0.f, 0.f, 0.f, 0.f), cm = cb, cr = cb;
+    float4 cr = make_float4(0.f, 0.f, 0.f, 0.f), cc = cr;      // APRO 1: rstd and c = (bias - mean) rstd of this thread's channels
     if constexpr (APRO == 1) {
-        float t[12];
+        float t[8];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const bool ok = i < AV && ac + i < a.M;
-            t[i] = ok ? a.abias[ac + i] : 0.0f;
-            t[4 + i] = ok ? a.abn[ac + i] : 0.0f;
-            t[8 + i] = ok ? a.abn[a.M + ac + i] : 0.0f;
+            t[i] = ok ? a.abn[a.M + ac + i] : 0.0f;
+            t[4 + i] = ok ? xhat_c(a.abias[ac + i], a.abn[ac + i], t[i]) : 0.0f;
         }
-        cb = make_float4(t[0], t[1], t[2], t[3]);
-        cm = make_float4(t[4], t[5], t[6], t[7]);
-        cr = make_float4(t[8], t[9], t[10], t[11]);
+        cr = make_float4(t[0], t[1], t[2], t[3]);
+        cc = make_float4(t[4], t[5], t[6], t[7]);
     }
 
-    [[maybe_unused]] float kb[4], km[4], kr[4], ka[4], kq[4], dsum[4] = {0.f, 0.f, 0.f, 0.f};
+    [[maybe_unused]] float kr[4], kc[4], ka[4], kq[4], dsum[4] = {0.f, 0.f, 0.f, 0.f};
     if constexpr (BPRO == 2) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const bool ok = i < BV && bc + i < a.N;
-            kb[i] = ok ? a.bbias[bc + i] : 0.0f;
-            km[i] = ok ? a.bbn[bc + i] : 0.0f;
             kr[i] = ok ? a.bbn[a.N + bc + i] : 0.0f;
+            kc[i] = ok ? xhat_c(a.bbias[bc + i], a.bbn[bc + i], kr[i]) : 0.0f;
             ka[i] = ok ? a.bbb[bc + i] : 0.0f;
             kq[i] = ok ? a.bbb[a.N + bc + i] : 0.0f;
         }
@@ -579,41 +604,72 @@ __global__ __launch_bounds__(kT) void k_mm_kpix(const KpixArgs a)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[tm][tn][v] = 0.0f;
 
+    // Operand addresses = a wavefront-uniform base (chunk position: scalar registers) + a per-lane 32-bit byte offset that never
+    // changes (pixel row within the staged tile, channel): scalar-base loads, no vector address arithmetic in the K loop
+    uint32_t aoff[APASS], boff[BPASS];
+#pragma unroll
+    for (int i = 0; i < APASS; ++i) aoff[i] = (uint32_t)((apr + ARS * i) * a.lda + AV * acq) * 4u;
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i) boff[i] = (uint32_t)((bpr + BRS * i) * a.ldb + BV * bcq) * 4u;
+    auto at = [](const float *base, uint32_t off) { return reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + off); };
+    const bool a_in = m0 + BM <= a.M, b_in = n0 + BN <= a.N;   // workgroup-uniform: every staged channel of the operand exists
+
     float4 ra[AV == 4 ? APASS : (APASS + 3) / 4], rb[BV == 4 ? BPASS : (BPASS + 3) / 4];
     float sa1[AV == 4 ? 1 : APASS], sb1[BV == 4 ? 1 : BPASS];
     [[maybe_unused]] float4 rh[(BPRO == 2 && BV == 4) ? BPASS : 1];
     [[maybe_unused]] float sh1[(BPRO == 2 && BV == 1) ? BPASS : 1];
     [[maybe_unused]] int64_t bpk = 0;   // first pixel of the tile the B registers hold
     auto fetch = [&](int64_t pk) {
-        if constexpr (AV == 4) {
+        const float *const ab = a.A + pk * a.lda + m0, *const bb = a.B + pk * a.ldb + n0;
+        [[maybe_unused]] const float *const hb = BPRO == 2 ? a.B2 + pk * a.ldb + n0 : nullptr;
+        const bool rows_in = pk + kBK <= p1;                // workgroup-uniform: no predicates around the loads of a whole tile
+        bpk = pk;
+        if (rows_in && a_in) {
+            if constexpr (AV == 4) {
 #pragma unroll
-            for (int i = 0; i < APASS; ++i) {
-                const int64_t p = pk + apr + ARS * i;
-                ra[i] = (p < p1 && ac < a.M) ? ld4(a.A + p * a.lda + ac) : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int i = 0; i < APASS; ++i) ra[i] = ld4(at(ab, aoff[i]));
+            } else {
+#pragma unroll
+                for (int i = 0; i < APASS; ++i) sa1[i] = *at(ab, aoff[i]);
             }
         } else {
+            if constexpr (AV == 4) {
 #pragma unroll
-            for (int i = 0; i < APASS; ++i) {
-                const int64_t p = pk + apr + ARS * i;
-                sa1[i] = (p < p1 && ac < a.M) ? a.A[p * a.lda + ac] : 0.0f;
+                for (int i = 0; i < APASS; ++i) ra[i] = (pk + apr + ARS * i < p1 && ac < a.M) ? ld4(at(ab, aoff[i])) : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+#pragma unroll
+                for (int i = 0; i < APASS; ++i) sa1[i] = (pk + apr + ARS * i < p1 && ac < a.M) ? *at(ab, aoff[i]) : 0.0f;
             }
         }
-        bpk = pk;
-        if constexpr (BV == 4) {
+        if (rows_in && b_in) {
+            if constexpr (BV == 4) {
 #pragma unroll
-            for (int i = 0; i < BPASS; ++i) {
-                const int64_t p = pk + bpr + BRS * i;
-                const bool ok = p < p1 && bc < a.N;
-                rb[i] = ok ? ld4(a.B + p * a.ldb + bc) : make_float4(0.f, 0.f, 0.f, 0.f);
-                if constexpr (BPRO == 2) rh[i] = ok ? ld4(a.B2 + p * a.ldb + bc) : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int i = 0; i < BPASS; ++i) {
+                    rb[i] = ld4(at(bb, boff[i]));
+                    if constexpr (BPRO == 2) rh[i] = ld4(at(hb, boff[i]));
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < BPASS; ++i) {
+                    sb1[i] = *at(bb, boff[i]);
+                    if constexpr (BPRO == 2) sh1[i] = *at(hb, boff[i]);
+                }
             }
         } else {
+            if constexpr (BV == 4) {
 #pragma unroll
-            for (int i = 0; i < BPASS; ++i) {
-                const int64_t p = pk + bpr + BRS * i;
-                const bool ok = p < p1 && bc < a.N;
-                sb1[i] = ok ? a.B[p * a.ldb + bc] : 0.0f;
-                if constexpr (BPRO == 2) sh1[i] = ok ? a.B2[p * a.ldb + bc] : 0.0f;
+                for (int i = 0; i < BPASS; ++i) {
+                    const bool ok = pk + bpr + BRS * i < p1 && bc < a.N;
+                    rb[i] = ok ? ld4(at(bb, boff[i])) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    if constexpr (BPRO == 2) rh[i] = ok ? ld4(at(hb, boff[i])) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < BPASS; ++i) {
+                    const bool ok = pk + bpr + BRS * i < p1 && bc < a.N;
+                    sb1[i] = ok ? *at(bb, boff[i]) : 0.0f;
+                    if constexpr (BPRO == 2) sh1[i] = ok ? *at(hb, boff[i]) : 0.0f;
+                }
             }
         }
     };
@@ -624,10 +680,10 @@ __global__ __launch_bounds__(kT) void k_mm_kpix(const KpixArgs a)
             for (int i = 0; i < APASS; ++i) {
                 float4 v = ra[i];
                 if constexpr (APRO == 1) {
-                    v.x = fmaxf(xhat(v.x, cb.x, cm.x, cr.x), 0.0f);
-                    v.y = fmaxf(xhat(v.y, cb.y, cm.y, cr.y), 0.0f);
-                    v.z = fmaxf(xhat(v.z, cb.z, cm.z, cr.z), 0.0f);
-                    v.w = fmaxf(xhat(v.w, cb.w, cm.w, cr.w), 0.0f);
+                    v.x = fmaxf(xhat(v.x, cr.x, cc.x), 0.0f);
+                    v.y = fmaxf(xhat(v.y, cr.y, cc.y), 0.0f);
+                    v.z = fmaxf(xhat(v.z, cr.z, cc.z), 0.0f);
+                    v.w = fmaxf(xhat(v.w, cr.w, cc.w), 0.0f);
                 }
                 *reinterpret_cast<float4 *>(da + (apr + ARS * i) * BM + 4 * acq) = v;
             }
@@ -635,7 +691,7 @@ __global__ __launch_bounds__(kT) void k_mm_kpix(const KpixArgs a)
 #pragma unroll
             for (int i = 0; i < APASS; ++i) {
                 float v = sa1[i];
-                if constexpr (APRO == 1) v = fmaxf(xhat(v, cb.x, cm.x, cr.x), 0.0f);
+                if constexpr (APRO == 1) v = fmaxf(xhat(v, cr.x, cc.x), 0.0f);
                 da[(apr + ARS * i) * BM + acq] = v;
             }
         }
@@ -645,10 +701,10 @@ __global__ __launch_bounds__(kT) void k_mm_kpix(const KpixArgs a)
                 float4 v = rb[i];
                 if constexpr (BPRO == 2) {
                     const bool in = bpk + bpr + BRS * i < p1 && bc < a.N;     // rows past the chunk stay zero (and out of d bias)
-                    v.x = in ? bn_bwd(v.x, rh[i].x, kb[0], km[0], kr[0], ka[0], kq[0]) : 0.0f;
-                    v.y = in ? bn_bwd(v.y, rh[i].y, kb[1], km[1], kr[1], ka[1], kq[1]) : 0.0f;
-                    v.z = in ? bn_bwd(v.z, rh[i].z, kb[2], km[2], kr[2], ka[2], kq[2]) : 0.0f;
-                    v.w = in ? bn_bwd(v.w, rh[i].w, kb[3], km[3], kr[3], ka[3], kq[3]) : 0.0f;
+                    v.x = in ? bn_bwd(v.x, rh[i].x, kr[0], kc[0], ka[0], kq[0]) : 0.0f;
+                    v.y = in ? bn_bwd(v.y, rh[i].y, kr[1], kc[1], ka[1], kq[1]) : 0.0f;
+                    v.z = in ? bn_bwd(v.z, rh[i].z, kr[2], kc[2], ka[2], kq[2]) : 0.0f;
+                    v.w = in ? bn_bwd(v.w, rh[i].w, kr[3], kc[3], ka[3], kq[3]) : 0.0f;
                     dsum[0] += v.x; dsum[1] += v.y; dsum[2] += v.z; dsum[3] += v.w;
                 }
                 *reinterpret_cast<float4 *>(db + (bpr + BRS * i) * BN + 4 * bcq) = v;
@@ -659,7 +715,7 @@ __global__ __launch_bounds__(kT) void k_mm_kpix(const KpixArgs a)
                 float v = sb1[i];
                 if constexpr (BPRO == 2) {
                     const bool in = bpk + bpr + BRS * i < p1 && bc < a.N;
-                    v = in ? bn_bwd(v, sh1[i], kb[0], km[0], kr[0], ka[0], kq[0]) : 0.0f;
+                    v = in ? bn_bwd(v, sh1[i], kr[0], kc[0], ka[0], kq[0]) : 0.0f;
                     dsum[0] += v;
                 }
                 db[(bpr + BRS * i) * BN + bcq] = v;
@@ -678,27 +734,55 @@ __global__ __launch_bounds__(kT) void k_mm_kpix(const KpixArgs a)
         if (kt + 1 < nkt) fetch(p0 + (int64_t)(kt + 1) * kBK);
         const float *pa = sA + buf * kBK * BM + g * BM + wm * TM * 32 + TM * n;
         const float *pb = sB + buf * kBK * BN + g * BN + wn * TN * 32 + TN * n;
+        if constexpr (TM * TN == 4) {
+            // operand registers in a ring of 4 steps: the LDS reads of step st + 3 are ISSUED before the MFMAs of step st (left alone
+            // the compiler reads each step's pair right before its MFMAs and waits for it: an exposed LDS round trip per 4 MFMAs).
+            // d l_2/W at width 512: 610 -> 578 us
+            constexpr int NST = kBK / 2, LEAD = 3;
+            float av[4][TM], bv[4][TN];
+            auto rd = [&](int st) {
+                const float2 ta = *reinterpret_cast<const float2 *>(pa + 2 * st * BM), tb = *reinterpret_cast<const float2 *>(pb + 2 * st * BN);
+                av[st & 3][0] = ta.x;
+                av[st & 3][1] = ta.y;
+                bv[st & 3][0] = tb.x;
+                bv[st & 3][1] = tb.y;
+            };
 #pragma unroll
-        for (int st = 0; st < kBK / 2; ++st) {
-            float av[TM], bv[TN];
-            if constexpr (TM == 2) {
-                const float2 t = *reinterpret_cast<const float2 *>(pa + 2 * st * BM);
-                av[0] = t.x;
-                av[1] = t.y;
-            } else {
-                av[0] = pa[2 * st * BM];
+            for (int st = 0; st < LEAD; ++st) rd(st);
+#pragma unroll
+            for (int st = 0; st < NST; ++st) {
+                if (st + LEAD < NST) rd(st + LEAD);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st & 3][tm], bv[st & 3][tn], acc[tm][tn], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            if constexpr (TN == 2) {
-                const float2 t = *reinterpret_cast<const float2 *>(pb + 2 * st * BN);
-                bv[0] = t.x;
-                bv[1] = t.y;
-            } else {
-                bv[0] = pb[2 * st * BN];
+        } else {
+            // (with 1 or 2 MFMAs per step the pinned order LOSES — 100 -> 143 us for d l_last/W: the scheduler's own order stays)
+#pragma unroll
+            for (int st = 0; st < kBK / 2; ++st) {
+                float av[TM], bv[TN];
+                if constexpr (TM == 2) {
+                    const float2 t = *reinterpret_cast<const float2 *>(pa + 2 * st * BM);
+                    av[0] = t.x;
+                    av[1] = t.y;
+                } else {
+                    av[0] = pa[2 * st * BM];
+                }
+                if constexpr (TN == 2) {
+                    const float2 t = *reinterpret_cast<const float2 *>(pb + 2 * st * BN);
+                    bv[0] = t.x;
+                    bv[1] = t.y;
+                } else {
+                    bv[0] = pb[2 * st * BN];
+                }
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm], bv[tn], acc[tm][tn], 0, 0, 0);
             }
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm], bv[tn], acc[tm][tn], 0, 0, 0);
         }
         if (kt + 1 < nkt) park(buf ^ 1);
         __syncthreads();

@@ -28,7 +28,7 @@ static std::vector<float> host(const float *p, size_t n) { std::vector<float> v(
 static int fails = 0;
 static mm::Ctx cx{256, 0};
 
-static float hxhat(float h, float b, float m, float r) { return ((h + b) - m) * r; }
+static float hxhat(float h, float b, float m, float r) { return fmaf(h, r, (b - m) * r); }
 
 template <int APRO, int EPI, int AV>
 static void check_pix(int64_t P, int N, int K, int nslot)
