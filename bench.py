@@ -34,7 +34,7 @@ Rank 0 prints ONE JSON line.  Besides the contract keys it carries
   sharded_1m    configs[3] on this one GPU (2^20 resident patches, no process group)
   training      one training step (fwd batch-BN + bwd + EMA + Adam) at the reference's minibatch of 138: the shipped
                 architecture (width 4) and, nested as `width32`, the paper-scale coupling width on the matrix cores;
-                `width512`: the reference's default width (library GEMMs between run-time-width kernels)
+                `width512`: the reference's default width (hand-written fp32 matrix-core GEMMs, csrc/nf_train_mm.h)
   two_streams   the headline workload with consecutive steps alternating between two HIP streams
   large_patches 256x256x4 images (beyond the 64x64 a workgroup holds): overlapping tiles, DESIGN 4.8
 """
@@ -845,8 +845,9 @@ def _training(ctx, batches, cond, wide):
     trw.close()
     out["width32"] = {"workload": "the same step, coupling width 32 (fresh initialisation), 138 patches 32x32x4", "ms_per_step": msw,
                       "value": TB_ / (msw * 1e-3), "unit": "patches/s"}
-    # ... and at the width the reference's flags default to (sidd/ArgParser.py:43: 512): the dense products of a step are library
-    # GEMMs (rocBLAS sgemm, exact fp32) between hand-written kernels of run-time width (csrc/nf_train_gemm.h)
+    # ... and at the width the reference's flags default to (sidd/ArgParser.py:43: 512): the dense products of a step are the
+    # hand-written fp32 matrix-core GEMMs of csrc/nf_train_mm.h (v_mfma_f32_32x32x2_f32, BN + ReLU fused into the operand staging,
+    # batch sums into the epilogues) between kernels of run-time width (csrc/nf_train_gemm.h)
     try:
         trg = Trainer([32, 32, 4], default_hps(width=512), device=dev.index, max_batch=TB_)
         for _ in range(2):
@@ -864,8 +865,9 @@ def _training(ctx, batches, cond, wide):
         out["width512"] = {"workload": "the same step, coupling width 512 (the reference's default flag; fresh initialisation), "
                                        "138 patches 32x32x4", "steps": kg, "ms_per_step": msg, "value": TB_ / (msg * 1e-3), "unit": "patches/s",
                            "dense_tflops": flop / (msg * 1e-3) / 1e12,
-                           "note": "fp32 products on rocBLAS sgemm (f32 matrix peak 157.3 TFLOP/s)"}
-    except Exception as ex:    # e.g. librocblas missing on the box: reported, the other sections stand
+                           "dense_frac_of_f32_matrix_peak": flop / (msg * 1e-3) / 1e12 / 157.3,
+                           "note": "fp32 products on this repo's own v_mfma_f32_32x32x2_f32 GEMMs (csrc/nf_train_mm.h; f32 matrix peak 157.3 TFLOP/s); no library GEMM"}
+    except Exception as ex:    # reported, the other sections stand
         out["width512"] = {"error": str(ex)[:300]}
     return out
 

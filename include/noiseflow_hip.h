@@ -298,8 +298,8 @@ int nf_set_sync(nf_handle *h, nf_allreduce_fn fn, void *user, double *sync_buf, 
  * slots and an activation workspace sized for `max_batch` patches; a step only enqueues kernels on
  * `stream` — and on an internal side stream forked from and joined back into it with events — with no
  * allocation and no host synchronisation.  One stream at a time per trainer.
- * Layers: every NF_LAYER_* above (COUPLING at any width 1..512: 4/8/16/32 on kernels of their own, at every other width the dense products run on rocBLAS sgemm,
- * loaded with dlopen when such a trainer is created — NF_EINVAL with a message if librocblas cannot be loaded) — the whole
+ * Layers: every NF_LAYER_* above (COUPLING at any width 1..512: 4/8/16/32 on stage kernels of their own, every other width on the
+ * fp32 matrix-core GEMMs of csrc/nf_train_mm.h — no library GEMM, nothing loaded at run time) — the whole
  * vocabulary of noise_flow_arch under every
  * setting of hps.flow_permutation / hps.decomp; fp32 (nf_config.flags must be 0).
  * Trainable = everything except P / sign_S of CONV1X1 / CONV1X1_LU2, the BN statistics and c_i of SDN5 / SDN6.

@@ -110,7 +110,7 @@ __device__ __forceinline__ void flat_store(const float (&v)[4], float *red, cons
 // The pre-BN activations h stay WITHOUT their bias in memory: every consumer adds it on the fly (mm::xhat).
 
 // l_1 itself where the width allows the flat walk (a multiple of 4): h1 = Z18 . W1 has K = 18 — less arithmetic than the write
-// of its own result — so the library GEMM, its read-back for the statistics and their launches collapse into ONE pass: every
+// of its own result — so the product, the read-back for the statistics and their launches collapse into ONE pass: every
 // thread keeps the 18 x 4 filter entries of its four channels in registers, reads a pixel's 18 gathered inputs (the lanes that
 // share a pixel share the cache line), writes its float4 of h1 (without the bias, as everywhere here) and accumulates the batch
 // sums of h1 + bias.

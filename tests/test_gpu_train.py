@@ -703,8 +703,8 @@ def test_variables_shared_between_layers_receive_the_summed_gradient():
 def test_a_training_run_is_reproducible_bit_for_bit(shipped_variables, width):
     """Gradients, BN moments and updates come from slot reductions in a fixed order; on patches of a multiple of 64 pixels
     the reported loss / sd_z do too (one partial per wavefront, summed in order).  Two trainers fed the same minibatches
-    end in identical parameters and identical logged values, to the bit — also on the library-GEMM path (width 64: rocBLAS with
-    atomically accumulated products switched off, filter gradients as pixel-split partial products added up in a fixed order)."""
+    end in identical parameters and identical logged values, to the bit — also on the matrix-core GEMM path (width 64, csrc/nf_train_mm.h:
+    batch sums as slotted partials, filter gradients as pixel-chunk partial products added up in a fixed order, no atomics)."""
     import torch
     outs = []
     for rep in range(2):
@@ -844,7 +844,8 @@ def test_round_off_allowance_where_a_gradient_cancels():
                                                      ("unc", 2, (8, 6), 3, 3200, 4)])    # (width 1: torch's CPU conv backward refuses the oracle's graph)
 def test_gradients_at_coupling_widths_beyond_32(arch, width, hw, B, iso, cam):
     """sidd/ArgParser.py:43 defaults --width to 512 and train_noise_flow.py:50-77 trains at whatever width is set: beyond 32 the
-    step's dense products are library GEMMs (rocBLAS sgemm) between hand-written kernels over [pixel][w] tensors of run-time
+    step's dense products are this repo's fp32 matrix-core GEMMs (csrc/nf_train_mm.h: pixels on M resp. on K, BN + ReLU and the BN
+    backward formed while the operands are staged, batch sums in the epilogues) between kernels over [pixel][w] tensors of run-time
     width (csrc/nf_train_gemm.h) — and so are the widths below 32 that have no kernels of their own (1 .. 31 except 4, 8, 16):
     the trainer refuses nothing the reference's flag accepts up to 512.  Loss, sd_z, every gradient tensor and the BN running statistics against the fp64 autograd
     oracle; one Adam step against the float32 restatement of TF's update rule."""
