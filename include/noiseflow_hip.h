@@ -265,11 +265,13 @@ int nf_sample_host(nf_handle *h, const void *y, int32_t y_dtype, const float *ep
  *                (layers.py:392-393, decay 0.1) consumes; applying it is the caller's business.
  * Unlike nf_nll / nf_sample these calls run 2 statistics passes per coupling before the fused pass,
  * SYNCHRONISE `stream`, use a per-handle scratch (allocated on first use; concurrent calls on one
- * handle serialise) and are fp32 only.  B must be >= 1.  At coupling widths other than 4 the statistics
- * passes run on the scalar-weight kernel, whose two LDS tiles bound the patch: up to 1024 pixels at
- * width 32, ~2270 at width 16 (e.g. 45x48), ~4090 at width 8 (e.g. 62x62); larger -> NF_EINVAL.  Coupling widths 1 .. 32 (a
- * width between two kernel widths runs zero-padded on the next one and has that one's limit; moments_out rows keep the model's
- * own w channels); widths beyond 32 -> NF_EINVAL (nf_trainer_forward evaluates a minibatch's loss under batch statistics there). */
+ * handle serialise) and are fp32 only.  B must be >= 1.  Every coupling width 1 .. 512 and every patch size the handle was
+ * created for: width 4 on the matrix-core schedule of the fused kernel (images beyond 64x64 as overlapping tiles); widths up to 32
+ * on the scalar-weight kernel while its two LDS tiles hold the patch (1024 pixels at width 32, ~2270 at 16, ~4090 at 8; a width
+ * between two kernel widths runs zero-padded on the next one); everything else — widths beyond 32 (sidd/ArgParser.py:43 defaults to
+ * 512), 64x64 at the paper's width 32 — layer by layer on the trainer's matrix-core GEMM path (csrc/nf_train_mm.h) over one
+ * resident tensor, batch sums in the GEMM epilogues.  moments_out rows keep the model's own w channels on every route.
+ * NF_BS_WIDE=1 in the environment sends every call down the last route (A/B aid). */
 int nf_nll_batchstats(nf_handle *h, const float *x, const float *y, int64_t B, const nf_cond *cond,
                       float *nll_out, float *sd_out, float *logdet_out, float *z_out,
                       double *sums_out, uint32_t flags, float *moments_out, void *stream);

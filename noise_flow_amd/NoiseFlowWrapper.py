@@ -9,7 +9,10 @@ Two reference quirks are explicit options here:
 * Q1 ``binding``: the reference wrapper builds ONLY the sampling graph, which by
   TF-1.12 ``make_template`` semantics attaches the trained coupling-CNN weights
   to the layers in reversed order (``'sample_first'``).  The default here is
-  ``'loss_first'`` — the binding the model was trained with.
+  ``'loss_first'`` — the binding the model was trained with, and the one that reproduces the camera: on the shipped
+  checkpoint its samples carry 1.1 - 1.3 x the S6 NLF's standard deviation at temperature 1 (the "too-high noise variance"
+  ``sample_noise_flow.py:36-39`` tempers with 0.6), the reversed binding 3 - 47 x (pinned by
+  ``tests/test_gpu_scripts.py::test_wrapper_default_is_the_mode_that_reproduces_the_camera_noise``).
 * Q2 ``is_training=True`` in the reference's feed (``NoiseFlowWrapper.py:86``)
   switches BN to batch statistics.  The default here, ``bn_mode='running'``,
   uses the stored running statistics (the evaluation mode of

@@ -2031,8 +2031,10 @@ struct nf_bs_state {
     size_t T_cap = 0;                  // floats per scratch tensor
     float *d_carry = nullptr;          // [B][1024] per-thread log-det of the segments behind the resident tensor
     size_t carry_cap = 0;
+    nf_trainer *wide = nullptr;        // the layer-by-layer evaluator on the trainer's GEMM path (nf_bs_wide_*), where the passes above do not reach
     ~nf_bs_state()
     {
+        if (wide) (void)nf_trainer_destroy(wide);
         for (int d = 0; d < 2; ++d) {
             if (plan[d].d_ident) (void)hipFree(plan[d].d_ident);
             if (plan[d].d_ident2) (void)hipFree(plan[d].d_ident2);
@@ -2183,11 +2185,63 @@ static int bs_sync(nf_handle *h, double *stats, int nvals, hipStream_t st)
     return NF_OK;
 }
 
-static int run_batchstats(nf_handle *h, int direction, NfLaunch a, float *moments_out, hipStream_t st)
+// Where the statistics passes of the fused kernels do not reach — coupling widths beyond 32 (sidd/ArgParser.py:43 defaults to 512),
+// and patches beyond the scalar-weight kernel's two LDS tiles at widths 5 .. 32 (64x64 at the paper's width 32) — the call is a
+// layer-by-layer walk on the trainer's matrix-core GEMM path (nf_train.hip: nf_bs_wide_run): same moments, same outputs, one
+// resident tensor; the evaluator is created on first use and grows with B.
+static int run_batchstats_wide(nf_handle *h, int direction, const NfLaunch &a, const nf_cond *cond, float *moments_out, hipStream_t st)
+{
+    std::lock_guard<std::mutex> lock(h->bs_mu);   // one evaluator per handle: calls serialise
+    if (!h->bs) h->bs = new (std::nothrow) nf_bs_state();
+    if (!h->bs) return fail(NF_ENOMEM, "out of host memory");
+    nf_bs_state &S = *h->bs;
+    if (S.wide && nf_bs_wide_capacity(S.wide) < a.B) {
+        (void)nf_trainer_destroy(S.wide);
+        S.wide = nullptr;
+    }
+    if (!S.wide) {
+        nf_config cfg = h->cfg;
+        cfg.device = h->device;
+        int rc = nf_bs_wide_create(&cfg, h->layers.data(), h->raw.data(), h->raw.size(), a.B, &S.wide);
+        if (rc != NF_OK) return rc;
+    }
+    nf_bs_wide_args w;
+    memset(&w, 0, sizeof(w));
+    w.direction = direction;
+    w.in = (a.flags & NF_K_PHILOX_IN) ? nullptr : a.in;
+    w.y = a.y;
+    w.B = a.B;
+    w.cond = cond;
+    w.seed = a.seed;
+    w.patch_base = a.patch_base;
+    w.in_scale = a.in_scale;
+    w.out = a.out;
+    w.nll_out = a.nll_out;
+    w.sd_out = a.sd_out;
+    w.ld_out = a.ld_out;
+    w.sums = a.sums;
+    w.prior = (a.flags & NF_K_PRIOR) != 0;
+    w.moments_out = moments_out;
+    w.sync_fn = h->sync_fn;
+    w.sync_user = h->sync_user;
+    w.sync_buf = h->sync_buf;
+    w.sync_world = h->sync_world;
+    return nf_bs_wide_run(S.wide, w, st);
+}
+
+static int run_batchstats(nf_handle *h, int direction, NfLaunch a, float *moments_out, hipStream_t st, const nf_cond *cond)
 {
     if (h->cfg.flags & NF_CFG_FP16_CNN) return fail(NF_EINVAL, "batch-statistics mode is fp32 only");
-    if (h->fwd.prog.width > 32)
-        return fail(NF_EINVAL, "batch-statistics mode covers the coupling widths 1 .. 32 (the model has %d)", h->fwd.raw_width);
+    {
+        // the generic schedule below runs on the scalar-weight kernel: both LDS tiles of a patch on one CU, one pixel per lane at
+        // width 32; the width-4 schedule on the matrix-core kernel takes every size (images beyond 64x64 as overlapping tiles)
+        const int pw = h->fwd.prog.width;
+        const size_t tile_px = ((size_t)(a.H + 2) * (a.W + 2) + 1) & ~(size_t)1;
+        const bool scalar_fits = sizeof(float) * (tile_px * (2 + (size_t)pw) + 64) <= 160 * 1024 && !(pw >= 32 && a.H * a.W > 1024) && h->scalar_ok && !h->fwd.tiled;
+        const bool mc4 = pw == 4 && !h->fwd.block2.empty() && use_matrix_core();
+        if (pw > 32 || (!mc4 && !scalar_fits) || getenv("NF_BS_WIDE"))   // (NF_BS_WIDE=1: A/B aid)
+            return run_batchstats_wide(h, direction, a, cond, moments_out, st);
+    }
     const int wr = h->fwd.raw_width;   // rows of moments_out are [4][wr]; the kernels' rows [4][prog.width] (zero-padded widths)
     // images beyond 64x64 (nf_device.h, "overlapping tiles"): the width-4 matrix-core schedule below, every launch tiled with
     // ONE halo for the whole call — 3 = the deepest launch (re-run coupling c-1, then l_1 of coupling c for its statistics) —
@@ -2493,7 +2547,7 @@ int nf_nll_batchstats(nf_handle *h, const float *x, const float *y, int64_t B, c
         hipError_t e = hipMemsetAsync(sums_out, 0, nb * sizeof(double), st);
         if (e != hipSuccess) return fail_hip(e, "hipMemsetAsync(sums)");
     }
-    return run_batchstats(h, 0, a, moments_out, st);
+    return run_batchstats(h, 0, a, moments_out, st, cond);
 }
 
 int nf_sample_batchstats(nf_handle *h, const float *y, const float *eps, uint64_t seed, int64_t patch_index_base,
@@ -2505,7 +2559,7 @@ int nf_sample_batchstats(nf_handle *h, const float *y, const float *eps, uint64_
     if (B == 0) return fail(NF_EINVAL, "batch statistics of an empty batch are undefined");
     DeviceGuard guard;
     if ((rc = guard.enter(h->device)) != NF_OK) return rc;
-    return run_batchstats(h, 1, a, moments_out, (hipStream_t)stream);
+    return run_batchstats(h, 1, a, moments_out, (hipStream_t)stream, cond);
 }
 
 int nf_set_sync(nf_handle *h, nf_allreduce_fn fn, void *user, double *sync_buf, int32_t world_size)

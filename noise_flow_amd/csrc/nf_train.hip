@@ -29,6 +29,7 @@
 
 #include "../../include/noiseflow_hip.h"
 #include "nf_internal.h"
+#include "nf_dev_util.h"   // philox_normal4 (the evaluator draws the fused kernels' epsilon)
 
 namespace {
 
@@ -1528,6 +1529,14 @@ struct nf_trainer {
     float *gpack = nullptr;         // every coupling's weights in the GEMMs' packed layouts (gemm_pack_floats(w) each; written by the forward pass)
     float *gdw = nullptr;           // filter gradients of every coupling as the pixel-K GEMMs leave them: 3 per coupling x gemm_part_floats(w)
     int gnp[3 * kMaxLayers] = {};   // how many partial products each of them holds (this step)
+    // evaluation under batch statistics at the widths / patch sizes the fused kernels' statistics passes do not take (nf_bs_wide_*,
+    // called by nf_*_batchstats): a trimmed trainer — every coupling on the GEMM path, ONE pair of hidden tensors, no backward state
+    bool all_gemm = false, eval_only = false;
+    float *ebuf = nullptr;          // [max_batch][H][W][4] working tensor (when the caller gives no output tensor)
+    double *eldp = nullptr;         // [max_batch] per-patch data-dependent log-det
+    float *emom = nullptr;          // [n_cpl][4][w] batch mean1, var1, mean2, var2 of the current call
+    float *eAinv = nullptr;         // [n_mix][16] inverse Conv2d1x1 matrices (sampling direction)
+    int n_mix = 0;
     bool gemm_c1_fused = false;     // NF_TRAIN_GEMM_C1=1: l_1 forward on the VALU kernel k_g_c1_fwd (widths that are a multiple of 4; A/B aid)
 };
 
@@ -1867,7 +1876,7 @@ bool tiled_ok(const nf_trainer *t, const Geo &g, int width, int pass /* 1 backwa
     // near 400 (one 1024-thread workgroup per CU: past one round over the 256 CUs the layer kernels' finer grain wins)
     const int64_t npatch = g.npix / g.HW;
     // (NF_TRAIN_GEMM=1 sends widths 4 / 8 down the GEMM path: the create-time allocation and this dispatch share gemm_width())
-    return (t->tiled & pass) && !gemm_width(width) && (width == 4 || width == 8) && g.HW <= 1024 && npatch <= g.nslot && npatch <= 384;
+    return (t->tiled & pass) && !(t->all_gemm || gemm_width(width)) && (width == 4 || width == 8) && g.HW <= 1024 && npatch <= g.nslot && npatch <= 384;
 }
 
 #define NF_WIDTH_SWITCH(w, CALL)            \
@@ -1921,8 +1930,17 @@ int nf_trainer_destroy(nf_trainer *t)
     return NF_OK;
 }
 
+static int trainer_create_impl(const nf_config *cfg, const nf_layer_desc *layers, const float *params, size_t n_params,
+                               int64_t max_batch, int32_t optimizer, bool eval_only, nf_trainer **out);
+
 int nf_trainer_create(const nf_config *cfg, const nf_layer_desc *layers, const float *params, size_t n_params,
                       int64_t max_batch, int32_t optimizer, nf_trainer **out)
+{
+    return trainer_create_impl(cfg, layers, params, n_params, max_batch, optimizer, false, out);
+}
+
+static int trainer_create_impl(const nf_config *cfg, const nf_layer_desc *layers, const float *params, size_t n_params,
+                               int64_t max_batch, int32_t optimizer, bool eval_only, nf_trainer **out)
 {
     if (!out) return nf_fail(NF_EINVAL, "out is NULL");
     *out = nullptr;
@@ -1938,6 +1956,7 @@ int nf_trainer_create(const nf_config *cfg, const nf_layer_desc *layers, const f
     nf_trainer *t = new (std::nothrow) nf_trainer();
     if (!t) return nf_fail(NF_ENOMEM, "out of host memory");
     t->cfg = *cfg;
+    t->eval_only = t->all_gemm = eval_only;
     if (const char *e = getenv("NF_TRAIN_TILED")) t->tiled = atoi(e);
     if (const char *e = getenv("NF_TRAIN_WIDE_MFMA")) t->wide_mfma = atoi(e);
     if (const char *e = getenv("NF_TRAIN_SERIAL")) t->serial = atoi(e) != 0;
@@ -2058,19 +2077,28 @@ int nf_trainer_create(const nf_config *cfg, const nf_layer_desc *layers, const f
 
     const int w = t->width ? t->width : 4;
     const size_t act = (size_t)max_batch * cfg->height * cfg->width;   // pixels
+    t->n_mix = n_mix;
+    const bool gemm_path = t->all_gemm || gemm_width(w);
     // double workspace
-    size_t nd = n_params;
-    t->d_dA = (int)nd; nd += 16 * (size_t)n_mix;
-    t->d_dab = (int)nd; nd += 2 * (size_t)n_sdn;
-    t->d_dg = (int)nd; nd += (size_t)n_gain;
-    t->d_ld0 = (int)nd; nd += (size_t)cfg->n_layers;   // batch total of each layer's data-dependent log-det
+    size_t nd = eval_only ? 0 : n_params;
+    t->d_dA = (int)nd; nd += eval_only ? 0 : 16 * (size_t)n_mix;
+    t->d_dab = (int)nd; nd += eval_only ? 0 : 2 * (size_t)n_sdn;
+    t->d_dg = (int)nd; nd += eval_only ? 0 : (size_t)n_gain;
+    t->d_ld0 = (int)nd; nd += eval_only ? 0 : (size_t)cfg->n_layers;   // batch total of each layer's data-dependent log-det
     t->cpl.resize(n_cpl);
     for (Cpl &c : t->cpl) {
+        if (eval_only) {            // one coupling at a time: every coupling's batch sums share the same slots
+            c.d_st1 = 0;
+            c.d_st2 = 2 * w;
+            c.d_bs1 = c.d_bs2 = 0;
+            continue;
+        }
         c.d_st1 = (int)nd; nd += 2 * w;
         c.d_st2 = (int)nd; nd += 2 * w;
         c.d_bs1 = (int)nd; nd += 2 * w;
         c.d_bs2 = (int)nd; nd += 2 * w;
     }
+    if (eval_only) nd = 4 * (size_t)w;
     t->d_ldc = (int)nd; nd += 1;   // last: the only value accumulated directly (k_prep), not through slots
     t->n_dbl = nd;
     // float scalars
@@ -2092,13 +2120,40 @@ int nf_trainer_create(const nf_config *cfg, const nf_layer_desc *layers, const f
         return rc;                \
     }
     NF_TRY(dev_alloc(t, (void **)&t->d_params, n_params * sizeof(float)));
+    NF_TRY(dev_alloc(t, (void **)&t->d_dbl, nd * sizeof(double)));
+    NF_TRY(dev_alloc(t, (void **)&t->d_part, (nd - 1) * NSLOT * sizeof(float)));
+    NF_TRY(dev_alloc(t, (void **)&t->d_flt, nf * sizeof(float)));
+    if (eval_only) {
+        NF_TRY(dev_alloc(t, (void **)&t->ebuf, act * 4 * sizeof(float)));
+        NF_TRY(dev_alloc(t, (void **)&t->eldp, (size_t)max_batch * sizeof(double)));
+        NF_TRY(dev_alloc(t, (void **)&t->emom, (size_t)std::max(n_cpl, 1) * 4 * w * sizeof(float)));
+        NF_TRY(dev_alloc(t, (void **)&t->eAinv, (size_t)std::max(n_mix, 1) * 16 * sizeof(float)));
+        if (n_cpl > 0) {
+            float *h1 = nullptr, *h2 = nullptr;
+            NF_TRY(dev_alloc(t, (void **)&h1, act * w * sizeof(float)));
+            NF_TRY(dev_alloc(t, (void **)&h2, act * w * sizeof(float)));
+            for (Cpl &c : t->cpl) {
+                c.h1 = h1;
+                c.h2 = h2;
+            }
+            NF_TRY(dev_alloc(t, (void **)&t->gz18, act * kZ18 * sizeof(float)));
+            NF_TRY(dev_alloc(t, (void **)&t->gp36, act * 36 * sizeof(float)));
+            NF_TRY(dev_alloc(t, (void **)&t->gpack, gemm_pack_floats(w) * sizeof(float)));
+        }
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, t->device) == hipSuccess && cus > 0) t->n_cu = cus;
+        if ((e = hipMemcpy(t->d_params, params, n_params * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess ||
+            (e = hipMemset(t->d_part, 0, (nd - 1) * NSLOT * sizeof(float))) != hipSuccess) {
+            nf_trainer_destroy(t);
+            return nf_fail_hip(e, "evaluator initialisation");
+        }
+        *out = t;
+        return NF_OK;
+    }
     NF_TRY(dev_alloc(t, (void **)&t->d_m, n_params * sizeof(float)));
     NF_TRY(dev_alloc(t, (void **)&t->d_v, n_params * sizeof(float)));
     NF_TRY(dev_alloc(t, (void **)&t->d_gradf, n_params * sizeof(float)));
     NF_TRY(dev_alloc(t, (void **)&t->d_mask, n_params));
-    NF_TRY(dev_alloc(t, (void **)&t->d_dbl, nd * sizeof(double)));
-    NF_TRY(dev_alloc(t, (void **)&t->d_part, (nd - 1) * NSLOT * sizeof(float)));
-    NF_TRY(dev_alloc(t, (void **)&t->d_flt, nf * sizeof(float)));
     NF_TRY(dev_alloc(t, (void **)&t->d_patch, 2 * (size_t)max_batch * sizeof(float)));
     NF_TRY(dev_alloc(t, (void **)&t->d_wpart, 2 * ((act + 63) / 64) * sizeof(float)));
     t->zs.assign(cfg->n_layers + 1, nullptr);
@@ -2106,9 +2161,9 @@ int nf_trainer_create(const nf_config *cfg, const nf_layer_desc *layers, const f
     for (Cpl &c : t->cpl) {
         NF_TRY(dev_alloc(t, (void **)&c.h1, act * w * sizeof(float)));
         NF_TRY(dev_alloc(t, (void **)&c.h2, act * w * sizeof(float)));
-        if (w >= 16 || gemm_width(w)) NF_TRY(dev_alloc(t, (void **)&c.u, act * 4 * sizeof(float)));
+        if (w >= 16 || gemm_path) NF_TRY(dev_alloc(t, (void **)&c.u, act * 4 * sizeof(float)));
     }
-    if (gemm_width(w) && n_cpl > 0) {   // nf_train_gemm.h
+    if (gemm_path && n_cpl > 0) {   // nf_train_gemm.h
         NF_TRY(dev_alloc(t, (void **)&t->gz18, act * kZ18 * sizeof(float)));
         NF_TRY(dev_alloc(t, (void **)&t->gp36, act * 36 * sizeof(float)));
         NF_TRY(dev_alloc(t, (void **)&t->gq18, act * 18 * sizeof(float)));
@@ -2118,7 +2173,7 @@ int nf_trainer_create(const nf_config *cfg, const nf_layer_desc *layers, const f
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, t->device) == hipSuccess && cus > 0) t->n_cu = cus;
     }
-    for (int k = 0; k < (gemm_width(w) ? 1 : 3); ++k) {
+    for (int k = 0; k < (gemm_path ? 1 : 3); ++k) {
         NF_TRY(dev_alloc(t, (void **)&t->t1[k], act * w * sizeof(float)));
         NF_TRY(dev_alloc(t, (void **)&t->t2[k], act * w * sizeof(float)));
         NF_TRY(dev_alloc(t, (void **)&t->gu[k], act * 4 * sizeof(float)));
@@ -2239,7 +2294,7 @@ static int trainer_run(nf_trainer *t, const float *x, const float *y, int64_t B,
                 if (L.width == 4) NF_CALL(4); else NF_CALL(8);
 #undef NF_CALL
                 f1_done = nxt != nullptr;
-            } else if (gemm_width(L.width)) {
+            } else if (t->all_gemm || gemm_width(L.width)) {
                 if (!coupling_forward_gemm(t, g, L, zin, zout, t->acc(t->d_ld0 + l), zpre, Am, st)) mm_failed = true;
             } else {
 #define NF_CALL(WW) coupling_forward<WW>(t, g, L, zin, zout, t->acc(t->d_ld0 + l), zpre, Am, st)
@@ -2309,7 +2364,7 @@ static int trainer_run(nf_trainer *t, const float *x, const float *y, int64_t B,
                 if (L.width == 4) NF_CALL(4); else NF_CALL(8);
 #undef NF_CALL
                 a_done = nxt != nullptr;
-            } else if (gemm_width(L.width)) {
+            } else if (t->all_gemm || gemm_width(L.width)) {
                 if (!coupling_backward_gemm(t, g, L, t->zs[l], invB, zmix_in, Am, dA, st, zlat)) mm_failed = true;
             } else {
 #define NF_CALL(WW) coupling_backward<WW>(t, g, L, t->zs[l], invB, zmix_in, Am, dA, st, zlat)
@@ -2327,7 +2382,7 @@ static int trainer_run(nf_trainer *t, const float *x, const float *y, int64_t B,
             (void)hipStreamWaitEvent(st, t->ev_done[par], 0);
             t->done_pending[par] = false;
         }
-    if (gemm_width(t->width)) {
+    if (t->all_gemm || gemm_width(t->width)) {
         // the filters of wide couplings get their gradients whole from the GEMMs: the slotted sums are added up for every other
         // value only (the runs between the filters), then the GEMM results are stored next to them
         int lo = 0;
@@ -2438,3 +2493,108 @@ int nf_trainer_set_params(nf_trainer *t, const float *params, size_t n_params, v
 int64_t nf_trainer_steps(const nf_trainer *t) { return t ? t->step : -1; }
 
 }  // extern "C"
+
+// ---- evaluation under batch statistics on the GEMM path (not part of the ABI: nf_*_batchstats of nf_host.hip call these) ---------
+int nf_bs_wide_create(const nf_config *cfg, const nf_layer_desc *layers, const float *params, size_t n_params, int64_t max_batch,
+                      nf_trainer **out)
+{
+    nf_config c = *cfg;
+    c.flags = 0;
+    return trainer_create_impl(&c, layers, params, n_params, max_batch, NF_OPT_ADAM, true, out);
+}
+
+int64_t nf_bs_wide_capacity(const nf_trainer *t) { return t ? t->max_batch : 0; }
+
+int nf_bs_wide_run(nf_trainer *t, const nf_bs_wide_args &a, hipStream_t st)
+{
+    if (!t || !t->eval_only) return nf_fail(NF_EINVAL, "internal: not an evaluator");
+    if (a.B < 1 || a.B > t->max_batch) return nf_fail(NF_EINVAL, "internal: evaluator capacity %lld < B", (long long)t->max_batch);
+    CondIdx ci;
+    int rc = cond_index(a.cond, t->has_sdn || t->needs_cond, t->needs_cam, ci);
+    if (rc != NF_OK) return rc;
+    if (t->has_sdn && !a.y) return nf_fail(NF_EINVAL, "model has a signal-dependent layer but y is NULL");
+    Guard guard;
+    if ((rc = guard.enter(t->device)) != NF_OK) return rc;
+    t->sync_fn = a.sync_fn;
+    t->sync_user = a.sync_user;
+    t->sync_buf = a.sync_fn ? a.sync_buf : nullptr;
+    t->sync_world = a.sync_fn ? a.sync_world : 1;
+    t->sync_rc = 0;
+
+    Geo g;
+    g.B = (int)a.B;
+    g.H = t->cfg.height;
+    g.W = t->cfg.width;
+    g.HW = g.H * g.W;
+    g.npix = a.B * (int64_t)g.HW;
+    g.nloop = (g.npix + 63) & ~(int64_t)63;
+    const unsigned nb = blocks_for(g.npix);
+    g.nslot = (t->sync_fn && t->sync_world > 1) ? std::max((int)nb, 2) : (int)nb;
+    const int n = t->cfg.n_layers, w = t->width ? t->width : 4;
+    const unsigned nB = (unsigned)a.B;
+    double *G = t->d_dbl;
+    float *z = a.out ? a.out : t->ebuf;
+    bool ok = true;
+    hipError_t e;
+
+    hipLaunchKernelGGL(k_prep, dim3(1), dim3(64), 0, st, t->tl, t->d_params, ci, g.HW, t->d_flt + t->f_A, t->d_flt + t->f_ab, t->d_flt + t->f_s,
+                       G + t->d_ldc, t->d_flt, 0);
+    if ((e = hipMemsetAsync(t->eldp, 0, (size_t)a.B * sizeof(double), st)) != hipSuccess) return nf_fail_hip(e, "evaluator set-up");
+    hipLaunchKernelGGL(k_e_input, dim3(nb), dim3(TB), 0, st, g, a.in, a.in_scale, a.seed, a.patch_base, z);
+    if (a.direction == 0) {
+        for (int l = 0; l < n; ++l) {
+            const TLayer &L = t->tl.l[l];
+            switch (L.type) {
+            case NF_LAYER_SDN5:
+            case NF_LAYER_SDN4:
+                hipLaunchKernelGGL(k_e_sdn<false>, dim3(nB), dim3(TB), 0, st, g.HW, z, a.y, t->d_flt + t->f_ab + 2 * L.aux, t->eldp);
+                break;
+            case NF_LAYER_GAIN4:
+                hipLaunchKernelGGL(k_scale_fwd, dim3(nb), dim3(TB), 0, st, g, (const float *)z, t->d_flt + t->f_s + L.aux, z);
+                break;
+            case NF_LAYER_CONV1X1:
+                hipLaunchKernelGGL(k_mix_fwd, dim3(nb), dim3(TB), 0, st, g, (const float *)z, t->d_flt + t->f_A + 16 * L.aux, z);
+                break;
+            case NF_LAYER_COUPLING:
+                ok = coupling_cnn_gemm(t, g, L, z, st, t->emom + (size_t)L.aux * 4 * w) && ok;
+                hipLaunchKernelGGL(k_e_c3<false>, dim3(nB), dim3(TB), 0, st, g.H, g.W, L.width, z, (const float *)t->gp36, (const float *)t->d_params,
+                                   L.off + 24 * L.width + L.width * L.width, t->eldp);
+                break;
+            }
+        }
+        if (a.nll_out || a.sd_out || a.ld_out || a.sums)
+            hipLaunchKernelGGL(k_e_finish, dim3(nB), dim3(TB), 0, st, g.HW, (const float *)z, (const double *)t->eldp, (const double *)(G + t->d_ldc),
+                               a.prior ? 1 : 0, a.nll_out, a.sd_out, a.ld_out, a.sums);
+    } else {
+        if (t->n_mix > 0)
+            hipLaunchKernelGGL(k_e_inv4, dim3((unsigned)((t->n_mix + 63) / 64)), dim3(64), 0, st, t->n_mix, (const float *)(t->d_flt + t->f_A), t->eAinv);
+        for (int l = n - 1; l >= 0; --l) {
+            const TLayer &L = t->tl.l[l];
+            switch (L.type) {
+            case NF_LAYER_SDN5:
+            case NF_LAYER_SDN4:
+                hipLaunchKernelGGL(k_e_sdn<true>, dim3(nB), dim3(TB), 0, st, g.HW, z, a.y, t->d_flt + t->f_ab + 2 * L.aux, t->eldp);
+                break;
+            case NF_LAYER_GAIN4:
+                hipLaunchKernelGGL(k_e_scale_mul, dim3(nb), dim3(TB), 0, st, g, z, (const float *)(t->d_flt + t->f_s + L.aux));
+                break;
+            case NF_LAYER_CONV1X1:
+                hipLaunchKernelGGL(k_mix_fwd, dim3(nb), dim3(TB), 0, st, g, (const float *)z, (const float *)(t->eAinv + 16 * L.aux), z);
+                break;
+            case NF_LAYER_COUPLING:
+                ok = coupling_cnn_gemm(t, g, L, z, st, t->emom + (size_t)L.aux * 4 * w) && ok;
+                hipLaunchKernelGGL(k_e_c3<true>, dim3(nB), dim3(TB), 0, st, g.H, g.W, L.width, z, (const float *)t->gp36, (const float *)t->d_params,
+                                   L.off + 24 * L.width + L.width * L.width, t->eldp);
+                break;
+            }
+        }
+    }
+    if ((e = hipGetLastError()) != hipSuccess) return nf_fail_hip(e, "evaluator launch");
+    if (!ok) return nf_fail(NF_EHIP, "a matrix-core GEMM of the batch-statistics evaluation could not be launched");
+    const size_t nmom = t->cpl.size() * 4 * (size_t)w;
+    if (a.moments_out && nmom) e = hipMemcpyAsync(a.moments_out, t->emom, nmom * sizeof(float), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);   // like every nf_*_batchstats call
+    if (e != hipSuccess) return nf_fail_hip(e, "batch-statistics evaluation");
+    if (t->sync_rc) return nf_fail(NF_EINVAL, "the all-reduce callback of nf_set_sync failed (status %d)", t->sync_rc);
+    return NF_OK;
+}

