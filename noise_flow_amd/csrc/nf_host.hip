@@ -1368,6 +1368,7 @@ struct nf_handle {
         size_t bytes = 0;
         hipEvent_t ev = nullptr;   // recorded behind the last launch that used the buffer
         bool busy = false;         // a host thread is enqueueing on it
+        bool used = false;         // `ev` was recorded behind real work (a freshly reserved buffer has no prior user to wait for)
     };
     std::mutex ws_mu;
     std::vector<Workspace *> ws;
@@ -1692,42 +1693,51 @@ static int ws_acquire(nf_handle *h, size_t bytes, hipStream_t st, nf_handle::Wor
 {
     *out = nullptr;
     if (bytes == 0) return NF_OK;
-    std::lock_guard<std::mutex> lk(h->ws_mu);
     nf_handle::Workspace *w = nullptr;
-    for (nf_handle::Workspace *c : h->ws)      // smallest free buffer that is large enough, else the largest free one (to grow)
-        if (!c->busy && (!w || (c->bytes >= bytes ? (w->bytes < bytes || c->bytes < w->bytes) : (w->bytes < bytes && c->bytes > w->bytes)))) w = c;
     hipError_t e = hipSuccess;
-    if (!w) {
-        w = new (std::nothrow) nf_handle::Workspace();
-        if (!w) return fail(NF_ENOMEM, "out of host memory");
-        if ((e = hipEventCreateWithFlags(&w->ev, hipEventDisableTiming)) != hipSuccess) {
-            delete w;
-            return fail_hip(e, "hipEventCreate");
+    {
+        std::lock_guard<std::mutex> lk(h->ws_mu);
+        for (nf_handle::Workspace *c : h->ws)      // smallest free buffer that is large enough, else the largest free one (to grow)
+            if (!c->busy && (!w || (c->bytes >= bytes ? (w->bytes < bytes || c->bytes < w->bytes) : (w->bytes < bytes && c->bytes > w->bytes)))) w = c;
+        if (!w) {
+            w = new (std::nothrow) nf_handle::Workspace();
+            if (!w) return fail(NF_ENOMEM, "out of host memory");
+            if ((e = hipEventCreateWithFlags(&w->ev, hipEventDisableTiming)) != hipSuccess) {
+                delete w;
+                return fail_hip(e, "hipEventCreate");
+            }
+            h->ws.push_back(w);
         }
-        h->ws.push_back(w);
+        w->busy = true;                            // ours from here on: the lock is NOT held across the (device-synchronising) grow below
     }
-    if (w->bytes < bytes) {                    // grow: the only allocation a call can make (the first one of its size)
+    if (w->bytes < bytes) {                        // grow: the only allocation a call can make (the first one of its size)
         if (w->p) {
             (void)hipEventSynchronize(w->ev);
             (void)hipFree(w->p);
             w->p = nullptr;
             w->bytes = 0;
         }
-        if ((e = hipMalloc((void **)&w->p, bytes)) != hipSuccess) return fail_hip(e, "hipMalloc(tiled workspace)");
+        if ((e = hipMalloc((void **)&w->p, bytes)) != hipSuccess) {
+            std::lock_guard<std::mutex> lk(h->ws_mu);
+            w->busy = false;
+            return fail_hip(e, "hipMalloc(tiled workspace)");
+        }
         w->bytes = bytes;
-    } else if ((e = hipStreamWaitEvent(st, w->ev, 0)) != hipSuccess) {
+    } else if (w->used && (e = hipStreamWaitEvent(st, w->ev, 0)) != hipSuccess) {
+        std::lock_guard<std::mutex> lk(h->ws_mu);
+        w->busy = false;
         return fail_hip(e, "hipStreamWaitEvent");
     }
-    w->busy = true;
     *out = w;
     return NF_OK;
 }
 
-static void ws_release(nf_handle *h, nf_handle::Workspace *w, hipStream_t st)
+static void ws_release(nf_handle *h, nf_handle::Workspace *w, hipStream_t st, bool worked = true)
 {
     if (!w) return;
-    (void)hipEventRecord(w->ev, st);
+    if (worked) (void)hipEventRecord(w->ev, st);   // (nf_reserve_workspace only sized the buffer: nothing for its first user to wait for)
     std::lock_guard<std::mutex> lk(h->ws_mu);
+    if (worked) w->used = true;
     w->busy = false;
 }
 
@@ -1934,7 +1944,7 @@ int nf_reserve_workspace(nf_handle *h, int64_t B, int32_t calls_in_flight)
         rc = ws_acquire(h, need, nullptr, &w);   // marks it busy, so that the next iteration takes (or makes) another one
         if (w) got.push_back(w);
     }
-    for (nf_handle::Workspace *w : got) ws_release(h, w, nullptr);
+    for (nf_handle::Workspace *w : got) ws_release(h, w, nullptr, false);
     return rc;
 }
 

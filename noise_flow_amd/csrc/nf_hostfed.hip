@@ -349,7 +349,9 @@ struct PipeLease {   // hands the pipe back when the call returns
             std::lock_guard<std::mutex> lk(g_pipes_mu);
             p->busy = false;
         }
-        g_pipes_cv.notify_one();
+        // every waiter, not one: the condition variable is shared by the waiters of EVERY handle, and a waiter of another handle
+        // woken alone would find no free pipe of its own, sleep again and leave this handle's waiter asleep beside an idle pipe
+        g_pipes_cv.notify_all();
     }
 };
 

@@ -145,6 +145,8 @@ __global__ __launch_bounds__(kT) void k_mm_pix(const PixArgs a)
     const int j = tid & 7, r0 = tid >> 3;      // staging: k4 group j of the rows r0 + 32 i
     const int n0 = nt * BN;
 
+    // (Measured and dropped: starting the second workgroup of every CU half a tile late, so that one's epilogue falls into the
+    // other's K loop — 670 vs 672 us for l_2 at width 512: the two are not in lockstep to begin with.)
     if constexpr (APRO != 0) {
         for (int i = tid; i < Kc; i += kT) {
             const float rs = i < a.K ? a.abn[a.K + i] : 0.0f;
