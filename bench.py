@@ -54,6 +54,9 @@ sys.path.insert(0, ROOT)
 ARCH_LABEL = "sdn5|unc|unc|unc|unc|gain4|unc|unc|unc|unc"
 ALGO_BYTES_PER_PATCH = 2 * 32 * 32 * 4 * 4          # read x and y once (fp32): 32768 B
 ALGO_FLOP_PER_PATCH = 5.1e6
+# ... of which the kernels EXECUTE less: §8d counts l_last at 36 x 5 = 180 MAC per pixel and coupling (the edge-indicator channel as a
+# fifth input), the kernels fold that channel into a 16-entry border table and run 36 x 4 = 144 — both fractions are reported
+EXEC_FLOP_PER_PATCH = ALGO_FLOP_PER_PATCH - 8 * 1024 * 36 * 2
 HBM_PEAK_GBS = 8000.0                                # MI355X_MICROARCH.md: 8 TB/s spec
 VALU_PEAK_TFLOPS = 157.3                             # fp32 vector peak = fp32-input matrix peak
 FP16_SHAPE_PEAK_TFLOPS = 248.0 / (216.0 / 512 + 16.0 / 128 + 16.0 / 32) * 2 * 1024 * 2.4e9 / 1e12   # see _fp16_cnn
@@ -539,6 +542,8 @@ def single_gpu_leg(ctx):
                      "kernel": "nf_flow_kernel<4,256,4,false,true,true,0,false>", "kernel_ms": kernel_ms,
                      "frac_from_kernel_ms": ALGO_FLOP_PER_PATCH * B / (kernel_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS,
                      "algorithmic_flop_per_launch": ALGO_FLOP_PER_PATCH * B,
+                     "executed_flop_per_launch": EXEC_FLOP_PER_PATCH * B,
+                     "frac_executed": EXEC_FLOP_PER_PATCH * B / (ms_step * 1e-3) / 1e12 / VALU_PEAK_TFLOPS,
                      "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                              "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PATCH * B,
                              "note": "structurally capped near 13 %: 32 KiB and 5.1 MFLOP per patch"}},
@@ -630,6 +635,8 @@ def _sampling(ctx, batches, cond, wide):
                          "traffic": traffic, "traffic_source": traffic_src, "time_base": "HIP events over the timed launches",
                          "kernel": "nf_flow_kernel<4,256,4,true,true,true,0,false>", "kernel_ms": kms,
                          "algorithmic_flop_per_launch": ALGO_FLOP_PER_PATCH * SB,
+                         "executed_flop_per_launch": EXEC_FLOP_PER_PATCH * SB,
+                         "frac_executed": EXEC_FLOP_PER_PATCH * SB / (kms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS,
                          "hbm": {"achieved": sbytes / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": sbytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": sbytes}}}
 
@@ -845,30 +852,33 @@ def _training(ctx, batches, cond, wide):
     trw.close()
     out["width32"] = {"workload": "the same step, coupling width 32 (fresh initialisation), 138 patches 32x32x4", "ms_per_step": msw,
                       "value": TB_ / (msw * 1e-3), "unit": "patches/s"}
-    # ... and at the width the reference's flags default to (sidd/ArgParser.py:43: 512): the dense products of a step are the
+    # ... and at the width the reference's flags default to (sidd/ArgParser.py:43: 512), and at 64: the dense products of a step are the
     # hand-written fp32 matrix-core GEMMs of csrc/nf_train_mm.h (v_mfma_f32_32x32x2_f32, BN + ReLU fused into the operand staging,
     # batch sums into the epilogues) between kernels of run-time width (csrc/nf_train_gemm.h)
-    try:
-        trg = Trainer([32, 32, 4], default_hps(width=512), device=dev.index, max_batch=TB_)
-        for _ in range(2):
-            trg.step(xt_, yt_, [0.0], [0.0], [100.0], [2.0], lr=1e-4, sync=False)
-        torch.cuda.synchronize(dev)
-        kg = 5
-        g0.record(stream)
-        for _ in range(kg):
-            trg.step(xt_, yt_, [0.0], [0.0], [100.0], [2.0], lr=1e-4, sync=False)
-        g1.record(stream)
-        torch.cuda.synchronize(dev)
-        msg = g0.elapsed_time(g1) / kg
-        trg.close()
-        flop = 3.0 * 2.0 * (18 * 512 + 512 * 512 + 512 * 36) * 8 * TB_ * 1024      # forward + two transposed products per filter
-        out["width512"] = {"workload": "the same step, coupling width 512 (the reference's default flag; fresh initialisation), "
-                                       "138 patches 32x32x4", "steps": kg, "ms_per_step": msg, "value": TB_ / (msg * 1e-3), "unit": "patches/s",
-                           "dense_tflops": flop / (msg * 1e-3) / 1e12,
-                           "dense_frac_of_f32_matrix_peak": flop / (msg * 1e-3) / 1e12 / 157.3,
-                           "note": "fp32 products on this repo's own v_mfma_f32_32x32x2_f32 GEMMs (csrc/nf_train_mm.h; f32 matrix peak 157.3 TFLOP/s); no library GEMM"}
-    except Exception as ex:    # reported, the other sections stand
-        out["width512"] = {"error": str(ex)[:300]}
+    for wg_, kg in ((512, 5), (64, 20)):
+        key = "width%d" % wg_
+        try:
+            trg = Trainer([32, 32, 4], default_hps(width=wg_), device=dev.index, max_batch=TB_)
+            for _ in range(2):
+                trg.step(xt_, yt_, [0.0], [0.0], [100.0], [2.0], lr=1e-4, sync=False)
+            torch.cuda.synchronize(dev)
+            g0.record(stream)
+            for _ in range(kg):
+                trg.step(xt_, yt_, [0.0], [0.0], [100.0], [2.0], lr=1e-4, sync=False)
+            g1.record(stream)
+            torch.cuda.synchronize(dev)
+            msg = g0.elapsed_time(g1) / kg
+            trg.close()
+            flop = 3.0 * 2.0 * (18 * wg_ + wg_ * wg_ + wg_ * 36) * 8 * TB_ * 1024      # forward + two transposed products per filter
+            out[key] = {"workload": "the same step, coupling width %d (%sfresh initialisation), 138 patches 32x32x4"
+                                    % (wg_, "the reference's default flag; " if wg_ == 512 else ""),
+                        "steps": kg, "ms_per_step": msg, "value": TB_ / (msg * 1e-3), "unit": "patches/s",
+                        "dense_tflops": flop / (msg * 1e-3) / 1e12,
+                        "dense_frac_of_f32_matrix_peak": flop / (msg * 1e-3) / 1e12 / VALU_PEAK_TFLOPS,
+                        "note": "fp32 products on this repo's own v_mfma_f32_32x32x2_f32 GEMMs (csrc/nf_train_mm.h; f32 matrix peak "
+                                "157.3 TFLOP/s); no library GEMM"}
+        except Exception as ex:    # reported, the other sections stand
+            out[key] = {"error": str(ex)[:300]}
     return out
 
 

@@ -1529,6 +1529,7 @@ struct nf_trainer {
     float *gpack = nullptr;         // every coupling's weights in the GEMMs' packed layouts (gemm_pack_floats(w) each; written by the forward pass)
     float *gdw = nullptr;           // filter gradients of every coupling as the pixel-K GEMMs leave them: 3 per coupling x gemm_part_floats(w)
     int gnp[3 * kMaxLayers] = {};   // how many partial products each of them holds (this step)
+    bool gdual[kMaxLayers] = {};    // d l_last/W was left as [chunk][relu | mask][w][36] (k_mm_kpix <APRO 3>)
     // evaluation under batch statistics at the widths / patch sizes the fused kernels' statistics passes do not take (nf_bs_wide_*,
     // called by nf_*_batchstats): a trimmed trainer — every coupling on the GEMM path, ONE pair of hidden tensors, no backward state
     bool all_gemm = false, eval_only = false;
@@ -2407,7 +2408,7 @@ static int trainer_run(nf_trainer *t, const float *x, const float *y, int64_t B,
             if (L.type != NF_LAYER_COUPLING) continue;
             const int w = L.width;
             const float *gdw = t->gdw + (size_t)(3 * L.aux + 2) * gemm_part_floats(w);
-            store_grad(st, 36 * w, w, 1, gdw, t->gnp[3 * L.aux + 2], G, L.off + 24 * w + w * w);
+            store_grad(st, 36 * w, w, 1, gdw, t->gnp[3 * L.aux + 2], G, L.off + 24 * w + w * w, t->gdual[L.aux] ? 2 * 36 * w : 0);
         }
     } else {
         hipLaunchKernelGGL(k_reduce, dim3((unsigned)t->d_ldc), dim3(64), 0, st, t->d_ldc, t->d_part, g.nslot, G);

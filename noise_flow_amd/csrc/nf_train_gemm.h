@@ -16,9 +16,10 @@
 //             u = gather of the 9 taps of P + edge channel + b3; affine transform   k_g_c3_fwd
 //   backward  affine / tanh / exp(3 logs) backward -> gu, d b3, d logs, d scale     k_g_c3_bwd
 //             G36[p][tap*4+k] = gu[p - tap][k]; d edge-channel weights              k_g_gather36
-//             d l_last/W = relu(bn2(h2 + b2))^T . G36                               k_mm_kpix <APRO 1>
-//             the two batch sums of BN2's backward over g_a2 = G36 . W3r^T          k_mm_pix <EPI 4> (nothing stored)        -> k_bnb_fin
-//             g_h2 = BN2 backward of the masked g_a2 (formed again: K = 36); d b2   k_mm_pix <EPI 3>
+//             d l_last/W = relu(bn2(h2 + b2))^T . G36  (w >= 256: and mask2^T . G36)   k_mm_kpix <APRO 1 / 3> (one pass over h2)
+//             the two batch sums of BN2's backward: those products . W3r            k_g_bnb_from_parts                       -> k_bnb_fin
+//                                    (w < 256: a sums-only pass over G36 . W3r^T)   k_mm_pix <EPI 4>
+//             g_h2 = BN2 backward of the masked g_a2 = G36 . W3r^T (K = 36); d b2   k_mm_pix <EPI 3>
 //             d l_2/W = relu(bn1(h1 + b1))^T . g_h2                                 k_mm_kpix <APRO 1>
 //             g_a1 = g_h2 . W2^T + the two batch sums of BN1's backward             k_mm_pix <EPI 2>                         -> k_bnb_fin
 //             d l_1/W = Z18^T . g_h1, g_h1 = BN1 backward of the masked g_a1; d b1  k_mm_kpix <BPRO 2>
@@ -329,13 +330,13 @@ __global__ void k_g_c1_dz(Geo g, const float *__restrict__ Q18, float *__restric
 // mode 0: G[dst + e];  mode 1 (l_last/W): the partials are [w][36] = (i, tap*4 + k) -> G[dst + (tap*(w+1) + i)*4 + k]
 constexpr int kStoreY = 16;   // threads that share one gradient entry's partial products
 __global__ void __launch_bounds__(64 * kStoreY) k_g_store_grad(int n, int w, int mode, const float *__restrict__ part, int nparts,
-                                                                double *__restrict__ G, int dst)
+                                                                double *__restrict__ G, int dst, int pstride)
 {
     __shared__ double acc[kStoreY][64];
     const int e = blockIdx.x * 64 + threadIdx.x;
     double s = 0.0;
     if (e < n)
-        for (int q = threadIdx.y; q < nparts; q += kStoreY) s += (double)part[(size_t)q * n + e];
+        for (int q = threadIdx.y; q < nparts; q += kStoreY) s += (double)part[(size_t)q * pstride + e];
     acc[threadIdx.y][threadIdx.x] = s;
     __syncthreads();
     if (threadIdx.y != 0 || e >= n) return;
@@ -347,9 +348,37 @@ __global__ void __launch_bounds__(64 * kStoreY) k_g_store_grad(int n, int w, int
         G[dst + (tap * (w + 1) + i) * 4 + k] = s;
     }
 }
-inline void store_grad(hipStream_t st, int n, int w, int mode, const float *part, int nparts, double *G, int dst)
+// pstride: floats between two partial products (0: n)
+inline void store_grad(hipStream_t st, int n, int w, int mode, const float *part, int nparts, double *G, int dst, int pstride = 0)
 {
-    hipLaunchKernelGGL(k_g_store_grad, dim3((n + 63) / 64), dim3(64, kStoreY), 0, st, n, w, mode, part, nparts, G, dst);
+    hipLaunchKernelGGL(k_g_store_grad, dim3((n + 63) / 64), dim3(64, kStoreY), 0, st, n, w, mode, part, nparts, G, dst, pstride ? pstride : n);
+}
+
+// The two batch sums of BN2's backward from the two products of k_mm_kpix <APRO 3> (part[s][0] = relu(xhat)^T . G36 = d l_last/W as
+// [w][36], part[s][1] = mask^T . G36), contracted with the filter W3r [w][36]:
+//   sum_p gx xhat = sum_col W3r[i][col] (relu(xhat)^T G36)[i][col]      (gx = mask g_a2, g_a2 = G36 . W3r^T, relu(xhat) = mask xhat)
+//   sum_p gx      = sum_col W3r[i][col] (mask^T G36)[i][col]
+// in fp64 over the chunks, left as slot 0 (hi) + slot 1 (lo) of the slotted sums k_bnb_fin / sync_slots read.  One wavefront per channel.
+__global__ __launch_bounds__(64) void k_g_bnb_from_parts(int w, int S, const float *__restrict__ part, const float *__restrict__ W3r, Acc bstats,
+                                                          int nslot)
+{
+    const int i = blockIdx.x, lane = threadIdx.x;
+    double sx = 0.0, sg = 0.0;
+    for (int e = lane; e < S * 36; e += 64) {
+        const int sidx = e / 36, col = e - sidx * 36;
+        const float wv = W3r[i * 36 + col];
+        const float *ps = part + ((size_t)sidx * 2 * w + i) * 36 + col;
+        sx += (double)wv * (double)ps[0];
+        sg += (double)wv * (double)ps[(size_t)w * 36];
+    }
+    sx = wsum(sx);
+    sg = wsum(sg);
+    float *pg = (bstats + i).p, *px = (bstats + (w + i)).p;
+    const float gh = (float)sg, xh = (float)sx;
+    for (int k = lane; k < nslot; k += 64) {
+        pg[k] = k == 0 ? gh : k == 1 ? (float)(sg - (double)gh) : 0.0f;
+        px[k] = k == 0 ? xh : k == 1 ? (float)(sx - (double)xh) : 0.0f;
+    }
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------------
@@ -476,24 +505,33 @@ bool coupling_backward_gemm(nf_trainer *t, const Geo &g, const TLayer &L, const 
     mm::PixArgs a{};
     a.P = g.npix;
     a.nslot = g.nslot;
-    // ---- d l_last/W = relu(bn2(h2 + b2))^T . G36 ----
+    // ---- d l_last/W = relu(bn2(h2 + b2))^T . G36 — and the two batch sums of BN2's backward over g_a2 = G36 . W3r^T.  At wide
+    //      couplings the same kernel also forms mask2^T . G36: contracted with the filter the two products ARE those sums
+    //      (k_g_bnb_from_parts) and no pass over a [pixel][w] tensor is spent on them (width 512: 228 -> 186 us per coupling); below
+    //      256 channels the sums-only pass over the K = 36 product is the cheaper way (width 64: 3.7 against 3.9 ms per step) ----
+    const bool dual = w >= 256;
     k.M = w; k.N = 36;
     k.A = c.h2; k.lda = w; k.B = t->gp36; k.ldb = 36; k.part = dW3r;
     k.abias = P + off_b2; k.abn = bn2;
-    if (w > 64) np[2] = v4 ? mm::mm_kpix_launch<2, 2, 1, 1, 4, 4>(cx, st, k) : mm::mm_kpix_launch<2, 2, 1, 1, 1, 4>(cx, st, k);
+    if (dual) np[2] = v4 ? mm::mm_kpix_launch<2, 2, 1, 3, 4, 4>(cx, st, k) : mm::mm_kpix_launch<2, 2, 1, 3, 1, 4>(cx, st, k);
+    else if (w > 64) np[2] = v4 ? mm::mm_kpix_launch<2, 2, 1, 1, 4, 4>(cx, st, k) : mm::mm_kpix_launch<2, 2, 1, 1, 1, 4>(cx, st, k);
     else np[2] = v4 ? mm::mm_kpix_launch<2, 1, 1, 1, 4, 4>(cx, st, k) : mm::mm_kpix_launch<2, 1, 1, 1, 1, 4>(cx, st, k);
     ok = ok && np[2] > 0;
-    // ---- g_a2 = G36 . W3r^T is a K = 36 product — cheap enough to form TWICE instead of passing a [pixel][w] tensor through
-    //      memory three more times: pass 1 leaves only the two batch sums of BN2's backward, pass 2 forms it again and stores
-    //      g_h2 = BN2 backward of the masked g_a2 (and adds up d b2)
+    t->gdual[L.aux] = dual;
     a.N = w; a.K = 36;
     a.A = t->gp36; a.lda = 36;
     a.Bt = pk + pl.o_w3b; a.ldb = 36;
     a.C = t1; a.ldc = w;
-    a.ebias = P + off_b2; a.ebn = bn2; a.eh = c.h2; a.ldh = w; a.stats = t->acc(c.d_bs2).p;
-    ok = mm::mm_pix<0, 4, 4>(cx, st, a) && ok;
+    a.ebias = P + off_b2; a.ebn = bn2; a.eh = c.h2; a.ldh = w;
+    if (dual) {
+        hipLaunchKernelGGL(k_g_bnb_from_parts, dim3(w), dim3(64), 0, st, w, np[2], (const float *)dW3r, pk + pl.o_w3b, t->acc(c.d_bs2), g.nslot);
+    } else {
+        a.stats = t->acc(c.d_bs2).p;
+        ok = mm::mm_pix<0, 4, 4>(cx, st, a) && ok;
+    }
     sync_slots(t, t->acc(c.d_bs2), 2 * w, g.nslot, st);
     hipLaunchKernelGGL(k_bnb_fin, dim3(w), dim3(64), 0, st, t->acc(c.d_bs2), w, g.nslot, n, t->d_flt + c.f_bb2);
+    // ---- g_h2 = BN2 backward of the masked g_a2 = G36 . W3r^T (K = 36), stored once; d b2 = its column sums ----
     a.ebb = bb2; a.stats = (G + off_b2).p;
     ok = mm::mm_pix<0, 3, 4>(cx, st, a) && ok;
     // ---- d l_2/W = relu(bn1(h1 + b1))^T . g_h2 ----

@@ -548,13 +548,18 @@ struct KpixArgs {
 //   TM, TN    32-channel tiles per wavefront along M / N (1 or 2): the workgroup's tile is (32 WMv TM) x (32 (4 / WMv) TN)
 //   AV, BV    4: the operand's rows are 16-byte aligned and its width is a multiple of 4;  1: anything
 //   BPRO      0: B as stored;  2: B = BN backward of the masked B, formed while the tile is staged (and its column sums = d bias)
+//   APRO      0: A as stored;  1: A = relu(xhat(A + bias));  3: TWO products from one pass over A — part[s][0] with A = relu(xhat)
+//             and part[s][1] with A = the ReLU mask (xhat > 0): with B = G36 the first is d l_last/W and, contracted with the
+//             filter, sum gx xhat of BN2's backward; the second contracted with the filter is sum gx (k_g_bnb_from_parts) — the
+//             batch sums of BN2's backward without a pass over a [pixel][w] tensor of their own
 template <int WMv, int TM, int TN, int APRO, int AV, int BV, int BPRO = 0>
 __global__ __launch_bounds__(kT) void k_mm_kpix(const KpixArgs a)
 {
     constexpr int WNv = 4 / WMv, BM = WMv * TM * 32, BN = WNv * TN * 32;
+    constexpr int NA = APRO == 3 ? 2 : 1;      // A tiles staged / accumulator sets
     extern __shared__ __attribute__((aligned(16))) float mm_smem[];
-    float *const sA = mm_smem;                 // [2][kBK][BM]
-    float *const sB = sA + 2 * kBK * BM;       // [2][kBK][BN]
+    float *const sA = mm_smem;                 // [2][NA][kBK][BM]
+    float *const sB = sA + 2 * NA * kBK * BM;  // [2][kBK][BN]
 
     const int tiles = a.m_tiles * a.n_tiles;
     const int id = blockIdx.x, xcd = id & 7, q = id >> 3;
@@ -572,8 +577,8 @@ __global__ __launch_bounds__(kT) void k_mm_kpix(const KpixArgs a)
     static_assert(kT % AQ == 0 && kT % BQ == 0 && kBK % ARS == 0 && kBK % BRS == 0 && APASS >= 1 && BPASS >= 1, "staging split");
     const int acq = tid % AQ, apr = tid / AQ, bcq = tid % BQ, bpr = tid / BQ;
     const int ac = m0 + AV * acq, bc = n0 + BV * bcq;      // first channel this thread stages
-    float4 cr = make_float4(0.f, 0.f, 0.f, 0.f), cc = cr;      // APRO 1: rstd and c = (bias - mean) rstd of this thread's channels
-    if constexpr (APRO == 1) {
+    float4 cr = make_float4(0.f, 0.f, 0.f, 0.f), cc = cr;      // APRO 1 / 3: rstd and c = (bias - mean) rstd of this thread's channels
+    if constexpr (APRO == 1 || APRO == 3) {
         float t[8];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -598,13 +603,15 @@ __global__ __launch_bounds__(kT) void k_mm_kpix(const KpixArgs a)
     }
     const bool sums = BPRO == 2 && tile / a.n_tiles == 0;   // one workgroup row adds up d bias (every m tile stages the same B)
 
-    v16f acc[TM][TN];
+    v16f acc[NA][TM][TN];
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
+    for (int na = 0; na < NA; ++na)
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
+        for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-            for (int v = 0; v < 16; ++v) acc[tm][tn][v] = 0.0f;
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[na][tm][tn][v] = 0.0f;
 
     // Operand addresses = a wavefront-uniform base (chunk position: scalar registers) + a per-lane 32-bit byte offset that never
     // changes (pixel row within the staged tile, channel): scalar-base loads, no vector address arithmetic in the K loop
@@ -626,6 +633,29 @@ __global__ __launch_bounds__(kT) void k_mm_kpix(const KpixArgs a)
         [[maybe_unused]] const float *const hb = BPRO == 2 ? a.B2 + pk * a.ldb + n0 : nullptr;
         const bool rows_in = pk + kBK <= p1;                // workgroup-uniform: no predicates around the loads of a whole tile
         bpk = pk;
+        if (rows_in && a_in && b_in) {                      // the common case as ONE straight block (measured: split into a block per
+            if constexpr (AV == 4) {                        // operand the 512 x 512 product lost 8 %)
+#pragma unroll
+                for (int i = 0; i < APASS; ++i) ra[i] = ld4(at(ab, aoff[i]));
+            } else {
+#pragma unroll
+                for (int i = 0; i < APASS; ++i) sa1[i] = *at(ab, aoff[i]);
+            }
+            if constexpr (BV == 4) {
+#pragma unroll
+                for (int i = 0; i < BPASS; ++i) {
+                    rb[i] = ld4(at(bb, boff[i]));
+                    if constexpr (BPRO == 2) rh[i] = ld4(at(hb, boff[i]));
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < BPASS; ++i) {
+                    sb1[i] = *at(bb, boff[i]);
+                    if constexpr (BPRO == 2) sh1[i] = *at(hb, boff[i]);
+                }
+            }
+            return;
+        }
         if (rows_in && a_in) {
             if constexpr (AV == 4) {
 #pragma unroll
@@ -643,58 +673,46 @@ __global__ __launch_bounds__(kT) void k_mm_kpix(const KpixArgs a)
                 for (int i = 0; i < APASS; ++i) sa1[i] = (pk + apr + ARS * i < p1 && ac < a.M) ? *at(ab, aoff[i]) : 0.0f;
             }
         }
-        if (rows_in && b_in) {
-            if constexpr (BV == 4) {
+        if constexpr (BV == 4) {
 #pragma unroll
-                for (int i = 0; i < BPASS; ++i) {
-                    rb[i] = ld4(at(bb, boff[i]));
-                    if constexpr (BPRO == 2) rh[i] = ld4(at(hb, boff[i]));
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < BPASS; ++i) {
-                    sb1[i] = *at(bb, boff[i]);
-                    if constexpr (BPRO == 2) sh1[i] = *at(hb, boff[i]);
-                }
+            for (int i = 0; i < BPASS; ++i) {
+                const bool ok = pk + bpr + BRS * i < p1 && bc < a.N;
+                rb[i] = ok ? ld4(at(bb, boff[i])) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (BPRO == 2) rh[i] = ok ? ld4(at(hb, boff[i])) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         } else {
-            if constexpr (BV == 4) {
 #pragma unroll
-                for (int i = 0; i < BPASS; ++i) {
-                    const bool ok = pk + bpr + BRS * i < p1 && bc < a.N;
-                    rb[i] = ok ? ld4(at(bb, boff[i])) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    if constexpr (BPRO == 2) rh[i] = ok ? ld4(at(hb, boff[i])) : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < BPASS; ++i) {
-                    const bool ok = pk + bpr + BRS * i < p1 && bc < a.N;
-                    sb1[i] = ok ? *at(bb, boff[i]) : 0.0f;
-                    if constexpr (BPRO == 2) sh1[i] = ok ? *at(hb, boff[i]) : 0.0f;
-                }
+            for (int i = 0; i < BPASS; ++i) {
+                const bool ok = pk + bpr + BRS * i < p1 && bc < a.N;
+                sb1[i] = ok ? *at(bb, boff[i]) : 0.0f;
+                if constexpr (BPRO == 2) sh1[i] = ok ? *at(hb, boff[i]) : 0.0f;
             }
         }
     };
     auto park = [&](int buf) {
-        float *da = sA + buf * kBK * BM, *db = sB + buf * kBK * BN;
+        float *da = sA + buf * NA * kBK * BM, *db = sB + buf * kBK * BN;
         if constexpr (AV == 4) {
 #pragma unroll
             for (int i = 0; i < APASS; ++i) {
                 float4 v = ra[i];
-                if constexpr (APRO == 1) {
+                if constexpr (APRO == 1 || APRO == 3) {
                     v.x = fmaxf(xhat(v.x, cr.x, cc.x), 0.0f);
                     v.y = fmaxf(xhat(v.y, cr.y, cc.y), 0.0f);
                     v.z = fmaxf(xhat(v.z, cr.z, cc.z), 0.0f);
                     v.w = fmaxf(xhat(v.w, cr.w, cc.w), 0.0f);
                 }
                 *reinterpret_cast<float4 *>(da + (apr + ARS * i) * BM + 4 * acq) = v;
+                if constexpr (APRO == 3)      // the ReLU mask: relu(xhat) > 0 <=> xhat > 0 (rows past the chunk: a zero row of B beside them)
+                    *reinterpret_cast<float4 *>(da + kBK * BM + (apr + ARS * i) * BM + 4 * acq) =
+                        make_float4(v.x > 0.f ? 1.f : 0.f, v.y > 0.f ? 1.f : 0.f, v.z > 0.f ? 1.f : 0.f, v.w > 0.f ? 1.f : 0.f);
             }
         } else {
 #pragma unroll
             for (int i = 0; i < APASS; ++i) {
                 float v = sa1[i];
-                if constexpr (APRO == 1) v = fmaxf(xhat(v, cr.x, cc.x), 0.0f);
+                if constexpr (APRO == 1 || APRO == 3) v = fmaxf(xhat(v, cr.x, cc.x), 0.0f);
                 da[(apr + ARS * i) * BM + acq] = v;
+                if constexpr (APRO == 3) da[kBK * BM + (apr + ARS * i) * BM + acq] = v > 0.f ? 1.f : 0.f;
             }
         }
         if constexpr (BV == 4) {
@@ -734,9 +752,9 @@ __global__ __launch_bounds__(kT) void k_mm_kpix(const KpixArgs a)
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nkt) fetch(p0 + (int64_t)(kt + 1) * kBK);
-        const float *pa = sA + buf * kBK * BM + g * BM + wm * TM * 32 + TM * n;
+        const float *pa = sA + buf * NA * kBK * BM + g * BM + wm * TM * 32 + TM * n;
         const float *pb = sB + buf * kBK * BN + g * BN + wn * TN * 32 + TN * n;
-        if constexpr (TM * TN == 4) {
+        if constexpr (TM * TN == 4 && NA == 1) {
             // operand registers in a ring of 4 steps: the LDS reads of step st + 3 are ISSUED before the MFMAs of step st (left alone
             // the compiler reads each step's pair right before its MFMAs and waits for it: an exposed LDS round trip per 4 MFMAs).
             // d l_2/W at width 512: 610 -> 578 us
@@ -758,20 +776,23 @@ __global__ __launch_bounds__(kT) void k_mm_kpix(const KpixArgs a)
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                    for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st & 3][tm], bv[st & 3][tn], acc[tm][tn], 0, 0, 0);
+                    for (int tn = 0; tn < TN; ++tn) acc[0][tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st & 3][tm], bv[st & 3][tn], acc[0][tm][tn], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
             // (with 1 or 2 MFMAs per step the pinned order LOSES — 100 -> 143 us for d l_last/W: the scheduler's own order stays)
 #pragma unroll
             for (int st = 0; st < kBK / 2; ++st) {
-                float av[TM], bv[TN];
-                if constexpr (TM == 2) {
-                    const float2 t = *reinterpret_cast<const float2 *>(pa + 2 * st * BM);
-                    av[0] = t.x;
-                    av[1] = t.y;
-                } else {
-                    av[0] = pa[2 * st * BM];
+                float av[NA][TM], bv[TN];
+#pragma unroll
+                for (int na = 0; na < NA; ++na) {
+                    if constexpr (TM == 2) {
+                        const float2 t = *reinterpret_cast<const float2 *>(pa + na * kBK * BM + 2 * st * BM);
+                        av[na][0] = t.x;
+                        av[na][1] = t.y;
+                    } else {
+                        av[na][0] = pa[na * kBK * BM + 2 * st * BM];
+                    }
                 }
                 if constexpr (TN == 2) {
                     const float2 t = *reinterpret_cast<const float2 *>(pb + 2 * st * BN);
@@ -781,9 +802,12 @@ __global__ __launch_bounds__(kT) void k_mm_kpix(const KpixArgs a)
                     bv[0] = pb[2 * st * BN];
                 }
 #pragma unroll
-                for (int tm = 0; tm < TM; ++tm)
+                for (int na = 0; na < NA; ++na)
 #pragma unroll
-                    for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tm], bv[tn], acc[tm][tn], 0, 0, 0);
+                    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                        for (int tn = 0; tn < TN; ++tn)
+                            acc[na][tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[na][tm], bv[tn], acc[na][tm][tn], 0, 0, 0);
             }
         }
         if (kt + 1 < nkt) park(buf ^ 1);
@@ -791,18 +815,20 @@ __global__ __launch_bounds__(kT) void k_mm_kpix(const KpixArgs a)
     }
 
     // D register v of lane (n, g): MFMA row r = 8 (v >> 2) + 4 g + (v & 3) -> channel m0 + wm TM 32 + TM r + tm; column n -> n0 + wn TN 32 + TN n + tn
-    float *const out = a.part + (size_t)s * a.M * a.N;
+    float *const out = a.part + (size_t)s * NA * a.M * a.N;     // [NA][M][N] per chunk
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
+    for (int na = 0; na < NA; ++na)
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            const int col = n0 + wn * TN * 32 + TN * n + tn;
+        for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int row = m0 + wm * TM * 32 + TM * (8 * (v >> 2) + 4 * g + (v & 3)) + tm;
-                if (row < a.M && col < a.N) out[(size_t)row * a.N + col] = acc[tm][tn][v];
+            for (int tn = 0; tn < TN; ++tn) {
+                const int col = n0 + wn * TN * 32 + TN * n + tn;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int row = m0 + wm * TM * 32 + TM * (8 * (v >> 2) + 4 * g + (v & 3)) + tm;
+                    if (row < a.M && col < a.N) out[((size_t)na * a.M + row) * a.N + col] = acc[na][tm][tn][v];
+                }
             }
-        }
 
     if constexpr (BPRO == 2) {
         if (!sums) return;                       // workgroup-uniform
@@ -825,9 +851,9 @@ __global__ __launch_bounds__(kT) void k_mm_kpix(const KpixArgs a)
 }
 
 template <int WMv, int TM, int TN>
-constexpr size_t kpix_lds_bytes()
+constexpr size_t kpix_lds_bytes(int na = 1)
 {
-    return (size_t)2 * kBK * (WMv * TM * 32 + (4 / WMv) * TN * 32) * sizeof(float);   // (>= the [BRS][BN] floats of the d-bias reduction)
+    return (size_t)2 * kBK * (na * WMv * TM * 32 + (4 / WMv) * TN * 32) * sizeof(float);   // (>= the [BRS][BN] floats of the d-bias reduction)
 }
 
 // ---- weights into the layout k_mm_pix reads: dst [rows][ld], ld % 4 == 0, zero beyond `cols` ----------------------------------
@@ -922,12 +948,12 @@ inline int mm_kpix_launch(const Ctx &cx, hipStream_t st, KpixArgs a)
     a.n_tiles = (a.N + BN - 1) / BN;
     const int tiles = a.m_tiles * a.n_tiles;
     int64_t S = std::max<int64_t>(1, (4 * (int64_t)cx.n_cu + tiles - 1) / tiles);     // ~4 workgroups per CU over the whole launch
-    S = std::min<int64_t>(S, std::min<int64_t>(256, kGradPartFloats / ((int64_t)a.M * a.N)));
+    S = std::min<int64_t>(S, std::min<int64_t>(256, kGradPartFloats / ((APRO == 3 ? 2 : 1) * (int64_t)a.M * a.N)));
     S = std::min<int64_t>(S, std::max<int64_t>(1, a.npix / (4 * kBK)));            // chunks of at least 128 pixels
     if (BPRO == 2) S = std::min<int64_t>(S, std::max(1, a.nslot));                     // one d-bias slot per chunk
     a.chunk = ((a.npix + S - 1) / S + kBK - 1) / kBK * kBK;
     a.S = (int)((a.npix + a.chunk - 1) / a.chunk);
-    const size_t lds = kpix_lds_bytes<WMv, TM, TN>();
+    const size_t lds = kpix_lds_bytes<WMv, TM, TN>(APRO == 3 ? 2 : 1);
     auto fn = &k_mm_kpix<WMv, TM, TN, APRO, AV, BV, BPRO>;
     static std::atomic<size_t> enabled[16];
     if (!mm_enable_lds(reinterpret_cast<const void *>(fn), lds, cx.device, enabled)) return 0;

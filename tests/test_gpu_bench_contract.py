@@ -39,6 +39,13 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
             assert k in rr, (sec, k)
         assert abs(rr["frac"] - rr["achieved"] / rr["peak"]) < 1e-9 and 0 < rr["hbm"]["frac"] < 1
     assert d["fp16_cnn_64x64"]["roofline"]["peak"] == 2500.0 and d["fp16_cnn_64x64"]["roofline"]["shape_peak"]["frac"] > 0
+    # both flop counts in the line: SURVEY 8(d)'s algorithmic 5.1 MFLOP per patch and what the kernels execute (144-MAC l_last)
+    for rr in (r, d["sampling"]["roofline"]):
+        assert 0 < rr["executed_flop_per_launch"] < rr["algorithmic_flop_per_launch"] and 0 < rr["frac_executed"] < rr["frac"] * 1.05
+    # the trainer at the widths without stage kernels: this repo's own GEMMs (no library GEMM in the note, a measured fraction)
+    for key in ("width512", "width64"):
+        tw = d["training"][key]
+        assert "error" not in tw and tw["ms_per_step"] > 0 and 0 < tw["dense_frac_of_f32_matrix_peak"] < 1 and "no library GEMM" in tw["note"]
     w512 = d["wide_cnn"]["w512"]     # Glow's default width (sidd/ArgParser.py:43) on the LDS-staged GEMM kernel
     assert w512["finite"] and w512["value"] > 0 and "nf_gemm_kernel" in w512["kernel_path"] and w512["roofline"]["frac"] > 0.3
     lp = d["large_patches"]          # 256x256 images as overlapping tiles

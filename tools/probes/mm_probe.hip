@@ -115,18 +115,21 @@ static void check_kpix(int64_t npix, int M, int N, int nslot = 1024)
     std::vector<float> abn(2 * M);
     for (int k = 0; k < M; ++k) { abn[k] = am[k]; abn[M + k] = ar[k]; }
     float *dA = dev(A), *dB = dev(B), *dab = dev(ab), *dabn = dev(abn), *dP;
-    CK(hipMalloc(&dP, (size_t)(mm::kGradPartFloats + 2 * (size_t)M * N) * sizeof(float)));
+    CK(hipMalloc(&dP, (size_t)(mm::kGradPartFloats + 4 * (size_t)M * N) * sizeof(float)));
     mm::KpixArgs k{};
     k.npix = npix; k.M = M; k.N = N; k.A = dA; k.lda = M; k.B = dB; k.ldb = N; k.part = dP; k.abias = dab; k.abn = dabn;
     k.B2 = dB2; k.bbias = dbb; k.bbn = dbbn; k.bbb = dbbb; k.dbias = dD; k.nslot = nslot;
     const int S = mm::mm_kpix_launch<WMv, TM, TN, APRO, AV, BV, BPRO>(cx, 0, k);
     CK(hipDeviceSynchronize());
-    auto part = host(dP, (size_t)S * M * N);
-    std::vector<double> ref((size_t)M * N, 0.0), mag((size_t)M * N, 0.0);
+    constexpr int NA = APRO == 3 ? 2 : 1;
+    auto part = host(dP, (size_t)S * NA * M * N);
+    std::vector<double> ref((size_t)M * N, 0.0), mag((size_t)M * N, 0.0), ref2((size_t)M * N, 0.0);
     for (int64_t p = 0; p < npix; ++p)
         for (int m = 0; m < M; ++m) {
             float v = A[p * M + m];
-            if (APRO == 1) v = fmaxf(hxhat(v, ab[m], am[m], ar[m]), 0.0f);
+            if (APRO == 1 || APRO == 3) v = fmaxf(hxhat(v, ab[m], am[m], ar[m]), 0.0f);
+            if (APRO == 3 && v > 0.f)
+                for (int n = 0; n < N; ++n) ref2[(size_t)m * N + n] += (double)B[p * N + n];
             for (int n = 0; n < N; ++n) {
                 float bv = B[p * N + n];
                 if (BPRO == 2) { const float xh = hxhat(B2[p * N + n], bb[n], bm[n], br[n]); bv = br[n] * ((xh > 0.f ? bv : 0.f) - bbb[n] - xh * bbb[N + n]); }
@@ -145,9 +148,13 @@ static void check_kpix(int64_t npix, int M, int N, int nslot = 1024)
         if (S > nslot) dworst = 1.0;
     }
     for (size_t e = 0; e < (size_t)M * N; ++e) {
-        double t = 0.0;
-        for (int s = 0; s < S; ++s) t += part[(size_t)s * M * N + e];
+        double t = 0.0, t2 = 0.0;
+        for (int s = 0; s < S; ++s) {
+            t += part[(size_t)s * NA * M * N + e];
+            if (NA == 2) t2 += part[((size_t)s * NA + 1) * M * N + e];
+        }
         worst = std::max(worst, fabs(t - ref[e]) / (mag[e] + 1e-30));
+        if (NA == 2) worst = std::max(worst, fabs(t2 - ref2[e]) / (fabs(ref2[e]) + (double)npix * 0.5 * 1e-3 + 1e-30) * 1e-3);
     }
     const bool ok = worst < 1e-5 && S > 0 && dworst < 1e-5;
     printf("%s kpix<%d %d %d APRO %d AV %d BV %d BPRO %d> npix=%lld M=%d N=%d S=%d: max err / sum|terms| %.2e, d bias %.2e\n", ok ? "ok  " : "FAIL", WMv, TM, TN, APRO, AV, BV, BPRO,
@@ -205,7 +212,7 @@ static void timing(int w, int64_t P)
     k.npix = P; k.M = w; k.N = w; k.A = dA; k.lda = w; k.B = dH; k.ldb = w; k.part = dP; k.abias = dc; k.abn = dc;
     run("d l_2/W  kpix<2,2,2,APRO 1>", f2, [&] { mm::mm_kpix_launch<2, 2, 2, 1, 4, 4>(cx, 0, k); });
     k.N = 36; k.B = dG; k.ldb = 36;
-    run("d l_last/W kpix<2,2,1,APRO 1>", 2.0 * P * w * 36, [&] { mm::mm_kpix_launch<2, 2, 1, 1, 4, 4>(cx, 0, k); });
+    run("d l_last/W + mask kpix<2,2,1,APRO 3>", 2.0 * P * w * 36, [&] { mm::mm_kpix_launch<2, 2, 1, 3, 4, 4>(cx, 0, k); });
     k.M = 18; k.N = w; k.A = dG; k.lda = 20; k.B = dH; k.ldb = w; k.B2 = dA; k.bbias = dc; k.bbn = dc; k.bbb = dc; k.dbias = dS; k.nslot = nslot;
     run("d l_1/W  kpix<1,1,2,BPRO 2>", 2.0 * P * w * 18, [&] { mm::mm_kpix_launch<1, 1, 2, 0, 1, 4, 2>(cx, 0, k); });
     (void)hipFree(dA); (void)hipFree(dH); (void)hipFree(dC); (void)hipFree(dBt); (void)hipFree(dc); (void)hipFree(dS); (void)hipFree(dP); (void)hipFree(dG);
@@ -254,10 +261,10 @@ int main(int argc, char **argv)
     check_kpix<2, 1, 1, 1, 4, 4>(999, 64, 64);
     check_kpix<2, 1, 1, 1, 4, 4>(999, 24, 24);
     check_kpix<2, 1, 1, 1, 1, 1>(400, 50, 50);
-    check_kpix<2, 2, 1, 1, 4, 4>(3000, 512, 36);
-    check_kpix<2, 2, 1, 1, 1, 4>(800, 70, 36);
-    check_kpix<2, 1, 1, 1, 4, 4>(800, 48, 36);
-    check_kpix<2, 1, 1, 1, 1, 4>(300, 5, 36);
+    check_kpix<2, 2, 1, 3, 4, 4>(3000, 512, 36);      // d l_last/W and the mask product beside it
+    check_kpix<2, 2, 1, 3, 1, 4>(800, 70, 36);
+    check_kpix<2, 1, 1, 3, 4, 4>(800, 48, 36);
+    check_kpix<2, 1, 1, 3, 1, 4>(300, 5, 36);
     check_kpix<1, 1, 2, 0, 1, 4, 2>(2000, 18, 512, 9);
     check_kpix<1, 1, 2, 0, 1, 4, 2>(600, 18, 48, 2);
     check_kpix<1, 1, 2, 0, 1, 1, 2>(600, 18, 50, 1024);

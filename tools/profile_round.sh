@@ -3,7 +3,7 @@
 # Writes everything under gpurun_out/<tag>/; copy the summaries you want judged into profiles/.
 # Every counter pass is its own run with --kernel-trace only (never combined with other trace domains).
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
@@ -39,6 +39,19 @@ done
 # per-config kernel stats
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_fp16 -- python $R/tools/prof_nll.py 1024 200 64 fp16 > $OUT/kt_fp16.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_samp -- python $R/tools/prof_nll.py 4096 100 32 fp32 sample > $OUT/kt_samp.log 2>&1
+# per-kernel stats of bench.py's wide_cnn section (same model / batch, warm clocks): w16, w32, w32_fp16, w128, w512, w512_fp16
+for spec in "16 fp32 w16" "32 fp32 w32" "32 fp16 w32_fp16" "128 fp32 w128" "512 fp32 w512" "512 fp16 w512_fp16"; do
+  set -- $spec
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$3 -- python $R/tools/prof_wide.py $1 $2 > $OUT/kt_$3.log 2>&1
+  K=$(find $OUT/kt_$3 -name "*kernel_stats.csv" | head -1); cp $K $OUT/kernel_stats_$3.csv 2>/dev/null
+done
+set -- $TAG
+# the training step at the reference's default width 512 and at 64 (csrc/nf_train_mm.h: this repo's own GEMMs)
+for w in 512 64; do
+  NF_TOOL_STEPS=10 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_train$w -- python $R/tools/bench_train_width.py $w 138 > $OUT/kt_train$w.log 2>&1
+  K=$(find $OUT/kt_train$w -name "*kernel_stats.csv" | head -1); cp $K $OUT/kernel_stats_train_w$w.csv 2>/dev/null
+done
+(timeout 300 $R/tools/probes/mm_probe time > $OUT/mm_probe.log 2>&1)
 # 3. SQ counters: headline kernel at B = 16384, fp16-CNN 64x64, wide CNN width 32
 SQ1="SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU GRBM_GUI_ACTIVE"
 SQ2="SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE"
@@ -87,3 +100,4 @@ K=$(find $OUT/kt_samp -name "*kernel_stats.csv" | head -1); cp $K $OUT/kernel_st
 K=$(find $OUT/kt_full -name "*kernel_stats.csv" | head -1); cp $K $OUT/kernel_stats_all_sections.csv 2>/dev/null
 cp $F $OUT/pmc_fetch_counter_collection.csv; cp $W $OUT/pmc_write_counter_collection.csv
 for f in $OUT/sq_fp32_report.txt $OUT/sq_fp16_report.txt $OUT/sq_w32_report.txt $OUT/sq_w16_report.txt $OUT/sq_w32h_report.txt $OUT/sq_gemm512_report.txt $OUT/sq_gemm128_report.txt $OUT/sq_gemm512_fp16_report.txt $OUT/sq_gemm128_fp16_report.txt $OUT/gemm512_traffic.txt; do tail -n 3 $f; done; head -c 600 $OUT/bench.json; echo; tail -5 $OUT/traffic.log; head -8 $OUT/kernel_stats.csv
+python tools/check_profile_map.py $OUT/bench.json $OUT "" > $OUT/profile_map.md 2>&1; tail -12 $OUT/profile_map.md
