@@ -52,6 +52,16 @@ for w in 512 64; do
   K=$(find $OUT/kt_train$w -name "*kernel_stats.csv" | head -1); cp $K $OUT/kernel_stats_train_w$w.csv 2>/dev/null
 done
 (timeout 300 $R/tools/probes/mm_probe time > $OUT/mm_probe.log 2>&1)
+# SQ counters of the trainer's three GEMM shapes at width 512 (probe products 0 = l_2 forward, 2 = plain, 8 = d l_2/W)
+SQA="SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU GRBM_GUI_ACTIVE"
+SQB="SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE"
+for spec in "0 l2fwd" "2 plain" "8 dw2"; do
+  set -- $spec
+  rocprofv3 --pmc $SQA --kernel-trace --output-format csv -d $OUT/sq_mm_$2/p1 -- $R/tools/probes/mm_probe time $1 512 > /dev/null 2>&1
+  rocprofv3 --pmc $SQB --kernel-trace --output-format csv -d $OUT/sq_mm_$2/p2 -- $R/tools/probes/mm_probe time $1 512 > /dev/null 2>&1
+  (cd $R && python tools/pmc_report.py $OUT/sq_mm_$2 k_mm_ > $OUT/sq_mm_$2.txt 2>&1)
+done
+set -- $TAG
 # 3. SQ counters: headline kernel at B = 16384, fp16-CNN 64x64, wide CNN width 32
 SQ1="SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU GRBM_GUI_ACTIVE"
 SQ2="SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE"
