@@ -1,5 +1,5 @@
 // Stand-alone check + timing of the trainer's matrix-core GEMMs (noise_flow_amd/csrc/nf_train_mm.h) against fp64 CPU sums.
-//   hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/probes/mm_probe.hip -o tools/probes/mm_probe && tools/probes/mm_probe [time]
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -munsafe-fp-atomics -mllvm -amdgpu-mfma-vgpr-form tools/probes/mm_probe.hip -o tools/probes/mm_probe && tools/probes/mm_probe [time]
 // Every (prologue, epilogue, vector width, tile) combination the trainer launches is run at a ragged shape; `time` adds the
 // width-512 shapes of a 138-patch step (TFLOP/s of each product).
 #include <hip/hip_runtime.h>
