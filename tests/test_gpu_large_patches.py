@@ -197,16 +197,19 @@ def test_wrapper_samples_large_patches(compat):
     assert np.abs(xs - ref).max() <= 5e-5 * np.abs(ref).max()
 
 
-def test_large_patches_limits():
+def test_batch_statistics_beyond_64x64_at_other_widths():
+    """Batch-statistics mode beyond 64x64 used to exist on the width-4 matrix-core schedule only (NF_EINVAL elsewhere); since round
+    5 every other width walks the layers on the trainer's GEMM path over the whole resident image (csrc/nf_train.hip:
+    nf_bs_wide_run) — no tiles, no halo: width 8 on 80x80 against the fp64 oracle."""
     from noise_flow_amd import NoiseFlow, default_hps
-    from noise_flow_amd._lib import NoiseFlowLibError, NF_EINVAL
-    # batch-statistics mode beyond 64x64: the width-4 matrix-core schedule only
-    v8 = trained_like_variables("unc", 8)
-    m = NoiseFlow([80, 80, 4], True, default_hps(arch="unc", width=8), variables=v8)
+    from oracle.nf_oracle import NoiseFlowOracle
+    v8 = trained_like_variables("unc|unc", 8)
+    m = NoiseFlow([80, 80, 4], True, default_hps(arch="unc|unc", width=8), variables=v8)
     x, y = make_inputs(2, 80, 80, seed=1)
-    with pytest.raises(NoiseFlowLibError) as ei:
-        m._loss(x, y, [0.0], [0.0], [100], [2])
-    assert ei.value.code == NF_EINVAL and "64x64" in str(ei.value)
+    nll, sd = m._loss(x, y, [0.0], [0.0], [100], [2])
+    ref, ref_sd, _ = NoiseFlowOracle("unc|unc", v8).nll(x, y, 100, 2, training=True)
+    np.testing.assert_allclose(nll, ref, rtol=1e-5)
+    assert abs(sd - ref_sd) <= 1e-5 * ref_sd
 
 
 @pytest.mark.parametrize("hw,B,arch", [((96, 80), 3, None), ((65, 130), 2, "sdn5|unc|gain4|unc|unc"), ((128, 40), 4, "unc|unc|unc")])
