@@ -165,7 +165,9 @@ def _launch_ranks(n: int) -> int:
 
 
 def main():
+    global _SECTION_RAMP_MS
     args = parse_args()
+    _SECTION_RAMP_MS = min(float(args.ramp_ms), 80.0)
     # stdout carries exactly ONE line, the JSON, written last: native libraries (RCCL prints a version
     # banner through C stdio, flushed at exit AFTER Python's output) would otherwise follow it.  Everything
     # else that targets fd 1 goes to stderr; the JSON is written straight to the saved descriptor.
@@ -227,6 +229,9 @@ def main():
     if rank == 0:
         os.write(json_fd, (line + "\n").encode())
     os.close(json_fd)
+
+
+_SECTION_RAMP_MS = 80.0     # per extra section (set from --ramp-ms in main: min(ramp_ms, 80))
 
 
 def _clock_ramp(step, ramp_ms, dev):
@@ -659,6 +664,13 @@ def _time_nll(model, x, y, cond, n, dev):
     for _ in range(5):
         step()
     torch.cuda.synchronize(dev)
+    # untimed clock ramp of this section (each section builds its model on the host first: the GPU idles and its clocks drop; a
+    # section timed from there read up to 10 % slower than the kernel-stats csv of the same launches, profiles/README.md)
+    t_r = time.perf_counter()
+    while (time.perf_counter() - t_r) * 1e3 < _SECTION_RAMP_MS:
+        for _ in range(4):
+            step()
+        torch.cuda.synchronize(dev)
     f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     f0.record(stream)
     for _ in range(n):

@@ -1,7 +1,7 @@
 """Every `kernel_ms` of a bench line against the rocprofv3 kernel-stats csv that backs it (profiles/README.md's table):
     python tools/check_profile_map.py profiles/r05_bench.json profiles r05
 prints one row per roofline block: bench kernel_ms (HIP events), the csv's AverageNs of the dominant kernel, the ratio."""
-import csv, json, os, sys
+import csv, json, os, re, sys
 
 bench, pdir, tag = sys.argv[1], sys.argv[2], sys.argv[3]
 d = json.loads(open(bench).read().strip().splitlines()[-1])
@@ -11,7 +11,8 @@ def dominant(path):
     rows = list(csv.DictReader(open(path)))
     rows = [r for r in rows if "nf_" in r["Name"] and "synth" not in r["Name"]]
     r = max(rows, key=lambda r: float(r["TotalDurationNs"]))
-    return r["Name"].split("(")[0][:60], float(r["AverageNs"]) * 1e-6, int(r["Calls"])
+    m = re.search(r"(nf_\w+(?:<[^>]*>)?)", r["Name"])
+    return (m.group(1) if m else r["Name"][:60]).replace(" ", ""), float(r["AverageNs"]) * 1e-6, int(r["Calls"])
 
 
 m = [("headline (configs[1])", d["roofline"]["kernel_ms"], "kernel_stats.csv"),
