@@ -1493,8 +1493,21 @@ struct nf_trainer {
     uint8_t *d_mask = nullptr;
     double *d_dbl = nullptr;        // [0,n_params) gradients, then dA / dab / dgain / BN sums, last: ldc
     size_t n_dbl = 0;
-    float *d_part = nullptr;        // per-workgroup partials of every reducible value: [n_dbl - 1][NSLOT]
-    Acc acc(int idx) const { return Acc{d_part + (size_t)idx * NSLOT}; }
+    float *d_part = nullptr;        // per-workgroup partials of every reducible value: [n_dbl - 1 - hole rows][NSLOT]
+    // Values that never take slotted sums have no rows: the l_2/W bodies of couplings on the GEMM path (their gradients come whole
+    // from the GEMMs; at width 512 they would be 9 of the 10 GB).  `holes` lists them (first value, count), ascending.
+    std::vector<std::pair<int, int>> holes;
+    size_t hole_rows = 0;
+    Acc acc(int idx) const
+    {
+        size_t row = (size_t)idx;
+        for (const auto &h : holes) {
+            if (h.first >= idx) break;
+            row -= (size_t)h.second;
+        }
+        return Acc{d_part + row * NSLOT};
+    }
+    size_t part_floats() const { return (n_dbl - 1 - hole_rows) * NSLOT; }
     int d_dA = 0, d_dab = 0, d_dg = 0, d_ld0 = 0, d_ldc = 0;
     float *d_flt = nullptr;         // A matrices, sdn5 (a,b), BN scalars
     size_t n_flt = 0;
@@ -2102,6 +2115,13 @@ static int trainer_create_impl(const nf_config *cfg, const nf_layer_desc *layers
     if (eval_only) nd = 4 * (size_t)w;
     t->d_ldc = (int)nd; nd += 1;   // last: the only value accumulated directly (k_prep), not through slots
     t->n_dbl = nd;
+    if (gemm_path && !eval_only)
+        for (int l = 0; l < t->tl.n; ++l) {
+            const TLayer &L = t->tl.l[l];
+            if (L.type != NF_LAYER_COUPLING) continue;
+            t->holes.emplace_back(L.off + 21 * L.width, L.width * L.width);
+            t->hole_rows += (size_t)L.width * L.width;
+        }
     // float scalars
     size_t nf = 0;
     t->f_A = (int)nf; nf += 16 * (size_t)n_mix;
@@ -2122,7 +2142,7 @@ static int trainer_create_impl(const nf_config *cfg, const nf_layer_desc *layers
     }
     NF_TRY(dev_alloc(t, (void **)&t->d_params, n_params * sizeof(float)));
     NF_TRY(dev_alloc(t, (void **)&t->d_dbl, nd * sizeof(double)));
-    NF_TRY(dev_alloc(t, (void **)&t->d_part, (nd - 1) * NSLOT * sizeof(float)));
+    NF_TRY(dev_alloc(t, (void **)&t->d_part, t->part_floats() * sizeof(float)));
     NF_TRY(dev_alloc(t, (void **)&t->d_flt, nf * sizeof(float)));
     if (eval_only) {
         NF_TRY(dev_alloc(t, (void **)&t->ebuf, act * 4 * sizeof(float)));
@@ -2144,7 +2164,7 @@ static int trainer_create_impl(const nf_config *cfg, const nf_layer_desc *layers
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, t->device) == hipSuccess && cus > 0) t->n_cu = cus;
         if ((e = hipMemcpy(t->d_params, params, n_params * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess ||
-            (e = hipMemset(t->d_part, 0, (nd - 1) * NSLOT * sizeof(float))) != hipSuccess) {
+            (e = hipMemset(t->d_part, 0, t->part_floats() * sizeof(float))) != hipSuccess) {
             nf_trainer_destroy(t);
             return nf_fail_hip(e, "evaluator initialisation");
         }
@@ -2188,7 +2208,7 @@ static int trainer_create_impl(const nf_config *cfg, const nf_layer_desc *layers
         (e = hipMemset(t->d_v, 0, n_params * sizeof(float))) != hipSuccess ||
         (e = hipMemset(t->d_gradf, 0, n_params * sizeof(float))) != hipSuccess ||
         // slots of values no kernel ever writes (constants, the gain parameters of other ISOs) stay zero
-        (e = hipMemset(t->d_part, 0, (nd - 1) * NSLOT * sizeof(float))) != hipSuccess) {
+        (e = hipMemset(t->d_part, 0, t->part_floats() * sizeof(float))) != hipSuccess) {
         nf_trainer_destroy(t);
         return nf_fail_hip(e, "trainer initialisation");
     }
@@ -2388,7 +2408,7 @@ static int trainer_run(nf_trainer *t, const float *x, const float *y, int64_t B,
         // value only (the runs between the filters), then the GEMM results are stored next to them
         int lo = 0;
         auto reduce_run = [&](int a, int b) {
-            if (b > a) hipLaunchKernelGGL(k_reduce, dim3((unsigned)(b - a)), dim3(64), 0, st, b - a, t->d_part + (size_t)a * NSLOT, g.nslot, G + a);
+            if (b > a) hipLaunchKernelGGL(k_reduce, dim3((unsigned)(b - a)), dim3(64), 0, st, b - a, t->acc(a).p, g.nslot, G + a);
         };
         for (int l = 0; l < n; ++l) {
             const TLayer &L = t->tl.l[l];

@@ -487,7 +487,8 @@ bool coupling_backward_gemm(nf_trainer *t, const Geo &g, const TLayer &L, const 
     (void)off_w1; (void)off_w2;
     const double n = (double)g.npix * t->sync_world;
     const float *P = t->d_params, *bn1 = t->d_flt + c.f_bn1, *bn2 = t->d_flt + c.f_bn2, *bb1 = t->d_flt + c.f_bb1, *bb2 = t->d_flt + c.f_bb2;
-    const Acc G = t->acc(0);
+    // in-kernel offsets from G are all behind this coupling's l_2/W (the rows before it are shifted by the holes: nf_trainer::acc)
+    const Acc G = Acc{t->acc(off_w3).p - (size_t)off_w3 * NSLOT};
     float *t1 = t->t1[0], *t2 = t->t2[0], *gu = t->gu[0];
     const bool v4 = w % 4 == 0;
     const mm::PackAll pl = mm::pack_layout(w);
@@ -532,7 +533,7 @@ bool coupling_backward_gemm(nf_trainer *t, const Geo &g, const TLayer &L, const 
     sync_slots(t, t->acc(c.d_bs2), 2 * w, g.nslot, st);
     hipLaunchKernelGGL(k_bnb_fin, dim3(w), dim3(64), 0, st, t->acc(c.d_bs2), w, g.nslot, n, t->d_flt + c.f_bb2);
     // ---- g_h2 = BN2 backward of the masked g_a2 = G36 . W3r^T (K = 36), stored once; d b2 = its column sums ----
-    a.ebb = bb2; a.stats = (G + off_b2).p;
+    a.ebb = bb2; a.stats = t->acc(off_b2).p;
     ok = mm::mm_pix<0, 3, 4>(cx, st, a) && ok;
     // ---- d l_2/W = relu(bn1(h1 + b1))^T . g_h2 ----
     k.M = w; k.N = w;
@@ -556,7 +557,7 @@ bool coupling_backward_gemm(nf_trainer *t, const Geo &g, const TLayer &L, const 
     k.M = 18; k.N = w;
     k.A = t->gz18; k.lda = kZ18; k.B = t2; k.ldb = w; k.part = dW1;
     k.abias = nullptr; k.abn = nullptr;
-    k.B2 = c.h1; k.bbias = P + off_b1; k.bbn = bn1; k.bbb = bb1; k.dbias = (G + off_b1).p;
+    k.B2 = c.h1; k.bbias = P + off_b1; k.bbn = bn1; k.bbb = bb1; k.dbias = t->acc(off_b1).p;
     np[0] = v4 ? mm::mm_kpix_launch<1, 1, 2, 0, 1, 4, 2>(cx, st, k) : mm::mm_kpix_launch<1, 1, 2, 0, 1, 1, 2>(cx, st, k);
     ok = ok && np[0] > 0;
     a.N = 18; a.K = w;
