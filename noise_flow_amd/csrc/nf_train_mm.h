@@ -35,6 +35,15 @@
 #include <algorithm>
 #include <atomic>
 
+#ifndef MM_ABL
+// tools/probes/mm_probe.hip only (timing ablations of k_mm_pix; results are wrong): 1 = no barrier in the K loop, 2 = no global
+// loads in it, 4 = no LDS writes in it, 8 = every pixel tile reads tile 0 of A (cache hits), 16 = no B loads, 32 = no A loads, 64 = no epilogue, 128 = every load hits one L1-resident 4 KiB
+#define MM_ABL 0
+#endif
+#ifndef MM_KREP
+#define MM_KREP 1   // with MM_ABL 7: the K loop runs this many times (loop time apart from the tile boundaries)
+#endif
+
 namespace {
 namespace mm {
 
@@ -186,11 +195,15 @@ __global__ __launch_bounds__(kT) void k_mm_pix(const PixArgs a)
     for (int i = 0; i < NB; ++i) {
         const int r = r0 + 32 * i;
         bmask[i] = n0 + r < a.N ? 1.0f : 0.0f;
-        boff[i] = (uint32_t)((n0 + r < a.N ? r : 0) * a.ldb + 4 * j) * 4u;
+        boff[i] = (MM_ABL & 128) ? (uint32_t)(tid * 16) : (uint32_t)((n0 + r < a.N ? r : 0) * a.ldb + 4 * j) * 4u;
     }
     const bool bragged = n0 + BN > a.N;   // workgroup-uniform
     const int nkt = Kc / kBK;
     const int nkt_full = a.K / kBK;   // K tiles every load of which is in range (ldb >= K)
+    // (Measured and dropped: every workgroup starting its K loop at a K tile of its own, so that workgroups in step do not pull the
+    // same 128 bytes of every 2 KiB row at a time — 649 vs 651 us for the plain product at width 512: the L2 channel hash already
+    // spreads them.  What the feed costs is issue, not the memory system: with every load hitting one L1-resident 4 KiB the kernel
+    // still runs 618 us against 587 us without loads; K loop alone, no tile boundaries: 0.975 of the matrix-pipe rate.)
 
     // the A side of the tile being staged: origin and per-lane offsets (set by `origin`).  (Issuing a tile's FIRST loads before the
     // previous tile's epilogue — so that the round trip at a tile boundary hides behind the stores — was measured: no gain, the
@@ -200,13 +213,13 @@ __global__ __launch_bounds__(kT) void k_mm_pix(const PixArgs a)
     uint32_t aoff[4];
     auto origin = [&](int64_t mt) {
         const int64_t m0 = mt * kBM;
-        abase = a.A + m0 * a.lda;
+        abase = a.A + ((MM_ABL & (8 | 128)) ? 0 : m0) * a.lda;
         if constexpr (APRO == 2) hbase = a.A2 + m0 * a.lda;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int r = r0 + 32 * i;
             r = m0 + r < a.P ? r : (int)(a.P - 1 - m0);   // rows past the end: loaded (valid memory), never stored nor summed
-            aoff[i] = (uint32_t)(r * a.lda + 4 * j) * 4u;
+            aoff[i] = (MM_ABL & 128) ? (uint32_t)(tid * 16) : (uint32_t)(r * a.lda + 4 * j) * 4u;
         }
     };
     // Staging registers (ONE set: the loads of K tile t + 1 are issued before the MFMAs of tile t and parked after them.  A
@@ -218,17 +231,21 @@ __global__ __launch_bounds__(kT) void k_mm_pix(const PixArgs a)
     Stage SR;
     auto at = [](const float *base, uint32_t off) { return reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + off); };
     auto fetch = [&](int kt, Stage &R) {
-        const float *const ak = abase + kt * kBK, *const bk = bbase + kt * kBK;
+        const float *const ak = abase + ((MM_ABL & 128) ? 0 : kt * kBK), *const bk = bbase + ((MM_ABL & 128) ? 0 : kt * kBK);
         [[maybe_unused]] const float *const hk = hbase + kt * kBK;
         if (kt < nkt_full) {     // workgroup-uniform: the whole tile is inside K, no predicates around the loads
+            if (!(MM_ABL & 32)) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) R.ra[i] = row4<AV>(at(ak, aoff[i]), 0, 4);
+            }
             if constexpr (APRO == 2) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) R.rh[i] = row4<AV>(at(hk, aoff[i]), 0, 4);
             }
+            if (!(MM_ABL & 16)) {
 #pragma unroll
             for (int i = 0; i < NB; ++i) R.rb[i] = ld4(at(bk, boff[i]));
+            }
         } else {
             const int k = kt * kBK + 4 * j;
 #pragma unroll
@@ -320,12 +337,9 @@ __global__ __launch_bounds__(kT) void k_mm_pix(const PixArgs a)
             }
         };
 
-#ifndef MM_ABL
-#define MM_ABL 0   // tools/probes/mm_probe.hip only: 1 = no barrier in the K loop, 2 = no global loads in it, 4 = no LDS writes in it (timing ablations; results are wrong)
-#endif
         park(0, 0, SR);
         __syncthreads();
-        for (int kt = 0; kt < nkt; ++kt) {
+        for (int kt = 0; kt < nkt * MM_KREP; ++kt) {
             const int buf = kt & 1;
             if (kt + 1 < nkt && !(MM_ABL & 2)) fetch(kt + 1, SR);
             compute(buf);
@@ -334,6 +348,7 @@ __global__ __launch_bounds__(kT) void k_mm_pix(const PixArgs a)
         }
 
         // ---- epilogue: D register v of lane (n, g) = pixel 8 (v >> 2) + 4 g + (v & 3) of the tile, channel n ----
+        if ((MM_ABL & 64) && acc[0][0][0] != 12345.0f) continue;
         if constexpr (CV == 4) {
             // through LDS (the operand tiles are dead: every wavefront is past the K loop's last barrier): D registers -> [pixel][SP]
             // (32 lanes = 32 consecutive channels: conflict-free), then every thread takes 16-byte pieces of the rows — its 4 channels
