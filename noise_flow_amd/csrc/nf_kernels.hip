@@ -453,6 +453,13 @@ __device__ __forceinline__ void nf_flow_body(const NfProgram &prog, const NfLaun
     double acc_nll = 0.0, acc_sd = 0.0;   // thread 0 only
     const double inv_n = 1.0 / ((double)HW * 4.0);   // once per launch: two fp64 divisions per patch were a third of the epilogue
     [[maybe_unused]] int red_sel = 0;
+    // Workgroups of 1 024 threads (one per CU, several patches each: 64x64 patches and tiles) finish the cross-wavefront sum of a
+    // patch's results one patch LATE (see the epilogue): + 1.4 % at 64x64 fp16, same box; at 256 threads a workgroup sees 1 - 2
+    // patches per launch and the extra barrier behind the loop costs what the deferral saves (- 0.3 %).  pend_b = the patch whose
+    // wavefront partials sit in the other scratch set; synced = this patch's body has passed a barrier since they were written
+    constexpr bool DEFER = THREADS == 1024;
+    [[maybe_unused]] int64_t pend_b = -1;
+    [[maybe_unused]] bool synced = false;
     [[maybe_unused]] int cpl_total = 0;
 #if NF_FAIR
     for (int op = 0; op < n_ops; ++op)
@@ -460,7 +467,44 @@ __device__ __forceinline__ void nf_flow_body(const NfProgram &prog, const NfLaun
     if (cpl_total < 1) cpl_total = 1;
 #endif
 
+    // nll / sd / log-det of patch (tile) pb from its three sums: the wavefronts' partials in `rd`, or (one wavefront) r0 r1 r2
+    auto finish_patch = [&](const float *rd, int64_t pb, float r0, float r1, float r2) {
+        constexpr int NW = THREADS / 64;
+        if constexpr (NW > 1) {
+            if (t < 16) {   // one DPP row adds the wavefronts' partials: 3 reads + 12 adds instead of thread 0's chain of 3 NW
+                static_assert(NW <= 16, "one lane per wavefront");
+                r0 = row16_sum(t < NW ? rd[t] : 0.f);
+                r1 = row16_sum(t < NW ? rd[NW + t] : 0.f);
+                r2 = row16_sum(t < NW ? rd[2 * NW + t] : 0.f);
+            }
+        }
+        if (tiled) {
+            // the tile's share of its image's sums; nf_tile_combine_kernel forms nll / sd / log-det per image
+            if (t == 0) *reinterpret_cast<float4 *>(a.tile_part + (size_t)pb * 4u) = make_float4(r0, r1, r2, 0.f);
+        } else if (t == 0) {
+            const double n = (double)HW * 4.0;
+            const double logdet = (double)r0 + a.ld_const;
+            // prior: sum -0.5*(log 2pi + z^2)   (noise_flow_model.py:537-539)
+            double nll = -logdet;
+            if (a.flags & NF_K_PRIOR) nll += 0.5 * n * 1.8378770664093453 + 0.5 * (double)r2;
+            // sd of the base measure: population variance over the patch (noise_flow_model.py:477-478)
+            const double mean = (double)r1 * inv_n;
+            double var = (double)r2 * inv_n - mean * mean;
+            var = var > 0.0 ? var : 0.0;
+            // the result is rounded to fp32 anyway: v_sqrt_f32 (1 ulp) instead of the ~60-instruction fp64 routine
+            const double sd = (double)__builtin_amdgcn_sqrtf((float)var);
+            if (a.nll_out) a.nll_out[pb] = (float)nll;
+#ifndef NF_TIMELINE
+            if (a.sd_out) a.sd_out[pb] = (float)sd;
+#endif
+            if (a.ld_out) a.ld_out[pb] = (float)logdet;
+            acc_nll += (double)(float)nll;
+            acc_sd += (double)(float)sd;
+        }
+    };
+
     for (int64_t b = blockIdx.x; b < a.B; b += gridDim.x) {
+        synced = false;
         size_t patch_off = (size_t)b * (size_t)HW * 4u;
         [[maybe_unused]] int64_t patch_id = b;   // Philox key of the patch (NF_K_TILED: of the image the tile belongs to)
 #ifdef NF_TIMELINE
@@ -615,6 +659,7 @@ __device__ __forceinline__ void nf_flow_body(const NfProgram &prog, const NfLaun
                 // coupling updates its transformed half in place — instead of being copied between the loop-carried set and a
                 // working set around every op (28 v_mov_b64 per mix + coupling, a fifth of the VALU instructions)
                 bool patch_done = false;
+                synced = true;   // every coupling passes barriers (the exchange of the pass-through half and of h2)
                 for (;;) {
 #if NF_FAIR
                 if constexpr (MFMA && !(NF_WAVE_PRIO && THREADS == 1024)) {
@@ -1254,9 +1299,27 @@ __device__ __forceinline__ void nf_flow_body(const NfProgram &prog, const NfLaun
                 }
             float r0 = wave_sum(fmaf(ld2, 0.6931471805599453f, ld)), r1 = wave_sum(s1), r2 = wave_sum(s2);
             constexpr int NW = THREADS / 64;
-            if (NW > 1) {
-                // two scratch sets, alternating by patch: thread 0 finishes this patch (the fp64 tail below) while the other
-                // wavefronts are already in the next one — the next barrier any of them reaches comes after its reads
+            if constexpr (NW > 1 && DEFER) {
+                // Two scratch sets, alternating by patch.  The wavefronts leave their partials of THIS patch in one set and go on;
+                // the other set holds the PREVIOUS patch's partials, complete since the barriers of this patch's body, and wavefront
+                // 0 finishes that patch now — the epilogue itself has no barrier (the last patch is finished behind the loop).  A
+                // body without couplings has no barrier: then one stands here, in front of the writes (the set being overwritten
+                // was read in the previous epilogue).
+                if (!synced) __syncthreads();
+                float *const rd = red + (red_sel ? 3 * NW : 0);
+                const float *const prev = red + (red_sel ? 0 : 3 * NW);
+                red_sel ^= 1;
+                const int wv = t >> 6;
+                if ((t & 63) == 0) {
+                    rd[wv] = r0;
+                    rd[NW + wv] = r1;
+                    rd[2 * NW + wv] = r2;
+                }
+                if (pend_b >= 0) finish_patch(prev, pend_b, 0.f, 0.f, 0.f);
+                pend_b = b;
+            } else if constexpr (NW > 1) {
+                // two scratch sets, alternating by patch: wavefront 0 finishes this patch while the others are already in the next
+                // one — the next barrier any of them reaches comes after its reads
                 float *const rd = red + (red_sel ? 3 * NW : 0);
                 red_sel ^= 1;
                 const int wv = t >> 6;
@@ -1266,38 +1329,18 @@ __device__ __forceinline__ void nf_flow_body(const NfProgram &prog, const NfLaun
                     rd[2 * NW + wv] = r2;
                 }
                 __syncthreads();
-                if (t < 16) {   // one DPP row adds the wavefronts' partials: 3 reads + 12 adds instead of thread 0's chain of 3 NW
-                    static_assert(NW <= 16, "one lane per wavefront");
-                    r0 = row16_sum(t < NW ? rd[t] : 0.f);
-                    r1 = row16_sum(t < NW ? rd[NW + t] : 0.f);
-                    r2 = row16_sum(t < NW ? rd[2 * NW + t] : 0.f);
-                }
-            }
-            if (tiled) {
-                // the tile's share of its image's sums; nf_tile_combine_kernel forms nll / sd / log-det per image
-                if (t == 0) *reinterpret_cast<float4 *>(a.tile_part + (size_t)b * 4u) = make_float4(r0, r1, r2, 0.f);
-            } else if (t == 0) {
-                const double n = (double)HW * 4.0;
-                const double logdet = (double)r0 + a.ld_const;
-                // prior: sum -0.5*(log 2pi + z^2)   (noise_flow_model.py:537-539)
-                double nll = -logdet;
-                if (a.flags & NF_K_PRIOR) nll += 0.5 * n * 1.8378770664093453 + 0.5 * (double)r2;
-                // sd of the base measure: population variance over the patch (noise_flow_model.py:477-478)
-                const double mean = (double)r1 * inv_n;
-                double var = (double)r2 * inv_n - mean * mean;
-                var = var > 0.0 ? var : 0.0;
-                // the result is rounded to fp32 anyway: v_sqrt_f32 (1 ulp) instead of the ~60-instruction fp64 routine
-                const double sd = (double)__builtin_amdgcn_sqrtf((float)var);
-                if (a.nll_out) a.nll_out[b] = (float)nll;
-#ifndef NF_TIMELINE
-                if (a.sd_out) a.sd_out[b] = (float)sd;
-#endif
-                if (a.ld_out) a.ld_out[b] = (float)logdet;
-                acc_nll += (double)(float)nll;
-                acc_sd += (double)(float)sd;
+                finish_patch(rd, b, 0.f, 0.f, 0.f);
+            } else {
+                finish_patch(nullptr, b, r0, r1, r2);
             }
         }
         NF_STAMP(11);
+    }
+    if constexpr (DEFER) {
+        if (pend_b >= 0) {   // the last patch
+            __syncthreads();
+            finish_patch(red + (red_sel ? 0 : 3 * (THREADS / 64)), pend_b, 0.f, 0.f, 0.f);
+        }
     }
 
     if (a.sums && t == 0 && !tiled) {
