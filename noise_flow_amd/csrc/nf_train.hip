@@ -1539,6 +1539,7 @@ struct nf_trainer {
     // coupling widths without stage kernels of their own (nf_train_gemm.h): the operands of the matrix-core GEMMs of nf_train_mm.h
     int n_cu = 256;
     float *gz18 = nullptr, *gp36 = nullptr, *gq18 = nullptr;   // [pixels][20] windows (18 + 2 zero columns), [pixels][36] taps, [pixels][18]
+    size_t gz18_stride = 0;         // trainer: every coupling keeps its windows for the backward pass (floats between two couplings')
     float *gpack = nullptr;         // every coupling's weights in the GEMMs' packed layouts (gemm_pack_floats(w) each; written by the forward pass)
     float *gdw = nullptr;           // filter gradients of every coupling as the pixel-K GEMMs leave them: 3 per coupling x gemm_part_floats(w)
     int gnp[3 * kMaxLayers] = {};   // how many partial products each of them holds (this step)
@@ -2185,7 +2186,8 @@ static int trainer_create_impl(const nf_config *cfg, const nf_layer_desc *layers
         if (w >= 16 || gemm_path) NF_TRY(dev_alloc(t, (void **)&c.u, act * 4 * sizeof(float)));
     }
     if (gemm_path && n_cpl > 0) {   // nf_train_gemm.h
-        NF_TRY(dev_alloc(t, (void **)&t->gz18, act * kZ18 * sizeof(float)));
+        t->gz18_stride = act * kZ18;
+        NF_TRY(dev_alloc(t, (void **)&t->gz18, (size_t)n_cpl * t->gz18_stride * sizeof(float)));
         NF_TRY(dev_alloc(t, (void **)&t->gp36, act * 36 * sizeof(float)));
         NF_TRY(dev_alloc(t, (void **)&t->gq18, act * 18 * sizeof(float)));
         NF_TRY(dev_alloc(t, (void **)&t->gpack, (size_t)n_cpl * gemm_pack_floats(w) * sizeof(float)));
@@ -2407,29 +2409,30 @@ static int trainer_run(nf_trainer *t, const float *x, const float *y, int64_t B,
         // the filters of wide couplings get their gradients whole from the GEMMs: the slotted sums are added up for every other
         // value only (the runs between the filters), then the GEMM results are stored next to them
         int lo = 0;
-        auto reduce_run = [&](int a, int b) {
-            if (b > a) hipLaunchKernelGGL(k_reduce, dim3((unsigned)(b - a)), dim3(64), 0, st, b - a, t->acc(a).p, g.nslot, G + a);
-        };
+        ReduceRuns runs;
+        StoreJobs jobs;
+        auto run = [&](int a, int b) { reduce_run(st, runs, g.nslot, G, t->acc(a).p, a, b); };
         for (int l = 0; l < n; ++l) {
             const TLayer &L = t->tl.l[l];
             if (L.type != NF_LAYER_COUPLING) continue;
-            const int w = L.width, off_w2 = L.off + 21 * w, off_w3 = L.off + 24 * w + w * w;
-            reduce_run(lo, L.off);                  // ... up to l_1/W
-            reduce_run(L.off + 18 * w, off_w2);     // l_1/b (and the BN statistics, masked out)
-            lo = off_w2 + w * w;                    // behind l_2/W: l_2/b, BN, l_last/W (edge rows), b, logs, scale
-            const float *gdw = t->gdw + (size_t)(3 * L.aux) * gemm_part_floats(w);
-            store_grad(st, 18 * w, w, 0, gdw, t->gnp[3 * L.aux], G, L.off);
-            store_grad(st, w * w, w, 0, gdw + gemm_part_floats(w), t->gnp[3 * L.aux + 1], G, off_w2);
-            (void)off_w3;
+            const int w = L.width, off_w2 = L.off + 21 * w;
+            run(lo, L.off);                  // ... up to l_1/W
+            run(L.off + 18 * w, off_w2);     // l_1/b (and the BN statistics, masked out)
+            lo = off_w2 + w * w;             // behind l_2/W: l_2/b, BN, l_last/W (edge rows), b, logs, scale
         }
-        reduce_run(lo, t->d_ldc);
-        for (int l = 0; l < n; ++l) {               // l_last/W: after the run that holds its edge rows was reduced
+        run(lo, t->d_ldc);
+        reduce_runs_flush(st, runs, g.nslot, G);
+        for (int l = 0; l < n; ++l) {        // the filters: l_last/W after the run that holds its edge rows was reduced
             const TLayer &L = t->tl.l[l];
             if (L.type != NF_LAYER_COUPLING) continue;
             const int w = L.width;
-            const float *gdw = t->gdw + (size_t)(3 * L.aux + 2) * gemm_part_floats(w);
-            store_grad(st, 36 * w, w, 1, gdw, t->gnp[3 * L.aux + 2], G, L.off + 24 * w + w * w, t->gdual[L.aux] ? 2 * 36 * w : 0);
+            const float *gdw = t->gdw + (size_t)(3 * L.aux) * gemm_part_floats(w);
+            store_grad(st, jobs, 18 * w, w, 0, gdw, t->gnp[3 * L.aux], G, L.off);
+            store_grad(st, jobs, w * w, w, 0, gdw + gemm_part_floats(w), t->gnp[3 * L.aux + 1], G, L.off + 21 * w);
+            store_grad(st, jobs, 36 * w, w, 1, gdw + 2 * gemm_part_floats(w), t->gnp[3 * L.aux + 2], G, L.off + 24 * w + w * w,
+                       t->gdual[L.aux] ? 2 * 36 * w : 0);
         }
+        store_grads_flush(st, jobs, G);
     } else {
         hipLaunchKernelGGL(k_reduce, dim3((unsigned)t->d_ldc), dim3(64), 0, st, t->d_ldc, t->d_part, g.nslot, G);
     }

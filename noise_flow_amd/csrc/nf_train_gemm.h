@@ -325,33 +325,86 @@ __global__ void k_g_c1_dz(Geo g, const float *__restrict__ Q18, float *__restric
     if (MIX) acc_add_n<16>(dA, acc, g.nslot);
 }
 
-// a filter gradient as the split GEMM left it — `nparts` partial products [nparts][n] — added up in fp64 into the gradient vector
-// (after k_reduce has written the slotted values).
+// Filter gradients as the split GEMMs left them — `nparts` partial products [nparts][n] each — added up in fp64 into the gradient
+// vector, every filter of the step in ONE launch (3 per coupling: at width 64 the 24 separate launches were 6 % of the step).
 // mode 0: G[dst + e];  mode 1 (l_last/W): the partials are [w][36] = (i, tap*4 + k) -> G[dst + (tap*(w+1) + i)*4 + k]
 constexpr int kStoreY = 16;   // threads that share one gradient entry's partial products
-__global__ void __launch_bounds__(64 * kStoreY) k_g_store_grad(int n, int w, int mode, const float *__restrict__ part, int nparts,
-                                                                double *__restrict__ G, int dst, int pstride)
+struct StoreJob {
+    const float *part;
+    int n, w, mode, nparts, dst, pstride;   // pstride: floats between two partial products
+};
+struct StoreJobs {
+    static constexpr int kMax = 24;
+    int count = 0;
+    int first[kMax + 1] = {0};   // first workgroup of job i (64 entries per workgroup)
+    StoreJob j[kMax];
+};
+__global__ void __launch_bounds__(64 * kStoreY) k_g_store_grads(const StoreJobs J, double *__restrict__ G)
 {
     __shared__ double acc[kStoreY][64];
-    const int e = blockIdx.x * 64 + threadIdx.x;
+    int job = 0;
+    while (job + 1 < J.count && (int)blockIdx.x >= J.first[job + 1]) ++job;   // workgroup-uniform
+    const StoreJob q = J.j[job];
+    const int e = ((int)blockIdx.x - J.first[job]) * 64 + threadIdx.x;
     double s = 0.0;
-    if (e < n)
-        for (int q = threadIdx.y; q < nparts; q += kStoreY) s += (double)part[(size_t)q * pstride + e];
+    if (e < q.n)
+        for (int k = threadIdx.y; k < q.nparts; k += kStoreY) s += (double)q.part[(size_t)k * q.pstride + e];
     acc[threadIdx.y][threadIdx.x] = s;
     __syncthreads();
-    if (threadIdx.y != 0 || e >= n) return;
+    if (threadIdx.y != 0 || e >= q.n) return;
     for (int y = 1; y < kStoreY; ++y) s += acc[y][threadIdx.x];
-    if (mode == 0) {
-        G[dst + e] = s;
+    if (q.mode == 0) {
+        G[q.dst + e] = s;
     } else {
         const int i = e / 36, col = e - i * 36, tap = col >> 2, k = col & 3;
-        G[dst + (tap * (w + 1) + i) * 4 + k] = s;
+        G[q.dst + (tap * (q.w + 1) + i) * 4 + k] = s;
     }
 }
-// pstride: floats between two partial products (0: n)
-inline void store_grad(hipStream_t st, int n, int w, int mode, const float *part, int nparts, double *G, int dst, int pstride = 0)
+inline void store_grads_flush(hipStream_t st, StoreJobs &J, double *G)
 {
-    hipLaunchKernelGGL(k_g_store_grad, dim3((n + 63) / 64), dim3(64, kStoreY), 0, st, n, w, mode, part, nparts, G, dst, pstride ? pstride : n);
+    if (J.count) hipLaunchKernelGGL(k_g_store_grads, dim3((unsigned)J.first[J.count]), dim3(64, kStoreY), 0, st, J, G);
+    J = StoreJobs{};
+}
+inline void store_grad(hipStream_t st, StoreJobs &J, int n, int w, int mode, const float *part, int nparts, double *G, int dst, int pstride = 0)
+{
+    if (J.count == StoreJobs::kMax) store_grads_flush(st, J, G);
+    J.j[J.count] = StoreJob{part, n, w, mode, nparts, dst, pstride ? pstride : n};
+    J.first[J.count + 1] = J.first[J.count] + (n + 63) / 64;
+    ++J.count;
+}
+
+// The slotted sums of runs of values (everything but the filters the GEMMs deliver whole) added up in fp64, all runs in ONE launch
+struct ReduceRuns {
+    static constexpr int kMax = 32;
+    int count = 0;
+    int first[kMax + 1] = {0};   // first workgroup (= value) of run i
+    const float *part[kMax];     // the run's first row of slots
+    int dst[kMax];
+};
+__global__ void __launch_bounds__(64) k_g_reduce_runs(const ReduceRuns R, int nslot, double *__restrict__ G)
+{
+    int run = 0;
+    while (run + 1 < R.count && (int)blockIdx.x >= R.first[run + 1]) ++run;
+    const int i = (int)blockIdx.x - R.first[run];
+    const float *row = R.part[run] + (size_t)i * NSLOT;
+    double s = 0.0;
+    for (int k = threadIdx.x; k < nslot; k += 64) s += (double)row[k];
+    s = wsum(s);
+    if (threadIdx.x == 0) G[R.dst[run] + i] = s;
+}
+inline void reduce_runs_flush(hipStream_t st, ReduceRuns &R, int nslot, double *G)
+{
+    if (R.count) hipLaunchKernelGGL(k_g_reduce_runs, dim3((unsigned)R.first[R.count]), dim3(64), 0, st, R, nslot, G);
+    R = ReduceRuns{};
+}
+inline void reduce_run(hipStream_t st, ReduceRuns &R, int nslot, double *G, const float *part, int a, int b)
+{
+    if (b <= a) return;
+    if (R.count == ReduceRuns::kMax) reduce_runs_flush(st, R, nslot, G);
+    R.part[R.count] = part;
+    R.dst[R.count] = a;
+    R.first[R.count + 1] = R.first[R.count] + (b - a);
+    ++R.count;
 }
 
 // The two batch sums of BN2's backward from the two products of k_mm_kpix <APRO 3> (part[s][0] = relu(xhat)^T . G36 = d l_last/W as
@@ -422,7 +475,8 @@ bool coupling_cnn_gemm(nf_trainer *t, const Geo &g, const TLayer &L, const float
     // this coupling's packed weights: written here, read again by the backward pass (an evaluator keeps one coupling's at a time)
     float *pk = t->gpack + (t->eval_only ? 0 : (size_t)L.aux * gemm_pack_floats(w));
     hipLaunchKernelGGL(mm::k_mm_pack_all, dim3((unsigned)((pl.total + 255) / 256)), dim3(256), 0, st, w, pl, P + off_w1, P + off_w2, P + off_w3, pk);
-    hipLaunchKernelGGL(k_g_gather18, dim3(nb), dim3(TB), 0, st, g, zin, t->gz18);
+    float *const z18 = t->gz18 + (size_t)L.aux * t->gz18_stride;   // kept for the backward pass (a trainer; an evaluator: stride 0)
+    hipLaunchKernelGGL(k_g_gather18, dim3(nb), dim3(TB), 0, st, g, zin, z18);
     const mm::Ctx cx{t->n_cu, t->device};
     bool ok = true;
     mm::PixArgs a{};
@@ -435,10 +489,10 @@ bool coupling_cnn_gemm(nf_trainer *t, const Geo &g, const TLayer &L, const float
     };
     // ---- l_1: h1 = Z18 . W1 and the batch sums of h1 + b1 ----
     if (v4 && t->gemm_c1_fused) {
-        hipLaunchKernelGGL(k_g_c1_fwd, dim3(ns), dim3(256), 0, st, g, w, (const float *)t->gz18, P + off_w1, P + off_b1, c.h1, t->acc(c.d_st1));
+        hipLaunchKernelGGL(k_g_c1_fwd, dim3(ns), dim3(256), 0, st, g, w, (const float *)z18, P + off_w1, P + off_b1, c.h1, t->acc(c.d_st1));
     } else {
         a.N = w; a.K = kZ18;                                   // the two spare columns of Z18 and of the packed W1^T are zero
-        a.A = t->gz18; a.lda = kZ18;
+        a.A = z18; a.lda = kZ18;
         a.Bt = pk + pl.o_w1t; a.ldb = 20;
         a.C = c.h1; a.ldc = w;
         a.ebias = P + off_b1; a.stats = t->acc(c.d_st1).p;
@@ -553,9 +607,9 @@ bool coupling_backward_gemm(nf_trainer *t, const Geo &g, const TLayer &L, const 
     hipLaunchKernelGGL(k_bnb_fin, dim3(w), dim3(64), 0, st, t->acc(c.d_bs1), w, g.nslot, n, t->d_flt + c.f_bb1);
     // ---- g_h1 = BN1 backward of the masked g_a1 is never stored: both of its consumers form it while they stage their tiles ----
     // d l_1/W = Z18^T . g_h1 (and d b1 = its column sums) ;  Q = g_h1 . W1^T
-    hipLaunchKernelGGL(k_g_gather18, dim3(nb), dim3(TB), 0, st, g, zin, t->gz18);
     k.M = 18; k.N = w;
-    k.A = t->gz18; k.lda = kZ18; k.B = t2; k.ldb = w; k.part = dW1;
+    k.A = t->gz18 + (size_t)L.aux * t->gz18_stride; k.lda = kZ18;   // the forward pass's windows of this coupling's input
+    k.B = t2; k.ldb = w; k.part = dW1;
     k.abias = nullptr; k.abn = nullptr;
     k.B2 = c.h1; k.bbias = P + off_b1; k.bbn = bn1; k.bbb = bb1; k.dbias = t->acc(off_b1).p;
     np[0] = v4 ? mm::mm_kpix_launch<1, 1, 2, 0, 1, 4, 2>(cx, st, k) : mm::mm_kpix_launch<1, 1, 2, 0, 1, 1, 2>(cx, st, k);
