@@ -1539,6 +1539,7 @@ struct nf_trainer {
     // coupling widths without stage kernels of their own (nf_train_gemm.h): the operands of the matrix-core GEMMs of nf_train_mm.h
     int n_cu = 256;
     float *gz18 = nullptr, *gp36 = nullptr, *gq18 = nullptr;   // [pixels][20] windows (18 + 2 zero columns), [pixels][36] taps, [pixels][18]
+    int nb_floor = 0;               // GEMM path: at least this many slots / workgroups of the pixel kernels (blocks_for)
     size_t gz18_stride = 0;         // trainer: every coupling keeps its windows for the backward pass (floats between two couplings')
     float *gpack = nullptr;         // every coupling's weights in the GEMMs' packed layouts (gemm_pack_floats(w) each; written by the forward pass)
     float *gdw = nullptr;           // filter gradients of every coupling as the pixel-K GEMMs leave them: 3 per coupling x gemm_part_floats(w)
@@ -1572,6 +1573,14 @@ inline unsigned blocks_for(int64_t npix)
     // launch), every SIMD 4 waves deep for large ones
     int64_t b = (npix + 2 * TB - 1) / (2 * TB);
     return (unsigned)std::min<int64_t>(std::max<int64_t>(b, 1), NSLOT);
+}
+// The GEMM path wants more slots at small minibatches: a GEMM with batch sums runs one workgroup per slot and pixel-tile share
+// (138 patches: 276 slots = ONE workgroup per CU at widths <= 128, where the channel axis is a single tile)
+inline unsigned blocks_for(const nf_trainer *t, int64_t npix)
+{
+    int64_t b = blocks_for(npix);
+    if (t->nb_floor) b = std::max<int64_t>(b, std::min<int64_t>(t->nb_floor, (npix + 127) / 128));
+    return (unsigned)std::min<int64_t>(b, NSLOT);
 }
 
 struct Guard {
@@ -1623,7 +1632,7 @@ void coupling_forward(nf_trainer *t, const Geo &g, const TLayer &L, const float 
                       const float *zpre, const float *A, hipStream_t st)
 {
     const Cpl &c = t->cpl[L.aux];
-    const unsigned nb = blocks_for(g.npix);
+    const unsigned nb = blocks_for(t, g.npix);
     const int w = W, off_w1 = L.off, off_m1 = L.off + 19 * w, off_w2 = L.off + 21 * w, off_m2 = L.off + 22 * w + w * w,
               off_w3 = L.off + 24 * w + w * w;
     const double n = (double)g.npix * t->sync_world;   // the moments are over the GLOBAL minibatch when the ranks are synchronised
@@ -1681,7 +1690,7 @@ void coupling_backward(nf_trainer *t, const Geo &g, const TLayer &L, const float
                        const float *A, Acc dA, hipStream_t st, const float *zlat)
 {
     const Cpl &c = t->cpl[L.aux];
-    const unsigned nb = blocks_for(g.npix);
+    const unsigned nb = blocks_for(t, g.npix);
     const int w = W, off_w1 = L.off, off_b1 = L.off + 18 * w, off_w2 = L.off + 21 * w, off_w3 = L.off + 24 * w + w * w;
     const double n = (double)g.npix * t->sync_world;
     const float *bn1 = t->d_flt + c.f_bn1, *bn2 = t->d_flt + c.f_bn2;
@@ -1792,7 +1801,7 @@ void coupling_forward_tiled(nf_trainer *t, const Geo &g, const TLayer &L, const 
                             float *nxt_zin)
 {
     const Cpl &c = t->cpl[L.aux];
-    const unsigned nb = blocks_for(g.npix), npatch = (unsigned)(g.npix / g.HW);
+    const unsigned nb = blocks_for(t, g.npix), npatch = (unsigned)(g.npix / g.HW);
     const int w = W, off_w1 = L.off, off_m1 = L.off + 19 * w, off_w2 = L.off + 21 * w, off_m2 = L.off + 22 * w + w * w,
               off_w3 = L.off + 24 * w + w * w;
     const double n = (double)g.npix * t->sync_world;
@@ -1831,7 +1840,7 @@ void coupling_backward_tiled(nf_trainer *t, const Geo &g, const TLayer &L, const
                              const float *nxt_zin)
 {
     const Cpl &c = t->cpl[L.aux];
-    const unsigned nb = blocks_for(g.npix), npatch = (unsigned)(g.npix / g.HW);
+    const unsigned nb = blocks_for(t, g.npix), npatch = (unsigned)(g.npix / g.HW);
     const int w = W, off_w1 = L.off, off_w2 = L.off + 21 * w, off_w3 = L.off + 24 * w + w * w;
     const double n = (double)g.npix * t->sync_world;
     const float *bn1 = t->d_flt + c.f_bn1, *bn2 = t->d_flt + c.f_bn2;
@@ -2193,6 +2202,8 @@ static int trainer_create_impl(const nf_config *cfg, const nf_layer_desc *layers
         NF_TRY(dev_alloc(t, (void **)&t->gpack, (size_t)n_cpl * gemm_pack_floats(w) * sizeof(float)));
         NF_TRY(dev_alloc(t, (void **)&t->gdw, (size_t)n_cpl * 3 * gemm_part_floats(w) * sizeof(float)));
         if (const char *ev = getenv("NF_TRAIN_GEMM_C1")) t->gemm_c1_fused = atoi(ev) != 0;
+        t->nb_floor = w <= 128 ? 512 : 0;   // measured at 138 patches: width 64 3.35 -> 3.21 ms, 128 5.37 -> 4.93; 256 / 512 + 1 % with it
+        if (const char *ev = getenv("NF_TRAIN_NB_FLOOR")) t->nb_floor = atoi(ev);   // A/B aid
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, t->device) == hipSuccess && cus > 0) t->n_cu = cus;
     }
@@ -2265,7 +2276,7 @@ static int trainer_run(nf_trainer *t, const float *x, const float *y, int64_t B,
     g.HW = g.H * g.W;
     g.npix = B * (int64_t)g.HW;
     g.nloop = (g.npix + 63) & ~(int64_t)63;
-    const unsigned nb = blocks_for(g.npix);
+    const unsigned nb = blocks_for(t, g.npix);
     g.nslot = (t->sync_fn && t->sync_world > 1) ? std::max((int)nb, 2) : (int)nb;   // the synchronised totals occupy slots 0 and 1
     t->sync_rc = 0;
     bool mm_failed = false;
@@ -2552,7 +2563,7 @@ int nf_bs_wide_run(nf_trainer *t, const nf_bs_wide_args &a, hipStream_t st)
     g.HW = g.H * g.W;
     g.npix = a.B * (int64_t)g.HW;
     g.nloop = (g.npix + 63) & ~(int64_t)63;
-    const unsigned nb = blocks_for(g.npix);
+    const unsigned nb = blocks_for(t, g.npix);
     g.nslot = (t->sync_fn && t->sync_world > 1) ? std::max((int)nb, 2) : (int)nb;
     const int n = t->cfg.n_layers, w = t->width ? t->width : 4;
     const unsigned nB = (unsigned)a.B;

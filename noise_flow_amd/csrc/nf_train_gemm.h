@@ -465,7 +465,7 @@ __global__ __launch_bounds__(64) void k_bn_fin_eval(Acc stats, int W, int nslot,
 bool coupling_cnn_gemm(nf_trainer *t, const Geo &g, const TLayer &L, const float *zin, hipStream_t st, float *mom)
 {
     const Cpl &c = t->cpl[L.aux];
-    const unsigned nb = blocks_for(g.npix), ns = gemm_grid(g);
+    const unsigned nb = blocks_for(t, g.npix), ns = gemm_grid(g);
     const int w = L.width, off_w1 = L.off, off_b1 = L.off + 18 * w, off_m1 = L.off + 19 * w, off_w2 = L.off + 21 * w,
               off_b2 = off_w2 + w * w, off_m2 = L.off + 22 * w + w * w, off_w3 = L.off + 24 * w + w * w;
     const double n = (double)g.npix * t->sync_world;
@@ -523,7 +523,7 @@ bool coupling_forward_gemm(nf_trainer *t, const Geo &g, const TLayer &L, const f
                            const float *A, hipStream_t st)
 {
     const Cpl &c = t->cpl[L.aux];
-    const unsigned nb = blocks_for(g.npix);
+    const unsigned nb = blocks_for(t, g.npix);
     const int w = L.width, off_w3 = L.off + 24 * w + w * w;
     if (zpre) hipLaunchKernelGGL(k_mix_fwd, dim3(nb), dim3(TB), 0, st, g, zpre, A, const_cast<float *>(zin));
     const bool ok = coupling_cnn_gemm(t, g, L, zin, st, nullptr);
@@ -535,7 +535,7 @@ bool coupling_backward_gemm(nf_trainer *t, const Geo &g, const TLayer &L, const 
                             const float *A, Acc dA, hipStream_t st, const float *zlat)
 {
     const Cpl &c = t->cpl[L.aux];
-    const unsigned nb = blocks_for(g.npix);
+    const unsigned nb = blocks_for(t, g.npix);
     const int w = L.width, off_w1 = L.off, off_b1 = L.off + 18 * w, off_w2 = L.off + 21 * w, off_b2 = off_w2 + w * w,
               off_w3 = L.off + 24 * w + w * w;
     (void)off_w1; (void)off_w2;

@@ -923,8 +923,8 @@ inline bool mm_pix_launch(const Ctx &cx, hipStream_t st, PixArgs a)
     int gm = a.m_tiles;
     if (EPI != 0) {
         const int want = std::max(1, 2 * cx.n_cu / a.n_tiles);
-        gm = std::min(std::min(a.nslot, a.m_tiles), std::max(want, 1));
-        if (gm < 1) gm = 1;
+        gm = std::max(1, std::min(std::min(a.nslot, a.m_tiles), want));
+        gm = (a.m_tiles + (a.m_tiles + gm - 1) / gm - 1) / ((a.m_tiles + gm - 1) / gm);   // the fewest workgroups with the same longest share
     }
     a.gm = gm;
     const size_t lds = pix_lds_bytes<WN, TN>(a.K, APRO);
