@@ -53,23 +53,24 @@ inline bool gemm_width(int w)
 // Z18[p][tap*2 + c] = z0 of pixel p + tap (zero outside the patch): the im2col of l_1 (layers.py:586-613, 'SAME').  Rows of
 // kZ18 = 20 floats (16-byte aligned; the two spare columns are zero, so a GEMM may run K = 20)
 constexpr int kZ18 = 20;
+// one thread per 16-byte piece (2 taps) of a row: a wavefront writes 1 KiB of consecutive memory (one thread per ROW wrote 5 pieces
+// 80 bytes apart: 0.8 TB/s, 113 us per coupling at 1 024 patches)
 __global__ void k_g_gather18(Geo g, const float *__restrict__ z, float *__restrict__ Z18)
 {
-    NF_PIXEL_LOOP(g, p) {
-        if (p < g.npix) {
-            const int b = (int)(p / g.HW), rem = (int)(p - (int64_t)b * g.HW), r = rem / g.W, c = rem - r * g.W;
-            float *o = Z18 + p * kZ18;
+    const int64_t total = g.npix * 5;
+    for (int64_t it = (int64_t)blockIdx.x * TB + threadIdx.x; it < total; it += (int64_t)gridDim.x * TB) {
+        const int64_t p = it / 5;
+        const int q = (int)(it - p * 5);
+        const int b = (int)(p / g.HW), rem = (int)(p - (int64_t)b * g.HW), r = rem / g.W, c = rem - r * g.W;
+        float2 v[2];
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int rr = r + tap / 3 - 1, cc = c + tap % 3 - 1;
-                float2 v = make_float2(0.f, 0.f);
-                if (rr >= 0 && rr < g.H && cc >= 0 && cc < g.W) v = *reinterpret_cast<const float2 *>(z + ((int64_t)b * g.HW + rr * g.W + cc) * 4);
-                o[2 * tap] = v.x;
-                o[2 * tap + 1] = v.y;
-            }
-            o[18] = 0.0f;
-            o[19] = 0.0f;
+        for (int h = 0; h < 2; ++h) {
+            const int tap = 2 * q + h;
+            const int rr = r + tap / 3 - 1, cc = c + tap % 3 - 1;
+            v[h] = make_float2(0.f, 0.f);
+            if (tap < 9 && rr >= 0 && rr < g.H && cc >= 0 && cc < g.W) v[h] = *reinterpret_cast<const float2 *>(z + ((int64_t)b * g.HW + rr * g.W + cc) * 4);
         }
+        reinterpret_cast<float4 *>(Z18)[it] = make_float4(v[0].x, v[0].y, v[1].x, v[1].y);
     }
 }
 
@@ -248,34 +249,40 @@ __global__ void k_g_c3_bwd(Geo g, int w, const float *__restrict__ zin, const fl
 // G36[q][tap*4 + k] = gu[q - tap][k], i.e. the gradient that reaches pixel q's activation through filter tap `tap`
 // (q = p + tap  <=>  p = q - tap; zero where p falls outside the patch) — the operand of both d l_last/W = a2^T . G36 and
 // g_a2 = G36 . W3r^T; and the edge channel: d W3[tap][w][k] = sum of gu[p][k] over the pixels whose tap falls on the padding ring
-__global__ void k_g_gather36(Geo g, int w, const float *__restrict__ gu, float *__restrict__ G36, int off_w3, Acc G)
+// 288 threads = 32 pixels x 9 taps: a thread keeps its tap, so a wavefront writes 1 KiB of consecutive memory and the ring sums of
+// a tap stay in 4 registers (one thread per PIXEL wrote 9 pieces 144 bytes apart: 1.2 TB/s)
+constexpr int kG36T = 288;
+__global__ __launch_bounds__(kG36T) void k_g_gather36(Geo g, int w, const float *__restrict__ gu, float *__restrict__ G36, int off_w3, Acc G)
 {
-    float edge[36];
-#pragma unroll
-    for (int i = 0; i < 36; ++i) edge[i] = 0.0f;
-    NF_PIXEL_LOOP(g, p) {
-        if (p < g.npix) {
-            const int b = (int)(p / g.HW), rem = (int)(p - (int64_t)b * g.HW), r = rem / g.W, c = rem - r * g.W;
-            const float4 own = reinterpret_cast<const float4 *>(gu)[p];
-            float *o = G36 + p * 36;
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int di = tap / 3 - 1, dj = tap % 3 - 1;
-                const int pr = r - di, pc = c - dj;          // the output pixel whose tap `tap` reads this pixel
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (pr >= 0 && pr < g.H && pc >= 0 && pc < g.W) v = reinterpret_cast<const float4 *>(gu)[(int64_t)b * g.HW + pr * g.W + pc];
-                *reinterpret_cast<float4 *>(o + tap * 4) = v;
-                const int rr = r + di, cc = c + dj;          // this pixel's own tap: on the ring?
-                if (rr < 0 || rr >= g.H || cc < 0 || cc >= g.W) {
-                    edge[tap * 4 + 0] += own.x; edge[tap * 4 + 1] += own.y; edge[tap * 4 + 2] += own.z; edge[tap * 4 + 3] += own.w;
-                }
-            }
+    __shared__ float red[kG36T][4];
+    const int t = threadIdx.x, tap = t % 9, lp = t / 9;
+    const int di = tap / 3 - 1, dj = tap % 3 - 1;
+    const float4 *const gu4 = reinterpret_cast<const float4 *>(gu);
+    float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t ngroups = (g.npix + 31) / 32;
+    for (int64_t gi = blockIdx.x; gi < ngroups; gi += gridDim.x) {
+        const int64_t p = gi * 32 + lp;
+        if (p >= g.npix) continue;
+        const int b = (int)(p / g.HW), rem = (int)(p - (int64_t)b * g.HW), r = rem / g.W, c = rem - r * g.W;
+        const int pr = r - di, pc = c - dj;          // the output pixel whose tap `tap` reads this pixel
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (pr >= 0 && pr < g.H && pc >= 0 && pc < g.W) v = gu4[(int64_t)b * g.HW + pr * g.W + pc];
+        reinterpret_cast<float4 *>(G36)[p * 9 + tap] = v;
+        const int rr = r + di, cc = c + dj;          // this pixel's own tap: on the ring?
+        if (rr < 0 || rr >= g.H || cc < 0 || cc >= g.W) {
+            const float4 own = gu4[p];
+            e.x += own.x; e.y += own.y; e.z += own.z; e.w += own.w;
         }
     }
-    // 9 groups of 4 adjacent values at l_last/W[tap][w][0..3]
-    for (int tap = 0; tap < 9; ++tap) {
-        const float v4[4] = {edge[tap * 4], edge[tap * 4 + 1], edge[tap * 4 + 2], edge[tap * 4 + 3]};
-        acc_add_n<4>(G + off_w3 + (tap * (w + 1) + w) * 4, v4, g.nslot);
+    red[t][0] = e.x; red[t][1] = e.y; red[t][2] = e.z; red[t][3] = e.w;
+    __syncthreads();
+    if (t < 36) {   // 9 groups of 4 adjacent values at l_last/W[tap][w][0..3]: this workgroup's partial into its slot
+        const int tp = t >> 2, k = t & 3;
+        float sum = 0.0f;
+        for (int i = 0; i < 32; ++i) sum += red[i * 9 + tp][k];
+        float *d = (G + off_w3 + (tp * (w + 1) + w) * 4 + k).p;
+        d[blockIdx.x] = sum;
+        for (int q = blockIdx.x + gridDim.x; q < g.nslot; q += gridDim.x) d[q] = 0.0f;
     }
 }
 
@@ -551,7 +558,7 @@ bool coupling_backward_gemm(nf_trainer *t, const Geo &g, const TLayer &L, const 
     float *dW1 = t->gdw + (size_t)(3 * L.aux) * gemm_part_floats(w), *dW2 = dW1 + gemm_part_floats(w), *dW3r = dW2 + gemm_part_floats(w);
     int *np = t->gnp + 3 * L.aux;
     hipLaunchKernelGGL(k_g_c3_bwd, dim3(nb), dim3(TB), 0, st, g, w, zin, P, off_w3, invB, t->dz, gu, G, zlat, (const float *)c.u);
-    hipLaunchKernelGGL(k_g_gather36, dim3(nb), dim3(TB), 0, st, g, w, (const float *)gu, t->gp36, off_w3, G);
+    hipLaunchKernelGGL(k_g_gather36, dim3(nb), dim3(kG36T), 0, st, g, w, (const float *)gu, t->gp36, off_w3, G);
     const mm::Ctx cx{t->n_cu, t->device};
     bool ok = true;
     mm::KpixArgs k{};
@@ -612,7 +619,11 @@ bool coupling_backward_gemm(nf_trainer *t, const Geo &g, const TLayer &L, const 
     k.B = t2; k.ldb = w; k.part = dW1;
     k.abias = nullptr; k.abn = nullptr;
     k.B2 = c.h1; k.bbias = P + off_b1; k.bbn = bn1; k.bbb = bb1; k.dbias = t->acc(off_b1).p;
-    np[0] = v4 ? mm::mm_kpix_launch<1, 1, 2, 0, 1, 4, 2>(cx, st, k) : mm::mm_kpix_launch<1, 1, 2, 0, 1, 1, 2>(cx, st, k);
+    // channel tile of the workgroup: 256 / 128 / 64 (at width 64 on the 256-wide tile three of four wavefronts multiplied zeros
+    // and the staged B tile was three quarters padding: 425 us per coupling at 1 024 patches)
+    if (w > 128) np[0] = v4 ? mm::mm_kpix_launch<1, 1, 2, 0, 1, 4, 2>(cx, st, k) : mm::mm_kpix_launch<1, 1, 2, 0, 1, 1, 2>(cx, st, k);
+    else if (w > 64) np[0] = v4 ? mm::mm_kpix_launch<1, 1, 1, 0, 1, 4, 2>(cx, st, k) : mm::mm_kpix_launch<1, 1, 1, 0, 1, 1, 2>(cx, st, k);
+    else np[0] = v4 ? mm::mm_kpix_launch<2, 1, 1, 0, 1, 4, 2>(cx, st, k) : mm::mm_kpix_launch<2, 1, 1, 0, 1, 1, 2>(cx, st, k);
     ok = ok && np[0] > 0;
     a.N = 18; a.K = w;
     a.A = t2; a.lda = w; a.A2 = c.h1;

@@ -268,6 +268,11 @@ int main(int argc, char **argv)
     check_kpix<1, 1, 2, 0, 1, 4, 2>(2000, 18, 512, 9);
     check_kpix<1, 1, 2, 0, 1, 4, 2>(600, 18, 48, 2);
     check_kpix<1, 1, 2, 0, 1, 1, 2>(600, 18, 50, 1024);
+    check_kpix<1, 1, 1, 0, 1, 4, 2>(900, 18, 96, 7);
+    check_kpix<1, 1, 1, 0, 1, 1, 2>(900, 18, 70, 7);
+    check_kpix<2, 1, 1, 0, 1, 4, 2>(900, 18, 64, 5);
+    check_kpix<2, 1, 1, 0, 1, 4, 2>(700, 18, 24, 300);
+    check_kpix<2, 1, 1, 0, 1, 1, 2>(500, 18, 5, 3);
     printf("%s (%d failures)\n", fails ? "PROBE FAILED" : "PROBE OK", fails);
     if (argc > 1 && !strcmp(argv[1], "time")) {
         timing(512, 138 * 1024);
