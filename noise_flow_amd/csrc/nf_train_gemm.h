@@ -444,7 +444,7 @@ __global__ __launch_bounds__(64) void k_g_bnb_from_parts(int w, int S, const flo
 // ---- host side -------------------------------------------------------------------------------------------------------------
 
 inline unsigned gemm_grid(const Geo &g) { return (unsigned)g.nslot; }   // one workgroup per slot: nobody's slot stays stale
-// floats of partial products one filter gradient may leave (up to 256 partials of M x N, at least one)
+// floats of partial products one filter gradient may leave (up to 256 partials of M x N — 512 at widths <= 128 —, at least one)
 inline size_t gemm_part_floats(int w) { return (size_t)mm::kGradPartFloats + 2 * (size_t)w * w; }
 // floats of packed weights one coupling's GEMMs read (nf_train_mm.h: pack_layout)
 inline size_t gemm_pack_floats(int w) { return (mm::pack_layout(w).total + 3) & ~(size_t)3; }
