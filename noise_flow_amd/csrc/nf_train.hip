@@ -2280,6 +2280,7 @@ static int trainer_run(nf_trainer *t, const float *x, const float *y, int64_t B,
     g.nslot = (t->sync_fn && t->sync_world > 1) ? std::max((int)nb, 2) : (int)nb;   // the synchronised totals occupy slots 0 and 1
     t->sync_rc = 0;
     bool mm_failed = false;
+    if ((t->all_gemm || gemm_width(t->width ? t->width : 4)) && !t->cpl.empty()) gemm_pack_step(t, st);
     const float invB = 1.0f / (float)B;
     const int n = t->cfg.n_layers;
     hipError_t e;

@@ -469,19 +469,46 @@ __global__ __launch_bounds__(64) void k_bn_fin_eval(Acc stats, int W, int nslot,
 
 // The coupling CNN up to the 36 columns of l_last's transposed evaluation (t->gp36), batch statistics formed on the way.
 // mom = nullptr: a training step (running statistics move); else the [4][w] moments of an evaluation call are left there.
+// the packed weights of every coupling of a training step (they do not change between its forward and backward pass)
+void gemm_pack_step(nf_trainer *t, hipStream_t st)
+{
+    const int w = t->width ? t->width : 4;
+    const mm::PackAll pl = mm::pack_layout(w);
+    mm::PackCpl pc{};
+    int n = 0, first = 0;
+    auto flush = [&] {
+        if (n)
+            hipLaunchKernelGGL(mm::k_mm_pack_all, dim3((unsigned)((pl.total + 255) / 256), (unsigned)n), dim3(256), 0, st, w, pl,
+                               (const float *)t->d_params, pc, t->gpack + (size_t)first * gemm_pack_floats(w), gemm_pack_floats(w));
+        first += n;
+        n = 0;
+    };
+    for (int l = 0; l < t->tl.n; ++l) {
+        const TLayer &L = t->tl.l[l];
+        if (L.type != NF_LAYER_COUPLING) continue;
+        if (n == mm::PackCpl::kMax) flush();
+        pc.off[n++] = L.off;   // couplings in layer order = aux order
+    }
+    flush();
+}
+
 bool coupling_cnn_gemm(nf_trainer *t, const Geo &g, const TLayer &L, const float *zin, hipStream_t st, float *mom)
 {
     const Cpl &c = t->cpl[L.aux];
     const unsigned nb = blocks_for(t, g.npix), ns = gemm_grid(g);
     const int w = L.width, off_w1 = L.off, off_b1 = L.off + 18 * w, off_m1 = L.off + 19 * w, off_w2 = L.off + 21 * w,
-              off_b2 = off_w2 + w * w, off_m2 = L.off + 22 * w + w * w, off_w3 = L.off + 24 * w + w * w;
+              off_b2 = off_w2 + w * w, off_m2 = L.off + 22 * w + w * w;
     const double n = (double)g.npix * t->sync_world;
     const float *P = t->d_params;
     const bool v4 = w % 4 == 0;
     const mm::PackAll pl = mm::pack_layout(w);
     // this coupling's packed weights: written here, read again by the backward pass (an evaluator keeps one coupling's at a time)
     float *pk = t->gpack + (t->eval_only ? 0 : (size_t)L.aux * gemm_pack_floats(w));
-    hipLaunchKernelGGL(mm::k_mm_pack_all, dim3((unsigned)((pl.total + 255) / 256)), dim3(256), 0, st, w, pl, P + off_w1, P + off_w2, P + off_w3, pk);
+    if (t->eval_only) {   // (a trainer packs every coupling's weights in one launch at the start of the step: gemm_pack_step)
+        mm::PackCpl pc{};
+        pc.off[0] = off_w1;
+        hipLaunchKernelGGL(mm::k_mm_pack_all, dim3((unsigned)((pl.total + 255) / 256), 1), dim3(256), 0, st, w, pl, P, pc, pk, (size_t)0);
+    }
     float *const z18 = t->gz18 + (size_t)L.aux * t->gz18_stride;   // kept for the backward pass (a trainer; an evaluator: stride 0)
     hipLaunchKernelGGL(k_g_gather18, dim3(nb), dim3(TB), 0, st, g, zin, z18);
     const mm::Ctx cx{t->n_cu, t->device};

@@ -1009,11 +1009,18 @@ inline PackAll pack_layout(int w)
     L.total = L.o_w1t + (size_t)w * 20;
     return L;
 }
-__global__ void k_mm_pack_all(int w, PackAll L, const float *__restrict__ W1, const float *__restrict__ W2, const float *__restrict__ W3,
-                              float *__restrict__ dst)
+// blockIdx.y = the coupling: its parameter block starts at P + C.off[y] (l_1/W, then l_2/W at + 21 w, l_last/W at + 24 w + w w), its
+// packed weights at dst + y * dst_stride
+struct PackCpl {
+    static constexpr int kMax = 32;
+    int off[kMax];
+};
+__global__ void k_mm_pack_all(int w, PackAll L, const float *__restrict__ P, PackCpl C, float *__restrict__ dst0, size_t dst_stride)
 {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= L.total) return;
+    const float *const W1 = P + C.off[blockIdx.y], *const W2 = W1 + 21 * (size_t)w, *const W3 = W1 + 24 * (size_t)w + (size_t)w * w;
+    float *const dst = dst0 + blockIdx.y * dst_stride;
     const int w4 = L.w4;
     float v = 0.0f;
     if (e < L.o_w2) {                     // Bt[j][i] = W2[i][j]
