@@ -963,10 +963,15 @@ inline int mm_kpix_launch(const Ctx &cx, hipStream_t st, KpixArgs a)
     a.m_tiles = (a.M + BM - 1) / BM;
     a.n_tiles = (a.N + BN - 1) / BN;
     const int tiles = a.m_tiles * a.n_tiles;
-    int64_t S = std::max<int64_t>(1, (4 * (int64_t)cx.n_cu + tiles - 1) / tiles);     // ~4 workgroups per CU over the whole launch
-    // at most 256 partial products; 512 where one or two tiles cover the output (widths <= 128: the launch is short and wants the
-    // CUs 2 - 4 workgroups deep — measured at 138 patches: width 64 2.93 -> 2.75 ms, 128 4.72 -> 4.55; width 512 loses 1.5 % with it)
-    const int scap = (a.M <= 128 && a.N <= 128) ? 512 : 256;
+    // workgroups over the whole launch: ~4 per CU, ~2 per CU for the 2 x 2-tile products (64 accumulator registers, 64 KiB of LDS:
+    // two are resident, and more chunks are only more partial products to write and add up — width 512, 138 patches: d l_2/W on
+    // 32 instead of 64 chunks and the dual product on 128 instead of 256 took the step from 22.7 to 22.3 ms)
+    const int per_cu = TM * TN == 4 ? 2 : 4;
+    int64_t S = std::max<int64_t>(1, (per_cu * (int64_t)cx.n_cu + tiles - 1) / tiles);
+    // at most 256 partial products (128 of the dual product); 512 where one or two tiles cover the output (widths <= 128: the launch
+    // is short and wants the CUs 2 - 4 workgroups deep — measured at 138 patches: width 64 2.93 -> 2.75 ms, 128 4.72 -> 4.55; width
+    // 512 loses 1.5 % with it)
+    const int scap = APRO == 3 ? 128 : (a.M <= 128 && a.N <= 128) ? 512 : 256;
     S = std::min<int64_t>(S, std::min<int64_t>(scap, kGradPartFloats / ((APRO == 3 ? 2 : 1) * (int64_t)a.M * a.N)));
     S = std::min<int64_t>(S, std::max<int64_t>(1, a.npix / (4 * kBK)));            // chunks of at least 128 pixels
     if (BPRO == 2) S = std::min<int64_t>(S, std::max(1, a.nslot));                     // one d-bias slot per chunk
