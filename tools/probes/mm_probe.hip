@@ -167,7 +167,7 @@ static int only = -1;   // time <k>: just the k-th product of the list (for coun
 static void timing(int w, int64_t P)
 {
     int idx = 0;
-    const int nslot = 276;
+    const int nslot = w <= 128 ? 512 : 276;   // as the trainer at 138 patches (nf_train.hip: blocks_for)
     std::vector<float> z((size_t)P * w, 0.5f), wz((size_t)w * w, 0.01f), c(2 * w, 1.0f);
     float *dA = dev(z), *dH = dev(z), *dC, *dBt = dev(wz), *dc = dev(c), *dS, *dP, *dG = nullptr;
     CK(hipMalloc(&dC, (size_t)P * w * sizeof(float)));
@@ -214,7 +214,11 @@ static void timing(int w, int64_t P)
     k.N = 36; k.B = dG; k.ldb = 36;
     run("d l_last/W + mask kpix<2,2,1,APRO 3>", 2.0 * P * w * 36, [&] { mm::mm_kpix_launch<2, 2, 1, 3, 4, 4>(cx, 0, k); });
     k.M = 18; k.N = w; k.A = dG; k.lda = 20; k.B = dH; k.ldb = w; k.B2 = dA; k.bbias = dc; k.bbn = dc; k.bbb = dc; k.dbias = dS; k.nslot = nslot;
-    run("d l_1/W  kpix<1,1,2,BPRO 2>", 2.0 * P * w * 18, [&] { mm::mm_kpix_launch<1, 1, 2, 0, 1, 4, 2>(cx, 0, k); });
+    run("d l_1/W  kpix<.,1,.,BPRO 2>", 2.0 * P * w * 18, [&] {   // the channel tile the trainer picks for the width
+        if (w > 128) mm::mm_kpix_launch<1, 1, 2, 0, 1, 4, 2>(cx, 0, k);
+        else if (w > 64) mm::mm_kpix_launch<1, 1, 1, 0, 1, 4, 2>(cx, 0, k);
+        else mm::mm_kpix_launch<2, 1, 1, 0, 1, 4, 2>(cx, 0, k);
+    });
     (void)hipFree(dA); (void)hipFree(dH); (void)hipFree(dC); (void)hipFree(dBt); (void)hipFree(dc); (void)hipFree(dS); (void)hipFree(dP); (void)hipFree(dG);
 }
 
