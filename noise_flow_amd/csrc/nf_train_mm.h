@@ -919,7 +919,7 @@ inline bool mm_pix_launch(const Ctx &cx, hipStream_t st, PixArgs a)
     constexpr int BN = WN * TN * 32;
     a.n_tiles = (a.N + BN - 1) / BN;
     a.m_tiles = (int)((a.P + kBM - 1) / kBM);
-    // without batch sums: one workgroup per tile, the dispatcher balances.  With them: one SLOT per workgroup, each walking its
+    // without batch sums: one workgroup per tile, the dispatcher balances (persistent workgroups, 2 or 4 per CU: measured, no difference).  With them: one SLOT per workgroup, each walking its
     // share of the pixel tiles — two workgroups per CU in flight
     int gm = a.m_tiles;
     if (EPI != 0) {
