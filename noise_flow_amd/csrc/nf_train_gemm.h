@@ -346,25 +346,48 @@ struct StoreJobs {
     int first[kMax + 1] = {0};   // first workgroup of job i (64 entries per workgroup)
     StoreJob j[kMax];
 };
-__global__ void __launch_bounds__(64 * kStoreY) k_g_store_grads(const StoreJobs J, double *__restrict__ G)
+// A workgroup = 64 x kStoreY threads: x owns kStoreV = 4 consecutive entries (one 16-byte load per partial product; jobs whose
+// partial products are not 16-byte aligned fall back to one entry per thread of a 4 x shorter row), y strides over the partials.
+constexpr int kStoreV = 4;
+__device__ __forceinline__ void store_entry(const StoreJob &q, double *__restrict__ G, int e, double s)
 {
-    __shared__ double acc[kStoreY][64];
-    int job = 0;
-    while (job + 1 < J.count && (int)blockIdx.x >= J.first[job + 1]) ++job;   // workgroup-uniform
-    const StoreJob q = J.j[job];
-    const int e = ((int)blockIdx.x - J.first[job]) * 64 + threadIdx.x;
-    double s = 0.0;
-    if (e < q.n)
-        for (int k = threadIdx.y; k < q.nparts; k += kStoreY) s += (double)q.part[(size_t)k * q.pstride + e];
-    acc[threadIdx.y][threadIdx.x] = s;
-    __syncthreads();
-    if (threadIdx.y != 0 || e >= q.n) return;
-    for (int y = 1; y < kStoreY; ++y) s += acc[y][threadIdx.x];
     if (q.mode == 0) {
         G[q.dst + e] = s;
     } else {
         const int i = e / 36, col = e - i * 36, tap = col >> 2, k = col & 3;
         G[q.dst + (tap * (q.w + 1) + i) * 4 + k] = s;
+    }
+}
+__global__ void __launch_bounds__(64 * kStoreY) k_g_store_grads(const StoreJobs J, double *__restrict__ G)
+{
+    __shared__ double acc[kStoreY][64][kStoreV];
+    int job = 0;
+    while (job + 1 < J.count && (int)blockIdx.x >= J.first[job + 1]) ++job;   // workgroup-uniform
+    const StoreJob q = J.j[job];
+    const int e0 = (((int)blockIdx.x - J.first[job]) * 64 + threadIdx.x) * kStoreV;
+    const bool vec = (q.n % kStoreV == 0) && (q.pstride % kStoreV == 0) && ((reinterpret_cast<uintptr_t>(q.part) & 15) == 0);   // workgroup-uniform
+    double s[kStoreV] = {0.0, 0.0, 0.0, 0.0};
+    if (e0 < q.n) {
+        if (vec) {
+            for (int k = threadIdx.y; k < q.nparts; k += kStoreY) {
+                const float4 v = *reinterpret_cast<const float4 *>(q.part + (size_t)k * q.pstride + e0);
+                s[0] += (double)v.x; s[1] += (double)v.y; s[2] += (double)v.z; s[3] += (double)v.w;
+            }
+        } else {
+            for (int k = threadIdx.y; k < q.nparts; k += kStoreY)
+#pragma unroll
+                for (int i = 0; i < kStoreV; ++i)
+                    if (e0 + i < q.n) s[i] += (double)q.part[(size_t)k * q.pstride + e0 + i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < kStoreV; ++i) acc[threadIdx.y][threadIdx.x][i] = s[i];
+    __syncthreads();
+    if (threadIdx.y != 0 || e0 >= q.n) return;
+#pragma unroll
+    for (int i = 0; i < kStoreV; ++i) {
+        for (int y = 1; y < kStoreY; ++y) s[i] += acc[y][threadIdx.x][i];
+        if (e0 + i < q.n) store_entry(q, G, e0 + i, s[i]);
     }
 }
 inline void store_grads_flush(hipStream_t st, StoreJobs &J, double *G)
@@ -376,7 +399,7 @@ inline void store_grad(hipStream_t st, StoreJobs &J, int n, int w, int mode, con
 {
     if (J.count == StoreJobs::kMax) store_grads_flush(st, J, G);
     J.j[J.count] = StoreJob{part, n, w, mode, nparts, dst, pstride ? pstride : n};
-    J.first[J.count + 1] = J.first[J.count] + (n + 63) / 64;
+    J.first[J.count + 1] = J.first[J.count] + (n + 64 * kStoreV - 1) / (64 * kStoreV);
     ++J.count;
 }
 
