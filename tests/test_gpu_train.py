@@ -842,6 +842,9 @@ def test_round_off_allowance_where_a_gradient_cancels():
                                                      ("sdn5|unc|unc|gain4", 24, (10, 12), 4, 800, 2),        # between two kernel widths
                                                      ("unc|unc", 5, (8, 8), 3, 100, 0),
                                                      ("|".join(["unc"] * 17), 12, (6, 6), 3, 400, 1),       # more couplings than one store / reduce launch holds
+                                                     ("unc|unc", 36, (64, 64), 2, 800, 2),                  # 64x64 patches; a ragged 64-channel tile
+                                                     ("unc", 200, (16, 24), 1, 100, 0),                     # one patch; two channel tiles, the second ragged
+                                                     ("sdn5|unc|gain4", 132, (7, 5), 3, 1600, 3),           # 35 pixels per patch; 128 + 4 channels
                                                      ("unc", 2, (8, 6), 3, 3200, 4)])    # (width 1: torch's CPU conv backward refuses the oracle's graph)
 def test_gradients_at_coupling_widths_beyond_32(arch, width, hw, B, iso, cam):
     """sidd/ArgParser.py:43 defaults --width to 512 and train_noise_flow.py:50-77 trains at whatever width is set: beyond 32 the
