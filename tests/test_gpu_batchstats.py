@@ -126,7 +126,9 @@ def test_batchstats_other_shapes(arch, width, hw, B):
                                                      ("unc|unc", 512, (32, 32), 2, 100, 1),        # the reference's default --width
                                                      ("sdn5|unc|unc|gain4|unc", 32, (64, 64), 2, 400, 0),   # configs[4] geometry at the paper's width
                                                      ("unc|unc", 50, (9, 7), 4, 1600, 3),           # not a multiple of 4, ragged shape
-                                                     ("unc|gain4|unc", 16, (48, 64), 2, 800, 2)])   # beyond the scalar kernel's LDS tiles
+                                                     ("unc|gain4|unc", 16, (48, 64), 2, 800, 2),    # beyond the scalar kernel's LDS tiles
+                                                     ("unc|unc", 132, (12, 20), 1, 400, 1),         # ONE patch: the batch is its pixels; 128 + 4 channels
+                                                     ("|".join(["unc"] * 9), 40, (8, 8), 3, 100, 0)])   # 9 couplings
 def test_batchstats_on_the_gemm_route(arch, width, hw, B, iso, cam):
     """NoiseFlowWrapper.py:86 runs the sampling graph with is_training=True and sidd/ArgParser.py:43 defaults --width to 512: the
     batch-statistics calls take every width and patch size.  Beyond 32 channels, and where a patch outgrows the scalar-weight
