@@ -821,3 +821,27 @@ def test_per_patch_temperature_draws_the_kernels_own_philox_stream(shipped_varia
     c = m.sample(y, np.asarray([0.7, 0.7, 0.7, 0.2, 0.7, 0.7], np.float32), y, [0.0], [0.0], [100], [2], seed=13)
     assert np.array_equal(a, b)
     assert np.array_equal(a[[0, 1, 2, 4, 5]], c[[0, 1, 2, 4, 5]]) and np.abs(c[3]).max() < np.abs(a[3]).max()
+
+
+@pytest.mark.parametrize("cnn_dtype", ["fp32", "fp16"])
+def test_a_patch_result_at_64x64_does_not_depend_on_the_batch(shipped_variables, cnn_dtype):
+    """At 64x64 a workgroup of 1 024 threads walks several patches per launch and finishes the cross-wavefront sum of each one
+    while it is already in the next (csrc/nf_kernels.hip: the deferred epilogue; the last patch behind the loop).  Per-patch NLL
+    and sd_z of a batch that gives some workgroups one patch and others two or three must be, bit for bit, what the same patches
+    give alone or at the head / tail of smaller batches (noise_flow_model.py:458-480 is per patch)."""
+    import torch
+    from noise_flow_amd import NoiseFlow, default_hps
+    B = 600                      # 256 CUs: workgroups with 2 and with 3 patches
+    x, y = make_inputs(B, 64, 64, seed=23)
+    m = NoiseFlow([64, 64, 4], False, default_hps(), variables=shipped_variables, cnn_dtype=cnn_dtype)
+
+    def run(sel):
+        xs, ys = torch.as_tensor(x[sel]).cuda(), torch.as_tensor(y[sel]).cuda()
+        nll, sd, _, _, _, _ = m._run_nll(xs, ys, m._cond([0.0], [0.0], [800], [2]), False)
+        return nll.cpu().numpy().copy(), sd.cpu().numpy().copy()
+
+    nll, sd = run(slice(0, B))
+    assert np.isfinite(nll).all() and np.isfinite(sd).all()
+    for sel in (slice(0, 1), slice(B - 1, B), slice(254, 259), slice(0, 257), slice(300, 600)):
+        n2, s2 = run(sel)
+        assert np.array_equal(n2, nll[sel]) and np.array_equal(s2, sd[sel]), sel
