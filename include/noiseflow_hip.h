@@ -271,7 +271,7 @@ int nf_sample_host(nf_handle *h, const void *y, int32_t y_dtype, const float *ep
  * between two kernel widths runs zero-padded on the next one); everything else — widths beyond 32 (sidd/ArgParser.py:43 defaults to
  * 512), 64x64 at the paper's width 32 — layer by layer on the trainer's matrix-core GEMM path (csrc/nf_train_mm.h) over one
  * resident tensor, batch sums in the GEMM epilogues.  moments_out rows keep the model's own w channels on every route.
- * NF_BS_WIDE=1 in the environment sends every call down the last route (A/B aid). */
+ * NF_BS_WIDE=1 in the environment sends every call down the last route (A/B aid; read per call, 0 = off). */
 int nf_nll_batchstats(nf_handle *h, const float *x, const float *y, int64_t B, const nf_cond *cond,
                       float *nll_out, float *sd_out, float *logdet_out, float *z_out,
                       double *sums_out, uint32_t flags, float *moments_out, void *stream);
@@ -281,8 +281,10 @@ int nf_sample_batchstats(nf_handle *h, const float *y, const float *eps, uint64_
 
 /* Cross-rank batch statistics for nf_nll_batchstats / nf_sample_batchstats: the reference's batch_norm takes its moments over
  * the WHOLE minibatch (layers.py:386-398), which under data parallelism is the union of the ranks' shards.  With a callback
- * installed the library calls fn(user, sync_buf, count, stream) after every statistics pass (2 per coupling): sync_buf (DEVICE,
- * caller-owned, >= 64 doubles) holds this rank's `count` sums, written by work already enqueued on `stream`; the callback must
+ * installed the library calls fn(user, sync_buf, count, stream) after every statistics pass — 2 per coupling on the fused
+ * kernels' routes (widths up to 32), ceil(2 w / 64) per normalisation on the GEMM route (widths beyond 32 and the sizes listed
+ * above: the 2 w sums of a normalisation go in chunks of at most 64 doubles, i.e. 2 x ceil(2 w / 64) per coupling) —: sync_buf
+ * (DEVICE, caller-owned, >= 64 doubles) holds this rank's `count` sums, written by work already enqueued on `stream`; the callback must
  * enqueue a SUM all-reduce over the ranks so that later work on `stream` sees the totals, and return 0 (the contract of
  * nf_trainer_set_sync, declared below with nf_allreduce_fn).  Every rank must call with the same B; the moments then use
  * world_size x the local pixel count, and every rank normalises with the same, global moments — N ranks x B patches evaluate

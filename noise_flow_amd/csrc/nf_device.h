@@ -130,6 +130,14 @@ __host__ __device__ constexpr int nf_cpl_size(int w)   { return 64 + 36 * w + 18
 #define NF11_CPL_A1 84
 #define NF11_CPL_A3 340
 #define NF11_CPL_SIZE 852
+// 64x64 patches (one 16-wavefront workgroup per CU: LDS to spare) carry l_2 as v_mfma_f32_16x16x32_f16 operands too, so that the
+// 2-pass v_mfma_f32_4x4x4_16b_f16 (owns the issue port for 2.85 plain-VALU slots) leaves the coupling: the B operand of one
+// instruction is the PAIR {relu(h1) of unit 2u, relu(h1) of unit 2u + 1} (8 halves of the lane's own two pixels = K slot
+// gk = lane >> 4), A2[half][lane (gk, m = 4 g + j)][e] = W2[e - 4 half][j] for gk == g and 4 half <= e < 4 half + 4, else 0:
+// instruction `half` evaluates unit 2u + half.  12.5 % of the multiplies useful, one issue slot each.
+//             A2 [2][64][4w] @852
+#define NF11_CPL_A2 852
+#define NF11_CPL_SIZE_L2 1364
 #define NF11_MAX_FLOATS 12288   // 48 KiB of LDS for the whole model's weights in this layout
 __host__ __device__ constexpr int nf11_l1_row(int gk) { return 2 * (gk & 1) + (gk >> 1); }
 __host__ __device__ constexpr int nf11_l3_row(int gk, int m3) { return 2 * (gk & 1) + m3; }
@@ -336,6 +344,10 @@ struct NfLaunch {
     int32_t tile_ny, tile_nx;
     int32_t tile_halo;
     float *tile_part;
+    // matrix-core kernels (filled by nf_launch_flow from the program, not by callers): the first run of `mix, coupling` pairs whose
+    // parameter blocks sit a constant stride apart — walked as a counted loop without scalar loads — and the number of couplings
+    int32_t run_first, run_n, run_moff, run_coff, run_stride, run_type, n_cpl;
+    int32_t fair_t1, fair_t2, fair_t3;   // progress-based wave priority (NF_FAIR): the smallest coupling count c with 4 c / n_cpl >= 1, 2, 3
 };
 
 #define NF_STATS_SLOTS 64   // power of two

@@ -347,7 +347,7 @@ void relayout_coupling_v3(const float *v1, float *out)
 }
 
 // fp16-CNN re-layout for v_mfma_f32_16x16x32_f16 (nf_device.h, NF11_*): the A operands in the order the lanes fetch them.
-void relayout_coupling_v11(const float *v1, float *out)
+void relayout_coupling_v11(const float *v1, float *out, bool with_a2)
 {
     const int w = 4;
     const double log2e = 1.4426950408889634;
@@ -377,6 +377,15 @@ void relayout_coupling_v11(const float *v1, float *out)
                 a3[(m3 * 64 + l) * 8 + e] = tap_ok(di) && tap_ok(dj) ? to_half(v1[nf_cpl_off_W3(w) + ((di * 3 + dj) * 4 + c) * 4 + j]) : (uint16_t)0;
             }
         }
+    }
+    if (with_a2) {   // l_2 on the same instruction (nf_device.h, NF11_CPL_A2): block-diagonal over the lane's own K slot
+        uint16_t *a2 = reinterpret_cast<uint16_t *>(out + NF11_CPL_A2);
+        for (int half = 0; half < 2; ++half)
+            for (int l = 0; l < 64; ++l) {
+                const int gk = l >> 4, m = l & 15, g = m >> 2, j = m & 3;
+                for (int e = 0; e < 8; ++e)
+                    a2[(half * 64 + l) * 8 + e] = (gk == g && (e >> 2) == half) ? to_half(v1[nf_cpl_off_W2(w) + (e & 3) * 4 + j]) : (uint16_t)0;
+            }
     }
 }
 
@@ -1270,8 +1279,10 @@ int build_program(const nf_config *cfg, const nf_layer_desc *layers, const float
                 for (int j = 0; j < 4; ++j)
                     for (int c = 0; c < 4; ++c) out.block3.push_back(v1[c * 4 + j]);
             } else if (src.type == NF_OP_COUPLING_FWD || src.type == NF_OP_COUPLING_REV) {
-                out.block3.resize(out.block3.size() + (out.fp16_big ? NF11_CPL_SIZE : NF3_CPL_SIZE));
-                if (out.fp16_big) relayout_coupling_v11(v1, out.block3.data() + dst.off);
+                // 64x64 patches / tiles: l_2's operands for v_mfma_f32_16x16x32_f16 ride along (NF11_CPL_A2)
+                const bool with_a2 = th == 64 && tw == 64;
+                out.block3.resize(out.block3.size() + (out.fp16_big ? (with_a2 ? NF11_CPL_SIZE_L2 : NF11_CPL_SIZE) : NF3_CPL_SIZE));
+                if (out.fp16_big) relayout_coupling_v11(v1, out.block3.data() + dst.off, with_a2);
                 else relayout_coupling_v3(v1, out.block3.data() + dst.off);
             } else if (src.type == NF_OP_SCALE) {
                 out.block3.insert(out.block3.end(), v1, v1 + 4);
@@ -2205,14 +2216,18 @@ static int run_batchstats_wide(nf_handle *h, int direction, const NfLaunch &a, c
     if (!h->bs) h->bs = new (std::nothrow) nf_bs_state();
     if (!h->bs) return fail(NF_ENOMEM, "out of host memory");
     nf_bs_state &S = *h->bs;
+    int64_t cap = a.B;
     if (S.wide && nf_bs_wide_capacity(S.wide) < a.B) {
+        // grow geometrically: a caller that ramps its batch size pays O(log B) re-allocations of the evaluator's tensors, not one per step
+        cap = std::max<int64_t>(a.B, 2 * nf_bs_wide_capacity(S.wide));
         (void)nf_trainer_destroy(S.wide);
         S.wide = nullptr;
     }
     if (!S.wide) {
         nf_config cfg = h->cfg;
         cfg.device = h->device;
-        int rc = nf_bs_wide_create(&cfg, h->layers.data(), h->raw.data(), h->raw.size(), a.B, &S.wide);
+        int rc = nf_bs_wide_create(&cfg, h->layers.data(), h->raw.data(), h->raw.size(), cap, &S.wide);
+        if (rc != NF_OK && cap > a.B) rc = nf_bs_wide_create(&cfg, h->layers.data(), h->raw.data(), h->raw.size(), a.B, &S.wide);   // (no room for the head-room)
         if (rc != NF_OK) return rc;
     }
     nf_bs_wide_args w;
@@ -2249,7 +2264,9 @@ static int run_batchstats(nf_handle *h, int direction, NfLaunch a, float *moment
         const size_t tile_px = ((size_t)(a.H + 2) * (a.W + 2) + 1) & ~(size_t)1;
         const bool scalar_fits = sizeof(float) * (tile_px * (2 + (size_t)pw) + 64) <= 160 * 1024 && !(pw >= 32 && a.H * a.W > 1024) && h->scalar_ok && !h->fwd.tiled;
         const bool mc4 = pw == 4 && !h->fwd.block2.empty() && use_matrix_core();
-        if (pw > 32 || (!mc4 && !scalar_fits) || getenv("NF_BS_WIDE"))   // (NF_BS_WIDE=1: A/B aid)
+        // NF_BS_WIDE=1: A/B aid; read per call on purpose (tests/test_gpu_batchstats.py flips it inside one process), =0 means off
+        const char *bw = getenv("NF_BS_WIDE");
+        if (pw > 32 || (!mc4 && !scalar_fits) || (bw && atoi(bw) != 0))
             return run_batchstats_wide(h, direction, a, cond, moments_out, st);
     }
     const int wr = h->fwd.raw_width;   // rows of moments_out are [4][wr]; the kernels' rows [4][prog.width] (zero-padded widths)

@@ -1993,6 +1993,7 @@ static int trainer_create_impl(const nf_config *cfg, const nf_layer_desc *layers
     int n_mix = 0, n_cpl = 0, n_sdn = 0, n_gain = 0;
     memset(&t->tl, 0, sizeof(t->tl));
     t->tl.n = cfg->n_layers;
+    int64_t prev_end = 0;
     for (int i = 0; i < cfg->n_layers; ++i) {
         const nf_layer_desc &L = layers[i];
         const int64_t cnt = nf_layer_param_count(L.type, L.width);
@@ -2000,6 +2001,14 @@ static int trainer_create_impl(const nf_config *cfg, const nf_layer_desc *layers
             delete t;
             return nf_fail(NF_EINVAL, "layer %d: bad type / width / parameter range", i);
         }
+        // the slotted-sum storage is indexed by parameter position with the l_2/W bodies cut out (`holes`, `acc()`): that
+        // bookkeeping — and the one-gradient-per-variable contract — needs the layers' parameter blocks in ascending order, disjoint
+        if (L.param_offset < prev_end) {
+            delete t;
+            return nf_fail(NF_EINVAL, "layer %d: parameter blocks must be ascending and must not overlap (offset %lld, previous block ends at %lld)",
+                           i, (long long)L.param_offset, (long long)prev_end);
+        }
+        prev_end = L.param_offset + cnt;
         TLayer &T = t->tl.l[i];
         T.type = L.type;
         T.kind = L.type;

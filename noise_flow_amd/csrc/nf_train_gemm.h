@@ -468,7 +468,15 @@ __global__ __launch_bounds__(64) void k_g_bnb_from_parts(int w, int S, const flo
 
 inline unsigned gemm_grid(const Geo &g) { return (unsigned)g.nslot; }   // one workgroup per slot: nobody's slot stays stale
 // floats of partial products one filter gradient may leave (up to 256 partials of M x N — 512 at widths <= 128 —, at least one)
-inline size_t gemm_part_floats(int w) { return (size_t)mm::kGradPartFloats + 2 * (size_t)w * w; }
+// — sized from what mm_kpix_launch can ask for at this width, not a flat 64 MiB: S <= 512 partials (x 2 for the dual product) of at most
+// max(w x w, 36 x w) floats (17 couplings at width 12 reserved 3.2 GiB and used a few MiB); the launches are handed this capacity
+// (KpixArgs::part_cap) and cut their chunk count to it
+inline size_t gemm_part_cap(int w)
+{
+    const size_t mn = std::max((size_t)w * w, (size_t)64 * std::max(w, 32));
+    return std::min<size_t>((size_t)mm::kGradPartFloats, 1024 * mn);
+}
+inline size_t gemm_part_floats(int w) { return gemm_part_cap(w) + 2 * (size_t)w * w; }
 // floats of packed weights one coupling's GEMMs read (nf_train_mm.h: pack_layout)
 inline size_t gemm_pack_floats(int w) { return (mm::pack_layout(w).total + 3) & ~(size_t)3; }
 
@@ -614,6 +622,7 @@ bool coupling_backward_gemm(nf_trainer *t, const Geo &g, const TLayer &L, const 
     mm::KpixArgs k{};
     k.npix = g.npix;
     k.nslot = g.nslot;
+    k.part_cap = (int64_t)gemm_part_cap(w);
     mm::PixArgs a{};
     a.P = g.npix;
     a.nslot = g.nslot;

@@ -551,6 +551,7 @@ struct KpixArgs {
     const float *B;         // [npix][ldb]
     int ldb;
     float *part;            // [S][M][N]
+    int64_t part_cap;       // floats `part` holds (0: kGradPartFloats) — the launch never leaves more partial products than fit
     int64_t chunk;          // pixels per partial product (a multiple of kBK)
     int S;                  // partial products
     int m_tiles, n_tiles;
@@ -973,7 +974,9 @@ inline int mm_kpix_launch(const Ctx &cx, hipStream_t st, KpixArgs a)
     // is short and wants the CUs 2 - 4 workgroups deep — measured at 138 patches: width 64 2.93 -> 2.75 ms, 128 4.72 -> 4.55; width
     // 512 loses 1.5 % with it)
     const int scap = APRO == 3 ? 128 : (a.M <= 128 && a.N <= 128) ? 512 : 256;
-    S = std::min<int64_t>(S, std::min<int64_t>(scap, kGradPartFloats / ((APRO == 3 ? 2 : 1) * (int64_t)a.M * a.N)));
+    const int64_t cap = a.part_cap > 0 ? std::min<int64_t>(a.part_cap, kGradPartFloats) : kGradPartFloats;
+    if (cap < (APRO == 3 ? 2 : 1) * (int64_t)a.M * a.N) return 0;
+    S = std::min<int64_t>(S, std::min<int64_t>(scap, cap / ((APRO == 3 ? 2 : 1) * (int64_t)a.M * a.N)));
     S = std::min<int64_t>(S, std::max<int64_t>(1, a.npix / (4 * kBK)));            // chunks of at least 128 pixels
     if (BPRO == 2) S = std::min<int64_t>(S, std::max(1, a.nslot));                     // one d-bias slot per chunk
     a.chunk = ((a.npix + S - 1) / S + kBK - 1) / kBK * kBK;

@@ -30,9 +30,9 @@ def _oracle(arch, variables, binding="loss_first"):
 
 
 def _close_elem(a, ref, rtol=ELEM_RTOL):
-    scale = np.abs(ref).max()
-    err = np.abs(np.asarray(a, np.float64) - ref).max()
-    assert err <= rtol * scale, "max err %.3e > %.1e * %.3e" % (err, rtol, scale)
+    """Scale-relative bound + the masked per-element relative error for the session summary (tests/conftest.py::close_elem)."""
+    from conftest import close_elem
+    return close_elem(a, ref, rtol)
 
 
 def _coupling_scopes(m):
@@ -191,7 +191,6 @@ def test_the_two_batchstats_routes_agree(shipped_variables, monkeypatch):
     for k in res["0"][2]:
         assert np.abs(res["1"][2][k] - res["0"][2][k]).max() <= 1e-5 * max(np.abs(res["0"][2][k]).max(), 1e-3), k
     _close_elem(res["1"][3], res["0"][3].astype(np.float64))
-    assert not np.array_equal(res["1"][0], res["0"][0]) or True
 
 
 def test_batchstats_single_patch_and_large_batch(shipped_variables):
