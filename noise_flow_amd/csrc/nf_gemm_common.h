@@ -140,7 +140,7 @@ __device__ __forceinline__ void gemm_scale(float s, float (&z)[OWN][4])
 
 // The affine half of a coupling behind its CNN: o = the 4 raw outputs of l_last per owned pixel (without the border-table /
 // bias entry), etab = the coupling's 16 x 4 border table, scl / m2scl = scale log2(e), -2 scale log2(e).
-//   HALF   fp16-CNN layouts: the raw columns are NOT pre-scaled by 2 log2(e) (their weights' rounding points are the oracle's)
+//   HALF   fp16-CNN layouts (the raw columns are pre-scaled by 2 log2(e) there too: inside the rounded weights, nf_host.hip::to_half_w3)
 template <int OWN, bool HALF>
 __device__ __forceinline__ void gemm_finish_coupling(int type, const float *__restrict__ etab, float scl, float m2scl, const GemmTile &T,
                                                      const int (&pr)[OWN], const int (&pc)[OWN], const bool (&act)[OWN], float (&o)[OWN][4],
@@ -150,12 +150,7 @@ __device__ __forceinline__ void gemm_finish_coupling(int type, const float *__re
     for (int m = 0; m < OWN; ++m) {
         const float4 eb = *reinterpret_cast<const float4 *>(etab + 4 * (act[m] ? T.border(pr[m], pc[m]) : 0));
         o[m][0] += eb.x; o[m][1] += eb.y;
-        if constexpr (HALF) {
-            o[m][2] = fmaf(o[m][2], 2.8853900817779268f, eb.z);
-            o[m][3] = fmaf(o[m][3], 2.8853900817779268f, eb.w);
-        } else {
-            o[m][2] += eb.z; o[m][3] += eb.w;
-        }
+        o[m][2] += eb.z; o[m][3] += eb.w;
         // raw columns pre-scaled by 2 log2(e):  t = exp2(raw') = exp(2 raw);
         // ls*log2(e) = scl*tanh(raw) = scl - 2 scl/(t + 1); log-det accumulated in log2 units
         const float l0 = fmaf(__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(o[m][2]) + 1.0f), m2scl, scl);

@@ -313,11 +313,28 @@ uint16_t to_half(float f)
     return u;
 }
 
+// l_last weights of the fp16-CNN layouts: output channel j of 4 = (shift, shift, raw, raw).  The raw columns carry the 2 log2(e)
+// of  t = exp2(2 log2(e) raw) = exp(2 raw)  INSIDE the rounded weight — folded before the rounding to half, like the batch-norm
+// scale and exp(3 logs) — so that no kernel multiplies behind its matrix instructions (oracle/nf_oracle.py::coupling_cnn_fp16
+// rounds at the same point).
+uint16_t to_half_w3(float wv, int j)
+{
+    const double k2 = 2.0 * 1.4426950408889634;
+    _Float16 h = (_Float16)(j >= 2 ? (double)wv * k2 : (double)wv);
+    uint16_t u;
+    memcpy(&u, &h, 2);
+    return u;
+}
+
 void relayout_coupling_v3(const float *v1, float *out)
 {
     const int w = 4;
-    const double log2e = 1.4426950408889634;
-    memcpy(out + NF3_CPL_E, v1 + nf_cpl_off_E(w), 64 * sizeof(float));
+    const double log2e = 1.4426950408889634, k2 = 2.0 * log2e;
+    for (int m = 0; m < 16; ++m)
+        for (int j = 0; j < 4; ++j) {
+            const double e = v1[nf_cpl_off_E(w) + 4 * m + j];
+            out[NF3_CPL_E + 4 * m + j] = (float)(j >= 2 ? e * k2 : e);   // raw columns feed exp2() directly
+        }
     memcpy(out + NF3_CPL_B1, v1 + nf_cpl_off_B1(w), 4 * sizeof(float));
     memcpy(out + NF3_CPL_B2, v1 + nf_cpl_off_B2(w), 4 * sizeof(float));
     const double sc = v1[nf_cpl_off_S(w)];
@@ -342,7 +359,7 @@ void relayout_coupling_v3(const float *v1, float *out)
         }
         for (int i = 0; i < 4; ++i) h2[j * 4 + i] = to_half(v1[nf_cpl_off_W2(w) + i * 4 + j]);
         for (int tap = 0; tap < 9; ++tap)
-            for (int i = 0; i < 4; ++i) h3[j * (2 * NF3_W3H_STRIDE) + tap * 4 + i] = to_half(v1[nf_cpl_off_W3(w) + (tap * 4 + i) * 4 + j]);
+            for (int i = 0; i < 4; ++i) h3[j * (2 * NF3_W3H_STRIDE) + tap * 4 + i] = to_half_w3(v1[nf_cpl_off_W3(w) + (tap * 4 + i) * 4 + j], j);
     }
 }
 
@@ -350,8 +367,12 @@ void relayout_coupling_v3(const float *v1, float *out)
 void relayout_coupling_v11(const float *v1, float *out, bool with_a2)
 {
     const int w = 4;
-    const double log2e = 1.4426950408889634;
-    memcpy(out + NF11_CPL_E, v1 + nf_cpl_off_E(w), 64 * sizeof(float));
+    const double log2e = 1.4426950408889634, k2 = 2.0 * log2e;
+    for (int m = 0; m < 16; ++m)
+        for (int j = 0; j < 4; ++j) {
+            const double e = v1[nf_cpl_off_E(w) + 4 * m + j];
+            out[NF11_CPL_E + 4 * m + j] = (float)(j >= 2 ? e * k2 : e);   // raw columns feed exp2() directly
+        }
     memcpy(out + NF11_CPL_B1, v1 + nf_cpl_off_B1(w), 4 * sizeof(float));
     memcpy(out + NF11_CPL_B2, v1 + nf_cpl_off_B2(w), 4 * sizeof(float));
     const double sc = v1[nf_cpl_off_S(w)];
@@ -374,7 +395,7 @@ void relayout_coupling_v11(const float *v1, float *out, bool with_a2)
             }
             for (int m3 = 0; m3 < 2; ++m3) {   // l_last: element e = 4 px + c of window row nf11_l3_row(gk, m3), column pair gk >> 1
                 const int wc = 2 * (gk >> 1) + (e >> 2), c = e & 3, di = nf11_l3_row(gk, m3) - a, dj = wc - p;
-                a3[(m3 * 64 + l) * 8 + e] = tap_ok(di) && tap_ok(dj) ? to_half(v1[nf_cpl_off_W3(w) + ((di * 3 + dj) * 4 + c) * 4 + j]) : (uint16_t)0;
+                a3[(m3 * 64 + l) * 8 + e] = tap_ok(di) && tap_ok(dj) ? to_half_w3(v1[nf_cpl_off_W3(w) + ((di * 3 + dj) * 4 + c) * 4 + j], j) : (uint16_t)0;
             }
         }
     }
@@ -553,7 +574,7 @@ void relayout_coupling_gemm16(const float *v1, int w, int wp, float *out)
                 }
                 for (int m2 = 0; m2 < 2; ++m2) {       // P rows of taps 0 .. 7 from INPUT tile m
                     const int cin = 32 * m + nf4_chan(8 * m2 + q, g), row = l & 31, tap = row >> 2, j = row & 3;
-                    h[2 * ((size_t)nf8_img_A3H(wp) + ((m * 2 + m2) * 64 + l) * 4) + q] = cin < w ? to_half(W3[((size_t)tap * w + cin) * 4 + j]) : 0;
+                    h[2 * ((size_t)nf8_img_A3H(wp) + ((m * 2 + m2) * 64 + l) * 4) + q] = cin < w ? to_half_w3(W3[((size_t)tap * w + cin) * 4 + j], j) : 0;
                 }
             }
         }
@@ -569,7 +590,7 @@ void relayout_coupling_gemm16(const float *v1, int w, int wp, float *out)
                     for (int r = 0; r < 4; ++r) {
                         const int cin = 32 * m + nf4_chan(4 * q4 + r, g);
                         h[2 * ((size_t)nf8_img_A3CH(wp) + ((m * 4 + q4) * 8 + g * 4 + j) * 2) + r] =
-                            cin < w ? to_half(W3[((size_t)8 * w + cin) * 4 + j]) : 0;
+                            cin < w ? to_half_w3(W3[((size_t)8 * w + cin) * 4 + j], j) : 0;
                     }
     }
 }
@@ -672,7 +693,7 @@ void relayout_coupling_wide32_fp16(const float *v1, int w, float *out)
                 const int cin = nf4_chan(8 * m + q, g);
                 h[2 * (NF5_IMG_A2H + (m * 64 + l) * 4) + q] = (cin < w && i < w) ? to_half(W2[cin * w + i]) : 0;
                 const int a = i >> 3, gp = (i >> 2) & 1, j = i & 3;
-                h[2 * (NF5_IMG_A3H + (m * 64 + l) * 4) + q] = cin < w ? to_half(W3[(tap_of[a][gp] * w + cin) * 4 + j]) : 0;
+                h[2 * (NF5_IMG_A3H + (m * 64 + l) * 4) + q] = cin < w ? to_half_w3(W3[(tap_of[a][gp] * w + cin) * 4 + j], j) : 0;
             }
         }
     }
@@ -687,7 +708,7 @@ void relayout_coupling_wide32_fp16(const float *v1, int w, float *out)
             for (int j = 0; j < 4; ++j)
                 for (int r = 0; r < 4; ++r) {
                     const int cin = nf4_chan(4 * q + r, g);
-                    h[2 * (NF5_IMG_A3CH + (q * 8 + g * 4 + j) * 2) + r] = cin < w ? to_half(W3[(4 * w + cin) * 4 + j]) : 0;   // centre tap
+                    h[2 * (NF5_IMG_A3CH + (q * 8 + g * 4 + j) * 2) + r] = cin < w ? to_half_w3(W3[(4 * w + cin) * 4 + j], j) : 0;   // centre tap
                 }
 }
 

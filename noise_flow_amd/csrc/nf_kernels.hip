@@ -256,6 +256,25 @@ __device__ __forceinline__ void nf_flow_body(const NfProgram &prog, const NfLaun
         }
     }
 
+    // The model image on its way to LDS: every lane's share is requested HERE, in one batch ahead of everything else (the copy loop
+    // at the end of the set-up was np4 / THREADS dependent round trips to L2 — 3 at 32x32 —, and requests issued behind the x / y
+    // touches below would make the stores wait for those HBM loads too: the counter retires loads in order); the stores follow the
+    // tile zeroing.  NF_WSTAGE 0: the old loop.
+#ifndef NF_WSTAGE
+#define NF_WSTAGE 1
+#endif
+    constexpr int WU = MFMA && NF_WSTAGE ? (THREADS >= 1024 ? 3 : 6) : 1;   // float4 per lane in the batch: NF11_MAX_FLOATS / NF2_MAX_FLOATS fit
+    [[maybe_unused]] float4 wreg[WU];
+    if constexpr (MFMA && NF_WSTAGE) {
+        const int np4 = a.n_params >> 2;
+        const float4 *const p4 = reinterpret_cast<const float4 *>(a.params);
+#pragma unroll
+        for (int u = 0; u < WU; ++u) {
+            const int i = t + u * THREADS;
+            wreg[u] = p4[i < np4 ? i : 0];
+        }
+    }
+
     // Touch the first patch's inputs before the LDS set-up below: with one patch per workgroup (B = the
     // resident capacity) every workgroup would otherwise sit through the set-up and THEN through the HBM
     // latency of its first loads, all at the same time.  The values are discarded; the real loads hit L2.
@@ -378,7 +397,16 @@ __device__ __forceinline__ void nf_flow_body(const NfProgram &prog, const NfLaun
             const int np4 = a.n_params >> 2;   // every section of the matrix-core layouts is a multiple of 4 floats
             const float4 *const p4 = reinterpret_cast<const float4 *>(a.params);
             float4 *const w4 = reinterpret_cast<float4 *>(wl);
-            for (int i = t; i < np4; i += THREADS) w4[i] = p4[i];
+            if constexpr (NF_WSTAGE) {
+#pragma unroll
+                for (int u = 0; u < WU; ++u) {
+                    const int i = t + u * THREADS;
+                    if (i < np4) w4[i] = wreg[u];
+                }
+                for (int i = t + WU * THREADS; i < np4; i += THREADS) w4[i] = p4[i];   // (beyond the batch: models that barely fit)
+            } else {
+                for (int i = t; i < np4; i += THREADS) w4[i] = p4[i];
+            }
             for (int i = (np4 << 2) + t; i < a.n_params; i += THREADS) wl[i] = a.params[i];
             if (t < 16) wl[ident_off + t] = (t >> 2) == (t & 3) ? 1.0f : 0.0f;
         }
@@ -582,8 +610,8 @@ __device__ __forceinline__ void nf_flow_body(const NfProgram &prog, const NfLaun
         [[maybe_unused]] int cpl_seen = 0;
 
         // Conv2d1x1 on the matrix cores: per-pixel z <- z @ M   (layers.py:108-124)
-        [[maybe_unused]] auto mix_mfma_at = [&](int moff) {
-            const float4 m = *reinterpret_cast<const float4 *>(wl + moff + 4 * j4);   // M[0..3][j4]
+        [[maybe_unused]] auto mix_load = [&](int moff) { return *reinterpret_cast<const float4 *>(wl + moff + 4 * j4); };   // M[0..3][j4]
+        [[maybe_unused]] auto mix_apply = [&](const float4 m) {
 #pragma unroll
             for (int k = 0; k < PX; ++k) {
                 v4f acc = {0.f, 0.f, 0.f, 0.f};
@@ -595,7 +623,7 @@ __device__ __forceinline__ void nf_flow_body(const NfProgram &prog, const NfLaun
                 for (int j = 0; j < 4; ++j) z[k][j] = acc[j];
             }
         };
-        [[maybe_unused]] auto mix_mfma = [&](int mop) { mix_mfma_at(prog.ops[mop].off); };
+        [[maybe_unused]] auto mix_mfma = [&](int mop) { mix_apply(mix_load(prog.ops[mop].off)); };
 
         // AffineCouplingSdnEx5 and its relatives: scale = sqrt(beta1*y/gain + beta2)  (cond_utils.py:238)
         auto sdn_apply = [&](int stype, int slot, const float4 (&yv)[PX]) {
@@ -699,12 +727,21 @@ __device__ __forceinline__ void nf_flow_body(const NfProgram &prog, const NfLaun
                 bool patch_done = false;
                 synced = true;   // every coupling passes barriers (the exchange of the pass-through half and of h2)
                 if constexpr (MFMA) op -= 2;
+                // NF_MIX_AHEAD 1: the mix matrix of a pair is read one coupling ahead (in front of the previous coupling's second
+                // barrier) instead of at the head of the loop body, where the read sits between the affine stage and the mix's first
+                // MFMA.  Measured neutral (fp32 32x32: 2.131e7 / 2.130e7; fp16 64x64 within the 1 % run-to-run band): left off
+#ifndef NF_MIX_AHEAD
+#define NF_MIX_AHEAD 0
+#endif
+                [[maybe_unused]] float4 mix_m = make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (MFMA) mix_m = mix_load(pr_moff);
 #pragma nounroll
                 for (int pr_i = 0; pr_i < pr_n; ++pr_i) {
                 if constexpr (MFMA) {
-                    mix_mfma_at(pr_moff);
+                    if (!NF_MIX_AHEAD) mix_m = mix_load(pr_moff);
+                    mix_apply(mix_m);
                     coff = pr_coff;
-                    pr_moff += pr_stride;
+                    pr_moff += pr_i + 1 < pr_n ? pr_stride : 0;   // (the last pair re-reads its own matrix: always inside the image)
                     pr_coff += pr_stride;
                     op += 2;
                 }
@@ -1041,6 +1078,7 @@ __device__ __forceinline__ void nf_flow_body(const NfProgram &prog, const NfLaun
                         if (stats_stage) stats_flush<WIDTH>(st1, st2, stats, t);
                     }
                 }
+                if constexpr (MFMA && NF_MIX_AHEAD) mix_m = mix_load(pr_moff);
                 __syncthreads();
                 if constexpr (BS) {
                     if (a.stats && op == a.stats_op && t < 8) {
@@ -1072,14 +1110,30 @@ __device__ __forceinline__ void nf_flow_body(const NfProgram &prog, const NfLaun
                             for (int k = 0; k < PX; ++k) hb_e[k] = *reinterpret_cast<const float4 *>(wb + NF11_CPL_E + 4 * bmask[k]);
                         }
                         const v8h a3a = hb_a3a, a3b = hb_a3b;
+                        // K slot of this lane: two adjacent window pixels x 4 channels = one aligned 16-byte read per instruction.
+                        // NF_HB_RDAHEAD units' reads are requested before the first matrix instruction.  Left to itself (0) the compiler
+                        // reads two operands, waits, multiplies, and only then reads the next two — four LDS latencies per phase;
+                        // requesting all eight first (4) needs the whole 128-register budget of a 16-wavefront workgroup and measured
+                        // SLOWER (same box, 64x64 fp16, B = 1 024: 1.226e7 against 1.258e7 patches/s; 2: 1.241e7): left at 0
+#ifndef NF_HB_RDAHEAD
+#define NF_HB_RDAHEAD 0
+#endif
+                        uint4 q0[PX], q1[PX];
+#pragma unroll
+                        for (int k = 0; k < PX && k < NF_HB_RDAHEAD; ++k) {
+                            q0[k] = *reinterpret_cast<const uint4 *>(thh + wbase3 + 2 * k * Wp);
+                            q1[k] = *reinterpret_cast<const uint4 *>(thh + wbase3 + (2 * k + 1) * Wp);
+                        }
+                        if (NF_HB_RDAHEAD) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int k = 0; k < PX; ++k) {
                             const float4 e = hb_e[k];
-                            // K slot of this lane: two adjacent window pixels x 4 channels = one aligned 16-byte read per instruction
-                            const uint4 q0 = *reinterpret_cast<const uint4 *>(thh + wbase3 + 2 * k * Wp);
-                            const uint4 q1 = *reinterpret_cast<const uint4 *>(thh + wbase3 + (2 * k + 1) * Wp);
-                            v4f acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a3a, __builtin_bit_cast(v8h, q0), v4f{e.x, e.y, e.z, e.w}, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a3b, __builtin_bit_cast(v8h, q1), acc, 0, 0, 0);
+                            if (k >= NF_HB_RDAHEAD) {
+                                q0[k] = *reinterpret_cast<const uint4 *>(thh + wbase3 + 2 * k * Wp);
+                                q1[k] = *reinterpret_cast<const uint4 *>(thh + wbase3 + (2 * k + 1) * Wp);
+                            }
+                            v4f acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a3a, __builtin_bit_cast(v8h, q0[k]), v4f{e.x, e.y, e.z, e.w}, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a3b, __builtin_bit_cast(v8h, q1[k]), acc, 0, 0, 0);
 #pragma unroll
                             for (int j = 0; j < 4; ++j) o[k][j] = acc[j];
                         }
@@ -1231,21 +1285,11 @@ __device__ __forceinline__ void nf_flow_body(const NfProgram &prog, const NfLaun
                     }
                     // shift = o[0:2], raw log-scale = o[2:4]  (tf.split, layers.py:494)
                     if constexpr (MFMA) {
-                        // matrix-core layout: the host pre-scaled the raw columns by 2*log2(e), so
+                        // matrix-core layouts (fp32 and fp16-CNN alike): the host pre-scaled the raw columns by 2*log2(e), so
                         //   t = exp2(raw') = exp(2 raw);  ls*log2(e) = scl*tanh(raw) = scl - 2 scl/(t + 1)
                         // and the log-det is accumulated in log2 units (ld2), converted once per patch.
                         const float scl = wl[coff + NF2_CPL_S + 1];     // (NF3_CPL_S == NF2_CPL_S)
                         const float m2scl = wl[coff + NF2_CPL_S + 2];
-#ifndef NF_X_NOK2   // (timing experiment only: -DNF_X_NOK2 drops the scaling and with it the right answer)
-#define NF_X_NOK2 0
-#endif
-                        if constexpr (HALF && !NF_X_NOK2) {
-#pragma unroll
-                            for (int k = 0; k < PX; ++k) {
-                                o[k][2] *= 2.8853900817779268f;   // fp16 weights are not pre-scaled by 2*log2(e)
-                                o[k][3] *= 2.8853900817779268f;
-                            }
-                        }
                         if (type == NF_OP_COUPLING_FWD) {
 #pragma unroll
                             for (int k = 0; k < PX; ++k) {

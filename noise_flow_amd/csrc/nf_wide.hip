@@ -469,13 +469,7 @@ __device__ __forceinline__ void nf_wide32_body(const NfProgram &prog, const NfLa
                     const bool own = r < H && col_own && R >= cy0 && R < cy1;
                     const int bm = (R == 0 ? 1 : 0) | (R == IH - 1 ? 2 : 0) | cmask;
                     const float4 eb = *reinterpret_cast<const float4 *>(wblk + NF4_CPL_E + 4 * (act ? bm : 0));
-                    if constexpr (H16) {   // fp16 weights are not pre-scaled (their rounding points are the oracle's); the table is
-                        o[0] += eb.x; o[1] += eb.y;
-                        o[2] = fmaf(o[2], 2.8853900817779268f, eb.z);
-                        o[3] = fmaf(o[3], 2.8853900817779268f, eb.w);
-                    } else {
-                        o[0] += eb.x; o[1] += eb.y; o[2] += eb.z; o[3] += eb.w;
-                    }
+                    o[0] += eb.x; o[1] += eb.y; o[2] += eb.z; o[3] += eb.w;   // (fp16 layouts too: 2 log2(e) sits inside the rounded weights)
                     // raw columns are pre-scaled by 2 log2(e):  t = exp2(raw') = exp(2 raw);
                     // ls*log2(e) = scl*tanh(raw) = scl - 2 scl/(t + 1); log-det accumulated in log2 units
                     const float l0 = fmaf(__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(o[2]) + 1.0f), m2scl, scl);

@@ -252,7 +252,8 @@ def coupling_cnn_fp16(z0: np.ndarray, p: Dict[str, np.ndarray]):
     """The coupling CNN as the HIP library's fp16 mode evaluates it (BASELINE configs[4]:
     "fp16 coupling CNN with fp32 log-det accumulate"): BN-eval and exp(3*logs) are folded
     into the conv weights FIRST (as csrc/nf_host.hip does), then the folded weights and the
-    three CNN inputs (z0, relu(h1), relu(h2)) are rounded to fp16; biases, the border table
+    three CNN inputs (z0, relu(h1), relu(h2)) are rounded to fp16 (the raw half of l_last's output channels
+    after one more fold, see below); biases, the border table
     and every accumulation stay in fp32 (here: the working dtype).  Same math as
     :func:`coupling_cnn` when nothing is rounded."""
     dt = z0.dtype.type
@@ -267,6 +268,11 @@ def coupling_cnn_fp16(z0: np.ndarray, p: Dict[str, np.ndarray]):
     W3 = p["l_last/W"] * es
     W3h = W3.copy()
     W3h[:, :, :w, :] = _h(W3[:, :, :w, :])                       # activations x fp16 weights ...
+    # ... the raw (log-scale) half of the output channels carries the 2*log2(e) of tanh's  t = exp2(2 log2(e) raw)  inside the
+    # rounded weight (csrc/nf_host.hip::to_half_w3: folded BEFORE the rounding, like the BN scale and exp(3 logs))
+    c2o = W3.shape[-1] // 2
+    k2 = dt(2.0 * 1.4426950408889634)
+    W3h[:, :, :w, c2o:] = _h(W3[:, :, :w, c2o:] * k2) / k2
     h = np.maximum(conv2d_nhwc(_h(z0), W1, True) + b1, dt(0))
     h = np.maximum(conv2d_nhwc(_h(h), W2, True) + b2, dt(0))
     hp = add_edge_padding(_h(h))                                 # ... the edge channel stays exact (fp32 table)

@@ -457,6 +457,8 @@ def test_fp16_big_mfma_layout_emulated_lane_by_lane_matches_the_oracle_cnn(side)
     W2h = halves(off + 76, 8).reshape(4, 4)                 # [j][i]
     A1 = halves(off + 84, 256).reshape(64, 8)
     A3 = halves(off + 340, 512).reshape(2, 64, 8)
+    A2 = halves(off + 852, 512).reshape(2, 64, 8) if side == 64 else None   # NF11_CPL_A2: l_2 on the same instruction (64x64 layouts)
+    K2 = 2.0 * 1.4426950408889634   # the raw output channels come out pre-scaled by 2 log2(e) (inside the rounded weights / the table)
     Wp = 80 if side == 64 else 48
     l1_row = lambda g: 2 * (g & 1) + (g >> 1)
     l3_row = lambda g, m3: 2 * (g & 1) + m3
@@ -472,6 +474,7 @@ def test_fp16_big_mfma_layout_emulated_lane_by_lane_matches_the_oracle_cnn(side)
     for phase in (0, 1):
         for wv in range(n_waves):
             q, band = (wv & 1, wv >> 1) if side == 64 else (0, wv)
+            r1_of = {}
             for k in range(4):
                 lanes = range(64)
                 g = [l >> 4 for l in lanes]; n = [l & 15 for l in lanes]
@@ -485,10 +488,26 @@ def test_fp16_big_mfma_layout_emulated_lane_by_lane_matches_the_oracle_cnn(side)
                         Bop[l] = t0h[base:base + 4].reshape(-1)
                     d = _mfma_16x16x32(A1, Bop, np.repeat(B1[:, None], 64, 1))
                     r1 = h16(np.maximum(d, 0))
-                    h2 = B2[:, None] + W2h @ r1                 # 4x4x4: D[j][pixel] = sum_i W2h[j][i] r1[i][pixel]
-                    r2 = h16(np.maximum(h2, 0))
+                    r1_of[k] = r1
+                    if A2 is None:
+                        h2 = B2[:, None] + W2h @ r1                 # 4x4x4: D[j][pixel] = sum_i W2h[j][i] r1[i][pixel]
+                    elif k & 1:
+                        # units k - 1 and k share ONE B operand: the lane's two pixels, 8 halves; the A operand picks the unit
+                        Bop = np.concatenate([r1_of[k - 1].T, r1_of[k].T], axis=1)
+                        pair = [_mfma_16x16x32(A2[half], Bop, np.repeat(B2[:, None], 64, 1)) for half in (0, 1)]
+                        # unit k - 1's rows were visited one trip ago: store them now
+                        rr0 = [band * 8 + 2 * (k - 1) + (g[l] >> 1) for l in lanes]
+                        r2 = h16(np.maximum(pair[0], 0))
+                        for l in lanes:
+                            thh[(rr0[l] + 1) * Wp + cc[l] + 1] = r2[:, l]
+                        h2 = pair[1]
+                    else:
+                        h2 = None
+                    if h2 is not None:
+                        r2 = h16(np.maximum(h2, 0))
+                        for l in lanes:
+                            thh[lidx[l]] = r2[:, l]
                     for l in lanes:
-                        thh[lidx[l]] = r2[:, l]
                         assert (rr[l], cc[l]) not in own
                         own[(rr[l], cc[l])] = 1
                 else:
@@ -507,7 +526,7 @@ def test_fp16_big_mfma_layout_emulated_lane_by_lane_matches_the_oracle_cnn(side)
     assert len(own) == side * side
     cp = [L["p"] for L in O.bind_variables(arch, v) if L["type"] == "coupling"][0]
     shift, raw = O.coupling_cnn_fp16(z0[None], cp)
-    ref = np.concatenate([shift[0], raw[0]], -1)
+    ref = np.concatenate([shift[0], raw[0] * K2], -1)
     assert np.abs(o - ref).max() <= 1e-5 * np.abs(ref).max(), np.abs(o - ref).max() / np.abs(ref).max()
 
 
