@@ -41,6 +41,16 @@
 // loads in it, 4 = no LDS writes in it, 8 = every pixel tile reads tile 0 of A (cache hits), 16 = no B loads, 32 = no A loads, 64 = no epilogue, 128 = every load hits one L1-resident 4 KiB
 #define MM_ABL 0
 #endif
+#ifndef MM_DEFAULT_MODE
+#define MM_DEFAULT_MODE 2   // pix_mode() without NF_MM_MODE in the environment
+#endif
+#ifndef MM_INTERLEAVE
+// bf16 x 6: N VALU instructions of the next tile's prologue + split scheduled behind each matrix instruction of a tile's second K = 16
+// step (sched_group_barrier), 0: prologue + split behind the tile's last matrix instruction.  Measured (width 512, 141 312 pixels, 4
+// wavefronts): 6 -> plain 394 us, l_2 forward 453, its transpose 647 (48 more live registers: the epilogue variants spill into AGPRs);
+// 0 -> 381 / 466 / 437.  Left at 0.
+#define MM_INTERLEAVE 0
+#endif
 #ifndef MM_KREP
 #define MM_KREP 1   // with MM_ABL 7: the K loop runs this many times (loop time apart from the tile boundaries)
 #endif
@@ -92,12 +102,36 @@ __device__ __forceinline__ float4 row4(const float *row, int at, int n)
     }
 }
 
-// floats of LDS k_mm_pix shares between its operand tiles (2 x 8 x (129 + BN + 1) float4), the finished tile on its way out
-// ([128][BN + 4]) and the final sums
-constexpr int pix_region0_floats(int BN)
+// pixels per tile of k_mm_pix by workgroup size (4 or 8 wavefronts)
+constexpr int pix_bm(int NW) { return NW == 8 ? 256 : kBM; }
+
+// floats of LDS k_mm_pix shares between its operand tiles (fp32: 2 x 8 x (BM + 1 + BN + 1) float4; bf16 x 6: 2 x 12 x (BM + 2 + BN + 2)
+// 16-byte units), the finished tile on its way out ([BM][BN + 4]) and the final sums
+constexpr int pix_region0_floats(int BN, int BM = kBM, int prec = 0)
 {
-    const int ops = 2 * 8 * (kBM + 1 + BN + 1) * 4, out = kBM * (BN + 4);
+    const int nbuf = prec && BM == kBM ? 1 : 2;   // (bf16 x 6 on 4 wavefronts: one operand buffer, see k_mm_pix)
+    const int ops = prec ? nbuf * 12 * (BM + 2 + BN + 2) * 4 : 2 * 8 * (BM + 1 + BN + 1) * 4, out = BM * (BN + 4);
     return ops > out ? ops : out;
+}
+
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
+
+// v = v1 + v2 + v3 per element, each part a bf16 (round to nearest even), packed 4 to a uint2 per part
+__device__ __forceinline__ void split_bf16x3(const float4 v, uint2 (&pl)[3])
+{
+    float r[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const v2bf h01 = {(__bf16)r[0], (__bf16)r[1]}, h23 = {(__bf16)r[2], (__bf16)r[3]};
+        pl[q] = make_uint2(__builtin_bit_cast(uint32_t, h01), __builtin_bit_cast(uint32_t, h23));
+        if (q < 2) {
+            r[0] -= (float)h01[0];
+            r[1] -= (float)h01[1];
+            r[2] -= (float)h23[0];
+            r[3] -= (float)h23[1];
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -120,8 +154,16 @@ struct PixArgs {
     int n_tiles, m_tiles;
 };
 
-//   WN     wavefronts along the channel axis (1 or 2); 4 / WN along the pixel axis
-//   TN     32-channel tiles per wavefront: the workgroup's tile is 128 pixels x (32 WN TN) channels
+//   WN     wavefronts along the channel axis (1 or 2); NW / WN along the pixel axis
+//   TN     32-channel tiles per wavefront: the workgroup's tile is BM pixels x (32 WN TN) channels
+//   NW     wavefronts per workgroup: 4 (BM = 128 pixels, two workgroups per CU) or 8 (BM = 256, one per CU: 25 % fewer operand bytes per
+//          flop through the staging path — the tile DESIGN.md §4.7's ablation asked for)
+//   PREC   0: exact fp32 products on v_mfma_f32_32x32x2_f32.
+//          1: "bf16 x 6" on v_mfma_f32_32x32x16_bf16 — every operand element is split while its tile is staged into three bf16 numbers
+//             a = a1 + a2 + a3 (round-to-nearest each: |a - a1 - a2 - a3| <= 2^-27 |a|), and a b is taken as the six exact products
+//             a1 b1 + (a1 b2 + a2 b1) + (a1 b3 + a2 b2 + a3 b1), added in fp32 smallest first; the three dropped products are
+//             <= 2^-26 |a b| together — a quarter of the rounding of ONE fp32 product — so the result carries fp32 round-off, not bf16's.
+//             6 matrix instructions of 32 cycles per 32 x 32 x 16 block instead of 8 of 64: 2.67 x the fp32 matrix rate.
 //   APRO   0: A as stored;  1: A = relu(xhat(A + bias));  2: A = BN backward of (A masked by xhat(A2) > 0)
 //   EPI    0: store;  1: + batch sums of C + bias;  2: + masked batch sums against xhat(eh);  4: those sums WITHOUT the store;
 //          3: store BN backward of the masked C (the batch means are known: second pass over a cheap product) + its column sums
@@ -129,17 +171,28 @@ struct PixArgs {
 //   CV     4: C (and eh) rows are 16-byte aligned and N % 4 == 0: the tile leaves through LDS as whole 16-byte pieces of its rows
 //          (one global_store_dwordx4 / global_load_dwordx4 per 4 channels, 512 contiguous bytes per 32 lanes);  1: D registers
 //          straight to memory, 4 bytes per lane
-template <int WN, int TN, int APRO, int EPI, int AV, int CV>
-__global__ __launch_bounds__(kT) void k_mm_pix(const PixArgs a)
+template <int WN, int TN, int APRO, int EPI, int AV, int CV, int NW = 4, int PREC = 0>
+__global__ __launch_bounds__(64 * NW) void k_mm_pix(const PixArgs a)
 {
-    constexpr int WM = 4 / WN, TM = kBM / (32 * WM), BN = WN * TN * 32;
-    constexpr int AP = kBM + 1, BP = BN + 1;   // float4 units per k4 row
-    constexpr int NB = BN / 32;                // B-tile float4s per thread
+    constexpr int kT = 64 * NW, kBM = pix_bm(NW);
+    constexpr int WM = NW / WN, TM = kBM / (32 * WM), BN = WN * TN * 32;
+    constexpr int SR8 = kT / 8;                // rows one staging pass covers (a thread stages 4 consecutive k of a row)
+    constexpr int NA = kBM / SR8;              // A-tile float4s per thread
+    constexpr int NB = BN / SR8;               // B-tile float4s per thread
+    static_assert(NA == 4 && NB >= 1 && TM >= 1, "tile / workgroup shape");
+    // PREC 0: float4 units per k4 row (odd pitch).  PREC 1: 16-byte units (8 bf16 = one lane's operand of a K = 16 step) per
+    // (plane, k8 group) row — pitch = 2 mod 8 units keeps the 8-byte staging stores of a 16-lane group on distinct banks
+    constexpr int AP = PREC ? kBM + 2 : kBM + 1, BP = PREC ? BN + 2 : BN + 1;
     extern __shared__ __attribute__((aligned(16))) float mm_smem[];
     constexpr int SP = BN + 4;                 // row pitch (floats) of the tile on its way out (CV 4)
-    constexpr int R0 = pix_region0_floats(BN); // the operand tiles; between two K loops the finished tile [128][SP]; at the end the sums
-    float4 *const sA = reinterpret_cast<float4 *>(mm_smem);   // [2][8][AP]
-    float4 *const sB = sA + 2 * 8 * AP;                        // [2][8][BP]
+    constexpr int R0 = pix_region0_floats(BN, kBM, PREC); // the operand tiles; between two K loops the finished tile [BM][SP]; at the end the sums
+    constexpr int KG = PREC ? 12 : 8;          // rows of AP / BP units per buffer: 8 k4 groups, or 3 planes x 4 k8 groups
+    // bf16 x 6 on 4 wavefronts: ONE operand buffer (50 KiB; two would leave one 4-wavefront workgroup per CU) and two barriers per K
+    // tile — two workgroups per CU cover each other's barriers and epilogues, as the fp32 kernel's do
+    constexpr bool SB = PREC == 1 && NW == 4;
+    constexpr int NBUF = SB ? 1 : 2;
+    float4 *const sA = reinterpret_cast<float4 *>(mm_smem);   // [NBUF][KG][AP]
+    float4 *const sB = sA + NBUF * KG * AP;                    // [NBUF][KG][BP]
     float *const stg = mm_smem;                                // [kBM][SP]
     float *const red = mm_smem;                                // [2][WM or kT / (BN / 4)][BN]
     float *const cst = mm_smem + R0;                           // APRO 1: [2][Kc] (rstd, c = (bias - mean) rstd); APRO 2: [4][Kc] (+ ba, bq)
@@ -152,7 +205,7 @@ __global__ __launch_bounds__(kT) void k_mm_pix(const PixArgs a)
 
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, n = lane & 31, g = lane >> 5;
     const int wm = wv / WN, wn = wv % WN;
-    const int j = tid & 7, r0 = tid >> 3;      // staging: k4 group j of the rows r0 + 32 i
+    const int j = tid & 7, r0 = tid >> 3;      // staging: k4 group j of the rows r0 + SR8 i
     const int n0 = nt * BN;
 
     // (Measured and dropped: starting the second workgroup of every CU half a tile late, so that one's epilogue falls into the
@@ -194,7 +247,7 @@ __global__ __launch_bounds__(kT) void k_mm_pix(const PixArgs a)
     float bmask[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-        const int r = r0 + 32 * i;
+        const int r = r0 + SR8 * i;
         bmask[i] = n0 + r < a.N ? 1.0f : 0.0f;
         boff[i] = (MM_ABL & 128) ? (uint32_t)(tid * 16) : (uint32_t)((n0 + r < a.N ? r : 0) * a.ldb + 4 * j) * 4u;
     }
@@ -218,7 +271,7 @@ __global__ __launch_bounds__(kT) void k_mm_pix(const PixArgs a)
         if constexpr (APRO == 2) hbase = a.A2 + m0 * a.lda;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            int r = r0 + 32 * i;
+            int r = r0 + SR8 * i;
             r = m0 + r < a.P ? r : (int)(a.P - 1 - m0);   // rows past the end: loaded (valid memory), never stored nor summed
             aoff[i] = (MM_ABL & 128) ? (uint32_t)(tid * 16) : (uint32_t)(r * a.lda + 4 * j) * 4u;
         }
@@ -259,7 +312,13 @@ __global__ __launch_bounds__(kT) void k_mm_pix(const PixArgs a)
             for (int i = 0; i < NB; ++i) R.rb[i] = k < a.ldb ? ld4(at(bk, boff[i])) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    auto park = [&](int kt, int buf, Stage &R) {
+    // PREC 1: the staged operands split into their three bf16 parts (registers), between the prologue and the LDS stores — pure VALU
+    // work that `compute` interleaves with the matrix instructions of the tile before
+    struct Parts {
+        uint2 a[PREC ? 4 : 1][3], b[PREC ? NB : 1][3];
+    };
+    [[maybe_unused]] Parts PK;
+    auto prologue = [&](int kt, Stage &R) {
         if constexpr (APRO == 1) {
             const int k = kt * kBK + 4 * j;
             const float4 cr = ld4(cst + k), cc = ld4(cst + Kc + k);
@@ -281,16 +340,42 @@ __global__ __launch_bounds__(kT) void k_mm_pix(const PixArgs a)
                 R.ra[i].w = bn_bwd(R.ra[i].w, R.rh[i].w, cr.w, cc.w, ca.w, cq.w);
             }
         }
+        if constexpr (PREC == 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) split_bf16x3(R.ra[i], PK.a[i]);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                float4 v = R.rb[i];
+                if (bragged) v = make_float4(v.x * bmask[i], v.y * bmask[i], v.z * bmask[i], v.w * bmask[i]);
+                split_bf16x3(v, PK.b[i]);
+            }
+        }
+    };
+    auto store = [&](int buf, Stage &R) {
+        if constexpr (PREC == 1) {
+            // plane p, k8 group j >> 1, row, half j & 1 of the 16-byte unit: one 8-byte store per plane and staged float4
+            uint2 *da = reinterpret_cast<uint2 *>(sA + (buf * KG + (j >> 1)) * AP + r0) + (j & 1);
+            uint2 *db = reinterpret_cast<uint2 *>(sB + (buf * KG + (j >> 1)) * BP + r0) + (j & 1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) da[2 * ((q * 4) * AP + SR8 * i)] = PK.a[i][q];
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) db[2 * ((q * 4) * BP + SR8 * i)] = PK.b[i][q];
+        } else {
         float4 *da = sA + (buf * 8 + j) * AP + r0, *db = sB + (buf * 8 + j) * BP + r0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) da[32 * i] = R.ra[i];
+        for (int i = 0; i < 4; ++i) da[SR8 * i] = R.ra[i];
         if (bragged) {
 #pragma unroll
             for (int i = 0; i < NB; ++i)
-                db[32 * i] = make_float4(R.rb[i].x * bmask[i], R.rb[i].y * bmask[i], R.rb[i].z * bmask[i], R.rb[i].w * bmask[i]);
+                db[SR8 * i] = make_float4(R.rb[i].x * bmask[i], R.rb[i].y * bmask[i], R.rb[i].z * bmask[i], R.rb[i].w * bmask[i]);
         } else {
 #pragma unroll
-            for (int i = 0; i < NB; ++i) db[32 * i] = R.rb[i];
+            for (int i = 0; i < NB; ++i) db[SR8 * i] = R.rb[i];
+        }
         }
     };
     for (int64_t mt = ms; mt < a.m_tiles; mt += a.gm) {
@@ -310,7 +395,47 @@ __global__ __launch_bounds__(kT) void k_mm_pix(const PixArgs a)
         // also waits for the prefetched operands at every join).  Operand registers in ping-pong: the LDS reads of chunk c + 1 are
         // ISSUED before the 16 MFMAs of chunk c (left alone, the machine scheduler sinks them to just before their first use and
         // every chunk starts with an exposed LDS round trip)
-        auto compute = [&](int buf) {
+        // `next`: the K tile whose staged operands (already in SR) get their prologue + split between this tile's matrix instructions
+        auto compute = [&](int buf, int next) {
+            if constexpr (PREC == 1) {
+                // K = 16 step s: lane half g holds the 8 k of k8 group 2 s + g of its row — in each of the three planes
+                const float4 *pa = sA + (buf * KG + g) * AP + wm * TM * 32 + n;
+                const float4 *pb = sB + (buf * KG + g) * BP + wn * TN * 32 + n;
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    v8bf af[3][TM], bf[3][TN];
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+#pragma unroll
+                        for (int tm = 0; tm < TM; ++tm) af[q][tm] = __builtin_bit_cast(v8bf, pa[(q * 4 + 2 * st) * AP + tm * 32]);
+#pragma unroll
+                        for (int tn = 0; tn < TN; ++tn) bf[q][tn] = __builtin_bit_cast(v8bf, pb[(q * 4 + 2 * st) * BP + tn * 32]);
+                    }
+                    // the next tile's operands arrived while step 0 ran: their prologue and split are VALU work for the 28 idle issue
+                    // cycles behind every matrix instruction of step 1 (left in front of the LDS stores they would run with the matrix pipe idle)
+                    if (MM_INTERLEAVE && st == 1 && next >= 0) prologue(next, SR);
+                    // smallest products first: (a1 b3, a3 b1, a2 b2), (a1 b2, a2 b1), a1 b1
+                    constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+                    for (int t6 = 0; t6 < 6; ++t6)
+#pragma unroll
+                        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                            for (int tn = 0; tn < TN; ++tn)
+                                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[t6]][tm], bf[PB[t6]][tn], acc[tm][tn], 0, 0, 0);
+#if MM_INTERLEAVE
+                    if (st == 1 && next >= 0) {
+#pragma unroll
+                        for (int t6 = 0; t6 < 6 * TM * TN; ++t6) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              // one matrix instruction
+                            __builtin_amdgcn_sched_group_barrier(0x002, MM_INTERLEAVE, 0);  // ... then VALU of the split
+                        }
+                    }
+#endif
+                }
+                if (!MM_INTERLEAVE && next >= 0) prologue(next, SR);
+                return;
+            }
             const float4 *pa = sA + (buf * 8 + g) * AP + wm * TM * 32 + n;
             const float4 *pb = sB + (buf * 8 + g) * BP + wn * TN * 32 + n;
             float4 af[2][TM], bf[2][TN];
@@ -336,15 +461,19 @@ __global__ __launch_bounds__(kT) void k_mm_pix(const PixArgs a)
                             acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4c(af[c & 1][tm], s), f4c(bf[c & 1][tn], s), acc[tm][tn], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (next >= 0) prologue(next, SR);   // (fp32: behind the matrix instructions, where it always was)
         };
 
-        park(0, 0, SR);
+        prologue(0, SR);
+        store(0, SR);
         __syncthreads();
         for (int kt = 0; kt < nkt * MM_KREP; ++kt) {
-            const int buf = kt & 1;
-            if (kt + 1 < nkt && !(MM_ABL & 2)) fetch(kt + 1, SR);
-            compute(buf);
-            if (kt + 1 < nkt && !(MM_ABL & 4)) park(kt + 1, buf ^ 1, SR);
+            const int buf = SB ? 0 : kt & 1;
+            const bool more = kt + 1 < nkt;
+            if (more && !(MM_ABL & 2)) fetch(kt + 1, SR);
+            compute(buf, more && !(MM_ABL & 4) ? kt + 1 : -1);
+            if constexpr (SB) __syncthreads();   // every wavefront has read the tile
+            if (more && !(MM_ABL & 4)) store(SB ? 0 : buf ^ 1, SR);
             if (!(MM_ABL & 1)) __syncthreads();
         }
 
@@ -535,11 +664,11 @@ __global__ __launch_bounds__(kT) void k_mm_pix(const PixArgs a)
     }
 }
 
-template <int WN, int TN>
+template <int WN, int TN, int NW = 4, int PREC = 0>
 constexpr size_t pix_lds_bytes(int K, int apro)
 {
     constexpr int BN = WN * TN * 32;
-    return ((size_t)pix_region0_floats(BN) + (apro == 2 ? 4 : apro ? 2 : 0) * (size_t)((K + kBK - 1) / kBK * kBK)) * sizeof(float);
+    return ((size_t)pix_region0_floats(BN, pix_bm(NW), PREC) + (apro == 2 ? 4 : apro ? 2 : 0) * (size_t)((K + kBK - 1) / kBK * kBK)) * sizeof(float);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -914,35 +1043,52 @@ inline bool mm_enable_lds(const void *fn, size_t lds, int device, std::atomic<si
 }
 
 // C[P x N] = pro(A) . Bt^T with the prologue / epilogue of the template (nf_train_mm.h); `a` carries everything but the work split
-template <int WN, int TN, int APRO, int EPI, int AV, int CV>
+template <int WN, int TN, int APRO, int EPI, int AV, int CV, int NW = 4, int PREC = 0>
 inline bool mm_pix_launch(const Ctx &cx, hipStream_t st, PixArgs a)
 {
-    constexpr int BN = WN * TN * 32;
+    constexpr int BN = WN * TN * 32, BM = pix_bm(NW);
     a.n_tiles = (a.N + BN - 1) / BN;
-    a.m_tiles = (int)((a.P + kBM - 1) / kBM);
+    a.m_tiles = (int)((a.P + BM - 1) / BM);
     // without batch sums: one workgroup per tile, the dispatcher balances (persistent workgroups, 2 or 4 per CU: measured, no difference).  With them: one SLOT per workgroup, each walking its
     // share of the pixel tiles — two workgroups per CU in flight
     int gm = a.m_tiles;
     if (EPI != 0) {
         // (measured: 3 or 4 per CU lose 2 - 5 % at widths 64 - 256; so does trimming the count to the fewest workgroups with the same
         // longest share — 368 instead of 512 at width 128 leave the CUs unevenly filled: 4.53 vs 4.33 ms per step)
-        const int want = std::max(1, 2 * cx.n_cu / a.n_tiles);
+        const int want = std::max(1, (NW == 8 ? 1 : 2) * cx.n_cu / a.n_tiles);
         gm = std::max(1, std::min(std::min(a.nslot, a.m_tiles), want));
     }
     a.gm = gm;
-    const size_t lds = pix_lds_bytes<WN, TN>(a.K, APRO);
-    auto fn = &k_mm_pix<WN, TN, APRO, EPI, AV, CV>;
+    const size_t lds = pix_lds_bytes<WN, TN, NW, PREC>(a.K, APRO);
+    auto fn = &k_mm_pix<WN, TN, APRO, EPI, AV, CV, NW, PREC>;
     static std::atomic<size_t> enabled[16];
     if (!mm_enable_lds(reinterpret_cast<const void *>(fn), lds, cx.device, enabled)) return false;
     const unsigned grid = (unsigned)((gm + 7) / 8 * 8 * a.n_tiles);
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(kT), lds, st, a);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * NW), lds, st, a);
     return true;
+}
+
+// How the 128-column products (widths beyond 64: the l_2 products) run.  0: fp32, 4 wavefronts on 128 x 128 (two workgroups per CU);
+// 1: fp32, 8 wavefronts on 256 x 128; 2: bf16 x 6 (k_mm_pix, PREC 1), 8 wavefronts on 256 x 128; 3: bf16 x 6, 4 wavefronts on 128 x 128, one
+// operand buffer.  NF_MM_MODE overrides (A/B aid, read once).
+inline int pix_mode(int64_t P, int n_cu)
+{
+    static const int forced = [] { const char *e = getenv("NF_MM_MODE"); return e ? atoi(e) : -1; }();
+    if (forced >= 0) return forced;                                       // (every size: the probe checks small products this way)
+    if (MM_DEFAULT_MODE == 1 || MM_DEFAULT_MODE == 2) return P >= (int64_t)pix_bm(8) * n_cu / 2 ? MM_DEFAULT_MODE : 0;   // 256-pixel tiles want enough of them to fill the chip
+    return MM_DEFAULT_MODE;
 }
 // the tile width follows the channel count: 128 / 64 / 32 columns
 template <int APRO, int EPI, int AV, int CV>
 inline bool mm_pix_cv(const Ctx &cx, hipStream_t st, const PixArgs &a)
 {
-    if (a.N > 64) return mm_pix_launch<2, 2, APRO, EPI, AV, CV>(cx, st, a);
+    if (a.N > 64) {
+        const int mode = pix_mode(a.P, cx.n_cu);
+        if (mode == 3) return mm_pix_launch<2, 2, APRO, EPI, AV, CV, 4, 1>(cx, st, a);
+        if (mode == 2) return mm_pix_launch<2, 2, APRO, EPI, AV, CV, 8, 1>(cx, st, a);
+        if (mode == 1) return mm_pix_launch<2, 2, APRO, EPI, AV, CV, 8, 0>(cx, st, a);
+        return mm_pix_launch<2, 2, APRO, EPI, AV, CV>(cx, st, a);
+    }
     if (a.N > 32) return mm_pix_launch<1, 2, APRO, EPI, AV, CV>(cx, st, a);
     return mm_pix_launch<1, 1, APRO, EPI, AV, CV>(cx, st, a);
 }
