@@ -996,6 +996,154 @@ __global__ __launch_bounds__(kT) void k_mm_kpix(const KpixArgs a)
     }
 }
 
+// k_mm_kpix at M, N multiples of 4 on the bf16 matrix pipe ("bf16 x 6", see k_mm_pix PREC 1): part[s][m][n] = sum over the pixels of
+// chunk s of pro(A)[pixel][m] B[pixel][n] with the error of fp32 products.  128 x 128 channels per workgroup (4 wavefronts, 2 x 2
+// tiles of 32 x 32 each), 32 pixels per staged tile, ONE operand buffer (50 KiB: two workgroups per CU cover each other's barriers).
+// The reduction index is the pixel, which is the SLOW index of both operands in memory: a staging thread therefore takes 4 channels
+// x 8 consecutive pixels (8 x 16-byte loads, 512 contiguous bytes per 32 lanes each), so that after the split it holds, per channel
+// and part, exactly one lane operand of a K = 16 step (8 bf16 of consecutive pixels = 16 bytes) and stores it with ds_write_b128
+// into k_mm_pix's layout [part][k8 group][row][16 B].  Channel 4 q + c of a tile sits in LDS row 32 c + q (consecutive lanes ->
+// consecutive rows: conflict-free stores), i.e. the 32 x 32 accumulator tile c of a wavefront holds the channels = c (mod 4).
+//   APRO  0: A as stored;  1: A = relu(xhat(A + bias))
+template <int APRO>
+__global__ __launch_bounds__(kT) void k_mm_kpix6(const KpixArgs a)
+{
+    constexpr int BM = 128, BN = 128, AP = BM + 2, BP = BN + 2, KG = 12;
+    extern __shared__ __attribute__((aligned(16))) float mm_smem[];
+    float4 *const sA = reinterpret_cast<float4 *>(mm_smem);   // [KG][AP]
+    float4 *const sB = sA + KG * AP;                           // [KG][BP]
+    const int tiles = a.m_tiles * a.n_tiles;
+    const int id = blockIdx.x, xcd = id & 7, q = id >> 3;
+    const int tile = q % tiles, s = (q / tiles) * 8 + xcd;   // the tiles of one pixel chunk share an XCD
+    if (s >= a.S) return;
+    const int m0 = (tile / a.n_tiles) * BM, n0 = (tile % a.n_tiles) * BN;
+    const int64_t p0 = (int64_t)s * a.chunk, p1 = p0 + a.chunk < a.npix ? p0 + a.chunk : a.npix;
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, n = lane & 31, g = lane >> 5;
+    const int wm = wv >> 1, wn = wv & 1;
+    // staging task of this thread: operand (A: threads 0 .. 127, B: 128 .. 255), channel quad cq, k8 group kg
+    const bool isA = tid < 128;
+    const int cq = tid & 31, kg = (tid >> 5) & 3;
+    const int ch = (isA ? m0 : n0) + 4 * cq;
+    const bool ch_ok = ch < (isA ? a.M : a.N);                // (widths are multiples of 4: the whole quad exists or none of it)
+    const float *const src = isA ? a.A : a.B;
+    const int ld = isA ? a.lda : a.ldb;
+    float4 cr = make_float4(0.f, 0.f, 0.f, 0.f), cc = cr;
+    if constexpr (APRO == 1) {
+        if (isA && ch_ok) {
+            cr = ld4u(a.abn + a.M + ch);
+            const float4 mb = ld4u(a.abias + ch), mm_ = ld4u(a.abn + ch);
+            cc = make_float4(xhat_c(mb.x, mm_.x, cr.x), xhat_c(mb.y, mm_.y, cr.y), xhat_c(mb.z, mm_.z, cr.z), xhat_c(mb.w, mm_.w, cr.w));
+        }
+    }
+    v16f acc[2][2];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[tm][tn][v] = 0.0f;
+
+    float4 rg[8];
+    auto fetch = [&](int64_t pk) {
+        const float *const b0 = src + (pk + 8 * kg) * ld + ch;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) rg[i] = (ch_ok && pk + 8 * kg + i < p1) ? ld4(b0 + (int64_t)i * ld) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    uint4 pk4[4][3];   // [channel of the quad][part]: 8 pixels x bf16
+    auto prep = [&]() {
+        if constexpr (APRO == 1) {
+            if (isA) {       // (rows past the chunk were loaded as zeros: relu(xhat(0)) need not be zero, so they are masked again below)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    rg[i].x = fmaxf(xhat(rg[i].x, cr.x, cc.x), 0.0f);
+                    rg[i].y = fmaxf(xhat(rg[i].y, cr.y, cc.y), 0.0f);
+                    rg[i].z = fmaxf(xhat(rg[i].z, cr.z, cc.z), 0.0f);
+                    rg[i].w = fmaxf(xhat(rg[i].w, cr.w, cc.w), 0.0f);
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float r[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) r[i] = f4c(rg[i], c);
+#pragma unroll
+            for (int part = 0; part < 3; ++part) {
+                uint32_t w[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const v2bf h = {(__bf16)r[2 * i], (__bf16)r[2 * i + 1]};
+                    w[i] = __builtin_bit_cast(uint32_t, h);
+                    if (part < 2) {
+                        r[2 * i] -= (float)h[0];
+                        r[2 * i + 1] -= (float)h[1];
+                    }
+                }
+                pk4[c][part] = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+        }
+    };
+    [[maybe_unused]] int64_t fetched = 0;
+    auto store = [&]() {
+        float4 *const d = (isA ? sA : sB) + kg * (isA ? AP : BP) + cq;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int part = 0; part < 3; ++part)
+                d[(part * 4) * (isA ? AP : BP) + 32 * c] = __builtin_bit_cast(float4, pk4[c][part]);
+    };
+    const int nkt = (int)((p1 - p0 + kBK - 1) / kBK);
+    // APRO 1 turns the zeros loaded for pixels past the chunk into relu(c): those pixels' B rows are zero, which is what keeps them out
+    if (nkt > 0) {
+        fetch(p0);
+        prep();
+        store();
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const bool more = kt + 1 < nkt;
+        if (more) fetch(p0 + (int64_t)(kt + 1) * kBK);
+        const float4 *pa = sA + g * AP + wm * 64 + n;
+        const float4 *pb = sB + g * BP + wn * 64 + n;
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            v8bf af[3][2], bf[3][2];
+#pragma unroll
+            for (int part = 0; part < 3; ++part) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    af[part][t] = __builtin_bit_cast(v8bf, pa[(part * 4 + 2 * st) * AP + t * 32]);
+                    bf[part][t] = __builtin_bit_cast(v8bf, pb[(part * 4 + 2 * st) * BP + t * 32]);
+                }
+            }
+            constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};   // smallest products first
+#pragma unroll
+            for (int t6 = 0; t6 < 6; ++t6)
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[t6]][tm], bf[PB[t6]][tn], acc[tm][tn], 0, 0, 0);
+        }
+        if (more) prep();
+        __syncthreads();   // every wavefront has read the tile
+        if (more) store();
+        __syncthreads();
+    }
+    // D register v of lane (n, g): MFMA row r = 8 (v >> 2) + 4 g + (v & 3) of tile (wm, tm) = channel m0 + 4 r + (2 wm + tm);
+    // column n of tile (wn, tn) = channel n0 + 4 n + (2 wn + tn): a lane's two column tiles are neighbours -> one 8-byte store
+    float *const out = a.part + (size_t)s * a.M * a.N;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int row = m0 + 4 * (8 * (v >> 2) + 4 * g + (v & 3)) + 2 * wm + tm;
+            const int col = n0 + 4 * n + 2 * wn;
+            if (row < a.M && col < a.N) *reinterpret_cast<float2 *>(out + (size_t)row * a.N + col) = make_float2(acc[tm][0][v], acc[tm][1][v]);
+        }
+}
+constexpr size_t kpix6_lds_bytes() { return (size_t)12 * (130 + 130) * 16; }
+
 template <int WMv, int TM, int TN>
 constexpr size_t kpix_lds_bytes(int na = 1)
 {
@@ -1127,6 +1275,13 @@ inline int mm_kpix_launch(const Ctx &cx, hipStream_t st, KpixArgs a)
     if (BPRO == 2) S = std::min<int64_t>(S, std::max(1, a.nslot));                     // one d-bias slot per chunk
     a.chunk = ((a.npix + S - 1) / S + kBK - 1) / kBK * kBK;
     a.S = (int)((a.npix + a.chunk - 1) / a.chunk);
+    if constexpr (WMv == 2 && TM == 2 && TN == 2 && APRO <= 1 && AV == 4 && BV == 4 && BPRO == 0) {
+        if (pix_mode(a.npix, cx.n_cu) >= 2 && a.M % 4 == 0 && a.N % 4 == 0) {   // the bf16 x 6 twin (same tiles, same chunks)
+            const unsigned grid6 = (unsigned)((a.S + 7) / 8 * 8 * tiles);
+            hipLaunchKernelGGL(k_mm_kpix6<APRO>, dim3(grid6), dim3(kT), kpix6_lds_bytes(), st, a);
+            return a.S;
+        }
+    }
     const size_t lds = kpix_lds_bytes<WMv, TM, TN>(APRO == 3 ? 2 : 1);
     auto fn = &k_mm_kpix<WMv, TM, TN, APRO, AV, BV, BPRO>;
     static std::atomic<size_t> enabled[16];
