@@ -7,5 +7,6 @@ HIP kernels behind a C ABI (``include/noiseflow_hip.h``), under the reference's
 """
 from .noise_flow_model import NoiseFlow, default_hps  # noqa: F401
 from .NoiseFlowWrapper import NoiseFlowWrapper  # noqa: F401
+from .squeeze import squeeze2d, unsqueeze2d  # noqa: F401   (borealisflows/utils.py:30-86; host-side index maps)
 
-__all__ = ["NoiseFlow", "NoiseFlowWrapper", "default_hps"]
+__all__ = ["NoiseFlow", "NoiseFlowWrapper", "default_hps", "squeeze2d", "unsqueeze2d"]

@@ -516,29 +516,14 @@ size_t gemm16b_lds_bytes(int wp, int H, int W)
 template <int WP, bool PHILOX, int OWN>
 hipError_t launch_gemm16b(const NfProgram &prog, const NfLaunch &a, int n_cu, int device, hipStream_t stream)
 {
-    const size_t lds = gemm16b_lds_bytes(WP, a.H, a.W);
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
-    const void *fn = reinterpret_cast<const void *>(&nf_gemm16b_kernel<WP, PHILOX, OWN>);
     static std::atomic<size_t> lds_set[16];
-    std::atomic<size_t> &cur = lds_set[device & 15];
-    if (lds > cur.load(std::memory_order_relaxed) || device > 15) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        cur.store(lds, std::memory_order_relaxed);
-    }
-    int64_t groups = n_cu;
-    if (a.B < groups) groups = a.B;
-    if (groups < 1) groups = 1;
-    hipLaunchKernelGGL((nf_gemm16b_kernel<WP, PHILOX, OWN>), dim3((unsigned)groups), dim3(GT), lds, stream, prog, a);
-    return hipGetLastError();
+    return gemm_launch_per_cu<GT>(&nf_gemm16b_kernel<WP, PHILOX, OWN>, gemm16b_lds_bytes(WP, a.H, a.W), lds_set, prog, a, n_cu, device, stream);
 }
 
 template <int WP, bool PHILOX>
 hipError_t dispatch_own16b(const NfProgram &prog, const NfLaunch &a, int n_cu, int device, hipStream_t stream)
 {
-    if (a.H * a.W <= 2 * GT) return launch_gemm16b<WP, PHILOX, 2>(prog, a, n_cu, device, stream);
-    if (a.H * a.W <= 4 * GT) return launch_gemm16b<WP, PHILOX, 4>(prog, a, n_cu, device, stream);
-    return launch_gemm16b<WP, PHILOX, 8>(prog, a, n_cu, device, stream);
+    return gemm_by_own<GT>(a.H * a.W, [&](auto own) { return launch_gemm16b<WP, PHILOX, decltype(own)::value>(prog, a, n_cu, device, stream); });
 }
 
 template <bool PHILOX>
@@ -560,30 +545,14 @@ size_t gemm16_lds_bytes(int H, int W)
 template <int WP, bool PHILOX, int OWN>
 hipError_t launch_gemm16(const NfProgram &prog, const NfLaunch &a, int n_cu, int device, hipStream_t stream)
 {
-    const size_t lds = gemm16_lds_bytes(a.H, a.W);
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
-    const void *fn = reinterpret_cast<const void *>(&nf_gemm16_kernel<WP, PHILOX, OWN>);
-    // largest dynamic-LDS size this instantiation was enabled for, per device (racy but idempotent)
     static std::atomic<size_t> lds_set[16];
-    std::atomic<size_t> &cur = lds_set[device & 15];
-    if (lds > cur.load(std::memory_order_relaxed) || device > 15) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        cur.store(lds, std::memory_order_relaxed);
-    }
-    int64_t groups = n_cu;   // one 512-thread workgroup with > 128 KiB of LDS per CU
-    if (a.B < groups) groups = a.B;
-    if (groups < 1) groups = 1;
-    hipLaunchKernelGGL((nf_gemm16_kernel<WP, PHILOX, OWN>), dim3((unsigned)groups), dim3(GT), lds, stream, prog, a);
-    return hipGetLastError();
+    return gemm_launch_per_cu<GT>(&nf_gemm16_kernel<WP, PHILOX, OWN>, gemm16_lds_bytes(a.H, a.W), lds_set, prog, a, n_cu, device, stream);
 }
 
 template <int WP, bool PHILOX>
 hipError_t dispatch_own16(const NfProgram &prog, const NfLaunch &a, int n_cu, int device, hipStream_t stream)
 {
-    if (a.H * a.W <= 2 * GT) return launch_gemm16<WP, PHILOX, 2>(prog, a, n_cu, device, stream);
-    if (a.H * a.W <= 4 * GT) return launch_gemm16<WP, PHILOX, 4>(prog, a, n_cu, device, stream);
-    return launch_gemm16<WP, PHILOX, 8>(prog, a, n_cu, device, stream);
+    return gemm_by_own<GT>(a.H * a.W, [&](auto own) { return launch_gemm16<WP, PHILOX, decltype(own)::value>(prog, a, n_cu, device, stream); });
 }
 
 template <bool PHILOX>

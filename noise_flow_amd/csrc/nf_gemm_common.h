@@ -8,6 +8,8 @@
 // Replaces (reference, /root/reference): layers.py:108-124 (Conv2d1x1), :251-375 (AffineCoupling, the part behind the CNN),
 // cond_utils.py:205-239 (sdn), noise_flow_model.py:394-428, :477-478, :537-539 (objective, sd_z, prior).
 #pragma once
+#include <atomic>
+#include <type_traits>
 
 namespace {
 
@@ -240,6 +242,38 @@ __device__ __forceinline__ void gemm_flush_sums(const NfLaunch &a, double acc_nl
         atomicAdd(&sp[1], acc_sd);
         if (blockIdx.x == 0) atomicAdd(&sp[2], (double)a.B);
     }
+}
+
+// ---- launching (host) ------------------------------------------------------------------------------------------------------------
+// What nf_gemm.hip and nf_gemm16.hip share around their kernels: one persistent workgroup of GT threads per CU (the band / slab
+// images take most of a CU's LDS), dynamic LDS beyond 64 KiB opted into once per device and kernel instantiation (`lds_set`: the
+// caller's static per-instantiation record of the largest size enabled so far; racy but idempotent), and the choice of pixels
+// per thread by patch size.
+template <int GT, typename K>
+inline hipError_t gemm_launch_per_cu(K kern, size_t lds, std::atomic<size_t> (&lds_set)[16], const NfProgram &prog, const NfLaunch &a, int n_cu,
+                                     int device, hipStream_t stream)
+{
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    std::atomic<size_t> &cur = lds_set[device & 15];
+    if (lds > cur.load(std::memory_order_relaxed) || device > 15) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        cur.store(lds, std::memory_order_relaxed);
+    }
+    int64_t groups = n_cu;
+    if (a.B < groups) groups = a.B;
+    if (groups < 1) groups = 1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3(GT), lds, stream, prog, a);
+    return hipGetLastError();
+}
+
+// f(std::integral_constant<int, OWN>) with OWN = pixels per thread for a patch of hw pixels (2, 4 or 8: up to 64 x 64)
+template <int GT, typename F>
+inline hipError_t gemm_by_own(int hw, F &&f)
+{
+    if (hw <= 2 * GT) return f(std::integral_constant<int, 2>{});
+    if (hw <= 4 * GT) return f(std::integral_constant<int, 4>{});
+    return f(std::integral_constant<int, 8>{});
 }
 
 }  // namespace
