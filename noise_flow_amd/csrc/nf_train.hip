@@ -1296,6 +1296,7 @@ __global__ void k_c1_dz(Geo g, const float *__restrict__ t2, const float *__rest
 
 #include "nf_train_tiled.h"   // k_tiled_fwd, k_tiled_CA: one workgroup per patch, widths 4 / 8
 #include "nf_train_wide.h"    // widths 16 / 32 on the matrix cores
+#include "nf_train_pr.h"      // width 32 on 32x32 patches: patch-resident stages (no [pixel][32] tensor in HBM)
 
 // chain rule of the scalar parameterisations: dA -> PLU factors, d(a,b) -> sdn5 variables, gain_val
 __global__ void k_finish(TLayers ls, const float *__restrict__ P, CondIdx ci, int HW, const double *__restrict__ dAbuf,
@@ -1525,6 +1526,8 @@ struct nf_trainer {
     int band_cap = 320;        // pixels (rows x width, halo included) a band kernel keeps in LDS
     bool serial = false;   // NF_TRAIN_SERIAL=1: everything on the caller's stream (kernel durations without overlap, for profiling)
     int wide_mfma = 4095;   // NF_TRAIN_WIDE_MFMA: width-32 stages on the matrix cores (bit 0 filter gradients, 1 l_2 forward, 2 l_2 backward, 3 statistics finalisers, 4 l_last forward, 5 l_last transposed, 6 l_1 transposed, 7 filter gradients inside the stage that holds their operands, 8 l_1 forward, 11 affine/tanh backward inside the transposed l_last; 0: layer kernels only)
+    int pr = 1;            // NF_TRAIN_PR: width 32 on 32x32 patches on the patch-resident stages of nf_train_pr.h (1: 8 wavefronts per patch, 2: 4; 0: the stage kernels of nf_train_wide.h)
+    float *pr_img = nullptr;   // [couplings][PR_SIZE] packed weights of this step (k_pr_pack)
     int tiled = 3;   // NF_TRAIN_TILED: bit 0 = tiled backward stages, bit 1 = tiled forward stages (0: layer kernels only)
     std::vector<void *> owned;
     bool has_sdn = false;
@@ -1627,6 +1630,163 @@ inline int patch_split(const Geo &g)
 #include "nf_train_gemm.h"    // widths without stage kernels of their own: matrix-core GEMMs (nf_train_mm.h) + pixel kernels of run-time width
 namespace {
 
+// ---- width 32 on 32x32 patches: the patch-resident stages (nf_train_pr.h) ----
+template <int NW>
+int pr_set_attributes_nw()
+{
+    struct { const void *fn; size_t lds; } ks[] = {
+        {reinterpret_cast<const void *>(&k_pr_fwd<2, false, NW>), pr_fwd_lds(2, NW)},
+        {reinterpret_cast<const void *>(&k_pr_bwd<0, false, NW>), pr_bwd_lds(0, NW)},
+        {reinterpret_cast<const void *>(&k_pr_bwd<1, false, NW>), pr_bwd_lds(1, NW)},
+        {reinterpret_cast<const void *>(&k_pr_bwd<2, false, NW>), pr_bwd_lds(2, NW)},
+        {reinterpret_cast<const void *>(&k_pr_bwd<2, true, NW>), pr_bwd_lds(2, NW)},
+    };
+    for (const auto &k : ks) {
+        if (k.lds <= 64 * 1024) continue;
+        const hipError_t e = hipFuncSetAttribute(k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)k.lds);
+        if (e != hipSuccess) return nf_fail_hip(e, "hipFuncSetAttribute(patch-resident training stage)");
+    }
+    return NF_OK;
+}
+int pr_set_attributes(int mode) { return mode == 2 ? pr_set_attributes_nw<4>() : pr_set_attributes_nw<8>(); }
+
+void pr_pack_step(nf_trainer *t, hipStream_t st)
+{
+    PrOffs offs{};
+    int n = 0;
+    for (int l = 0; l < t->tl.n; ++l)
+        if (t->tl.l[l].type == NF_LAYER_COUPLING) {
+            offs.off[t->tl.l[l].aux] = t->tl.l[l].off;
+            n = std::max(n, t->tl.l[l].aux + 1);
+        }
+    if (n) hipLaunchKernelGGL(k_pr_pack, dim3((unsigned)n, 13), dim3(256), 0, st, (const float *)t->d_params, offs, t->pr_img);
+}
+
+// One workgroup per patch up to one per CU (the stages keep ~100 KB of LDS: one resident workgroup per CU); beyond that every
+// workgroup walks its share of the patches, so that set-up, moment finalisation and the slotted sums are paid once per CU.
+inline unsigned pr_grid(const nf_trainer *t, const Geo &g)
+{
+    const int64_t npatch = g.npix / g.HW, per = (npatch + t->n_cu - 1) / t->n_cu;
+    return (unsigned)std::min<int64_t>((npatch + per - 1) / per, g.nslot);
+}
+// the slots a consumer adds up: the producer's grid — or the two slots the cross-rank totals come back in (sync_slots)
+inline int pr_nred(const nf_trainer *t, unsigned grid) { return (t->sync_fn && t->sync_world > 1) ? std::max<int>((int)grid, 2) : (int)grid; }
+
+template <int NW>
+void pr_coupling_forward(nf_trainer *t, const Geo &g, const TLayer &L, const float *zin, float *zout, Acc ldacc, const float *zpre,
+                         const float *A, hipStream_t st)
+{
+    constexpr int w = 32;
+    const Cpl &c = t->cpl[L.aux];
+    const int off_m1 = L.off + 19 * w, off_m2 = L.off + 22 * w + w * w, off_w3 = L.off + 24 * w + w * w;
+    const unsigned grid = pr_grid(t, g);
+    PrFwdArgs a{};
+    a.img = t->pr_img + (size_t)L.aux * PR_SIZE;
+    a.bn1 = t->d_flt + c.f_bn1;
+    a.bn2 = t->d_flt + c.f_bn2;
+    a.n = (double)g.npix * t->sync_world;   // the moments are over the GLOBAL minibatch when the ranks are synchronised
+    a.nred = pr_nred(t, grid);
+    a.tail3 = t->d_params + off_w3 + 36 * (w + 1);
+    a.stats = t->acc(c.d_st1);
+    if (zpre) {
+        a.zsrc = zpre;
+        a.A = A;
+        a.zmixed = const_cast<float *>(zin);
+        hipLaunchKernelGGL((k_pr_fwd<0, true, NW>), dim3(grid), dim3(64 * NW), pr_fwd_lds(0, NW), st, g, a);
+    } else {
+        a.zsrc = zin;
+        hipLaunchKernelGGL((k_pr_fwd<0, false, NW>), dim3(grid), dim3(64 * NW), pr_fwd_lds(0, NW), st, g, a);
+    }
+    sync_slots(t, t->acc(c.d_st1), 2 * w, g.nslot, st);
+    a.zsrc = zin;
+    a.A = nullptr;
+    a.zmixed = nullptr;
+    a.stats_in = t->acc(c.d_st1);
+    a.run_mean = t->d_params + off_m1;
+    a.run_var = t->d_params + off_m1 + w;
+    a.stats = t->acc(c.d_st2);
+    hipLaunchKernelGGL((k_pr_fwd<1, false, NW>), dim3(grid), dim3(64 * NW), pr_fwd_lds(1, NW), st, g, a);
+    sync_slots(t, t->acc(c.d_st2), 2 * w, g.nslot, st);
+    a.stats_in = t->acc(c.d_st2);
+    a.run_mean = t->d_params + off_m2;
+    a.run_var = t->d_params + off_m2 + w;
+    a.zout = zout;
+    a.u_out = c.u;
+    a.ldacc = ldacc;
+    hipLaunchKernelGGL((k_pr_fwd<2, false, NW>), dim3(grid), dim3(64 * NW), pr_fwd_lds(2, NW), st, g, a);
+}
+
+template <int NW>
+void pr_coupling_backward(nf_trainer *t, const Geo &g, const TLayer &L, const float *zin, float invB, const float *zmix_in, const float *A,
+                          Acc dA, hipStream_t st, const float *zlat)
+{
+    constexpr int w = 32;
+    const Cpl &c = t->cpl[L.aux];
+    const unsigned grid = pr_grid(t, g);
+    PrBwdArgs a{};
+    a.zin = zin;
+    a.img = t->pr_img + (size_t)L.aux * PR_SIZE;
+    a.bn1 = t->d_flt + c.f_bn1;
+    a.bn2 = t->d_flt + c.f_bn2;
+    a.bb2 = t->d_flt + c.f_bb2;
+    a.bb1 = t->d_flt + c.f_bb1;
+    a.n = (double)g.npix * t->sync_world;
+    a.nred = pr_nred(t, grid);
+    a.off_w1 = L.off;
+    a.off_b1 = L.off + 18 * w;
+    a.off_w2 = L.off + 21 * w;
+    a.off_w3 = L.off + 24 * w + w * w;
+    a.tail3 = t->d_params + a.off_w3 + 36 * (w + 1);
+    a.u = c.u;
+    a.zlat = zlat;
+    a.dz = t->dz;
+    a.dz2 = t->dz2;
+    a.gu = t->gu[0];
+    a.invB = invB;
+    a.G = t->acc(0);
+    a.bstats = t->acc(c.d_bs2);
+#ifdef NF_PR_TIMELINE
+    a.dz_out = t->t1[0];   // the stamps of stage A (nf_train_pr.h, PR_TL)
+#endif
+    hipLaunchKernelGGL((k_pr_bwd<0, false, NW>), dim3(grid), dim3(64 * NW), pr_bwd_lds(0, NW), st, g, a);
+#ifdef NF_PR_TIMELINE
+    {   // average phase lengths over the workgroups, printed for a few launches (100 MHz counter: 10 ns units)
+        static int shown = 0;
+        if (shown < 40 && (++shown % 8) == 0) {
+            (void)hipStreamSynchronize(st);
+            std::vector<long long> h((size_t)grid * 16);
+            (void)hipMemcpy(h.data(), t->t1[0], h.size() * sizeof(long long), hipMemcpyDeviceToHost);
+            static const int ph[6] = {0, 1, 2, 3, 4, 7};   // the stamps the kernel takes
+            double d[6] = {0};
+            long long t0 = h[0], t1 = h[7];
+            for (unsigned b = 0; b < grid; ++b) {
+                for (int i = 1; i < 6; ++i) d[i] += (double)(h[b * 16 + ph[i]] - h[b * 16 + ph[i - 1]]) / grid;
+                t0 = std::min(t0, h[b * 16]);
+                t1 = std::max(t1, h[b * 16 + 7]);
+            }
+            fprintf(stderr, "stage A timeline (us, mean over %u workgroups): set-up %.2f | gu + tiles %.2f | strip loop %.2f | partials to LDS %.2f | "
+                    "sums + stores %.2f | first start to last end %.2f\n", grid, d[1] / 100, d[2] / 100, d[3] / 100, d[4] / 100, d[5] / 100,
+                    (double)(t1 - t0) / 100);
+        }
+    }
+#endif
+    sync_slots(t, t->acc(c.d_bs2), 2 * w, g.nslot, st);
+    a.bstats_in = t->acc(c.d_bs2);
+    a.bstats = t->acc(c.d_bs1);
+    hipLaunchKernelGGL((k_pr_bwd<1, false, NW>), dim3(grid), dim3(64 * NW), pr_bwd_lds(1, NW), st, g, a);
+    sync_slots(t, t->acc(c.d_bs1), 2 * w, g.nslot, st);
+    a.bstats_in = t->acc(c.d_bs1);
+    a.dz_out = t->dz;
+    a.dA = dA;
+    if (zmix_in) {
+        a.zmix_in = zmix_in;
+        a.A = A;
+        hipLaunchKernelGGL((k_pr_bwd<2, true, NW>), dim3(grid), dim3(64 * NW), pr_bwd_lds(2, NW), st, g, a);
+    } else {
+        hipLaunchKernelGGL((k_pr_bwd<2, false, NW>), dim3(grid), dim3(64 * NW), pr_bwd_lds(2, NW), st, g, a);
+    }
+}
+
 template <int W>
 void coupling_forward(nf_trainer *t, const Geo &g, const TLayer &L, const float *zin, float *zout, Acc ldacc,
                       const float *zpre, const float *A, hipStream_t st)
@@ -1637,6 +1797,11 @@ void coupling_forward(nf_trainer *t, const Geo &g, const TLayer &L, const float 
               off_w3 = L.off + 24 * w + w * w;
     const double n = (double)g.npix * t->sync_world;   // the moments are over the GLOBAL minibatch when the ranks are synchronised
     // zpre != null: the preceding Conv2d1x1 is folded into l_1 (which then also writes `zin`)
+    if (W == 32 && t->pr) {
+        if (t->pr == 2) pr_coupling_forward<4>(t, g, L, zin, zout, ldacc, zpre, A, st);
+        else pr_coupling_forward<8>(t, g, L, zin, zout, ldacc, zpre, A, st);
+        return;
+    }
     const size_t z_tile = ((size_t)(g.H + 2) * (g.W + 2) * 2 + g.HW) * sizeof(float);
     constexpr bool kWide = W == 16 || W == 32;   // widths with matrix-core stage kernels
     constexpr int WM = kWide ? W : 32;           // (only instantiated for the widths they exist for)
@@ -1695,6 +1860,11 @@ void coupling_backward(nf_trainer *t, const Geo &g, const TLayer &L, const float
     const double n = (double)g.npix * t->sync_world;
     const float *bn1 = t->d_flt + c.f_bn1, *bn2 = t->d_flt + c.f_bn2;
     const Acc G = t->acc(0);
+    if (W == 32 && t->pr) {
+        if (t->pr == 2) pr_coupling_backward<4>(t, g, L, zin, invB, zmix_in, A, dA, st, zlat);
+        else pr_coupling_backward<8>(t, g, L, zin, invB, zmix_in, A, dA, st, zlat);
+        return;
+    }
     const unsigned ng = std::min(nb, 96u);   // filter-gradient kernels: grid.y multiplies the workgroup count
     // The three filter-gradient kernels only feed the parameter gradient, not d loss / d z: they run
     // on the side stream, forked after their producer, while the main stream walks on.  The
@@ -1984,6 +2154,7 @@ static int trainer_create_impl(const nf_config *cfg, const nf_layer_desc *layers
     if (const char *e = getenv("NF_TRAIN_TILED")) t->tiled = atoi(e);
     if (const char *e = getenv("NF_TRAIN_WIDE_MFMA")) t->wide_mfma = atoi(e);
     if (const char *e = getenv("NF_TRAIN_SERIAL")) t->serial = atoi(e) != 0;
+    if (const char *e = getenv("NF_TRAIN_PR")) t->pr = atoi(e);
     if (const char *e = getenv("NF_TRAIN_BAND")) t->band_cap = std::min(320, std::max(96, atoi(e)));
     t->max_batch = max_batch;
     t->optimizer = optimizer;
@@ -2223,6 +2394,17 @@ static int trainer_create_impl(const nf_config *cfg, const nf_layer_desc *layers
     }
     NF_TRY(dev_alloc(t, (void **)&t->dz, act * 4 * sizeof(float)));
     if (w >= 16) NF_TRY(dev_alloc(t, (void **)&t->dz2, act * 4 * sizeof(float)));
+    t->pr = (t->pr && t->wide_mfma != 0 && w == 32 && !gemm_path && cfg->height == 32 && cfg->width == 32 && n_cpl > 0) ? t->pr : 0;
+    if (t->pr) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, t->device) == hipSuccess && cus > 0) t->n_cu = cus;
+        if (const char *ev = getenv("NF_TRAIN_PR_GRID")) t->n_cu = std::max(1, atoi(ev));   // A/B aid: workgroups of the patch-resident stages
+        NF_TRY(dev_alloc(t, (void **)&t->pr_img, (size_t)n_cpl * PR_SIZE * sizeof(float)));
+        if ((rc = pr_set_attributes(t->pr)) != NF_OK) {
+            nf_trainer_destroy(t);
+            return rc;
+        }
+    }
 #undef NF_TRY
     if ((e = hipMemcpy(t->d_params, params, n_params * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess ||
         (e = hipMemcpy(t->d_mask, mask.data(), n_params, hipMemcpyHostToDevice)) != hipSuccess ||
@@ -2290,6 +2472,7 @@ static int trainer_run(nf_trainer *t, const float *x, const float *y, int64_t B,
     t->sync_rc = 0;
     bool mm_failed = false;
     if ((t->all_gemm || gemm_width(t->width ? t->width : 4)) && !t->cpl.empty()) gemm_pack_step(t, st);
+    if (t->pr) pr_pack_step(t, st);
     const float invB = 1.0f / (float)B;
     const int n = t->cfg.n_layers;
     hipError_t e;

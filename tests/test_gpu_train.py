@@ -117,8 +117,9 @@ def _oracle_check_next_to_kinks(tr, arch, v, x, y, iso, cam, width, rtol=GRAD_RT
         assert abs(lv[0] - ref_loss) <= 1e-5 * abs(ref_loss)
         assert abs(lv[1] - ref_sd) <= 1e-5 * ref_sd
         _check_grads(tr, grads, ref_grads, rtol=rtol, oracle=o)     # o.grad_abs_terms belongs to the evaluation being compared
-    excused = grads_match_up_to_kinks(o, x, y, iso, cam, compare)
-    assert excused <= 1, excused
+    # (an input with MANY on-kink candidates: the branch subset is solved for from the gradients and re-evaluated exactly)
+    excused = grads_match_up_to_kinks(o, x, y, iso, cam, compare, max_kinks=64, got=tr.raw_to_variables(grads.cpu().numpy().copy()))
+    assert excused <= 2, excused
     return excused
 
 
@@ -538,11 +539,12 @@ def test_sync_bn_rejects_unequal_shards(tmp_path):
         assert "same number of patches on every rank" in msg and "between 7 and 8" in msg, msg
 
 
-@pytest.mark.parametrize("width", [32, 96])
-def test_two_rank_sync_bn_at_width_32(tmp_path, width):
+@pytest.mark.parametrize("width,hw,per", [(32, 16, 6), (96, 16, 6), (32, 32, 3)])
+def test_two_rank_sync_bn_at_width_32(tmp_path, width, hw, per):
     """The same property on the matrix-core stage kernels (width 32) and on the library-GEMM path of the widths beyond (96;
     csrc/nf_train_gemm.h): behind a cross-rank all-reduce the statistics are finalised by k_bn_fin / k_bnb_fin from the scattered
-    totals; 2 ranks x 6 patches of 16x16 = 1 rank on the 12."""
+    totals; 2 ranks x 6 patches of 16x16 = 1 rank on the 12.  (32, 32, 3): the patch-resident stages of csrc/nf_train_pr.h, whose
+    consumers finalise the moments themselves from the two slots the global totals come back in."""
     import socket
     import torch.multiprocessing as mp
     from oracle.nf_grad_oracle import is_trainable
@@ -551,7 +553,7 @@ def test_two_rank_sync_bn_at_width_32(tmp_path, width):
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_syncbn_worker, args=(r, 2, port, str(tmp_path), width, 16, 6)) for r in range(2)]
+    procs = [ctx.Process(target=_syncbn_worker, args=(r, 2, port, str(tmp_path), width, hw, per)) for r in range(2)]
     [p.start() for p in procs]
     [p.join(timeout=300) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
@@ -559,21 +561,21 @@ def test_two_rank_sync_bn_at_width_32(tmp_path, width):
     g0, g1 = load("grad", 0), load("grad", 1)
     assert np.array_equal(g0, g1) and np.array_equal(load("params", 0), load("params", 1))
     v = trained_like_variables(DP_ARCH, width, seed=9)
-    x, y = make_inputs(12, 16, 16, seed=500, b1=0.003696)
-    one = _trainer(DP_ARCH, v, (16, 16, 4), width, max_batch=12)
+    x, y = make_inputs(2 * per, hw, hw, seed=500, b1=0.003696)
+    one = _trainer(DP_ARCH, v, (hw, hw, 4), width, max_batch=2 * per)
     g_one, loss_one = one.forward_backward(x, y, [0.0], [0.0], [800], [2])
     ref, got = one.raw_to_variables(g_one.cpu().numpy().copy()), one.raw_to_variables(g0)
     gmax = max(np.abs(ref[n]).max() for n in ref if is_trainable(n))
-    tol = 8.0 / (12 * 256)            # a few pixels' worth: ReLU kinks under a different summation order (wide couplings)
+    tol = 8.0 / (2 * per * hw * hw)   # a few pixels' worth: ReLU kinks under a different summation order (wide couplings)
     for name in ref:
         if is_trainable(name) and not name.endswith(("l_1/b", "l_2/b")):
             assert np.abs(got[name] - ref[name]).max() <= tol * max(np.abs(ref[name]).max(), 1e-6 * gmax), name
     l2 = 0.5 * (load("loss", 0)[0] + load("loss", 1)[0])
     assert abs(l2 - float(loss_one.cpu().numpy()[0])) <= 1e-5 * abs(l2)
     # per-rank statistics on the same shards: a different gradient
-    a, b = _trainer(DP_ARCH, v, (16, 16, 4), width, max_batch=6), _trainer(DP_ARCH, v, (16, 16, 4), width, max_batch=6)
-    ga, _ = a.forward_backward(x[:6], y[:6], [0.0], [0.0], [800], [2])
-    gb, _ = b.forward_backward(x[6:], y[6:], [0.0], [0.0], [800], [2])
+    a, b = _trainer(DP_ARCH, v, (hw, hw, 4), width, max_batch=per), _trainer(DP_ARCH, v, (hw, hw, 4), width, max_batch=per)
+    ga, _ = a.forward_backward(x[:per], y[:per], [0.0], [0.0], [800], [2])
+    gb, _ = b.forward_backward(x[per:], y[per:], [0.0], [0.0], [800], [2])
     g_local = one.raw_to_variables(((ga + gb) / 2).cpu().numpy())
     worst = max(np.abs(g_local[n] - ref[n]).max() / max(np.abs(ref[n]).max(), 1e-6 * gmax) for n in ref
                 if is_trainable(n) and not n.endswith(("l_1/b", "l_2/b")))
@@ -791,6 +793,7 @@ def test_wide_filter_gradients_fused_into_the_stage_kernels(monkeypatch):
     v = trained_like_variables(arch, width, seed=10)
     x, y = make_inputs(B, 32, 32, seed=31)
     res = {}
+    monkeypatch.setenv("NF_TRAIN_PR", "0")   # the stage kernels of nf_train_wide.h (32x32 patches run on nf_train_pr.h by default)
     for mode in ("0", "127", "511", "4095"):
         monkeypatch.setenv("NF_TRAIN_WIDE_MFMA", mode)
         tr = _trainer(arch, v, (32, 32, 4), width, max_batch=B)
