@@ -1746,7 +1746,7 @@ void pr_coupling_backward(nf_trainer *t, const Geo &g, const TLayer &L, const fl
     a.G = t->acc(0);
     a.bstats = t->acc(c.d_bs2);
 #ifdef NF_PR_TIMELINE
-    a.dz_out = t->t1[0];   // the stamps of stage A (nf_train_pr.h, PR_TL)
+    a.dz_out = t->gu[1];   // the stamps of stage A (nf_train_pr.h, PR_TL)
 #endif
     hipLaunchKernelGGL((k_pr_bwd<0, false, NW>), dim3(grid), dim3(64 * NW), pr_bwd_lds(0, NW), st, g, a);
 #ifdef NF_PR_TIMELINE
@@ -1755,7 +1755,7 @@ void pr_coupling_backward(nf_trainer *t, const Geo &g, const TLayer &L, const fl
         if (shown < 40 && (++shown % 8) == 0) {
             (void)hipStreamSynchronize(st);
             std::vector<long long> h((size_t)grid * 16);
-            (void)hipMemcpy(h.data(), t->t1[0], h.size() * sizeof(long long), hipMemcpyDeviceToHost);
+            (void)hipMemcpy(h.data(), t->gu[1], h.size() * sizeof(long long), hipMemcpyDeviceToHost);
             static const int ph[6] = {0, 1, 2, 3, 4, 7};   // the stamps the kernel takes
             double d[6] = {0};
             long long t0 = h[0], t1 = h[7];
@@ -2283,6 +2283,8 @@ static int trainer_create_impl(const nf_config *cfg, const nf_layer_desc *layers
     const size_t act = (size_t)max_batch * cfg->height * cfg->width;   // pixels
     t->n_mix = n_mix;
     const bool gemm_path = t->all_gemm || gemm_width(w);
+    // width 32 on 32x32 patches: the patch-resident stages (nf_train_pr.h) — no [pixel][32] tensor exists, none is allocated
+    t->pr = (t->pr && t->wide_mfma != 0 && w == 32 && !gemm_path && cfg->height == 32 && cfg->width == 32 && n_cpl > 0) ? t->pr : 0;
     // double workspace
     size_t nd = eval_only ? 0 : n_params;
     t->d_dA = (int)nd; nd += eval_only ? 0 : 16 * (size_t)n_mix;
@@ -2370,8 +2372,10 @@ static int trainer_create_impl(const nf_config *cfg, const nf_layer_desc *layers
     t->zs.assign(cfg->n_layers + 1, nullptr);
     for (int i = 1; i <= cfg->n_layers; ++i) NF_TRY(dev_alloc(t, (void **)&t->zs[i], act * 4 * sizeof(float)));
     for (Cpl &c : t->cpl) {
-        NF_TRY(dev_alloc(t, (void **)&c.h1, act * w * sizeof(float)));
-        NF_TRY(dev_alloc(t, (void **)&c.h2, act * w * sizeof(float)));
+        if (!t->pr) {
+            NF_TRY(dev_alloc(t, (void **)&c.h1, act * w * sizeof(float)));
+            NF_TRY(dev_alloc(t, (void **)&c.h2, act * w * sizeof(float)));
+        }
         if (w >= 16 || gemm_path) NF_TRY(dev_alloc(t, (void **)&c.u, act * 4 * sizeof(float)));
     }
     if (gemm_path && n_cpl > 0) {   // nf_train_gemm.h
@@ -2388,13 +2392,14 @@ static int trainer_create_impl(const nf_config *cfg, const nf_layer_desc *layers
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, t->device) == hipSuccess && cus > 0) t->n_cu = cus;
     }
     for (int k = 0; k < (gemm_path ? 1 : 3); ++k) {
-        NF_TRY(dev_alloc(t, (void **)&t->t1[k], act * w * sizeof(float)));
-        NF_TRY(dev_alloc(t, (void **)&t->t2[k], act * w * sizeof(float)));
+        if (!t->pr) {
+            NF_TRY(dev_alloc(t, (void **)&t->t1[k], act * w * sizeof(float)));
+            NF_TRY(dev_alloc(t, (void **)&t->t2[k], act * w * sizeof(float)));
+        }
         NF_TRY(dev_alloc(t, (void **)&t->gu[k], act * 4 * sizeof(float)));
     }
     NF_TRY(dev_alloc(t, (void **)&t->dz, act * 4 * sizeof(float)));
     if (w >= 16) NF_TRY(dev_alloc(t, (void **)&t->dz2, act * 4 * sizeof(float)));
-    t->pr = (t->pr && t->wide_mfma != 0 && w == 32 && !gemm_path && cfg->height == 32 && cfg->width == 32 && n_cpl > 0) ? t->pr : 0;
     if (t->pr) {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, t->device) == hipSuccess && cus > 0) t->n_cu = cus;

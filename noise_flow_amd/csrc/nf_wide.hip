@@ -66,6 +66,12 @@ constexpr int TPW = 8;   // tiles (= rows of a strip) per wavefront
 #ifndef NF_WIDE_WPE
 #define NF_WIDE_WPE 3
 #endif
+#ifndef NF_WIDE_WPE16
+#define NF_WIDE_WPE16 3   // the fp16 instantiation
+#endif
+#ifndef NF_WIDE_HOIST16
+#define NF_WIDE_HOIST16 0
+#endif
 
 // value of the lane one pixel to the left / right (callers multiply the tile ends away: lane 32 receives lane 31's
 // value and vice versa).  NF_WIDE_DPP=1: DPP wave_shr:1 / wave_shl:1 — a VALU operand modifier, no LDS traffic and no
@@ -280,6 +286,25 @@ __device__ __forceinline__ void nf_wide32_body(const NfProgram &prog, const NfLa
 
                 // ---- phase B: the CNN on the matrix cores, strip-local shift-add ----
                 const float4 *const wb4 = reinterpret_cast<const float4 *>(wbuf);
+#if NF_WIDE_HOIST16
+                // fp16: the six A operands and the centre-tap rows of the coupling are read ONCE, ahead of the strip (the tile loop
+                // stores to LDS, so the compiler must otherwise re-read them for every tile: 13 of the 21 LDS reads of a tile, each
+                // a wait in front of the matrix instruction that consumes it)
+                [[maybe_unused]] uint4 hA1[2], hA2[2], hA3[2];
+                [[maybe_unused]] uint2 hC[4];
+                if constexpr (H16) {
+                    const uint4 *const wq0 = reinterpret_cast<const uint4 *>(wbuf);
+                    const uint2 *const wc0 = reinterpret_cast<const uint2 *>(wbuf + NF5_IMG_A3CH);
+#pragma unroll
+                    for (int mm = 0; mm < 2; ++mm) {
+                        hA1[mm] = wq0[NF5_IMG_A1H / 4 + mm * 64 + lane];
+                        hA2[mm] = wq0[NF5_IMG_A2H / 4 + mm * 64 + lane];
+                        hA3[mm] = wq0[NF5_IMG_A3H / 4 + mm * 64 + lane];
+                        hC[2 * mm] = wc0[(2 * mm + 0) * 8 + g * 4 + (lane & 3)];
+                        hC[2 * mm + 1] = wc0[(2 * mm + 1) * 8 + g * 4 + (lane & 3)];
+                    }
+                }
+#endif
                 float cp[TPW][4];
 #pragma unroll
                 for (int k = 0; k < TPW; ++k)
@@ -302,7 +327,11 @@ __device__ __forceinline__ void nf_wide32_body(const NfProgram &prog, const NfLa
                             d[4 * q + 0] = bb.x; d[4 * q + 1] = bb.y; d[4 * q + 2] = bb.z; d[4 * q + 3] = bb.w;
                         }
                         {   // l_1: K = 18 in two instructions; lane half g brings taps 4g .. 4g+3, then (half 0) tap 8
+#if NF_WIDE_HOIST16
+                            const uint4 a0 = hA1[0], a1 = hA1[1];
+#else
                             const uint4 a0 = wq[NF5_IMG_A1H / 4 + lane], a1 = wq[NF5_IMG_A1H / 4 + 64 + lane];
+#endif
                             const v8h b0 = as_v8h(zh[toff[0]], zh[toff[1]], zh[toff[2]], zh[toff[3]]);
                             const v8h b1 = as_v8h(zh[2 * Wp + 2], 0u, 0u, 0u);
                             d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, a0), b0, d, 0, 0, 0);
@@ -316,7 +345,11 @@ __device__ __forceinline__ void nf_wide32_body(const NfProgram &prog, const NfLa
                         }
 #pragma unroll
                         for (int mm = 0; mm < 2; ++mm) {
+#if NF_WIDE_HOIST16
+                            const uint4 aw = hA2[mm];
+#else
                             const uint4 aw = wq[NF5_IMG_A2H / 4 + mm * 64 + lane];
+#endif
                             const v8h hb = as_v8h(relu_pack_h2(d[8 * mm + 0], d[8 * mm + 1]), relu_pack_h2(d[8 * mm + 2], d[8 * mm + 3]),
                                                   relu_pack_h2(d[8 * mm + 4], d[8 * mm + 5]), relu_pack_h2(d[8 * mm + 6], d[8 * mm + 7]));
                             e = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, aw), hb, e, 0, 0, 0);
@@ -326,11 +359,19 @@ __device__ __forceinline__ void nf_wide32_body(const NfProgram &prog, const NfLa
                         const uint2 *const wc = reinterpret_cast<const uint2 *>(wbuf + NF5_IMG_A3CH);
 #pragma unroll
                         for (int mm = 0; mm < 2; ++mm) {
+#if NF_WIDE_HOIST16
+                            const uint4 aw = hA3[mm];
+#else
                             const uint4 aw = wq[NF5_IMG_A3H / 4 + mm * 64 + lane];
+#endif
                             const uint32_t h0 = relu_pack_h2(e[8 * mm + 0], e[8 * mm + 1]), h1 = relu_pack_h2(e[8 * mm + 2], e[8 * mm + 3]);
                             const uint32_t h2 = relu_pack_h2(e[8 * mm + 4], e[8 * mm + 5]), h3 = relu_pack_h2(e[8 * mm + 6], e[8 * mm + 7]);
                             p = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, aw), as_v8h(h0, h1, h2, h3), p, 0, 0, 0);
+#if NF_WIDE_HOIST16
+                            const uint2 c0 = hC[2 * mm], c1 = hC[2 * mm + 1];
+#else
                             const uint2 c0 = wc[(2 * mm + 0) * 8 + g * 4 + (lane & 3)], c1 = wc[(2 * mm + 1) * 8 + g * 4 + (lane & 3)];
+#endif
                             pc = __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(v4hh, c0), __builtin_bit_cast(v4hh, make_uint2(h0, h1)), pc, 0, 0, 0);
                             pc = __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(v4hh, c1), __builtin_bit_cast(v4hh, make_uint2(h2, h3)), pc, 0, 0, 0);
                         }
@@ -593,7 +634,7 @@ __device__ __forceinline__ void nf_wide32_body(const NfProgram &prog, const NfLa
 }
 
 template <int THREADS, bool PHILOX, int TPR, int PREC>
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS == 256 ? NF_WIDE_WPE : 1))) void nf_wide32_kernel(const NfProgram prog, const NfLaunch a)
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS == 256 ? (PREC == 1 ? NF_WIDE_WPE16 : NF_WIDE_WPE) : 1))) void nf_wide32_kernel(const NfProgram prog, const NfLaunch a)
 {
     nf_wide32_body<THREADS, PHILOX, TPR, PREC, false>(prog, a);
 }
