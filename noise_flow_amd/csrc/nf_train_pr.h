@@ -465,7 +465,6 @@ __global__ __launch_bounds__(64 * NW) void k_pr_fwd(Geo g, PrFwdArgs a)
     __syncthreads();
     for (int b = blockIdx.x; b < npatch; b += gridDim.x) {
         const int64_t pb = (int64_t)b * 1024;
-        if (b != (int)blockIdx.x) load_patch(b);
         float z[OWN][4];
 #pragma unroll
         for (int m = 0; m < OWN; ++m) {
@@ -488,6 +487,7 @@ __global__ __launch_bounds__(64 * NW) void k_pr_fwd(Geo g, PrFwdArgs a)
             z0s[(r + 1) * PR_WP + n + 1] = z[m][0];
             z0s[PR_PL + (r + 1) * PR_WP + n + 1] = z[m][1];
         }
+        if (b + (int)gridDim.x < npatch) load_patch(b + gridDim.x);   // the next patch of this workgroup: in flight during the strip loop
         __syncthreads();
         float cp[TPW][4];
         if (STAGE == 2) {
@@ -668,7 +668,6 @@ __global__ __launch_bounds__(64 * NW) void k_pr_bwd(Geo g, PrBwdArgs a)
     PR_TL(1);
     for (int b = blockIdx.x; b < npatch; b += gridDim.x) {
         const int64_t pb = (int64_t)b * 1024;
-        if (b != (int)blockIdx.x) load_patch(b);
 #pragma unroll
         for (int m = 0; m < OWN; ++m) {
             const int64_t p = pb + (row0 + 2 * m + gh) * 32 + n;
@@ -710,6 +709,7 @@ __global__ __launch_bounds__(64 * NW) void k_pr_bwd(Geo g, PrBwdArgs a)
             z0s[PR_PL + tp] = zv[m].y;
             reinterpret_cast<float4 *>(gus)[tp] = gv[m];
         }
+        if (b + (int)gridDim.x < npatch) load_patch(b + gridDim.x);   // the next patch of this workgroup: in flight during the strip loop
         __syncthreads();
         PR_TL(2);
         [[maybe_unused]] float cp[TPW][4];

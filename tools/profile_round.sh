@@ -51,6 +51,15 @@ for w in 512 64; do
   NF_TOOL_STEPS=10 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_train$w -- python $R/tools/bench_train_width.py $w 138 > $OUT/kt_train$w.log 2>&1
   K=$(find $OUT/kt_train$w -name "*kernel_stats.csv" | head -1); cp $K $OUT/kernel_stats_train_w$w.csv 2>/dev/null
 done
+# the width-32 step on the patch-resident stages (csrc/nf_train_pr.h): per-kernel durations in serial mode at 138 and 1 024 patches,
+# HBM bytes per kernel and SQ counters at 1 024
+for b in 138 1024; do
+  NF_TRAIN_SERIAL=1 NF_TOOL_STEPS=10 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_train32_$b -- python $R/tools/bench_train_width.py 32 $b > $OUT/kt_train32_$b.log 2>&1
+  K=$(find $OUT/kt_train32_$b -name "*kernel_stats.csv" | head -1); cp $K $OUT/kernel_stats_train_w32_b$b.csv 2>/dev/null
+done
+(cd $R && bash tools/prof_train_traffic.sh 32 1024 > $OUT/train_w32_traffic.txt 2>&1)
+(cd $R && bash tools/sq_train32.sh 1024 > $OUT/sq_train32.txt 2>&1)
+cd /tmp
 (timeout 300 $R/tools/probes/mm_probe time > $OUT/mm_probe.log 2>&1)
 # SQ counters of the trainer's three GEMM shapes at width 512 (probe products 0 = l_2 forward, 2 = plain, 8 = d l_2/W)
 SQA="SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU GRBM_GUI_ACTIVE"
