@@ -303,7 +303,7 @@ int nf_set_sync(nf_handle *h, nf_allreduce_fn fn, void *user, double *sync_buf, 
  * `stream` — and on an internal side stream forked from and joined back into it with events — with no
  * allocation and no host synchronisation.  One stream at a time per trainer.
  * Layers: every NF_LAYER_* above (COUPLING at any width 1..512: 4/8/16/32 on stage kernels of their own, every other width on the
- * fp32 matrix-core GEMMs of csrc/nf_train_mm.h — no library GEMM, nothing loaded at run time) — the whole
+ * matrix-core GEMMs of csrc/nf_train_mm.h — no library GEMM, nothing loaded at run time) — the whole
  * vocabulary of noise_flow_arch under every
  * setting of hps.flow_permutation / hps.decomp; fp32 (nf_config.flags must be 0).
  * Trainable = everything except P / sign_S of CONV1X1 / CONV1X1_LU2, the BN statistics and c_i of SDN5 / SDN6.
@@ -315,6 +315,12 @@ int nf_set_sync(nf_handle *h, nf_allreduce_fn fn, void *user, double *sync_buf, 
  *                       6 l_1 transposed (8: l_1 forward) on v_mfma_f32_32x32x2_f32; 3 one-pass statistics finalisers (widths >= 16);
  *                       7 filter gradients inside the stage kernels (>= 400k pixels per step), 8 l_1 forward,
  *                       11 affine / tanh backward inside the transposed l_last kernel.  Default 4095.
+ *   NF_TRAIN_PR         width 32 on 32x32 patches: the patch-resident stages of csrc/nf_train_pr.h (the coupling CNN recomputed from z
+ *                       between the batch-statistics barriers; no [pixel][32] tensor is allocated).  1 (default): 8 wavefronts per
+ *                       patch, 2: 4 wavefronts, 0: the stage kernels NF_TRAIN_WIDE_MFMA selects.  NF_TRAIN_PR_GRID=<n>: at most n
+ *                       workgroups walk the patches (default: one per CU).
+ *   NF_MM_MODE          the 128-column GEMMs of the widths beyond 64: 2 (default) fp32-accurate products on the bf16 matrix pipe,
+ *                       8 wavefronts on 256 x 128; 3 the same on 128 x 128; 0 / 1 fp32 products on 128 x 128 / 256 x 128.
  *   NF_TRAIN_BAND       pixels (rows x patch width, halo included; 96..320, default 320) a band kernel keeps in LDS.
  *   NF_TRAIN_GEMM=1     widths 4/8/16/32 on the library-GEMM path of the other widths as well.
  *   NF_TRAIN_GEMM_C1=0  library-GEMM path: l_1 forward as sgemm + statistics pass instead of the fused kernel.

@@ -15,7 +15,7 @@
 //             B : ... BN2 backward, transposed l_2, ReLU mask                    -> the two batch sums of BN1's backward;  d l_2/W, d l_2/b
 //             C : ... BN1 backward, transposed l_1 (+ the folded Conv2d1x1 backward) -> d loss / d z;  d l_1/W, d l_1/b, d A
 //
-// Layout (as nf_wide.hip): 256 threads = 4 wavefronts, a wavefront owns a strip of 8 image rows, a TILE is one row (32 pixels on
+// Layout (as nf_wide.hip): NW = 8 (or 4) wavefronts, a wavefront owns a strip of 32 / NW image rows, a TILE is one row (32 pixels on
 // the N axis of v_mfma_f32_32x32x2_f32, lane n = lane & 31, lane half g = lane >> 5 = the instruction's K slice).  D register v of
 // lane half g holds channel c(v, g) = 8 (v >> 2) + 4 g + (v & 3) of the lane's pixel and IS the B operand of K step v of the next
 // layer, forward and transposed alike.  The filter gradients are products over the PIXELS: the two operands go through a
@@ -26,8 +26,8 @@
 // Reference: layers.py:251-375 (AffineCoupling), :378-401 (batch norm under is_training), :463-497 (the CNN),
 // train_noise_flow.py:50-77,187-198 (the step).
 constexpr int PR_WP = 34, PR_PL = 34 * 34, PR_RP = 36;
-// -DNF_PR_TIMELINE (tools/pr_timeline.py only): thread 0 of every workgroup of stage A stamps the 100 MHz counter at its phase
-// boundaries into PrBwdArgs::dz_out (unused by that stage) as int64[grid][16]
+// -DNF_PR_TIMELINE (a tools/build_variant.sh build, OBJ=nf_train): thread 0 of every workgroup of stage A stamps the 100 MHz counter at
+// its phase boundaries into PrBwdArgs::dz_out (unused by that stage) as int64[grid][16]; pr_coupling_backward prints their means
 #ifdef NF_PR_TIMELINE
 #define PR_TL(i) do { if (STAGE == 0 && threadIdx.x == 0) reinterpret_cast<long long *>(a.dz_out)[(size_t)blockIdx.x * 16 + (i)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
 #else
