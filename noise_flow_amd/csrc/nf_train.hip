@@ -652,19 +652,40 @@ __global__ void k_c2_fwd(Geo g, const float *__restrict__ h1, Acc stats1, double
                          bool fin)
 {   // Pw = P, read-only view for the filters (see k_tiled_fwd)
     __shared__ float bn1[2 * W];
+    // the pixel's row is requested before the statistics are added up, and the next iteration's before this one's arithmetic: at
+    // 138 patches a thread has two pixels, and two exposed memory latencies were a third of the kernel (width 4: 7.5 us)
+    constexpr bool kAhead = W <= 8;
+    const int64_t pstride = (int64_t)gridDim.x * TB;
+    float hn[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) hn[j] = 0.0f;
+    if (kAhead) {
+        const int64_t p0 = (int64_t)blockIdx.x * TB + threadIdx.x;
+        if (p0 < g.npix) {
+#pragma unroll
+            for (int j = 0; j < W; ++j) hn[j] = h1[p0 * W + j];
+        }
+    }
     bn_from_slots<W>(stats1, g.nslot, n, bn1, P, off_m1, off_m1 + W, bn1_out, fin);
     const float *W2 = Pw + off_w2, *b2 = W2 + W * W;
     float s[W], q[W];
 #pragma unroll
     for (int j = 0; j < W; ++j) s[j] = q[j] = 0.0f;
     NF_PIXEL_LOOP(g, p) {
+        float hc[W];
+#pragma unroll
+        for (int j = 0; j < W; ++j) hc[j] = hn[j];
+        if (kAhead && p + pstride < g.npix) {
+#pragma unroll
+            for (int j = 0; j < W; ++j) hn[j] = h1[(p + pstride) * W + j];
+        }
         if (p < g.npix) {
             float h[W];
 #pragma unroll
             for (int j = 0; j < W; ++j) h[j] = b2[j];
 #pragma unroll
             for (int i = 0; i < W; ++i) {
-                const float a = fmaxf((h1[p * W + i] - bn1[i]) * bn1[W + i], 0.0f);
+                const float a = fmaxf(((kAhead ? hc[i] : h1[p * W + i]) - bn1[i]) * bn1[W + i], 0.0f);
 #pragma unroll
                 for (int j = 0; j < W; ++j) h[j] = fmaf(a, W2[i * W + j], h[j]);
             }
@@ -1077,24 +1098,56 @@ __global__ void k_c2_bwd(Geo g, const float *__restrict__ h1, const float *__res
                          int off_w2, float *__restrict__ t1, float *__restrict__ t2, Acc bstats, Acc G, const float *__restrict__ pre)
 {
     __shared__ float bb2[2 * W];
+    // (rows requested ahead of their use, as in k_c2_fwd)
+    constexpr bool kAhead = W <= 8;
+    const int64_t pstride = (int64_t)gridDim.x * TB;
+    float n2[W], n1[W], nt[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) n2[j] = n1[j] = nt[j] = 0.0f;
+    if (kAhead) {
+        const int64_t p0 = (int64_t)blockIdx.x * TB + threadIdx.x;
+        if (p0 < g.npix) {
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+                n2[j] = h2[p0 * W + j];
+                nt[j] = t1[p0 * W + j];
+                n1[j] = h1[p0 * W + j];
+            }
+        }
+    }
     bnb_from_slots<W>(bstats2, g.nslot, n, bb2, pre);
     const float *W2 = P + off_w2;
     float s[W], q[W], gb[W];
 #pragma unroll
     for (int j = 0; j < W; ++j) s[j] = q[j] = gb[j] = 0.0f;
     NF_PIXEL_LOOP(g, p) {
+        float c2[W], c1[W], ct[W];
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            c2[j] = n2[j];
+            c1[j] = n1[j];
+            ct[j] = nt[j];
+        }
+        if (kAhead && p + pstride < g.npix) {
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+                n2[j] = h2[(p + pstride) * W + j];
+                nt[j] = t1[(p + pstride) * W + j];
+                n1[j] = h1[(p + pstride) * W + j];
+            }
+        }
         if (p < g.npix) {
             float gh2[W];
 #pragma unroll
             for (int j = 0; j < W; ++j) {
-                const float xh = (h2[p * W + j] - bn2[j]) * bn2[W + j];
-                gh2[j] = bn2[W + j] * (t1[p * W + j] - bb2[j] - xh * bb2[W + j]);
+                const float xh = ((kAhead ? c2[j] : h2[p * W + j]) - bn2[j]) * bn2[W + j];
+                gh2[j] = bn2[W + j] * ((kAhead ? ct[j] : t1[p * W + j]) - bb2[j] - xh * bb2[W + j]);
                 t1[p * W + j] = gh2[j];
                 gb[j] += gh2[j];
             }
 #pragma unroll
             for (int i = 0; i < W; ++i) {
-                const float xh = (h1[p * W + i] - bn1[i]) * bn1[W + i];
+                const float xh = ((kAhead ? c1[i] : h1[p * W + i]) - bn1[i]) * bn1[W + i];
                 float gh = 0.0f;
 #pragma unroll
                 for (int j = 0; j < W; ++j) gh = fmaf(W2[i * W + j], gh2[j], gh);
@@ -1975,7 +2028,7 @@ void coupling_forward_tiled(nf_trainer *t, const Geo &g, const TLayer &L, const 
     const int w = W, off_w1 = L.off, off_m1 = L.off + 19 * w, off_w2 = L.off + 21 * w, off_m2 = L.off + 22 * w + w * w,
               off_w3 = L.off + 24 * w + w * w;
     const double n = (double)g.npix * t->sync_world;
-    const size_t smem = ((size_t)(g.H + 2) * (g.W + 2) * (W + 2) + 1 + 2 * W + (NT / 16) * 2 * W) * sizeof(float);
+    const size_t smem = ((size_t)(g.H + 2) * (g.W + 2) * (W + 2) + (NT / 16) * (1 + 2 * W)) * sizeof(float);
     if (!f1_done) {
         const TiledF1 f1{A, const_cast<float *>(zin), off_w1, c.h1, t->acc(c.d_st1)};
         if (zpre)
@@ -2019,8 +2072,7 @@ void coupling_backward_tiled(nf_trainer *t, const Geo &g, const TLayer &L, const
     const int set = L.aux % 3;
     float *t1 = t->t1[set], *t2 = t->t2[set], *gu = t->gu[set];
     hipStream_t sd = t->serial ? st : t->side;
-    const size_t smem = ((size_t)(g.H + 2) * (g.W + 2) * (W + 4) + (W + 16) + (9 + 2 * W) + (NT / 16) * (2 * W > 16 ? 2 * W : 16)) *
-                        sizeof(float);
+    const size_t smem = ((size_t)(g.H + 2) * (g.W + 2) * (W + 4) + (NT / 16) * (W + 16 + 2 * W + 9)) * sizeof(float);
     auto wait_set = [&](int k) {
         if (t->done_pending[k]) {
             (void)hipStreamWaitEvent(st, t->ev_done[k], 0);

@@ -11,35 +11,33 @@
 // instead of 5.  The three filter-gradient kernels stay what they are, on the side stream, fed by the tensors these
 // stages leave in HBM (gu, t1, t2) — fusing THEM in was measured to cost more than it saves (their ~290 value sums per
 // coupling multiply with the wavefront count).  One thread per pixel, NT = 256 / 512 / 1024 threads by patch size.
+// The sums of a launch are reduced at its END, all groups together: every group parks its 16-lane row sums (row_sum16: 4 issues per
+// value instead of wsum's 11) in a region of its own, ONE barrier, then thread t0 + k adds value k up — wavefront by wavefront, its four
+// rows joined as wsum joins them — and stores this workgroup's slot directly.  (Round 6; before, every group had a barrier pair of
+// its own and went through a staging array: 9 barriers of 16 wavefronts per k_tiled_CA launch.)
 template <int N, int NT>
-__device__ __forceinline__ void stage_add_n(float *dst, const float (&v)[N], float *part /* [NT/16][N]: one partial per 16-lane row */)
+__device__ __forceinline__ void stage_put_n(const float (&v)[N], float *part /* [NT/16][N] */)
 {
     const int row = threadIdx.x >> 4;
-    __syncthreads();                       // the previous use of `part` is over
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-        const float sv = row_sum16(v[k]);  // 4 issues per value instead of wsum's 11: the rows are joined below, once
+        const float sv = row_sum16(v[k]);
         if ((threadIdx.x & 15) == 0) part[row * N + k] = sv;
     }
-    __syncthreads();
-    for (int k = threadIdx.x; k < N; k += NT) {
+}
+template <int N, int NT>
+__device__ __forceinline__ void stage_sum_flush(Acc dst, const float *part, int t0, int nslot)
+{
+    const int k = (int)threadIdx.x - t0;
+    if (k >= 0 && k < N) {
         float tot = 0.0f;
 #pragma unroll
-        for (int i = 0; i < NT / 64; ++i) {   // wavefront by wavefront, its four rows joined as wsum joins them (same bits)
+        for (int i = 0; i < NT / 64; ++i) {
             const float *q = part + (4 * i) * N + k;
             tot += (q[0] + q[N]) + (q[2 * N] + q[3 * N]);
         }
-        dst[k] = tot;
-    }
-}
-
-// staged[0..n) -> this workgroup's slot of n consecutive accumulator values (call after a barrier)
-template <int NT>
-__device__ __forceinline__ void stage_flush(Acc dst, const float *staged, int n, int nslot)
-{
-    for (int k = threadIdx.x; k < n; k += NT) {
         float *d = dst.p + (size_t)k * NSLOT;
-        d[blockIdx.x] = staged[k];
+        d[blockIdx.x] = tot;
         for (int q = blockIdx.x + gridDim.x; q < nslot; q += gridDim.x) d[q] = 0.0f;
     }
 }
@@ -89,7 +87,7 @@ template <int W, int NT>
 __device__ __forceinline__ void tiled_phase_A(const Geo &g, int b, int r, int c, bool ok, float (&dz)[4], const float4 zi,
                                               const float (&h2v)[W], const float *__restrict__ bn2,
                                               const float *__restrict__ P, int off_w3, float invB,
-                                              float *__restrict__ gu, float *__restrict__ t1, float *stg, float *part, float *TH,
+                                              float *__restrict__ gu, float *__restrict__ t1, float (&sq)[2 * W], float (&tail)[9], float *TH,
                                               float *TU)
 {
     const int Wp = g.W + 2, tile_px = (g.H + 2) * Wp;
@@ -107,7 +105,8 @@ __device__ __forceinline__ void tiled_phase_A(const Geo &g, int b, int r, int c,
         lds_put<W>(TH + tp * W, a2v);
     }
     __syncthreads();
-    float tail[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // d b (4), d logs (4), d rescale
+#pragma unroll
+    for (int k = 0; k < 9; ++k) tail[k] = 0.0f;                      // d b (4), d logs (4), d rescale
     if (ok) {
         float u[4];
 #pragma unroll
@@ -162,7 +161,6 @@ __device__ __forceinline__ void tiled_phase_A(const Geo &g, int b, int r, int c,
     }
     __syncthreads();
     // transposed l_last + ReLU mask -> d loss / d xhat2 (t1) and the two batch sums of the BN backward formula
-    float sq[2 * W];
 #pragma unroll
     for (int j = 0; j < 2 * W; ++j) sq[j] = 0.0f;
     if (ok) {
@@ -190,8 +188,6 @@ __device__ __forceinline__ void tiled_phase_A(const Geo &g, int b, int r, int c,
             sq[W + i] = gx * xh;
         }
     }
-    stage_add_n<2 * W, NT>(stg + 9, sq, part);
-    stage_add_n<9, NT>(stg, tail, part);
 }
 
 // C'.  dz: the A' result of this coupling (read back from HBM) in, d loss / d (input of the layer below) out.
@@ -200,8 +196,8 @@ template <int W, int NT, bool MIX>
 __device__ __forceinline__ void tiled_phase_C(const Geo &g, int b, int r, int c, bool ok, float (&dz)[4], const float4 zv,
                                               const float *__restrict__ A, const float (&h1v)[W], const float (&t2v)[W],
                                               const float *__restrict__ bn1, const float *bb1,
-                                              const float *__restrict__ P, int off_w1, float *__restrict__ t2, float *stg,
-                                              float *part, float *TG)
+                                              const float *__restrict__ P, int off_w1, float *__restrict__ t2, float (&gh)[W],
+                                              float (&accA)[16], float *TG)
 {
     const int Wp = g.W + 2, tile_px = (g.H + 2) * Wp;
     const float *W1 = P + off_w1;
@@ -209,7 +205,6 @@ __device__ __forceinline__ void tiled_phase_C(const Geo &g, int b, int r, int c,
     const int tp = (r + 1) * Wp + c + 1;
     zero_floats<NT>(TG, tile_px * W);
     __syncthreads();
-    float gh[W];
 #pragma unroll
     for (int j = 0; j < W; ++j) gh[j] = 0.0f;
     if (ok) {
@@ -222,7 +217,6 @@ __device__ __forceinline__ void tiled_phase_C(const Geo &g, int b, int r, int c,
         lds_put<W>(TG + tp * W, gh);
     }
     __syncthreads();
-    float accA[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) accA[i] = 0.0f;
     if (ok) {
@@ -254,8 +248,6 @@ __device__ __forceinline__ void tiled_phase_C(const Geo &g, int b, int r, int c,
             for (int i = 0; i < 4; ++i) dz[i] = d[i];
         }
     }
-    stage_add_n<W, NT>(stg, gh, part);
-    if (MIX) stage_add_n<16, NT>(stg + W, accA, part);
 }
 
 struct TiledA {   // operands of a stage A'
@@ -280,7 +272,8 @@ __global__ __launch_bounds__(NT) void k_tiled_CA(Geo g, TiledC cc, TiledA a, dou
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ float bb1[2 * W];
     const int tile_px = (g.H + 2) * (g.W + 2);
-    float *stgC = smem + tile_px * (W + 4), *stgA = stgC + W + 16, *part = stgA + 9 + 2 * W;
+    float *part = smem + tile_px * (W + 4);   // row sums of the four groups: [NT/16][W], [..][16], [..][2 W], [..][9]
+    float *const partB = part + (NT / 16) * W, *const partS = partB + (NT / 16) * 16, *const partT = partS + (NT / 16) * 2 * W;
     const bool ok = (int)threadIdx.x < g.HW;
     const int r = ok ? (int)threadIdx.x / g.W : 0, c = ok ? (int)threadIdx.x - r * g.W : 0;
     const int b = blockIdx.x;
@@ -314,18 +307,28 @@ __global__ __launch_bounds__(NT) void k_tiled_CA(Geo g, TiledC cc, TiledA a, dou
     }
     if (HAS_C) bnb_from_slots_nt<W, NT>(cc.bstats1, g.nslot, n, bb1);
     float d[4] = {v.x, v.y, v.z, v.w};
-    if (HAS_C) tiled_phase_C<W, NT, MIX>(g, b, r, c, ok, d, zv, cc.A, h1v, t2v, cc.bn1, bb1, P, cc.off_w1, cc.t2, stgC, part, smem);
-    if (NEXT_A)
-        tiled_phase_A<W, NT>(g, b, r, c, ok, d, zi, h2v, a.bn2, P, a.off_w3, invB, a.gu, a.t1, stgA, part, smem, smem + tile_px * W);
+    [[maybe_unused]] float gb1[W], accA[16], sq[2 * W], tail[9];
+    if (HAS_C) tiled_phase_C<W, NT, MIX>(g, b, r, c, ok, d, zv, cc.A, h1v, t2v, cc.bn1, bb1, P, cc.off_w1, cc.t2, gb1, accA, smem);
+    if (HAS_C && NEXT_A) __syncthreads();   // phase A's tiles take the place of phase C's
+    if (NEXT_A) tiled_phase_A<W, NT>(g, b, r, c, ok, d, zi, h2v, a.bn2, P, a.off_w3, invB, a.gu, a.t1, sq, tail, smem, smem + tile_px * W);
     if (ok) reinterpret_cast<float4 *>(dz)[gp] = make_float4(d[0], d[1], d[2], d[3]);
-    __syncthreads();
+    // the launch's sums: parked, one barrier, added up and stored by their owner threads
     if (HAS_C) {
-        stage_flush<NT>(G + cc.off_w1 + 18 * W, stgC, W, g.nslot);            // d l_1/b
-        if (MIX) stage_flush<NT>(cc.dA, stgC + W, 16, g.nslot);
+        stage_put_n<W, NT>(gb1, part);
+        if (MIX) stage_put_n<16, NT>(accA, partB);
     }
     if (NEXT_A) {
-        stage_flush<NT>(G + a.off_w3 + 36 * (W + 1), stgA, 9, g.nslot);       // d l_last/b, d logs, d rescale
-        stage_flush<NT>(a.bstats2, stgA + 9, 2 * W, g.nslot);
+        stage_put_n<2 * W, NT>(sq, partS);
+        stage_put_n<9, NT>(tail, partT);
+    }
+    __syncthreads();
+    if (HAS_C) {
+        stage_sum_flush<W, NT>(G + cc.off_w1 + 18 * W, part, 0, g.nslot);            // d l_1/b
+        if (MIX) stage_sum_flush<16, NT>(cc.dA, partB, 64, g.nslot);
+    }
+    if (NEXT_A) {
+        stage_sum_flush<9, NT>(G + a.off_w3 + 36 * (W + 1), partT, 128, g.nslot);    // d l_last/b, d logs, d rescale
+        stage_sum_flush<2 * W, NT>(a.bstats2, partS, 192, g.nslot);
     }
 }
 
@@ -383,7 +386,8 @@ __global__ __launch_bounds__(NT) void k_tiled_fwd(Geo g, TiledF3 f3, TiledF1 f1,
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ float bn2[2 * W];
     const int Wp = g.W + 2, tile_px = (g.H + 2) * Wp;
-    float *TH = smem, *TZ = smem + tile_px * W, *stg = TZ + tile_px * 2, *part = stg + 1 + 2 * W;
+    float *TH = smem, *TZ = smem + tile_px * W, *part = TZ + tile_px * 2;   // row sums: [NT/16][1] (log-det), [NT/16][2 W] (statistics)
+    float *const partS = part + NT / 16;
     const bool ok = (int)threadIdx.x < g.HW;
     const int r = ok ? (int)threadIdx.x / g.W : 0, c = ok ? (int)threadIdx.x - r * g.W : 0;
     const int b = blockIdx.x, tp = (r + 1) * Wp + c + 1;
@@ -405,6 +409,7 @@ __global__ __launch_bounds__(NT) void k_tiled_fwd(Geo g, TiledF3 f3, TiledF1 f1,
     zero_floats<NT>(smem, tile_px * (W + 2));
     if (HAS_3) bn_from_slots_nt<W, NT>(f3.stats2, g.nslot, n, bn2, P, f3.off_m2, f3.off_m2 + W, f3.bn2_out);
     __syncthreads();
+    float lv[1] = {0.0f};
     if (HAS_3) {
         const float *W3 = Pw + f3.off_w3, *b3 = W3 + 36 * (W + 1), *logs = b3 + 4;
         if (ok) {
@@ -414,7 +419,6 @@ __global__ __launch_bounds__(NT) void k_tiled_fwd(Geo g, TiledF3 f3, TiledF1 f1,
             lds_put<W>(TH + tp * W, a2v);
         }
         __syncthreads();
-        float lv[1] = {0.0f};
         if (ok) {
             float u[4];
 #pragma unroll
@@ -449,8 +453,10 @@ __global__ __launch_bounds__(NT) void k_tiled_fwd(Geo g, TiledF3 f3, TiledF1 f1,
             reinterpret_cast<float4 *>(f3.zout)[gp] = z;
             lv[0] = ls0 + ls1;
         }
-        stage_add_n<1, NT>(stg, lv, part);
     }
+    [[maybe_unused]] float sq[2 * W];
+#pragma unroll
+    for (int j = 0; j < 2 * W; ++j) sq[j] = 0.0f;
     if (HAS_1) {
         const float *W1 = Pw + f1.off_w1, *b1 = W1 + 18 * W;
         if (ok) {
@@ -465,9 +471,6 @@ __global__ __launch_bounds__(NT) void k_tiled_fwd(Geo g, TiledF3 f3, TiledF1 f1,
             *reinterpret_cast<float2 *>(TZ + tp * 2) = v;
         }
         __syncthreads();
-        float sq[2 * W];
-#pragma unroll
-        for (int j = 0; j < 2 * W; ++j) sq[j] = 0.0f;
         if (ok) {
             float h[W];
 #pragma unroll
@@ -490,10 +493,11 @@ __global__ __launch_bounds__(NT) void k_tiled_fwd(Geo g, TiledF3 f3, TiledF1 f1,
                 sq[W + j] = h[j] * h[j];
             }
         }
-        stage_add_n<2 * W, NT>(stg + 1, sq, part);
     }
+    if (HAS_3) stage_put_n<1, NT>(lv, part);
+    if (HAS_1) stage_put_n<2 * W, NT>(sq, partS);
     __syncthreads();
-    if (HAS_3) stage_flush<NT>(f3.ldacc, stg, 1, g.nslot);
-    if (HAS_1) stage_flush<NT>(f1.stats1, stg + 1, 2 * W, g.nslot);
+    if (HAS_3) stage_sum_flush<1, NT>(f3.ldacc, part, 0, g.nslot);
+    if (HAS_1) stage_sum_flush<2 * W, NT>(f1.stats1, partS, 64, g.nslot);
 }
 
