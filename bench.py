@@ -849,8 +849,9 @@ def _training(ctx, batches, cond, wide):
                        "(train_noise_flow.py:64-66,187-198), shipped architecture, 138 patches 32x32x4",
            "batch": TB_, "steps": kt, "ms_per_step": mst, "value": TB_ / (mst * 1e-3), "unit": "patches/s",
            "bound": "kernel latency: a chain of stream-ordered launches per step (profiles/)"}
-    # the same step at the paper-scale coupling width (job_noise_flow.sh:19: "for Noise Flow it is 32"), fresh initialisation:
-    # every dense stage on v_mfma_f32_32x32x2_f32 (DESIGN 4.5 v)
+    # the same step at the paper-scale coupling width (job_noise_flow.sh:19: "for Noise Flow it is 32"), fresh initialisation: the
+    # patch-resident stages of csrc/nf_train_pr.h (the CNN recomputed from z between the batch-statistics barriers, every dense
+    # stage on v_mfma_f32_32x32x2_f32, no [pixel][32] tensor in HBM)
     trw = Trainer([32, 32, 4], default_hps(width=32), device=dev.index, max_batch=TB_)
     for _ in range(3):
         trw.step(xt_, yt_, [0.0], [0.0], [100.0], [2.0], lr=1e-4, sync=False)
@@ -862,11 +863,37 @@ def _training(ctx, batches, cond, wide):
     torch.cuda.synchronize(dev)
     msw = g0.elapsed_time(g1) / kt
     trw.close()
+    # matrix instructions a step issues per 32-pixel row tile and coupling (9 / 25 / 43 / 75 / 75 / 93 for the six stages),
+    # each 32 x 32 x 2 MACs: the recomputation included — executed work, not the algorithmic 3 x forward
+    mfma_flop = 320 * 2.0 * 32 * 32 * 2 * 32 * 8
     out["width32"] = {"workload": "the same step, coupling width 32 (fresh initialisation), 138 patches 32x32x4", "ms_per_step": msw,
-                      "value": TB_ / (msw * 1e-3), "unit": "patches/s"}
+                      "value": TB_ / (msw * 1e-3), "unit": "patches/s",
+                      "executed_matrix_tflops": mfma_flop * TB_ / (msw * 1e-3) / 1e12,
+                      "note": "patch-resident stages (csrc/nf_train_pr.h): 6 launches per coupling, one workgroup per patch on "
+                              "138 of the CUs; fixed cost per launch and the idle CUs bound it (DESIGN 4.7)"}
+    try:   # ... and with the GPU full: 1 024 patches (one workgroup per CU walks 4 patches)
+        xb_, yb_ = synth_patches(args.seed, 1 << 43, 1024, device=dev.index)
+        trb = Trainer([32, 32, 4], default_hps(width=32), device=dev.index, max_batch=1024)
+        for _ in range(2):
+            trb.step(xb_, yb_, [0.0], [0.0], [100.0], [2.0], lr=1e-4, sync=False)
+        torch.cuda.synchronize(dev)
+        g0.record(stream)
+        for _ in range(10):
+            trb.step(xb_, yb_, [0.0], [0.0], [100.0], [2.0], lr=1e-4, sync=False)
+        g1.record(stream)
+        torch.cuda.synchronize(dev)
+        msb = g0.elapsed_time(g1) / 10
+        trb.close()
+        del xb_, yb_
+        out["width32"]["b1024"] = {"batch": 1024, "ms_per_step": msb, "value": 1024 / (msb * 1e-3), "unit": "patches/s",
+                                    "executed_matrix_tflops": mfma_flop * 1024 / (msb * 1e-3) / 1e12,
+                                    "executed_frac_of_f32_matrix_peak": mfma_flop * 1024 / (msb * 1e-3) / 1e12 / VALU_PEAK_TFLOPS}
+    except Exception as ex:
+        out["width32"]["b1024"] = {"error": str(ex)[:300]}
     # ... and at the width the reference's flags default to (sidd/ArgParser.py:43: 512), and at 64: the dense products of a step are the
-    # hand-written fp32 matrix-core GEMMs of csrc/nf_train_mm.h (v_mfma_f32_32x32x2_f32, BN + ReLU fused into the operand staging,
-    # batch sums into the epilogues) between kernels of run-time width (csrc/nf_train_gemm.h)
+    # hand-written matrix-core GEMMs of csrc/nf_train_mm.h (BN + ReLU fused into the operand staging, batch sums into the epilogues;
+    # the 128-column products and the pixel-K filter gradients as fp32-ACCURATE products on v_mfma_f32_32x32x16_bf16: three-way
+    # operand split, six partial products, "bf16 x 6") between kernels of run-time width (csrc/nf_train_gemm.h)
     for wg_, kg in ((512, 5), (64, 20)):
         key = "width%d" % wg_
         try:
@@ -887,8 +914,9 @@ def _training(ctx, batches, cond, wide):
                         "steps": kg, "ms_per_step": msg, "value": TB_ / (msg * 1e-3), "unit": "patches/s",
                         "dense_tflops": flop / (msg * 1e-3) / 1e12,
                         "dense_frac_of_f32_matrix_peak": flop / (msg * 1e-3) / 1e12 / VALU_PEAK_TFLOPS,
-                        "note": "fp32 products on this repo's own v_mfma_f32_32x32x2_f32 GEMMs (csrc/nf_train_mm.h; f32 matrix peak "
-                                "157.3 TFLOP/s); no library GEMM"}
+                        "note": "this repo's own matrix-core GEMMs (csrc/nf_train_mm.h): fp32-accurate products, the large ones on the "
+                                "bf16 pipe as six partial products of three-way split operands — the fraction is against the f32 "
+                                "matrix peak (157.3 TFLOP/s), which such products may exceed; no library GEMM"}
         except Exception as ex:    # reported, the other sections stand
             out[key] = {"error": str(ex)[:300]}
     return out

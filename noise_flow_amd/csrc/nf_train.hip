@@ -1581,6 +1581,12 @@ struct nf_trainer {
     int wide_mfma = 4095;   // NF_TRAIN_WIDE_MFMA: width-32 stages on the matrix cores (bit 0 filter gradients, 1 l_2 forward, 2 l_2 backward, 3 statistics finalisers, 4 l_last forward, 5 l_last transposed, 6 l_1 transposed, 7 filter gradients inside the stage that holds their operands, 8 l_1 forward, 11 affine/tanh backward inside the transposed l_last; 0: layer kernels only)
     int pr = 1;            // NF_TRAIN_PR: width 32 on 32x32 patches on the patch-resident stages of nf_train_pr.h (1: 8 wavefronts per patch, 2: 4; 0: the stage kernels of nf_train_wide.h)
     float *pr_img = nullptr;   // [couplings][PR_SIZE] packed weights of this step (k_pr_pack)
+    // the coupling above the one a patch-resident forward is launched for, when only a Conv2d1x1 lies between them: its stage 0 rides in
+    // this coupling's last launch (set by the layer loop; pr_f0_done: the next call's stage 0 already ran)
+    const TLayer *pr_next = nullptr;
+    const float *pr_next_A = nullptr;
+    float *pr_next_zin = nullptr;
+    bool pr_f0_done = false;
     int tiled = 3;   // NF_TRAIN_TILED: bit 0 = tiled backward stages, bit 1 = tiled forward stages (0: layer kernels only)
     std::vector<void *> owned;
     bool has_sdn = false;
@@ -1689,6 +1695,7 @@ int pr_set_attributes_nw()
 {
     struct { const void *fn; size_t lds; } ks[] = {
         {reinterpret_cast<const void *>(&k_pr_fwd<2, false, NW>), pr_fwd_lds(2, NW)},
+        {reinterpret_cast<const void *>(&k_pr_fwd<2, false, NW, true>), pr_fwd_lds(2, NW)},
         {reinterpret_cast<const void *>(&k_pr_bwd<0, false, NW>), pr_bwd_lds(0, NW)},
         {reinterpret_cast<const void *>(&k_pr_bwd<1, false, NW>), pr_bwd_lds(1, NW)},
         {reinterpret_cast<const void *>(&k_pr_bwd<2, false, NW>), pr_bwd_lds(2, NW)},
@@ -1741,7 +1748,9 @@ void pr_coupling_forward(nf_trainer *t, const Geo &g, const TLayer &L, const flo
     a.nred = pr_nred(t, grid);
     a.tail3 = t->d_params + off_w3 + 36 * (w + 1);
     a.stats = t->acc(c.d_st1);
-    if (zpre) {
+    if (t->pr_f0_done) {
+        // stage 0 ran in the last launch of the coupling below
+    } else if (zpre) {
         a.zsrc = zpre;
         a.A = A;
         a.zmixed = const_cast<float *>(zin);
@@ -1750,6 +1759,7 @@ void pr_coupling_forward(nf_trainer *t, const Geo &g, const TLayer &L, const flo
         a.zsrc = zin;
         hipLaunchKernelGGL((k_pr_fwd<0, false, NW>), dim3(grid), dim3(64 * NW), pr_fwd_lds(0, NW), st, g, a);
     }
+    t->pr_f0_done = false;
     sync_slots(t, t->acc(c.d_st1), 2 * w, g.nslot, st);
     a.zsrc = zin;
     a.A = nullptr;
@@ -1766,7 +1776,17 @@ void pr_coupling_forward(nf_trainer *t, const Geo &g, const TLayer &L, const flo
     a.zout = zout;
     a.u_out = c.u;
     a.ldacc = ldacc;
-    hipLaunchKernelGGL((k_pr_fwd<2, false, NW>), dim3(grid), dim3(64 * NW), pr_fwd_lds(2, NW), st, g, a);
+    if (t->pr_next && (t->pr & 4) == 0) {
+        const Cpl &cn = t->cpl[t->pr_next->aux];
+        a.next_A = t->pr_next_A;
+        a.next_zmixed = t->pr_next_zin;
+        a.next_img = t->pr_img + (size_t)t->pr_next->aux * PR_SIZE;
+        a.next_stats = t->acc(cn.d_st1);
+        hipLaunchKernelGGL((k_pr_fwd<2, false, NW, true>), dim3(grid), dim3(64 * NW), pr_fwd_lds(2, NW), st, g, a);
+        t->pr_f0_done = true;
+    } else {
+        hipLaunchKernelGGL((k_pr_fwd<2, false, NW>), dim3(grid), dim3(64 * NW), pr_fwd_lds(2, NW), st, g, a);
+    }
 }
 
 template <int NW>
@@ -2530,6 +2550,8 @@ static int trainer_run(nf_trainer *t, const float *x, const float *y, int64_t B,
     bool mm_failed = false;
     if ((t->all_gemm || gemm_width(t->width ? t->width : 4)) && !t->cpl.empty()) gemm_pack_step(t, st);
     if (t->pr) pr_pack_step(t, st);
+    t->pr_f0_done = false;
+    t->pr_next = nullptr;
     const float invB = 1.0f / (float)B;
     const int n = t->cfg.n_layers;
     hipError_t e;
@@ -2581,6 +2603,13 @@ static int trainer_run(nf_trainer *t, const float *x, const float *y, int64_t B,
             } else if (t->all_gemm || gemm_width(L.width)) {
                 if (!coupling_forward_gemm(t, g, L, zin, zout, t->acc(t->d_ld0 + l), zpre, Am, st)) mm_failed = true;
             } else {
+                t->pr_next = nullptr;
+                if (t->pr && l + 2 < n && t->tl.l[l + 1].type == NF_LAYER_CONV1X1 && t->tl.l[l + 2].type == NF_LAYER_COUPLING &&
+                    t->tl.l[l + 2].width == L.width) {
+                    t->pr_next = &t->tl.l[l + 2];
+                    t->pr_next_A = t->d_flt + t->f_A + 16 * t->tl.l[l + 1].aux;
+                    t->pr_next_zin = t->zs[l + 2];
+                }
 #define NF_CALL(WW) coupling_forward<WW>(t, g, L, zin, zout, t->acc(t->d_ld0 + l), zpre, Am, st)
                 NF_WIDTH_SWITCH(L.width, NF_CALL)
 #undef NF_CALL

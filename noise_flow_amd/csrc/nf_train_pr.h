@@ -404,25 +404,33 @@ struct PrFwdArgs {
     Acc stats;               // stage 0: sums of h1, h1^2; stage 1: of h2
     float *zout, *u_out;     // stage 2
     Acc ldacc;
+    // stage 2 with NEXT: stage 0 of the coupling above (behind one folded Conv2d1x1) in the same launch
+    const float *next_A;     // that Conv2d1x1's matrix
+    float *next_zmixed;      // where that coupling's input goes
+    const float *next_img;   // its packed weights (A1, B1 are used)
+    Acc next_stats;          // its sums of h1, h1^2
 };
 constexpr size_t pr_fwd_lds(int stage, int nw)
 {
-    return (size_t)(2 * PR_PL + (stage == 0 ? PR_A2 : stage == 1 ? PR_A3 : PR_FWD) + 128 + nw * 256 + nw * 128) * sizeof(float);
+    return (size_t)(2 * PR_PL + (stage == 0 ? PR_A2 : stage == 1 ? PR_A3 : PR_FWD + PR_A2) + 128 + nw * 256 + nw * 192) * sizeof(float);
 }
 
 // NW wavefronts (4 or 8) of 32 / NW rows each: 8 wavefronts put two on every SIMD, so that one's LDS / VALU phases run under the
 // other's matrix instructions
-template <int STAGE, bool MIX, int NW>
+// NEXT (stage 2 only): the launch goes on with stage 0 of the coupling above — its Conv2d1x1 applied to the pixels this stage has
+// just produced, its l_1 on the tile they are written back to, its batch sums — one launch and one trip of z through HBM less
+template <int STAGE, bool MIX, int NW, bool NEXT = false>
 __global__ __launch_bounds__(64 * NW) void k_pr_fwd(Geo g, PrFwdArgs a)
 {
+    static_assert(!NEXT || (STAGE == 2 && !MIX), "only stage 2 continues into the next coupling");
     constexpr int TPW = 32 / NW, OWN = TPW / 2, NTH = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int NIMG = STAGE == 0 ? PR_A2 : STAGE == 1 ? PR_A3 : PR_FWD;
+    constexpr int NIMG = STAGE == 0 ? PR_A2 : STAGE == 1 ? PR_A3 : PR_FWD + PR_A2;   // (stage 2: + A1, B1 of the coupling above)
     float *const z0s = smem;              // [2][PL] zero-bordered planes of the pass-through half
     float *const img = z0s + 2 * PR_PL;
     float *const bnc = img + NIMG;        // [2 layers][mean | rstd][g][v]
     float *const exch = bnc + 128;        // [NW][2][32][4] strip-boundary rows
-    float *const red = exch + NW * 256;   // 2 x [NW][4][16]
+    float *const red = exch + NW * 256;   // 3 x [NW][4][16]
     const int t = threadIdx.x, w = t >> 6, lane = t & 63, n = lane & 31, gh = lane >> 5, row0 = w * TPW;
     const float4 *const wb4 = reinterpret_cast<const float4 *>(img);
     const int npatch = (int)(g.npix / g.HW);
@@ -433,7 +441,10 @@ __global__ __launch_bounds__(64 * NW) void k_pr_fwd(Geo g, PrFwdArgs a)
         for (int m = 0; m < OWN; ++m) zr[m] = reinterpret_cast<const float4 *>(a.zsrc)[(int64_t)b * 1024 + (row0 + 2 * m + gh) * 32 + n];
     };
     if ((int)blockIdx.x < npatch) load_patch(blockIdx.x);
-    for (int i = t; i < NIMG / 4; i += NTH) reinterpret_cast<float4 *>(img)[i] = reinterpret_cast<const float4 *>(a.img)[i];
+    constexpr int NOWN = STAGE == 2 ? PR_FWD : NIMG;
+    for (int i = t; i < NOWN / 4; i += NTH) reinterpret_cast<float4 *>(img)[i] = reinterpret_cast<const float4 *>(a.img)[i];
+    if (NEXT)
+        for (int i = t; i < PR_A2 / 4; i += NTH) reinterpret_cast<float4 *>(img + PR_FWD)[i] = reinterpret_cast<const float4 *>(a.next_img)[i];
     for (int i = t; i < 2 * PR_PL; i += NTH) z0s[i] = 0.0f;
     if (STAGE == 1) pr_bn_finalize<NW>(a.stats_in, a.nred, a.n, bnc, a.bn1, a.run_mean, a.run_var);
     if (STAGE == 2) {
@@ -452,6 +463,8 @@ __global__ __launch_bounds__(64 * NW) void k_pr_fwd(Geo g, PrFwdArgs a)
 #pragma unroll
         for (int i = 0; i < 16; ++i) mm[i] = a.A[i];
     }
+    if (NEXT)   // the row sums of the coupling above are added up in LDS patch by patch (its 32 running sums do not fit the registers)
+        for (int i = t; i < 2 * NW * 64; i += NTH) red[NW * 64 + i] = 0.0f;
     float s1[16], q1[16];
 #pragma unroll
     for (int v = 0; v < 16; ++v) s1[v] = q1[v] = 0.0f;
@@ -527,6 +540,10 @@ __global__ __launch_bounds__(64 * NW) void k_pr_fwd(Geo g, PrFwdArgs a)
         if (STAGE == 2) {
             __syncthreads();
             pr_shift_join<TPW, NW>(cp, exch, w, n, gh);
+            if (NEXT) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) mm[i] = a.next_A[i];
+            }
 #pragma unroll
             for (int m = 0; m < OWN; ++m) {
                 const int r = row0 + 2 * m + gh;
@@ -541,8 +558,41 @@ __global__ __launch_bounds__(64 * NW) void k_pr_fwd(Geo g, PrFwdArgs a)
                 reinterpret_cast<float4 *>(a.u_out)[p] = make_float4(u[0], u[1], u[2], u[3]);
                 const float sh0 = u[0] * e3[0], sh1 = u[1] * e3[1];
                 const float ls0 = sc * tanhf(u[2] * e3[2]), ls1 = sc * tanhf(u[3] * e3[3]);
-                reinterpret_cast<float4 *>(a.zout)[p] = make_float4(z[m][0], z[m][1], fmaf(z[m][2], expf(ls0), sh0), fmaf(z[m][3], expf(ls1), sh1));
+                const float zo2 = fmaf(z[m][2], expf(ls0), sh0), zo3 = fmaf(z[m][3], expf(ls1), sh1);
+                reinterpret_cast<float4 *>(a.zout)[p] = make_float4(z[m][0], z[m][1], zo2, zo3);
                 lsum += ls0 + ls1;
+                if (NEXT) {   // the coupling above: its input, and the pass-through half of it into the tile (every strip loop is over)
+                    const float u0 = z[m][0], u1 = z[m][1];
+                    const float v0 = u0 * mm[0] + u1 * mm[4] + zo2 * mm[8] + zo3 * mm[12], v1 = u0 * mm[1] + u1 * mm[5] + zo2 * mm[9] + zo3 * mm[13];
+                    reinterpret_cast<float4 *>(a.next_zmixed)[p] =
+                        make_float4(v0, v1, u0 * mm[2] + u1 * mm[6] + zo2 * mm[10] + zo3 * mm[14], u0 * mm[3] + u1 * mm[7] + zo2 * mm[11] + zo3 * mm[15]);
+                    z0s[(r + 1) * PR_WP + n + 1] = v0;
+                    z0s[PR_PL + (r + 1) * PR_WP + n + 1] = v1;
+                }
+            }
+            if (NEXT) {
+                __syncthreads();
+                const float4 *const wn4 = reinterpret_cast<const float4 *>(img + PR_FWD);
+                float sn[16], qn[16];
+#pragma unroll
+                for (int v = 0; v < 16; ++v) sn[v] = qn[v] = 0.0f;
+#pragma unroll
+                for (int k = 0; k < TPW; ++k) {
+                    const v16f d = pr_l1(wn4, z0s + gh * PR_PL + (row0 + k) * PR_WP + n, lane, gh);
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        sn[v] += d[v];
+                        qn[v] = fmaf(d[v], d[v], qn[v]);
+                    }
+                }
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {   // (the entries a 16-lane row adds to are its own)
+                    const float rs = row_sum16(sn[v]), rq = row_sum16(qn[v]);
+                    if ((lane & 15) == 0) {
+                        red[NW * 64 + (w * 4 + (lane >> 4)) * 16 + v] += rs;
+                        red[NW * 128 + (w * 4 + (lane >> 4)) * 16 + v] += rq;
+                    }
+                }
             }
         }
     }
@@ -557,6 +607,10 @@ __global__ __launch_bounds__(64 * NW) void k_pr_fwd(Geo g, PrFwdArgs a)
         pr_acc_put<1, NW>(lv, red);
         __syncthreads();
         pr_acc_get<1, NW>(red, a.ldacc, g.nslot, t);
+        if (NEXT) {
+            pr_chan_get<NW>(red + NW * 64, a.next_stats, g.nslot, t - 64);
+            pr_chan_get<NW>(red + NW * 128, a.next_stats + 32, g.nslot, t - 128);
+        }
     }
 }
 
