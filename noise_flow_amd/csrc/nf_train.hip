@@ -1579,7 +1579,7 @@ struct nf_trainer {
     int band_cap = 320;        // pixels (rows x width, halo included) a band kernel keeps in LDS
     bool serial = false;   // NF_TRAIN_SERIAL=1: everything on the caller's stream (kernel durations without overlap, for profiling)
     int wide_mfma = 4095;   // NF_TRAIN_WIDE_MFMA: width-32 stages on the matrix cores (bit 0 filter gradients, 1 l_2 forward, 2 l_2 backward, 3 statistics finalisers, 4 l_last forward, 5 l_last transposed, 6 l_1 transposed, 7 filter gradients inside the stage that holds their operands, 8 l_1 forward, 11 affine/tanh backward inside the transposed l_last; 0: layer kernels only)
-    int pr = 1;            // NF_TRAIN_PR: width 32 on 32x32 patches on the patch-resident stages of nf_train_pr.h (1: 8 wavefronts per patch, 2: 4; 0: the stage kernels of nf_train_wide.h)
+    int pr = 1;            // NF_TRAIN_PR: width 32 on 32x32 patches on the patch-resident stages of nf_train_pr.h (1: 8 wavefronts per patch, 2: 4; + 4 / + 8: no forward / backward launch fusion; 0: the stage kernels of nf_train_wide.h)
     float *pr_img = nullptr;   // [couplings][PR_SIZE] packed weights of this step (k_pr_pack)
     // the coupling above the one a patch-resident forward is launched for, when only a Conv2d1x1 lies between them: its stage 0 rides in
     // this coupling's last launch (set by the layer loop; pr_f0_done: the next call's stage 0 already ran)
@@ -1587,6 +1587,10 @@ struct nf_trainer {
     const float *pr_next_A = nullptr;
     float *pr_next_zin = nullptr;
     bool pr_f0_done = false;
+    // ... and in the backward pass: stage A of the coupling BELOW rides in this coupling's last launch
+    const TLayer *pr_below = nullptr;
+    const float *pr_below_zin = nullptr;
+    bool pr_a_done = false;
     int tiled = 3;   // NF_TRAIN_TILED: bit 0 = tiled backward stages, bit 1 = tiled forward stages (0: layer kernels only)
     std::vector<void *> owned;
     bool has_sdn = false;
@@ -1700,6 +1704,8 @@ int pr_set_attributes_nw()
         {reinterpret_cast<const void *>(&k_pr_bwd<1, false, NW>), pr_bwd_lds(1, NW)},
         {reinterpret_cast<const void *>(&k_pr_bwd<2, false, NW>), pr_bwd_lds(2, NW)},
         {reinterpret_cast<const void *>(&k_pr_bwd<2, true, NW>), pr_bwd_lds(2, NW)},
+        {reinterpret_cast<const void *>(&k_pr_bwd_CA<true, NW>), std::max(pr_bwd_lds(2, NW), pr_bwd_lds(0, NW))},
+        {reinterpret_cast<const void *>(&k_pr_bwd_CA<false, NW>), std::max(pr_bwd_lds(2, NW), pr_bwd_lds(0, NW))},
     };
     for (const auto &k : ks) {
         if (k.lds <= 64 * 1024) continue;
@@ -1708,7 +1714,7 @@ int pr_set_attributes_nw()
     }
     return NF_OK;
 }
-int pr_set_attributes(int mode) { return mode == 2 ? pr_set_attributes_nw<4>() : pr_set_attributes_nw<8>(); }
+int pr_set_attributes(int mode) { return (mode & 3) == 2 ? pr_set_attributes_nw<4>() : pr_set_attributes_nw<8>(); }
 
 void pr_pack_step(nf_trainer *t, hipStream_t st)
 {
@@ -1789,13 +1795,11 @@ void pr_coupling_forward(nf_trainer *t, const Geo &g, const TLayer &L, const flo
     }
 }
 
-template <int NW>
-void pr_coupling_backward(nf_trainer *t, const Geo &g, const TLayer &L, const float *zin, float invB, const float *zmix_in, const float *A,
-                          Acc dA, hipStream_t st, const float *zlat)
+// the operands every backward stage of a coupling shares (stage A reads dz / zlat and writes dz2, gu; B and C read gu)
+PrBwdArgs pr_bwd_args(nf_trainer *t, const Geo &g, const TLayer &L, const float *zin, float invB, const float *zlat, unsigned grid)
 {
     constexpr int w = 32;
     const Cpl &c = t->cpl[L.aux];
-    const unsigned grid = pr_grid(t, g);
     PrBwdArgs a{};
     a.zin = zin;
     a.img = t->pr_img + (size_t)L.aux * PR_SIZE;
@@ -1818,31 +1822,45 @@ void pr_coupling_backward(nf_trainer *t, const Geo &g, const TLayer &L, const fl
     a.invB = invB;
     a.G = t->acc(0);
     a.bstats = t->acc(c.d_bs2);
+    return a;
+}
+
+template <int NW>
+void pr_coupling_backward(nf_trainer *t, const Geo &g, const TLayer &L, const float *zin, float invB, const float *zmix_in, const float *A,
+                          Acc dA, hipStream_t st, const float *zlat)
+{
+    constexpr int w = 32;
+    const Cpl &c = t->cpl[L.aux];
+    const unsigned grid = pr_grid(t, g);
+    PrBwdArgs a = pr_bwd_args(t, g, L, zin, invB, zlat, grid);
+    if (!t->pr_a_done) {   // (else: stage A rode in the last launch of the coupling above)
 #ifdef NF_PR_TIMELINE
-    a.dz_out = t->gu[1];   // the stamps of stage A (nf_train_pr.h, PR_TL)
+        a.dz_out = t->gu[1];   // the stamps of stage A (nf_train_pr.h, PR_TL)
 #endif
-    hipLaunchKernelGGL((k_pr_bwd<0, false, NW>), dim3(grid), dim3(64 * NW), pr_bwd_lds(0, NW), st, g, a);
+        hipLaunchKernelGGL((k_pr_bwd<0, false, NW>), dim3(grid), dim3(64 * NW), pr_bwd_lds(0, NW), st, g, a);
 #ifdef NF_PR_TIMELINE
-    {   // average phase lengths over the workgroups, printed for a few launches (100 MHz counter: 10 ns units)
-        static int shown = 0;
-        if (shown < 40 && (++shown % 8) == 0) {
-            (void)hipStreamSynchronize(st);
-            std::vector<long long> h((size_t)grid * 16);
-            (void)hipMemcpy(h.data(), t->gu[1], h.size() * sizeof(long long), hipMemcpyDeviceToHost);
-            static const int ph[6] = {0, 1, 2, 3, 4, 7};   // the stamps the kernel takes
-            double d[6] = {0};
-            long long t0 = h[0], t1 = h[7];
-            for (unsigned b = 0; b < grid; ++b) {
-                for (int i = 1; i < 6; ++i) d[i] += (double)(h[b * 16 + ph[i]] - h[b * 16 + ph[i - 1]]) / grid;
-                t0 = std::min(t0, h[b * 16]);
-                t1 = std::max(t1, h[b * 16 + 7]);
+        {   // average phase lengths over the workgroups, printed for a few launches (100 MHz counter: 10 ns units)
+            static int shown = 0;
+            if (shown < 40 && (++shown % 8) == 0) {
+                (void)hipStreamSynchronize(st);
+                std::vector<long long> h((size_t)grid * 16);
+                (void)hipMemcpy(h.data(), t->gu[1], h.size() * sizeof(long long), hipMemcpyDeviceToHost);
+                static const int ph[6] = {0, 1, 2, 3, 4, 7};   // the stamps the kernel takes
+                double d[6] = {0};
+                long long t0 = h[0], t1 = h[7];
+                for (unsigned b = 0; b < grid; ++b) {
+                    for (int i = 1; i < 6; ++i) d[i] += (double)(h[b * 16 + ph[i]] - h[b * 16 + ph[i - 1]]) / grid;
+                    t0 = std::min(t0, h[b * 16]);
+                    t1 = std::max(t1, h[b * 16 + 7]);
+                }
+                fprintf(stderr, "stage A timeline (us, mean over %u workgroups): set-up %.2f | gu + tiles %.2f | strip loop %.2f | partials to LDS %.2f | "
+                        "sums + stores %.2f | first start to last end %.2f\n", grid, d[1] / 100, d[2] / 100, d[3] / 100, d[4] / 100, d[5] / 100,
+                        (double)(t1 - t0) / 100);
             }
-            fprintf(stderr, "stage A timeline (us, mean over %u workgroups): set-up %.2f | gu + tiles %.2f | strip loop %.2f | partials to LDS %.2f | "
-                    "sums + stores %.2f | first start to last end %.2f\n", grid, d[1] / 100, d[2] / 100, d[3] / 100, d[4] / 100, d[5] / 100,
-                    (double)(t1 - t0) / 100);
         }
-    }
 #endif
+    }
+    t->pr_a_done = false;
     sync_slots(t, t->acc(c.d_bs2), 2 * w, g.nslot, st);
     a.bstats_in = t->acc(c.d_bs2);
     a.bstats = t->acc(c.d_bs1);
@@ -1851,13 +1869,25 @@ void pr_coupling_backward(nf_trainer *t, const Geo &g, const TLayer &L, const fl
     a.bstats_in = t->acc(c.d_bs1);
     a.dz_out = t->dz;
     a.dA = dA;
-    if (zmix_in) {
-        a.zmix_in = zmix_in;
-        a.A = A;
-        hipLaunchKernelGGL((k_pr_bwd<2, true, NW>), dim3(grid), dim3(64 * NW), pr_bwd_lds(2, NW), st, g, a);
-    } else {
-        hipLaunchKernelGGL((k_pr_bwd<2, false, NW>), dim3(grid), dim3(64 * NW), pr_bwd_lds(2, NW), st, g, a);
+    a.zmix_in = zmix_in;
+    a.A = A;
+#ifndef NF_PR_TIMELINE
+    if (t->pr_below && (t->pr & 8) == 0) {
+        // stage A of the coupling below in the same launch (nf_train_pr.h, k_pr_bwd_CA)
+        const PrBwdArgs an = pr_bwd_args(t, g, *t->pr_below, t->pr_below_zin, invB, nullptr, grid);
+        const size_t lds = std::max(pr_bwd_lds(2, NW), pr_bwd_lds(0, NW));
+        if (zmix_in)
+            hipLaunchKernelGGL((k_pr_bwd_CA<true, NW>), dim3(grid), dim3(64 * NW), lds, st, g, a, an);
+        else
+            hipLaunchKernelGGL((k_pr_bwd_CA<false, NW>), dim3(grid), dim3(64 * NW), lds, st, g, a, an);
+        t->pr_a_done = true;
+        return;
     }
+#endif
+    if (zmix_in)
+        hipLaunchKernelGGL((k_pr_bwd<2, true, NW>), dim3(grid), dim3(64 * NW), pr_bwd_lds(2, NW), st, g, a);
+    else
+        hipLaunchKernelGGL((k_pr_bwd<2, false, NW>), dim3(grid), dim3(64 * NW), pr_bwd_lds(2, NW), st, g, a);
 }
 
 template <int W>
@@ -1871,7 +1901,7 @@ void coupling_forward(nf_trainer *t, const Geo &g, const TLayer &L, const float 
     const double n = (double)g.npix * t->sync_world;   // the moments are over the GLOBAL minibatch when the ranks are synchronised
     // zpre != null: the preceding Conv2d1x1 is folded into l_1 (which then also writes `zin`)
     if (W == 32 && t->pr) {
-        if (t->pr == 2) pr_coupling_forward<4>(t, g, L, zin, zout, ldacc, zpre, A, st);
+        if ((t->pr & 3) == 2) pr_coupling_forward<4>(t, g, L, zin, zout, ldacc, zpre, A, st);
         else pr_coupling_forward<8>(t, g, L, zin, zout, ldacc, zpre, A, st);
         return;
     }
@@ -1934,7 +1964,7 @@ void coupling_backward(nf_trainer *t, const Geo &g, const TLayer &L, const float
     const float *bn1 = t->d_flt + c.f_bn1, *bn2 = t->d_flt + c.f_bn2;
     const Acc G = t->acc(0);
     if (W == 32 && t->pr) {
-        if (t->pr == 2) pr_coupling_backward<4>(t, g, L, zin, invB, zmix_in, A, dA, st, zlat);
+        if ((t->pr & 3) == 2) pr_coupling_backward<4>(t, g, L, zin, invB, zmix_in, A, dA, st, zlat);
         else pr_coupling_backward<8>(t, g, L, zin, invB, zmix_in, A, dA, st, zlat);
         return;
     }
@@ -2550,8 +2580,8 @@ static int trainer_run(nf_trainer *t, const float *x, const float *y, int64_t B,
     bool mm_failed = false;
     if ((t->all_gemm || gemm_width(t->width ? t->width : 4)) && !t->cpl.empty()) gemm_pack_step(t, st);
     if (t->pr) pr_pack_step(t, st);
-    t->pr_f0_done = false;
-    t->pr_next = nullptr;
+    t->pr_f0_done = t->pr_a_done = false;
+    t->pr_next = t->pr_below = nullptr;
     const float invB = 1.0f / (float)B;
     const int n = t->cfg.n_layers;
     hipError_t e;
@@ -2680,6 +2710,14 @@ static int trainer_run(nf_trainer *t, const float *x, const float *y, int64_t B,
             } else if (t->all_gemm || gemm_width(L.width)) {
                 if (!coupling_backward_gemm(t, g, L, t->zs[l], invB, zmix_in, Am, dA, st, zlat)) mm_failed = true;
             } else {
+                t->pr_below = nullptr;
+                {
+                    const int lb = fold ? l - 2 : l - 1;   // the layer below this coupling (and its folded Conv2d1x1)
+                    if (t->pr && lb >= 0 && t->tl.l[lb].type == NF_LAYER_COUPLING && t->tl.l[lb].width == L.width) {
+                        t->pr_below = &t->tl.l[lb];
+                        t->pr_below_zin = t->zs[lb];
+                    }
+                }
 #define NF_CALL(WW) coupling_backward<WW>(t, g, L, t->zs[l], invB, zmix_in, Am, dA, st, zlat)
                 NF_WIDTH_SWITCH(L.width, NF_CALL)
 #undef NF_CALL

@@ -646,342 +646,25 @@ constexpr size_t pr_bwd_lds(int stage, int nw)
 template <int STAGE, bool MIX, int NW>
 __global__ __launch_bounds__(64 * NW) void k_pr_bwd(Geo g, PrBwdArgs a)
 {
-    constexpr int W = 32, TPW = 32 / NW, OWN = TPW / 2, NTH = 64 * NW;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    PR_TL(0);
-    constexpr int NB = pr_bwd_nb(STAGE), NT = pr_bwd_tiles(STAGE);
-    constexpr int kStrip = STAGE == 2 ? TPW : 1;   // stage C keeps the rows of its shift-add in registers: the strip loop is unrolled
-    float *const z0s = smem;                   // [2][PL]
-    float *const gus = z0s + 2 * PR_PL;        // [PL][4] zero-bordered gu
-    float *const imgF = gus + 4 * PR_PL;       // A1 .. B2
-    float *const imgBs = imgF + PR_A3;         // A3T ..
-    float *const bnc = imgBs + NB;             // bn1 (64), bn2 (64), bb2 (64), bb1 (64) by (kind, g, v)
-    float *const tiles = bnc + 256;            // [NW][NT][32][36]
-    float *const exch = tiles + NW * NT * 32 * PR_RP;   // [NW][2][32][4] (stage C); stage A: column sums [2][NW][64] + [40]
-    const int t = threadIdx.x, w = t >> 6, lane = t & 63, n = lane & 31, gh = lane >> 5, row0 = w * TPW;
-    const float4 *const wf4 = reinterpret_cast<const float4 *>(imgF);
-    const float4 *const wr4 = reinterpret_cast<const float4 *>(imgBs) - PR_A3T / 4;   // index with the PR_* offsets of the backward images
-    const int npatch = (int)(g.npix / g.HW);
-    // the first patch is requested ahead of the set-up (its latency runs under the image copies and the moment finalisation)
-    float4 zv[OWN], gv[OWN];
-    [[maybe_unused]] float4 uv[OWN];
-    auto load_patch = [&](int b) {
-#pragma unroll
-        for (int m = 0; m < OWN; ++m) {
-            const int64_t p = (int64_t)b * 1024 + (row0 + 2 * m + gh) * 32 + n;
-            zv[m] = reinterpret_cast<const float4 *>(a.zin)[p];
-            if (STAGE == 0) {
-                uv[m] = reinterpret_cast<const float4 *>(a.u)[p];
-                gv[m] = a.zlat ? reinterpret_cast<const float4 *>(a.zlat)[p] : reinterpret_cast<const float4 *>(a.dz)[p];
-            } else {
-                gv[m] = reinterpret_cast<const float4 *>(a.gu)[p];
-            }
-        }
-    };
-    if ((int)blockIdx.x < npatch) load_patch(blockIdx.x);
-    for (int i = t; i < PR_A3 / 4; i += NTH) reinterpret_cast<float4 *>(imgF)[i] = reinterpret_cast<const float4 *>(a.img)[i];
-    for (int i = t; i < NB / 4; i += NTH) reinterpret_cast<float4 *>(imgBs)[i] = reinterpret_cast<const float4 *>(a.img + PR_A3T)[i];
-    for (int i = t; i < 6 * PR_PL; i += NTH) z0s[i] = 0.0f;
-    pr_load_bn(bnc, a.bn1, 0);
-    pr_load_bn(bnc + 64, a.bn2, 64);
-    if (STAGE == 1) pr_bnb_finalize<NW>(a.bstats_in, a.nred, a.n, bnc + 128, a.bb2);
-    if (STAGE == 2) {
-        pr_load_bn(bnc + 128, a.bb2, 128);
-        pr_bnb_finalize<NW>(a.bstats_in, a.nred, a.n, bnc + 192, a.bb1);
-    }
-    float *const tile0 = tiles + (w * NT) * 32 * PR_RP;
-    [[maybe_unused]] float *const tile1 = tile0 + (NT - 1) * 32 * PR_RP;
+#include "nf_train_pr_bwd.inc"
+}
 
-    // per-stage accumulators
-    float sA[16], sQ[16];                      // A: sums of BN2's backward; B: of BN1's
-    [[maybe_unused]] float gb[16];             // B: d l_2/b; C: d l_1/b
-    v16f D0 = pr_zero16();                     // A: d l_last/W taps 0..7; B: d l_2/W; C: d l_1/W
-    [[maybe_unused]] v16f D1 = pr_zero16();    // A: tap 8
-    [[maybe_unused]] float S0 = 0.0f, S1 = 0.0f;
-    [[maybe_unused]] float tail[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    [[maybe_unused]] float accA[16];
-#pragma unroll
-    for (int v = 0; v < 16; ++v) sA[v] = sQ[v] = gb[v] = accA[v] = 0.0f;
-    [[maybe_unused]] float e3[4] = {1.f, 1.f, 1.f, 1.f}, sc = 0.0f;
-    if (STAGE == 0) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) e3[k] = expf(kLogscale * a.tail3[4 + k]);
-        sc = a.tail3[8];
-    }
-    PrLaneMasks lm;
-    lm.ml = n > 0 ? 1.0f : 0.0f;
-    lm.mr = n < 31 ? 1.0f : 0.0f;
-    lm.mg0 = gh == 0 ? 1.0f : 0.0f;
-    lm.mg1 = gh == 1 ? 1.0f : 0.0f;
-    lm.ml0 = lm.ml * lm.mg0;
-    lm.mr1 = lm.mr * lm.mg1;
-    // pixel-K products: lane (col = n, half = gh) of the A / B operand
-    const int wq = n & 3, wd0 = ((n >> 2) / 3 - 1) * PR_WP + ((n >> 2) % 3 - 1), wd1 = PR_WP + 1;   // A: d l_last/W columns (tap, q)
-    const int w1tap = n >> 1, w1ch = n & 1, w1da = (w1tap / 3 - 1) * PR_WP + (w1tap % 3 - 1);       // C: d l_1/W rows (tap, c)
-    __syncthreads();
-    PR_TL(1);
-    for (int b = blockIdx.x; b < npatch; b += gridDim.x) {
-        const int64_t pb = (int64_t)b * 1024;
-#pragma unroll
-        for (int m = 0; m < OWN; ++m) {
-            const int64_t p = pb + (row0 + 2 * m + gh) * 32 + n;
-            if (STAGE == 0) {
-                // affine / tanh / exp(3 logs) backward from the kept l_last output u (k_c3_bwd)
-                float4 d = gv[m];
-                if (a.zlat) d = make_float4(d.x * a.invB, d.y * a.invB, d.z * a.invB, d.w * a.invB);
-                const float uu[4] = {uv[m].x, uv[m].y, uv[m].z, uv[m].w}, z1[2] = {zv[m].z, zv[m].w}, gx1[2] = {d.z, d.w};
-                float go[4], o[4], guv[4], gz1[2];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) o[k] = uu[k] * e3[k];
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const float th = tanhf(o[2 + k]), E = expf(sc * th);
-                    gz1[k] = gx1[k] * E;
-                    const float gls = gx1[k] * z1[k] * E - a.invB;   // loss = mean(-(sum ls + ...))
-                    tail[8] = fmaf(gls, th, tail[8]);
-                    go[k] = gx1[k];                                  // shift
-                    go[2 + k] = gls * sc * (1.0f - th * th);         // raw
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    guv[k] = go[k] * e3[k];
-                    tail[4 + k] = fmaf(kLogscale * go[k], o[k], tail[4 + k]);
-                    tail[k] += guv[k];
-                }
-                gv[m] = make_float4(guv[0], guv[1], guv[2], guv[3]);
-                reinterpret_cast<float4 *>(a.gu)[p] = gv[m];
-                d.z = gz1[0];
-                d.w = gz1[1];
-                reinterpret_cast<float4 *>(a.dz2)[p] = d;
-            }
-        }
-        if (b != (int)blockIdx.x) __syncthreads();   // the previous patch's tiles have been read
-#pragma unroll
-        for (int m = 0; m < OWN; ++m) {
-            const int tp = (row0 + 2 * m + gh + 1) * PR_WP + n + 1;
-            z0s[tp] = zv[m].x;
-            z0s[PR_PL + tp] = zv[m].y;
-            reinterpret_cast<float4 *>(gus)[tp] = gv[m];
-        }
-        if (b + (int)gridDim.x < npatch) load_patch(b + gridDim.x);   // the next patch of this workgroup: in flight during the strip loop
-        __syncthreads();
-        PR_TL(2);
-        [[maybe_unused]] float cp[TPW][4];
-        if (STAGE == 2) {
-#pragma unroll
-            for (int k = 0; k < TPW; ++k)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) cp[k][j] = 0.0f;
-        }
-#pragma unroll kStrip
-        for (int k = 0; k < TPW; ++k) {
-            const int r = row0 + k;
-            v16f x1 = pr_l1(wf4, z0s + gh * PR_PL + r * PR_WP + n, lane, gh);
-            pr_bn(x1, bnc, gh);
-            v16f x2 = pr_mm16<true>(wf4 + PR_A2 / 4, x1, pr_bias(wf4, PR_B2 / 4, gh), lane);
-            pr_bn(x2, bnc + 64, gh);
-            // transposed l_last: g_a2[c] = sum_(tap, q) W3[tap][c][q] gu[p - tap][q]
-            v16f ga = pr_zero16();
-            {
-                const float *gt = gus + ((r + 1) * PR_WP + n + 1) * 4 + 2 * gh;
-#pragma unroll
-                for (int grp = 0; grp < 5; ++grp) {
-                    const float4 aw = wr4[PR_A3T / 4 + grp * 64 + lane];
-                    const float as[4] = {aw.x, aw.y, aw.z, aw.w};
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) {
-                        const int tap = grp * 2 + s2;
-                        if (tap < 9) {
-                            const float2 bv = *reinterpret_cast<const float2 *>(gt - ((tap / 3 - 1) * PR_WP + (tap % 3 - 1)) * 4);
-                            ga = __builtin_amdgcn_mfma_f32_32x32x2f32(as[2 * s2], bv.x, ga, 0, 0, 0);
-                            ga = __builtin_amdgcn_mfma_f32_32x32x2f32(as[2 * s2 + 1], bv.y, ga, 0, 0, 0);
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int v = 0; v < 16; ++v) ga[v] = x2[v] > 0.0f ? ga[v] : 0.0f;
-            if (STAGE == 0) {
-#pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    sA[v] += ga[v];
-                    sQ[v] = fmaf(ga[v], x2[v], sQ[v]);
-                }
-                // d l_last/W[tap][i][q] = sum_p a2[p][i] gu[p - tap][q]: K = the 32 pixels of the row
-                wave_lds_fence();
-                pr_park<true>(tile0, x2, n, gh);
-                wave_lds_fence();
-                {   // (straight-line: every operand of the 32 products is requested before the first one is used; lanes without a
-                    // tap-8 column read entry 0 of the tile — the zero border — instead of branching)
-                    const float *g0 = gus + ((r + 1) * PR_WP + gh + 1 - wd0) * 4 + wq;
-                    const float *g1 = n < 4 ? gus + ((r + 1) * PR_WP + gh + 1 - wd1) * 4 + wq : gus;
-                    const int st1 = n < 4 ? 8 : 0;
-                    const float *ta = tile0 + gh * PR_RP + n;
-#pragma unroll
-                    for (int kk = 0; kk < 16; ++kk) {
-                        const float b0 = g0[kk * 8], b1 = g1[kk * st1], av = ta[kk * 2 * PR_RP];
-                        S0 += b0;
-                        S1 += b1;
-                        D0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, D0, 0, 0, 0);
-                        D1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, D1, 0, 0, 0);
-                    }
-                }
-                continue;
-            }
-            // BN2 backward: g_h2 = rstd2 (g - mean(g) - xhat2 mean(g xhat2))
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 rs = *reinterpret_cast<const float4 *>(bnc + 64 + 32 + gh * 16 + 4 * q);
-                const float4 ba = *reinterpret_cast<const float4 *>(bnc + 128 + gh * 16 + 4 * q);
-                const float4 bq = *reinterpret_cast<const float4 *>(bnc + 128 + 32 + gh * 16 + 4 * q);
-                ga[4 * q + 0] = rs.x * (ga[4 * q + 0] - ba.x - x2[4 * q + 0] * bq.x);
-                ga[4 * q + 1] = rs.y * (ga[4 * q + 1] - ba.y - x2[4 * q + 1] * bq.y);
-                ga[4 * q + 2] = rs.z * (ga[4 * q + 2] - ba.z - x2[4 * q + 2] * bq.z);
-                ga[4 * q + 3] = rs.w * (ga[4 * q + 3] - ba.w - x2[4 * q + 3] * bq.w);
-            }
-            // transposed l_2 + ReLU mask
-            v16f g1 = pr_mm16<false>(wr4 + PR_A2T / 4, ga, pr_zero16(), lane);
-#pragma unroll
-            for (int v = 0; v < 16; ++v) g1[v] = x1[v] > 0.0f ? g1[v] : 0.0f;
-            if (STAGE == 1) {
-#pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    gb[v] += ga[v];
-                    sA[v] += g1[v];
-                    sQ[v] = fmaf(g1[v], x1[v], sQ[v]);
-                }
-                // d l_2/W[i][j] = sum_p a1[p][i] g_h2[p][j]
-                wave_lds_fence();
-                pr_park<true>(tile0, x1, n, gh);
-                pr_park<false>(tile1, ga, n, gh);
-                wave_lds_fence();
-#pragma unroll
-                for (int kk = 0; kk < 16; ++kk) {
-                    const int px = 2 * kk + gh;
-                    D0 = __builtin_amdgcn_mfma_f32_32x32x2f32(tile0[px * PR_RP + n], tile1[px * PR_RP + n], D0, 0, 0, 0);
-                }
-                continue;
-            }
-            // BN1 backward
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 rs = *reinterpret_cast<const float4 *>(bnc + 32 + gh * 16 + 4 * q);
-                const float4 ba = *reinterpret_cast<const float4 *>(bnc + 192 + gh * 16 + 4 * q);
-                const float4 bq = *reinterpret_cast<const float4 *>(bnc + 192 + 32 + gh * 16 + 4 * q);
-                g1[4 * q + 0] = rs.x * (g1[4 * q + 0] - ba.x - x1[4 * q + 0] * bq.x);
-                g1[4 * q + 1] = rs.y * (g1[4 * q + 1] - ba.y - x1[4 * q + 1] * bq.y);
-                g1[4 * q + 2] = rs.z * (g1[4 * q + 2] - ba.z - x1[4 * q + 2] * bq.z);
-                g1[4 * q + 3] = rs.w * (g1[4 * q + 3] - ba.w - x1[4 * q + 3] * bq.w);
-            }
-#pragma unroll
-            for (int v = 0; v < 16; ++v) gb[v] += g1[v];
-            // d l_1/W[tap][c][j] = sum_p z[p + tap][c] g_h1[p][j]: rows (tap, c) = 18 of the 32
-            wave_lds_fence();
-            pr_park<false>(tile0, g1, n, gh);
-            wave_lds_fence();
-            {   // (rows beyond the 18 read entry 0 of the tile: the zero border)
-                const float *za = n < 18 ? z0s + w1ch * PR_PL + (r + 1) * PR_WP + gh + 1 + w1da : z0s;
-                const int sta = n < 18 ? 2 : 0;
-                const float *tb = tile0 + gh * PR_RP + n;
-#pragma unroll 8
-                for (int kk = 0; kk < 16; ++kk) D0 = __builtin_amdgcn_mfma_f32_32x32x2f32(za[kk * sta], tb[kk * 2 * PR_RP], D0, 0, 0, 0);
-            }
-            // transposed l_1: Q[p][(tap', c)] with mirrored taps, then the forward's shift-add
-            v16f qp;
-            v4f qc;
-            pr_taps<false>(wr4 + PR_A1Q / 4, wr4 + PR_A1QC / 4, g1, lane, gh, qp, qc);
-            pr_shift_add<TPW, NW>(qp, qc, k, cp, lm, exch, w, n, gh);
-        }
-        if (STAGE == 2) {
-            __syncthreads();
-            pr_shift_join<TPW, NW>(cp, exch, w, n, gh);
-            [[maybe_unused]] float mm[16];   // (read here, not ahead of the strip loop: 16 registers the loop needs)
-            if (MIX) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) mm[i] = a.A[i];
-            }
-#pragma unroll
-            for (int m = 0; m < OWN; ++m) {
-                const int64_t p = pb + (row0 + 2 * m + gh) * 32 + n;
-                const float a0 = pr_half_sums(cp[2 * m][0], cp[2 * m + 1][0]), a1 = pr_half_sums(cp[2 * m][1], cp[2 * m + 1][1]);
-                const float4 dv = reinterpret_cast<const float4 *>(a.dz2)[p];
-                const float d[4] = {dv.x + a0, dv.y + a1, dv.z, dv.w};
-                if (MIX) {
-                    const float4 zq = reinterpret_cast<const float4 *>(a.zmix_in)[p];
-                    const float zi[4] = {zq.x, zq.y, zq.z, zq.w};
-                    float o[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        o[i] = mm[i * 4] * d[0] + mm[i * 4 + 1] * d[1] + mm[i * 4 + 2] * d[2] + mm[i * 4 + 3] * d[3];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) accA[i * 4 + j] = fmaf(zi[i], d[j], accA[i * 4 + j]);
-                    }
-                    reinterpret_cast<float4 *>(a.dz_out)[p] = make_float4(o[0], o[1], o[2], o[3]);
-                } else {
-                    reinterpret_cast<float4 *>(a.dz_out)[p] = make_float4(d[0], d[1], d[2], d[3]);
-                }
-            }
-        }
-    }
-    // ---- reductions: everything is parked in LDS (the tiles and images are dead), one barrier, then added up and stored ----
-    PR_TL(3);
-    __syncthreads();
-    float *const rD0 = smem;                        // [NW][16][64]
-    float *const rD1 = rD0 + NW * 1024;             // stage A: [NW][16][64]
-    float *const rS = rD1 + (STAGE == 0 ? NW * 1024 : 0);   // three per-channel sums [NW][4][16] each
-    float *const rT = rS + 3 * NW * 64;             // stage A: [NW][4][9]; stage C: [NW][4][16]
-    float *const rC = rT + NW * 64;                 // stage A: column sums [2][NW][64]
-    static_assert(pr_bwd_lds(STAGE, NW) >= (size_t)((STAGE == 0 ? 2 : 1) * NW * 1024 + 3 * NW * 64 + NW * 64 + 2 * NW * 64) * sizeof(float),
-                  "the reduction regions must fit the kernel's LDS");
-    pr_tile_put(D0, rD0);
-    if (STAGE == 0) {
-        pr_tile_put(D1, rD1);
-        pr_chan_put<NW>(sA, rS);
-        pr_chan_put<NW>(sQ, rS + NW * 64);
-        pr_acc_put<9, NW>(tail, rT);
-        rC[(0 * NW + w) * 64 + lane] = S0;
-        rC[(1 * NW + w) * 64 + lane] = S1;
-    } else if (STAGE == 1) {
-        pr_chan_put<NW>(sA, rS);
-        pr_chan_put<NW>(sQ, rS + NW * 64);
-        pr_chan_put<NW>(gb, rS + 2 * NW * 64);
-    } else {
-        pr_chan_put<NW>(gb, rS);
-        if (MIX) pr_acc_put<16, NW>(accA, rT);
+// Stage C of a coupling and stage A of the coupling below it in ONE launch: A of a patch needs nothing but C of the same patch (the
+// d loss / d z the same lanes have just stored), so a workgroup walks its patches through C, then through A — one launch and one
+// wait for the slowest workgroup less per coupling.
+template <bool MIXC, int NW>
+__global__ __launch_bounds__(64 * NW) void k_pr_bwd_CA(Geo g, PrBwdArgs a, PrBwdArgs below)
+{
+    {
+        constexpr int STAGE = 2;
+        constexpr bool MIX = MIXC;
+#include "nf_train_pr_bwd.inc"
     }
     __syncthreads();
-    PR_TL(4);
-    if (STAGE == 0) {
-        const Acc dst = a.G + a.off_w3;
-        pr_tile_get<NW>(rD0, dst, g.nslot, [](int i, int c) { return (c >> 2) * (W + 1) * 4 + i * 4 + (c & 3); });
-        pr_tile_get<NW>(rD1, dst, g.nslot, [](int i, int c) { return c < 4 ? 8 * (W + 1) * 4 + i * 4 + c : -1; });
-        pr_chan_get<NW>(rS, a.bstats, g.nslot, t);
-        pr_chan_get<NW>(rS + NW * 64, a.bstats + 32, g.nslot, t - 32);
-        pr_acc_get<9, NW>(rT, a.G + a.off_w3 + 36 * (W + 1), g.nslot, t - 64);
-        // the indicator channel's gradient: the gu of the pixels whose tap falls on the padding ring = the column sum of ALL of gu
-        // (the centre tap's) minus the column sum over the taps that land inside
-        const int tq = t - 128;
-        if (tq >= 0 && tq < 36) {   // tq = tap * 4 + q
-            auto col = [&](int c36) {
-                const int kq = c36 < 32 ? 0 : 1, c = c36 < 32 ? c36 : c36 - 32;
-                float tot = 0.0f;
-#pragma unroll
-                for (int ww = 0; ww < NW; ++ww) tot += rC[(kq * NW + ww) * 64 + c] + rC[(kq * NW + ww) * 64 + c + 32];
-                return tot;
-            };
-            float *d = dst.p + (size_t)((tq >> 2) * (W + 1) * 4 + W * 4 + (tq & 3)) * NSLOT;
-            d[blockIdx.x] = col(16 + (tq & 3)) - col(tq);
-            for (int q = blockIdx.x + gridDim.x; q < g.nslot; q += gridDim.x) d[q] = 0.0f;
-        }
-    } else if (STAGE == 1) {
-        pr_tile_get<NW>(rD0, a.G + a.off_w2, g.nslot, [](int i, int j) { return i * W + j; });
-        pr_chan_get<NW>(rS, a.bstats, g.nslot, t);
-        pr_chan_get<NW>(rS + NW * 64, a.bstats + 32, g.nslot, t - 32);
-        pr_chan_get<NW>(rS + 2 * NW * 64, a.G + a.off_w2 + W * W, g.nslot, t - 64);
-    } else {
-        pr_tile_get<NW>(rD0, a.G + a.off_w1, g.nslot, [](int i, int j) { return i < 18 ? (i >> 1) * 2 * W + (i & 1) * W + j : -1; });
-        pr_chan_get<NW>(rS, a.G + a.off_b1, g.nslot, t);
-        if (MIX) pr_acc_get<16, NW>(rT, a.dA, g.nslot, t - 32);
+    {
+        constexpr int STAGE = 0;
+        constexpr bool MIX = false;
+        const PrBwdArgs &a = below;
+#include "nf_train_pr_bwd.inc"
     }
-    PR_TL(7);
 }

@@ -45,17 +45,20 @@ def test_patch_resident_stages_against_the_stage_kernels(monkeypatch):
     v = trained_like_variables(arch, 32, seed=2)
     x, y = make_inputs(B, 32, 32, seed=22)
     res = {}
-    for key, pr, grid in (("wide", "0", None), ("pr8", "1", None), ("pr4", "2", None), ("pr8_grid7", "1", 7)):
+    # NF_TRAIN_PR bit 2 / bit 3: stage 0 of the coupling above / stage A of the coupling below in launches of their own
+    for key, pr, grid in (("wide", "0", None), ("pr8", "1", None), ("pr4", "2", None), ("pr8_grid7", "1", 7), ("pr8_unfused", "13", None)):
         tr, res[key] = _run(monkeypatch, pr, arch, v, x, y, grid)
         tr.close()
     g0, l0, p0 = res["wide"]
     tol = 8.0 / (B * 1024)
-    for key in ("pr8", "pr4", "pr8_grid7"):
+    for key in ("pr8", "pr4", "pr8_grid7", "pr8_unfused"):
         g, l, p = res[key]
         assert np.allclose(l, l0, rtol=1e-6, atol=0), (key, l, l0)
         assert np.abs(g - g0).max() <= tol * np.abs(g0).max(), (key, np.abs(g - g0).max(), np.abs(g0).max())
         assert np.allclose(p, p0, rtol=1e-5, atol=1e-5), key
     assert not np.array_equal(res["pr8"][0], res["wide"][0])      # it really is another code path
+    # fused or not, a stage does the same arithmetic in the same order
+    assert np.array_equal(res["pr8"][0], res["pr8_unfused"][0]) and np.array_equal(res["pr8"][2], res["pr8_unfused"][2])
 
 
 def test_patch_resident_training_is_bit_reproducible(monkeypatch):
