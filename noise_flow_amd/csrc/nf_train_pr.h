@@ -137,16 +137,17 @@ __device__ __forceinline__ v16f pr_l1(const float4 *wb4, const float *zb, int la
     }
     return d;
 }
-// x <- (x - mean) * rstd, constants by (g, v): bnc[g * 16 + v] = mean, bnc[32 + g * 16 + v] = rstd
+// x <- xhat = x * rstd + c, c = -mean * rstd: ONE fma per element and the one expression every stage shares, so that a ReLU mask
+// re-derived in a later stage is the forward's.  Constants by (g, v): bnc[g * 16 + v] = c, bnc[32 + g * 16 + v] = rstd
 __device__ __forceinline__ void pr_bn(v16f &x, const float *bnc, int g)
 {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const float4 m = *reinterpret_cast<const float4 *>(bnc + g * 16 + 4 * q), r = *reinterpret_cast<const float4 *>(bnc + 32 + g * 16 + 4 * q);
-        x[4 * q + 0] = (x[4 * q + 0] - m.x) * r.x;
-        x[4 * q + 1] = (x[4 * q + 1] - m.y) * r.y;
-        x[4 * q + 2] = (x[4 * q + 2] - m.z) * r.z;
-        x[4 * q + 3] = (x[4 * q + 3] - m.w) * r.w;
+        x[4 * q + 0] = fmaf(x[4 * q + 0], r.x, m.x);
+        x[4 * q + 1] = fmaf(x[4 * q + 1], r.y, m.y);
+        x[4 * q + 2] = fmaf(x[4 * q + 2], r.z, m.z);
+        x[4 * q + 3] = fmaf(x[4 * q + 3], r.w, m.w);
     }
 }
 // D = init + sum_s A[s] * f(B[s]) over 16 K steps, A image [4][64][4] at wa4
@@ -323,10 +324,14 @@ __device__ __forceinline__ void pr_park(float *tile, const v16f &x, int n, int g
     }
 }
 // permuted copy of a [mean W][rstd W] pair (or the two BN-backward means) into (g, v) order: dst[kind * 32 + g * 16 + v]
+template <bool BN = false>   // BN: src = [mean][rstd] -> [c = -mean rstd][rstd] (pr_bn)
 __device__ __forceinline__ void pr_load_bn(float *dst, const float *__restrict__ src, int t0)
 {
     const int t = (int)threadIdx.x - t0;
-    if (t >= 0 && t < 64) dst[t] = src[(t >> 5) * 32 + pr_chan(t & 15, (t >> 4) & 1)];
+    if (t >= 0 && t < 64) {
+        const int ch = pr_chan(t & 15, (t >> 4) & 1);
+        dst[t] = (BN && t < 32) ? -src[ch] * src[32 + ch] : src[(t >> 5) * 32 + ch];
+    }
 }
 
 // The batch moments are finalised by their CONSUMER: every workgroup adds the producer's `nred` slots up itself (2 NW threads per
@@ -363,7 +368,7 @@ __device__ __forceinline__ void pr_bn_finalize(Acc stats, int nred, double n, fl
         double v = sq / n - m * m;
         if (v < 0.0) v = 0.0;
         const float mf = (float)m, rf = (float)(1.0 / sqrt(v + (double)kBnEps));
-        bnc[gv] = mf;
+        bnc[gv] = -mf * rf;
         bnc[32 + gv] = rf;
         if (blockIdx.x == 0) {
             bn_out[c] = mf;
@@ -448,7 +453,7 @@ __global__ __launch_bounds__(64 * NW) void k_pr_fwd(Geo g, PrFwdArgs a)
     for (int i = t; i < 2 * PR_PL; i += NTH) z0s[i] = 0.0f;
     if (STAGE == 1) pr_bn_finalize<NW>(a.stats_in, a.nred, a.n, bnc, a.bn1, a.run_mean, a.run_var);
     if (STAGE == 2) {
-        pr_load_bn(bnc, a.bn1, 0);
+        pr_load_bn<true>(bnc, a.bn1, 0);
         pr_bn_finalize<NW>(a.stats_in, a.nred, a.n, bnc + 64, a.bn2, a.run_mean, a.run_var);
     }
     PrLaneMasks lm;
