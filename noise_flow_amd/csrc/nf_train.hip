@@ -1579,7 +1579,7 @@ struct nf_trainer {
     int band_cap = 320;        // pixels (rows x width, halo included) a band kernel keeps in LDS
     bool serial = false;   // NF_TRAIN_SERIAL=1: everything on the caller's stream (kernel durations without overlap, for profiling)
     int wide_mfma = 4095;   // NF_TRAIN_WIDE_MFMA: width-32 stages on the matrix cores (bit 0 filter gradients, 1 l_2 forward, 2 l_2 backward, 3 statistics finalisers, 4 l_last forward, 5 l_last transposed, 6 l_1 transposed, 7 filter gradients inside the stage that holds their operands, 8 l_1 forward, 11 affine/tanh backward inside the transposed l_last; 0: layer kernels only)
-    int pr = 1;            // NF_TRAIN_PR: width 32 on 32x32 patches on the patch-resident stages of nf_train_pr.h (1: 8 wavefronts per patch, 2: 4; + 4 / + 8: no forward / backward launch fusion; 0: the stage kernels of nf_train_wide.h)
+    int pr = 1;            // NF_TRAIN_PR: width 32 on 32x32 patches on the patch-resident stages of nf_train_pr.h (1: 8 wavefronts per patch, 2: 4; + 4 / + 8: no forward / backward launch fusion, + 16: no side-stream d l_last/W; 0: the stage kernels of nf_train_wide.h)
     float *pr_img = nullptr;   // [couplings][PR_SIZE] packed weights of this step (k_pr_pack)
     // the coupling above the one a patch-resident forward is launched for, when only a Conv2d1x1 lies between them: its stage 0 rides in
     // this coupling's last launch (set by the layer loop; pr_f0_done: the next call's stage 0 already ran)
@@ -1697,15 +1697,20 @@ namespace {
 template <int NW>
 int pr_set_attributes_nw()
 {
+    const size_t ca = std::max(pr_bwd_lds(2, NW), pr_bwd_lds(0, NW));
     struct { const void *fn; size_t lds; } ks[] = {
         {reinterpret_cast<const void *>(&k_pr_fwd<2, false, NW>), pr_fwd_lds(2, NW)},
         {reinterpret_cast<const void *>(&k_pr_fwd<2, false, NW, true>), pr_fwd_lds(2, NW)},
-        {reinterpret_cast<const void *>(&k_pr_bwd<0, false, NW>), pr_bwd_lds(0, NW)},
-        {reinterpret_cast<const void *>(&k_pr_bwd<1, false, NW>), pr_bwd_lds(1, NW)},
-        {reinterpret_cast<const void *>(&k_pr_bwd<2, false, NW>), pr_bwd_lds(2, NW)},
-        {reinterpret_cast<const void *>(&k_pr_bwd<2, true, NW>), pr_bwd_lds(2, NW)},
-        {reinterpret_cast<const void *>(&k_pr_bwd_CA<true, NW>), std::max(pr_bwd_lds(2, NW), pr_bwd_lds(0, NW))},
-        {reinterpret_cast<const void *>(&k_pr_bwd_CA<false, NW>), std::max(pr_bwd_lds(2, NW), pr_bwd_lds(0, NW))},
+        {reinterpret_cast<const void *>(&k_pr_bwd<0, false, NW, 0>), pr_bwd_lds(0, NW)},
+        {reinterpret_cast<const void *>(&k_pr_bwd<0, false, NW, 1>), pr_bwd_lds(0, NW)},
+        {reinterpret_cast<const void *>(&k_pr_bwd<0, false, NW, 2>), pr_bwd_lds(0, NW)},
+        {reinterpret_cast<const void *>(&k_pr_bwd<1, false, NW, 2>), pr_bwd_lds(1, NW)},
+        {reinterpret_cast<const void *>(&k_pr_bwd<2, false, NW, 2>), pr_bwd_lds(2, NW)},
+        {reinterpret_cast<const void *>(&k_pr_bwd<2, true, NW, 2>), pr_bwd_lds(2, NW)},
+        {reinterpret_cast<const void *>(&k_pr_bwd_CA<true, NW, 0>), ca},
+        {reinterpret_cast<const void *>(&k_pr_bwd_CA<true, NW, 2>), ca},
+        {reinterpret_cast<const void *>(&k_pr_bwd_CA<false, NW, 0>), ca},
+        {reinterpret_cast<const void *>(&k_pr_bwd_CA<false, NW, 2>), ca},
     };
     for (const auto &k : ks) {
         if (k.lds <= 64 * 1024) continue;
@@ -1818,11 +1823,24 @@ PrBwdArgs pr_bwd_args(nf_trainer *t, const Geo &g, const TLayer &L, const float 
     a.zlat = zlat;
     a.dz = t->dz;
     a.dz2 = t->dz2;
-    a.gu = t->gu[0];
+    a.gu = t->gu[L.aux % 3];   // (by coupling index: the filter-gradient launches of a coupling may still read it on the side stream)
     a.invB = invB;
     a.G = t->acc(0);
     a.bstats = t->acc(c.d_bs2);
     return a;
+}
+
+// Small minibatches leave CUs idle (138 patches on 256): d l_last/W — 32 of the 75 matrix instructions per tile of stage A — then runs
+// as a launch of its own on the side stream, in the idle CUs (GRAD 1: the CNN recomputed once more up to the product's operands; at
+// most as many workgroups as there are idle CUs: a stage keeps ~100 KB of LDS, so two never share a CU), and stage A drops it
+// (GRAD 0).  The products of stages B and C stay where they are: offloaded too (measured), the side stream needs the CUs the next
+// main launch is waiting for, and every extra launch + event pair costs ~20 us of host time per coupling.
+inline bool pr_split(const nf_trainer *t, const Geo &g)
+{
+    const int64_t npatch = g.npix / g.HW;
+    // (its launch walks ceil(patches / idle CUs) patches per workgroup: beyond 3/4 of the CUs busy it would outlast the main launches —
+    // 250 patches on 6 workgroups measured 6.7 ms per step; below a quarter the stages are too short to gain)
+    return (t->pr & 16) == 0 && !t->serial && 4 * npatch <= 3 * (int64_t)t->n_cu && 4 * npatch >= t->n_cu;
 }
 
 template <int NW>
@@ -1832,19 +1850,36 @@ void pr_coupling_backward(nf_trainer *t, const Geo &g, const TLayer &L, const fl
     constexpr int w = 32;
     const Cpl &c = t->cpl[L.aux];
     const unsigned grid = pr_grid(t, g);
+    const bool split = pr_split(t, g);
+    const int par = L.aux % 3;
+    hipStream_t sd = t->serial ? st : t->side;
+    auto wait_side = [&](int p) {   // the side work of the coupling that used buffer set p last
+        if (t->done_pending[p]) {
+            (void)hipStreamWaitEvent(st, t->ev_done[p], 0);
+            t->done_pending[p] = false;
+        }
+    };
+    auto fork = [&] {               // the side stream picks up behind the main stream's last launch
+        (void)hipEventRecord(t->ev_fork[0], st);
+        (void)hipStreamWaitEvent(sd, t->ev_fork[0], 0);
+    };
     PrBwdArgs a = pr_bwd_args(t, g, L, zin, invB, zlat, grid);
     if (!t->pr_a_done) {   // (else: stage A rode in the last launch of the coupling above)
+        wait_side(par);
 #ifdef NF_PR_TIMELINE
-        a.dz_out = t->gu[1];   // the stamps of stage A (nf_train_pr.h, PR_TL)
+        a.dz_out = t->gu[(par + 1) % 3];   // the stamps of stage A (nf_train_pr.h, PR_TL)
 #endif
-        hipLaunchKernelGGL((k_pr_bwd<0, false, NW>), dim3(grid), dim3(64 * NW), pr_bwd_lds(0, NW), st, g, a);
+        if (split)
+            hipLaunchKernelGGL((k_pr_bwd<0, false, NW, 0>), dim3(grid), dim3(64 * NW), pr_bwd_lds(0, NW), st, g, a);
+        else
+            hipLaunchKernelGGL((k_pr_bwd<0, false, NW, 2>), dim3(grid), dim3(64 * NW), pr_bwd_lds(0, NW), st, g, a);
 #ifdef NF_PR_TIMELINE
         {   // average phase lengths over the workgroups, printed for a few launches (100 MHz counter: 10 ns units)
             static int shown = 0;
             if (shown < 40 && (++shown % 8) == 0) {
                 (void)hipStreamSynchronize(st);
                 std::vector<long long> h((size_t)grid * 16);
-                (void)hipMemcpy(h.data(), t->gu[1], h.size() * sizeof(long long), hipMemcpyDeviceToHost);
+                (void)hipMemcpy(h.data(), t->gu[(par + 1) % 3], h.size() * sizeof(long long), hipMemcpyDeviceToHost);
                 static const int ph[6] = {0, 1, 2, 3, 4, 7};   // the stamps the kernel takes
                 double d[6] = {0};
                 long long t0 = h[0], t1 = h[7];
@@ -1861,33 +1896,43 @@ void pr_coupling_backward(nf_trainer *t, const Geo &g, const TLayer &L, const fl
 #endif
     }
     t->pr_a_done = false;
+    if (split) {
+        const unsigned idle = (unsigned)t->n_cu - grid;
+        fork();
+        hipLaunchKernelGGL((k_pr_bwd<0, false, NW, 1>), dim3(std::max(1u, std::min(grid, idle))), dim3(64 * NW), pr_bwd_lds(0, NW), sd, g, a);
+        (void)hipEventRecord(t->ev_done[par], sd);
+        t->done_pending[par] = true;
+    }
     sync_slots(t, t->acc(c.d_bs2), 2 * w, g.nslot, st);
     a.bstats_in = t->acc(c.d_bs2);
     a.bstats = t->acc(c.d_bs1);
-    hipLaunchKernelGGL((k_pr_bwd<1, false, NW>), dim3(grid), dim3(64 * NW), pr_bwd_lds(1, NW), st, g, a);
+    hipLaunchKernelGGL((k_pr_bwd<1, false, NW, 2>), dim3(grid), dim3(64 * NW), pr_bwd_lds(1, NW), st, g, a);
     sync_slots(t, t->acc(c.d_bs1), 2 * w, g.nslot, st);
     a.bstats_in = t->acc(c.d_bs1);
     a.dz_out = t->dz;
     a.dA = dA;
     a.zmix_in = zmix_in;
     a.A = A;
+    bool fused = false;
 #ifndef NF_PR_TIMELINE
     if (t->pr_below && (t->pr & 8) == 0) {
         // stage A of the coupling below in the same launch (nf_train_pr.h, k_pr_bwd_CA)
+        wait_side(t->pr_below->aux % 3);
         const PrBwdArgs an = pr_bwd_args(t, g, *t->pr_below, t->pr_below_zin, invB, nullptr, grid);
         const size_t lds = std::max(pr_bwd_lds(2, NW), pr_bwd_lds(0, NW));
-        if (zmix_in)
-            hipLaunchKernelGGL((k_pr_bwd_CA<true, NW>), dim3(grid), dim3(64 * NW), lds, st, g, a, an);
-        else
-            hipLaunchKernelGGL((k_pr_bwd_CA<false, NW>), dim3(grid), dim3(64 * NW), lds, st, g, a, an);
+        // (CA_GRAD 0: the whole stage C, stage A without its product)
+        if (zmix_in && split) hipLaunchKernelGGL((k_pr_bwd_CA<true, NW, 0>), dim3(grid), dim3(64 * NW), lds, st, g, a, an);
+        else if (zmix_in) hipLaunchKernelGGL((k_pr_bwd_CA<true, NW, 2>), dim3(grid), dim3(64 * NW), lds, st, g, a, an);
+        else if (split) hipLaunchKernelGGL((k_pr_bwd_CA<false, NW, 0>), dim3(grid), dim3(64 * NW), lds, st, g, a, an);
+        else hipLaunchKernelGGL((k_pr_bwd_CA<false, NW, 2>), dim3(grid), dim3(64 * NW), lds, st, g, a, an);
         t->pr_a_done = true;
-        return;
+        fused = true;
     }
 #endif
-    if (zmix_in)
-        hipLaunchKernelGGL((k_pr_bwd<2, true, NW>), dim3(grid), dim3(64 * NW), pr_bwd_lds(2, NW), st, g, a);
-    else
-        hipLaunchKernelGGL((k_pr_bwd<2, false, NW>), dim3(grid), dim3(64 * NW), pr_bwd_lds(2, NW), st, g, a);
+    if (!fused) {
+        if (zmix_in) hipLaunchKernelGGL((k_pr_bwd<2, true, NW, 2>), dim3(grid), dim3(64 * NW), pr_bwd_lds(2, NW), st, g, a);
+        else hipLaunchKernelGGL((k_pr_bwd<2, false, NW, 2>), dim3(grid), dim3(64 * NW), pr_bwd_lds(2, NW), st, g, a);
+    }
 }
 
 template <int W>

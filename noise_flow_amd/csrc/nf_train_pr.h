@@ -648,7 +648,7 @@ constexpr size_t pr_bwd_lds(int stage, int nw)
            sizeof(float);
 }
 
-template <int STAGE, bool MIX, int NW>
+template <int STAGE, bool MIX, int NW, int GRAD = 2>
 __global__ __launch_bounds__(64 * NW) void k_pr_bwd(Geo g, PrBwdArgs a)
 {
 #include "nf_train_pr_bwd.inc"
@@ -657,17 +657,17 @@ __global__ __launch_bounds__(64 * NW) void k_pr_bwd(Geo g, PrBwdArgs a)
 // Stage C of a coupling and stage A of the coupling below it in ONE launch: A of a patch needs nothing but C of the same patch (the
 // d loss / d z the same lanes have just stored), so a workgroup walks its patches through C, then through A — one launch and one
 // wait for the slowest workgroup less per coupling.
-template <bool MIXC, int NW>
+template <bool MIXC, int NW, int GRAD_A = 2>   // GRAD_A: stage A with (2) or without (0) its filter gradient
 __global__ __launch_bounds__(64 * NW) void k_pr_bwd_CA(Geo g, PrBwdArgs a, PrBwdArgs below)
 {
     {
-        constexpr int STAGE = 2;
+        constexpr int STAGE = 2, GRAD = 2;
         constexpr bool MIX = MIXC;
 #include "nf_train_pr_bwd.inc"
     }
     __syncthreads();
     {
-        constexpr int STAGE = 0;
+        constexpr int STAGE = 0, GRAD = GRAD_A;
         constexpr bool MIX = false;
         const PrBwdArgs &a = below;
 #include "nf_train_pr_bwd.inc"

@@ -45,8 +45,9 @@ def test_patch_resident_stages_against_the_stage_kernels(monkeypatch):
     v = trained_like_variables(arch, 32, seed=2)
     x, y = make_inputs(B, 32, 32, seed=22)
     res = {}
-    # NF_TRAIN_PR bit 2 / bit 3: stage 0 of the coupling above / stage A of the coupling below in launches of their own
-    for key, pr, grid in (("wide", "0", None), ("pr8", "1", None), ("pr4", "2", None), ("pr8_grid7", "1", 7), ("pr8_unfused", "13", None)):
+    # NF_TRAIN_PR bit 2 / bit 3: stage 0 of the coupling above / stage A of the coupling below in launches of their own; bit 4: d l_last/W
+    # inside stage A instead of on the side stream (40 patches would not take the side stream: the second test below does)
+    for key, pr, grid in (("wide", "0", None), ("pr8", "1", None), ("pr4", "2", None), ("pr8_grid7", "1", 7), ("pr8_unfused", "29", None)):
         tr, res[key] = _run(monkeypatch, pr, arch, v, x, y, grid)
         tr.close()
     g0, l0, p0 = res["wide"]
@@ -59,6 +60,29 @@ def test_patch_resident_stages_against_the_stage_kernels(monkeypatch):
     assert not np.array_equal(res["pr8"][0], res["wide"][0])      # it really is another code path
     # fused or not, a stage does the same arithmetic in the same order
     assert np.array_equal(res["pr8"][0], res["pr8_unfused"][0]) and np.array_equal(res["pr8"][2], res["pr8_unfused"][2])
+
+
+def test_patch_resident_filter_gradient_on_the_side_stream(monkeypatch):
+    """Between a quarter and three quarters of the CUs busy (here 70 patches), d l_last/W runs as a launch of its own on the side stream,
+    in the idle CUs, from the gu its stage left in HBM: the same products, each patch's in the same order — the other gradients are
+    bit-identical to the in-stage variant's, d l_last/W differs by the order its per-workgroup partials are added in at most."""
+    arch, B = "unc|unc|unc|unc", 70
+    v = trained_like_variables(arch, 32, seed=7)
+    x, y = make_inputs(B, 32, 32, seed=27)
+    res, grads = {}, {}
+    for key, pr in (("side", "1"), ("inside", "17")):
+        tr, res[key] = _run(monkeypatch, pr, arch, v, x, y, None, max_batch=B)
+        grads[key] = tr.raw_to_variables(res[key][0])
+        tr.close()
+    gs, gi = grads["side"], grads["inside"]
+    assert np.allclose(res["side"][1], res["inside"][1], rtol=0, atol=0)
+    for nm in gs:
+        a, b = np.asarray(gs[nm], np.float64), np.asarray(gi[nm], np.float64)
+        if nm.endswith("l_last/W"):
+            assert np.abs(a - b).max() <= 1e-6 * max(np.abs(b).max(), 1e-30), nm
+        else:
+            assert np.array_equal(a, b), nm
+    assert np.array_equal(res["side"][2], res["inside"][2])
 
 
 def test_patch_resident_training_is_bit_reproducible(monkeypatch):
