@@ -2287,7 +2287,13 @@ static int run_batchstats(nf_handle *h, int direction, NfLaunch a, float *moment
         const bool mc4 = pw == 4 && !h->fwd.block2.empty() && use_matrix_core();
         // NF_BS_WIDE=1: A/B aid; read per call on purpose (tests/test_gpu_batchstats.py flips it inside one process), =0 means off
         const char *bw = getenv("NF_BS_WIDE");
-        if (pw > 32 || (!mc4 && !scalar_fits) || (bw && atoi(bw) != 0))
+        // width 32 on 32x32 patches (the paper's coupling CNN on the training patch size): the evaluator runs the trainer's patch-resident
+        // forward stages on the matrix cores (csrc/nf_train_pr.h) — 3 launches per coupling instead of the scalar-weight schedule
+        // (1 024 patches: 3.7 -> 1.1 ms).  NF_TRAIN_PR=0 keeps the scalar schedule.
+        const char *pe = getenv("NF_TRAIN_PR");   // (read per call, like NF_BS_WIDE: the tests flip it inside one process)
+        const bool pr_off = pe && atoi(pe) == 0;
+        const bool pr32 = h->fwd.raw_width == 32 && a.H == 32 && a.W == 32 && !h->fwd.tiled && !pr_off;
+        if (pw > 32 || pr32 || (!mc4 && !scalar_fits) || (bw && atoi(bw) != 0))
             return run_batchstats_wide(h, direction, a, cond, moments_out, st);
     }
     const int wr = h->fwd.raw_width;   // rows of moments_out are [4][wr]; the kernels' rows [4][prog.width] (zero-padded widths)

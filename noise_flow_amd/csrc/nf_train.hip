@@ -1701,6 +1701,8 @@ int pr_set_attributes_nw()
     struct { const void *fn; size_t lds; } ks[] = {
         {reinterpret_cast<const void *>(&k_pr_fwd<2, false, NW>), pr_fwd_lds(2, NW)},
         {reinterpret_cast<const void *>(&k_pr_fwd<2, false, NW, true>), pr_fwd_lds(2, NW)},
+        {reinterpret_cast<const void *>(&k_pr_fwd<2, false, NW, false, 1>), pr_fwd_lds(2, NW)},
+        {reinterpret_cast<const void *>(&k_pr_fwd<2, false, NW, false, 2>), pr_fwd_lds(2, NW)},
         {reinterpret_cast<const void *>(&k_pr_bwd<0, false, NW, 0>), pr_bwd_lds(0, NW)},
         {reinterpret_cast<const void *>(&k_pr_bwd<0, false, NW, 1>), pr_bwd_lds(0, NW)},
         {reinterpret_cast<const void *>(&k_pr_bwd<0, false, NW, 2>), pr_bwd_lds(0, NW)},
@@ -1933,6 +1935,40 @@ void pr_coupling_backward(nf_trainer *t, const Geo &g, const TLayer &L, const fl
         if (zmix_in) hipLaunchKernelGGL((k_pr_bwd<2, true, NW, 2>), dim3(grid), dim3(64 * NW), pr_bwd_lds(2, NW), st, g, a);
         else hipLaunchKernelGGL((k_pr_bwd<2, false, NW, 2>), dim3(grid), dim3(64 * NW), pr_bwd_lds(2, NW), st, g, a);
     }
+}
+
+// a coupling of the batch-statistics evaluator (nf_bs_wide_run) on the patch-resident forward stages: in place on z, the moments of
+// both normalisations left in mom [4][32], the per-patch log-det share added to t->eldp (NLL direction)
+template <int NW>
+void pr_coupling_eval(nf_trainer *t, const Geo &g, const TLayer &L, float *z, hipStream_t st, float *mom, bool inverse)
+{
+    constexpr int w = 32;
+    const Cpl &c = t->cpl[L.aux];
+    const unsigned grid = pr_grid(t, g);
+    PrFwdArgs a{};
+    a.img = t->pr_img + (size_t)L.aux * PR_SIZE;
+    a.bn1 = t->d_flt + c.f_bn1;
+    a.bn2 = t->d_flt + c.f_bn2;
+    a.n = (double)g.npix * t->sync_world;
+    a.nred = pr_nred(t, grid);
+    a.tail3 = t->d_params + L.off + 24 * w + w * w + 36 * (w + 1);
+    a.zsrc = z;
+    a.stats = t->acc(c.d_st1);
+    hipLaunchKernelGGL((k_pr_fwd<0, false, NW>), dim3(grid), dim3(64 * NW), pr_fwd_lds(0, NW), st, g, a);
+    sync_slots(t, t->acc(c.d_st1), 2 * w, g.nslot, st);
+    a.stats_in = t->acc(c.d_st1);
+    a.stats = t->acc(c.d_st2);
+    a.mom = mom;
+    hipLaunchKernelGGL((k_pr_fwd<1, false, NW>), dim3(grid), dim3(64 * NW), pr_fwd_lds(1, NW), st, g, a);
+    sync_slots(t, t->acc(c.d_st2), 2 * w, g.nslot, st);
+    a.stats_in = t->acc(c.d_st2);
+    a.mom = mom ? mom + 2 * w : nullptr;
+    a.zout = z;
+    a.ldp = t->eldp;
+    if (inverse)
+        hipLaunchKernelGGL((k_pr_fwd<2, false, NW, false, 2>), dim3(grid), dim3(64 * NW), pr_fwd_lds(2, NW), st, g, a);
+    else
+        hipLaunchKernelGGL((k_pr_fwd<2, false, NW, false, 1>), dim3(grid), dim3(64 * NW), pr_fwd_lds(2, NW), st, g, a);
 }
 
 template <int W>
@@ -2431,7 +2467,8 @@ static int trainer_create_impl(const nf_config *cfg, const nf_layer_desc *layers
     t->n_mix = n_mix;
     const bool gemm_path = t->all_gemm || gemm_width(w);
     // width 32 on 32x32 patches: the patch-resident stages (nf_train_pr.h) — no [pixel][32] tensor exists, none is allocated
-    t->pr = (t->pr && t->wide_mfma != 0 && w == 32 && !gemm_path && cfg->height == 32 && cfg->width == 32 && n_cpl > 0) ? t->pr : 0;
+    // (the batch-statistics evaluator, a trimmed trainer otherwise on the GEMM path, takes its forward stages too)
+    t->pr = (t->pr && t->wide_mfma != 0 && w == 32 && (!gemm_path || eval_only) && cfg->height == 32 && cfg->width == 32 && n_cpl > 0) ? t->pr : 0;
     // double workspace
     size_t nd = eval_only ? 0 : n_params;
     t->d_dA = (int)nd; nd += eval_only ? 0 : 16 * (size_t)n_mix;
@@ -2488,7 +2525,13 @@ static int trainer_create_impl(const nf_config *cfg, const nf_layer_desc *layers
         NF_TRY(dev_alloc(t, (void **)&t->eldp, (size_t)max_batch * sizeof(double)));
         NF_TRY(dev_alloc(t, (void **)&t->emom, (size_t)std::max(n_cpl, 1) * 4 * w * sizeof(float)));
         NF_TRY(dev_alloc(t, (void **)&t->eAinv, (size_t)std::max(n_mix, 1) * 16 * sizeof(float)));
-        if (n_cpl > 0) {
+        if (t->pr) {   // width 32 on 32x32 patches: the patch-resident forward stages need their packed weights and nothing else
+            NF_TRY(dev_alloc(t, (void **)&t->pr_img, (size_t)n_cpl * PR_SIZE * sizeof(float)));
+            if ((rc = pr_set_attributes(t->pr)) != NF_OK) {
+                nf_trainer_destroy(t);
+                return rc;
+            }
+        } else if (n_cpl > 0) {
             float *h1 = nullptr, *h2 = nullptr;
             NF_TRY(dev_alloc(t, (void **)&h1, act * w * sizeof(float)));
             NF_TRY(dev_alloc(t, (void **)&h2, act * w * sizeof(float)));
@@ -2938,6 +2981,7 @@ int nf_bs_wide_run(nf_trainer *t, const nf_bs_wide_args &a, hipStream_t st)
                        G + t->d_ldc, t->d_flt, 0);
     if ((e = hipMemsetAsync(t->eldp, 0, (size_t)a.B * sizeof(double), st)) != hipSuccess) return nf_fail_hip(e, "evaluator set-up");
     hipLaunchKernelGGL(k_e_input, dim3(nb), dim3(TB), 0, st, g, a.in, a.in_scale, a.seed, a.patch_base, z);
+    if (t->pr) pr_pack_step(t, st);
     if (a.direction == 0) {
         for (int l = 0; l < n; ++l) {
             const TLayer &L = t->tl.l[l];
@@ -2953,6 +2997,11 @@ int nf_bs_wide_run(nf_trainer *t, const nf_bs_wide_args &a, hipStream_t st)
                 hipLaunchKernelGGL(k_mix_fwd, dim3(nb), dim3(TB), 0, st, g, (const float *)z, t->d_flt + t->f_A + 16 * L.aux, z);
                 break;
             case NF_LAYER_COUPLING:
+                if (t->pr) {
+                    if ((t->pr & 3) == 2) pr_coupling_eval<4>(t, g, L, z, st, t->emom + (size_t)L.aux * 4 * w, false);
+                    else pr_coupling_eval<8>(t, g, L, z, st, t->emom + (size_t)L.aux * 4 * w, false);
+                    break;
+                }
                 ok = coupling_cnn_gemm(t, g, L, z, st, t->emom + (size_t)L.aux * 4 * w) && ok;
                 hipLaunchKernelGGL(k_e_c3<false>, dim3(nB), dim3(TB), 0, st, g.H, g.W, L.width, z, (const float *)t->gp36, (const float *)t->d_params,
                                    L.off + 24 * L.width + L.width * L.width, t->eldp);
@@ -2979,6 +3028,11 @@ int nf_bs_wide_run(nf_trainer *t, const nf_bs_wide_args &a, hipStream_t st)
                 hipLaunchKernelGGL(k_mix_fwd, dim3(nb), dim3(TB), 0, st, g, (const float *)z, (const float *)(t->eAinv + 16 * L.aux), z);
                 break;
             case NF_LAYER_COUPLING:
+                if (t->pr) {
+                    if ((t->pr & 3) == 2) pr_coupling_eval<4>(t, g, L, z, st, t->emom + (size_t)L.aux * 4 * w, true);
+                    else pr_coupling_eval<8>(t, g, L, z, st, t->emom + (size_t)L.aux * 4 * w, true);
+                    break;
+                }
                 ok = coupling_cnn_gemm(t, g, L, z, st, t->emom + (size_t)L.aux * 4 * w) && ok;
                 hipLaunchKernelGGL(k_e_c3<true>, dim3(nB), dim3(TB), 0, st, g.H, g.W, L.width, z, (const float *)t->gp36, (const float *)t->d_params,
                                    L.off + 24 * L.width + L.width * L.width, t->eldp);

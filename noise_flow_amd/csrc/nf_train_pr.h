@@ -356,9 +356,9 @@ __device__ __forceinline__ void pr_slot_sums(Acc acc, int nred, double &s, doubl
         q += __shfl_xor(q, o);
     }
 }
-template <int NW>
+template <int NW>   // run_mean != null: a training step (the running statistics move); mom != null: an evaluation call ([mean W][var W] left there)
 __device__ __forceinline__ void pr_bn_finalize(Acc stats, int nred, double n, float *bnc, float *__restrict__ bn_out, float *__restrict__ run_mean,
-                                               float *__restrict__ run_var)
+                                               float *__restrict__ run_var, float *__restrict__ mom = nullptr)
 {
     double sm, sq;
     pr_slot_sums<NW>(stats, nred, sm, sq);
@@ -373,8 +373,14 @@ __device__ __forceinline__ void pr_bn_finalize(Acc stats, int nred, double n, fl
         if (blockIdx.x == 0) {
             bn_out[c] = mf;
             bn_out[32 + c] = rf;
-            run_mean[c] -= kBnDecay * (run_mean[c] - mf);
-            run_var[c] -= kBnDecay * (run_var[c] - (float)v);
+            if (run_mean) {
+                run_mean[c] -= kBnDecay * (run_mean[c] - mf);
+                run_var[c] -= kBnDecay * (run_var[c] - (float)v);
+            }
+            if (mom) {
+                mom[c] = mf;
+                mom[32 + c] = (float)v;
+            }
         }
     }
 }
@@ -414,6 +420,10 @@ struct PrFwdArgs {
     float *next_zmixed;      // where that coupling's input goes
     const float *next_img;   // its packed weights (A1, B1 are used)
     Acc next_stats;          // its sums of h1, h1^2
+    // evaluation under batch statistics (nf_bs_wide_run; EVAL 1 = NLL direction, 2 = sampling direction): the moments of the finalised
+    // layer for the caller's EMA, the per-patch data-dependent log-det
+    float *mom;
+    double *ldp;
 };
 constexpr size_t pr_fwd_lds(int stage, int nw)
 {
@@ -424,10 +434,11 @@ constexpr size_t pr_fwd_lds(int stage, int nw)
 // other's matrix instructions
 // NEXT (stage 2 only): the launch goes on with stage 0 of the coupling above — its Conv2d1x1 applied to the pixels this stage has
 // just produced, its l_1 on the tile they are written back to, its batch sums — one launch and one trip of z through HBM less
-template <int STAGE, bool MIX, int NW, bool NEXT = false>
+template <int STAGE, bool MIX, int NW, bool NEXT = false, int EVAL = 0>
 __global__ __launch_bounds__(64 * NW) void k_pr_fwd(Geo g, PrFwdArgs a)
 {
     static_assert(!NEXT || (STAGE == 2 && !MIX), "only stage 2 continues into the next coupling");
+    static_assert(!EVAL || !NEXT, "the evaluator walks the layers one by one");
     constexpr int TPW = 32 / NW, OWN = TPW / 2, NTH = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NIMG = STAGE == 0 ? PR_A2 : STAGE == 1 ? PR_A3 : PR_FWD + PR_A2;   // (stage 2: + A1, B1 of the coupling above)
@@ -451,10 +462,10 @@ __global__ __launch_bounds__(64 * NW) void k_pr_fwd(Geo g, PrFwdArgs a)
     if (NEXT)
         for (int i = t; i < PR_A2 / 4; i += NTH) reinterpret_cast<float4 *>(img + PR_FWD)[i] = reinterpret_cast<const float4 *>(a.next_img)[i];
     for (int i = t; i < 2 * PR_PL; i += NTH) z0s[i] = 0.0f;
-    if (STAGE == 1) pr_bn_finalize<NW>(a.stats_in, a.nred, a.n, bnc, a.bn1, a.run_mean, a.run_var);
+    if (STAGE == 1) pr_bn_finalize<NW>(a.stats_in, a.nred, a.n, bnc, a.bn1, a.run_mean, a.run_var, a.mom);
     if (STAGE == 2) {
         pr_load_bn<true>(bnc, a.bn1, 0);
-        pr_bn_finalize<NW>(a.stats_in, a.nred, a.n, bnc + 64, a.bn2, a.run_mean, a.run_var);
+        pr_bn_finalize<NW>(a.stats_in, a.nred, a.n, bnc + 64, a.bn2, a.run_mean, a.run_var, a.mom);
     }
     PrLaneMasks lm;
     lm.ml = n > 0 ? 1.0f : 0.0f;
@@ -549,6 +560,7 @@ __global__ __launch_bounds__(64 * NW) void k_pr_fwd(Geo g, PrFwdArgs a)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) mm[i] = a.next_A[i];
             }
+            [[maybe_unused]] double lpatch = 0.0;   // EVAL 1: this lane's share of the patch's log-det
 #pragma unroll
             for (int m = 0; m < OWN; ++m) {
                 const int r = row0 + 2 * m + gh;
@@ -560,12 +572,14 @@ __global__ __launch_bounds__(64 * NW) void k_pr_fwd(Geo g, PrFwdArgs a)
                 u[2] = pr_half_sums(cp[2 * m][2], cp[2 * m + 1][2]) + eb.z;
                 u[3] = pr_half_sums(cp[2 * m][3], cp[2 * m + 1][3]) + eb.w;
                 const int64_t p = pb + r * 32 + n;
-                reinterpret_cast<float4 *>(a.u_out)[p] = make_float4(u[0], u[1], u[2], u[3]);
+                if (!EVAL) reinterpret_cast<float4 *>(a.u_out)[p] = make_float4(u[0], u[1], u[2], u[3]);
                 const float sh0 = u[0] * e3[0], sh1 = u[1] * e3[1];
                 const float ls0 = sc * tanhf(u[2] * e3[2]), ls1 = sc * tanhf(u[3] * e3[3]);
-                const float zo2 = fmaf(z[m][2], expf(ls0), sh0), zo3 = fmaf(z[m][3], expf(ls1), sh1);
+                const float zo2 = EVAL == 2 ? (z[m][2] - sh0) * expf(-ls0) : fmaf(z[m][2], expf(ls0), sh0);
+                const float zo3 = EVAL == 2 ? (z[m][3] - sh1) * expf(-ls1) : fmaf(z[m][3], expf(ls1), sh1);
                 reinterpret_cast<float4 *>(a.zout)[p] = make_float4(z[m][0], z[m][1], zo2, zo3);
-                lsum += ls0 + ls1;
+                if (EVAL == 1) lpatch += (double)ls0 + (double)ls1;
+                else lsum += ls0 + ls1;
                 if (NEXT) {   // the coupling above: its input, and the pass-through half of it into the tile (every strip loop is over)
                     const float u0 = z[m][0], u1 = z[m][1];
                     const float v0 = u0 * mm[0] + u1 * mm[4] + zo2 * mm[8] + zo3 * mm[12], v1 = u0 * mm[1] + u1 * mm[5] + zo2 * mm[9] + zo3 * mm[13];
@@ -573,6 +587,19 @@ __global__ __launch_bounds__(64 * NW) void k_pr_fwd(Geo g, PrFwdArgs a)
                         make_float4(v0, v1, u0 * mm[2] + u1 * mm[6] + zo2 * mm[10] + zo3 * mm[14], u0 * mm[3] + u1 * mm[7] + zo2 * mm[11] + zo3 * mm[15]);
                     z0s[(r + 1) * PR_WP + n + 1] = v0;
                     z0s[PR_PL + (r + 1) * PR_WP + n + 1] = v1;
+                }
+            }
+            if (EVAL == 1) {   // the patch's log-det share of this coupling: one fp64 sum over the workgroup, in a fixed order
+                double *const dred = reinterpret_cast<double *>(red);
+                const double ws = wsum(lpatch);
+                __syncthreads();
+                if (lane == 0) dred[w] = ws;
+                __syncthreads();
+                if (t == 0) {
+                    double tot = 0.0;
+#pragma unroll
+                    for (int i = 0; i < NW; ++i) tot += dred[i];
+                    a.ldp[b] += tot;
                 }
             }
             if (NEXT) {
@@ -607,7 +634,7 @@ __global__ __launch_bounds__(64 * NW) void k_pr_fwd(Geo g, PrFwdArgs a)
         __syncthreads();
         pr_chan_get<NW>(red, a.stats, g.nslot, t);
         pr_chan_get<NW>(red + NW * 64, a.stats + 32, g.nslot, t - 64);
-    } else {
+    } else if (!EVAL) {
         const float lv[1] = {lsum};
         pr_acc_put<1, NW>(lv, red);
         __syncthreads();

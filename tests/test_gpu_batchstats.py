@@ -128,7 +128,10 @@ def test_batchstats_other_shapes(arch, width, hw, B):
                                                      ("unc|unc", 50, (9, 7), 4, 1600, 3),           # not a multiple of 4, ragged shape
                                                      ("unc|gain4|unc", 16, (48, 64), 2, 800, 2),    # beyond the scalar kernel's LDS tiles
                                                      ("unc|unc", 132, (12, 20), 1, 400, 1),         # ONE patch: the batch is its pixels; 128 + 4 channels
-                                                     ("|".join(["unc"] * 9), 40, (8, 8), 3, 100, 0)])   # 9 couplings
+                                                     ("|".join(["unc"] * 9), 40, (8, 8), 3, 100, 0),    # 9 couplings
+                                                     # the paper's width on the training patch size: the patch-resident forward stages
+                                                     # (csrc/nf_train_pr.h; 7 patches on 7 workgroups)
+                                                     ("sdn5|unc|unc|gain4|unc", 32, (32, 32), 7, 800, 2)])
 def test_batchstats_on_the_gemm_route(arch, width, hw, B, iso, cam):
     """NoiseFlowWrapper.py:86 runs the sampling graph with is_training=True and sidd/ArgParser.py:43 defaults --width to 512: the
     batch-statistics calls take every width and patch size.  Beyond 32 channels, and where a patch outgrows the scalar-weight
@@ -286,7 +289,8 @@ def _bs_sync_worker(rank, world, port, outdir, arch, width, hw, per):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("arch,width,hw,per", [("sdn5|unc|unc|gain4|unc", 4, 32, 6), ("sdn5|unc|gain4|unc", 16, 16, 5)])
+@pytest.mark.parametrize("arch,width,hw,per", [("sdn5|unc|unc|gain4|unc", 4, 32, 6), ("sdn5|unc|gain4|unc", 16, 16, 5),
+                                               ("sdn5|unc|gain4|unc", 32, 32, 3)])     # the patch-resident forward stages
 def test_two_rank_batch_statistics_evaluation_equals_one_rank_on_the_union(tmp_path, arch, width, hw, per):
     """`is_training=True` forward / sampling across ranks (layers.py:386-398: the moments are those of the whole minibatch):
     with the nf_set_sync hook, 2 ranks x `per` patches give per-patch NLLs, samples and running-statistics updates equal to
