@@ -869,8 +869,9 @@ def _training(ctx, batches, cond, wide):
     out["width32"] = {"workload": "the same step, coupling width 32 (fresh initialisation), 138 patches 32x32x4", "ms_per_step": msw,
                       "value": TB_ / (msw * 1e-3), "unit": "patches/s",
                       "executed_matrix_tflops": mfma_flop * TB_ / (msw * 1e-3) / 1e12,
-                      "note": "patch-resident stages (csrc/nf_train_pr.h): 6 launches per coupling, one workgroup per patch on "
-                              "138 of the CUs; fixed cost per launch and the idle CUs bound it (DESIGN 4.7)"}
+                      "note": "patch-resident stages (csrc/nf_train_pr.h): 4 launches per coupling on the critical path (+ d l_last/W on "
+                              "the side stream, in the idle CUs), one workgroup per patch on 138 of the CUs; fixed cost per launch "
+                              "and the idle CUs bound it (DESIGN 4.7)"}
     try:   # ... and with the GPU full: 1 024 patches (one workgroup per CU walks 4 patches)
         xb_, yb_ = synth_patches(args.seed, 1 << 43, 1024, device=dev.index)
         trb = Trainer([32, 32, 4], default_hps(width=32), device=dev.index, max_batch=1024)
