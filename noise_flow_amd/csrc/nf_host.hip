@@ -2289,7 +2289,7 @@ static int run_batchstats(nf_handle *h, int direction, NfLaunch a, float *moment
         const char *bw = getenv("NF_BS_WIDE");
         // width 32 on 32x32 patches (the paper's coupling CNN on the training patch size): the evaluator runs the trainer's patch-resident
         // forward stages on the matrix cores (csrc/nf_train_pr.h) — 3 launches per coupling instead of the scalar-weight schedule
-        // (1 024 patches: 3.7 -> 1.1 ms).  NF_TRAIN_PR=0 keeps the scalar schedule.
+        // (1 024 patches: 3.7 -> 1.1 ms, 138: 1.24 -> 0.48).  NF_TRAIN_PR=0 keeps the scalar schedule.
         const char *pe = getenv("NF_TRAIN_PR");   // (read per call, like NF_BS_WIDE: the tests flip it inside one process)
         const bool pr_off = pe && atoi(pe) == 0;
         const bool pr32 = h->fwd.raw_width == 32 && a.H == 32 && a.W == 32 && !h->fwd.tiled && !pr_off;

@@ -1940,7 +1940,8 @@ void pr_coupling_backward(nf_trainer *t, const Geo &g, const TLayer &L, const fl
 // a coupling of the batch-statistics evaluator (nf_bs_wide_run) on the patch-resident forward stages: in place on z, the moments of
 // both normalisations left in mom [4][32], the per-patch log-det share added to t->eldp (NLL direction)
 template <int NW>
-void pr_coupling_eval(nf_trainer *t, const Geo &g, const TLayer &L, float *z, hipStream_t st, float *mom, bool inverse)
+void pr_coupling_eval(nf_trainer *t, const Geo &g, const TLayer &L, float *z, hipStream_t st, float *mom, bool inverse,
+                      const float *mixA = nullptr)   // mixA: the Conv2d1x1 in front of the coupling (NLL direction), applied by its first stage
 {
     constexpr int w = 32;
     const Cpl &c = t->cpl[L.aux];
@@ -1954,7 +1955,15 @@ void pr_coupling_eval(nf_trainer *t, const Geo &g, const TLayer &L, float *z, hi
     a.tail3 = t->d_params + L.off + 24 * w + w * w + 36 * (w + 1);
     a.zsrc = z;
     a.stats = t->acc(c.d_st1);
-    hipLaunchKernelGGL((k_pr_fwd<0, false, NW>), dim3(grid), dim3(64 * NW), pr_fwd_lds(0, NW), st, g, a);
+    if (mixA) {   // in place: every lane reads its own pixels and writes them back mixed
+        a.A = mixA;
+        a.zmixed = z;
+        hipLaunchKernelGGL((k_pr_fwd<0, true, NW>), dim3(grid), dim3(64 * NW), pr_fwd_lds(0, NW), st, g, a);
+        a.A = nullptr;
+        a.zmixed = nullptr;
+    } else {
+        hipLaunchKernelGGL((k_pr_fwd<0, false, NW>), dim3(grid), dim3(64 * NW), pr_fwd_lds(0, NW), st, g, a);
+    }
     sync_slots(t, t->acc(c.d_st1), 2 * w, g.nslot, st);
     a.stats_in = t->acc(c.d_st1);
     a.stats = t->acc(c.d_st2);
@@ -2994,12 +3003,14 @@ int nf_bs_wide_run(nf_trainer *t, const nf_bs_wide_args &a, hipStream_t st)
                 hipLaunchKernelGGL(k_scale_fwd, dim3(nb), dim3(TB), 0, st, g, (const float *)z, t->d_flt + t->f_s + L.aux, z);
                 break;
             case NF_LAYER_CONV1X1:
+                if (t->pr && l + 1 < n && t->tl.l[l + 1].type == NF_LAYER_COUPLING) break;   // folded into the coupling's first stage
                 hipLaunchKernelGGL(k_mix_fwd, dim3(nb), dim3(TB), 0, st, g, (const float *)z, t->d_flt + t->f_A + 16 * L.aux, z);
                 break;
             case NF_LAYER_COUPLING:
                 if (t->pr) {
-                    if ((t->pr & 3) == 2) pr_coupling_eval<4>(t, g, L, z, st, t->emom + (size_t)L.aux * 4 * w, false);
-                    else pr_coupling_eval<8>(t, g, L, z, st, t->emom + (size_t)L.aux * 4 * w, false);
+                    const float *Am = (l > 0 && t->tl.l[l - 1].type == NF_LAYER_CONV1X1) ? t->d_flt + t->f_A + 16 * t->tl.l[l - 1].aux : nullptr;
+                    if ((t->pr & 3) == 2) pr_coupling_eval<4>(t, g, L, z, st, t->emom + (size_t)L.aux * 4 * w, false, Am);
+                    else pr_coupling_eval<8>(t, g, L, z, st, t->emom + (size_t)L.aux * 4 * w, false, Am);
                     break;
                 }
                 ok = coupling_cnn_gemm(t, g, L, z, st, t->emom + (size_t)L.aux * 4 * w) && ok;
