@@ -1955,7 +1955,7 @@ void pr_coupling_eval(nf_trainer *t, const Geo &g, const TLayer &L, float *z, hi
     a.tail3 = t->d_params + L.off + 24 * w + w * w + 36 * (w + 1);
     a.zsrc = z;
     a.stats = t->acc(c.d_st1);
-    if (mixA) {   // in place: every lane reads its own pixels and writes them back mixed
+    if (mixA && !inverse) {   // in place: every lane reads its own pixels and writes them back mixed
         a.A = mixA;
         a.zmixed = z;
         hipLaunchKernelGGL((k_pr_fwd<0, true, NW>), dim3(grid), dim3(64 * NW), pr_fwd_lds(0, NW), st, g, a);
@@ -1974,6 +1974,7 @@ void pr_coupling_eval(nf_trainer *t, const Geo &g, const TLayer &L, float *z, hi
     a.mom = mom ? mom + 2 * w : nullptr;
     a.zout = z;
     a.ldp = t->eldp;
+    if (inverse) a.A = mixA;   // (sampling direction: mixA is the INVERSE matrix of the Conv2d1x1, applied behind the coupling)
     if (inverse)
         hipLaunchKernelGGL((k_pr_fwd<2, false, NW, false, 2>), dim3(grid), dim3(64 * NW), pr_fwd_lds(2, NW), st, g, a);
     else
@@ -3036,12 +3037,14 @@ int nf_bs_wide_run(nf_trainer *t, const nf_bs_wide_args &a, hipStream_t st)
                 hipLaunchKernelGGL(k_e_scale_mul, dim3(nb), dim3(TB), 0, st, g, z, (const float *)(t->d_flt + t->f_s + L.aux));
                 break;
             case NF_LAYER_CONV1X1:
+                if (t->pr && l + 1 < n && t->tl.l[l + 1].type == NF_LAYER_COUPLING) break;   // applied by the coupling's last stage
                 hipLaunchKernelGGL(k_mix_fwd, dim3(nb), dim3(TB), 0, st, g, (const float *)z, (const float *)(t->eAinv + 16 * L.aux), z);
                 break;
             case NF_LAYER_COUPLING:
                 if (t->pr) {
-                    if ((t->pr & 3) == 2) pr_coupling_eval<4>(t, g, L, z, st, t->emom + (size_t)L.aux * 4 * w, true);
-                    else pr_coupling_eval<8>(t, g, L, z, st, t->emom + (size_t)L.aux * 4 * w, true);
+                    const float *Ai = (l > 0 && t->tl.l[l - 1].type == NF_LAYER_CONV1X1) ? t->eAinv + 16 * t->tl.l[l - 1].aux : nullptr;
+                    if ((t->pr & 3) == 2) pr_coupling_eval<4>(t, g, L, z, st, t->emom + (size_t)L.aux * 4 * w, true, Ai);
+                    else pr_coupling_eval<8>(t, g, L, z, st, t->emom + (size_t)L.aux * 4 * w, true, Ai);
                     break;
                 }
                 ok = coupling_cnn_gemm(t, g, L, z, st, t->emom + (size_t)L.aux * 4 * w) && ok;

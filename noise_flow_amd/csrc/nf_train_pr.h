@@ -584,7 +584,15 @@ __global__ __launch_bounds__(64 * NW) void k_pr_fwd(Geo g, PrFwdArgs a)
                 const float ls0 = sc * pr_tanh(u[2] * e3[2]), ls1 = sc * pr_tanh(u[3] * e3[3]);
                 const float zo2 = EVAL == 2 ? (z[m][2] - sh0) * pr_exp(-ls0) : fmaf(z[m][2], pr_exp(ls0), sh0);
                 const float zo3 = EVAL == 2 ? (z[m][3] - sh1) * pr_exp(-ls1) : fmaf(z[m][3], pr_exp(ls1), sh1);
-                reinterpret_cast<float4 *>(a.zout)[p] = make_float4(z[m][0], z[m][1], zo2, zo3);
+                if (EVAL == 2 && a.A) {   // sampling direction: the inverse of the Conv2d1x1 in front of the coupling follows it
+                    const float q0 = z[m][0], q1 = z[m][1];
+                    const float *mi = a.A;
+                    reinterpret_cast<float4 *>(a.zout)[p] =
+                        make_float4(q0 * mi[0] + q1 * mi[4] + zo2 * mi[8] + zo3 * mi[12], q0 * mi[1] + q1 * mi[5] + zo2 * mi[9] + zo3 * mi[13],
+                                    q0 * mi[2] + q1 * mi[6] + zo2 * mi[10] + zo3 * mi[14], q0 * mi[3] + q1 * mi[7] + zo2 * mi[11] + zo3 * mi[15]);
+                } else {
+                    reinterpret_cast<float4 *>(a.zout)[p] = make_float4(z[m][0], z[m][1], zo2, zo3);
+                }
                 if (EVAL == 1) lpatch += (double)ls0 + (double)ls1;
                 else lsum += ls0 + ls1;
                 if (NEXT) {   // the coupling above: its input, and the pass-through half of it into the tile (every strip loop is over)
