@@ -320,7 +320,8 @@ int nf_set_sync(nf_handle *h, nf_allreduce_fn fn, void *user, double *sync_buf, 
  *                       patch, 2: 4 wavefronts, 0: the stage kernels NF_TRAIN_WIDE_MFMA selects; + 4: the first stage of the coupling
  *                       above in a launch of its own, + 8: likewise the first backward stage of the coupling below (by default they
  *                       ride in the neighbouring coupling's last launch), + 16: d l_last/W inside its stage at every minibatch size
- *                       (by default a launch of its own on the side stream while a quarter .. three quarters of the CUs hold a patch).
+ *                       (by default a launch of its own on the side stream while a quarter .. three quarters of the CUs hold a patch;
+ *                       up to half of them, d l_1/W of the coupling above rides in the same side launch: + 32 keeps that one inside).
  *                       NF_TRAIN_PR_GRID=<n>: at most n workgroups walk the
  *                       patches (default: one per CU).
  *   NF_MM_MODE          the 128-column GEMMs of the widths beyond 64: 2 (default) fp32-accurate products on the bf16 matrix pipe,

@@ -1709,10 +1709,13 @@ int pr_set_attributes_nw()
         {reinterpret_cast<const void *>(&k_pr_bwd<1, false, NW, 2>), pr_bwd_lds(1, NW)},
         {reinterpret_cast<const void *>(&k_pr_bwd<2, false, NW, 2>), pr_bwd_lds(2, NW)},
         {reinterpret_cast<const void *>(&k_pr_bwd<2, true, NW, 2>), pr_bwd_lds(2, NW)},
-        {reinterpret_cast<const void *>(&k_pr_bwd_CA<true, NW, 0>), ca},
-        {reinterpret_cast<const void *>(&k_pr_bwd_CA<true, NW, 2>), ca},
-        {reinterpret_cast<const void *>(&k_pr_bwd_CA<false, NW, 0>), ca},
-        {reinterpret_cast<const void *>(&k_pr_bwd_CA<false, NW, 2>), ca},
+        {reinterpret_cast<const void *>(&k_pr_bwd_CA<true, NW, 0, 0>), ca},
+        {reinterpret_cast<const void *>(&k_pr_bwd_CA<true, NW, 0, 2>), ca},
+        {reinterpret_cast<const void *>(&k_pr_bwd_CA<true, NW, 2, 2>), ca},
+        {reinterpret_cast<const void *>(&k_pr_bwd_CA<false, NW, 0, 0>), ca},
+        {reinterpret_cast<const void *>(&k_pr_bwd_CA<false, NW, 0, 2>), ca},
+        {reinterpret_cast<const void *>(&k_pr_bwd_CA<false, NW, 2, 2>), ca},
+        {reinterpret_cast<const void *>(&k_pr_bwd_grads<NW>), ca},
     };
     for (const auto &k : ks) {
         if (k.lds <= 64 * 1024) continue;
@@ -1897,11 +1900,16 @@ void pr_coupling_backward(nf_trainer *t, const Geo &g, const TLayer &L, const fl
         }
 #endif
     }
+    const bool a_rode = t->pr_a_done;   // stage A ran in the launch of the coupling above: its product was launched behind that one
     t->pr_a_done = false;
-    if (split) {
-        const unsigned idle = (unsigned)t->n_cu - grid;
+    // both products (stage C's and the next stage A's) leave the main launches while every side workgroup has ONE patch — at most half
+    // of the CUs busy; beyond (138 patches: 118 side workgroups, 20 of them with two patches) the side launch outlasts the main one
+    // (measured: 1.25 against 1.19 ms) and only d l_last/W goes.  NF_TRAIN_PR + 32: d l_last/W only, at every size
+    const bool both_ok = (t->pr & 32) == 0 && 2 * (g.npix / g.HW) <= (int64_t)t->n_cu;
+    const unsigned side_grid = split ? std::max(1u, std::min(grid, (unsigned)t->n_cu - grid)) : 0u;
+    if (split && !(a_rode && both_ok)) {
         fork();
-        hipLaunchKernelGGL((k_pr_bwd<0, false, NW, 1>), dim3(std::max(1u, std::min(grid, idle))), dim3(64 * NW), pr_bwd_lds(0, NW), sd, g, a);
+        hipLaunchKernelGGL((k_pr_bwd<0, false, NW, 1>), dim3(side_grid), dim3(64 * NW), pr_bwd_lds(0, NW), sd, g, a);
         (void)hipEventRecord(t->ev_done[par], sd);
         t->done_pending[par] = true;
     }
@@ -1922,11 +1930,23 @@ void pr_coupling_backward(nf_trainer *t, const Geo &g, const TLayer &L, const fl
         wait_side(t->pr_below->aux % 3);
         const PrBwdArgs an = pr_bwd_args(t, g, *t->pr_below, t->pr_below_zin, invB, nullptr, grid);
         const size_t lds = std::max(pr_bwd_lds(2, NW), pr_bwd_lds(0, NW));
-        // (CA_GRAD 0: the whole stage C, stage A without its product)
-        if (zmix_in && split) hipLaunchKernelGGL((k_pr_bwd_CA<true, NW, 0>), dim3(grid), dim3(64 * NW), lds, st, g, a, an);
-        else if (zmix_in) hipLaunchKernelGGL((k_pr_bwd_CA<true, NW, 2>), dim3(grid), dim3(64 * NW), lds, st, g, a, an);
-        else if (split) hipLaunchKernelGGL((k_pr_bwd_CA<false, NW, 0>), dim3(grid), dim3(64 * NW), lds, st, g, a, an);
-        else hipLaunchKernelGGL((k_pr_bwd_CA<false, NW, 2>), dim3(grid), dim3(64 * NW), lds, st, g, a, an);
+        // split: both stages without their products — d l_1/W of this coupling and d l_last/W of the one below follow in ONE
+        // launch on the side stream (NF_TRAIN_PR + 32: stage C keeps its product, stage A's is launched with the coupling below)
+        const bool both = split && both_ok;
+        if (zmix_in && both) hipLaunchKernelGGL((k_pr_bwd_CA<true, NW, 0, 0>), dim3(grid), dim3(64 * NW), lds, st, g, a, an);
+        else if (zmix_in && split) hipLaunchKernelGGL((k_pr_bwd_CA<true, NW, 0, 2>), dim3(grid), dim3(64 * NW), lds, st, g, a, an);
+        else if (zmix_in) hipLaunchKernelGGL((k_pr_bwd_CA<true, NW, 2, 2>), dim3(grid), dim3(64 * NW), lds, st, g, a, an);
+        else if (both) hipLaunchKernelGGL((k_pr_bwd_CA<false, NW, 0, 0>), dim3(grid), dim3(64 * NW), lds, st, g, a, an);
+        else if (split) hipLaunchKernelGGL((k_pr_bwd_CA<false, NW, 0, 2>), dim3(grid), dim3(64 * NW), lds, st, g, a, an);
+        else hipLaunchKernelGGL((k_pr_bwd_CA<false, NW, 2, 2>), dim3(grid), dim3(64 * NW), lds, st, g, a, an);
+        if (both) {
+            const int pb = t->pr_below->aux % 3;
+            fork();
+            hipLaunchKernelGGL((k_pr_bwd_grads<NW>), dim3(side_grid), dim3(64 * NW), lds, sd, g, a, an);
+            (void)hipEventRecord(t->ev_done[par], sd);
+            (void)hipEventRecord(t->ev_done[pb], sd);
+            t->done_pending[par] = t->done_pending[pb] = true;
+        }
         t->pr_a_done = true;
         fused = true;
     }

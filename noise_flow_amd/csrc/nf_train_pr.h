@@ -699,17 +699,36 @@ __global__ __launch_bounds__(64 * NW) void k_pr_bwd(Geo g, PrBwdArgs a)
 // Stage C of a coupling and stage A of the coupling below it in ONE launch: A of a patch needs nothing but C of the same patch (the
 // d loss / d z the same lanes have just stored), so a workgroup walks its patches through C, then through A — one launch and one
 // wait for the slowest workgroup less per coupling.
-template <bool MIXC, int NW, int GRAD_A = 2>   // GRAD_A: stage A with (2) or without (0) its filter gradient
+template <bool MIXC, int NW, int GRAD_A = 2, int GRAD_C = 2>   // GRAD_x: the stage with (2) or without (0) its filter gradient
 __global__ __launch_bounds__(64 * NW) void k_pr_bwd_CA(Geo g, PrBwdArgs a, PrBwdArgs below)
 {
     {
-        constexpr int STAGE = 2, GRAD = 2;
+        constexpr int STAGE = 2, GRAD = GRAD_C;
         constexpr bool MIX = MIXC;
 #include "nf_train_pr_bwd.inc"
     }
     __syncthreads();
     {
         constexpr int STAGE = 0, GRAD = GRAD_A;
+        constexpr bool MIX = false;
+        const PrBwdArgs &a = below;
+#include "nf_train_pr_bwd.inc"
+    }
+}
+
+// The two filter gradients a k_pr_bwd_CA launch leaves out (GRAD 0), on the side stream: d l_1/W of the coupling (stage C's product) and
+// d l_last/W of the coupling below it (stage A's) — one launch, in the CUs a small minibatch leaves idle.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_pr_bwd_grads(Geo g, PrBwdArgs a, PrBwdArgs below)
+{
+    {
+        constexpr int STAGE = 2, GRAD = 1;
+        constexpr bool MIX = false;
+#include "nf_train_pr_bwd.inc"
+    }
+    __syncthreads();
+    {
+        constexpr int STAGE = 0, GRAD = 1;
         constexpr bool MIX = false;
         const PrBwdArgs &a = below;
 #include "nf_train_pr_bwd.inc"
