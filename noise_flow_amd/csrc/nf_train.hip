@@ -1591,6 +1591,8 @@ struct nf_trainer {
     const TLayer *pr_below = nullptr;
     const float *pr_below_zin = nullptr;
     bool pr_a_done = false;
+    int pr_side_full = 0;      // NF_TRAIN_PR_SIDE_FULL=1 (A/B aid): one side workgroup per patch even when fewer CUs are idle
+    int pr_both_max = 0;       // NF_TRAIN_PR_BOTH_MAX=<patches> (A/B aid): up to how many patches both products take the side stream (default CUs / 2)
     int tiled = 3;   // NF_TRAIN_TILED: bit 0 = tiled backward stages, bit 1 = tiled forward stages (0: layer kernels only)
     std::vector<void *> owned;
     bool has_sdn = false;
@@ -1905,8 +1907,8 @@ void pr_coupling_backward(nf_trainer *t, const Geo &g, const TLayer &L, const fl
     // both products (stage C's and the next stage A's) leave the main launches while every side workgroup has ONE patch — at most half
     // of the CUs busy; beyond (138 patches: 118 side workgroups, 20 of them with two patches) the side launch outlasts the main one
     // (measured: 1.25 against 1.19 ms) and only d l_last/W goes.  NF_TRAIN_PR + 32: d l_last/W only, at every size
-    const bool both_ok = (t->pr & 32) == 0 && 2 * (g.npix / g.HW) <= (int64_t)t->n_cu;
-    const unsigned side_grid = split ? std::max(1u, std::min(grid, (unsigned)t->n_cu - grid)) : 0u;
+    const bool both_ok = (t->pr & 32) == 0 && (t->pr_both_max ? g.npix / g.HW <= t->pr_both_max : 2 * (g.npix / g.HW) <= (int64_t)t->n_cu);
+    const unsigned side_grid = !split ? 0u : t->pr_side_full ? grid : std::max(1u, std::min(grid, (unsigned)t->n_cu - grid));
     if (split && !(a_rode && both_ok)) {
         fork();
         hipLaunchKernelGGL((k_pr_bwd<0, false, NW, 1>), dim3(side_grid), dim3(64 * NW), pr_bwd_lds(0, NW), sd, g, a);
@@ -2624,6 +2626,8 @@ static int trainer_create_impl(const nf_config *cfg, const nf_layer_desc *layers
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, t->device) == hipSuccess && cus > 0) t->n_cu = cus;
         if (const char *ev = getenv("NF_TRAIN_PR_GRID")) t->n_cu = std::max(1, atoi(ev));   // A/B aid: workgroups of the patch-resident stages
+        if (const char *ev = getenv("NF_TRAIN_PR_SIDE_FULL")) t->pr_side_full = atoi(ev);
+        if (const char *ev = getenv("NF_TRAIN_PR_BOTH_MAX")) t->pr_both_max = atoi(ev);
         NF_TRY(dev_alloc(t, (void **)&t->pr_img, (size_t)n_cpl * PR_SIZE * sizeof(float)));
         if ((rc = pr_set_attributes(t->pr)) != NF_OK) {
             nf_trainer_destroy(t);
